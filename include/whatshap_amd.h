@@ -1,0 +1,189 @@
+/*
+ * whatshap_amd.h -- C ABI of the MI355X-native wMEC / PedMEC solver.
+ *
+ * This is the drop-in boundary for the hot path of `whatshap phase`: the C++ class
+ * PedigreeDPTable that whatshap/core.pyx:364-416 binds through whatshap/cpp.pxd:85-90
+ *
+ *     PedigreeDPTable(ReadSet*, vector[unsigned int] recombcost, Pedigree*, bool distrust_genotypes,
+ *                     vector[unsigned int]* positions) except +
+ *     void get_super_reads(vector[ReadSet*]*, vector[unsigned int]* transmission_vector) except +
+ *     int  get_optimal_score() except +
+ *     vector[bool]* get_optimal_partitioning()
+ *
+ * Every entry point below replaces one of those four members (cited per function).  The ABI uses
+ * plain pointers and sizes only: a ReadSet is handed over as a CSR "view" of what
+ * src/readset.h / src/read.h store, a Pedigree as a view of what src/pedigree.h stores.  No torch,
+ * no C++ types, no ownership transfer: every input pointer is borrowed for the duration of the call
+ * that takes it (the table copies what it needs, unlike the reference, which keeps ReadSet* /
+ * Pedigree* and re-reads them in get_super_reads, src/pedigreedptable.h:80-86).
+ *
+ * Error model: functions that can fail return a whamd_status_t; the message a Python binding
+ * should raise as RuntimeError (the reference's `except +` path) is returned by
+ * whamd_last_error().  The two messages of the reference's hot path are reproduced verbatim:
+ *   "Error: Mendelian conflict"                          (src/pedigreedptable.cpp:302)
+ *   "ColumnIterator: reads in ReadSet are not sorted."   (src/columniterator.cpp:29)
+ *
+ * Device selection: one table lives on one HIP device (one process per GPU, or one worker
+ * thread per device); independent tables never communicate (no RCCL on this path).
+ */
+#ifndef WHATSHAP_AMD_H
+#define WHATSHAP_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WHAMD_ABI_VERSION 1
+
+/* allele codes, identical to Entry::allele_t (src/entry.h:8) */
+#define WHAMD_ALLELE_REF 0
+#define WHAMD_ALLELE_ALT 1
+#define WHAMD_ALLELE_BLANK 2
+#define WHAMD_ALLELE_EQUAL_SCORES 3
+
+/* genotype codes of the pedigree view: canonical index of a diploid bi-allelic genotype
+ * (src/genotype.h:22-27: 0 -> 0/0, 1 -> 0/1, 2 -> 1/1); anything else (other ploidy, other
+ * alleles, empty genotype) is WHAMD_GT_OTHER and is compatible with no allele assignment,
+ * exactly as Genotype::operator!= on the 64-bit code behaves (src/genotype.cpp:148-150). */
+#define WHAMD_GT_OTHER 255
+
+typedef enum whamd_status_t {
+	WHAMD_OK = 0,
+	WHAMD_ERR_INVALID = 1,           /* malformed input (message says what) */
+	WHAMD_ERR_MENDELIAN_CONFLICT = 2, /* "Error: Mendelian conflict" */
+	WHAMD_ERR_UNSORTED = 3,          /* ColumnIterator sortedness errors */
+	WHAMD_ERR_UNSUPPORTED = 4,       /* outside the limits of the device path (coverage > 23, ...) */
+	WHAMD_ERR_DEVICE = 5,            /* HIP runtime error / no device / extension missing */
+	WHAMD_ERR_OVERFLOW = 6           /* costs could exceed 32 bits; reference behaviour undefined there */
+} whamd_status_t;
+
+/* View of a ReadSet (src/readset.h:14-26, src/read.h:10-83).  Reads in ReadSet order; the
+ * variants of read r are entries read_ptr[r] .. read_ptr[r+1]-1 of the three var_* arrays. */
+typedef struct whamd_readset_view {
+	uint32_t n_reads;
+	const uint64_t* read_ptr;       /* [n_reads + 1] */
+	const int32_t* var_position;    /* Read::getPosition   */
+	const uint8_t* var_allele;      /* Read::getAllele (0 = REF, 1 = ALT) */
+	const uint32_t* var_quality;    /* Read::getVariantQuality (phred) */
+	const int32_t* read_sample_id;  /* [n_reads] Read::getSampleID (numeric sample id) */
+} whamd_readset_view;
+
+/* View of a Pedigree (src/pedigree.h:16-86).  Individuals in insertion order (that order is
+ * the "individual index"); triples by numeric id as passed to Pedigree::addRelationship. */
+typedef struct whamd_pedigree_view {
+	uint32_t n_individuals;
+	const uint32_t* individual_id; /* [n_individuals] */
+	uint32_t n_triples;
+	const uint32_t* triple_ids;    /* [3 * n_triples]: father id, mother id, child id */
+	uint32_t n_variants;           /* Pedigree::get_variant_count() (0 if no individual) */
+	const uint8_t* genotype;       /* [n_individuals * n_variants] WHAMD genotype codes */
+	const double* genotype_likelihoods; /* [n_individuals * n_variants * 3] phred GL of 0/0, 0/1, 1/1, or NULL */
+	const uint8_t* gl_present;     /* [n_individuals * n_variants] 1 if the GL triple is set, or NULL (= all set iff genotype_likelihoods != NULL) */
+} whamd_pedigree_view;
+
+typedef struct whamd_dptable whamd_dptable; /* opaque */
+
+/* Per-solve measurements taken with HIP events on the table's own stream. */
+typedef struct whamd_solve_stats {
+	uint64_t n_columns;
+	uint64_t n_cells;            /* sum_c 2^k_c (unique bipartitions) */
+	uint64_t n_costs;            /* n_cells * T */
+	uint64_t algorithmic_bytes;  /* sum_c 4*T*2^b_c + 12*T*2^f_c + 12*k_c   */
+	uint64_t forward_launches;   /* launches of the dominant (column-step) kernel */
+	double forward_ms;           /* HIP-event time of the forward pass (all column steps) */
+	double backtrace_ms;         /* HIP-event time of the device backtrace */
+	double total_ms;             /* HIP-event time forward + backtrace + path download */
+	double host_prepare_ms;      /* wall: flattening + descriptor build + upload (outside total_ms) */
+	double host_finish_ms;       /* wall: superreads + partitioning on the host */
+	uint32_t max_coverage;       /* max_c k_c */
+	uint32_t transmissions;      /* T = 4^triples */
+} whamd_solve_stats;
+
+/* Library / device introspection. */
+int whamd_abi_version(void);
+/* number of visible HIP devices (0 if none; never fails) */
+int whamd_device_count(void);
+/* thread-local message of the last failing call on this thread ("" if none) */
+const char* whamd_last_error(void);
+
+/*
+ * Replaces PedigreeDPTable::PedigreeDPTable (src/pedigreedptable.cpp:15-37), split in two so that
+ * a benchmark can time the device part alone:
+ *
+ *   whamd_dptable_create : ColumnIterator construction + validation (src/columniterator.cpp:10-59),
+ *                          ColumnIndexingScheme per column (src/columnindexingscheme.cpp:7-34,62-85),
+ *                          PedigreePartitions (src/pedigreepartitions.cpp:7-42), allele-assignment
+ *                          tables (src/pedigreecolumncostcomputer.cpp:14-50); uploads them to `device`.
+ *   whamd_dptable_solve  : compute_table() (src/pedigreedptable.cpp:84-174) on the device:
+ *                          forward pass over all columns, backtrace -> index path; then the host
+ *                          part of get_super_reads / get_optimal_partitioning is evaluated once and
+ *                          cached.  May be called repeatedly (re-solves from the uploaded input).
+ *
+ * recombcost has n_recombcost entries; the reference indexes recombcost[column] without a bounds
+ * check (src/pedigreedptable.cpp:289) -- here a missing tail is padded with the last given value
+ * (0 if empty).  positions == NULL means ReadSet::get_positions() (src/readset.cpp:54-62).
+ * Does NOT mutate the caller's ReadSet (the reference's reassignReadIds(), :24, has no
+ * counterpart on a view).
+ */
+whamd_status_t whamd_dptable_create(const whamd_readset_view* readset, const uint32_t* recombcost,
+                                    size_t n_recombcost, const whamd_pedigree_view* pedigree,
+                                    int distrust_genotypes, const uint32_t* positions, size_t n_positions,
+                                    int device, whamd_dptable** out);
+whamd_status_t whamd_dptable_solve(whamd_dptable* table);
+/* ~PedigreeDPTable (src/pedigreedptable.cpp:40-46) */
+void whamd_dptable_destroy(whamd_dptable* table);
+
+/* Shape queries (valid after create). */
+uint64_t whamd_dptable_column_count(const whamd_dptable* table);     /* ColumnIterator::get_column_count */
+uint32_t whamd_dptable_individual_count(const whamd_dptable* table); /* Pedigree::size */
+uint32_t whamd_dptable_read_count(const whamd_dptable* table);       /* ReadSet::size */
+/* positions[column_count]: ColumnIterator::get_positions (src/columniterator.cpp:81-83) */
+whamd_status_t whamd_dptable_positions(const whamd_dptable* table, uint32_t* positions_out);
+
+/* PedigreeDPTable::get_optimal_score (src/pedigreedptable.cpp:338-341). Valid after solve. */
+whamd_status_t whamd_dptable_get_optimal_score(const whamd_dptable* table, uint32_t* score_out);
+
+/*
+ * PedigreeDPTable::get_super_reads (src/pedigreedptable.cpp:344-388).  Instead of building Read
+ * objects the ABI returns their contents; the binding creates, per individual i (pedigree order),
+ * Read("superread_0_<i>", -1, -1, sample_id_out[i]) and Read("superread_1_<i>", ...) and adds, for
+ * column c, (positions[c], allele0_out[i*n + c], quality_out[i*n + c]) resp. allele1_out.
+ *   allele*_out  : [n_individuals * n_columns], values 0, 1 or 3 (EQUAL_SCORES)
+ *   quality_out  : [n_individuals * n_columns]
+ *   transmission_out : [n_columns]  (index_path[c].inheritance_value)
+ *   sample_id_out    : [n_individuals] (Pedigree::index_to_id)
+ * Any output pointer may be NULL to skip it.
+ */
+whamd_status_t whamd_dptable_get_super_reads(const whamd_dptable* table, uint8_t* allele0_out,
+                                             uint8_t* allele1_out, uint32_t* quality_out,
+                                             uint32_t* transmission_out, uint32_t* sample_id_out);
+
+/* PedigreeDPTable::get_optimal_partitioning (src/pedigreedptable.cpp:391-406) with the Cython
+ * post-processing of core.pyx:413-416 already applied: partition_out[r] in {0, 1} is the side
+ * (the bit) of read r; reads never active get 1. */
+whamd_status_t whamd_dptable_get_optimal_partitioning(const whamd_dptable* table, uint8_t* partition_out);
+
+/* The raw backtrace result (index_path, src/pedigreedptable.h:17-21,54): bipartition index and
+ * transmission value per column.  Not exposed by the reference's Cython layer; used by parity tests. */
+whamd_status_t whamd_dptable_get_index_path(const whamd_dptable* table, uint32_t* index_out,
+                                            uint32_t* transmission_out);
+
+/* Measurements of the last whamd_dptable_solve on this table. */
+whamd_status_t whamd_dptable_get_stats(const whamd_dptable* table, whamd_solve_stats* stats_out);
+
+/* Solver variant selection (for A/B measurements and tests): "auto" (default), "column" (one
+ * launch per column, the general path), or other names documented in DESIGN.md. */
+whamd_status_t whamd_dptable_set_option(whamd_dptable* table, const char* key, const char* value);
+
+/* The tie-break hash of ReadSet::sort (src/readset.h:39-66,76-82): std::hash<std::string>(name) ^
+ * std::hash<int>(source_id) of the libstdc++ this library is built against.  Used by the Python
+ * mirror of ReadSet.sort(); not part of the DP path. */
+uint64_t whamd_read_sort_hash(const char* name, int source_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WHATSHAP_AMD_H */

@@ -1,0 +1,323 @@
+"""ctypes binding of the C ABI in include/whatshap_amd.h.
+
+This is the *only* place the shared library is loaded.  There is no CPU fallback: if
+``libwhatshap_amd.so`` has not been built (``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C whatshap_amd/csrc``) importing this module raises, and creating a table on a machine
+without a HIP device raises ``RuntimeError`` from the library's own message.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwhatshap_amd.so")
+
+WHAMD_OK = 0
+WHAMD_ERR_INVALID = 1
+WHAMD_ERR_MENDELIAN_CONFLICT = 2
+WHAMD_ERR_UNSORTED = 3
+WHAMD_ERR_UNSUPPORTED = 4
+WHAMD_ERR_DEVICE = 5
+WHAMD_ERR_OVERFLOW = 6
+GT_OTHER = 255
+
+
+class ReadSetView(C.Structure):
+    _fields_ = [
+        ("n_reads", C.c_uint32),
+        ("read_ptr", C.POINTER(C.c_uint64)),
+        ("var_position", C.POINTER(C.c_int32)),
+        ("var_allele", C.POINTER(C.c_uint8)),
+        ("var_quality", C.POINTER(C.c_uint32)),
+        ("read_sample_id", C.POINTER(C.c_int32)),
+    ]
+
+
+class PedigreeView(C.Structure):
+    _fields_ = [
+        ("n_individuals", C.c_uint32),
+        ("individual_id", C.POINTER(C.c_uint32)),
+        ("n_triples", C.c_uint32),
+        ("triple_ids", C.POINTER(C.c_uint32)),
+        ("n_variants", C.c_uint32),
+        ("genotype", C.POINTER(C.c_uint8)),
+        ("genotype_likelihoods", C.POINTER(C.c_double)),
+        ("gl_present", C.POINTER(C.c_uint8)),
+    ]
+
+
+class SolveStats(C.Structure):
+    _fields_ = [
+        ("n_columns", C.c_uint64),
+        ("n_cells", C.c_uint64),
+        ("n_costs", C.c_uint64),
+        ("algorithmic_bytes", C.c_uint64),
+        ("forward_launches", C.c_uint64),
+        ("forward_ms", C.c_double),
+        ("backtrace_ms", C.c_double),
+        ("total_ms", C.c_double),
+        ("host_prepare_ms", C.c_double),
+        ("host_finish_ms", C.c_double),
+        ("max_coverage", C.c_uint32),
+        ("transmissions", C.c_uint32),
+    ]
+
+    def as_dict(self) -> dict:
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+def _ptr(arr: Optional[np.ndarray], ctype):
+    if arr is None:
+        return C.cast(None, C.POINTER(ctype))
+    return arr.ctypes.data_as(C.POINTER(ctype))
+
+
+class ProblemArrays:
+    """Owns the numpy arrays behind a (readset view, pedigree view, recombcost, positions) tuple.
+
+    The same object feeds the product library, the oracle restatement and the compiled reference
+    driver, so all three see byte-identical inputs.
+    """
+
+    def __init__(
+        self,
+        read_ptr,
+        var_position,
+        var_allele,
+        var_quality,
+        read_sample_id,
+        individual_id,
+        triple_ids,
+        genotype,
+        genotype_likelihoods,
+        recombcost,
+        positions,
+        distrust_genotypes: bool,
+        n_variants: Optional[int] = None,
+    ):
+        self.read_ptr = np.ascontiguousarray(read_ptr, dtype=np.uint64)
+        if self.read_ptr.size == 0:
+            self.read_ptr = np.zeros(1, dtype=np.uint64)
+        self.var_position = np.ascontiguousarray(var_position, dtype=np.int32)
+        self.var_allele = np.ascontiguousarray(var_allele, dtype=np.uint8)
+        self.var_quality = np.ascontiguousarray(var_quality, dtype=np.uint32)
+        self.read_sample_id = np.ascontiguousarray(read_sample_id, dtype=np.int32)
+        self.individual_id = np.ascontiguousarray(individual_id, dtype=np.uint32)
+        self.triple_ids = np.ascontiguousarray(triple_ids, dtype=np.uint32).reshape(-1)
+        n_ind = self.individual_id.size
+        genotype = np.ascontiguousarray(genotype, dtype=np.uint8)
+        if n_variants is None:
+            n_variants = genotype.size // n_ind if n_ind else 0
+        self.n_variants = int(n_variants)
+        self.genotype = genotype.reshape(-1)
+        assert self.genotype.size == n_ind * self.n_variants
+        if genotype_likelihoods is None:
+            self.genotype_likelihoods = None
+        else:
+            self.genotype_likelihoods = np.ascontiguousarray(genotype_likelihoods, dtype=np.float64).reshape(-1)
+            assert self.genotype_likelihoods.size == n_ind * self.n_variants * 3
+        self.recombcost = np.ascontiguousarray(recombcost, dtype=np.uint32)
+        self.positions = None if positions is None else np.ascontiguousarray(positions, dtype=np.uint32)
+        self.distrust_genotypes = bool(distrust_genotypes)
+        self.n_reads = self.read_sample_id.size
+        assert self.read_ptr.size == self.n_reads + 1
+
+        self.readset_view = ReadSetView(
+            self.n_reads,
+            _ptr(self.read_ptr, C.c_uint64),
+            _ptr(self.var_position, C.c_int32),
+            _ptr(self.var_allele, C.c_uint8),
+            _ptr(self.var_quality, C.c_uint32),
+            _ptr(self.read_sample_id, C.c_int32),
+        )
+        self.pedigree_view = PedigreeView(
+            n_ind,
+            _ptr(self.individual_id, C.c_uint32),
+            self.triple_ids.size // 3,
+            _ptr(self.triple_ids, C.c_uint32),
+            self.n_variants,
+            _ptr(self.genotype, C.c_uint8),
+            _ptr(self.genotype_likelihoods, C.c_double),
+            _ptr(None, C.c_uint8),
+        )
+
+    @property
+    def n_individuals(self) -> int:
+        return int(self.individual_id.size)
+
+    def call_args(self):
+        """(readset*, recombcost*, n_recomb, pedigree*, distrust, positions*, n_positions)"""
+        return (
+            C.byref(self.readset_view),
+            _ptr(self.recombcost, C.c_uint32),
+            C.c_size_t(self.recombcost.size),
+            C.byref(self.pedigree_view),
+            C.c_int(1 if self.distrust_genotypes else 0),
+            _ptr(self.positions, C.c_uint32),
+            C.c_size_t(0 if self.positions is None else self.positions.size),
+        )
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Loads libwhatshap_amd.so (once).  Raises if it is missing -- there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C whatshap_amd/csrc). "
+            "whatshap_amd has no CPU fallback."
+        )
+    L = C.CDLL(LIB_PATH)
+    H = C.c_void_p
+    L.whamd_abi_version.restype = C.c_int
+    L.whamd_device_count.restype = C.c_int
+    L.whamd_last_error.restype = C.c_char_p
+    L.whamd_dptable_create.restype = C.c_int
+    L.whamd_dptable_create.argtypes = [
+        C.POINTER(ReadSetView), C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(PedigreeView), C.c_int,
+        C.POINTER(C.c_uint32), C.c_size_t, C.c_int, C.POINTER(H),
+    ]
+    L.whamd_dptable_solve.restype = C.c_int
+    L.whamd_dptable_solve.argtypes = [H]
+    L.whamd_dptable_destroy.restype = None
+    L.whamd_dptable_destroy.argtypes = [H]
+    L.whamd_dptable_column_count.restype = C.c_uint64
+    L.whamd_dptable_column_count.argtypes = [H]
+    L.whamd_dptable_individual_count.restype = C.c_uint32
+    L.whamd_dptable_individual_count.argtypes = [H]
+    L.whamd_dptable_read_count.restype = C.c_uint32
+    L.whamd_dptable_read_count.argtypes = [H]
+    L.whamd_dptable_positions.restype = C.c_int
+    L.whamd_dptable_positions.argtypes = [H, C.POINTER(C.c_uint32)]
+    L.whamd_dptable_get_optimal_score.restype = C.c_int
+    L.whamd_dptable_get_optimal_score.argtypes = [H, C.POINTER(C.c_uint32)]
+    L.whamd_dptable_get_super_reads.restype = C.c_int
+    L.whamd_dptable_get_super_reads.argtypes = [
+        H, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+    ]
+    L.whamd_dptable_get_optimal_partitioning.restype = C.c_int
+    L.whamd_dptable_get_optimal_partitioning.argtypes = [H, C.POINTER(C.c_uint8)]
+    L.whamd_dptable_get_index_path.restype = C.c_int
+    L.whamd_dptable_get_index_path.argtypes = [H, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.whamd_dptable_get_stats.restype = C.c_int
+    L.whamd_dptable_get_stats.argtypes = [H, C.POINTER(SolveStats)]
+    L.whamd_dptable_set_option.restype = C.c_int
+    L.whamd_dptable_set_option.argtypes = [H, C.c_char_p, C.c_char_p]
+    L.whamd_read_sort_hash.restype = C.c_uint64
+    L.whamd_read_sort_hash.argtypes = [C.c_char_p, C.c_int]
+    if L.whamd_abi_version() != 1:
+        raise ImportError("libwhatshap_amd.so has an unexpected ABI version")
+    _lib = L
+    return L
+
+
+# every symbol include/whatshap_amd.h declares (tests check the library exports all of them)
+EXPORTED_SYMBOLS = [
+    "whamd_abi_version", "whamd_device_count", "whamd_last_error", "whamd_dptable_create", "whamd_dptable_solve",
+    "whamd_dptable_destroy", "whamd_dptable_column_count", "whamd_dptable_individual_count",
+    "whamd_dptable_read_count", "whamd_dptable_positions", "whamd_dptable_get_optimal_score",
+    "whamd_dptable_get_super_reads", "whamd_dptable_get_optimal_partitioning", "whamd_dptable_get_index_path",
+    "whamd_dptable_get_stats", "whamd_dptable_set_option", "whamd_read_sort_hash",
+]
+
+
+class SolverError(RuntimeError):
+    """RuntimeError with the library's status code attached (the reference raises plain RuntimeError)."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(message)
+        self.status = status
+
+
+def _check(status: int):
+    if status != WHAMD_OK:
+        raise SolverError(status, lib().whamd_last_error().decode("utf-8", "replace"))
+
+
+class NativeTable:
+    """Thin RAII wrapper of whamd_dptable: create -> (set_option) -> solve -> getters."""
+
+    def __init__(self, problem: ProblemArrays, device: int = 0, path: Optional[str] = None, solve: bool = True):
+        L = lib()
+        self._h = C.c_void_p()
+        self._problem = problem  # keep the arrays alive while create() reads them
+        _check(L.whamd_dptable_create(*problem.call_args(), C.c_int(device), C.byref(self._h)))
+        self.n_columns = int(L.whamd_dptable_column_count(self._h))
+        self.n_individuals = int(L.whamd_dptable_individual_count(self._h))
+        self.n_reads = int(L.whamd_dptable_read_count(self._h))
+        if path is not None:
+            self.set_option("path", path)
+        if solve:
+            self.solve()
+
+    def set_option(self, key: str, value: str):
+        _check(lib().whamd_dptable_set_option(self._h, key.encode(), value.encode()))
+
+    def solve(self):
+        _check(lib().whamd_dptable_solve(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().whamd_dptable_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def positions(self) -> np.ndarray:
+        out = np.zeros(self.n_columns, dtype=np.uint32)
+        _check(lib().whamd_dptable_positions(self._h, _ptr(out, C.c_uint32)))
+        return out
+
+    def optimal_score(self) -> int:
+        v = C.c_uint32()
+        _check(lib().whamd_dptable_get_optimal_score(self._h, C.byref(v)))
+        return int(v.value)
+
+    def super_reads(self):
+        n, ni = self.n_columns, self.n_individuals
+        a0 = np.zeros((ni, n), dtype=np.uint8)
+        a1 = np.zeros((ni, n), dtype=np.uint8)
+        q = np.zeros((ni, n), dtype=np.uint32)
+        tv = np.zeros(n, dtype=np.uint32)
+        sid = np.zeros(ni, dtype=np.uint32)
+        _check(lib().whamd_dptable_get_super_reads(
+            self._h, _ptr(a0, C.c_uint8), _ptr(a1, C.c_uint8), _ptr(q, C.c_uint32), _ptr(tv, C.c_uint32), _ptr(sid, C.c_uint32)))
+        return a0, a1, q, tv, sid
+
+    def partitioning(self) -> np.ndarray:
+        out = np.zeros(self.n_reads, dtype=np.uint8)
+        _check(lib().whamd_dptable_get_optimal_partitioning(self._h, _ptr(out, C.c_uint8)))
+        return out
+
+    def index_path(self):
+        idx = np.zeros(self.n_columns, dtype=np.uint32)
+        tv = np.zeros(self.n_columns, dtype=np.uint32)
+        _check(lib().whamd_dptable_get_index_path(self._h, _ptr(idx, C.c_uint32), _ptr(tv, C.c_uint32)))
+        return idx, tv
+
+    def stats(self) -> dict:
+        s = SolveStats()
+        _check(lib().whamd_dptable_get_stats(self._h, C.byref(s)))
+        return s.as_dict()
+
+
+def device_count() -> int:
+    return int(lib().whamd_device_count())
+
+
+def read_sort_hash(name: str, source_id: int) -> int:
+    return int(lib().whamd_read_sort_hash(name.encode("utf-8"), int(source_id)))

@@ -1,0 +1,169 @@
+// c_api.cpp -- the extern "C" boundary declared in include/whatshap_amd.h.
+#include <chrono>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <string>
+
+#include "device_table.h"
+#include "problem.h"
+
+using namespace whamd;
+
+struct whamd_dptable {
+	Problem problem;
+	Solution solution;
+	DeviceTable device;
+	whamd_solve_stats stats{};
+	int device_index = 0;
+	bool uploaded = false;
+	bool solved = false;
+	bool force_keys = false;
+};
+
+namespace {
+
+thread_local std::string g_last_error;
+
+whamd_status_t fail(whamd_status_t st, const std::string& msg) {
+	g_last_error = msg;
+	return st;
+}
+
+double now_ms() {
+	return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+extern "C" {
+
+int whamd_abi_version(void) { return WHAMD_ABI_VERSION; }
+
+int whamd_device_count(void) { return DeviceTable::device_count(); }
+
+const char* whamd_last_error(void) { return g_last_error.c_str(); }
+
+whamd_status_t whamd_dptable_create(const whamd_readset_view* readset, const uint32_t* recombcost,
+                                    size_t n_recombcost, const whamd_pedigree_view* pedigree,
+                                    int distrust_genotypes, const uint32_t* positions, size_t n_positions,
+                                    int device, whamd_dptable** out) {
+	if (!out) return fail(WHAMD_ERR_INVALID, "out is NULL");
+	*out = nullptr;
+	const double t0 = now_ms();
+	std::unique_ptr<whamd_dptable> t(new whamd_dptable());
+	std::string msg;
+	whamd_status_t st = build_problem(readset, recombcost, n_recombcost, pedigree, distrust_genotypes != 0,
+	                                  positions, n_positions, t->problem, msg);
+	if (st != WHAMD_OK) return fail(st, msg);
+	t->device_index = device;
+	st = t->device.upload(t->problem, device, msg);
+	if (st != WHAMD_OK) return fail(st, msg);
+	t->uploaded = true;
+	t->stats.host_prepare_ms = now_ms() - t0;
+	*out = t.release();
+	return WHAMD_OK;
+}
+
+whamd_status_t whamd_dptable_solve(whamd_dptable* t) {
+	if (!t) return fail(WHAMD_ERR_INVALID, "table is NULL");
+	std::string msg;
+	if (!t->uploaded) {
+		t->device.set_force_keys(t->force_keys);
+		whamd_status_t st = t->device.upload(t->problem, t->device_index, msg);
+		if (st != WHAMD_OK) return fail(st, msg);
+		t->uploaded = true;
+	}
+	const Problem& p = t->problem;
+	whamd_solve_stats& s = t->stats;
+	s.n_columns = p.n_cols;
+	s.n_cells = p.n_cells;
+	s.n_costs = p.n_cells * p.T;
+	s.algorithmic_bytes = p.algorithmic_bytes;
+	s.max_coverage = p.max_k;
+	s.transmissions = p.T;
+	whamd_status_t st = t->device.solve(p, t->solution, s, msg);
+	if (st != WHAMD_OK) return fail(st, msg);
+	const double t0 = now_ms();
+	st = finish_solution(p, t->solution, msg);
+	if (st != WHAMD_OK) return fail(st, msg);
+	s.host_finish_ms = now_ms() - t0;
+	t->solved = true;
+	return WHAMD_OK;
+}
+
+void whamd_dptable_destroy(whamd_dptable* t) { delete t; }
+
+uint64_t whamd_dptable_column_count(const whamd_dptable* t) { return t ? t->problem.n_cols : 0; }
+uint32_t whamd_dptable_individual_count(const whamd_dptable* t) { return t ? t->problem.n_ind : 0; }
+uint32_t whamd_dptable_read_count(const whamd_dptable* t) { return t ? t->problem.n_reads : 0; }
+
+whamd_status_t whamd_dptable_positions(const whamd_dptable* t, uint32_t* out) {
+	if (!t || !out) return fail(WHAMD_ERR_INVALID, "null argument");
+	std::memcpy(out, t->problem.positions.data(), t->problem.positions.size() * sizeof(uint32_t));
+	return WHAMD_OK;
+}
+
+#define REQUIRE_SOLVED(t)                                                            \
+	if (!(t)) return fail(WHAMD_ERR_INVALID, "table is NULL");                       \
+	if (!(t)->solved) return fail(WHAMD_ERR_INVALID, "whamd_dptable_solve has not run")
+
+whamd_status_t whamd_dptable_get_optimal_score(const whamd_dptable* t, uint32_t* score_out) {
+	REQUIRE_SOLVED(t);
+	*score_out = t->solution.optimal_score;
+	return WHAMD_OK;
+}
+
+whamd_status_t whamd_dptable_get_super_reads(const whamd_dptable* t, uint8_t* allele0_out, uint8_t* allele1_out,
+                                             uint32_t* quality_out, uint32_t* transmission_out,
+                                             uint32_t* sample_id_out) {
+	REQUIRE_SOLVED(t);
+	const Solution& s = t->solution;
+	if (allele0_out) std::memcpy(allele0_out, s.allele0.data(), s.allele0.size());
+	if (allele1_out) std::memcpy(allele1_out, s.allele1.data(), s.allele1.size());
+	if (quality_out) std::memcpy(quality_out, s.quality.data(), s.quality.size() * sizeof(uint32_t));
+	if (transmission_out) std::memcpy(transmission_out, s.path_trans.data(), s.path_trans.size() * sizeof(uint32_t));
+	if (sample_id_out) std::memcpy(sample_id_out, t->problem.individual_id.data(), t->problem.individual_id.size() * sizeof(uint32_t));
+	return WHAMD_OK;
+}
+
+whamd_status_t whamd_dptable_get_optimal_partitioning(const whamd_dptable* t, uint8_t* partition_out) {
+	REQUIRE_SOLVED(t);
+	std::memcpy(partition_out, t->solution.partition.data(), t->solution.partition.size());
+	return WHAMD_OK;
+}
+
+whamd_status_t whamd_dptable_get_index_path(const whamd_dptable* t, uint32_t* index_out, uint32_t* transmission_out) {
+	REQUIRE_SOLVED(t);
+	const Solution& s = t->solution;
+	if (index_out) std::memcpy(index_out, s.path_index.data(), s.path_index.size() * sizeof(uint32_t));
+	if (transmission_out) std::memcpy(transmission_out, s.path_trans.data(), s.path_trans.size() * sizeof(uint32_t));
+	return WHAMD_OK;
+}
+
+whamd_status_t whamd_dptable_get_stats(const whamd_dptable* t, whamd_solve_stats* stats_out) {
+	if (!t || !stats_out) return fail(WHAMD_ERR_INVALID, "null argument");
+	*stats_out = t->stats;
+	return WHAMD_OK;
+}
+
+whamd_status_t whamd_dptable_set_option(whamd_dptable* t, const char* key, const char* value) {
+	if (!t || !key || !value) return fail(WHAMD_ERR_INVALID, "null argument");
+	const std::string k(key), v(value);
+	if (k == "path") {
+		if (v == "auto" || v == "column") t->force_keys = false;
+		else if (v == "column_keys") t->force_keys = true;
+		else return fail(WHAMD_ERR_INVALID, "unknown path '" + v + "' (auto, column, column_keys)");
+		t->uploaded = false;  // descriptors are rebuilt at the next solve
+		return WHAMD_OK;
+	}
+	return fail(WHAMD_ERR_INVALID, "unknown option '" + k + "'");
+}
+
+// std::hash tie-break of ReadSet::sort (src/readset.h:52-55,78-82): exported so that the Python mirror of
+// ReadSet.sort() orders reads exactly like the reference built against the same libstdc++.
+uint64_t whamd_read_sort_hash(const char* name, int source_id) {
+	return (uint64_t)(std::hash<std::string>()(std::string(name)) ^ std::hash<int>()(source_id));
+}
+
+}  // extern "C"

@@ -1,0 +1,30 @@
+// device_table.h -- host-visible interface of the device driver (dp_device.hip).
+#pragma once
+#include <string>
+
+#include "device_types.h"
+#include "problem.h"
+
+namespace whamd {
+
+class DeviceTable {
+public:
+	DeviceTable();
+	~DeviceTable();
+	DeviceTable(const DeviceTable&) = delete;
+	DeviceTable& operator=(const DeviceTable&) = delete;
+
+	static int device_count();
+	// Builds the per-column descriptors for `p` and uploads everything the kernels read.
+	whamd_status_t upload(const Problem& p, int device, std::string& msg);
+	// Forward pass + backtrace on the device; fills s.path_*, s.optimal_score and the timing fields of st.
+	whamd_status_t solve(const Problem& p, Solution& s, whamd_solve_stats& st, std::string& msg);
+	// Route every column through the key (atomic) path; takes effect at the next upload().
+	void set_force_keys(bool v);
+
+private:
+	struct Impl;
+	Impl* impl_;
+};
+
+}  // namespace whamd

@@ -1,0 +1,45 @@
+// device_types.h -- plain structs shared between the host driver and the gfx950 kernels.
+#pragma once
+#include <cstdint>
+
+namespace whamd {
+
+// Per-column descriptor, read wave-uniformly (scalar loads) by every kernel.
+struct DevColumn {
+	uint32_t k;          // active reads (bits of a bipartition index)
+	uint32_t b;          // backward width: low b bits index the previous projection
+	uint32_t f;          // forward width: bits that survive into the next column (0 for the last column)
+	uint32_t recomb;     // recombcost[c]
+	uint32_t delta_off;  // into DevProblem::delta: [n_ind][k] signed per-bit deltas
+	uint32_t term_off;   // into DevProblem::term_ptr: T+1 offsets into DevProblem::terms
+	uint32_t seg_off;    // into DevProblem::segs: nseg_fwd forward segments, then nseg_end ending segments
+	uint16_t nseg_fwd, nseg_end;
+	uint32_t mode;       // 0: fused column step, bit-plane backtrace; 1: key (atomic) path, raw u32 backtrace
+	uint32_t ebits;      // k - f: reads that end in this column
+	uint32_t eloop;      // log2 of the ending-bit patterns each thread enumerates itself
+	uint32_t nplanes;    // mode 0: ebits + transmission bits
+	uint64_t bt_off;     // byte offset of this column's backtrace record in the arena
+	uint32_t is_last;
+	uint32_t pad;
+};
+
+struct DevTerm {
+	uint32_t c, plus, minus;
+};
+
+struct DevProblem {
+	const DevColumn* cols;
+	const int32_t* delta;
+	const uint32_t* term_ptr;
+	const DevTerm* terms;
+	const uint32_t* segs;   // packed: src_shift | dst_shift << 8 | len << 16
+	uint8_t* bt;            // backtrace arena
+	unsigned long long* keys;       // [2^max_f * T] scratch of the key path, all-ones between uses
+	unsigned long long* last_keys;  // [T] keys of the last column
+	uint32_t n_cols;
+	uint32_t T;
+	uint32_t tbits;         // 2 * triples
+	uint32_t n_ind;
+};
+
+}  // namespace whamd

@@ -1,0 +1,435 @@
+// problem.cpp -- host precompute for the device DP and host post-processing of its result.
+// See problem.h for the map to the reference's classes.
+#include "problem.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <unordered_map>
+
+namespace whamd {
+
+namespace {
+
+// Pedigree::id_to_index (src/pedigree.cpp:47-55): later insertions of the same id win.
+bool id_to_index(const Problem& p, uint32_t id, uint32_t& index, std::string& msg) {
+	for (uint32_t i = p.n_ind; i-- > 0;) {
+		if (p.individual_id[i] == id) {
+			index = i;
+			return true;
+		}
+	}
+	msg = "Individual with ID " + std::to_string(id) + " not present in pedigree.";
+	return false;
+}
+
+// PedigreePartitions (src/pedigreepartitions.cpp:7-42): founders get partitions (2r, 2r+1) in
+// individual order; a child's haplotype 0 is the father's haplotype !(t >> 2*trio & 1), haplotype 1
+// the mother's haplotype !(t >> (2*trio+1) & 1).
+bool build_partitions(Problem& p, std::string& msg) {
+	p.P = 2 * (p.n_ind - p.n_triples);
+	p.h2p.assign((size_t)p.T * p.n_ind * 2, -1);
+	std::vector<int> child_triple(p.n_ind, -1);
+	for (uint32_t i = 0; i < p.n_triples; ++i) child_triple[p.triples[i][2]] = (int)i;
+	// resolution order: parents before children (the reference recurses; a cycle would recurse forever there)
+	std::vector<uint32_t> order;
+	std::vector<uint8_t> state(p.n_ind, 0);
+	for (uint32_t root = 0; root < p.n_ind; ++root) {
+		std::vector<std::pair<uint32_t, int>> stack{{root, 0}};
+		while (!stack.empty()) {
+			auto [i, phase] = stack.back();
+			stack.pop_back();
+			if (state[i] == 2) continue;
+			if (phase == 1) {
+				state[i] = 2;
+				order.push_back(i);
+				continue;
+			}
+			if (state[i] == 1) {
+				msg = "pedigree relationships contain a cycle";
+				return false;
+			}
+			state[i] = 1;
+			stack.push_back({i, 1});
+			if (child_triple[i] >= 0) {
+				stack.push_back({p.triples[child_triple[i]][1], 0});
+				stack.push_back({p.triples[child_triple[i]][0], 0});
+			}
+		}
+	}
+	for (uint32_t t = 0; t < p.T; ++t) {
+		int8_t* map = p.h2p.data() + (size_t)t * p.n_ind * 2;
+		int next = 0;
+		for (uint32_t i = 0; i < p.n_ind; ++i) {
+			if (child_triple[i] < 0) {
+				map[2 * i] = (int8_t)next;
+				map[2 * i + 1] = (int8_t)(next + 1);
+				next += 2;
+			}
+		}
+		for (uint32_t i : order) {
+			int ti = child_triple[i];
+			if (ti < 0) continue;
+			uint32_t father = p.triples[ti][0], mother = p.triples[ti][1];
+			map[2 * i] = map[2 * father + (((t >> (2 * ti)) & 1) ? 0 : 1)];
+			map[2 * i + 1] = map[2 * mother + (((t >> (2 * ti + 1)) & 1) ? 0 : 1)];
+		}
+	}
+	return true;
+}
+
+}  // namespace
+
+whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recombcost, size_t n_recombcost,
+                             const whamd_pedigree_view* ped, bool distrust, const uint32_t* positions,
+                             size_t n_positions, Problem& p, std::string& msg) {
+	if (!rs || !ped) {
+		msg = "null readset or pedigree view";
+		return WHAMD_ERR_INVALID;
+	}
+	// ---- copy the views
+	p.n_reads = rs->n_reads;
+	const uint64_t nnz = rs->n_reads ? rs->read_ptr[rs->n_reads] : 0;
+	p.read_ptr.assign(rs->n_reads + 1, 0);
+	if (rs->n_reads) std::copy(rs->read_ptr, rs->read_ptr + rs->n_reads + 1, p.read_ptr.begin());
+	p.var_position.assign(rs->var_position, rs->var_position + nnz);
+	p.var_allele.assign(rs->var_allele, rs->var_allele + nnz);
+	p.var_quality.assign(rs->var_quality, rs->var_quality + nnz);
+	for (uint64_t i = 0; i < nnz; ++i) {
+		if (p.var_allele[i] > 1) {  // Entry::allele_t other than REF/ALT asserts in the reference (pedigreecolumncostcomputer.cpp:71-72)
+			msg = "read allele must be 0 (REF) or 1 (ALT)";
+			return WHAMD_ERR_INVALID;
+		}
+	}
+	p.n_ind = ped->n_individuals;
+	p.n_triples = ped->n_triples;
+	p.n_variants = ped->n_variants;
+	p.individual_id.assign(ped->individual_id, ped->individual_id + p.n_ind);
+	const size_t ng = (size_t)p.n_ind * p.n_variants;
+	if (ng) p.genotype.assign(ped->genotype, ped->genotype + ng);
+	p.have_gl = ped->genotype_likelihoods != nullptr;
+	if (p.have_gl && ng) {
+		p.gl.assign(ped->genotype_likelihoods, ped->genotype_likelihoods + ng * 3);
+		if (ped->gl_present) {
+			for (size_t i = 0; i < ng; ++i) {
+				if (!ped->gl_present[i]) p.gl[3 * i] = p.gl[3 * i + 1] = p.gl[3 * i + 2] = std::nan("");
+			}
+		}
+	}
+	p.distrust = distrust;
+	p.triples.resize(p.n_triples);
+	for (uint32_t i = 0; i < p.n_triples; ++i) {
+		for (int m = 0; m < 3; ++m) {
+			if (!id_to_index(p, ped->triple_ids[3 * i + m], p.triples[i][m], msg)) return WHAMD_ERR_INVALID;
+		}
+	}
+	if (p.n_triples > 2 || p.n_ind > (uint32_t)MAX_IND) {
+		msg = "pedigree too large for the device path (at most " + std::to_string(MAX_IND) + " individuals and 2 trios)";
+		return WHAMD_ERR_UNSUPPORTED;
+	}
+	p.T = 1u << (2 * p.n_triples);
+
+	// ---- ColumnIterator::ColumnIterator (src/columniterator.cpp:10-59): positions + validation
+	if (positions == nullptr) {  // ReadSet::get_positions (src/readset.cpp:54-62)
+		p.positions.resize(nnz);
+		for (uint64_t i = 0; i < nnz; ++i) p.positions[i] = (uint32_t)p.var_position[i];
+		std::sort(p.positions.begin(), p.positions.end());
+		p.positions.erase(std::unique(p.positions.begin(), p.positions.end()), p.positions.end());
+	} else {
+		p.positions.assign(positions, positions + n_positions);
+	}
+	p.n_cols = (uint32_t)p.positions.size();
+	const uint32_t n = p.n_cols;
+	std::unordered_map<uint32_t, uint32_t> position_map;  // later duplicates win, as position_map[pos] = i does
+	position_map.reserve(n * 2 + 1);
+	for (uint32_t i = 0; i < n; ++i) position_map[p.positions[i]] = i;
+	std::vector<uint32_t> first_col(p.n_reads), last_col(p.n_reads);
+	int pos = 0;
+	for (uint32_t r = 0; r < p.n_reads; ++r) {
+		const uint64_t lo = p.read_ptr[r], hi = p.read_ptr[r + 1];
+		if (hi <= lo) {  // Read::firstPosition (src/read.cpp:75-78)
+			msg = "No variants present";
+			return WHAMD_ERR_INVALID;
+		}
+		if (p.var_position[lo] < pos) {
+			msg = "ColumnIterator: reads in ReadSet are not sorted.";
+			return WHAMD_ERR_UNSORTED;
+		}
+		for (uint64_t i = lo + 1; i < hi; ++i) {  // Read::isSorted (src/read.cpp:210-218): strictly increasing
+			if (!(p.var_position[i - 1] < p.var_position[i])) {
+				msg = "ColumnIterator: encountered read with unsorted variants.";
+				return WHAMD_ERR_UNSORTED;
+			}
+		}
+		auto fi = position_map.find((uint32_t)p.var_position[lo]);
+		auto li = position_map.find((uint32_t)p.var_position[hi - 1]);
+		if (p.var_position[lo] < 0 || fi == position_map.end() || li == position_map.end() || fi->second > li->second) {
+			// the reference asserts here (src/columniterator.cpp:36-39) and aborts the process
+			msg = "read " + std::to_string(r) + " starts or ends at a position that is not in the position list";
+			return WHAMD_ERR_INVALID;
+		}
+		first_col[r] = fi->second;
+		last_col[r] = li->second;
+		pos = p.var_position[lo];
+	}
+	for (uint32_t i = 1; i < n; ++i) {
+		if (!(p.positions[i - 1] < p.positions[i])) {
+			msg = "positions must be strictly increasing";
+			return WHAMD_ERR_INVALID;
+		}
+	}
+	// read -> individual (src/pedigreedptable.cpp:32-34)
+	p.read_source.resize(p.n_reads);
+	for (uint32_t r = 0; r < p.n_reads; ++r) {
+		if (!id_to_index(p, (uint32_t)rs->read_sample_id[r], p.read_source[r], msg)) return WHAMD_ERR_INVALID;
+	}
+	if (n && p.n_ind && p.n_variants < n) {
+		msg = "pedigree has fewer variants (" + std::to_string(p.n_variants) + ") than there are columns (" + std::to_string(n) + ")";
+		return WHAMD_ERR_INVALID;
+	}
+	if (n && p.n_ind && distrust) {
+		bool ok = p.have_gl;
+		for (uint32_t i = 0; ok && i < p.n_ind; ++i) {
+			for (uint32_t c = 0; ok && c < n; ++c) {
+				for (int g = 0; g < 3; ++g) {
+					const double v = p.gl[((size_t)i * p.n_variants + c) * 3 + g];
+					if (!(v >= 0.0 && v <= 1e9)) ok = false;  // also rejects NaN (= missing GL; the reference asserts gls != nullptr)
+				}
+			}
+		}
+		if (!ok) {
+			msg = "distrust_genotypes requires genotype likelihoods in [0, 1e9] for every individual and column";
+			return WHAMD_ERR_INVALID;
+		}
+	}
+	// recombination costs, padded (see include/whatshap_amd.h)
+	p.recomb.assign(n, n_recombcost ? recombcost[n_recombcost - 1] : 0u);
+	for (uint32_t c = 0; c < n && c < n_recombcost; ++c) p.recomb[c] = recombcost[c];
+
+	if (!build_partitions(p, msg)) return WHAMD_ERR_INVALID;
+	if (n == 0) return WHAMD_OK;
+
+	// ---- columns (ColumnIterator::get_next, src/columniterator.cpp:91-139): read r is active in
+	// columns first_col[r]..last_col[r]; entries in read-index order; BLANK where the read has no variant.
+	p.col_ptr.assign(n + 1, 0);
+	for (uint32_t r = 0; r < p.n_reads; ++r) {
+		for (uint32_t c = first_col[r]; c <= last_col[r]; ++c) p.col_ptr[c + 1]++;
+	}
+	for (uint32_t c = 0; c < n; ++c) {
+		if (p.col_ptr[c + 1] > (uint64_t)MAX_COVERAGE) {
+			msg = "coverage " + std::to_string(p.col_ptr[c + 1]) + " at column " + std::to_string(c) + " exceeds the device limit of " + std::to_string(MAX_COVERAGE);
+			return WHAMD_ERR_UNSUPPORTED;
+		}
+		p.col_ptr[c + 1] += p.col_ptr[c];
+	}
+	p.entries.resize(p.col_ptr[n]);
+	{
+		std::vector<uint64_t> fill(p.col_ptr.begin(), p.col_ptr.end() - 1);
+		for (uint32_t r = 0; r < p.n_reads; ++r) {
+			uint64_t v = p.read_ptr[r];
+			for (uint32_t c = first_col[r]; c <= last_col[r]; ++c) {
+				const int cpos = (int)p.positions[c];
+				while (p.var_position[v] < cpos) ++v;
+				ColumnEntry& e = p.entries[fill[c]++];
+				e.read_id = r;
+				e.sample = (uint8_t)p.read_source[r];
+				if (p.var_position[v] == cpos) {
+					e.allele = p.var_allele[v];
+					e.phred = p.var_quality[v];
+				} else {
+					e.allele = WHAMD_ALLELE_BLANK;
+					e.phred = 0;
+				}
+			}
+		}
+	}
+	// ---- ColumnIndexingScheme: k, backward width b, forward mask / width f
+	p.k.resize(n);
+	p.b.resize(n);
+	p.f.resize(n);
+	p.fwd_mask.assign(n, 0);
+	for (uint32_t c = 0; c < n; ++c) {
+		const ColumnEntry* cur = p.col_begin(c);
+		const uint32_t kc = (uint32_t)(p.col_ptr[c + 1] - p.col_ptr[c]);
+		p.k[c] = (uint8_t)kc;
+		p.max_k = std::max(p.max_k, kc);
+		uint32_t bw = 0;
+		if (c > 0) {  // merge of the two sorted id lists (src/columnindexingscheme.cpp:19-33)
+			const ColumnEntry* prev = p.col_begin(c - 1);
+			const uint32_t kp = p.k[c - 1];
+			uint32_t i = 0, j = 0, mask = 0;
+			while (i < kp && j < kc) {
+				if (prev[i].read_id == cur[j].read_id) {
+					mask |= 1u << i;
+					++bw; ++i; ++j;
+				} else if (prev[i].read_id < cur[j].read_id) ++i; else ++j;
+			}
+			p.fwd_mask[c - 1] = mask;
+			p.f[c - 1] = (uint8_t)bw;
+			// shared reads are exactly the low bw bits of column c (they started earlier than any new read)
+			for (uint32_t q = 0; q < bw; ++q) {
+				if (q >= kc) { msg = "internal: shared reads are not a prefix"; return WHAMD_ERR_INVALID; }
+			}
+		}
+		p.b[c] = (uint8_t)bw;
+	}
+	p.f[n - 1] = 0;  // last column: everything is minimised out (global optimum, src/pedigreedptable.cpp:306-315)
+	p.fwd_mask[n - 1] = 0;
+
+	// ---- per-bit deltas and cost terms
+	p.delta.assign((size_t)p.col_ptr[n] * std::max<uint32_t>(p.n_ind, 1), 0);
+	p.term_ptr.assign((size_t)n * p.T + 1, 0);
+	p.terms.clear();
+	p.terms.reserve((size_t)n * p.T * 2);
+	double bound = 0.0;  // upper bound on any DP value, to rule out 32-bit wrap-around
+	std::vector<uint32_t> R(p.n_ind), W(p.n_ind);
+	for (uint32_t c = 0; c < n; ++c) {
+		const ColumnEntry* col = p.col_begin(c);
+		const uint32_t kc = p.k[c];
+		std::fill(R.begin(), R.end(), 0u);
+		std::fill(W.begin(), W.end(), 0u);
+		int32_t* dl = p.delta.data() + (size_t)p.col_ptr[c] * p.n_ind;
+		double wsum = 0.0;
+		for (uint32_t j = 0; j < kc; ++j) {
+			const ColumnEntry& e = col[j];
+			if (e.allele == WHAMD_ALLELE_BLANK) continue;
+			W[e.sample] += e.phred;
+			wsum += e.phred;
+			if (e.allele == WHAMD_ALLELE_ALT) {
+				R[e.sample] += e.phred;
+				dl[(size_t)e.sample * kc + j] = (int32_t)(0u - e.phred);
+			} else {
+				dl[(size_t)e.sample * kc + j] = (int32_t)e.phred;
+			}
+		}
+		double max_acost = 0.0;
+		bool any = false;
+		for (uint32_t t = 0; t < p.T; ++t) {
+			const int8_t* map = p.h2p.data() + (size_t)t * p.n_ind * 2;
+			const size_t begin = p.terms.size();
+			for (uint32_t a = 0; a < (1u << p.P); ++a) {  // src/pedigreecolumncostcomputer.cpp:25-49
+				bool compatible = true;
+				uint32_t acost = 0;
+				CostTerm term{0, 0, 0};
+				for (uint32_t s = 0; s < p.n_ind; ++s) {
+					const uint32_t a0 = (a >> map[2 * s]) & 1, a1 = (a >> map[2 * s + 1]) & 1;
+					const size_t gi = (size_t)s * p.n_variants + c;
+					if (distrust) {
+						acost = (uint32_t)((double)acost + p.gl[gi * 3 + a0 + a1]);  // `cost += gls->get(genotype)` on an unsigned, :37
+					} else if (p.genotype[gi] != a0 + a1) {
+						compatible = false;
+						break;
+					}
+					// cost of individual s if haplotype 0 carries a0 and haplotype 1 carries a1:
+					//   (0,0): R_s   (1,1): W_s - R_s   (0,1): R_s + L_s(x)   (1,0): W_s - R_s - L_s(x)
+					if (a0 == 0 && a1 == 0) term.c += R[s];
+					else if (a0 == 1 && a1 == 1) term.c += W[s] - R[s];
+					else if (a0 == 0) { term.c += R[s]; term.plus |= 1u << s; }
+					else { term.c += W[s] - R[s]; term.minus |= 1u << s; }
+				}
+				if (!compatible) continue;
+				term.c += acost;
+				max_acost = std::max(max_acost, (double)acost);
+				// a term with the same L-dependence and a constant that is not smaller can never be the strict minimum
+				bool dominated = false;
+				for (size_t q = begin; q < p.terms.size(); ++q) {
+					if (p.terms[q].plus == term.plus && p.terms[q].minus == term.minus) {
+						if (term.c < p.terms[q].c) p.terms[q].c = term.c;
+						dominated = true;
+						break;
+					}
+				}
+				if (!dominated) p.terms.push_back(term);
+			}
+			if (p.terms.size() > begin) any = true;
+			p.term_ptr[(size_t)c * p.T + t + 1] = p.terms.size();
+		}
+		if (!any) {  // every transmission value infeasible at every cell (src/pedigreedptable.cpp:301-303)
+			msg = "Error: Mendelian conflict";
+			return WHAMD_ERR_MENDELIAN_CONFLICT;
+		}
+		bound += wsum + max_acost + 2.0 * p.n_triples * (double)p.recomb[c];
+		const uint64_t Tl = p.T;
+		p.n_cells += 1ull << kc;
+		p.algorithmic_bytes += (c > 0 ? 4 * Tl * (1ull << p.b[c]) : 0) + (c + 1 < n ? 12 * Tl * (1ull << p.f[c]) : 0) + 12ull * kc;
+	}
+	if (bound >= 4294967295.0) {
+		msg = "costs may exceed 32 bits (upper bound " + std::to_string(bound) + "); the reference's unsigned arithmetic wraps there and results are undefined";
+		return WHAMD_ERR_OVERFLOW;
+	}
+	return WHAMD_OK;
+}
+
+// get_super_reads / get_alleles / get_optimal_partitioning on the host from the finished path.
+whamd_status_t finish_solution(const Problem& p, Solution& s, std::string& msg) {
+	const uint32_t n = p.n_cols;
+	s.allele0.assign((size_t)p.n_ind * n, 0);
+	s.allele1.assign((size_t)p.n_ind * n, 0);
+	s.quality.assign((size_t)p.n_ind * n, 0);
+	s.partition.assign(p.n_reads, 1);
+	std::vector<std::array<uint32_t, 2>> cp(std::max<uint32_t>(p.P, 1));
+	std::vector<std::array<uint32_t, 4>> best_for(std::max<uint32_t>(p.n_ind, 1));  // [ind][hap*2 + allele]
+	for (uint32_t c = 0; c < n; ++c) {
+		const uint32_t x = s.path_index[c], t = s.path_trans[c];
+		const ColumnEntry* col = p.col_begin(c);
+		const uint32_t kc = p.k[c];
+		const int8_t* map = p.h2p.data() + (size_t)t * p.n_ind * 2;
+		// partitioning: read is in partition 0 wherever its bit is 0 (src/pedigreedptable.cpp:398-400, core.pyx:414)
+		for (uint32_t j = 0; j < kc; ++j) {
+			if (((x >> j) & 1u) == 0) s.partition[col[j].read_id] = 0;
+		}
+		// set_partitioning (src/pedigreecolumncostcomputer.cpp:53-76)
+		for (auto& v : cp) v = {0, 0};
+		for (uint32_t j = 0; j < kc; ++j) {
+			const ColumnEntry& e = col[j];
+			const int part = map[2 * e.sample + ((x >> j) & 1u)];
+			if (e.allele == WHAMD_ALLELE_REF) cp[part][1] += e.phred;
+			else if (e.allele == WHAMD_ALLELE_ALT) cp[part][0] += e.phred;
+		}
+		// get_alleles (src/pedigreecolumncostcomputer.cpp:117-175)
+		uint32_t best = INF;
+		for (auto& v : best_for) v = {INF, INF, INF, INF};
+		uint32_t best_a = 0;
+		bool have = false;
+		for (uint32_t a = 0; a < (1u << p.P); ++a) {
+			bool compatible = true;
+			uint32_t cost = 0;
+			for (uint32_t i = 0; i < p.n_ind; ++i) {
+				const uint32_t a0 = (a >> map[2 * i]) & 1, a1 = (a >> map[2 * i + 1]) & 1;
+				const size_t gi = (size_t)i * p.n_variants + c;
+				if (p.distrust) cost = (uint32_t)((double)cost + p.gl[gi * 3 + a0 + a1]);
+				else if (p.genotype[gi] != a0 + a1) { compatible = false; break; }
+			}
+			if (!compatible) continue;
+			for (uint32_t q = 0; q < p.P; ++q) cost += cp[q][(a >> q) & 1];
+			if (cost <= best) {  // `<=`: the last minimal assignment wins (:131)
+				best = cost;
+				best_a = a;
+				have = true;
+			}
+			for (uint32_t i = 0; i < p.n_ind; ++i) {
+				const uint32_t a0 = (a >> map[2 * i]) & 1, a1 = (a >> map[2 * i + 1]) & 1;
+				best_for[i][a0] = std::min(best_for[i][a0], cost);
+				best_for[i][2 + a1] = std::min(best_for[i][2 + a1], cost);
+			}
+		}
+		if (!have || best == INF) {
+			msg = "Error: Mendelian conflict";
+			return WHAMD_ERR_MENDELIAN_CONFLICT;
+		}
+		for (uint32_t i = 0; i < p.n_ind; ++i) {
+			uint8_t a0 = (uint8_t)((best_a >> map[2 * i]) & 1), a1 = (uint8_t)((best_a >> map[2 * i + 1]) & 1);
+			const int q0 = std::abs((int)best_for[i][0] - (int)best_for[i][1]);
+			const int q1 = std::abs((int)best_for[i][2] - (int)best_for[i][3]);
+			if (q0 == 0) a0 = WHAMD_ALLELE_EQUAL_SCORES;
+			if (q1 == 0) a1 = WHAMD_ALLELE_EQUAL_SCORES;
+			s.allele0[(size_t)i * n + c] = a0;
+			s.allele1[(size_t)i * n + c] = a1;
+			s.quality[(size_t)i * n + c] = (uint32_t)q1;  // only the haplotype-1 value survives (:162-163)
+		}
+	}
+	return WHAMD_OK;
+}
+
+}  // namespace whamd

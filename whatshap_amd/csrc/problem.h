@@ -1,0 +1,97 @@
+// problem.h -- host-side model of one PedigreeDPTable instance: the flattened ReadSet (columns in
+// CSR form), the per-column indexing scheme, the pedigree partitions and the per-column cost terms.
+// Everything here is precomputed once on the host and uploaded; the device never sees Read/Entry objects.
+//
+// Reference counterparts (whatshap/whatshap @ 2025-07-11):
+//   ColumnIterator            src/columniterator.cpp:10-59,91-169   -> build_columns()
+//   ColumnIndexingScheme      src/columnindexingscheme.cpp:7-34,62-85 -> k/b/f/forward mask per column
+//   PedigreePartitions        src/pedigreepartitions.cpp:7-42        -> h2p
+//   PedigreeColumnCostComputer ctor  src/pedigreecolumncostcomputer.cpp:14-50 -> cost terms
+#pragma once
+
+#include <array>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/whatshap_amd.h"
+
+namespace whamd {
+
+constexpr uint32_t INF = 0xFFFFFFFFu;
+constexpr int MAX_COVERAGE = 25;   // device limit on reads per column (the CLI caps at 23, cli/phase.py:1181)
+constexpr int MAX_IND = 6;         // individuals per pedigree on the device path
+constexpr int MAX_T = 16;          // transmission values = 4^triples (<= 2 trios)
+
+struct ColumnEntry {  // Entry (src/entry.h) plus the individual index of its read
+	uint32_t read_id;
+	uint32_t phred;
+	uint8_t allele;  // 0 REF, 1 ALT, 2 BLANK
+	uint8_t sample;  // individual index (read_sources, src/pedigreedptable.cpp:32-34)
+};
+
+// One candidate of min_a in get_cost() (src/pedigreecolumncostcomputer.cpp:101-114), rewritten
+// per individual: value(x) = c + sum_s sigma_s * L_s(x), sigma in {-1, 0, +1}, where
+// L_s(x) = sum over the set bits of x that belong to reads of individual s of d_bit, d = +q (REF),
+// -q (ALT), 0 (BLANK)  (DESIGN.md "cost closed form").
+struct CostTerm {
+	uint32_t c;      // constant part (u32, modular)
+	uint32_t plus;   // bit s set: + L_s(x)
+	uint32_t minus;  // bit s set: - L_s(x)
+};
+
+struct Problem {
+	// ---- inputs (copied from the views)
+	uint32_t n_reads = 0;
+	std::vector<uint64_t> read_ptr;
+	std::vector<int32_t> var_position;
+	std::vector<uint8_t> var_allele;
+	std::vector<uint32_t> var_quality;
+	std::vector<uint32_t> read_source;
+	uint32_t n_ind = 0, n_triples = 0, n_variants = 0;
+	std::vector<uint32_t> individual_id;
+	std::vector<std::array<uint32_t, 3>> triples;  // by individual index
+	std::vector<uint8_t> genotype;
+	std::vector<double> gl;
+	bool have_gl = false;
+	bool distrust = false;
+	std::vector<uint32_t> recomb;     // padded to n_cols
+	std::vector<uint32_t> positions;  // n_cols
+	// ---- derived
+	uint32_t n_cols = 0;
+	uint32_t T = 1, P = 0;
+	std::vector<int8_t> h2p;  // [T][n_ind][2]
+	std::vector<uint64_t> col_ptr;  // [n_cols + 1]
+	std::vector<ColumnEntry> entries;
+	std::vector<uint8_t> k, b, f;        // per column
+	std::vector<uint32_t> fwd_mask;      // per column: bits of reads that continue into the next column
+	// cost terms per (column, transmission value)
+	std::vector<uint64_t> term_ptr;  // [n_cols * T + 1] offsets into terms
+	std::vector<CostTerm> terms;
+	// per column and individual: signed per-bit deltas d (REF +q, ALT -q, BLANK 0) of L_s(x) - R_s
+	std::vector<int32_t> delta;  // [col_ptr[c] * n_ind ... ): for column c, delta[(col_ptr[c] * n_ind) + s * k_c + bit]
+	uint32_t max_k = 0;
+	uint64_t n_cells = 0, algorithmic_bytes = 0;
+
+	const ColumnEntry* col_begin(uint32_t c) const { return entries.data() + col_ptr[c]; }
+	uint64_t term_begin(uint32_t c, uint32_t t) const { return term_ptr[(size_t)c * T + t]; }
+	uint64_t term_end(uint32_t c, uint32_t t) const { return term_ptr[(size_t)c * T + t + 1]; }
+};
+
+// Builds the problem; on failure returns a status != WHAMD_OK and sets msg.
+whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recombcost, size_t n_recombcost,
+                             const whamd_pedigree_view* ped, bool distrust, const uint32_t* positions,
+                             size_t n_positions, Problem& out, std::string& msg);
+
+// Host part of get_super_reads (src/pedigreedptable.cpp:344-388 + get_alleles,
+// src/pedigreecolumncostcomputer.cpp:117-175) and get_optimal_partitioning (:391-406) from a finished path.
+struct Solution {
+	uint32_t optimal_score = 0;
+	std::vector<uint32_t> path_index, path_trans;  // n_cols
+	std::vector<uint8_t> allele0, allele1;         // [n_ind * n_cols]
+	std::vector<uint32_t> quality;                 // [n_ind * n_cols]
+	std::vector<uint8_t> partition;                // [n_reads]
+};
+whamd_status_t finish_solution(const Problem& p, Solution& s, std::string& msg);
+
+}  // namespace whamd

@@ -1,0 +1,169 @@
+"""Seeded synthetic ReadSets for benchmarks and parity tests.
+
+``synthetic_block`` is the workload of BASELINE.json's configs 2-5: positions 1000*(i+1), two
+complementary haplotypes, reads spanning ``step*coverage`` consecutive variants with a new read every
+``step`` variants (steady-state coverage == ``coverage``), 2 % allele errors, phred ~ U{5..40}, 10 % of
+interior positions dropped (BLANK entries).  ``random_small_instance`` is the tie-heavy generator of
+SURVEY.md Appendix A used to pin tie-breaking.
+
+Everything is returned as ``whatshap_amd._native.ProblemArrays`` (the arrays behind the C-ABI views).
+"""
+
+from __future__ import annotations
+
+import math
+import random
+from typing import List, Optional
+
+import numpy as np
+
+from ._native import ProblemArrays
+
+
+def centimorgen_to_phred(distance: float) -> float:
+    """whatshap/pedigree.py:240-250."""
+    if distance == 0:
+        raise ValueError("Cannot convert genetic distance of zero to phred.")
+    if distance < 1e-10:
+        return -10.0 * (math.log10(distance) - 2.0)
+    p = (1.0 - math.exp(-(2.0 * distance) / 100.0)) / 2.0
+    return -10.0 * math.log10(p)
+
+
+def uniform_recombination_costs(positions, recombrate: float = 1.26) -> np.ndarray:
+    """UniformRecombinationCostComputer (whatshap/pedigree.py:104-122)."""
+    positions = np.asarray(positions, dtype=np.int64)
+    out = np.zeros(positions.size, dtype=np.uint32)
+    for i in range(1, positions.size):
+        out[i] = round(centimorgen_to_phred((positions[i] - positions[i - 1]) * 1e-6 * recombrate))
+    return out
+
+
+def synthetic_block(n_variants: int, coverage: int, seed: int, step: int = 2, trio: bool = False,
+                    distrust_genotypes: bool = False, error_rate: float = 0.02, drop_rate: float = 0.10,
+                    n_columns_limit: Optional[int] = None) -> ProblemArrays:
+    """One connected phasing block.  ``n_columns_limit`` keeps only the first columns of the SAME
+    ReadSet (reads are clipped to the prefix), for bounded CPU-baseline samples."""
+    rng = np.random.default_rng(seed)
+    n = int(n_variants)
+    hap = rng.integers(0, 2, size=n, dtype=np.uint8)  # haplotype 0; haplotype 1 is its complement
+    span = step * coverage
+    starts = np.arange(0, n, step, dtype=np.int64)
+    ends = np.minimum(starts + span, n)
+    keep = (ends - starts) >= 2
+    starts, ends = starts[keep], ends[keep]
+    n_reads = starts.size
+    lengths = (ends - starts).astype(np.int64)
+    read_of = np.repeat(np.arange(n_reads), lengths)
+    offs = np.arange(lengths.sum()) - np.repeat(np.cumsum(lengths) - lengths, lengths)
+    var_idx = np.repeat(starts, lengths) + offs
+    read_hap = rng.integers(0, 2, size=n_reads, dtype=np.uint8)
+    allele = hap[var_idx] ^ read_hap[read_of]
+    flip = rng.random(allele.size) < error_rate
+    allele = (allele ^ flip.astype(np.uint8)).astype(np.uint8)
+    quality = rng.integers(5, 41, size=allele.size, dtype=np.uint32)
+    interior = (offs > 0) & (offs < np.repeat(lengths, lengths) - 1)
+    dropped = interior & (rng.random(allele.size) < drop_rate)
+    if n_columns_limit is not None and n_columns_limit < n:
+        dropped |= var_idx >= n_columns_limit
+        # the last kept variant of a clipped read must exist in the prefix: un-drop it
+        last_in_prefix = (var_idx == n_columns_limit - 1)
+        dropped &= ~last_in_prefix
+    keepv = ~dropped
+    read_of, var_idx, allele, quality = read_of[keepv], var_idx[keepv], allele[keepv], quality[keepv]
+    counts = np.bincount(read_of, minlength=n_reads)
+    ok_reads = counts >= 2
+    if not ok_reads.all():
+        sel = ok_reads[read_of]
+        read_of, var_idx, allele, quality = read_of[sel], var_idx[sel], allele[sel], quality[sel]
+        remap = np.cumsum(ok_reads) - 1
+        read_of = remap[read_of]
+        counts = counts[ok_reads]
+        n_reads = int(ok_reads.sum())
+    read_ptr = np.zeros(n_reads + 1, dtype=np.uint64)
+    read_ptr[1:] = np.cumsum(counts)
+    n_cols = n if n_columns_limit is None else min(n, n_columns_limit)
+    positions = (1000 * (np.arange(n_cols, dtype=np.int64) + 1)).astype(np.uint32)
+    var_position = (1000 * (var_idx + 1)).astype(np.int32)
+    if trio:
+        sample = (np.arange(n_reads) % 3).astype(np.int32)  # father, mother, child round-robin
+        individual_id = np.array([0, 1, 2], dtype=np.uint32)
+        triples = np.array([0, 1, 2], dtype=np.uint32)
+        genotype = np.ones((3, n_cols), dtype=np.uint8)
+        recomb = np.zeros(n_cols, dtype=np.uint32)
+        if n_cols > 1:
+            recomb[1:] = round(centimorgen_to_phred(1000 * 1e-6 * 1.26))
+        gl = np.tile(np.array([30.0, 0.0, 30.0]), (3, n_cols, 1)) if distrust_genotypes else None
+    else:
+        sample = np.zeros(n_reads, dtype=np.int32)
+        individual_id = np.array([0], dtype=np.uint32)
+        triples = np.zeros(0, dtype=np.uint32)
+        genotype = np.ones((1, n_cols), dtype=np.uint8)
+        recomb = np.ones(n_cols, dtype=np.uint32)
+        gl = np.tile(np.array([30.0, 0.0, 30.0]), (1, n_cols, 1)) if distrust_genotypes else None
+    return ProblemArrays(read_ptr, var_position, allele, quality, sample, individual_id, triples, genotype, gl,
+                         recomb, positions, distrust_genotypes, n_variants=n_cols)
+
+
+def random_small_instance(rng: random.Random, mode: Optional[str] = None, max_variants: int = 9,
+                          max_reads: int = 7, allow_conflict: bool = True) -> ProblemArrays:
+    """Tie-heavy random instance: few phred values, gapped reads, random
+    recombination costs, optional extra positions, optional genotype inconsistency."""
+    if mode is None:
+        mode = rng.choice(["single", "trio", "quartet"])
+    n_var = rng.randint(2, max_variants)
+    n_reads = rng.randint(1, max_reads)
+    n_ind = {"single": 1, "trio": 3, "quartet": 4}[mode]
+    var_positions = [10 * (i + 1) for i in range(n_var)]
+    reads = []
+    for _ in range(n_reads):
+        s = rng.randint(0, n_var - 2)
+        e = rng.randint(s + 1, n_var - 1)
+        variants = []
+        for i in range(s, e + 1):
+            if i in (s, e) or rng.random() < 0.75:
+                variants.append((var_positions[i], rng.randint(0, 1), rng.choice([1, 1, 2, 7])))
+        reads.append((variants, rng.randrange(n_ind)))
+    reads.sort(key=lambda r: r[0][0][0])  # by first position; ties keep generation order (any order is a valid sorted ReadSet)
+    positions = list(var_positions)
+    if rng.random() < 0.6:
+        extra = set()
+        for _ in range(rng.randint(1, 3)):
+            extra.add(rng.choice([5, 15, 25, 35, 45, 10 * n_var + 5, 10 * n_var + 15]))
+        positions = sorted(set(positions) | extra)
+    n_cols = len(positions)
+    distrust = rng.random() < 0.5
+    genotype = np.ones((n_ind, n_cols), dtype=np.uint8)
+    if mode != "single" and rng.random() < 0.5:
+        for c in range(n_cols):
+            f = [rng.randint(0, 1), rng.randint(0, 1)]
+            m = [rng.randint(0, 1), rng.randint(0, 1)]
+            genotype[0, c] = sum(f)
+            genotype[1, c] = sum(m)
+            for child in range(2, n_ind):
+                genotype[child, c] = rng.choice(f) + rng.choice(m)
+    if allow_conflict and rng.random() < 0.3:
+        genotype[rng.randrange(n_ind), rng.randrange(n_cols)] = rng.randint(0, 2)
+    gl = np.zeros((n_ind, n_cols, 3), dtype=np.float64)
+    for i in range(n_ind):
+        for c in range(n_cols):
+            for g in range(3):
+                gl[i, c, g] = rng.choice([0, 0, 3, 10])
+    recomb = np.array([rng.choice([0, 1, 2, 5]) for _ in range(n_cols)], dtype=np.uint32)
+    triples: List[int] = []
+    if mode == "trio":
+        triples = [0, 1, 2]
+    elif mode == "quartet":
+        triples = [0, 1, 2, 0, 1, 3]
+    read_ptr = [0]
+    pos, alle, qual, samples = [], [], [], []
+    for variants, sample in reads:
+        for p, a, q in variants:
+            pos.append(p)
+            alle.append(a)
+            qual.append(q)
+        read_ptr.append(len(pos))
+        samples.append(sample)
+    return ProblemArrays(read_ptr, pos, alle, qual, samples, np.arange(n_ind, dtype=np.uint32),
+                         np.asarray(triples, dtype=np.uint32), genotype, gl, recomb,
+                         np.asarray(positions, dtype=np.uint32), distrust, n_variants=n_cols)
