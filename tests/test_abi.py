@@ -1,0 +1,124 @@
+"""CPU: the C-ABI library loads, exports every symbol include/whatshap_amd.h declares, validates inputs
+like the reference does (same messages), and fails loudly without a GPU (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import string_to_readset
+from whatshap_amd import _native
+from whatshap_amd.core import NumericSampleIds, Pedigree, PedigreeDPTable, Read, ReadSet, problem_from_objects
+from helpers import biallelic_gt
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "whatshap_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(whamd_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 15
+    for name in names:
+        assert hasattr(lib, name), name
+    assert sorted(_native.EXPORTED_SYMBOLS) == names
+    assert lib.whamd_abi_version() == 1
+
+
+def het_pedigree(n_positions):
+    ped = Pedigree(NumericSampleIds())
+    ped.add_individual("individual0", [biallelic_gt(1)] * n_positions)
+    return ped
+
+
+def test_unsorted_readset_message():
+    rs = ReadSet()
+    for name, start in (("a", 30), ("b", 10)):
+        r = Read(name, 50, 0, 0)
+        r.add_variant(start, 0, 1)
+        r.add_variant(start + 10, 1, 1)
+        rs.add(r)
+    with pytest.raises(RuntimeError, match="ColumnIterator: reads in ReadSet are not sorted."):
+        PedigreeDPTable(rs, [1] * 4, het_pedigree(4))
+
+
+def test_unsorted_variants_message():
+    rs = ReadSet()
+    r = Read("a", 50, 0, 0)
+    r.add_variant(20, 0, 1)
+    r.add_variant(10, 1, 1)
+    rs.add(r)
+    with pytest.raises(RuntimeError, match="encountered read with unsorted variants"):
+        PedigreeDPTable(rs, [1, 1], het_pedigree(2))
+
+
+def test_unknown_sample_message():
+    rs = ReadSet()
+    r = Read("a", 50, 0, 7)
+    r.add_variant(10, 0, 1)
+    r.add_variant(20, 1, 1)
+    rs.add(r)
+    with pytest.raises(RuntimeError, match="Individual with ID 7 not present in pedigree."):
+        PedigreeDPTable(rs, [1, 1], het_pedigree(2))
+
+
+def test_mendelian_conflict_message():
+    rs = string_to_readset("""
+      11
+      01
+    """, sample_ids=[0, 2])
+    ped = Pedigree(NumericSampleIds())
+    ped.add_individual("f", [biallelic_gt(0), biallelic_gt(0)])
+    ped.add_individual("m", [biallelic_gt(0), biallelic_gt(0)])
+    ped.add_individual("c", [biallelic_gt(2), biallelic_gt(1)])  # 1/1 child of two 0/0 parents
+    ped.add_relationship("f", "m", "c")
+    with pytest.raises(RuntimeError, match="Error: Mendelian conflict"):
+        PedigreeDPTable(rs, [1, 1], ped)
+
+
+def test_coverage_limit_is_an_error_not_a_fallback():
+    rs = ReadSet()
+    for i in range(26):
+        r = Read(f"r{i}", 50, 0, 0)
+        r.add_variant(10, i & 1, 1)
+        r.add_variant(20, 1, 1)
+        rs.add(r)
+    with pytest.raises(_native.SolverError) as e:
+        PedigreeDPTable(rs, [1, 1], het_pedigree(2))
+    assert e.value.status == _native.WHAMD_ERR_UNSUPPORTED
+
+
+def test_overflow_guard():
+    rs = ReadSet()
+    r = Read("a", 50, 0, 0)
+    r.add_variant(10, 0, 2**31)
+    r.add_variant(20, 1, 2**31)
+    rs.add(r)
+    with pytest.raises(_native.SolverError) as e:
+        PedigreeDPTable(rs, [1, 1], het_pedigree(2))
+    assert e.value.status == _native.WHAMD_ERR_OVERFLOW
+
+
+@pytest.mark.skipif(_native.device_count() > 0, reason="only meaningful on a machine without a GPU")
+def test_no_gpu_fails_loudly():
+    rs = string_to_readset("""
+      11
+      01
+    """)
+    with pytest.raises(_native.SolverError) as e:
+        PedigreeDPTable(rs, [1, 1], het_pedigree(2))
+    assert e.value.status == _native.WHAMD_ERR_DEVICE
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_read_sort_hash_is_libstdcxx_string_hash():
+    # std::hash<int> is the identity, so xor-ing source ids must commute like this
+    h0 = _native.read_sort_hash("Read 1", 0)
+    assert _native.read_sort_hash("Read 1", 5) == h0 ^ 5
+    assert _native.read_sort_hash("Read 2", 0) != h0

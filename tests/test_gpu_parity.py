@@ -1,0 +1,163 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against (i) the reference's known answers through the
+drop-in class API, (ii) the committed golden vectors of the compiled reference, (iii) the oracle on seeded inputs,
+(iv) size-independent properties at BASELINE.json's full sizes.  Bit-exact everywhere (integer path)."""
+import random
+
+import numpy as np
+import pytest
+
+import oracle
+from helpers import (first_difference, load_golden, native_solution, problem_from_json, table_solution,
+                     wmec_cost_of_partitioning)
+from reference_cases import all_cases
+from whatshap_amd import _native
+from whatshap_amd.core import PedigreeDPTable
+from whatshap_amd.synthetic import random_small_instance, synthetic_block
+
+pytestmark = pytest.mark.gpu
+PATHS = ["auto", "column_keys"]
+
+
+def oracle_outcome(problem):
+    try:
+        return table_solution(oracle.OracleTable(problem)), None
+    except oracle.OracleError as e:
+        return None, str(e)
+
+
+def native_outcome(problem, path):
+    try:
+        return native_solution(problem, path), None
+    except _native.SolverError as e:
+        return None, str(e)
+
+
+@pytest.mark.parametrize("case", all_cases(), ids=lambda c: c.name)
+def test_reference_unit_tests_through_the_class_api(case):
+    """The reference's own assertions (tests/test_phasing.py, tests/test_pedigreephasing.py) on our PedigreeDPTable."""
+    dp_table = PedigreeDPTable(case.readset, case.recombcost, case.pedigree, case.distrust_genotypes, case.positions)
+    superreads_list, transmission_vector = dp_table.get_super_reads()
+    cost = dp_table.get_optimal_cost()
+    partition = dp_table.get_optimal_partitioning()
+    assert len(superreads_list) == len(case.pedigree)
+    assert len(partition) == len(case.readset)
+    if case.expected_cost is not None:
+        assert cost == case.expected_cost
+    if case.constant_transmission:
+        assert len(set(transmission_vector)) <= 1
+    if case.allowed_transmission is not None:
+        assert transmission_vector in case.allowed_transmission
+    for superreads in superreads_list:
+        assert len(superreads) == 2
+        assert [v.position for v in superreads[0]] == [v.position for v in superreads[1]]
+    if case.expected_haplotypes is not None:
+        for superreads, expected in zip(superreads_list, case.expected_haplotypes):
+            haplotypes = tuple(sorted("".join(str(v.allele) for v in sr) for sr in superreads))
+            assert haplotypes == tuple(sorted(expected))
+    if len(case.pedigree) == 3 and case.expected_haplotypes is not None and case.name.startswith("trio"):
+        father, mother, child = superreads_list  # assert_trio_allele_order, tests/test_pedigreephasing.py:46-71
+        for pos, tv in enumerate(transmission_vector):
+            assert father[int(not (tv % 2))][pos].allele == child[0][pos].allele
+            assert mother[int(not (tv // 2))][pos].allele == child[1][pos].allele
+
+
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("fixture", ["reference_cases.json", "random_tie_heavy.json", "synthetic_small.json"])
+def test_golden_vectors(fixture, path):
+    for rec in load_golden(fixture):
+        got, err = native_outcome(problem_from_json(rec["problem"]), path)
+        assert err == rec["error"], rec["name"]
+        if err is None:
+            assert got == rec["solution"], f"{rec['name']}: {first_difference(rec['solution'], got)}"
+
+
+@pytest.mark.parametrize("path", PATHS)
+def test_random_tie_heavy_vs_oracle(path):
+    rng = random.Random(987 if path == "auto" else 654)
+    conflicts = 0
+    for i in range(500):
+        p = random_small_instance(rng)
+        want, werr = oracle_outcome(p)
+        got, gerr = native_outcome(p, path)
+        assert gerr == werr, i
+        conflicts += werr is not None
+        assert got == want, f"{i}: {first_difference(want, got) if want else ''}"
+    assert conflicts > 0
+
+
+SYNTHETIC = [
+    dict(n_variants=1500, coverage=10, seed=101),
+    dict(n_variants=800, coverage=12, seed=102, distrust_genotypes=True),
+    dict(n_variants=600, coverage=14, seed=103),
+    dict(n_variants=400, coverage=13, seed=104, step=1),
+    dict(n_variants=500, coverage=9, seed=105, trio=True),
+    dict(n_variants=300, coverage=12, seed=106, trio=True),
+    dict(n_variants=200, coverage=9, seed=107, trio=True, distrust_genotypes=True),
+    dict(n_variants=300, coverage=8, seed=108, drop_rate=0.6),
+    dict(n_variants=300, coverage=3, seed=109),  # every column below one wavefront of projection entries
+    dict(n_variants=100000, coverage=15, seed=2, n_columns_limit=120),  # prefix of BASELINE config 2
+    dict(n_variants=100000, coverage=15, seed=4, trio=True, n_columns_limit=60),  # prefix of config 4
+]
+
+
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("kw", SYNTHETIC, ids=str)
+def test_synthetic_vs_oracle(kw, path):
+    p = synthetic_block(**kw)
+    want = table_solution(oracle.OracleTable(p))
+    got = native_solution(p, path)
+    assert got == want, first_difference(want, got)
+
+
+def test_coverage_20_prefix_vs_oracle():
+    """Prefix of BASELINE config 3 (2^20 bipartitions per column): ~45 columns is ~5 s of oracle time."""
+    p = synthetic_block(n_variants=200000, coverage=20, seed=3, n_columns_limit=45)
+    want = table_solution(oracle.OracleTable(p))
+    got = native_solution(p, "auto")
+    assert got == want, first_difference(want, got)
+
+
+def test_many_reads_ending_at_once():
+    """All reads start and end together: k - f jumps from 0 to 12 in one column (the key path's chunked enumeration)."""
+    rng = np.random.default_rng(5)
+    n_reads, n_var = 12, 6
+    read_ptr = np.arange(0, (n_reads + 1) * n_var, n_var)
+    pos = np.tile(10 * (np.arange(n_var) + 1), n_reads)
+    p = _native.ProblemArrays(read_ptr, pos, rng.integers(0, 2, n_reads * n_var), rng.integers(1, 4, n_reads * n_var),
+                              np.zeros(n_reads), [0], [], np.ones((1, n_var)), None, [1] * n_var, None, False)
+    want = table_solution(oracle.OracleTable(p))
+    for path in PATHS:
+        assert native_solution(p, path) == want
+
+
+@pytest.mark.parametrize("kw", [dict(n_variants=50000, coverage=15, seed=2), dict(n_variants=20000, coverage=20, seed=3)], ids=str)
+def test_full_size_properties_single_individual(kw):
+    """BASELINE config 2 at full size, config 3 at a tenth of its length (same per-column work): the reported optimum
+    equals the wMEC objective re-evaluated independently from the reported bipartition; the path is consistent
+    between adjacent columns; a second solve reproduces it bit for bit."""
+    p = synthetic_block(**kw)
+    t = _native.NativeTable(p)
+    cost, part = t.optimal_score(), t.partitioning()
+    assert wmec_cost_of_partitioning(p, part) == cost
+    idx1, tv1 = t.index_path()
+    t.solve()
+    idx2, tv2 = t.index_path()
+    assert t.optimal_score() == cost and (idx1 == idx2).all() and (tv1 == tv2).all()
+    a0, a1, q, tv, sid = t.super_reads()
+    assert set(np.unique(a0)) <= {0, 1, 3} and ((a0 != a1) | (a0 == 3)).all()  # heterozygous everywhere
+    # flipping any single read to the other side must not improve the objective (local optimality of a global optimum)
+    rng = np.random.default_rng(1)
+    for r in rng.integers(0, p.n_reads, 25):
+        flipped = part.copy()
+        flipped[r] ^= 1
+        assert wmec_cost_of_partitioning(p, flipped) >= cost
+
+
+def test_full_size_trio_paths_agree():
+    """BASELINE config 4 shape (trio, coverage 15) at a fifth of its length: the fused path and the independent key
+    path produce identical cost, backtrace, transmission vector and superreads."""
+    p = synthetic_block(n_variants=20000, coverage=15, seed=4, trio=True)
+    a = native_solution(p, "auto")
+    b = native_solution(p, "column_keys")
+    assert a == b, first_difference(a, b)
+    assert len(set(a["transmission"])) >= 1

@@ -1,0 +1,102 @@
+"""CPU: the oracle restatement against the golden vectors of the compiled reference, against the
+reference's own known answers, against brute force, and (where oracle/_ref exists) against the
+compiled reference on fresh random instances."""
+import itertools
+import random
+
+import pytest
+
+import oracle
+from helpers import first_difference, load_golden, problem_from_json, table_solution
+from reference_cases import all_cases
+from whatshap_amd.core import problem_from_objects
+from whatshap_amd.synthetic import random_small_instance, synthetic_block
+
+
+def oracle_outcome(problem):
+    try:
+        return table_solution(oracle.OracleTable(problem)), None
+    except oracle.OracleError as e:
+        return None, str(e)
+
+
+@pytest.mark.parametrize("fixture", ["reference_cases.json", "random_tie_heavy.json", "synthetic_small.json"])
+def test_oracle_matches_golden(fixture):
+    records = load_golden(fixture)
+    assert records
+    n_errors = 0
+    for rec in records:
+        solution, error = oracle_outcome(problem_from_json(rec["problem"]))
+        assert error == rec["error"], rec["name"]
+        if error is None:
+            assert solution == rec["solution"], f"{rec['name']}: {first_difference(rec['solution'], solution)}"
+        else:
+            n_errors += 1
+    if fixture == "random_tie_heavy.json":
+        assert n_errors > 0  # the generator injects Mendelian conflicts; both sides must raise on the same inputs
+
+
+def brute_force(readset, all_heterozygous):
+    """min over all bipartitions of sum over columns of the cheapest allele pair (tests/testhelpers.py:125-177 idea)."""
+    reads = list(readset)
+    positions = readset.get_positions()
+    pairs = [(0, 1), (1, 0)] if all_heterozygous else [(0, 0), (0, 1), (1, 0), (1, 1)]
+    best, count = None, 0
+    for partition in range(2 ** len(reads)):
+        cost = 0
+        for p in positions:
+            side = [[], []]
+            for n, read in enumerate(reads):
+                for v in read:
+                    if v.position == p:
+                        side[(partition >> n) & 1].append(v)
+            cost += min(sum(v.quality for v in side[0] if v.allele != a0) + sum(v.quality for v in side[1] if v.allele != a1)
+                        for a0, a1 in pairs)
+        if best is None or cost < best:
+            best, count = cost, 1
+        elif cost == best:
+            count += 1
+    return best, count
+
+
+@pytest.mark.parametrize("case", all_cases(), ids=lambda c: c.name)
+def test_reference_known_answers(case):
+    problem = problem_from_objects(case.readset, case.recombcost, case.pedigree, case.distrust_genotypes, case.positions)
+    sol, err = oracle_outcome(problem)
+    assert err is None
+    if case.expected_cost is not None:
+        assert sol["cost"] == case.expected_cost
+    if case.all_heterozygous is not None and len(case.readset) < 10:
+        expected, _ = brute_force(case.readset, case.all_heterozygous)
+        assert sol["cost"] == expected
+    if case.constant_transmission:
+        assert len(set(sol["transmission"])) <= 1
+    if case.allowed_transmission is not None:
+        assert sol["transmission"] in case.allowed_transmission
+    if case.expected_haplotypes is not None:
+        for ind, expected in enumerate(case.expected_haplotypes):
+            got = tuple(sorted(["".join(map(str, sol["allele0"][ind])), "".join(map(str, sol["allele1"][ind]))]))
+            assert got == tuple(sorted(expected)), (case.name, ind)
+
+
+@pytest.mark.skipif(not oracle.have_reference(), reason="oracle/_ref not built (no reference tree here)")
+def test_oracle_vs_compiled_reference_random():
+    rng = random.Random(4242)
+    for i in range(300):
+        p = random_small_instance(rng)
+        want, werr = None, None
+        try:
+            want = table_solution(oracle.ReferenceTable(p))
+        except oracle.OracleError as e:
+            werr = str(e)
+        got, gerr = oracle_outcome(p)
+        assert gerr == werr, i
+        assert got == want, f"{i}: {first_difference(want, got)}"
+
+
+@pytest.mark.skipif(not oracle.have_reference(), reason="oracle/_ref not built (no reference tree here)")
+@pytest.mark.parametrize("kw", [dict(n_variants=300, coverage=10, seed=31), dict(n_variants=150, coverage=9, seed=32, trio=True),
+                                dict(n_variants=3000, coverage=14, seed=33, n_columns_limit=40)], ids=str)
+def test_oracle_vs_compiled_reference_synthetic(kw):
+    p = synthetic_block(**kw)
+    assert table_solution(oracle.OracleTable(p)) == table_solution(oracle.ReferenceTable(p))

@@ -1,0 +1,108 @@
+"""Host-side sharding of independent phasing blocks over the GPUs of a node (no collective on the data path).
+
+Two levels, both exact:
+
+* separate PedigreeDPTable instances (chromosomes, families) are independent by construction
+  (whatshap/cli/phase.py:467,486,604);
+* *within* a single-individual instance (T = 1) the column chain can be cut wherever no read is active across
+  a column boundary (f_c = 0): the projection there collapses to one scalar (src/pedigreedptable.cpp:319-325)
+  that is added to every cell of the next column (:274-283), so arg-minima -- including the Gray-code tie-breaks
+  -- are unchanged; total cost = sum of block costs, index path / partitioning / superreads = concatenation.
+  With trios (T > 1) blocks are coupled through the transmission vector; such instances are never split.
+
+Blocks are assigned longest-processing-time-first to the least loaded rank (the same heuristic the reference
+uses for its only worker pool, whatshap/polyphase/algorithm.py:101-128).  Each rank (one process per GPU) solves
+its blocks; results are concatenated on the host.
+"""
+
+from __future__ import annotations
+
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+
+from ._native import ProblemArrays
+
+
+def block_weight(n_columns: int, coverage: int, transmissions: int = 1) -> float:
+    """Work estimate of a block: number of bipartition costs."""
+    return float(n_columns) * float(2 ** coverage) * float(transmissions) ** 2
+
+
+def assign_blocks(weights: Sequence[float], world_size: int) -> List[List[int]]:
+    """LPT: blocks sorted by descending weight (ties by index) go to the currently least loaded rank
+    (ties by rank).  Deterministic, so every rank computes the same assignment without communicating."""
+    order = sorted(range(len(weights)), key=lambda b: (-weights[b], b))
+    load = [0.0] * world_size
+    out: List[List[int]] = [[] for _ in range(world_size)]
+    for b in order:
+        r = min(range(world_size), key=lambda i: (load[i], i))
+        out[r].append(b)
+        load[r] += weights[b]
+    return out
+
+
+def _column_spans(problem: ProblemArrays) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    positions = problem.positions
+    if positions is None:
+        positions = np.unique(problem.var_position.astype(np.int64)).astype(np.uint32)
+    ptr = problem.read_ptr.astype(np.int64)
+    first = np.searchsorted(positions, problem.var_position[ptr[:-1]].astype(np.int64)) if problem.n_reads else np.zeros(0, np.int64)
+    last = np.searchsorted(positions, problem.var_position[ptr[1:] - 1].astype(np.int64)) if problem.n_reads else np.zeros(0, np.int64)
+    return positions, first, last
+
+
+def split_independent_blocks(problem: ProblemArrays) -> List[Tuple[ProblemArrays, np.ndarray, Tuple[int, int]]]:
+    """Cuts a single-individual problem at every column boundary no read is active across.
+    Returns [(sub-problem, read indices of the block, (first column, end column))]."""
+    if problem.triple_ids.size:
+        raise ValueError("instances with trios are coupled through the transmission vector and cannot be split")
+    positions, first, last = _column_spans(problem)
+    n = positions.size
+    crossing = np.zeros(n + 1, dtype=np.int64)  # crossing[c] = reads active in both column c-1 and c
+    np.add.at(crossing, first + 1, 1)
+    np.add.at(crossing, last + 1, -1)
+    crossing = np.cumsum(crossing)[:n]
+    starts = [0] + [c for c in range(1, n) if crossing[c] == 0]
+    bounds = list(zip(starts, starts[1:] + [n]))
+    ptr = problem.read_ptr.astype(np.int64)
+    geno = problem.genotype.reshape(problem.n_individuals, problem.n_variants)
+    gl = None if problem.genotype_likelihoods is None else problem.genotype_likelihoods.reshape(problem.n_individuals, problem.n_variants, 3)
+    recomb = np.zeros(n, dtype=np.uint32)
+    m = min(n, problem.recombcost.size)
+    recomb[:m] = problem.recombcost[:m]
+    if m < n:
+        recomb[m:] = problem.recombcost[-1] if problem.recombcost.size else 0
+    out = []
+    for c0, c1 in bounds:
+        reads = np.nonzero((first >= c0) & (first < c1))[0]
+        lengths = (ptr[reads + 1] - ptr[reads]).astype(np.int64)
+        sel = np.concatenate([np.arange(ptr[r], ptr[r + 1]) for r in reads]) if reads.size else np.zeros(0, np.int64)
+        sub_ptr = np.zeros(reads.size + 1, dtype=np.uint64)
+        sub_ptr[1:] = np.cumsum(lengths)
+        sub = ProblemArrays(sub_ptr, problem.var_position[sel], problem.var_allele[sel], problem.var_quality[sel],
+                            problem.read_sample_id[reads], problem.individual_id, problem.triple_ids, geno[:, c0:c1],
+                            None if gl is None else gl[:, c0:c1, :], recomb[c0:c1], positions[c0:c1],
+                            problem.distrust_genotypes, n_variants=c1 - c0)
+        out.append((sub, reads, (c0, c1)))
+    return out
+
+
+def merge_block_solutions(n_reads: int, n_individuals: int, blocks, solutions: Dict[int, dict]) -> dict:
+    """Concatenates per-block solutions (dicts as produced by tests/helpers.table_solution) into the
+    solution of the whole instance."""
+    merged = {"cost": 0, "index_path": [], "transmission": [], "path_transmission": [], "positions": [],
+              "partitioning": [1] * n_reads, "allele0": [[] for _ in range(n_individuals)],
+              "allele1": [[] for _ in range(n_individuals)], "quality": [[] for _ in range(n_individuals)]}
+    for b, (_, reads, _) in enumerate(blocks):
+        s = solutions[b]
+        merged["cost"] += s["cost"]
+        for key in ("index_path", "transmission", "path_transmission", "positions"):
+            merged[key].extend(s[key])
+        for i in range(n_individuals):
+            for key in ("allele0", "allele1", "quality"):
+                merged[key][i].extend(s[key][i])
+        for local, r in enumerate(reads):
+            merged["partitioning"][int(r)] = s["partitioning"][local]
+        merged["sample_ids"] = s["sample_ids"]
+    return merged
