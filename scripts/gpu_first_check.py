@@ -15,7 +15,7 @@ def native_tuple(t):
 print("devices", _native.device_count())
 rng = random.Random(11)
 bad = 0
-for path in ("auto", "column_keys"):
+for path in ("resident", "column", "column_keys"):
     ok = conf = 0
     for it in range(400):
         p = random_small_instance(rng)
@@ -43,7 +43,7 @@ for kw in [dict(n_variants=300, coverage=8, seed=2), dict(n_variants=200, covera
            dict(n_variants=300, coverage=12, seed=9, trio=True), dict(n_variants=120, coverage=14, seed=13, step=1)]:
     p = synthetic_block(**kw)
     o = solution_tuple(OracleTable(p))
-    for path in ("auto", "column_keys"):
+    for path in ("resident", "column", "column_keys"):
         n = native_tuple(_native.NativeTable(p, path=path))
         eq = o == n
         if not eq:
@@ -52,14 +52,15 @@ for kw in [dict(n_variants=300, coverage=8, seed=2), dict(n_variants=200, covera
                 if o[k] != n[k]: print("MISMATCH", k, str(o[k])[:200], str(n[k])[:200]); break
         print(kw, path, "cost", o["cost"], "equal", eq)
 
-for kw in [dict(n_variants=5000, coverage=15, seed=2), dict(n_variants=2000, coverage=20, seed=3), dict(n_variants=2000, coverage=15, seed=4, trio=True)]:
+for kw in [dict(n_variants=5000, coverage=15, seed=2), dict(n_variants=4000, coverage=20, seed=3), dict(n_variants=2000, coverage=15, seed=4, trio=True)]:
     p = synthetic_block(**kw)
-    t = _native.NativeTable(p, solve=False)
-    for rep in range(2):
-        t0 = time.time(); t.solve(); dt = time.time() - t0
-        s = t.stats()
-        print(kw, "wall %.3fs fwd %.1fms bt %.1fms total %.1fms launches %d cols/s %.0f cells/s %.2fG algGB/s %.1f" % (
-            dt, s["forward_ms"], s["backtrace_ms"], s["total_ms"], s["forward_launches"], s["n_columns"]/(s["total_ms"]/1e3),
-            s["n_cells"]/(s["total_ms"]/1e3)/1e9, s["algorithmic_bytes"]/(s["total_ms"]/1e3)/1e9), "cost", t.optimal_score())
+    for path in ("resident", "column"):
+        t = _native.NativeTable(p, solve=False, path=path)
+        for rep in range(2):
+            t0 = time.time(); t.solve(); dt = time.time() - t0
+            s = t.stats()
+            print(path, kw, "wall %.3fs fwd %.1fms bt %.1fms total %.1fms launches %d cols/s %.0f cells/s %.2fG algGB/s %.1f" % (
+                dt, s["forward_ms"], s["backtrace_ms"], s["total_ms"], s["forward_launches"], s["n_columns"]/(s["total_ms"]/1e3),
+                s["n_cells"]/(s["total_ms"]/1e3)/1e9, s["algorithmic_bytes"]/(s["total_ms"]/1e3)/1e9), "cost", t.optimal_score())
 print("BAD", bad)
 sys.exit(1 if bad else 0)

@@ -1,5 +1,6 @@
 // c_api.cpp -- the extern "C" boundary declared in include/whatshap_amd.h.
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <memory>
@@ -18,7 +19,6 @@ struct whamd_dptable {
 	int device_index = 0;
 	bool uploaded = false;
 	bool solved = false;
-	bool force_keys = false;
 };
 
 namespace {
@@ -69,7 +69,6 @@ whamd_status_t whamd_dptable_solve(whamd_dptable* t) {
 	if (!t) return fail(WHAMD_ERR_INVALID, "table is NULL");
 	std::string msg;
 	if (!t->uploaded) {
-		t->device.set_force_keys(t->force_keys);
 		whamd_status_t st = t->device.upload(t->problem, t->device_index, msg);
 		if (st != WHAMD_OK) return fail(st, msg);
 		t->uploaded = true;
@@ -151,10 +150,13 @@ whamd_status_t whamd_dptable_set_option(whamd_dptable* t, const char* key, const
 	if (!t || !key || !value) return fail(WHAMD_ERR_INVALID, "null argument");
 	const std::string k(key), v(value);
 	if (k == "path") {
-		if (v == "auto" || v == "column") t->force_keys = false;
-		else if (v == "column_keys") t->force_keys = true;
-		else return fail(WHAMD_ERR_INVALID, "unknown path '" + v + "' (auto, column, column_keys)");
+		if (!t->device.set_path(v)) return fail(WHAMD_ERR_INVALID, "unknown path '" + v + "' (auto, resident, column, column_keys)");
 		t->uploaded = false;  // descriptors are rebuilt at the next solve
+		return WHAMD_OK;
+	}
+	if (k == "resident_l") {
+		t->device.set_l_pref(std::atoi(value));
+		t->uploaded = false;
 		return WHAMD_OK;
 	}
 	return fail(WHAMD_ERR_INVALID, "unknown option '" + k + "'");

@@ -19,8 +19,10 @@ public:
 	whamd_status_t upload(const Problem& p, int device, std::string& msg);
 	// Forward pass + backtrace on the device; fills s.path_*, s.optimal_score and the timing fields of st.
 	whamd_status_t solve(const Problem& p, Solution& s, whamd_solve_stats& st, std::string& msg);
-	// Route every column through the key (atomic) path; takes effect at the next upload().
-	void set_force_keys(bool v);
+	// Solver variant ("auto", "column", "column_keys", "resident"); takes effect at the next upload().
+	bool set_path(const std::string& path);
+	// Preferred log2 slice size of the resident path (tuning knob); takes effect at the next upload().
+	void set_l_pref(int l);
 
 private:
 	struct Impl;

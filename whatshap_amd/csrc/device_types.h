@@ -2,6 +2,8 @@
 #pragma once
 #include <cstdint>
 
+#include "resident.h"
+
 namespace whamd {
 
 // Per-column descriptor, read wave-uniformly (scalar loads) by every kernel.
@@ -14,13 +16,14 @@ struct DevColumn {
 	uint32_t term_off;   // into DevProblem::term_ptr: T+1 offsets into DevProblem::terms
 	uint32_t seg_off;    // into DevProblem::segs: nseg_fwd forward segments, then nseg_end ending segments
 	uint16_t nseg_fwd, nseg_end;
-	uint32_t mode;       // 0: fused column step, bit-plane backtrace; 1: key (atomic) path, raw u32 backtrace
+	uint32_t mode;       // 0: fused column step, bit-plane backtrace; 1: key (atomic) path, raw u32 backtrace;
+	                     // 2: resident run (resident.h), per-workgroup bit planes
 	uint32_t ebits;      // k - f: reads that end in this column
 	uint32_t eloop;      // log2 of the ending-bit patterns each thread enumerates itself
 	uint32_t nplanes;    // mode 0: ebits + transmission bits
 	uint64_t bt_off;     // byte offset of this column's backtrace record in the arena
 	uint32_t is_last;
-	uint32_t pad;
+	uint32_t res_idx;    // mode 2: index into DevProblem::res_bt / res_cols
 };
 
 struct DevTerm {
@@ -36,6 +39,11 @@ struct DevProblem {
 	uint8_t* bt;            // backtrace arena
 	unsigned long long* keys;       // [2^max_f * T] scratch of the key path, all-ones between uses
 	unsigned long long* last_keys;  // [T] keys of the last column
+	// resident path (resident.h)
+	const ResColumn* res_cols;
+	const ResBacktrace* res_bt;
+	const uint32_t* res_segs;
+	unsigned long long* dbg;  // optional cycle-counter dump (WHAMD_DEBUG_TIMING)
 	uint32_t n_cols;
 	uint32_t T;
 	uint32_t tbits;         // 2 * triples

@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -221,6 +222,250 @@ __global__ __launch_bounds__(256) void column_finalize(DevProblem P, uint32_t c,
 	if (col.is_last) P.last_keys[idx] = key;
 }
 
+// ------------------------------------------------------------------------------------------------ resident run
+// One launch = one run of consecutive columns (resident.h).  Workgroup w owns the slice of the projection column whose
+// grid-read bits equal w; the slice lives in LDS (two buffers), Pr touches HBM only at the load and the store.
+// Single individual (T = 1): cost(x) = min(Cp + S, Cm - S, Cc), S = S_grid(w) + tab_lo[l & 127] + tab_hi[l >> 7].
+// Everything a column needs (descriptor, lookup tables) is staged in LDS before the first column, so the sequential
+// column chain contains no global-memory latency.
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ uint32_t deposit_args(uint32_t v, const uint32_t* segs, uint32_t nseg) {
+	uint32_t x = 0;
+	for (uint32_t i = 0; i < nseg; ++i) {
+		const uint32_t sg = segs[i];
+		x |= ((v >> (sg & 31u)) & ((1u << ((sg >> 16) & 31u)) - 1u)) << ((sg >> 8) & 31u);
+	}
+	return x;
+}
+
+constexpr int RES_OPT = 2;  // generic path: projection entries a thread evaluates together
+
+// local cell index with a zero inserted at bit position p
+__device__ __forceinline__ uint32_t insert_zero(uint32_t v, uint32_t p) {
+	return ((v >> p) << (p + 1u)) | (v & ((1u << p) - 1u));
+}
+
+// min(Cp + S, Cm - S, Cc): an absent plus/minus term is RES_ABSENT and can never be the minimum (resident.h)
+__device__ __forceinline__ uint32_t res_cost(uint32_t Cp, uint32_t Cm, uint32_t Cc, int32_t S) {
+	return min(min(Cp + (uint32_t)S, Cm - (uint32_t)S), Cc);
+}
+
+__global__ __launch_bounds__(1024) void resident_segment(DevProblem P, ResSegment sg, const uint32_t* __restrict__ prev,
+                                                          uint32_t* __restrict__ cur) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+	const uint32_t w = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+	const unsigned long long t_begin = P.dbg ? __builtin_readcyclecounter() : 0ull;
+	uint32_t* ldsc = smem;                                             // ncols * 64 words: column descriptors
+	int32_t* tab = reinterpret_cast<int32_t*>(smem + sg.ncols * 64);   // ncols * 256 words: lookup tables
+	uint32_t* bufP = smem + sg.ncols * (64 + RES_TABLE);
+	uint32_t* bufQ = bufP + (1u << sg.max_l);
+	unsigned long long* stage = reinterpret_cast<unsigned long long*>(bufQ + (1u << sg.max_l));  // backtrace ballots of the run
+	// stage the descriptors (coalesced copy) and the entering slice (re-layout from the logical order in HBM)
+	const uint32_t* __restrict__ gcols = reinterpret_cast<const uint32_t*>(P.res_cols + sg.col_off);
+	for (uint32_t i = tid; i < sg.ncols * 64; i += NT) ldsc[i] = gcols[i];
+	if (!sg.has_prev) {
+		if (tid == 0) bufP[0] = 0;
+	} else {
+		const uint32_t wpart = deposit_args(w, sg.in_grid, sg.n_in_grid);
+		for (uint32_t l = tid; l < (1u << sg.Lb0); l += NT) bufP[l] = prev[wpart | deposit_args(l, sg.in_local, sg.n_in_local)];
+	}
+	__syncthreads();
+	// per-column scalars that depend on the workgroup index, and the lookup tables of the local part of S
+	if (tid < sg.ncols) {
+		ResColumn* rc = reinterpret_cast<ResColumn*>(ldsc + tid * 64);
+		int32_t Sg = 0;
+		for (uint32_t i = 0; i < sg.g; ++i) Sg += ((w >> i) & 1u) ? rc->dgrid[i] : 0;
+		uint32_t PG = 0;
+		for (uint32_t q = 0; q < RES_EMAX; ++q) PG |= ((uint32_t)__popc(w & rc->mG[q]) & 1u) << q;
+		rc->Sg = Sg;
+		rc->PG = PG;
+	}
+	for (uint32_t idx = tid; idx < sg.ncols * RES_TABLE; idx += NT) {
+		const uint32_t ci = idx >> 8, half = (idx >> 7) & 1u, v = idx & 127u;
+		const int32_t* d = reinterpret_cast<const int32_t*>(ldsc + ci * 64 + offsetof(ResColumn, dloc) / 4 + half * 7);
+		int32_t sum = 0;
+#pragma unroll
+		for (int j = 0; j < 7; ++j) sum += ((v >> j) & 1u) ? d[j] : 0;
+		tab[idx] = sum;
+	}
+	__syncthreads();
+	const unsigned long long t_ready = P.dbg ? __builtin_readcyclecounter() : 0ull;
+	// hot words of the current column live in VECTOR registers (LDS broadcast reads): no per-wave scalar work
+	uint4 h0, h1, h2, h3, h4, h5;
+	{
+		const uint4* hp = reinterpret_cast<const uint4*>(ldsc);
+		h0 = hp[0]; h1 = hp[1]; h2 = hp[2]; h3 = hp[3]; h4 = hp[4]; h5 = hp[5];
+	}
+	unsigned long long acc_cmp = 0, acc_bar = 0;
+	for (uint32_t ci = 0; ci < sg.ncols; ++ci) {
+		const unsigned long long tc0 = P.dbg ? __builtin_readcyclecounter() : 0ull;
+		const uint32_t Cp = h0.x, Cm = h0.y, Cc = h0.z;
+		const uint32_t mode = uni(h0.w);
+		const uint32_t lowmask = h1.x, nthr = uni(h1.y), stage_off = h1.z, nwords = h1.w;
+		const uint32_t ep0 = h2.x, mL0 = h3.x;
+		const int32_t Sg = (int32_t)h4.x;
+		const uint32_t PG = h4.y;
+		const int32_t d0 = (int32_t)h5.x, d1 = (int32_t)h5.y, d2 = (int32_t)h5.z, dE = (int32_t)h5.w;
+		const uint4* hn = reinterpret_cast<const uint4*>(ldsc + (ci + 1 < sg.ncols ? ci + 1 : ci) * 64);
+		const uint4 n0 = hn[0], n1 = hn[1], n2 = hn[2], n3 = hn[3], n4 = hn[4], n5 = hn[5];  // prefetch (static data)
+		const int32_t* tlo = tab + ci * RES_TABLE;
+		const int32_t* thi = tlo + 128;
+		unsigned long long* planes = stage + stage_off;
+		if (mode != RES_MODE_GENERIC) {
+			// a thread owns the 4 consecutive entries 4t .. 4t+3; backtrace bit of entry 4t+u: word (t >> 6) * 4 + u, bit t & 63
+			const int32_t sc[4] = {0, d0, d1, d0 + d1};
+			for (uint32_t t0 = 0; t0 < nthr; t0 += NT) {
+				const uint32_t t = t0 + tid;
+				const bool valid = t < nthr;
+				const uint32_t l4 = valid ? (t << 2) : 0u;
+				uint32_t D[4];
+				uint32_t takes = 0;
+				if (mode == RES_MODE_E0) {
+					const int32_t Sb = Sg + tlo[l4 & 127u] + thi[(l4 >> 7) & 127u];
+					const uint4 p4 = *reinterpret_cast<const uint4*>(bufP + (l4 & lowmask));
+					const uint32_t pv[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+					for (int u = 0; u < 4; ++u) D[u] = res_cost(Cp, Cm, Cc, Sb + sc[u]) + pv[u];
+				} else if (mode == RES_MODE_E1_HIGH) {
+					const uint32_t base0 = insert_zero(l4, ep0), base1 = base0 | (1u << ep0);
+					const int32_t Sb = Sg + tlo[base0 & 127u] + thi[(base0 >> 7) & 127u];
+					const uint4 a4 = *reinterpret_cast<const uint4*>(bufP + (base0 & lowmask));
+					const uint4 b4 = *reinterpret_cast<const uint4*>(bufP + (base1 & lowmask));
+					const uint32_t pa[4] = {a4.x, a4.y, a4.z, a4.w}, pb[4] = {b4.x, b4.y, b4.z, b4.w};
+					// tie: the smaller Gray rank has x_h == parity of the bits above the ending read
+					const uint32_t par0 = PG ^ (uint32_t)__popc(base0 & mL0);
+#pragma unroll
+					for (int u = 0; u < 4; ++u) {
+						const int32_t S0 = Sb + sc[u];
+						const uint32_t D0 = res_cost(Cp, Cm, Cc, S0) + pa[u], D1 = res_cost(Cp, Cm, Cc, S0 + dE) + pb[u];
+						const uint32_t par = (par0 ^ (uint32_t)__popc((uint32_t)u & mL0)) & 1u;
+						const bool take1 = D1 < D0 || (D1 == D0 && par);
+						D[u] = take1 ? D1 : D0;
+						takes |= take1 ? (1u << u) : 0u;
+					}
+				} else {
+					// the ending read is local bit 0 or 1: the 8 cells of this thread are the 8 consecutive indices 8t .. 8t+7
+					const uint32_t base8 = l4 << 1;
+					const int32_t Sb = Sg + tlo[base8 & 127u] + thi[(base8 >> 7) & 127u];
+					const uint4 a4 = *reinterpret_cast<const uint4*>(bufP + (base8 & lowmask));
+					const uint4 b4 = *reinterpret_cast<const uint4*>(bufP + ((base8 + 4u) & lowmask));
+					const uint32_t pv[8] = {a4.x, a4.y, a4.z, a4.w, b4.x, b4.y, b4.z, b4.w};
+					const int32_t s8[8] = {0, d0, d1, d0 + d1, d2, d2 + d0, d2 + d1, d2 + d0 + d1};
+					uint32_t Dc[8];
+#pragma unroll
+					for (int c8 = 0; c8 < 8; ++c8) Dc[c8] = res_cost(Cp, Cm, Cc, Sb + s8[c8]) + pv[c8];
+					const uint32_t par0 = PG ^ (uint32_t)__popc(base8 & mL0);
+					if (mode == RES_MODE_E1_BIT0) {
+#pragma unroll
+						for (int u = 0; u < 4; ++u) {  // cells 2u (ending read on side 0) and 2u + 1
+							const uint32_t par = (par0 ^ (uint32_t)__popc((uint32_t)(2 * u) & mL0)) & 1u;
+							const bool take1 = Dc[2 * u + 1] < Dc[2 * u] || (Dc[2 * u + 1] == Dc[2 * u] && par);
+							D[u] = take1 ? Dc[2 * u + 1] : Dc[2 * u];
+							takes |= take1 ? (1u << u) : 0u;
+						}
+					} else {
+#pragma unroll
+						for (int u = 0; u < 4; ++u) {  // cells (u >> 1) * 4 + (u & 1) and + 2
+							const int c0 = ((u >> 1) << 2) | (u & 1);
+							const uint32_t par = (par0 ^ (uint32_t)__popc((uint32_t)c0 & mL0)) & 1u;
+							const bool take1 = Dc[c0 + 2] < Dc[c0] || (Dc[c0 + 2] == Dc[c0] && par);
+							D[u] = take1 ? Dc[c0 + 2] : Dc[c0];
+							takes |= take1 ? (1u << u) : 0u;
+						}
+					}
+				}
+				if (valid) *reinterpret_cast<uint4*>(bufQ + l4) = make_uint4(D[0], D[1], D[2], D[3]);
+				if (mode != RES_MODE_E0) {
+#pragma unroll
+					for (int u = 0; u < 4; ++u) {
+						const unsigned long long word = __ballot(valid && ((takes >> u) & 1u));
+						if ((tid & 63u) == 0 && valid) planes[(t >> 6) * 4 + u] = word;
+					}
+				}
+			}
+		} else {
+			const uint32_t Lf = uni(h4.w), ebits = uni(ldsc[ci * 64 + offsetof(ResColumn, ebits) / 4]);
+			const uint32_t nout = 1u << Lf;
+			const uint32_t epos[RES_EMAX] = {uni(h2.x), uni(h2.y), uni(h2.z)};
+			const uint32_t mL[RES_EMAX] = {uni(h3.x), uni(h3.y), uni(h3.z)};
+			const uint32_t nw = uni(nwords);
+			for (uint32_t l0 = 0; l0 < nout; l0 += NT * RES_OPT) {
+				uint32_t l_out[RES_OPT], base[RES_OPT], bestD[RES_OPT], beste[RES_OPT];
+				bool valid[RES_OPT];
+				uint32_t ebit[RES_EMAX];
+#pragma unroll
+				for (int q = 0; q < RES_EMAX; ++q) ebit[q] = (uint32_t)q < ebits ? (1u << epos[q]) : 0u;
+#pragma unroll
+				for (int u = 0; u < RES_OPT; ++u) {
+					l_out[u] = l0 + u * NT + tid;
+					valid[u] = l_out[u] < nout;
+					base[u] = valid[u] ? l_out[u] : 0u;
+					beste[u] = 0;
+#pragma unroll
+					for (int q = 0; q < RES_EMAX; ++q) if ((uint32_t)q < ebits) base[u] = insert_zero(base[u], epos[q]);
+					bestD[u] = 0xFFFFFFFFu;
+				}
+				const uint32_t ne = 1u << ebits;
+#pragma unroll
+				for (uint32_t e = 0; e < (1u << RES_EMAX); ++e) {
+					if (e < ne) {
+#pragma unroll
+						for (int u = 0; u < RES_OPT; ++u) {
+							uint32_t lc = base[u];
+#pragma unroll
+							for (int q = 0; q < RES_EMAX; ++q) lc |= ((e >> q) & 1u) ? ebit[q] : 0u;
+							const int32_t S = Sg + tlo[lc & 127u] + thi[(lc >> 7) & 127u];
+							const uint32_t D = res_cost(Cp, Cm, Cc, S) + bufP[lc & lowmask];
+							bool take = D < bestD[u];
+							if (e > 0 && D == bestD[u]) {
+								// candidates differ first (from the top) at ending read h; e ascends, so the new one has x_h = 1
+								const uint32_t h = 31u - (uint32_t)__clz((int)(e ^ beste[u]));
+								uint32_t par = 0;
+#pragma unroll
+								for (int q = 0; q < RES_EMAX; ++q)
+									if (h == (uint32_t)q) par = ((PG >> q) ^ (uint32_t)__popc(lc & mL[q])) & 1u;
+								take = par != 0;
+							}
+							if (take) { bestD[u] = D; beste[u] = e; }
+						}
+					}
+				}
+#pragma unroll
+				for (int u = 0; u < RES_OPT; ++u) {
+					if (valid[u]) bufQ[l_out[u]] = bestD[u];
+#pragma unroll
+					for (int q = 0; q < RES_EMAX; ++q) {
+						if ((uint32_t)q < ebits) {
+							const unsigned long long word = __ballot(valid[u] && ((beste[u] >> q) & 1u));
+							if ((tid & 63u) == 0 && valid[u]) planes[q * nw + (l_out[u] >> 6)] = word;
+						}
+					}
+				}
+			}
+		}
+		h0 = n0; h1 = n1; h2 = n2; h3 = n3; h4 = n4; h5 = n5;
+		const unsigned long long tc2 = P.dbg ? __builtin_readcyclecounter() : 0ull;
+		__syncthreads();
+		uint32_t* tmp = bufP; bufP = bufQ; bufQ = tmp;
+		if (P.dbg) { const unsigned long long tc3 = __builtin_readcyclecounter(); acc_cmp += tc2 - tc0; acc_bar += tc3 - tc2; }
+	}
+	const unsigned long long t_cols = P.dbg ? __builtin_readcyclecounter() : 0ull;
+	// exit slice in logical order, and the run's backtrace record [workgroup][stage_words]
+	const uint32_t wout = deposit_args(w, sg.out_grid, sg.n_out_grid);
+	for (uint32_t l = tid; l < (1u << sg.Lf_last); l += NT) cur[wout | deposit_args(l, sg.out_local, sg.n_out_local)] = bufP[l];
+	unsigned long long* rec = reinterpret_cast<unsigned long long*>(P.bt + (((unsigned long long)sg.bt_hi << 32) | sg.bt_lo)) + (size_t)w * sg.stage_words;
+	for (uint32_t i = tid; i < sg.stage_words; i += NT) rec[i] = stage[i];
+	if (P.dbg && w == 0 && tid == 0) {
+		unsigned long long* d = P.dbg + (size_t)sg.pad * 8;
+		d[0] = t_ready - t_begin;
+		d[1] = t_cols - t_ready;
+		d[2] = __builtin_readcyclecounter() - t_cols;
+		d[3] = sg.ncols;
+		d[4] = 0; d[5] = acc_cmp; d[6] = acc_bar;
+	}
+}
+
 // Backtrace (src/pedigreedptable.cpp:137-173) by one lane; out: index / transmission per column, out_score[0] = optimum.
 __global__ void backtrace_kernel(DevProblem P, uint32_t* __restrict__ path_index, uint32_t* __restrict__ path_trans,
                                  uint32_t* __restrict__ out_score) {
@@ -259,6 +504,22 @@ __global__ void backtrace_kernel(DevProblem P, uint32_t* __restrict__ path_index
 			}
 			const uint32_t e = v & ((1u << pc.ebits) - 1u);
 			aj = v >> pc.ebits;
+			const uint32_t* segs = P.segs + pc.seg_off;
+			xp = deposit(y, segs, pc.nseg_fwd) | deposit(e, segs + pc.nseg_fwd, pc.nseg_end);
+		} else if (pc.mode == 2) {
+			const ResBacktrace rb = P.res_bt[pc.res_idx];
+			const uint32_t* xs = P.res_segs + rb.ext_off;
+			const uint32_t w = deposit(y, xs, rb.n_grid), l = deposit(y, xs + rb.n_grid, rb.n_local);
+			const unsigned long long* planes = reinterpret_cast<const unsigned long long*>(P.bt + rb.seg_bt_off) +
+			                                   (size_t)w * rb.stage_words + rb.stage_off;
+			uint32_t e = 0;
+			const uint32_t widx = rb.layout ? (((l >> 2) >> 6) * 4 + (l & 3u)) : (l >> 6);
+			const uint32_t bpos = rb.layout ? ((l >> 2) & 63u) : (l & 63u);
+			for (uint32_t q = 0; q < pc.ebits; ++q) {
+				const unsigned long long word = planes[(size_t)q * rb.nwords + widx];
+				e |= (uint32_t)((word >> bpos) & 1ull) << q;
+			}
+			aj = 0;
 			const uint32_t* segs = P.segs + pc.seg_off;
 			xp = deposit(y, segs, pc.nseg_fwd) | deposit(e, segs + pc.nseg_fwd, pc.nseg_end);
 		} else {
@@ -304,43 +565,28 @@ struct DeviceTable::Impl {
 	int device = 0;
 	hipStream_t stream = nullptr;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
-	// device allocations
+	std::vector<void*> allocations;
 	DevColumn* d_cols = nullptr;
-	int32_t* d_delta = nullptr;
-	uint32_t* d_term_ptr = nullptr;
-	DevTerm* d_terms = nullptr;
-	uint32_t* d_segs = nullptr;
-	uint8_t* d_bt = nullptr;
-	unsigned long long* d_keys = nullptr;
-	unsigned long long* d_last_keys = nullptr;
 	uint32_t* d_pr[2] = {nullptr, nullptr};
 	uint32_t* d_path_index = nullptr;
 	uint32_t* d_path_trans = nullptr;
 	uint32_t* d_score = nullptr;
 	std::vector<DevColumn> cols;
+	ResidentPlan plan;
 	DevProblem dp{};
 	FusedFn fused = nullptr;
 	KeysFn keysfn = nullptr;
 	size_t key_entries = 0;
-	bool force_keys = false;
+	std::string path = "auto";
+	int l_pref = 11;
 	uint64_t bt_bytes = 0;
 
 	void release() {
-		if (d_cols) (void)hipFree(d_cols);
-		if (d_delta) (void)hipFree(d_delta);
-		if (d_term_ptr) (void)hipFree(d_term_ptr);
-		if (d_terms) (void)hipFree(d_terms);
-		if (d_segs) (void)hipFree(d_segs);
-		if (d_bt) (void)hipFree(d_bt);
-		if (d_keys) (void)hipFree(d_keys);
-		if (d_last_keys) (void)hipFree(d_last_keys);
-		if (d_pr[0]) (void)hipFree(d_pr[0]);
-		if (d_pr[1]) (void)hipFree(d_pr[1]);
-		if (d_path_index) (void)hipFree(d_path_index);
-		if (d_path_trans) (void)hipFree(d_path_trans);
-		if (d_score) (void)hipFree(d_score);
-		d_cols = nullptr; d_delta = nullptr; d_term_ptr = nullptr; d_terms = nullptr; d_segs = nullptr; d_bt = nullptr;
-		d_keys = nullptr; d_last_keys = nullptr; d_pr[0] = d_pr[1] = nullptr; d_path_index = d_path_trans = d_score = nullptr;
+		for (void* a : allocations) (void)hipFree(a);
+		allocations.clear();
+		d_cols = nullptr;
+		d_pr[0] = d_pr[1] = nullptr;
+		d_path_index = d_path_trans = d_score = nullptr;
 	}
 };
 
@@ -365,7 +611,7 @@ int DeviceTable::device_count() {
 	return n;
 }
 
-// Runs of set bits of `mask` as deposit segments; `src` counts the bits of the compact value consumed so far.
+// Runs of set bits of `mask` as deposit segments (compact position | mask position << 8 | length << 16).
 static void append_segments(uint32_t mask, std::vector<uint32_t>& out, uint16_t& count) {
 	uint32_t src = 0;
 	count = 0;
@@ -379,6 +625,14 @@ static void append_segments(uint32_t mask, std::vector<uint32_t>& out, uint16_t&
 		bit += len;
 	}
 }
+
+bool DeviceTable::set_path(const std::string& path) {
+	if (path != "auto" && path != "column" && path != "column_keys" && path != "resident") return false;
+	impl_->path = path;
+	return true;
+}
+
+void DeviceTable::set_l_pref(int l) { impl_->l_pref = std::max(4, std::min(l, RES_LMAX)); }
 
 whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& msg) {
 	Impl& m = *impl_;
@@ -407,6 +661,9 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		msg = "no device kernel for T=" + std::to_string(p.T) + ", individuals=" + std::to_string(p.n_ind);
 		return WHAMD_ERR_UNSUPPORTED;
 	}
+	const bool force_keys = m.path == "column_keys";
+	const bool want_resident = m.path == "auto" || m.path == "resident";
+	plan_forward(p, want_resident, m.l_pref, m.plan);
 	const uint32_t tbits = 2 * p.n_triples;
 	const uint32_t ni = std::max<uint32_t>(p.n_ind, 1);
 	// ---- descriptors
@@ -419,7 +676,8 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		msg = "problem too large for 32-bit device offsets";
 		return WHAMD_ERR_UNSUPPORTED;
 	}
-	uint64_t bt = 0;
+	uint64_t bt = 0, seg_bt = 0;
+	size_t seg_cursor = 0;
 	uint32_t max_f = 0, max_keys_f = 0;
 	for (uint32_t c = 0; c < n; ++c) {
 		DevColumn& d = m.cols[c];
@@ -436,13 +694,28 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		append_segments(kmask & ~p.fwd_mask[c], segs, d.nseg_end);
 		d.ebits = d.k - d.f;
 		d.is_last = (c + 1 == n);
-		const bool fused_ok = !m.force_keys && !d.is_last && d.f >= 6 && d.ebits <= (uint32_t)QMAX;
-		d.mode = fused_ok ? 0u : 1u;
 		d.eloop = std::min<uint32_t>(d.ebits, QMAX);
 		d.nplanes = d.ebits + tbits;
 		d.bt_off = bt;
-		if (d.mode == 0) bt += (uint64_t)d.nplanes * p.T * (1ull << (d.f - 6)) * 8ull;
-		else { bt += (uint64_t)p.T * (1ull << d.f) * 4ull; max_keys_f = std::max(max_keys_f, d.f); }
+		if (m.plan.col_to_res[c] >= 0) {
+			d.mode = 2;
+			d.res_idx = (uint32_t)m.plan.col_to_res[c];
+			if (seg_cursor < m.plan.segments.size() && m.plan.segments[seg_cursor].c0 == c) {  // first column of a run
+				ResSegment& sgm = m.plan.segments[seg_cursor];
+				sgm.bt_lo = (uint32_t)bt;
+				sgm.bt_hi = (uint32_t)(bt >> 32);
+				seg_bt = bt;
+				bt += (uint64_t)sgm.stage_words * (1ull << sgm.g) * 8ull;
+				++seg_cursor;
+			}
+			d.bt_off = seg_bt;
+			m.plan.backtrace[d.res_idx].seg_bt_off = seg_bt;
+		} else {
+			const bool fused_ok = !force_keys && !d.is_last && d.f >= 6 && d.ebits <= (uint32_t)QMAX;
+			d.mode = fused_ok ? 0u : 1u;
+			if (d.mode == 0) bt += (uint64_t)d.nplanes * p.T * (1ull << (d.f - 6)) * 8ull;
+			else { bt += (uint64_t)p.T * (1ull << d.f) * 4ull; max_keys_f = std::max(max_keys_f, d.f); }
+		}
 		bt = (bt + 15ull) & ~15ull;
 		max_f = std::max(max_f, d.f);
 	}
@@ -455,47 +728,69 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		return WHAMD_ERR_UNSUPPORTED;
 	}
 	// ---- allocate + upload
-	auto up = [&](auto*& dptr, const void* src, size_t bytes) -> hipError_t {
-		hipError_t e = hipMalloc((void**)&dptr, std::max<size_t>(bytes, 16));
-		if (e != hipSuccess) return e;
-		if (bytes) e = hipMemcpyAsync(dptr, src, bytes, hipMemcpyHostToDevice, m.stream);
+	auto alloc = [&](void** dptr, size_t bytes) -> hipError_t {
+		hipError_t e = hipMalloc(dptr, std::max<size_t>(bytes, 16));
+		if (e == hipSuccess) m.allocations.push_back(*dptr);
 		return e;
 	};
-	HIP_TRY(up(m.d_cols, m.cols.data(), m.cols.size() * sizeof(DevColumn)));
+	auto up = [&](void** dptr, const void* src, size_t bytes) -> hipError_t {
+		hipError_t e = alloc(dptr, bytes);
+		if (e != hipSuccess) return e;
+		if (bytes) e = hipMemcpyAsync(*dptr, src, bytes, hipMemcpyHostToDevice, m.stream);
+		return e;
+	};
 	std::vector<int32_t> delta_fallback;
 	const int32_t* delta_src = p.delta.data();
 	size_t delta_count = (size_t)p.col_ptr[n] * p.n_ind;
 	if (p.n_ind == 0) { delta_fallback.assign(std::max<size_t>(p.col_ptr[n], 1), 0); delta_src = delta_fallback.data(); delta_count = delta_fallback.size(); }
-	HIP_TRY(up(m.d_delta, delta_src, delta_count * sizeof(int32_t)));
-	HIP_TRY(up(m.d_term_ptr, term_ptr32.data(), term_ptr32.size() * sizeof(uint32_t)));
-	HIP_TRY(up(m.d_terms, terms.data(), terms.size() * sizeof(DevTerm)));
-	HIP_TRY(up(m.d_segs, segs.data(), segs.size() * sizeof(uint32_t)));
-	HIP_TRY(hipMalloc((void**)&m.d_bt, std::max<uint64_t>(bt, 16)));
+	void *d_delta, *d_term_ptr, *d_terms, *d_segs, *d_bt, *d_keys, *d_last_keys, *d_rcol, *d_rbt, *d_rsegs;
+	HIP_TRY(up((void**)&m.d_cols, m.cols.data(), m.cols.size() * sizeof(DevColumn)));
+	HIP_TRY(up(&d_delta, delta_src, delta_count * sizeof(int32_t)));
+	HIP_TRY(up(&d_term_ptr, term_ptr32.data(), term_ptr32.size() * sizeof(uint32_t)));
+	HIP_TRY(up(&d_terms, terms.data(), terms.size() * sizeof(DevTerm)));
+	HIP_TRY(up(&d_segs, segs.data(), segs.size() * sizeof(uint32_t)));
+	HIP_TRY(up(&d_rcol, m.plan.columns.data(), m.plan.columns.size() * sizeof(ResColumn)));
+	HIP_TRY(up(&d_rbt, m.plan.backtrace.data(), m.plan.backtrace.size() * sizeof(ResBacktrace)));
+	HIP_TRY(up(&d_rsegs, m.plan.segs.data(), m.plan.segs.size() * sizeof(uint32_t)));
+	HIP_TRY(alloc(&d_bt, bt));
 	m.key_entries = (size_t)(1ull << max_keys_f) * p.T;
-	HIP_TRY(hipMalloc((void**)&m.d_keys, m.key_entries * 8));
-	HIP_TRY(hipMalloc((void**)&m.d_last_keys, (size_t)MAX_T * 8));
-	HIP_TRY(hipMalloc((void**)&m.d_pr[0], (size_t)(1ull << max_f) * p.T * 4));
-	HIP_TRY(hipMalloc((void**)&m.d_pr[1], (size_t)(1ull << max_f) * p.T * 4));
-	HIP_TRY(hipMalloc((void**)&m.d_path_index, (size_t)n * 4));
-	HIP_TRY(hipMalloc((void**)&m.d_path_trans, (size_t)n * 4));
-	HIP_TRY(hipMalloc((void**)&m.d_score, 16));
+	HIP_TRY(alloc(&d_keys, m.key_entries * 8));
+	HIP_TRY(alloc(&d_last_keys, (size_t)MAX_T * 8));
+	HIP_TRY(alloc((void**)&m.d_pr[0], (size_t)(1ull << max_f) * p.T * 4));
+	HIP_TRY(alloc((void**)&m.d_pr[1], (size_t)(1ull << max_f) * p.T * 4));
+	HIP_TRY(alloc((void**)&m.d_path_index, (size_t)n * 4));
+	HIP_TRY(alloc((void**)&m.d_path_trans, (size_t)n * 4));
+	HIP_TRY(alloc((void**)&m.d_score, 16));
 	HIP_TRY(hipStreamSynchronize(m.stream));
 	m.dp.cols = m.d_cols;
-	m.dp.delta = m.d_delta;
-	m.dp.term_ptr = m.d_term_ptr;
-	m.dp.terms = m.d_terms;
-	m.dp.segs = m.d_segs;
-	m.dp.bt = m.d_bt;
-	m.dp.keys = m.d_keys;
-	m.dp.last_keys = m.d_last_keys;
+	m.dp.delta = (const int32_t*)d_delta;
+	m.dp.term_ptr = (const uint32_t*)d_term_ptr;
+	m.dp.terms = (const DevTerm*)d_terms;
+	m.dp.segs = (const uint32_t*)d_segs;
+	m.dp.bt = (uint8_t*)d_bt;
+	m.dp.keys = (unsigned long long*)d_keys;
+	m.dp.last_keys = (unsigned long long*)d_last_keys;
+	m.dp.res_cols = (const ResColumn*)d_rcol;
+	m.dp.res_bt = (const ResBacktrace*)d_rbt;
+	m.dp.res_segs = (const uint32_t*)d_rsegs;
+	m.dp.dbg = nullptr;
+	if (getenv("WHAMD_DEBUG_TIMING")) {
+		void* d_dbg = nullptr;
+		HIP_TRY(alloc(&d_dbg, (m.plan.segments.size() + 1) * 64));
+		HIP_TRY(hipMemset(d_dbg, 0, (m.plan.segments.size() + 1) * 64));
+		m.dp.dbg = (unsigned long long*)d_dbg;
+	}
 	m.dp.n_cols = n;
 	m.dp.T = p.T;
 	m.dp.tbits = tbits;
 	m.dp.n_ind = p.n_ind;
+	static bool lds_opt_in = false;
+	if (!lds_opt_in) {
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		lds_opt_in = true;
+	}
 	return WHAMD_OK;
 }
-
-void DeviceTable::set_force_keys(bool v) { impl_->force_keys = v; }
 
 whamd_status_t DeviceTable::solve(const Problem& p, Solution& s, whamd_solve_stats& st, std::string& msg) {
 	Impl& m = *impl_;
@@ -507,14 +802,26 @@ whamd_status_t DeviceTable::solve(const Problem& p, Solution& s, whamd_solve_sta
 		return WHAMD_OK;
 	}
 	HIP_TRY(hipSetDevice(m.device));
-	HIP_TRY(hipMemsetAsync(m.d_keys, 0xFF, m.key_entries * 8, m.stream));
-	HIP_TRY(hipMemsetAsync(m.d_last_keys, 0xFF, (size_t)MAX_T * 8, m.stream));
+	HIP_TRY(hipMemsetAsync(m.dp.keys, 0xFF, m.key_entries * 8, m.stream));
+	HIP_TRY(hipMemsetAsync(m.dp.last_keys, 0xFF, (size_t)MAX_T * 8, m.stream));
 	HIP_TRY(hipEventRecord(m.ev0, m.stream));
 	uint64_t launches = 0;
-	for (uint32_t c = 0; c < n; ++c) {
+	uint32_t flip = 0;  // every step reads d_pr[flip] and writes d_pr[flip ^ 1]
+	for (const Step& step : m.plan.steps) {
+		const uint32_t* prev = m.d_pr[flip];
+		uint32_t* cur = m.d_pr[flip ^ 1];
+		flip ^= 1;
+		if (step.kind == 1) {
+			const ResSegment& sg = m.plan.segments[step.index];
+			const size_t lds = (size_t)sg.ncols * (64 + RES_TABLE) * 4 + 2 * ((size_t)4 << sg.max_l) + (size_t)sg.stage_words * 8;
+			ResSegment arg = sg;
+			arg.pad = step.index;
+			hipLaunchKernelGGL(resident_segment, dim3(1u << sg.g), dim3(sg.threads), lds, m.stream, m.dp, arg, prev, cur);
+			++launches;
+			continue;
+		}
+		const uint32_t c = step.index;
 		const DevColumn& d = m.cols[c];
-		const uint32_t* prev = m.d_pr[(c + 1) & 1];
-		uint32_t* cur = m.d_pr[c & 1];
 		if (d.mode == 0) {
 			const uint32_t threads = 1u << d.f;
 			const uint32_t block = std::min<uint32_t>(256, threads);
@@ -550,6 +857,18 @@ whamd_status_t DeviceTable::solve(const Problem& p, Solution& s, whamd_solve_sta
 	st.backtrace_ms = f12;
 	st.total_ms = f03;
 	st.forward_launches = launches;
+	if (m.dp.dbg) {
+		std::vector<unsigned long long> d(m.plan.segments.size() * 8);
+		HIP_TRY(hipMemcpy(d.data(), m.dp.dbg, d.size() * 8, hipMemcpyDeviceToHost));
+		unsigned long long a = 0, b = 0, c2 = 0, cols = 0, p1 = 0, p2 = 0, p3 = 0;
+		for (size_t i = 0; i < m.plan.segments.size(); ++i) { a += d[8 * i]; b += d[8 * i + 1]; c2 += d[8 * i + 2]; cols += d[8 * i + 3]; p1 += d[8 * i + 4]; p2 += d[8 * i + 5]; p3 += d[8 * i + 6]; }
+		fprintf(stderr, "[whamd timing] per column (wave 0 of workgroup 0): compute %.0f barrier %.0f cycles\n",
+		        (double)p2 / std::max<unsigned long long>(cols, 1), (double)p3 / std::max<unsigned long long>(cols, 1));
+		(void)p1;
+		fprintf(stderr, "[whamd timing] segments %zu cols %llu | cycles/segment: prologue %.0f columns %.0f (%.0f per column) store %.0f | fwd %.3f ms, %.2f us per segment\n",
+		        m.plan.segments.size(), cols, (double)a / m.plan.segments.size(), (double)b / m.plan.segments.size(),
+		        (double)b / std::max<unsigned long long>(cols, 1), (double)c2 / m.plan.segments.size(), f01, f01 * 1e3 / m.plan.segments.size());
+	}
 	return WHAMD_OK;
 }
 

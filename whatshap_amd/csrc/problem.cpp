@@ -354,6 +354,7 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 		p.n_cells += 1ull << kc;
 		p.algorithmic_bytes += (c > 0 ? 4 * Tl * (1ull << p.b[c]) : 0) + (c + 1 < n ? 12 * Tl * (1ull << p.f[c]) : 0) + 12ull * kc;
 	}
+	p.value_bound = bound;
 	if (bound >= 4294967295.0) {
 		msg = "costs may exceed 32 bits (upper bound " + std::to_string(bound) + "); the reference's unsigned arithmetic wraps there and results are undefined";
 		return WHAMD_ERR_OVERFLOW;

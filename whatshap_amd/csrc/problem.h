@@ -72,6 +72,7 @@ struct Problem {
 	std::vector<int32_t> delta;  // [col_ptr[c] * n_ind ... ): for column c, delta[(col_ptr[c] * n_ind) + s * k_c + bit]
 	uint32_t max_k = 0;
 	uint64_t n_cells = 0, algorithmic_bytes = 0;
+	double value_bound = 0.0;  // upper bound on every finite DP value
 
 	const ColumnEntry* col_begin(uint32_t c) const { return entries.data() + col_ptr[c]; }
 	uint64_t term_begin(uint32_t c, uint32_t t) const { return term_ptr[(size_t)c * T + t]; }

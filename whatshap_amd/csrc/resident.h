@@ -1,0 +1,98 @@
+// resident.h -- the "resident" forward path (single individual, T = 1): a run of consecutive columns is processed by
+// ONE launch in which every workgroup keeps its slice of the projection column in LDS.
+//
+// Bits of the state are split per run ("segment"): g *grid reads* -- reads that stay active through the whole run --
+// index the 2^g workgroups; all other reads are *local* bits of a workgroup's LDS slice.  Reads that start inside the
+// run become new (top) local bits, reads that end inside the run are minimised out of the local index.  Between runs
+// the projection column is stored in HBM in logical order, so the next run is free to choose other grid reads
+// (the re-layout is the only time Pr touches HBM).  Columns that do not fit a run (last column, > 3 reads ending at
+// once, slices larger than LDS) are executed by the per-column kernels of dp_device.hip.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "problem.h"
+
+namespace whamd {
+
+constexpr int RES_EMAX = 3;        // reads that may end in one resident column
+constexpr int RES_LMAX = 13;       // log2 of the largest LDS slice (entries)
+constexpr int RES_GMAX = 8;        // log2 of the largest grid (workgroups) of one run
+constexpr int RES_MAXCOLS = 48;    // columns per run (bounds the LDS lookup tables)
+constexpr int RES_TABLE = 256;     // per column: two 128-entry tables (low / high 7 local bits)
+
+// Self-contained descriptor of one resident column (256 B); a run's descriptors are copied to LDS at kernel start
+// so that no per-column global (HBM-latency) load sits on the sequential column chain.  The first 24 words are the
+// "hot" part every lane reads as LDS broadcasts into vector registers once per column (six 16-byte reads) -- the CU has
+// ONE scalar ALU shared by all waves, so per-column scalar work replicated per wave is what must be avoided.
+// Sg / PG are filled in per workgroup by the kernel.
+struct ResColumn {
+	// ---- hot words 0..23
+	uint32_t Cp, Cm, Cc, mode;        // cost = min(Cp + S, Cm - S, Cc); an absent Cp / Cm is RES_ABSENT (never the minimum:
+	                                  // the planner guarantees every real value < 2^30).  mode: RES_MODE_*
+	uint32_t lowmask, nthr, stage_off, nwords;  // 2^Lb - 1; threads of the vectorised path (2^Lf / 4); word offset of this
+	                                  // column's ballot words in the workgroup's staging area; words per plane
+	uint32_t epos[4];                 // local bit position of ending read q (ascending logical position); [3] unused
+	uint32_t mL[4];                   // per ending read: local cell bits logically above it (tie-break parity); [3] unused
+	int32_t Sg;                       // written by the kernel: sum of the grid-read deltas selected by the workgroup index
+	uint32_t PG;                      // written by the kernel: bit q = parity of the workgroup-index bits above ending read q
+	uint32_t Lb, Lf;
+	int32_t d0, d1, d2, dE;           // deltas of local cell bits 0, 1, 2 and of ending read 0
+	// ---- cold part
+	uint32_t ebits, pad0;
+	uint32_t mG[4];                   // per ending read: grid bits logically above it
+	int32_t dgrid[RES_GMAX];          // signed deltas of the grid reads at this column
+	int32_t dloc[14];                 // signed deltas of the local bits
+	uint32_t pad1[12];
+};
+static_assert(sizeof(ResColumn) == 256, "ResColumn must stay 64 words");
+constexpr uint32_t RES_ABSENT = 0xC0000000u;
+// vectorised modes: a thread owns 4 consecutive projection entries and moves them with 16-byte LDS accesses
+constexpr uint32_t RES_MODE_E0 = 0;       // no read ends
+constexpr uint32_t RES_MODE_E1_HIGH = 1;  // one read ends, local bit >= 2
+constexpr uint32_t RES_MODE_E1_BIT0 = 2;  // one read ends, local bit 0
+constexpr uint32_t RES_MODE_E1_BIT1 = 3;  // one read ends, local bit 1
+constexpr uint32_t RES_MODE_GENERIC = 4;  // anything else (<= 3 reads ending, tiny slices)
+
+// Passed to the kernel by value (kernel arguments live in SGPRs: no memory round trip before the first column).
+constexpr int RES_IOSEG = 6;       // runs per mask of the load / store layouts held in the kernel arguments
+struct ResSegment {
+	uint32_t c0, ncols, g, col_off;
+	uint32_t Lb0, Lf_last, has_prev, threads;
+	uint32_t max_l, pad;
+	uint32_t stage_words;  // ballot words (u64) one workgroup produces in this run
+	uint32_t bt_lo, bt_hi; // byte offset of the run's backtrace record: [workgroup][stage_words] u64
+	uint16_t n_in_grid, n_in_local, n_out_grid, n_out_local;
+	// packed runs (compact position | mask position << 8 | length << 16): logical index = OR of deposits of w and l
+	uint32_t in_grid[RES_IOSEG], in_local[RES_IOSEG], out_grid[RES_IOSEG], out_local[RES_IOSEG];
+};
+
+// How the backtrace finds a resident column's record: extraction of (w, l) from the logical projection index.
+struct ResBacktrace {
+	uint32_t ext_off;      // extract segments: n_grid (-> w), then n_local (-> l)
+	uint16_t n_grid, n_local;
+	uint32_t g, nwords;
+	uint32_t layout;       // 0: bit of entry l = word l >> 6, bit l & 63;  1: word ((l >> 2) >> 6) * 4 + (l & 3), bit (l >> 2) & 63
+	uint32_t stage_off, stage_words;  // record of (workgroup w, plane q, word i): run base + (w * stage_words + stage_off + q * nwords + i) * 8
+	uint64_t seg_bt_off;
+};
+
+struct Step {
+	uint32_t kind;         // 0 = one column through the column kernels, 1 = resident run
+	uint32_t index;        // column index, or index into segments
+};
+
+struct ResidentPlan {
+	std::vector<Step> steps;
+	std::vector<ResSegment> segments;
+	std::vector<ResColumn> columns;      // resident columns in run order
+	std::vector<int32_t> col_to_res;     // [n_cols] index into `columns` or -1
+	std::vector<ResBacktrace> backtrace; // parallel to `columns`
+	std::vector<uint32_t> segs;          // deposit / extract segment pool
+	uint64_t n_resident_columns = 0;
+};
+
+// Plans the whole forward pass.  `resident` false -> every step is a per-column step.
+void plan_forward(const Problem& p, bool resident, int l_pref, ResidentPlan& plan);
+
+}  // namespace whamd

@@ -1,0 +1,226 @@
+// resident_plan.cpp -- host planner of the forward pass: which columns run as resident segments (resident.h) and
+// which go through the per-column kernels; builds every descriptor the resident kernel and the backtrace need.
+#include <algorithm>
+#include <cstring>
+
+#include "resident.h"
+
+namespace whamd {
+
+namespace {
+
+// Runs of set bits of `mask` as (compact position | mask position << 8 | length << 16); `swap` exchanges the roles
+// (deposit: compact -> mask position; extract: mask position -> compact).
+uint16_t append_runs(uint32_t mask, bool extract, std::vector<uint32_t>& out) {
+	uint32_t compact = 0;
+	uint16_t count = 0;
+	for (uint32_t bit = 0; bit < 32;) {
+		if (!((mask >> bit) & 1u)) { ++bit; continue; }
+		uint32_t len = 0;
+		while (bit + len < 32 && ((mask >> (bit + len)) & 1u)) ++len;
+		const uint32_t src = extract ? bit : compact, dst = extract ? compact : bit;
+		out.push_back(src | (dst << 8) | (len << 16));
+		++count;
+		compact += len;
+		bit += len;
+	}
+	return count;
+}
+
+}  // namespace
+
+void plan_forward(const Problem& p, bool resident, int l_pref, ResidentPlan& plan) {
+	const uint32_t n = p.n_cols;
+	plan = ResidentPlan();
+	plan.col_to_res.assign(n, -1);
+	const bool eligible = resident && p.T == 1 && p.n_ind == 1 && p.value_bound < 1073741824.0;
+	std::vector<uint32_t> last_col;
+	if (eligible) {
+		last_col.assign(p.n_reads, 0);
+		for (uint32_t c = 0; c < n; ++c) {
+			const ColumnEntry* col = p.col_begin(c);
+			for (uint32_t j = 0; j < p.k[c]; ++j) last_col[col[j].read_id] = c;
+		}
+	}
+	uint32_t c = 0;
+	while (c < n) {
+		if (!eligible) {
+			plan.steps.push_back(Step{0, c});
+			++c;
+			continue;
+		}
+		const uint32_t b0 = p.b[c];
+		const ColumnEntry* first = p.col_begin(c);
+		uint32_t g = 0;
+		if ((int)b0 > l_pref) g = std::min<uint32_t>(b0 - (uint32_t)l_pref, RES_GMAX);
+		// grid reads: the g entering reads that end last (ties: the younger read)
+		std::vector<uint32_t> order(b0);
+		for (uint32_t j = 0; j < b0; ++j) order[j] = j;
+		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t bb) {
+			const uint32_t ea = last_col[first[a].read_id], eb = last_col[first[bb].read_id];
+			if (ea != eb) return ea > eb;
+			return a > bb;
+		});
+		std::vector<uint32_t> grid_reads;
+		uint32_t grid_end = 0xFFFFFFFFu;
+		for (uint32_t i = 0; i < g; ++i) {
+			grid_reads.push_back(first[order[i]].read_id);
+			grid_end = std::min(grid_end, last_col[first[order[i]].read_id]);
+		}
+		std::sort(grid_reads.begin(), grid_reads.end());
+		uint32_t c1 = c, run_max_l = 0;
+		uint64_t run_stage = 0;
+		while (c1 < n && c1 - c < (uint32_t)RES_MAXCOLS) {
+			if (c1 + 1 == n) break;      // the last column needs the global optimum
+			if (c1 >= grid_end) break;   // a grid read is minimised out at this column
+			const uint32_t kc = p.k[c1];
+			if (kc < g) break;
+			const uint32_t Lb = p.b[c1] - g, Lf = p.f[c1] - g, Lk = kc - g;
+			if (Lb > (uint32_t)RES_LMAX || Lf > (uint32_t)RES_LMAX || Lk > 14 || kc - p.f[c1] > (uint32_t)RES_EMAX) break;
+			run_max_l = std::max(run_max_l, std::max(Lb, Lf));
+			run_stage += (uint64_t)(kc - p.f[c1]) * std::max<uint32_t>(4, (1u << Lf) / 64);
+			const uint64_t lds_bytes = (uint64_t)(c1 - c + 1) * (64 + RES_TABLE) * 4 + 2 * (4ull << run_max_l) + run_stage * 8;
+			if (lds_bytes > 150 * 1024) break;
+			++c1;
+		}
+		if (c1 - c < 2) {
+			plan.steps.push_back(Step{0, c});
+			++c;
+			continue;
+		}
+		// ---- emit the segment [c, c1)
+		ResSegment seg{};
+		seg.c0 = c;
+		seg.ncols = c1 - c;
+		seg.g = g;
+		seg.col_off = (uint32_t)plan.columns.size();
+		seg.has_prev = c > 0;
+		uint32_t max_l = 0, stage_words = 0;
+		bool out_ok = true;
+		const size_t columns_mark = plan.columns.size(), segs_mark = plan.segs.size();
+		auto is_grid = [&](uint32_t read) { return std::binary_search(grid_reads.begin(), grid_reads.end(), read); };
+		{   // load layout: positions in the entering index == positions in column c (shared reads are its low bits)
+			uint32_t gm = 0;
+			for (uint32_t j = 0; j < b0; ++j) if (is_grid(first[j].read_id)) gm |= 1u << j;
+			const uint32_t lm = (b0 >= 32 ? 0xFFFFFFFFu : ((1u << b0) - 1u)) & ~gm;
+			std::vector<uint32_t> rg, rl;
+			seg.n_in_grid = append_runs(gm, false, rg);
+			seg.n_in_local = append_runs(lm, false, rl);
+			if (rg.size() > (size_t)RES_IOSEG || rl.size() > (size_t)RES_IOSEG) {  // exotic layout: leave this column to the column kernels
+				plan.steps.push_back(Step{0, c});
+				++c;
+				continue;
+			}
+			std::copy(rg.begin(), rg.end(), seg.in_grid);
+			std::copy(rl.begin(), rl.end(), seg.in_local);
+			seg.Lb0 = b0 - g;
+		}
+		for (uint32_t cc = c; cc < c1; ++cc) {
+			const ColumnEntry* col = p.col_begin(cc);
+			const uint32_t kc = p.k[cc];
+			const int32_t* dl = p.delta.data() + (size_t)p.col_ptr[cc];  // n_ind == 1
+			ResColumn rc{};
+			rc.Lb = p.b[cc] - g;
+			rc.Lf = p.f[cc] - g;
+			rc.ebits = kc - p.f[cc];
+			max_l = std::max(max_l, std::max(rc.Lb, rc.Lf));
+			rc.Cp = rc.Cm = RES_ABSENT;
+			rc.Cc = INF;
+			for (uint64_t q = p.term_begin(cc, 0); q < p.term_end(cc, 0); ++q) {
+				const CostTerm& t = p.terms[q];
+				if (t.plus) rc.Cp = t.c;
+				else if (t.minus) rc.Cm = t.c;
+				else rc.Cc = std::min(rc.Cc, t.c);
+			}
+			// logical -> (grid slot | local bit)
+			uint32_t li = 0, gi = 0;
+			std::vector<int> local_of(kc, -1), grid_of(kc, -1);
+			for (uint32_t j = 0; j < kc; ++j) {
+				if (is_grid(col[j].read_id)) {
+					grid_of[j] = (int)gi;
+					rc.dgrid[gi++] = dl[j];
+				} else {
+					local_of[j] = (int)li;
+					rc.dloc[li] = dl[j];
+					++li;
+				}
+			}
+			uint32_t en = 0;
+			for (uint32_t j = 0; j < kc; ++j) {  // ending reads in ascending logical position
+				if (local_of[j] < 0 || ((p.fwd_mask[cc] >> j) & 1u)) continue;
+				uint32_t mg = 0, ml = 0;
+				for (uint32_t q = j + 1; q < kc; ++q) {
+					if (grid_of[q] >= 0) mg |= 1u << grid_of[q]; else ml |= 1u << local_of[q];
+				}
+				rc.epos[en] = (uint32_t)local_of[j];
+				rc.mG[en] = mg;
+				rc.mL[en] = ml;
+				++en;
+			}
+			rc.d0 = rc.dloc[0];
+			rc.d1 = rc.dloc[1];
+			rc.d2 = rc.dloc[2];
+			rc.dE = rc.ebits ? rc.dloc[rc.epos[0]] : 0;
+			rc.lowmask = (1u << rc.Lb) - 1u;
+			rc.nthr = (1u << rc.Lf) >> 2;
+			// vectorised path: a thread owns 4 consecutive projection entries (8 cells when a read ends) and moves them
+			// with 16-byte LDS accesses; needs aligned groups in the previous slice
+			const bool fast = rc.ebits <= 1 && rc.Lf >= 2 && rc.Lb >= 3;
+			if (!fast) rc.mode = RES_MODE_GENERIC;
+			else if (rc.ebits == 0) rc.mode = RES_MODE_E0;
+			else rc.mode = rc.epos[0] >= 2 ? RES_MODE_E1_HIGH : (rc.epos[0] == 0 ? RES_MODE_E1_BIT0 : RES_MODE_E1_BIT1);
+			rc.nwords = fast ? std::max<uint32_t>(4, (1u << rc.Lf) / 64) : std::max<uint32_t>(1, (1u << rc.Lf) / 64);
+			rc.stage_off = stage_words;
+			stage_words += rc.ebits * rc.nwords;
+			// backtrace: (w, l) from the logical projection index of this column
+			ResBacktrace rb{};
+			uint32_t gmf = 0, fi = 0;
+			for (uint32_t j = 0; j < kc; ++j) {
+				if (!((p.fwd_mask[cc] >> j) & 1u)) continue;
+				if (grid_of[j] >= 0) gmf |= 1u << fi;
+				++fi;
+			}
+			const uint32_t lmf = (fi >= 32 ? 0xFFFFFFFFu : ((1u << fi) - 1u)) & ~gmf;
+			rb.ext_off = (uint32_t)plan.segs.size();
+			rb.n_grid = append_runs(gmf, true, plan.segs);
+			rb.n_local = append_runs(lmf, true, plan.segs);
+			rb.g = g;
+			rb.nwords = rc.nwords;
+			rb.layout = fast ? 1u : 0u;
+			rb.stage_off = rc.stage_off;
+			if (cc + 1 == c1) {  // store layout of the exit state
+				std::vector<uint32_t> rg, rl;
+				seg.n_out_grid = append_runs(gmf, false, rg);
+				seg.n_out_local = append_runs(lmf, false, rl);
+				out_ok = rg.size() <= (size_t)RES_IOSEG && rl.size() <= (size_t)RES_IOSEG;
+				if (out_ok) {
+					std::copy(rg.begin(), rg.end(), seg.out_grid);
+					std::copy(rl.begin(), rl.end(), seg.out_local);
+				}
+				seg.Lf_last = rc.Lf;
+			}
+			plan.col_to_res[cc] = (int32_t)plan.columns.size();
+			plan.columns.push_back(rc);
+			plan.backtrace.push_back(rb);
+		}
+		if (!out_ok) {  // exotic exit layout: undo and leave the first column to the column kernels
+			for (uint32_t cc = c; cc < c1; ++cc) plan.col_to_res[cc] = -1;
+			plan.columns.resize(columns_mark);
+			plan.backtrace.resize(columns_mark);
+			plan.segs.resize(segs_mark);
+			plan.steps.push_back(Step{0, c});
+			++c;
+			continue;
+		}
+		seg.threads = std::min<uint32_t>(1024, std::max<uint32_t>(64, (1u << max_l) / 4));
+		seg.max_l = max_l;
+		seg.stage_words = stage_words;
+		for (size_t i = columns_mark; i < plan.backtrace.size(); ++i) plan.backtrace[i].stage_words = stage_words;
+		plan.steps.push_back(Step{1, (uint32_t)plan.segments.size()});
+		plan.segments.push_back(seg);
+		plan.n_resident_columns += seg.ncols;
+		c = c1;
+	}
+}
+
+}  // namespace whamd
