@@ -15,7 +15,7 @@ from whatshap_amd.core import PedigreeDPTable
 from whatshap_amd.synthetic import random_small_instance, synthetic_block
 
 pytestmark = pytest.mark.gpu
-PATHS = ["auto", "column_keys"]
+PATHS = ["auto", "column", "column_keys"]  # auto = resident runs where they apply
 
 
 def oracle_outcome(problem):
@@ -157,7 +157,61 @@ def test_full_size_trio_paths_agree():
     """BASELINE config 4 shape (trio, coverage 15) at a fifth of its length: the fused path and the independent key
     path produce identical cost, backtrace, transmission vector and superreads."""
     p = synthetic_block(n_variants=20000, coverage=15, seed=4, trio=True)
-    a = native_solution(p, "auto")
+    a = native_solution(p, "column")
     b = native_solution(p, "column_keys")
     assert a == b, first_difference(a, b)
     assert len(set(a["transmission"])) >= 1
+
+
+def test_full_size_resident_equals_column_path():
+    """BASELINE config 2 at full size: the resident path (LDS-resident runs, per-workgroup backtrace records) and the
+    per-column path (HBM projection column, bit-plane backtrace) agree on every output."""
+    p = synthetic_block(n_variants=50000, coverage=15, seed=2)
+    a = native_solution(p, "resident")
+    b = native_solution(p, "column")
+    assert a == b, first_difference(a, b)
+
+
+@pytest.mark.parametrize("l_pref", [4, 7, 9, 13])
+def test_resident_slice_sizes(l_pref):
+    """Different grid/local splits of the resident path (1 .. 256 workgroups per run) give identical results."""
+    p = synthetic_block(n_variants=700, coverage=14, seed=77)
+    want = table_solution(oracle.OracleTable(p))
+    t = _native.NativeTable(p, solve=False, path="resident")
+    t.set_option("resident_l", str(l_pref))
+    t.solve()
+    assert table_solution(t) == want
+
+
+def test_resident_irregular_reads_vs_oracle():
+    """Reads of very different lengths, nested and paired-end-like gapped reads: grid reads are not simply the youngest
+    reads, several reads end in one column, runs are short and interleave with per-column steps."""
+    rng = np.random.default_rng(123)
+    n_var = 400
+    reads = []
+    for start in range(0, n_var - 2):
+        for _ in range(rng.integers(0, 3)):
+            length = int(rng.choice([2, 3, 5, 9, 17, 30]))
+            end = min(n_var, start + length)
+            cols = [c for c in range(start, end) if c in (start, end - 1) or rng.random() < 0.7]
+            if len(cols) >= 2:
+                reads.append(cols)
+    read_ptr, pos, alle, qual = [0], [], [], []
+    hap = rng.integers(0, 2, n_var)
+    for cols in reads:
+        side = rng.integers(0, 2)
+        for c in cols:
+            pos.append(10 * (c + 1))
+            alle.append(int(hap[c] ^ side ^ (rng.random() < 0.05)))
+            qual.append(int(rng.integers(1, 30)))
+        read_ptr.append(len(pos))
+    p = _native.ProblemArrays(read_ptr, pos, alle, qual, np.zeros(len(reads)), [0], [], np.ones((1, n_var)), None,
+                              [1] * n_var, [10 * (c + 1) for c in range(n_var)], False)
+    cov = np.zeros(n_var, dtype=int)
+    for cols in reads:
+        cov[cols[0]:cols[-1] + 1] += 1
+    assert cov.max() <= 25
+    want = table_solution(oracle.OracleTable(p))
+    for path in PATHS:
+        got = native_solution(p, path)
+        assert got == want, (path, first_difference(want, got))

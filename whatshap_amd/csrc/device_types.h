@@ -42,7 +42,6 @@ struct DevProblem {
 	// resident path (resident.h)
 	const ResColumn* res_cols;
 	const ResBacktrace* res_bt;
-	const uint32_t* res_segs;
 	unsigned long long* dbg;  // optional cycle-counter dump (WHAMD_DEBUG_TIMING)
 	uint32_t n_cols;
 	uint32_t T;

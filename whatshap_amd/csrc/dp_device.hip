@@ -263,12 +263,32 @@ __global__ __launch_bounds__(1024) void resident_segment(DevProblem P, ResSegmen
 	unsigned long long* stage = reinterpret_cast<unsigned long long*>(bufQ + (1u << sg.max_l));  // backtrace ballots of the run
 	// stage the descriptors (coalesced copy) and the entering slice (re-layout from the logical order in HBM)
 	const uint32_t* __restrict__ gcols = reinterpret_cast<const uint32_t*>(P.res_cols + sg.col_off);
-	for (uint32_t i = tid; i < sg.ncols * 64; i += NT) ldsc[i] = gcols[i];
+	// (loads are issued in batches of 8 before the first use, so one memory latency covers the whole copy)
+	{
+		const uint32_t total = sg.ncols * 64;
+		for (uint32_t i0 = 0; i0 < total; i0 += NT * 8) {
+			uint32_t v[8];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) { const uint32_t i = i0 + u * NT + tid; v[u] = i < total ? gcols[i] : 0u; }
+#pragma unroll
+			for (int u = 0; u < 8; ++u) { const uint32_t i = i0 + u * NT + tid; if (i < total) ldsc[i] = v[u]; }
+		}
+	}
 	if (!sg.has_prev) {
 		if (tid == 0) bufP[0] = 0;
 	} else {
 		const uint32_t wpart = deposit_args(w, sg.in_grid, sg.n_in_grid);
-		for (uint32_t l = tid; l < (1u << sg.Lb0); l += NT) bufP[l] = prev[wpart | deposit_args(l, sg.in_local, sg.n_in_local)];
+		const uint32_t total = 1u << sg.Lb0;
+		for (uint32_t l0 = 0; l0 < total; l0 += NT * 8) {
+			uint32_t v[8];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) {
+				const uint32_t l = l0 + u * NT + tid;
+				v[u] = l < total ? prev[wpart | deposit_args(l, sg.in_local, sg.n_in_local)] : 0u;
+			}
+#pragma unroll
+			for (int u = 0; u < 8; ++u) { const uint32_t l = l0 + u * NT + tid; if (l < total) bufP[l] = v[u]; }
+		}
 	}
 	__syncthreads();
 	// per-column scalars that depend on the workgroup index, and the lookup tables of the local part of S
@@ -466,10 +486,20 @@ __global__ __launch_bounds__(1024) void resident_segment(DevProblem P, ResSegmen
 	}
 }
 
-// Backtrace (src/pedigreedptable.cpp:137-173) by one lane; out: index / transmission per column, out_score[0] = optimum.
-__global__ void backtrace_kernel(DevProblem P, uint32_t* __restrict__ path_index, uint32_t* __restrict__ path_trans,
-                                 uint32_t* __restrict__ out_score) {
-	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// Backtrace (src/pedigreedptable.cpp:137-173) by one wave; out: index / transmission per column, out_score[0] = optimum.
+// The steps of the forward plan are walked in reverse.  For a resident run the argmin bits the path can touch all
+// belong to ONE workgroup's record (the grid-read bits of the path do not change inside a run), so the wave copies
+// that record (a few KiB) and the run's column records into LDS with one coalesced load and then follows the path
+// with LDS latency instead of one dependent HBM access per column.
+__global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const Step* __restrict__ steps, uint32_t n_steps,
+                                                       const ResSegment* __restrict__ segments,
+                                                       uint32_t* __restrict__ path_index, uint32_t* __restrict__ path_trans,
+                                                       uint32_t* __restrict__ out_score) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+	uint32_t* recs = smem;                                                              // RES_MAXCOLS * 32 words
+	uint32_t* xshare = smem + RES_MAXCOLS * 32;                                         // 4 words
+	unsigned long long* stage = reinterpret_cast<unsigned long long*>(smem + RES_MAXCOLS * 32 + 4);
+	const uint32_t lane = threadIdx.x;
 	const uint32_t n = P.n_cols, T = P.T;
 	// optimum of the last column: first (rank(x), i) attaining the minimum (strict '<' scan, :306-315)
 	unsigned long long bestk = ~0ull;
@@ -479,59 +509,116 @@ __global__ void backtrace_kernel(DevProblem P, uint32_t* __restrict__ path_index
 		if ((key >> 4) < (bestk >> 4)) { bestk = key; t = i; }
 	}
 	if (bestk == ~0ull) {  // unreachable for valid inputs (the host rejects Mendelian conflicts); keep defined output
-		out_score[0] = 0xFFFFFFFFu;
+		if (lane == 0) out_score[0] = 0xFFFFFFFFu;
 		bestk = 0;
-	} else {
+	} else if (lane == 0) {
 		out_score[0] = (uint32_t)(bestk >> 32);
 	}
 	const uint32_t rlast = (uint32_t)(bestk >> 4) & 0x0FFFFFFFu;
 	uint32_t x = rlast ^ (rlast >> 1);
 	tprev = (uint32_t)bestk & 15u;
-	path_index[n - 1] = x;
-	path_trans[n - 1] = t;
-	for (uint32_t c = n - 1; c > 0; --c) {
-		const DevColumn cc = P.cols[c];
-		const DevColumn pc = P.cols[c - 1];
-		const uint32_t y = x & ((1u << cc.b) - 1u);
-		uint32_t xp, aj;
-		if (pc.mode == 0) {
-			const unsigned long long* planes = reinterpret_cast<const unsigned long long*>(P.bt + pc.bt_off);
-			const uint32_t words = 1u << (pc.f - 6);
-			uint32_t v = 0;
-			for (uint32_t p = 0; p < pc.nplanes; ++p) {
-				const unsigned long long word = planes[(size_t)(p * T + tprev) * words + (y >> 6)];
-				v |= (uint32_t)((word >> (y & 63u)) & 1ull) << p;
+	if (lane == 0) {
+		path_index[n - 1] = x;
+		path_trans[n - 1] = t;
+	}
+	// steps[n_steps - 1] is the last column itself; every earlier step yields x_c from x_{c+1}
+	for (uint32_t si = n_steps - 1; si-- > 0;) {
+		const Step st = steps[si];
+		if (st.kind == 0) {
+			const uint32_t c = st.index;
+			const DevColumn pc = P.cols[c];
+			const uint32_t y = x & ((1u << pc.f) - 1u);
+			uint32_t xp, aj;
+			if (pc.mode == 0) {
+				const unsigned long long* planes = reinterpret_cast<const unsigned long long*>(P.bt + pc.bt_off);
+				const uint32_t words = 1u << (pc.f - 6);
+				uint32_t v = 0;
+				for (uint32_t p = 0; p < pc.nplanes; ++p) {
+					const unsigned long long word = planes[(size_t)(p * T + tprev) * words + (y >> 6)];
+					v |= (uint32_t)((word >> (y & 63u)) & 1ull) << p;
+				}
+				const uint32_t e = v & ((1u << pc.ebits) - 1u);
+				aj = v >> pc.ebits;
+				const uint32_t* segs = P.segs + pc.seg_off;
+				xp = deposit(y, segs, pc.nseg_fwd) | deposit(e, segs + pc.nseg_fwd, pc.nseg_end);
+			} else {
+				const uint32_t raw = reinterpret_cast<const uint32_t*>(P.bt + pc.bt_off)[(size_t)y * T + tprev];
+				const uint32_t r = raw >> 4;
+				xp = r ^ (r >> 1);
+				aj = raw & 15u;
 			}
-			const uint32_t e = v & ((1u << pc.ebits) - 1u);
-			aj = v >> pc.ebits;
-			const uint32_t* segs = P.segs + pc.seg_off;
-			xp = deposit(y, segs, pc.nseg_fwd) | deposit(e, segs + pc.nseg_fwd, pc.nseg_end);
-		} else if (pc.mode == 2) {
-			const ResBacktrace rb = P.res_bt[pc.res_idx];
-			const uint32_t* xs = P.res_segs + rb.ext_off;
-			const uint32_t w = deposit(y, xs, rb.n_grid), l = deposit(y, xs + rb.n_grid, rb.n_local);
-			const unsigned long long* planes = reinterpret_cast<const unsigned long long*>(P.bt + rb.seg_bt_off) +
-			                                   (size_t)w * rb.stage_words + rb.stage_off;
-			uint32_t e = 0;
-			const uint32_t widx = rb.layout ? (((l >> 2) >> 6) * 4 + (l & 3u)) : (l >> 6);
-			const uint32_t bpos = rb.layout ? ((l >> 2) & 63u) : (l & 63u);
-			for (uint32_t q = 0; q < pc.ebits; ++q) {
-				const unsigned long long word = planes[(size_t)q * rb.nwords + widx];
-				e |= (uint32_t)((word >> bpos) & 1ull) << q;
+			if (lane == 0) {
+				path_index[c] = xp;
+				path_trans[c] = tprev;
 			}
-			aj = 0;
-			const uint32_t* segs = P.segs + pc.seg_off;
-			xp = deposit(y, segs, pc.nseg_fwd) | deposit(e, segs + pc.nseg_fwd, pc.nseg_end);
-		} else {
-			const uint32_t raw = reinterpret_cast<const uint32_t*>(P.bt + pc.bt_off)[(size_t)y * T + tprev];
-			const uint32_t r = raw >> 4;
-			xp = r ^ (r >> 1);
-			aj = raw & 15u;
+			tprev = aj;
+			x = xp;
+			continue;
 		}
-		path_index[c - 1] = xp;
-		path_trans[c - 1] = tprev;
-		tprev = aj;
-		x = xp;
+		// ---- resident run [c0, c0 + ncols)
+		const ResSegment sg = segments[st.index];
+		const uint32_t yexit = x & ((1u << (sg.Lf_last + sg.g)) - 1u);
+		uint32_t w = 0;
+		for (uint32_t i = 0; i < sg.n_wext; ++i) {
+			const uint32_t r = sg.wext[i];
+			w |= ((yexit >> (r & 31u)) & ((1u << ((r >> 16) & 31u)) - 1u)) << ((r >> 8) & 31u);
+		}
+		const uint32_t* __restrict__ grec = reinterpret_cast<const uint32_t*>(P.res_bt + sg.col_off);
+		for (uint32_t i = lane; i < sg.ncols * 32; i += blockDim.x) recs[i] = grec[i];
+		const unsigned long long* __restrict__ gst = reinterpret_cast<const unsigned long long*>(
+			P.bt + (((unsigned long long)sg.bt_hi << 32) | sg.bt_lo)) + (size_t)w * sg.stage_words;
+		for (uint32_t i = lane; i < sg.stage_words; i += blockDim.x) stage[i] = gst[i];
+		__syncthreads();
+		if (lane < 64) {  // one wave follows the path; the others only helped with the copy
+		// walk the run backwards; a column's record (22 words) is fetched with six 16-byte LDS reads, one column ahead
+		auto load_rec = [&](uint32_t ci, uint4 (&r)[6]) {
+			const uint4* q = reinterpret_cast<const uint4*>(recs + ci * 32);
+#pragma unroll
+			for (int i = 0; i < 6; ++i) r[i] = q[i];
+		};
+		uint4 rn[6];
+		load_rec(sg.ncols - 1, rn);
+		for (uint32_t ci = sg.ncols; ci-- > 0;) {
+			uint4 r[6];
+#pragma unroll
+			for (int i = 0; i < 6; ++i) r[i] = rn[i];
+			if (ci > 0) load_rec(ci - 1, rn);
+			// words: 0 ymask 1 ebits 2 nwords 3 stage_off | 4 layout 5 n_ext 6 n_fwd 7 pad | 8..13 ext | 14..17 fwd | 18..21 endpos
+			const uint32_t y = x & r[0].x;
+			const uint32_t ext[6] = {r[2].x, r[2].y, r[2].z, r[2].w, r[3].x, r[3].y};
+			const uint32_t fwd[4] = {r[3].z, r[3].w, r[4].x, r[4].y};
+			const uint32_t endpos[3] = {r[4].z, r[4].w, r[5].x};
+			uint32_t l = 0, xp = 0;
+#pragma unroll
+			for (int i = 0; i < 6; ++i) {
+				const uint32_t rr = (uint32_t)i < r[1].y ? ext[i] : 0u;  // a zero run has length 0 and contributes nothing
+				l |= ((y >> (rr & 31u)) & ((1u << ((rr >> 16) & 31u)) - 1u)) << ((rr >> 8) & 31u);
+			}
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				const uint32_t rr = (uint32_t)i < r[1].z ? fwd[i] : 0u;
+				xp |= ((y >> (rr & 31u)) & ((1u << ((rr >> 16) & 31u)) - 1u)) << ((rr >> 8) & 31u);
+			}
+			const uint32_t widx = r[1].x ? (((l >> 2) >> 6) * 4 + (l & 3u)) : (l >> 6);
+			const uint32_t bpos = r[1].x ? ((l >> 2) & 63u) : (l & 63u);
+			unsigned long long words[3];
+#pragma unroll
+			for (int q = 0; q < 3; ++q) words[q] = (uint32_t)q < r[0].y ? stage[r[0].w + q * r[0].z + widx] : 0ull;
+#pragma unroll
+			for (int q = 0; q < 3; ++q) xp |= (uint32_t)((words[q] >> bpos) & 1ull) << endpos[q];
+			if (lane == 0) {
+				path_index[sg.c0 + ci] = xp;
+				path_trans[sg.c0 + ci] = 0;
+			}
+			x = xp;
+		}
+		}
+		// hand the path position to every wave (they all need x to address the next run's record)
+		if (lane == 0) xshare[0] = x;
+		__syncthreads();
+		x = xshare[0];
+		tprev = 0;
+		__syncthreads();
 	}
 }
 
@@ -571,6 +658,9 @@ struct DeviceTable::Impl {
 	uint32_t* d_path_index = nullptr;
 	uint32_t* d_path_trans = nullptr;
 	uint32_t* d_score = nullptr;
+	Step* d_steps = nullptr;
+	ResSegment* d_segments = nullptr;
+	size_t bt_lds = 0;
 	std::vector<DevColumn> cols;
 	ResidentPlan plan;
 	DevProblem dp{};
@@ -585,6 +675,8 @@ struct DeviceTable::Impl {
 		for (void* a : allocations) (void)hipFree(a);
 		allocations.clear();
 		d_cols = nullptr;
+		d_steps = nullptr;
+		d_segments = nullptr;
 		d_pr[0] = d_pr[1] = nullptr;
 		d_path_index = d_path_trans = d_score = nullptr;
 	}
@@ -709,7 +801,6 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 				++seg_cursor;
 			}
 			d.bt_off = seg_bt;
-			m.plan.backtrace[d.res_idx].seg_bt_off = seg_bt;
 		} else {
 			const bool fused_ok = !force_keys && !d.is_last && d.f >= 6 && d.ebits <= (uint32_t)QMAX;
 			d.mode = fused_ok ? 0u : 1u;
@@ -743,7 +834,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	const int32_t* delta_src = p.delta.data();
 	size_t delta_count = (size_t)p.col_ptr[n] * p.n_ind;
 	if (p.n_ind == 0) { delta_fallback.assign(std::max<size_t>(p.col_ptr[n], 1), 0); delta_src = delta_fallback.data(); delta_count = delta_fallback.size(); }
-	void *d_delta, *d_term_ptr, *d_terms, *d_segs, *d_bt, *d_keys, *d_last_keys, *d_rcol, *d_rbt, *d_rsegs;
+	void *d_delta, *d_term_ptr, *d_terms, *d_segs, *d_bt, *d_keys, *d_last_keys, *d_rcol, *d_rbt;
 	HIP_TRY(up((void**)&m.d_cols, m.cols.data(), m.cols.size() * sizeof(DevColumn)));
 	HIP_TRY(up(&d_delta, delta_src, delta_count * sizeof(int32_t)));
 	HIP_TRY(up(&d_term_ptr, term_ptr32.data(), term_ptr32.size() * sizeof(uint32_t)));
@@ -751,7 +842,13 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	HIP_TRY(up(&d_segs, segs.data(), segs.size() * sizeof(uint32_t)));
 	HIP_TRY(up(&d_rcol, m.plan.columns.data(), m.plan.columns.size() * sizeof(ResColumn)));
 	HIP_TRY(up(&d_rbt, m.plan.backtrace.data(), m.plan.backtrace.size() * sizeof(ResBacktrace)));
-	HIP_TRY(up(&d_rsegs, m.plan.segs.data(), m.plan.segs.size() * sizeof(uint32_t)));
+	HIP_TRY(up((void**)&m.d_steps, m.plan.steps.data(), m.plan.steps.size() * sizeof(Step)));
+	HIP_TRY(up((void**)&m.d_segments, m.plan.segments.data(), m.plan.segments.size() * sizeof(ResSegment)));
+	{
+		uint32_t max_stage = 0;
+		for (const ResSegment& sgm : m.plan.segments) max_stage = std::max(max_stage, sgm.stage_words);
+		m.bt_lds = (size_t)RES_MAXCOLS * 128 + 16 + (size_t)max_stage * 8 + 16;
+	}
 	HIP_TRY(alloc(&d_bt, bt));
 	m.key_entries = (size_t)(1ull << max_keys_f) * p.T;
 	HIP_TRY(alloc(&d_keys, m.key_entries * 8));
@@ -772,7 +869,6 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	m.dp.last_keys = (unsigned long long*)d_last_keys;
 	m.dp.res_cols = (const ResColumn*)d_rcol;
 	m.dp.res_bt = (const ResBacktrace*)d_rbt;
-	m.dp.res_segs = (const uint32_t*)d_rsegs;
 	m.dp.dbg = nullptr;
 	if (getenv("WHAMD_DEBUG_TIMING")) {
 		void* d_dbg = nullptr;
@@ -787,6 +883,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	static bool lds_opt_in = false;
 	if (!lds_opt_in) {
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(backtrace_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		lds_opt_in = true;
 	}
 	return WHAMD_OK;
@@ -839,7 +936,8 @@ whamd_status_t DeviceTable::solve(const Problem& p, Solution& s, whamd_solve_sta
 	}
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(m.ev1, m.stream));
-	hipLaunchKernelGGL(backtrace_kernel, dim3(1), dim3(64), 0, m.stream, m.dp, m.d_path_index, m.d_path_trans, m.d_score);
+	hipLaunchKernelGGL(backtrace_kernel, dim3(1), dim3(1024), m.bt_lds, m.stream, m.dp, m.d_steps, (uint32_t)m.plan.steps.size(),
+	                   m.d_segments, m.d_path_index, m.d_path_trans, m.d_score);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(m.ev2, m.stream));
 	HIP_TRY(hipMemcpyAsync(s.path_index.data(), m.d_path_index, (size_t)n * 4, hipMemcpyDeviceToHost, m.stream));

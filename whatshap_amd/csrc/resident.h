@@ -62,20 +62,28 @@ struct ResSegment {
 	uint32_t max_l, pad;
 	uint32_t stage_words;  // ballot words (u64) one workgroup produces in this run
 	uint32_t bt_lo, bt_hi; // byte offset of the run's backtrace record: [workgroup][stage_words] u64
+	uint32_t n_wext;       // runs extracting the workgroup index from the logical exit index
+	uint32_t wext[RES_IOSEG];
 	uint16_t n_in_grid, n_in_local, n_out_grid, n_out_local;
 	// packed runs (compact position | mask position << 8 | length << 16): logical index = OR of deposits of w and l
 	uint32_t in_grid[RES_IOSEG], in_local[RES_IOSEG], out_grid[RES_IOSEG], out_local[RES_IOSEG];
 };
 
-// How the backtrace finds a resident column's record: extraction of (w, l) from the logical projection index.
+// Everything the backtrace needs for one resident column, self-contained (128 B) so that a run's records can be staged
+// in LDS with one coalesced copy.  Given x_{c+1}: y = x_{c+1} & ymask (logical projection index of column c),
+// l = OR_i extract(y, ext[i]) (local part), bit of plane q = word[stage_off + q * nwords + widx(l)] >> bpos(l),
+// x_c = OR_i deposit(y, fwd[i]) | OR_q bit_q << endpos[q].
+constexpr int RES_BT_EXT = 6;
 struct ResBacktrace {
-	uint32_t ext_off;      // extract segments: n_grid (-> w), then n_local (-> l)
-	uint16_t n_grid, n_local;
-	uint32_t g, nwords;
-	uint32_t layout;       // 0: bit of entry l = word l >> 6, bit l & 63;  1: word ((l >> 2) >> 6) * 4 + (l & 3), bit (l >> 2) & 63
-	uint32_t stage_off, stage_words;  // record of (workgroup w, plane q, word i): run base + (w * stage_words + stage_off + q * nwords + i) * 8
-	uint64_t seg_bt_off;
+	uint32_t ymask, ebits, nwords, stage_off;
+	uint32_t layout;       // 0: word l >> 6, bit l & 63;  1: word ((l >> 2) >> 6) * 4 + (l & 3), bit (l >> 2) & 63
+	uint32_t n_ext, n_fwd, pad0;
+	uint32_t ext[RES_BT_EXT];  // packed runs: source position | destination position << 8 | length << 16
+	uint32_t fwd[4];
+	uint32_t endpos[4];
+	uint32_t pad1[10];
 };
+static_assert(sizeof(ResBacktrace) == 128, "ResBacktrace must stay 32 words");
 
 struct Step {
 	uint32_t kind;         // 0 = one column through the column kernels, 1 = resident run
@@ -88,7 +96,6 @@ struct ResidentPlan {
 	std::vector<ResColumn> columns;      // resident columns in run order
 	std::vector<int32_t> col_to_res;     // [n_cols] index into `columns` or -1
 	std::vector<ResBacktrace> backtrace; // parallel to `columns`
-	std::vector<uint32_t> segs;          // deposit / extract segment pool
 	uint64_t n_resident_columns = 0;
 };
 

@@ -96,8 +96,8 @@ void plan_forward(const Problem& p, bool resident, int l_pref, ResidentPlan& pla
 		seg.col_off = (uint32_t)plan.columns.size();
 		seg.has_prev = c > 0;
 		uint32_t max_l = 0, stage_words = 0;
-		bool out_ok = true;
-		const size_t columns_mark = plan.columns.size(), segs_mark = plan.segs.size();
+		bool out_ok = true, bt_ok = true;
+		const size_t columns_mark = plan.columns.size();
 		auto is_grid = [&](uint32_t read) { return std::binary_search(grid_reads.begin(), grid_reads.end(), read); };
 		{   // load layout: positions in the entering index == positions in column c (shared reads are its low bits)
 			uint32_t gm = 0;
@@ -172,7 +172,7 @@ void plan_forward(const Problem& p, bool resident, int l_pref, ResidentPlan& pla
 			rc.nwords = fast ? std::max<uint32_t>(4, (1u << rc.Lf) / 64) : std::max<uint32_t>(1, (1u << rc.Lf) / 64);
 			rc.stage_off = stage_words;
 			stage_words += rc.ebits * rc.nwords;
-			// backtrace: (w, l) from the logical projection index of this column
+			// backtrace record: local part of the logical projection index of this column, logical deposit of the argmin
 			ResBacktrace rb{};
 			uint32_t gmf = 0, fi = 0;
 			for (uint32_t j = 0; j < kc; ++j) {
@@ -181,10 +181,18 @@ void plan_forward(const Problem& p, bool resident, int l_pref, ResidentPlan& pla
 				++fi;
 			}
 			const uint32_t lmf = (fi >= 32 ? 0xFFFFFFFFu : ((1u << fi) - 1u)) & ~gmf;
-			rb.ext_off = (uint32_t)plan.segs.size();
-			rb.n_grid = append_runs(gmf, true, plan.segs);
-			rb.n_local = append_runs(lmf, true, plan.segs);
-			rb.g = g;
+			{
+				std::vector<uint32_t> runs;
+				rb.n_ext = append_runs(lmf, true, runs);
+				if (runs.size() > (size_t)RES_BT_EXT) bt_ok = false; else std::copy(runs.begin(), runs.end(), rb.ext);
+				runs.clear();
+				rb.n_fwd = append_runs(p.fwd_mask[cc], false, runs);
+				if (runs.size() > 4) bt_ok = false; else std::copy(runs.begin(), runs.end(), rb.fwd);
+				uint32_t en2 = 0;
+				for (uint32_t j = 0; j < kc; ++j) if (!((p.fwd_mask[cc] >> j) & 1u) && en2 < 4) rb.endpos[en2++] = j;
+			}
+			rb.ymask = (fi >= 32 ? 0xFFFFFFFFu : ((1u << fi) - 1u));  // == 2^b_{c+1} - 1
+			rb.ebits = rc.ebits;
 			rb.nwords = rc.nwords;
 			rb.layout = fast ? 1u : 0u;
 			rb.stage_off = rc.stage_off;
@@ -196,6 +204,9 @@ void plan_forward(const Problem& p, bool resident, int l_pref, ResidentPlan& pla
 				if (out_ok) {
 					std::copy(rg.begin(), rg.end(), seg.out_grid);
 					std::copy(rl.begin(), rl.end(), seg.out_local);
+					std::vector<uint32_t> we;
+					seg.n_wext = append_runs(gmf, true, we);
+					std::copy(we.begin(), we.end(), seg.wext);
 				}
 				seg.Lf_last = rc.Lf;
 			}
@@ -203,11 +214,10 @@ void plan_forward(const Problem& p, bool resident, int l_pref, ResidentPlan& pla
 			plan.columns.push_back(rc);
 			plan.backtrace.push_back(rb);
 		}
-		if (!out_ok) {  // exotic exit layout: undo and leave the first column to the column kernels
+		if (!out_ok || !bt_ok) {  // exotic layout: undo and leave the first column to the column kernels
 			for (uint32_t cc = c; cc < c1; ++cc) plan.col_to_res[cc] = -1;
 			plan.columns.resize(columns_mark);
 			plan.backtrace.resize(columns_mark);
-			plan.segs.resize(segs_mark);
 			plan.steps.push_back(Step{0, c});
 			++c;
 			continue;
@@ -215,7 +225,7 @@ void plan_forward(const Problem& p, bool resident, int l_pref, ResidentPlan& pla
 		seg.threads = std::min<uint32_t>(1024, std::max<uint32_t>(64, (1u << max_l) / 4));
 		seg.max_l = max_l;
 		seg.stage_words = stage_words;
-		for (size_t i = columns_mark; i < plan.backtrace.size(); ++i) plan.backtrace[i].stage_words = stage_words;
+
 		plan.steps.push_back(Step{1, (uint32_t)plan.segments.size()});
 		plan.segments.push_back(seg);
 		plan.n_resident_columns += seg.ncols;
