@@ -251,44 +251,29 @@ __device__ __forceinline__ uint32_t res_cost(uint32_t Cp, uint32_t Cm, uint32_t 
 	return min(min(Cp + (uint32_t)S, Cm - (uint32_t)S), Cc);
 }
 
+// PMC finding (profiles/r01_pmc_resident_v1.txt): the per-column loop is bound by instruction ISSUE, first of all by the
+// scalar unit the 16 waves of a workgroup share -- so the loop keeps per-column constants in vector registers (LDS
+// broadcast reads), lets whole waves without work branch straight to the barrier, and records the argmin bits as one
+// byte per thread (no ballot / exec-mask sequences).
+template <bool DBG>
 __global__ __launch_bounds__(1024) void resident_segment(DevProblem P, ResSegment sg, const uint32_t* __restrict__ prev,
                                                           uint32_t* __restrict__ cur) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
 	const uint32_t w = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
-	const unsigned long long t_begin = P.dbg ? __builtin_readcyclecounter() : 0ull;
+	const unsigned long long t_begin = DBG ? __builtin_readcyclecounter() : 0ull;
 	uint32_t* ldsc = smem;                                             // ncols * 64 words: column descriptors
 	int32_t* tab = reinterpret_cast<int32_t*>(smem + sg.ncols * 64);   // ncols * 256 words: lookup tables
 	uint32_t* bufP = smem + sg.ncols * (64 + RES_TABLE);
 	uint32_t* bufQ = bufP + (1u << sg.max_l);
-	unsigned long long* stage = reinterpret_cast<unsigned long long*>(bufQ + (1u << sg.max_l));  // backtrace ballots of the run
+	uint8_t* stage = reinterpret_cast<uint8_t*>(bufQ + (1u << sg.max_l));  // backtrace record of the run (stage_words * 8 bytes)
 	// stage the descriptors (coalesced copy) and the entering slice (re-layout from the logical order in HBM)
 	const uint32_t* __restrict__ gcols = reinterpret_cast<const uint32_t*>(P.res_cols + sg.col_off);
-	// (loads are issued in batches of 8 before the first use, so one memory latency covers the whole copy)
-	{
-		const uint32_t total = sg.ncols * 64;
-		for (uint32_t i0 = 0; i0 < total; i0 += NT * 8) {
-			uint32_t v[8];
-#pragma unroll
-			for (int u = 0; u < 8; ++u) { const uint32_t i = i0 + u * NT + tid; v[u] = i < total ? gcols[i] : 0u; }
-#pragma unroll
-			for (int u = 0; u < 8; ++u) { const uint32_t i = i0 + u * NT + tid; if (i < total) ldsc[i] = v[u]; }
-		}
-	}
+	for (uint32_t i = tid; i < sg.ncols * 64; i += NT) ldsc[i] = gcols[i];
 	if (!sg.has_prev) {
 		if (tid == 0) bufP[0] = 0;
 	} else {
 		const uint32_t wpart = deposit_args(w, sg.in_grid, sg.n_in_grid);
-		const uint32_t total = 1u << sg.Lb0;
-		for (uint32_t l0 = 0; l0 < total; l0 += NT * 8) {
-			uint32_t v[8];
-#pragma unroll
-			for (int u = 0; u < 8; ++u) {
-				const uint32_t l = l0 + u * NT + tid;
-				v[u] = l < total ? prev[wpart | deposit_args(l, sg.in_local, sg.n_in_local)] : 0u;
-			}
-#pragma unroll
-			for (int u = 0; u < 8; ++u) { const uint32_t l = l0 + u * NT + tid; if (l < total) bufP[l] = v[u]; }
-		}
+		for (uint32_t l = tid; l < (1u << sg.Lb0); l += NT) bufP[l] = prev[wpart | deposit_args(l, sg.in_local, sg.n_in_local)];
 	}
 	__syncthreads();
 	// per-column scalars that depend on the workgroup index, and the lookup tables of the local part of S
@@ -310,106 +295,100 @@ __global__ __launch_bounds__(1024) void resident_segment(DevProblem P, ResSegmen
 		tab[idx] = sum;
 	}
 	__syncthreads();
-	const unsigned long long t_ready = P.dbg ? __builtin_readcyclecounter() : 0ull;
-	// hot words of the current column live in VECTOR registers (LDS broadcast reads): no per-wave scalar work
-	uint4 h0, h1, h2, h3, h4, h5;
-	{
-		const uint4* hp = reinterpret_cast<const uint4*>(ldsc);
-		h0 = hp[0]; h1 = hp[1]; h2 = hp[2]; h3 = hp[3]; h4 = hp[4]; h5 = hp[5];
-	}
-	unsigned long long acc_cmp = 0, acc_bar = 0;
+	const unsigned long long t_ready = DBG ? __builtin_readcyclecounter() : 0ull;
+	const uint32_t wave_first = tid & ~63u;  // first thread index of this wave
 	for (uint32_t ci = 0; ci < sg.ncols; ++ci) {
-		const unsigned long long tc0 = P.dbg ? __builtin_readcyclecounter() : 0ull;
-		const uint32_t Cp = h0.x, Cm = h0.y, Cc = h0.z;
-		const uint32_t mode = uni(h0.w);
-		const uint32_t lowmask = h1.x, nthr = uni(h1.y), stage_off = h1.z, nwords = h1.w;
-		const uint32_t ep0 = h2.x, mL0 = h3.x;
-		const int32_t Sg = (int32_t)h4.x;
-		const uint32_t PG = h4.y;
-		const int32_t d0 = (int32_t)h5.x, d1 = (int32_t)h5.y, d2 = (int32_t)h5.z, dE = (int32_t)h5.w;
-		const uint4* hn = reinterpret_cast<const uint4*>(ldsc + (ci + 1 < sg.ncols ? ci + 1 : ci) * 64);
-		const uint4 n0 = hn[0], n1 = hn[1], n2 = hn[2], n3 = hn[3], n4 = hn[4], n5 = hn[5];  // prefetch (static data)
+		// hot words as LDS broadcasts into VECTOR registers (resident.h); only mode / nthr become scalars
+		const uint4* hp = reinterpret_cast<const uint4*>(ldsc + ci * 64);
+		const uint4 h0 = hp[0], h1 = hp[1];
+		const uint32_t mode = uni(h0.w), nthr = uni(h1.y);
 		const int32_t* tlo = tab + ci * RES_TABLE;
 		const int32_t* thi = tlo + 128;
-		unsigned long long* planes = stage + stage_off;
 		if (mode != RES_MODE_GENERIC) {
-			// a thread owns the 4 consecutive entries 4t .. 4t+3; backtrace bit of entry 4t+u: word (t >> 6) * 4 + u, bit t & 63
-			const int32_t sc[4] = {0, d0, d1, d0 + d1};
-			for (uint32_t t0 = 0; t0 < nthr; t0 += NT) {
-				const uint32_t t = t0 + tid;
-				const bool valid = t < nthr;
-				const uint32_t l4 = valid ? (t << 2) : 0u;
-				uint32_t D[4];
-				uint32_t takes = 0;
-				if (mode == RES_MODE_E0) {
-					const int32_t Sb = Sg + tlo[l4 & 127u] + thi[(l4 >> 7) & 127u];
-					const uint4 p4 = *reinterpret_cast<const uint4*>(bufP + (l4 & lowmask));
-					const uint32_t pv[4] = {p4.x, p4.y, p4.z, p4.w};
+			if (wave_first < nthr) {  // a wave whose 64 threads all lie beyond nthr goes straight to the barrier
+				const uint4 h2 = hp[2], h3 = hp[3], h4 = hp[4], h5 = hp[5];
+				const uint32_t Cp = h0.x, Cm = h0.y, Cc = h0.z;
+				const uint32_t lowmask = h1.x;
+				const uint32_t ep0 = h2.x, mL0 = h3.x;
+				const int32_t Sg = (int32_t)h4.x;
+				const uint32_t PG = h4.y;
+				const int32_t d0 = (int32_t)h5.x, d1 = (int32_t)h5.y, d2 = (int32_t)h5.z, dE = (int32_t)h5.w;
+				uint8_t* rec = stage + h1.z * 8u;  // one byte per thread: bit u = argmin side of the ending read for entry 4t+u
+				// a thread owns the 4 consecutive entries 4t .. 4t+3
+				const int32_t sc[4] = {0, d0, d1, d0 + d1};
+				for (uint32_t t = tid; t < nthr; t += NT) {
+					const uint32_t l4 = t << 2;
+					uint32_t D[4];
+					uint32_t takes = 0;
+					if (mode == RES_MODE_E0) {
+						const int32_t Sb = Sg + tlo[l4 & 127u] + thi[(l4 >> 7) & 127u];
+						const uint4 p4 = *reinterpret_cast<const uint4*>(bufP + (l4 & lowmask));
+						const uint32_t pv[4] = {p4.x, p4.y, p4.z, p4.w};
 #pragma unroll
-					for (int u = 0; u < 4; ++u) D[u] = res_cost(Cp, Cm, Cc, Sb + sc[u]) + pv[u];
-				} else if (mode == RES_MODE_E1_HIGH) {
-					const uint32_t base0 = insert_zero(l4, ep0), base1 = base0 | (1u << ep0);
-					const int32_t Sb = Sg + tlo[base0 & 127u] + thi[(base0 >> 7) & 127u];
-					const uint4 a4 = *reinterpret_cast<const uint4*>(bufP + (base0 & lowmask));
-					const uint4 b4 = *reinterpret_cast<const uint4*>(bufP + (base1 & lowmask));
-					const uint32_t pa[4] = {a4.x, a4.y, a4.z, a4.w}, pb[4] = {b4.x, b4.y, b4.z, b4.w};
-					// tie: the smaller Gray rank has x_h == parity of the bits above the ending read
-					const uint32_t par0 = PG ^ (uint32_t)__popc(base0 & mL0);
+						for (int u = 0; u < 4; ++u) D[u] = res_cost(Cp, Cm, Cc, Sb + sc[u]) + pv[u];
+					} else if (mode == RES_MODE_E1_HIGH) {
+						const uint32_t base0 = insert_zero(l4, ep0), base1 = base0 | (1u << ep0);
+						const int32_t Sb = Sg + tlo[base0 & 127u] + thi[(base0 >> 7) & 127u];
+						const uint4 a4 = *reinterpret_cast<const uint4*>(bufP + (base0 & lowmask));
+						const uint4 b4 = *reinterpret_cast<const uint4*>(bufP + (base1 & lowmask));
+						const uint32_t pa[4] = {a4.x, a4.y, a4.z, a4.w}, pb[4] = {b4.x, b4.y, b4.z, b4.w};
+						// tie: the smaller Gray rank has x_h == parity of the bits above the ending read
+						const uint32_t par0 = PG ^ (uint32_t)__popc(base0 & mL0);
 #pragma unroll
-					for (int u = 0; u < 4; ++u) {
-						const int32_t S0 = Sb + sc[u];
-						const uint32_t D0 = res_cost(Cp, Cm, Cc, S0) + pa[u], D1 = res_cost(Cp, Cm, Cc, S0 + dE) + pb[u];
-						const uint32_t par = (par0 ^ (uint32_t)__popc((uint32_t)u & mL0)) & 1u;
-						const bool take1 = D1 < D0 || (D1 == D0 && par);
-						D[u] = take1 ? D1 : D0;
-						takes |= take1 ? (1u << u) : 0u;
-					}
-				} else {
-					// the ending read is local bit 0 or 1: the 8 cells of this thread are the 8 consecutive indices 8t .. 8t+7
-					const uint32_t base8 = l4 << 1;
-					const int32_t Sb = Sg + tlo[base8 & 127u] + thi[(base8 >> 7) & 127u];
-					const uint4 a4 = *reinterpret_cast<const uint4*>(bufP + (base8 & lowmask));
-					const uint4 b4 = *reinterpret_cast<const uint4*>(bufP + ((base8 + 4u) & lowmask));
-					const uint32_t pv[8] = {a4.x, a4.y, a4.z, a4.w, b4.x, b4.y, b4.z, b4.w};
-					const int32_t s8[8] = {0, d0, d1, d0 + d1, d2, d2 + d0, d2 + d1, d2 + d0 + d1};
-					uint32_t Dc[8];
-#pragma unroll
-					for (int c8 = 0; c8 < 8; ++c8) Dc[c8] = res_cost(Cp, Cm, Cc, Sb + s8[c8]) + pv[c8];
-					const uint32_t par0 = PG ^ (uint32_t)__popc(base8 & mL0);
-					if (mode == RES_MODE_E1_BIT0) {
-#pragma unroll
-						for (int u = 0; u < 4; ++u) {  // cells 2u (ending read on side 0) and 2u + 1
-							const uint32_t par = (par0 ^ (uint32_t)__popc((uint32_t)(2 * u) & mL0)) & 1u;
-							const bool take1 = Dc[2 * u + 1] < Dc[2 * u] || (Dc[2 * u + 1] == Dc[2 * u] && par);
-							D[u] = take1 ? Dc[2 * u + 1] : Dc[2 * u];
+						for (int u = 0; u < 4; ++u) {
+							const int32_t S0 = Sb + sc[u];
+							const uint32_t D0 = res_cost(Cp, Cm, Cc, S0) + pa[u], D1 = res_cost(Cp, Cm, Cc, S0 + dE) + pb[u];
+							const uint32_t par = (par0 ^ (uint32_t)__popc((uint32_t)u & mL0)) & 1u;
+							const bool take1 = D1 < D0 || (D1 == D0 && par);
+							D[u] = take1 ? D1 : D0;
 							takes |= take1 ? (1u << u) : 0u;
 						}
 					} else {
+						// the ending read is local bit 0 or 1: the 8 cells of this thread are the 8 consecutive indices 8t .. 8t+7
+						const uint32_t base8 = l4 << 1;
+						const int32_t Sb = Sg + tlo[base8 & 127u] + thi[(base8 >> 7) & 127u];
+						const uint4 a4 = *reinterpret_cast<const uint4*>(bufP + (base8 & lowmask));
+						const uint4 b4 = *reinterpret_cast<const uint4*>(bufP + ((base8 + 4u) & lowmask));
+						const uint32_t pv[8] = {a4.x, a4.y, a4.z, a4.w, b4.x, b4.y, b4.z, b4.w};
+						const int32_t s8[8] = {0, d0, d1, d0 + d1, d2, d2 + d0, d2 + d1, d2 + d0 + d1};
+						uint32_t Dc[8];
 #pragma unroll
-						for (int u = 0; u < 4; ++u) {  // cells (u >> 1) * 4 + (u & 1) and + 2
-							const int c0 = ((u >> 1) << 2) | (u & 1);
-							const uint32_t par = (par0 ^ (uint32_t)__popc((uint32_t)c0 & mL0)) & 1u;
-							const bool take1 = Dc[c0 + 2] < Dc[c0] || (Dc[c0 + 2] == Dc[c0] && par);
-							D[u] = take1 ? Dc[c0 + 2] : Dc[c0];
-							takes |= take1 ? (1u << u) : 0u;
+						for (int c8 = 0; c8 < 8; ++c8) Dc[c8] = res_cost(Cp, Cm, Cc, Sb + s8[c8]) + pv[c8];
+						const uint32_t par0 = PG ^ (uint32_t)__popc(base8 & mL0);
+						if (mode == RES_MODE_E1_BIT0) {
+#pragma unroll
+							for (int u = 0; u < 4; ++u) {  // cells 2u (ending read on side 0) and 2u + 1
+								const uint32_t par = (par0 ^ (uint32_t)__popc((uint32_t)(2 * u) & mL0)) & 1u;
+								const bool take1 = Dc[2 * u + 1] < Dc[2 * u] || (Dc[2 * u + 1] == Dc[2 * u] && par);
+								D[u] = take1 ? Dc[2 * u + 1] : Dc[2 * u];
+								takes |= take1 ? (1u << u) : 0u;
+							}
+						} else {
+#pragma unroll
+							for (int u = 0; u < 4; ++u) {  // cells (u >> 1) * 4 + (u & 1) and + 2
+								const int c0 = ((u >> 1) << 2) | (u & 1);
+								const uint32_t par = (par0 ^ (uint32_t)__popc((uint32_t)c0 & mL0)) & 1u;
+								const bool take1 = Dc[c0 + 2] < Dc[c0] || (Dc[c0 + 2] == Dc[c0] && par);
+								D[u] = take1 ? Dc[c0 + 2] : Dc[c0];
+								takes |= take1 ? (1u << u) : 0u;
+							}
 						}
 					}
-				}
-				if (valid) *reinterpret_cast<uint4*>(bufQ + l4) = make_uint4(D[0], D[1], D[2], D[3]);
-				if (mode != RES_MODE_E0) {
-#pragma unroll
-					for (int u = 0; u < 4; ++u) {
-						const unsigned long long word = __ballot(valid && ((takes >> u) & 1u));
-						if ((tid & 63u) == 0 && valid) planes[(t >> 6) * 4 + u] = word;
-					}
+					*reinterpret_cast<uint4*>(bufQ + l4) = make_uint4(D[0], D[1], D[2], D[3]);
+					if (mode != RES_MODE_E0) rec[t] = (uint8_t)takes;
 				}
 			}
 		} else {
+			const uint4 h2 = hp[2], h3 = hp[3], h4 = hp[4];
+			const uint32_t Cp = h0.x, Cm = h0.y, Cc = h0.z, lowmask = h1.x;
+			const int32_t Sg = (int32_t)h4.x;
+			const uint32_t PG = h4.y;
 			const uint32_t Lf = uni(h4.w), ebits = uni(ldsc[ci * 64 + offsetof(ResColumn, ebits) / 4]);
 			const uint32_t nout = 1u << Lf;
 			const uint32_t epos[RES_EMAX] = {uni(h2.x), uni(h2.y), uni(h2.z)};
 			const uint32_t mL[RES_EMAX] = {uni(h3.x), uni(h3.y), uni(h3.z)};
-			const uint32_t nw = uni(nwords);
+			const uint32_t nw = uni(h1.w);
+			unsigned long long* planes = reinterpret_cast<unsigned long long*>(stage) + uni(h1.z);
 			for (uint32_t l0 = 0; l0 < nout; l0 += NT * RES_OPT) {
 				uint32_t l_out[RES_OPT], base[RES_OPT], bestD[RES_OPT], beste[RES_OPT];
 				bool valid[RES_OPT];
@@ -464,25 +443,23 @@ __global__ __launch_bounds__(1024) void resident_segment(DevProblem P, ResSegmen
 				}
 			}
 		}
-		h0 = n0; h1 = n1; h2 = n2; h3 = n3; h4 = n4; h5 = n5;
-		const unsigned long long tc2 = P.dbg ? __builtin_readcyclecounter() : 0ull;
 		__syncthreads();
 		uint32_t* tmp = bufP; bufP = bufQ; bufQ = tmp;
-		if (P.dbg) { const unsigned long long tc3 = __builtin_readcyclecounter(); acc_cmp += tc2 - tc0; acc_bar += tc3 - tc2; }
 	}
-	const unsigned long long t_cols = P.dbg ? __builtin_readcyclecounter() : 0ull;
+	const unsigned long long t_cols = DBG ? __builtin_readcyclecounter() : 0ull;
 	// exit slice in logical order, and the run's backtrace record [workgroup][stage_words]
 	const uint32_t wout = deposit_args(w, sg.out_grid, sg.n_out_grid);
 	for (uint32_t l = tid; l < (1u << sg.Lf_last); l += NT) cur[wout | deposit_args(l, sg.out_local, sg.n_out_local)] = bufP[l];
 	unsigned long long* rec = reinterpret_cast<unsigned long long*>(P.bt + (((unsigned long long)sg.bt_hi << 32) | sg.bt_lo)) + (size_t)w * sg.stage_words;
-	for (uint32_t i = tid; i < sg.stage_words; i += NT) rec[i] = stage[i];
-	if (P.dbg && w == 0 && tid == 0) {
+	const unsigned long long* st64 = reinterpret_cast<const unsigned long long*>(stage);
+	for (uint32_t i = tid; i < sg.stage_words; i += NT) rec[i] = st64[i];
+	if (DBG && w == 0 && tid == 0) {
 		unsigned long long* d = P.dbg + (size_t)sg.pad * 8;
 		d[0] = t_ready - t_begin;
 		d[1] = t_cols - t_ready;
 		d[2] = __builtin_readcyclecounter() - t_cols;
 		d[3] = sg.ncols;
-		d[4] = 0; d[5] = acc_cmp; d[6] = acc_bar;
+		d[4] = 0; d[5] = 0; d[6] = 0;
 	}
 }
 
@@ -599,13 +576,19 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const Ste
 				const uint32_t rr = (uint32_t)i < r[1].z ? fwd[i] : 0u;
 				xp |= ((y >> (rr & 31u)) & ((1u << ((rr >> 16) & 31u)) - 1u)) << ((rr >> 8) & 31u);
 			}
-			const uint32_t widx = r[1].x ? (((l >> 2) >> 6) * 4 + (l & 3u)) : (l >> 6);
-			const uint32_t bpos = r[1].x ? ((l >> 2) & 63u) : (l & 63u);
-			unsigned long long words[3];
+			if (r[1].x) {  // layout 1: one byte per thread t = l >> 2, bit l & 3 (at most one ending read)
+				if (r[0].y) {
+				const uint8_t byte = reinterpret_cast<const uint8_t*>(stage + r[0].w)[l >> 2];
+				xp |= (uint32_t)((byte >> (l & 3u)) & 1u) << endpos[0];
+				}
+			} else {
+				const uint32_t widx = l >> 6, bpos = l & 63u;
+				unsigned long long words[3];
 #pragma unroll
-			for (int q = 0; q < 3; ++q) words[q] = (uint32_t)q < r[0].y ? stage[r[0].w + q * r[0].z + widx] : 0ull;
+				for (int q = 0; q < 3; ++q) words[q] = (uint32_t)q < r[0].y ? stage[r[0].w + q * r[0].z + widx] : 0ull;
 #pragma unroll
-			for (int q = 0; q < 3; ++q) xp |= (uint32_t)((words[q] >> bpos) & 1ull) << endpos[q];
+				for (int q = 0; q < 3; ++q) xp |= (uint32_t)((words[q] >> bpos) & 1ull) << endpos[q];
+			}
 			if (lane == 0) {
 				path_index[sg.c0 + ci] = xp;
 				path_trans[sg.c0 + ci] = 0;
@@ -756,6 +739,19 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	const bool force_keys = m.path == "column_keys";
 	const bool want_resident = m.path == "auto" || m.path == "resident";
 	plan_forward(p, want_resident, m.l_pref, m.plan);
+	if (getenv("WHAMD_DEBUG_PLAN")) {
+		for (const Step& st : m.plan.steps) {
+			if (st.kind == 0) { fprintf(stderr, "[plan] column %u k=%u b=%u f=%u\n", st.index, p.k[st.index], p.b[st.index], p.f[st.index]); continue; }
+			const ResSegment& sgm = m.plan.segments[st.index];
+			fprintf(stderr, "[plan] run c0=%u ncols=%u g=%u threads=%u max_l=%u stage_words=%u\n", sgm.c0, sgm.ncols, sgm.g, sgm.threads, sgm.max_l, sgm.stage_words);
+			for (uint32_t i = 0; i < sgm.ncols; ++i) {
+				const ResColumn& rc = m.plan.columns[sgm.col_off + i];
+				const ResBacktrace& rb = m.plan.backtrace[sgm.col_off + i];
+				fprintf(stderr, "[plan]   col %u mode=%u Lb=%u Lf=%u ebits=%u epos0=%u nthr=%u stage_off=%u nwords=%u | bt layout=%u n_ext=%u n_fwd=%u endpos0=%u ymask=%x\n",
+				        sgm.c0 + i, rc.mode, rc.Lb, rc.Lf, rc.ebits, rc.epos[0], rc.nthr, rc.stage_off, rc.nwords, rb.layout, rb.n_ext, rb.n_fwd, rb.endpos[0], rb.ymask);
+			}
+		}
+	}
 	const uint32_t tbits = 2 * p.n_triples;
 	const uint32_t ni = std::max<uint32_t>(p.n_ind, 1);
 	// ---- descriptors
@@ -882,7 +878,8 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	m.dp.n_ind = p.n_ind;
 	static bool lds_opt_in = false;
 	if (!lds_opt_in) {
-		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(backtrace_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		lds_opt_in = true;
 	}
@@ -913,7 +910,8 @@ whamd_status_t DeviceTable::solve(const Problem& p, Solution& s, whamd_solve_sta
 			const size_t lds = (size_t)sg.ncols * (64 + RES_TABLE) * 4 + 2 * ((size_t)4 << sg.max_l) + (size_t)sg.stage_words * 8;
 			ResSegment arg = sg;
 			arg.pad = step.index;
-			hipLaunchKernelGGL(resident_segment, dim3(1u << sg.g), dim3(sg.threads), lds, m.stream, m.dp, arg, prev, cur);
+			if (m.dp.dbg) hipLaunchKernelGGL(resident_segment<true>, dim3(1u << sg.g), dim3(sg.threads), lds, m.stream, m.dp, arg, prev, cur);
+			else hipLaunchKernelGGL(resident_segment<false>, dim3(1u << sg.g), dim3(sg.threads), lds, m.stream, m.dp, arg, prev, cur);
 			++launches;
 			continue;
 		}

@@ -76,7 +76,7 @@ struct ResSegment {
 constexpr int RES_BT_EXT = 6;
 struct ResBacktrace {
 	uint32_t ymask, ebits, nwords, stage_off;
-	uint32_t layout;       // 0: word l >> 6, bit l & 63;  1: word ((l >> 2) >> 6) * 4 + (l & 3), bit (l >> 2) & 63
+	uint32_t layout;       // 0: ballot planes, word l >> 6, bit l & 63;  1: one byte per thread l >> 2, bit l & 3
 	uint32_t n_ext, n_fwd, pad0;
 	uint32_t ext[RES_BT_EXT];  // packed runs: source position | destination position << 8 | length << 16
 	uint32_t fwd[4];

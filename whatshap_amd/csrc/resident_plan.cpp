@@ -78,7 +78,7 @@ void plan_forward(const Problem& p, bool resident, int l_pref, ResidentPlan& pla
 			const uint32_t Lb = p.b[c1] - g, Lf = p.f[c1] - g, Lk = kc - g;
 			if (Lb > (uint32_t)RES_LMAX || Lf > (uint32_t)RES_LMAX || Lk > 14 || kc - p.f[c1] > (uint32_t)RES_EMAX) break;
 			run_max_l = std::max(run_max_l, std::max(Lb, Lf));
-			run_stage += (uint64_t)(kc - p.f[c1]) * std::max<uint32_t>(4, (1u << Lf) / 64);
+			run_stage += (uint64_t)(kc - p.f[c1]) * std::max<uint32_t>(4, (1u << Lf) / 32);
 			const uint64_t lds_bytes = (uint64_t)(c1 - c + 1) * (64 + RES_TABLE) * 4 + 2 * (4ull << run_max_l) + run_stage * 8;
 			if (lds_bytes > 150 * 1024) break;
 			++c1;
@@ -169,7 +169,8 @@ void plan_forward(const Problem& p, bool resident, int l_pref, ResidentPlan& pla
 			if (!fast) rc.mode = RES_MODE_GENERIC;
 			else if (rc.ebits == 0) rc.mode = RES_MODE_E0;
 			else rc.mode = rc.epos[0] >= 2 ? RES_MODE_E1_HIGH : (rc.epos[0] == 0 ? RES_MODE_E1_BIT0 : RES_MODE_E1_BIT1);
-			rc.nwords = fast ? std::max<uint32_t>(4, (1u << rc.Lf) / 64) : std::max<uint32_t>(1, (1u << rc.Lf) / 64);
+			// record of a vectorised column: one byte per thread (nthr bytes); otherwise ballot words per plane
+			rc.nwords = fast ? std::max<uint32_t>(1, rc.nthr / 8) : std::max<uint32_t>(1, (1u << rc.Lf) / 64);
 			rc.stage_off = stage_words;
 			stage_words += rc.ebits * rc.nwords;
 			// backtrace record: local part of the logical projection index of this column, logical deposit of the argmin
