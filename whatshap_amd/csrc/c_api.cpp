@@ -154,6 +154,11 @@ whamd_status_t whamd_dptable_set_option(whamd_dptable* t, const char* key, const
 		t->uploaded = false;  // descriptors are rebuilt at the next solve
 		return WHAMD_OK;
 	}
+	if (k == "resident_fold") {
+		t->device.set_fold(v != "0");
+		t->uploaded = false;
+		return WHAMD_OK;
+	}
 	if (k == "resident_l") {
 		t->device.set_l_pref(std::atoi(value));
 		t->uploaded = false;

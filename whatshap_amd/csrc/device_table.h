@@ -23,6 +23,8 @@ public:
 	bool set_path(const std::string& path);
 	// Preferred log2 slice size of the resident path (tuning knob); takes effect at the next upload().
 	void set_l_pref(int l);
+	// Fold columns in which no read ends into the next resident column (default on); next upload().
+	void set_fold(bool v);
 
 private:
 	struct Impl;

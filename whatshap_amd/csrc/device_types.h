@@ -43,6 +43,8 @@ struct DevProblem {
 	const ResColumn* res_cols;
 	const ResBacktrace* res_bt;
 	unsigned long long* dbg;  // optional cycle-counter dump (WHAMD_DEBUG_TIMING)
+	uint32_t dbg_wg_off;      // word offset of the per-workgroup start/end stamps inside dbg
+	uint32_t dbg_flags;       // experiments: bit 0 skip the slice store, bit 1 skip the record store (results invalid)
 	uint32_t n_cols;
 	uint32_t T;
 	uint32_t tbits;         // 2 * triples

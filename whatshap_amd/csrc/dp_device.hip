@@ -251,6 +251,92 @@ __device__ __forceinline__ uint32_t res_cost(uint32_t Cp, uint32_t Cm, uint32_t 
 	return min(min(Cp + (uint32_t)S, Cm - (uint32_t)S), Cc);
 }
 
+// One vectorised column of a resident run for the calling thread's entries (resident.h RES_MODE_E0 .. E1_BIT1), with
+// the costs of up to RES_MAXFOLD preceding folded columns added per cell.  A thread owns the 4 consecutive entries
+// 4t .. 4t+3 (8 cells when a read ends) and moves them with 16-byte LDS accesses.
+template <uint32_t MODE>
+__device__ __forceinline__ void res_fast_column(const uint32_t* ldsc, const int32_t* tab, uint32_t ci, uint32_t nfold,
+                                                const uint32_t* bufP, uint32_t* bufQ, uint8_t* stage, uint32_t tid,
+                                                uint32_t NT, uint32_t nthr, const uint4 h0, const uint4 h1) {
+	constexpr int NC = MODE == RES_MODE_E0 ? 4 : 8;  // cells per thread
+	const uint4* hp = reinterpret_cast<const uint4*>(ldsc + ci * 64);
+	const uint4 h2 = hp[2], h3 = hp[3], h4 = hp[4];
+	const uint32_t lowmask = h1.x, ep0 = h2.x, mL0 = h3.x, PG = h4.y;
+	uint8_t* rec = stage + h1.z * 8u;  // one byte per thread: bit u = argmin side of the ending read for entry 4t+u
+	for (uint32_t t = tid; t < nthr; t += NT) {
+		const uint32_t l4 = t << 2;
+		// cell c of this thread: index and (per column) the delta pattern on top of the base index
+		uint32_t base, base1 = 0;
+		if (MODE == RES_MODE_E0) base = l4;
+		else if (MODE == RES_MODE_E1_HIGH) { base = insert_zero(l4, ep0); base1 = base | (1u << ep0); }
+		else base = l4 << 1;
+		uint32_t acc[NC];
+		// slice entries of the cells (the run's entering slice or the previous terminal column)
+		if (MODE == RES_MODE_E0) {
+			const uint4 p4 = *reinterpret_cast<const uint4*>(bufP + (base & lowmask));
+			acc[0] = p4.x; acc[1] = p4.y; acc[2] = p4.z; acc[3] = p4.w;
+		} else if (MODE == RES_MODE_E1_HIGH) {  // cells 0..3: ending read on side 0, cells 4..7: side 1
+			const uint4 a4 = *reinterpret_cast<const uint4*>(bufP + (base & lowmask));
+			const uint4 b4 = *reinterpret_cast<const uint4*>(bufP + (base1 & lowmask));
+			acc[0] = a4.x; acc[1] = a4.y; acc[2] = a4.z; acc[3] = a4.w; acc[4] = b4.x; acc[5] = b4.y; acc[6] = b4.z; acc[7] = b4.w;
+		} else {  // the 8 consecutive cells 8t .. 8t+7
+			const uint4 a4 = *reinterpret_cast<const uint4*>(bufP + (base & lowmask));
+			const uint4 b4 = *reinterpret_cast<const uint4*>(bufP + ((base + 4u) & lowmask));
+			acc[0] = a4.x; acc[1] = a4.y; acc[2] = a4.z; acc[3] = a4.w; acc[4] = b4.x; acc[5] = b4.y; acc[6] = b4.z; acc[7] = b4.w;
+		}
+		// this column (f == 0) and the folded ones before it: acc[c] += cost_column(cell c)
+		for (uint32_t f = 0; f <= nfold; ++f) {
+			const uint32_t cf = ci - f;
+			const uint4* fp = reinterpret_cast<const uint4*>(ldsc + cf * 64);
+			const uint4 f0 = fp[0], f4 = fp[4], f5 = fp[5];
+			const uint32_t Cp = f0.x, Cm = f0.y, Cc = f0.z;
+			const int32_t* tlo = tab + cf * RES_TABLE;
+			const int32_t Sb = (int32_t)f4.x + tlo[base & 127u] + tlo[128u + ((base >> 7) & 127u)];
+			const int32_t d0 = (int32_t)f5.x, d1 = (int32_t)f5.y, d2 = (int32_t)f5.z;
+			if (MODE == RES_MODE_E0) {
+				const int32_t pat[4] = {0, d0, d1, d0 + d1};
+#pragma unroll
+				for (int c = 0; c < 4; ++c) acc[c] += res_cost(Cp, Cm, Cc, Sb + pat[c]);
+			} else if (MODE == RES_MODE_E1_HIGH) {
+				// delta of the ending read in column cf (zero if that read was not active there yet)
+				const int32_t dE = reinterpret_cast<const int32_t*>(ldsc + cf * 64 + offsetof(ResColumn, dloc) / 4)[ep0];
+				const int32_t pat[4] = {0, d0, d1, d0 + d1};
+#pragma unroll
+				for (int c = 0; c < 4; ++c) {
+					acc[c] += res_cost(Cp, Cm, Cc, Sb + pat[c]);
+					acc[4 + c] += res_cost(Cp, Cm, Cc, Sb + pat[c] + dE);
+				}
+			} else {
+				const int32_t pat[8] = {0, d0, d1, d0 + d1, d2, d2 + d0, d2 + d1, d2 + d0 + d1};
+#pragma unroll
+				for (int c = 0; c < 8; ++c) acc[c] += res_cost(Cp, Cm, Cc, Sb + pat[c]);
+			}
+		}
+		uint32_t D[4];
+		uint32_t takes = 0;
+		if (MODE == RES_MODE_E0) {
+#pragma unroll
+			for (int u = 0; u < 4; ++u) D[u] = acc[u];
+		} else {
+			// tie: the smaller Gray rank has x_h == parity of the bits above the ending read
+			const uint32_t par0 = PG ^ (uint32_t)__popc(base & mL0);
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				// cell pair of entry 4t+u: E1_HIGH (u, 4+u); E1_BIT0 (2u, 2u+1); E1_BIT1 ((u>>1)*4 + (u&1), +2)
+				const int c0 = MODE == RES_MODE_E1_HIGH ? u : (MODE == RES_MODE_E1_BIT0 ? 2 * u : (((u >> 1) << 2) | (u & 1)));
+				const int c1 = MODE == RES_MODE_E1_HIGH ? 4 + u : (MODE == RES_MODE_E1_BIT0 ? 2 * u + 1 : c0 + 2);
+				const uint32_t low = MODE == RES_MODE_E1_HIGH ? (uint32_t)u : (uint32_t)c0;  // low bits of the side-0 cell index
+				const uint32_t par = (par0 ^ (uint32_t)__popc(low & mL0)) & 1u;
+				const bool take1 = acc[c1] < acc[c0] || (acc[c1] == acc[c0] && par);
+				D[u] = take1 ? acc[c1] : acc[c0];
+				takes |= take1 ? (1u << u) : 0u;
+			}
+		}
+		*reinterpret_cast<uint4*>(bufQ + l4) = make_uint4(D[0], D[1], D[2], D[3]);
+		if (MODE != RES_MODE_E0) rec[t] = (uint8_t)takes;
+	}
+}
+
 // PMC finding (profiles/r01_pmc_resident_v1.txt): the per-column loop is bound by instruction ISSUE, first of all by the
 // scalar unit the 16 waves of a workgroup share -- so the loop keeps per-column constants in vector registers (LDS
 // broadcast reads), lets whole waves without work branch straight to the barrier, and records the argmin bits as one
@@ -261,6 +347,7 @@ __global__ __launch_bounds__(1024) void resident_segment(DevProblem P, ResSegmen
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
 	const uint32_t w = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
 	const unsigned long long t_begin = DBG ? __builtin_readcyclecounter() : 0ull;
+	const unsigned long long rt_begin = DBG ? wall_clock64() : 0ull;
 	uint32_t* ldsc = smem;                                             // ncols * 64 words: column descriptors
 	int32_t* tab = reinterpret_cast<int32_t*>(smem + sg.ncols * 64);   // ncols * 256 words: lookup tables
 	uint32_t* bufP = smem + sg.ncols * (64 + RES_TABLE);
@@ -302,83 +389,18 @@ __global__ __launch_bounds__(1024) void resident_segment(DevProblem P, ResSegmen
 		const uint4* hp = reinterpret_cast<const uint4*>(ldsc + ci * 64);
 		const uint4 h0 = hp[0], h1 = hp[1];
 		const uint32_t mode = uni(h0.w), nthr = uni(h1.y);
-		const int32_t* tlo = tab + ci * RES_TABLE;
-		const int32_t* thi = tlo + 128;
+		if (mode == RES_MODE_FOLDED) continue;  // evaluated inside the next vectorised column: no slice traffic, no barrier
 		if (mode != RES_MODE_GENERIC) {
 			if (wave_first < nthr) {  // a wave whose 64 threads all lie beyond nthr goes straight to the barrier
-				const uint4 h2 = hp[2], h3 = hp[3], h4 = hp[4], h5 = hp[5];
-				const uint32_t Cp = h0.x, Cm = h0.y, Cc = h0.z;
-				const uint32_t lowmask = h1.x;
-				const uint32_t ep0 = h2.x, mL0 = h3.x;
-				const int32_t Sg = (int32_t)h4.x;
-				const uint32_t PG = h4.y;
-				const int32_t d0 = (int32_t)h5.x, d1 = (int32_t)h5.y, d2 = (int32_t)h5.z, dE = (int32_t)h5.w;
-				uint8_t* rec = stage + h1.z * 8u;  // one byte per thread: bit u = argmin side of the ending read for entry 4t+u
-				// a thread owns the 4 consecutive entries 4t .. 4t+3
-				const int32_t sc[4] = {0, d0, d1, d0 + d1};
-				for (uint32_t t = tid; t < nthr; t += NT) {
-					const uint32_t l4 = t << 2;
-					uint32_t D[4];
-					uint32_t takes = 0;
-					if (mode == RES_MODE_E0) {
-						const int32_t Sb = Sg + tlo[l4 & 127u] + thi[(l4 >> 7) & 127u];
-						const uint4 p4 = *reinterpret_cast<const uint4*>(bufP + (l4 & lowmask));
-						const uint32_t pv[4] = {p4.x, p4.y, p4.z, p4.w};
-#pragma unroll
-						for (int u = 0; u < 4; ++u) D[u] = res_cost(Cp, Cm, Cc, Sb + sc[u]) + pv[u];
-					} else if (mode == RES_MODE_E1_HIGH) {
-						const uint32_t base0 = insert_zero(l4, ep0), base1 = base0 | (1u << ep0);
-						const int32_t Sb = Sg + tlo[base0 & 127u] + thi[(base0 >> 7) & 127u];
-						const uint4 a4 = *reinterpret_cast<const uint4*>(bufP + (base0 & lowmask));
-						const uint4 b4 = *reinterpret_cast<const uint4*>(bufP + (base1 & lowmask));
-						const uint32_t pa[4] = {a4.x, a4.y, a4.z, a4.w}, pb[4] = {b4.x, b4.y, b4.z, b4.w};
-						// tie: the smaller Gray rank has x_h == parity of the bits above the ending read
-						const uint32_t par0 = PG ^ (uint32_t)__popc(base0 & mL0);
-#pragma unroll
-						for (int u = 0; u < 4; ++u) {
-							const int32_t S0 = Sb + sc[u];
-							const uint32_t D0 = res_cost(Cp, Cm, Cc, S0) + pa[u], D1 = res_cost(Cp, Cm, Cc, S0 + dE) + pb[u];
-							const uint32_t par = (par0 ^ (uint32_t)__popc((uint32_t)u & mL0)) & 1u;
-							const bool take1 = D1 < D0 || (D1 == D0 && par);
-							D[u] = take1 ? D1 : D0;
-							takes |= take1 ? (1u << u) : 0u;
-						}
-					} else {
-						// the ending read is local bit 0 or 1: the 8 cells of this thread are the 8 consecutive indices 8t .. 8t+7
-						const uint32_t base8 = l4 << 1;
-						const int32_t Sb = Sg + tlo[base8 & 127u] + thi[(base8 >> 7) & 127u];
-						const uint4 a4 = *reinterpret_cast<const uint4*>(bufP + (base8 & lowmask));
-						const uint4 b4 = *reinterpret_cast<const uint4*>(bufP + ((base8 + 4u) & lowmask));
-						const uint32_t pv[8] = {a4.x, a4.y, a4.z, a4.w, b4.x, b4.y, b4.z, b4.w};
-						const int32_t s8[8] = {0, d0, d1, d0 + d1, d2, d2 + d0, d2 + d1, d2 + d0 + d1};
-						uint32_t Dc[8];
-#pragma unroll
-						for (int c8 = 0; c8 < 8; ++c8) Dc[c8] = res_cost(Cp, Cm, Cc, Sb + s8[c8]) + pv[c8];
-						const uint32_t par0 = PG ^ (uint32_t)__popc(base8 & mL0);
-						if (mode == RES_MODE_E1_BIT0) {
-#pragma unroll
-							for (int u = 0; u < 4; ++u) {  // cells 2u (ending read on side 0) and 2u + 1
-								const uint32_t par = (par0 ^ (uint32_t)__popc((uint32_t)(2 * u) & mL0)) & 1u;
-								const bool take1 = Dc[2 * u + 1] < Dc[2 * u] || (Dc[2 * u + 1] == Dc[2 * u] && par);
-								D[u] = take1 ? Dc[2 * u + 1] : Dc[2 * u];
-								takes |= take1 ? (1u << u) : 0u;
-							}
-						} else {
-#pragma unroll
-							for (int u = 0; u < 4; ++u) {  // cells (u >> 1) * 4 + (u & 1) and + 2
-								const int c0 = ((u >> 1) << 2) | (u & 1);
-								const uint32_t par = (par0 ^ (uint32_t)__popc((uint32_t)c0 & mL0)) & 1u;
-								const bool take1 = Dc[c0 + 2] < Dc[c0] || (Dc[c0 + 2] == Dc[c0] && par);
-								D[u] = take1 ? Dc[c0 + 2] : Dc[c0];
-								takes |= take1 ? (1u << u) : 0u;
-							}
-						}
-					}
-					*reinterpret_cast<uint4*>(bufQ + l4) = make_uint4(D[0], D[1], D[2], D[3]);
-					if (mode != RES_MODE_E0) rec[t] = (uint8_t)takes;
-				}
+				const uint32_t nfold = uni(ldsc[ci * 64 + offsetof(ResColumn, nfold) / 4]);
+				if (mode == RES_MODE_E0) res_fast_column<RES_MODE_E0>(ldsc, tab, ci, nfold, bufP, bufQ, stage, tid, NT, nthr, h0, h1);
+				else if (mode == RES_MODE_E1_HIGH) res_fast_column<RES_MODE_E1_HIGH>(ldsc, tab, ci, nfold, bufP, bufQ, stage, tid, NT, nthr, h0, h1);
+				else if (mode == RES_MODE_E1_BIT0) res_fast_column<RES_MODE_E1_BIT0>(ldsc, tab, ci, nfold, bufP, bufQ, stage, tid, NT, nthr, h0, h1);
+				else res_fast_column<RES_MODE_E1_BIT1>(ldsc, tab, ci, nfold, bufP, bufQ, stage, tid, NT, nthr, h0, h1);
 			}
 		} else {
+			const int32_t* tlo = tab + ci * RES_TABLE;
+			const int32_t* thi = tlo + 128;
 			const uint4 h2 = hp[2], h3 = hp[3], h4 = hp[4];
 			const uint32_t Cp = h0.x, Cm = h0.y, Cc = h0.z, lowmask = h1.x;
 			const int32_t Sg = (int32_t)h4.x;
@@ -449,10 +471,17 @@ __global__ __launch_bounds__(1024) void resident_segment(DevProblem P, ResSegmen
 	const unsigned long long t_cols = DBG ? __builtin_readcyclecounter() : 0ull;
 	// exit slice in logical order, and the run's backtrace record [workgroup][stage_words]
 	const uint32_t wout = deposit_args(w, sg.out_grid, sg.n_out_grid);
+	if (!(DBG && (P.dbg_flags & 1u)))
 	for (uint32_t l = tid; l < (1u << sg.Lf_last); l += NT) cur[wout | deposit_args(l, sg.out_local, sg.n_out_local)] = bufP[l];
 	unsigned long long* rec = reinterpret_cast<unsigned long long*>(P.bt + (((unsigned long long)sg.bt_hi << 32) | sg.bt_lo)) + (size_t)w * sg.stage_words;
 	const unsigned long long* st64 = reinterpret_cast<const unsigned long long*>(stage);
+	if (!(DBG && (P.dbg_flags & 2u)))
 	for (uint32_t i = tid; i < sg.stage_words; i += NT) rec[i] = st64[i];
+	if (DBG && tid == 0 && sg.pad >= 100 && sg.pad < 104) {
+		unsigned long long* dw = P.dbg + (size_t)P.dbg_wg_off + ((size_t)(sg.pad - 100) * 512 + w) * 2;
+		dw[0] = rt_begin;
+		dw[1] = wall_clock64();
+	}
 	if (DBG && w == 0 && tid == 0) {
 		unsigned long long* d = P.dbg + (size_t)sg.pad * 8;
 		d[0] = t_ready - t_begin;
@@ -652,6 +681,7 @@ struct DeviceTable::Impl {
 	size_t key_entries = 0;
 	std::string path = "auto";
 	int l_pref = 11;
+	bool fold = true;
 	uint64_t bt_bytes = 0;
 
 	void release() {
@@ -708,6 +738,7 @@ bool DeviceTable::set_path(const std::string& path) {
 }
 
 void DeviceTable::set_l_pref(int l) { impl_->l_pref = std::max(4, std::min(l, RES_LMAX)); }
+void DeviceTable::set_fold(bool v) { impl_->fold = v; }
 
 whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& msg) {
 	Impl& m = *impl_;
@@ -738,7 +769,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	}
 	const bool force_keys = m.path == "column_keys";
 	const bool want_resident = m.path == "auto" || m.path == "resident";
-	plan_forward(p, want_resident, m.l_pref, m.plan);
+	plan_forward(p, want_resident, m.l_pref, m.fold, m.plan);
 	if (getenv("WHAMD_DEBUG_PLAN")) {
 		for (const Step& st : m.plan.steps) {
 			if (st.kind == 0) { fprintf(stderr, "[plan] column %u k=%u b=%u f=%u\n", st.index, p.k[st.index], p.b[st.index], p.f[st.index]); continue; }
@@ -868,9 +899,12 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	m.dp.dbg = nullptr;
 	if (getenv("WHAMD_DEBUG_TIMING")) {
 		void* d_dbg = nullptr;
-		HIP_TRY(alloc(&d_dbg, (m.plan.segments.size() + 1) * 64));
-		HIP_TRY(hipMemset(d_dbg, 0, (m.plan.segments.size() + 1) * 64));
+		const size_t dbg_bytes = (m.plan.segments.size() + 1) * 64 + 4 * 512 * 16;
+		HIP_TRY(alloc(&d_dbg, dbg_bytes));
+		HIP_TRY(hipMemset(d_dbg, 0, dbg_bytes));
 		m.dp.dbg = (unsigned long long*)d_dbg;
+		m.dp.dbg_wg_off = (uint32_t)((m.plan.segments.size() + 1) * 8);
+		m.dp.dbg_flags = (uint32_t)atoi(getenv("WHAMD_DEBUG_TIMING"));
 	}
 	m.dp.n_cols = n;
 	m.dp.T = p.T;
@@ -961,6 +995,22 @@ whamd_status_t DeviceTable::solve(const Problem& p, Solution& s, whamd_solve_sta
 		fprintf(stderr, "[whamd timing] per column (wave 0 of workgroup 0): compute %.0f barrier %.0f cycles\n",
 		        (double)p2 / std::max<unsigned long long>(cols, 1), (double)p3 / std::max<unsigned long long>(cols, 1));
 		(void)p1;
+		if (m.plan.segments.size() > 104) {
+			std::vector<unsigned long long> wg(4 * 512 * 2);
+			HIP_TRY(hipMemcpy(wg.data(), m.dp.dbg + m.dp.dbg_wg_off, wg.size() * 8, hipMemcpyDeviceToHost));
+			unsigned long long prev_end = 0;
+			for (int sgi = 0; sgi < 4; ++sgi) {
+				const uint32_t G = 1u << m.plan.segments[100 + sgi].g;
+				unsigned long long s0 = ~0ull, s1 = 0, e0 = ~0ull, e1 = 0;
+				for (uint32_t ww = 0; ww < G; ++ww) {
+					const unsigned long long a2 = wg[((size_t)sgi * 512 + ww) * 2], b2 = wg[((size_t)sgi * 512 + ww) * 2 + 1];
+					s0 = std::min(s0, a2); s1 = std::max(s1, a2); e0 = std::min(e0, b2); e1 = std::max(e1, b2);
+				}
+				fprintf(stderr, "[whamd timing] run %d (%u workgroups): first start +%.2f us after previous run's last end; starts spread %.2f us; first end %.2f us, last end %.2f us after first start\n",
+				        100 + sgi, G, prev_end ? (double)(s0 - prev_end) / 100.0 : 0.0, (double)(s1 - s0) / 100.0, (double)(e0 - s0) / 100.0, (double)(e1 - s0) / 100.0);
+				prev_end = e1;
+			}
+		}
 		fprintf(stderr, "[whamd timing] segments %zu cols %llu | cycles/segment: prologue %.0f columns %.0f (%.0f per column) store %.0f | fwd %.3f ms, %.2f us per segment\n",
 		        m.plan.segments.size(), cols, (double)a / m.plan.segments.size(), (double)b / m.plan.segments.size(),
 		        (double)b / std::max<unsigned long long>(cols, 1), (double)c2 / m.plan.segments.size(), f01, f01 * 1e3 / m.plan.segments.size());

@@ -39,7 +39,7 @@ struct ResColumn {
 	uint32_t Lb, Lf;
 	int32_t d0, d1, d2, dE;           // deltas of local cell bits 0, 1, 2 and of ending read 0
 	// ---- cold part
-	uint32_t ebits, pad0;
+	uint32_t ebits, nfold;            // nfold: preceding columns folded into this one (they have mode RES_MODE_FOLDED)
 	uint32_t mG[4];                   // per ending read: grid bits logically above it
 	int32_t dgrid[RES_GMAX];          // signed deltas of the grid reads at this column
 	int32_t dloc[14];                 // signed deltas of the local bits
@@ -53,6 +53,9 @@ constexpr uint32_t RES_MODE_E1_HIGH = 1;  // one read ends, local bit >= 2
 constexpr uint32_t RES_MODE_E1_BIT0 = 2;  // one read ends, local bit 0
 constexpr uint32_t RES_MODE_E1_BIT1 = 3;  // one read ends, local bit 1
 constexpr uint32_t RES_MODE_GENERIC = 4;  // anything else (<= 3 reads ending, tiny slices)
+constexpr uint32_t RES_MODE_FOLDED = 5;   // no read ends here and the next column is vectorised: this column's cost is added
+                                          // inside the next column's evaluation (no slice traffic, no barrier of its own)
+constexpr uint32_t RES_MAXFOLD = 3;
 
 // Passed to the kernel by value (kernel arguments live in SGPRs: no memory round trip before the first column).
 constexpr int RES_IOSEG = 6;       // runs per mask of the load / store layouts held in the kernel arguments
@@ -100,6 +103,6 @@ struct ResidentPlan {
 };
 
 // Plans the whole forward pass.  `resident` false -> every step is a per-column step.
-void plan_forward(const Problem& p, bool resident, int l_pref, ResidentPlan& plan);
+void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, ResidentPlan& plan);
 
 }  // namespace whamd

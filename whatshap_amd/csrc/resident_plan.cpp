@@ -27,9 +27,22 @@ uint16_t append_runs(uint32_t mask, bool extract, std::vector<uint32_t>& out) {
 	return count;
 }
 
+// Packed runs (source position | destination position << 8 | length << 16) for an arbitrary bit move given as
+// (source, destination) pairs sorted by source.
+std::vector<uint32_t> runs_from_pairs(const std::vector<std::pair<uint32_t, uint32_t>>& pairs) {
+	std::vector<uint32_t> out;
+	for (size_t i = 0; i < pairs.size();) {
+		size_t j = i + 1;
+		while (j < pairs.size() && pairs[j].first == pairs[j - 1].first + 1 && pairs[j].second == pairs[j - 1].second + 1) ++j;
+		out.push_back(pairs[i].first | (pairs[i].second << 8) | ((uint32_t)(j - i) << 16));
+		i = j;
+	}
+	return out;
+}
+
 }  // namespace
 
-void plan_forward(const Problem& p, bool resident, int l_pref, ResidentPlan& plan) {
+void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, ResidentPlan& plan) {
 	const uint32_t n = p.n_cols;
 	plan = ResidentPlan();
 	plan.col_to_res.assign(n, -1);
@@ -42,6 +55,8 @@ void plan_forward(const Problem& p, bool resident, int l_pref, ResidentPlan& pla
 			for (uint32_t j = 0; j < p.k[c]; ++j) last_col[col[j].read_id] = c;
 		}
 	}
+	// per run: which bits of the entering / exit logical index are grid reads (for the exchange layouts below)
+	std::vector<std::vector<uint8_t>> entry_grid, exit_grid;
 	uint32_t c = 0;
 	while (c < n) {
 		if (!eligible) {
@@ -96,6 +111,7 @@ void plan_forward(const Problem& p, bool resident, int l_pref, ResidentPlan& pla
 		seg.col_off = (uint32_t)plan.columns.size();
 		seg.has_prev = c > 0;
 		uint32_t max_l = 0, stage_words = 0;
+		std::vector<uint8_t> run_entry_grid, run_exit_grid;
 		bool out_ok = true, bt_ok = true;
 		const size_t columns_mark = plan.columns.size();
 		auto is_grid = [&](uint32_t read) { return std::binary_search(grid_reads.begin(), grid_reads.end(), read); };
@@ -103,6 +119,8 @@ void plan_forward(const Problem& p, bool resident, int l_pref, ResidentPlan& pla
 			uint32_t gm = 0;
 			for (uint32_t j = 0; j < b0; ++j) if (is_grid(first[j].read_id)) gm |= 1u << j;
 			const uint32_t lm = (b0 >= 32 ? 0xFFFFFFFFu : ((1u << b0) - 1u)) & ~gm;
+			run_entry_grid.assign(b0, 0);
+			for (uint32_t j = 0; j < b0; ++j) run_entry_grid[j] = (gm >> j) & 1u;
 			std::vector<uint32_t> rg, rl;
 			seg.n_in_grid = append_runs(gm, false, rg);
 			seg.n_in_local = append_runs(lm, false, rl);
@@ -198,6 +216,8 @@ void plan_forward(const Problem& p, bool resident, int l_pref, ResidentPlan& pla
 			rb.layout = fast ? 1u : 0u;
 			rb.stage_off = rc.stage_off;
 			if (cc + 1 == c1) {  // store layout of the exit state
+				run_exit_grid.assign(fi, 0);
+				for (uint32_t j = 0; j < fi; ++j) run_exit_grid[j] = (gmf >> j) & 1u;
 				std::vector<uint32_t> rg, rl;
 				seg.n_out_grid = append_runs(gmf, false, rg);
 				seg.n_out_local = append_runs(lmf, false, rl);
@@ -215,6 +235,24 @@ void plan_forward(const Problem& p, bool resident, int l_pref, ResidentPlan& pla
 			plan.columns.push_back(rc);
 			plan.backtrace.push_back(rb);
 		}
+		// fold columns in which no read ends into the next vectorised column (resident.h RES_MODE_FOLDED)
+		if (fold) {
+			uint32_t run = 0;
+			for (size_t i = columns_mark; i < plan.columns.size(); ++i) {
+				ResColumn& rc = plan.columns[i];
+				const bool has_next = i + 1 < plan.columns.size();
+				if (rc.mode == RES_MODE_E0 && has_next && plan.columns[i + 1].mode != RES_MODE_GENERIC && run < RES_MAXFOLD) {
+					rc.mode = RES_MODE_FOLDED;
+					++run;
+				} else {
+					if (run) {
+						rc.nfold = run;
+						rc.lowmask = plan.columns[i - run].lowmask;  // the slice read is the one the first folded column would have read
+					}
+					run = 0;
+				}
+			}
+		}
 		if (!out_ok || !bt_ok) {  // exotic layout: undo and leave the first column to the column kernels
 			for (uint32_t cc = c; cc < c1; ++cc) plan.col_to_res[cc] = -1;
 			plan.columns.resize(columns_mark);
@@ -229,8 +267,44 @@ void plan_forward(const Problem& p, bool resident, int l_pref, ResidentPlan& pla
 
 		plan.steps.push_back(Step{1, (uint32_t)plan.segments.size()});
 		plan.segments.push_back(seg);
+		entry_grid.push_back(run_entry_grid);
+		exit_grid.push_back(run_exit_grid);
 		plan.n_resident_columns += seg.ncols;
 		c = c1;
+	}
+	// ---- exchange layouts between consecutive runs.  A re-layout is an all-to-all between workgroups; in logical
+	// order the writer of run A scatters 4..16-byte pieces (its grid reads sit in the middle of the index), which costs
+	// ~9 us per boundary on MI355X.  Instead the slice is stored as [grid reads of B | grid reads of A | bits local in
+	// both], so A writes 2^(shared bits) contiguous entries per destination block and B reads one contiguous block.
+	for (size_t si = 0; si + 1 < plan.steps.size(); ++si) {
+		if (plan.steps[si].kind != 1 || plan.steps[si + 1].kind != 1) continue;
+		ResSegment& A = plan.segments[plan.steps[si].index];
+		ResSegment& B = plan.segments[plan.steps[si + 1].index];
+		const std::vector<uint8_t>& ga = exit_grid[plan.steps[si].index];
+		const std::vector<uint8_t>& gb = entry_grid[plan.steps[si + 1].index];
+		if (ga.size() != gb.size()) continue;
+		const uint32_t f = (uint32_t)ga.size();
+		std::vector<uint32_t> pi(f);
+		uint32_t next = 0;
+		for (uint32_t j = 0; j < f; ++j) if (!ga[j] && !gb[j]) pi[j] = next++;
+		for (uint32_t j = 0; j < f; ++j) if (ga[j] && !gb[j]) pi[j] = next++;
+		for (uint32_t j = 0; j < f; ++j) if (gb[j]) pi[j] = next++;
+		std::vector<std::pair<uint32_t, uint32_t>> aw, al, bw, bl;
+		uint32_t sa = 0, la = 0, sb = 0, lb = 0;
+		for (uint32_t j = 0; j < f; ++j) {
+			if (ga[j]) aw.push_back({sa++, pi[j]}); else al.push_back({la++, pi[j]});
+			if (gb[j]) bw.push_back({sb++, pi[j]}); else bl.push_back({lb++, pi[j]});
+		}
+		const std::vector<uint32_t> raw = runs_from_pairs(aw), ral = runs_from_pairs(al), rbw = runs_from_pairs(bw), rbl = runs_from_pairs(bl);
+		if (raw.size() > (size_t)RES_IOSEG || ral.size() > (size_t)RES_IOSEG || rbw.size() > (size_t)RES_IOSEG || rbl.size() > (size_t)RES_IOSEG) continue;
+		A.n_out_grid = (uint16_t)raw.size();
+		A.n_out_local = (uint16_t)ral.size();
+		std::copy(raw.begin(), raw.end(), A.out_grid);
+		std::copy(ral.begin(), ral.end(), A.out_local);
+		B.n_in_grid = (uint16_t)rbw.size();
+		B.n_in_local = (uint16_t)rbl.size();
+		std::copy(rbw.begin(), rbw.end(), B.in_grid);
+		std::copy(rbl.begin(), rbl.end(), B.in_local);
 	}
 }
 
