@@ -251,6 +251,19 @@ __device__ __forceinline__ uint32_t res_cost(uint32_t Cp, uint32_t Cm, uint32_t 
 	return min(min(Cp + (uint32_t)S, Cm - (uint32_t)S), Cc);
 }
 
+// Lookup tables of the local part of S for every resident column (two 128-entry tables: low / high 7 local bits),
+// computed once per solve at full-chip width; a run copies its columns' tables into LDS.
+__global__ __launch_bounds__(256) void resident_tables(const ResColumn* __restrict__ cols, uint32_t n_cols, int32_t* __restrict__ tables) {
+	const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= n_cols * RES_TABLE) return;
+	const uint32_t ci = idx >> 8, half = (idx >> 7) & 1u, v = idx & 127u;
+	const int32_t* __restrict__ d = cols[ci].dloc + half * 7;
+	int32_t sum = 0;
+#pragma unroll
+	for (int j = 0; j < 7; ++j) sum += ((v >> j) & 1u) ? d[j] : 0;
+	tables[idx] = sum;
+}
+
 // One vectorised column of a resident run for the calling thread's entries (resident.h RES_MODE_E0 .. E1_BIT1), with
 // the costs of up to RES_MAXFOLD preceding folded columns added per cell.  A thread owns the 4 consecutive entries
 // 4t .. 4t+3 (8 cells when a read ends) and moves them with 16-byte LDS accesses.
@@ -353,33 +366,56 @@ __global__ __launch_bounds__(1024) void resident_segment(DevProblem P, ResSegmen
 	uint32_t* bufP = smem + sg.ncols * (64 + RES_TABLE);
 	uint32_t* bufQ = bufP + (1u << sg.max_l);
 	uint8_t* stage = reinterpret_cast<uint8_t*>(bufQ + (1u << sg.max_l));  // backtrace record of the run (stage_words * 8 bytes)
-	// stage the descriptors (coalesced copy) and the entering slice (re-layout from the logical order in HBM)
-	const uint32_t* __restrict__ gcols = reinterpret_cast<const uint32_t*>(P.res_cols + sg.col_off);
-	for (uint32_t i = tid; i < sg.ncols * 64; i += NT) ldsc[i] = gcols[i];
-	if (!sg.has_prev) {
-		if (tid == 0) bufP[0] = 0;
-	} else {
+	// stage descriptors + lookup tables (coalesced 16-byte copies) and the entering slice (from the exchange layout).
+	// All global loads of a batch are issued before the first LDS store, so one memory latency covers the batch.
+	{
+		const uint4* __restrict__ gc = reinterpret_cast<const uint4*>(P.res_cols + sg.col_off);
+		const uint4* __restrict__ gt = reinterpret_cast<const uint4*>(P.res_tables + (size_t)sg.col_off * RES_TABLE);
+		uint4* lc = reinterpret_cast<uint4*>(ldsc);
+		uint4* lt = reinterpret_cast<uint4*>(tab);
+		const uint32_t ndesc = sg.ncols * 16, ntab = sg.ncols * (RES_TABLE / 4), nslice = sg.has_prev ? (1u << sg.Lb0) : 0u;
 		const uint32_t wpart = deposit_args(w, sg.in_grid, sg.n_in_grid);
-		for (uint32_t l = tid; l < (1u << sg.Lb0); l += NT) bufP[l] = prev[wpart | deposit_args(l, sg.in_local, sg.n_in_local)];
+		uint4 vd[2], vt[4];
+		uint32_t vs[4];
+#pragma unroll
+		for (int u = 0; u < 2; ++u) { const uint32_t i = u * NT + tid; vd[u] = i < ndesc ? gc[i] : make_uint4(0, 0, 0, 0); }
+#pragma unroll
+		for (int u = 0; u < 4; ++u) { const uint32_t i = u * NT + tid; vt[u] = i < ntab ? gt[i] : make_uint4(0, 0, 0, 0); }
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const uint32_t l = u * NT + tid;
+			vs[u] = l < nslice ? prev[wpart | deposit_args(l, sg.in_local, sg.n_in_local)] : 0u;
+		}
+#pragma unroll
+		for (int u = 0; u < 2; ++u) { const uint32_t i = u * NT + tid; if (i < ndesc) lc[i] = vd[u]; }
+#pragma unroll
+		for (int u = 0; u < 4; ++u) { const uint32_t i = u * NT + tid; if (i < ntab) lt[i] = vt[u]; }
+#pragma unroll
+		for (int u = 0; u < 4; ++u) { const uint32_t l = u * NT + tid; if (l < nslice) bufP[l] = vs[u]; }
+		// remainders (long runs with few threads)
+		for (uint32_t i = 2 * NT + tid; i < ndesc; i += NT) lc[i] = gc[i];
+		for (uint32_t i = 4 * NT + tid; i < ntab; i += NT) lt[i] = gt[i];
+		for (uint32_t l = 4 * NT + tid; l < nslice; l += NT) bufP[l] = prev[wpart | deposit_args(l, sg.in_local, sg.n_in_local)];
+		if (!sg.has_prev && tid == 0) bufP[0] = 0;
 	}
 	__syncthreads();
-	// per-column scalars that depend on the workgroup index, and the lookup tables of the local part of S
-	if (tid < sg.ncols) {
-		ResColumn* rc = reinterpret_cast<ResColumn*>(ldsc + tid * 64);
-		int32_t Sg = 0;
-		for (uint32_t i = 0; i < sg.g; ++i) Sg += ((w >> i) & 1u) ? rc->dgrid[i] : 0;
-		uint32_t PG = 0;
-		for (uint32_t q = 0; q < RES_EMAX; ++q) PG |= ((uint32_t)__popc(w & rc->mG[q]) & 1u) << q;
-		rc->Sg = Sg;
-		rc->PG = PG;
-	}
-	for (uint32_t idx = tid; idx < sg.ncols * RES_TABLE; idx += NT) {
-		const uint32_t ci = idx >> 8, half = (idx >> 7) & 1u, v = idx & 127u;
-		const int32_t* d = reinterpret_cast<const int32_t*>(ldsc + ci * 64 + offsetof(ResColumn, dloc) / 4 + half * 7);
-		int32_t sum = 0;
-#pragma unroll
-		for (int j = 0; j < 7; ++j) sum += ((v >> j) & 1u) ? d[j] : 0;
-		tab[idx] = sum;
+	// per-column scalars that depend on the workgroup index: 8 lanes per column (one per grid read), xor-shuffle reduce
+	for (uint32_t ci0 = 0; ci0 < sg.ncols; ci0 += NT / 8) {
+		const uint32_t ci = ci0 + (tid >> 3), i = tid & 7u;
+		int32_t part = 0;
+		uint32_t pg = 0;
+		if (ci < sg.ncols) {
+			const ResColumn* rc = reinterpret_cast<const ResColumn*>(ldsc + ci * 64);
+			if (i < sg.g && ((w >> i) & 1u)) part = rc->dgrid[i];
+			if (i < RES_EMAX) pg = ((uint32_t)__popc(w & rc->mG[i]) & 1u) << i;
+		}
+		part += __shfl_xor(part, 1); part += __shfl_xor(part, 2); part += __shfl_xor(part, 4);
+		pg |= __shfl_xor(pg, 1); pg |= __shfl_xor(pg, 2); pg |= __shfl_xor(pg, 4);
+		if (ci < sg.ncols && i == 0) {
+			ResColumn* rc = reinterpret_cast<ResColumn*>(ldsc + ci * 64);
+			rc->Sg = part;
+			rc->PG = pg;
+		}
 	}
 	__syncthreads();
 	const unsigned long long t_ready = DBG ? __builtin_readcyclecounter() : 0ull;
@@ -492,20 +528,21 @@ __global__ __launch_bounds__(1024) void resident_segment(DevProblem P, ResSegmen
 	}
 }
 
-// Backtrace (src/pedigreedptable.cpp:137-173) by one wave; out: index / transmission per column, out_score[0] = optimum.
-// The steps of the forward plan are walked in reverse.  For a resident run the argmin bits the path can touch all
-// belong to ONE workgroup's record (the grid-read bits of the path do not change inside a run), so the wave copies
-// that record (a few KiB) and the run's column records into LDS with one coalesced load and then follows the path
-// with LDS latency instead of one dependent HBM access per column.
-__global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const Step* __restrict__ steps, uint32_t n_steps,
-                                                       const ResSegment* __restrict__ segments,
-                                                       uint32_t* __restrict__ path_index, uint32_t* __restrict__ path_trans,
-                                                       uint32_t* __restrict__ out_score) {
+// Backtrace (src/pedigreedptable.cpp:137-173); out: index / transmission per column, out_score[0] = optimum.
+// The steps of the forward plan are walked in reverse (`units`, newest first).  For a resident run the argmin bits the
+// path can touch all belong to ONE workgroup's record (the grid-read bits of the path do not change inside a run), so
+// the workgroup copies that record (a few KiB) into LDS with one coalesced load while it prefetches the NEXT run's
+// column records and the header of the run after that; one wave then follows the path with LDS latency instead of one
+// dependent HBM access per column.
+__global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtUnit* __restrict__ units, uint32_t n_units,
+                                                         uint32_t* __restrict__ path_index, uint32_t* __restrict__ path_trans,
+                                                         uint32_t* __restrict__ out_score) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-	uint32_t* recs = smem;                                                              // RES_MAXCOLS * 32 words
-	uint32_t* xshare = smem + RES_MAXCOLS * 32;                                         // 4 words
-	unsigned long long* stage = reinterpret_cast<unsigned long long*>(smem + RES_MAXCOLS * 32 + 4);
-	const uint32_t lane = threadIdx.x;
+	uint32_t* recs0 = smem;                                   // 2 x RES_MAXCOLS * 32 words: column records (double buffer)
+	uint32_t* hdr = smem + 2 * RES_MAXCOLS * 32;              // 4 x 16 words: unit headers (ring)
+	uint32_t* xshare = hdr + 64;                              // 4 words
+	unsigned long long* stage = reinterpret_cast<unsigned long long*>(xshare + 4);
+	const uint32_t lane = threadIdx.x, NT = blockDim.x;
 	const uint32_t n = P.n_cols, T = P.T;
 	// optimum of the last column: first (rank(x), i) attaining the minimum (strict '<' scan, :306-315)
 	unsigned long long bestk = ~0ull;
@@ -527,11 +564,36 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const Ste
 		path_index[n - 1] = x;
 		path_trans[n - 1] = t;
 	}
-	// steps[n_steps - 1] is the last column itself; every earlier step yields x_c from x_{c+1}
-	for (uint32_t si = n_steps - 1; si-- > 0;) {
-		const Step st = steps[si];
-		if (st.kind == 0) {
-			const uint32_t c = st.index;
+	// units[0] is the last column itself; every later unit yields x_c from x_{c+1}.
+	// prime the pipeline: headers of units 1 and 2, records of unit 1
+	if (lane < 32) {
+		const uint32_t u = 1 + (lane >> 4);
+		if (u < n_units) hdr[(u & 3u) * 16 + (lane & 15u)] = reinterpret_cast<const uint32_t*>(units + u)[lane & 15u];
+	}
+	__syncthreads();
+	if (n_units > 1 && hdr[16] == 1u) {
+		const uint32_t* __restrict__ g1 = reinterpret_cast<const uint32_t*>(P.res_bt + hdr[16 + 3]);
+		for (uint32_t i = lane; i < hdr[16 + 2] * 32; i += NT) recs0[RES_MAXCOLS * 32 + i] = g1[i];
+	}
+	__syncthreads();
+	for (uint32_t ui = 1; ui < n_units; ++ui) {
+		const uint32_t* h = hdr + (ui & 3u) * 16;
+		const uint32_t kind = h[0], c0 = h[1], ncols = h[2];
+		uint32_t* recs = recs0 + (ui & 1u) * RES_MAXCOLS * 32;
+		// prefetch: header of unit ui + 2, records of unit ui + 1 (its header arrived one iteration ago)
+		uint32_t hv = 0;
+		const bool hload = lane < 16 && ui + 2 < n_units;
+		if (hload) hv = reinterpret_cast<const uint32_t*>(units + ui + 2)[lane];
+		const uint32_t* hn = hdr + ((ui + 1) & 3u) * 16;
+		const bool next_run = ui + 1 < n_units && hn[0] == 1u;
+		const uint32_t nrec = next_run ? hn[2] * 32 : 0u;
+		const uint32_t* __restrict__ gnext = reinterpret_cast<const uint32_t*>(P.res_bt + (next_run ? hn[3] : 0u));
+		uint32_t rv[2];
+#pragma unroll
+		for (int u = 0; u < 2; ++u) { const uint32_t i = u * NT + lane; rv[u] = i < nrec ? gnext[i] : 0u; }
+		if (kind == 0) {
+			// ---- one column through the column kernels' records (global loads; rare in steady state)
+			const uint32_t c = c0;
 			const DevColumn pc = P.cols[c];
 			const uint32_t y = x & ((1u << pc.f) - 1u);
 			uint32_t xp, aj;
@@ -559,78 +621,88 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const Ste
 			}
 			tprev = aj;
 			x = xp;
-			continue;
+		} else {
+			// ---- resident run [c0, c0 + ncols): this workgroup's record -> LDS
+			const uint32_t g = h[4], Lf_last = h[5], stage_words = h[6], n_wext = h[7];
+			const uint32_t yexit = x & ((1u << (Lf_last + g)) - 1u);
+			uint32_t w = 0;
+			for (uint32_t i = 0; i < n_wext; ++i) {
+				const uint32_t r = h[10 + i];
+				w |= ((yexit >> (r & 31u)) & ((1u << ((r >> 16) & 31u)) - 1u)) << ((r >> 8) & 31u);
+			}
+			const unsigned long long* __restrict__ gst = reinterpret_cast<const unsigned long long*>(
+				P.bt + (((unsigned long long)h[9] << 32) | h[8])) + (size_t)w * stage_words;
+			unsigned long long sv[2];
+#pragma unroll
+			for (int u = 0; u < 2; ++u) { const uint32_t i = u * NT + lane; sv[u] = i < stage_words ? gst[i] : 0ull; }
+#pragma unroll
+			for (int u = 0; u < 2; ++u) { const uint32_t i = u * NT + lane; if (i < stage_words) stage[i] = sv[u]; }
+			for (uint32_t i = 2 * NT + lane; i < stage_words; i += NT) stage[i] = gst[i];
 		}
-		// ---- resident run [c0, c0 + ncols)
-		const ResSegment sg = segments[st.index];
-		const uint32_t yexit = x & ((1u << (sg.Lf_last + sg.g)) - 1u);
-		uint32_t w = 0;
-		for (uint32_t i = 0; i < sg.n_wext; ++i) {
-			const uint32_t r = sg.wext[i];
-			w |= ((yexit >> (r & 31u)) & ((1u << ((r >> 16) & 31u)) - 1u)) << ((r >> 8) & 31u);
+		// land the prefetches
+		if (hload) hdr[((ui + 2) & 3u) * 16 + lane] = hv;
+		{
+			uint32_t* rnext = recs0 + ((ui + 1) & 1u) * RES_MAXCOLS * 32;
+#pragma unroll
+			for (int u = 0; u < 2; ++u) { const uint32_t i = u * NT + lane; if (i < nrec) rnext[i] = rv[u]; }
+			for (uint32_t i = 2 * NT + lane; i < nrec; i += NT) rnext[i] = gnext[i];
 		}
-		const uint32_t* __restrict__ grec = reinterpret_cast<const uint32_t*>(P.res_bt + sg.col_off);
-		for (uint32_t i = lane; i < sg.ncols * 32; i += blockDim.x) recs[i] = grec[i];
-		const unsigned long long* __restrict__ gst = reinterpret_cast<const unsigned long long*>(
-			P.bt + (((unsigned long long)sg.bt_hi << 32) | sg.bt_lo)) + (size_t)w * sg.stage_words;
-		for (uint32_t i = lane; i < sg.stage_words; i += blockDim.x) stage[i] = gst[i];
 		__syncthreads();
-		if (lane < 64) {  // one wave follows the path; the others only helped with the copy
-		// walk the run backwards; a column's record (22 words) is fetched with six 16-byte LDS reads, one column ahead
-		auto load_rec = [&](uint32_t ci, uint4 (&r)[6]) {
-			const uint4* q = reinterpret_cast<const uint4*>(recs + ci * 32);
+		if (kind == 1) {
+			if (lane < 64) {  // one wave follows the path; the others only helped with the copies
+				auto load_rec = [&](uint32_t ci, uint4 (&r)[6]) {
+					const uint4* q = reinterpret_cast<const uint4*>(recs + ci * 32);
 #pragma unroll
-			for (int i = 0; i < 6; ++i) r[i] = q[i];
-		};
-		uint4 rn[6];
-		load_rec(sg.ncols - 1, rn);
-		for (uint32_t ci = sg.ncols; ci-- > 0;) {
-			uint4 r[6];
+					for (int i = 0; i < 6; ++i) r[i] = q[i];
+				};
+				uint4 rn[6];
+				load_rec(ncols - 1, rn);
+				for (uint32_t ci = ncols; ci-- > 0;) {
+					uint4 r[6];
 #pragma unroll
-			for (int i = 0; i < 6; ++i) r[i] = rn[i];
-			if (ci > 0) load_rec(ci - 1, rn);
-			// words: 0 ymask 1 ebits 2 nwords 3 stage_off | 4 layout 5 n_ext 6 n_fwd 7 pad | 8..13 ext | 14..17 fwd | 18..21 endpos
-			const uint32_t y = x & r[0].x;
-			const uint32_t ext[6] = {r[2].x, r[2].y, r[2].z, r[2].w, r[3].x, r[3].y};
-			const uint32_t fwd[4] = {r[3].z, r[3].w, r[4].x, r[4].y};
-			const uint32_t endpos[3] = {r[4].z, r[4].w, r[5].x};
-			uint32_t l = 0, xp = 0;
+					for (int i = 0; i < 6; ++i) r[i] = rn[i];
+					if (ci > 0) load_rec(ci - 1, rn);
+					// words: 0 ymask 1 ebits 2 nwords 3 stage_off | 4 layout 5 n_ext 6 n_fwd 7 pad | 8..13 ext | 14..17 fwd | 18..21 endpos
+					const uint32_t y = x & r[0].x;
+					const uint32_t ext[6] = {r[2].x, r[2].y, r[2].z, r[2].w, r[3].x, r[3].y};
+					const uint32_t fwd[4] = {r[3].z, r[3].w, r[4].x, r[4].y};
+					const uint32_t endpos[3] = {r[4].z, r[4].w, r[5].x};
+					uint32_t l = 0, xp = 0;
 #pragma unroll
-			for (int i = 0; i < 6; ++i) {
-				const uint32_t rr = (uint32_t)i < r[1].y ? ext[i] : 0u;  // a zero run has length 0 and contributes nothing
-				l |= ((y >> (rr & 31u)) & ((1u << ((rr >> 16) & 31u)) - 1u)) << ((rr >> 8) & 31u);
-			}
+					for (int i = 0; i < 6; ++i) {
+						const uint32_t rr = (uint32_t)i < r[1].y ? ext[i] : 0u;  // a zero run has length 0 and contributes nothing
+						l |= ((y >> (rr & 31u)) & ((1u << ((rr >> 16) & 31u)) - 1u)) << ((rr >> 8) & 31u);
+					}
 #pragma unroll
-			for (int i = 0; i < 4; ++i) {
-				const uint32_t rr = (uint32_t)i < r[1].z ? fwd[i] : 0u;
-				xp |= ((y >> (rr & 31u)) & ((1u << ((rr >> 16) & 31u)) - 1u)) << ((rr >> 8) & 31u);
-			}
-			if (r[1].x) {  // layout 1: one byte per thread t = l >> 2, bit l & 3 (at most one ending read)
-				if (r[0].y) {
-				const uint8_t byte = reinterpret_cast<const uint8_t*>(stage + r[0].w)[l >> 2];
-				xp |= (uint32_t)((byte >> (l & 3u)) & 1u) << endpos[0];
+					for (int i = 0; i < 4; ++i) {
+						const uint32_t rr = (uint32_t)i < r[1].z ? fwd[i] : 0u;
+						xp |= ((y >> (rr & 31u)) & ((1u << ((rr >> 16) & 31u)) - 1u)) << ((rr >> 8) & 31u);
+					}
+					if (r[1].x) {  // layout 1: one byte per thread t = l >> 2, bit l & 3 (at most one ending read)
+						if (r[0].y) {
+							const uint8_t byte = reinterpret_cast<const uint8_t*>(stage + r[0].w)[l >> 2];
+							xp |= (uint32_t)((byte >> (l & 3u)) & 1u) << endpos[0];
+						}
+					} else {
+						const uint32_t widx = l >> 6, bpos = l & 63u;
+						unsigned long long words[3];
+#pragma unroll
+						for (int q = 0; q < 3; ++q) words[q] = (uint32_t)q < r[0].y ? stage[r[0].w + q * r[0].z + widx] : 0ull;
+#pragma unroll
+						for (int q = 0; q < 3; ++q) xp |= (uint32_t)((words[q] >> bpos) & 1ull) << endpos[q];
+					}
+					if (lane == 0) {
+						path_index[c0 + ci] = xp;
+						path_trans[c0 + ci] = 0;
+					}
+					x = xp;
 				}
-			} else {
-				const uint32_t widx = l >> 6, bpos = l & 63u;
-				unsigned long long words[3];
-#pragma unroll
-				for (int q = 0; q < 3; ++q) words[q] = (uint32_t)q < r[0].y ? stage[r[0].w + q * r[0].z + widx] : 0ull;
-#pragma unroll
-				for (int q = 0; q < 3; ++q) xp |= (uint32_t)((words[q] >> bpos) & 1ull) << endpos[q];
+				if (lane == 0) xshare[0] = x;
 			}
-			if (lane == 0) {
-				path_index[sg.c0 + ci] = xp;
-				path_trans[sg.c0 + ci] = 0;
-			}
-			x = xp;
+			__syncthreads();
+			x = xshare[0];
+			tprev = 0;
 		}
-		}
-		// hand the path position to every wave (they all need x to address the next run's record)
-		if (lane == 0) xshare[0] = x;
-		__syncthreads();
-		x = xshare[0];
-		tprev = 0;
-		__syncthreads();
 	}
 }
 
@@ -670,8 +742,8 @@ struct DeviceTable::Impl {
 	uint32_t* d_path_index = nullptr;
 	uint32_t* d_path_trans = nullptr;
 	uint32_t* d_score = nullptr;
-	Step* d_steps = nullptr;
-	ResSegment* d_segments = nullptr;
+	BtUnit* d_units = nullptr;
+	std::vector<BtUnit> units;
 	size_t bt_lds = 0;
 	std::vector<DevColumn> cols;
 	ResidentPlan plan;
@@ -688,8 +760,7 @@ struct DeviceTable::Impl {
 		for (void* a : allocations) (void)hipFree(a);
 		allocations.clear();
 		d_cols = nullptr;
-		d_steps = nullptr;
-		d_segments = nullptr;
+		d_units = nullptr;
 		d_pr[0] = d_pr[1] = nullptr;
 		d_path_index = d_path_trans = d_score = nullptr;
 	}
@@ -869,13 +940,33 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	HIP_TRY(up(&d_segs, segs.data(), segs.size() * sizeof(uint32_t)));
 	HIP_TRY(up(&d_rcol, m.plan.columns.data(), m.plan.columns.size() * sizeof(ResColumn)));
 	HIP_TRY(up(&d_rbt, m.plan.backtrace.data(), m.plan.backtrace.size() * sizeof(ResBacktrace)));
-	HIP_TRY(up((void**)&m.d_steps, m.plan.steps.data(), m.plan.steps.size() * sizeof(Step)));
-	HIP_TRY(up((void**)&m.d_segments, m.plan.segments.data(), m.plan.segments.size() * sizeof(ResSegment)));
+	{
+		m.units.clear();
+		for (size_t si = m.plan.steps.size(); si-- > 0;) {
+			const Step& st = m.plan.steps[si];
+			BtUnit u{};
+			u.kind = st.kind;
+			if (st.kind == 0) {
+				u.c0 = st.index;
+				u.ncols = 1;
+			} else {
+				const ResSegment& sgm = m.plan.segments[st.index];
+				u.c0 = sgm.c0; u.ncols = sgm.ncols; u.col_off = sgm.col_off; u.g = sgm.g; u.Lf_last = sgm.Lf_last;
+				u.stage_words = sgm.stage_words; u.n_wext = sgm.n_wext; u.bt_lo = sgm.bt_lo; u.bt_hi = sgm.bt_hi;
+				std::copy(sgm.wext, sgm.wext + RES_IOSEG, u.wext);
+			}
+			m.units.push_back(u);
+		}
+	}
+	HIP_TRY(up((void**)&m.d_units, m.units.data(), m.units.size() * sizeof(BtUnit)));
 	{
 		uint32_t max_stage = 0;
 		for (const ResSegment& sgm : m.plan.segments) max_stage = std::max(max_stage, sgm.stage_words);
-		m.bt_lds = (size_t)RES_MAXCOLS * 128 + 16 + (size_t)max_stage * 8 + 16;
+		m.bt_lds = (size_t)2 * RES_MAXCOLS * 128 + 256 + 16 + (size_t)max_stage * 8 + 16;
 	}
+	void* d_rtab = nullptr;
+	HIP_TRY(alloc(&d_rtab, m.plan.columns.size() * RES_TABLE * sizeof(int32_t)));
+	m.dp.res_tables = (int32_t*)d_rtab;
 	HIP_TRY(alloc(&d_bt, bt));
 	m.key_entries = (size_t)(1ull << max_keys_f) * p.T;
 	HIP_TRY(alloc(&d_keys, m.key_entries * 8));
@@ -933,6 +1024,10 @@ whamd_status_t DeviceTable::solve(const Problem& p, Solution& s, whamd_solve_sta
 	HIP_TRY(hipMemsetAsync(m.dp.keys, 0xFF, m.key_entries * 8, m.stream));
 	HIP_TRY(hipMemsetAsync(m.dp.last_keys, 0xFF, (size_t)MAX_T * 8, m.stream));
 	HIP_TRY(hipEventRecord(m.ev0, m.stream));
+	if (!m.plan.columns.empty()) {
+		const uint32_t entries = (uint32_t)m.plan.columns.size() * RES_TABLE;
+		hipLaunchKernelGGL(resident_tables, dim3((entries + 255) / 256), dim3(256), 0, m.stream, m.dp.res_cols, (uint32_t)m.plan.columns.size(), m.dp.res_tables);
+	}
 	uint64_t launches = 0;
 	uint32_t flip = 0;  // every step reads d_pr[flip] and writes d_pr[flip ^ 1]
 	for (const Step& step : m.plan.steps) {
@@ -968,8 +1063,8 @@ whamd_status_t DeviceTable::solve(const Problem& p, Solution& s, whamd_solve_sta
 	}
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(m.ev1, m.stream));
-	hipLaunchKernelGGL(backtrace_kernel, dim3(1), dim3(1024), m.bt_lds, m.stream, m.dp, m.d_steps, (uint32_t)m.plan.steps.size(),
-	                   m.d_segments, m.d_path_index, m.d_path_trans, m.d_score);
+	hipLaunchKernelGGL(backtrace_kernel, dim3(1), dim3(1024), m.bt_lds, m.stream, m.dp, m.d_units, (uint32_t)m.units.size(),
+	                   m.d_path_index, m.d_path_trans, m.d_score);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(m.ev2, m.stream));
 	HIP_TRY(hipMemcpyAsync(s.path_index.data(), m.d_path_index, (size_t)n * 4, hipMemcpyDeviceToHost, m.stream));

@@ -88,6 +88,18 @@ struct ResBacktrace {
 };
 static_assert(sizeof(ResBacktrace) == 128, "ResBacktrace must stay 32 words");
 
+// Backtrace unit list (reverse processing order): what the backtrace needs to know about a step without chasing
+// pointers, 64 bytes, so that headers can be prefetched two units ahead.
+struct BtUnit {
+	uint32_t kind;         // 0 = column step, 1 = resident run
+	uint32_t c0, ncols;    // first column / number of columns
+	uint32_t col_off;      // run: index of its first record in the ResBacktrace array
+	uint32_t g, Lf_last, stage_words, n_wext;
+	uint32_t bt_lo, bt_hi;
+	uint32_t wext[RES_IOSEG];
+};
+static_assert(sizeof(BtUnit) == 64, "BtUnit must stay 16 words");
+
 struct Step {
 	uint32_t kind;         // 0 = one column through the column kernels, 1 = resident run
 	uint32_t index;        // column index, or index into segments
