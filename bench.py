@@ -64,6 +64,16 @@ def cpu_baseline(args, n_columns):
     }
 
 
+def measured_traffic(args):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), valid for the
+    default workload only; bench.py cannot run the profiler itself."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if args.trio or args.coverage != 20 or args.path not in ("auto", "resident") or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)["traffic_bytes_per_launch"]
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -181,7 +191,7 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None,
+                "traffic": measured_traffic(args),
                 "avg_launch_us": avg_launch_us,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "forward_ms_per_step": fwd_ms / args.steps,
