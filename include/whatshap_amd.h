@@ -178,6 +178,30 @@ whamd_status_t whamd_dptable_get_stats(const whamd_dptable* table, whamd_solve_s
  * launch per column, the general path), or other names documented in DESIGN.md. */
 whamd_status_t whamd_dptable_set_option(whamd_dptable* table, const char* key, const char* value);
 
+/*
+ * Host-only diagnostics (no device needed): builds the flattened problem and the forward plan exactly as
+ * whamd_dptable_create would and reports how the columns are scheduled.  Used by the CPU test-suite to check
+ * the planner's invariants (every column in exactly one step, runs within the LDS budget, ...).
+ */
+typedef struct whamd_plan_summary {
+	uint64_t n_columns;
+	uint64_t n_steps;             /* launches of the forward pass (runs + per-column steps) */
+	uint64_t n_runs;              /* resident runs (one launch each) */
+	uint64_t n_resident_columns;  /* columns executed inside runs */
+	uint64_t n_folded_columns;    /* resident columns evaluated inside their successor (no barrier of their own) */
+	uint64_t n_vectorised_columns;/* resident columns on the 4-entries-per-thread path (incl. folded) */
+	uint64_t max_run_columns;
+	uint64_t max_workgroups;      /* largest grid of a run */
+	uint64_t max_lds_bytes;       /* largest dynamic LDS request of a run */
+	uint64_t backtrace_bytes;     /* size of the backtrace arena */
+	uint32_t max_coverage;
+	uint32_t invariants_ok;       /* 1 if the internal consistency checks passed */
+} whamd_plan_summary;
+whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uint32_t* recombcost, size_t n_recombcost,
+                                    const whamd_pedigree_view* pedigree, int distrust_genotypes,
+                                    const uint32_t* positions, size_t n_positions, const char* path,
+                                    whamd_plan_summary* out);
+
 /* The tie-break hash of ReadSet::sort (src/readset.h:39-66,76-82): std::hash<std::string>(name) ^
  * std::hash<int>(source_id) of the libstdc++ this library is built against.  Used by the Python
  * mirror of ReadSet.sort(); not part of the DP path. */

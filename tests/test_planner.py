@@ -1,0 +1,66 @@
+"""CPU: the host planner of the forward pass (resident runs / folded columns / per-column steps) -- no device needed.
+Checks the invariants the kernels rely on and that the expected schedule comes out for the benchmark shapes."""
+import random
+
+import numpy as np
+import pytest
+
+from whatshap_amd import _native
+from whatshap_amd.synthetic import random_small_instance, synthetic_block
+
+
+def test_benchmark_shape_is_scheduled_as_resident_runs():
+    p = synthetic_block(n_variants=3000, coverage=20, seed=3)
+    s = _native.plan_summary(p)
+    assert s["invariants_ok"] == 1 and s["n_columns"] == 3000 and s["max_coverage"] == 20
+    assert s["n_resident_columns"] >= 2990          # everything but the last column(s)
+    assert s["max_workgroups"] == 256               # 8 grid reads at coverage 20
+    assert 15 <= s["n_resident_columns"] / s["n_runs"] <= 48
+    assert s["n_folded_columns"] >= 0.4 * s["n_columns"]  # every second column starts a read and ends none
+    assert s["max_lds_bytes"] <= 160 * 1024
+    assert s["n_steps"] < s["n_columns"] / 10
+
+
+def test_column_path_request_and_trios_have_no_runs():
+    p = synthetic_block(n_variants=500, coverage=12, seed=5)
+    s = _native.plan_summary(p, "column")
+    assert s["n_runs"] == 0 and s["n_steps"] == 500 and s["invariants_ok"] == 1
+    trio = synthetic_block(n_variants=300, coverage=9, seed=6, trio=True)
+    s = _native.plan_summary(trio)
+    assert s["n_runs"] == 0 and s["n_steps"] == 300 and s["invariants_ok"] == 1
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_invariants_on_irregular_reads(seed):
+    rng = np.random.default_rng(seed)
+    n_var = 600
+    read_ptr, pos, alle, qual = [0], [], [], []
+    n_reads = 0
+    cov = np.zeros(n_var, dtype=int)
+    for start in range(0, n_var - 2):
+        for _ in range(int(rng.integers(0, 3))):
+            end = min(n_var, start + int(rng.choice([2, 3, 5, 9, 17, 30, 60])))
+            if cov[start:end].max() >= 22:
+                continue
+            cols = [c for c in range(start, end) if c in (start, end - 1) or rng.random() < 0.7]
+            cov[start:end] += 1
+            for c in cols:
+                pos.append(10 * (c + 1)); alle.append(int(rng.integers(0, 2))); qual.append(int(rng.integers(1, 30)))
+            read_ptr.append(len(pos))
+            n_reads += 1
+    p = _native.ProblemArrays(read_ptr, pos, alle, qual, np.zeros(n_reads), [0], [], np.ones((1, n_var)), None, [1] * n_var,
+                              [10 * (c + 1) for c in range(n_var)], False)
+    s = _native.plan_summary(p)
+    assert s["invariants_ok"] == 1 and s["n_columns"] == n_var
+    assert s["n_resident_columns"] > 0
+
+
+def test_invariants_on_random_small_instances():
+    rng = random.Random(5)
+    checked = 0
+    for _ in range(300):
+        p = random_small_instance(rng, allow_conflict=False)
+        s = _native.plan_summary(p)
+        assert s["invariants_ok"] == 1
+        checked += s["n_runs"] > 0
+    assert checked > 20

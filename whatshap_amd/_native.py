@@ -51,6 +51,16 @@ class PedigreeView(C.Structure):
     ]
 
 
+class PlanSummary(C.Structure):
+    _fields_ = [(name, C.c_uint64) for name in (
+        "n_columns", "n_steps", "n_runs", "n_resident_columns", "n_folded_columns", "n_vectorised_columns",
+        "max_run_columns", "max_workgroups", "max_lds_bytes", "backtrace_bytes")] + [
+        ("max_coverage", C.c_uint32), ("invariants_ok", C.c_uint32)]
+
+    def as_dict(self) -> dict:
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
 class SolveStats(C.Structure):
     _fields_ = [
         ("n_columns", C.c_uint64),
@@ -213,6 +223,11 @@ def lib() -> C.CDLL:
     L.whamd_dptable_get_stats.argtypes = [H, C.POINTER(SolveStats)]
     L.whamd_dptable_set_option.restype = C.c_int
     L.whamd_dptable_set_option.argtypes = [H, C.c_char_p, C.c_char_p]
+    L.whamd_plan_summarize.restype = C.c_int
+    L.whamd_plan_summarize.argtypes = [
+        C.POINTER(ReadSetView), C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(PedigreeView), C.c_int,
+        C.POINTER(C.c_uint32), C.c_size_t, C.c_char_p, C.POINTER(PlanSummary),
+    ]
     L.whamd_read_sort_hash.restype = C.c_uint64
     L.whamd_read_sort_hash.argtypes = [C.c_char_p, C.c_int]
     if L.whamd_abi_version() != 1:
@@ -227,7 +242,7 @@ EXPORTED_SYMBOLS = [
     "whamd_dptable_destroy", "whamd_dptable_column_count", "whamd_dptable_individual_count",
     "whamd_dptable_read_count", "whamd_dptable_positions", "whamd_dptable_get_optimal_score",
     "whamd_dptable_get_super_reads", "whamd_dptable_get_optimal_partitioning", "whamd_dptable_get_index_path",
-    "whamd_dptable_get_stats", "whamd_dptable_set_option", "whamd_read_sort_hash",
+    "whamd_dptable_get_stats", "whamd_dptable_set_option", "whamd_read_sort_hash", "whamd_plan_summarize",
 ]
 
 
@@ -313,6 +328,13 @@ class NativeTable:
         s = SolveStats()
         _check(lib().whamd_dptable_get_stats(self._h, C.byref(s)))
         return s.as_dict()
+
+
+def plan_summary(problem: ProblemArrays, path: str = "auto") -> dict:
+    """Host-only: how whamd_dptable_create would schedule the columns of `problem` (no device needed)."""
+    out = PlanSummary()
+    _check(lib().whamd_plan_summarize(*problem.call_args(), path.encode(), C.byref(out)))
+    return out.as_dict()
 
 
 def device_count() -> int:

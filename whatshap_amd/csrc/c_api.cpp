@@ -8,6 +8,9 @@
 
 #include "device_table.h"
 #include "problem.h"
+#include "resident.h"
+#include <algorithm>
+#include <vector>
 
 using namespace whamd;
 
@@ -165,6 +168,69 @@ whamd_status_t whamd_dptable_set_option(whamd_dptable* t, const char* key, const
 		return WHAMD_OK;
 	}
 	return fail(WHAMD_ERR_INVALID, "unknown option '" + k + "'");
+}
+
+whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uint32_t* recombcost, size_t n_recombcost,
+                                    const whamd_pedigree_view* pedigree, int distrust_genotypes,
+                                    const uint32_t* positions, size_t n_positions, const char* path,
+                                    whamd_plan_summary* out) {
+	if (!out) return fail(WHAMD_ERR_INVALID, "out is NULL");
+	Problem p;
+	std::string msg;
+	whamd_status_t st = build_problem(readset, recombcost, n_recombcost, pedigree, distrust_genotypes != 0, positions,
+	                                  n_positions, p, msg);
+	if (st != WHAMD_OK) return fail(st, msg);
+	const std::string mode(path ? path : "auto");
+	ResidentPlan plan;
+	plan_forward(p, mode == "auto" || mode == "resident", 11, true, plan);
+	whamd_plan_summary s{};
+	s.n_columns = p.n_cols;
+	s.n_steps = plan.steps.size();
+	s.n_runs = plan.segments.size();
+	s.max_coverage = p.max_k;
+	bool ok = true;
+	std::vector<uint8_t> seen(p.n_cols, 0);
+	uint32_t expect = 0;
+	for (const Step& step : plan.steps) {
+		if (step.kind == 0) {
+			ok = ok && step.index == expect && step.index < p.n_cols;
+			if (step.index < p.n_cols) seen[step.index]++;
+			expect = step.index + 1;
+			continue;
+		}
+		const ResSegment& sg = plan.segments[step.index];
+		ok = ok && sg.c0 == expect && sg.ncols >= 2 && sg.ncols <= (uint32_t)RES_MAXCOLS && sg.g <= (uint32_t)RES_GMAX;
+		expect = sg.c0 + sg.ncols;
+		uint64_t stage = 0;
+		for (uint32_t i = 0; i < sg.ncols; ++i) {
+			const uint32_t c = sg.c0 + i;
+			if (c >= p.n_cols) { ok = false; break; }
+			seen[c]++;
+			const ResColumn& rc = plan.columns[sg.col_off + i];
+			ok = ok && plan.col_to_res[c] == (int32_t)(sg.col_off + i);
+			ok = ok && rc.Lb == p.b[c] - sg.g && rc.Lf == p.f[c] - sg.g && rc.ebits == (uint32_t)p.k[c] - p.f[c];
+			ok = ok && rc.Lb <= (uint32_t)RES_LMAX && rc.Lf <= (uint32_t)RES_LMAX && rc.ebits <= (uint32_t)RES_EMAX;
+			ok = ok && rc.stage_off == stage;
+			stage += (uint64_t)rc.ebits * rc.nwords;
+			if (rc.mode == RES_MODE_FOLDED) { s.n_folded_columns++; ok = ok && i + 1 < sg.ncols && rc.ebits == 0; }
+			if (rc.mode != RES_MODE_GENERIC) s.n_vectorised_columns++;
+			if (rc.nfold) ok = ok && rc.nfold <= RES_MAXFOLD && i >= rc.nfold;
+			ok = ok && c + 1 < p.n_cols;  // the last column never runs resident
+		}
+		ok = ok && stage == sg.stage_words;
+		const uint64_t lds = (uint64_t)sg.ncols * (64 + RES_TABLE) * 4 + 2 * (4ull << sg.max_l) + (uint64_t)sg.stage_words * 8;
+		ok = ok && lds <= 160 * 1024;
+		s.max_lds_bytes = std::max<uint64_t>(s.max_lds_bytes, lds);
+		s.max_run_columns = std::max<uint64_t>(s.max_run_columns, sg.ncols);
+		s.max_workgroups = std::max<uint64_t>(s.max_workgroups, 1ull << sg.g);
+		s.n_resident_columns += sg.ncols;
+		s.backtrace_bytes += (uint64_t)sg.stage_words * (1ull << sg.g) * 8;
+	}
+	ok = ok && expect == p.n_cols;
+	for (uint32_t c = 0; c < p.n_cols; ++c) ok = ok && seen[c] == 1;
+	s.invariants_ok = ok ? 1 : 0;
+	*out = s;
+	return WHAMD_OK;
 }
 
 // std::hash tie-break of ReadSet::sort (src/readset.h:52-55,78-82): exported so that the Python mirror of
