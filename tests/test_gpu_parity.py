@@ -130,9 +130,9 @@ def test_many_reads_ending_at_once():
         assert native_solution(p, path) == want
 
 
-@pytest.mark.parametrize("kw", [dict(n_variants=50000, coverage=15, seed=2), dict(n_variants=20000, coverage=20, seed=3)], ids=str)
+@pytest.mark.parametrize("kw", [dict(n_variants=50000, coverage=15, seed=2), dict(n_variants=200000, coverage=20, seed=3)], ids=str)
 def test_full_size_properties_single_individual(kw):
-    """BASELINE config 2 at full size, config 3 at a tenth of its length (same per-column work): the reported optimum
+    """BASELINE configs 2 and 3 at full size (50 000 x coverage 15; 200 000 x coverage 20): the reported optimum
     equals the wMEC objective re-evaluated independently from the reported bipartition; the path is consistent
     between adjacent columns; a second solve reproduces it bit for bit."""
     p = synthetic_block(**kw)
@@ -154,13 +154,30 @@ def test_full_size_properties_single_individual(kw):
 
 
 def test_full_size_trio_paths_agree():
-    """BASELINE config 4 shape (trio, coverage 15) at a fifth of its length: the fused path and the independent key
+    """BASELINE config 4 at full size (trio PedMEC, 100 000 SNVs, coverage 15): the fused path and the independent key
     path produce identical cost, backtrace, transmission vector and superreads."""
-    p = synthetic_block(n_variants=20000, coverage=15, seed=4, trio=True)
+    p = synthetic_block(n_variants=100000, coverage=15, seed=4, trio=True)
     a = native_solution(p, "column")
     b = native_solution(p, "column_keys")
     assert a == b, first_difference(a, b)
     assert len(set(a["transmission"])) >= 1
+
+
+def test_config5_shape_blocks_on_one_rank():
+    """BASELINE config 5 (24 blocks x 100 000 SNVs, coverage 20, over 8 GPUs): one rank's LPT share (3 blocks), each
+    solved independently; the optimum of every block equals the independently re-evaluated objective and differs
+    between blocks (different seeds); the assignment covers all 24 blocks exactly once."""
+    from whatshap_amd.blocks import assign_blocks, block_weight
+
+    shares = assign_blocks([block_weight(100000, 20)] * 24, 8)
+    assert sorted(b for r in shares for b in r) == list(range(24)) and all(len(r) == 3 for r in shares)
+    costs = []
+    for b in shares[0]:
+        p = synthetic_block(n_variants=100000, coverage=20, seed=100 + b)
+        t = _native.NativeTable(p)
+        assert wmec_cost_of_partitioning(p, t.partitioning()) == t.optimal_score()
+        costs.append(t.optimal_score())
+    assert len(set(costs)) == 3
 
 
 def test_full_size_resident_equals_column_path():

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <unordered_map>
 
 namespace whamd {
@@ -363,22 +364,22 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 }
 
 // get_super_reads / get_alleles / get_optimal_partitioning on the host from the finished path.
-whamd_status_t finish_solution(const Problem& p, Solution& s, std::string& msg) {
+// Columns are independent given the path, so they are split over a few host threads (results per column are written
+// to disjoint slots; the partition flag of a read is only ever set to 0, with a relaxed atomic store).
+namespace {
+
+whamd_status_t finish_columns(const Problem& p, Solution& s, uint32_t c_begin, uint32_t c_end, std::string& msg) {
 	const uint32_t n = p.n_cols;
-	s.allele0.assign((size_t)p.n_ind * n, 0);
-	s.allele1.assign((size_t)p.n_ind * n, 0);
-	s.quality.assign((size_t)p.n_ind * n, 0);
-	s.partition.assign(p.n_reads, 1);
 	std::vector<std::array<uint32_t, 2>> cp(std::max<uint32_t>(p.P, 1));
 	std::vector<std::array<uint32_t, 4>> best_for(std::max<uint32_t>(p.n_ind, 1));  // [ind][hap*2 + allele]
-	for (uint32_t c = 0; c < n; ++c) {
+	for (uint32_t c = c_begin; c < c_end; ++c) {
 		const uint32_t x = s.path_index[c], t = s.path_trans[c];
 		const ColumnEntry* col = p.col_begin(c);
 		const uint32_t kc = p.k[c];
 		const int8_t* map = p.h2p.data() + (size_t)t * p.n_ind * 2;
 		// partitioning: read is in partition 0 wherever its bit is 0 (src/pedigreedptable.cpp:398-400, core.pyx:414)
 		for (uint32_t j = 0; j < kc; ++j) {
-			if (((x >> j) & 1u) == 0) s.partition[col[j].read_id] = 0;
+			if (((x >> j) & 1u) == 0) __atomic_store_n(&s.partition[col[j].read_id], (uint8_t)0, __ATOMIC_RELAXED);
 		}
 		// set_partitioning (src/pedigreecolumncostcomputer.cpp:53-76)
 		for (auto& v : cp) v = {0, 0};
@@ -428,6 +429,33 @@ whamd_status_t finish_solution(const Problem& p, Solution& s, std::string& msg) 
 			s.allele0[(size_t)i * n + c] = a0;
 			s.allele1[(size_t)i * n + c] = a1;
 			s.quality[(size_t)i * n + c] = (uint32_t)q1;  // only the haplotype-1 value survives (:162-163)
+		}
+	}
+	return WHAMD_OK;
+}
+
+}  // namespace
+
+whamd_status_t finish_solution(const Problem& p, Solution& s, std::string& msg) {
+	const uint32_t n = p.n_cols;
+	s.allele0.assign((size_t)p.n_ind * n, 0);
+	s.allele1.assign((size_t)p.n_ind * n, 0);
+	s.quality.assign((size_t)p.n_ind * n, 0);
+	s.partition.assign(p.n_reads, 1);
+	const uint32_t n_threads = n < 20000 ? 1u : std::min<uint32_t>(8, std::max<uint32_t>(1, std::thread::hardware_concurrency()));
+	if (n_threads == 1) return finish_columns(p, s, 0, n, msg);
+	std::vector<std::thread> workers;
+	std::vector<whamd_status_t> status(n_threads, WHAMD_OK);
+	std::vector<std::string> messages(n_threads);
+	for (uint32_t w = 0; w < n_threads; ++w) {
+		const uint32_t c0 = (uint32_t)((uint64_t)n * w / n_threads), c1 = (uint32_t)((uint64_t)n * (w + 1) / n_threads);
+		workers.emplace_back([&, w, c0, c1] { status[w] = finish_columns(p, s, c0, c1, messages[w]); });
+	}
+	for (auto& t : workers) t.join();
+	for (uint32_t w = 0; w < n_threads; ++w) {
+		if (status[w] != WHAMD_OK) {
+			msg = messages[w];
+			return status[w];
 		}
 	}
 	return WHAMD_OK;
