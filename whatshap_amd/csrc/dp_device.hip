@@ -267,63 +267,77 @@ __global__ __launch_bounds__(256) void resident_tables(const ResColumn* __restri
 // One vectorised column of a resident run for the calling thread's entries (resident.h RES_MODE_E0 .. E1_BIT1), with
 // the costs of up to RES_MAXFOLD preceding folded columns added per cell.  A thread owns the 4 consecutive entries
 // 4t .. 4t+3 (8 cells when a read ends) and moves them with 16-byte LDS accesses.
+// All LDS reads of a step (slice entries, the records and table lookups of this column and of the first folded
+// column) are issued before the first use, so one LDS latency covers them instead of one per folded column.
 template <uint32_t MODE>
 __device__ __forceinline__ void res_fast_column(const uint32_t* ldsc, const int32_t* tab, uint32_t ci, uint32_t nfold,
                                                 const uint32_t* bufP, uint32_t* bufQ, uint8_t* stage, uint32_t tid,
                                                 uint32_t NT, uint32_t nthr, const uint4 h0, const uint4 h1) {
 	constexpr int NC = MODE == RES_MODE_E0 ? 4 : 8;  // cells per thread
 	const uint4* hp = reinterpret_cast<const uint4*>(ldsc + ci * 64);
-	const uint4 h2 = hp[2], h3 = hp[3], h4 = hp[4];
+	const uint4 h2 = hp[2], h3 = hp[3], h4 = hp[4], h5 = hp[5];
 	const uint32_t lowmask = h1.x, ep0 = h2.x, mL0 = h3.x, PG = h4.y;
 	uint8_t* rec = stage + h1.z * 8u;  // one byte per thread: bit u = argmin side of the ending read for entry 4t+u
+	// record of the first folded column (or of this column again when nothing is folded: loaded but not used)
+	const uint32_t c1 = ci - (nfold ? 1u : 0u);
+	const uint4* gp = reinterpret_cast<const uint4*>(ldsc + c1 * 64);
+	const uint4 g0 = gp[0], g4 = gp[4], g5 = gp[5];
+	const int32_t* tl0 = tab + ci * RES_TABLE;
+	const int32_t* tl1 = tab + c1 * RES_TABLE;
+	const int32_t* dl0 = reinterpret_cast<const int32_t*>(ldsc + ci * 64 + offsetof(ResColumn, dloc) / 4);
+	const int32_t* dl1 = reinterpret_cast<const int32_t*>(ldsc + c1 * 64 + offsetof(ResColumn, dloc) / 4);
 	for (uint32_t t = tid; t < nthr; t += NT) {
 		const uint32_t l4 = t << 2;
-		// cell c of this thread: index and (per column) the delta pattern on top of the base index
 		uint32_t base, base1 = 0;
 		if (MODE == RES_MODE_E0) base = l4;
 		else if (MODE == RES_MODE_E1_HIGH) { base = insert_zero(l4, ep0); base1 = base | (1u << ep0); }
 		else base = l4 << 1;
+		// ---- issue every LDS read of this thread
+		uint4 pa, pb = make_uint4(0, 0, 0, 0);
+		pa = *reinterpret_cast<const uint4*>(bufP + (base & lowmask));
+		if (MODE == RES_MODE_E1_HIGH) pb = *reinterpret_cast<const uint4*>(bufP + (base1 & lowmask));
+		else if (MODE != RES_MODE_E0) pb = *reinterpret_cast<const uint4*>(bufP + ((base + 4u) & lowmask));
+		const uint32_t ilo = base & 127u, ihi = 128u + ((base >> 7) & 127u);
+		const int32_t ta0 = tl0[ilo], tb0 = tl0[ihi], ta1 = tl1[ilo], tb1 = tl1[ihi];
+		int32_t dE0 = 0, dE1 = 0;
+		if (MODE == RES_MODE_E1_HIGH) { dE0 = dl0[ep0]; dE1 = dl1[ep0]; }  // delta of the ending read (0 where it was not active yet)
 		uint32_t acc[NC];
-		// slice entries of the cells (the run's entering slice or the previous terminal column)
-		if (MODE == RES_MODE_E0) {
-			const uint4 p4 = *reinterpret_cast<const uint4*>(bufP + (base & lowmask));
-			acc[0] = p4.x; acc[1] = p4.y; acc[2] = p4.z; acc[3] = p4.w;
-		} else if (MODE == RES_MODE_E1_HIGH) {  // cells 0..3: ending read on side 0, cells 4..7: side 1
-			const uint4 a4 = *reinterpret_cast<const uint4*>(bufP + (base & lowmask));
-			const uint4 b4 = *reinterpret_cast<const uint4*>(bufP + (base1 & lowmask));
-			acc[0] = a4.x; acc[1] = a4.y; acc[2] = a4.z; acc[3] = a4.w; acc[4] = b4.x; acc[5] = b4.y; acc[6] = b4.z; acc[7] = b4.w;
-		} else {  // the 8 consecutive cells 8t .. 8t+7
-			const uint4 a4 = *reinterpret_cast<const uint4*>(bufP + (base & lowmask));
-			const uint4 b4 = *reinterpret_cast<const uint4*>(bufP + ((base + 4u) & lowmask));
-			acc[0] = a4.x; acc[1] = a4.y; acc[2] = a4.z; acc[3] = a4.w; acc[4] = b4.x; acc[5] = b4.y; acc[6] = b4.z; acc[7] = b4.w;
-		}
-		// this column (f == 0) and the folded ones before it: acc[c] += cost_column(cell c)
-		for (uint32_t f = 0; f <= nfold; ++f) {
-			const uint32_t cf = ci - f;
-			const uint4* fp = reinterpret_cast<const uint4*>(ldsc + cf * 64);
-			const uint4 f0 = fp[0], f4 = fp[4], f5 = fp[5];
-			const uint32_t Cp = f0.x, Cm = f0.y, Cc = f0.z;
-			const int32_t* tlo = tab + cf * RES_TABLE;
-			const int32_t Sb = (int32_t)f4.x + tlo[base & 127u] + tlo[128u + ((base >> 7) & 127u)];
-			const int32_t d0 = (int32_t)f5.x, d1 = (int32_t)f5.y, d2 = (int32_t)f5.z;
+		acc[0] = pa.x; acc[1] = pa.y; acc[2] = pa.z; acc[3] = pa.w;
+		if (NC == 8) { acc[4] = pb.x; acc[5] = pb.y; acc[6] = pb.z; acc[7] = pb.w; }
+		// ---- acc[c] += cost_column(cell c) for this column and the folded ones before it
+		// cost(S) = min3(Cp + S, Cm - S, Cc) with A = Cp + S: min3(A, (Cp + Cm) - A, Cc) -- one add per cell after the base
+		auto add_column = [&](const uint4 f0, const uint4 f4, const uint4 f5, int32_t ta, int32_t tb, int32_t dE) {
+			const uint32_t K = f0.x + f0.y, Cc = f0.z;
+			const uint32_t A0 = f0.x + (uint32_t)((int32_t)f4.x + ta + tb);
+			const uint32_t d0 = f5.x, d1 = f5.y, d2 = f5.z;
+			auto cell = [&](uint32_t A) -> uint32_t { return min(min(A, K - A), Cc); };
 			if (MODE == RES_MODE_E0) {
-				const int32_t pat[4] = {0, d0, d1, d0 + d1};
+				const uint32_t pat[4] = {0, d0, d1, d0 + d1};
 #pragma unroll
-				for (int c = 0; c < 4; ++c) acc[c] += res_cost(Cp, Cm, Cc, Sb + pat[c]);
+				for (int c = 0; c < 4; ++c) acc[c] += cell(A0 + pat[c]);
 			} else if (MODE == RES_MODE_E1_HIGH) {
-				// delta of the ending read in column cf (zero if that read was not active there yet)
-				const int32_t dE = reinterpret_cast<const int32_t*>(ldsc + cf * 64 + offsetof(ResColumn, dloc) / 4)[ep0];
-				const int32_t pat[4] = {0, d0, d1, d0 + d1};
+				const uint32_t pat[4] = {0, d0, d1, d0 + d1};
+				const uint32_t A1 = A0 + (uint32_t)dE;
 #pragma unroll
 				for (int c = 0; c < 4; ++c) {
-					acc[c] += res_cost(Cp, Cm, Cc, Sb + pat[c]);
-					acc[4 + c] += res_cost(Cp, Cm, Cc, Sb + pat[c] + dE);
+					acc[c] += cell(A0 + pat[c]);
+					acc[(NC == 8 ? 4 : 0) + c] += NC == 8 ? cell(A1 + pat[c]) : 0u;
 				}
 			} else {
-				const int32_t pat[8] = {0, d0, d1, d0 + d1, d2, d2 + d0, d2 + d1, d2 + d0 + d1};
+				const uint32_t pat[8] = {0, d0, d1, d0 + d1, d2, d2 + d0, d2 + d1, d2 + d0 + d1};
 #pragma unroll
-				for (int c = 0; c < 8; ++c) acc[c] += res_cost(Cp, Cm, Cc, Sb + pat[c]);
+				for (int c = 0; c < NC; ++c) acc[c] += cell(A0 + pat[c & 7]);
 			}
+		};
+		add_column(h0, h4, h5, ta0, tb0, dE0);
+		if (nfold) add_column(g0, g4, g5, ta1, tb1, dE1);
+		for (uint32_t f = 2; f <= nfold; ++f) {  // further folded columns (rare)
+			const uint32_t cf = ci - f;
+			const uint4* fp = reinterpret_cast<const uint4*>(ldsc + cf * 64);
+			const int32_t* tlf = tab + cf * RES_TABLE;
+			int32_t dEf = 0;
+			if (MODE == RES_MODE_E1_HIGH) dEf = reinterpret_cast<const int32_t*>(ldsc + cf * 64 + offsetof(ResColumn, dloc) / 4)[ep0];
+			add_column(fp[0], fp[4], fp[5], tlf[ilo], tlf[ihi], dEf);
 		}
 		uint32_t D[4];
 		uint32_t takes = 0;
@@ -337,12 +351,13 @@ __device__ __forceinline__ void res_fast_column(const uint32_t* ldsc, const int3
 			for (int u = 0; u < 4; ++u) {
 				// cell pair of entry 4t+u: E1_HIGH (u, 4+u); E1_BIT0 (2u, 2u+1); E1_BIT1 ((u>>1)*4 + (u&1), +2)
 				const int c0 = MODE == RES_MODE_E1_HIGH ? u : (MODE == RES_MODE_E1_BIT0 ? 2 * u : (((u >> 1) << 2) | (u & 1)));
-				const int c1 = MODE == RES_MODE_E1_HIGH ? 4 + u : (MODE == RES_MODE_E1_BIT0 ? 2 * u + 1 : c0 + 2);
+				const int c1i = MODE == RES_MODE_E1_HIGH ? 4 + u : (MODE == RES_MODE_E1_BIT0 ? 2 * u + 1 : c0 + 2);
 				const uint32_t low = MODE == RES_MODE_E1_HIGH ? (uint32_t)u : (uint32_t)c0;  // low bits of the side-0 cell index
 				const uint32_t par = (par0 ^ (uint32_t)__popc(low & mL0)) & 1u;
-				const bool take1 = acc[c1] < acc[c0] || (acc[c1] == acc[c0] && par);
-				D[u] = take1 ? acc[c1] : acc[c0];
-				takes |= take1 ? (1u << u) : 0u;
+				const uint32_t A0 = acc[c0 & (NC - 1)], A1 = acc[c1i & (NC - 1)];
+				// side 1 wins if strictly smaller, or equal and favoured by the tie rule: A1 < A0 + par
+				D[u] = min(A0, A1);
+				takes |= (A1 < A0 + par) ? (1u << u) : 0u;
 			}
 		}
 		*reinterpret_cast<uint4*>(bufQ + l4) = make_uint4(D[0], D[1], D[2], D[3]);
@@ -420,12 +435,15 @@ __global__ __launch_bounds__(1024) void resident_segment(DevProblem P, ResSegmen
 	__syncthreads();
 	const unsigned long long t_ready = DBG ? __builtin_readcyclecounter() : 0ull;
 	const uint32_t wave_first = tid & ~63u;  // first thread index of this wave
+	unsigned long long acc_a = 0, acc_b = 0, acc_c = 0, nsteps_dbg = 0;
 	for (uint32_t ci = 0; ci < sg.ncols; ++ci) {
+		const unsigned long long tq0 = DBG ? __builtin_readcyclecounter() : 0ull;
 		// hot words as LDS broadcasts into VECTOR registers (resident.h); only mode / nthr become scalars
 		const uint4* hp = reinterpret_cast<const uint4*>(ldsc + ci * 64);
 		const uint4 h0 = hp[0], h1 = hp[1];
 		const uint32_t mode = uni(h0.w), nthr = uni(h1.y);
 		if (mode == RES_MODE_FOLDED) continue;  // evaluated inside the next vectorised column: no slice traffic, no barrier
+		const unsigned long long tq1 = DBG ? __builtin_readcyclecounter() : 0ull;
 		if (mode != RES_MODE_GENERIC) {
 			if (wave_first < nthr) {  // a wave whose 64 threads all lie beyond nthr goes straight to the barrier
 				const uint32_t nfold = uni(ldsc[ci * 64 + offsetof(ResColumn, nfold) / 4]);
@@ -501,8 +519,10 @@ __global__ __launch_bounds__(1024) void resident_segment(DevProblem P, ResSegmen
 				}
 			}
 		}
+		const unsigned long long tq2 = DBG ? __builtin_readcyclecounter() : 0ull;
 		__syncthreads();
 		uint32_t* tmp = bufP; bufP = bufQ; bufQ = tmp;
+		if (DBG) { const unsigned long long tq3 = __builtin_readcyclecounter(); acc_a += tq1 - tq0; acc_b += tq2 - tq1; acc_c += tq3 - tq2; nsteps_dbg++; }
 	}
 	const unsigned long long t_cols = DBG ? __builtin_readcyclecounter() : 0ull;
 	// exit slice in logical order, and the run's backtrace record [workgroup][stage_words]
@@ -524,7 +544,7 @@ __global__ __launch_bounds__(1024) void resident_segment(DevProblem P, ResSegmen
 		d[1] = t_cols - t_ready;
 		d[2] = __builtin_readcyclecounter() - t_cols;
 		d[3] = sg.ncols;
-		d[4] = 0; d[5] = 0; d[6] = 0;
+		d[4] = acc_a; d[5] = acc_b; d[6] = acc_c; d[7] = nsteps_dbg;
 	}
 }
 
@@ -1085,11 +1105,10 @@ whamd_status_t DeviceTable::solve(const Problem& p, Solution& s, whamd_solve_sta
 	if (m.dp.dbg) {
 		std::vector<unsigned long long> d(m.plan.segments.size() * 8);
 		HIP_TRY(hipMemcpy(d.data(), m.dp.dbg, d.size() * 8, hipMemcpyDeviceToHost));
-		unsigned long long a = 0, b = 0, c2 = 0, cols = 0, p1 = 0, p2 = 0, p3 = 0;
-		for (size_t i = 0; i < m.plan.segments.size(); ++i) { a += d[8 * i]; b += d[8 * i + 1]; c2 += d[8 * i + 2]; cols += d[8 * i + 3]; p1 += d[8 * i + 4]; p2 += d[8 * i + 5]; p3 += d[8 * i + 6]; }
-		fprintf(stderr, "[whamd timing] per column (wave 0 of workgroup 0): compute %.0f barrier %.0f cycles\n",
-		        (double)p2 / std::max<unsigned long long>(cols, 1), (double)p3 / std::max<unsigned long long>(cols, 1));
-		(void)p1;
+		unsigned long long a = 0, b = 0, c2 = 0, cols = 0, p1 = 0, p2 = 0, p3 = 0, ns = 0;
+		for (size_t i = 0; i < m.plan.segments.size(); ++i) { a += d[8 * i]; b += d[8 * i + 1]; c2 += d[8 * i + 2]; cols += d[8 * i + 3]; p1 += d[8 * i + 4]; p2 += d[8 * i + 5]; p3 += d[8 * i + 6]; ns += d[8 * i + 7]; }
+		fprintf(stderr, "[whamd timing] per barrier step (wave 0 of workgroup 0, %.1f steps per run): hot words %.0f, evaluate %.0f, barrier %.0f cycles\n",
+		        (double)ns / m.plan.segments.size(), (double)p1 / std::max<unsigned long long>(ns, 1), (double)p2 / std::max<unsigned long long>(ns, 1), (double)p3 / std::max<unsigned long long>(ns, 1));
 		if (m.plan.segments.size() > 104) {
 			std::vector<unsigned long long> wg(4 * 512 * 2);
 			HIP_TRY(hipMemcpy(wg.data(), m.dp.dbg + m.dp.dbg_wg_off, wg.size() * 8, hipMemcpyDeviceToHost));
