@@ -113,8 +113,11 @@ def main():
                                           solve=False))
 
     def step():
+        # host-side work queue: every block of this rank is submitted to its own stream, then collected
         for t in tables:
-            t.solve()
+            t.enqueue()
+        for t in tables:
+            t.wait()
 
     def sync():
         torch.cuda.synchronize()

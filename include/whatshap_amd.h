@@ -133,6 +133,11 @@ whamd_status_t whamd_dptable_create(const whamd_readset_view* readset, const uin
                                     int distrust_genotypes, const uint32_t* positions, size_t n_positions,
                                     int device, whamd_dptable** out);
 whamd_status_t whamd_dptable_solve(whamd_dptable* table);
+/* The two halves of whamd_dptable_solve, for the host-side work queue: _enqueue submits the table's launches to its
+ * own HIP stream and returns; _wait blocks until the index path has arrived and evaluates the host part.  Several
+ * tables (independent phasing blocks) may be in flight on one device at once -- their kernels overlap. */
+whamd_status_t whamd_dptable_enqueue(whamd_dptable* table);
+whamd_status_t whamd_dptable_wait(whamd_dptable* table);
 /* ~PedigreeDPTable (src/pedigreedptable.cpp:40-46) */
 void whamd_dptable_destroy(whamd_dptable* table);
 

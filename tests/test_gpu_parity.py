@@ -232,3 +232,17 @@ def test_resident_irregular_reads_vs_oracle():
     for path in PATHS:
         got = native_solution(p, path)
         assert got == want, (path, first_difference(want, got))
+
+
+def test_blocks_in_flight_concurrently():
+    """The host-side work queue: several independent blocks submitted to their own streams on one device before any
+    is collected give the same results as solving them one after the other."""
+    problems = [synthetic_block(n_variants=6000, coverage=c, seed=200 + i) for i, c in enumerate((15, 12, 18, 15))]
+    tables = [_native.NativeTable(p, solve=False) for p in problems]
+    for t in tables:
+        t.enqueue()
+    for t in tables:
+        t.wait()
+    for p, t in zip(problems, tables):
+        want = native_solution(p)
+        assert table_solution(t) == want

@@ -199,6 +199,10 @@ def lib() -> C.CDLL:
     ]
     L.whamd_dptable_solve.restype = C.c_int
     L.whamd_dptable_solve.argtypes = [H]
+    L.whamd_dptable_enqueue.restype = C.c_int
+    L.whamd_dptable_enqueue.argtypes = [H]
+    L.whamd_dptable_wait.restype = C.c_int
+    L.whamd_dptable_wait.argtypes = [H]
     L.whamd_dptable_destroy.restype = None
     L.whamd_dptable_destroy.argtypes = [H]
     L.whamd_dptable_column_count.restype = C.c_uint64
@@ -243,6 +247,7 @@ EXPORTED_SYMBOLS = [
     "whamd_dptable_read_count", "whamd_dptable_positions", "whamd_dptable_get_optimal_score",
     "whamd_dptable_get_super_reads", "whamd_dptable_get_optimal_partitioning", "whamd_dptable_get_index_path",
     "whamd_dptable_get_stats", "whamd_dptable_set_option", "whamd_read_sort_hash", "whamd_plan_summarize",
+    "whamd_dptable_enqueue", "whamd_dptable_wait",
 ]
 
 
@@ -280,6 +285,13 @@ class NativeTable:
 
     def solve(self):
         _check(lib().whamd_dptable_solve(self._h))
+
+    def enqueue(self):
+        """Submit the solve to the table's stream without waiting (pair with wait())."""
+        _check(lib().whamd_dptable_enqueue(self._h))
+
+    def wait(self):
+        _check(lib().whamd_dptable_wait(self._h))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:

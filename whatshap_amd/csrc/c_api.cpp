@@ -22,6 +22,7 @@ struct whamd_dptable {
 	int device_index = 0;
 	bool uploaded = false;
 	bool solved = false;
+	bool in_flight = false;
 };
 
 namespace {
@@ -68,7 +69,7 @@ whamd_status_t whamd_dptable_create(const whamd_readset_view* readset, const uin
 	return WHAMD_OK;
 }
 
-whamd_status_t whamd_dptable_solve(whamd_dptable* t) {
+whamd_status_t whamd_dptable_enqueue(whamd_dptable* t) {
 	if (!t) return fail(WHAMD_ERR_INVALID, "table is NULL");
 	std::string msg;
 	if (!t->uploaded) {
@@ -84,14 +85,32 @@ whamd_status_t whamd_dptable_solve(whamd_dptable* t) {
 	s.algorithmic_bytes = p.algorithmic_bytes;
 	s.max_coverage = p.max_k;
 	s.transmissions = p.T;
-	whamd_status_t st = t->device.solve(p, t->solution, s, msg);
+	t->solved = false;
+	whamd_status_t st = t->device.enqueue(p, t->solution, msg);
+	if (st != WHAMD_OK) return fail(st, msg);
+	t->in_flight = true;
+	return WHAMD_OK;
+}
+
+whamd_status_t whamd_dptable_wait(whamd_dptable* t) {
+	if (!t) return fail(WHAMD_ERR_INVALID, "table is NULL");
+	if (!t->in_flight) return fail(WHAMD_ERR_INVALID, "whamd_dptable_enqueue has not run");
+	t->in_flight = false;
+	std::string msg;
+	whamd_status_t st = t->device.wait(t->problem, t->solution, t->stats, msg);
 	if (st != WHAMD_OK) return fail(st, msg);
 	const double t0 = now_ms();
-	st = finish_solution(p, t->solution, msg);
+	st = finish_solution(t->problem, t->solution, msg);
 	if (st != WHAMD_OK) return fail(st, msg);
-	s.host_finish_ms = now_ms() - t0;
+	t->stats.host_finish_ms = now_ms() - t0;
 	t->solved = true;
 	return WHAMD_OK;
+}
+
+whamd_status_t whamd_dptable_solve(whamd_dptable* t) {
+	whamd_status_t st = whamd_dptable_enqueue(t);
+	if (st != WHAMD_OK) return st;
+	return whamd_dptable_wait(t);
 }
 
 void whamd_dptable_destroy(whamd_dptable* t) { delete t; }

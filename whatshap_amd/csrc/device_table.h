@@ -19,6 +19,10 @@ public:
 	whamd_status_t upload(const Problem& p, int device, std::string& msg);
 	// Forward pass + backtrace on the device; fills s.path_*, s.optimal_score and the timing fields of st.
 	whamd_status_t solve(const Problem& p, Solution& s, whamd_solve_stats& st, std::string& msg);
+	// The two halves of solve(): enqueue() only submits the launches to the table's stream (several tables can be in
+	// flight at once on one device), wait() blocks until the path has arrived and reads the event timings.
+	whamd_status_t enqueue(const Problem& p, Solution& s, std::string& msg);
+	whamd_status_t wait(const Problem& p, Solution& s, whamd_solve_stats& st, std::string& msg);
 	// Solver variant ("auto", "column", "column_keys", "resident"); takes effect at the next upload().
 	bool set_path(const std::string& path);
 	// Preferred log2 slice size of the resident path (tuning knob); takes effect at the next upload().

@@ -775,10 +775,14 @@ struct DeviceTable::Impl {
 	int l_pref = 11;
 	bool fold = true;
 	uint64_t bt_bytes = 0;
+	uint64_t launches = 0;
+	uint32_t* h_pinned = nullptr;  // [2 n + 1]: path index, path transmission, optimal score
 
 	void release() {
 		for (void* a : allocations) (void)hipFree(a);
 		allocations.clear();
+		if (h_pinned) (void)hipHostFree(h_pinned);
+		h_pinned = nullptr;
 		d_cols = nullptr;
 		d_units = nullptr;
 		d_pr[0] = d_pr[1] = nullptr;
@@ -996,6 +1000,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	HIP_TRY(alloc((void**)&m.d_path_index, (size_t)n * 4));
 	HIP_TRY(alloc((void**)&m.d_path_trans, (size_t)n * 4));
 	HIP_TRY(alloc((void**)&m.d_score, 16));
+	HIP_TRY(hipHostMalloc((void**)&m.h_pinned, (2 * (size_t)n + 4) * sizeof(uint32_t), hipHostMallocDefault));
 	HIP_TRY(hipStreamSynchronize(m.stream));
 	m.dp.cols = m.d_cols;
 	m.dp.delta = (const int32_t*)d_delta;
@@ -1032,10 +1037,17 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 }
 
 whamd_status_t DeviceTable::solve(const Problem& p, Solution& s, whamd_solve_stats& st, std::string& msg) {
+	whamd_status_t status = enqueue(p, s, msg);
+	if (status != WHAMD_OK) return status;
+	return wait(p, s, st, msg);
+}
+
+whamd_status_t DeviceTable::enqueue(const Problem& p, Solution& s, std::string& msg) {
 	Impl& m = *impl_;
 	const uint32_t n = p.n_cols;
 	s.path_index.assign(n, 0);
 	s.path_trans.assign(n, 0);
+	m.launches = 0;
 	if (n == 0) {  // src/pedigreedptable.cpp:88-92
 		s.optimal_score = 0;
 		return WHAMD_OK;
@@ -1087,13 +1099,25 @@ whamd_status_t DeviceTable::solve(const Problem& p, Solution& s, whamd_solve_sta
 	                   m.d_path_index, m.d_path_trans, m.d_score);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(m.ev2, m.stream));
-	HIP_TRY(hipMemcpyAsync(s.path_index.data(), m.d_path_index, (size_t)n * 4, hipMemcpyDeviceToHost, m.stream));
-	HIP_TRY(hipMemcpyAsync(s.path_trans.data(), m.d_path_trans, (size_t)n * 4, hipMemcpyDeviceToHost, m.stream));
-	uint32_t score = 0;
-	HIP_TRY(hipMemcpyAsync(&score, m.d_score, 4, hipMemcpyDeviceToHost, m.stream));
+	// downloads go to pinned host buffers: a copy into pageable memory would block this call until the stream drains
+	HIP_TRY(hipMemcpyAsync(m.h_pinned, m.d_path_index, (size_t)n * 4, hipMemcpyDeviceToHost, m.stream));
+	HIP_TRY(hipMemcpyAsync(m.h_pinned + n, m.d_path_trans, (size_t)n * 4, hipMemcpyDeviceToHost, m.stream));
+	HIP_TRY(hipMemcpyAsync(m.h_pinned + 2 * (size_t)n, m.d_score, 4, hipMemcpyDeviceToHost, m.stream));
 	HIP_TRY(hipEventRecord(m.ev3, m.stream));
+	m.launches = launches;
+	return WHAMD_OK;
+}
+
+whamd_status_t DeviceTable::wait(const Problem& p, Solution& s, whamd_solve_stats& st, std::string& msg) {
+	Impl& m = *impl_;
+	if (p.n_cols == 0) return WHAMD_OK;
+	HIP_TRY(hipSetDevice(m.device));
+	const uint64_t launches = m.launches;
 	HIP_TRY(hipStreamSynchronize(m.stream));
-	s.optimal_score = score;
+	const uint32_t n = p.n_cols;
+	std::memcpy(s.path_index.data(), m.h_pinned, (size_t)n * 4);
+	std::memcpy(s.path_trans.data(), m.h_pinned + n, (size_t)n * 4);
+	s.optimal_score = m.h_pinned[2 * (size_t)n];
 	float f01 = 0, f12 = 0, f03 = 0;
 	HIP_TRY(hipEventElapsedTime(&f01, m.ev0, m.ev1));
 	HIP_TRY(hipEventElapsedTime(&f12, m.ev1, m.ev2));
