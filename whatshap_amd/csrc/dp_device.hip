@@ -321,7 +321,7 @@ __device__ __forceinline__ void res_fast_column(const uint32_t* ldsc, const int3
 #pragma unroll
 				for (int c = 0; c < 4; ++c) {
 					acc[c] += cell(A0 + pat[c]);
-					acc[(NC == 8 ? 4 : 0) + c] += NC == 8 ? cell(A1 + pat[c]) : 0u;
+					if constexpr (NC == 8) acc[4 + c] += cell(A1 + pat[c]);
 				}
 			} else {
 				const uint32_t pat[8] = {0, d0, d1, d0 + d1, d2, d2 + d0, d2 + d1, d2 + d0 + d1};
@@ -559,9 +559,10 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
                                                          uint32_t* __restrict__ out_score) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
 	uint32_t* recs0 = smem;                                   // 2 x RES_MAXCOLS * 32 words: column records (double buffer)
-	uint32_t* hdr = smem + 2 * RES_MAXCOLS * 32;              // 4 x 16 words: unit headers (ring)
-	uint32_t* xshare = hdr + 64;                              // 4 words
-	unsigned long long* stage = reinterpret_cast<unsigned long long*>(xshare + 4);
+	uint32_t* hdr = smem + 2 * RES_MAXCOLS * 32;              // 4 x 32 words: unit headers (ring)
+	uint32_t* xshare = hdr + 128;                             // 4 words
+	uint32_t* cells = xshare + 4;                             // RES_MAXCOLS words: local cell index of the path per column
+	unsigned long long* stage = reinterpret_cast<unsigned long long*>(cells + RES_MAXCOLS);
 	const uint32_t lane = threadIdx.x, NT = blockDim.x;
 	const uint32_t n = P.n_cols, T = P.T;
 	// optimum of the last column: first (rank(x), i) attaining the minimum (strict '<' scan, :306-315)
@@ -586,25 +587,27 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 	}
 	// units[0] is the last column itself; every later unit yields x_c from x_{c+1}.
 	// prime the pipeline: headers of units 1 and 2, records of unit 1
-	if (lane < 32) {
-		const uint32_t u = 1 + (lane >> 4);
-		if (u < n_units) hdr[(u & 3u) * 16 + (lane & 15u)] = reinterpret_cast<const uint32_t*>(units + u)[lane & 15u];
+	if (lane < 64) {
+		const uint32_t u = 1 + (lane >> 5);
+		if (u < n_units) hdr[(u & 3u) * 32 + (lane & 31u)] = reinterpret_cast<const uint32_t*>(units + u)[lane & 31u];
 	}
 	__syncthreads();
-	if (n_units > 1 && hdr[16] == 1u) {
-		const uint32_t* __restrict__ g1 = reinterpret_cast<const uint32_t*>(P.res_bt + hdr[16 + 3]);
-		for (uint32_t i = lane; i < hdr[16 + 2] * 32; i += NT) recs0[RES_MAXCOLS * 32 + i] = g1[i];
+	if (n_units > 1 && hdr[32] == 1u) {
+		const uint32_t* __restrict__ g1 = reinterpret_cast<const uint32_t*>(P.res_bt + hdr[32 + 3]);
+		for (uint32_t i = lane; i < hdr[32 + 2] * 32; i += NT) recs0[RES_MAXCOLS * 32 + i] = g1[i];
 	}
 	__syncthreads();
+	unsigned long long bt_load = 0, bt_walk = 0, bt_runs = 0;
 	for (uint32_t ui = 1; ui < n_units; ++ui) {
-		const uint32_t* h = hdr + (ui & 3u) * 16;
+		const unsigned long long tb0 = P.dbg ? __builtin_readcyclecounter() : 0ull;
+		const uint32_t* h = hdr + (ui & 3u) * 32;
 		const uint32_t kind = h[0], c0 = h[1], ncols = h[2];
 		uint32_t* recs = recs0 + (ui & 1u) * RES_MAXCOLS * 32;
 		// prefetch: header of unit ui + 2, records of unit ui + 1 (its header arrived one iteration ago)
-		uint32_t hv = 0;
-		const bool hload = lane < 16 && ui + 2 < n_units;
+		uint32_t hv = 0, wrun = 0;
+		const bool hload = lane < 32 && ui + 2 < n_units;
 		if (hload) hv = reinterpret_cast<const uint32_t*>(units + ui + 2)[lane];
-		const uint32_t* hn = hdr + ((ui + 1) & 3u) * 16;
+		const uint32_t* hn = hdr + ((ui + 1) & 3u) * 32;
 		const bool next_run = ui + 1 < n_units && hn[0] == 1u;
 		const uint32_t nrec = next_run ? hn[2] * 32 : 0u;
 		const uint32_t* __restrict__ gnext = reinterpret_cast<const uint32_t*>(P.res_bt + (next_run ? hn[3] : 0u));
@@ -647,9 +650,10 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 			const uint32_t yexit = x & ((1u << (Lf_last + g)) - 1u);
 			uint32_t w = 0;
 			for (uint32_t i = 0; i < n_wext; ++i) {
-				const uint32_t r = h[10 + i];
+				const uint32_t r = h[12 + i];
 				w |= ((yexit >> (r & 31u)) & ((1u << ((r >> 16) & 31u)) - 1u)) << ((r >> 8) & 31u);
 			}
+			wrun = w;
 			const unsigned long long* __restrict__ gst = reinterpret_cast<const unsigned long long*>(
 				P.bt + (((unsigned long long)h[9] << 32) | h[8])) + (size_t)w * stage_words;
 			unsigned long long sv[2];
@@ -660,7 +664,7 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 			for (uint32_t i = 2 * NT + lane; i < stage_words; i += NT) stage[i] = gst[i];
 		}
 		// land the prefetches
-		if (hload) hdr[((ui + 2) & 3u) * 16 + lane] = hv;
+		if (hload) hdr[((ui + 2) & 3u) * 32 + lane] = hv;
 		{
 			uint32_t* rnext = recs0 + ((ui + 1) & 1u) * RES_MAXCOLS * 32;
 #pragma unroll
@@ -668,61 +672,76 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 			for (uint32_t i = 2 * NT + lane; i < nrec; i += NT) rnext[i] = gnext[i];
 		}
 		__syncthreads();
+		const unsigned long long tb1 = P.dbg ? __builtin_readcyclecounter() : 0ull;
 		if (kind == 1) {
 			if (lane < 64) {  // one wave follows the path; the others only helped with the copies
-				auto load_rec = [&](uint32_t ci, uint4 (&r)[6]) {
-					const uint4* q = reinterpret_cast<const uint4*>(recs + ci * 32);
-#pragma unroll
-					for (int i = 0; i < 6; ++i) r[i] = q[i];
-				};
-				uint4 rn[6];
-				load_rec(ncols - 1, rn);
-				for (uint32_t ci = ncols; ci-- > 0;) {
-					uint4 r[6];
-#pragma unroll
-					for (int i = 0; i < 6; ++i) r[i] = rn[i];
-					if (ci > 0) load_rec(ci - 1, rn);
-					// words: 0 ymask 1 ebits 2 nwords 3 stage_off | 4 layout 5 n_ext 6 n_fwd 7 pad | 8..13 ext | 14..17 fwd | 18..21 endpos
-					const uint32_t y = x & r[0].x;
-					const uint32_t ext[6] = {r[2].x, r[2].y, r[2].z, r[2].w, r[3].x, r[3].y};
-					const uint32_t fwd[4] = {r[3].z, r[3].w, r[4].x, r[4].y};
-					const uint32_t endpos[3] = {r[4].z, r[4].w, r[5].x};
-					uint32_t l = 0, xp = 0;
-#pragma unroll
-					for (int i = 0; i < 6; ++i) {
-						const uint32_t rr = (uint32_t)i < r[1].y ? ext[i] : 0u;  // a zero run has length 0 and contributes nothing
-						l |= ((y >> (rr & 31u)) & ((1u << ((rr >> 16) & 31u)) - 1u)) << ((rr >> 8) & 31u);
-					}
-#pragma unroll
-					for (int i = 0; i < 4; ++i) {
-						const uint32_t rr = (uint32_t)i < r[1].z ? fwd[i] : 0u;
-						xp |= ((y >> (rr & 31u)) & ((1u << ((rr >> 16) & 31u)) - 1u)) << ((rr >> 8) & 31u);
-					}
-					if (r[1].x) {  // layout 1: one byte per thread t = l >> 2, bit l & 3 (at most one ending read)
-						if (r[0].y) {
-							const uint8_t byte = reinterpret_cast<const uint8_t*>(stage + r[0].w)[l >> 2];
-							xp |= (uint32_t)((byte >> (l & 3u)) & 1u) << endpos[0];
-						}
-					} else {
-						const uint32_t widx = l >> 6, bpos = l & 63u;
-						unsigned long long words[3];
-#pragma unroll
-						for (int q = 0; q < 3; ++q) words[q] = (uint32_t)q < r[0].y ? stage[r[0].w + q * r[0].z + widx] : 0ull;
-#pragma unroll
-						for (int q = 0; q < 3; ++q) xp |= (uint32_t)((words[q] >> bpos) & 1ull) << endpos[q];
-					}
-					if (lane == 0) {
-						path_index[c0 + ci] = xp;
-						path_trans[c0 + ci] = 0;
-					}
-					x = xp;
+				// local exit index of the path
+				const uint32_t yexit = x & ((1u << (h[5] + h[4])) - 1u);
+				uint32_t l = 0;
+				for (uint32_t i = 0; i < h[10]; ++i) {
+					const uint32_t r = h[18 + i];
+					l |= ((yexit >> (r & 31u)) & ((1u << ((r >> 16) & 31u)) - 1u)) << ((r >> 8) & 31u);
 				}
-				if (lane == 0) xshare[0] = x;
+				// sequential part, in local index space: only columns where a read ends touch the record
+				uint4 rn = *reinterpret_cast<const uint4*>(recs + (ncols - 1) * 32);
+				uint4 rm = *reinterpret_cast<const uint4*>(recs + (ncols - 1) * 32 + 4);
+				for (uint32_t ci = ncols; ci-- > 0;) {
+					const uint4 r0 = rn, r1 = rm;  // Lf, ebits, layout, stage_off | nwords, epos0, epos1, epos2
+					if (ci > 0) {
+						rn = *reinterpret_cast<const uint4*>(recs + (ci - 1) * 32);
+						rm = *reinterpret_cast<const uint4*>(recs + (ci - 1) * 32 + 4);
+					}
+					const uint32_t lout = l & ((1u << r0.x) - 1u);
+					uint32_t cell = lout;
+					if (r0.y) {
+						if (r0.z) {  // one byte per thread: bit (lout & 3) of byte lout >> 2
+							const uint32_t byte = reinterpret_cast<const uint8_t*>(stage + r0.w)[lout >> 2];
+							cell = insert_zero(lout, r1.y) | (((byte >> (lout & 3u)) & 1u) << r1.y);
+						} else {     // ballot planes, up to 3 ending reads (ascending positions)
+							const uint32_t epos[3] = {r1.y, r1.z, r1.w};
+							uint32_t bits = 0;
+#pragma unroll
+							for (int q = 0; q < 3; ++q) {
+								if ((uint32_t)q < r0.y) {
+									cell = insert_zero(cell, epos[q]);
+									const unsigned long long word = stage[r0.w + q * r1.x + (lout >> 6)];
+									bits |= (uint32_t)((word >> (lout & 63u)) & 1ull) << epos[q];
+								}
+							}
+							cell |= bits;
+						}
+					}
+					if (lane == 0) cells[ci] = cell;
+					l = cell;
+				}
+				// logical indices, one lane per column
+				uint32_t xl = 0;
+				if (lane < ncols) {
+					const uint32_t* rb = recs + lane * 32;
+					const uint32_t cell = cells[lane];
+					const uint32_t ng = rb[8], nl = rb[9];
+					for (uint32_t i = 0; i < ng; ++i) {
+						const uint32_t r = rb[10 + i];
+						xl |= ((wrun >> (r & 31u)) & ((1u << ((r >> 16) & 31u)) - 1u)) << ((r >> 8) & 31u);
+					}
+					for (uint32_t i = 0; i < nl; ++i) {
+						const uint32_t r = rb[18 + i];
+						xl |= ((cell >> (r & 31u)) & ((1u << ((r >> 16) & 31u)) - 1u)) << ((r >> 8) & 31u);
+					}
+					path_index[c0 + lane] = xl;
+					path_trans[c0 + lane] = 0;
+				}
+				if (lane == 0) xshare[0] = xl;
 			}
 			__syncthreads();
 			x = xshare[0];
 			tprev = 0;
+			if (P.dbg) { bt_load += tb1 - tb0; bt_walk += __builtin_readcyclecounter() - tb1; bt_runs++; }
 		}
+	}
+	if (P.dbg && lane == 0) {
+		unsigned long long* d = P.dbg + P.dbg_wg_off + 4 * 512 * 2;
+		d[0] = bt_load; d[1] = bt_walk; d[2] = bt_runs;
 	}
 }
 
@@ -873,8 +892,8 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 			for (uint32_t i = 0; i < sgm.ncols; ++i) {
 				const ResColumn& rc = m.plan.columns[sgm.col_off + i];
 				const ResBacktrace& rb = m.plan.backtrace[sgm.col_off + i];
-				fprintf(stderr, "[plan]   col %u mode=%u Lb=%u Lf=%u ebits=%u epos0=%u nthr=%u stage_off=%u nwords=%u | bt layout=%u n_ext=%u n_fwd=%u endpos0=%u ymask=%x\n",
-				        sgm.c0 + i, rc.mode, rc.Lb, rc.Lf, rc.ebits, rc.epos[0], rc.nthr, rc.stage_off, rc.nwords, rb.layout, rb.n_ext, rb.n_fwd, rb.endpos[0], rb.ymask);
+				fprintf(stderr, "[plan]   col %u mode=%u nfold=%u Lb=%u Lf=%u ebits=%u epos0=%u nthr=%u stage_off=%u nwords=%u | bt layout=%u n_g=%u n_l=%u\n",
+				        sgm.c0 + i, rc.mode, rc.nfold, rc.Lb, rc.Lf, rc.ebits, rc.epos[0], rc.nthr, rc.stage_off, rc.nwords, rb.layout, rb.n_g, rb.n_l);
 			}
 		}
 	}
@@ -977,7 +996,9 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 				const ResSegment& sgm = m.plan.segments[st.index];
 				u.c0 = sgm.c0; u.ncols = sgm.ncols; u.col_off = sgm.col_off; u.g = sgm.g; u.Lf_last = sgm.Lf_last;
 				u.stage_words = sgm.stage_words; u.n_wext = sgm.n_wext; u.bt_lo = sgm.bt_lo; u.bt_hi = sgm.bt_hi;
+				u.n_lext = sgm.n_lext;
 				std::copy(sgm.wext, sgm.wext + RES_IOSEG, u.wext);
+				std::copy(sgm.lext, sgm.lext + RES_BT_LRUNS, u.lext);
 			}
 			m.units.push_back(u);
 		}
@@ -986,7 +1007,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	{
 		uint32_t max_stage = 0;
 		for (const ResSegment& sgm : m.plan.segments) max_stage = std::max(max_stage, sgm.stage_words);
-		m.bt_lds = (size_t)2 * RES_MAXCOLS * 128 + 256 + 16 + (size_t)max_stage * 8 + 16;
+		m.bt_lds = (size_t)2 * RES_MAXCOLS * 128 + 512 + 16 + (size_t)RES_MAXCOLS * 4 + (size_t)max_stage * 8 + 16;
 	}
 	void* d_rtab = nullptr;
 	HIP_TRY(alloc(&d_rtab, m.plan.columns.size() * RES_TABLE * sizeof(int32_t)));
@@ -1015,7 +1036,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	m.dp.dbg = nullptr;
 	if (getenv("WHAMD_DEBUG_TIMING")) {
 		void* d_dbg = nullptr;
-		const size_t dbg_bytes = (m.plan.segments.size() + 1) * 64 + 4 * 512 * 16;
+		const size_t dbg_bytes = (m.plan.segments.size() + 1) * 64 + 4 * 512 * 16 + 64;
 		HIP_TRY(alloc(&d_dbg, dbg_bytes));
 		HIP_TRY(hipMemset(d_dbg, 0, dbg_bytes));
 		m.dp.dbg = (unsigned long long*)d_dbg;
@@ -1133,6 +1154,12 @@ whamd_status_t DeviceTable::wait(const Problem& p, Solution& s, whamd_solve_stat
 		for (size_t i = 0; i < m.plan.segments.size(); ++i) { a += d[8 * i]; b += d[8 * i + 1]; c2 += d[8 * i + 2]; cols += d[8 * i + 3]; p1 += d[8 * i + 4]; p2 += d[8 * i + 5]; p3 += d[8 * i + 6]; ns += d[8 * i + 7]; }
 		fprintf(stderr, "[whamd timing] per barrier step (wave 0 of workgroup 0, %.1f steps per run): hot words %.0f, evaluate %.0f, barrier %.0f cycles\n",
 		        (double)ns / m.plan.segments.size(), (double)p1 / std::max<unsigned long long>(ns, 1), (double)p2 / std::max<unsigned long long>(ns, 1), (double)p3 / std::max<unsigned long long>(ns, 1));
+		{
+			unsigned long long b3[3] = {0, 0, 0};
+			HIP_TRY(hipMemcpy(b3, m.dp.dbg + m.dp.dbg_wg_off + 4 * 512 * 2, sizeof b3, hipMemcpyDeviceToHost));
+			if (b3[2]) fprintf(stderr, "[whamd timing] backtrace per run: record load + prefetch %.0f cycles, walk + hand-over %.0f cycles (%llu runs)\n",
+			                   (double)b3[0] / b3[2], (double)b3[1] / b3[2], b3[2]);
+		}
 		if (m.plan.segments.size() > 104) {
 			std::vector<unsigned long long> wg(4 * 512 * 2);
 			HIP_TRY(hipMemcpy(wg.data(), m.dp.dbg + m.dp.dbg_wg_off, wg.size() * 8, hipMemcpyDeviceToHost));

@@ -67,38 +67,43 @@ struct ResSegment {
 	uint32_t bt_lo, bt_hi; // byte offset of the run's backtrace record: [workgroup][stage_words] u64
 	uint32_t n_wext;       // runs extracting the workgroup index from the logical exit index
 	uint32_t wext[RES_IOSEG];
+	uint32_t n_lext;       // runs extracting the local exit index from the logical exit index
+	uint32_t lext[10];
 	uint16_t n_in_grid, n_in_local, n_out_grid, n_out_local;
 	// packed runs (compact position | mask position << 8 | length << 16): logical index = OR of deposits of w and l
 	uint32_t in_grid[RES_IOSEG], in_local[RES_IOSEG], out_grid[RES_IOSEG], out_local[RES_IOSEG];
 };
 
 // Everything the backtrace needs for one resident column, self-contained (128 B) so that a run's records can be staged
-// in LDS with one coalesced copy.  Given x_{c+1}: y = x_{c+1} & ymask (logical projection index of column c),
-// l = OR_i extract(y, ext[i]) (local part), bit of plane q = word[stage_off + q * nwords + widx(l)] >> bpos(l),
-// x_c = OR_i deposit(y, fwd[i]) | OR_q bit_q << endpos[q].
-constexpr int RES_BT_EXT = 6;
+// in LDS with one coalesced copy.  The walk stays in the run's LOCAL index space (the grid-read bits of the path are
+// constant inside a run): with cell_{c+1} the local cell index of the path at column c+1,
+//   l_out(c) = cell_{c+1} & (2^Lf - 1),  cell_c = l_out with zeros inserted at epos[] and the recorded argmin bits OR-ed in.
+// Only columns in which a read ends cost an LDS access on the sequential chain.  The logical bipartition index
+// x_c = deposit(w, gruns) | deposit(cell_c, lruns) is produced afterwards, one lane per column.
+constexpr int RES_BT_GRUNS = 8, RES_BT_LRUNS = 10;
 struct ResBacktrace {
-	uint32_t ymask, ebits, nwords, stage_off;
-	uint32_t layout;       // 0: ballot planes, word l >> 6, bit l & 63;  1: one byte per thread l >> 2, bit l & 3
-	uint32_t n_ext, n_fwd, pad0;
-	uint32_t ext[RES_BT_EXT];  // packed runs: source position | destination position << 8 | length << 16
-	uint32_t fwd[4];
-	uint32_t endpos[4];
-	uint32_t pad1[10];
+	uint32_t Lf, ebits, layout, stage_off;  // layout 0: ballot planes (word l >> 6, bit l & 63);  1: one byte per thread l >> 2, bit l & 3
+	uint32_t nwords, epos[3];               // local bit positions of the ending reads (ascending logical position)
+	uint32_t n_g, n_l;                      // runs in use
+	uint32_t gruns[RES_BT_GRUNS];           // workgroup-index bits -> logical positions (source | destination << 8 | length << 16)
+	uint32_t lruns[RES_BT_LRUNS];           // local cell bits      -> logical positions
+	uint32_t pad[4];
 };
 static_assert(sizeof(ResBacktrace) == 128, "ResBacktrace must stay 32 words");
 
 // Backtrace unit list (reverse processing order): what the backtrace needs to know about a step without chasing
-// pointers, 64 bytes, so that headers can be prefetched two units ahead.
+// pointers, 128 bytes, so that headers can be prefetched two units ahead.
 struct BtUnit {
 	uint32_t kind;         // 0 = column step, 1 = resident run
 	uint32_t c0, ncols;    // first column / number of columns
 	uint32_t col_off;      // run: index of its first record in the ResBacktrace array
 	uint32_t g, Lf_last, stage_words, n_wext;
-	uint32_t bt_lo, bt_hi;
-	uint32_t wext[RES_IOSEG];
+	uint32_t bt_lo, bt_hi, n_lext, pad0;
+	uint32_t wext[RES_IOSEG];  // logical exit index -> workgroup index
+	uint32_t lext[RES_BT_LRUNS];  // logical exit index -> local exit index
+	uint32_t pad1[4];
 };
-static_assert(sizeof(BtUnit) == 64, "BtUnit must stay 16 words");
+static_assert(sizeof(BtUnit) == 128, "BtUnit must stay 32 words");
 
 struct Step {
 	uint32_t kind;         // 0 = one column through the column kernels, 1 = resident run

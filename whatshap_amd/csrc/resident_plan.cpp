@@ -191,7 +191,7 @@ void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, Reside
 			rc.nwords = fast ? std::max<uint32_t>(1, rc.nthr / 8) : std::max<uint32_t>(1, (1u << rc.Lf) / 64);
 			rc.stage_off = stage_words;
 			stage_words += rc.ebits * rc.nwords;
-			// backtrace record: local part of the logical projection index of this column, logical deposit of the argmin
+			// backtrace record (resident.h): local-space walk + logical index from (workgroup index, local cell index)
 			ResBacktrace rb{};
 			uint32_t gmf = 0, fi = 0;
 			for (uint32_t j = 0; j < kc; ++j) {
@@ -201,20 +201,25 @@ void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, Reside
 			}
 			const uint32_t lmf = (fi >= 32 ? 0xFFFFFFFFu : ((1u << fi) - 1u)) & ~gmf;
 			{
-				std::vector<uint32_t> runs;
-				rb.n_ext = append_runs(lmf, true, runs);
-				if (runs.size() > (size_t)RES_BT_EXT) bt_ok = false; else std::copy(runs.begin(), runs.end(), rb.ext);
-				runs.clear();
-				rb.n_fwd = append_runs(p.fwd_mask[cc], false, runs);
-				if (runs.size() > 4) bt_ok = false; else std::copy(runs.begin(), runs.end(), rb.fwd);
-				uint32_t en2 = 0;
-				for (uint32_t j = 0; j < kc; ++j) if (!((p.fwd_mask[cc] >> j) & 1u) && en2 < 4) rb.endpos[en2++] = j;
+				std::vector<std::pair<uint32_t, uint32_t>> gp, lp;
+				for (uint32_t j = 0; j < kc; ++j) {
+					if (grid_of[j] >= 0) gp.push_back({(uint32_t)grid_of[j], j}); else lp.push_back({(uint32_t)local_of[j], j});
+				}
+				const std::vector<uint32_t> gr = runs_from_pairs(gp), lr = runs_from_pairs(lp);
+				if (gr.size() > (size_t)RES_BT_GRUNS || lr.size() > (size_t)RES_BT_LRUNS) bt_ok = false;
+				else {
+					rb.n_g = (uint32_t)gr.size();
+					rb.n_l = (uint32_t)lr.size();
+					std::copy(gr.begin(), gr.end(), rb.gruns);
+					std::copy(lr.begin(), lr.end(), rb.lruns);
+				}
 			}
-			rb.ymask = (fi >= 32 ? 0xFFFFFFFFu : ((1u << fi) - 1u));  // == 2^b_{c+1} - 1
+			rb.Lf = rc.Lf;
 			rb.ebits = rc.ebits;
 			rb.nwords = rc.nwords;
 			rb.layout = fast ? 1u : 0u;
 			rb.stage_off = rc.stage_off;
+			for (uint32_t q = 0; q < 3; ++q) rb.epos[q] = rc.epos[q];
 			if (cc + 1 == c1) {  // store layout of the exit state
 				run_exit_grid.assign(fi, 0);
 				for (uint32_t j = 0; j < fi; ++j) run_exit_grid[j] = (gmf >> j) & 1u;
@@ -225,9 +230,11 @@ void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, Reside
 				if (out_ok) {
 					std::copy(rg.begin(), rg.end(), seg.out_grid);
 					std::copy(rl.begin(), rl.end(), seg.out_local);
-					std::vector<uint32_t> we;
+					std::vector<uint32_t> we, le;
 					seg.n_wext = append_runs(gmf, true, we);
 					std::copy(we.begin(), we.end(), seg.wext);
+					seg.n_lext = append_runs(lmf, true, le);
+					if (le.size() > 10) out_ok = false; else std::copy(le.begin(), le.end(), seg.lext);
 				}
 				seg.Lf_last = rc.Lf;
 			}
