@@ -63,26 +63,55 @@ __device__ __forceinline__ uint32_t gray_rank(uint32_t x) {
 	return x;
 }
 
+// Per-launch staging of a column's cost data in LDS: 5-bit lookup tables of the per-individual sums L_s(x) and the
+// term lists of every transmission value, so that a cell costs ceil(k/5) LDS reads per individual instead of a
+// k-step loop over scalar global loads.
+constexpr int COL_CHUNKS = 5, COL_MAXTERMS = 1024;
+template <int T, int NIND>
+struct ColumnStage {
+	int32_t lut[NIND][COL_CHUNKS][32];
+	DevTerm terms[COL_MAXTERMS];
+	uint32_t tptr[T + 1];
+};
+
+template <int T, int NIND>
+__device__ __forceinline__ void stage_column(ColumnStage<T, NIND>& S, const DevProblem& P, const DevColumn& col) {
+	const int32_t* __restrict__ dl = P.delta + col.delta_off;
+	const uint32_t k = col.k;
+	for (uint32_t idx = threadIdx.x; idx < (uint32_t)(NIND * COL_CHUNKS * 32); idx += blockDim.x) {
+		const uint32_t s = idx / (COL_CHUNKS * 32), chunk = (idx / 32) % COL_CHUNKS, v = idx & 31u;
+		int32_t sum = 0;
+#pragma unroll
+		for (int j = 0; j < 5; ++j) {
+			const uint32_t bit = chunk * 5 + j;
+			if (bit < k && ((v >> j) & 1u)) sum += dl[s * k + bit];
+		}
+		S.lut[s][chunk][v] = sum;
+	}
+	const uint32_t* __restrict__ tp = P.term_ptr + col.term_off;
+	const uint32_t t0 = tp[0], nterms = min(tp[T] - t0, (uint32_t)COL_MAXTERMS);
+	for (uint32_t i = threadIdx.x; i < nterms; i += blockDim.x) S.terms[i] = P.terms[t0 + i];
+	if (threadIdx.x <= (uint32_t)T) S.tptr[threadIdx.x] = min(tp[threadIdx.x] - t0, (uint32_t)COL_MAXTERMS);
+	__syncthreads();
+}
+
 // cost_{c,t}(x) for all t (get_cost, src/pedigreecolumncostcomputer.cpp:101-114) from the per-individual sums L_s(x).
 template <int T, int NIND>
-__device__ __forceinline__ void cell_costs(uint32_t x, const DevProblem& P, const DevColumn& col, uint32_t (&cost)[T]) {
+__device__ __forceinline__ void cell_costs(uint32_t x, const ColumnStage<T, NIND>& S, uint32_t nchunks, uint32_t (&cost)[T]) {
 	int32_t L[NIND];
 #pragma unroll
 	for (int s = 0; s < NIND; ++s) L[s] = 0;
-	const int32_t* __restrict__ dl = P.delta + col.delta_off;
-	const uint32_t k = col.k;
-	for (uint32_t j = 0; j < k; ++j) {
-		const bool bit = (x >> j) & 1u;
+	for (uint32_t c = 0; c < nchunks; ++c) {
+		const uint32_t v = (x >> (5 * c)) & 31u;
 #pragma unroll
-		for (int s = 0; s < NIND; ++s) L[s] += bit ? dl[s * k + j] : 0;
+		for (int s = 0; s < NIND; ++s) L[s] += S.lut[s][c][v];
 	}
-	const uint32_t* __restrict__ tp = P.term_ptr + col.term_off;
 #pragma unroll
 	for (int t = 0; t < T; ++t) {
 		uint32_t best = 0xFFFFFFFFu;
-		const uint32_t e = tp[t + 1];
-		for (uint32_t q = tp[t]; q < e; ++q) {
-			const DevTerm tm = P.terms[q];
+		const uint32_t e = S.tptr[t + 1];
+		for (uint32_t q = S.tptr[t]; q < e; ++q) {
+			const DevTerm tm = S.terms[q];
 			uint32_t v = tm.c;
 #pragma unroll
 			for (int s = 0; s < NIND; ++s) {
@@ -136,6 +165,9 @@ template <int T, int NIND>
 __global__ __launch_bounds__(256) void column_step_fused(DevProblem P, uint32_t c, const uint32_t* __restrict__ prev,
                                                           uint32_t* __restrict__ cur) {
 	const DevColumn col = P.cols[c];
+	__shared__ ColumnStage<T, NIND> stage;
+	stage_column<T, NIND>(stage, P, col);
+	const uint32_t nchunks = (col.k + 4) / 5;
 	const uint32_t y = blockIdx.x * blockDim.x + threadIdx.x;  // grid covers exactly 2^f entries (f >= 6)
 	const uint32_t* __restrict__ segs = P.segs + col.seg_off;
 	const uint32_t xbase = deposit(y, segs, col.nseg_fwd);
@@ -148,7 +180,7 @@ __global__ __launch_bounds__(256) void column_step_fused(DevProblem P, uint32_t 
 	for (uint32_t e = 0; e < ne; ++e) {
 		const uint32_t x = xbase | deposit(e, segs + col.nseg_fwd, col.nseg_end);
 		uint32_t cost[T], D[T], aj[T];
-		cell_costs<T, NIND>(x, P, col, cost);
+		cell_costs<T, NIND>(x, stage, nchunks, cost);
 		cell_dp<T>(cost, pr, x & lowmask, col.recomb, D, aj);
 		const uint32_t r = gray_rank(x);
 #pragma unroll
@@ -181,6 +213,9 @@ template <int T, int NIND>
 __global__ __launch_bounds__(256) void column_step_keys(DevProblem P, uint32_t c, const uint32_t* __restrict__ prev,
                                                          uint32_t total_threads) {
 	const DevColumn col = P.cols[c];
+	__shared__ ColumnStage<T, NIND> stage;
+	stage_column<T, NIND>(stage, P, col);
+	const uint32_t nchunks = (col.k + 4) / 5;
 	const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
 	if (gid >= total_threads) return;
 	const uint32_t y = gid & ((1u << col.f) - 1u);
@@ -197,7 +232,7 @@ __global__ __launch_bounds__(256) void column_step_keys(DevProblem P, uint32_t c
 		const uint32_t e = (chunk << col.eloop) | el;
 		const uint32_t x = xbase | deposit(e, segs + col.nseg_fwd, col.nseg_end);
 		uint32_t cost[T], D[T], aj[T];
-		cell_costs<T, NIND>(x, P, col, cost);
+		cell_costs<T, NIND>(x, stage, nchunks, cost);
 		cell_dp<T>(cost, pr, x & lowmask, col.recomb, D, aj);
 		const uint32_t r = gray_rank(x);
 #pragma unroll
@@ -617,23 +652,27 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 		if (kind == 0) {
 			// ---- one column through the column kernels' records (global loads; rare in steady state)
 			const uint32_t c = c0;
-			const DevColumn pc = P.cols[c];
-			const uint32_t y = x & ((1u << pc.f) - 1u);
+			// header words of a column unit: 4 f, 5 mode, 6 nplanes, 7 ebits, 8/9 record offset, 10 nseg_fwd, 11 nseg_end,
+			// 12..27 deposit runs (if word 28 is set; else they are read from the column descriptor)
+			const uint32_t cf = h[4], cmode = h[5], cnplanes = h[6], cebits = h[7], nsf = h[10], nse = h[11];
+			const unsigned long long cbt = ((unsigned long long)h[9] << 32) | h[8];
+			const uint32_t* segs = h[28] ? (h + 12) : (P.segs + P.cols[c].seg_off);
+			const uint32_t y = x & ((1u << cf) - 1u);
 			uint32_t xp, aj;
-			if (pc.mode == 0) {
-				const unsigned long long* planes = reinterpret_cast<const unsigned long long*>(P.bt + pc.bt_off);
-				const uint32_t words = 1u << (pc.f - 6);
+			if (cmode == 0) {
+				const unsigned long long* planes = reinterpret_cast<const unsigned long long*>(P.bt + cbt);
+				const uint32_t words = 1u << (cf - 6);
+				unsigned long long wv[8];
+#pragma unroll
+				for (int p = 0; p < 8; ++p) wv[p] = (uint32_t)p < cnplanes ? planes[(size_t)(p * T + tprev) * words + (y >> 6)] : 0ull;
 				uint32_t v = 0;
-				for (uint32_t p = 0; p < pc.nplanes; ++p) {
-					const unsigned long long word = planes[(size_t)(p * T + tprev) * words + (y >> 6)];
-					v |= (uint32_t)((word >> (y & 63u)) & 1ull) << p;
-				}
-				const uint32_t e = v & ((1u << pc.ebits) - 1u);
-				aj = v >> pc.ebits;
-				const uint32_t* segs = P.segs + pc.seg_off;
-				xp = deposit(y, segs, pc.nseg_fwd) | deposit(e, segs + pc.nseg_fwd, pc.nseg_end);
+#pragma unroll
+				for (int p = 0; p < 8; ++p) v |= (uint32_t)((wv[p] >> (y & 63u)) & 1ull) << p;
+				const uint32_t e = v & ((1u << cebits) - 1u);
+				aj = v >> cebits;
+				xp = deposit(y, segs, nsf) | deposit(e, segs + nsf, nse);
 			} else {
-				const uint32_t raw = reinterpret_cast<const uint32_t*>(P.bt + pc.bt_off)[(size_t)y * T + tprev];
+				const uint32_t raw = reinterpret_cast<const uint32_t*>(P.bt + cbt)[(size_t)y * T + tprev];
 				const uint32_t r = raw >> 4;
 				xp = r ^ (r >> 1);
 				aj = raw & 15u;
@@ -905,6 +944,12 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	std::vector<uint32_t> term_ptr32((size_t)n * (p.T + 1));
 	std::vector<DevTerm> terms(p.terms.size());
 	for (size_t i = 0; i < p.terms.size(); ++i) terms[i] = DevTerm{p.terms[i].c, p.terms[i].plus, p.terms[i].minus};
+	for (uint32_t c = 0; c < n; ++c) {
+		if (p.term_end(c, p.T - 1) - p.term_begin(c, 0) > (uint64_t)COL_MAXTERMS) {
+			msg = "more than " + std::to_string(COL_MAXTERMS) + " allele-assignment terms in one column: pedigree too complex for the device path";
+			return WHAMD_ERR_UNSUPPORTED;
+		}
+	}
 	if (p.terms.size() >= 0xFFFFFFFFull || (uint64_t)p.col_ptr[n] * ni >= 0xFFFFFFFFull) {
 		msg = "problem too large for 32-bit device offsets";
 		return WHAMD_ERR_UNSUPPORTED;
@@ -990,8 +1035,19 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 			BtUnit u{};
 			u.kind = st.kind;
 			if (st.kind == 0) {
+				// column step: everything the backtrace needs, so that its chain holds no descriptor load
+				const DevColumn& d = m.cols[st.index];
 				u.c0 = st.index;
 				u.ncols = 1;
+				u.g = d.f; u.Lf_last = d.mode; u.stage_words = d.nplanes; u.n_wext = d.ebits;
+				u.bt_lo = (uint32_t)d.bt_off; u.bt_hi = (uint32_t)(d.bt_off >> 32);
+				u.n_lext = d.nseg_fwd; u.pad0 = d.nseg_end;
+				const uint32_t nseg = (uint32_t)d.nseg_fwd + d.nseg_end;
+				if (nseg <= (uint32_t)(RES_IOSEG + RES_BT_LRUNS)) {
+					uint32_t* dst = u.wext;  // wext[6] and lext[10] are contiguous: 16 run slots
+					for (uint32_t i = 0; i < nseg; ++i) dst[i] = segs[d.seg_off + i];
+					u.pad1[0] = 1;  // runs are inline
+				}
 			} else {
 				const ResSegment& sgm = m.plan.segments[st.index];
 				u.c0 = sgm.c0; u.ncols = sgm.ncols; u.col_off = sgm.col_off; u.g = sgm.g; u.Lf_last = sgm.Lf_last;
@@ -1047,13 +1103,10 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	m.dp.T = p.T;
 	m.dp.tbits = tbits;
 	m.dp.n_ind = p.n_ind;
-	static bool lds_opt_in = false;
-	if (!lds_opt_in) {
-		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(backtrace_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-		lds_opt_in = true;
-	}
+	// kernels with more than 64 KiB of dynamic LDS need the opt-in on every device they run on
+	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(backtrace_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 	return WHAMD_OK;
 }
 
