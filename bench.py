@@ -188,8 +188,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": ("column_step_fused<4,3>" if args.trio or args.path in ("column", "column_keys") else "resident_segment")
-                          if not (args.path in ("column", "column_keys") and not args.trio) else "column_step_fused<1,1>",
+                "kernel": ("column_step_fused<%d,%d>" % ((4, 3) if args.trio else (1, 1))) if args.path in ("column", "column_keys")
+                          else ("resident_segment_ped" if args.trio else "resident_segment"),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",

@@ -1,0 +1,12 @@
+"""Timing probe for the trio (config 4) shape: resident slice-size sweep vs the per-column path."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from whatshap_amd import _native
+from whatshap_amd.synthetic import synthetic_block
+p = synthetic_block(n_variants=20000, coverage=15, seed=4, trio=True)
+for path, lp in [("column", None), ("resident", 8), ("resident", 7), ("resident", 6), ("resident", 5), ("resident", 4)]:
+    t = _native.NativeTable(p, solve=False, path=path)
+    if lp is not None: t.set_option("resident_l", str(lp))
+    for rep in range(2): t.solve()
+    s = t.stats()
+    print(path, lp, "fwd %.2fms bt %.2fms launches %d us/col %.3f cols/s %.0f" % (s["forward_ms"], s["backtrace_ms"], s["forward_launches"], s["forward_ms"]*1e3/s["n_columns"], s["n_columns"]/(s["total_ms"]/1e3)), "cost", t.optimal_score(), flush=True)

@@ -161,6 +161,8 @@ def test_full_size_trio_paths_agree():
     b = native_solution(p, "column_keys")
     assert a == b, first_difference(a, b)
     assert len(set(a["transmission"])) >= 1
+    r = native_solution(p, "resident")  # trio runs: LDS-resident slices of T-vectors, per-entry u32 argmin records
+    assert r == a, first_difference(a, r)
 
 
 def test_config5_shape_blocks_on_one_rank():

@@ -21,13 +21,18 @@ def test_benchmark_shape_is_scheduled_as_resident_runs():
     assert s["n_steps"] < s["n_columns"] / 10
 
 
-def test_column_path_request_and_trios_have_no_runs():
+def test_column_path_request_has_no_runs_and_trios_get_their_own_runs():
     p = synthetic_block(n_variants=500, coverage=12, seed=5)
     s = _native.plan_summary(p, "column")
     assert s["n_runs"] == 0 and s["n_steps"] == 500 and s["invariants_ok"] == 1
-    trio = synthetic_block(n_variants=300, coverage=9, seed=6, trio=True)
+    trio = synthetic_block(n_variants=600, coverage=15, seed=6, trio=True)
     s = _native.plan_summary(trio)
-    assert s["n_runs"] == 0 and s["n_steps"] == 300 and s["invariants_ok"] == 1
+    assert s["invariants_ok"] == 1 and s["n_runs"] > 0 and s["n_resident_columns"] >= 580
+    assert s["n_folded_columns"] == 0          # the transmission argmin is recorded on every column
+    assert s["max_workgroups"] >= 32 and s["max_lds_bytes"] <= 160 * 1024
+    quartet = random_small_instance(random.Random(3), mode="quartet", allow_conflict=False)
+    s = _native.plan_summary(quartet)
+    assert s["n_runs"] == 0 and s["invariants_ok"] == 1  # two trios: per-column kernels
 
 
 @pytest.mark.parametrize("seed", range(6))

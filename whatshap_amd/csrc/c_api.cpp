@@ -228,16 +228,19 @@ whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uin
 			const ResColumn& rc = plan.columns[sg.col_off + i];
 			ok = ok && plan.col_to_res[c] == (int32_t)(sg.col_off + i);
 			ok = ok && rc.Lb == p.b[c] - sg.g && rc.Lf == p.f[c] - sg.g && rc.ebits == (uint32_t)p.k[c] - p.f[c];
-			ok = ok && rc.Lb <= (uint32_t)RES_LMAX && rc.Lf <= (uint32_t)RES_LMAX && rc.ebits <= (uint32_t)RES_EMAX;
+			const uint32_t lmax = sg.kind == 1 ? (uint32_t)PED_LMAX : (uint32_t)RES_LMAX;
+			ok = ok && rc.Lb <= lmax && rc.Lf <= lmax && rc.ebits <= (uint32_t)RES_EMAX;
 			ok = ok && rc.stage_off == stage;
-			stage += (uint64_t)rc.ebits * rc.nwords;
+			stage += sg.kind == 1 ? (uint64_t)rc.nwords : (uint64_t)rc.ebits * rc.nwords;
 			if (rc.mode == RES_MODE_FOLDED) { s.n_folded_columns++; ok = ok && i + 1 < sg.ncols && rc.ebits == 0; }
 			if (rc.mode != RES_MODE_GENERIC) s.n_vectorised_columns++;
 			if (rc.nfold) ok = ok && rc.nfold <= RES_MAXFOLD && i >= rc.nfold;
 			ok = ok && c + 1 < p.n_cols;  // the last column never runs resident
 		}
 		ok = ok && stage == sg.stage_words;
-		const uint64_t lds = (uint64_t)sg.ncols * (64 + RES_TABLE) * 4 + 2 * (4ull << sg.max_l) + (uint64_t)sg.stage_words * 8;
+		const uint64_t lds = sg.kind == 1
+			? (((uint64_t)sg.ncols * (128 + PED_TABLE) + (uint64_t)sg.n_terms * 3 + 3) & ~3ull) * 4 + 2 * (16ull << sg.max_l) + (uint64_t)sg.stage_words * 8
+			: (uint64_t)sg.ncols * (64 + RES_TABLE) * 4 + 2 * (4ull << sg.max_l) + (uint64_t)sg.stage_words * 8;
 		ok = ok && lds <= 160 * 1024;
 		s.max_lds_bytes = std::max<uint64_t>(s.max_lds_bytes, lds);
 		s.max_run_columns = std::max<uint64_t>(s.max_run_columns, sg.ncols);

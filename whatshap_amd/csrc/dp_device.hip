@@ -583,6 +583,148 @@ __global__ __launch_bounds__(1024) void resident_segment(DevProblem P, ResSegmen
 	}
 }
 
+// ------------------------------------------------------------------------------------------------ trio runs
+// Resident run for a trio (T = 4 transmission values, three individuals; resident.h PedColumn).  Same run / grid-read /
+// exchange machinery as resident_segment; a slice entry is the vector of T projection values.  A thread evaluates one
+// projection entry: for every cell projecting onto it, the per-individual sums L_s (two 6-bit lookup tables each), the
+// cost of every transmission value (min over its terms), the T x T min-plus step against the previous slice
+// (src/pedigreedptable.cpp:264-300) and the per-t argmin with the Gray-rank tie rule.  Record: one u32 per entry and
+// column, field t = ending-read bits | argj << 3.
+__global__ __launch_bounds__(1024) void resident_segment_ped(DevProblem P, ResSegment sg, const uint32_t* __restrict__ prev,
+                                                              uint32_t* __restrict__ cur) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+	constexpr int T = PED_T, NIND = PED_NIND;
+	const uint32_t w = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+	uint32_t* ldsc = smem;                                                   // ncols * 128 words
+	int32_t* tab = reinterpret_cast<int32_t*>(ldsc + sg.ncols * 128);        // ncols * NIND * 128 words
+	PedTerm* terms = reinterpret_cast<PedTerm*>(tab + sg.ncols * PED_TABLE);  // n_terms * 3 words
+	uint4* bufP = reinterpret_cast<uint4*>(smem + ((sg.ncols * (128 + PED_TABLE) + sg.n_terms * 3 + 3) & ~3u));
+	uint4* bufQ = bufP + (1u << sg.max_l);
+	uint32_t* stage = reinterpret_cast<uint32_t*>(bufQ + (1u << sg.max_l));
+	{
+		const uint4* __restrict__ gc = reinterpret_cast<const uint4*>(P.ped_cols + sg.col_off);
+		uint4* lc = reinterpret_cast<uint4*>(ldsc);
+		for (uint32_t i = tid; i < sg.ncols * 32; i += NT) lc[i] = gc[i];
+		const uint32_t* __restrict__ gt = reinterpret_cast<const uint32_t*>(P.ped_terms + sg.term_off);
+		uint32_t* lt = reinterpret_cast<uint32_t*>(terms);
+		for (uint32_t i = tid; i < sg.n_terms * 3; i += NT) lt[i] = gt[i];
+		if (!sg.has_prev) {
+			if (tid == 0) bufP[0] = make_uint4(0, 0, 0, 0);
+		} else {
+			const uint32_t wpart = deposit_args(w, sg.in_grid, sg.n_in_grid);
+			const uint4* __restrict__ p4 = reinterpret_cast<const uint4*>(prev);
+			for (uint32_t l = tid; l < (1u << sg.Lb0); l += NT) bufP[l] = p4[wpart | deposit_args(l, sg.in_local, sg.n_in_local)];
+		}
+	}
+	__syncthreads();
+	// per-column scalars that depend on the workgroup index; lookup tables (two 6-bit tables per individual)
+	for (uint32_t i = tid; i < sg.ncols * 4; i += NT) {
+		PedColumn* pc = reinterpret_cast<PedColumn*>(ldsc + (i >> 2) * 128);
+		const uint32_t s = i & 3u;
+		if (s < (uint32_t)NIND) {
+			int32_t Sg = 0;
+			for (uint32_t q = 0; q < sg.g; ++q) Sg += ((w >> q) & 1u) ? pc->dgrid[s][q] : 0;
+			pc->Sg[s] = Sg;
+		} else {
+			uint32_t PG = 0;
+			for (uint32_t q = 0; q < RES_EMAX; ++q) PG |= ((uint32_t)__popc(w & pc->mG[q]) & 1u) << q;
+			pc->PG = PG;
+		}
+	}
+	for (uint32_t idx = tid; idx < sg.ncols * PED_TABLE; idx += NT) {
+		const uint32_t ci = idx / PED_TABLE, r = idx % PED_TABLE, s = r >> 7, half = (r >> 6) & 1u, v = r & 63u;
+		const PedColumn* pc = reinterpret_cast<const PedColumn*>(ldsc + ci * 128);
+		int32_t sum = 0;
+#pragma unroll
+		for (int j = 0; j < 6; ++j) sum += ((v >> j) & 1u) ? pc->dloc[s][half * 6 + j] : 0;
+		tab[idx] = sum;
+	}
+	__syncthreads();
+	// a lane evaluates ONE transmission value of one projection entry: 4 lanes per entry (all read the same slice
+	// vector; each writes its own value and its own record byte), so a 256-entry slice keeps 16 waves busy
+	const uint32_t ti = tid & 3u;
+	for (uint32_t ci = 0; ci < sg.ncols; ++ci) {
+		const PedColumn* pc = reinterpret_cast<const PedColumn*>(ldsc + ci * 128);
+		const uint32_t Lf = uni(pc->Lf), ebits = uni(pc->ebits);
+		const uint32_t lowmask = pc->lowmask, recomb = pc->recomb, PG = pc->PG;
+		const uint32_t epos[RES_EMAX] = {uni(pc->epos[0]), uni(pc->epos[1]), uni(pc->epos[2])};
+		const uint32_t mL[RES_EMAX] = {pc->mL[0], pc->mL[1], pc->mL[2]};
+		const uint32_t tq0 = pc->term_off + pc->tptr[ti], tq1 = pc->term_off + pc->tptr[ti + 1];  // this lane's terms
+		int32_t Sg[NIND];
+#pragma unroll
+		for (int s = 0; s < NIND; ++s) Sg[s] = pc->Sg[s];
+		const int32_t* tb = tab + ci * PED_TABLE;
+		uint8_t* rec = reinterpret_cast<uint8_t*>(stage + uni(pc->stage_off));
+		const uint32_t nout = 1u << Lf, ne = 1u << ebits;
+		uint32_t ebit[RES_EMAX];
+#pragma unroll
+		for (int q = 0; q < RES_EMAX; ++q) ebit[q] = (uint32_t)q < ebits ? (1u << epos[q]) : 0u;
+		// recombination cost of switching from transmission value j to this lane's value
+		uint32_t rc[T];
+#pragma unroll
+		for (int j = 0; j < T; ++j) rc[j] = (uint32_t)__popc(ti ^ (uint32_t)j) * recomb;
+		for (uint32_t idx = tid; idx < nout * T; idx += NT) {
+			const uint32_t l_out = idx >> 2;
+			uint32_t base = l_out;
+#pragma unroll
+			for (int q = 0; q < RES_EMAX; ++q) if ((uint32_t)q < ebits) base = insert_zero(base, epos[q]);
+			uint32_t bD = 0xFFFFFFFFu, bE = 0, bJ = 0;
+			for (uint32_t e = 0; e < ne; ++e) {
+				uint32_t lc = base;
+#pragma unroll
+				for (int q = 0; q < RES_EMAX; ++q) lc |= ((e >> q) & 1u) ? ebit[q] : 0u;
+				int32_t L[NIND];
+#pragma unroll
+				for (int s = 0; s < NIND; ++s) L[s] = Sg[s] + tb[s * 128 + (lc & 63u)] + tb[s * 128 + 64 + ((lc >> 6) & 63u)];
+				uint32_t cost = 0xFFFFFFFFu;
+				for (uint32_t q = tq0; q < tq1; ++q) {
+					const PedTerm tm = terms[q];
+					uint32_t v = tm.c;
+#pragma unroll
+					for (int s = 0; s < NIND; ++s) {
+						v += ((tm.plus >> s) & 1u) ? (uint32_t)L[s] : 0u;
+						v -= ((tm.minus >> s) & 1u) ? (uint32_t)L[s] : 0u;
+					}
+					cost = min(cost, v);
+				}
+				const uint4 p4 = bufP[lc & lowmask];
+				const uint32_t pv[T] = {p4.x, p4.y, p4.z, p4.w};
+				uint32_t m = 0xFFFFFFFFu, mj = 0;
+				if (cost != 0xFFFFFFFFu) {
+#pragma unroll
+					for (int j = 0; j < T; ++j) {
+						if (pv[j] != 0xFFFFFFFFu) {
+							const uint32_t val = cost + pv[j] + rc[j];
+							if (val < m) { m = val; mj = j; }
+						}
+					}
+				}
+				bool take = m < bD;
+				if (e > 0 && m == bD && m != 0xFFFFFFFFu) {
+					// tie between cells: they differ first (from the top) at ending read h; the one with x_h == parity of the
+					// bits above h has the smaller Gray rank; e ascends, so the new cell has x_h = 1
+					const uint32_t h = 31u - (uint32_t)__clz((int)(e ^ bE));
+					uint32_t par = 0;
+#pragma unroll
+					for (int q = 0; q < RES_EMAX; ++q) if (h == (uint32_t)q) par = ((PG >> q) ^ (uint32_t)__popc(lc & mL[q])) & 1u;
+					take = par != 0;
+				}
+				if (take) { bD = m; bE = e; bJ = mj; }
+			}
+			reinterpret_cast<uint32_t*>(bufQ)[idx] = bD;
+			rec[idx] = (uint8_t)(bE | (bJ << 3));
+		}
+		__syncthreads();
+		uint4* tmp = bufP; bufP = bufQ; bufQ = tmp;
+	}
+	const uint32_t wout = deposit_args(w, sg.out_grid, sg.n_out_grid);
+	uint4* c4 = reinterpret_cast<uint4*>(cur);
+	for (uint32_t l = tid; l < (1u << sg.Lf_last); l += NT) c4[wout | deposit_args(l, sg.out_local, sg.n_out_local)] = bufP[l];
+	unsigned long long* grec = reinterpret_cast<unsigned long long*>(P.bt + (((unsigned long long)sg.bt_hi << 32) | sg.bt_lo)) + (size_t)w * sg.stage_words;
+	const unsigned long long* st64 = reinterpret_cast<const unsigned long long*>(stage);
+	for (uint32_t i = tid; i < sg.stage_words; i += NT) grec[i] = st64[i];
+}
+
 // Backtrace (src/pedigreedptable.cpp:137-173); out: index / transmission per column, out_score[0] = optimum.
 // The steps of the forward plan are walked in reverse (`units`, newest first).  For a resident run the argmin bits the
 // path can touch all belong to ONE workgroup's record (the grid-read bits of the path do not change inside a run), so
@@ -597,7 +739,8 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 	uint32_t* hdr = smem + 2 * RES_MAXCOLS * 32;              // 4 x 32 words: unit headers (ring)
 	uint32_t* xshare = hdr + 128;                             // 4 words
 	uint32_t* cells = xshare + 4;                             // RES_MAXCOLS words: local cell index of the path per column
-	unsigned long long* stage = reinterpret_cast<unsigned long long*>(cells + RES_MAXCOLS);
+	uint32_t* tsarr = cells + RES_MAXCOLS;                    // RES_MAXCOLS words: transmission value of the path per column
+	unsigned long long* stage = reinterpret_cast<unsigned long long*>(tsarr + RES_MAXCOLS);
 	const uint32_t lane = threadIdx.x, NT = blockDim.x;
 	const uint32_t n = P.n_cols, T = P.T;
 	// optimum of the last column: first (rank(x), i) attaining the minimum (strict '<' scan, :306-315)
@@ -722,6 +865,7 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 					l |= ((yexit >> (r & 31u)) & ((1u << ((r >> 16) & 31u)) - 1u)) << ((r >> 8) & 31u);
 				}
 				// sequential part, in local index space: only columns where a read ends touch the record
+				uint32_t tcur = tprev;
 				uint4 rn = *reinterpret_cast<const uint4*>(recs + (ncols - 1) * 32);
 				uint4 rm = *reinterpret_cast<const uint4*>(recs + (ncols - 1) * 32 + 4);
 				for (uint32_t ci = ncols; ci-- > 0;) {
@@ -732,7 +876,21 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 					}
 					const uint32_t lout = l & ((1u << r0.x) - 1u);
 					uint32_t cell = lout;
-					if (r0.y) {
+					if (r0.z == 2u) {  // trio: one u32 per entry, field of the current transmission value: ending-read bits | argj << 3
+						const uint32_t fld = reinterpret_cast<const uint8_t*>(stage + r0.w)[lout * 4u + tcur] & 31u;
+						const uint32_t epos[3] = {r1.y, r1.z, r1.w};
+						uint32_t bits = 0;
+#pragma unroll
+						for (int q = 0; q < 3; ++q) {
+							if ((uint32_t)q < r0.y) {
+								cell = insert_zero(cell, epos[q]);
+								bits |= ((fld >> q) & 1u) << epos[q];
+							}
+						}
+						cell |= bits;
+						if (lane == 0) tsarr[ci] = tcur;
+						tcur = fld >> 3;
+					} else if (r0.y) {
 						if (r0.z) {  // one byte per thread: bit (lout & 3) of byte lout >> 2
 							const uint32_t byte = reinterpret_cast<const uint8_t*>(stage + r0.w)[lout >> 2];
 							cell = insert_zero(lout, r1.y) | (((byte >> (lout & 3u)) & 1u) << r1.y);
@@ -768,13 +926,13 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 						xl |= ((cell >> (r & 31u)) & ((1u << ((r >> 16) & 31u)) - 1u)) << ((r >> 8) & 31u);
 					}
 					path_index[c0 + lane] = xl;
-					path_trans[c0 + lane] = 0;
+					path_trans[c0 + lane] = rb[2] == 2u ? tsarr[lane] : 0u;
 				}
-				if (lane == 0) xshare[0] = xl;
+				if (lane == 0) { xshare[0] = xl; xshare[1] = tcur; }
 			}
 			__syncthreads();
 			x = xshare[0];
-			tprev = 0;
+			tprev = xshare[1];
 			if (P.dbg) { bt_load += tb1 - tb0; bt_walk += __builtin_readcyclecounter() - tb1; bt_runs++; }
 		}
 	}
@@ -1028,6 +1186,12 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	HIP_TRY(up(&d_segs, segs.data(), segs.size() * sizeof(uint32_t)));
 	HIP_TRY(up(&d_rcol, m.plan.columns.data(), m.plan.columns.size() * sizeof(ResColumn)));
 	HIP_TRY(up(&d_rbt, m.plan.backtrace.data(), m.plan.backtrace.size() * sizeof(ResBacktrace)));
+	void *d_pcol = nullptr, *d_pterm = nullptr;
+	m.plan.ped_columns.resize(m.plan.ped_columns.empty() ? 0 : m.plan.columns.size());
+	HIP_TRY(up(&d_pcol, m.plan.ped_columns.data(), m.plan.ped_columns.size() * sizeof(PedColumn)));
+	HIP_TRY(up(&d_pterm, m.plan.ped_terms.data(), m.plan.ped_terms.size() * sizeof(PedTerm)));
+	m.dp.ped_cols = (const PedColumn*)d_pcol;
+	m.dp.ped_terms = (const PedTerm*)d_pterm;
 	{
 		m.units.clear();
 		for (size_t si = m.plan.steps.size(); si-- > 0;) {
@@ -1063,7 +1227,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	{
 		uint32_t max_stage = 0;
 		for (const ResSegment& sgm : m.plan.segments) max_stage = std::max(max_stage, sgm.stage_words);
-		m.bt_lds = (size_t)2 * RES_MAXCOLS * 128 + 512 + 16 + (size_t)RES_MAXCOLS * 4 + (size_t)max_stage * 8 + 16;
+		m.bt_lds = (size_t)2 * RES_MAXCOLS * 128 + 512 + 16 + (size_t)RES_MAXCOLS * 8 + (size_t)max_stage * 8 + 16;
 	}
 	void* d_rtab = nullptr;
 	HIP_TRY(alloc(&d_rtab, m.plan.columns.size() * RES_TABLE * sizeof(int32_t)));
@@ -1107,6 +1271,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(backtrace_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment_ped), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 	return WHAMD_OK;
 }
 
@@ -1142,6 +1307,13 @@ whamd_status_t DeviceTable::enqueue(const Problem& p, Solution& s, std::string& 
 		flip ^= 1;
 		if (step.kind == 1) {
 			const ResSegment& sg = m.plan.segments[step.index];
+			if (sg.kind == 1) {
+				const size_t words = ((size_t)sg.ncols * (128 + PED_TABLE) + (size_t)sg.n_terms * 3 + 3) & ~(size_t)3;
+				const size_t lds_ped = words * 4 + 2 * ((size_t)16 << sg.max_l) + (size_t)sg.stage_words * 8;
+				hipLaunchKernelGGL(resident_segment_ped, dim3(1u << sg.g), dim3(sg.threads), lds_ped, m.stream, m.dp, sg, prev, cur);
+				++launches;
+				continue;
+			}
 			const size_t lds = (size_t)sg.ncols * (64 + RES_TABLE) * 4 + 2 * ((size_t)4 << sg.max_l) + (size_t)sg.stage_words * 8;
 			ResSegment arg = sg;
 			arg.pad = step.index;

@@ -57,12 +57,34 @@ constexpr uint32_t RES_MODE_FOLDED = 5;   // no read ends here and the next colu
                                           // inside the next column's evaluation (no slice traffic, no barrier of its own)
 constexpr uint32_t RES_MAXFOLD = 3;
 
+// ---- trio runs (T = 4, three individuals): every slice entry is a vector of T values; a thread evaluates one
+// projection entry (all T transmission values, all cells projecting onto it).  Descriptor of one column, 512 bytes.
+constexpr int PED_T = 4, PED_NIND = 3;
+constexpr int PED_LMAX = 10;       // log2 of the largest slice (entries of T values)
+constexpr int PED_LKMAX = 12;      // local cell bits (two 6-bit lookup tables per individual)
+constexpr int PED_TABLE = PED_NIND * 128;  // table words per column
+struct PedColumn {
+	uint32_t Lb, Lf, ebits, stage_off;   // stage_off: u32 words into the workgroup's record (one u32 per projection entry)
+	uint32_t lowmask, recomb, n_terms, term_off;  // term_off: index into the run's term pool
+	uint32_t epos[4], mL[4], mG[4];      // ending reads (ascending logical position): local position, tie-break masks
+	uint32_t PG, pad0[3];                // written by the kernel
+	uint32_t tptr[8];                    // [T + 1] term ranges per transmission value, relative to term_off
+	int32_t Sg[4];                       // per individual, written by the kernel
+	int32_t dgrid[PED_NIND][RES_GMAX];   // signed deltas of the grid reads, per individual (0 for reads of other individuals)
+	int32_t dloc[PED_NIND][PED_LKMAX];   // signed deltas of the local bits, per individual
+	uint32_t pad1[32];
+};
+static_assert(sizeof(PedColumn) == 512, "PedColumn must stay 128 words");
+struct PedTerm { uint32_t c, plus, minus; };
+
 // Passed to the kernel by value (kernel arguments live in SGPRs: no memory round trip before the first column).
 constexpr int RES_IOSEG = 6;       // runs per mask of the load / store layouts held in the kernel arguments
 struct ResSegment {
 	uint32_t c0, ncols, g, col_off;
 	uint32_t Lb0, Lf_last, has_prev, threads;
 	uint32_t max_l, pad;
+	uint32_t kind;         // 0: single individual (resident_segment), 1: trio (resident_segment_ped)
+	uint32_t term_off, n_terms;  // trio: this run's slice of the term pool
 	uint32_t stage_words;  // ballot words (u64) one workgroup produces in this run
 	uint32_t bt_lo, bt_hi; // byte offset of the run's backtrace record: [workgroup][stage_words] u64
 	uint32_t n_wext;       // runs extracting the workgroup index from the logical exit index
@@ -82,7 +104,8 @@ struct ResSegment {
 // x_c = deposit(w, gruns) | deposit(cell_c, lruns) is produced afterwards, one lane per column.
 constexpr int RES_BT_GRUNS = 8, RES_BT_LRUNS = 10;
 struct ResBacktrace {
-	uint32_t Lf, ebits, layout, stage_off;  // layout 0: ballot planes (word l >> 6, bit l & 63);  1: one byte per thread l >> 2, bit l & 3
+	uint32_t Lf, ebits, layout, stage_off;  // layout 0: ballot planes (word l >> 6, bit l & 63);  1: one byte per thread l >> 2, bit l & 3;
+	                                        // 2: trio, one byte per (entry, transmission value): ending-read bits | argj << 3
 	uint32_t nwords, epos[3];               // local bit positions of the ending reads (ascending logical position)
 	uint32_t n_g, n_l;                      // runs in use
 	uint32_t gruns[RES_BT_GRUNS];           // workgroup-index bits -> logical positions (source | destination << 8 | length << 16)
@@ -116,6 +139,8 @@ struct ResidentPlan {
 	std::vector<ResColumn> columns;      // resident columns in run order
 	std::vector<int32_t> col_to_res;     // [n_cols] index into `columns` or -1
 	std::vector<ResBacktrace> backtrace; // parallel to `columns`
+	std::vector<PedColumn> ped_columns;  // parallel to `columns` (filled for trio runs only)
+	std::vector<PedTerm> ped_terms;      // term pool of the trio runs
 	uint64_t n_resident_columns = 0;
 };
 

@@ -46,7 +46,10 @@ void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, Reside
 	const uint32_t n = p.n_cols;
 	plan = ResidentPlan();
 	plan.col_to_res.assign(n, -1);
-	const bool eligible = resident && p.T == 1 && p.n_ind == 1 && p.value_bound < 1073741824.0;
+	const bool single = p.T == 1 && p.n_ind == 1 && p.value_bound < 1073741824.0;
+	const bool ped = p.T == (uint32_t)PED_T && p.n_ind == (uint32_t)PED_NIND && p.n_triples == 1;
+	const bool eligible = resident && (single || ped);
+	if (ped && l_pref > 8) l_pref = 8;  // trio slices hold T values per entry and every entry is much more work
 	std::vector<uint32_t> last_col;
 	if (eligible) {
 		last_col.assign(p.n_reads, 0);
@@ -84,18 +87,28 @@ void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, Reside
 		}
 		std::sort(grid_reads.begin(), grid_reads.end());
 		uint32_t c1 = c, run_max_l = 0;
-		uint64_t run_stage = 0;
+		uint64_t run_stage = 0, run_terms = 0;
 		while (c1 < n && c1 - c < (uint32_t)RES_MAXCOLS) {
 			if (c1 + 1 == n) break;      // the last column needs the global optimum
 			if (c1 >= grid_end) break;   // a grid read is minimised out at this column
 			const uint32_t kc = p.k[c1];
 			if (kc < g) break;
 			const uint32_t Lb = p.b[c1] - g, Lf = p.f[c1] - g, Lk = kc - g;
-			if (Lb > (uint32_t)RES_LMAX || Lf > (uint32_t)RES_LMAX || Lk > 14 || kc - p.f[c1] > (uint32_t)RES_EMAX) break;
-			run_max_l = std::max(run_max_l, std::max(Lb, Lf));
-			run_stage += (uint64_t)(kc - p.f[c1]) * std::max<uint32_t>(4, (1u << Lf) / 32);
-			const uint64_t lds_bytes = (uint64_t)(c1 - c + 1) * (64 + RES_TABLE) * 4 + 2 * (4ull << run_max_l) + run_stage * 8;
-			if (lds_bytes > 150 * 1024) break;
+			if (kc - p.f[c1] > (uint32_t)RES_EMAX) break;
+			if (ped) {
+				if (Lb > (uint32_t)PED_LMAX || Lf > (uint32_t)PED_LMAX || Lk > (uint32_t)PED_LKMAX) break;
+				run_max_l = std::max(run_max_l, std::max(Lb, Lf));
+				run_stage += ((1ull << Lf) + 1) / 2;  // one u32 per projection entry
+				run_terms += p.term_end(c1, p.T - 1) - p.term_begin(c1, 0);
+				const uint64_t lds_bytes = (uint64_t)(c1 - c + 1) * (128 + PED_TABLE) * 4 + run_terms * 12 + 2 * (16ull << run_max_l) + run_stage * 8;
+				if (lds_bytes > 150 * 1024) break;
+			} else {
+				if (Lb > (uint32_t)RES_LMAX || Lf > (uint32_t)RES_LMAX || Lk > 14) break;
+				run_max_l = std::max(run_max_l, std::max(Lb, Lf));
+				run_stage += (uint64_t)(kc - p.f[c1]) * std::max<uint32_t>(4, (1u << Lf) / 32);
+				const uint64_t lds_bytes = (uint64_t)(c1 - c + 1) * (64 + RES_TABLE) * 4 + 2 * (4ull << run_max_l) + run_stage * 8;
+				if (lds_bytes > 150 * 1024) break;
+			}
 			++c1;
 		}
 		if (c1 - c < 2) {
@@ -110,6 +123,8 @@ void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, Reside
 		seg.g = g;
 		seg.col_off = (uint32_t)plan.columns.size();
 		seg.has_prev = c > 0;
+		seg.kind = ped ? 1u : 0u;
+		seg.term_off = (uint32_t)plan.ped_terms.size();
 		uint32_t max_l = 0, stage_words = 0;
 		std::vector<uint8_t> run_entry_grid, run_exit_grid;
 		bool out_ok = true, bt_ok = true;
@@ -189,8 +204,32 @@ void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, Reside
 			else rc.mode = rc.epos[0] >= 2 ? RES_MODE_E1_HIGH : (rc.epos[0] == 0 ? RES_MODE_E1_BIT0 : RES_MODE_E1_BIT1);
 			// record of a vectorised column: one byte per thread (nthr bytes); otherwise ballot words per plane
 			rc.nwords = fast ? std::max<uint32_t>(1, rc.nthr / 8) : std::max<uint32_t>(1, (1u << rc.Lf) / 64);
-			rc.stage_off = stage_words;
-			stage_words += rc.ebits * rc.nwords;
+			if (ped) {
+				// one u32 per projection entry on EVERY column (the transmission argmin is needed everywhere)
+				rc.mode = RES_MODE_GENERIC;
+				rc.nwords = ((1u << rc.Lf) + 1) / 2;
+				rc.stage_off = stage_words;
+				stage_words += rc.nwords;
+				PedColumn pc{};
+				pc.Lb = rc.Lb; pc.Lf = rc.Lf; pc.ebits = rc.ebits; pc.stage_off = rc.stage_off * 2;
+				pc.lowmask = rc.lowmask; pc.recomb = p.recomb[cc];
+				for (uint32_t q = 0; q < 4; ++q) { pc.epos[q] = rc.epos[q]; pc.mL[q] = rc.mL[q]; pc.mG[q] = rc.mG[q]; }
+				for (uint32_t j = 0; j < kc; ++j) {
+					const uint32_t smp = col[j].sample;
+					const int32_t dj = p.delta[(size_t)p.col_ptr[cc] * p.n_ind + (size_t)smp * kc + j];
+					if (grid_of[j] >= 0) pc.dgrid[smp][grid_of[j]] = dj; else pc.dloc[smp][local_of[j]] = dj;
+				}
+				pc.term_off = (uint32_t)plan.ped_terms.size() - seg.term_off;
+				const uint64_t tb = p.term_begin(cc, 0);
+				for (uint32_t t = 0; t <= p.T; ++t) pc.tptr[t] = (uint32_t)((t < p.T ? p.term_begin(cc, t) : p.term_end(cc, p.T - 1)) - tb);
+				pc.n_terms = pc.tptr[p.T];
+				for (uint64_t q = tb; q < tb + pc.n_terms; ++q) plan.ped_terms.push_back(PedTerm{p.terms[q].c, p.terms[q].plus, p.terms[q].minus});
+				plan.ped_columns.resize(plan.columns.size() + 1);
+				plan.ped_columns.back() = pc;
+			} else {
+				rc.stage_off = stage_words;
+				stage_words += rc.ebits * rc.nwords;
+			}
 			// backtrace record (resident.h): local-space walk + logical index from (workgroup index, local cell index)
 			ResBacktrace rb{};
 			uint32_t gmf = 0, fi = 0;
@@ -217,7 +256,7 @@ void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, Reside
 			rb.Lf = rc.Lf;
 			rb.ebits = rc.ebits;
 			rb.nwords = rc.nwords;
-			rb.layout = fast ? 1u : 0u;
+			rb.layout = ped ? 2u : (fast ? 1u : 0u);
 			rb.stage_off = rc.stage_off;
 			for (uint32_t q = 0; q < 3; ++q) rb.epos[q] = rc.epos[q];
 			if (cc + 1 == c1) {  // store layout of the exit state
@@ -243,7 +282,7 @@ void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, Reside
 			plan.backtrace.push_back(rb);
 		}
 		// fold columns in which no read ends into the next vectorised column (resident.h RES_MODE_FOLDED)
-		if (fold) {
+		if (fold && !ped) {
 			uint32_t run = 0;
 			for (size_t i = columns_mark; i < plan.columns.size(); ++i) {
 				ResColumn& rc = plan.columns[i];
@@ -264,11 +303,15 @@ void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, Reside
 			for (uint32_t cc = c; cc < c1; ++cc) plan.col_to_res[cc] = -1;
 			plan.columns.resize(columns_mark);
 			plan.backtrace.resize(columns_mark);
+			if (plan.ped_columns.size() > columns_mark) plan.ped_columns.resize(columns_mark);
+			plan.ped_terms.resize(seg.term_off);
 			plan.steps.push_back(Step{0, c});
 			++c;
 			continue;
 		}
-		seg.threads = std::min<uint32_t>(1024, std::max<uint32_t>(64, (1u << max_l) / 4));
+		seg.threads = ped ? std::min<uint32_t>(1024, std::max<uint32_t>(64, 4u << max_l))
+		                  : std::min<uint32_t>(1024, std::max<uint32_t>(64, (1u << max_l) / 4));
+		seg.n_terms = (uint32_t)plan.ped_terms.size() - seg.term_off;
 		seg.max_l = max_l;
 		seg.stage_words = stage_words;
 
