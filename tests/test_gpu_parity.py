@@ -117,6 +117,19 @@ def test_coverage_20_prefix_vs_oracle():
     assert got == want, first_difference(want, got)
 
 
+@pytest.mark.parametrize("kw", [dict(n_variants=200000, coverage=22, seed=31, n_columns_limit=58),
+                                dict(n_variants=2000, coverage=16, seed=32, distrust_genotypes=True, n_columns_limit=400),
+                                dict(n_variants=2000, coverage=17, seed=33, step=3, n_columns_limit=300)], ids=str)
+def test_high_coverage_prefixes_vs_oracle(kw):
+    """Coverage 22 (10 grid reads + 12-13 local bits: 1024 workgroups per run), three-term costs at coverage 16
+    (distrusted genotypes) and a step-3 read layout (two columns without a new read between starts)."""
+    p = synthetic_block(**kw)
+    want = table_solution(oracle.OracleTable(p))
+    for path in ("auto", "column"):
+        got = native_solution(p, path)
+        assert got == want, (path, first_difference(want, got))
+
+
 def test_many_reads_ending_at_once():
     """All reads start and end together: k - f jumps from 0 to 12 in one column (the key path's chunked enumeration)."""
     rng = np.random.default_rng(5)

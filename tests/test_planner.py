@@ -21,6 +21,13 @@ def test_benchmark_shape_is_scheduled_as_resident_runs():
     assert s["n_steps"] < s["n_columns"] / 10
 
 
+def test_coverage_23_still_runs_resident():
+    p = synthetic_block(n_variants=400, coverage=23, seed=9)
+    s = _native.plan_summary(p)
+    assert s["invariants_ok"] == 1 and s["max_coverage"] == 23
+    assert s["max_workgroups"] == 1024 and s["n_resident_columns"] >= 300
+
+
 def test_column_path_request_has_no_runs_and_trios_get_their_own_runs():
     p = synthetic_block(n_variants=500, coverage=12, seed=5)
     s = _native.plan_summary(p, "column")

@@ -449,9 +449,9 @@ __global__ __launch_bounds__(1024) void resident_segment(DevProblem P, ResSegmen
 		if (!sg.has_prev && tid == 0) bufP[0] = 0;
 	}
 	__syncthreads();
-	// per-column scalars that depend on the workgroup index: 8 lanes per column (one per grid read), xor-shuffle reduce
-	for (uint32_t ci0 = 0; ci0 < sg.ncols; ci0 += NT / 8) {
-		const uint32_t ci = ci0 + (tid >> 3), i = tid & 7u;
+	// per-column scalars that depend on the workgroup index: 16 lanes per column (one per grid read), xor-shuffle reduce
+	for (uint32_t ci0 = 0; ci0 < sg.ncols; ci0 += NT / 16) {
+		const uint32_t ci = ci0 + (tid >> 4), i = tid & 15u;
 		int32_t part = 0;
 		uint32_t pg = 0;
 		if (ci < sg.ncols) {
@@ -459,8 +459,8 @@ __global__ __launch_bounds__(1024) void resident_segment(DevProblem P, ResSegmen
 			if (i < sg.g && ((w >> i) & 1u)) part = rc->dgrid[i];
 			if (i < RES_EMAX) pg = ((uint32_t)__popc(w & rc->mG[i]) & 1u) << i;
 		}
-		part += __shfl_xor(part, 1); part += __shfl_xor(part, 2); part += __shfl_xor(part, 4);
-		pg |= __shfl_xor(pg, 1); pg |= __shfl_xor(pg, 2); pg |= __shfl_xor(pg, 4);
+		part += __shfl_xor(part, 1); part += __shfl_xor(part, 2); part += __shfl_xor(part, 4); part += __shfl_xor(part, 8);
+		pg |= __shfl_xor(pg, 1); pg |= __shfl_xor(pg, 2); pg |= __shfl_xor(pg, 4); pg |= __shfl_xor(pg, 8);
 		if (ci < sg.ncols && i == 0) {
 			ResColumn* rc = reinterpret_cast<ResColumn*>(ldsc + ci * 64);
 			rc->Sg = part;

@@ -17,7 +17,7 @@ namespace whamd {
 
 constexpr int RES_EMAX = 3;        // reads that may end in one resident column
 constexpr int RES_LMAX = 13;       // log2 of the largest LDS slice (entries)
-constexpr int RES_GMAX = 8;        // log2 of the largest grid (workgroups) of one run
+constexpr int RES_GMAX = 10;       // log2 of the largest grid (workgroups) of one run (coverage 23 = 10 grid + 13 local bits)
 constexpr int RES_MAXCOLS = 48;    // columns per run (bounds the LDS lookup tables)
 constexpr int RES_TABLE = 256;     // per column: two 128-entry tables (low / high 7 local bits)
 
@@ -43,7 +43,7 @@ struct ResColumn {
 	uint32_t mG[4];                   // per ending read: grid bits logically above it
 	int32_t dgrid[RES_GMAX];          // signed deltas of the grid reads at this column
 	int32_t dloc[14];                 // signed deltas of the local bits
-	uint32_t pad1[12];
+	uint32_t pad1[10];
 };
 static_assert(sizeof(ResColumn) == 256, "ResColumn must stay 64 words");
 constexpr uint32_t RES_ABSENT = 0xC0000000u;
@@ -72,7 +72,7 @@ struct PedColumn {
 	int32_t Sg[4];                       // per individual, written by the kernel
 	int32_t dgrid[PED_NIND][RES_GMAX];   // signed deltas of the grid reads, per individual (0 for reads of other individuals)
 	int32_t dloc[PED_NIND][PED_LKMAX];   // signed deltas of the local bits, per individual
-	uint32_t pad1[32];
+	uint32_t pad1[26];
 };
 static_assert(sizeof(PedColumn) == 512, "PedColumn must stay 128 words");
 struct PedTerm { uint32_t c, plus, minus; };

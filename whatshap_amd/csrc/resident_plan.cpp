@@ -70,7 +70,10 @@ void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, Reside
 		const uint32_t b0 = p.b[c];
 		const ColumnEntry* first = p.col_begin(c);
 		uint32_t g = 0;
-		if ((int)b0 > l_pref) g = std::min<uint32_t>(b0 - (uint32_t)l_pref, RES_GMAX);
+		// one workgroup per CU (256 = 2^8) as long as the slice stays <= 2^12 entries; more workgroups only for the
+		// highest coverages (22, 23), where the slice would not fit otherwise
+		if ((int)b0 > l_pref) g = std::min<uint32_t>(b0 - (uint32_t)l_pref, 8);
+		if (b0 - g > 12) g = std::min<uint32_t>(b0 - 12, RES_GMAX);
 		// grid reads: the g entering reads that end last (ties: the younger read)
 		std::vector<uint32_t> order(b0);
 		for (uint32_t j = 0; j < b0; ++j) order[j] = j;
