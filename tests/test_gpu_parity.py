@@ -261,3 +261,59 @@ def test_blocks_in_flight_concurrently():
     for p, t in zip(problems, tables):
         want = native_solution(p)
         assert table_solution(t) == want
+
+
+def _irregular_problem(seed, n_var, trio, max_cov):
+    """Reads of very different lengths, nested and gapped, random samples (trio) -- exotic grid/local layouts."""
+    rng = np.random.default_rng(seed)
+    cov = np.zeros(n_var, dtype=int)
+    read_ptr, pos, alle, qual, samples = [0], [], [], [], []
+    hap = rng.integers(0, 2, n_var)
+    for start in range(0, n_var - 2):
+        for _ in range(int(rng.integers(0, 3))):
+            end = min(n_var, start + int(rng.choice([2, 3, 5, 9, 17, 30])))
+            if cov[start:end].max() >= max_cov:
+                continue
+            cols = [c for c in range(start, end) if c in (start, end - 1) or rng.random() < 0.7]
+            cov[start:end] += 1
+            side = rng.integers(0, 2)
+            for c in cols:
+                pos.append(10 * (c + 1))
+                alle.append(int(hap[c] ^ side ^ (rng.random() < 0.05)))
+                qual.append(int(rng.integers(1, 30)))
+            read_ptr.append(len(pos))
+            samples.append(int(rng.integers(0, 3)) if trio else 0)
+    n_ind = 3 if trio else 1
+    recomb = [0] + [int(rng.integers(1, 40)) for _ in range(n_var - 1)]
+    return _native.ProblemArrays(read_ptr, pos, alle, qual, samples, list(range(n_ind)), [0, 1, 2] if trio else [],
+                                 np.ones((n_ind, n_var)), None, recomb, [10 * (c + 1) for c in range(n_var)], False)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_irregular_trio_reads_vs_oracle(seed):
+    """Trio runs on reads of irregular lengths: runs are short, several reads end in one column, grid reads are
+    scattered over the index, recombination costs vary per column; both device paths must equal the oracle."""
+    p = _irregular_problem(seed, 260, True, 12)
+    want = table_solution(oracle.OracleTable(p))
+    for path in ("auto", "column"):
+        got = native_solution(p, path)
+        assert got == want, (path, first_difference(want, got))
+    s = _native.plan_summary(p)
+    assert s["n_runs"] > 0 and s["invariants_ok"] == 1
+
+
+def test_quartet_and_unrelated_individuals_vs_oracle():
+    """Two trios sharing parents (T = 16) and a table of unrelated individuals (T = 1, several samples): the
+    per-column kernels with their LDS-staged lookup tables."""
+    rng = random.Random(77)
+    for _ in range(60):
+        p = random_small_instance(rng, mode="quartet", max_variants=9, max_reads=7)
+        want, werr = oracle_outcome(p)
+        got, gerr = native_outcome(p, "auto")
+        assert gerr == werr
+        assert got == want
+    q = synthetic_block(n_variants=300, coverage=9, seed=11, trio=True)
+    unrelated = _native.ProblemArrays(q.read_ptr, q.var_position, q.var_allele, q.var_quality, q.read_sample_id, [0, 1, 2],
+                                      [], np.ones((3, 300)), None, [1] * 300, q.positions, False)
+    want = table_solution(oracle.OracleTable(unrelated))
+    assert native_solution(unrelated, "auto") == want
