@@ -109,6 +109,12 @@ int whamd_device_count(void);
 /* thread-local message of the last failing call on this thread ("" if none) */
 const char* whamd_last_error(void);
 
+/* Frees everything the table holds on the device (buffers, stream, events) while keeping the solution: the getters
+ * below stay valid, a later enqueue/solve uploads again.  For callers that keep thousands of solved blocks alive
+ * (one table per connected component of a chromosome).  No reference counterpart: the reference frees its
+ * backtrace tables only in ~PedigreeDPTable (src/pedigreedptable.cpp:40-48). */
+whamd_status_t whamd_dptable_release_device(whamd_dptable* table);
+
 /*
  * Replaces PedigreeDPTable::PedigreeDPTable (src/pedigreedptable.cpp:15-37), split in two so that
  * a benchmark can time the device part alone:

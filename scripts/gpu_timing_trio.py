@@ -1,10 +1,11 @@
-"""Timing probe for the trio (config 4) shape: resident slice-size sweep vs the per-column path."""
+"""Timing probe for the trio (config 4) shape: in-kernel cycle split (WHAMD_DEBUG_TIMING) and slice-size sweep."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from whatshap_amd import _native
 from whatshap_amd.synthetic import synthetic_block
 p = synthetic_block(n_variants=20000, coverage=15, seed=4, trio=True)
-for path, lp in [("column", None), ("resident", 8), ("resident", 7), ("resident", 6), ("resident", 5), ("resident", 4)]:
+print(_native.plan_summary(p))
+for path, lp in [("resident", 7), ("resident", 8), ("resident", 6)]:
     t = _native.NativeTable(p, solve=False, path=path)
     if lp is not None: t.set_option("resident_l", str(lp))
     for rep in range(2): t.solve()

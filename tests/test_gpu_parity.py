@@ -317,3 +317,40 @@ def test_quartet_and_unrelated_individuals_vs_oracle():
                                       [], np.ones((3, 300)), None, [1] * 300, q.positions, False)
     want = table_solution(oracle.OracleTable(unrelated))
     assert native_solution(unrelated, "auto") == want
+
+
+def test_drop_in_class_splits_and_overlaps_independent_blocks():
+    """A single-individual table whose reads fall into several disconnected stretches: the drop-in class cuts it at
+    the column boundaries no read spans, keeps the blocks in flight on separate streams and concatenates; cost,
+    partitioning, superreads and transmission vector equal the whole-table oracle (and the unsplit device solve)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from dist_worker import multi_block_instance
+    from whatshap_amd.core import Pedigree, NumericSampleIds, Read, ReadSet, Genotype
+
+    for seed in (5, 6, 7, 8):
+        whole = multi_block_instance(seed)
+        rs = ReadSet()
+        for r in range(whole.n_reads):
+            read = Read(f"r{r}", 50, 0, 0)
+            for i in range(int(whole.read_ptr[r]), int(whole.read_ptr[r + 1])):
+                read.add_variant(int(whole.var_position[i]), int(whole.var_allele[i]), int(whole.var_quality[i]))
+            rs.add(read)
+        ped = Pedigree(NumericSampleIds())
+        from whatshap_amd.core import PhredGenotypeLikelihoods
+        gl = whole.genotype_likelihoods.reshape(1, -1, 3)
+        ped.add_individual(0, [Genotype([0, 1])] * whole.n_variants, [PhredGenotypeLikelihoods(list(gl[0, v])) for v in range(whole.n_variants)])
+        ped.numeric_sample_ids.mapping = {0: 0}
+        want = table_solution(oracle.OracleTable(whole))
+        for split in (True, False):
+            dp = PedigreeDPTable(rs, whole.recombcost.tolist(), ped, whole.distrust_genotypes, whole.positions.tolist(), split_blocks=split)
+            assert dp.get_optimal_cost() == want["cost"]
+            assert dp.get_optimal_partitioning() == want["partitioning"]
+            superreads, tv = dp.get_super_reads()
+            assert [v.allele for v in superreads[0][0]] == want["allele0"][0]
+            assert [v.allele for v in superreads[0][1]] == want["allele1"][0]
+            assert [v.quality for v in superreads[0][0]] == want["quality"][0]
+            assert [v.position for v in superreads[0][0]] == want["positions"]
+            assert tv == want["transmission"]
+            assert dp.get_index_path()[0].tolist() == want["index_path"]
+        assert dp.get_stats()["n_columns"] == len(want["positions"])

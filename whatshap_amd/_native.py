@@ -203,6 +203,8 @@ def lib() -> C.CDLL:
     L.whamd_dptable_enqueue.argtypes = [H]
     L.whamd_dptable_wait.restype = C.c_int
     L.whamd_dptable_wait.argtypes = [H]
+    L.whamd_dptable_release_device.restype = C.c_int
+    L.whamd_dptable_release_device.argtypes = [H]
     L.whamd_dptable_destroy.restype = None
     L.whamd_dptable_destroy.argtypes = [H]
     L.whamd_dptable_column_count.restype = C.c_uint64
@@ -243,7 +245,7 @@ def lib() -> C.CDLL:
 # every symbol include/whatshap_amd.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = [
     "whamd_abi_version", "whamd_device_count", "whamd_last_error", "whamd_dptable_create", "whamd_dptable_solve",
-    "whamd_dptable_destroy", "whamd_dptable_column_count", "whamd_dptable_individual_count",
+    "whamd_dptable_release_device", "whamd_dptable_destroy", "whamd_dptable_column_count", "whamd_dptable_individual_count",
     "whamd_dptable_read_count", "whamd_dptable_positions", "whamd_dptable_get_optimal_score",
     "whamd_dptable_get_super_reads", "whamd_dptable_get_optimal_partitioning", "whamd_dptable_get_index_path",
     "whamd_dptable_get_stats", "whamd_dptable_set_option", "whamd_read_sort_hash", "whamd_plan_summarize",
@@ -292,6 +294,10 @@ class NativeTable:
 
     def wait(self):
         _check(lib().whamd_dptable_wait(self._h))
+
+    def release_device(self):
+        """Frees the device side of a solved table; the getters keep working."""
+        _check(lib().whamd_dptable_release_device(self._h))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:

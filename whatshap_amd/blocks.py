@@ -73,11 +73,19 @@ def split_independent_blocks(problem: ProblemArrays) -> List[Tuple[ProblemArrays
     recomb[:m] = problem.recombcost[:m]
     if m < n:
         recomb[m:] = problem.recombcost[-1] if problem.recombcost.size else 0
+    # block of every read = block of its first column; reads of a block keep their ReadSet order
+    block_of = np.searchsorted(np.asarray(starts), first, side="right") - 1
+    order = np.argsort(block_of, kind="stable")
+    cuts = np.searchsorted(block_of[order], np.arange(len(bounds) + 1))
+    lengths_all = (ptr[1:] - ptr[:-1]).astype(np.int64)
     out = []
-    for c0, c1 in bounds:
-        reads = np.nonzero((first >= c0) & (first < c1))[0]
-        lengths = (ptr[reads + 1] - ptr[reads]).astype(np.int64)
-        sel = np.concatenate([np.arange(ptr[r], ptr[r + 1]) for r in reads]) if reads.size else np.zeros(0, np.int64)
+    for b, (c0, c1) in enumerate(bounds):
+        reads = order[cuts[b]:cuts[b + 1]]
+        lengths = lengths_all[reads]
+        if reads.size and np.all(np.diff(reads) == 1):  # the usual case: a contiguous stretch of the sorted ReadSet
+            sel = slice(int(ptr[reads[0]]), int(ptr[reads[-1] + 1]))
+        else:
+            sel = np.concatenate([np.arange(ptr[r], ptr[r + 1]) for r in reads]) if reads.size else np.zeros(0, np.int64)
         sub_ptr = np.zeros(reads.size + 1, dtype=np.uint64)
         sub_ptr[1:] = np.cumsum(lengths)
         sub = ProblemArrays(sub_ptr, problem.var_position[sel], problem.var_allele[sel], problem.var_quality[sel],
@@ -86,6 +94,33 @@ def split_independent_blocks(problem: ProblemArrays) -> List[Tuple[ProblemArrays
                             problem.distrust_genotypes, n_variants=c1 - c0)
         out.append((sub, reads, (c0, c1)))
     return out
+
+
+def solve_blocks(problems: Sequence[ProblemArrays], device: int = 0, path=None, max_in_flight: int = 8,
+                 release: bool = True):
+    """Host-side work queue for one device: solves independent blocks with ``max_in_flight`` of them submitted
+    at any time, each on its own stream (``whamd_dptable_enqueue`` / ``_wait``), so that small blocks -- which
+    cannot fill 256 CUs on their own -- overlap.  Returns the solved tables in input order; with ``release`` their
+    device buffers and streams are freed as soon as the solution is on the host."""
+    from ._native import NativeTable
+
+    tables = []
+    pending = []
+    for sub in problems:
+        t = NativeTable(sub, device=device, path=path, solve=False)
+        t.enqueue()
+        tables.append(t)
+        pending.append(t)
+        if len(pending) >= max_in_flight:
+            done = pending.pop(0)
+            done.wait()
+            if release:
+                done.release_device()
+    for t in pending:
+        t.wait()
+        if release:
+            t.release_device()
+    return tables
 
 
 def merge_block_solutions(n_reads: int, n_individuals: int, blocks, solutions: Dict[int, dict]) -> dict:

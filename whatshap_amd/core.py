@@ -434,23 +434,55 @@ class PedigreeDPTable:
 
     ``PedigreeDPTable(readset, recombcost, pedigree, distrust_genotypes=False, positions=None)``;
     all the work happens in the constructor, as in the reference (src/pedigreedptable.cpp:36).
-    Extra keyword-only arguments: ``device`` (HIP device index) and ``path`` (solver variant, see
-    ``whamd_dptable_set_option``).
+    Extra keyword-only arguments: ``device`` (HIP device index), ``path`` (solver variant, see
+    ``whamd_dptable_set_option``) and ``split_blocks`` (default off): a table without trios is cut wherever no read
+    is active across a column boundary (exact, including tie-breaks -- whatshap_amd/blocks.py) and the independent
+    blocks go through the host-side work queue, ``max_in_flight`` at a time on their own streams.  Off by default
+    because one table already walks through such boundaries at full speed while every extra table costs ~4 ms of
+    allocation and stream set-up (scripts/gpu_multiblock.py: 200 blocks of coverage 15, 160k columns: 0.16 s as one
+    table, 1.0 s as 200 tables); the queue pays off for few, large blocks (bench.py --blocks-per-gpu).
     """
 
     def __init__(self, readset, recombcost, pedigree: Pedigree, distrust_genotypes: bool = False, positions=None,
-                 *, device: int = 0, path: Optional[str] = None):
+                 *, device: int = 0, path: Optional[str] = None, split_blocks: bool = False, max_in_flight: int = 8):
         self.pedigree = pedigree
         self._problem = problem_from_objects(readset, recombcost, pedigree, distrust_genotypes, positions)
-        self._table = _native.NativeTable(self._problem, device=device, path=path, solve=True)
+        self._tables: List[_native.NativeTable] = []
+        self._blocks = None
+        blocks = None
+        if split_blocks and self._problem.triple_ids.size == 0 and self._problem.n_individuals == 1:
+            from .blocks import split_independent_blocks
+
+            firsts = self._problem.var_position[self._problem.read_ptr[:-1][np.diff(self._problem.read_ptr) > 0].astype(np.int64)]
+            if np.any(np.diff(firsts.astype(np.int64)) < 0):  # the check the whole-table constructor would have made
+                raise RuntimeError("ColumnIterator: reads in ReadSet are not sorted.")
+            blocks = split_independent_blocks(self._problem)
+            if len(blocks) <= 1:
+                blocks = None
+        if blocks is None:
+            self._tables = [_native.NativeTable(self._problem, device=device, path=path, solve=True)]
+            return
+        self._blocks = blocks
+        from .blocks import solve_blocks
+
+        self._tables = solve_blocks([sub for sub, _, _ in blocks], device=device, path=path, max_in_flight=max_in_flight)
+
+    def _merged(self):
+        """(allele0, allele1, quality, transmission, sample ids, positions) of the whole table."""
+        parts = [t.super_reads() for t in self._tables]
+        positions = np.concatenate([t.positions() for t in self._tables]) if self._tables else np.zeros(0, np.uint32)
+        a0 = np.concatenate([p[0] for p in parts], axis=1)
+        a1 = np.concatenate([p[1] for p in parts], axis=1)
+        q = np.concatenate([p[2] for p in parts], axis=1)
+        tv = np.concatenate([p[3] for p in parts])
+        return a0, a1, q, tv, parts[0][4], positions
 
     def get_super_reads(self) -> Tuple[List[ReadSet], List[int]]:
         """Optimal-score haplotypes as one ReadSet of two superreads per individual, plus the
         transmission vector (core.pyx:381-404, src/pedigreedptable.cpp:344-388)."""
-        a0, a1, q, tv, sid = self._table.super_reads()
-        positions = self._table.positions()
+        a0, a1, q, tv, sid, positions = self._merged()
         results = []
-        for i in range(self._table.n_individuals):
+        for i in range(len(sid)):
             rs = ReadSet()
             for h, alleles in ((0, a0), (1, a1)):
                 read = Read(f"superread_{h}_{i}", -1, -1, int(sid[i]))
@@ -462,14 +494,30 @@ class PedigreeDPTable:
         return results, [int(t) for t in tv]
 
     def get_optimal_cost(self) -> int:
-        return self._table.optimal_score()
+        return sum(t.optimal_score() for t in self._tables)
 
     def get_optimal_partitioning(self) -> List[int]:
-        return [int(x) for x in self._table.partitioning()]
+        if self._blocks is None:
+            return [int(x) for x in self._tables[0].partitioning()]
+        out = [1] * self._problem.n_reads
+        for (_, reads, _), t in zip(self._blocks, self._tables):
+            for local, r in enumerate(reads):
+                out[int(r)] = int(t.partitioning()[local])
+        return out
 
     # not part of the reference API: raw backtrace and device measurements
     def get_index_path(self):
-        return self._table.index_path()
+        idx = np.concatenate([t.index_path()[0] for t in self._tables])
+        tv = np.concatenate([t.index_path()[1] for t in self._tables])
+        return idx, tv
 
     def get_stats(self) -> dict:
-        return self._table.stats()
+        stats = [t.stats() for t in self._tables]
+        out = dict(stats[0])
+        for s in stats[1:]:
+            for key in ("n_columns", "n_cells", "n_costs", "algorithmic_bytes", "forward_launches", "forward_ms",
+                        "backtrace_ms", "total_ms", "host_prepare_ms", "host_finish_ms"):
+                out[key] += s[key]
+            out["max_coverage"] = max(out["max_coverage"], s["max_coverage"])
+        out["blocks"] = len(stats)
+        return out

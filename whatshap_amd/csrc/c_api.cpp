@@ -113,6 +113,14 @@ whamd_status_t whamd_dptable_solve(whamd_dptable* t) {
 	return whamd_dptable_wait(t);
 }
 
+whamd_status_t whamd_dptable_release_device(whamd_dptable* t) {
+	if (!t) return fail(WHAMD_ERR_INVALID, "table is NULL");
+	if (t->in_flight) return fail(WHAMD_ERR_INVALID, "a solve is in flight: call whamd_dptable_wait first");
+	t->device.release_device();
+	t->uploaded = false;
+	return WHAMD_OK;
+}
+
 void whamd_dptable_destroy(whamd_dptable* t) { delete t; }
 
 uint64_t whamd_dptable_column_count(const whamd_dptable* t) { return t ? t->problem.n_cols : 0; }

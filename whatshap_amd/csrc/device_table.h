@@ -23,6 +23,8 @@ public:
 	// flight at once on one device), wait() blocks until the path has arrived and reads the event timings.
 	whamd_status_t enqueue(const Problem& p, Solution& s, std::string& msg);
 	whamd_status_t wait(const Problem& p, Solution& s, whamd_solve_stats& st, std::string& msg);
+	// Frees the device buffers, the stream and the events; the next upload() recreates them.
+	void release_device();
 	// Solver variant ("auto", "column", "column_keys", "resident"); takes effect at the next upload().
 	bool set_path(const std::string& path);
 	// Preferred log2 slice size of the resident path (tuning knob); takes effect at the next upload().

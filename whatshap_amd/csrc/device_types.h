@@ -44,6 +44,7 @@ struct DevProblem {
 	const ResBacktrace* res_bt;
 	const PedColumn* ped_cols;   // trio runs: descriptors parallel to res_cols
 	const PedTerm* ped_terms;    // trio runs: term pool
+	int32_t* ped_tables;    // [trio columns][PED_TABLE] lookup tables (computed at the start of each solve)
 	int32_t* res_tables;    // [resident columns][RES_TABLE] lookup tables (computed at the start of each solve)
 	unsigned long long* dbg;  // optional cycle-counter dump (WHAMD_DEBUG_TIMING)
 	uint32_t dbg_wg_off;      // word offset of the per-workgroup start/end stamps inside dbg

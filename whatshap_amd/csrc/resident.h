@@ -8,6 +8,7 @@
 // (the re-layout is the only time Pr touches HBM).  Columns that do not fit a run (last column, > 3 reads ending at
 // once, slices larger than LDS) are executed by the per-column kernels of dp_device.hip.
 #pragma once
+#include <cstddef>
 #include <cstdint>
 #include <vector>
 
@@ -63,19 +64,30 @@ constexpr int PED_T = 4, PED_NIND = 3;
 constexpr int PED_LMAX = 10;       // log2 of the largest slice (entries of T values)
 constexpr int PED_LKMAX = 12;      // local cell bits (two 6-bit lookup tables per individual)
 constexpr int PED_TABLE = PED_NIND * 128;  // table words per column
+// One cost term of a transmission value: c + sum_s sig_s * L_s, sig_s in {-1, 0, +1} as signed byte s of `sig`
+// (restates the plus / minus individual masks of CostTerm).  |L_s| < 2^23 is a planner guarantee (24-bit multiply-add).
+struct PedTerm { uint32_t c, sig; };
+constexpr int PED_REGTERMS = 4;    // terms per transmission value held in the descriptor (and in registers)
+constexpr int PED_LDSWORDS = 80;   // leading words of PedColumn a run copies into LDS
 struct PedColumn {
+	// ---- LDS part: every address below depends only on (column, lane), so one LDS latency covers all of it
 	uint32_t Lb, Lf, ebits, stage_off;   // stage_off: u32 words into the workgroup's record (one u32 per projection entry)
 	uint32_t lowmask, recomb, n_terms, term_off;  // term_off: index into the run's term pool
-	uint32_t epos[4], mL[4], mG[4];      // ending reads (ascending logical position): local position, tie-break masks
-	uint32_t PG, pad0[3];                // written by the kernel
+	uint32_t epos[4], mL[4];             // ending reads (ascending logical position): local position, tie-break mask
+	uint32_t PG, maxcnt, pad0[2];        // PG written by the kernel; maxcnt: most terms any transmission value has
 	uint32_t tptr[8];                    // [T + 1] term ranges per transmission value, relative to term_off
 	int32_t Sg[4];                       // per individual, written by the kernel
+	int32_t dE[RES_EMAX][4];             // delta of ending read q for individual s (non-zero for its own individual only)
+	uint32_t pad1[4];
+	PedTerm rterms[PED_T][PED_REGTERMS]; // first terms of every transmission value, padded with {INF, 0}
+	// ---- global only
+	uint32_t mG[4];                      // grid part of the tie-break masks
 	int32_t dgrid[PED_NIND][RES_GMAX];   // signed deltas of the grid reads, per individual (0 for reads of other individuals)
 	int32_t dloc[PED_NIND][PED_LKMAX];   // signed deltas of the local bits, per individual
-	uint32_t pad1[26];
+	uint32_t pad2[10];
 };
-static_assert(sizeof(PedColumn) == 512, "PedColumn must stay 128 words");
-struct PedTerm { uint32_t c, plus, minus; };
+static_assert(sizeof(PedColumn) == 640, "PedColumn must stay 160 words");
+static_assert(offsetof(PedColumn, mG) == PED_LDSWORDS * 4, "LDS part of PedColumn");
 
 // Passed to the kernel by value (kernel arguments live in SGPRs: no memory round trip before the first column).
 constexpr int RES_IOSEG = 6;       // runs per mask of the load / store layouts held in the kernel arguments

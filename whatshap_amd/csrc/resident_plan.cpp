@@ -1,6 +1,7 @@
 // resident_plan.cpp -- host planner of the forward pass: which columns run as resident segments (resident.h) and
 // which go through the per-column kernels; builds every descriptor the resident kernel and the backtrace need.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "resident.h"
@@ -58,6 +59,18 @@ void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, Reside
 			for (uint32_t j = 0; j < p.k[c]; ++j) last_col[col[j].read_id] = c;
 		}
 	}
+	std::vector<uint32_t> ped_abs;  // trio: max over individuals of sum |delta| per column (bound on |L_s|)
+	if (eligible && ped) {
+		ped_abs.assign(n, 0);
+		for (uint32_t cc = 0; cc < n; ++cc) {
+			const uint32_t kc = p.k[cc];
+			for (uint32_t smp = 0; smp < p.n_ind; ++smp) {
+				uint64_t sum = 0;
+				for (uint32_t j = 0; j < kc; ++j) sum += (uint64_t)std::llabs((long long)p.delta[(size_t)p.col_ptr[cc] * p.n_ind + (size_t)smp * kc + j]);
+				ped_abs[cc] = (uint32_t)std::max<uint64_t>(ped_abs[cc], std::min<uint64_t>(sum, 0xFFFFFFFFull));
+			}
+		}
+	}
 	// per run: which bits of the entering / exit logical index are grid reads (for the exchange layouts below)
 	std::vector<std::vector<uint8_t>> entry_grid, exit_grid;
 	uint32_t c = 0;
@@ -103,8 +116,9 @@ void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, Reside
 				run_max_l = std::max(run_max_l, std::max(Lb, Lf));
 				run_stage += ((1ull << Lf) + 1) / 2;  // one u32 per projection entry
 				run_terms += p.term_end(c1, p.T - 1) - p.term_begin(c1, 0);
-				const uint64_t lds_bytes = (uint64_t)(c1 - c + 1) * (128 + PED_TABLE) * 4 + run_terms * 12 + 2 * (16ull << run_max_l) + run_stage * 8;
+				const uint64_t lds_bytes = (uint64_t)(c1 - c + 1) * (PED_LDSWORDS + PED_TABLE) * 4 + run_terms * 8 + 2 * (16ull << run_max_l) + run_stage * 8 + 16;
 				if (lds_bytes > 150 * 1024) break;
+				if (ped_abs[c1] >= (1u << 23)) break;  // L_s must fit the 24-bit multiply-add of the term evaluation
 			} else {
 				if (Lb > (uint32_t)RES_LMAX || Lf > (uint32_t)RES_LMAX || Lk > 14) break;
 				run_max_l = std::max(run_max_l, std::max(Lb, Lf));
@@ -226,7 +240,25 @@ void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, Reside
 				const uint64_t tb = p.term_begin(cc, 0);
 				for (uint32_t t = 0; t <= p.T; ++t) pc.tptr[t] = (uint32_t)((t < p.T ? p.term_begin(cc, t) : p.term_end(cc, p.T - 1)) - tb);
 				pc.n_terms = pc.tptr[p.T];
-				for (uint64_t q = tb; q < tb + pc.n_terms; ++q) plan.ped_terms.push_back(PedTerm{p.terms[q].c, p.terms[q].plus, p.terms[q].minus});
+				for (uint32_t t = 0; t < p.T; ++t) {
+					pc.maxcnt = std::max(pc.maxcnt, pc.tptr[t + 1] - pc.tptr[t]);
+					for (uint32_t k = 0; k < (uint32_t)PED_REGTERMS; ++k) pc.rterms[t][k] = PedTerm{0xFFFFFFFFu, 0u};
+				}
+				for (uint32_t q = 0; q < rc.ebits; ++q)
+					for (uint32_t smp = 0; smp < p.n_ind; ++smp) pc.dE[q][smp] = pc.dloc[smp][rc.epos[q]];
+				for (uint64_t q = tb; q < tb + pc.n_terms; ++q) {
+					uint32_t sig = 0;
+					for (uint32_t smp = 0; smp < p.n_ind; ++smp) {
+						const int sg1 = (int)((p.terms[q].plus >> smp) & 1u) - (int)((p.terms[q].minus >> smp) & 1u);
+						sig |= ((uint32_t)sg1 & 0xFFu) << (8 * smp);
+					}
+					plan.ped_terms.push_back(PedTerm{p.terms[q].c, sig});
+					for (uint32_t t = 0; t < p.T; ++t) {
+						const uint64_t rel = q - tb;
+						if (rel >= pc.tptr[t] && rel < pc.tptr[t + 1] && rel - pc.tptr[t] < (uint64_t)PED_REGTERMS)
+							pc.rterms[t][rel - pc.tptr[t]] = PedTerm{p.terms[q].c, sig};
+					}
+				}
 				plan.ped_columns.resize(plan.columns.size() + 1);
 				plan.ped_columns.back() = pc;
 			} else {
