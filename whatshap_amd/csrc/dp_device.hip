@@ -265,6 +265,19 @@ __global__ __launch_bounds__(256) void column_finalize(DevProblem P, uint32_t c,
 // column chain contains no global-memory latency.
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// The by-value arguments of the run kernels span several 64-byte lines and the compiler fetches them with one scalar
+// load per use, waiting each time: ~3600 cycles (1.5 us) of serialized scalar-cache misses at the start of every run
+// (measured, scripts/gpu_timing_trio.py).  Touching every line with independent loads first costs one miss latency.
+template <int BYTES>
+__device__ __forceinline__ void touch_kernel_arguments() {
+	typedef const __attribute__((address_space(4))) uint32_t* karg_ptr;
+	const karg_ptr ka = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+	uint32_t acc = 0;
+#pragma unroll
+	for (int l = 0; l < (BYTES + 63) / 64; ++l) acc |= ka[l * 16];
+	asm volatile("" ::"s"(acc));
+}
+
 __device__ __forceinline__ uint32_t deposit_args(uint32_t v, const uint32_t* segs, uint32_t nseg) {
 	uint32_t x = 0;
 	for (uint32_t i = 0; i < nseg; ++i) {
@@ -408,9 +421,11 @@ template <bool DBG>
 __global__ __launch_bounds__(1024) void resident_segment(DevProblem P, ResSegment sg, const uint32_t* __restrict__ prev,
                                                           uint32_t* __restrict__ cur) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-	const uint32_t w = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
 	const unsigned long long t_begin = DBG ? __builtin_readcyclecounter() : 0ull;
+	touch_kernel_arguments<sizeof(DevProblem) + sizeof(ResSegment) + 16>();
+	const uint32_t w = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
 	const unsigned long long rt_begin = DBG ? wall_clock64() : 0ull;
+	unsigned long long t_args = 0, t_first = 0;
 	uint32_t* ldsc = smem;                                             // ncols * 64 words: column descriptors
 	int32_t* tab = reinterpret_cast<int32_t*>(smem + sg.ncols * 64);   // ncols * 256 words: lookup tables
 	uint32_t* bufP = smem + sg.ncols * (64 + RES_TABLE);
@@ -425,6 +440,7 @@ __global__ __launch_bounds__(1024) void resident_segment(DevProblem P, ResSegmen
 		uint4* lt = reinterpret_cast<uint4*>(tab);
 		const uint32_t ndesc = sg.ncols * 16, ntab = sg.ncols * (RES_TABLE / 4), nslice = sg.has_prev ? (1u << sg.Lb0) : 0u;
 		const uint32_t wpart = deposit_args(w, sg.in_grid, sg.n_in_grid);
+		if (DBG) t_args = __builtin_readcyclecounter() + (wpart & 0u);
 		uint4 vd[2], vt[4];
 		uint32_t vs[4];
 #pragma unroll
@@ -438,6 +454,7 @@ __global__ __launch_bounds__(1024) void resident_segment(DevProblem P, ResSegmen
 		}
 #pragma unroll
 		for (int u = 0; u < 2; ++u) { const uint32_t i = u * NT + tid; if (i < ndesc) lc[i] = vd[u]; }
+		if (DBG) t_first = __builtin_readcyclecounter();
 #pragma unroll
 		for (int u = 0; u < 4; ++u) { const uint32_t i = u * NT + tid; if (i < ntab) lt[i] = vt[u]; }
 #pragma unroll
@@ -448,6 +465,7 @@ __global__ __launch_bounds__(1024) void resident_segment(DevProblem P, ResSegmen
 		for (uint32_t l = 4 * NT + tid; l < nslice; l += NT) bufP[l] = prev[wpart | deposit_args(l, sg.in_local, sg.n_in_local)];
 		if (!sg.has_prev && tid == 0) bufP[0] = 0;
 	}
+	const unsigned long long t_loaded = DBG ? __builtin_readcyclecounter() : 0ull;
 	__syncthreads();
 	// per-column scalars that depend on the workgroup index: 16 lanes per column (one per grid read), xor-shuffle reduce
 	for (uint32_t ci0 = 0; ci0 < sg.ncols; ci0 += NT / 16) {
@@ -579,7 +597,10 @@ __global__ __launch_bounds__(1024) void resident_segment(DevProblem P, ResSegmen
 		d[1] = t_cols - t_ready;
 		d[2] = __builtin_readcyclecounter() - t_cols;
 		d[3] = sg.ncols;
+		if (P.dbg_flags & 4u) { d[4] = (t_loaded - t_begin) * nsteps_dbg; d[5] = (t_args - t_begin) * nsteps_dbg; d[6] = (t_first - t_begin) * nsteps_dbg; d[7] = nsteps_dbg; }
+		else {
 		d[4] = acc_a; d[5] = acc_b; d[6] = acc_c; d[7] = nsteps_dbg;
+		}
 	}
 }
 
@@ -729,8 +750,9 @@ template <bool DBG>
 __global__ __launch_bounds__(1024) void resident_segment_ped(DevProblem P, ResSegment sg, const uint32_t* __restrict__ prev,
                                                               uint32_t* __restrict__ cur) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-	const uint32_t w = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
 	const unsigned long long t_begin = DBG ? __builtin_readcyclecounter() : 0ull;
+	touch_kernel_arguments<sizeof(DevProblem) + sizeof(ResSegment) + 16>();
+	const uint32_t w = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
 	uint32_t* ldsc = smem;                                                           // ncols * PED_LDSWORDS
 	int32_t* tab = reinterpret_cast<int32_t*>(ldsc + sg.ncols * PED_LDSWORDS);       // ncols * PED_TABLE words
 	uint2* terms = reinterpret_cast<uint2*>(tab + sg.ncols * PED_TABLE);             // n_terms * 2 words
@@ -740,14 +762,18 @@ __global__ __launch_bounds__(1024) void resident_segment_ped(DevProblem P, ResSe
 	// per-column scalars that depend on the workgroup index, straight from the global descriptors: 64 lanes per column
 	// = 16 lanes per individual (one per grid read) + 16 lanes for the tie-break parities of the grid part
 	unsigned long long t_args = 0, t_first = 0;
-	int32_t part[2] = {0, 0};
+	// per-column scalars that depend on the workgroup index, straight from the global descriptors: 64 lanes per column
+	// = 16 lanes per individual (one per grid read) + 16 lanes for the tie-break parities of the grid part.  The raw
+	// words are loaded here, in the same batch as everything else, and combined after the first barrier.
+	uint32_t raw[2] = {0, 0};
+	const uint32_t gs = (tid >> 4) & 3u, gq = tid & 15u;
+	const bool graw = gs < (uint32_t)PED_NIND ? (gq < sg.g && ((w >> gq) & 1u)) : gq < (uint32_t)RES_EMAX;
 #pragma unroll
 	for (int u = 0; u < 2; ++u) {
-		const uint32_t ci = u * (NT / 64) + (tid >> 6), s = (tid >> 4) & 3u, q = tid & 15u;
-		if (ci < sg.ncols) {
-			const PedColumn& gcol = P.ped_cols[sg.col_off + ci];
-			if (s < (uint32_t)PED_NIND) { if (q < sg.g && ((w >> q) & 1u)) part[u] = gcol.dgrid[s][q]; }
-			else if (q < (uint32_t)RES_EMAX) part[u] = (int32_t)(((uint32_t)__popc(w & gcol.mG[q]) & 1u) << q);
+		const uint32_t ci = u * (NT / 64) + (tid >> 6);
+		if (ci < sg.ncols && graw) {
+			const uint32_t* gw = reinterpret_cast<const uint32_t*>(P.ped_cols + sg.col_off + ci);
+			raw[u] = gw[gs < (uint32_t)PED_NIND ? offsetof(PedColumn, dgrid) / 4 + gs * RES_GMAX + gq : offsetof(PedColumn, mG) / 4 + gq];
 		}
 	}
 	{
@@ -795,8 +821,8 @@ __global__ __launch_bounds__(1024) void resident_segment_ped(DevProblem P, ResSe
 	__syncthreads();
 #pragma unroll
 	for (int u = 0; u < 2; ++u) {
-		const uint32_t ci = u * (NT / 64) + (tid >> 6), s = (tid >> 4) & 3u, q = tid & 15u;
-		int32_t v = part[u];
+		const uint32_t ci = u * (NT / 64) + (tid >> 6), s = gs, q = gq;
+		int32_t v = s < (uint32_t)PED_NIND ? (int32_t)raw[u] : (int32_t)((graw ? (uint32_t)__popc(w & raw[u]) & 1u : 0u) << q);
 		v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
 		if (ci < sg.ncols && q == 0) {
 			PedColumn* pc = reinterpret_cast<PedColumn*>(ldsc + ci * PED_LDSWORDS);
@@ -1524,8 +1550,8 @@ whamd_status_t DeviceTable::wait(const Problem& p, Solution& s, whamd_solve_stat
 		HIP_TRY(hipMemcpy(d.data(), m.dp.dbg, d.size() * 8, hipMemcpyDeviceToHost));
 		unsigned long long a = 0, b = 0, c2 = 0, cols = 0, p1 = 0, p2 = 0, p3 = 0, ns = 0;
 		for (size_t i = 0; i < m.plan.segments.size(); ++i) { a += d[8 * i]; b += d[8 * i + 1]; c2 += d[8 * i + 2]; cols += d[8 * i + 3]; p1 += d[8 * i + 4]; p2 += d[8 * i + 5]; p3 += d[8 * i + 6]; ns += d[8 * i + 7]; }
-		if (!m.plan.ped_columns.empty())
-			fprintf(stderr, "[whamd timing] trio prologue (wave 0 of workgroup 0), cycles after the first instruction: kernel arguments usable %.0f, first loaded data %.0f, everything staged %.0f\n",
+		if (!m.plan.ped_columns.empty() || (m.dp.dbg_flags & 4u))
+			fprintf(stderr, "[whamd timing] run prologue (wave 0 of workgroup 0), cycles after the first instruction: kernel arguments usable %.0f, first loaded data %.0f, everything staged %.0f\n",
 			        (double)p2 / std::max<unsigned long long>(ns, 1), (double)p3 / std::max<unsigned long long>(ns, 1), (double)p1 / std::max<unsigned long long>(ns, 1));
 		else
 		fprintf(stderr, "[whamd timing] per barrier step (wave 0 of workgroup 0, %.1f steps per run): hot words %.0f, evaluate %.0f, barrier %.0f cycles\n",
