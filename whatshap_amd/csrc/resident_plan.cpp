@@ -10,9 +10,26 @@ namespace whamd {
 
 namespace {
 
+// Fixed-capacity vector on the stack (the planner builds a handful of tiny lists per column: heap allocations were
+// half of its time).  Elements beyond the capacity are counted but dropped; every user checks size() against a limit
+// far below the capacity.
+template <class T, int N>
+struct Small {
+	T v[N];
+	uint32_t n = 0;
+	void push_back(const T& x) { if (n < (uint32_t)N) v[n] = x; ++n; }
+	size_t size() const { return n; }
+	const T* begin() const { return v; }
+	const T* end() const { return v + std::min<uint32_t>(n, (uint32_t)N); }
+	T& operator[](size_t i) { return v[i]; }
+	const T& operator[](size_t i) const { return v[i]; }
+};
+using Runs = Small<uint32_t, 40>;
+using Pairs = Small<std::pair<uint32_t, uint32_t>, 40>;
+
 // Runs of set bits of `mask` as (compact position | mask position << 8 | length << 16); `swap` exchanges the roles
 // (deposit: compact -> mask position; extract: mask position -> compact).
-uint16_t append_runs(uint32_t mask, bool extract, std::vector<uint32_t>& out) {
+uint16_t append_runs(uint32_t mask, bool extract, Runs& out) {
 	uint32_t compact = 0;
 	uint16_t count = 0;
 	for (uint32_t bit = 0; bit < 32;) {
@@ -30,8 +47,8 @@ uint16_t append_runs(uint32_t mask, bool extract, std::vector<uint32_t>& out) {
 
 // Packed runs (source position | destination position << 8 | length << 16) for an arbitrary bit move given as
 // (source, destination) pairs sorted by source.
-std::vector<uint32_t> runs_from_pairs(const std::vector<std::pair<uint32_t, uint32_t>>& pairs) {
-	std::vector<uint32_t> out;
+Runs runs_from_pairs(const Pairs& pairs) {
+	Runs out;
 	for (size_t i = 0; i < pairs.size();) {
 		size_t j = i + 1;
 		while (j < pairs.size() && pairs[j].first == pairs[j - 1].first + 1 && pairs[j].second == pairs[j - 1].second + 1) ++j;
@@ -153,7 +170,7 @@ void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, Reside
 			const uint32_t lm = (b0 >= 32 ? 0xFFFFFFFFu : ((1u << b0) - 1u)) & ~gm;
 			run_entry_grid.assign(b0, 0);
 			for (uint32_t j = 0; j < b0; ++j) run_entry_grid[j] = (gm >> j) & 1u;
-			std::vector<uint32_t> rg, rl;
+			Runs rg, rl;
 			seg.n_in_grid = append_runs(gm, false, rg);
 			seg.n_in_local = append_runs(lm, false, rl);
 			if (rg.size() > (size_t)RES_IOSEG || rl.size() > (size_t)RES_IOSEG) {  // exotic layout: leave this column to the column kernels
@@ -184,7 +201,8 @@ void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, Reside
 			}
 			// logical -> (grid slot | local bit)
 			uint32_t li = 0, gi = 0;
-			std::vector<int> local_of(kc, -1), grid_of(kc, -1);
+			int local_of[40], grid_of[40];
+			for (uint32_t j = 0; j < kc && j < 40; ++j) local_of[j] = grid_of[j] = -1;
 			for (uint32_t j = 0; j < kc; ++j) {
 				if (is_grid(col[j].read_id)) {
 					grid_of[j] = (int)gi;
@@ -275,11 +293,11 @@ void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, Reside
 			}
 			const uint32_t lmf = (fi >= 32 ? 0xFFFFFFFFu : ((1u << fi) - 1u)) & ~gmf;
 			{
-				std::vector<std::pair<uint32_t, uint32_t>> gp, lp;
+				Pairs gp, lp;
 				for (uint32_t j = 0; j < kc; ++j) {
 					if (grid_of[j] >= 0) gp.push_back({(uint32_t)grid_of[j], j}); else lp.push_back({(uint32_t)local_of[j], j});
 				}
-				const std::vector<uint32_t> gr = runs_from_pairs(gp), lr = runs_from_pairs(lp);
+				const Runs gr = runs_from_pairs(gp), lr = runs_from_pairs(lp);
 				if (gr.size() > (size_t)RES_BT_GRUNS || lr.size() > (size_t)RES_BT_LRUNS) bt_ok = false;
 				else {
 					rb.n_g = (uint32_t)gr.size();
@@ -297,14 +315,14 @@ void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, Reside
 			if (cc + 1 == c1) {  // store layout of the exit state
 				run_exit_grid.assign(fi, 0);
 				for (uint32_t j = 0; j < fi; ++j) run_exit_grid[j] = (gmf >> j) & 1u;
-				std::vector<uint32_t> rg, rl;
+				Runs rg, rl;
 				seg.n_out_grid = append_runs(gmf, false, rg);
 				seg.n_out_local = append_runs(lmf, false, rl);
 				out_ok = rg.size() <= (size_t)RES_IOSEG && rl.size() <= (size_t)RES_IOSEG;
 				if (out_ok) {
 					std::copy(rg.begin(), rg.end(), seg.out_grid);
 					std::copy(rl.begin(), rl.end(), seg.out_local);
-					std::vector<uint32_t> we, le;
+					Runs we, le;
 					seg.n_wext = append_runs(gmf, true, we);
 					std::copy(we.begin(), we.end(), seg.wext);
 					seg.n_lext = append_runs(lmf, true, le);
@@ -369,18 +387,18 @@ void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, Reside
 		const std::vector<uint8_t>& gb = entry_grid[plan.steps[si + 1].index];
 		if (ga.size() != gb.size()) continue;
 		const uint32_t f = (uint32_t)ga.size();
-		std::vector<uint32_t> pi(f);
+		uint32_t pi[40] = {0};
 		uint32_t next = 0;
 		for (uint32_t j = 0; j < f; ++j) if (!ga[j] && !gb[j]) pi[j] = next++;
 		for (uint32_t j = 0; j < f; ++j) if (ga[j] && !gb[j]) pi[j] = next++;
 		for (uint32_t j = 0; j < f; ++j) if (gb[j]) pi[j] = next++;
-		std::vector<std::pair<uint32_t, uint32_t>> aw, al, bw, bl;
+		Pairs aw, al, bw, bl;
 		uint32_t sa = 0, la = 0, sb = 0, lb = 0;
 		for (uint32_t j = 0; j < f; ++j) {
 			if (ga[j]) aw.push_back({sa++, pi[j]}); else al.push_back({la++, pi[j]});
 			if (gb[j]) bw.push_back({sb++, pi[j]}); else bl.push_back({lb++, pi[j]});
 		}
-		const std::vector<uint32_t> raw = runs_from_pairs(aw), ral = runs_from_pairs(al), rbw = runs_from_pairs(bw), rbl = runs_from_pairs(bl);
+		const Runs raw = runs_from_pairs(aw), ral = runs_from_pairs(al), rbw = runs_from_pairs(bw), rbl = runs_from_pairs(bl);
 		if (raw.size() > (size_t)RES_IOSEG || ral.size() > (size_t)RES_IOSEG || rbw.size() > (size_t)RES_IOSEG || rbl.size() > (size_t)RES_IOSEG) continue;
 		A.n_out_grid = (uint16_t)raw.size();
 		A.n_out_local = (uint16_t)ral.size();
