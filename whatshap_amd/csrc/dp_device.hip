@@ -927,7 +927,7 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 		for (uint32_t i = lane; i < hdr[32 + 2] * 32; i += NT) recs0[RES_MAXCOLS * 32 + i] = g1[i];
 	}
 	__syncthreads();
-	unsigned long long bt_load = 0, bt_walk = 0, bt_runs = 0;
+	unsigned long long bt_load = 0, bt_walk = 0, bt_runs = 0, bt_a = 0, bt_b = 0, bt_c = 0;
 	for (uint32_t ui = 1; ui < n_units; ++ui) {
 		const unsigned long long tb0 = P.dbg ? __builtin_readcyclecounter() : 0ull;
 		const uint32_t* h = hdr + (ui & 3u) * 32;
@@ -1016,58 +1016,92 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 					const uint32_t r = h[18 + i];
 					l |= ((yexit >> (r & 31u)) & ((1u << ((r >> 16) & 31u)) - 1u)) << ((r >> 8) & 31u);
 				}
-				// sequential part, in local index space: only columns where a read ends touch the record
-				uint32_t tcur = tprev;
-				uint4 rn = *reinterpret_cast<const uint4*>(recs + (ncols - 1) * 32);
-				uint4 rm = *reinterpret_cast<const uint4*>(recs + (ncols - 1) * 32 + 4);
-				for (uint32_t ci = ncols; ci-- > 0;) {
-					const uint4 r0 = rn, r1 = rm;  // Lf, ebits, layout, stage_off | nwords, epos0, epos1, epos2
-					if (ci > 0) {
-						rn = *reinterpret_cast<const uint4*>(recs + (ci - 1) * 32);
-						rm = *reinterpret_cast<const uint4*>(recs + (ci - 1) * 32 + 4);
+				// sequential part, in local index space: only columns where a read ends touch the record.  Lanes keep the
+				// per-column parameters in registers; the loop fetches them with v_readlane (off the dependent chain), so the
+				// chain per visited column is: mask, record byte from LDS, bit insert.
+				const unsigned long long tw0 = P.dbg ? __builtin_readcyclecounter() + (l & 0u) : 0ull;
+				const uint32_t n_active = h[11] & 0xFFFFu, simple = h[11] >> 16;
+				const uint32_t* rmine = recs + (lane < ncols ? lane : 0u) * 32;
+				uint32_t tcur = tprev, mycell = 0, myts = 0;
+				if (simple) {
+					// single individual, every record one byte per thread: the chain visits only the columns in which a read ends
+					// (ResBacktrace kpos / src / cmask / kcol); lane k holds the parameters of chain position k
+					const uint32_t kc = rmine[31] < ncols ? rmine[31] : 0u;
+					const uint32_t* rk = recs + kc * 32;
+					const uint32_t c_cmask = rk[30], c_soff = rk[3] * 8u, c_e0 = rk[5];
+					const uint32_t my_kpos = rmine[28], my_src = rmine[29], my_cmask = rmine[30];
+					const uint8_t* stage8 = reinterpret_cast<const uint8_t*>(stage);
+					const uint32_t l_exit = l;
+					for (uint32_t k = 0; k < n_active; ++k) {
+						const uint32_t s_cmask = __builtin_amdgcn_readlane(c_cmask, k), s_soff = __builtin_amdgcn_readlane(c_soff, k),
+						               s_e0 = __builtin_amdgcn_readlane(c_e0, k);
+						const uint32_t lout = l & s_cmask;
+						const uint32_t byte = stage8[s_soff + (lout >> 2)];
+						const uint32_t cell = insert_zero(lout, s_e0) | (((byte >> (lout & 3u)) & 1u) << s_e0);
+						if (my_kpos == k) mycell = cell;
+						l = cell;
 					}
-					const uint32_t lout = l & ((1u << r0.x) - 1u);
-					uint32_t cell = lout;
-					if (r0.z == 2u) {  // trio: one u32 per entry, field of the current transmission value: ending-read bits | argj << 3
-						const uint32_t fld = reinterpret_cast<const uint8_t*>(stage + r0.w)[lout * 4u + tcur] & 31u;
-						const uint32_t epos[3] = {r1.y, r1.z, r1.w};
-						uint32_t bits = 0;
-#pragma unroll
-						for (int q = 0; q < 3; ++q) {
-							if ((uint32_t)q < r0.y) {
-								cell = insert_zero(cell, epos[q]);
-								bits |= ((fld >> q) & 1u) << epos[q];
-							}
-						}
-						cell |= bits;
-						if (lane == 0) tsarr[ci] = tcur;
-						tcur = fld >> 3;
-					} else if (r0.y) {
-						if (r0.z) {  // one byte per thread: bit (lout & 3) of byte lout >> 2
-							const uint32_t byte = reinterpret_cast<const uint8_t*>(stage + r0.w)[lout >> 2];
-							cell = insert_zero(lout, r1.y) | (((byte >> (lout & 3u)) & 1u) << r1.y);
-						} else {     // ballot planes, up to 3 ending reads (ascending positions)
-							const uint32_t epos[3] = {r1.y, r1.z, r1.w};
-							uint32_t bits = 0;
-#pragma unroll
-							for (int q = 0; q < 3; ++q) {
-								if ((uint32_t)q < r0.y) {
-									cell = insert_zero(cell, epos[q]);
-									const unsigned long long word = stage[r0.w + q * r1.x + (lout >> 6)];
-									bits |= (uint32_t)((word >> (lout & 63u)) & 1ull) << epos[q];
+					// columns without an ending read: the cell of the next active column above (or the exit index), masked
+					const uint32_t from = __shfl(mycell, my_src == RES_BT_NONE ? 0u : my_src);
+					if (my_kpos == RES_BT_NONE) mycell = (my_src == RES_BT_NONE ? l_exit : from) & my_cmask;
+				} else {
+					const uint4 q0 = *reinterpret_cast<const uint4*>(rmine);      // Lf, ebits, layout, stage_off
+					const uint4 q1 = *reinterpret_cast<const uint4*>(rmine + 4);  // nwords, epos0, epos1, epos2
+					const uint32_t p_mask = (1u << q0.x) - 1u, p_eb = q0.y | (q0.z << 8), p_soff = q0.w * 8u, p_e0 = q1.y, p_e1 = q1.z, p_e2 = q1.w, p_nw = q1.x;
+					const uint8_t* stage8 = reinterpret_cast<const uint8_t*>(stage);
+					for (uint32_t ci = ncols; ci-- > 0;) {
+						const uint32_t s_mask = __builtin_amdgcn_readlane(p_mask, ci), s_eb = __builtin_amdgcn_readlane(p_eb, ci);
+						const uint32_t lout = l & s_mask;
+						uint32_t cell = lout;
+						const uint32_t eb = s_eb & 255u, layout = s_eb >> 8;
+						if (layout == 2u) {  // trio: one byte per (entry, transmission value): ending-read bits | argj << 3
+							const uint32_t s_soff = __builtin_amdgcn_readlane(p_soff, ci);
+							const uint32_t fld = stage8[s_soff + lout * 4u + tcur] & 31u;
+							if (eb) {
+								const uint32_t epos[3] = {(uint32_t)__builtin_amdgcn_readlane(p_e0, ci), (uint32_t)__builtin_amdgcn_readlane(p_e1, ci),
+								                          (uint32_t)__builtin_amdgcn_readlane(p_e2, ci)};
+								uint32_t bits = 0;
+	#pragma unroll
+								for (int q = 0; q < 3; ++q) {
+									if ((uint32_t)q < eb) {
+										cell = insert_zero(cell, epos[q]);
+										bits |= ((fld >> q) & 1u) << epos[q];
+									}
 								}
+								cell |= bits;
 							}
-							cell |= bits;
+							if (lane == ci) myts = tcur;
+							tcur = fld >> 3;
+						} else if (eb) {
+							const uint32_t s_soff = __builtin_amdgcn_readlane(p_soff, ci), s_e0 = __builtin_amdgcn_readlane(p_e0, ci);
+							if (layout == 1u) {  // one byte per thread: bit (lout & 3) of byte lout >> 2
+								const uint32_t byte = stage8[s_soff + (lout >> 2)];
+								cell = insert_zero(lout, s_e0) | (((byte >> (lout & 3u)) & 1u) << s_e0);
+							} else {             // ballot planes, up to 3 ending reads (ascending positions)
+								const uint32_t epos[3] = {s_e0, (uint32_t)__builtin_amdgcn_readlane(p_e1, ci), (uint32_t)__builtin_amdgcn_readlane(p_e2, ci)};
+								const uint32_t s_nw = __builtin_amdgcn_readlane(p_nw, ci);
+								uint32_t bits = 0;
+	#pragma unroll
+								for (int q = 0; q < 3; ++q) {
+									if ((uint32_t)q < eb) {
+										cell = insert_zero(cell, epos[q]);
+										const unsigned long long word = stage[(s_soff >> 3) + q * s_nw + (lout >> 6)];
+										bits |= (uint32_t)((word >> (lout & 63u)) & 1ull) << epos[q];
+									}
+								}
+								cell |= bits;
+							}
 						}
+						if (lane == ci) mycell = cell;
+						l = cell;
 					}
-					if (lane == 0) cells[ci] = cell;
-					l = cell;
 				}
+				const unsigned long long tw1 = P.dbg ? __builtin_readcyclecounter() + (l & 0u) : 0ull;
 				// logical indices, one lane per column
 				uint32_t xl = 0;
 				if (lane < ncols) {
 					const uint32_t* rb = recs + lane * 32;
-					const uint32_t cell = cells[lane];
+					const uint32_t cell = mycell;
 					const uint32_t ng = rb[8], nl = rb[9];
 					for (uint32_t i = 0; i < ng; ++i) {
 						const uint32_t r = rb[10 + i];
@@ -1078,9 +1112,10 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 						xl |= ((cell >> (r & 31u)) & ((1u << ((r >> 16) & 31u)) - 1u)) << ((r >> 8) & 31u);
 					}
 					path_index[c0 + lane] = xl;
-					path_trans[c0 + lane] = rb[2] == 2u ? tsarr[lane] : 0u;
+					path_trans[c0 + lane] = rb[2] == 2u ? myts : 0u;
 				}
 				if (lane == 0) { xshare[0] = xl; xshare[1] = tcur; }
+				if (P.dbg) { const unsigned long long tw2 = __builtin_readcyclecounter() + (xl & 0u); bt_a += tw0 - tb1; bt_b += tw1 - tw0; bt_c += tw2 - tw1; }
 			}
 			__syncthreads();
 			x = xshare[0];
@@ -1090,7 +1125,7 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 	}
 	if (P.dbg && lane == 0) {
 		unsigned long long* d = P.dbg + P.dbg_wg_off + 4 * 512 * 2;
-		d[0] = bt_load; d[1] = bt_walk; d[2] = bt_runs;
+		d[0] = bt_load; d[1] = bt_walk; d[2] = bt_runs; d[3] = bt_a; d[4] = bt_b; d[5] = bt_c;
 	}
 }
 
@@ -1381,6 +1416,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 				u.c0 = sgm.c0; u.ncols = sgm.ncols; u.col_off = sgm.col_off; u.g = sgm.g; u.Lf_last = sgm.Lf_last;
 				u.stage_words = sgm.stage_words; u.n_wext = sgm.n_wext; u.bt_lo = sgm.bt_lo; u.bt_hi = sgm.bt_hi;
 				u.n_lext = sgm.n_lext;
+				u.pad0 = (uint32_t)sgm.bt_active | ((uint32_t)sgm.bt_simple << 16);
 				std::copy(sgm.wext, sgm.wext + RES_IOSEG, u.wext);
 				std::copy(sgm.lext, sgm.lext + RES_BT_LRUNS, u.lext);
 			}
@@ -1557,10 +1593,10 @@ whamd_status_t DeviceTable::wait(const Problem& p, Solution& s, whamd_solve_stat
 		fprintf(stderr, "[whamd timing] per barrier step (wave 0 of workgroup 0, %.1f steps per run): hot words %.0f, evaluate %.0f, barrier %.0f cycles\n",
 		        (double)ns / m.plan.segments.size(), (double)p1 / std::max<unsigned long long>(ns, 1), (double)p2 / std::max<unsigned long long>(ns, 1), (double)p3 / std::max<unsigned long long>(ns, 1));
 		{
-			unsigned long long b3[3] = {0, 0, 0};
+			unsigned long long b3[6] = {0, 0, 0, 0, 0, 0};
 			HIP_TRY(hipMemcpy(b3, m.dp.dbg + m.dp.dbg_wg_off + 4 * 512 * 2, sizeof b3, hipMemcpyDeviceToHost));
-			if (b3[2]) fprintf(stderr, "[whamd timing] backtrace per run: record load + prefetch %.0f cycles, walk + hand-over %.0f cycles (%llu runs)\n",
-			                   (double)b3[0] / b3[2], (double)b3[1] / b3[2], b3[2]);
+			if (b3[2]) fprintf(stderr, "[whamd timing] backtrace per run: record load + prefetch %.0f cycles, walk + hand-over %.0f cycles (%llu runs); of the latter: local exit index %.0f, chain %.0f, logical indices + stores %.0f\n",
+			                   (double)b3[0] / b3[2], (double)b3[1] / b3[2], b3[2], (double)b3[3] / b3[2], (double)b3[4] / b3[2], (double)b3[5] / b3[2]);
 		}
 		if (m.plan.segments.size() > 104) {
 			std::vector<unsigned long long> wg(4 * 512 * 2);

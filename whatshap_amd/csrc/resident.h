@@ -95,6 +95,7 @@ struct ResSegment {
 	uint32_t c0, ncols, g, col_off;
 	uint32_t Lb0, Lf_last, has_prev, threads;
 	uint32_t max_l, pad;
+	uint16_t bt_active, bt_simple;  // backtrace chain: columns in which a read ends; 1 if all of them use one-byte-per-thread records
 	uint32_t kind;         // 0: single individual (resident_segment), 1: trio (resident_segment_ped)
 	uint32_t term_off, n_terms;  // trio: this run's slice of the term pool
 	uint32_t stage_words;  // ballot words (u64) one workgroup produces in this run
@@ -122,8 +123,15 @@ struct ResBacktrace {
 	uint32_t n_g, n_l;                      // runs in use
 	uint32_t gruns[RES_BT_GRUNS];           // workgroup-index bits -> logical positions (source | destination << 8 | length << 16)
 	uint32_t lruns[RES_BT_LRUNS];           // local cell bits      -> logical positions
-	uint32_t pad[4];
+	// The sequential chain visits only the columns in which a read ends ("active", in descending column order); a
+	// column without an ending read is derived afterwards: cell = (cell of the next active column above it, or the
+	// run's exit index) & cmask.
+	uint32_t kpos;                          // position of this column in the chain, RES_BT_NONE if no read ends here
+	uint32_t src;                           // column (in the run) of the next active column above, RES_BT_NONE: the exit index
+	uint32_t cmask;                         // AND of (2^Lf - 1) from this column up to (excluding) column `src`
+	uint32_t kcol;                          // record k: column (in the run) of chain position k
 };
+constexpr uint32_t RES_BT_NONE = 0xFFFFFFFFu;
 static_assert(sizeof(ResBacktrace) == 128, "ResBacktrace must stay 32 words");
 
 // Backtrace unit list (reverse processing order): what the backtrace needs to know about a step without chasing
@@ -133,7 +141,7 @@ struct BtUnit {
 	uint32_t c0, ncols;    // first column / number of columns
 	uint32_t col_off;      // run: index of its first record in the ResBacktrace array
 	uint32_t g, Lf_last, stage_words, n_wext;
-	uint32_t bt_lo, bt_hi, n_lext, pad0;
+	uint32_t bt_lo, bt_hi, n_lext, pad0;   // run: pad0 = active columns | simple << 16 (ResSegment bt_active / bt_simple)
 	uint32_t wext[RES_IOSEG];  // logical exit index -> workgroup index
 	uint32_t lext[RES_BT_LRUNS];  // logical exit index -> local exit index
 	uint32_t pad1[4];

@@ -367,6 +367,28 @@ void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, Reside
 		seg.n_terms = (uint32_t)plan.ped_terms.size() - seg.term_off;
 		seg.max_l = max_l;
 		seg.stage_words = stage_words;
+		{   // backtrace chain of the run (resident.h ResBacktrace)
+			ResBacktrace* rb = plan.backtrace.data() + columns_mark;
+			const uint32_t nc = seg.ncols;
+			uint32_t k = 0, src = RES_BT_NONE, cm = 0xFFFFFFFFu;
+			bool simple = !ped;  // trio records carry the transmission argmin on every column: general walk
+			for (uint32_t ci = nc; ci-- > 0;) {
+				cm &= (1u << rb[ci].Lf) - 1u;
+				rb[ci].src = src;
+				rb[ci].cmask = cm;
+				rb[ci].kpos = RES_BT_NONE;
+				if (rb[ci].ebits) {
+					rb[ci].kpos = k;
+					rb[k].kcol = ci;
+					++k;
+					src = ci;
+					cm = 0xFFFFFFFFu;
+					simple = simple && rb[ci].layout == 1u && rb[ci].ebits == 1u;
+				}
+			}
+			seg.bt_active = (uint16_t)k;
+			seg.bt_simple = simple ? 1 : 0;
+		}
 
 		plan.steps.push_back(Step{1, (uint32_t)plan.segments.size()});
 		plan.segments.push_back(seg);
