@@ -22,31 +22,46 @@ constexpr int RES_GMAX = 10;       // log2 of the largest grid (workgroups) of o
 constexpr int RES_MAXCOLS = 48;    // columns per run (bounds the LDS lookup tables)
 constexpr int RES_TABLE = 256;     // per column: two 128-entry tables (low / high 7 local bits)
 
-// Self-contained descriptor of one resident column (256 B); a run's descriptors are copied to LDS at kernel start
-// so that no per-column global (HBM-latency) load sits on the sequential column chain.  The first 24 words are the
-// "hot" part every lane reads as LDS broadcasts into vector registers once per column (six 16-byte reads) -- the CU has
-// ONE scalar ALU shared by all waves, so per-column scalar work replicated per wave is what must be avoided.
-// Sg / PG are filled in per workgroup by the kernel.
+// Self-contained descriptor of one resident column (320 B); a run copies the leading RES_LDSWORDS of its descriptors
+// to LDS at kernel start so that no per-column global (HBM-latency) load sits on the sequential column chain.
+// Per-column constants reach the lanes as 16-byte LDS broadcast reads -- the CU has ONE scalar ALU shared by all waves,
+// so per-column scalar work replicated per wave must be avoided -- but a broadcast read still occupies the LDS pipe
+// for the full 64 x 16 bytes (8 cycles): with 16 waves the 13 reads per step of the first layout were ~1 700 of the
+// ~2 000 cycles of a step.  The words the packed evaluation needs are therefore packed into Q0..Q3 (4 reads for the
+// column, 2 per folded column).
+constexpr int RES_LDSWORDS = 64;
 struct ResColumn {
-	// ---- hot words 0..23
+	// ---- Q0..Q3 (words 0..15): everything the packed 16-bit evaluation of a vectorised column reads
+	uint32_t A;                       // Cp from the host; the kernel adds S_grid of its workgroup (A + table entries = Cp + S)
+	uint32_t Kpk, Ccpk;               // (Cp + Cm) and min(Cc, 0xFFFF), each in both 16-bit halves
+	uint32_t flags;                   // mode | nfold << 8 | pk_ok << 12
+	uint32_t pk[4];                   // subset sums of d0, d1, d2 for the cell pairs (0,1) (2,3) (4,5) (6,7): low | high << 16
+	uint32_t lowmask, nthr, stage_off, nwords;  // 2^Lb - 1; threads of the vectorised path (2^Lf / 4); word offset of this
+	                                  // column's record in the workgroup's staging area; words per plane
+	uint32_t ep0, mL0, PGq, Lfq;      // copies of epos[0], mL[0], PG (kernel), Lf
+	// ---- words 16..35: the 32-bit paths (vectorised without pk_ok, generic)
 	uint32_t Cp, Cm, Cc, mode;        // cost = min(Cp + S, Cm - S, Cc); an absent Cp / Cm is RES_ABSENT (never the minimum:
 	                                  // the planner guarantees every real value < 2^30).  mode: RES_MODE_*
-	uint32_t lowmask, nthr, stage_off, nwords;  // 2^Lb - 1; threads of the vectorised path (2^Lf / 4); word offset of this
-	                                  // column's ballot words in the workgroup's staging area; words per plane
 	uint32_t epos[4];                 // local bit position of ending read q (ascending logical position); [3] unused
 	uint32_t mL[4];                   // per ending read: local cell bits logically above it (tie-break parity); [3] unused
 	int32_t Sg;                       // written by the kernel: sum of the grid-read deltas selected by the workgroup index
 	uint32_t PG;                      // written by the kernel: bit q = parity of the workgroup-index bits above ending read q
 	uint32_t Lb, Lf;
 	int32_t d0, d1, d2, dE;           // deltas of local cell bits 0, 1, 2 and of ending read 0
-	// ---- cold part
+	// ---- cold
 	uint32_t ebits, nfold;            // nfold: preceding columns folded into this one (they have mode RES_MODE_FOLDED)
+	int32_t dloc[14];                 // signed deltas of the local bits
+	uint32_t pk_ok;                   // Cp + Cm < 2^14 for this column and every column folded into it: four column costs
+	                                  // still add up in 16 bits
+	uint32_t pad1[11];
+	// ---- global only (words 64..79): read once per run for the workgroup-dependent scalars
 	uint32_t mG[4];                   // per ending read: grid bits logically above it
 	int32_t dgrid[RES_GMAX];          // signed deltas of the grid reads at this column
-	int32_t dloc[14];                 // signed deltas of the local bits
-	uint32_t pad1[10];
+	uint32_t pad2[2];
 };
-static_assert(sizeof(ResColumn) == 256, "ResColumn must stay 64 words");
+static_assert(offsetof(ResColumn, mG) == RES_LDSWORDS * 4, "LDS part of ResColumn");
+static_assert(offsetof(ResColumn, Cp) == 64 && offsetof(ResColumn, d0) == 128, "32-bit hot words of ResColumn");
+static_assert(sizeof(ResColumn) == 320, "ResColumn must stay 80 words");
 constexpr uint32_t RES_ABSENT = 0xC0000000u;
 // vectorised modes: a thread owns 4 consecutive projection entries and moves them with 16-byte LDS accesses
 constexpr uint32_t RES_MODE_E0 = 0;       // no read ends

@@ -231,6 +231,22 @@ void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, Reside
 			rc.dE = rc.ebits ? rc.dloc[rc.epos[0]] : 0;
 			rc.lowmask = (1u << rc.Lb) - 1u;
 			rc.nthr = (1u << rc.Lf) >> 2;
+			{   // packed 16-bit evaluation words
+				const uint32_t s01 = (uint32_t)rc.d0, s2 = (uint32_t)rc.d1, s4 = (uint32_t)rc.d2;
+				auto pack = [](uint32_t lo, uint32_t hi) { return (lo & 0xFFFFu) | (hi << 16); };
+				rc.pk[0] = pack(0, s01);
+				rc.pk[1] = pack(s2, s2 + s01);
+				rc.pk[2] = pack(s4, s4 + s01);
+				rc.pk[3] = pack(s4 + s2, s4 + s2 + s01);
+				const uint32_t K = rc.Cp + rc.Cm, cc = std::min<uint32_t>(rc.Cc, 0xFFFFu);
+				rc.A = rc.Cp;
+				rc.Kpk = pack(K, K);
+				rc.Ccpk = pack(cc, cc);
+				rc.pk_ok = (rc.Cp != RES_ABSENT && rc.Cm != RES_ABSENT && rc.Cp < (1u << 14) && rc.Cm < (1u << 14) && K < (1u << 14)) ? 1u : 0u;
+				rc.ep0 = rc.epos[0];
+				rc.mL0 = rc.mL[0];
+				rc.Lfq = rc.Lf;
+			}
 			// vectorised path: a thread owns 4 consecutive projection entries (8 cells when a read ends) and moves them
 			// with 16-byte LDS accesses; needs aligned groups in the previous slice
 			const bool fast = rc.ebits <= 1 && rc.Lf >= 2 && rc.Lb >= 3;
@@ -347,10 +363,15 @@ void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, Reside
 					if (run) {
 						rc.nfold = run;
 						rc.lowmask = plan.columns[i - run].lowmask;  // the slice read is the one the first folded column would have read
+						for (uint32_t f = 1; f <= run; ++f) rc.pk_ok &= plan.columns[i - f].pk_ok;
 					}
 					run = 0;
 				}
 			}
+		}
+		for (size_t i = columns_mark; i < plan.columns.size(); ++i) {
+			ResColumn& rc = plan.columns[i];
+			rc.flags = rc.mode | (rc.nfold << 8) | (rc.pk_ok << 12);
 		}
 		if (!out_ok || !bt_ok) {  // exotic layout: undo and leave the first column to the column kernels
 			for (uint32_t cc = c; cc < c1; ++cc) plan.col_to_res[cc] = -1;
