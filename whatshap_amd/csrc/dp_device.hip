@@ -1152,7 +1152,25 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 				const uint32_t n_active = h[11] & 0xFFFFu, simple = h[11] >> 16;
 				const uint32_t* rmine = recs + (lane < ncols ? lane : 0u) * 32;
 				uint32_t tcur = tprev, mycell = 0, myts = 0;
-				if (simple) {
+				if (simple == 2u) {
+					// trio, at most one read ends per column: every column reads one record byte (the transmission argmin lives
+					// there), the chain per column is mask, byte, (bit insert); parameters by v_readlane from lane ci
+					const uint4 q0 = *reinterpret_cast<const uint4*>(rmine);      // Lf, ebits, layout, stage_off
+					const uint32_t p_mask = (1u << q0.x) - 1u, p_soff = q0.w * 8u, p_eb = q0.y | (rmine[5] << 8);
+					const uint8_t* stage8 = reinterpret_cast<const uint8_t*>(stage);
+					for (uint32_t ci = ncols; ci-- > 0;) {
+						const uint32_t s_mask = __builtin_amdgcn_readlane(p_mask, ci), s_soff = __builtin_amdgcn_readlane(p_soff, ci),
+						               s_eb = __builtin_amdgcn_readlane(p_eb, ci);
+						const uint32_t lout = l & s_mask;
+						const uint32_t fld = stage8[s_soff + lout * 4u + tcur];
+						const uint32_t e0 = s_eb >> 8;
+						const uint32_t with_bit = insert_zero(lout, e0) | ((fld & 1u) << e0);
+						const uint32_t cell = (s_eb & 255u) ? with_bit : lout;
+						if (lane == ci) { mycell = cell; myts = tcur; }
+						tcur = (fld >> 3) & 3u;
+						l = cell;
+					}
+				} else if (simple) {
 					// single individual, every record one byte per thread: the chain visits only the columns in which a read ends
 					// (ResBacktrace kpos / src / cmask / kcol); lane k holds the parameters of chain position k
 					const uint32_t kc = rmine[31] < ncols ? rmine[31] : 0u;

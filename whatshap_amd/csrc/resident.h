@@ -110,7 +110,8 @@ struct ResSegment {
 	uint32_t c0, ncols, g, col_off;
 	uint32_t Lb0, Lf_last, has_prev, threads;
 	uint32_t max_l, pad;
-	uint16_t bt_active, bt_simple;  // backtrace chain: columns in which a read ends; 1 if all of them use one-byte-per-thread records
+	uint16_t bt_active, bt_simple;  // backtrace chain: columns in which a read ends; 1: all of them use one-byte-per-thread
+	                                // records (single individual); 2: trio run with at most one ending read per column
 	uint32_t kind;         // 0: single individual (resident_segment), 1: trio (resident_segment_ped)
 	uint32_t term_off, n_terms;  // trio: this run's slice of the term pool
 	uint32_t stage_words;  // ballot words (u64) one workgroup produces in this run

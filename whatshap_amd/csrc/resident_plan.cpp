@@ -408,7 +408,9 @@ void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, Reside
 				}
 			}
 			seg.bt_active = (uint16_t)k;
-			seg.bt_simple = simple ? 1 : 0;
+			bool ped_simple = ped;  // trio: every column has a one-byte-per-(entry, value) record and at most one ending read
+			for (uint32_t ci = 0; ci < nc; ++ci) ped_simple = ped_simple && rb[ci].layout == 2u && rb[ci].ebits <= 1u;
+			seg.bt_simple = simple ? 1 : (ped_simple ? 2 : 0);
 		}
 
 		plan.steps.push_back(Step{1, (uint32_t)plan.segments.size()});
