@@ -32,6 +32,13 @@ def build(reference: str = "/root/reference") -> None:
     subprocess.run(["make", "-C", _HERE, "oracle"], check=True, stdout=subprocess.DEVNULL)
     if os.path.isdir(os.path.join(reference, "src")):
         subprocess.run(["make", "-C", _HERE, "ref", f"REFERENCE={reference}"], check=True, stdout=subprocess.DEVNULL)
+        # the reference's Python extension modules (whatshap.core, readselect) for the class-switch tests; optional
+        try:
+            from . import build_cython_ref
+
+            build_cython_ref.build()
+        except Exception as exc:  # a missing cython / compiler problem must not take the C oracle down with it
+            print(f"oracle: reference extension modules not built ({exc})")
 
 
 def have_reference() -> bool:

@@ -354,3 +354,44 @@ def test_drop_in_class_splits_and_overlaps_independent_blocks():
             assert tv == want["transmission"]
             assert dp.get_index_path()[0].tolist() == want["index_path"]
         assert dp.get_stats()["n_columns"] == len(want["positions"])
+
+
+def _reference_cases():
+    from reference_cases import all_cases
+    return all_cases()
+
+
+@pytest.mark.parametrize("case", _reference_cases(), ids=[c.name for c in _reference_cases()])
+def test_switching_the_reference_class_for_the_drop_in(case):
+    """What a WhatsHap user does: the reference's OWN ReadSet / Pedigree objects, the
+    reference's PedigreeDPTable on one side, whatshap_amd.shim's replacement (device) on the other; every return value
+    of the PhasingAlgorithm interface -- cost, partitioning, superreads as reference ReadSets (names, sample ids,
+    positions, alleles, qualities), transmission vector -- is identical."""
+    from refobjects import reference_core, table_outputs, to_reference
+    from whatshap_amd import shim
+
+    ref = reference_core()
+    rs, ped = to_reference(case, ref)
+    want = table_outputs(ref.PedigreeDPTable(rs, case.recombcost, ped, case.distrust_genotypes, case.positions))
+    table = shim.table_factory(ref)(rs, case.recombcost, ped, case.distrust_genotypes, case.positions)
+    superreads, _ = table.get_super_reads()
+    assert all(isinstance(x, ref.ReadSet) for x in superreads)
+    assert table_outputs(table) == want
+
+
+@pytest.mark.parametrize("trio", [False, True])
+def test_switching_classes_on_synthetic_blocks(trio):
+    """Same switch on synthetic blocks large enough for the resident kernels (several runs, folded columns)."""
+    from refobjects import problem_to_reference, reference_core, table_outputs
+    from whatshap_amd import shim
+    from whatshap_amd.synthetic import synthetic_block
+
+    ref = reference_core()
+    for seed, coverage, n in ((11, 12, 260), (12, 9, 400)):
+        problem = synthetic_block(n, coverage, seed=seed, trio=trio, distrust_genotypes=(seed == 12))
+        rs, ped = problem_to_reference(problem, ref)
+        recomb = problem.recombcost.tolist()
+        positions = None if problem.positions is None else problem.positions.tolist()
+        want = table_outputs(ref.PedigreeDPTable(rs, recomb, ped, problem.distrust_genotypes, positions))
+        got = table_outputs(shim.table_factory(ref)(rs, recomb, ped, problem.distrust_genotypes, positions))
+        assert got == want

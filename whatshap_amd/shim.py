@@ -1,0 +1,113 @@
+"""Glue for running the MI355X solver inside an unmodified WhatsHap.
+
+WhatsHap's ``phase`` command binds ``Pedigree`` and ``PedigreeDPTable`` at import (``whatshap/cli/phase.py:34-42``) and
+uses them at ``:604-612`` ("phase" stage) and ``:901-935`` (``create_pedigree``).  The reference ``Pedigree`` is opaque
+from Python -- no accessor for the order of individuals or for the trios (``whatshap/core.pxd:22-24``) -- so the shim
+swaps in a subclass that forwards every call to the C++ object *and* records it in a ``whatshap_amd.core.Pedigree``;
+the table factory then hands the recorded pedigree and the reference's own ``ReadSet`` (iterated through its public
+API) to ``whatshap_amd.core.PedigreeDPTable`` and converts the superreads back into reference ``ReadSet`` objects, as
+``core.pyx:381-404`` builds them.
+
+    import whatshap.cli.phase as phase, whatshap.core as ref
+    from whatshap_amd import shim
+    shim.install(phase, ref)          # phase.Pedigree / phase.PedigreeDPTable now run on the GPU
+    phase.run_whatshap(...)
+
+Nothing here imports WhatsHap: the reference module objects are passed in.
+"""
+
+from __future__ import annotations
+
+from typing import Optional
+
+from . import core as amd
+
+
+def convert_genotype(genotype) -> amd.Genotype:
+    """Reference ``Genotype`` (core.pyx:511-545) -> mirror."""
+    return amd.Genotype(list(genotype.as_vector()))
+
+
+def convert_likelihoods(gl) -> Optional[amd.PhredGenotypeLikelihoods]:
+    """Reference ``PhredGenotypeLikelihoods`` (core.pyx:469-504; iterates in genotype-index order) -> mirror."""
+    if gl is None:
+        return None
+    return amd.PhredGenotypeLikelihoods([float(x) for x in gl])
+
+
+def recording_pedigree_class(reference_pedigree_class):
+    """Subclass of the reference's ``Pedigree`` whose instances carry ``.amd``, a ``whatshap_amd.core.Pedigree`` with
+    the same individuals and relationships.  Typed Cython arguments (``Pedigree pedigree``) accept the subclass."""
+
+    class RecordingPedigree(reference_pedigree_class):
+        # the cdef class allocates in __cinit__(numeric_sample_ids); __init__ receives the same argument
+        def __init__(self, numeric_sample_ids):
+            self.amd = amd.Pedigree(numeric_sample_ids)
+
+        def add_individual(self, id, genotypes, genotype_likelihoods=None):
+            genotypes = list(genotypes)
+            gls = list(genotype_likelihoods) if genotype_likelihoods else None
+            super().add_individual(id, genotypes, gls)
+            self.amd.add_individual(id, [convert_genotype(g) for g in genotypes],
+                                    None if gls is None else [convert_likelihoods(g) for g in gls])
+
+        def add_relationship(self, father_id, mother_id, child_id):
+            super().add_relationship(father_id, mother_id, child_id)
+            self.amd.add_relationship(father_id, mother_id, child_id)
+
+    RecordingPedigree.__name__ = "Pedigree"
+    return RecordingPedigree
+
+
+class _TableAdapter:
+    """``PhasingAlgorithm`` interface (``whatshap/types.py:7-15``) over ``whatshap_amd.core.PedigreeDPTable``; superreads
+    are returned as the reference's own ReadSet / Read objects when the reference module is known."""
+
+    def __init__(self, table: amd.PedigreeDPTable, reference_core=None):
+        self._table = table
+        self._ref = reference_core
+
+    def get_optimal_cost(self) -> int:
+        return self._table.get_optimal_cost()
+
+    def get_optimal_partitioning(self):
+        return self._table.get_optimal_partitioning()
+
+    def get_super_reads(self):
+        superreads, transmission = self._table.get_super_reads()
+        if self._ref is None:
+            return superreads, transmission
+        converted = []
+        for readset in superreads:
+            out = self._ref.ReadSet()
+            for read in readset:
+                r = self._ref.Read(read.name, -1, -1, read.sample_id)  # core.pyx:390-397: mapq -1, source id -1
+                for v in read:
+                    r.add_variant(v.position, v.allele, v.quality)
+                out.add(r)
+            converted.append(out)
+        return converted, transmission
+
+
+def table_factory(reference_core=None, **solver_options):
+    """Callable with the constructor signature of the reference's ``PedigreeDPTable`` (core.pyx:364-379).  The pedigree
+    must come from ``recording_pedigree_class`` (or be a ``whatshap_amd.core.Pedigree``)."""
+
+    def make(readset, recombcost, pedigree, distrust_genotypes=False, positions=None):
+        recorded = getattr(pedigree, "amd", pedigree)
+        if not isinstance(recorded, amd.Pedigree):
+            raise TypeError("the pedigree was not created through whatshap_amd.shim (no recorded individuals / trios)")
+        table = amd.PedigreeDPTable(readset, recombcost, recorded, distrust_genotypes, positions, **solver_options)
+        return _TableAdapter(table, reference_core)
+
+    return make
+
+
+def install(phase_module, reference_core=None, **solver_options):
+    """Rebinds ``Pedigree`` and ``PedigreeDPTable`` in ``phase_module`` (normally ``whatshap.cli.phase``).  Returns the
+    previous bindings so that a caller can restore them."""
+    previous = (phase_module.Pedigree, phase_module.PedigreeDPTable)
+    ref_pedigree = reference_core.Pedigree if reference_core is not None else phase_module.Pedigree
+    phase_module.Pedigree = recording_pedigree_class(ref_pedigree)
+    phase_module.PedigreeDPTable = table_factory(reference_core, **solver_options)
+    return previous
