@@ -395,3 +395,63 @@ def test_switching_classes_on_synthetic_blocks(trio):
         want = table_outputs(ref.PedigreeDPTable(rs, recomb, ped, problem.distrust_genotypes, positions))
         got = table_outputs(shim.table_factory(ref)(rs, recomb, ped, problem.distrust_genotypes, positions))
         assert got == want
+
+
+def _variant_of(p, quality=None, genotype=None, gl=None, distrust=None, recomb=None):
+    """Copy of a ProblemArrays with some inputs replaced."""
+    return _native.ProblemArrays(
+        p.read_ptr, p.var_position, p.var_allele, p.var_quality if quality is None else quality, p.read_sample_id,
+        p.individual_id, p.triple_ids, p.genotype.reshape(p.n_individuals, p.n_variants) if genotype is None else genotype,
+        (None if p.genotype_likelihoods is None else p.genotype_likelihoods.reshape(p.n_individuals, p.n_variants, 3)) if gl is None else gl,
+        p.recombcost if recomb is None else recomb, p.positions, p.distrust_genotypes if distrust is None else distrust,
+        n_variants=p.n_variants)
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_resident_kernel_variants_single_individual(seed):
+    """Inputs that steer the single-individual run kernel through each of its evaluation variants, against the oracle:
+    heavy weights (Cp + Cm >= 2^14: 32-bit evaluation instead of the packed 16-bit one), homozygous genotypes (a missing
+    orientation term), untrusted genotypes with per-column likelihoods (constant term present), two-valued weights
+    (ties everywhere, decided by the Gray-rank rule inside the packed path), irregular recombination costs."""
+    rng = np.random.default_rng(seed)
+    base = synthetic_block(n_variants=420, coverage=13, seed=seed)
+    n = base.n_variants
+    variants = {
+        "heavy": _variant_of(base, quality=base.var_quality * np.uint32(450)),
+        "mixed_heavy": _variant_of(base, quality=np.where(rng.random(base.var_quality.size) < 0.3, base.var_quality * np.uint32(900), base.var_quality).astype(np.uint32)),
+        "homozygous": _variant_of(base, genotype=rng.choice([0, 1, 1, 2], size=(1, n)).astype(np.uint8)),
+        "distrust": _variant_of(base, gl=rng.integers(0, 60, size=(1, n, 3)).astype(np.float64), distrust=True),
+        "distrust_heavy": _variant_of(base, quality=base.var_quality * np.uint32(450), gl=rng.integers(0, 9000, size=(1, n, 3)).astype(np.float64), distrust=True),
+        "ties": _variant_of(base, quality=(1 + (base.var_quality % 2)).astype(np.uint32)),
+    }
+    for name, p in variants.items():
+        want = table_solution(oracle.OracleTable(p))
+        got = native_solution(p, "auto")
+        assert got == want, (name, first_difference(want, got))
+        assert _native.plan_summary(p)["n_vectorised_columns"] > 300, name
+
+
+@pytest.mark.parametrize("seed", [31, 32])
+def test_resident_kernel_variants_trio(seed):
+    """Trio run kernel: genotype combinations with different numbers of cost terms per transmission value, untrusted
+    genotypes (16 terms per value: more than the register-resident four, the rest comes from the LDS pool), heavy
+    weights, ties, per-column recombination costs."""
+    rng = np.random.default_rng(seed)
+    base = synthetic_block(n_variants=300, coverage=10, seed=seed, trio=True)
+    n = base.n_variants
+    # Mendel-consistent genotype triples (father, mother, child)
+    triples = np.array([(1, 1, 1), (1, 1, 0), (1, 1, 2), (0, 1, 0), (0, 1, 1), (1, 0, 1), (1, 2, 2), (2, 1, 1), (0, 2, 1), (2, 0, 1), (0, 0, 0), (2, 2, 2)], dtype=np.uint8)
+    mixed = triples[rng.integers(0, len(triples), size=n)].T.copy()
+    recomb = rng.integers(0, 40, size=n).astype(np.uint32)
+    variants = {
+        "mixed_genotypes": _variant_of(base, genotype=mixed, recomb=recomb),
+        "distrust": _variant_of(base, gl=rng.integers(0, 50, size=(3, n, 3)).astype(np.float64), distrust=True, recomb=recomb),
+        "heavy": _variant_of(base, quality=base.var_quality * np.uint32(3000)),
+        "ties": _variant_of(base, quality=(1 + (base.var_quality % 2)).astype(np.uint32), recomb=(recomb % 3).astype(np.uint32)),
+    }
+    for name, p in variants.items():
+        want = table_solution(oracle.OracleTable(p))
+        for path in ("auto", "column"):
+            got = native_solution(p, path)
+            assert got == want, (name, path, first_difference(want, got))
+        assert _native.plan_summary(p)["n_resident_columns"] > 200, name
