@@ -455,3 +455,9 @@ def test_resident_kernel_variants_trio(seed):
             got = native_solution(p, path)
             assert got == want, (name, path, first_difference(want, got))
         assert _native.plan_summary(p)["n_resident_columns"] > 200, name
+    # weights so large that the per-individual sums leave the 24-bit range of the term evaluation: the planner must keep
+    # those columns away from the run kernel, and the result must still be exact
+    small = synthetic_block(n_variants=40, coverage=10, seed=seed, trio=True)
+    huge = _variant_of(small, quality=small.var_quality * np.uint32(80000))
+    assert _native.plan_summary(huge)["n_resident_columns"] < 40
+    assert native_solution(huge, "auto") == table_solution(oracle.OracleTable(huge))

@@ -247,7 +247,7 @@ whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uin
 		}
 		ok = ok && stage == sg.stage_words;
 		const uint64_t lds = sg.kind == 1
-			? (((uint64_t)sg.ncols * (128 + PED_TABLE) + (uint64_t)sg.n_terms * 3 + 3) & ~3ull) * 4 + 2 * (16ull << sg.max_l) + (uint64_t)sg.stage_words * 8
+			? (((uint64_t)sg.ncols * (PED_LDSWORDS + PED_TABLE) + (uint64_t)sg.n_terms * 2 + 3) & ~3ull) * 4 + 2 * (16ull << sg.max_l) + (uint64_t)sg.stage_words * 8
 			: (uint64_t)sg.ncols * (64 + RES_TABLE) * 4 + 2 * (4ull << sg.max_l) + (uint64_t)sg.stage_words * 8;
 		ok = ok && lds <= 160 * 1024;
 		s.max_lds_bytes = std::max<uint64_t>(s.max_lds_bytes, lds);
