@@ -113,9 +113,9 @@ def main():
                                           solve=False))
 
     def step():
-        # host-side work queue: every block of this rank is submitted to its own stream, then collected
-        for t in tables:
-            t.enqueue()
+        # host-side work queue: the blocks of this rank are submitted to their own streams (launch sequences
+        # interleaved, so that they start together), then collected
+        _native.enqueue_many(tables)
         for t in tables:
             t.wait()
 

@@ -115,6 +115,13 @@ const char* whamd_last_error(void);
  * backtrace tables only in ~PedigreeDPTable (src/pedigreedptable.cpp:40-48). */
 whamd_status_t whamd_dptable_release_device(whamd_dptable* table);
 
+/* whamd_dptable_enqueue for several tables at once: their launch sequences are submitted round robin, a few launches
+ * per table and turn, so that the streams of independent blocks fill up side by side and the blocks overlap on the
+ * device from the first column on (submitting table after table lets each one run alone for as long as the host needs
+ * to submit the next).  Collect every table with whamd_dptable_wait.  No reference counterpart (the reference solves
+ * blocks one after the other, cli/phase.py:604). */
+whamd_status_t whamd_dptable_enqueue_many(whamd_dptable* const* tables, size_t n_tables);
+
 /*
  * Replaces PedigreeDPTable::PedigreeDPTable (src/pedigreedptable.cpp:15-37), split in two so that
  * a benchmark can time the device part alone:

@@ -261,6 +261,22 @@ def test_blocks_in_flight_concurrently():
     for p, t in zip(problems, tables):
         want = native_solution(p)
         assert table_solution(t) == want
+    # the same through whamd_dptable_enqueue_many (launch sequences interleaved), twice on the same tables, including a
+    # trio and an empty table in the batch
+    extra = [synthetic_block(n_variants=1500, coverage=10, seed=300, trio=True),
+             _native.ProblemArrays([0], [], [], [], [], [0], [], np.zeros((1, 0)), None, [], [], False, n_variants=0)]
+    problems += extra
+    tables += [_native.NativeTable(p, solve=False) for p in extra]
+    for _ in range(2):
+        _native.enqueue_many(tables)
+        for t in tables:
+            t.wait()
+        for p, t in zip(problems, tables):
+            assert table_solution(t) == native_solution(p)
+    with pytest.raises(_native.SolverError):
+        _native.enqueue_many([tables[0]])
+        tables[0].enqueue()  # already in flight
+    tables[0].wait()
 
 
 def _irregular_problem(seed, n_var, trio, max_cov):

@@ -203,6 +203,8 @@ def lib() -> C.CDLL:
     L.whamd_dptable_enqueue.argtypes = [H]
     L.whamd_dptable_wait.restype = C.c_int
     L.whamd_dptable_wait.argtypes = [H]
+    L.whamd_dptable_enqueue_many.restype = C.c_int
+    L.whamd_dptable_enqueue_many.argtypes = [C.POINTER(H), C.c_size_t]
     L.whamd_dptable_release_device.restype = C.c_int
     L.whamd_dptable_release_device.argtypes = [H]
     L.whamd_dptable_destroy.restype = None
@@ -249,7 +251,7 @@ EXPORTED_SYMBOLS = [
     "whamd_dptable_read_count", "whamd_dptable_positions", "whamd_dptable_get_optimal_score",
     "whamd_dptable_get_super_reads", "whamd_dptable_get_optimal_partitioning", "whamd_dptable_get_index_path",
     "whamd_dptable_get_stats", "whamd_dptable_set_option", "whamd_read_sort_hash", "whamd_plan_summarize",
-    "whamd_dptable_enqueue", "whamd_dptable_wait",
+    "whamd_dptable_enqueue", "whamd_dptable_wait", "whamd_dptable_enqueue_many",
 ]
 
 
@@ -264,6 +266,15 @@ class SolverError(RuntimeError):
 def _check(status: int):
     if status != WHAMD_OK:
         raise SolverError(status, lib().whamd_last_error().decode("utf-8", "replace"))
+
+
+def enqueue_many(tables) -> None:
+    """whamd_dptable_enqueue_many: submits the solves of several tables with interleaved launch sequences."""
+    tables = list(tables)
+    if not tables:
+        return
+    arr = (C.c_void_p * len(tables))(*[t._h.value for t in tables])
+    _check(lib().whamd_dptable_enqueue_many(arr, len(tables)))
 
 
 class NativeTable:

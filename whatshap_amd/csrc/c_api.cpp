@@ -69,8 +69,12 @@ whamd_status_t whamd_dptable_create(const whamd_readset_view* readset, const uin
 	return WHAMD_OK;
 }
 
-whamd_status_t whamd_dptable_enqueue(whamd_dptable* t) {
+namespace {
+
+// Everything whamd_dptable_enqueue does before the first launch.
+whamd_status_t begin_enqueue(whamd_dptable* t) {
 	if (!t) return fail(WHAMD_ERR_INVALID, "table is NULL");
+	if (t->in_flight) return fail(WHAMD_ERR_INVALID, "a solve of this table is already in flight");
 	std::string msg;
 	if (!t->uploaded) {
 		whamd_status_t st = t->device.upload(t->problem, t->device_index, msg);
@@ -86,9 +90,45 @@ whamd_status_t whamd_dptable_enqueue(whamd_dptable* t) {
 	s.max_coverage = p.max_k;
 	s.transmissions = p.T;
 	t->solved = false;
-	whamd_status_t st = t->device.enqueue(p, t->solution, msg);
+	return WHAMD_OK;
+}
+
+}  // namespace
+
+whamd_status_t whamd_dptable_enqueue(whamd_dptable* t) {
+	whamd_status_t st = begin_enqueue(t);
+	if (st != WHAMD_OK) return st;
+	std::string msg;
+	st = t->device.enqueue(t->problem, t->solution, msg);
 	if (st != WHAMD_OK) return fail(st, msg);
 	t->in_flight = true;
+	return WHAMD_OK;
+}
+
+whamd_status_t whamd_dptable_enqueue_many(whamd_dptable* const* tables, size_t n_tables) {
+	if (!tables && n_tables) return fail(WHAMD_ERR_INVALID, "tables is NULL");
+	for (size_t i = 0; i < n_tables; ++i) {
+		whamd_status_t st = begin_enqueue(tables[i]);
+		if (st != WHAMD_OK) return st;
+	}
+	// round robin over the tables, a few launches each: their streams fill up side by side
+	constexpr uint64_t SLICE = 16;
+	std::vector<uint8_t> done(n_tables, 0);
+	size_t open = n_tables;
+	std::string msg;
+	while (open) {
+		for (size_t i = 0; i < n_tables; ++i) {
+			if (done[i]) continue;
+			bool finished = false;
+			whamd_status_t st = tables[i]->device.enqueue_some(tables[i]->problem, tables[i]->solution, SLICE, finished, msg);
+			if (st != WHAMD_OK) return fail(st, msg);
+			if (finished) {
+				done[i] = 1;
+				tables[i]->in_flight = true;
+				--open;
+			}
+		}
+	}
 	return WHAMD_OK;
 }
 

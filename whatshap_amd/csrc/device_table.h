@@ -22,6 +22,8 @@ public:
 	// The two halves of solve(): enqueue() only submits the launches to the table's stream (several tables can be in
 	// flight at once on one device), wait() blocks until the path has arrived and reads the event timings.
 	whamd_status_t enqueue(const Problem& p, Solution& s, std::string& msg);
+	// Resumable enqueue(): at most `budget` forward launches per call; `done` once backtrace and downloads are submitted.
+	whamd_status_t enqueue_some(const Problem& p, Solution& s, uint64_t budget, bool& done, std::string& msg);
 	whamd_status_t wait(const Problem& p, Solution& s, whamd_solve_stats& st, std::string& msg);
 	// Frees the device buffers, the stream and the events; the next upload() recreates them.
 	void release_device();

@@ -1337,6 +1337,9 @@ struct DeviceTable::Impl {
 	bool fold = true;
 	uint64_t bt_bytes = 0;
 	uint64_t launches = 0;
+	size_t next_step = 0;       // resumable enqueue (enqueue_some)
+	uint32_t flip = 0;
+	bool enqueue_open = false;
 	uint32_t* h_pinned = nullptr;  // [2 n + 1]: path index, path transmission, optimal score
 
 	void release() {
@@ -1643,32 +1646,50 @@ whamd_status_t DeviceTable::solve(const Problem& p, Solution& s, whamd_solve_sta
 }
 
 whamd_status_t DeviceTable::enqueue(const Problem& p, Solution& s, std::string& msg) {
+	bool done = false;
+	whamd_status_t status = WHAMD_OK;
+	while (status == WHAMD_OK && !done) status = enqueue_some(p, s, ~0ull, done, msg);
+	return status;
+}
+
+// Resumable submission: the first call does the preamble, every call launches at most `budget` forward steps, the call
+// that runs out of steps appends backtrace + downloads and reports done.  Lets one host thread interleave the launch
+// sequences of several tables, so that their streams start together instead of one after the other.
+whamd_status_t DeviceTable::enqueue_some(const Problem& p, Solution& s, uint64_t budget, bool& done, std::string& msg) {
 	Impl& m = *impl_;
 	const uint32_t n = p.n_cols;
-	s.path_index.assign(n, 0);
-	s.path_trans.assign(n, 0);
-	m.launches = 0;
-	if (n == 0) {  // src/pedigreedptable.cpp:88-92
-		s.optimal_score = 0;
-		return WHAMD_OK;
-	}
-	HIP_TRY(hipSetDevice(m.device));
-	HIP_TRY(hipMemsetAsync(m.dp.keys, 0xFF, m.key_entries * 8, m.stream));
-	HIP_TRY(hipMemsetAsync(m.dp.last_keys, 0xFF, (size_t)MAX_T * 8, m.stream));
-	HIP_TRY(hipEventRecord(m.ev0, m.stream));
-	if (!m.plan.ped_columns.empty()) {
-		const uint32_t entries = (uint32_t)m.plan.ped_columns.size() * PED_TABLE;
-		hipLaunchKernelGGL(ped_tables, dim3((entries + 255) / 256), dim3(256), 0, m.stream, m.dp.ped_cols, (uint32_t)m.plan.ped_columns.size(), m.dp.ped_tables);
-	} else if (!m.plan.columns.empty()) {
-		const uint32_t entries = (uint32_t)m.plan.columns.size() * RES_TABLE;
-		hipLaunchKernelGGL(resident_tables, dim3((entries + 255) / 256), dim3(256), 0, m.stream, m.dp.res_cols, (uint32_t)m.plan.columns.size(), m.dp.res_tables);
+	done = false;
+	if (n) HIP_TRY(hipSetDevice(m.device));
+	if (!m.enqueue_open) {
+		m.enqueue_open = true;
+		m.next_step = 0;
+		m.flip = 0;
+		s.path_index.assign(n, 0);
+		s.path_trans.assign(n, 0);
+		m.launches = 0;
+		if (n == 0) {  // src/pedigreedptable.cpp:88-92
+			s.optimal_score = 0;
+			m.enqueue_open = false;
+			done = true;
+			return WHAMD_OK;
+		}
+		HIP_TRY(hipMemsetAsync(m.dp.keys, 0xFF, m.key_entries * 8, m.stream));
+		HIP_TRY(hipMemsetAsync(m.dp.last_keys, 0xFF, (size_t)MAX_T * 8, m.stream));
+		HIP_TRY(hipEventRecord(m.ev0, m.stream));
+		if (!m.plan.ped_columns.empty()) {
+			const uint32_t entries = (uint32_t)m.plan.ped_columns.size() * PED_TABLE;
+			hipLaunchKernelGGL(ped_tables, dim3((entries + 255) / 256), dim3(256), 0, m.stream, m.dp.ped_cols, (uint32_t)m.plan.ped_columns.size(), m.dp.ped_tables);
+		} else if (!m.plan.columns.empty()) {
+			const uint32_t entries = (uint32_t)m.plan.columns.size() * RES_TABLE;
+			hipLaunchKernelGGL(resident_tables, dim3((entries + 255) / 256), dim3(256), 0, m.stream, m.dp.res_cols, (uint32_t)m.plan.columns.size(), m.dp.res_tables);
+		}
 	}
 	uint64_t launches = 0;
-	uint32_t flip = 0;  // every step reads d_pr[flip] and writes d_pr[flip ^ 1]
-	for (const Step& step : m.plan.steps) {
-		const uint32_t* prev = m.d_pr[flip];
-		uint32_t* cur = m.d_pr[flip ^ 1];
-		flip ^= 1;
+	while (m.next_step < m.plan.steps.size() && launches < budget) {
+		const Step& step = m.plan.steps[m.next_step++];
+		const uint32_t* prev = m.d_pr[m.flip];  // every step reads d_pr[flip] and writes d_pr[flip ^ 1]
+		uint32_t* cur = m.d_pr[m.flip ^ 1];
+		m.flip ^= 1;
 		if (step.kind == 1) {
 			const ResSegment& sg = m.plan.segments[step.index];
 			if (sg.kind == 1) {
@@ -1706,6 +1727,8 @@ whamd_status_t DeviceTable::enqueue(const Problem& p, Solution& s, std::string& 
 			launches += 2;
 		}
 	}
+	m.launches += launches;
+	if (m.next_step < m.plan.steps.size()) return WHAMD_OK;
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(m.ev1, m.stream));
 	hipLaunchKernelGGL(backtrace_kernel, dim3(1), dim3(1024), m.bt_lds, m.stream, m.dp, m.d_units, (uint32_t)m.units.size(),
@@ -1717,7 +1740,8 @@ whamd_status_t DeviceTable::enqueue(const Problem& p, Solution& s, std::string& 
 	HIP_TRY(hipMemcpyAsync(m.h_pinned + n, m.d_path_trans, (size_t)n * 4, hipMemcpyDeviceToHost, m.stream));
 	HIP_TRY(hipMemcpyAsync(m.h_pinned + 2 * (size_t)n, m.d_score, 4, hipMemcpyDeviceToHost, m.stream));
 	HIP_TRY(hipEventRecord(m.ev3, m.stream));
-	m.launches = launches;
+	m.enqueue_open = false;
+	done = true;
 	return WHAMD_OK;
 }
 
