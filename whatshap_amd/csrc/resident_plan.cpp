@@ -384,10 +384,10 @@ void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, Reside
 			continue;
 		}
 		// 512 threads per workgroup: a thread of the vectorised path then owns two groups of 4 entries (same speed as 1024
-		// threads for one table, the step is VALU-bound either way), but two workgroups of DIFFERENT tables fit on a CU,
+		// threads for one table at 2^12-entry slices: the step is VALU-bound either way; smaller slices keep one group per thread), but two workgroups of DIFFERENT tables fit on a CU,
 		// which 2 x 16 waves never did: independent blocks in flight overlap (2 blocks: 1.07 -> 1.46 M columns/s)
 		seg.threads = ped ? std::min<uint32_t>(512, std::max<uint32_t>(64, 4u << max_l))
-		                  : std::min<uint32_t>(512, std::max<uint32_t>(64, (1u << max_l) / 8));
+		                  : std::min<uint32_t>(512, std::max<uint32_t>(64, (1u << max_l) / 4));
 		seg.n_terms = (uint32_t)plan.ped_terms.size() - seg.term_off;
 		seg.max_l = max_l;
 		seg.stage_words = stage_words;
