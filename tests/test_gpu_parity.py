@@ -477,3 +477,39 @@ def test_resident_kernel_variants_trio(seed):
     huge = _variant_of(small, quality=small.var_quality * np.uint32(80000))
     assert _native.plan_summary(huge)["n_resident_columns"] < 40
     assert native_solution(huge, "auto") == table_solution(oracle.OracleTable(huge))
+
+
+def test_tables_created_and_solved_from_several_host_threads():
+    """The library is used from worker threads (one per chromosome / family): creation (flattening, planning, upload) and
+    solves running concurrently in four host threads give the single-threaded results; errors stay per thread."""
+    import threading
+
+    problems = [synthetic_block(n_variants=3000 + 500 * i, coverage=12 + (i % 3) * 3, seed=400 + i, trio=(i % 4 == 3)) for i in range(8)]
+    want = [native_solution(p) for p in problems]
+    got = [None] * len(problems)
+    errors = []
+
+    def work(indices):
+        try:
+            for i in indices:
+                table = _native.NativeTable(problems[i], solve=False)
+                table.solve()
+                got[i] = table_solution(table)
+                table.close()
+            bad = _native.ProblemArrays([0, 2], [20, 10], [0, 1], [1, 1], [0], [0], [], np.ones((1, 2)), None, [1, 1], None, False)
+            try:
+                _native.NativeTable(bad)
+                errors.append("unsorted variants accepted")
+            except _native.SolverError as exc:
+                if "unsorted" not in str(exc):
+                    errors.append(str(exc))
+        except Exception as exc:  # noqa: BLE001
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=work, args=(list(range(k, len(problems), 4)),)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert got == want
