@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void resident_tables(const ResColumn* __restri
 // Shared tail of both variants: per-entry minimum over the (up to two) cells with the Gray-rank tie rule, slice store,
 // one record byte per thread (bit u = argmin side of the ending read for entry 4t+u).
 template <uint32_t MODE, int NC>
-__device__ __forceinline__ void res_finish_entries(const uint32_t (&acc)[NC], uint32_t base, uint32_t mL0, uint32_t PG,
+__device__ __forceinline__ void res_finish_entries(const uint32_t (&acc)[NC], uint32_t base, uint32_t mL0, uint32_t PG, uint32_t pbits,
                                                    uint32_t* bufQ, uint8_t* rec, uint32_t t) {
 	uint32_t D[4];
 	uint32_t takes = 0;
@@ -345,15 +345,15 @@ __device__ __forceinline__ void res_finish_entries(const uint32_t (&acc)[NC], ui
 #pragma unroll
 		for (int u = 0; u < 4; ++u) D[u] = acc[u];
 	} else {
-		// tie: the smaller Gray rank has x_h == parity of the bits above the ending read
-		const uint32_t par0 = PG ^ (uint32_t)__popc(base & mL0);
+		// tie: the smaller Gray rank has x_h == parity of the bits above the ending read; bit u of parx is
+		// that parity for entry 4t+u (grid part PG, this thread's part, the per-entry constant pbits)
+		const uint32_t parx = (0u - ((PG ^ (uint32_t)__popc(base & mL0)) & 1u)) ^ pbits;
 #pragma unroll
 		for (int u = 0; u < 4; ++u) {
 			// cell pair of entry 4t+u: E1_HIGH (u, 4+u); E1_BIT0 (2u, 2u+1); E1_BIT1 ((u>>1)*4 + (u&1), +2)
 			const int c0 = MODE == RES_MODE_E1_HIGH ? u : (MODE == RES_MODE_E1_BIT0 ? 2 * u : (((u >> 1) << 2) | (u & 1)));
 			const int c1i = MODE == RES_MODE_E1_HIGH ? 4 + u : (MODE == RES_MODE_E1_BIT0 ? 2 * u + 1 : c0 + 2);
-			const uint32_t low = MODE == RES_MODE_E1_HIGH ? (uint32_t)u : (uint32_t)c0;  // low bits of the side-0 cell index
-			const uint32_t par = (par0 ^ (uint32_t)__popc(low & mL0)) & 1u;
+			const uint32_t par = (parx >> u) & 1u;
 			const uint32_t A0 = acc[c0 & (NC - 1)], A1 = acc[c1i & (NC - 1)];
 			// side 1 wins if strictly smaller, or equal and favoured by the tie rule: A1 < A0 + par
 			D[u] = min(A0, A1);
@@ -374,6 +374,7 @@ __device__ __forceinline__ void res_fast_column(const uint32_t* ldsc, const int3
 	const uint4* hp = reinterpret_cast<const uint4*>(ldsc + ci * RES_LDSWORDS);
 	const uint4 h0 = hp[H0], h2 = hp[H0 + 1], h3 = hp[H0 + 2], h4 = hp[H0 + 3], h5 = hp[H0 + 4];
 	const uint32_t lowmask = q2.x, ep0 = h2.x, mL0 = h3.x, PG = h4.y;
+	const uint32_t pbits = ldsc[ci * RES_LDSWORDS + offsetof(ResColumn, pbits) / 4];
 	uint8_t* rec = stage + q2.z * 8u;
 	// record of the first folded column (or of this column again when nothing is folded: loaded but not used)
 	const uint32_t c1 = ci - (nfold ? 1u : 0u);
@@ -436,7 +437,7 @@ __device__ __forceinline__ void res_fast_column(const uint32_t* ldsc, const int3
 			if (MODE == RES_MODE_E1_HIGH) dEf = reinterpret_cast<const int32_t*>(ldsc + cf * RES_LDSWORDS + offsetof(ResColumn, dloc) / 4)[ep0];
 			add_column(fp[H0], fp[H0 + 3], fp[H0 + 4], tlf[ilo], tlf[ihi], dEf);
 		}
-		res_finish_entries<MODE, NC>(acc, base, mL0, PG, bufQ, rec, t);
+		res_finish_entries<MODE, NC>(acc, base, mL0, PG, pbits, bufQ, rec, t);
 	}
 }
 
@@ -514,7 +515,7 @@ __device__ __forceinline__ void res_pk_column(const uint32_t* ldsc, const int32_
 		}
 #pragma unroll
 		for (int i = 0; i < NC / 2; ++i) { acc[2 * i] += (uint32_t)tot[i].x; acc[2 * i + 1] += (uint32_t)tot[i].y; }
-		res_finish_entries<MODE, NC>(acc, base, mL0, PG, bufQ, rec, t);
+		res_finish_entries<MODE, NC>(acc, base, mL0, PG, q3.w, bufQ, rec, t);
 	}
 }
 

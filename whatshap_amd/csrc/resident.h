@@ -38,7 +38,8 @@ struct ResColumn {
 	uint32_t pk[4];                   // subset sums of d0, d1, d2 for the cell pairs (0,1) (2,3) (4,5) (6,7): low | high << 16
 	uint32_t lowmask, nthr, stage_off, nwords;  // 2^Lb - 1; threads of the vectorised path (2^Lf / 4); word offset of this
 	                                  // column's record in the workgroup's staging area; words per plane
-	uint32_t ep0, mL0, PGq, Lfq;      // copies of epos[0], mL[0], PG (kernel), Lf
+	uint32_t ep0, mL0, PGq, pbits;    // copies of epos[0], mL[0], PG (kernel); pbits: bit u = parity of (low cell bits of
+	                                  // entry 4t+u's side-0 cell) & mL0 -- the part of the tie-break parity that is the same for every thread
 	// ---- words 16..35: the 32-bit paths (vectorised without pk_ok, generic)
 	uint32_t Cp, Cm, Cc, mode;        // cost = min(Cp + S, Cm - S, Cc); an absent Cp / Cm is RES_ABSENT (never the minimum:
 	                                  // the planner guarantees every real value < 2^30).  mode: RES_MODE_*

@@ -245,7 +245,6 @@ void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, Reside
 				rc.pk_ok = (rc.Cp != RES_ABSENT && rc.Cm != RES_ABSENT && rc.Cp < (1u << 14) && rc.Cm < (1u << 14) && K < (1u << 14)) ? 1u : 0u;
 				rc.ep0 = rc.epos[0];
 				rc.mL0 = rc.mL[0];
-				rc.Lfq = rc.Lf;
 			}
 			// vectorised path: a thread owns 4 consecutive projection entries (8 cells when a read ends) and moves them
 			// with 16-byte LDS accesses; needs aligned groups in the previous slice
@@ -253,6 +252,11 @@ void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, Reside
 			if (!fast) rc.mode = RES_MODE_GENERIC;
 			else if (rc.ebits == 0) rc.mode = RES_MODE_E0;
 			else rc.mode = rc.epos[0] >= 2 ? RES_MODE_E1_HIGH : (rc.epos[0] == 0 ? RES_MODE_E1_BIT0 : RES_MODE_E1_BIT1);
+			rc.pbits = 0;
+			for (uint32_t u = 0; u < 4; ++u) {  // low bits of the side-0 cell of entry 4t+u (dp_device.hip res_finish_entries)
+				const uint32_t low = rc.mode == RES_MODE_E1_HIGH ? u : (rc.mode == RES_MODE_E1_BIT0 ? 2 * u : (((u >> 1) << 2) | (u & 1)));
+				rc.pbits |= ((uint32_t)__builtin_popcount(low & rc.mL[0]) & 1u) << u;
+			}
 			// record of a vectorised column: one byte per thread (nthr bytes); otherwise ballot words per plane
 			rc.nwords = fast ? std::max<uint32_t>(1, rc.nthr / 8) : std::max<uint32_t>(1, (1u << rc.Lf) / 64);
 			if (ped) {
