@@ -1,5 +1,6 @@
 // c_api.cpp -- the extern "C" boundary declared in include/whatshap_amd.h.
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -60,9 +61,12 @@ whamd_status_t whamd_dptable_create(const whamd_readset_view* readset, const uin
 	whamd_status_t st = build_problem(readset, recombcost, n_recombcost, pedigree, distrust_genotypes != 0,
 	                                  positions, n_positions, t->problem, msg);
 	if (st != WHAMD_OK) return fail(st, msg);
+	const double t1 = now_ms();
 	t->device_index = device;
 	st = t->device.upload(t->problem, device, msg);
 	if (st != WHAMD_OK) return fail(st, msg);
+	if (getenv("WHAMD_DEBUG_TIMING"))
+		fprintf(stderr, "[whamd timing] create: flatten %.1f ms, plan + upload %.1f ms\n", t1 - t0, now_ms() - t1);
 	t->uploaded = true;
 	t->stats.host_prepare_ms = now_ms() - t0;
 	*out = t.release();

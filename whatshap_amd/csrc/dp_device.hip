@@ -1441,7 +1441,9 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	}
 	const bool force_keys = m.path == "column_keys";
 	const bool want_resident = m.path == "auto" || m.path == "resident";
+	const auto tu0 = std::chrono::steady_clock::now();
 	plan_forward(p, want_resident, m.l_pref, m.fold, m.plan);
+	const auto tu1 = std::chrono::steady_clock::now();
 	if (getenv("WHAMD_DEBUG_PLAN")) {
 		for (const Step& st : m.plan.steps) {
 			if (st.kind == 0) { fprintf(stderr, "[plan] column %u k=%u b=%u f=%u\n", st.index, p.k[st.index], p.b[st.index], p.f[st.index]); continue; }
@@ -1596,7 +1598,9 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	HIP_TRY(alloc(&d_rtab, m.plan.columns.size() * (ped_plan ? PED_TABLE : RES_TABLE) * sizeof(int32_t)));
 	m.dp.res_tables = ped_plan ? nullptr : (int32_t*)d_rtab;
 	m.dp.ped_tables = ped_plan ? (int32_t*)d_rtab : nullptr;
+	const auto tu2 = std::chrono::steady_clock::now();
 	HIP_TRY(alloc(&d_bt, bt));
+	const auto tu3 = std::chrono::steady_clock::now();
 	m.key_entries = (size_t)(1ull << max_keys_f) * p.T;
 	HIP_TRY(alloc(&d_keys, m.key_entries * 8));
 	HIP_TRY(alloc(&d_last_keys, (size_t)MAX_T * 8));
@@ -1618,6 +1622,11 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	m.dp.res_cols = (const ResColumn*)d_rcol;
 	m.dp.res_bt = (const ResBacktrace*)d_rbt;
 	m.dp.dbg = nullptr;
+	if (getenv("WHAMD_DEBUG_TIMING")) {
+		auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+		fprintf(stderr, "[whamd timing] upload: plan %.1f ms, descriptors + copies %.1f ms, backtrace arena (%.2f GB) %.1f ms, rest %.1f ms\n",
+		        ms(tu0, tu1), ms(tu1, tu2), (double)bt / 1e9, ms(tu2, tu3), ms(tu3, std::chrono::steady_clock::now()));
+	}
 	if (getenv("WHAMD_DEBUG_TIMING")) {
 		void* d_dbg = nullptr;
 		const size_t dbg_bytes = (m.plan.segments.size() + 1) * 64 + 4 * 512 * 16 + 64;
