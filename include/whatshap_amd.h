@@ -192,8 +192,12 @@ whamd_status_t whamd_dptable_get_index_path(const whamd_dptable* table, uint32_t
 /* Measurements of the last whamd_dptable_solve on this table. */
 whamd_status_t whamd_dptable_get_stats(const whamd_dptable* table, whamd_solve_stats* stats_out);
 
-/* Solver variant selection (for A/B measurements and tests): "auto" (default), "column" (one
- * launch per column, the general path), or other names documented in DESIGN.md. */
+/* Options (for A/B measurements and tests), effective at the next solve:
+ *   "path"          "auto" (default) | "resident" | "column" (one launch per column, the general path) | "column_keys"
+ *   "resident_l"    preferred log2 slice size of the run kernels
+ *   "resident_fold" "0" disables folding of columns without an ending read
+ *   "lanes"         streams over which the connected components of a single-individual table are spread (default 4;
+ *                   "1" solves them one after the other) */
 whamd_status_t whamd_dptable_set_option(whamd_dptable* table, const char* key, const char* value);
 
 /*

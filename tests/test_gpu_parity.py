@@ -513,3 +513,36 @@ def test_tables_created_and_solved_from_several_host_threads():
         t.join()
     assert not errors, errors
     assert got == want
+
+
+def test_connected_components_on_their_own_streams():
+    """A single-individual ReadSet made of many connected components, solved as ONE table: every component but the
+    last becomes its own job (forward steps from cost 0, score added on the host, backtrace from entry 0) and the jobs
+    are spread over streams.  Cost, path, partitioning and superreads equal the oracle's for the whole ReadSet, for
+    every number of streams."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    from gpu_multiblock import chromosome
+
+    for coverage, n_blocks, seed in ((9, 25, 1), (12, 12, 2)):
+        rng = np.random.default_rng(seed)
+        whole = chromosome(n_blocks, coverage, seed=seed, max_len=120)
+        # irregular weights, some homozygous columns: not every run takes the packed path
+        whole = _variant_of(whole, quality=np.where(rng.random(whole.var_quality.size) < 0.2, whole.var_quality * np.uint32(700), whole.var_quality).astype(np.uint32),
+                            genotype=rng.choice([0, 1, 1, 1, 2], size=(1, whole.n_variants)).astype(np.uint8))
+        want = table_solution(oracle.OracleTable(whole))
+        for lanes in (1, 2, 4, 7):
+            t = _native.NativeTable(whole, solve=False)
+            t.set_option("lanes", str(lanes))
+            for _ in range(2):  # solved twice: the lanes' scratch must be re-armed
+                t.solve()
+                got = table_solution(t)
+                assert got == want, (coverage, lanes, first_difference(want, got))
+            t.close()
+    # through the interleaved multi-table submission as well
+    tables = [_native.NativeTable(chromosome(6, 10, seed=s, max_len=80), solve=False) for s in (3, 4, 5)]
+    _native.enqueue_many(tables)
+    for t in tables:
+        t.wait()
+    for s, t in zip((3, 4, 5), tables):
+        assert table_solution(t) == table_solution(oracle.OracleTable(chromosome(6, 10, seed=s, max_len=80)))

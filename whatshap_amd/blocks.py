@@ -98,28 +98,21 @@ def split_independent_blocks(problem: ProblemArrays) -> List[Tuple[ProblemArrays
 
 def solve_blocks(problems: Sequence[ProblemArrays], device: int = 0, path=None, max_in_flight: int = 8,
                  release: bool = True):
-    """Host-side work queue for one device: solves independent blocks with ``max_in_flight`` of them submitted
-    at any time, each on its own stream (``whamd_dptable_enqueue`` / ``_wait``), so that small blocks -- which
-    cannot fill 256 CUs on their own -- overlap.  Returns the solved tables in input order; with ``release`` their
-    device buffers and streams are freed as soon as the solution is on the host."""
-    from ._native import NativeTable
+    """Host-side work queue for one device: solves independent blocks ``max_in_flight`` at a time, each on its own
+    stream with interleaved launch sequences (``whamd_dptable_enqueue_many``), so that blocks -- which cannot fill 256
+    CUs on their own -- overlap.  Returns the solved tables in input order; with ``release`` their device buffers and
+    streams are freed as soon as the solution is on the host."""
+    from ._native import NativeTable, enqueue_many
 
     tables = []
-    pending = []
-    for sub in problems:
-        t = NativeTable(sub, device=device, path=path, solve=False)
-        t.enqueue()
-        tables.append(t)
-        pending.append(t)
-        if len(pending) >= max_in_flight:
-            done = pending.pop(0)
-            done.wait()
+    for start in range(0, len(problems), max_in_flight):
+        window = [NativeTable(sub, device=device, path=path, solve=False) for sub in problems[start:start + max_in_flight]]
+        enqueue_many(window)
+        for t in window:
+            t.wait()
             if release:
-                done.release_device()
-    for t in pending:
-        t.wait()
-        if release:
-            t.release_device()
+                t.release_device()
+        tables.extend(window)
     return tables
 
 

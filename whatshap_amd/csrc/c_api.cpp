@@ -233,6 +233,11 @@ whamd_status_t whamd_dptable_set_option(whamd_dptable* t, const char* key, const
 		t->uploaded = false;
 		return WHAMD_OK;
 	}
+	if (k == "lanes") {
+		t->device.set_lanes(std::atoi(value));
+		t->uploaded = false;
+		return WHAMD_OK;
+	}
 	if (k == "resident_l") {
 		t->device.set_l_pref(std::atoi(value));
 		t->uploaded = false;

@@ -33,6 +33,8 @@ public:
 	void set_l_pref(int l);
 	// Fold columns in which no read ends into the next resident column (default on); next upload().
 	void set_fold(bool v);
+	// Streams over which the connected components of a single-individual table are spread (default 4, 1 = off); next upload().
+	void set_lanes(int n);
 
 private:
 	struct Impl;

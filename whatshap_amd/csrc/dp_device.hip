@@ -1024,9 +1024,14 @@ __global__ __launch_bounds__(1024) void resident_segment_ped(DevProblem P, ResSe
 // the workgroup copies that record (a few KiB) into LDS with one coalesced load while it prefetches the NEXT run's
 // column records and the header of the run after that; one wave then follows the path with LDS latency instead of one
 // dependent HBM access per column.
+//
+// `with_last_column` != 0: units[0] is the table's last column (its optimum comes from P.last_keys), the walk starts at
+// units[1].  == 0: the units are the runs of ONE connected component that ends before the table does (its last column
+// projects onto a single entry): the walk starts at units[0] with entry 0 and no score is written -- several such
+// launches run side by side on different streams.
 __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtUnit* __restrict__ units, uint32_t n_units,
-                                                         uint32_t* __restrict__ path_index, uint32_t* __restrict__ path_trans,
-                                                         uint32_t* __restrict__ out_score) {
+                                                         uint32_t with_last_column, uint32_t* __restrict__ path_index,
+                                                         uint32_t* __restrict__ path_trans, uint32_t* __restrict__ out_score) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
 	uint32_t* recs0 = smem;                                   // 2 x RES_MAXCOLS * 32 words: column records (double buffer)
 	uint32_t* hdr = smem + 2 * RES_MAXCOLS * 32;              // 4 x 32 words: unit headers (ring)
@@ -1036,40 +1041,45 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 	unsigned long long* stage = reinterpret_cast<unsigned long long*>(tsarr + RES_MAXCOLS);
 	const uint32_t lane = threadIdx.x, NT = blockDim.x;
 	const uint32_t n = P.n_cols, T = P.T;
-	// optimum of the last column: first (rank(x), i) attaining the minimum (strict '<' scan, :306-315)
-	unsigned long long bestk = ~0ull;
-	uint32_t t = 0, tprev = 0;
-	for (uint32_t i = 0; i < T; ++i) {
-		const unsigned long long key = P.last_keys[i];
-		if ((key >> 4) < (bestk >> 4)) { bestk = key; t = i; }
+	const uint32_t u_first = with_last_column ? 1u : 0u;
+	uint32_t x = 0, tprev = 0;
+	if (with_last_column) {
+		// optimum of the last column: first (rank(x), i) attaining the minimum (strict '<' scan, :306-315)
+		unsigned long long bestk = ~0ull;
+		uint32_t t = 0;
+		for (uint32_t i = 0; i < T; ++i) {
+			const unsigned long long key = P.last_keys[i];
+			if ((key >> 4) < (bestk >> 4)) { bestk = key; t = i; }
+		}
+		if (bestk == ~0ull) {  // unreachable for valid inputs (the host rejects Mendelian conflicts); keep defined output
+			if (lane == 0) out_score[0] = 0xFFFFFFFFu;
+			bestk = 0;
+		} else if (lane == 0) {
+			out_score[0] = (uint32_t)(bestk >> 32);
+		}
+		const uint32_t rlast = (uint32_t)(bestk >> 4) & 0x0FFFFFFFu;
+		x = rlast ^ (rlast >> 1);
+		tprev = (uint32_t)bestk & 15u;
+		if (lane == 0) {
+			path_index[n - 1] = x;
+			path_trans[n - 1] = t;
+		}
 	}
-	if (bestk == ~0ull) {  // unreachable for valid inputs (the host rejects Mendelian conflicts); keep defined output
-		if (lane == 0) out_score[0] = 0xFFFFFFFFu;
-		bestk = 0;
-	} else if (lane == 0) {
-		out_score[0] = (uint32_t)(bestk >> 32);
-	}
-	const uint32_t rlast = (uint32_t)(bestk >> 4) & 0x0FFFFFFFu;
-	uint32_t x = rlast ^ (rlast >> 1);
-	tprev = (uint32_t)bestk & 15u;
-	if (lane == 0) {
-		path_index[n - 1] = x;
-		path_trans[n - 1] = t;
-	}
-	// units[0] is the last column itself; every later unit yields x_c from x_{c+1}.
-	// prime the pipeline: headers of units 1 and 2, records of unit 1
+	// every unit from u_first on yields x_c from x_{c+1}.
+	// prime the pipeline: headers of the first two units, records of the first
 	if (lane < 64) {
-		const uint32_t u = 1 + (lane >> 5);
+		const uint32_t u = u_first + (lane >> 5);
 		if (u < n_units) hdr[(u & 3u) * 32 + (lane & 31u)] = reinterpret_cast<const uint32_t*>(units + u)[lane & 31u];
 	}
 	__syncthreads();
-	if (n_units > 1 && hdr[32] == 1u) {
-		const uint32_t* __restrict__ g1 = reinterpret_cast<const uint32_t*>(P.res_bt + hdr[32 + 3]);
-		for (uint32_t i = lane; i < hdr[32 + 2] * 32; i += NT) recs0[RES_MAXCOLS * 32 + i] = g1[i];
+	if (n_units > u_first && hdr[(u_first & 3u) * 32] == 1u) {
+		const uint32_t* h1 = hdr + (u_first & 3u) * 32;
+		const uint32_t* __restrict__ g1 = reinterpret_cast<const uint32_t*>(P.res_bt + h1[3]);
+		for (uint32_t i = lane; i < h1[2] * 32; i += NT) recs0[(u_first & 1u) * RES_MAXCOLS * 32 + i] = g1[i];
 	}
 	__syncthreads();
 	unsigned long long bt_load = 0, bt_walk = 0, bt_runs = 0, bt_a = 0, bt_b = 0, bt_c = 0;
-	for (uint32_t ui = 1; ui < n_units; ++ui) {
+	for (uint32_t ui = u_first; ui < n_units; ++ui) {
 		const unsigned long long tb0 = P.dbg ? __builtin_readcyclecounter() : 0ull;
 		const uint32_t* h = hdr + (ui & 3u) * 32;
 		const uint32_t kind = h[0], c0 = h[1], ncols = h[2];
@@ -1338,12 +1348,47 @@ struct DeviceTable::Impl {
 	bool fold = true;
 	uint64_t bt_bytes = 0;
 	uint64_t launches = 0;
-	size_t next_step = 0;       // resumable enqueue (enqueue_some)
-	uint32_t flip = 0;
-	bool enqueue_open = false;
-	uint32_t* h_pinned = nullptr;  // [2 n + 1]: path index, path transmission, optimal score
+	bool enqueue_open = false;  // resumable enqueue (enqueue_some)
+	uint32_t* h_pinned = nullptr;  // [2 n + 1 + jobs]: path index, path transmission, score of the final job, scores of the others
+	// A job is a sequence of forward steps followed by ONE backtrace launch.  Job 0 ("final") is the last connected
+	// component (it ends with the table's last column, whose optimum comes from the key scratch); every other job is
+	// one earlier connected component: it starts from cost 0, its last column projects onto a single entry -- that value
+	// is added on the host -- and its backtrace starts at entry 0.  Jobs are independent, so they are spread over lanes (streams) and overlap.
+	struct Job {
+		std::vector<uint32_t> steps;  // indices into plan.steps, execution order
+		uint32_t unit_off = 0, unit_count = 0;
+		bool final = false;
+	};
+	struct Lane {
+		hipStream_t stream = nullptr;  // lane 0: the table's stream
+		hipEvent_t done = nullptr;
+		uint32_t* d_pr[2] = {nullptr, nullptr};
+		unsigned long long* d_keys = nullptr;  // atomic-min scratch of the per-column kernels (one per lane: components overlap)
+		std::vector<uint32_t> jobs;
+		size_t job_i = 0, step_i = 0;  // cursor of the resumable enqueue
+		uint32_t flip = 0;             // every step reads d_pr[flip] and writes d_pr[flip ^ 1]
+	};
+	std::vector<Job> jobs;
+	std::vector<Lane> lanes;
+	uint32_t* d_job_scores = nullptr;
+	hipEvent_t ev_ready = nullptr;
+	int max_lanes = 4;  // measured: 4 streams saturate the dispatch rate (~200 k launches/s); more streams (or more hardware queues) lose
+	size_t lanes_open = 0;
+
+	void launch_step(const Problem& p, const Step& step, const Lane& lane, const uint32_t* prev, uint32_t* cur, uint64_t& launches);
+	whamd_status_t submit_lane(const Problem& p, size_t li, uint64_t max_launches, uint64_t& launches, bool& finished, std::string& msg);
+
+	void release_lanes() {
+		for (size_t i = 1; i < lanes.size(); ++i) {
+			if (lanes[i].done) (void)hipEventDestroy(lanes[i].done);
+			if (lanes[i].stream) (void)hipStreamDestroy(lanes[i].stream);
+		}
+		lanes.clear();
+		jobs.clear();
+	}
 
 	void release() {
+		release_lanes();
 		for (void* a : allocations) (void)hipFree(a);
 		allocations.clear();
 		if (h_pinned) (void)hipHostFree(h_pinned);
@@ -1365,6 +1410,7 @@ DeviceTable::~DeviceTable() {
 		if (impl_->ev1) (void)hipEventDestroy(impl_->ev1);
 		if (impl_->ev2) (void)hipEventDestroy(impl_->ev2);
 		if (impl_->ev3) (void)hipEventDestroy(impl_->ev3);
+		if (impl_->ev_ready) (void)hipEventDestroy(impl_->ev_ready);
 		if (impl_->stream) (void)hipStreamDestroy(impl_->stream);
 		delete impl_;
 	}
@@ -1374,7 +1420,7 @@ void DeviceTable::release_device() {
 	Impl& m = *impl_;
 	(void)hipSetDevice(m.device);
 	m.release();
-	for (hipEvent_t* e : {&m.ev0, &m.ev1, &m.ev2, &m.ev3}) {
+	for (hipEvent_t* e : {&m.ev0, &m.ev1, &m.ev2, &m.ev3, &m.ev_ready}) {
 		if (*e) (void)hipEventDestroy(*e);
 		*e = nullptr;
 	}
@@ -1410,6 +1456,8 @@ bool DeviceTable::set_path(const std::string& path) {
 }
 
 void DeviceTable::set_l_pref(int l) { impl_->l_pref = std::max(4, std::min(l, RES_LMAX)); }
+void DeviceTable::set_lanes(int n) { impl_->max_lanes = n < 1 ? 1 : (n > 16 ? 16 : n); }
+
 void DeviceTable::set_fold(bool v) { impl_->fold = v; }
 
 whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& msg) {
@@ -1555,10 +1603,33 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	HIP_TRY(up(&d_pterm, m.plan.ped_terms.data(), m.plan.ped_terms.size() * sizeof(PedTerm)));
 	m.dp.ped_cols = (const PedColumn*)d_pcol;
 	m.dp.ped_terms = (const PedTerm*)d_pterm;
+	// ---- jobs (see Impl::Job): connected components made of runs only get their own job
+	m.release_lanes();
+	{
+		Impl::Job final_job;
+		final_job.final = true;
+		std::vector<Impl::Job> component_jobs;
+		const std::vector<uint32_t>& first = m.plan.component_first_step;
+		const bool split = m.max_lanes > 1 && first.size() > 1 && !getenv("WHAMD_DEBUG_TIMING");
+		if (!split) {
+			for (uint32_t si = 0; si < m.plan.steps.size(); ++si) final_job.steps.push_back(si);
+		} else {
+			for (size_t k = 0; k < first.size(); ++k) {
+				const uint32_t s0 = first[k], s1 = k + 1 < first.size() ? first[k + 1] : (uint32_t)m.plan.steps.size();
+				Impl::Job* job = &final_job;
+				if (k + 1 < first.size()) { component_jobs.emplace_back(); job = &component_jobs.back(); }
+				for (uint32_t si = s0; si < s1; ++si) job->steps.push_back(si);
+			}
+		}
+		m.jobs.push_back(std::move(final_job));
+		for (Impl::Job& j : component_jobs) m.jobs.push_back(std::move(j));
+	}
 	{
 		m.units.clear();
-		for (size_t si = m.plan.steps.size(); si-- > 0;) {
-			const Step& st = m.plan.steps[si];
+		for (Impl::Job& job : m.jobs) {
+		job.unit_off = (uint32_t)m.units.size();
+		for (size_t sj = job.steps.size(); sj-- > 0;) {
+			const Step& st = m.plan.steps[job.steps[sj]];
 			BtUnit u{};
 			u.kind = st.kind;
 			if (st.kind == 0) {
@@ -1586,6 +1657,8 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 			}
 			m.units.push_back(u);
 		}
+		job.unit_count = (uint32_t)m.units.size() - job.unit_off;
+		}
 	}
 	HIP_TRY(up((void**)&m.d_units, m.units.data(), m.units.size() * sizeof(BtUnit)));
 	{
@@ -1609,7 +1682,35 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	HIP_TRY(alloc((void**)&m.d_path_index, (size_t)n * 4));
 	HIP_TRY(alloc((void**)&m.d_path_trans, (size_t)n * 4));
 	HIP_TRY(alloc((void**)&m.d_score, 16));
-	HIP_TRY(hipHostMalloc((void**)&m.h_pinned, (2 * (size_t)n + 4) * sizeof(uint32_t), hipHostMallocDefault));
+	HIP_TRY(hipHostMalloc((void**)&m.h_pinned, (2 * (size_t)n + 4 + m.jobs.size()) * sizeof(uint32_t), hipHostMallocDefault));
+	HIP_TRY(alloc((void**)&m.d_job_scores, (m.jobs.size() + 1) * 4));
+	{   // lanes: longest job first to the least loaded lane; lane 0 always runs the final job
+		const size_t n_lanes = std::max<size_t>(1, std::min<size_t>((size_t)m.max_lanes, m.jobs.size()));
+		m.lanes.assign(n_lanes, Impl::Lane());
+		std::vector<uint64_t> load(n_lanes, 0);
+		std::vector<uint32_t> order;
+		for (uint32_t j = 1; j < m.jobs.size(); ++j) order.push_back(j);
+		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return m.jobs[a].steps.size() > m.jobs[b].steps.size(); });
+		m.lanes[0].jobs.push_back(0);
+		load[0] = m.jobs[0].steps.size() + 1;
+		for (uint32_t j : order) {
+			const size_t l = (size_t)(std::min_element(load.begin(), load.end()) - load.begin());
+			m.lanes[l].jobs.push_back(j);
+			load[l] += m.jobs[j].steps.size() + 1;
+		}
+		m.lanes[0].stream = m.stream;
+		m.lanes[0].d_pr[0] = m.d_pr[0];
+		m.lanes[0].d_pr[1] = m.d_pr[1];
+		for (size_t l = 1; l < n_lanes; ++l) {
+			HIP_TRY(hipStreamCreateWithFlags(&m.lanes[l].stream, hipStreamNonBlocking));
+			HIP_TRY(hipEventCreateWithFlags(&m.lanes[l].done, hipEventDisableTiming));
+			HIP_TRY(alloc((void**)&m.lanes[l].d_pr[0], (size_t)(1ull << max_f) * p.T * 4));
+			HIP_TRY(alloc((void**)&m.lanes[l].d_pr[1], (size_t)(1ull << max_f) * p.T * 4));
+			HIP_TRY(alloc((void**)&m.lanes[l].d_keys, m.key_entries * 8));
+		}
+		m.lanes[0].d_keys = (unsigned long long*)d_keys;
+		if (!m.ev_ready) HIP_TRY(hipEventCreateWithFlags(&m.ev_ready, hipEventDisableTiming));
+	}
 	HIP_TRY(hipStreamSynchronize(m.stream));
 	m.dp.cols = m.d_cols;
 	m.dp.delta = (const int32_t*)d_delta;
@@ -1662,9 +1763,101 @@ whamd_status_t DeviceTable::enqueue(const Problem& p, Solution& s, std::string& 
 	return status;
 }
 
-// Resumable submission: the first call does the preamble, every call launches at most `budget` forward steps, the call
-// that runs out of steps appends backtrace + downloads and reports done.  Lets one host thread interleave the launch
-// sequences of several tables, so that their streams start together instead of one after the other.
+// Launches one forward step on a lane's stream: reads `prev`, writes `cur`.
+void DeviceTable::Impl::launch_step(const Problem& p, const Step& step, const Lane& lane, const uint32_t* prev, uint32_t* cur,
+                                    uint64_t& launches) {
+	Impl& m = *this;
+	hipStream_t stream = lane.stream;
+	DevProblem dp = m.dp;
+	dp.keys = lane.d_keys;
+	if (step.kind == 1) {
+		const ResSegment& sg = m.plan.segments[step.index];
+		if (sg.kind == 1) {
+			const size_t words = ((size_t)sg.ncols * (PED_LDSWORDS + PED_TABLE) + (size_t)sg.n_terms * 2 + 3) & ~(size_t)3;
+			const size_t lds_ped = words * 4 + 2 * ((size_t)16 << sg.max_l) + (size_t)sg.stage_words * 8;
+			ResSegment parg = sg;
+			parg.pad = step.index;
+			if (m.dp.dbg) hipLaunchKernelGGL(resident_segment_ped<true>, dim3(1u << sg.g), dim3(sg.threads), lds_ped, stream, dp, parg, prev, cur);
+			else hipLaunchKernelGGL(resident_segment_ped<false>, dim3(1u << sg.g), dim3(sg.threads), lds_ped, stream, dp, parg, prev, cur);
+			launches += 1;
+			return;
+		}
+		const size_t lds = (size_t)sg.ncols * (64 + RES_TABLE) * 4 + 2 * ((size_t)4 << sg.max_l) + (size_t)sg.stage_words * 8;
+		ResSegment arg = sg;
+		arg.pad = step.index;
+		if (m.dp.dbg) hipLaunchKernelGGL(resident_segment<true>, dim3(1u << sg.g), dim3(sg.threads), lds, stream, dp, arg, prev, cur);
+		else hipLaunchKernelGGL(resident_segment<false>, dim3(1u << sg.g), dim3(sg.threads), lds, stream, dp, arg, prev, cur);
+		launches += 1;
+		return;
+	}
+	const uint32_t c = step.index;
+	const DevColumn& d = m.cols[c];
+	if (d.mode == 0) {
+		const uint32_t threads = 1u << d.f;
+		const uint32_t block = std::min<uint32_t>(256, threads);
+		hipLaunchKernelGGL(m.fused, dim3(threads / block), dim3(block), 0, stream, dp, c, prev, cur);
+		launches += 1;
+	} else {
+		const uint64_t total = 1ull << (d.f + d.ebits - d.eloop);
+		const uint32_t block = (uint32_t)std::min<uint64_t>(256, (total + 63) / 64 * 64);
+		hipLaunchKernelGGL(m.keysfn, dim3((uint32_t)((total + block - 1) / block)), dim3(block), 0, stream, dp, c, prev, (uint32_t)total);
+		const uint32_t entries = (1u << d.f) * p.T;
+		const uint32_t fblock = std::min<uint32_t>(256, (entries + 63) / 64 * 64);
+		hipLaunchKernelGGL(column_finalize, dim3((entries + fblock - 1) / fblock), dim3(fblock), 0, stream, dp, c, cur, entries);
+		launches += 2;
+	}
+}
+
+// Submits up to `max_launches` launches of lane `li` (forward steps of its jobs in order; after a job's last step its
+// score copy and backtrace).  `finished`: the lane has nothing left.
+whamd_status_t DeviceTable::Impl::submit_lane(const Problem& p, size_t li, uint64_t max_launches, uint64_t& launches, bool& finished,
+                                              std::string& msg) {
+	Impl& m = *this;
+	Impl::Lane& lane = m.lanes[li];
+	uint64_t in_turn = 0;
+	while (lane.job_i < lane.jobs.size() && in_turn < max_launches) {
+		const Impl::Job& job = m.jobs[lane.jobs[lane.job_i]];
+		const uint32_t job_id = lane.jobs[lane.job_i];
+		if (lane.step_i == 0)  // a job starts from cost 0: the single entry the first step may read
+			HIP_TRY(hipMemsetAsync(lane.d_pr[lane.flip], 0, 4 * (size_t)p.T, lane.stream));
+		if (lane.step_i < job.steps.size()) {
+			const uint32_t si = job.steps[lane.step_i++];
+			uint64_t issued = 0;
+			m.launch_step(p, m.plan.steps[si], lane, lane.d_pr[lane.flip], lane.d_pr[lane.flip ^ 1], issued);
+			lane.flip ^= 1;
+			launches += issued;
+			in_turn += issued;
+			if (lane.step_i < job.steps.size()) continue;
+		}
+		// ---- the job's forward pass is submitted: its score (components) and its backtrace
+		HIP_TRY(hipGetLastError());
+		if (job.final) {
+			HIP_TRY(hipEventRecord(m.ev1, lane.stream));
+		} else {
+			HIP_TRY(hipMemcpyAsync(m.d_job_scores + job_id, lane.d_pr[lane.flip], 4, hipMemcpyDeviceToDevice, lane.stream));
+		}
+		if (job.unit_count)
+			hipLaunchKernelGGL(backtrace_kernel, dim3(1), dim3(1024), m.bt_lds, lane.stream, m.dp, m.d_units + job.unit_off, job.unit_count,
+			                   job.final ? 1u : 0u, m.d_path_index, m.d_path_trans, m.d_score);
+		HIP_TRY(hipGetLastError());
+		if (job.final) HIP_TRY(hipEventRecord(m.ev2, lane.stream));
+		++lane.job_i;
+		lane.step_i = 0;
+		in_turn += 1;
+	}
+	if (lane.job_i == lane.jobs.size() && lane.step_i != ~(size_t)0) {
+		lane.step_i = ~(size_t)0;  // lane finished (marker)
+		if (li) HIP_TRY(hipEventRecord(lane.done, lane.stream));
+		if (m.lanes_open) --m.lanes_open;
+	}
+	finished = lane.job_i == lane.jobs.size();
+	return WHAMD_OK;
+}
+
+// Resumable submission: the first call does the preamble, every call submits at most `budget` forward launches -- round
+// robin over the lanes, a few launches per lane and turn, so that the lanes' streams fill up side by side -- and the
+// call that runs out of work joins the lanes and appends the downloads.  Lets one host thread interleave the launch
+// sequences of several tables as well (whamd_dptable_enqueue_many).
 whamd_status_t DeviceTable::enqueue_some(const Problem& p, Solution& s, uint64_t budget, bool& done, std::string& msg) {
 	Impl& m = *impl_;
 	const uint32_t n = p.n_cols;
@@ -1672,8 +1865,6 @@ whamd_status_t DeviceTable::enqueue_some(const Problem& p, Solution& s, uint64_t
 	if (n) HIP_TRY(hipSetDevice(m.device));
 	if (!m.enqueue_open) {
 		m.enqueue_open = true;
-		m.next_step = 0;
-		m.flip = 0;
 		s.path_index.assign(n, 0);
 		s.path_trans.assign(n, 0);
 		m.launches = 0;
@@ -1683,7 +1874,7 @@ whamd_status_t DeviceTable::enqueue_some(const Problem& p, Solution& s, uint64_t
 			done = true;
 			return WHAMD_OK;
 		}
-		HIP_TRY(hipMemsetAsync(m.dp.keys, 0xFF, m.key_entries * 8, m.stream));
+		for (const Impl::Lane& lane : m.lanes) HIP_TRY(hipMemsetAsync(lane.d_keys, 0xFF, m.key_entries * 8, m.stream));
 		HIP_TRY(hipMemsetAsync(m.dp.last_keys, 0xFF, (size_t)MAX_T * 8, m.stream));
 		HIP_TRY(hipEventRecord(m.ev0, m.stream));
 		if (!m.plan.ped_columns.empty()) {
@@ -1693,62 +1884,33 @@ whamd_status_t DeviceTable::enqueue_some(const Problem& p, Solution& s, uint64_t
 			const uint32_t entries = (uint32_t)m.plan.columns.size() * RES_TABLE;
 			hipLaunchKernelGGL(resident_tables, dim3((entries + 255) / 256), dim3(256), 0, m.stream, m.dp.res_cols, (uint32_t)m.plan.columns.size(), m.dp.res_tables);
 		}
-	}
-	uint64_t launches = 0;
-	while (m.next_step < m.plan.steps.size() && launches < budget) {
-		const Step& step = m.plan.steps[m.next_step++];
-		const uint32_t* prev = m.d_pr[m.flip];  // every step reads d_pr[flip] and writes d_pr[flip ^ 1]
-		uint32_t* cur = m.d_pr[m.flip ^ 1];
-		m.flip ^= 1;
-		if (step.kind == 1) {
-			const ResSegment& sg = m.plan.segments[step.index];
-			if (sg.kind == 1) {
-				const size_t words = ((size_t)sg.ncols * (PED_LDSWORDS + PED_TABLE) + (size_t)sg.n_terms * 2 + 3) & ~(size_t)3;
-				const size_t lds_ped = words * 4 + 2 * ((size_t)16 << sg.max_l) + (size_t)sg.stage_words * 8;
-				ResSegment parg = sg;
-				parg.pad = step.index;
-				if (m.dp.dbg) hipLaunchKernelGGL(resident_segment_ped<true>, dim3(1u << sg.g), dim3(sg.threads), lds_ped, m.stream, m.dp, parg, prev, cur);
-				else hipLaunchKernelGGL(resident_segment_ped<false>, dim3(1u << sg.g), dim3(sg.threads), lds_ped, m.stream, m.dp, parg, prev, cur);
-				++launches;
-				continue;
-			}
-			const size_t lds = (size_t)sg.ncols * (64 + RES_TABLE) * 4 + 2 * ((size_t)4 << sg.max_l) + (size_t)sg.stage_words * 8;
-			ResSegment arg = sg;
-			arg.pad = step.index;
-			if (m.dp.dbg) hipLaunchKernelGGL(resident_segment<true>, dim3(1u << sg.g), dim3(sg.threads), lds, m.stream, m.dp, arg, prev, cur);
-			else hipLaunchKernelGGL(resident_segment<false>, dim3(1u << sg.g), dim3(sg.threads), lds, m.stream, m.dp, arg, prev, cur);
-			++launches;
-			continue;
+		if (m.lanes.size() > 1) {
+			HIP_TRY(hipEventRecord(m.ev_ready, m.stream));
+			for (size_t l = 1; l < m.lanes.size(); ++l) HIP_TRY(hipStreamWaitEvent(m.lanes[l].stream, m.ev_ready, 0));
 		}
-		const uint32_t c = step.index;
-		const DevColumn& d = m.cols[c];
-		if (d.mode == 0) {
-			const uint32_t threads = 1u << d.f;
-			const uint32_t block = std::min<uint32_t>(256, threads);
-			hipLaunchKernelGGL(m.fused, dim3(threads / block), dim3(block), 0, m.stream, m.dp, c, prev, cur);
-			++launches;
-		} else {
-			const uint64_t total = 1ull << (d.f + d.ebits - d.eloop);
-			const uint32_t block = (uint32_t)std::min<uint64_t>(256, (total + 63) / 64 * 64);
-			hipLaunchKernelGGL(m.keysfn, dim3((uint32_t)((total + block - 1) / block)), dim3(block), 0, m.stream, m.dp, c, prev, (uint32_t)total);
-			const uint32_t entries = (1u << d.f) * p.T;
-			const uint32_t fblock = std::min<uint32_t>(256, (entries + 63) / 64 * 64);
-			hipLaunchKernelGGL(column_finalize, dim3((entries + fblock - 1) / fblock), dim3(fblock), 0, m.stream, m.dp, c, cur, entries);
-			launches += 2;
+		for (Impl::Lane& lane : m.lanes) { lane.job_i = 0; lane.step_i = 0; lane.flip = 0; }
+		m.lanes_open = m.lanes.size();
+	}
+	constexpr uint64_t SLICE = 16;
+	uint64_t launches = 0;
+	while (m.lanes_open && launches < budget) {
+		for (size_t li = 0; li < m.lanes.size() && launches < budget; ++li) {
+			bool finished = false;
+			uint64_t issued = 0;
+			const whamd_status_t st = m.submit_lane(p, li, std::min<uint64_t>(SLICE, budget - launches), issued, finished, msg);
+			if (st != WHAMD_OK) return st;
+			launches += issued;
 		}
 	}
 	m.launches += launches;
-	if (m.next_step < m.plan.steps.size()) return WHAMD_OK;
-	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipEventRecord(m.ev1, m.stream));
-	hipLaunchKernelGGL(backtrace_kernel, dim3(1), dim3(1024), m.bt_lds, m.stream, m.dp, m.d_units, (uint32_t)m.units.size(),
-	                   m.d_path_index, m.d_path_trans, m.d_score);
-	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipEventRecord(m.ev2, m.stream));
+	if (m.lanes_open) return WHAMD_OK;
+	for (size_t l = 1; l < m.lanes.size(); ++l) HIP_TRY(hipStreamWaitEvent(m.stream, m.lanes[l].done, 0));
 	// downloads go to pinned host buffers: a copy into pageable memory would block this call until the stream drains
 	HIP_TRY(hipMemcpyAsync(m.h_pinned, m.d_path_index, (size_t)n * 4, hipMemcpyDeviceToHost, m.stream));
 	HIP_TRY(hipMemcpyAsync(m.h_pinned + n, m.d_path_trans, (size_t)n * 4, hipMemcpyDeviceToHost, m.stream));
 	HIP_TRY(hipMemcpyAsync(m.h_pinned + 2 * (size_t)n, m.d_score, 4, hipMemcpyDeviceToHost, m.stream));
+	if (m.jobs.size() > 1)
+		HIP_TRY(hipMemcpyAsync(m.h_pinned + 2 * (size_t)n + 1, m.d_job_scores + 1, (m.jobs.size() - 1) * 4, hipMemcpyDeviceToHost, m.stream));
 	HIP_TRY(hipEventRecord(m.ev3, m.stream));
 	m.enqueue_open = false;
 	done = true;
@@ -1765,6 +1927,7 @@ whamd_status_t DeviceTable::wait(const Problem& p, Solution& s, whamd_solve_stat
 	std::memcpy(s.path_index.data(), m.h_pinned, (size_t)n * 4);
 	std::memcpy(s.path_trans.data(), m.h_pinned + n, (size_t)n * 4);
 	s.optimal_score = m.h_pinned[2 * (size_t)n];
+	for (size_t j = 1; j < m.jobs.size(); ++j) s.optimal_score += m.h_pinned[2 * (size_t)n + j];  // connected components solved as their own jobs
 	float f01 = 0, f12 = 0, f03 = 0;
 	HIP_TRY(hipEventElapsedTime(&f01, m.ev0, m.ev1));
 	HIP_TRY(hipEventElapsedTime(&f12, m.ev1, m.ev2));

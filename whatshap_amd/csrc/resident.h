@@ -179,6 +179,10 @@ struct ResidentPlan {
 	std::vector<PedColumn> ped_columns;  // parallel to `columns` (filled for trio runs only)
 	std::vector<PedTerm> ped_terms;      // term pool of the trio runs
 	uint64_t n_resident_columns = 0;
+	// Single individual: indices into `steps` at which a new connected component of the ReadSet starts (no read is active
+	// across the boundary, b == 0; always contains 0).  Components are independent sub-problems whose optimal costs add
+	// up (whatshap_amd/blocks.py has the exactness argument); runs never span such a boundary.
+	std::vector<uint32_t> component_first_step;
 };
 
 // Plans the whole forward pass.  `resident` false -> every step is a per-column step.

@@ -124,6 +124,7 @@ void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, Reside
 		while (c1 < n && c1 - c < (uint32_t)RES_MAXCOLS) {
 			if (c1 + 1 == n) break;      // the last column needs the global optimum
 			if (c1 >= grid_end) break;   // a grid read is minimised out at this column
+			if (single && c1 > c && p.b[c1] == 0) break;  // next connected component: its own run (and maybe its own stream)
 			const uint32_t kc = p.k[c1];
 			if (kc < g) break;
 			const uint32_t Lb = p.b[c1] - g, Lf = p.f[c1] - g, Lk = kc - g;
@@ -426,6 +427,12 @@ void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, Reside
 		exit_grid.push_back(run_exit_grid);
 		plan.n_resident_columns += seg.ncols;
 		c = c1;
+	}
+	if (single) {
+		for (size_t si = 0; si < plan.steps.size(); ++si) {
+			const uint32_t c0 = plan.steps[si].kind == 1 ? plan.segments[plan.steps[si].index].c0 : plan.steps[si].index;
+			if (si == 0 || p.b[c0] == 0) plan.component_first_step.push_back((uint32_t)si);
+		}
 	}
 	// ---- exchange layouts between consecutive runs.  A re-layout is an all-to-all between workgroups; in logical
 	// order the writer of run A scatters 4..16-byte pieces (its grid reads sit in the middle of the index), which costs
