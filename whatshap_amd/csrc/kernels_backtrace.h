@@ -1,0 +1,281 @@
+// kernels_backtrace.h -- backtrace_kernel: follows the stored argmins from a job's last column to its first (src/pedigreedptable.cpp:137-173).
+// Included by dp_device.hip inside namespace whamd { namespace { ... } }: not a stand-alone header.
+// Backtrace (src/pedigreedptable.cpp:137-173); out: index / transmission per column, out_score[0] = optimum.
+// The steps of the forward plan are walked in reverse (`units`, newest first).  For a resident run the argmin bits the
+// path can touch all belong to ONE workgroup's record (the grid-read bits of the path do not change inside a run), so
+// the workgroup copies that record (a few KiB) into LDS with one coalesced load while it prefetches the NEXT run's
+// column records and the header of the run after that; one wave then follows the path with LDS latency instead of one
+// dependent HBM access per column.
+//
+// `with_last_column` != 0: units[0] is the table's last column (its optimum comes from P.last_keys), the walk starts at
+// units[1].  == 0: the units are the runs of ONE connected component that ends before the table does (its last column
+// projects onto a single entry): the walk starts at units[0] with entry 0 and no score is written -- several such
+// launches run side by side on different streams.
+__global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtUnit* __restrict__ units, uint32_t n_units,
+                                                         uint32_t with_last_column, uint32_t* __restrict__ path_index,
+                                                         uint32_t* __restrict__ path_trans, uint32_t* __restrict__ out_score) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+	uint32_t* recs0 = smem;                                   // 2 x RES_MAXCOLS * 32 words: column records (double buffer)
+	uint32_t* hdr = smem + 2 * RES_MAXCOLS * 32;              // 4 x 32 words: unit headers (ring)
+	uint32_t* xshare = hdr + 128;                             // 4 words
+	uint32_t* cells = xshare + 4;                             // RES_MAXCOLS words: local cell index of the path per column
+	uint32_t* tsarr = cells + RES_MAXCOLS;                    // RES_MAXCOLS words: transmission value of the path per column
+	unsigned long long* stage = reinterpret_cast<unsigned long long*>(tsarr + RES_MAXCOLS);
+	const uint32_t lane = threadIdx.x, NT = blockDim.x;
+	const uint32_t n = P.n_cols, T = P.T;
+	const uint32_t u_first = with_last_column ? 1u : 0u;
+	uint32_t x = 0, tprev = 0;
+	if (with_last_column) {
+		// optimum of the last column: first (rank(x), i) attaining the minimum (strict '<' scan, :306-315)
+		unsigned long long bestk = ~0ull;
+		uint32_t t = 0;
+		for (uint32_t i = 0; i < T; ++i) {
+			const unsigned long long key = P.last_keys[i];
+			if ((key >> 4) < (bestk >> 4)) { bestk = key; t = i; }
+		}
+		if (bestk == ~0ull) {  // unreachable for valid inputs (the host rejects Mendelian conflicts); keep defined output
+			if (lane == 0) out_score[0] = 0xFFFFFFFFu;
+			bestk = 0;
+		} else if (lane == 0) {
+			out_score[0] = (uint32_t)(bestk >> 32);
+		}
+		const uint32_t rlast = (uint32_t)(bestk >> 4) & 0x0FFFFFFFu;
+		x = rlast ^ (rlast >> 1);
+		tprev = (uint32_t)bestk & 15u;
+		if (lane == 0) {
+			path_index[n - 1] = x;
+			path_trans[n - 1] = t;
+		}
+	}
+	// every unit from u_first on yields x_c from x_{c+1}.
+	// prime the pipeline: headers of the first two units, records of the first
+	if (lane < 64) {
+		const uint32_t u = u_first + (lane >> 5);
+		if (u < n_units) hdr[(u & 3u) * 32 + (lane & 31u)] = reinterpret_cast<const uint32_t*>(units + u)[lane & 31u];
+	}
+	__syncthreads();
+	if (n_units > u_first && hdr[(u_first & 3u) * 32] == 1u) {
+		const uint32_t* h1 = hdr + (u_first & 3u) * 32;
+		const uint32_t* __restrict__ g1 = reinterpret_cast<const uint32_t*>(P.res_bt + h1[3]);
+		for (uint32_t i = lane; i < h1[2] * 32; i += NT) recs0[(u_first & 1u) * RES_MAXCOLS * 32 + i] = g1[i];
+	}
+	__syncthreads();
+	unsigned long long bt_load = 0, bt_walk = 0, bt_runs = 0, bt_a = 0, bt_b = 0, bt_c = 0;
+	for (uint32_t ui = u_first; ui < n_units; ++ui) {
+		const unsigned long long tb0 = P.dbg ? __builtin_readcyclecounter() : 0ull;
+		const uint32_t* h = hdr + (ui & 3u) * 32;
+		const uint32_t kind = h[0], c0 = h[1], ncols = h[2];
+		uint32_t* recs = recs0 + (ui & 1u) * RES_MAXCOLS * 32;
+		// prefetch: header of unit ui + 2, records of unit ui + 1 (its header arrived one iteration ago)
+		uint32_t hv = 0, wrun = 0;
+		const bool hload = lane < 32 && ui + 2 < n_units;
+		if (hload) hv = reinterpret_cast<const uint32_t*>(units + ui + 2)[lane];
+		const uint32_t* hn = hdr + ((ui + 1) & 3u) * 32;
+		const bool next_run = ui + 1 < n_units && hn[0] == 1u;
+		const uint32_t nrec = next_run ? hn[2] * 32 : 0u;
+		const uint32_t* __restrict__ gnext = reinterpret_cast<const uint32_t*>(P.res_bt + (next_run ? hn[3] : 0u));
+		uint32_t rv[2];
+#pragma unroll
+		for (int u = 0; u < 2; ++u) { const uint32_t i = u * NT + lane; rv[u] = i < nrec ? gnext[i] : 0u; }
+		if (kind == 0) {
+			// ---- one column through the column kernels' records (global loads; rare in steady state)
+			const uint32_t c = c0;
+			// header words of a column unit: 4 f, 5 mode, 6 nplanes, 7 ebits, 8/9 record offset, 10 nseg_fwd, 11 nseg_end,
+			// 12..27 deposit runs (if word 28 is set; else they are read from the column descriptor)
+			const uint32_t cf = h[4], cmode = h[5], cnplanes = h[6], cebits = h[7], nsf = h[10], nse = h[11];
+			const unsigned long long cbt = ((unsigned long long)h[9] << 32) | h[8];
+			const uint32_t* segs = h[28] ? (h + 12) : (P.segs + P.cols[c].seg_off);
+			const uint32_t y = x & ((1u << cf) - 1u);
+			uint32_t xp, aj;
+			if (cmode == 0) {
+				const unsigned long long* planes = reinterpret_cast<const unsigned long long*>(P.bt + cbt);
+				const uint32_t words = 1u << (cf - 6);
+				unsigned long long wv[8];
+#pragma unroll
+				for (int p = 0; p < 8; ++p) wv[p] = (uint32_t)p < cnplanes ? planes[(size_t)(p * T + tprev) * words + (y >> 6)] : 0ull;
+				uint32_t v = 0;
+#pragma unroll
+				for (int p = 0; p < 8; ++p) v |= (uint32_t)((wv[p] >> (y & 63u)) & 1ull) << p;
+				const uint32_t e = v & ((1u << cebits) - 1u);
+				aj = v >> cebits;
+				xp = deposit(y, segs, nsf) | deposit(e, segs + nsf, nse);
+			} else {
+				const uint32_t raw = reinterpret_cast<const uint32_t*>(P.bt + cbt)[(size_t)y * T + tprev];
+				const uint32_t r = raw >> 4;
+				xp = r ^ (r >> 1);
+				aj = raw & 15u;
+			}
+			if (lane == 0) {
+				path_index[c] = xp;
+				path_trans[c] = tprev;
+			}
+			tprev = aj;
+			x = xp;
+		} else {
+			// ---- resident run [c0, c0 + ncols): this workgroup's record -> LDS
+			const uint32_t g = h[4], Lf_last = h[5], stage_words = h[6], n_wext = h[7];
+			const uint32_t yexit = x & ((1u << (Lf_last + g)) - 1u);
+			uint32_t w = 0;
+			for (uint32_t i = 0; i < n_wext; ++i) {
+				const uint32_t r = h[12 + i];
+				w |= ((yexit >> (r & 31u)) & ((1u << ((r >> 16) & 31u)) - 1u)) << ((r >> 8) & 31u);
+			}
+			wrun = w;
+			const unsigned long long* __restrict__ gst = reinterpret_cast<const unsigned long long*>(
+				P.bt + (((unsigned long long)h[9] << 32) | h[8])) + (size_t)w * stage_words;
+			unsigned long long sv[2];
+#pragma unroll
+			for (int u = 0; u < 2; ++u) { const uint32_t i = u * NT + lane; sv[u] = i < stage_words ? gst[i] : 0ull; }
+#pragma unroll
+			for (int u = 0; u < 2; ++u) { const uint32_t i = u * NT + lane; if (i < stage_words) stage[i] = sv[u]; }
+			for (uint32_t i = 2 * NT + lane; i < stage_words; i += NT) stage[i] = gst[i];
+		}
+		// land the prefetches
+		if (hload) hdr[((ui + 2) & 3u) * 32 + lane] = hv;
+		{
+			uint32_t* rnext = recs0 + ((ui + 1) & 1u) * RES_MAXCOLS * 32;
+#pragma unroll
+			for (int u = 0; u < 2; ++u) { const uint32_t i = u * NT + lane; if (i < nrec) rnext[i] = rv[u]; }
+			for (uint32_t i = 2 * NT + lane; i < nrec; i += NT) rnext[i] = gnext[i];
+		}
+		__syncthreads();
+		const unsigned long long tb1 = P.dbg ? __builtin_readcyclecounter() : 0ull;
+		if (kind == 1) {
+			if (lane < 64) {  // one wave follows the path; the others only helped with the copies
+				// local exit index of the path
+				const uint32_t yexit = x & ((1u << (h[5] + h[4])) - 1u);
+				uint32_t l = 0;
+				for (uint32_t i = 0; i < h[10]; ++i) {
+					const uint32_t r = h[18 + i];
+					l |= ((yexit >> (r & 31u)) & ((1u << ((r >> 16) & 31u)) - 1u)) << ((r >> 8) & 31u);
+				}
+				// sequential part, in local index space: only columns where a read ends touch the record.  Lanes keep the
+				// per-column parameters in registers; the loop fetches them with v_readlane (off the dependent chain), so the
+				// chain per visited column is: mask, record byte from LDS, bit insert.
+				const unsigned long long tw0 = P.dbg ? __builtin_readcyclecounter() + (l & 0u) : 0ull;
+				const uint32_t n_active = h[11] & 0xFFFFu, simple = h[11] >> 16;
+				const uint32_t* rmine = recs + (lane < ncols ? lane : 0u) * 32;
+				uint32_t tcur = tprev, mycell = 0, myts = 0;
+				if (simple == 2u) {
+					// trio, at most one read ends per column: every column reads one record byte (the transmission argmin lives
+					// there), the chain per column is mask, byte, (bit insert); parameters by v_readlane from lane ci
+					const uint4 q0 = *reinterpret_cast<const uint4*>(rmine);      // Lf, ebits, layout, stage_off
+					const uint32_t p_mask = (1u << q0.x) - 1u, p_soff = q0.w * 8u, p_eb = q0.y | (rmine[5] << 8);
+					const uint8_t* stage8 = reinterpret_cast<const uint8_t*>(stage);
+					for (uint32_t ci = ncols; ci-- > 0;) {
+						const uint32_t s_mask = __builtin_amdgcn_readlane(p_mask, ci), s_soff = __builtin_amdgcn_readlane(p_soff, ci),
+						               s_eb = __builtin_amdgcn_readlane(p_eb, ci);
+						const uint32_t lout = l & s_mask;
+						const uint32_t fld = stage8[s_soff + lout * 4u + tcur];
+						const uint32_t e0 = s_eb >> 8;
+						const uint32_t with_bit = insert_zero(lout, e0) | ((fld & 1u) << e0);
+						const uint32_t cell = (s_eb & 255u) ? with_bit : lout;
+						if (lane == ci) { mycell = cell; myts = tcur; }
+						tcur = (fld >> 3) & 3u;
+						l = cell;
+					}
+				} else if (simple) {
+					// single individual, every record one byte per thread: the chain visits only the columns in which a read ends
+					// (ResBacktrace kpos / src / cmask / kcol); lane k holds the parameters of chain position k
+					const uint32_t kc = rmine[31] < ncols ? rmine[31] : 0u;
+					const uint32_t* rk = recs + kc * 32;
+					const uint32_t c_cmask = rk[30], c_soff = rk[3] * 8u, c_e0 = rk[5];
+					const uint32_t my_kpos = rmine[28], my_src = rmine[29], my_cmask = rmine[30];
+					const uint8_t* stage8 = reinterpret_cast<const uint8_t*>(stage);
+					const uint32_t l_exit = l;
+					for (uint32_t k = 0; k < n_active; ++k) {
+						const uint32_t s_cmask = __builtin_amdgcn_readlane(c_cmask, k), s_soff = __builtin_amdgcn_readlane(c_soff, k),
+						               s_e0 = __builtin_amdgcn_readlane(c_e0, k);
+						const uint32_t lout = l & s_cmask;
+						const uint32_t byte = stage8[s_soff + (lout >> 2)];
+						const uint32_t cell = insert_zero(lout, s_e0) | (((byte >> (lout & 3u)) & 1u) << s_e0);
+						if (my_kpos == k) mycell = cell;
+						l = cell;
+					}
+					// columns without an ending read: the cell of the next active column above (or the exit index), masked
+					const uint32_t from = __shfl(mycell, my_src == RES_BT_NONE ? 0u : my_src);
+					if (my_kpos == RES_BT_NONE) mycell = (my_src == RES_BT_NONE ? l_exit : from) & my_cmask;
+				} else {
+					const uint4 q0 = *reinterpret_cast<const uint4*>(rmine);      // Lf, ebits, layout, stage_off
+					const uint4 q1 = *reinterpret_cast<const uint4*>(rmine + 4);  // nwords, epos0, epos1, epos2
+					const uint32_t p_mask = (1u << q0.x) - 1u, p_eb = q0.y | (q0.z << 8), p_soff = q0.w * 8u, p_e0 = q1.y, p_e1 = q1.z, p_e2 = q1.w, p_nw = q1.x;
+					const uint8_t* stage8 = reinterpret_cast<const uint8_t*>(stage);
+					for (uint32_t ci = ncols; ci-- > 0;) {
+						const uint32_t s_mask = __builtin_amdgcn_readlane(p_mask, ci), s_eb = __builtin_amdgcn_readlane(p_eb, ci);
+						const uint32_t lout = l & s_mask;
+						uint32_t cell = lout;
+						const uint32_t eb = s_eb & 255u, layout = s_eb >> 8;
+						if (layout == 2u) {  // trio: one byte per (entry, transmission value): ending-read bits | argj << 3
+							const uint32_t s_soff = __builtin_amdgcn_readlane(p_soff, ci);
+							const uint32_t fld = stage8[s_soff + lout * 4u + tcur] & 31u;
+							if (eb) {
+								const uint32_t epos[3] = {(uint32_t)__builtin_amdgcn_readlane(p_e0, ci), (uint32_t)__builtin_amdgcn_readlane(p_e1, ci),
+								                          (uint32_t)__builtin_amdgcn_readlane(p_e2, ci)};
+								uint32_t bits = 0;
+	#pragma unroll
+								for (int q = 0; q < 3; ++q) {
+									if ((uint32_t)q < eb) {
+										cell = insert_zero(cell, epos[q]);
+										bits |= ((fld >> q) & 1u) << epos[q];
+									}
+								}
+								cell |= bits;
+							}
+							if (lane == ci) myts = tcur;
+							tcur = fld >> 3;
+						} else if (eb) {
+							const uint32_t s_soff = __builtin_amdgcn_readlane(p_soff, ci), s_e0 = __builtin_amdgcn_readlane(p_e0, ci);
+							if (layout == 1u) {  // one byte per thread: bit (lout & 3) of byte lout >> 2
+								const uint32_t byte = stage8[s_soff + (lout >> 2)];
+								cell = insert_zero(lout, s_e0) | (((byte >> (lout & 3u)) & 1u) << s_e0);
+							} else {             // ballot planes, up to 3 ending reads (ascending positions)
+								const uint32_t epos[3] = {s_e0, (uint32_t)__builtin_amdgcn_readlane(p_e1, ci), (uint32_t)__builtin_amdgcn_readlane(p_e2, ci)};
+								const uint32_t s_nw = __builtin_amdgcn_readlane(p_nw, ci);
+								uint32_t bits = 0;
+	#pragma unroll
+								for (int q = 0; q < 3; ++q) {
+									if ((uint32_t)q < eb) {
+										cell = insert_zero(cell, epos[q]);
+										const unsigned long long word = stage[(s_soff >> 3) + q * s_nw + (lout >> 6)];
+										bits |= (uint32_t)((word >> (lout & 63u)) & 1ull) << epos[q];
+									}
+								}
+								cell |= bits;
+							}
+						}
+						if (lane == ci) mycell = cell;
+						l = cell;
+					}
+				}
+				const unsigned long long tw1 = P.dbg ? __builtin_readcyclecounter() + (l & 0u) : 0ull;
+				// logical indices, one lane per column
+				uint32_t xl = 0;
+				if (lane < ncols) {
+					const uint32_t* rb = recs + lane * 32;
+					const uint32_t cell = mycell;
+					const uint32_t ng = rb[8], nl = rb[9];
+					for (uint32_t i = 0; i < ng; ++i) {
+						const uint32_t r = rb[10 + i];
+						xl |= ((wrun >> (r & 31u)) & ((1u << ((r >> 16) & 31u)) - 1u)) << ((r >> 8) & 31u);
+					}
+					for (uint32_t i = 0; i < nl; ++i) {
+						const uint32_t r = rb[18 + i];
+						xl |= ((cell >> (r & 31u)) & ((1u << ((r >> 16) & 31u)) - 1u)) << ((r >> 8) & 31u);
+					}
+					path_index[c0 + lane] = xl;
+					path_trans[c0 + lane] = rb[2] == 2u ? myts : 0u;
+				}
+				if (lane == 0) { xshare[0] = xl; xshare[1] = tcur; }
+				if (P.dbg) { const unsigned long long tw2 = __builtin_readcyclecounter() + (xl & 0u); bt_a += tw0 - tb1; bt_b += tw1 - tw0; bt_c += tw2 - tw1; }
+			}
+			__syncthreads();
+			x = xshare[0];
+			tprev = xshare[1];
+			if (P.dbg) { bt_load += tb1 - tb0; bt_walk += __builtin_readcyclecounter() - tb1; bt_runs++; }
+		}
+	}
+	if (P.dbg && lane == 0) {
+		unsigned long long* d = P.dbg + P.dbg_wg_off + 4 * 512 * 2;
+		d[0] = bt_load; d[1] = bt_walk; d[2] = bt_runs; d[3] = bt_a; d[4] = bt_b; d[5] = bt_c;
+	}
+}
