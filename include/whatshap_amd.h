@@ -216,6 +216,7 @@ typedef struct whamd_plan_summary {
 	uint64_t max_workgroups;      /* largest grid of a run */
 	uint64_t max_lds_bytes;       /* largest dynamic LDS request of a run */
 	uint64_t backtrace_bytes;     /* size of the backtrace arena */
+	uint64_t n_components;        /* connected components the device driver may run as independent jobs (single individual) */
 	uint32_t max_coverage;
 	uint32_t invariants_ok;       /* 1 if the internal consistency checks passed */
 } whamd_plan_summary;

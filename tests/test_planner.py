@@ -76,3 +76,22 @@ def test_invariants_on_random_small_instances():
         assert s["invariants_ok"] == 1
         checked += s["n_runs"] > 0
     assert checked > 20
+
+
+def test_components_are_found_and_no_run_spans_one():
+    """Single individual: the planner records where connected components start (the device driver runs them as independent
+    jobs) and cuts runs there; the count equals what the Python block splitter finds."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from dist_worker import multi_block_instance
+    from whatshap_amd.blocks import split_independent_blocks
+
+    for seed in range(8):
+        whole = multi_block_instance(seed)
+        s = _native.plan_summary(whole)
+        assert s["invariants_ok"] == 1
+        assert s["n_components"] == len(split_independent_blocks(whole))
+    single = synthetic_block(n_variants=600, coverage=12, seed=3)
+    assert _native.plan_summary(single)["n_components"] == 1
+    trio = synthetic_block(n_variants=300, coverage=9, seed=3, trio=True)
+    assert _native.plan_summary(trio)["n_components"] == 0  # coupled through the transmission vector: never split

@@ -264,7 +264,21 @@ whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uin
 	s.n_steps = plan.steps.size();
 	s.n_runs = plan.segments.size();
 	s.max_coverage = p.max_k;
+	s.n_components = plan.component_first_step.size();
 	bool ok = true;
+	// components: boundaries are exactly the steps whose first column no read enters, and no run spans one
+	if (!plan.component_first_step.empty()) {
+		size_t k = 0;
+		for (size_t si = 0; si < plan.steps.size(); ++si) {
+			const Step& step = plan.steps[si];
+			const uint32_t c0 = step.kind == 1 ? plan.segments[step.index].c0 : step.index;
+			const bool boundary = si == 0 || p.b[c0] == 0;
+			if (boundary) { ok = ok && k < plan.component_first_step.size() && plan.component_first_step[k] == si; ++k; }
+			if (step.kind == 1)
+				for (uint32_t i = 1; i < plan.segments[step.index].ncols; ++i) ok = ok && p.b[c0 + i] != 0;
+		}
+		ok = ok && k == plan.component_first_step.size();
+	}
 	std::vector<uint8_t> seen(p.n_cols, 0);
 	uint32_t expect = 0;
 	for (const Step& step : plan.steps) {
