@@ -482,16 +482,18 @@ class PedigreeDPTable:
         transmission vector (core.pyx:381-404, src/pedigreedptable.cpp:344-388)."""
         a0, a1, q, tv, sid, positions = self._merged()
         results = []
+        position_list = positions.tolist()
         for i in range(len(sid)):
             rs = ReadSet()
+            quality_list = q[i].tolist()
             for h, alleles in ((0, a0), (1, a1)):
                 read = Read(f"superread_{h}_{i}", -1, -1, int(sid[i]))
-                read._positions = [int(p) for p in positions]
-                read._alleles = [int(a) for a in alleles[i]]
-                read._qualities = [int(x) for x in q[i]]
+                read._positions = position_list  # ReadSet.add copies the read (and its lists)
+                read._alleles = alleles[i].tolist()
+                read._qualities = quality_list
                 rs.add(read)
             results.append(rs)
-        return results, [int(t) for t in tv]
+        return results, tv.tolist()
 
     def get_optimal_cost(self) -> int:
         return sum(t.optimal_score() for t in self._tables)
