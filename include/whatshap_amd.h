@@ -196,8 +196,8 @@ whamd_status_t whamd_dptable_get_stats(const whamd_dptable* table, whamd_solve_s
  *   "path"          "auto" (default) | "resident" | "column" (one launch per column, the general path) | "column_keys"
  *   "resident_l"    preferred log2 slice size of the run kernels
  *   "resident_fold" "0" disables folding of columns without an ending read
- *   "lanes"         streams over which the connected components of a single-individual table are spread (default 4;
- *                   "1" solves them one after the other) */
+ *   "lanes"         how many connected components of a single-individual table advance side by side (default 32, their
+ *                   runs go out as batched launches; "1" solves them one after the other) */
 whamd_status_t whamd_dptable_set_option(whamd_dptable* table, const char* key, const char* value);
 
 /*

@@ -515,11 +515,11 @@ def test_tables_created_and_solved_from_several_host_threads():
     assert got == want
 
 
-def test_connected_components_on_their_own_streams():
+def test_connected_components_as_independent_jobs():
     """A single-individual ReadSet made of many connected components, solved as ONE table: every component but the
-    last becomes its own job (forward steps from cost 0, score added on the host, backtrace from entry 0) and the jobs
-    are spread over streams.  Cost, path, partitioning and superreads equal the oracle's for the whole ReadSet, for
-    every number of streams."""
+    last becomes its own job (forward steps from cost 0, score added on the host, backtrace from entry 0); the jobs are
+    spread over lanes that advance in lockstep (batched launches).  Cost, path, partitioning and superreads equal the
+    oracle's for the whole ReadSet, for every number of lanes."""
     import os, sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
     from gpu_multiblock import chromosome
@@ -531,7 +531,7 @@ def test_connected_components_on_their_own_streams():
         whole = _variant_of(whole, quality=np.where(rng.random(whole.var_quality.size) < 0.2, whole.var_quality * np.uint32(700), whole.var_quality).astype(np.uint32),
                             genotype=rng.choice([0, 1, 1, 1, 2], size=(1, whole.n_variants)).astype(np.uint8))
         want = table_solution(oracle.OracleTable(whole))
-        for lanes in (1, 2, 4, 7):
+        for lanes in (1, 2, 7, 32):
             t = _native.NativeTable(whole, solve=False)
             t.set_option("lanes", str(lanes))
             for _ in range(2):  # solved twice: the lanes' scratch must be re-armed

@@ -438,9 +438,9 @@ class PedigreeDPTable:
     ``whamd_dptable_set_option``) and ``split_blocks`` (default off): a table without trios is cut wherever no read
     is active across a column boundary (exact, including tie-breaks -- whatshap_amd/blocks.py) and the independent
     blocks go through the host-side work queue, ``max_in_flight`` at a time on their own streams.  Off by default
-    because one table already spreads its connected components over four streams on the device
+    because one table already runs its connected components side by side on the device
     while every extra table costs ~4 ms of allocation and stream set-up (200 components of coverage 15, 160k columns:
-    0.04 s as one table, 1.0 s as 200 tables); separate tables pay off for few, large blocks (bench.py --blocks-per-gpu).
+    0.012 s as one table, 1.0 s as 200 tables); separate tables pay off for few, large blocks (bench.py --blocks-per-gpu).
     """
 
     def __init__(self, readset, recombcost, pedigree: Pedigree, distrust_genotypes: bool = False, positions=None,

@@ -98,41 +98,51 @@ struct DeviceTable::Impl {
 	uint64_t launches = 0;
 	bool enqueue_open = false;  // resumable enqueue (enqueue_some)
 	uint32_t* h_pinned = nullptr;  // [2 n + 1 + jobs]: path index, path transmission, score of the final job, scores of the others
-	// A job is a sequence of forward steps followed by ONE backtrace launch.  Job 0 ("final") is the last connected
-	// component (it ends with the table's last column, whose optimum comes from the key scratch); every other job is
-	// one earlier connected component: it starts from cost 0, its last column projects onto a single entry -- that value
-	// is added on the host -- and its backtrace starts at entry 0.  Jobs are independent, so they are spread over lanes (streams) and overlap.
+	// A job is a sequence of forward steps with its own backtrace.  Job 0 ("final") is the last connected component (it
+	// ends with the table's last column, whose optimum comes from the key scratch); every other job is one earlier
+	// connected component: it starts from cost 0, its last column projects onto a single entry -- that value is added on
+	// the host -- and its backtrace starts at entry 0.  Jobs are independent: they are spread over lanes (private
+	// exchange buffers and key scratch) and the lanes advance in lockstep, one *super-step* at a time: the runs of a
+	// super-step go out as ONE batched launch (resident_batch), per-column steps as launches of their own; one backtrace
+	// launch at the end walks all jobs, one workgroup each.
 	struct Job {
 		std::vector<uint32_t> steps;  // indices into plan.steps, execution order
 		uint32_t unit_off = 0, unit_count = 0;
 		bool final = false;
 	};
 	struct Lane {
-		hipStream_t stream = nullptr;  // lane 0: the table's stream
-		hipEvent_t done = nullptr;
 		uint32_t* d_pr[2] = {nullptr, nullptr};
-		unsigned long long* d_keys = nullptr;  // atomic-min scratch of the per-column kernels (one per lane: components overlap)
+		unsigned long long* d_keys = nullptr;  // atomic-min scratch of the per-column kernels
 		std::vector<uint32_t> jobs;
-		size_t job_i = 0, step_i = 0;  // cursor of the resumable enqueue
-		uint32_t flip = 0;             // every step reads d_pr[flip] and writes d_pr[flip ^ 1]
+	};
+	struct Single {        // a per-column step inside a super-step
+		uint32_t lane, step, flip;
+		bool zero_prev;    // first step of its job: the entry it may read must hold cost 0
+		int32_t score_job; // >= 0: last step of that (non-final) job: copy its single exit value aside
+	};
+	struct SuperStep {
+		uint32_t entry_off = 0, entry_count = 0, grid_x = 0, threads = 0;
+		size_t lds = 0;
+		std::vector<Single> singles;
 	};
 	std::vector<Job> jobs;
 	std::vector<Lane> lanes;
+	std::vector<SuperStep> schedule;
+	std::vector<ResBatchEntry> entries;
+	ResBatchEntry* d_entries = nullptr;
+	BtJob* d_btjobs = nullptr;
 	uint32_t* d_job_scores = nullptr;
-	hipEvent_t ev_ready = nullptr;
-	int max_lanes = 4;  // measured: 4 streams saturate the dispatch rate (~200 k launches/s); more streams (or more hardware queues) lose
-	size_t lanes_open = 0;
+	int max_lanes = 32;
+	size_t next_super = 0;  // cursor of the resumable enqueue
 
-	void launch_step(const Problem& p, const Step& step, const Lane& lane, const uint32_t* prev, uint32_t* cur, uint64_t& launches);
-	whamd_status_t submit_lane(const Problem& p, size_t li, uint64_t max_launches, uint64_t& launches, bool& finished, std::string& msg);
+	void launch_column_step(const Problem& p, const Step& step, const Lane& lane, const uint32_t* prev, uint32_t* cur, uint64_t& launches);
+	void launch_run(const ResBatchEntry& e, uint32_t step_index, uint64_t& launches);
 
 	void release_lanes() {
-		for (size_t i = 1; i < lanes.size(); ++i) {
-			if (lanes[i].done) (void)hipEventDestroy(lanes[i].done);
-			if (lanes[i].stream) (void)hipStreamDestroy(lanes[i].stream);
-		}
 		lanes.clear();
 		jobs.clear();
+		schedule.clear();
+		entries.clear();
 	}
 
 	void release() {
@@ -158,7 +168,6 @@ DeviceTable::~DeviceTable() {
 		if (impl_->ev1) (void)hipEventDestroy(impl_->ev1);
 		if (impl_->ev2) (void)hipEventDestroy(impl_->ev2);
 		if (impl_->ev3) (void)hipEventDestroy(impl_->ev3);
-		if (impl_->ev_ready) (void)hipEventDestroy(impl_->ev_ready);
 		if (impl_->stream) (void)hipStreamDestroy(impl_->stream);
 		delete impl_;
 	}
@@ -168,7 +177,7 @@ void DeviceTable::release_device() {
 	Impl& m = *impl_;
 	(void)hipSetDevice(m.device);
 	m.release();
-	for (hipEvent_t* e : {&m.ev0, &m.ev1, &m.ev2, &m.ev3, &m.ev_ready}) {
+	for (hipEvent_t* e : {&m.ev0, &m.ev1, &m.ev2, &m.ev3}) {
 		if (*e) (void)hipEventDestroy(*e);
 		*e = nullptr;
 	}
@@ -204,7 +213,7 @@ bool DeviceTable::set_path(const std::string& path) {
 }
 
 void DeviceTable::set_l_pref(int l) { impl_->l_pref = std::max(4, std::min(l, RES_LMAX)); }
-void DeviceTable::set_lanes(int n) { impl_->max_lanes = n < 1 ? 1 : (n > 16 ? 16 : n); }
+void DeviceTable::set_lanes(int n) { impl_->max_lanes = n < 1 ? 1 : (n > 64 ? 64 : n); }
 
 void DeviceTable::set_fold(bool v) { impl_->fold = v; }
 
@@ -433,7 +442,10 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	HIP_TRY(hipHostMalloc((void**)&m.h_pinned, (2 * (size_t)n + 4 + m.jobs.size()) * sizeof(uint32_t), hipHostMallocDefault));
 	HIP_TRY(alloc((void**)&m.d_job_scores, (m.jobs.size() + 1) * 4));
 	{   // lanes: longest job first to the least loaded lane; lane 0 always runs the final job
-		const size_t n_lanes = std::max<size_t>(1, std::min<size_t>((size_t)m.max_lanes, m.jobs.size()));
+		// at most 1 GiB of private exchange buffers (coverage 23: 64 MiB per lane)
+		const size_t lane_bytes = 2 * ((size_t)(1ull << max_f) * p.T * 4);
+		const size_t by_memory = std::max<size_t>(1, ((size_t)1 << 30) / std::max<size_t>(lane_bytes, 1));
+		const size_t n_lanes = std::max<size_t>(1, std::min<size_t>(std::min<size_t>((size_t)m.max_lanes, by_memory), m.jobs.size()));
 		m.lanes.assign(n_lanes, Impl::Lane());
 		std::vector<uint64_t> load(n_lanes, 0);
 		std::vector<uint32_t> order;
@@ -446,18 +458,63 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 			m.lanes[l].jobs.push_back(j);
 			load[l] += m.jobs[j].steps.size() + 1;
 		}
-		m.lanes[0].stream = m.stream;
 		m.lanes[0].d_pr[0] = m.d_pr[0];
 		m.lanes[0].d_pr[1] = m.d_pr[1];
+		m.lanes[0].d_keys = (unsigned long long*)d_keys;
 		for (size_t l = 1; l < n_lanes; ++l) {
-			HIP_TRY(hipStreamCreateWithFlags(&m.lanes[l].stream, hipStreamNonBlocking));
-			HIP_TRY(hipEventCreateWithFlags(&m.lanes[l].done, hipEventDisableTiming));
 			HIP_TRY(alloc((void**)&m.lanes[l].d_pr[0], (size_t)(1ull << max_f) * p.T * 4));
 			HIP_TRY(alloc((void**)&m.lanes[l].d_pr[1], (size_t)(1ull << max_f) * p.T * 4));
 			HIP_TRY(alloc((void**)&m.lanes[l].d_keys, m.key_entries * 8));
 		}
-		m.lanes[0].d_keys = (unsigned long long*)d_keys;
-		if (!m.ev_ready) HIP_TRY(hipEventCreateWithFlags(&m.ev_ready, hipEventDisableTiming));
+	}
+	{   // schedule: the lanes advance in lockstep; super-step t holds step t of every lane that still has one
+		struct Cursor { size_t job_i = 0, step_i = 0; uint32_t flip = 0; };
+		std::vector<Cursor> cur(m.lanes.size());
+		for (;;) {
+			Impl::SuperStep ss;
+			ss.entry_off = (uint32_t)m.entries.size();
+			for (size_t li = 0; li < m.lanes.size(); ++li) {
+				Impl::Lane& lane = m.lanes[li];
+				Cursor& c = cur[li];
+				if (c.job_i == lane.jobs.size()) continue;
+				const uint32_t job_id = lane.jobs[c.job_i];
+				const Impl::Job& job = m.jobs[job_id];
+				const uint32_t si = job.steps[c.step_i];
+				const bool first = c.step_i == 0, last = c.step_i + 1 == job.steps.size();
+				const Step& step = m.plan.steps[si];
+				if (step.kind == 1) {
+					ResBatchEntry e{};
+					e.sg = m.plan.segments[step.index];
+					e.sg.pad = step.index;
+					if (first) e.sg.has_prev = 0;  // a job starts from cost 0
+					e.prev = lane.d_pr[c.flip];
+					e.cur = lane.d_pr[c.flip ^ 1];
+					e.score_out = (last && !job.final) ? m.d_job_scores + job_id : nullptr;
+					const size_t lds = e.sg.kind == 1
+						? ((((size_t)e.sg.ncols * (PED_LDSWORDS + PED_TABLE) + (size_t)e.sg.n_terms * 2 + 3) & ~(size_t)3) * 4 + 2 * ((size_t)16 << e.sg.max_l) + (size_t)e.sg.stage_words * 8)
+						: ((size_t)e.sg.ncols * (64 + RES_TABLE) * 4 + 2 * ((size_t)4 << e.sg.max_l) + (size_t)e.sg.stage_words * 8);
+					ss.lds = std::max(ss.lds, lds);
+					ss.grid_x = std::max(ss.grid_x, 1u << e.sg.g);
+					ss.threads = std::max(ss.threads, e.sg.threads);
+					m.entries.push_back(e);
+					++ss.entry_count;
+				} else {
+					ss.singles.push_back(Impl::Single{(uint32_t)li, si, c.flip, first, (last && !job.final) ? (int32_t)job_id : -1});
+				}
+				c.flip ^= 1;
+				if (last) { ++c.job_i; c.step_i = 0; } else ++c.step_i;
+			}
+			if (!ss.entry_count && ss.singles.empty()) break;
+			m.schedule.push_back(std::move(ss));
+		}
+		void* d_entries = nullptr;
+		HIP_TRY(up(&d_entries, m.entries.data(), m.entries.size() * sizeof(ResBatchEntry)));
+		m.d_entries = (ResBatchEntry*)d_entries;
+		std::vector<BtJob> btjobs;
+		for (const Impl::Job& job : m.jobs) btjobs.push_back(BtJob{job.unit_off, job.unit_count, job.final ? 1u : 0u, 0u});
+		void* d_btjobs = nullptr;
+		HIP_TRY(up(&d_btjobs, btjobs.data(), btjobs.size() * sizeof(BtJob)));
+		m.d_btjobs = (BtJob*)d_btjobs;
 	}
 	HIP_TRY(hipStreamSynchronize(m.stream));
 	m.dp.cols = m.d_cols;
@@ -512,100 +569,50 @@ whamd_status_t DeviceTable::enqueue(const Problem& p, Solution& s, std::string& 
 }
 
 // Launches one forward step on a lane's stream: reads `prev`, writes `cur`.
-void DeviceTable::Impl::launch_step(const Problem& p, const Step& step, const Lane& lane, const uint32_t* prev, uint32_t* cur,
-                                    uint64_t& launches) {
+// One per-column step (column_step_fused, or column_step_keys + column_finalize) of a lane.
+void DeviceTable::Impl::launch_column_step(const Problem& p, const Step& step, const Lane& lane, const uint32_t* prev, uint32_t* cur,
+                                           uint64_t& launches) {
 	Impl& m = *this;
-	hipStream_t stream = lane.stream;
 	DevProblem dp = m.dp;
 	dp.keys = lane.d_keys;
-	if (step.kind == 1) {
-		const ResSegment& sg = m.plan.segments[step.index];
-		if (sg.kind == 1) {
-			const size_t words = ((size_t)sg.ncols * (PED_LDSWORDS + PED_TABLE) + (size_t)sg.n_terms * 2 + 3) & ~(size_t)3;
-			const size_t lds_ped = words * 4 + 2 * ((size_t)16 << sg.max_l) + (size_t)sg.stage_words * 8;
-			ResSegment parg = sg;
-			parg.pad = step.index;
-			if (m.dp.dbg) hipLaunchKernelGGL(resident_segment_ped<true>, dim3(1u << sg.g), dim3(sg.threads), lds_ped, stream, dp, parg, prev, cur);
-			else hipLaunchKernelGGL(resident_segment_ped<false>, dim3(1u << sg.g), dim3(sg.threads), lds_ped, stream, dp, parg, prev, cur);
-			launches += 1;
-			return;
-		}
-		const size_t lds = (size_t)sg.ncols * (64 + RES_TABLE) * 4 + 2 * ((size_t)4 << sg.max_l) + (size_t)sg.stage_words * 8;
-		ResSegment arg = sg;
-		arg.pad = step.index;
-		if (m.dp.dbg) hipLaunchKernelGGL(resident_segment<true>, dim3(1u << sg.g), dim3(sg.threads), lds, stream, dp, arg, prev, cur);
-		else hipLaunchKernelGGL(resident_segment<false>, dim3(1u << sg.g), dim3(sg.threads), lds, stream, dp, arg, prev, cur);
-		launches += 1;
-		return;
-	}
 	const uint32_t c = step.index;
 	const DevColumn& d = m.cols[c];
 	if (d.mode == 0) {
 		const uint32_t threads = 1u << d.f;
 		const uint32_t block = std::min<uint32_t>(256, threads);
-		hipLaunchKernelGGL(m.fused, dim3(threads / block), dim3(block), 0, stream, dp, c, prev, cur);
+		hipLaunchKernelGGL(m.fused, dim3(threads / block), dim3(block), 0, m.stream, dp, c, prev, cur);
 		launches += 1;
 	} else {
 		const uint64_t total = 1ull << (d.f + d.ebits - d.eloop);
 		const uint32_t block = (uint32_t)std::min<uint64_t>(256, (total + 63) / 64 * 64);
-		hipLaunchKernelGGL(m.keysfn, dim3((uint32_t)((total + block - 1) / block)), dim3(block), 0, stream, dp, c, prev, (uint32_t)total);
+		hipLaunchKernelGGL(m.keysfn, dim3((uint32_t)((total + block - 1) / block)), dim3(block), 0, m.stream, dp, c, prev, (uint32_t)total);
 		const uint32_t entries = (1u << d.f) * p.T;
 		const uint32_t fblock = std::min<uint32_t>(256, (entries + 63) / 64 * 64);
-		hipLaunchKernelGGL(column_finalize, dim3((entries + fblock - 1) / fblock), dim3(fblock), 0, stream, dp, c, cur, entries);
+		hipLaunchKernelGGL(column_finalize, dim3((entries + fblock - 1) / fblock), dim3(fblock), 0, m.stream, dp, c, cur, entries);
 		launches += 2;
 	}
 }
 
-// Submits up to `max_launches` launches of lane `li` (forward steps of its jobs in order; after a job's last step its
-// score copy and backtrace).  `finished`: the lane has nothing left.
-whamd_status_t DeviceTable::Impl::submit_lane(const Problem& p, size_t li, uint64_t max_launches, uint64_t& launches, bool& finished,
-                                              std::string& msg) {
+// One run as a launch of its own (kernel arguments by value).
+void DeviceTable::Impl::launch_run(const ResBatchEntry& e, uint32_t step_index, uint64_t& launches) {
 	Impl& m = *this;
-	Impl::Lane& lane = m.lanes[li];
-	uint64_t in_turn = 0;
-	while (lane.job_i < lane.jobs.size() && in_turn < max_launches) {
-		const Impl::Job& job = m.jobs[lane.jobs[lane.job_i]];
-		const uint32_t job_id = lane.jobs[lane.job_i];
-		if (lane.step_i == 0)  // a job starts from cost 0: the single entry the first step may read
-			HIP_TRY(hipMemsetAsync(lane.d_pr[lane.flip], 0, 4 * (size_t)p.T, lane.stream));
-		if (lane.step_i < job.steps.size()) {
-			const uint32_t si = job.steps[lane.step_i++];
-			uint64_t issued = 0;
-			m.launch_step(p, m.plan.steps[si], lane, lane.d_pr[lane.flip], lane.d_pr[lane.flip ^ 1], issued);
-			lane.flip ^= 1;
-			launches += issued;
-			in_turn += issued;
-			if (lane.step_i < job.steps.size()) continue;
-		}
-		// ---- the job's forward pass is submitted: its score (components) and its backtrace
-		HIP_TRY(hipGetLastError());
-		if (job.final) {
-			HIP_TRY(hipEventRecord(m.ev1, lane.stream));
-		} else {
-			HIP_TRY(hipMemcpyAsync(m.d_job_scores + job_id, lane.d_pr[lane.flip], 4, hipMemcpyDeviceToDevice, lane.stream));
-		}
-		if (job.unit_count)
-			hipLaunchKernelGGL(backtrace_kernel, dim3(1), dim3(1024), m.bt_lds, lane.stream, m.dp, m.d_units + job.unit_off, job.unit_count,
-			                   job.final ? 1u : 0u, m.d_path_index, m.d_path_trans, m.d_score);
-		HIP_TRY(hipGetLastError());
-		if (job.final) HIP_TRY(hipEventRecord(m.ev2, lane.stream));
-		++lane.job_i;
-		lane.step_i = 0;
-		in_turn += 1;
+	const ResSegment& sg = e.sg;
+	if (sg.kind == 1) {
+		const size_t words = ((size_t)sg.ncols * (PED_LDSWORDS + PED_TABLE) + (size_t)sg.n_terms * 2 + 3) & ~(size_t)3;
+		const size_t lds_ped = words * 4 + 2 * ((size_t)16 << sg.max_l) + (size_t)sg.stage_words * 8;
+		if (m.dp.dbg) hipLaunchKernelGGL(resident_segment_ped<true>, dim3(1u << sg.g), dim3(sg.threads), lds_ped, m.stream, m.dp, sg, e.prev, e.cur);
+		else hipLaunchKernelGGL(resident_segment_ped<false>, dim3(1u << sg.g), dim3(sg.threads), lds_ped, m.stream, m.dp, sg, e.prev, e.cur);
+	} else {
+		const size_t lds = (size_t)sg.ncols * (64 + RES_TABLE) * 4 + 2 * ((size_t)4 << sg.max_l) + (size_t)sg.stage_words * 8;
+		if (m.dp.dbg) hipLaunchKernelGGL(resident_segment<true>, dim3(1u << sg.g), dim3(sg.threads), lds, m.stream, m.dp, sg, e.prev, e.cur, e.score_out);
+		else hipLaunchKernelGGL(resident_segment<false>, dim3(1u << sg.g), dim3(sg.threads), lds, m.stream, m.dp, sg, e.prev, e.cur, e.score_out);
 	}
-	if (lane.job_i == lane.jobs.size() && lane.step_i != ~(size_t)0) {
-		lane.step_i = ~(size_t)0;  // lane finished (marker)
-		if (li) HIP_TRY(hipEventRecord(lane.done, lane.stream));
-		if (m.lanes_open) --m.lanes_open;
-	}
-	finished = lane.job_i == lane.jobs.size();
-	return WHAMD_OK;
+	launches += 1;
 }
 
-// Resumable submission: the first call does the preamble, every call submits at most `budget` forward launches -- round
-// robin over the lanes, a few launches per lane and turn, so that the lanes' streams fill up side by side -- and the
-// call that runs out of work joins the lanes and appends the downloads.  Lets one host thread interleave the launch
-// sequences of several tables as well (whamd_dptable_enqueue_many).
+// Resumable submission: the first call does the preamble, every call submits super-steps until at least `budget`
+// launches went out, the call that runs out of super-steps appends the backtrace and the downloads.  Lets one host
+// thread interleave the launch sequences of several tables (whamd_dptable_enqueue_many).
 whamd_status_t DeviceTable::enqueue_some(const Problem& p, Solution& s, uint64_t budget, bool& done, std::string& msg) {
 	Impl& m = *impl_;
 	const uint32_t n = p.n_cols;
@@ -616,6 +623,7 @@ whamd_status_t DeviceTable::enqueue_some(const Problem& p, Solution& s, uint64_t
 		s.path_index.assign(n, 0);
 		s.path_trans.assign(n, 0);
 		m.launches = 0;
+		m.next_super = 0;
 		if (n == 0) {  // src/pedigreedptable.cpp:88-92
 			s.optimal_score = 0;
 			m.enqueue_open = false;
@@ -632,27 +640,32 @@ whamd_status_t DeviceTable::enqueue_some(const Problem& p, Solution& s, uint64_t
 			const uint32_t entries = (uint32_t)m.plan.columns.size() * RES_TABLE;
 			hipLaunchKernelGGL(resident_tables, dim3((entries + 255) / 256), dim3(256), 0, m.stream, m.dp.res_cols, (uint32_t)m.plan.columns.size(), m.dp.res_tables);
 		}
-		if (m.lanes.size() > 1) {
-			HIP_TRY(hipEventRecord(m.ev_ready, m.stream));
-			for (size_t l = 1; l < m.lanes.size(); ++l) HIP_TRY(hipStreamWaitEvent(m.lanes[l].stream, m.ev_ready, 0));
-		}
-		for (Impl::Lane& lane : m.lanes) { lane.job_i = 0; lane.step_i = 0; lane.flip = 0; }
-		m.lanes_open = m.lanes.size();
 	}
-	constexpr uint64_t SLICE = 16;
 	uint64_t launches = 0;
-	while (m.lanes_open && launches < budget) {
-		for (size_t li = 0; li < m.lanes.size() && launches < budget; ++li) {
-			bool finished = false;
-			uint64_t issued = 0;
-			const whamd_status_t st = m.submit_lane(p, li, std::min<uint64_t>(SLICE, budget - launches), issued, finished, msg);
-			if (st != WHAMD_OK) return st;
-			launches += issued;
+	while (m.next_super < m.schedule.size() && launches < budget) {
+		const Impl::SuperStep& ss = m.schedule[m.next_super++];
+		if (ss.entry_count == 1) {
+			m.launch_run(m.entries[ss.entry_off], 0, launches);
+		} else if (ss.entry_count > 1) {
+			hipLaunchKernelGGL(resident_batch, dim3(ss.grid_x, ss.entry_count), dim3(ss.threads), ss.lds, m.stream, m.dp, m.d_entries + ss.entry_off);
+			launches += 1;
+		}
+		for (const Impl::Single& sg : ss.singles) {
+			const Impl::Lane& lane = m.lanes[sg.lane];
+			if (sg.zero_prev) HIP_TRY(hipMemsetAsync(lane.d_pr[sg.flip], 0, 4 * (size_t)p.T, m.stream));
+			m.launch_column_step(p, m.plan.steps[sg.step], lane, lane.d_pr[sg.flip], lane.d_pr[sg.flip ^ 1], launches);
+			if (sg.score_job >= 0)
+				HIP_TRY(hipMemcpyAsync(m.d_job_scores + sg.score_job, lane.d_pr[sg.flip ^ 1], 4, hipMemcpyDeviceToDevice, m.stream));
 		}
 	}
 	m.launches += launches;
-	if (m.lanes_open) return WHAMD_OK;
-	for (size_t l = 1; l < m.lanes.size(); ++l) HIP_TRY(hipStreamWaitEvent(m.stream, m.lanes[l].done, 0));
+	if (m.next_super < m.schedule.size()) return WHAMD_OK;
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipEventRecord(m.ev1, m.stream));
+	hipLaunchKernelGGL(backtrace_kernel, dim3((uint32_t)m.jobs.size()), dim3(1024), m.bt_lds, m.stream, m.dp, m.d_units, m.d_btjobs,
+	                   m.d_path_index, m.d_path_trans, m.d_score);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipEventRecord(m.ev2, m.stream));
 	// downloads go to pinned host buffers: a copy into pageable memory would block this call until the stream drains
 	HIP_TRY(hipMemcpyAsync(m.h_pinned, m.d_path_index, (size_t)n * 4, hipMemcpyDeviceToHost, m.stream));
 	HIP_TRY(hipMemcpyAsync(m.h_pinned + n, m.d_path_trans, (size_t)n * 4, hipMemcpyDeviceToHost, m.stream));

@@ -7,13 +7,16 @@
 // column records and the header of the run after that; one wave then follows the path with LDS latency instead of one
 // dependent HBM access per column.
 //
-// `with_last_column` != 0: units[0] is the table's last column (its optimum comes from P.last_keys), the walk starts at
-// units[1].  == 0: the units are the runs of ONE connected component that ends before the table does (its last column
-// projects onto a single entry): the walk starts at units[0] with entry 0 and no score is written -- several such
-// launches run side by side on different streams.
-__global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtUnit* __restrict__ units, uint32_t n_units,
-                                                         uint32_t with_last_column, uint32_t* __restrict__ path_index,
-                                                         uint32_t* __restrict__ path_trans, uint32_t* __restrict__ out_score) {
+// One workgroup per job (BtJob).  `with_last_column` != 0: units[0] is the table's last column (its optimum comes from
+// P.last_keys), the walk starts at units[1].  == 0: the units are the steps of ONE connected component that ends before
+// the table does (its last column projects onto a single entry): the walk starts at units[0] with entry 0 and no score
+// is written.
+__global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtUnit* __restrict__ all_units, const BtJob* __restrict__ jobs,
+                                                         uint32_t* __restrict__ path_index, uint32_t* __restrict__ path_trans,
+                                                         uint32_t* __restrict__ out_score) {
+	const BtJob job = jobs[blockIdx.x];  // one workgroup per job: jobs are independent (DeviceTable jobs)
+	const BtUnit* __restrict__ units = all_units + job.unit_off;
+	const uint32_t n_units = job.unit_count, with_last_column = job.with_last_column;
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
 	uint32_t* recs0 = smem;                                   // 2 x RES_MAXCOLS * 32 words: column records (double buffer)
 	uint32_t* hdr = smem + 2 * RES_MAXCOLS * 32;              // 4 x 32 words: unit headers (ring)

@@ -255,13 +255,14 @@ __device__ __forceinline__ void res_pk_column(const uint32_t* ldsc, const int32_
 // scalar unit the 16 waves of a workgroup share -- so the loop keeps per-column constants in vector registers (LDS
 // broadcast reads), lets whole waves without work branch straight to the barrier, and records the argmin bits as one
 // byte per thread (no ballot / exec-mask sequences).
+// Body of one run for workgroup `w` (shared by the one-run launch and the batched launch below).  `score_out` != nullptr:
+// the run ends a connected component -- workgroup 0 stores the single exit value there (DeviceTable jobs).
 template <bool DBG>
-__global__ __launch_bounds__(1024) void resident_segment(DevProblem P, ResSegment sg, const uint32_t* __restrict__ prev,
-                                                          uint32_t* __restrict__ cur) {
+__device__ __forceinline__ void resident_segment_body(const DevProblem& P, const ResSegment& sg, const uint32_t* __restrict__ prev,
+                                                      uint32_t* __restrict__ cur, const uint32_t w, uint32_t* score_out,
+                                                      const unsigned long long t_begin) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-	const unsigned long long t_begin = DBG ? __builtin_readcyclecounter() : 0ull;
-	touch_kernel_arguments<sizeof(DevProblem) + sizeof(ResSegment) + 16>();
-	const uint32_t w = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+	const uint32_t tid = threadIdx.x, NT = blockDim.x;
 	const unsigned long long rt_begin = DBG ? wall_clock64() : 0ull;
 	unsigned long long t_args = 0, t_first = 0;
 	uint32_t* ldsc = smem;                                             // ncols * 64 words: column descriptors
@@ -459,6 +460,7 @@ __global__ __launch_bounds__(1024) void resident_segment(DevProblem P, ResSegmen
 	const unsigned long long* st64 = reinterpret_cast<const unsigned long long*>(stage);
 	if (!(DBG && (P.dbg_flags & 2u)))
 	for (uint32_t i = tid; i < sg.stage_words; i += NT) rec[i] = st64[i];
+	if (score_out && w == 0 && tid == 0) *score_out = bufP[0];
 	if (DBG && tid == 0 && sg.pad >= 100 && sg.pad < 104) {
 		unsigned long long* dw = P.dbg + (size_t)P.dbg_wg_off + ((size_t)(sg.pad - 100) * 512 + w) * 2;
 		dw[0] = rt_begin;
@@ -475,4 +477,29 @@ __global__ __launch_bounds__(1024) void resident_segment(DevProblem P, ResSegmen
 		d[4] = acc_a; d[5] = acc_b; d[6] = acc_c; d[7] = nsteps_dbg;
 		}
 	}
+}
+
+template <bool DBG>
+__global__ __launch_bounds__(1024) void resident_segment(DevProblem P, ResSegment sg, const uint32_t* __restrict__ prev,
+                                                          uint32_t* __restrict__ cur, uint32_t* __restrict__ score_out) {
+	const unsigned long long t_begin = DBG ? __builtin_readcyclecounter() : 0ull;
+	touch_kernel_arguments<sizeof(DevProblem) + sizeof(ResSegment) + 24>();
+	resident_segment_body<DBG>(P, sg, prev, cur, blockIdx.x, score_out, t_begin);
+}
+
+// One launch = the next run of SEVERAL independent jobs (connected components of one table): blockIdx.y selects the
+// entry, blockIdx.x the workgroup of that run (workgroups beyond the run's grid leave at once).  A table of many small
+// components is otherwise limited by the dispatch rate (~200 k launches/s), not by the work.
+__global__ __launch_bounds__(1024) void resident_batch(DevProblem P, const ResBatchEntry* __restrict__ entries) {
+	const ResBatchEntry* __restrict__ e = entries + blockIdx.y;
+	{   // pull every 64-byte line of the entry into the scalar cache with independent loads (see touch_kernel_arguments)
+		const uint32_t* lines = reinterpret_cast<const uint32_t*>(e);
+		uint32_t acc = 0;
+#pragma unroll
+		for (uint32_t l = 0; l < (sizeof(ResBatchEntry) + 63) / 64; ++l) acc |= lines[l * 16];
+		asm volatile("" ::"s"(__builtin_amdgcn_readfirstlane(acc)));
+	}
+	const ResSegment sg = e->sg;
+	if (blockIdx.x >= (1u << sg.g)) return;
+	resident_segment_body<false>(P, sg, e->prev, e->cur, blockIdx.x, e->score_out, 0ull);
 }

@@ -126,6 +126,15 @@ struct ResSegment {
 	uint32_t in_grid[RES_IOSEG], in_local[RES_IOSEG], out_grid[RES_IOSEG], out_local[RES_IOSEG];
 };
 
+// One run of a batched launch (resident_batch): the segment and the buffers of its job's lane.
+struct ResBatchEntry {
+	ResSegment sg;
+	const uint32_t* prev;
+	uint32_t* cur;
+	uint32_t* score_out;  // non-null: the run ends a connected component, its single exit value goes here
+};
+static_assert(sizeof(ResBatchEntry) % 8 == 0, "entries hold pointers");
+
 // Everything the backtrace needs for one resident column, self-contained (128 B) so that a run's records can be staged
 // in LDS with one coalesced copy.  The walk stays in the run's LOCAL index space (the grid-read bits of the path are
 // constant inside a run): with cell_{c+1} the local cell index of the path at column c+1,
@@ -164,6 +173,13 @@ struct BtUnit {
 	uint32_t pad1[4];
 };
 static_assert(sizeof(BtUnit) == 128, "BtUnit must stay 32 words");
+
+// One backtrace job (blockIdx.x of backtrace_kernel): a contiguous range of units, newest first.
+struct BtJob {
+	uint32_t unit_off, unit_count;
+	uint32_t with_last_column;  // 1: units[0] is the table's last column (optimum from the key scratch); 0: start at entry 0
+	uint32_t pad;
+};
 
 struct Step {
 	uint32_t kind;         // 0 = one column through the column kernels, 1 = resident run
