@@ -546,3 +546,24 @@ def test_connected_components_as_independent_jobs():
         t.wait()
     for s, t in zip((3, 4, 5), tables):
         assert table_solution(t) == table_solution(oracle.OracleTable(chromosome(6, 10, seed=s, max_len=80)))
+
+
+def test_many_small_component_instances_vs_oracle():
+    """Fuzz of the job machinery: ReadSets glued from 3-6 random tie-heavy single-individual instances (components of a
+    few columns, per-column kernels and runs mixed inside a job, reads of one variant-gap, extra positions), default
+    lanes and one lane, both forward paths."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from dist_worker import multi_block_instance
+
+    for seed in range(100, 160):
+        whole = multi_block_instance(seed)
+        want = table_solution(oracle.OracleTable(whole))
+        for path, lanes in (("auto", None), ("auto", "1"), ("column", None)):
+            t = _native.NativeTable(whole, solve=False, path=path)
+            if lanes:
+                t.set_option("lanes", lanes)
+            t.solve()
+            got = table_solution(t)
+            assert got == want, (seed, path, lanes, first_difference(want, got))
+            t.close()
