@@ -203,10 +203,12 @@ def main():
         }
         n_cpu = args.cpu_baseline_columns
         if n_cpu < 0:
-            per_col_s = {20: 0.113, 18: 0.021, 16: 0.005, 15: 0.0025}.get(args.coverage, 0.113 * 2.0 ** (args.coverage - 20))
-            if args.trio:
-                per_col_s *= 6
-            n_cpu = int(max(20, min(args.variants, 16.0 / per_col_s)))
+            # bounded sample of ~15 s of CPU work.  Calibrated on two short prefixes (host CPUs differ by 2x): the first
+            # 2 * coverage columns are the coverage ramp of the synthetic ReadSet and cost next to nothing
+            ramp = 2 * args.coverage
+            a, b = cpu_baseline(args, ramp + 8), cpu_baseline(args, ramp + 24)
+            per_col = max((b["seconds"] - a["seconds"]) / 16.0, 1e-6)
+            n_cpu = int(max(ramp + 24, min(args.variants, ramp + 8 + (15.0 - a["seconds"]) / per_col)))
         if n_cpu > 0:
             out["cpu_baseline"] = cpu_baseline(args, n_cpu)
             out["speedup_vs_cpu_baseline"] = out["value"] / world / out["cpu_baseline"]["value"]
