@@ -1,12 +1,13 @@
-// resident.h -- the "resident" forward path (single individual, T = 1): a run of consecutive columns is processed by
-// ONE launch in which every workgroup keeps its slice of the projection column in LDS.
+// resident.h -- the "resident" forward path: a run of consecutive columns is processed by ONE launch in which every
+// workgroup keeps its slice of the projection column in LDS (single individual: kernels_resident.h; trio: kernels_trio.h).
 //
 // Bits of the state are split per run ("segment"): g *grid reads* -- reads that stay active through the whole run --
 // index the 2^g workgroups; all other reads are *local* bits of a workgroup's LDS slice.  Reads that start inside the
-// run become new (top) local bits, reads that end inside the run are minimised out of the local index.  Between runs
-// the projection column is stored in HBM in logical order, so the next run is free to choose other grid reads
-// (the re-layout is the only time Pr touches HBM).  Columns that do not fit a run (last column, > 3 reads ending at
-// once, slices larger than LDS) are executed by the per-column kernels of dp_device.hip.
+// run become new (top) local bits, reads that end inside the run are minimised out of the local index.  Between two
+// runs the projection column goes through HBM in an *exchange layout* chosen per boundary (next run's grid reads on
+// top, then the previous run's, then the bits local in both), so the next run is free to choose other grid reads; the
+// re-layout is the only time Pr touches HBM.  Columns that do not fit a run (last column, > 3 reads ending at once,
+// slices larger than LDS) are executed by the per-column kernels (kernels_column.h).
 #pragma once
 #include <cstddef>
 #include <cstdint>
