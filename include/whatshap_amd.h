@@ -196,6 +196,8 @@ whamd_status_t whamd_dptable_get_stats(const whamd_dptable* table, whamd_solve_s
  *   "path"          "auto" (default) | "resident" | "column" (one launch per column, the general path) | "column_keys"
  *   "resident_l"    preferred log2 slice size of the run kernels
  *   "resident_fold" "0" disables folding of columns without an ending read
+ *   "symmetry"      single individual: D[~x] == D[x], so a run may compute half of its workgroups only: "0" never,
+ *                   "1" runs that would fill the chip (default), "2" every run with a grid read (tests)
  *   "lanes"         how many connected components of a single-individual table advance side by side (default 32, their
  *                   runs go out as batched launches; "1" solves them one after the other) */
 whamd_status_t whamd_dptable_set_option(whamd_dptable* table, const char* key, const char* value);
@@ -217,6 +219,7 @@ typedef struct whamd_plan_summary {
 	uint64_t max_lds_bytes;       /* largest dynamic LDS request of a run */
 	uint64_t backtrace_bytes;     /* size of the backtrace arena */
 	uint64_t n_components;        /* connected components the device driver may run as independent jobs (single individual) */
+	uint64_t n_halved_runs;       /* runs that launch only half of their workgroups (complement symmetry) */
 	uint32_t max_coverage;
 	uint32_t invariants_ok;       /* 1 if the internal consistency checks passed */
 } whamd_plan_summary;

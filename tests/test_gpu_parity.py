@@ -567,3 +567,31 @@ def test_many_small_component_instances_vs_oracle():
             got = table_solution(t)
             assert got == want, (seed, path, lanes, first_difference(want, got))
             t.close()
+
+
+@pytest.mark.parametrize("seed", [41, 42, 43])
+def test_complement_symmetry_on_every_run(seed):
+    """Single individual: D[~x] == D[x].  With symmetry=2 every run that has a grid read launches only the workgroups
+    whose top grid-read bit is 0, readers fetch the missing half from the complement index, and the backtrace reads the
+    mirror-image decisions when the path runs through the half that was not computed.  Everything must equal the oracle
+    (and the run with the symmetry switched off), including ties."""
+    rng = np.random.default_rng(seed)
+    base = synthetic_block(n_variants=500, coverage=14, seed=seed, step=int(rng.integers(1, 4)))
+    n = base.n_variants
+    variants = {
+        "plain": base,
+        "ties": _variant_of(base, quality=(1 + (base.var_quality % 2)).astype(np.uint32)),
+        "distrust": _variant_of(base, gl=rng.integers(0, 40, size=(1, n, 3)).astype(np.float64), distrust=True),
+        "homozygous": _variant_of(base, genotype=rng.choice([0, 1, 1, 2], size=(1, n)).astype(np.uint8)),
+        "heavy": _variant_of(base, quality=base.var_quality * np.uint32(450)),
+        "irregular": _irregular_problem(seed, 300, False, 13),
+    }
+    for name, p in variants.items():
+        want = table_solution(oracle.OracleTable(p))
+        for level in ("2", "0", "1"):
+            t = _native.NativeTable(p, solve=False)
+            t.set_option("symmetry", level)
+            t.solve()
+            got = table_solution(t)
+            assert got == want, (name, level, first_difference(want, got))
+            t.close()

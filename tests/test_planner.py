@@ -14,7 +14,8 @@ def test_benchmark_shape_is_scheduled_as_resident_runs():
     s = _native.plan_summary(p)
     assert s["invariants_ok"] == 1 and s["n_columns"] == 3000 and s["max_coverage"] == 20
     assert s["n_resident_columns"] >= 2990          # everything but the last column(s)
-    assert s["max_workgroups"] == 256               # 8 grid reads at coverage 20
+    assert s["max_workgroups"] == 256               # 9 grid reads at coverage 20, half of the workgroups launched
+    assert s["n_halved_runs"] >= 0.9 * s["n_runs"]
     assert 15 <= s["n_resident_columns"] / s["n_runs"] <= 48
     assert s["n_folded_columns"] >= 0.4 * s["n_columns"]  # every second column starts a read and ends none
     assert s["max_lds_bytes"] <= 160 * 1024
@@ -25,7 +26,7 @@ def test_coverage_23_still_runs_resident():
     p = synthetic_block(n_variants=400, coverage=23, seed=9)
     s = _native.plan_summary(p)
     assert s["invariants_ok"] == 1 and s["max_coverage"] == 23
-    assert s["max_workgroups"] == 1024 and s["n_resident_columns"] >= 300
+    assert s["max_workgroups"] == 512 and s["n_resident_columns"] >= 300  # 10 grid reads, halved
 
 
 def test_column_path_request_has_no_runs_and_trios_get_their_own_runs():

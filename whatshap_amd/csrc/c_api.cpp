@@ -233,6 +233,11 @@ whamd_status_t whamd_dptable_set_option(whamd_dptable* t, const char* key, const
 		t->uploaded = false;
 		return WHAMD_OK;
 	}
+	if (k == "symmetry") {
+		t->device.set_symmetry(std::atoi(value));
+		t->uploaded = false;
+		return WHAMD_OK;
+	}
 	if (k == "lanes") {
 		t->device.set_lanes(std::atoi(value));
 		t->uploaded = false;
@@ -315,7 +320,8 @@ whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uin
 		ok = ok && lds <= 160 * 1024;
 		s.max_lds_bytes = std::max<uint64_t>(s.max_lds_bytes, lds);
 		s.max_run_columns = std::max<uint64_t>(s.max_run_columns, sg.ncols);
-		s.max_workgroups = std::max<uint64_t>(s.max_workgroups, 1ull << sg.g);
+		s.max_workgroups = std::max<uint64_t>(s.max_workgroups, 1ull << (sg.g - sg.half));  // launched workgroups
+		if (sg.half) s.n_halved_runs++;
 		s.n_resident_columns += sg.ncols;
 		s.backtrace_bytes += (uint64_t)sg.stage_words * (1ull << sg.g) * 8;
 	}

@@ -33,6 +33,8 @@ public:
 	void set_l_pref(int l);
 	// Fold columns in which no read ends into the next resident column (default on); next upload().
 	void set_fold(bool v);
+	// Exploit D[~x] == D[x] in single-individual runs: 0 off, 1 full-chip runs (default), 2 every run; next upload().
+	void set_symmetry(int level);
 	// Lanes over which the connected components of a single-individual table are spread (default 32, 1 = off); the
 	// lanes advance in lockstep, their runs go out as batched launches; next upload().
 	void set_lanes(int n);

@@ -94,6 +94,7 @@ struct DeviceTable::Impl {
 	std::string path = "auto";
 	int l_pref = 11;
 	bool fold = true;
+	int symmetry = 1;  // single individual: compute only half of a run, the rest is its mirror image (plan_forward)
 	uint64_t bt_bytes = 0;
 	uint64_t launches = 0;
 	bool enqueue_open = false;  // resumable enqueue (enqueue_some)
@@ -123,6 +124,7 @@ struct DeviceTable::Impl {
 	struct SuperStep {
 		uint32_t entry_off = 0, entry_count = 0, grid_x = 0, threads = 0;
 		size_t lds = 0;
+		bool sym = false;  // some run of the batch takes part in the complement symmetry
 		std::vector<Single> singles;
 	};
 	std::vector<Job> jobs;
@@ -217,6 +219,8 @@ void DeviceTable::set_lanes(int n) { impl_->max_lanes = n < 1 ? 1 : (n > 64 ? 64
 
 void DeviceTable::set_fold(bool v) { impl_->fold = v; }
 
+void DeviceTable::set_symmetry(int level) { impl_->symmetry = level < 0 ? 0 : (level > 2 ? 2 : level); }
+
 whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& msg) {
 	Impl& m = *impl_;
 	m.device = device;
@@ -247,7 +251,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	const bool force_keys = m.path == "column_keys";
 	const bool want_resident = m.path == "auto" || m.path == "resident";
 	const auto tu0 = std::chrono::steady_clock::now();
-	plan_forward(p, want_resident, m.l_pref, m.fold, m.plan);
+	plan_forward(p, want_resident, m.l_pref, m.fold, m.plan, m.symmetry);
 	const auto tu1 = std::chrono::steady_clock::now();
 	if (getenv("WHAMD_DEBUG_PLAN")) {
 		for (const Step& st : m.plan.steps) {
@@ -408,7 +412,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 				u.c0 = sgm.c0; u.ncols = sgm.ncols; u.col_off = sgm.col_off; u.g = sgm.g; u.Lf_last = sgm.Lf_last;
 				u.stage_words = sgm.stage_words; u.n_wext = sgm.n_wext; u.bt_lo = sgm.bt_lo; u.bt_hi = sgm.bt_hi;
 				u.n_lext = sgm.n_lext;
-				u.pad0 = (uint32_t)sgm.bt_active | ((uint32_t)sgm.bt_simple << 16);
+				u.pad0 = (uint32_t)sgm.bt_active | ((uint32_t)sgm.bt_simple << 16) | (sgm.half << 20);
 				std::copy(sgm.wext, sgm.wext + RES_IOSEG, u.wext);
 				std::copy(sgm.lext, sgm.lext + RES_BT_LRUNS, u.lext);
 			}
@@ -494,8 +498,9 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 						? ((((size_t)e.sg.ncols * (PED_LDSWORDS + PED_TABLE) + (size_t)e.sg.n_terms * 2 + 3) & ~(size_t)3) * 4 + 2 * ((size_t)16 << e.sg.max_l) + (size_t)e.sg.stage_words * 8)
 						: ((size_t)e.sg.ncols * (64 + RES_TABLE) * 4 + 2 * ((size_t)4 << e.sg.max_l) + (size_t)e.sg.stage_words * 8);
 					ss.lds = std::max(ss.lds, lds);
-					ss.grid_x = std::max(ss.grid_x, 1u << e.sg.g);
+					ss.grid_x = std::max(ss.grid_x, 1u << (e.sg.g - e.sg.half));
 					ss.threads = std::max(ss.threads, e.sg.threads);
+					ss.sym = ss.sym || e.sg.half || e.sg.in_half || e.sg.mirror_out;
 					m.entries.push_back(e);
 					++ss.entry_count;
 				} else {
@@ -547,8 +552,11 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	m.dp.tbits = tbits;
 	m.dp.n_ind = p.n_ind;
 	// kernels with more than 64 KiB of dynamic LDS need the opt-in on every device they run on
-	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_batch<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_batch<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(backtrace_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment_ped<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment_ped<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -604,8 +612,11 @@ void DeviceTable::Impl::launch_run(const ResBatchEntry& e, uint32_t step_index, 
 		else hipLaunchKernelGGL(resident_segment_ped<false>, dim3(1u << sg.g), dim3(sg.threads), lds_ped, m.stream, m.dp, sg, e.prev, e.cur);
 	} else {
 		const size_t lds = (size_t)sg.ncols * (64 + RES_TABLE) * 4 + 2 * ((size_t)4 << sg.max_l) + (size_t)sg.stage_words * 8;
-		if (m.dp.dbg) hipLaunchKernelGGL(resident_segment<true>, dim3(1u << sg.g), dim3(sg.threads), lds, m.stream, m.dp, sg, e.prev, e.cur, e.score_out);
-		else hipLaunchKernelGGL(resident_segment<false>, dim3(1u << sg.g), dim3(sg.threads), lds, m.stream, m.dp, sg, e.prev, e.cur, e.score_out);
+		const bool sym = sg.half || sg.in_half || sg.mirror_out;
+		const dim3 grid(1u << (sg.g - sg.half)), block(sg.threads);
+		if (m.dp.dbg) hipLaunchKernelGGL((resident_segment<true, true>), grid, block, lds, m.stream, m.dp, sg, e.prev, e.cur, e.score_out);
+		else if (sym) hipLaunchKernelGGL((resident_segment<false, true>), grid, block, lds, m.stream, m.dp, sg, e.prev, e.cur, e.score_out);
+		else hipLaunchKernelGGL((resident_segment<false, false>), grid, block, lds, m.stream, m.dp, sg, e.prev, e.cur, e.score_out);
 	}
 	launches += 1;
 }
@@ -647,7 +658,8 @@ whamd_status_t DeviceTable::enqueue_some(const Problem& p, Solution& s, uint64_t
 		if (ss.entry_count == 1) {
 			m.launch_run(m.entries[ss.entry_off], 0, launches);
 		} else if (ss.entry_count > 1) {
-			hipLaunchKernelGGL(resident_batch, dim3(ss.grid_x, ss.entry_count), dim3(ss.threads), ss.lds, m.stream, m.dp, m.d_entries + ss.entry_off);
+			if (ss.sym) hipLaunchKernelGGL(resident_batch<true>, dim3(ss.grid_x, ss.entry_count), dim3(ss.threads), ss.lds, m.stream, m.dp, m.d_entries + ss.entry_off);
+			else hipLaunchKernelGGL(resident_batch<false>, dim3(ss.grid_x, ss.entry_count), dim3(ss.threads), ss.lds, m.stream, m.dp, m.d_entries + ss.entry_off);
 			launches += 1;
 		}
 		for (const Impl::Single& sg : ss.singles) {

@@ -124,8 +124,11 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 				w |= ((yexit >> (r & 31u)) & ((1u << ((r >> 16) & 31u)) - 1u)) << ((r >> 8) & 31u);
 			}
 			wrun = w;
+			// halved run (ResSegment::half) and the path lies in the half that was not computed: the record of the
+			// complement workgroup holds the mirror-image decisions (bits 4..7 of every record byte)
+			const uint32_t wrec = (((h[11] >> 20) & 1u) && ((w >> (g - 1u)) & 1u)) ? (~w & ((1u << g) - 1u)) : w;
 			const unsigned long long* __restrict__ gst = reinterpret_cast<const unsigned long long*>(
-				P.bt + (((unsigned long long)h[9] << 32) | h[8])) + (size_t)w * stage_words;
+				P.bt + (((unsigned long long)h[9] << 32) | h[8])) + (size_t)wrec * stage_words;
 			unsigned long long sv[2];
 #pragma unroll
 			for (int u = 0; u < 2; ++u) { const uint32_t i = u * NT + lane; sv[u] = i < stage_words ? gst[i] : 0ull; }
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 				// per-column parameters in registers; the loop fetches them with v_readlane (off the dependent chain), so the
 				// chain per visited column is: mask, record byte from LDS, bit insert.
 				const unsigned long long tw0 = P.dbg ? __builtin_readcyclecounter() + (l & 0u) : 0ull;
-				const uint32_t n_active = h[11] & 0xFFFFu, simple = h[11] >> 16;
+				const uint32_t n_active = h[11] & 0xFFFFu, simple = (h[11] >> 16) & 15u;
 				const uint32_t* rmine = recs + (lane < ncols ? lane : 0u) * 32;
 				uint32_t tcur = tprev, mycell = 0, myts = 0;
 				if (simple == 2u) {
@@ -182,7 +185,10 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 					// (ResBacktrace kpos / src / cmask / kcol); lane k holds the parameters of chain position k
 					const uint32_t kc = rmine[31] < ncols ? rmine[31] : 0u;
 					const uint32_t* rk = recs + kc * 32;
-					const uint32_t c_cmask = rk[30], c_soff = rk[3] * 8u, c_e0 = rk[5];
+					const uint32_t c_cmask = rk[30], c_soff = rk[3] * 8u, c_e0 = rk[5], c_lfmask = (1u << rk[0]) - 1u;
+					const uint32_t gg = h[4];
+					const bool mirrored = ((h[11] >> 20) & 1u) && ((wrun >> (gg - 1u)) & 1u);
+					const uint32_t mxor = mirrored ? 0xFFFFFFFFu : 0u, mshift = mirrored ? 4u : 0u;
 					const uint32_t my_kpos = rmine[28], my_src = rmine[29], my_cmask = rmine[30];
 					const uint8_t* stage8 = reinterpret_cast<const uint8_t*>(stage);
 					const uint32_t l_exit = l;
@@ -190,8 +196,9 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 						const uint32_t s_cmask = __builtin_amdgcn_readlane(c_cmask, k), s_soff = __builtin_amdgcn_readlane(c_soff, k),
 						               s_e0 = __builtin_amdgcn_readlane(c_e0, k);
 						const uint32_t lout = l & s_cmask;
-						const uint32_t byte = stage8[s_soff + (lout >> 2)];
-						const uint32_t cell = insert_zero(lout, s_e0) | (((byte >> (lout & 3u)) & 1u) << s_e0);
+						const uint32_t look = (lout ^ mxor) & __builtin_amdgcn_readlane(c_lfmask, k);  // mirrored: the complement entry
+						const uint32_t byte = stage8[s_soff + (look >> 2)];
+						const uint32_t cell = insert_zero(lout, s_e0) | (((byte >> ((look & 3u) + mshift)) & 1u) << s_e0);
 						if (my_kpos == k) mycell = cell;
 						l = cell;
 					}

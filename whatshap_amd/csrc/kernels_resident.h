@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void resident_tables(const ResColumn* __restri
 //
 // Shared tail of both variants: per-entry minimum over the (up to two) cells with the Gray-rank tie rule, slice store,
 // one record byte per thread (bit u = argmin side of the ending read for entry 4t+u).
-template <uint32_t MODE, int NC>
+template <uint32_t MODE, int NC, bool MIRROR>
 __device__ __forceinline__ void res_finish_entries(const uint32_t (&acc)[NC], uint32_t base, uint32_t mL0, uint32_t PG, uint32_t pbits,
                                                    uint32_t* bufQ, uint8_t* rec, uint32_t t) {
 	uint32_t D[4];
@@ -80,6 +80,7 @@ __device__ __forceinline__ void res_finish_entries(const uint32_t (&acc)[NC], ui
 		// tie: the smaller Gray rank has x_h == parity of the bits above the ending read; bit u of parx is
 		// that parity for entry 4t+u (grid part PG, this thread's part, the per-entry constant pbits)
 		const uint32_t parx = (0u - ((PG ^ (uint32_t)__popc(base & mL0)) & 1u)) ^ pbits;
+		const uint32_t mflip = (pbits >> 8) & 1u;
 #pragma unroll
 		for (int u = 0; u < 4; ++u) {
 			// cell pair of entry 4t+u: E1_HIGH (u, 4+u); E1_BIT0 (2u, 2u+1); E1_BIT1 ((u>>1)*4 + (u&1), +2)
@@ -90,6 +91,9 @@ __device__ __forceinline__ void res_finish_entries(const uint32_t (&acc)[NC], ui
 			// side 1 wins if strictly smaller, or equal and favoured by the tie rule: A1 < A0 + par
 			D[u] = min(A0, A1);
 			takes |= (A1 < A0 + par) ? (1u << u) : 0u;
+			// the mirror image of this entry (all bits complemented) has the two sides swapped and its own parity:
+			// its decision goes to bit 4 + u (read by the backtrace when the path runs through the half not computed)
+			if (MIRROR) takes |= (A0 < A1 + (par ^ mflip)) ? (16u << u) : 0u;
 		}
 	}
 	*reinterpret_cast<uint4*>(bufQ + (t << 2)) = make_uint4(D[0], D[1], D[2], D[3]);
@@ -169,7 +173,7 @@ __device__ __forceinline__ void res_fast_column(const uint32_t* ldsc, const int3
 			if (MODE == RES_MODE_E1_HIGH) dEf = reinterpret_cast<const int32_t*>(ldsc + cf * RES_LDSWORDS + offsetof(ResColumn, dloc) / 4)[ep0];
 			add_column(fp[H0], fp[H0 + 3], fp[H0 + 4], tlf[ilo], tlf[ihi], dEf);
 		}
-		res_finish_entries<MODE, NC>(acc, base, mL0, PG, pbits, bufQ, rec, t);
+		res_finish_entries<MODE, NC, true>(acc, base, mL0, PG, pbits, bufQ, rec, t);  // rare path: always both decisions
 	}
 }
 
@@ -178,7 +182,8 @@ __device__ __forceinline__ void res_fast_column(const uint32_t* ldsc, const int3
 typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u16x2 as_pk(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
 
-template <uint32_t MODE>
+// MIRROR: the run is halved (ResSegment::half) -- records carry the mirror-image decisions as well.
+template <uint32_t MODE, bool MIRROR>
 __device__ __forceinline__ void res_pk_column(const uint32_t* ldsc, const int32_t* tab, uint32_t ci, uint32_t nfold,
                                               const uint32_t* bufP, uint32_t* bufQ, uint8_t* stage, uint32_t tid,
                                               uint32_t NT, uint32_t nthr, const uint4 q0, const uint4 q2) {
@@ -247,7 +252,7 @@ __device__ __forceinline__ void res_pk_column(const uint32_t* ldsc, const int32_
 		}
 #pragma unroll
 		for (int i = 0; i < NC / 2; ++i) { acc[2 * i] += (uint32_t)tot[i].x; acc[2 * i + 1] += (uint32_t)tot[i].y; }
-		res_finish_entries<MODE, NC>(acc, base, mL0, PG, q3.w, bufQ, rec, t);
+		res_finish_entries<MODE, NC, MIRROR>(acc, base, mL0, PG, q3.w, bufQ, rec, t);
 	}
 }
 
@@ -257,7 +262,9 @@ __device__ __forceinline__ void res_pk_column(const uint32_t* ldsc, const int32_
 // byte per thread (no ballot / exec-mask sequences).
 // Body of one run for workgroup `w` (shared by the one-run launch and the batched launch below).  `score_out` != nullptr:
 // the run ends a connected component -- workgroup 0 stores the single exit value there (DeviceTable jobs).
-template <bool DBG>
+// SYM: the run takes part in the complement symmetry (it is halved, reads what a halved run wrote, or must store the
+// mirror image); runs that do not are launched without that code (it costs ~4 % where a run is latency-bound).
+template <bool DBG, bool SYM>
 __device__ __forceinline__ void resident_segment_body(const DevProblem& P, const ResSegment& sg, const uint32_t* __restrict__ prev,
                                                       uint32_t* __restrict__ cur, const uint32_t w, uint32_t* score_out,
                                                       const unsigned long long t_begin) {
@@ -297,6 +304,13 @@ __device__ __forceinline__ void resident_segment_body(const DevProblem& P, const
 		const uint32_t wpart = deposit_args(w, sg.in_grid, sg.n_in_grid);
 		if (DBG) t_args = __builtin_readcyclecounter() + (wpart & 0u);
 		auto desc_at = [&](uint32_t i) { return gc[(i / DQ) * GQ + i % DQ]; };  // the leading RES_LDSWORDS of every descriptor
+		// entering slice element l; after a halved run only the entries with a clear mirror bit exist: the others are read
+		// from their complement (D[~x] == D[x])
+		const uint32_t in_flip = (SYM && sg.in_half) ? sg.in_fullmask : 0u, in_bit = sg.in_mirror_bit & 31u;
+		auto in_index = [&](uint32_t l) {
+			const uint32_t idx = wpart | deposit_args(l, sg.in_local, sg.n_in_local);
+			return (SYM && ((idx >> in_bit) & 1u)) ? idx ^ in_flip : idx;
+		};
 		uint4 vd[2], vt[4];
 		uint32_t vs[4];
 #pragma unroll
@@ -306,7 +320,7 @@ __device__ __forceinline__ void resident_segment_body(const DevProblem& P, const
 #pragma unroll
 		for (int u = 0; u < 4; ++u) {
 			const uint32_t l = u * NT + tid;
-			vs[u] = l < nslice ? prev[wpart | deposit_args(l, sg.in_local, sg.n_in_local)] : 0u;
+			vs[u] = l < nslice ? prev[in_index(l)] : 0u;
 		}
 #pragma unroll
 		for (int u = 0; u < 2; ++u) { const uint32_t i = u * NT + tid; if (i < ndesc) lc[i] = vd[u]; }
@@ -318,7 +332,7 @@ __device__ __forceinline__ void resident_segment_body(const DevProblem& P, const
 		// remainders (long runs with few threads)
 		for (uint32_t i = 2 * NT + tid; i < ndesc; i += NT) lc[i] = desc_at(i);
 		for (uint32_t i = 4 * NT + tid; i < ntab; i += NT) lt[i] = gt[i];
-		for (uint32_t l = 4 * NT + tid; l < nslice; l += NT) bufP[l] = prev[wpart | deposit_args(l, sg.in_local, sg.n_in_local)];
+		for (uint32_t l = 4 * NT + tid; l < nslice; l += NT) bufP[l] = prev[in_index(l)];
 		if (!sg.has_prev && tid == 0) bufP[0] = 0;
 	}
 	const unsigned long long t_loaded = DBG ? __builtin_readcyclecounter() : 0ull;
@@ -366,10 +380,16 @@ __device__ __forceinline__ void resident_segment_body(const DevProblem& P, const
 			if (wave_first < nthr) {  // a wave whose 64 threads all lie beyond nthr goes straight to the barrier
 				const uint32_t nfold = (flags >> 8) & 15u;
 				if (flags & (1u << 12)) {
-					if (mode == RES_MODE_E0) res_pk_column<RES_MODE_E0>(ldsc, tab, ci, nfold, bufP, bufQ, stage, tid, NT, nthr, q0, q2);
-					else if (mode == RES_MODE_E1_HIGH) res_pk_column<RES_MODE_E1_HIGH>(ldsc, tab, ci, nfold, bufP, bufQ, stage, tid, NT, nthr, q0, q2);
-					else if (mode == RES_MODE_E1_BIT0) res_pk_column<RES_MODE_E1_BIT0>(ldsc, tab, ci, nfold, bufP, bufQ, stage, tid, NT, nthr, q0, q2);
-					else res_pk_column<RES_MODE_E1_BIT1>(ldsc, tab, ci, nfold, bufP, bufQ, stage, tid, NT, nthr, q0, q2);
+					if (mode == RES_MODE_E0) res_pk_column<RES_MODE_E0, false>(ldsc, tab, ci, nfold, bufP, bufQ, stage, tid, NT, nthr, q0, q2);
+					else if (SYM && sg.half) {
+						if (mode == RES_MODE_E1_HIGH) res_pk_column<RES_MODE_E1_HIGH, true>(ldsc, tab, ci, nfold, bufP, bufQ, stage, tid, NT, nthr, q0, q2);
+						else if (mode == RES_MODE_E1_BIT0) res_pk_column<RES_MODE_E1_BIT0, true>(ldsc, tab, ci, nfold, bufP, bufQ, stage, tid, NT, nthr, q0, q2);
+						else res_pk_column<RES_MODE_E1_BIT1, true>(ldsc, tab, ci, nfold, bufP, bufQ, stage, tid, NT, nthr, q0, q2);
+					} else {
+						if (mode == RES_MODE_E1_HIGH) res_pk_column<RES_MODE_E1_HIGH, false>(ldsc, tab, ci, nfold, bufP, bufQ, stage, tid, NT, nthr, q0, q2);
+						else if (mode == RES_MODE_E1_BIT0) res_pk_column<RES_MODE_E1_BIT0, false>(ldsc, tab, ci, nfold, bufP, bufQ, stage, tid, NT, nthr, q0, q2);
+						else res_pk_column<RES_MODE_E1_BIT1, false>(ldsc, tab, ci, nfold, bufP, bufQ, stage, tid, NT, nthr, q0, q2);
+					}
 				} else {
 					if (mode == RES_MODE_E0) res_fast_column<RES_MODE_E0>(ldsc, tab, ci, nfold, bufP, bufQ, stage, tid, NT, nthr, q2);
 					else if (mode == RES_MODE_E1_HIGH) res_fast_column<RES_MODE_E1_HIGH>(ldsc, tab, ci, nfold, bufP, bufQ, stage, tid, NT, nthr, q2);
@@ -455,7 +475,12 @@ __device__ __forceinline__ void resident_segment_body(const DevProblem& P, const
 	// exit slice in logical order, and the run's backtrace record [workgroup][stage_words]
 	const uint32_t wout = deposit_args(w, sg.out_grid, sg.n_out_grid);
 	if (!(DBG && (P.dbg_flags & 1u)))
-	for (uint32_t l = tid; l < (1u << sg.Lf_last); l += NT) cur[wout | deposit_args(l, sg.out_local, sg.n_out_local)] = bufP[l];
+	for (uint32_t l = tid; l < (1u << sg.Lf_last); l += NT) {
+		const uint32_t idx = wout | deposit_args(l, sg.out_local, sg.n_out_local);
+		const uint32_t v = bufP[l];
+		cur[idx] = v;
+		if (SYM && sg.mirror_out) cur[idx ^ sg.out_fullmask] = v;  // halved run whose reader wants every entry
+	}
 	unsigned long long* rec = reinterpret_cast<unsigned long long*>(P.bt + (((unsigned long long)sg.bt_hi << 32) | sg.bt_lo)) + (size_t)w * sg.stage_words;
 	const unsigned long long* st64 = reinterpret_cast<const unsigned long long*>(stage);
 	if (!(DBG && (P.dbg_flags & 2u)))
@@ -479,17 +504,18 @@ __device__ __forceinline__ void resident_segment_body(const DevProblem& P, const
 	}
 }
 
-template <bool DBG>
+template <bool DBG, bool SYM>
 __global__ __launch_bounds__(1024) void resident_segment(DevProblem P, ResSegment sg, const uint32_t* __restrict__ prev,
                                                           uint32_t* __restrict__ cur, uint32_t* __restrict__ score_out) {
 	const unsigned long long t_begin = DBG ? __builtin_readcyclecounter() : 0ull;
 	touch_kernel_arguments<sizeof(DevProblem) + sizeof(ResSegment) + 24>();
-	resident_segment_body<DBG>(P, sg, prev, cur, blockIdx.x, score_out, t_begin);
+	resident_segment_body<DBG, SYM>(P, sg, prev, cur, blockIdx.x, score_out, t_begin);
 }
 
 // One launch = the next run of SEVERAL independent jobs (connected components of one table): blockIdx.y selects the
 // entry, blockIdx.x the workgroup of that run (workgroups beyond the run's grid leave at once).  A table of many small
 // components is otherwise limited by the dispatch rate (~200 k launches/s), not by the work.
+template <bool SYM>
 __global__ __launch_bounds__(1024) void resident_batch(DevProblem P, const ResBatchEntry* __restrict__ entries) {
 	const ResBatchEntry* __restrict__ e = entries + blockIdx.y;
 	{   // pull every 64-byte line of the entry into the scalar cache with independent loads (see touch_kernel_arguments)
@@ -500,6 +526,6 @@ __global__ __launch_bounds__(1024) void resident_batch(DevProblem P, const ResBa
 		asm volatile("" ::"s"(__builtin_amdgcn_readfirstlane(acc)));
 	}
 	const ResSegment sg = e->sg;
-	if (blockIdx.x >= (1u << sg.g)) return;
-	resident_segment_body<false>(P, sg, e->prev, e->cur, blockIdx.x, e->score_out, 0ull);
+	if (blockIdx.x >= (1u << (sg.g - sg.half))) return;
+	resident_segment_body<false, SYM>(P, sg, e->prev, e->cur, blockIdx.x, e->score_out, 0ull);
 }

@@ -40,7 +40,8 @@ struct ResColumn {
 	uint32_t lowmask, nthr, stage_off, nwords;  // 2^Lb - 1; threads of the vectorised path (2^Lf / 4); word offset of this
 	                                  // column's record in the workgroup's staging area; words per plane
 	uint32_t ep0, mL0, PGq, pbits;    // copies of epos[0], mL[0], PG (kernel); pbits: bit u = parity of (low cell bits of
-	                                  // entry 4t+u's side-0 cell) & mL0 -- the part of the tie-break parity that is the same for every thread
+	                                  // entry 4t+u's side-0 cell) & mL0 -- the part of the tie-break parity that is the same for every thread;
+	                                  // bit 8 = parity of the number of cell bits above the ending read (mirror-image tie rule)
 	// ---- words 16..35: the 32-bit paths (vectorised without pk_ok, generic)
 	uint32_t Cp, Cm, Cc, mode;        // cost = min(Cp + S, Cm - S, Cc); an absent Cp / Cm is RES_ABSENT (never the minimum:
 	                                  // the planner guarantees every real value < 2^30).  mode: RES_MODE_*
@@ -125,6 +126,13 @@ struct ResSegment {
 	uint16_t n_in_grid, n_in_local, n_out_grid, n_out_local;
 	// packed runs (compact position | mask position << 8 | length << 16): logical index = OR of deposits of w and l
 	uint32_t in_grid[RES_IOSEG], in_local[RES_IOSEG], out_grid[RES_IOSEG], out_local[RES_IOSEG];
+	// Complement symmetry (single individual: D[~x] = D[x]): a run with `half` set launches only
+	// the workgroups whose top grid-read bit is 0; the other half of every column is its mirror image.
+	uint32_t half;          // 1: launch 2^(g-1) workgroups
+	uint32_t mirror_out;    // 1: also store the mirror image of the exit slice (the next step reads every entry)
+	uint32_t in_half;       // 1: the entering slice was written by a halved run without mirror_out: entries whose bit
+	uint32_t in_mirror_bit; //    `in_mirror_bit` is set are read from their complement (index ^ in_fullmask)
+	uint32_t in_fullmask, out_fullmask;  // all index bits of the entering / exit slice
 };
 
 // One run of a batched launch (resident_batch): the segment and the buffers of its job's lane.
@@ -168,7 +176,7 @@ struct BtUnit {
 	uint32_t c0, ncols;    // first column / number of columns
 	uint32_t col_off;      // run: index of its first record in the ResBacktrace array
 	uint32_t g, Lf_last, stage_words, n_wext;
-	uint32_t bt_lo, bt_hi, n_lext, pad0;   // run: pad0 = active columns | simple << 16 (ResSegment bt_active / bt_simple)
+	uint32_t bt_lo, bt_hi, n_lext, pad0;   // run: pad0 = active columns | simple << 16 | half << 20 (ResSegment bt_active / bt_simple / half)
 	uint32_t wext[RES_IOSEG];  // logical exit index -> workgroup index
 	uint32_t lext[RES_BT_LRUNS];  // logical exit index -> local exit index
 	uint32_t pad1[4];
@@ -203,6 +211,7 @@ struct ResidentPlan {
 };
 
 // Plans the whole forward pass.  `resident` false -> every step is a per-column step.
-void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, ResidentPlan& plan);
+// use_symmetry: 0 never halve runs, 1 halve full-chip runs (>= 2^8 workgroups), 2 halve every run with a grid read (tests)
+void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, ResidentPlan& plan, int use_symmetry = 1);
 
 }  // namespace whamd

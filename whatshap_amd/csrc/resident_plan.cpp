@@ -60,7 +60,7 @@ Runs runs_from_pairs(const Pairs& pairs) {
 
 }  // namespace
 
-void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, ResidentPlan& plan) {
+void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, ResidentPlan& plan, int use_symmetry) {
 	const uint32_t n = p.n_cols;
 	plan = ResidentPlan();
 	plan.col_to_res.assign(n, -1);
@@ -102,7 +102,13 @@ void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, Reside
 		uint32_t g = 0;
 		// one workgroup per CU (256 = 2^8) as long as the slice stays <= 2^12 entries; more workgroups only for the
 		// highest coverages (22, 23), where the slice would not fit otherwise
-		if ((int)b0 > l_pref) g = std::min<uint32_t>(b0 - (uint32_t)l_pref, 8);
+		// with the complement symmetry only half of the workgroups are launched: one more grid read keeps 2^8 of them busy
+		// (only where the chip would otherwise be full: below that, a run is bound by latency and by its fixed cost, and
+		// one more grid read only shortens it -- measured at coverage 12..18)
+		const bool try_half = single && use_symmetry > 0;
+		const bool bump = try_half && (int)b0 - l_pref >= 8;
+		const int lp = bump ? l_pref - 1 : l_pref;
+		if ((int)b0 > lp) g = std::min<uint32_t>(b0 - (uint32_t)lp, bump ? 9u : 8u);
 		if (b0 - g > 12) g = std::min<uint32_t>(b0 - 12, RES_GMAX);
 		// grid reads: the g entering reads that end last (ties: the younger read)
 		std::vector<uint32_t> order(b0);
@@ -258,6 +264,7 @@ void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, Reside
 				const uint32_t low = rc.mode == RES_MODE_E1_HIGH ? u : (rc.mode == RES_MODE_E1_BIT0 ? 2 * u : (((u >> 1) << 2) | (u & 1)));
 				rc.pbits |= ((uint32_t)__builtin_popcount(low & rc.mL[0]) & 1u) << u;
 			}
+			rc.pbits |= (((uint32_t)__builtin_popcount(rc.mG[0]) + (uint32_t)__builtin_popcount(rc.mL[0])) & 1u) << 8;
 			// record of a vectorised column: one byte per thread (nthr bytes); otherwise ballot words per plane
 			rc.nwords = fast ? std::max<uint32_t>(1, rc.nthr / 8) : std::max<uint32_t>(1, (1u << rc.Lf) / 64);
 			if (ped) {
@@ -374,6 +381,19 @@ void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, Reside
 				}
 			}
 		}
+		{   // complement symmetry: every column vectorised and cost(~x) == cost(x), i.e. Cp + (sum of all deltas) == Cm
+			bool half = try_half && g >= (use_symmetry > 1 ? 1u : 8u);  // below 2^8 a run is latency-bound: nothing to gain
+			for (size_t i = columns_mark; half && i < plan.columns.size(); ++i) {
+				const ResColumn& rc = plan.columns[i];
+				if (rc.mode == RES_MODE_GENERIC) half = false;
+				uint32_t sum = 0;
+				for (uint32_t q = 0; q < g; ++q) sum += (uint32_t)rc.dgrid[q];
+				for (uint32_t q = 0; q < 14; ++q) sum += (uint32_t)rc.dloc[q];
+				const bool both_absent = rc.Cp == RES_ABSENT && rc.Cm == RES_ABSENT;
+				if (!both_absent && (rc.Cp == RES_ABSENT || rc.Cm == RES_ABSENT || rc.Cp + sum != rc.Cm)) half = false;
+			}
+			seg.half = half ? 1u : 0u;
+		}
 		for (size_t i = columns_mark; i < plan.columns.size(); ++i) {
 			ResColumn& rc = plan.columns[i];
 			rc.flags = rc.mode | (rc.nfold << 8) | (rc.pk_ok << 12);
@@ -467,6 +487,27 @@ void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, Reside
 		B.n_in_local = (uint16_t)rbl.size();
 		std::copy(rbw.begin(), rbw.end(), B.in_grid);
 		std::copy(rbl.begin(), rbl.end(), B.in_local);
+	}
+	// ---- complement symmetry across step boundaries: who reads what a halved run wrote
+	for (size_t si = 0; si < plan.steps.size(); ++si) {
+		if (plan.steps[si].kind != 1) continue;
+		ResSegment& A = plan.segments[plan.steps[si].index];
+		const uint32_t f_exit = A.Lf_last + A.g;
+		A.out_fullmask = f_exit >= 32 ? 0xFFFFFFFFu : ((1u << f_exit) - 1u);
+		if (!A.half) continue;
+		const bool next_is_run = si + 1 < plan.steps.size() && plan.steps[si + 1].kind == 1;
+		if (!next_is_run) { A.mirror_out = 1; continue; }
+		// position of A's top grid-read bit in the index A stores with (wout | deposit(l))
+		uint32_t bit = 0xFFFFFFFFu;
+		for (uint32_t r = 0; r < A.n_out_grid; ++r) {
+			const uint32_t run = A.out_grid[r], compact = run & 255u, pos = (run >> 8) & 255u, len = run >> 16;
+			if (A.g - 1 >= compact && A.g - 1 < compact + len) bit = pos + (A.g - 1 - compact);
+		}
+		if (bit == 0xFFFFFFFFu) { A.mirror_out = 1; continue; }
+		ResSegment& B = plan.segments[plan.steps[si + 1].index];
+		B.in_half = 1;
+		B.in_mirror_bit = bit;
+		B.in_fullmask = A.out_fullmask;
 	}
 }
 
