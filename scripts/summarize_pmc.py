@@ -2,7 +2,7 @@
 """Averages rocprofv3 --pmc counter_collection.csv files per dispatch of one kernel (full-width dispatches only)."""
 import csv, glob, sys, collections
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
-kernel = sys.argv[2] if len(sys.argv) > 2 else "resident_segment<false>"
+kernel = sys.argv[2] if len(sys.argv) > 2 else "resident_segment<false"
 out = collections.OrderedDict()
 for path in sorted(glob.glob(root + "/pmc_*/*/*counter_collection.csv")):
     sums, counts = collections.Counter(), collections.Counter()
