@@ -47,3 +47,34 @@ def test_oracle_on_flattened_views_equals_reference_class(case):
     assert table.partitioning().tolist() == want["partitioning"]
     assert tv.tolist() == want["transmission"]
     assert got_reads == want["superreads"]
+
+
+def test_shim_install_rebinds_a_phase_like_module():
+    """whatshap_amd.shim.install on a stand-in for whatshap.cli.phase (which binds Pedigree / PedigreeDPTable at import,
+    cli/phase.py:34-42): the pedigree class becomes the recording subclass of the reference's, the table class the device
+    factory; the recorded pedigree equals what the mirror classes hold; the previous bindings are returned."""
+    import types
+
+    from whatshap_amd import shim
+    from whatshap_amd.core import Pedigree as MirrorPedigree
+
+    ref = reference_core()
+    phase = types.SimpleNamespace(Pedigree=ref.Pedigree, PedigreeDPTable=ref.PedigreeDPTable)
+    previous = shim.install(phase, ref)
+    assert previous == (ref.Pedigree, ref.PedigreeDPTable)
+    assert issubclass(phase.Pedigree, ref.Pedigree) and phase.Pedigree is not ref.Pedigree
+    ids = ref.NumericSampleIds()
+    ped = phase.Pedigree(ids)  # what create_pedigree() does (cli/phase.py:901-935)
+    gts = [ref.Genotype([0, 1]), ref.Genotype([1, 1]), ref.Genotype([0, 0])]
+    gls = [ref.PhredGenotypeLikelihoods([10, 0, 20]), None, ref.PhredGenotypeLikelihoods([0, 5, 7])]
+    ped.add_individual("father", gts, gls)
+    ped.add_individual("mother", gts)
+    ped.add_individual("child", gts)
+    ped.add_relationship("father", "mother", "child")
+    assert len(ped) == 3 and ped.variant_count == 3  # the reference object is fully functional
+    rec = ped.amd
+    assert isinstance(rec, MirrorPedigree) and rec._ids == [0, 1, 2] and rec._triples == [(0, 1, 2)]
+    assert [g.as_vector() for g in rec._genotypes[0]] == [[0, 1], [1, 1], [0, 0]]
+    assert rec._gls[0][0].as_vector() == [10.0, 0.0, 20.0] and rec._gls[0][1] is None and rec._gls[1] == [None] * 3
+    with pytest.raises(TypeError):
+        phase.PedigreeDPTable(ref.ReadSet(), [1, 1, 1], ref.Pedigree(ids))  # a pedigree that was not recorded
