@@ -8,6 +8,19 @@ from helpers import table_solution, first_difference
 from whatshap_amd import _native
 from whatshap_amd.synthetic import random_small_instance, synthetic_block
 
+SYMMETRY = os.environ.get("WHAMD_SOAK_SYMMETRY")  # "2": force the complement symmetry onto every run
+
+
+def device_solution(p, path=None):
+    t = _native.NativeTable(p, solve=False, path=path)
+    if SYMMETRY:
+        t.set_option("symmetry", SYMMETRY)
+    t.solve()
+    out = table_solution(t)
+    t.close()
+    return out
+
+
 t0 = time.time()
 bad = 0
 rng = random.Random(2026)
@@ -20,7 +33,7 @@ for i in range(1500):
         want, werr = None, str(exc)
     for path in ("auto", "column"):
         try:
-            got = table_solution(_native.NativeTable(p, path=path)); gerr = None
+            got = device_solution(p, path); gerr = None
         except _native.SolverError as exc:
             got, gerr = None, str(exc)
         if got != want or (werr is None) != (gerr is None):
@@ -29,7 +42,7 @@ for i in range(1500):
     n_small += 1
 print(f"{n_small} random tie-heavy instances x 2 paths: {bad} mismatches, {time.time()-t0:.1f} s", flush=True)
 n_mid = 0
-for seed in range(40):
+for seed in range(int(os.environ.get("WHAMD_SOAK_BLOCKS", "40"))):
     r = np.random.default_rng(seed)
     cov = int(r.integers(6, 15))
     trio = bool(seed % 3 == 0)
@@ -37,7 +50,7 @@ for seed in range(40):
     p = synthetic_block(n, min(cov, 11) if trio else cov, seed=1000 + seed, trio=trio, distrust_genotypes=bool(seed % 5 == 0),
                         step=int(r.integers(1, 4)), error_rate=float(r.uniform(0, 0.2)), drop_rate=float(r.uniform(0, 0.4)))
     want = table_solution(oracle.OracleTable(p))
-    got = table_solution(_native.NativeTable(p))
+    got = device_solution(p)
     if got != want:
         bad += 1
         print("MISMATCH mid", seed, cov, trio, first_difference(want, got))
