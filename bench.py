@@ -1,26 +1,49 @@
 #!/usr/bin/env python3
 """Benchmark of the wMEC/PedMEC hot path (BASELINE.json metric) on 1..N MI355X.
 
-A *step* is one complete pass of the hot path -- forward DP over every column + backtrace to the index path --
-over the rank's synthetic phasing block(s), with the flattened input already resident in HBM.
-At N=1 the workload is BASELINE.json configs[2]: synthetic diploid single-individual ReadSet, 200 000 het SNVs,
-max-coverage 20 (2^20 bipartitions per column).  For N>1 every rank solves its own block of the same shape
-(seed 3 + rank): independent blocks, no data-path collective (weak scaling), timing = max over ranks.
+A *step* is one complete pass of the hot path -- forward DP over every column + backtrace to the index path + host
+result extraction -- over the rank's synthetic phasing block(s), with the flattened input already resident in HBM.
 
-Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` and `cpu_baseline`.
+Workloads (BASELINE.json `configs`):
+  N = 1 : configs[2] -- synthetic diploid single-individual ReadSet, 200 000 het SNVs, max-coverage 20 (2^20
+          bipartitions per column), ONE table.
+  N > 1 : configs[4] -- 24 independent blocks x 100 000 SNVs, max-coverage 20 (seeds 100..123), assigned longest-first
+          to the least loaded rank (LPT), every rank keeps its blocks in flight through the host-side work queue
+          (`whamd_dptable_enqueue_many`), no data-path collective; total work is fixed => "scaling": "strong".
+  (`--blocks-per-gpu B` instead gives every rank B blocks of `--variants` columns: weak scaling, for A/B runs.)
+
+`python bench.py --gpus N` starts its N ranks itself (one process per GPU through torch.distributed.run on
+127.0.0.1) when it was not already launched by torchrun, and fails loudly when fewer than N devices are visible.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  roofline      counter-based: the fraction of the chip's VALU issue slots the dominant kernel uses (the binding roof of
+                this integer min-plus path; no MFMA), next to the LDS-pipe and MEASURED HBM fractions.  The counters
+                come from rocprofv3 --pmc passes that bench.py itself runs after the timed region (separate passes,
+                only with --kernel-trace) on a short slice of the same workload; `hbm_model_ratio` keeps SURVEY.md
+                8(d)'s algorithmic-bytes figure, labelled as what it is (bytes the reference's tables would move).
+  cpu_baseline  the compiled reference (oracle/_ref, 1 thread) on steady-state columns of the same ReadSet.
+  end_to_end    a fresh table: create (flatten + plan + upload) + solve + getters, columns/s (host-inclusive).
 """
 
 import argparse
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+HBM_PEAK_GBPS = 8000.0   # MI355X spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+CLOCK_GHZ = 2.4          # max shader clock
+N_SIMD = 1024            # 256 CUs x 4 SIMD-32
+N_CU = 256
+CONFIG4_BLOCKS, CONFIG4_VARIANTS, CONFIG4_SEED0 = 24, 100000, 100
 
 
 def parse_args():
@@ -28,71 +51,301 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--variants", type=int, default=200000, help="columns per block (BASELINE configs[2]: 200000)")
+    ap.add_argument("--variants", type=int, default=None, help="columns per block (default: 200000 at N=1, 100000 at N>1)")
     ap.add_argument("--coverage", type=int, default=20)
-    ap.add_argument("--blocks-per-gpu", type=int, default=1)
-    ap.add_argument("--trio", action="store_true", help="configs[3]-shaped workload (trio PedMEC) instead")
+    ap.add_argument("--blocks", type=int, default=None, help="total independent blocks of the job (default: 1 at N=1, 24 at N>1)")
+    ap.add_argument("--blocks-per-gpu", type=int, default=None, help="weak-scaling mode: every rank gets this many blocks")
+    ap.add_argument("--in-flight", type=int, default=4, help="blocks a rank keeps in flight at once")
+    ap.add_argument("--trio", action="store_true", help="configs[3]-shaped workload (trio PedMEC, coverage 15) instead")
     ap.add_argument("--path", default="auto")
+    ap.add_argument("--option", action="append", default=[], help="key=value passed to whamd_dptable_set_option")
     ap.add_argument("--cpu-baseline-columns", type=int, default=-1,
-                    help="columns of the same ReadSet timed on the compiled reference (default: ~15-20 s worth; 0 = skip)")
+                    help="steady-state columns of the same ReadSet timed on the compiled reference (default: ~15 s worth; 0 = skip)")
+    ap.add_argument("--cpu-baseline-procs", type=int, default=0,
+                    help="also time P concurrent single-thread reference processes on independent blocks (BASELINE.md 3.5; -1 = nproc)")
+    ap.add_argument("--pmc", default="auto", choices=["auto", "on", "off"],
+                    help="run the rocprofv3 counter passes after the timed region (auto: N=1 and rocprofv3 present)")
+    ap.add_argument("--pmc-variants", type=int, default=8000)
+    ap.add_argument("--pmc-keep", default=os.path.join(ROOT, "gpurun_out", "pmc_live"), help="where the filtered counter CSVs are kept")
+    ap.add_argument("--pmc-inner", action="store_true", help=argparse.SUPPRESS)     # the profiled child: solve and exit
+    ap.add_argument("--cpu-sample-worker", type=int, default=0, help=argparse.SUPPRESS)  # child of --cpu-baseline-procs
     return ap.parse_args()
 
 
-def cpu_baseline(args, n_columns):
-    """The compiled reference (oracle/_ref, single thread) on a bounded prefix of the same workload."""
+# ------------------------------------------------------------------------------------------------ workload
+def resolve_workload(args, world):
+    """-> (list of (seed, n_variants) for every block of the job, scaling, description)."""
+    cov = args.coverage
+    if args.trio and args.coverage == 20:
+        cov = args.coverage = 15
+    if args.blocks_per_gpu is not None:
+        v = args.variants or 200000
+        blocks = [(3 + b, v) for b in range(world * args.blocks_per_gpu)]
+        return blocks, "weak", f"{args.blocks_per_gpu} block(s) of {v} SNVs per GPU"
+    if world == 1 and args.blocks is None:
+        v = args.variants or (100000 if args.trio else 200000)
+        tag = ""
+        if not args.trio and v == 200000 and cov == 20:
+            tag = " (BASELINE configs[2])"
+        if args.trio and v == 100000 and cov == 15:
+            tag = " (BASELINE configs[3])"
+        return [(4 if args.trio else 3, v)], "weak", f"1 block of {v} SNVs{tag}"
+    n = args.blocks or CONFIG4_BLOCKS
+    v = args.variants or CONFIG4_VARIANTS
+    tag = " (BASELINE configs[4])" if (n == CONFIG4_BLOCKS and v == CONFIG4_VARIANTS and cov == 20 and not args.trio) else ""
+    return [(CONFIG4_SEED0 + b, v) for b in range(n)], "strong", f"{n} independent blocks x {v} SNVs, LPT over {world} GPU(s){tag}"
+
+
+def apply_options(table, args):
+    for kv in args.option:
+        key, _, value = kv.partition("=")
+        table.set_option(key, value)
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_info():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"nproc": os.cpu_count(), "model": model}
+
+
+def reference_seconds(args, seed, n_columns):
+    """Constructor + the three getters of the compiled reference (oracle/_ref; the C restatement if it is absent) on the
+    first `n_columns` columns of the seeded ReadSet; single thread."""
     import oracle
     from whatshap_amd.synthetic import synthetic_block
 
     kind = "reference" if oracle.have_reference() else "port"
     table_cls = oracle.ReferenceTable if kind == "reference" else oracle.OracleTable
-    problem = synthetic_block(args.variants, args.coverage, seed=3, trio=args.trio, n_columns_limit=n_columns)
+    problem = synthetic_block(args.variants_for_cpu, args.coverage, seed=seed, trio=args.trio, n_columns_limit=n_columns)
     t0 = time.perf_counter()
     table = table_cls(problem)
     score = table.optimal_score()
     table.super_reads()
     table.partitioning()
-    dt = time.perf_counter() - t0
-    cols = table.n_columns
+    return time.perf_counter() - t0, table.n_columns, score, kind
+
+
+def cpu_baseline(args, seed):
+    """Steady-state columns/s of the single-thread reference: the first 2 * coverage columns of the synthetic ReadSet
+    are its coverage ramp (next to free), so the rate is the DIFFERENCE between two prefixes that both contain it."""
+    ramp = 2 * args.coverage
+    n_cpu = args.cpu_baseline_columns
+    ta, ca, _, kind = reference_seconds(args, seed, ramp + 8)
+    if n_cpu < 0:
+        tb, cb, _, _ = reference_seconds(args, seed, ramp + 24)
+        per_col = max((tb - ta) / max(cb - ca, 1), 1e-6)
+        n_cpu = int(max(24, min(args.variants_for_cpu - ramp - 8, 15.0 / per_col)))
+    tc, cc, score, _ = reference_seconds(args, seed, ramp + 8 + n_cpu)
+    steady_cols, steady_s = cc - ca, max(tc - ta, 1e-9)
+    info = cpu_info()
     return {
-        "value": cols / dt,
+        "value": steady_cols / steady_s,
         "unit": "variant-columns/s",
         "cores": 1,
         "kind": kind,
-        "sample": f"first {cols} columns of the same seeded ReadSet (coverage {args.coverage}"
-                  f"{', trio' if args.trio else ''}), constructor + 3 getters, {dt:.1f} s wall, optimal cost {score}",
-        "seconds": dt,
+        "sample": f"columns {ca}..{cc} of the same seeded ReadSet (coverage {args.coverage}{', trio' if args.trio else ''}; all at full "
+                  f"coverage: the {ramp}-column ramp is timed separately and subtracted), constructor + 3 getters, {steady_s:.1f} s of "
+                  f"{tc:.1f} s wall, optimal cost of the prefix {score}",
+        "seconds": tc + ta,
+        "host": info,
     }
 
 
-def measured_traffic(args):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), valid for the
-    default workload only; bench.py cannot run the profiler itself."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if args.trio or args.coverage != 20 or args.path not in ("auto", "resident") or not os.path.exists(path):
-        return None
-    with open(path) as f:
-        return json.load(f)["traffic_bytes_per_launch"]
+def cpu_baseline_procs(args, procs):
+    """P single-thread reference processes at once, each on its own block prefix (independent blocks
+    are the only parallelism the reference has).  Aggregate steady-state columns/s."""
+    ramp = 2 * args.coverage
+    cols = 16
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-sample-worker", str(cols), "--coverage", str(args.coverage),
+           "--variants", str(args.variants_for_cpu)] + (["--trio"] if args.trio else [])
+    t0 = time.perf_counter()
+    children = [subprocess.Popen(cmd + ["--blocks", str(CONFIG4_SEED0 + i)], stdout=subprocess.PIPE, text=True) for i in range(procs)]
+    rates = []
+    for ch in children:
+        out, _ = ch.communicate(timeout=600)
+        if ch.returncode == 0 and out.strip():
+            rates.append(float(out.strip().splitlines()[-1]))
+    return {"value": sum(rates), "unit": "variant-columns/s", "cores": len(rates), "kind": "reference",
+            "sample": f"{len(rates)} concurrent single-thread processes, each {cols} steady-state columns (after the {ramp}-column ramp) "
+                      f"of its own seeded block, {time.perf_counter() - t0:.1f} s wall", "host": cpu_info()}
+
+
+def cpu_sample_worker(args):
+    args.variants_for_cpu = args.variants or 100000
+    seed = args.blocks or CONFIG4_SEED0
+    ramp = 2 * args.coverage
+    ta, ca, _, _ = reference_seconds(args, seed, ramp + 4)
+    tb, cb, _, _ = reference_seconds(args, seed, ramp + 4 + args.cpu_sample_worker)
+    print((cb - ca) / max(tb - ta, 1e-9))
+
+
+# ------------------------------------------------------------------------------------------------ counters
+PMC_PASSES = [
+    ("insts", "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"),
+    ("fetch", "FETCH_SIZE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY"),
+    ("write", "WRITE_SIZE SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"),
+]
+
+
+def run_pmc_passes(args, kernel_substring, keep_dir):
+    """Runs the counter passes on `--pmc-variants` columns of the same workload (one rocprofv3 invocation per counter
+    group, --pmc only ever combined with --kernel-trace) and returns per-dispatch averages over the FULL-WIDTH dispatches
+    of the dominant kernel (the largest grid it was launched with)."""
+    import csv
+    import collections
+
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    inner = [sys.executable, os.path.abspath(__file__), "--pmc-inner", "--variants", str(args.pmc_variants), "--coverage", str(args.coverage),
+             "--path", args.path, "--steps", "1", "--warmup", "1"] + (["--trio"] if args.trio else [])
+    for kv in args.option:
+        inner += ["--option", kv]
+    env = dict(os.environ, TMPDIR="/tmp")
+    averages, counts, notes = {}, {}, []
+    os.makedirs(keep_dir, exist_ok=True)
+    for name, counters in PMC_PASSES:
+        out_dir = tempfile.mkdtemp(prefix=f"whamd_pmc_{name}_", dir="/tmp")
+        cmd = [rocprof, "--kernel-trace", "--pmc"] + counters.split() + ["--output-format", "csv", "-d", out_dir, "-o", "p", "--"] + inner
+        try:
+            res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+        except subprocess.TimeoutExpired:
+            notes.append(f"{name}: timeout")
+            continue
+        files = []
+        for base, _, names in os.walk(out_dir):
+            files += [os.path.join(base, n) for n in names if n.endswith("counter_collection.csv")]
+        if res.returncode != 0 or not files:
+            notes.append(f"{name}: rc={res.returncode} {res.stderr[-200:]}")
+            continue
+        rows = []
+        with open(files[0]) as f:
+            for row in csv.DictReader(f):
+                if kernel_substring in row["Kernel_Name"]:
+                    rows.append(row)
+        if not rows:
+            notes.append(f"{name}: kernel {kernel_substring} not in the trace")
+            continue
+        full = max(int(r["Grid_Size"]) for r in rows)
+        sums, cnt = collections.Counter(), collections.Counter()
+        kept = []
+        for r in rows:
+            if int(r["Grid_Size"]) != full:
+                continue
+            sums[r["Counter_Name"]] += float(r["Counter_Value"])
+            cnt[r["Counter_Name"]] += 1
+            kept.append(r)
+        for c in sums:
+            averages[c] = sums[c] / cnt[c]
+            counts[c] = cnt[c]
+        averages["_grid_size"] = full
+        averages["_workgroup_size"] = int(kept[0]["Workgroup_Size"])
+        with open(os.path.join(keep_dir, f"{name}_counter_collection.csv"), "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=list(kept[0].keys()))
+            w.writeheader()
+            w.writerows(kept)
+        shutil.rmtree(out_dir, ignore_errors=True)
+    if not averages:
+        return None, "; ".join(notes)
+    averages["_dispatches"] = max(counts.values()) if counts else 0
+    return averages, "; ".join(notes)
+
+
+def roofline_from_counters(pmc, avg_launch_us, kernel, bytes_per_launch_model, args):
+    """Counter-based fractions of the chip's peaks for the dominant kernel.  Durations are the
+    un-profiled HIP-event launch time of the timed region; counters are per-dispatch averages of the profiled slice."""
+    cycles = avg_launch_us * 1e-6 * CLOCK_GHZ * 1e9
+    out = {
+        "bound": "valu_issue",
+        "kernel": kernel,
+        "unit": "wave-instructions/cycle (chip)",
+        "peak": N_SIMD / 2.0,   # a wave64 VALU instruction occupies its SIMD-32 for 2 cycles
+        "avg_launch_us": avg_launch_us,
+        "clock_ghz_assumed": CLOCK_GHZ,
+    }
+    if pmc is None:
+        out.update({"achieved": None, "frac": None, "traffic": None})
+        return out
+    valu = pmc.get("SQ_INSTS_VALU")
+    if valu is not None:
+        out["achieved"] = valu / cycles
+        out["frac"] = out["achieved"] / out["peak"]
+        out["valu_issue_frac"] = out["frac"]
+    fetch_kb, write_kb = pmc.get("FETCH_SIZE"), pmc.get("WRITE_SIZE")
+    if fetch_kb is not None and write_kb is not None:
+        # MI355X_MICROARCH.md "HBM": gfx950's FETCH_SIZE reports half of a wide coalesced read stream -> doubled; WRITE_SIZE as is
+        traffic = 2.0 * fetch_kb * 1024.0 + write_kb * 1024.0
+        out["traffic"] = traffic
+        out["hbm_frac"] = traffic / (avg_launch_us * 1e-6) / (HBM_PEAK_GBPS * 1e9)
+        out["traffic_note"] = "bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KB counters of separate rocprofv3 --pmc passes)"
+    else:
+        out["traffic"] = None
+    lds = pmc.get("SQ_LDS_IDX_ACTIVE")
+    if lds is not None:
+        out["lds_pipe_frac"] = lds / (N_CU * cycles)
+    out["hbm_model_ratio"] = bytes_per_launch_model / (avg_launch_us * 1e-6) / (HBM_PEAK_GBPS * 1e9)
+    out["hbm_model_note"] = ("SURVEY.md 8(d) algorithmic bytes (4*T*2^b + 12*T*2^f + 12*k per column: the reference's three tables) per "
+                             "launch / launch time / 8 TB/s -- NOT a roofline fraction: those tables are never materialised here")
+    out["counters_per_launch"] = {k: v for k, v in pmc.items() if not k.startswith("_")}
+    out["counters_measured_on"] = (f"{pmc.get('_dispatches')} full-width dispatches ({pmc.get('_grid_size')} work-items, "
+                                   f"{pmc.get('_workgroup_size')} per workgroup) of `bench.py --variants {args.pmc_variants}` "
+                                   f"(same seed, coverage {args.coverage}), rocprofv3 --kernel-trace --pmc, one pass per counter group")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ ranks
+def self_launch(args):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves."""
+    from whatshap_amd import _native
+
+    visible = _native.device_count()
+    if visible < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {visible} HIP device(s) visible; refusing to run fewer ranks than asked for")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
 def main():
     args = parse_args()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-
-    import torch  # device selection, synchronisation and the rendezvous only
+    if args.cpu_sample_worker:
+        return cpu_sample_worker(args)
     import __graft_entry__ as entry
 
     if not os.path.exists(os.path.join(ROOT, "whatshap_amd", "libwhatshap_amd.so")):
         entry.build()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return self_launch(args)
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch  # device selection, synchronisation and the rendezvous only
+
     from whatshap_amd import _native
     from whatshap_amd.blocks import assign_blocks, block_weight
     from whatshap_amd.synthetic import synthetic_block
 
     if not torch.cuda.is_available() or _native.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if local_rank >= _native.device_count():
+        raise SystemExit(f"rank {rank}: device {local_rank} requested, {_native.device_count()} visible")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run (also with one rank, to exercise the path)
@@ -101,23 +354,26 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    # ---- the job: world * blocks_per_gpu independent blocks, assigned largest-first to the least loaded rank
-    n_blocks = world * args.blocks_per_gpu
-    seeds = [3 + b for b in range(n_blocks)]
-    weights = [block_weight(args.variants, args.coverage, 4 if args.trio else 1) for _ in seeds]
+    blocks, scaling, workload = resolve_workload(args, world)
+    T = 4 if args.trio else 1
+    weights = [block_weight(v, args.coverage, T) for _, v in blocks]
     mine = assign_blocks(weights, world)[rank]
     tables = []
     for b in mine:
-        problem = synthetic_block(args.variants, args.coverage, seed=seeds[b], trio=args.trio)
-        tables.append(_native.NativeTable(problem, device=local_rank, path=None if args.path == "auto" else args.path,
-                                          solve=False))
+        seed, v = blocks[b]
+        problem = synthetic_block(v, args.coverage, seed=seed, trio=args.trio)
+        t = _native.NativeTable(problem, device=local_rank, path=None if args.path == "auto" else args.path, solve=False)
+        apply_options(t, args)
+        tables.append(t)
 
     def step():
-        # host-side work queue: the blocks of this rank are submitted to their own streams (launch sequences
+        # host-side work queue: `in_flight` blocks of this rank at a time on their own streams (launch sequences
         # interleaved, so that they start together), then collected
-        _native.enqueue_many(tables)
-        for t in tables:
-            t.wait()
+        for start in range(0, len(tables), args.in_flight):
+            window = tables[start:start + args.in_flight]
+            _native.enqueue_many(window)
+            for t in window:
+                t.wait()
 
     def sync():
         torch.cuda.synchronize()
@@ -127,9 +383,12 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if args.pmc_inner:
+        step()
+        return
     sync()
     t0 = time.perf_counter()
-    fwd_ms = bt_ms = total_ms = 0.0
+    fwd_ms = bt_ms = 0.0
     launches = 0
     for _ in range(args.steps):
         step()
@@ -137,30 +396,28 @@ def main():
             s = t.stats()
             fwd_ms += s["forward_ms"]
             bt_ms += s["backtrace_ms"]
-            total_ms += s["total_ms"]
             launches += s["forward_launches"]
     sync()
     elapsed = time.perf_counter() - t0
+    stats = [t.stats() for t in tables]
+    totals = [float(sum(s["n_columns"] for s in stats)), float(sum(s["n_costs"] for s in stats)), float(sum(t.optimal_score() for t in tables))]
+    per_rank_checksums = [int(totals[2])]
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-
-    stats = [t.stats() for t in tables]
-    cols_rank = sum(s["n_columns"] for s in stats)
-    costs_rank = sum(s["n_costs"] for s in stats)
-    bytes_rank = sum(s["algorithmic_bytes"] for s in stats)
-    # every rank holds blocks of identical shape, so whole-job totals are world * per-rank totals
-    cols_job = cols_rank * world
-    costs_job = costs_rank * world
-    checksum = sum(t.optimal_score() for t in tables)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, totals)
+        per_rank_checksums = [int(g[2]) for g in gathered]
+        totals = [sum(g[i] for g in gathered) for i in range(3)]
+    cols_job, costs_job = totals[0], totals[1]
 
     if rank == 0:
-        # dominant kernel: the column step (one launch per column).  Algorithmic bytes per launch:
-        # 4*T*2^b (read previous projection) + 12*T*2^f (projection + two backtrace tables) + 12*k.
         avg_launch_us = fwd_ms * 1e3 / max(launches, 1)
+        bytes_rank = sum(s["algorithmic_bytes"] for s in stats)
         bytes_per_launch = bytes_rank / max(launches / args.steps, 1)
-        achieved = bytes_per_launch / (avg_launch_us * 1e-6) / 1e9
+        column_path = args.path in ("column", "column_keys")
+        kernel = ("column_step_fused" if column_path else ("resident_segment_ped" if args.trio else "resident_segment"))
         out = {
             "metric": "variant-columns/sec at max-coverage %d (bipartition-costs/sec reported alongside)" % args.coverage,
             "value": cols_job * args.steps / elapsed,
@@ -171,47 +428,62 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
             "config": {
-                "workload": ("synthetic trio PedMEC ReadSet" if args.trio else "synthetic diploid single-individual ReadSet")
-                            + f", {args.variants} het SNVs, max-coverage {args.coverage}, {args.blocks_per_gpu} block(s) per GPU"
-                            + (" (BASELINE configs[2])" if (not args.trio and args.variants == 200000 and args.coverage == 20) else ""),
-                "n_variants": args.variants,
+                "workload": ("synthetic trio PedMEC" if args.trio else "synthetic diploid single-individual") + f", max-coverage {args.coverage}: " + workload,
+                "blocks": len(blocks),
+                "blocks_per_rank": [len(r) for r in assign_blocks(weights, world)],
+                "blocks_in_flight_per_gpu": min(args.in_flight, len(mine)),
                 "max_coverage": args.coverage,
-                "transmission_values": 4 if args.trio else 1,
-                "blocks": n_blocks,
+                "transmission_values": T,
                 "path": args.path,
-                "optimal_cost_checksum_rank0": checksum,
+                "options": args.option,
+                "optimal_cost_checksum": int(totals[2]),
+                "optimal_cost_checksum_per_rank": per_rank_checksums,
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": ("column_step_fused<%d,%d>" % ((4, 3) if args.trio else (1, 1))) if args.path in ("column", "column_keys")
-                          else ("resident_segment_ped" if args.trio else "resident_segment"),
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": measured_traffic(args),
-                "avg_launch_us": avg_launch_us,
-                "algorithmic_bytes_per_launch": bytes_per_launch,
-                "forward_ms_per_step": fwd_ms / args.steps,
-                "backtrace_ms_per_step": bt_ms / args.steps,
-            },
+            "rank0": {"forward_ms_per_step": fwd_ms / args.steps, "backtrace_ms_per_step": bt_ms / args.steps,
+                      "forward_launches_per_step": launches / args.steps},
         }
-        n_cpu = args.cpu_baseline_columns
-        if n_cpu < 0:
-            # bounded sample of ~15 s of CPU work.  Calibrated on two short prefixes (host CPUs differ by 2x): the first
-            # 2 * coverage columns are the coverage ramp of the synthetic ReadSet and cost next to nothing
-            ramp = 2 * args.coverage
-            a, b = cpu_baseline(args, ramp + 8), cpu_baseline(args, ramp + 24)
-            per_col = max((b["seconds"] - a["seconds"]) / 16.0, 1e-6)
-            n_cpu = int(max(ramp + 24, min(args.variants, ramp + 8 + (15.0 - a["seconds"]) / per_col)))
-        if n_cpu > 0:
-            out["cpu_baseline"] = cpu_baseline(args, n_cpu)
-            out["speedup_vs_cpu_baseline"] = out["value"] / world / out["cpu_baseline"]["value"]
+        # ---- a fresh table end to end (host-inclusive): create + solve + getters
+        if world == 1:
+            seed, v = blocks[mine[0]]
+            problem = synthetic_block(v, args.coverage, seed=seed, trio=args.trio)
+            te0 = time.perf_counter()
+            fresh = _native.NativeTable(problem, device=local_rank, path=None if args.path == "auto" else args.path, solve=False)
+            apply_options(fresh, args)
+            te1 = time.perf_counter()
+            fresh.solve()
+            fresh.optimal_score(), fresh.super_reads(), fresh.partitioning()
+            te2 = time.perf_counter()
+            out["end_to_end"] = {"value": v / (te2 - te0), "unit": "variant-columns/s", "create_ms": (te1 - te0) * 1e3,
+                                 "solve_and_getters_ms": (te2 - te1) * 1e3,
+                                 "what": "whamd_dptable_create (flatten + plan + upload) + solve + 3 getters of ONE fresh table from host arrays"}
+            fresh.close()
+        # ---- counters of the dominant kernel
+        pmc, pmc_note = None, "skipped"
+        want_pmc = args.pmc == "on" or (args.pmc == "auto" and world == 1 and not column_path)
+        if want_pmc:
+            for t in tables:
+                t.release_device()
+            try:
+                pmc, pmc_note = run_pmc_passes(args, kernel, args.pmc_keep)
+            except Exception as exc:  # noqa: BLE001 -- the bench line must come out whatever the profiler does
+                pmc_note = repr(exc)
+        out["roofline"] = roofline_from_counters(pmc, avg_launch_us, kernel, bytes_per_launch, args)
+        out["roofline"]["pmc_note"] = pmc_note
+        # ---- CPU baseline (rank 0, N = 1 only)
+        args.variants_for_cpu = blocks[0][1]
+        if world == 1 and args.cpu_baseline_columns != 0:
+            out["cpu_baseline"] = cpu_baseline(args, blocks[0][0])
+            out["speedup_vs_cpu_baseline_device_only"] = out["value"] / out["cpu_baseline"]["value"]
+            if "end_to_end" in out:
+                out["speedup_vs_cpu_baseline"] = out["end_to_end"]["value"] / out["cpu_baseline"]["value"]
+        procs = args.cpu_baseline_procs if args.cpu_baseline_procs >= 0 else (os.cpu_count() or 1)
+        if world == 1 and procs > 0:
+            out["cpu_baseline_all_cores"] = cpu_baseline_procs(args, procs)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

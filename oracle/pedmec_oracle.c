@@ -535,7 +535,7 @@ int pmo_create(const whamd_readset_view* rs, const uint32_t* recombcost, size_t 
 	memcpy(t->var_position, rs->var_position, nnz * sizeof(int32_t));
 	memcpy(t->var_allele, rs->var_allele, nnz);
 	memcpy(t->var_quality, rs->var_quality, nnz * sizeof(uint32_t));
-	for (uint64_t i = 0; i < nnz; ++i) if (t->var_allele[i] > 1) fail(t, WHAMD_ERR_INVALID, "read allele must be 0 or 1");
+	for (uint64_t i = 0; i < nnz; ++i) if (t->var_allele[i] > WHAMD_ALLELE_BLANK) fail(t, WHAMD_ERR_INVALID, "read allele must be 0 (REF), 1 (ALT) or 2 (BLANK)"); /* BLANK is skipped, :69-70, 93-94 */
 	t->n_ind = ped->n_individuals;
 	t->n_triples = ped->n_triples;
 	t->n_variants = ped->n_variants;

@@ -55,5 +55,24 @@ for seed in range(int(os.environ.get("WHAMD_SOAK_BLOCKS", "40"))):
         bad += 1
         print("MISMATCH mid", seed, cov, trio, first_difference(want, got))
     n_mid += 1
-print(f"{n_mid} synthetic blocks (coverage 6-14, steps 1-3, error/drop rates varied, single + trio): total mismatches {bad}, {time.time()-t0:.1f} s")
+print(f"{n_mid} synthetic blocks (coverage 6-14, steps 1-3, error/drop rates varied, single + trio): total mismatches {bad}, {time.time()-t0:.1f} s", flush=True)
+# high coverage, single individual, DEFAULT symmetry unless WHAMD_SOAK_SYMMETRY is set: full-chip (and halved) runs chained
+# through the exchange layouts -- where the benchmark runs.  Prefixes: the ramp (2 * step... columns) + 30-70 full-width columns.
+n_high = 0
+for seed in range(int(os.environ.get("WHAMD_SOAK_HIGH", "15"))):
+    r = np.random.default_rng(7000 + seed)
+    cov = int(r.integers(16, 21))
+    step = int(r.integers(1, 4))
+    ncols = step * cov + int(r.integers(30, 70)) if cov < 20 else step * cov + int(r.integers(30, 50))
+    p = synthetic_block(100000, cov, seed=2000 + seed, step=step, distrust_genotypes=bool(seed % 6 == 5), error_rate=float(r.uniform(0, 0.1)),
+                        drop_rate=float(r.uniform(0, 0.3)), n_columns_limit=ncols)
+    want = table_solution(oracle.OracleTable(p))
+    for path in ("auto", "resident"):
+        got = device_solution(p, path)
+        if got != want:
+            bad += 1
+            print("MISMATCH high", seed, cov, step, path, first_difference(want, got))
+    n_high += 1
+    print(f"  high-coverage block {seed}: coverage {cov}, step {step}, {ncols} columns ok={bad == 0} ({time.time()-t0:.0f} s)", flush=True)
+print(f"{n_high} high-coverage prefixes (coverage 16-20, steps 1-3, symmetry {SYMMETRY or 'default'}): total mismatches {bad}, {time.time()-t0:.1f} s")
 sys.exit(1 if bad else 0)

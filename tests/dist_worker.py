@@ -55,7 +55,8 @@ def main():
         local = {}
         for b in mine:
             sub = blocks[b][0]
-            table = _native.NativeTable(sub, device=rank) if use_device else oracle.OracleTable(sub)
+            # one process per GPU; with fewer devices than ranks (a 1-GPU box) the ranks share device 0
+            table = _native.NativeTable(sub, device=rank % max(_native.device_count(), 1)) if use_device else oracle.OracleTable(sub)
             local[b] = table_solution(table)
         gathered = [None] * world
         dist.all_gather_object(gathered, local)

@@ -1,0 +1,68 @@
+"""GPU (-m gpu): bit-exact parity where the headline number is produced (BASELINE configs[2] / configs[4]).
+
+* coverage-20 prefix of the configs[2] ReadSet, >= 300 full-width columns, against the oracle, for every forward path
+  and every setting of the complement symmetry (SURVEY.md 8d parity protocol);
+* coverage 21 and 23 (the CLI's cap, whatshap/cli/phase.py:1181-1182) prefixes with >= 20 full-width columns;
+* at FULL size (configs[2] and one configs[4] block): every forward path / symmetry setting produces the same cost,
+  index path, partitioning and superreads (the tie rules of src/pedigreedptable.cpp:306-327 included), and the optimum
+  equals the independently re-evaluated objective.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from helpers import first_difference, table_solution, wmec_cost_of_partitioning
+from whatshap_amd import _native
+from whatshap_amd.synthetic import synthetic_block
+
+pytestmark = pytest.mark.gpu
+
+# (path, symmetry) combinations of the single-individual forward pass; "auto" is what bench.py runs
+VARIANTS = [("auto", "1"), ("auto", "0"), ("auto", "2"), ("resident", "1"), ("resident", "0"), ("resident", "2"), ("column", "1")]
+
+
+def solve(problem, path, symmetry, **options):
+    t = _native.NativeTable(problem, solve=False, path=path)
+    t.set_option("symmetry", symmetry)
+    for key, value in options.items():
+        t.set_option(key, str(value))
+    t.solve()
+    out = table_solution(t)
+    t.close()
+    return out
+
+
+@pytest.fixture(scope="module")
+def coverage20_prefix():
+    """First 340 columns of BASELINE configs[2] (seed 3): 40 columns of coverage ramp, 300 at 2^20 bipartitions."""
+    p = synthetic_block(n_variants=200000, coverage=20, seed=3, n_columns_limit=340)
+    return p, table_solution(oracle.OracleTable(p))
+
+
+@pytest.mark.parametrize("path,symmetry", VARIANTS)
+def test_coverage_20_prefix_300_full_width_columns_vs_oracle(coverage20_prefix, path, symmetry):
+    p, want = coverage20_prefix
+    got = solve(p, path, symmetry)
+    assert got == want, first_difference(want, got)
+
+
+@pytest.mark.parametrize("kw", [dict(n_variants=200000, coverage=21, seed=51, n_columns_limit=66),
+                                dict(n_variants=200000, coverage=23, seed=52, n_columns_limit=68)], ids=str)
+def test_coverage_21_and_23_prefixes_vs_oracle(kw):
+    p = synthetic_block(**kw)
+    want = table_solution(oracle.OracleTable(p))
+    for path, symmetry in (("auto", "1"), ("auto", "0"), ("resident", "1")):
+        got = solve(p, path, symmetry)
+        assert got == want, (path, symmetry, first_difference(want, got))
+
+
+@pytest.mark.parametrize("kw", [dict(n_variants=200000, coverage=20, seed=3),      # BASELINE configs[2]
+                                dict(n_variants=100000, coverage=20, seed=100)],   # first block of configs[4]
+                         ids=["config3_200k_cov20", "config5_block_100k_cov20"])
+def test_full_size_every_path_and_symmetry_setting_agree(kw):
+    p = synthetic_block(**kw)
+    base = solve(p, "auto", "1")
+    assert wmec_cost_of_partitioning(p, np.asarray(base["partitioning"], dtype=np.uint8)) == base["cost"]
+    for path, symmetry in VARIANTS[1:]:
+        got = solve(p, path, symmetry)
+        assert got == base, (path, symmetry, first_difference(base, got))

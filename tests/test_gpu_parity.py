@@ -595,3 +595,54 @@ def test_complement_symmetry_on_every_run(seed):
             got = table_solution(t)
             assert got == want, (name, level, first_difference(want, got))
             t.close()
+
+
+def test_blank_alleles_inside_reads_vs_oracle():
+    """Entry::BLANK as the allele of a read's own variant (legal for the reference, src/pedigreecolumncostcomputer.cpp:
+    69-70): skipped, its phred ignored -- on every device path."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_oracle import _with_blank_alleles
+
+    rng = random.Random(314)
+    for i in range(80):
+        p = _with_blank_alleles(random_small_instance(rng, allow_conflict=False), rng)
+        want = table_solution(oracle.OracleTable(p))
+        for path in PATHS:
+            got = native_solution(p, path)
+            assert got == want, (i, path, first_difference(want, got))
+    big = _with_blank_alleles(synthetic_block(n_variants=500, coverage=13, seed=77), rng)
+    assert native_solution(big, "auto") == table_solution(oracle.OracleTable(big))
+
+
+def test_work_queue_over_several_device_workers():
+    """solve_blocks(devices=[...]): LPT assignment of independent blocks to one worker thread per device entry (two
+    workers on device 0 here), results in input order and equal to solving every block on its own; a device that does
+    not exist is an error, not a fallback."""
+    from whatshap_amd.blocks import solve_blocks
+
+    problems = [synthetic_block(n_variants=2500 + 400 * i, coverage=10 + (i % 4) * 2, seed=500 + i) for i in range(7)]
+    want = [native_solution(p) for p in problems]
+    for devices in ([0], [0, 0], [0, 0, 0]):
+        tables = solve_blocks(problems, devices=devices, max_in_flight=2)
+        assert [table_solution(t) for t in tables] == want
+    with pytest.raises(RuntimeError, match="visible"):
+        solve_blocks(problems[:1], devices=[0, _native.device_count()])
+
+
+def test_two_ranks_on_the_device_path():
+    """tests/dist_worker.py with the HIP path (WHAMD_TEST_DEVICE=1): two processes (gloo rendezvous, both on device 0 of
+    a 1-GPU box), every rank solves its LPT share on the device, rank 0 checks the concatenation against the
+    whole-instance oracle."""
+    import os, socket, subprocess, sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", WHAMD_TEST_BACKEND="gloo", WHAMD_TEST_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(here, "dist_worker.py")]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "BLOCKS_OK" in res.stdout

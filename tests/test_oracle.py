@@ -100,3 +100,42 @@ def test_oracle_vs_compiled_reference_random():
 def test_oracle_vs_compiled_reference_synthetic(kw):
     p = synthetic_block(**kw)
     assert table_solution(oracle.OracleTable(p)) == table_solution(oracle.ReferenceTable(p))
+
+
+def _with_blank_alleles(p, rng):
+    """Copy of `p` in which some interior variants of reads carry Entry::BLANK (allele 2) with a non-zero phred."""
+    import numpy as np
+    from whatshap_amd import _native
+
+    alle = p.var_allele.copy()
+    ptr = p.read_ptr.astype(np.int64)
+    for r in range(p.n_reads):
+        for i in range(int(ptr[r]) + 1, int(ptr[r + 1]) - 1):
+            if rng.random() < 0.3:
+                alle[i] = 2
+    gl = None if p.genotype_likelihoods is None else p.genotype_likelihoods.reshape(p.n_individuals, p.n_variants, 3)
+    return _native.ProblemArrays(p.read_ptr, p.var_position, alle, p.var_quality, p.read_sample_id, p.individual_id, p.triple_ids,
+                                 p.genotype.reshape(p.n_individuals, p.n_variants), gl, p.recombcost, p.positions,
+                                 p.distrust_genotypes, n_variants=p.n_variants)
+
+
+@pytest.mark.skipif(not oracle.have_reference(), reason="oracle/_ref not built (no reference tree here)")
+def test_blank_alleles_inside_reads_vs_compiled_reference():
+    """Entry::BLANK (2) as the allele of a read's own variant is legal input for the reference: set/update_partitioning
+    skip it (src/pedigreecolumncostcomputer.cpp:69-70, 93-94).  The restatement must treat it the same way (its phred
+    is ignored); allele 3 (EQUAL_SCORES) is rejected (the reference's assert(false), :71-72)."""
+    import numpy as np
+    from whatshap_amd import _native
+
+    rng = random.Random(99)
+    n_with_blank = 0
+    for i in range(120):
+        p = _with_blank_alleles(random_small_instance(rng, allow_conflict=False, max_variants=9, max_reads=7), rng)
+        n_with_blank += int((p.var_allele == 2).any())
+        want = table_solution(oracle.ReferenceTable(p))
+        got, err = oracle_outcome(p)
+        assert err is None and got == want, f"{i}: {first_difference(want, got)}"
+    assert n_with_blank > 40
+    bad = _native.ProblemArrays([0, 2], [10, 20], [0, 3], [1, 1], [0], [0], [], np.ones((1, 2)), None, [1, 1], None, False)
+    _, err = oracle_outcome(bad)
+    assert err is not None and "allele" in err

@@ -78,3 +78,41 @@ def test_shim_install_rebinds_a_phase_like_module():
     assert rec._gls[0][0].as_vector() == [10.0, 0.0, 20.0] and rec._gls[0][1] is None and rec._gls[1] == [None] * 3
     with pytest.raises(TypeError):
         phase.PedigreeDPTable(ref.ReadSet(), [1, 1, 1], ref.Pedigree(ids))  # a pedigree that was not recorded
+
+
+def test_shim_falls_back_to_the_replaced_class_beyond_device_limits(monkeypatch):
+    """shim.install must not turn inputs the reference can phase into hard errors.  A refusal of the device
+    path for its OWN limits (UNSUPPORTED / OVERFLOW / DEVICE) is logged and the table is built by the class that was
+    replaced, from the original objects; algorithmic errors are re-raised; without a fallback class the refusal stays
+    an error (what tests and bench.py rely on)."""
+    import types
+
+    import pytest
+    from whatshap_amd import _native, core, shim
+
+    calls = []
+
+    class FakeReferenceTable:
+        def __init__(self, readset, recombcost, pedigree, distrust_genotypes=False, positions=None):
+            calls.append((readset, tuple(recombcost), pedigree, distrust_genotypes, positions))
+
+    def refusing(status, message):
+        def ctor(*args, **kwargs):
+            raise _native.SolverError(status, message)
+        return ctor
+
+    ped = core.Pedigree(core.NumericSampleIds())
+    rs = core.ReadSet()
+    phase = types.SimpleNamespace(Pedigree=core.Pedigree, PedigreeDPTable=FakeReferenceTable)
+    previous = shim.install(phase, None)
+    assert previous == (core.Pedigree, FakeReferenceTable)
+    for status in (_native.WHAMD_ERR_UNSUPPORTED, _native.WHAMD_ERR_OVERFLOW, _native.WHAMD_ERR_DEVICE):
+        monkeypatch.setattr(core, "PedigreeDPTable", refusing(status, "beyond the device path"))
+        table = phase.PedigreeDPTable(rs, [1, 2], ped, True, [10, 20])
+        assert isinstance(table, FakeReferenceTable) and calls[-1] == (rs, (1, 2), ped, True, [10, 20])
+    monkeypatch.setattr(core, "PedigreeDPTable", refusing(_native.WHAMD_ERR_MENDELIAN_CONFLICT, "Error: Mendelian conflict"))
+    with pytest.raises(RuntimeError, match="Mendelian conflict"):
+        phase.PedigreeDPTable(rs, [1, 2], ped)
+    monkeypatch.setattr(core, "PedigreeDPTable", refusing(_native.WHAMD_ERR_UNSUPPORTED, "beyond the device path"))
+    with pytest.raises(_native.SolverError):
+        shim.table_factory(None)(rs, [1, 2], ped)

@@ -97,23 +97,67 @@ def split_independent_blocks(problem: ProblemArrays) -> List[Tuple[ProblemArrays
 
 
 def solve_blocks(problems: Sequence[ProblemArrays], device: int = 0, path=None, max_in_flight: int = 8,
-                 release: bool = True):
-    """Host-side work queue for one device: solves independent blocks ``max_in_flight`` at a time, each on its own
-    stream with interleaved launch sequences (``whamd_dptable_enqueue_many``), so that blocks -- which cannot fill 256
-    CUs on their own -- overlap.  Returns the solved tables in input order; with ``release`` their device buffers and
-    streams are freed as soon as the solution is on the host."""
-    from ._native import NativeTable, enqueue_many
+                 release: bool = True, devices: Sequence[int] = None, weights: Sequence[float] = None):
+    """Host-side work queue (BASELINE north_star: "independent phasing blocks shard across the GPUs of one node via a
+    host-side work queue"; scheduling precedent: whatshap/polyphase/algorithm.py:101-128).
 
-    tables = []
-    for start in range(0, len(problems), max_in_flight):
-        window = [NativeTable(sub, device=device, path=path, solve=False) for sub in problems[start:start + max_in_flight]]
-        enqueue_many(window)
-        for t in window:
-            t.wait()
-            if release:
-                t.release_device()
-        tables.extend(window)
-    return tables
+    One device (``devices`` None): solves independent blocks ``max_in_flight`` at a time, each on its own stream with
+    interleaved launch sequences (``whamd_dptable_enqueue_many``), so that blocks -- which cannot fill 256 CUs on their
+    own -- overlap.
+
+    Several devices (``devices=[0, 1, ...]``; an index may repeat: two workers on one device): the blocks are assigned
+    longest-processing-time-first to the least loaded device (``assign_blocks``; ``weights`` defaults to the number of
+    variant entries of a block), one worker thread per entry of ``devices`` runs the single-device queue on its share
+    (the C library is thread-safe and ctypes releases the GIL inside every call).  No collective: the results are
+    concatenated on the host.  Raises if a requested device does not exist -- there is no fallback.
+
+    Returns the solved tables in input order; with ``release`` their device buffers and streams are freed as soon as
+    the solution is on the host."""
+    from ._native import NativeTable, device_count, enqueue_many
+
+    problems = list(problems)
+    if devices is None:
+        tables = []
+        for start in range(0, len(problems), max_in_flight):
+            window = [NativeTable(sub, device=device, path=path, solve=False) for sub in problems[start:start + max_in_flight]]
+            enqueue_many(window)
+            for t in window:
+                t.wait()
+                if release:
+                    t.release_device()
+            tables.extend(window)
+        return tables
+
+    import threading
+
+    devices = list(devices)
+    visible = device_count()
+    if not devices or any(d < 0 or d >= visible for d in devices):
+        raise RuntimeError(f"solve_blocks: devices {devices} requested but {visible} HIP device(s) visible")
+    if weights is None:
+        weights = [float(p.var_position.size) for p in problems]
+    shares = assign_blocks(weights, len(devices))
+    out = [None] * len(problems)
+    errors = []
+
+    def worker(slot):
+        try:
+            share = shares[slot]
+            solved = solve_blocks([problems[b] for b in share], device=devices[slot], path=path,
+                                  max_in_flight=max_in_flight, release=release)
+            for b, t in zip(share, solved):
+                out[b] = t
+        except BaseException as exc:  # noqa: BLE001 -- re-raised in the caller's thread
+            errors.append(exc)
+
+    threads = [threading.Thread(target=worker, args=(slot,), name=f"whamd-dev{devices[slot]}-{slot}") for slot in range(len(devices))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return out
 
 
 def merge_block_solutions(n_reads: int, n_individuals: int, blocks, solutions: Dict[int, dict]) -> dict:

@@ -398,7 +398,7 @@ def _flatten_readset(readset) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.nd
         read_ptr.append(len(pos))
     alle_arr = np.asarray(alle, dtype=np.int64)
     if alle_arr.size and (alle_arr.min() < 0 or alle_arr.max() > 255):
-        raise RuntimeError("read allele must be 0 (REF) or 1 (ALT)")
+        raise RuntimeError("read allele must be 0 (REF), 1 (ALT) or 2 (BLANK)")
     return (np.asarray(read_ptr, dtype=np.uint64), np.asarray(pos, dtype=np.int32), alle_arr.astype(np.uint8),
             np.asarray(qual, dtype=np.uint32), np.asarray(samples, dtype=np.int32))
 
@@ -503,8 +503,9 @@ class PedigreeDPTable:
             return [int(x) for x in self._tables[0].partitioning()]
         out = [1] * self._problem.n_reads
         for (_, reads, _), t in zip(self._blocks, self._tables):
+            part = t.partitioning().tolist()  # one native call (and one copy) per block
             for local, r in enumerate(reads):
-                out[int(r)] = int(t.partitioning()[local])
+                out[int(r)] = part[local]
         return out
 
     # not part of the reference API: raw backtrace and device measurements

@@ -125,7 +125,13 @@ whamd_status_t whamd_dptable_enqueue_many(whamd_dptable* const* tables, size_t n
 			if (done[i]) continue;
 			bool finished = false;
 			whamd_status_t st = tables[i]->device.enqueue_some(tables[i]->problem, tables[i]->solution, SLICE, finished, msg);
-			if (st != WHAMD_OK) return fail(st, msg);
+			if (st != WHAMD_OK) {
+				// the failing table has rewound itself; the others must not keep half-submitted schedules either: tables
+				// whose submission is complete stay in flight (collect them with whamd_dptable_wait), the rest is aborted
+				for (size_t j = 0; j < n_tables; ++j)
+					if (j != i && !done[j]) tables[j]->device.abort_enqueue();
+				return fail(st, msg);
+			}
 			if (finished) {
 				done[i] = 1;
 				tables[i]->in_flight = true;

@@ -25,6 +25,8 @@ public:
 	// Resumable enqueue(): at most `budget` forward launches per call; `done` once backtrace and downloads are submitted.
 	whamd_status_t enqueue_some(const Problem& p, Solution& s, uint64_t budget, bool& done, std::string& msg);
 	whamd_status_t wait(const Problem& p, Solution& s, whamd_solve_stats& st, std::string& msg);
+	// Drops a partially submitted solve (enqueue_some that has not reported `done`): drains the stream, rewinds the cursor.
+	void abort_enqueue();
 	// Frees the device buffers, the stream and the events; the next upload() recreates them.
 	void release_device();
 	// Solver variant ("auto", "column", "column_keys", "resident"); takes effect at the next upload().
@@ -40,6 +42,7 @@ public:
 	void set_lanes(int n);
 
 private:
+	whamd_status_t enqueue_some_unguarded(const Problem& p, Solution& s, uint64_t budget, bool& done, std::string& msg);
 	struct Impl;
 	Impl* impl_;
 };

@@ -625,6 +625,25 @@ void DeviceTable::Impl::launch_run(const ResBatchEntry& e, uint32_t step_index, 
 // launches went out, the call that runs out of super-steps appends the backtrace and the downloads.  Lets one host
 // thread interleave the launch sequences of several tables (whamd_dptable_enqueue_many).
 whamd_status_t DeviceTable::enqueue_some(const Problem& p, Solution& s, uint64_t budget, bool& done, std::string& msg) {
+	const whamd_status_t status = enqueue_some_unguarded(p, s, budget, done, msg);
+	if (status != WHAMD_OK) abort_enqueue();  // never leave a half-submitted schedule behind: the next enqueue starts over
+	return status;
+}
+
+// Drops a partially submitted solve: waits for what is already on the stream and rewinds the resumable cursor, so that
+// a later enqueue()/solve() of this table begins with the preamble again (key re-arm, events, path buffers).
+void DeviceTable::abort_enqueue() {
+	Impl& m = *impl_;
+	if (m.stream) {
+		(void)hipSetDevice(m.device);
+		(void)hipStreamSynchronize(m.stream);
+		(void)hipGetLastError();
+	}
+	m.enqueue_open = false;
+	m.next_super = 0;
+}
+
+whamd_status_t DeviceTable::enqueue_some_unguarded(const Problem& p, Solution& s, uint64_t budget, bool& done, std::string& msg) {
 	Impl& m = *impl_;
 	const uint32_t n = p.n_cols;
 	done = false;

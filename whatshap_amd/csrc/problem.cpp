@@ -98,8 +98,11 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 	p.var_allele.assign(rs->var_allele, rs->var_allele + nnz);
 	p.var_quality.assign(rs->var_quality, rs->var_quality + nnz);
 	for (uint64_t i = 0; i < nnz; ++i) {
-		if (p.var_allele[i] > 1) {  // Entry::allele_t other than REF/ALT asserts in the reference (pedigreecolumncostcomputer.cpp:71-72)
-			msg = "read allele must be 0 (REF) or 1 (ALT)";
+		// Entry::BLANK (2) inside a read is accepted and skipped by the reference (pedigreecolumncostcomputer.cpp:69-70,
+		// 93-94), exactly like the BLANK entries ColumnIterator inserts; only EQUAL_SCORES (3) and beyond reach its
+		// assert(false) (:71-72, asserts are live in the reference's build)
+		if (p.var_allele[i] > WHAMD_ALLELE_BLANK) {
+			msg = "read allele must be 0 (REF), 1 (ALT) or 2 (BLANK)";
 			return WHAMD_ERR_INVALID;
 		}
 	}

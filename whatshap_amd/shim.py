@@ -89,15 +89,39 @@ class _TableAdapter:
         return converted, transmission
 
 
-def table_factory(reference_core=None, **solver_options):
+# status codes of the device path's own limits (include/whatshap_amd.h): the reference has none of them
+_DEVICE_LIMIT_STATUSES = (4, 5, 6)  # WHAMD_ERR_UNSUPPORTED, WHAMD_ERR_DEVICE, WHAMD_ERR_OVERFLOW
+
+
+def table_factory(reference_core=None, fallback_table_class=None, **solver_options):
     """Callable with the constructor signature of the reference's ``PedigreeDPTable`` (core.pyx:364-379).  The pedigree
-    must come from ``recording_pedigree_class`` (or be a ``whatshap_amd.core.Pedigree``)."""
+    must come from ``recording_pedigree_class`` (or be a ``whatshap_amd.core.Pedigree``).
+
+    ``fallback_table_class`` (``install`` passes the binding it replaces, i.e. the reference's own ``PedigreeDPTable``):
+    the device path has limits the reference does not have -- at most 2 trios / 6 individuals per pedigree, 25 reads per
+    column, 1024 cost terms per column, a pessimistic 32-bit overflow bound, and of course a visible GPU.  When the
+    library refuses an input for one of those reasons (``WHAMD_ERR_UNSUPPORTED`` / ``_OVERFLOW`` / ``_DEVICE``) the run
+    must not die where the unmodified WhatsHap would have phased it: the refusal is logged and the table is built by the
+    fallback class from the ORIGINAL ReadSet and pedigree objects.  This is the integration shim of an end-user run,
+    not the measured product path: parity tests and ``bench.py`` never pass a fallback, so a refusal stays an error
+    there.  Errors of the algorithm itself (Mendelian conflict, unsorted ReadSet) are re-raised unchanged -- the
+    reference raises them too."""
 
     def make(readset, recombcost, pedigree, distrust_genotypes=False, positions=None):
         recorded = getattr(pedigree, "amd", pedigree)
         if not isinstance(recorded, amd.Pedigree):
             raise TypeError("the pedigree was not created through whatshap_amd.shim (no recorded individuals / trios)")
-        table = amd.PedigreeDPTable(readset, recombcost, recorded, distrust_genotypes, positions, **solver_options)
+        try:
+            table = amd.PedigreeDPTable(readset, recombcost, recorded, distrust_genotypes, positions, **solver_options)
+        except RuntimeError as exc:
+            status = getattr(exc, "status", None)
+            if fallback_table_class is None or status not in _DEVICE_LIMIT_STATUSES:
+                raise
+            import logging
+
+            logging.getLogger("whatshap_amd").warning(
+                "device path refused this table (%s); solving it with the reference PedigreeDPTable", exc)
+            return fallback_table_class(readset, recombcost, pedigree, distrust_genotypes, positions)
         return _TableAdapter(table, reference_core)
 
     return make
@@ -109,5 +133,6 @@ def install(phase_module, reference_core=None, **solver_options):
     previous = (phase_module.Pedigree, phase_module.PedigreeDPTable)
     ref_pedigree = reference_core.Pedigree if reference_core is not None else phase_module.Pedigree
     phase_module.Pedigree = recording_pedigree_class(ref_pedigree)
-    phase_module.PedigreeDPTable = table_factory(reference_core, **solver_options)
+    # keep the binding we replace: inputs beyond the device path's limits fall back to it (table_factory)
+    phase_module.PedigreeDPTable = table_factory(reference_core, fallback_table_class=previous[1], **solver_options)
     return previous
