@@ -25,7 +25,7 @@ t0 = time.time()
 bad = 0
 rng = random.Random(2026)
 n_small = 0
-for i in range(1500):
+for i in range(int(os.environ.get("WHAMD_SOAK_SMALL", "1500"))):
     p = random_small_instance(rng)
     try:
         want = table_solution(oracle.OracleTable(p)); werr = None
