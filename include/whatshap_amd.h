@@ -193,7 +193,9 @@ whamd_status_t whamd_dptable_get_index_path(const whamd_dptable* table, uint32_t
 whamd_status_t whamd_dptable_get_stats(const whamd_dptable* table, whamd_solve_stats* stats_out);
 
 /* Options (for A/B measurements and tests), effective at the next solve:
- *   "path"          "auto" (default) | "resident" | "column" (one launch per column, the general path) | "column_keys"
+ *   "path"          "auto" (default: slot runs for a single individual, LDS-resident runs for a trio) | "slots" | "resident" |
+ *                   "column" (one launch per column, the general path) | "column_keys"
+ *   "slot_l"        preferred number of local slots of a slot run (9 .. 12: 1 .. 8 waves per workgroup)
  *   "resident_l"    preferred log2 slice size of the run kernels
  *   "resident_fold" "0" disables folding of columns without an ending read
  *   "symmetry"      single individual: D[~x] == D[x], so a run may compute half of its workgroups only: "0" never,
@@ -227,6 +229,17 @@ whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uin
                                     const whamd_pedigree_view* pedigree, int distrust_genotypes,
                                     const uint32_t* positions, size_t n_positions, const char* path,
                                     whamd_plan_summary* out);
+
+/* Host-only diagnostic of the slot-run planner (no device needed, small inputs only): builds the forward plan of a
+ * single-individual table exactly as whamd_dptable_create would (slot_l local slots preferred, symmetry level) and
+ * executes it cell by cell on the CPU the way the kernels do -- same physical cell indices, decision bits, record
+ * layout, exchange layouts and mirror rules.  index_out[n_columns]: the index path (index_path[c].index,
+ * src/pedigreedptable.h:17-21), score_out: the optimal score.  Lets the CPU test-suite check the PLAN against the
+ * oracle; not a solver and never used by one (WHAMD_ERR_UNSUPPORTED for pedigrees). */
+whamd_status_t whamd_debug_emulate_slot_plan(const whamd_readset_view* readset, const uint32_t* recombcost, size_t n_recombcost,
+                                            const whamd_pedigree_view* pedigree, int distrust_genotypes,
+                                            const uint32_t* positions, size_t n_positions, int slot_l, int symmetry,
+                                            uint32_t* index_out, uint32_t* score_out, uint64_t* n_run_columns_out);
 
 /* The tie-break hash of ReadSet::sort (src/readset.h:39-66,76-82): std::hash<std::string>(name) ^
  * std::hash<int>(source_id) of the libstdc++ this library is built against.  Used by the Python

@@ -9,9 +9,24 @@ from whatshap_amd import _native
 from whatshap_amd.synthetic import random_small_instance, synthetic_block
 
 
-def test_benchmark_shape_is_scheduled_as_resident_runs():
+def test_benchmark_shape_is_scheduled_as_slot_runs():
+    """Default path of a single individual: register-resident slot runs (slots.h)."""
     p = synthetic_block(n_variants=3000, coverage=20, seed=3)
     s = _native.plan_summary(p)
+    assert s["invariants_ok"] == 1 and s["n_columns"] == 3000 and s["max_coverage"] == 20
+    assert s["n_resident_columns"] >= 2980          # everything but the ramp's odd columns and the last column
+    assert s["max_workgroups"] == 256               # 11 local slots, 9 grid slots, half of the workgroups launched
+    assert s["n_halved_runs"] >= 0.9 * s["n_runs"]
+    assert 15 <= s["n_resident_columns"] / s["n_runs"] <= 64
+    assert s["max_lds_bytes"] <= 64 * 1024
+    assert s["n_steps"] < s["n_columns"] / 10
+    # one byte per thread and ending read: far below the LDS-resident runs' records
+    assert s["backtrace_bytes"] < _native.plan_summary(p, "resident")["backtrace_bytes"]
+
+
+def test_benchmark_shape_is_scheduled_as_resident_runs():
+    p = synthetic_block(n_variants=3000, coverage=20, seed=3)
+    s = _native.plan_summary(p, "resident")
     assert s["invariants_ok"] == 1 and s["n_columns"] == 3000 and s["max_coverage"] == 20
     assert s["n_resident_columns"] >= 2990          # everything but the last column(s)
     assert s["max_workgroups"] == 256               # 9 grid reads at coverage 20, half of the workgroups launched
@@ -24,9 +39,11 @@ def test_benchmark_shape_is_scheduled_as_resident_runs():
 
 def test_coverage_23_still_runs_resident():
     p = synthetic_block(n_variants=400, coverage=23, seed=9)
-    s = _native.plan_summary(p)
+    s = _native.plan_summary(p, "resident")
     assert s["invariants_ok"] == 1 and s["max_coverage"] == 23
     assert s["max_workgroups"] == 512 and s["n_resident_columns"] >= 300  # 10 grid reads, halved
+    s = _native.plan_summary(p)   # slot runs: 11 local + 12 grid slots, halved
+    assert s["invariants_ok"] == 1 and s["max_workgroups"] == 2048 and s["n_resident_columns"] >= 300
 
 
 def test_column_path_request_has_no_runs_and_trios_get_their_own_runs():
@@ -63,9 +80,10 @@ def test_invariants_on_irregular_reads(seed):
             n_reads += 1
     p = _native.ProblemArrays(read_ptr, pos, alle, qual, np.zeros(n_reads), [0], [], np.ones((1, n_var)), None, [1] * n_var,
                               [10 * (c + 1) for c in range(n_var)], False)
-    s = _native.plan_summary(p)
-    assert s["invariants_ok"] == 1 and s["n_columns"] == n_var
-    assert s["n_resident_columns"] > 0
+    for path in ("auto", "resident"):
+        s = _native.plan_summary(p, path)
+        assert s["invariants_ok"] == 1 and s["n_columns"] == n_var, path
+        assert s["n_resident_columns"] > 0
 
 
 def test_invariants_on_random_small_instances():
@@ -75,6 +93,7 @@ def test_invariants_on_random_small_instances():
         p = random_small_instance(rng, allow_conflict=False)
         s = _native.plan_summary(p)
         assert s["invariants_ok"] == 1
+        assert _native.plan_summary(p, "resident")["invariants_ok"] == 1
         checked += s["n_runs"] > 0
     assert checked > 20
 

@@ -236,6 +236,11 @@ def lib() -> C.CDLL:
         C.POINTER(ReadSetView), C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(PedigreeView), C.c_int,
         C.POINTER(C.c_uint32), C.c_size_t, C.c_char_p, C.POINTER(PlanSummary),
     ]
+    L.whamd_debug_emulate_slot_plan.restype = C.c_int
+    L.whamd_debug_emulate_slot_plan.argtypes = [
+        C.POINTER(ReadSetView), C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(PedigreeView), C.c_int,
+        C.POINTER(C.c_uint32), C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
+    ]
     L.whamd_read_sort_hash.restype = C.c_uint64
     L.whamd_read_sort_hash.argtypes = [C.c_char_p, C.c_int]
     if L.whamd_abi_version() != 1:
@@ -251,7 +256,7 @@ EXPORTED_SYMBOLS = [
     "whamd_dptable_read_count", "whamd_dptable_positions", "whamd_dptable_get_optimal_score",
     "whamd_dptable_get_super_reads", "whamd_dptable_get_optimal_partitioning", "whamd_dptable_get_index_path",
     "whamd_dptable_get_stats", "whamd_dptable_set_option", "whamd_read_sort_hash", "whamd_plan_summarize",
-    "whamd_dptable_enqueue", "whamd_dptable_wait", "whamd_dptable_enqueue_many",
+    "whamd_dptable_enqueue", "whamd_dptable_wait", "whamd_dptable_enqueue_many", "whamd_debug_emulate_slot_plan",
 ]
 
 
@@ -364,6 +369,16 @@ def plan_summary(problem: ProblemArrays, path: str = "auto") -> dict:
     out = PlanSummary()
     _check(lib().whamd_plan_summarize(*problem.call_args(), path.encode(), C.byref(out)))
     return out.as_dict()
+
+
+def emulate_slot_plan(problem: ProblemArrays, n_columns: int, slot_l: int = 11, symmetry: int = 1):
+    """Host-only planner diagnostic (whamd_debug_emulate_slot_plan): (index path, optimal score, columns inside runs)."""
+    idx = np.zeros(max(n_columns, 1), dtype=np.uint32)
+    score = C.c_uint32()
+    ncols = C.c_uint64()
+    _check(lib().whamd_debug_emulate_slot_plan(*problem.call_args(), C.c_int(slot_l), C.c_int(symmetry), _ptr(idx, C.c_uint32),
+                                               C.byref(score), C.byref(ncols)))
+    return idx[:n_columns], int(score.value), int(ncols.value)
 
 
 def device_count() -> int:

@@ -10,6 +10,7 @@
 #include "device_table.h"
 #include "problem.h"
 #include "resident.h"
+#include "slots.h"
 #include <algorithm>
 #include <vector>
 
@@ -230,7 +231,7 @@ whamd_status_t whamd_dptable_set_option(whamd_dptable* t, const char* key, const
 	if (!t || !key || !value) return fail(WHAMD_ERR_INVALID, "null argument");
 	const std::string k(key), v(value);
 	if (k == "path") {
-		if (!t->device.set_path(v)) return fail(WHAMD_ERR_INVALID, "unknown path '" + v + "' (auto, resident, column, column_keys)");
+		if (!t->device.set_path(v)) return fail(WHAMD_ERR_INVALID, "unknown path '" + v + "' (auto, slots, resident, column, column_keys)");
 		t->uploaded = false;  // descriptors are rebuilt at the next solve
 		return WHAMD_OK;
 	}
@@ -254,6 +255,11 @@ whamd_status_t whamd_dptable_set_option(whamd_dptable* t, const char* key, const
 		t->uploaded = false;
 		return WHAMD_OK;
 	}
+	if (k == "slot_l") {
+		t->device.set_slot_l(std::atoi(value));
+		t->uploaded = false;
+		return WHAMD_OK;
+	}
 	return fail(WHAMD_ERR_INVALID, "unknown option '" + k + "'");
 }
 
@@ -268,6 +274,60 @@ whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uin
 	                                  n_positions, p, msg);
 	if (st != WHAMD_OK) return fail(st, msg);
 	const std::string mode(path ? path : "auto");
+	SlotPlan sp;
+	if ((mode == "auto" || mode == "slots") && plan_forward_slots(p, 11, 1, sp)) {
+		// slot runs (slots.h): every column in exactly one step, runs within their limits, slots consistent
+		whamd_plan_summary s{};
+		s.n_columns = p.n_cols;
+		s.n_steps = sp.steps.size();
+		s.n_runs = sp.runs.size();
+		s.max_coverage = p.max_k;
+		s.n_components = sp.component_first_step.size();
+		bool ok = true;
+		uint32_t expect = 0;
+		size_t kc = 0;
+		for (size_t si = 0; si < sp.steps.size(); ++si) {
+			const Step& step = sp.steps[si];
+			const uint32_t c0 = step.kind == 2 ? sp.runs[step.index].c0 : step.index;
+			if (si == 0 || p.b[c0] == 0) { ok = ok && kc < sp.component_first_step.size() && sp.component_first_step[kc] == si; ++kc; }
+			ok = ok && c0 == expect;
+			if (step.kind == 0) { expect = c0 + 1; ok = ok && sp.col_to_row[c0] < 0; continue; }
+			const SlotRun& run = sp.runs[step.index];
+			expect = c0 + run.ncols;
+			ok = ok && step.kind == 2 && run.ncols >= 2 && run.ncols <= (uint32_t)SLOT_MAXCOLS && run.g <= (uint32_t)SLOT_GMAX;
+			ok = ok && run.L == (uint32_t)(SLOT_LR + SLOT_LANE) + run.lw && run.lw <= (uint32_t)SLOT_LWMAX && run.threads == (64u << run.lw);
+			ok = ok && run.L + run.g <= (uint32_t)SLOT_MAXSLOTS && run.n_ends <= (uint32_t)SLOT_MAXENDS_RUN && (!run.half || run.g >= 1);
+			uint32_t ends = 0;
+			for (uint32_t i = 0; i < run.ncols && ok; ++i) {
+				const uint32_t c = c0 + i;
+				if (c + 1 >= p.n_cols) { ok = false; break; }   // the last column never runs inside a run
+				ok = ok && sp.col_to_row[c] == (int32_t)(run.row_off + i) && (i == 0 || p.b[c] != 0);
+				const SlotRow& row = sp.rows[run.row_off + i];
+				const SlotBtCol& bc = sp.bt_cols[run.row_off + i];
+				ok = ok && bc.k == p.k[c] && bc.kf == ends && row.n_end == (uint32_t)p.k[c] - p.f[c] && row.n_end <= (uint32_t)SLOT_MAXEND;
+				uint32_t used = 0;
+				for (uint32_t j = 0; j < bc.k; ++j) {   // distinct slots, ending reads local
+					ok = ok && bc.slot[j] < run.L + run.g && !((used >> bc.slot[j]) & 1u);
+					used |= 1u << bc.slot[j];
+					if (!((p.fwd_mask[c] >> j) & 1u)) ok = ok && bc.slot[j] < run.L;
+				}
+				for (uint32_t q = 0; q < row.n_end; ++q) ok = ok && sp.end_slots[sp.end_off[step.index] + ends + q] == (row.end[q].info & 255u);
+				ends += row.n_end;
+			}
+			ok = ok && ends == run.n_ends;
+			s.max_run_columns = std::max<uint64_t>(s.max_run_columns, run.ncols);
+			s.max_workgroups = std::max<uint64_t>(s.max_workgroups, 1ull << (run.g - run.half));
+			s.max_lds_bytes = std::max<uint64_t>(s.max_lds_bytes, 2ull * run.threads * (1u << SLOT_LR) * 4);
+			if (run.half) s.n_halved_runs++;
+			s.n_resident_columns += run.ncols;
+			s.n_vectorised_columns += run.ncols;
+			s.backtrace_bytes += (uint64_t)run.n_ends * run.threads * (1ull << (run.g - run.half));
+		}
+		ok = ok && expect == p.n_cols && kc == sp.component_first_step.size();
+		s.invariants_ok = ok ? 1 : 0;
+		*out = s;
+		return WHAMD_OK;
+	}
 	ResidentPlan plan;
 	plan_forward(p, mode == "auto" || mode == "resident", 11, true, plan);
 	whamd_plan_summary s{};
@@ -335,6 +395,26 @@ whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uin
 	for (uint32_t c = 0; c < p.n_cols; ++c) ok = ok && seen[c] == 1;
 	s.invariants_ok = ok ? 1 : 0;
 	*out = s;
+	return WHAMD_OK;
+}
+
+whamd_status_t whamd_debug_emulate_slot_plan(const whamd_readset_view* readset, const uint32_t* recombcost, size_t n_recombcost,
+                                            const whamd_pedigree_view* pedigree, int distrust_genotypes, const uint32_t* positions,
+                                            size_t n_positions, int slot_l, int symmetry, uint32_t* index_out, uint32_t* score_out,
+                                            uint64_t* n_run_columns_out) {
+	Problem p;
+	std::string msg;
+	whamd_status_t st = build_problem(readset, recombcost, n_recombcost, pedigree, distrust_genotypes != 0, positions,
+	                                  n_positions, p, msg);
+	if (st != WHAMD_OK) return fail(st, msg);
+	SlotPlan sp;
+	if (!plan_forward_slots(p, slot_l, symmetry, sp)) return fail(WHAMD_ERR_UNSUPPORTED, "slot runs apply to a single individual only");
+	std::vector<uint32_t> path;
+	uint32_t score = 0;
+	if (!emulate_slot_plan(p, sp, path, score, msg)) return fail(WHAMD_ERR_INVALID, "slot plan inconsistent: " + msg);
+	if (index_out && !path.empty()) std::memcpy(index_out, path.data(), path.size() * sizeof(uint32_t));
+	if (score_out) *score_out = score;
+	if (n_run_columns_out) *n_run_columns_out = sp.n_run_columns;
 	return WHAMD_OK;
 }
 

@@ -29,10 +29,13 @@ public:
 	void abort_enqueue();
 	// Frees the device buffers, the stream and the events; the next upload() recreates them.
 	void release_device();
-	// Solver variant ("auto", "column", "column_keys", "resident"); takes effect at the next upload().
+	// Solver variant ("auto", "column", "column_keys", "resident", "slots"); takes effect at the next upload().
+	// auto: slot runs (slots.h) for a single individual, LDS-resident runs for a trio, per-column kernels otherwise.
 	bool set_path(const std::string& path);
 	// Preferred log2 slice size of the resident path (tuning knob); takes effect at the next upload().
 	void set_l_pref(int l);
+	// Preferred number of local slots of a slot run (9 .. 12: 1 .. 8 waves per workgroup); next upload().
+	void set_slot_l(int l);
 	// Fold columns in which no read ends into the next resident column (default on); next upload().
 	void set_fold(bool v);
 	// Exploit D[~x] == D[x] in single-individual runs: 0 off, 1 full-chip runs (default), 2 every run; next upload().

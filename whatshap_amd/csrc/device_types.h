@@ -3,6 +3,7 @@
 #include <cstdint>
 
 #include "resident.h"
+#include "slots.h"
 
 namespace whamd {
 
@@ -17,7 +18,7 @@ struct DevColumn {
 	uint32_t seg_off;    // into DevProblem::segs: nseg_fwd forward segments, then nseg_end ending segments
 	uint16_t nseg_fwd, nseg_end;
 	uint32_t mode;       // 0: fused column step, bit-plane backtrace; 1: key (atomic) path, raw u32 backtrace;
-	                     // 2: resident run (resident.h), per-workgroup bit planes
+	                     // 2: resident run (resident.h), per-workgroup bit planes; 3: slot run (slots.h)
 	uint32_t ebits;      // k - f: reads that end in this column
 	uint32_t eloop;      // log2 of the ending-bit patterns each thread enumerates itself
 	uint32_t nplanes;    // mode 0: ebits + transmission bits
@@ -46,6 +47,9 @@ struct DevProblem {
 	const PedTerm* ped_terms;    // trio runs: term pool
 	int32_t* ped_tables;    // [trio columns][PED_TABLE] lookup tables (computed at the start of each solve)
 	int32_t* res_tables;    // [resident columns][RES_TABLE] lookup tables (computed at the start of each solve)
+	// slot runs (slots.h)
+	const SlotRow* slot_rows;    // per-column descriptors of the slot runs
+	const uint32_t* slot_blob;   // backtrace blobs of the slot runs (SlotBtUnit::blob_off)
 	unsigned long long* dbg;  // optional cycle-counter dump (WHAMD_DEBUG_TIMING)
 	uint32_t dbg_wg_off;      // word offset of the per-workgroup start/end stamps inside dbg
 	uint32_t dbg_flags;       // experiments: bit 0 skip the slice store, bit 1 skip the record store (results invalid)

@@ -44,6 +44,7 @@ namespace {
 #include "kernels_column.h"
 #include "kernels_resident.h"
 #include "kernels_trio.h"
+#include "kernels_slots.h"
 #include "kernels_backtrace.h"
 
 // ---------------------------------------------------------------------------------------------- launch tables
@@ -132,6 +133,12 @@ struct DeviceTable::Impl {
 	std::vector<SuperStep> schedule;
 	std::vector<ResBatchEntry> entries;
 	ResBatchEntry* d_entries = nullptr;
+	// slot runs (slots.h): the default forward path of a single individual
+	SlotPlan splan;
+	bool use_slots = false;
+	int slot_l = 11;            // preferred number of local slots (9 .. 12)
+	std::vector<SlotBatchEntry> slot_entries;
+	SlotBatchEntry* d_slot_entries = nullptr;
 	BtJob* d_btjobs = nullptr;
 	uint32_t* d_job_scores = nullptr;
 	int max_lanes = 32;
@@ -139,12 +146,14 @@ struct DeviceTable::Impl {
 
 	void launch_column_step(const Problem& p, const Step& step, const Lane& lane, const uint32_t* prev, uint32_t* cur, uint64_t& launches);
 	void launch_run(const ResBatchEntry& e, uint32_t step_index, uint64_t& launches);
+	void launch_slot_run(const SlotBatchEntry& e, uint64_t& launches);
 
 	void release_lanes() {
 		lanes.clear();
 		jobs.clear();
 		schedule.clear();
 		entries.clear();
+		slot_entries.clear();
 	}
 
 	void release() {
@@ -209,7 +218,7 @@ static void append_segments(uint32_t mask, std::vector<uint32_t>& out, uint16_t&
 }
 
 bool DeviceTable::set_path(const std::string& path) {
-	if (path != "auto" && path != "column" && path != "column_keys" && path != "resident") return false;
+	if (path != "auto" && path != "column" && path != "column_keys" && path != "resident" && path != "slots") return false;
 	impl_->path = path;
 	return true;
 }
@@ -218,6 +227,7 @@ void DeviceTable::set_l_pref(int l) { impl_->l_pref = std::max(4, std::min(l, RE
 void DeviceTable::set_lanes(int n) { impl_->max_lanes = n < 1 ? 1 : (n > 64 ? 64 : n); }
 
 void DeviceTable::set_fold(bool v) { impl_->fold = v; }
+void DeviceTable::set_slot_l(int l) { impl_->slot_l = std::max(9, std::min(l, 12)); }
 
 void DeviceTable::set_symmetry(int level) { impl_->symmetry = level < 0 ? 0 : (level > 2 ? 2 : level); }
 
@@ -251,11 +261,27 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	const bool force_keys = m.path == "column_keys";
 	const bool want_resident = m.path == "auto" || m.path == "resident";
 	const auto tu0 = std::chrono::steady_clock::now();
-	plan_forward(p, want_resident, m.l_pref, m.fold, m.plan, m.symmetry);
+	m.use_slots = (m.path == "auto" || m.path == "slots") && plan_forward_slots(p, m.slot_l, m.symmetry, m.splan);
+	if (m.use_slots) {
+		// the driver below walks plan.steps / plan.component_first_step; slot runs are steps of kind 2
+		m.plan = ResidentPlan();
+		m.plan.steps = m.splan.steps;
+		m.plan.component_first_step = m.splan.component_first_step;
+		m.plan.col_to_res.assign(p.n_cols, -1);
+	} else {
+		m.splan = SlotPlan();
+		plan_forward(p, want_resident, m.l_pref, m.fold, m.plan, m.symmetry);
+	}
 	const auto tu1 = std::chrono::steady_clock::now();
 	if (getenv("WHAMD_DEBUG_PLAN")) {
 		for (const Step& st : m.plan.steps) {
 			if (st.kind == 0) { fprintf(stderr, "[plan] column %u k=%u b=%u f=%u\n", st.index, p.k[st.index], p.b[st.index], p.f[st.index]); continue; }
+			if (st.kind == 2) {
+				const SlotRun& r = m.splan.runs[st.index];
+				fprintf(stderr, "[plan] slot run c0=%u ncols=%u g=%u L=%u half=%u ends=%u has_prev=%u in_identity=%u in_half=%u mirror_pos=%u in_occ=%x out_occ=%x mirror_out=%u\n",
+				        r.c0, r.ncols, r.g, r.L, r.half, r.n_ends, r.has_prev, r.in_identity, r.in_half, r.in_mirror_pos, r.in_occ, r.out_occ, r.mirror_out);
+				continue;
+			}
 			const ResSegment& sgm = m.plan.segments[st.index];
 			fprintf(stderr, "[plan] run c0=%u ncols=%u g=%u threads=%u max_l=%u stage_words=%u\n", sgm.c0, sgm.ncols, sgm.g, sgm.threads, sgm.max_l, sgm.stage_words);
 			for (uint32_t i = 0; i < sgm.ncols; ++i) {
@@ -285,7 +311,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		return WHAMD_ERR_UNSUPPORTED;
 	}
 	uint64_t bt = 0, seg_bt = 0;
-	size_t seg_cursor = 0;
+	size_t seg_cursor = 0, slot_cursor = 0;
 	uint32_t max_f = 0, max_keys_f = 0;
 	for (uint32_t c = 0; c < n; ++c) {
 		DevColumn& d = m.cols[c];
@@ -305,7 +331,20 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		d.eloop = std::min<uint32_t>(d.ebits, QMAX);
 		d.nplanes = d.ebits + tbits;
 		d.bt_off = bt;
-		if (m.plan.col_to_res[c] >= 0) {
+		if (m.use_slots && m.splan.col_to_row[c] >= 0) {
+			d.mode = 3;
+			d.res_idx = (uint32_t)m.splan.col_to_row[c];
+			if (slot_cursor < m.splan.runs.size() && m.splan.runs[slot_cursor].c0 == c) {  // first column of a slot run
+				SlotRun& run = m.splan.runs[slot_cursor];
+				run.rec_lo = (uint32_t)bt;
+				run.rec_hi = (uint32_t)(bt >> 32);
+				seg_bt = bt;
+				bt += (uint64_t)run.n_ends * run.threads * (1ull << (run.g - run.half));   // only launched workgroups write
+				max_f = std::max(max_f, run.L + run.g);   // entry / exit indices in physical order need 2^(L + g) entries
+				++slot_cursor;
+			}
+			d.bt_off = seg_bt;
+		} else if (m.plan.col_to_res[c] >= 0) {
 			d.mode = 2;
 			d.res_idx = (uint32_t)m.plan.col_to_res[c];
 			if (seg_cursor < m.plan.segments.size() && m.plan.segments[seg_cursor].c0 == c) {  // first column of a run
@@ -364,6 +403,25 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	HIP_TRY(up(&d_pterm, m.plan.ped_terms.data(), m.plan.ped_terms.size() * sizeof(PedTerm)));
 	m.dp.ped_cols = (const PedColumn*)d_pcol;
 	m.dp.ped_terms = (const PedTerm*)d_pterm;
+	// slot runs: per-column descriptors and the backtrace blobs ([ncols] SlotBtCol + ending slots per run)
+	std::vector<uint32_t> slot_blob;
+	std::vector<uint32_t> slot_blob_off(m.splan.runs.size(), 0), slot_blob_words(m.splan.runs.size(), 0);
+	for (size_t ri = 0; ri < m.splan.runs.size(); ++ri) {
+		const SlotRun& run = m.splan.runs[ri];
+		slot_blob_off[ri] = (uint32_t)slot_blob.size();
+		const uint32_t* cols32 = reinterpret_cast<const uint32_t*>(m.splan.bt_cols.data() + run.row_off);
+		slot_blob.insert(slot_blob.end(), cols32, cols32 + (size_t)run.ncols * (sizeof(SlotBtCol) / 4));
+		const size_t end_words = (run.n_ends + 3) / 4 + 1;
+		const size_t at = slot_blob.size();
+		slot_blob.resize(at + end_words, 0);
+		if (run.n_ends) std::memcpy(slot_blob.data() + at, m.splan.end_slots.data() + m.splan.end_off[ri], run.n_ends);
+		slot_blob_words[ri] = (uint32_t)(slot_blob.size() - slot_blob_off[ri]);
+	}
+	void *d_srows = nullptr, *d_sblob = nullptr;
+	HIP_TRY(up(&d_srows, m.splan.rows.data(), m.splan.rows.size() * sizeof(SlotRow)));
+	HIP_TRY(up(&d_sblob, slot_blob.data(), slot_blob.size() * sizeof(uint32_t)));
+	m.dp.slot_rows = (const SlotRow*)d_srows;
+	m.dp.slot_blob = (const uint32_t*)d_sblob;
 	// ---- jobs (see Impl::Job): connected components made of runs only get their own job
 	m.release_lanes();
 	{
@@ -407,6 +465,16 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 					for (uint32_t i = 0; i < nseg; ++i) dst[i] = segs[d.seg_off + i];
 					u.pad1[0] = 1;  // runs are inline
 				}
+			} else if (st.kind == 2) {
+				const SlotRun& run = m.splan.runs[st.index];
+				SlotBtUnit su{};
+				su.kind = 2; su.c0 = run.c0; su.ncols = run.ncols; su.blob_off = slot_blob_off[st.index];
+				su.g = run.g; su.L = run.L; su.n_ends = run.n_ends; su.threads = run.threads;
+				su.bt_lo = run.rec_lo; su.bt_hi = run.rec_hi; su.half = run.half; su.blob_words = slot_blob_words[st.index];
+				su.f_exit = m.splan.f_exit[st.index];
+				for (uint32_t j = 0; j < su.f_exit && j < 32; ++j) su.exit_slot[j] = m.splan.exit_slot[st.index][j];
+				static_assert(sizeof(SlotBtUnit) == sizeof(BtUnit), "unit headers share one array");
+				std::memcpy(&u, &su, sizeof u);
 			} else {
 				const ResSegment& sgm = m.plan.segments[st.index];
 				u.c0 = sgm.c0; u.ncols = sgm.ncols; u.col_off = sgm.col_off; u.g = sgm.g; u.Lf_last = sgm.Lf_last;
@@ -425,7 +493,8 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	{
 		uint32_t max_stage = 0;
 		for (const ResSegment& sgm : m.plan.segments) max_stage = std::max(max_stage, sgm.stage_words);
-		m.bt_lds = (size_t)2 * RES_MAXCOLS * 128 + 512 + 16 + (size_t)RES_MAXCOLS * 8 + (size_t)max_stage * 8 + 16;
+		for (const SlotRun& run : m.splan.runs) max_stage = std::max(max_stage, (run.n_ends * run.threads + 7) / 8);
+		m.bt_lds = (size_t)2 * RES_MAXCOLS * 128 + 512 + 16 + (size_t)BT_CELLS * 4 + (size_t)RES_MAXCOLS * 4 + (size_t)max_stage * 8 + 16;
 	}
 	void* d_rtab = nullptr;
 	const bool ped_plan = !m.plan.ped_columns.empty();
@@ -476,7 +545,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		std::vector<Cursor> cur(m.lanes.size());
 		for (;;) {
 			Impl::SuperStep ss;
-			ss.entry_off = (uint32_t)m.entries.size();
+			ss.entry_off = (uint32_t)(m.use_slots ? m.slot_entries.size() : m.entries.size());
 			for (size_t li = 0; li < m.lanes.size(); ++li) {
 				Impl::Lane& lane = m.lanes[li];
 				Cursor& c = cur[li];
@@ -486,7 +555,19 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 				const uint32_t si = job.steps[c.step_i];
 				const bool first = c.step_i == 0, last = c.step_i + 1 == job.steps.size();
 				const Step& step = m.plan.steps[si];
-				if (step.kind == 1) {
+				if (step.kind == 2) {
+					SlotBatchEntry e{};
+					e.run = m.splan.runs[step.index];
+					if (first) e.run.has_prev = 0;  // a job starts from cost 0
+					e.prev = lane.d_pr[c.flip];
+					e.cur = lane.d_pr[c.flip ^ 1];
+					e.score_out = (last && !job.final) ? m.d_job_scores + job_id : nullptr;
+					ss.lds = std::max<size_t>(ss.lds, (size_t)2 * e.run.threads * (1u << SLOT_LR) * 4);
+					ss.grid_x = std::max(ss.grid_x, 1u << (e.run.g - e.run.half));
+					ss.threads = std::max(ss.threads, e.run.threads);
+					m.slot_entries.push_back(e);
+					++ss.entry_count;
+				} else if (step.kind == 1) {
 					ResBatchEntry e{};
 					e.sg = m.plan.segments[step.index];
 					e.sg.pad = step.index;
@@ -515,6 +596,9 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		void* d_entries = nullptr;
 		HIP_TRY(up(&d_entries, m.entries.data(), m.entries.size() * sizeof(ResBatchEntry)));
 		m.d_entries = (ResBatchEntry*)d_entries;
+		void* d_slot_entries = nullptr;
+		HIP_TRY(up(&d_slot_entries, m.slot_entries.data(), m.slot_entries.size() * sizeof(SlotBatchEntry)));
+		m.d_slot_entries = (SlotBatchEntry*)d_slot_entries;
 		std::vector<BtJob> btjobs;
 		for (const Impl::Job& job : m.jobs) btjobs.push_back(BtJob{job.unit_off, job.unit_count, job.final ? 1u : 0u, 0u});
 		void* d_btjobs = nullptr;
@@ -621,6 +705,15 @@ void DeviceTable::Impl::launch_run(const ResBatchEntry& e, uint32_t step_index, 
 	launches += 1;
 }
 
+// One slot run as a launch of its own (kernel arguments by value).
+void DeviceTable::Impl::launch_slot_run(const SlotBatchEntry& e, uint64_t& launches) {
+	Impl& m = *this;
+	const SlotRun& run = e.run;
+	const size_t lds = (size_t)2 * run.threads * (1u << SLOT_LR) * 4;
+	hipLaunchKernelGGL(slot_run<SLOT_LR>, dim3(1u << (run.g - run.half)), dim3(run.threads), lds, m.stream, m.dp, run, e.prev, e.cur, e.score_out);
+	launches += 1;
+}
+
 // Resumable submission: the first call does the preamble, every call submits super-steps until at least `budget`
 // launches went out, the call that runs out of super-steps appends the backtrace and the downloads.  Lets one host
 // thread interleave the launch sequences of several tables (whamd_dptable_enqueue_many).
@@ -666,7 +759,7 @@ whamd_status_t DeviceTable::enqueue_some_unguarded(const Problem& p, Solution& s
 		if (!m.plan.ped_columns.empty()) {
 			const uint32_t entries = (uint32_t)m.plan.ped_columns.size() * PED_TABLE;
 			hipLaunchKernelGGL(ped_tables, dim3((entries + 255) / 256), dim3(256), 0, m.stream, m.dp.ped_cols, (uint32_t)m.plan.ped_columns.size(), m.dp.ped_tables);
-		} else if (!m.plan.columns.empty()) {
+		} else if (!m.use_slots && !m.plan.columns.empty()) {
 			const uint32_t entries = (uint32_t)m.plan.columns.size() * RES_TABLE;
 			hipLaunchKernelGGL(resident_tables, dim3((entries + 255) / 256), dim3(256), 0, m.stream, m.dp.res_cols, (uint32_t)m.plan.columns.size(), m.dp.res_tables);
 		}
@@ -674,7 +767,13 @@ whamd_status_t DeviceTable::enqueue_some_unguarded(const Problem& p, Solution& s
 	uint64_t launches = 0;
 	while (m.next_super < m.schedule.size() && launches < budget) {
 		const Impl::SuperStep& ss = m.schedule[m.next_super++];
-		if (ss.entry_count == 1) {
+		if (m.use_slots) {
+			if (ss.entry_count == 1) m.launch_slot_run(m.slot_entries[ss.entry_off], launches);
+			else if (ss.entry_count > 1) {
+				hipLaunchKernelGGL(slot_batch<SLOT_LR>, dim3(ss.grid_x, ss.entry_count), dim3(ss.threads), ss.lds, m.stream, m.dp, m.d_slot_entries + ss.entry_off);
+				launches += 1;
+			}
+		} else if (ss.entry_count == 1) {
 			m.launch_run(m.entries[ss.entry_off], 0, launches);
 		} else if (ss.entry_count > 1) {
 			if (ss.sym) hipLaunchKernelGGL(resident_batch<true>, dim3(ss.grid_x, ss.entry_count), dim3(ss.threads), ss.lds, m.stream, m.dp, m.d_entries + ss.entry_off);
@@ -728,7 +827,7 @@ whamd_status_t DeviceTable::wait(const Problem& p, Solution& s, whamd_solve_stat
 	st.backtrace_ms = f12;
 	st.total_ms = f03;
 	st.forward_launches = launches;
-	if (m.dp.dbg) {
+	if (m.dp.dbg && !m.plan.segments.empty()) {
 		std::vector<unsigned long long> d(m.plan.segments.size() * 8);
 		HIP_TRY(hipMemcpy(d.data(), m.dp.dbg, d.size() * 8, hipMemcpyDeviceToHost));
 		unsigned long long a = 0, b = 0, c2 = 0, cols = 0, p1 = 0, p2 = 0, p3 = 0, ns = 0;

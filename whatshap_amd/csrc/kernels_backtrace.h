@@ -11,6 +11,8 @@
 // P.last_keys), the walk starts at units[1].  == 0: the units are the steps of ONE connected component that ends before
 // the table does (its last column projects onto a single entry): the walk starts at units[0] with entry 0 and no score
 // is written.
+constexpr int BT_CELLS = 128;  // >= RES_MAXCOLS and >= SLOT_MAXENDS_RUN + 1
+
 __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtUnit* __restrict__ all_units, const BtJob* __restrict__ jobs,
                                                          uint32_t* __restrict__ path_index, uint32_t* __restrict__ path_trans,
                                                          uint32_t* __restrict__ out_score) {
@@ -21,8 +23,8 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 	uint32_t* recs0 = smem;                                   // 2 x RES_MAXCOLS * 32 words: column records (double buffer)
 	uint32_t* hdr = smem + 2 * RES_MAXCOLS * 32;              // 4 x 32 words: unit headers (ring)
 	uint32_t* xshare = hdr + 128;                             // 4 words
-	uint32_t* cells = xshare + 4;                             // RES_MAXCOLS words: local cell index of the path per column
-	uint32_t* tsarr = cells + RES_MAXCOLS;                    // RES_MAXCOLS words: transmission value of the path per column
+	uint32_t* cells = xshare + 4;                             // BT_CELLS words: local cell index of the path per column (slot runs: per chain position)
+	uint32_t* tsarr = cells + BT_CELLS;                       // RES_MAXCOLS words: transmission value of the path per column
 	unsigned long long* stage = reinterpret_cast<unsigned long long*>(tsarr + RES_MAXCOLS);
 	const uint32_t lane = threadIdx.x, NT = blockDim.x;
 	const uint32_t n = P.n_cols, T = P.T;
@@ -61,6 +63,10 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 		const uint32_t* h1 = hdr + (u_first & 3u) * 32;
 		const uint32_t* __restrict__ g1 = reinterpret_cast<const uint32_t*>(P.res_bt + h1[3]);
 		for (uint32_t i = lane; i < h1[2] * 32; i += NT) recs0[(u_first & 1u) * RES_MAXCOLS * 32 + i] = g1[i];
+	} else if (n_units > u_first && hdr[(u_first & 3u) * 32] == 2u) {
+		const uint32_t* h1 = hdr + (u_first & 3u) * 32;
+		const uint32_t* __restrict__ g1 = P.slot_blob + h1[3];
+		for (uint32_t i = lane; i < h1[11]; i += NT) recs0[(u_first & 1u) * RES_MAXCOLS * 32 + i] = g1[i];
 	}
 	__syncthreads();
 	unsigned long long bt_load = 0, bt_walk = 0, bt_runs = 0, bt_a = 0, bt_b = 0, bt_c = 0;
@@ -74,9 +80,11 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 		const bool hload = lane < 32 && ui + 2 < n_units;
 		if (hload) hv = reinterpret_cast<const uint32_t*>(units + ui + 2)[lane];
 		const uint32_t* hn = hdr + ((ui + 1) & 3u) * 32;
-		const bool next_run = ui + 1 < n_units && hn[0] == 1u;
-		const uint32_t nrec = next_run ? hn[2] * 32 : 0u;
-		const uint32_t* __restrict__ gnext = reinterpret_cast<const uint32_t*>(P.res_bt + (next_run ? hn[3] : 0u));
+		const bool next_run = ui + 1 < n_units && hn[0] == 1u, next_slots = ui + 1 < n_units && hn[0] == 2u;
+		const uint32_t nrec = next_run ? hn[2] * 32 : (next_slots ? hn[11] : 0u);
+		const uint32_t* __restrict__ gnext = next_slots ? P.slot_blob + hn[3] : reinterpret_cast<const uint32_t*>(P.res_bt + (next_run ? hn[3] : 0u));
+		uint32_t slot_w = 0, slot_l = 0;
+		bool slot_mirrored = false;
 		uint32_t rv[2];
 #pragma unroll
 		for (int u = 0; u < 2; ++u) { const uint32_t i = u * NT + lane; rv[u] = i < nrec ? gnext[i] : 0u; }
@@ -114,6 +122,26 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 			}
 			tprev = aj;
 			x = xp;
+		} else if (kind == 2) {
+			// ---- slot run (slots.h): physical exit index from the logical one, then the record of the workgroup the path
+			// runs through (the complement workgroup's when that half was not computed) -> LDS
+			const uint32_t g = h[4], L = h[5], n_ends = h[6], threads = h[7], f_exit = h[12];
+			const uint8_t* exit_slot = reinterpret_cast<const uint8_t*>(h + 16);
+			uint32_t pexit = 0;
+			for (uint32_t j = 0; j < f_exit; ++j) pexit |= ((x >> j) & 1u) << exit_slot[j];
+			slot_w = pexit >> L;
+			slot_l = pexit & ((1u << L) - 1u);
+			slot_mirrored = h[10] && ((slot_w >> (g - 1u)) & 1u);
+			const uint32_t wrec = slot_mirrored ? (~slot_w & ((1u << g) - 1u)) : slot_w;
+			const uint32_t stage_words = n_ends * threads / 8u;
+			const unsigned long long* __restrict__ gst = reinterpret_cast<const unsigned long long*>(
+				P.bt + (((unsigned long long)h[9] << 32) | h[8]) + (size_t)wrec * n_ends * threads);
+			unsigned long long sv[2];
+#pragma unroll
+			for (int u = 0; u < 2; ++u) { const uint32_t i = u * NT + lane; sv[u] = i < stage_words ? gst[i] : 0ull; }
+#pragma unroll
+			for (int u = 0; u < 2; ++u) { const uint32_t i = u * NT + lane; if (i < stage_words) stage[i] = sv[u]; }
+			for (uint32_t i = 2 * NT + lane; i < stage_words; i += NT) stage[i] = gst[i];
 		} else {
 			// ---- resident run [c0, c0 + ncols): this workgroup's record -> LDS
 			const uint32_t g = h[4], Lf_last = h[5], stage_words = h[6], n_wext = h[7];
@@ -146,6 +174,42 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 		}
 		__syncthreads();
 		const unsigned long long tb1 = P.dbg ? __builtin_readcyclecounter() : 0ull;
+		if (kind == 2) {
+			if (lane < 64) {   // one wave follows the path
+				const uint32_t g = h[4], L = h[5], n_ends = h[6], threads = h[7];
+				(void)g;
+				const SlotBtCol* bcols = reinterpret_cast<const SlotBtCol*>(recs);
+				const uint8_t* ends = reinterpret_cast<const uint8_t*>(recs + ncols * 8);
+				// lane k holds the slot of ending read k (and k + 64): the chain fetches it with v_readlane
+				const uint32_t e_lo = lane < n_ends ? ends[lane] : 0u, e_hi = lane + 64u < n_ends ? ends[lane + 64u] : 0u;
+				const uint8_t* stage8 = reinterpret_cast<const uint8_t*>(stage);
+				const uint32_t lmask = (1u << L) - 1u;
+				uint32_t l = slot_l;
+				if (lane == 0) cells[n_ends] = l;
+				// state S[k] = local index of the path after undoing the ending reads k, k+1, ...: one dependent LDS byte per step
+				for (uint32_t k = n_ends; k-- > 0;) {
+					const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)(k < 64u ? e_lo : e_hi), (int)(k & 63u));
+					const uint32_t look = slot_mirrored ? ((~l & lmask) | (1u << j)) : (l & ~(1u << j));
+					const uint32_t byte = stage8[k * threads + (look >> SLOT_LR)];
+					const uint32_t bit = (byte >> (look & ((1u << SLOT_LR) - 1u))) & 1u;
+					l = (l & ~(1u << j)) | (bit << j);
+					if (lane == 0) cells[k] = l;
+				}
+				__builtin_amdgcn_wave_barrier();
+				uint32_t xl = 0;
+				if (lane < ncols) {
+					const SlotBtCol& bc = bcols[lane];
+					const uint32_t pc = (slot_w << L) | cells[bc.kf];
+					for (uint32_t j = 0; j < bc.k; ++j) xl |= ((pc >> bc.slot[j]) & 1u) << j;
+					path_index[c0 + lane] = xl;
+					path_trans[c0 + lane] = 0u;
+				}
+				if (lane == 0) { xshare[0] = xl; xshare[1] = 0u; }
+			}
+			__syncthreads();
+			x = xshare[0];
+			tprev = xshare[1];
+		}
 		if (kind == 1) {
 			if (lane < 64) {  // one wave follows the path; the others only helped with the copies
 				// local exit index of the path

@@ -1,0 +1,262 @@
+// kernels_slots.h -- slot_run: the register-resident run kernel of a single individual (slots.h has the design).
+// Included by dp_device.hip inside namespace whamd { namespace { ... } }: not a stand-alone header.
+//
+// One launch = one run of consecutive columns.  Workgroup w, wave v, lane l and register r of a thread hold the cell
+// with physical index P = (w << L) | (v << (6 + LR)) | (l << LR) | r for the whole run; a column adds its closed-form
+// cost to every cell, an ending read is minimised out where it sits (registers / cross-lane move / LDS exchange
+// between two waves), a starting read just begins to contribute its delta.  Per-column constants are wave-uniform:
+// they arrive through the scalar cache (s_load) into SGPRs, the workgroup- and wave-dependent part of S is prepared
+// for all columns of the run at once by the lanes of the wave (lane c: column c) and picked up with v_readlane.
+//
+// Restates compute_column of the reference (src/pedigreedptable.cpp:177-335) for T = 1: cost per cell (:262-283 with
+// PedigreeColumnCostComputer::get_cost), strict-'<' projection with Gray-code visiting order (:306-327) as the tie
+// rule of slots.h.
+
+// min(Cp + S, Cm - S, Cc) with A = Cp + S and K = Cp + Cm (mod 2^32; absent terms are RES_ABSENT and never the minimum)
+__device__ __forceinline__ uint32_t slot_cost(uint32_t A, uint32_t K, uint32_t Cc) { return min(min(A, K - A), Cc); }
+
+// One ending read whose slot is reg slot J: the two cells of a pair live in the same thread.
+template <int LR, int J>
+__device__ __forceinline__ uint32_t slot_end_reg(uint32_t (&D)[1 << LR], uint32_t qthr, uint32_t qmask) {
+	constexpr int R = 1 << LR;
+	uint32_t takes = 0;
+#pragma unroll
+	for (int r0 = 0; r0 < R; ++r0) {
+		if (r0 & (1 << J)) continue;
+		const int r1 = r0 | (1 << J);
+		const uint32_t q0 = qthr ^ ((qmask >> r0) & 1u), q1 = qthr ^ ((qmask >> r1) & 1u);
+		const uint32_t a = D[r0], b = D[r1];
+		takes |= (b < a + q0) ? (1u << r0) : 0u;   // the pair's decision: side 1 wins if smaller, or equal and favoured
+		takes |= (a < b + q1) ? (1u << r1) : 0u;   // the decision of the pair's mirror image
+		D[r0] = D[r1] = min(a, b);
+	}
+	return takes;
+}
+
+// The partner cells are held by `other` (same register index r): lane slot (cross-lane move) or wave slot (LDS).
+template <int LR>
+__device__ __forceinline__ uint32_t slot_end_partner(uint32_t (&D)[1 << LR], const uint32_t (&other)[1 << LR], uint32_t qthr, uint32_t qmask) {
+	constexpr int R = 1 << LR;
+	uint32_t takes = 0;
+#pragma unroll
+	for (int r = 0; r < R; ++r) {
+		const uint32_t q = qthr ^ ((qmask >> r) & 1u);
+		takes |= (other[r] < D[r] + q) ? (1u << r) : 0u;   // side-0 cell: decision of the pair; side-1 cell: of its mirror image
+		D[r] = min(D[r], other[r]);
+	}
+	return takes;
+}
+
+// Wave-uniform data is read through the scalar cache: loads from the constant address space become s_load_dwordx8
+// (kernel arguments are the same kind of memory).  A generic pointer converts bit for bit.
+typedef uint32_t slot_u32x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t slot_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t slot_u32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(4))) slot_u32x8* slot_cptr8;
+typedef const __attribute__((address_space(4))) slot_u32x4* slot_cptr4;
+typedef const __attribute__((address_space(4))) slot_u32x2* slot_cptr2;
+// the hot words of one column (SlotRow): 8 + 4 + 4 + 2 dwords, every one of them read
+struct SlotHot { slot_u32x8 a; slot_u32x4 b, c; slot_u32x2 d; };
+__device__ __forceinline__ SlotHot slot_load_hot(const SlotRow* row) {
+	const unsigned long long p = (unsigned long long)row;
+	SlotHot h;
+	h.a = *(slot_cptr8)p; h.b = *(slot_cptr4)(p + 32); h.c = *(slot_cptr4)(p + 48); h.d = *(slot_cptr2)(p + 64);
+	return h;
+}
+template <class T>
+__device__ __forceinline__ slot_cptr8 slot_scalar_ptr(const T* p) { return (slot_cptr8)(unsigned long long)p; }
+
+// byte s of a packed position table held in SGPRs (static s)
+__device__ __forceinline__ uint32_t slot_pos_dev(const uint32_t (&w)[8], int s) { return (w[s >> 2] >> ((s & 3) * 8)) & 31u; }
+
+template <int LR>
+__device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun& run, const uint32_t* __restrict__ prev,
+                                              uint32_t* __restrict__ cur, const uint32_t w, uint32_t* score_out) {
+	constexpr int R = 1 << LR;
+	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];   // wave-slot exchange: 2 x [threads][R]
+	const uint32_t tid = threadIdx.x, lane = tid & 63u;
+	const uint32_t wave = uni(tid >> 6);
+	const uint32_t L = run.L;
+	const uint32_t lthr = tid << LR;               // local index of this thread's cell 0
+	const uint32_t Pthr = (w << L) | lthr;         // its physical index
+	const SlotRow* __restrict__ rows = P.slot_rows + run.row_off;
+	const uint32_t ncols = run.ncols;
+
+	// ---- prologue: one batch of loads.  (0) the hot words of column 0 (scalar cache)
+	SlotHot hn = slot_load_hot(rows);
+	// (1) lane c of every wave fetches the cold part of column c and prepares A = Cp + (deltas of the set grid / wave slots)
+	uint32_t Avec = 0;
+	{
+		const uint32_t cl = lane < ncols ? lane : 0u;
+		const SlotRow* __restrict__ rr = rows + cl;
+		const uint32_t Pu = (w << L) | (wave << (6 + LR));   // the wave-uniform part of the physical index
+		uint32_t acc = rr->Cp;
+#pragma unroll
+		for (int s = LR + 6; s < SLOT_MAXSLOTS; ++s) acc += ((Pu >> s) & 1u) ? (uint32_t)rr->dslot[s] : 0u;   // slots >= L + g: bit and delta are 0
+		Avec = acc;
+	}
+	// (2) the entering cells
+	uint32_t D[R];
+	if (run.has_prev) {
+		const uint32_t occ = run.in_occ;
+		if (run.in_identity && (occ & (uint32_t)(R - 1)) == (uint32_t)(R - 1) && (!run.in_half || run.in_mirror_pos >= (uint32_t)LR)) {
+			// the previous run stored in this run's physical order: R contiguous entries per thread; after a halved run
+			// the entries whose mirror bit is set come from the complement index, i.e. the mirrored group in reverse
+			uint32_t base = Pthr & occ;
+			const bool flip = run.in_half && ((base >> run.in_mirror_pos) & 1u);
+			if (flip) base = (base ^ run.in_fullmask) & ~(uint32_t)(R - 1);
+			uint32_t v[R];
+#pragma unroll
+			for (int q = 0; q < R / 4; ++q) {
+				const uint4 t = *reinterpret_cast<const uint4*>(prev + base + 4 * q);
+				v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+			}
+#pragma unroll
+			for (int r = 0; r < R; ++r) D[r] = flip ? v[R - 1 - r] : v[r];
+		} else {
+			// any layout (after a per-column step: logical order): index bit by bit, tables in SGPRs, static slot indices
+			uint32_t pos[SLOT_MAXSLOTS];
+#pragma unroll
+			for (int s = 0; s < SLOT_MAXSLOTS; ++s) pos[s] = run.in_identity ? (uint32_t)s : slot_pos_dev(run.in_pos, s);
+			uint32_t base = 0;
+#pragma unroll
+			for (int s = LR; s < SLOT_MAXSLOTS; ++s) base |= ((Pthr & occ) >> s & 1u) << pos[s];
+#pragma unroll
+			for (int r = 0; r < R; ++r) {
+				uint32_t idx = base;
+#pragma unroll
+				for (int s = 0; s < LR; ++s)
+					if ((r >> s) & 1) idx |= ((occ >> s) & 1u) << pos[s];
+				if (run.in_half && ((idx >> run.in_mirror_pos) & 1u)) idx ^= run.in_fullmask;
+				D[r] = prev[idx];
+			}
+		}
+	} else {
+#pragma unroll
+		for (int r = 0; r < R; ++r) D[r] = 0;
+	}
+	// per-lane constants of the column loop
+	int32_t lanebit[SLOT_LANE];
+#pragma unroll
+	for (int j = 0; j < SLOT_LANE; ++j) lanebit[j] = (int32_t)((lane >> j) & 1u);
+	uint8_t* __restrict__ rec = P.bt + (((unsigned long long)run.rec_hi << 32) | run.rec_lo) + (size_t)w * run.n_ends * run.threads + tid;
+	const uint32_t threads = run.threads;
+	const uint32_t xwords = threads * R;   // one exchange buffer
+	uint32_t xsel = 0;
+
+	for (uint32_t ci = 0; ci < ncols; ++ci) {
+		// this column's hot words are in SGPRs; fetch the next column's now (one scalar-cache latency, hidden by the column)
+		const SlotHot h = hn;
+		hn = slot_load_hot(rows + (ci + 1u < ncols ? ci + 1u : ci));
+		const uint32_t K = h.a[0], Cc = h.a[1], n_end = h.a[2];
+		uint32_t A = (uint32_t)__builtin_amdgcn_readlane((int)Avec, (int)ci);
+		A += (uint32_t)__mul24(lanebit[0], (int32_t)h.a[6]);
+		A += (uint32_t)__mul24(lanebit[1], (int32_t)h.a[7]);
+		A += (uint32_t)__mul24(lanebit[2], (int32_t)h.b[0]);
+		A += (uint32_t)__mul24(lanebit[3], (int32_t)h.b[1]);
+		A += (uint32_t)__mul24(lanebit[4], (int32_t)h.b[2]);
+		A += (uint32_t)__mul24(lanebit[5], (int32_t)h.b[3]);
+		const uint32_t dr[3] = {h.a[3], h.a[4], h.a[5]};
+#pragma unroll
+		for (int r = 0; r < R; ++r) {
+			uint32_t pat = 0;
+#pragma unroll
+			for (int s = 0; s < LR; ++s) pat += ((r >> s) & 1) ? dr[s] : 0u;
+			D[r] += slot_cost(A + pat, K, Cc);
+		}
+		for (uint32_t q = 0; q < n_end; ++q) {
+			const uint32_t info = q == 0 ? h.c[0] : (q == 1 ? h.c[2] : h.d[0]), M = q == 0 ? h.c[1] : (q == 1 ? h.c[3] : h.d[1]);
+			const uint32_t slot = info & 255u, qmask = (info >> 8) & 0xFFFFu, mflip = (info >> 24) & 1u;
+			uint32_t qthr = (uint32_t)__popc(Pthr & M) & 1u;
+			if (slot >= (uint32_t)LR) qthr ^= ((Pthr >> slot) & 1u) & mflip;
+			uint32_t takes;
+			if (slot < (uint32_t)LR) {
+				if (slot == 0) takes = slot_end_reg<LR, 0>(D, qthr, qmask);
+				else if (slot == 1) takes = slot_end_reg<LR, 1>(D, qthr, qmask);
+				else if (LR > 2 && slot == 2) takes = slot_end_reg<LR, (LR > 2 ? 2 : 0)>(D, qthr, qmask);
+				else takes = slot_end_reg<LR, (LR > 3 ? 3 : 0)>(D, qthr, qmask);
+			} else if (slot < (uint32_t)(LR + SLOT_LANE)) {
+				const int src = (int)((lane ^ (1u << (slot - LR))) << 2);
+				uint32_t other[R];
+#pragma unroll
+				for (int r = 0; r < R; ++r) other[r] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)D[r]);
+				takes = slot_end_partner<LR>(D, other, qthr, qmask);
+			} else {
+				// the partner cells are another wave's registers: exchange through LDS (two buffers: the barrier of the next
+				// exchange also protects this one's reads)
+				uint32_t* xb = smem + xsel * xwords;
+				uint4* mine = reinterpret_cast<uint4*>(xb + tid * R);
+#pragma unroll
+				for (int q4 = 0; q4 < R / 4; ++q4) mine[q4] = make_uint4(D[4 * q4], D[4 * q4 + 1], D[4 * q4 + 2], D[4 * q4 + 3]);
+				__syncthreads();
+				const uint32_t ptid = tid ^ (64u << (slot - LR - SLOT_LANE));
+				const uint4* theirs = reinterpret_cast<const uint4*>(xb + ptid * R);
+				uint32_t other[R];
+#pragma unroll
+				for (int q4 = 0; q4 < R / 4; ++q4) {
+					const uint4 t = theirs[q4];
+					other[4 * q4] = t.x; other[4 * q4 + 1] = t.y; other[4 * q4 + 2] = t.z; other[4 * q4 + 3] = t.w;
+				}
+				takes = slot_end_partner<LR>(D, other, qthr, qmask);
+				xsel ^= 1u;
+			}
+			*rec = (uint8_t)takes;
+			rec += threads;
+		}
+	}
+
+	// ---- exit: scatter into the next step's order (cells whose free-slot bits are zero hold the representatives)
+	{
+		const uint32_t occ = run.out_occ;
+		const uint32_t localmask = (1u << L) - 1u;
+		const bool thread_writes = ((lthr & ~(uint32_t)(R - 1)) & ~occ & localmask) == 0u;
+		uint32_t pos[SLOT_MAXSLOTS];
+#pragma unroll
+		for (int s = 0; s < SLOT_MAXSLOTS; ++s) pos[s] = slot_pos_dev(run.out_pos, s);
+		uint32_t base = 0;
+#pragma unroll
+		for (int s = LR; s < SLOT_MAXSLOTS; ++s) base |= ((Pthr & occ) >> s & 1u) << pos[s];
+		const uint32_t mirror_x = run.mirror_out ? run.out_fullmask : 0u;
+#pragma unroll
+		for (int r = 0; r < R; ++r) {
+			bool writes = thread_writes;
+			uint32_t x = 0;
+#pragma unroll
+			for (int s = 0; s < LR; ++s) {
+				if ((r >> s) & 1) {
+					x |= 1u << pos[s];
+					writes = writes && ((occ >> s) & 1u);
+				}
+			}
+			if (writes) {
+				const uint32_t idx = base | x;
+				cur[idx] = D[r];
+				if (run.mirror_out) cur[idx ^ mirror_x] = D[r];
+			}
+		}
+	}
+	if (score_out && w == 0 && tid == 0) *score_out = D[0];
+}
+
+template <int LR>
+__global__ __launch_bounds__(512) void slot_run(DevProblem P, SlotRun run, const uint32_t* __restrict__ prev, uint32_t* __restrict__ cur,
+                                                uint32_t* __restrict__ score_out) {
+	touch_kernel_arguments<sizeof(DevProblem) + sizeof(SlotRun) + 24>();
+	slot_run_body<LR>(P, run, prev, cur, blockIdx.x, score_out);
+}
+
+// One launch = the next run of SEVERAL independent jobs (connected components of one table): blockIdx.y selects the entry.
+template <int LR>
+__global__ __launch_bounds__(512) void slot_batch(DevProblem P, const SlotBatchEntry* __restrict__ entries) {
+	const SlotBatchEntry* __restrict__ e = entries + blockIdx.y;
+	{
+		const uint32_t* lines = reinterpret_cast<const uint32_t*>(e);
+		uint32_t acc = 0;
+#pragma unroll
+		for (uint32_t l = 0; l < (sizeof(SlotBatchEntry) + 63) / 64; ++l) acc |= lines[l * 16];
+		asm volatile("" ::"s"(__builtin_amdgcn_readfirstlane(acc)));
+	}
+	const SlotRun run = e->run;
+	if (blockIdx.x >= (1u << (run.g - run.half)) || threadIdx.x >= run.threads) return;
+	slot_run_body<LR>(P, run, e->prev, e->cur, blockIdx.x, e->score_out);
+}

@@ -1,0 +1,290 @@
+// slot_plan.cpp -- host planner of the register-resident forward path (slots.h): cuts the column chain of a
+// single-individual table into runs, assigns every read of a run its slot, builds the per-column descriptors, the
+// exchange layouts between steps and everything the backtrace needs.
+//
+// Reference semantics restated here: ColumnIndexingScheme (src/columnindexingscheme.cpp:7-34,62-85: the reads shared with
+// the previous column are the low b bits, the forward mask compacts the reads that continue), the cost terms of
+// PedigreeColumnCostComputer (src/pedigreecolumncostcomputer.cpp:14-114, closed form of DESIGN.md section 2) and the
+// Gray-rank tie rule of src/pedigreedptable.cpp:306-327.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "slots.h"
+
+namespace whamd {
+
+namespace {
+
+struct RunDraft {
+	uint32_t c0 = 0, ncols = 0, g = 0, L = 0, lw = 0;
+	std::vector<int32_t> entry_read;   // [L + g] read id per slot at entry (-1 free)
+	std::vector<int32_t> exit_read;    // [L + g] read id per slot after the last column
+	bool symmetric = true;
+};
+
+inline uint32_t parity32(uint32_t v) { return (uint32_t)__builtin_popcount(v) & 1u; }
+
+}  // namespace
+
+bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan& plan) {
+	plan = SlotPlan();
+	const uint32_t n = p.n_cols;
+	if (!(p.T == 1 && p.n_ind == 1 && p.value_bound < 1073741824.0)) return false;
+	plan.col_to_row.assign(n, -1);
+	const int LMIN = SLOT_LR + SLOT_LANE, LMAX = SLOT_LR + SLOT_LANE + SLOT_LWMAX;
+	l_pref = std::max(LMIN, std::min(l_pref, LMAX));
+	std::vector<uint32_t> last_col(p.n_reads, 0);
+	for (uint32_t c = 0; c < n; ++c) {
+		const ColumnEntry* col = p.col_begin(c);
+		for (uint32_t j = 0; j < p.k[c]; ++j) last_col[col[j].read_id] = c;
+	}
+	std::vector<int8_t> slot_of(p.n_reads, -1);
+	std::vector<RunDraft> drafts;
+	uint32_t c = 0;
+	while (c < n) {
+		auto column_step = [&]() { plan.steps.push_back(Step{0, c}); ++c; };
+		if (c + 1 >= n) { column_step(); continue; }   // the last column needs the global optimum (column_step_keys)
+		const uint32_t b0 = p.b[c];
+		const ColumnEntry* first = p.col_begin(c);
+		// ---- shape of the run: local slots L, grid slots g
+		uint32_t kmax = 0;
+		for (uint32_t cc = c; cc < std::min(n, c + 6); ++cc) {
+			if (cc > c && p.b[cc] == 0) break;
+			kmax = std::max<uint32_t>(kmax, p.k[cc]);
+		}
+		const uint32_t L = std::min<uint32_t>((uint32_t)l_pref, std::max<uint32_t>((uint32_t)LMIN, kmax));
+		uint32_t g = kmax > L ? kmax - L : 0;
+		if (g > b0 || g > (uint32_t)SLOT_GMAX || p.k[c] > L + g) { column_step(); continue; }
+		// grid reads: the g entering reads that end last (ties: the younger read)
+		std::vector<uint32_t> order(b0);
+		for (uint32_t j = 0; j < b0; ++j) order[j] = j;
+		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t bb) {
+			const uint32_t ea = last_col[first[a].read_id], eb = last_col[first[bb].read_id];
+			if (ea != eb) return ea > eb;
+			return a > bb;
+		});
+		RunDraft d;
+		d.c0 = c; d.g = g; d.L = L; d.lw = L - (uint32_t)LMIN;
+		const uint32_t nslots = L + g;
+		d.entry_read.assign(nslots, -1);
+		uint32_t grid_end = 0xFFFFFFFFu;
+		{
+			std::vector<uint32_t> grid_reads;
+			for (uint32_t i = 0; i < g; ++i) {
+				grid_reads.push_back(first[order[i]].read_id);
+				grid_end = std::min(grid_end, last_col[first[order[i]].read_id]);
+			}
+			std::sort(grid_reads.begin(), grid_reads.end());
+			for (uint32_t i = 0; i < g; ++i) d.entry_read[L + i] = (int32_t)grid_reads[i];
+			// local entering reads: the one that ends first gets the lowest slot (reg slots first, wave slots last)
+			uint32_t s = 0;
+			for (uint32_t i = b0; i-- > g;) d.entry_read[s++] = (int32_t)first[order[i]].read_id;
+		}
+		std::vector<int32_t> cur = d.entry_read;   // read per slot, updated column by column
+		auto release_marks = [&]() {
+			for (int32_t r : d.entry_read) if (r >= 0) slot_of[r] = -1;
+			for (int32_t r : cur) if (r >= 0) slot_of[r] = -1;
+		};
+		for (uint32_t s = 0; s < nslots; ++s) if (cur[s] >= 0) slot_of[cur[s]] = (int8_t)s;
+		// ---- walk the columns
+		const size_t rows_mark = plan.rows.size(), ends_mark = plan.end_slots.size();
+		std::vector<int32_t> started;   // reads that got their slot inside the run (marks to clear)
+		uint32_t c1 = c, n_ends = 0;
+		bool symmetric = true;
+		while (c1 < n && c1 - c < (uint32_t)SLOT_MAXCOLS) {
+			if (c1 + 1 == n) break;
+			if (c1 >= grid_end) break;
+			if (c1 > c && p.b[c1] == 0) break;
+			const ColumnEntry* col = p.col_begin(c1);
+			const uint32_t kc = p.k[c1], bc = c1 == c ? b0 : p.b[c1];
+			const uint32_t n_new = kc - bc, n_end = kc - p.f[c1];
+			if (n_end > (uint32_t)SLOT_MAXEND || n_ends + n_end > (uint32_t)SLOT_MAXENDS_RUN) break;
+			uint32_t n_free = 0;
+			for (uint32_t s = 0; s < L; ++s) n_free += cur[s] < 0;
+			if (n_new > n_free) break;
+			bool ok = true;
+			for (uint32_t j = 0; j < kc && ok; ++j) ok = std::abs(p.delta[(size_t)p.col_ptr[c1] + j]) < SLOT_DELTA_LIMIT;
+			for (uint32_t j = 0; j < bc && ok; ++j) ok = slot_of[col[j].read_id] >= 0;   // every shared read is tracked
+			if (!ok) break;
+			// reads that start here take the lowest free local slots
+			{
+				uint32_t s = 0;
+				for (uint32_t j = bc; j < kc; ++j) {
+					while (cur[s] >= 0) ++s;
+					cur[s] = (int32_t)col[j].read_id;
+					slot_of[col[j].read_id] = (int8_t)s;
+					started.push_back((int32_t)col[j].read_id);
+				}
+			}
+			const int32_t* dl = p.delta.data() + (size_t)p.col_ptr[c1];   // n_ind == 1
+			SlotRow row{};
+			SlotBtCol bc_rec{};
+			uint32_t Cp = RES_ABSENT, Cm = RES_ABSENT, Cc = INF;
+			for (uint64_t q = p.term_begin(c1, 0); q < p.term_end(c1, 0); ++q) {
+				const CostTerm& t = p.terms[q];
+				if (t.plus) Cp = t.c;
+				else if (t.minus) Cm = t.c;
+				else Cc = std::min(Cc, t.c);
+			}
+			row.K = Cp + Cm;
+			row.Cc = Cc;
+			row.Cp = Cp;
+			uint32_t dsum = 0;
+			bc_rec.k = (uint8_t)kc;
+			bc_rec.kf = (uint8_t)n_ends;
+			for (uint32_t j = 0; j < kc; ++j) {
+				const int s = slot_of[col[j].read_id];
+				row.dslot[s] = dl[j];
+				dsum += (uint32_t)dl[j];
+				bc_rec.slot[j] = (uint8_t)s;
+			}
+			for (int s = 0; s < SLOT_LR; ++s) row.dreg[s] = row.dslot[s];
+			for (int s = 0; s < SLOT_LANE; ++s) row.dlane[s] = row.dslot[SLOT_LR + s];
+			{   // cost(~x) == cost(x)  <=>  Cp + (sum of all deltas) == Cm, or no orientation term at all
+				const bool both_absent = Cp == RES_ABSENT && Cm == RES_ABSENT;
+				if (!both_absent && (Cp == RES_ABSENT || Cm == RES_ABSENT || Cp + dsum != Cm)) symmetric = false;
+			}
+			// ending reads, ascending logical position
+			uint32_t en = 0;
+			for (uint32_t j = 0; j < kc; ++j) {
+				if ((p.fwd_mask[c1] >> j) & 1u) continue;
+				const int s = slot_of[col[j].read_id];
+				if (s >= (int)L) { ok = false; break; }   // a grid read would end (excluded by grid_end)
+				uint32_t M = 0;
+				for (uint32_t q = j + 1; q < kc; ++q) M |= 1u << slot_of[col[q].read_id];
+				const uint32_t mflip = parity32(M);
+				uint32_t qmask = 0;
+				for (uint32_t r = 0; r < (1u << SLOT_LR); ++r) {
+					uint32_t bit = parity32(r & M);
+					if (s < SLOT_LR) bit ^= ((r >> s) & 1u) & mflip;
+					qmask |= bit << r;
+				}
+				row.end[en].info = (uint32_t)s | (qmask << 8) | (mflip << 24);
+				row.end[en].M = M;
+				plan.end_slots.push_back((uint8_t)s);
+				++en;
+			}
+			if (!ok) break;
+			row.n_end = en;
+			// after the projection the ended reads' slots are free again
+			for (uint32_t j = 0; j < kc; ++j) {
+				if ((p.fwd_mask[c1] >> j) & 1u) continue;
+				cur[slot_of[col[j].read_id]] = -1;
+			}
+			n_ends += en;
+			plan.col_to_row[c1] = (int32_t)plan.rows.size();
+			plan.rows.push_back(row);
+			plan.bt_cols.push_back(bc_rec);
+			++c1;
+		}
+		// a run whose bookkeeping stopped in the middle of a column: drop what that column appended
+		plan.rows.resize(rows_mark + (c1 - c));
+		plan.bt_cols.resize(rows_mark + (c1 - c));
+		{
+			size_t keep = 0;
+			for (size_t i = rows_mark; i < plan.rows.size(); ++i) keep += plan.rows[i].n_end;
+			plan.end_slots.resize(ends_mark + keep);
+		}
+		if (c1 - c < 2) {   // not worth a launch of its own
+			for (uint32_t cc = c; cc < c1; ++cc) plan.col_to_row[cc] = -1;
+			plan.rows.resize(rows_mark);
+			plan.bt_cols.resize(rows_mark);
+			plan.end_slots.resize(ends_mark);
+			release_marks();
+			for (int32_t r : started) slot_of[r] = -1;
+			column_step();
+			continue;
+		}
+		// exit state: the reads that continue after column c1 - 1 (recomputed: `cur` may hold marks of a dropped column)
+		d.exit_read.assign(nslots, -1);
+		{
+			const ColumnEntry* col = p.col_begin(c1 - 1);
+			for (uint32_t j = 0; j < p.k[c1 - 1]; ++j)
+				if ((p.fwd_mask[c1 - 1] >> j) & 1u) d.exit_read[plan.bt_cols[rows_mark + (c1 - 1 - c)].slot[j]] = (int32_t)col[j].read_id;
+		}
+		release_marks();
+		for (int32_t r : started) slot_of[r] = -1;
+		d.ncols = c1 - c;
+		d.symmetric = symmetric;
+		SlotRun run{};
+		run.c0 = c; run.ncols = d.ncols; run.g = g; run.L = L; run.lw = d.lw;
+		run.kind = 2;
+		run.row_off = (uint32_t)rows_mark;
+		run.n_ends = 0;
+		for (size_t i = rows_mark; i < plan.rows.size(); ++i) run.n_ends += plan.rows[i].n_end;
+		run.threads = 64u << d.lw;
+		run.has_prev = b0 > 0;
+		run.half = (use_symmetry > 0 && symmetric && g >= 1) ? 1u : 0u;
+		for (uint32_t s = 0; s < nslots; ++s) {
+			if (d.entry_read[s] >= 0) run.in_occ |= 1u << s;
+			if (d.exit_read[s] >= 0) run.out_occ |= 1u << s;
+		}
+		plan.steps.push_back(Step{2, (uint32_t)plan.runs.size()});
+		plan.runs.push_back(run);
+		plan.end_off.push_back((uint32_t)ends_mark);
+		drafts.push_back(d);
+		plan.n_run_columns += d.ncols;
+		c = c1;
+	}
+	for (size_t si = 0; si < plan.steps.size(); ++si) {
+		const uint32_t c0 = plan.steps[si].kind == 2 ? plan.runs[plan.steps[si].index].c0 : plan.steps[si].index;
+		if (si == 0 || p.b[c0] == 0) plan.component_first_step.push_back((uint32_t)si);
+	}
+	// ---- entry / exit layouts.  Exit index of a run in LOGICAL order: bit j = j-th continuing read of its last column.
+	plan.f_exit.assign(plan.runs.size(), 0);
+	plan.exit_slot.assign(plan.runs.size(), std::vector<uint8_t>());
+	for (size_t ri = 0; ri < plan.runs.size(); ++ri) {
+		const SlotRun& run = plan.runs[ri];
+		const uint32_t cl = run.c0 + run.ncols - 1;
+		const SlotBtCol& bc = plan.bt_cols[run.row_off + run.ncols - 1];
+		for (uint32_t j = 0; j < p.k[cl]; ++j)
+			if ((p.fwd_mask[cl] >> j) & 1u) plan.exit_slot[ri].push_back(bc.slot[j]);
+		plan.f_exit[ri] = (uint32_t)plan.exit_slot[ri].size();
+	}
+	for (size_t si = 0; si < plan.steps.size(); ++si) {
+		if (plan.steps[si].kind != 2) continue;
+		const uint32_t ri = plan.steps[si].index;
+		SlotRun& B = plan.runs[ri];
+		const RunDraft& db = drafts[ri];
+		// -- entry
+		const bool prev_is_run = si > 0 && plan.steps[si - 1].kind == 2 && B.has_prev;
+		if (prev_is_run) {
+			B.in_identity = 1;   // the previous run stores in THIS run's physical order
+			for (uint32_t s = 0; s < B.L + B.g; ++s) slot_set_pos(B.in_pos, s, s);
+			B.in_fullmask = B.in_occ;
+		} else if (B.has_prev) {
+			const ColumnEntry* first = p.col_begin(B.c0);
+			std::memset(B.in_pos, 0, sizeof B.in_pos);
+			for (uint32_t j = 0; j < p.b[B.c0]; ++j) {
+				for (uint32_t s = 0; s < B.L + B.g; ++s)
+					if (db.entry_read[s] == (int32_t)first[j].read_id) slot_set_pos(B.in_pos, s, j);
+			}
+			B.in_fullmask = p.b[B.c0] >= 32 ? 0xFFFFFFFFu : ((1u << p.b[B.c0]) - 1u);
+		}
+		// -- exit
+		const bool next_is_run = si + 1 < plan.steps.size() && plan.steps[si + 1].kind == 2 &&
+		                         plan.runs[plan.steps[si + 1].index].has_prev;
+		if (next_is_run) {
+			SlotRun& C = plan.runs[plan.steps[si + 1].index];
+			const RunDraft& dc = drafts[plan.steps[si + 1].index];
+			for (uint32_t s = 0; s < B.L + B.g; ++s) {
+				if (db.exit_read[s] < 0) continue;
+				for (uint32_t t = 0; t < C.L + C.g; ++t)
+					if (dc.entry_read[t] == db.exit_read[s]) slot_set_pos(B.out_pos, s, t);
+			}
+			B.out_fullmask = C.in_occ;
+			if (B.half) {
+				C.in_half = 1;
+				C.in_mirror_pos = slot_pos(B.out_pos, B.L + B.g - 1);   // where this run's top grid read sits in the next run's index
+			}
+		} else {
+			for (uint32_t j = 0; j < plan.f_exit[ri]; ++j) slot_set_pos(B.out_pos, plan.exit_slot[ri][j], j);
+			B.out_fullmask = plan.f_exit[ri] >= 32 ? 0xFFFFFFFFu : ((1u << plan.f_exit[ri]) - 1u);
+			B.mirror_out = B.half;   // a per-column step reads every entry
+		}
+	}
+	return true;
+}
+
+}  // namespace whamd

@@ -1,0 +1,142 @@
+// slots.h -- "slot runs": the register-resident forward path of a single individual (T = 1), kernels_slots.h.
+//
+// The projection column of a run never leaves the register file.  Every read that is active somewhere in the run owns
+// one *slot* = one bit of a PHYSICAL cell index P = (workgroup << L) | (wave << (6 + LR)) | (lane << LR) | reg:
+//
+//     reg slots   (LR bits)  the R = 2^LR cells a thread keeps in registers differ in these reads
+//     lane slots  (6 bits)   the 64 lanes of a wavefront
+//     wave slots  (LW bits)  the waves of the workgroup
+//     grid slots  (g bits)   the workgroups of the launch (reads that stay active through the whole run)
+//
+// A column adds cost(x) to every cell (closed form, DESIGN.md section 2: min3(Cp + S, Cm - S, Cc) with S the sum of the
+// deltas of the set bits); a read that ENDS is minimised out by combining the two cells that differ in its slot --
+// in registers (reg slot), with one cross-lane move (lane slot) or through a small LDS exchange (wave slot) -- after
+// which both cells hold the minimum: the slot is *free* (its two halves are duplicates) until a read that STARTS takes
+// it over.  Nothing is compacted or re-indexed between columns, so a column without an ending read costs no
+// communication at all, and a column with one costs no workgroup barrier unless the read sits in a wave slot.
+// Grid-slot reads cannot be minimised inside a launch: the run ends before the first of them does, the column goes
+// through HBM in the NEXT run's physical order (the writer scatters, the reader loads contiguously) and the next run
+// picks new grid reads.  (The LDS-resident runs of resident.h re-index the slice at every ending read: one LDS round
+// trip and one workgroup barrier per column step, which is what bounded them at ~13 % of the VALU issue rate.)
+//
+// Tie-breaking (src/pedigreedptable.cpp:306-327): of two cells that differ in ending read h the one whose
+// h-bit equals the parity of the bits of reads logically ABOVE h wins a tie.  Every cell stores one decision bit per
+// ending read: the side-0 cell of a pair the pair's decision, the side-1 cell the decision of the pair's MIRROR IMAGE
+// (all bits complemented) -- a halved run (complement symmetry, D[~x] = D[x]) computes only the workgroups whose top
+// grid-slot bit is 0, and the backtrace reads the mirror decisions where the path runs through the other half.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "problem.h"
+#include "resident.h"
+
+namespace whamd {
+
+constexpr int SLOT_LR = 3;           // reg slots (8 cells per thread)
+constexpr int SLOT_LANE = 6;         // lane slots
+constexpr int SLOT_LWMAX = 3;        // wave slots (at most 8 waves per workgroup)
+constexpr int SLOT_GMAX = 12;        // grid slots
+constexpr int SLOT_MAXSLOTS = 26;    // local + grid slots of one run (device limit: 25 reads per column)
+constexpr int SLOT_MAXCOLS = 64;     // columns per run: lane c of every wave prepares column c in the prologue
+constexpr int SLOT_MAXEND = 3;       // reads that may end in one column of a run
+constexpr int SLOT_MAXENDS_RUN = 96; // ending reads per run (one record byte per thread each)
+constexpr int32_t SLOT_DELTA_LIMIT = 1 << 22;  // |delta| of every read in a run (24-bit multiply-add of the lane part)
+
+// Per-column descriptor of a run, 64 dwords.  The first 32 ("hot") are fetched by every wave with scalar loads once per
+// column; the rest ("cold") is read in the prologue only (lane c of a wave reads column c).
+struct SlotRow {
+	// ---- hot (18 dwords, no gaps: the kernel loads them as 8 + 4 + 4 + 2 dwords into SGPRs one column ahead; a dword that
+	// is loaded but never read lets the register allocator reuse its SGPR while the load is in flight, which forces a wait)
+	uint32_t K;                      // Cp + Cm (mod 2^32; an absent term is RES_ABSENT, resident.h)
+	uint32_t Cc;                     // constant term (INF if none)
+	uint32_t n_end;                  // reads ending in this column (<= SLOT_MAXEND)
+	int32_t dreg[SLOT_LR];           // deltas of the reg slots
+	int32_t dlane[SLOT_LANE];        // deltas of the lane slots
+	struct End {
+		uint32_t info;               // slot | qmask << 8 | mflip << 24 (qmask bit r: reg-slot part of the tie-break parity of cell r,
+		                             //  including (side & mflip) when the ending read itself sits in a reg slot)
+		uint32_t M;                  // physical index bits of the reads logically above the ending read
+	} end[SLOT_MAXEND];              // ascending logical position
+	uint32_t pad2[14];
+	// ---- cold (128-byte aligned: lane c fetches its column with wide loads)
+	int32_t dslot[SLOT_MAXSLOTS];    // delta of every slot at this column (0: free slot, BLANK entry)
+	uint32_t Cp;
+	uint32_t pad3[5];
+};
+static_assert(SLOT_LR == 3 && SLOT_LANE == 6 && SLOT_MAXEND == 3, "hot layout of SlotRow: 3 + 3 + 6 + 6 dwords");
+static_assert(sizeof(SlotRow) == 256, "SlotRow must stay 64 dwords");
+
+// One run, passed to the kernel by value.
+struct SlotRun {
+	uint32_t c0, ncols, g, L;        // L = SLOT_LR + 6 + lw local slots
+	uint32_t lw, half, has_prev, row_off;   // half: launch 2^(g-1) workgroups (top grid slot = 0); row_off: first SlotRow of the run
+	uint32_t n_ends, rec_lo, rec_hi, threads;  // record: [workgroup][ending read][thread] bytes at this offset of the arena
+	uint32_t in_occ, in_identity, in_half, in_mirror_pos;  // entry: occupied slots; 1: entry index == P & in_occ; the entering column was
+	                                 // written by a halved run: entries whose bit in_mirror_pos is set are read at index ^ in_fullmask
+	uint32_t in_fullmask, out_occ, mirror_out, out_fullmask;  // exit: occupied slots; 1: also store the mirror image (index ^ out_fullmask)
+	uint32_t kind, pad[3];
+	uint32_t in_pos[8];              // entry index bit of every occupied slot, one byte each (when !in_identity)
+	uint32_t out_pos[8];             // exit index bit of every occupied slot, one byte each
+	// (words, not byte arrays: the kernel reads them with static indices out of SGPRs; see slot_pos / slot_set_pos)
+};
+inline uint32_t slot_pos(const uint32_t (&w)[8], uint32_t s) { return (w[s >> 2] >> ((s & 3u) * 8u)) & 255u; }
+inline void slot_set_pos(uint32_t (&w)[8], uint32_t s, uint32_t pos) {
+	w[s >> 2] = (w[s >> 2] & ~(255u << ((s & 3u) * 8u))) | (pos << ((s & 3u) * 8u));
+}
+static_assert(sizeof(SlotRun) == 160, "SlotRun layout");
+
+struct SlotBatchEntry {
+	SlotRun run;
+	const uint32_t* prev;
+	uint32_t* cur;
+	uint32_t* score_out;             // non-null: the run ends a connected component, its single exit value goes here
+	uint64_t pad;
+};
+static_assert(sizeof(SlotBatchEntry) % 16 == 0, "entries are fetched with wide scalar loads");
+
+// Backtrace side of a run's column: which slot holds the read of every logical bit, and how many ending reads of the
+// run lie in earlier columns (the path's state at this column = the state after undoing every later ending read).
+struct SlotBtCol {
+	uint8_t k, kf, pad[2];
+	uint8_t slot[28];                // [k] slot of the read at logical position j
+};
+static_assert(sizeof(SlotBtCol) == 32, "SlotBtCol must stay 8 dwords");
+
+// Header of a slot run in the backtrace unit list (same 128 bytes as BtUnit, kind == 2).
+struct SlotBtUnit {
+	uint32_t kind, c0, ncols, blob_off;    // blob_off: word offset of the run's backtrace blob ([ncols] SlotBtCol, then the local
+	                                       // slot of every ending read in forward order, one byte each, padded to a word)
+	uint32_t g, L, n_ends, threads;
+	uint32_t bt_lo, bt_hi, half, blob_words;
+	uint32_t f_exit, pad0[3];
+	uint8_t exit_slot[32];                 // [f_exit] slot of the read at bit j of the logical exit index
+	uint32_t pad1[8];
+};
+static_assert(sizeof(SlotBtUnit) == 128, "SlotBtUnit must stay 32 words");
+
+struct SlotPlan {
+	std::vector<Step> steps;                 // kind 0: per-column step (index = column), kind 2: slot run (index into runs)
+	std::vector<SlotRun> runs;
+	std::vector<SlotRow> rows;
+	std::vector<SlotBtCol> bt_cols;          // parallel to rows
+	std::vector<uint8_t> end_slots;          // per run (end_off): local slot of every ending read, forward order
+	std::vector<uint32_t> end_off;           // per run: first byte in end_slots
+	std::vector<uint32_t> f_exit;            // per run: bits of the logical exit index
+	std::vector<std::vector<uint8_t>> exit_slot;  // per run: slot of the read at bit j of the logical exit index
+	std::vector<int32_t> col_to_row;         // [n_cols] index into rows or -1
+	std::vector<uint32_t> component_first_step;
+	uint64_t n_run_columns = 0;
+};
+
+// Plans the forward pass of a single-individual table with slot runs wherever they apply (per-column steps elsewhere).
+// Returns false if the table is not eligible (pedigree, values beyond 2^30): the caller uses plan_forward().
+// use_symmetry: 0 never halve, >= 1 halve every run whose columns are symmetric and that has a grid slot.
+bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan& plan);
+
+// Host-only diagnostic (slot_emulate.cpp): executes `plan` cell by cell the way the kernels do.  For planner tests on
+// small inputs; never part of a solve.
+bool emulate_slot_plan(const Problem& p, const SlotPlan& plan, std::vector<uint32_t>& path_index, uint32_t& score, std::string& msg);
+
+}  // namespace whamd
