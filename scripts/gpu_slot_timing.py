@@ -1,0 +1,42 @@
+"""Forward / backtrace timings of the slot-run path with parts of the kernel switched off (WHAMD_SLOT_SKIP: results
+invalid, timings only), next to the LDS-resident path.  Usage: python scripts/gpu_slot_timing.py [variants] [coverage]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from whatshap_amd import _native
+from whatshap_amd.synthetic import synthetic_block
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 60000
+cov = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+p = synthetic_block(n, cov, seed=3)
+
+
+def run(label, path=None, skip=None, options=()):
+    if skip is None:
+        os.environ.pop("WHAMD_SLOT_SKIP", None)
+    else:
+        os.environ["WHAMD_SLOT_SKIP"] = str(skip)
+    t = _native.NativeTable(p, solve=False, path=path)
+    for k, v in options:
+        t.set_option(k, v)
+    best = None
+    for _ in range(3):
+        t.solve()
+        s = t.stats()
+        if best is None or s["forward_ms"] < best["forward_ms"]:
+            best = s
+    runs = best["forward_launches"]
+    print(f"{label:44s} forward {best['forward_ms']:8.2f} ms  backtrace {best['backtrace_ms']:7.2f} ms  launches {runs:6d}  "
+          f"{best['forward_ms'] * 1e3 / max(runs, 1):6.2f} us/launch  {n / (best['forward_ms'] + best['backtrace_ms']) / 1e3:7.3f} M col/s (device)", flush=True)
+    t.close()
+
+
+run("slots")
+run("slots, no exit stores (1)", skip=1)
+run("slots, no records (2)", skip=2)
+run("slots, no stores at all (3)", skip=3)
+run("slots, one column per run (4)", skip=4)
+run("slots, one column, no stores (7)", skip=7)
+for l in ("9", "10", "12"):
+    run(f"slots, slot_l={l}", options=(("slot_l", l),))
+run("slots, symmetry off", options=(("symmetry", "0"),))
+run("resident (LDS runs)", path="resident")

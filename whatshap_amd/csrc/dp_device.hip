@@ -631,6 +631,8 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		m.dp.dbg_wg_off = (uint32_t)((m.plan.segments.size() + 1) * 8);
 		m.dp.dbg_flags = (uint32_t)atoi(getenv("WHAMD_DEBUG_TIMING"));
 	}
+	if (const char* skip = getenv("WHAMD_SLOT_SKIP")) m.dp.dbg_flags = (uint32_t)atoi(skip);  // timing experiments (results invalid): 1 no exit
+	                                                                                          // stores, 2 no records, 4 one column per run
 	m.dp.n_cols = n;
 	m.dp.T = p.T;
 	m.dp.tbits = tbits;

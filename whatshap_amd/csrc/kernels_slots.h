@@ -49,6 +49,7 @@ __device__ __forceinline__ uint32_t slot_end_partner(uint32_t (&D)[1 << LR], con
 
 // Wave-uniform data is read through the scalar cache: loads from the constant address space become s_load_dwordx8
 // (kernel arguments are the same kind of memory).  A generic pointer converts bit for bit.
+constexpr int SLOT_HOT = 18;   // hot dwords of a SlotRow
 typedef uint32_t slot_u32x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t slot_u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t slot_u32x2 __attribute__((ext_vector_type(2)));
@@ -82,13 +83,23 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 	const SlotRow* __restrict__ rows = P.slot_rows + run.row_off;
 	const uint32_t ncols = run.ncols;
 
-	// ---- prologue: one batch of loads.  (0) the hot words of column 0 (scalar cache)
-	SlotHot hn = slot_load_hot(rows);
-	// (1) lane c of every wave fetches the cold part of column c and prepares A = Cp + (deltas of the set grid / wave slots)
+	// ---- prologue: one batch of loads.  (1) lane c of every wave fetches column c: its hot words stay in that lane's
+	// registers for the whole run (the column loop broadcasts them with v_readlane: no memory access, no scalar-cache
+	// miss on the sequential chain), the cold part becomes A = Cp + (deltas of the set grid / wave slots)
 	uint32_t Avec = 0;
+	uint32_t hotv[SLOT_HOT];
 	{
 		const uint32_t cl = lane < ncols ? lane : 0u;
 		const SlotRow* __restrict__ rr = rows + cl;
+		const uint4* __restrict__ hq = reinterpret_cast<const uint4*>(rr);
+#pragma unroll
+		for (int q = 0; q < (SLOT_HOT + 3) / 4; ++q) {
+			const uint4 t = hq[q];
+			hotv[4 * q] = t.x;
+			if (4 * q + 1 < SLOT_HOT) hotv[4 * q + 1] = t.y;
+			if (4 * q + 2 < SLOT_HOT) hotv[4 * q + 2] = t.z;
+			if (4 * q + 3 < SLOT_HOT) hotv[4 * q + 3] = t.w;
+		}
 		const uint32_t Pu = (w << L) | (wave << (6 + LR));   // the wave-uniform part of the physical index
 		uint32_t acc = rr->Cp;
 #pragma unroll
@@ -144,19 +155,13 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 	const uint32_t xwords = threads * R;   // one exchange buffer
 	uint32_t xsel = 0;
 
-	for (uint32_t ci = 0; ci < ncols; ++ci) {
-		// this column's hot words are in SGPRs; fetch the next column's now (one scalar-cache latency, hidden by the column)
-		const SlotHot h = hn;
-		hn = slot_load_hot(rows + (ci + 1u < ncols ? ci + 1u : ci));
-		const uint32_t K = h.a[0], Cc = h.a[1], n_end = h.a[2];
+	for (uint32_t ci = 0; ci < ((P.dbg_flags & 4u) ? 1u : ncols); ++ci) {
+		auto hot = [&](int i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)hotv[i], (int)ci); };
+		const uint32_t K = hot(0), Cc = hot(1), n_end = hot(2);
 		uint32_t A = (uint32_t)__builtin_amdgcn_readlane((int)Avec, (int)ci);
-		A += (uint32_t)__mul24(lanebit[0], (int32_t)h.a[6]);
-		A += (uint32_t)__mul24(lanebit[1], (int32_t)h.a[7]);
-		A += (uint32_t)__mul24(lanebit[2], (int32_t)h.b[0]);
-		A += (uint32_t)__mul24(lanebit[3], (int32_t)h.b[1]);
-		A += (uint32_t)__mul24(lanebit[4], (int32_t)h.b[2]);
-		A += (uint32_t)__mul24(lanebit[5], (int32_t)h.b[3]);
-		const uint32_t dr[3] = {h.a[3], h.a[4], h.a[5]};
+#pragma unroll
+		for (int j = 0; j < SLOT_LANE; ++j) A += (uint32_t)__mul24(lanebit[j], (int32_t)hot(6 + j));
+		const uint32_t dr[3] = {hot(3), hot(4), hot(5)};
 #pragma unroll
 		for (int r = 0; r < R; ++r) {
 			uint32_t pat = 0;
@@ -165,7 +170,7 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 			D[r] += slot_cost(A + pat, K, Cc);
 		}
 		for (uint32_t q = 0; q < n_end; ++q) {
-			const uint32_t info = q == 0 ? h.c[0] : (q == 1 ? h.c[2] : h.d[0]), M = q == 0 ? h.c[1] : (q == 1 ? h.c[3] : h.d[1]);
+			const uint32_t info = q == 0 ? hot(12) : (q == 1 ? hot(14) : hot(16)), M = q == 0 ? hot(13) : (q == 1 ? hot(15) : hot(17));
 			const uint32_t slot = info & 255u, qmask = (info >> 8) & 0xFFFFu, mflip = (info >> 24) & 1u;
 			uint32_t qthr = (uint32_t)__popc(Pthr & M) & 1u;
 			if (slot >= (uint32_t)LR) qthr ^= ((Pthr >> slot) & 1u) & mflip;
@@ -200,7 +205,7 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 				takes = slot_end_partner<LR>(D, other, qthr, qmask);
 				xsel ^= 1u;
 			}
-			*rec = (uint8_t)takes;
+			if (!(P.dbg_flags & 2u)) *rec = (uint8_t)takes;
 			rec += threads;
 		}
 	}
@@ -228,7 +233,7 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 					writes = writes && ((occ >> s) & 1u);
 				}
 			}
-			if (writes) {
+			if (writes && !(P.dbg_flags & 1u)) {
 				const uint32_t idx = base | x;
 				cur[idx] = D[r];
 				if (run.mirror_out) cur[idx ^ mirror_x] = D[r];

@@ -51,7 +51,6 @@ bool emulate_slot_plan(const Problem& p, const SlotPlan& plan, std::vector<uint3
 	std::vector<std::vector<uint8_t>> records(plan.runs.size());
 	uint32_t last_x = 0;
 	uint32_t total = 0;
-	std::vector<uint32_t> comp_scores;
 	for (size_t si = 0; si < plan.steps.size(); ++si) {
 		const Step& st = plan.steps[si];
 		if (st.kind == 0) {
@@ -62,7 +61,7 @@ bool emulate_slot_plan(const Problem& p, const SlotPlan& plan, std::vector<uint3
 			std::vector<uint32_t> best_rank((size_t)1 << f, 0xFFFFFFFFu);
 			uint32_t opt = INF, opt_rank = 0xFFFFFFFFu;
 			for (uint32_t x = 0; x < (1u << k); ++x) {
-				const uint32_t prev = b == 0 ? 0u : pr[x & ((1u << b) - 1u)];   // a component / the table starts from cost 0
+				const uint32_t prev = c == 0 ? 0u : pr[x & ((1u << b) - 1u)];   // b == 0: the single value the previous component projected onto
 				const uint32_t D = cell_cost(p, c, x) + prev;
 				const uint32_t rank = gray_rank_host(x);
 				if (is_last) {
@@ -74,7 +73,6 @@ bool emulate_slot_plan(const Problem& p, const SlotPlan& plan, std::vector<uint3
 				if (D < nx[y] || (D == nx[y] && rank < best_rank[y])) { nx[y] = D; best_rank[y] = rank; col_arg[c][y] = x; }
 			}
 			if (is_last) total = opt;
-			else if (f == 0) comp_scores.push_back(nx[0]);
 			pr.swap(nx);
 			continue;
 		}
@@ -83,8 +81,7 @@ bool emulate_slot_plan(const Problem& p, const SlotPlan& plan, std::vector<uint3
 		const uint32_t ncell = nwg << L;
 		std::vector<uint32_t> D(ncell, 0), D2(ncell);
 		records[st.index].assign((size_t)nwg * run.n_ends * threads, 0);
-		const bool has_prev = run.has_prev && p.b[run.c0] > 0;
-		if (has_prev) {
+		if (run.has_prev) {
 			for (uint32_t P = 0; P < ncell; ++P) {
 				uint32_t idx = 0;
 				if (run.in_identity) idx = P & run.in_occ;
@@ -134,12 +131,11 @@ bool emulate_slot_plan(const Problem& p, const SlotPlan& plan, std::vector<uint3
 			nx[idx] = D[P];
 			if (run.mirror_out) nx[idx ^ run.out_fullmask] = D[P];
 		}
-		if (plan.f_exit[st.index] == 0) comp_scores.push_back(D[0]);
 		pr.swap(nx);
 	}
 	score = total;
-	// every component but the last contributes the single value its last column projects onto
-	for (uint32_t v : comp_scores) score += v;
+	// (one job: the value a connected component projects onto is carried into the next component's cells, so the last
+	// column's optimum is the total -- the device splits components into jobs and adds their scores on the host instead)
 	// ---- backtrace (kernels_backtrace.h): newest step first
 	uint32_t x = last_x;
 	for (size_t si = plan.steps.size(); si-- > 0;) {

@@ -214,7 +214,7 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 		run.n_ends = 0;
 		for (size_t i = rows_mark; i < plan.rows.size(); ++i) run.n_ends += plan.rows[i].n_end;
 		run.threads = 64u << d.lw;
-		run.has_prev = b0 > 0;
+		run.has_prev = c > 0;   // a run that starts a connected component reads the single value the previous one projected onto
 		run.half = (use_symmetry > 0 && symmetric && g >= 1) ? 1u : 0u;
 		for (uint32_t s = 0; s < nslots; ++s) {
 			if (d.entry_read[s] >= 0) run.in_occ |= 1u << s;
