@@ -195,7 +195,8 @@ whamd_status_t whamd_dptable_get_stats(const whamd_dptable* table, whamd_solve_s
 /* Options (for A/B measurements and tests), effective at the next solve:
  *   "path"          "auto" (default: slot runs for a single individual, LDS-resident runs for a trio) | "slots" | "resident" |
  *                   "column" (one launch per column, the general path) | "column_keys"
- *   "slot_l"        preferred number of local slots of a slot run (9 .. 12: 1 .. 8 waves per workgroup)
+ *   "slot_l"        preferred number of local slots of a slot run (slot_r + 6 .. slot_r + 9: 1 .. 8 waves per workgroup)
+ *   "slot_r"        reg slots of a slot run: "2" (4 cells per thread, default) or "3" (8 cells per thread)
  *   "resident_l"    preferred log2 slice size of the run kernels
  *   "resident_fold" "0" disables folding of columns without an ending read
  *   "symmetry"      single individual: D[~x] == D[x], so a run may compute half of its workgroups only: "0" never,
@@ -231,7 +232,7 @@ whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uin
                                     whamd_plan_summary* out);
 
 /* Host-only diagnostic of the slot-run planner (no device needed, small inputs only): builds the forward plan of a
- * single-individual table exactly as whamd_dptable_create would (slot_l local slots preferred, symmetry level) and
+ * single-individual table exactly as whamd_dptable_create would (slot_l local slots preferred -- add 100 for 8 instead of 4 cells per thread --, symmetry level) and
  * executes it cell by cell on the CPU the way the kernels do -- same physical cell indices, decision bits, record
  * layout, exchange layouts and mirror rules.  index_out[n_columns]: the index path (index_path[c].index,
  * src/pedigreedptable.h:17-21), score_out: the optimal score.  Lets the CPU test-suite check the PLAN against the

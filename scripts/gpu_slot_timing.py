@@ -36,7 +36,8 @@ run("slots, no records (2)", skip=2)
 run("slots, no stores at all (3)", skip=3)
 run("slots, one column per run (4)", skip=4)
 run("slots, one column, no stores (7)", skip=7)
-for l in ("9", "10", "12"):
-    run(f"slots, slot_l={l}", options=(("slot_l", l),))
+for r, l in (("2", "10"), ("2", "9"), ("3", "11"), ("3", "12"), ("3", "10")):
+    run(f"slots, slot_r={r} slot_l={l}", options=(("slot_r", r), ("slot_l", l)))
+run("slots, slot_r=3 one column (4)", skip=4, options=(("slot_r", "3"),))
 run("slots, symmetry off", options=(("symmetry", "0"),))
 run("resident (LDS runs)", path="resident")

@@ -260,6 +260,11 @@ whamd_status_t whamd_dptable_set_option(whamd_dptable* t, const char* key, const
 		t->uploaded = false;
 		return WHAMD_OK;
 	}
+	if (k == "slot_r") {
+		t->device.set_slot_lr(std::atoi(value));
+		t->uploaded = false;
+		return WHAMD_OK;
+	}
 	return fail(WHAMD_ERR_INVALID, "unknown option '" + k + "'");
 }
 
@@ -295,7 +300,7 @@ whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uin
 			const SlotRun& run = sp.runs[step.index];
 			expect = c0 + run.ncols;
 			ok = ok && step.kind == 2 && run.ncols >= 2 && run.ncols <= (uint32_t)SLOT_MAXCOLS && run.g <= (uint32_t)SLOT_GMAX;
-			ok = ok && run.L == (uint32_t)(SLOT_LR + SLOT_LANE) + run.lw && run.lw <= (uint32_t)SLOT_LWMAX && run.threads == (64u << run.lw);
+			ok = ok && run.lr >= 2 && run.lr <= (uint32_t)SLOT_LR && run.L == run.lr + (uint32_t)SLOT_LANE + run.lw && run.lw <= (uint32_t)SLOT_LWMAX && run.threads == (64u << run.lw);
 			ok = ok && run.L + run.g <= (uint32_t)SLOT_MAXSLOTS && run.n_ends <= (uint32_t)SLOT_MAXENDS_RUN && (!run.half || run.g >= 1);
 			uint32_t ends = 0;
 			for (uint32_t i = 0; i < run.ncols && ok; ++i) {
@@ -317,7 +322,7 @@ whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uin
 			ok = ok && ends == run.n_ends;
 			s.max_run_columns = std::max<uint64_t>(s.max_run_columns, run.ncols);
 			s.max_workgroups = std::max<uint64_t>(s.max_workgroups, 1ull << (run.g - run.half));
-			s.max_lds_bytes = std::max<uint64_t>(s.max_lds_bytes, 2ull * run.threads * (1u << SLOT_LR) * 4);
+			s.max_lds_bytes = std::max<uint64_t>(s.max_lds_bytes, 2ull * run.threads * (1u << run.lr) * 4);
 			if (run.half) s.n_halved_runs++;
 			s.n_resident_columns += run.ncols;
 			s.n_vectorised_columns += run.ncols;
@@ -402,13 +407,15 @@ whamd_status_t whamd_debug_emulate_slot_plan(const whamd_readset_view* readset, 
                                             const whamd_pedigree_view* pedigree, int distrust_genotypes, const uint32_t* positions,
                                             size_t n_positions, int slot_l, int symmetry, uint32_t* index_out, uint32_t* score_out,
                                             uint64_t* n_run_columns_out) {
+	const int lr = slot_l >= 100 ? 3 : 2;   // slot_l + 100: 8 cells per thread
+	if (slot_l >= 100) slot_l -= 100;
 	Problem p;
 	std::string msg;
 	whamd_status_t st = build_problem(readset, recombcost, n_recombcost, pedigree, distrust_genotypes != 0, positions,
 	                                  n_positions, p, msg);
 	if (st != WHAMD_OK) return fail(st, msg);
 	SlotPlan sp;
-	if (!plan_forward_slots(p, slot_l, symmetry, sp)) return fail(WHAMD_ERR_UNSUPPORTED, "slot runs apply to a single individual only");
+	if (!plan_forward_slots(p, slot_l, symmetry, sp, lr)) return fail(WHAMD_ERR_UNSUPPORTED, "slot runs apply to a single individual only");
 	std::vector<uint32_t> path;
 	uint32_t score = 0;
 	if (!emulate_slot_plan(p, sp, path, score, msg)) return fail(WHAMD_ERR_INVALID, "slot plan inconsistent: " + msg);

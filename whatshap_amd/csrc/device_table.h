@@ -36,6 +36,8 @@ public:
 	void set_l_pref(int l);
 	// Preferred number of local slots of a slot run (9 .. 12: 1 .. 8 waves per workgroup); next upload().
 	void set_slot_l(int l);
+	// Reg slots of a slot run: 2 (4 cells per thread, default) or 3 (8 cells per thread); next upload().
+	void set_slot_lr(int lr);
 	// Fold columns in which no read ends into the next resident column (default on); next upload().
 	void set_fold(bool v);
 	// Exploit D[~x] == D[x] in single-individual runs: 0 off, 1 full-chip runs (default), 2 every run; next upload().

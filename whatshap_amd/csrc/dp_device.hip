@@ -136,7 +136,8 @@ struct DeviceTable::Impl {
 	// slot runs (slots.h): the default forward path of a single individual
 	SlotPlan splan;
 	bool use_slots = false;
-	int slot_l = 11;            // preferred number of local slots (9 .. 12)
+	int slot_l = 11;            // preferred number of local slots (lr + 6 .. lr + 9)
+	int slot_lr = 2;            // reg slots: 4 cells per thread -> 8 waves per workgroup at 11 local slots (two waves per SIMD)
 	std::vector<SlotBatchEntry> slot_entries;
 	SlotBatchEntry* d_slot_entries = nullptr;
 	BtJob* d_btjobs = nullptr;
@@ -227,7 +228,8 @@ void DeviceTable::set_l_pref(int l) { impl_->l_pref = std::max(4, std::min(l, RE
 void DeviceTable::set_lanes(int n) { impl_->max_lanes = n < 1 ? 1 : (n > 64 ? 64 : n); }
 
 void DeviceTable::set_fold(bool v) { impl_->fold = v; }
-void DeviceTable::set_slot_l(int l) { impl_->slot_l = std::max(9, std::min(l, 12)); }
+void DeviceTable::set_slot_l(int l) { impl_->slot_l = std::max(8, std::min(l, 12)); }
+void DeviceTable::set_slot_lr(int lr) { impl_->slot_lr = lr >= 3 ? 3 : 2; }
 
 void DeviceTable::set_symmetry(int level) { impl_->symmetry = level < 0 ? 0 : (level > 2 ? 2 : level); }
 
@@ -261,7 +263,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	const bool force_keys = m.path == "column_keys";
 	const bool want_resident = m.path == "auto" || m.path == "resident";
 	const auto tu0 = std::chrono::steady_clock::now();
-	m.use_slots = (m.path == "auto" || m.path == "slots") && plan_forward_slots(p, m.slot_l, m.symmetry, m.splan);
+	m.use_slots = (m.path == "auto" || m.path == "slots") && plan_forward_slots(p, m.slot_l, m.symmetry, m.splan, m.slot_lr);
 	if (m.use_slots) {
 		// the driver below walks plan.steps / plan.component_first_step; slot runs are steps of kind 2
 		m.plan = ResidentPlan();
@@ -472,6 +474,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 				su.g = run.g; su.L = run.L; su.n_ends = run.n_ends; su.threads = run.threads;
 				su.bt_lo = run.rec_lo; su.bt_hi = run.rec_hi; su.half = run.half; su.blob_words = slot_blob_words[st.index];
 				su.f_exit = m.splan.f_exit[st.index];
+				su.lr = run.lr;
 				for (uint32_t j = 0; j < su.f_exit && j < 32; ++j) su.exit_slot[j] = m.splan.exit_slot[st.index][j];
 				static_assert(sizeof(SlotBtUnit) == sizeof(BtUnit), "unit headers share one array");
 				std::memcpy(&u, &su, sizeof u);
@@ -562,7 +565,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 					e.prev = lane.d_pr[c.flip];
 					e.cur = lane.d_pr[c.flip ^ 1];
 					e.score_out = (last && !job.final) ? m.d_job_scores + job_id : nullptr;
-					ss.lds = std::max<size_t>(ss.lds, (size_t)2 * e.run.threads * (1u << SLOT_LR) * 4);
+					ss.lds = std::max<size_t>(ss.lds, (size_t)2 * e.run.threads * (1u << e.run.lr) * 4);
 					ss.grid_x = std::max(ss.grid_x, 1u << (e.run.g - e.run.half));
 					ss.threads = std::max(ss.threads, e.run.threads);
 					m.slot_entries.push_back(e);
@@ -711,8 +714,10 @@ void DeviceTable::Impl::launch_run(const ResBatchEntry& e, uint32_t step_index, 
 void DeviceTable::Impl::launch_slot_run(const SlotBatchEntry& e, uint64_t& launches) {
 	Impl& m = *this;
 	const SlotRun& run = e.run;
-	const size_t lds = (size_t)2 * run.threads * (1u << SLOT_LR) * 4;
-	hipLaunchKernelGGL(slot_run<SLOT_LR>, dim3(1u << (run.g - run.half)), dim3(run.threads), lds, m.stream, m.dp, run, e.prev, e.cur, e.score_out);
+	const size_t lds = (size_t)2 * run.threads * (1u << run.lr) * 4;
+	const dim3 grid(1u << (run.g - run.half)), block(run.threads);
+	if (run.lr == 3) hipLaunchKernelGGL(slot_run<3>, grid, block, lds, m.stream, m.dp, run, e.prev, e.cur, e.score_out);
+	else hipLaunchKernelGGL(slot_run<2>, grid, block, lds, m.stream, m.dp, run, e.prev, e.cur, e.score_out);
 	launches += 1;
 }
 
@@ -772,7 +777,8 @@ whamd_status_t DeviceTable::enqueue_some_unguarded(const Problem& p, Solution& s
 		if (m.use_slots) {
 			if (ss.entry_count == 1) m.launch_slot_run(m.slot_entries[ss.entry_off], launches);
 			else if (ss.entry_count > 1) {
-				hipLaunchKernelGGL(slot_batch<SLOT_LR>, dim3(ss.grid_x, ss.entry_count), dim3(ss.threads), ss.lds, m.stream, m.dp, m.d_slot_entries + ss.entry_off);
+				if (m.slot_lr == 3) hipLaunchKernelGGL(slot_batch<3>, dim3(ss.grid_x, ss.entry_count), dim3(ss.threads), ss.lds, m.stream, m.dp, m.d_slot_entries + ss.entry_off);
+				else hipLaunchKernelGGL(slot_batch<2>, dim3(ss.grid_x, ss.entry_count), dim3(ss.threads), ss.lds, m.stream, m.dp, m.d_slot_entries + ss.entry_off);
 				launches += 1;
 			}
 		} else if (ss.entry_count == 1) {

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 		const unsigned long long tb1 = P.dbg ? __builtin_readcyclecounter() : 0ull;
 		if (kind == 2) {
 			if (lane < 64) {   // one wave follows the path
-				const uint32_t g = h[4], L = h[5], n_ends = h[6], threads = h[7];
+				const uint32_t g = h[4], L = h[5], n_ends = h[6], threads = h[7], lr = h[13];
 				(void)g;
 				const SlotBtCol* bcols = reinterpret_cast<const SlotBtCol*>(recs);
 				const uint8_t* ends = reinterpret_cast<const uint8_t*>(recs + ncols * 8);
@@ -190,8 +190,8 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 				for (uint32_t k = n_ends; k-- > 0;) {
 					const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)(k < 64u ? e_lo : e_hi), (int)(k & 63u));
 					const uint32_t look = slot_mirrored ? ((~l & lmask) | (1u << j)) : (l & ~(1u << j));
-					const uint32_t byte = stage8[k * threads + (look >> SLOT_LR)];
-					const uint32_t bit = (byte >> (look & ((1u << SLOT_LR) - 1u))) & 1u;
+					const uint32_t byte = stage8[k * threads + (look >> lr)];
+					const uint32_t bit = (byte >> (look & ((1u << lr) - 1u))) & 1u;
 					l = (l & ~(1u << j)) | (bit << j);
 					if (lane == 0) cells[k] = l;
 				}

@@ -49,7 +49,6 @@ __device__ __forceinline__ uint32_t slot_end_partner(uint32_t (&D)[1 << LR], con
 
 // Wave-uniform data is read through the scalar cache: loads from the constant address space become s_load_dwordx8
 // (kernel arguments are the same kind of memory).  A generic pointer converts bit for bit.
-constexpr int SLOT_HOT = 18;   // hot dwords of a SlotRow
 typedef uint32_t slot_u32x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t slot_u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t slot_u32x2 __attribute__((ext_vector_type(2)));
@@ -161,7 +160,9 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 		uint32_t A = (uint32_t)__builtin_amdgcn_readlane((int)Avec, (int)ci);
 #pragma unroll
 		for (int j = 0; j < SLOT_LANE; ++j) A += (uint32_t)__mul24(lanebit[j], (int32_t)hot(6 + j));
-		const uint32_t dr[3] = {hot(3), hot(4), hot(5)};
+		uint32_t dr[LR];
+#pragma unroll
+		for (int s = 0; s < LR; ++s) dr[s] = hot(3 + s);
 #pragma unroll
 		for (int r = 0; r < R; ++r) {
 			uint32_t pat = 0;

@@ -45,7 +45,6 @@ bool emulate_slot_plan(const Problem& p, const SlotPlan& plan, std::vector<uint3
 	path_index.assign(n, 0);
 	score = 0;
 	if (n == 0) return true;
-	constexpr uint32_t R = 1u << SLOT_LR;
 	std::vector<uint32_t> pr, nx;                        // exchange buffers
 	std::vector<std::vector<uint32_t>> col_arg(n);        // per-column steps: argmin cell per projection entry
 	std::vector<std::vector<uint8_t>> records(plan.runs.size());
@@ -77,7 +76,7 @@ bool emulate_slot_plan(const Problem& p, const SlotPlan& plan, std::vector<uint3
 			continue;
 		}
 		const SlotRun& run = plan.runs[st.index];
-		const uint32_t L = run.L, nslots = L + run.g, nwg = 1u << (run.g - run.half), threads = run.threads;
+		const uint32_t L = run.L, nslots = L + run.g, nwg = 1u << (run.g - run.half), threads = run.threads, LRr = run.lr, R = 1u << LRr;
 		const uint32_t ncell = nwg << L;
 		std::vector<uint32_t> D(ncell, 0), D2(ncell);
 		records[st.index].assign((size_t)nwg * run.n_ends * threads, 0);
@@ -96,9 +95,9 @@ bool emulate_slot_plan(const Problem& p, const SlotPlan& plan, std::vector<uint3
 			const SlotRow& row = plan.rows[run.row_off + ci];
 			for (uint32_t P = 0; P < ncell; ++P) {
 				uint32_t A = row.Cp;
-				for (uint32_t s = SLOT_LR + SLOT_LANE; s < nslots; ++s) if (bit(P, s)) A += (uint32_t)row.dslot[s];
-				for (uint32_t s = 0; s < (uint32_t)SLOT_LANE; ++s) if (bit(P, SLOT_LR + s)) A += (uint32_t)row.dlane[s];
-				for (uint32_t s = 0; s < (uint32_t)SLOT_LR; ++s) if (bit(P, s)) A += (uint32_t)row.dreg[s];
+				for (uint32_t s = LRr + SLOT_LANE; s < nslots; ++s) if (bit(P, s)) A += (uint32_t)row.dslot[s];
+				for (uint32_t s = 0; s < (uint32_t)SLOT_LANE; ++s) if (bit(P, LRr + s)) A += (uint32_t)row.dlane[s];
+				for (uint32_t s = 0; s < LRr; ++s) if (bit(P, s)) A += (uint32_t)row.dreg[s];
 				D[P] += std::min(std::min(A, row.K - A), row.Cc);
 			}
 			for (uint32_t q = 0; q < row.n_end; ++q) {
@@ -108,10 +107,10 @@ bool emulate_slot_plan(const Problem& p, const SlotPlan& plan, std::vector<uint3
 				for (uint32_t P = 0; P < ncell; ++P) {
 					const uint32_t Pthr = P & ~(R - 1u), r = P & (R - 1u);
 					uint32_t qthr = (uint32_t)__builtin_popcount(Pthr & M) & 1u;
-					if (slot >= (uint32_t)SLOT_LR) qthr ^= bit(Pthr, slot) & mflip;
+					if (slot >= LRr) qthr ^= bit(Pthr, slot) & mflip;
 					const uint32_t qq = qthr ^ bit(qmask, r);
 					const uint32_t other = D[P ^ (1u << slot)];
-					const uint32_t w = P >> L, tid = (P & ((1u << L) - 1u)) >> SLOT_LR;
+					const uint32_t w = P >> L, tid = (P & ((1u << L) - 1u)) >> LRr;
 					if (other < D[P] + qq) records[st.index][((size_t)w * run.n_ends + k_end) * threads + tid] |= (uint8_t)(1u << r);
 					D2[P] = std::min(D[P], other);
 				}
@@ -149,7 +148,7 @@ bool emulate_slot_plan(const Problem& p, const SlotPlan& plan, std::vector<uint3
 			continue;
 		}
 		const SlotRun& run = plan.runs[st.index];
-		const uint32_t L = run.L, threads = run.threads;
+		const uint32_t L = run.L, threads = run.threads, LRr = run.lr, R = 1u << LRr;
 		const std::vector<uint8_t>& ex = plan.exit_slot[st.index];
 		uint32_t pexit = 0;
 		for (uint32_t j = 0; j < plan.f_exit[st.index]; ++j) pexit |= bit(x, j) << ex[j];
@@ -165,7 +164,7 @@ bool emulate_slot_plan(const Problem& p, const SlotPlan& plan, std::vector<uint3
 		for (uint32_t k = run.n_ends; k-- > 0;) {
 			const uint32_t j = ends[k];
 			const uint32_t look = mirrored ? ((~l & lmask) | (1u << j)) : (l & ~(1u << j));
-			const uint32_t byte = records[st.index][((size_t)wrec * run.n_ends + k) * threads + (look >> SLOT_LR)];
+			const uint32_t byte = records[st.index][((size_t)wrec * run.n_ends + k) * threads + (look >> LRr)];
 			const uint32_t b = (byte >> (look & (R - 1u))) & 1u;
 			l = (l & ~(1u << j)) | (b << j);
 			cells[k] = l;

@@ -27,12 +27,13 @@ inline uint32_t parity32(uint32_t v) { return (uint32_t)__builtin_popcount(v) & 
 
 }  // namespace
 
-bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan& plan) {
+bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan& plan, int lr) {
+	lr = std::max(2, std::min(lr, SLOT_LR));
 	plan = SlotPlan();
 	const uint32_t n = p.n_cols;
 	if (!(p.T == 1 && p.n_ind == 1 && p.value_bound < 1073741824.0)) return false;
 	plan.col_to_row.assign(n, -1);
-	const int LMIN = SLOT_LR + SLOT_LANE, LMAX = SLOT_LR + SLOT_LANE + SLOT_LWMAX;
+	const int LMIN = lr + SLOT_LANE, LMAX = lr + SLOT_LANE + SLOT_LWMAX;
 	l_pref = std::max(LMIN, std::min(l_pref, LMAX));
 	std::vector<uint32_t> last_col(p.n_reads, 0);
 	for (uint32_t c = 0; c < n; ++c) {
@@ -139,8 +140,8 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 				dsum += (uint32_t)dl[j];
 				bc_rec.slot[j] = (uint8_t)s;
 			}
-			for (int s = 0; s < SLOT_LR; ++s) row.dreg[s] = row.dslot[s];
-			for (int s = 0; s < SLOT_LANE; ++s) row.dlane[s] = row.dslot[SLOT_LR + s];
+			for (int s = 0; s < lr; ++s) row.dreg[s] = row.dslot[s];
+			for (int s = 0; s < SLOT_LANE; ++s) row.dlane[s] = row.dslot[lr + s];
 			{   // cost(~x) == cost(x)  <=>  Cp + (sum of all deltas) == Cm, or no orientation term at all
 				const bool both_absent = Cp == RES_ABSENT && Cm == RES_ABSENT;
 				if (!both_absent && (Cp == RES_ABSENT || Cm == RES_ABSENT || Cp + dsum != Cm)) symmetric = false;
@@ -155,9 +156,9 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 				for (uint32_t q = j + 1; q < kc; ++q) M |= 1u << slot_of[col[q].read_id];
 				const uint32_t mflip = parity32(M);
 				uint32_t qmask = 0;
-				for (uint32_t r = 0; r < (1u << SLOT_LR); ++r) {
+				for (uint32_t r = 0; r < (1u << lr); ++r) {
 					uint32_t bit = parity32(r & M);
-					if (s < SLOT_LR) bit ^= ((r >> s) & 1u) & mflip;
+					if (s < lr) bit ^= ((r >> s) & 1u) & mflip;
 					qmask |= bit << r;
 				}
 				row.end[en].info = (uint32_t)s | (qmask << 8) | (mflip << 24);
@@ -210,6 +211,7 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 		SlotRun run{};
 		run.c0 = c; run.ncols = d.ncols; run.g = g; run.L = L; run.lw = d.lw;
 		run.kind = 2;
+		run.lr = (uint32_t)lr;
 		run.row_off = (uint32_t)rows_mark;
 		run.n_ends = 0;
 		for (size_t i = rows_mark; i < plan.rows.size(); ++i) run.n_ends += plan.rows[i].n_end;

@@ -34,7 +34,7 @@
 
 namespace whamd {
 
-constexpr int SLOT_LR = 3;           // reg slots (8 cells per thread)
+constexpr int SLOT_LR = 3;           // most reg slots of a run (8 cells per thread); SlotRun::lr says how many a run uses (2 or 3)
 constexpr int SLOT_LANE = 6;         // lane slots
 constexpr int SLOT_LWMAX = 3;        // wave slots (at most 8 waves per workgroup)
 constexpr int SLOT_GMAX = 12;        // grid slots
@@ -66,17 +66,18 @@ struct SlotRow {
 	uint32_t pad3[5];
 };
 static_assert(SLOT_LR == 3 && SLOT_LANE == 6 && SLOT_MAXEND == 3, "hot layout of SlotRow: 3 + 3 + 6 + 6 dwords");
+constexpr int SLOT_HOT = 18;         // hot dwords of a SlotRow
 static_assert(sizeof(SlotRow) == 256, "SlotRow must stay 64 dwords");
 
 // One run, passed to the kernel by value.
 struct SlotRun {
-	uint32_t c0, ncols, g, L;        // L = SLOT_LR + 6 + lw local slots
+	uint32_t c0, ncols, g, L;        // L = lr + 6 + lw local slots
 	uint32_t lw, half, has_prev, row_off;   // half: launch 2^(g-1) workgroups (top grid slot = 0); row_off: first SlotRow of the run
 	uint32_t n_ends, rec_lo, rec_hi, threads;  // record: [workgroup][ending read][thread] bytes at this offset of the arena
 	uint32_t in_occ, in_identity, in_half, in_mirror_pos;  // entry: occupied slots; 1: entry index == P & in_occ; the entering column was
 	                                 // written by a halved run: entries whose bit in_mirror_pos is set are read at index ^ in_fullmask
 	uint32_t in_fullmask, out_occ, mirror_out, out_fullmask;  // exit: occupied slots; 1: also store the mirror image (index ^ out_fullmask)
-	uint32_t kind, pad[3];
+	uint32_t kind, lr, pad[2];       // lr: reg slots of this run (cells per thread = 2^lr)
 	uint32_t in_pos[8];              // entry index bit of every occupied slot, one byte each (when !in_identity)
 	uint32_t out_pos[8];             // exit index bit of every occupied slot, one byte each
 	// (words, not byte arrays: the kernel reads them with static indices out of SGPRs; see slot_pos / slot_set_pos)
@@ -110,7 +111,7 @@ struct SlotBtUnit {
 	                                       // slot of every ending read in forward order, one byte each, padded to a word)
 	uint32_t g, L, n_ends, threads;
 	uint32_t bt_lo, bt_hi, half, blob_words;
-	uint32_t f_exit, pad0[3];
+	uint32_t f_exit, lr, pad0[2];
 	uint8_t exit_slot[32];                 // [f_exit] slot of the read at bit j of the logical exit index
 	uint32_t pad1[8];
 };
@@ -133,7 +134,7 @@ struct SlotPlan {
 // Plans the forward pass of a single-individual table with slot runs wherever they apply (per-column steps elsewhere).
 // Returns false if the table is not eligible (pedigree, values beyond 2^30): the caller uses plan_forward().
 // use_symmetry: 0 never halve, >= 1 halve every run whose columns are symmetric and that has a grid slot.
-bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan& plan);
+bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan& plan, int lr = 2);
 
 // Host-only diagnostic (slot_emulate.cpp): executes `plan` cell by cell the way the kernels do.  For planner tests on
 // small inputs; never part of a solve.
