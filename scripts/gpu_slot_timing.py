@@ -36,8 +36,14 @@ run("slots, no records (2)", skip=2)
 run("slots, no stores at all (3)", skip=3)
 run("slots, one column per run (4)", skip=4)
 run("slots, one column, no stores (7)", skip=7)
-for r, l in (("2", "10"), ("2", "9"), ("3", "11"), ("3", "12"), ("3", "10")):
+run("slots, no ending reads (8)", skip=8)
+run("slots, no ending reads, no stores (11)", skip=11)
+run("slots, no endings, no cost, no stores (27)", skip=27)
+run("slots, no cost, no stores (19)", skip=19)
+for r, l in (("3", "11"),):
     run(f"slots, slot_r={r} slot_l={l}", options=(("slot_r", r), ("slot_l", l)))
-run("slots, slot_r=3 one column (4)", skip=4, options=(("slot_r", "3"),))
+    run(f"slots, slot_r={r} no stores (3)", skip=3, options=(("slot_r", r), ("slot_l", l)))
+    run(f"slots, slot_r={r} no endings no stores (11)", skip=11, options=(("slot_r", r), ("slot_l", l)))
+    run(f"slots, slot_r={r} no endings/cost/stores (27)", skip=27, options=(("slot_r", r), ("slot_l", l)))
 run("slots, symmetry off", options=(("symmetry", "0"),))
 run("resident (LDS runs)", path="resident")

@@ -635,7 +635,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		m.dp.dbg_flags = (uint32_t)atoi(getenv("WHAMD_DEBUG_TIMING"));
 	}
 	if (const char* skip = getenv("WHAMD_SLOT_SKIP")) m.dp.dbg_flags = (uint32_t)atoi(skip);  // timing experiments (results invalid): 1 no exit
-	                                                                                          // stores, 2 no records, 4 one column per run
+	                                                                                          // stores, 2 no records, 4 one column per run, 8 no ending reads, 16 no cost update
 	m.dp.n_cols = n;
 	m.dp.T = p.T;
 	m.dp.tbits = tbits;

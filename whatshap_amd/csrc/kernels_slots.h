@@ -156,7 +156,7 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 
 	for (uint32_t ci = 0; ci < ((P.dbg_flags & 4u) ? 1u : ncols); ++ci) {
 		auto hot = [&](int i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)hotv[i], (int)ci); };
-		const uint32_t K = hot(0), Cc = hot(1), n_end = hot(2);
+		const uint32_t K = hot(0), Cc = hot(1), n_end = (P.dbg_flags & 8u) ? 0u : hot(2);
 		uint32_t A = (uint32_t)__builtin_amdgcn_readlane((int)Avec, (int)ci);
 #pragma unroll
 		for (int j = 0; j < SLOT_LANE; ++j) A += (uint32_t)__mul24(lanebit[j], (int32_t)hot(6 + j));
@@ -168,7 +168,7 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 			uint32_t pat = 0;
 #pragma unroll
 			for (int s = 0; s < LR; ++s) pat += ((r >> s) & 1) ? dr[s] : 0u;
-			D[r] += slot_cost(A + pat, K, Cc);
+			if (!(P.dbg_flags & 16u)) D[r] += slot_cost(A + pat, K, Cc);
 		}
 		for (uint32_t q = 0; q < n_end; ++q) {
 			const uint32_t info = q == 0 ? hot(12) : (q == 1 ? hot(14) : hot(16)), M = q == 0 ? hot(13) : (q == 1 ? hot(15) : hot(17));
@@ -223,21 +223,44 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 #pragma unroll
 		for (int s = LR; s < SLOT_MAXSLOTS; ++s) base |= ((Pthr & occ) >> s & 1u) << pos[s];
 		const uint32_t mirror_x = run.mirror_out ? run.out_fullmask : 0u;
+		if ((occ & 3u) == 3u && pos[0] == 0u && pos[1] == 1u) {
+			// the reads of reg slots 0 and 1 are the two lowest bits of the exit index (the planner arranges that for reads
+			// that stay local in the next run): 4 cells = one 16-byte store
 #pragma unroll
-		for (int r = 0; r < R; ++r) {
-			bool writes = thread_writes;
-			uint32_t x = 0;
+			for (int r4 = 0; r4 < R; r4 += 4) {
+				bool writes = thread_writes;
+				uint32_t x = 0;
 #pragma unroll
-			for (int s = 0; s < LR; ++s) {
-				if ((r >> s) & 1) {
-					x |= 1u << pos[s];
-					writes = writes && ((occ >> s) & 1u);
+				for (int s = 2; s < LR; ++s) {
+					if ((r4 >> s) & 1) {
+						x |= 1u << pos[s];
+						writes = writes && ((occ >> s) & 1u);
+					}
+				}
+				if (writes && !(P.dbg_flags & 1u)) {
+					const uint32_t idx = base | x;
+					*reinterpret_cast<uint4*>(cur + idx) = make_uint4(D[r4], D[r4 + 1], D[r4 + 2], D[r4 + 3]);
+					if (run.mirror_out)   // the complement of a group of 4 is a group of 4 in reverse order
+						*reinterpret_cast<uint4*>(cur + ((idx ^ mirror_x) & ~3u)) = make_uint4(D[r4 + 3], D[r4 + 2], D[r4 + 1], D[r4]);
 				}
 			}
-			if (writes && !(P.dbg_flags & 1u)) {
-				const uint32_t idx = base | x;
-				cur[idx] = D[r];
-				if (run.mirror_out) cur[idx ^ mirror_x] = D[r];
+		} else {
+#pragma unroll
+			for (int r = 0; r < R; ++r) {
+				bool writes = thread_writes;
+				uint32_t x = 0;
+#pragma unroll
+				for (int s = 0; s < LR; ++s) {
+					if ((r >> s) & 1) {
+						x |= 1u << pos[s];
+						writes = writes && ((occ >> s) & 1u);
+					}
+				}
+				if (writes && !(P.dbg_flags & 1u)) {
+					const uint32_t idx = base | x;
+					cur[idx] = D[r];
+					if (run.mirror_out) cur[idx ^ mirror_x] = D[r];
+				}
 			}
 		}
 	}

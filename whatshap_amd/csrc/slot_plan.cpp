@@ -76,8 +76,22 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 				grid_reads.push_back(first[order[i]].read_id);
 				grid_end = std::min(grid_end, last_col[first[order[i]].read_id]);
 			}
-			std::sort(grid_reads.begin(), grid_reads.end());
-			for (uint32_t i = 0; i < g; ++i) d.entry_read[L + i] = (int32_t)grid_reads[i];
+			// Grid slots (bit i of the workgroup index).  Workgroup b runs on XCD b % 8 (observed placement; speed only) and
+			// each XCD has its own L2, so the reads that the NEXT run will keep in its lowest slots -- the ones that end
+			// first -- must not sit in the three low bits: workgroups that share a 128-byte line of the exit column then share
+			// an L2, which merges their 16-byte pieces into whole lines before the write-back.  Slots 0..2 and the top slot
+			// (the halved one) therefore take the reads that end LAST; the others follow in ascending end order.
+			std::stable_sort(grid_reads.begin(), grid_reads.end(), [&](uint32_t a, uint32_t bb) {
+				if (last_col[a] != last_col[bb]) return last_col[a] < last_col[bb];
+				return a < bb;
+			});
+			if (g >= 5) {
+				d.entry_read[L + g - 1] = (int32_t)grid_reads[g - 1];
+				for (uint32_t i = 0; i < 3; ++i) d.entry_read[L + i] = (int32_t)grid_reads[g - 4 + i];
+				for (uint32_t i = 3; i + 1 < g; ++i) d.entry_read[L + i] = (int32_t)grid_reads[i - 3];
+			} else {
+				for (uint32_t i = 0; i < g; ++i) d.entry_read[L + i] = (int32_t)grid_reads[i];
+			}
 			// local entering reads: the one that ends first gets the lowest slot (reg slots first, wave slots last)
 			uint32_t s = 0;
 			for (uint32_t i = b0; i-- > g;) d.entry_read[s++] = (int32_t)first[order[i]].read_id;
@@ -252,9 +266,7 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 		// -- entry
 		const bool prev_is_run = si > 0 && plan.steps[si - 1].kind == 2 && B.has_prev;
 		if (prev_is_run) {
-			B.in_identity = 1;   // the previous run stores in THIS run's physical order
-			for (uint32_t s = 0; s < B.L + B.g; ++s) slot_set_pos(B.in_pos, s, s);
-			B.in_fullmask = B.in_occ;
+			// filled in when the previous run's exit was linked (below): the exchange layout is chosen per boundary
 		} else if (B.has_prev) {
 			const ColumnEntry* first = p.col_begin(B.c0);
 			std::memset(B.in_pos, 0, sizeof B.in_pos);
@@ -268,17 +280,43 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 		const bool next_is_run = si + 1 < plan.steps.size() && plan.steps[si + 1].kind == 2 &&
 		                         plan.runs[plan.steps[si + 1].index].has_prev;
 		if (next_is_run) {
+			// Exchange layout between run B and the next run C: C's grid slots on top (workgroup w of C reads ONE contiguous
+			// block), inside the block the reads in the order of the WRITER's physical index -- B's reg slots first, so that
+			// the cells of a B thread that differ only in reads local to both runs are adjacent (one 16-byte store instead of
+			// four scattered ones), B's lane and wave slots, then B's grid slots with the XCD-selecting bits 0..2 and the
+			// halved top slot last (see the grid-slot assignment above).
 			SlotRun& C = plan.runs[plan.steps[si + 1].index];
 			const RunDraft& dc = drafts[plan.steps[si + 1].index];
-			for (uint32_t s = 0; s < B.L + B.g; ++s) {
-				if (db.exit_read[s] < 0) continue;
-				for (uint32_t t = 0; t < C.L + C.g; ++t)
-					if (dc.entry_read[t] == db.exit_read[s]) slot_set_pos(B.out_pos, s, t);
+			const uint32_t nb = B.L + B.g, nc = C.L + C.g;
+			std::vector<std::pair<uint32_t, uint32_t>> local_keys;   // (rank in B, slot in C) of C's local reads
+			std::vector<int> slot_in_b(nc, -1);
+			for (uint32_t t = 0; t < nc; ++t) {
+				if (dc.entry_read[t] < 0) continue;
+				for (uint32_t s2 = 0; s2 < nb; ++s2) if (db.exit_read[s2] == dc.entry_read[t]) slot_in_b[t] = (int)s2;
 			}
-			B.out_fullmask = C.in_occ;
+			for (uint32_t t = 0; t < C.L; ++t) {
+				if (dc.entry_read[t] < 0) continue;
+				const uint32_t s2 = (uint32_t)slot_in_b[t];
+				uint32_t key = s2;
+				if (s2 >= B.L) {
+					const uint32_t gi = s2 - B.L;
+					key = (B.g >= 5 && gi + 1 == B.g) ? 3000u : ((B.g >= 5 && gi < 3) ? 2000u + gi : 1000u + gi);
+				}
+				local_keys.push_back({key, t});
+			}
+			std::sort(local_keys.begin(), local_keys.end());
+			const uint32_t n_loc = (uint32_t)local_keys.size();
+			std::memset(C.in_pos, 0, sizeof C.in_pos);
+			for (uint32_t i = 0; i < n_loc; ++i) slot_set_pos(C.in_pos, local_keys[i].second, i);
+			for (uint32_t i = 0; i < C.g; ++i) slot_set_pos(C.in_pos, C.L + i, n_loc + i);
+			C.in_identity = 1;
+			for (uint32_t t = 0; t < nc; ++t) if (dc.entry_read[t] >= 0 && slot_pos(C.in_pos, t) != t) C.in_identity = 0;
+			C.in_fullmask = (n_loc + C.g) >= 32 ? 0xFFFFFFFFu : ((1u << (n_loc + C.g)) - 1u);
+			for (uint32_t t = 0; t < nc; ++t) if (slot_in_b[t] >= 0) slot_set_pos(B.out_pos, (uint32_t)slot_in_b[t], slot_pos(C.in_pos, t));
+			B.out_fullmask = C.in_fullmask;
 			if (B.half) {
 				C.in_half = 1;
-				C.in_mirror_pos = slot_pos(B.out_pos, B.L + B.g - 1);   // where this run's top grid read sits in the next run's index
+				C.in_mirror_pos = slot_pos(B.out_pos, B.L + B.g - 1);   // where this run's top grid read sits in the exchange index
 			}
 		} else {
 			for (uint32_t j = 0; j < plan.f_exit[ri]; ++j) slot_set_pos(B.out_pos, plan.exit_slot[ri][j], j);
