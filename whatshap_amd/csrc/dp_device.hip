@@ -420,6 +420,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		slot_blob_words[ri] = (uint32_t)(slot_blob.size() - slot_blob_off[ri]);
 	}
 	void *d_srows = nullptr, *d_sblob = nullptr;
+	if (!m.splan.rows.empty()) m.splan.rows.resize(m.splan.rows.size() + SLOT_ROW_PAD);   // the kernel's scalar-cache warm-up touches a fixed number of rows
 	HIP_TRY(up(&d_srows, m.splan.rows.data(), m.splan.rows.size() * sizeof(SlotRow)));
 	HIP_TRY(up(&d_sblob, slot_blob.data(), slot_blob.size() * sizeof(uint32_t)));
 	m.dp.slot_rows = (const SlotRow*)d_srows;

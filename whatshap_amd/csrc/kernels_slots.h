@@ -50,21 +50,33 @@ __device__ __forceinline__ uint32_t slot_end_partner(uint32_t (&D)[1 << LR], con
 // Wave-uniform data is read through the scalar cache: loads from the constant address space become s_load_dwordx8
 // (kernel arguments are the same kind of memory).  A generic pointer converts bit for bit.
 typedef uint32_t slot_u32x8 __attribute__((ext_vector_type(8)));
-typedef uint32_t slot_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t slot_u32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t slot_u32x2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(4))) slot_u32x8* slot_cptr8;
-typedef const __attribute__((address_space(4))) slot_u32x4* slot_cptr4;
+typedef const __attribute__((address_space(4))) slot_u32x16* slot_cptr16;
 typedef const __attribute__((address_space(4))) slot_u32x2* slot_cptr2;
-// the hot words of one column (SlotRow): 8 + 4 + 4 + 2 dwords, every one of them read
-struct SlotHot { slot_u32x8 a; slot_u32x4 b, c; slot_u32x2 d; };
-__device__ __forceinline__ SlotHot slot_load_hot(const SlotRow* row) {
-	const unsigned long long p = (unsigned long long)row;
-	SlotHot h;
-	h.a = *(slot_cptr8)p; h.b = *(slot_cptr4)(p + 32); h.c = *(slot_cptr4)(p + 48); h.d = *(slot_cptr2)(p + 64);
-	return h;
-}
 template <class T>
 __device__ __forceinline__ slot_cptr8 slot_scalar_ptr(const T* p) { return (slot_cptr8)(unsigned long long)p; }
+// the hot line of a column (SlotRow), one s_load_dwordx16
+__device__ __forceinline__ slot_u32x16 slot_load_hot(const SlotRow* row) { return *(slot_cptr16)(unsigned long long)row; }
+
+// Pulls the hot lines of the next 32 rows into the scalar cache: 32 independent scalar loads in flight at once (their
+// results are not used: one destination register, one wait inside the statement, so the compiler never sees a pending
+// load).  The column loop's own loads then hit.  Rows beyond the run exist (SLOT_ROW_PAD).
+__device__ __forceinline__ void slot_touch_rows(const SlotRow* rows) {
+	uint32_t sink;
+	asm volatile(
+		"s_load_dword %0, %1, 0x0\n\ts_load_dword %0, %1, 0x100\n\ts_load_dword %0, %1, 0x200\n\ts_load_dword %0, %1, 0x300\n\t"
+		"s_load_dword %0, %1, 0x400\n\ts_load_dword %0, %1, 0x500\n\ts_load_dword %0, %1, 0x600\n\ts_load_dword %0, %1, 0x700\n\t"
+		"s_load_dword %0, %1, 0x800\n\ts_load_dword %0, %1, 0x900\n\ts_load_dword %0, %1, 0xa00\n\ts_load_dword %0, %1, 0xb00\n\t"
+		"s_load_dword %0, %1, 0xc00\n\ts_load_dword %0, %1, 0xd00\n\ts_load_dword %0, %1, 0xe00\n\ts_load_dword %0, %1, 0xf00\n\t"
+		"s_load_dword %0, %1, 0x1000\n\ts_load_dword %0, %1, 0x1100\n\ts_load_dword %0, %1, 0x1200\n\ts_load_dword %0, %1, 0x1300\n\t"
+		"s_load_dword %0, %1, 0x1400\n\ts_load_dword %0, %1, 0x1500\n\ts_load_dword %0, %1, 0x1600\n\ts_load_dword %0, %1, 0x1700\n\t"
+		"s_load_dword %0, %1, 0x1800\n\ts_load_dword %0, %1, 0x1900\n\ts_load_dword %0, %1, 0x1a00\n\ts_load_dword %0, %1, 0x1b00\n\t"
+		"s_load_dword %0, %1, 0x1c00\n\ts_load_dword %0, %1, 0x1d00\n\ts_load_dword %0, %1, 0x1e00\n\ts_load_dword %0, %1, 0x1f00\n\t"
+		"s_waitcnt lgkmcnt(0)"
+		: "=&s"(sink) : "s"(rows) : "memory");
+}
 
 // byte s of a packed position table held in SGPRs (static s)
 __device__ __forceinline__ uint32_t slot_pos_dev(const uint32_t (&w)[8], int s) { return (w[s >> 2] >> ((s & 3) * 8)) & 31u; }
@@ -82,23 +94,12 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 	const SlotRow* __restrict__ rows = P.slot_rows + run.row_off;
 	const uint32_t ncols = run.ncols;
 
-	// ---- prologue: one batch of loads.  (1) lane c of every wave fetches column c: its hot words stay in that lane's
-	// registers for the whole run (the column loop broadcasts them with v_readlane: no memory access, no scalar-cache
-	// miss on the sequential chain), the cold part becomes A = Cp + (deltas of the set grid / wave slots)
+	// ---- prologue: one batch of loads.  (1) lane c of every wave fetches the cold part of column c and prepares
+	// A = Cp + (deltas of the set grid / wave slots) for it; the column loop picks it up with v_readlane
 	uint32_t Avec = 0;
-	uint32_t hotv[SLOT_HOT];
 	{
 		const uint32_t cl = lane < ncols ? lane : 0u;
 		const SlotRow* __restrict__ rr = rows + cl;
-		const uint4* __restrict__ hq = reinterpret_cast<const uint4*>(rr);
-#pragma unroll
-		for (int q = 0; q < (SLOT_HOT + 3) / 4; ++q) {
-			const uint4 t = hq[q];
-			hotv[4 * q] = t.x;
-			if (4 * q + 1 < SLOT_HOT) hotv[4 * q + 1] = t.y;
-			if (4 * q + 2 < SLOT_HOT) hotv[4 * q + 2] = t.z;
-			if (4 * q + 3 < SLOT_HOT) hotv[4 * q + 3] = t.w;
-		}
 		const uint32_t Pu = (w << L) | (wave << (6 + LR));   // the wave-uniform part of the physical index
 		uint32_t acc = rr->Cp;
 #pragma unroll
@@ -145,6 +146,10 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 #pragma unroll
 		for (int r = 0; r < R; ++r) D[r] = 0;
 	}
+	// (3) the hot lines of the run's columns into the scalar cache, while the vector loads above are in flight
+	slot_touch_rows(rows);
+	if (ncols > 32u) slot_touch_rows(rows + 32);
+	slot_u32x16 hn = slot_load_hot(rows);
 	// per-lane constants of the column loop
 	int32_t lanebit[SLOT_LANE];
 #pragma unroll
@@ -153,16 +158,23 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 	const uint32_t threads = run.threads;
 	const uint32_t xwords = threads * R;   // one exchange buffer
 	uint32_t xsel = 0;
+	uint32_t Anext = (uint32_t)__builtin_amdgcn_readlane((int)Avec, 0);
 
 	for (uint32_t ci = 0; ci < ((P.dbg_flags & 4u) ? 1u : ncols); ++ci) {
-		auto hot = [&](int i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)hotv[i], (int)ci); };
-		const uint32_t K = hot(0), Cc = hot(1), n_end = (P.dbg_flags & 8u) ? 0u : hot(2);
-		uint32_t A = (uint32_t)__builtin_amdgcn_readlane((int)Avec, (int)ci);
+		// this column's hot line is in SGPRs; the next column's is requested now and lands while this one is evaluated
+		const slot_u32x16 h = hn;
+		hn = slot_load_hot(rows + (ci + 1u < ncols ? ci + 1u : ci));
+		const uint32_t Cc = h[1], n_end = (P.dbg_flags & 8u) ? 0u : h[11];
+		uint32_t dr[SLOT_LR];
 #pragma unroll
-		for (int j = 0; j < SLOT_LANE; ++j) A += (uint32_t)__mul24(lanebit[j], (int32_t)hot(6 + j));
-		uint32_t dr[LR];
+		for (int s = 0; s < SLOT_LR; ++s) dr[s] = h[2 + s];
+		uint32_t K = h[0];
+		if (LR < 3) K += dr[2];   // 0 by construction: keeps the dword "read" (see SlotRow)
+		uint32_t A = Anext;
+		Anext = (uint32_t)__builtin_amdgcn_readlane((int)Avec, (int)(ci + 1u < ncols ? ci + 1u : ci));
+		// lane part of S: one 24-bit multiply-add per lane slot (|delta| < 2^22, lane bit 0 / 1)
 #pragma unroll
-		for (int s = 0; s < LR; ++s) dr[s] = hot(3 + s);
+		for (int j = 0; j < SLOT_LANE; ++j) asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(A) : "v"(lanebit[j]), "s"(h[5 + j]));
 #pragma unroll
 		for (int r = 0; r < R; ++r) {
 			uint32_t pat = 0;
@@ -171,7 +183,11 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 			if (!(P.dbg_flags & 16u)) D[r] += slot_cost(A + pat, K, Cc);
 		}
 		for (uint32_t q = 0; q < n_end; ++q) {
-			const uint32_t info = q == 0 ? hot(12) : (q == 1 ? hot(14) : hot(16)), M = q == 0 ? hot(13) : (q == 1 ? hot(15) : hot(17));
+			uint32_t info = q == 0 ? h[12] : h[14], M = q == 0 ? h[13] : h[15];
+			if (q == 2) {   // three reads ending at once: the third lies in the row's second line
+				const slot_u32x2 e2 = *(slot_cptr2)((unsigned long long)(rows + ci) + 64);
+				info = e2[0]; M = e2[1];
+			}
 			const uint32_t slot = info & 255u, qmask = (info >> 8) & 0xFFFFu, mflip = (info >> 24) & 1u;
 			uint32_t qthr = (uint32_t)__popc(Pthr & M) & 1u;
 			if (slot >= (uint32_t)LR) qthr ^= ((Pthr >> slot) & 1u) & mflip;

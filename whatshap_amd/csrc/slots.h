@@ -47,27 +47,28 @@ constexpr int32_t SLOT_DELTA_LIMIT = 1 << 22;  // |delta| of every read in a run
 // Per-column descriptor of a run, 64 dwords.  The first 32 ("hot") are fetched by every wave with scalar loads once per
 // column; the rest ("cold") is read in the prologue only (lane c of a wave reads column c).
 struct SlotRow {
-	// ---- hot (18 dwords, no gaps: the kernel loads them as 8 + 4 + 4 + 2 dwords into SGPRs one column ahead; a dword that
-	// is loaded but never read lets the register allocator reuse its SGPR while the load is in flight, which forces a wait)
+	// ---- hot: ONE 64-byte line that every wave fetches through the scalar cache (s_load_dwordx16) one column ahead.
+	// Every dword is read by the kernel: a dword that is loaded but never read lets the register allocator reuse its
+	// SGPR while the load is in flight, which forces a wait right after the load.
 	uint32_t K;                      // Cp + Cm (mod 2^32; an absent term is RES_ABSENT, resident.h)
 	uint32_t Cc;                     // constant term (INF if none)
-	uint32_t n_end;                  // reads ending in this column (<= SLOT_MAXEND)
-	int32_t dreg[SLOT_LR];           // deltas of the reg slots
+	int32_t dreg[SLOT_LR];           // deltas of the reg slots (0 for a slot the run does not have)
 	int32_t dlane[SLOT_LANE];        // deltas of the lane slots
+	uint32_t n_end;                  // reads ending in this column (<= SLOT_MAXEND)
 	struct End {
 		uint32_t info;               // slot | qmask << 8 | mflip << 24 (qmask bit r: reg-slot part of the tie-break parity of cell r,
 		                             //  including (side & mflip) when the ending read itself sits in a reg slot)
 		uint32_t M;                  // physical index bits of the reads logically above the ending read
-	} end[SLOT_MAXEND];              // ascending logical position
+	} end[SLOT_MAXEND];              // ascending logical position; end[2] lies in the next line (three reads ending at once are rare)
 	uint32_t pad2[14];
 	// ---- cold (128-byte aligned: lane c fetches its column with wide loads)
 	int32_t dslot[SLOT_MAXSLOTS];    // delta of every slot at this column (0: free slot, BLANK entry)
 	uint32_t Cp;
 	uint32_t pad3[5];
 };
-static_assert(SLOT_LR == 3 && SLOT_LANE == 6 && SLOT_MAXEND == 3, "hot layout of SlotRow: 3 + 3 + 6 + 6 dwords");
-constexpr int SLOT_HOT = 18;         // hot dwords of a SlotRow
+static_assert(SLOT_LR == 3 && SLOT_LANE == 6 && SLOT_MAXEND == 3, "hot layout of SlotRow: 2 + 3 + 6 + 1 + 4 dwords in the first line");
 static_assert(sizeof(SlotRow) == 256, "SlotRow must stay 64 dwords");
+constexpr int SLOT_ROW_PAD = 64;     // rows appended to the array: the kernel touches a fixed number of rows to warm the scalar cache
 
 // One run, passed to the kernel by value.
 struct SlotRun {
