@@ -36,8 +36,6 @@ run("slots, no records (2)", skip=2)
 run("slots, no stores at all (3)", skip=3)
 run("slots, one column per run (4)", skip=4)
 run("slots, one column, no stores (7)", skip=7)
-run("slots, same row every column, no end/stores (43)", skip=43)
-run("slots, no warm-up touches, no end/stores (75)", skip=75)
 run("slots, no ending reads (8)", skip=8)
 run("slots, no ending reads, no stores (11)", skip=11)
 run("slots, no endings, no cost, no stores (27)", skip=27)

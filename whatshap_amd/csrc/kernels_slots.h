@@ -97,17 +97,9 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 	// ---- prologue: one batch of loads.  (1) lane c of every wave fetches the cold part of column c and prepares
 	// A = Cp + (deltas of the set grid / wave slots) for it; the column loop picks it up with v_readlane
 	uint32_t Avec = 0;
-	uint32_t hotv[16];   // lane c: the hot line of column c (the column loop broadcasts it with v_readlane: no memory access and
-	                     // no scalar-cache latency -- ~300 cycles even on a hit -- on the sequential chain)
 	{
 		const uint32_t cl = lane < ncols ? lane : 0u;
 		const SlotRow* __restrict__ rr = rows + cl;
-		const uint4* __restrict__ hq = reinterpret_cast<const uint4*>(rr);
-#pragma unroll
-		for (int q = 0; q < 4; ++q) {
-			const uint4 t = hq[q];
-			hotv[4 * q] = t.x; hotv[4 * q + 1] = t.y; hotv[4 * q + 2] = t.z; hotv[4 * q + 3] = t.w;
-		}
 		const uint32_t Pu = (w << L) | (wave << (6 + LR));   // the wave-uniform part of the physical index
 		uint32_t acc = rr->Cp;
 #pragma unroll
@@ -154,12 +146,10 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 #pragma unroll
 		for (int r = 0; r < R; ++r) D[r] = 0;
 	}
-	// hot words of a column, broadcast from the lane that holds them (dwords of SlotRow: 0 K, 1 Cc, 2.. dreg, 5.. dlane, 11 n_end,
-	// 12 info0, 13 M0, 14 info1, 15 M1); requested one column ahead so that the VALU -> SGPR hop is off the chain
-	auto hot_of = [&](int i, uint32_t c) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)hotv[i], (int)c); };
-	uint32_t hn[14];
-#pragma unroll
-	for (int i = 0; i < 14; ++i) hn[i] = hot_of(i, 0u);
+	// (3) the hot lines of the run's columns into the scalar cache, while the vector loads above are in flight
+	slot_touch_rows(rows);
+	if (ncols > 32u) slot_touch_rows(rows + 32);
+	slot_u32x16 hn = slot_load_hot(rows);
 	// per-lane constants of the column loop
 	int32_t lanebit[SLOT_LANE];
 #pragma unroll
@@ -171,19 +161,15 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 	uint32_t Anext = (uint32_t)__builtin_amdgcn_readlane((int)Avec, 0);
 
 	for (uint32_t ci = 0; ci < ((P.dbg_flags & 4u) ? 1u : ncols); ++ci) {
-		uint32_t h[14];
-#pragma unroll
-		for (int i = 0; i < 14; ++i) h[i] = hn[i];
-		{
-			const uint32_t cn = ci + 1u < ncols ? ci + 1u : ci;
-#pragma unroll
-			for (int i = 0; i < 14; ++i) if (i < 2 + LR || i >= 5) hn[i] = hot_of(i, cn);
-		}
+		// this column's hot line is in SGPRs; the next column's is requested now and lands while this one is evaluated
+		const slot_u32x16 h = hn;
+		hn = slot_load_hot(rows + (ci + 1u < ncols ? ci + 1u : ci));
 		const uint32_t Cc = h[1], n_end = (P.dbg_flags & 8u) ? 0u : h[11];
-		uint32_t dr[LR];
+		uint32_t dr[SLOT_LR];
 #pragma unroll
-		for (int s = 0; s < LR; ++s) dr[s] = h[2 + s];
-		const uint32_t K = h[0];
+		for (int s = 0; s < SLOT_LR; ++s) dr[s] = h[2 + s];
+		uint32_t K = h[0];
+		if (LR < 3) K += dr[2];   // 0 by construction: keeps the dword "read" (see SlotRow)
 		uint32_t A = Anext;
 		Anext = (uint32_t)__builtin_amdgcn_readlane((int)Avec, (int)(ci + 1u < ncols ? ci + 1u : ci));
 		// lane part of S: one 24-bit multiply-add per lane slot (|delta| < 2^22, lane bit 0 / 1)
@@ -197,9 +183,8 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 			if (!(P.dbg_flags & 16u)) D[r] += slot_cost(A + pat, K, Cc);
 		}
 		for (uint32_t q = 0; q < n_end; ++q) {
-			uint32_t info = h[12], M = h[13];
-			if (q == 1) { info = hot_of(14, ci); M = hot_of(15, ci); }   // several reads ending at once: rare
-			if (q == 2) {   // the third lies in the row's second line
+			uint32_t info = q == 0 ? h[12] : h[14], M = q == 0 ? h[13] : h[15];
+			if (q == 2) {   // three reads ending at once: the third lies in the row's second line
 				const slot_u32x2 e2 = *(slot_cptr2)((unsigned long long)(rows + ci) + 64);
 				info = e2[0]; M = e2[1];
 			}
