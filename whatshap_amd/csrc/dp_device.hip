@@ -566,7 +566,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 					e.prev = lane.d_pr[c.flip];
 					e.cur = lane.d_pr[c.flip ^ 1];
 					e.score_out = (last && !job.final) ? m.d_job_scores + job_id : nullptr;
-					ss.lds = std::max<size_t>(ss.lds, (size_t)2 * e.run.threads * (1u << e.run.lr) * 4);
+					ss.lds = std::max<size_t>(ss.lds, (size_t)2 * e.run.threads * (1u << e.run.lr) * 4 + (SLOT_MAXCOLS + 2) * 64);
 					ss.grid_x = std::max(ss.grid_x, 1u << (e.run.g - e.run.half));
 					ss.threads = std::max(ss.threads, e.run.threads);
 					m.slot_entries.push_back(e);
@@ -715,7 +715,7 @@ void DeviceTable::Impl::launch_run(const ResBatchEntry& e, uint32_t step_index, 
 void DeviceTable::Impl::launch_slot_run(const SlotBatchEntry& e, uint64_t& launches) {
 	Impl& m = *this;
 	const SlotRun& run = e.run;
-	const size_t lds = (size_t)2 * run.threads * (1u << run.lr) * 4;
+	const size_t lds = (size_t)2 * run.threads * (1u << run.lr) * 4 + (SLOT_MAXCOLS + 2) * 64;   // wave-slot exchange + hot lines
 	const dim3 grid(1u << (run.g - run.half)), block(run.threads);
 	if (run.lr == 3) hipLaunchKernelGGL(slot_run<3>, grid, block, lds, m.stream, m.dp, run, e.prev, e.cur, e.score_out);
 	else hipLaunchKernelGGL(slot_run<2>, grid, block, lds, m.stream, m.dp, run, e.prev, e.cur, e.score_out);

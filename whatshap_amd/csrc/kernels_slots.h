@@ -146,10 +146,13 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 #pragma unroll
 		for (int r = 0; r < R; ++r) D[r] = 0;
 	}
-	// (3) the hot lines of the run's columns into the scalar cache, while the vector loads above are in flight
-	slot_touch_rows(rows);
-	if (ncols > 32u) slot_touch_rows(rows + 32);
-	slot_u32x16 hn = slot_load_hot(rows);
+	// (3) the hot lines of the run's columns go to LDS (one 16-byte piece per thread).  The column loop reads them back with
+	// uniform-address ds_read_b128 one column ahead: LDS returns in order (lgkmcnt), so the read of the next column stays in
+	// flight while this one is evaluated -- scalar loads cannot do that (they return out of order: every wait drains them all,
+	// and even a scalar-cache hit costs ~300 cycles), and v_readlane broadcasts cost ~35 cycles each.
+	uint32_t* hot_lds = smem + 2u * run.threads * R;
+	for (uint32_t i = tid; i < ncols * 4u; i += run.threads)
+		reinterpret_cast<uint4*>(hot_lds)[i] = reinterpret_cast<const uint4*>(rows + (i >> 2))[i & 3u];
 	// per-lane constants of the column loop
 	int32_t lanebit[SLOT_LANE];
 #pragma unroll
@@ -158,37 +161,39 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 	const uint32_t threads = run.threads;
 	const uint32_t xwords = threads * R;   // one exchange buffer
 	uint32_t xsel = 0;
-	uint32_t Anext = (uint32_t)__builtin_amdgcn_readlane((int)Avec, 0);
+	__syncthreads();
 
-	for (uint32_t ci = 0; ci < ((P.dbg_flags & 4u) ? 1u : ncols); ++ci) {
-		// this column's hot line is in SGPRs; the next column's is requested now and lands while this one is evaluated
-		const slot_u32x16 h = hn;
-		hn = slot_load_hot(rows + (ci + 1u < ncols ? ci + 1u : ci));
-		const uint32_t Cc = h[1], n_end = (P.dbg_flags & 8u) ? 0u : h[11];
-		uint32_t dr[SLOT_LR];
-#pragma unroll
-		for (int s = 0; s < SLOT_LR; ++s) dr[s] = h[2 + s];
-		uint32_t K = h[0];
-		if (LR < 3) K += dr[2];   // 0 by construction: keeps the dword "read" (see SlotRow)
-		uint32_t A = Anext;
-		Anext = (uint32_t)__builtin_amdgcn_readlane((int)Avec, (int)(ci + 1u < ncols ? ci + 1u : ci));
+	struct HotLine { uint4 a, b, c, d; };   // dwords of SlotRow: 0 K, 1 Cc, 2.. dreg, 5.. dlane, 11 n_end, 12 info0, 13 M0, 14 info1, 15 M1
+	auto load_hot = [&](uint32_t c) -> HotLine {
+		const uint4* hl = reinterpret_cast<const uint4*>(hot_lds + c * 16u);
+		HotLine h;
+		h.a = hl[0]; h.b = hl[1]; h.c = hl[2]; h.d = hl[3];
+		return h;
+	};
+	// One column for the calling thread's cells.  The hot words are wave-uniform values in VECTOR registers: operands of the
+	// cell arithmetic as they are; only what steers control flow (n_end, the ending read's slot) becomes scalar.
+	auto column = [&](const HotLine& h, const uint32_t ci) {
+		const uint32_t K = h.a.x, Cc = h.a.y;
+		const uint32_t dl[SLOT_LANE] = {h.b.y, h.b.z, h.b.w, h.c.x, h.c.y, h.c.z};
+		const uint32_t dr[SLOT_LR] = {h.a.z, h.a.w, h.b.x};
+		uint32_t A = (uint32_t)__builtin_amdgcn_readlane((int)Avec, (int)ci);
 		// lane part of S: one 24-bit multiply-add per lane slot (|delta| < 2^22, lane bit 0 / 1)
 #pragma unroll
-		for (int j = 0; j < SLOT_LANE; ++j) asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(A) : "v"(lanebit[j]), "s"(h[5 + j]));
+		for (int j = 0; j < SLOT_LANE; ++j) asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(A) : "v"(lanebit[j]), "v"(dl[j]));
+		uint32_t Ar[R];
+		Ar[0] = A;
 #pragma unroll
-		for (int r = 0; r < R; ++r) {
-			uint32_t pat = 0;
+		for (int r = 1; r < R; ++r) Ar[r] = Ar[r & (r - 1)] + dr[__builtin_ctz(r)];   // clear the lowest set bit: one add per cell
 #pragma unroll
-			for (int s = 0; s < LR; ++s) pat += ((r >> s) & 1) ? dr[s] : 0u;
-			if (!(P.dbg_flags & 16u)) D[r] += slot_cost(A + pat, K, Cc);
-		}
+		for (int r = 0; r < R; ++r) D[r] += slot_cost(Ar[r], K, Cc);
+		const uint32_t n_end = (P.dbg_flags & 8u) ? 0u : uni(h.c.w);
 		for (uint32_t q = 0; q < n_end; ++q) {
-			uint32_t info = q == 0 ? h[12] : h[14], M = q == 0 ? h[13] : h[15];
+			uint32_t info = q == 0 ? h.d.x : h.d.z, M = q == 0 ? h.d.y : h.d.w;
 			if (q == 2) {   // three reads ending at once: the third lies in the row's second line
 				const slot_u32x2 e2 = *(slot_cptr2)((unsigned long long)(rows + ci) + 64);
 				info = e2[0]; M = e2[1];
 			}
-			const uint32_t slot = info & 255u, qmask = (info >> 8) & 0xFFFFu, mflip = (info >> 24) & 1u;
+			const uint32_t slot = uni(info) & 255u, qmask = (info >> 8) & 0xFFFFu, mflip = (info >> 24) & 1u;
 			uint32_t qthr = (uint32_t)__popc(Pthr & M) & 1u;
 			if (slot >= (uint32_t)LR) qthr ^= ((Pthr >> slot) & 1u) & mflip;
 			uint32_t takes;
@@ -224,6 +229,18 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 			}
 			if (!(P.dbg_flags & 2u)) *rec = (uint8_t)takes;
 			rec += threads;
+		}
+	};
+	{
+		// two columns per trip: each column's hot line is requested while the previous column is evaluated, without register copies
+		const uint32_t nc = (P.dbg_flags & 4u) ? 1u : ncols;
+		HotLine ha = load_hot(0), hb;
+		for (uint32_t ci = 0; ci < nc; ci += 2) {
+			hb = load_hot(ci + 1u);        // (one line beyond the run may be read: the LDS area has room, the value is not used)
+			column(ha, ci);
+			if (ci + 1u >= nc) break;
+			ha = load_hot(ci + 2u);
+			column(hb, ci + 1u);
 		}
 	}
 
