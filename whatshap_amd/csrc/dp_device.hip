@@ -423,6 +423,9 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	if (!m.splan.rows.empty()) m.splan.rows.resize(m.splan.rows.size() + SLOT_ROW_PAD);   // the kernel's scalar-cache warm-up touches a fixed number of rows
 	HIP_TRY(up(&d_srows, m.splan.rows.data(), m.splan.rows.size() * sizeof(SlotRow)));
 	HIP_TRY(up(&d_sblob, slot_blob.data(), slot_blob.size() * sizeof(uint32_t)));
+	void* d_sctrl = nullptr;
+	HIP_TRY(up(&d_sctrl, m.splan.ctrl.data(), m.splan.ctrl.size() * sizeof(uint32_t)));
+	m.dp.slot_ctrl = (const uint32_t*)d_sctrl;
 	m.dp.slot_rows = (const SlotRow*)d_srows;
 	m.dp.slot_blob = (const uint32_t*)d_sblob;
 	// ---- jobs (see Impl::Job): connected components made of runs only get their own job
@@ -566,7 +569,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 					e.prev = lane.d_pr[c.flip];
 					e.cur = lane.d_pr[c.flip ^ 1];
 					e.score_out = (last && !job.final) ? m.d_job_scores + job_id : nullptr;
-					ss.lds = std::max<size_t>(ss.lds, (size_t)2 * e.run.threads * (1u << e.run.lr) * 4 + (SLOT_MAXCOLS + 2) * 64);
+					ss.lds = std::max<size_t>(ss.lds, (size_t)2 * e.run.threads * (1u << e.run.lr) * 4 + (SLOT_MAXCOLS + 2) * 64 + 8 * 64 * 4);
 					ss.grid_x = std::max(ss.grid_x, 1u << (e.run.g - e.run.half));
 					ss.threads = std::max(ss.threads, e.run.threads);
 					m.slot_entries.push_back(e);
@@ -715,7 +718,7 @@ void DeviceTable::Impl::launch_run(const ResBatchEntry& e, uint32_t step_index, 
 void DeviceTable::Impl::launch_slot_run(const SlotBatchEntry& e, uint64_t& launches) {
 	Impl& m = *this;
 	const SlotRun& run = e.run;
-	const size_t lds = (size_t)2 * run.threads * (1u << run.lr) * 4 + (SLOT_MAXCOLS + 2) * 64;   // wave-slot exchange + hot lines
+	const size_t lds = (size_t)2 * run.threads * (1u << run.lr) * 4 + (SLOT_MAXCOLS + 2) * 64 + 8 * 64 * 4;   // wave-slot exchange + hot lines + per-wave A
 	const dim3 grid(1u << (run.g - run.half)), block(run.threads);
 	if (run.lr == 3) hipLaunchKernelGGL(slot_run<3>, grid, block, lds, m.stream, m.dp, run, e.prev, e.cur, e.score_out);
 	else hipLaunchKernelGGL(slot_run<2>, grid, block, lds, m.stream, m.dp, run, e.prev, e.cur, e.score_out);

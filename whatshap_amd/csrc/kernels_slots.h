@@ -153,6 +153,12 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 	uint32_t* hot_lds = smem + 2u * run.threads * R;
 	for (uint32_t i = tid; i < ncols * 4u; i += run.threads)
 		reinterpret_cast<uint4*>(hot_lds)[i] = reinterpret_cast<const uint4*>(rows + (i >> 2))[i & 3u];
+	// ... and so does A of every column, one 64-entry row per wave: a VALU -> SGPR transfer (v_readlane, v_readfirstlane)
+	// costs ~35 cycles of issue, so nothing on the column chain goes that way.  What steers control flow (does a read end in
+	// this column, in which slot) comes from the run's control bytes, loaded once into SGPRs.
+	uint32_t* a_lds = hot_lds + (SLOT_MAXCOLS + 2) * 16 + wave * 64u;
+	a_lds[lane] = Avec;
+	slot_u32x16 ctrlq = *(slot_cptr16)(unsigned long long)(P.slot_ctrl + run.ctrl_off);
 	// per-lane constants of the column loop
 	int32_t lanebit[SLOT_LANE];
 #pragma unroll
@@ -163,20 +169,27 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 	uint32_t xsel = 0;
 	__syncthreads();
 
-	struct HotLine { uint4 a, b, c, d; };   // dwords of SlotRow: 0 K, 1 Cc, 2.. dreg, 5.. dlane, 11 n_end, 12 info0, 13 M0, 14 info1, 15 M1
+	struct HotLine { uint4 a, b, c, d; uint32_t A; };   // dwords of SlotRow: 0 K, 1 Cc, 2.. dreg, 5.. dlane, 11 n_end, 12 info0, 13 M0, 14 info1, 15 M1
 	auto load_hot = [&](uint32_t c) -> HotLine {
-		const uint4* hl = reinterpret_cast<const uint4*>(hot_lds + c * 16u);
+		// (the offset goes through an opaque move: the compiler must not learn that these loads are wave-uniform, or it selects
+		// scalar instructions for what is derived from them and pays a v_readfirstlane for every operand)
+		uint32_t off = c * 16u;
+		asm volatile("" : "+v"(off));
+		const uint4* hl = reinterpret_cast<const uint4*>(hot_lds + off);
 		HotLine h;
 		h.a = hl[0]; h.b = hl[1]; h.c = hl[2]; h.d = hl[3];
+		uint32_t aoff = c & 63u;
+		asm volatile("" : "+v"(aoff));
+		h.A = a_lds[aoff];
 		return h;
 	};
 	// One column for the calling thread's cells.  The hot words are wave-uniform values in VECTOR registers: operands of the
 	// cell arithmetic as they are; only what steers control flow (n_end, the ending read's slot) becomes scalar.
-	auto column = [&](const HotLine& h, const uint32_t ci) {
+	auto column = [&](const HotLine& h, const uint32_t ci, const uint32_t ctrl) {
 		const uint32_t K = h.a.x, Cc = h.a.y;
 		const uint32_t dl[SLOT_LANE] = {h.b.y, h.b.z, h.b.w, h.c.x, h.c.y, h.c.z};
 		const uint32_t dr[SLOT_LR] = {h.a.z, h.a.w, h.b.x};
-		uint32_t A = (uint32_t)__builtin_amdgcn_readlane((int)Avec, (int)ci);
+		uint32_t A = h.A;
 		// lane part of S: one 24-bit multiply-add per lane slot (|delta| < 2^22, lane bit 0 / 1)
 #pragma unroll
 		for (int j = 0; j < SLOT_LANE; ++j) asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(A) : "v"(lanebit[j]), "v"(dl[j]));
@@ -186,14 +199,10 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 		for (int r = 1; r < R; ++r) Ar[r] = Ar[r & (r - 1)] + dr[__builtin_ctz(r)];   // clear the lowest set bit: one add per cell
 #pragma unroll
 		for (int r = 0; r < R; ++r) D[r] += slot_cost(Ar[r], K, Cc);
-		const uint32_t n_end = (P.dbg_flags & 8u) ? 0u : uni(h.c.w);
-		for (uint32_t q = 0; q < n_end; ++q) {
-			uint32_t info = q == 0 ? h.d.x : h.d.z, M = q == 0 ? h.d.y : h.d.w;
-			if (q == 2) {   // three reads ending at once: the third lies in the row's second line
-				const slot_u32x2 e2 = *(slot_cptr2)((unsigned long long)(rows + ci) + 64);
-				info = e2[0]; M = e2[1];
-			}
-			const uint32_t slot = uni(info) & 255u, qmask = (info >> 8) & 0xFFFFu, mflip = (info >> 24) & 1u;
+		const uint32_t n_end = (P.dbg_flags & 8u) ? 0u : (ctrl & 3u);
+		// one ending read: `slot` is a scalar (control flow), info / M are wave-uniform vector values
+		auto ending = [&](const uint32_t info, const uint32_t M, const uint32_t slot) {
+			const uint32_t qmask = (info >> 8) & 0xFFFFu, mflip = (info >> 24) & 1u;
 			uint32_t qthr = (uint32_t)__popc(Pthr & M) & 1u;
 			if (slot >= (uint32_t)LR) qthr ^= ((Pthr >> slot) & 1u) & mflip;
 			uint32_t takes;
@@ -229,18 +238,42 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 			}
 			if (!(P.dbg_flags & 2u)) *rec = (uint8_t)takes;
 			rec += threads;
+		};
+		if (n_end) {
+			ending(h.d.x, h.d.y, (ctrl >> 2) & 31u);
+			if (n_end > 1u) {   // several reads ending in one column (rare): their slots come out of the hot line -- a VALU -> SGPR
+			                    // transfer, kept out of the common path (volatile: must not be hoisted above this branch)
+				uint32_t s1;
+				asm volatile("s_nop 0\n\tv_readfirstlane_b32 %0, %1" : "=s"(s1) : "v"(h.d.z));
+				ending(h.d.z, h.d.w, s1 & 255u);
+				if (n_end > 2u) {   // the third lies in the row's second line
+					const slot_u32x2 e2 = *(slot_cptr2)((unsigned long long)(rows + ci) + 64);
+					ending(e2[0], e2[1], e2[0] & 255u);
+				}
+			}
 		}
 	};
 	{
-		// two columns per trip: each column's hot line is requested while the previous column is evaluated, without register copies
+		// two columns per trip: each column's hot line is requested while the previous column is evaluated, without register
+		// copies; the control byte of column c is byte c of the 16 control words (static word index: four columns per word)
 		const uint32_t nc = (P.dbg_flags & 4u) ? 1u : ncols;
 		HotLine ha = load_hot(0), hb;
-		for (uint32_t ci = 0; ci < nc; ci += 2) {
-			hb = load_hot(ci + 1u);        // (one line beyond the run may be read: the LDS area has room, the value is not used)
-			column(ha, ci);
+		for (uint32_t ci = 0; ci < nc; ci += 4u) {
+			// control word of columns ci .. ci + 3: the head of the queue of 16 words held in SGPRs (rotated with scalar moves;
+			// a dynamically indexed register array would go through VGPRs or scratch)
+			const uint32_t cw = ctrlq[0];
+			ctrlq = __builtin_shufflevector(ctrlq, ctrlq, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 0);
+			hb = load_hot(ci + 1u);
+			column(ha, ci, cw & 255u);
 			if (ci + 1u >= nc) break;
 			ha = load_hot(ci + 2u);
-			column(hb, ci + 1u);
+			column(hb, ci + 1u, (cw >> 8) & 255u);
+			if (ci + 2u >= nc) break;
+			hb = load_hot(ci + 3u);
+			column(ha, ci + 2u, (cw >> 16) & 255u);
+			if (ci + 3u >= nc) break;
+			ha = load_hot(ci + 4u);
+			column(hb, ci + 3u, cw >> 24);
 		}
 	}
 

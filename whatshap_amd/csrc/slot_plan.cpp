@@ -225,6 +225,13 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 		SlotRun run{};
 		run.c0 = c; run.ncols = d.ncols; run.g = g; run.L = L; run.lw = d.lw;
 		run.kind = 2;
+		run.ctrl_off = (uint32_t)plan.ctrl.size();
+		plan.ctrl.resize(plan.ctrl.size() + SLOT_CTRL_WORDS, 0);
+		for (uint32_t i = 0; i < d.ncols; ++i) {
+			const SlotRow& rw = plan.rows[rows_mark + i];
+			const uint32_t byte = rw.n_end | ((rw.n_end ? (rw.end[0].info & 31u) : 0u) << 2);
+			plan.ctrl[run.ctrl_off + (i >> 2)] |= byte << ((i & 3u) * 8u);
+		}
 		run.lr = (uint32_t)lr;
 		run.row_off = (uint32_t)rows_mark;
 		run.n_ends = 0;

@@ -68,6 +68,7 @@ struct SlotRow {
 };
 static_assert(SLOT_LR == 3 && SLOT_LANE == 6 && SLOT_MAXEND == 3, "hot layout of SlotRow: 2 + 3 + 6 + 1 + 4 dwords in the first line");
 static_assert(sizeof(SlotRow) == 256, "SlotRow must stay 64 dwords");
+constexpr int SLOT_CTRL_WORDS = 16;  // control bytes of a run's columns (SLOT_MAXCOLS bytes)
 constexpr int SLOT_ROW_PAD = 64;     // rows appended to the array: the kernel touches a fixed number of rows to warm the scalar cache
 
 // One run, passed to the kernel by value.
@@ -78,7 +79,7 @@ struct SlotRun {
 	uint32_t in_occ, in_identity, in_half, in_mirror_pos;  // entry: occupied slots; 1: entry index == P & in_occ; the entering column was
 	                                 // written by a halved run: entries whose bit in_mirror_pos is set are read at index ^ in_fullmask
 	uint32_t in_fullmask, out_occ, mirror_out, out_fullmask;  // exit: occupied slots; 1: also store the mirror image (index ^ out_fullmask)
-	uint32_t kind, lr, pad[2];       // lr: reg slots of this run (cells per thread = 2^lr)
+	uint32_t kind, lr, ctrl_off, pad;   // lr: reg slots of this run (cells per thread = 2^lr); ctrl_off: the run's first word in slot_ctrl
 	uint32_t in_pos[8];              // entry index bit of every occupied slot, one byte each (when !in_identity)
 	uint32_t out_pos[8];             // exit index bit of every occupied slot, one byte each
 	// (words, not byte arrays: the kernel reads them with static indices out of SGPRs; see slot_pos / slot_set_pos)
@@ -127,6 +128,8 @@ struct SlotPlan {
 	std::vector<uint32_t> end_off;           // per run: first byte in end_slots
 	std::vector<uint32_t> f_exit;            // per run: bits of the logical exit index
 	std::vector<std::vector<uint8_t>> exit_slot;  // per run: slot of the read at bit j of the logical exit index
+	std::vector<uint32_t> ctrl;              // per run SLOT_CTRL_WORDS words (SlotRun::ctrl_off): one byte per column, n_end | slot of
+	                                         // the first ending read << 2 -- what steers the kernel's control flow, kept in SGPRs
 	std::vector<int32_t> col_to_row;         // [n_cols] index into rows or -1
 	std::vector<uint32_t> component_first_step;
 	uint64_t n_run_columns = 0;
