@@ -1,0 +1,17 @@
+"""In-kernel cycle stamps of the slot-run kernel (WHAMD_SLOT_STAMPS=1), for the variants of WHAMD_SLOT_SKIP."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["WHAMD_SLOT_STAMPS"] = "1"
+from whatshap_amd import _native
+from whatshap_amd.synthetic import synthetic_block
+
+p = synthetic_block(int(sys.argv[1]) if len(sys.argv) > 1 else 20000, 20, seed=3)
+for skip, options in ((0, ()), (3, ()), (11, ()), (27, ()), (0, (("slot_r", "3"),)), (11, (("slot_r", "3"),))):
+    os.environ["WHAMD_SLOT_SKIP"] = str(skip)
+    t = _native.NativeTable(p, solve=False)
+    for k, v in options:
+        t.set_option(k, v)
+    t.solve()
+    print(f"-- skip {skip} {options}: forward {t.stats()['forward_ms']:.2f} ms / {t.stats()['forward_launches']} launches", file=sys.stderr, flush=True)
+    t.solve()
+    t.close()

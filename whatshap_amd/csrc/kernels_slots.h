@@ -86,6 +86,7 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
                                               uint32_t* __restrict__ cur, const uint32_t w, uint32_t* score_out) {
 	constexpr int R = 1 << LR;
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];   // wave-slot exchange: 2 x [threads][R]
+	const unsigned long long t_start = P.dbg ? __builtin_readcyclecounter() : 0ull;
 	const uint32_t tid = threadIdx.x, lane = tid & 63u;
 	const uint32_t wave = uni(tid >> 6);
 	const uint32_t L = run.L;
@@ -94,38 +95,39 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 	const SlotRow* __restrict__ rows = P.slot_rows + run.row_off;
 	const uint32_t ncols = run.ncols;
 
-	// ---- prologue: one batch of loads.  (1) lane c of every wave fetches the cold part of column c and prepares
-	// A = Cp + (deltas of the set grid / wave slots) for it; the column loop picks it up with v_readlane
-	uint32_t Avec = 0;
+	// ---- prologue: ONE batch of global loads, issued before anything waits (vector loads return in order, so the first
+	// consumers below wait only for what was issued first).
+	// (1) lane c of every wave fetches the cold part of column c (slots 8 .. 25 and Cp, five 16-byte loads) to prepare
+	//     A = Cp + (deltas of the set grid / wave slots) of that column
+	uint4 cold[5];
 	{
 		const uint32_t cl = lane < ncols ? lane : 0u;
-		const SlotRow* __restrict__ rr = rows + cl;
-		const uint32_t Pu = (w << L) | (wave << (6 + LR));   // the wave-uniform part of the physical index
-		uint32_t acc = rr->Cp;
+		const uint4* __restrict__ cq = reinterpret_cast<const uint4*>(rows + cl) + 10;   // dwords 40 .. 59: dslot[8 .. 25], Cp, pad
 #pragma unroll
-		for (int s = LR + 6; s < SLOT_MAXSLOTS; ++s) acc += ((Pu >> s) & 1u) ? (uint32_t)rr->dslot[s] : 0u;   // slots >= L + g: bit and delta are 0
-		Avec = acc;
+		for (int q = 0; q < 5; ++q) cold[q] = cq[q];
 	}
-	// (2) the entering cells
-	uint32_t D[R];
+	// (2) one 16-byte piece of the hot lines per thread (they go to LDS below)
+	uint4 hot_piece = make_uint4(0, 0, 0, 0);
+	if (tid < ncols * 4u) hot_piece = reinterpret_cast<const uint4*>(rows + (tid >> 2))[tid & 3u];
+	// (3) the entering cells: raw loads only (nothing consumes them before the hot lines and the lane sums are in LDS)
+	uint32_t Draw[R];
+	bool flip = false;
 	if (run.has_prev) {
 		const uint32_t occ = run.in_occ;
 		if (run.in_identity && (occ & (uint32_t)(R - 1)) == (uint32_t)(R - 1) && (!run.in_half || run.in_mirror_pos >= (uint32_t)LR)) {
 			// the previous run stored in this run's physical order: R contiguous entries per thread; after a halved run
 			// the entries whose mirror bit is set come from the complement index, i.e. the mirrored group in reverse
 			uint32_t base = Pthr & occ;
-			const bool flip = run.in_half && ((base >> run.in_mirror_pos) & 1u);
+			flip = run.in_half && ((base >> run.in_mirror_pos) & 1u);
 			if (flip) base = (base ^ run.in_fullmask) & ~(uint32_t)(R - 1);
-			uint32_t v[R];
 #pragma unroll
 			for (int q = 0; q < R / 4; ++q) {
 				const uint4 t = *reinterpret_cast<const uint4*>(prev + base + 4 * q);
-				v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+				Draw[4 * q] = t.x; Draw[4 * q + 1] = t.y; Draw[4 * q + 2] = t.z; Draw[4 * q + 3] = t.w;
 			}
-#pragma unroll
-			for (int r = 0; r < R; ++r) D[r] = flip ? v[R - 1 - r] : v[r];
 		} else {
-			// any layout (after a per-column step: logical order): index bit by bit, tables in SGPRs, static slot indices
+			// any layout (the writer's order inside this workgroup's block; logical order after a per-column step): index bit by
+			// bit, tables in SGPRs, static slot indices
 			uint32_t pos[SLOT_MAXSLOTS];
 #pragma unroll
 			for (int s = 0; s < SLOT_MAXSLOTS; ++s) pos[s] = run.in_identity ? (uint32_t)s : slot_pos_dev(run.in_pos, s);
@@ -139,60 +141,92 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 				for (int s = 0; s < LR; ++s)
 					if ((r >> s) & 1) idx |= ((occ >> s) & 1u) << pos[s];
 				if (run.in_half && ((idx >> run.in_mirror_pos) & 1u)) idx ^= run.in_fullmask;
-				D[r] = prev[idx];
+				Draw[r] = prev[idx];
 			}
 		}
 	} else {
 #pragma unroll
-		for (int r = 0; r < R; ++r) D[r] = 0;
+		for (int r = 0; r < R; ++r) Draw[r] = 0;
 	}
-	// (3) the hot lines of the run's columns go to LDS (one 16-byte piece per thread).  The column loop reads them back with
-	// uniform-address ds_read_b128 one column ahead: LDS returns in order (lgkmcnt), so the read of the next column stays in
-	// flight while this one is evaluated -- scalar loads cannot do that (they return out of order: every wait drains them all,
-	// and even a scalar-cache hit costs ~300 cycles), and v_readlane broadcasts cost ~35 cycles each.
+	// The hot lines of the run's columns go to LDS.  The column loop reads them back with uniform-address LDS reads one column
+	// ahead: LDS returns in order (lgkmcnt), so the read of the next column stays in flight while this one is evaluated --
+	// scalar loads cannot do that (they return out of order: every wait drains them all, and even a scalar-cache hit costs
+	// ~300 cycles), and v_readlane broadcasts cost ~35 cycles each.
 	uint32_t* hot_lds = smem + 2u * run.threads * R;
-	for (uint32_t i = tid; i < ncols * 4u; i += run.threads)
+	if (tid < ncols * 4u) reinterpret_cast<uint4*>(hot_lds)[tid] = hot_piece;
+	for (uint32_t i = tid + run.threads; i < ncols * 4u; i += run.threads)   // narrow workgroups, long runs
 		reinterpret_cast<uint4*>(hot_lds)[i] = reinterpret_cast<const uint4*>(rows + (i >> 2))[i & 3u];
+	uint32_t Avec;
+	{
+		const uint32_t Pu = (w << L) | (wave << (6 + LR));   // the wave-uniform part of the physical index
+		const uint32_t dv[20] = {cold[0].x, cold[0].y, cold[0].z, cold[0].w, cold[1].x, cold[1].y, cold[1].z, cold[1].w, cold[2].x, cold[2].y,
+		                         cold[2].z, cold[2].w, cold[3].x, cold[3].y, cold[3].z, cold[3].w, cold[4].x, cold[4].y, cold[4].z, cold[4].w};
+		uint32_t acc = dv[18];   // Cp
+#pragma unroll
+		for (int s2 = LR + 6; s2 < SLOT_MAXSLOTS; ++s2) acc += dv[s2 - 8] & (0u - ((Pu >> s2) & 1u));   // slots >= L + g: bit and delta are 0
+		Avec = acc;
+	}
 	// ... and so does A of every column, one 64-entry row per wave: a VALU -> SGPR transfer (v_readlane, v_readfirstlane)
 	// costs ~35 cycles of issue, so nothing on the column chain goes that way.  What steers control flow (does a read end in
 	// this column, in which slot) comes from the run's control bytes, loaded once into SGPRs.
 	uint32_t* a_lds = hot_lds + (SLOT_MAXCOLS + 2) * 16 + wave * 64u;
 	a_lds[lane] = Avec;
+	uint32_t* sl_lds = hot_lds + (SLOT_MAXCOLS + 2) * 16 + 8 * 64;   // [column][lane]: lane part of S, the same for every wave
 	slot_u32x16 ctrlq = *(slot_cptr16)(unsigned long long)(P.slot_ctrl + run.ctrl_off);
-	// per-lane constants of the column loop
-	int32_t lanebit[SLOT_LANE];
-#pragma unroll
-	for (int j = 0; j < SLOT_LANE; ++j) lanebit[j] = (int32_t)((lane >> j) & 1u);
 	uint8_t* __restrict__ rec = P.bt + (((unsigned long long)run.rec_hi << 32) | run.rec_lo) + (size_t)w * run.n_ends * run.threads + tid;
 	const uint32_t threads = run.threads;
 	const uint32_t xwords = threads * R;   // one exchange buffer
 	uint32_t xsel = 0;
+	const unsigned long long t_issued = P.dbg ? __builtin_readcyclecounter() : 0ull;
 	__syncthreads();
+	// The lane part of S(column, lane) = sum of the deltas of the lane slots whose bit is set in `lane` does not depend on the
+	// wave: the waves share the columns (wave v: columns v, v + #waves, ...) and leave the sums in LDS -- one 4-byte read per
+	// column and thread on the chain instead of six multiply-adds fed by six broadcast words.
+	{
+		int32_t lanebit[SLOT_LANE];
+#pragma unroll
+		for (int j = 0; j < SLOT_LANE; ++j) lanebit[j] = (int32_t)((lane >> j) & 1u);
+		const uint32_t nw = threads >> 6;
+		for (uint32_t c = wave; c < ncols; c += nw) {
+			const uint4* hl = reinterpret_cast<const uint4*>(hot_lds + c * 16u);
+			const uint4 b = hl[1], cc = hl[2];
+			const uint32_t dl[SLOT_LANE] = {b.y, b.z, b.w, cc.x, cc.y, cc.z};
+			uint32_t acc = 0;
+#pragma unroll
+			for (int j = 0; j < SLOT_LANE; ++j) acc += (uint32_t)__mul24(lanebit[j], (int32_t)dl[j]);   // |delta| < 2^22
+			sl_lds[c * 64u + lane] = acc;
+		}
+	}
+	__syncthreads();
+	uint32_t D[R];
+#pragma unroll
+	for (int r = 0; r < R; ++r) D[r] = flip ? Draw[R - 1 - r] : Draw[r];
+	if (P.dbg) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	const unsigned long long t_loaded = P.dbg ? __builtin_readcyclecounter() + (D[0] & 0u) : 0ull;
 
-	struct HotLine { uint4 a, b, c, d; uint32_t A; };   // dwords of SlotRow: 0 K, 1 Cc, 2.. dreg, 5.. dlane, 11 n_end, 12 info0, 13 M0, 14 info1, 15 M1
+	// What a column needs from LDS, requested one column ahead: {K, Cc, dreg0, dreg1} (+ dreg2), {info0, M0} of the first ending
+	// read (wave-uniform words in VECTOR registers: operands of the cell arithmetic as they are) and the thread's own A.
+	struct HotLine { uint4 a; uint32_t d2; uint2 e; uint32_t A; };
 	auto load_hot = [&](uint32_t c) -> HotLine {
-		// (the offset goes through an opaque move: the compiler must not learn that these loads are wave-uniform, or it selects
+		// (offsets go through an opaque move: the compiler must not learn that these loads are wave-uniform, or it selects
 		// scalar instructions for what is derived from them and pays a v_readfirstlane for every operand)
 		uint32_t off = c * 16u;
 		asm volatile("" : "+v"(off));
-		const uint4* hl = reinterpret_cast<const uint4*>(hot_lds + off);
 		HotLine h;
-		h.a = hl[0]; h.b = hl[1]; h.c = hl[2]; h.d = hl[3];
+		h.a = *reinterpret_cast<const uint4*>(hot_lds + off);
+		h.d2 = LR > 2 ? hot_lds[off + 4u] : 0u;
+		h.e = *reinterpret_cast<const uint2*>(hot_lds + off + 12u);
 		uint32_t aoff = c & 63u;
 		asm volatile("" : "+v"(aoff));
-		h.A = a_lds[aoff];
+		h.A = a_lds[aoff] + sl_lds[(c & 63u) * 64u + lane];
 		return h;
 	};
 	// One column for the calling thread's cells.  The hot words are wave-uniform values in VECTOR registers: operands of the
 	// cell arithmetic as they are; only what steers control flow (n_end, the ending read's slot) becomes scalar.
 	auto column = [&](const HotLine& h, const uint32_t ci, const uint32_t ctrl) {
 		const uint32_t K = h.a.x, Cc = h.a.y;
-		const uint32_t dl[SLOT_LANE] = {h.b.y, h.b.z, h.b.w, h.c.x, h.c.y, h.c.z};
-		const uint32_t dr[SLOT_LR] = {h.a.z, h.a.w, h.b.x};
-		uint32_t A = h.A;
-		// lane part of S: one 24-bit multiply-add per lane slot (|delta| < 2^22, lane bit 0 / 1)
-#pragma unroll
-		for (int j = 0; j < SLOT_LANE; ++j) asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(A) : "v"(lanebit[j]), "v"(dl[j]));
+		const uint32_t dr[SLOT_LR] = {h.a.z, h.a.w, h.d2};
+		const uint32_t A = h.A;
 		uint32_t Ar[R];
 		Ar[0] = A;
 #pragma unroll
@@ -240,12 +274,15 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 			rec += threads;
 		};
 		if (n_end) {
-			ending(h.d.x, h.d.y, (ctrl >> 2) & 31u);
+			ending(h.e.x, h.e.y, (ctrl >> 2) & 31u);
 			if (n_end > 1u) {   // several reads ending in one column (rare): their slots come out of the hot line -- a VALU -> SGPR
 			                    // transfer, kept out of the common path (volatile: must not be hoisted above this branch)
+				uint32_t off1 = ci * 16u + 14u;
+				asm volatile("" : "+v"(off1));
+				const uint2 e1 = *reinterpret_cast<const uint2*>(hot_lds + off1);
 				uint32_t s1;
-				asm volatile("s_nop 0\n\tv_readfirstlane_b32 %0, %1" : "=s"(s1) : "v"(h.d.z));
-				ending(h.d.z, h.d.w, s1 & 255u);
+				asm volatile("s_nop 0\n\tv_readfirstlane_b32 %0, %1" : "=s"(s1) : "v"(e1.x));
+				ending(e1.x, e1.y, s1 & 255u);
 				if (n_end > 2u) {   // the third lies in the row's second line
 					const slot_u32x2 e2 = *(slot_cptr2)((unsigned long long)(rows + ci) + 64);
 					ending(e2[0], e2[1], e2[0] & 255u);
@@ -277,6 +314,7 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 		}
 	}
 
+	const unsigned long long t_loop = P.dbg ? __builtin_readcyclecounter() + (D[0] & 0u) : 0ull;
 	// ---- exit: scatter into the next step's order (cells whose free-slot bits are zero hold the representatives)
 	{
 		const uint32_t occ = run.out_occ;
@@ -331,6 +369,10 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 		}
 	}
 	if (score_out && w == 0 && tid == 0) *score_out = D[0];
+	if (P.dbg && w == 0 && tid == 0) {
+		unsigned long long* d = P.dbg + (size_t)run.pad * 8;
+		d[0] = t_issued - t_start; d[1] = t_loaded - t_start; d[2] = t_loop - t_loaded; d[3] = __builtin_readcyclecounter() - t_loop; d[4] = ncols; d[5] = 1;
+	}
 }
 
 template <int LR>
