@@ -417,7 +417,8 @@ def main():
         bytes_rank = sum(s["algorithmic_bytes"] for s in stats)
         bytes_per_launch = bytes_rank / max(launches / args.steps, 1)
         column_path = args.path in ("column", "column_keys")
-        kernel = ("column_step_fused" if column_path else ("resident_segment_ped" if args.trio else "resident_segment"))
+        kernel = ("column_step_fused" if column_path else ("resident_segment_ped" if args.trio else
+                  ("resident_segment" if args.path == "resident" else "slot_run")))
         out = {
             "metric": "variant-columns/sec at max-coverage %d (bipartition-costs/sec reported alongside)" % args.coverage,
             "value": cols_job * args.steps / elapsed,

@@ -322,7 +322,7 @@ whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uin
 			ok = ok && ends == run.n_ends;
 			s.max_run_columns = std::max<uint64_t>(s.max_run_columns, run.ncols);
 			s.max_workgroups = std::max<uint64_t>(s.max_workgroups, 1ull << (run.g - run.half));
-			s.max_lds_bytes = std::max<uint64_t>(s.max_lds_bytes, 2ull * run.threads * (1u << run.lr) * 4 + (SLOT_MAXCOLS + 2) * 64 + 8 * 64 * 4 + SLOT_MAXCOLS * 64 * 4);
+			s.max_lds_bytes = std::max<uint64_t>(s.max_lds_bytes, 2ull * run.threads * (1u << run.lr) * 4 + (SLOT_MAXCOLS + 8) * 64 + 8 * 64 * 4 + SLOT_MAXCOLS * 64 * 4);
 			if (run.half) s.n_halved_runs++;
 			s.n_resident_columns += run.ncols;
 			s.n_vectorised_columns += run.ncols;

@@ -569,7 +569,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 					e.prev = lane.d_pr[c.flip];
 					e.cur = lane.d_pr[c.flip ^ 1];
 					e.score_out = (last && !job.final) ? m.d_job_scores + job_id : nullptr;
-					ss.lds = std::max<size_t>(ss.lds, (size_t)2 * e.run.threads * (1u << e.run.lr) * 4 + (SLOT_MAXCOLS + 2) * 64 + 8 * 64 * 4 + SLOT_MAXCOLS * 64 * 4);
+					ss.lds = std::max<size_t>(ss.lds, (size_t)2 * e.run.threads * (1u << e.run.lr) * 4 + (SLOT_MAXCOLS + 8) * 64 + 8 * 64 * 4 + SLOT_MAXCOLS * 64 * 4);
 					ss.grid_x = std::max(ss.grid_x, 1u << (e.run.g - e.run.half));
 					ss.threads = std::max(ss.threads, e.run.threads);
 					m.slot_entries.push_back(e);
@@ -640,11 +640,11 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	}
 	if (getenv("WHAMD_SLOT_STAMPS") && m.use_slots) {   // in-kernel cycle stamps of workgroup 0 / wave 0 of every slot run
 		void* d_dbg = nullptr;
-		const size_t dbg_bytes = (m.splan.runs.size() + 1) * 64 + 4 * 512 * 16 + 128;   // + the backtrace kernel's own stamps
+		const size_t dbg_bytes = (m.splan.runs.size() + 1) * 48 * 8 + 4 * 512 * 16 + 128;   // + the backtrace kernel's own stamps
 		HIP_TRY(alloc(&d_dbg, dbg_bytes));
 		HIP_TRY(hipMemset(d_dbg, 0, dbg_bytes));
 		m.dp.dbg = (unsigned long long*)d_dbg;
-		m.dp.dbg_wg_off = (uint32_t)((m.splan.runs.size() + 1) * 8);
+		m.dp.dbg_wg_off = (uint32_t)((m.splan.runs.size() + 1) * 48);
 		for (size_t i = 0; i < m.slot_entries.size(); ++i) m.slot_entries[i].run.pad = (uint32_t)i;
 	}
 	if (const char* skip = getenv("WHAMD_SLOT_SKIP")) m.dp.dbg_flags = (uint32_t)atoi(skip);  // timing experiments (results invalid): 1 no exit
@@ -727,10 +727,16 @@ void DeviceTable::Impl::launch_run(const ResBatchEntry& e, uint32_t step_index, 
 void DeviceTable::Impl::launch_slot_run(const SlotBatchEntry& e, uint64_t& launches) {
 	Impl& m = *this;
 	const SlotRun& run = e.run;
-	const size_t lds = (size_t)2 * run.threads * (1u << run.lr) * 4 + (SLOT_MAXCOLS + 2) * 64 + 8 * 64 * 4 + SLOT_MAXCOLS * 64 * 4;   // wave-slot exchange + hot lines + per-wave A + lane sums
+	const size_t lds = (size_t)2 * run.threads * (1u << run.lr) * 4 + (SLOT_MAXCOLS + 8) * 64 + 8 * 64 * 4 + SLOT_MAXCOLS * 64 * 4;   // wave-slot exchange + hot lines + per-wave A + lane sums
 	const dim3 grid(1u << (run.g - run.half)), block(run.threads);
-	if (run.lr == 3) hipLaunchKernelGGL(slot_run<3>, grid, block, lds, m.stream, m.dp, run, e.prev, e.cur, e.score_out);
-	else hipLaunchKernelGGL(slot_run<2>, grid, block, lds, m.stream, m.dp, run, e.prev, e.cur, e.score_out);
+	const bool dbg = m.dp.dbg != nullptr || m.dp.dbg_flags != 0;
+	if (run.lr == 3) {
+		if (dbg) hipLaunchKernelGGL((slot_run<3, true>), grid, block, lds, m.stream, m.dp, run, e.prev, e.cur, e.score_out);
+		else hipLaunchKernelGGL((slot_run<3, false>), grid, block, lds, m.stream, m.dp, run, e.prev, e.cur, e.score_out);
+	} else {
+		if (dbg) hipLaunchKernelGGL((slot_run<2, true>), grid, block, lds, m.stream, m.dp, run, e.prev, e.cur, e.score_out);
+		else hipLaunchKernelGGL((slot_run<2, false>), grid, block, lds, m.stream, m.dp, run, e.prev, e.cur, e.score_out);
+	}
 	launches += 1;
 }
 
@@ -849,17 +855,24 @@ whamd_status_t DeviceTable::wait(const Problem& p, Solution& s, whamd_solve_stat
 	st.total_ms = f03;
 	st.forward_launches = launches;
 	if (m.dp.dbg && m.use_slots) {
-		std::vector<unsigned long long> d(m.splan.runs.size() * 8);
+		std::vector<unsigned long long> d(m.splan.runs.size() * 48);
 		HIP_TRY(hipMemcpy(d.data(), m.dp.dbg, d.size() * 8, hipMemcpyDeviceToHost));
 		double a[6] = {0, 0, 0, 0, 0, 0};
+		double percol[32] = {0};
 		size_t cnt = 0;
 		for (size_t i = 0; i < m.splan.runs.size(); ++i) {
-			if (m.splan.runs[i].ncols < 16 || d[8 * i + 5] == 0) continue;   // full-length runs only
-			for (int k = 0; k < 6; ++k) a[k] += (double)d[8 * i + k];
+			if (m.splan.runs[i].ncols != 22 || d[48 * i + 5] == 0) continue;   // full-length runs only
+			for (int k = 0; k < 6; ++k) a[k] += (double)d[48 * i + k];
+			for (int k = 0; k < 22; ++k) percol[k] += (double)d[48 * i + 8 + k];
 			++cnt;
 		}
 		if (cnt) fprintf(stderr, "[whamd slot stamps] %zu runs, wave 0 of workgroup 0, shader cycles: prologue issue %.0f, loads landed %.0f, column loop %.0f (%.1f per column, %.1f columns), exit %.0f\n",
 		                 cnt, a[0] / cnt, a[1] / cnt, a[2] / cnt, a[2] / std::max(a[4], 1.0), a[4] / cnt, a[3] / cnt);
+		if (cnt) {
+			fprintf(stderr, "[whamd slot stamps] cycles after the loop start at which column c had its cost added:");
+			for (int k = 0; k < 22; ++k) fprintf(stderr, " %.0f", percol[k] / cnt);
+			fprintf(stderr, "\n");
+		}
 	}
 	if (m.dp.dbg && !m.plan.segments.empty()) {
 		std::vector<unsigned long long> d(m.plan.segments.size() * 8);

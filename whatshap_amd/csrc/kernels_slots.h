@@ -81,12 +81,12 @@ __device__ __forceinline__ void slot_touch_rows(const SlotRow* rows) {
 // byte s of a packed position table held in SGPRs (static s)
 __device__ __forceinline__ uint32_t slot_pos_dev(const uint32_t (&w)[8], int s) { return (w[s >> 2] >> ((s & 3) * 8)) & 31u; }
 
-template <int LR>
+template <int LR, bool DBG>
 __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun& run, const uint32_t* __restrict__ prev,
                                               uint32_t* __restrict__ cur, const uint32_t w, uint32_t* score_out) {
 	constexpr int R = 1 << LR;
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];   // wave-slot exchange: 2 x [threads][R]
-	const unsigned long long t_start = P.dbg ? __builtin_readcyclecounter() : 0ull;
+	const unsigned long long t_start = (DBG && P.dbg) ? __builtin_readcyclecounter() : 0ull;
 	const uint32_t tid = threadIdx.x, lane = tid & 63u;
 	const uint32_t wave = uni(tid >> 6);
 	const uint32_t L = run.L;
@@ -169,15 +169,15 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 	// ... and so does A of every column, one 64-entry row per wave: a VALU -> SGPR transfer (v_readlane, v_readfirstlane)
 	// costs ~35 cycles of issue, so nothing on the column chain goes that way.  What steers control flow (does a read end in
 	// this column, in which slot) comes from the run's control bytes, loaded once into SGPRs.
-	uint32_t* a_lds = hot_lds + (SLOT_MAXCOLS + 2) * 16 + wave * 64u;
+	uint32_t* a_lds = hot_lds + (SLOT_MAXCOLS + 8) * 16 + wave * 64u;
 	a_lds[lane] = Avec;
-	uint32_t* sl_lds = hot_lds + (SLOT_MAXCOLS + 2) * 16 + 8 * 64;   // [column][lane]: lane part of S, the same for every wave
+	uint32_t* sl_lds = hot_lds + (SLOT_MAXCOLS + 8) * 16 + 8 * 64;   // [column][lane]: lane part of S, the same for every wave
 	slot_u32x16 ctrlq = *(slot_cptr16)(unsigned long long)(P.slot_ctrl + run.ctrl_off);
 	uint8_t* __restrict__ rec = P.bt + (((unsigned long long)run.rec_hi << 32) | run.rec_lo) + (size_t)w * run.n_ends * run.threads + tid;
 	const uint32_t threads = run.threads;
 	const uint32_t xwords = threads * R;   // one exchange buffer
 	uint32_t xsel = 0;
-	const unsigned long long t_issued = P.dbg ? __builtin_readcyclecounter() : 0ull;
+	const unsigned long long t_issued = (DBG && P.dbg) ? __builtin_readcyclecounter() : 0ull;
 	__syncthreads();
 	// The lane part of S(column, lane) = sum of the deltas of the lane slots whose bit is set in `lane` does not depend on the
 	// wave: the waves share the columns (wave v: columns v, v + #waves, ...) and leave the sums in LDS -- one 4-byte read per
@@ -201,8 +201,8 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 	uint32_t D[R];
 #pragma unroll
 	for (int r = 0; r < R; ++r) D[r] = flip ? Draw[R - 1 - r] : Draw[r];
-	if (P.dbg) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-	const unsigned long long t_loaded = P.dbg ? __builtin_readcyclecounter() + (D[0] & 0u) : 0ull;
+	if (DBG && P.dbg) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	const unsigned long long t_loaded = (DBG && P.dbg) ? __builtin_readcyclecounter() + (D[0] & 0u) : 0ull;
 
 	// What a column needs from LDS, requested one column ahead: {K, Cc, dreg0, dreg1} (+ dreg2), {info0, M0} of the first ending
 	// read (wave-uniform words in VECTOR registers: operands of the cell arithmetic as they are) and the thread's own A.
@@ -233,7 +233,7 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 		for (int r = 1; r < R; ++r) Ar[r] = Ar[r & (r - 1)] + dr[__builtin_ctz(r)];   // clear the lowest set bit: one add per cell
 #pragma unroll
 		for (int r = 0; r < R; ++r) D[r] += slot_cost(Ar[r], K, Cc);
-		const uint32_t n_end = (P.dbg_flags & 8u) ? 0u : (ctrl & 3u);
+		const uint32_t n_end = (DBG && (P.dbg_flags & 8u)) ? 0u : (ctrl & 3u);
 		// one ending read: `slot` is a scalar (control flow), info / M are wave-uniform vector values
 		auto ending = [&](const uint32_t info, const uint32_t M, const uint32_t slot) {
 			const uint32_t qmask = (info >> 8) & 0xFFFFu, mflip = (info >> 24) & 1u;
@@ -270,9 +270,10 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 				takes = slot_end_partner<LR>(D, other, qthr, qmask);
 				xsel ^= 1u;
 			}
-			if (!(P.dbg_flags & 2u)) *rec = (uint8_t)takes;
+			if (!(DBG && (P.dbg_flags & 2u))) *rec = (uint8_t)takes;
 			rec += threads;
 		};
+		if (DBG && P.dbg && w == 0 && tid == 0 && ci < 32u) P.dbg[(size_t)run.pad * 48 + 8 + ci] = __builtin_readcyclecounter() - t_loaded;
 		if (n_end) {
 			ending(h.e.x, h.e.y, (ctrl >> 2) & 31u);
 			if (n_end > 1u) {   // several reads ending in one column (rare): their slots come out of the hot line -- a VALU -> SGPR
@@ -293,28 +294,30 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 	{
 		// two columns per trip: each column's hot line is requested while the previous column is evaluated, without register
 		// copies; the control byte of column c is byte c of the 16 control words (static word index: four columns per word)
-		const uint32_t nc = (P.dbg_flags & 4u) ? 1u : ncols;
-		HotLine ha = load_hot(0), hb;
+		const uint32_t nc = (DBG && (P.dbg_flags & 4u)) ? 1u : ncols;
+		// four columns per trip (one control word), four line buffers: every line is requested THREE columns ahead (LDS returns
+		// in order, the waits count down) and no register is copied
+		HotLine h0 = load_hot(0), h1 = load_hot(1), h2 = load_hot(2), h3;
 		for (uint32_t ci = 0; ci < nc; ci += 4u) {
 			// control word of columns ci .. ci + 3: the head of the queue of 16 words held in SGPRs (rotated with scalar moves;
 			// a dynamically indexed register array would go through VGPRs or scratch)
 			const uint32_t cw = ctrlq[0];
 			ctrlq = __builtin_shufflevector(ctrlq, ctrlq, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 0);
-			hb = load_hot(ci + 1u);
-			column(ha, ci, cw & 255u);
+			h3 = load_hot(ci + 3u);        // (lines beyond the run may be read: the LDS areas have room, the values are not used)
+			column(h0, ci, cw & 255u);
 			if (ci + 1u >= nc) break;
-			ha = load_hot(ci + 2u);
-			column(hb, ci + 1u, (cw >> 8) & 255u);
+			h0 = load_hot(ci + 4u);
+			column(h1, ci + 1u, (cw >> 8) & 255u);
 			if (ci + 2u >= nc) break;
-			hb = load_hot(ci + 3u);
-			column(ha, ci + 2u, (cw >> 16) & 255u);
+			h1 = load_hot(ci + 5u);
+			column(h2, ci + 2u, (cw >> 16) & 255u);
 			if (ci + 3u >= nc) break;
-			ha = load_hot(ci + 4u);
-			column(hb, ci + 3u, cw >> 24);
+			h2 = load_hot(ci + 6u);
+			column(h3, ci + 3u, cw >> 24);
 		}
 	}
 
-	const unsigned long long t_loop = P.dbg ? __builtin_readcyclecounter() + (D[0] & 0u) : 0ull;
+	const unsigned long long t_loop = (DBG && P.dbg) ? __builtin_readcyclecounter() + (D[0] & 0u) : 0ull;
 	// ---- exit: scatter into the next step's order (cells whose free-slot bits are zero hold the representatives)
 	{
 		const uint32_t occ = run.out_occ;
@@ -341,7 +344,7 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 						writes = writes && ((occ >> s) & 1u);
 					}
 				}
-				if (writes && !(P.dbg_flags & 1u)) {
+				if (writes && !(DBG && (P.dbg_flags & 1u))) {
 					const uint32_t idx = base | x;
 					*reinterpret_cast<uint4*>(cur + idx) = make_uint4(D[r4], D[r4 + 1], D[r4 + 2], D[r4 + 3]);
 					if (run.mirror_out)   // the complement of a group of 4 is a group of 4 in reverse order
@@ -360,7 +363,7 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 						writes = writes && ((occ >> s) & 1u);
 					}
 				}
-				if (writes && !(P.dbg_flags & 1u)) {
+				if (writes && !(DBG && (P.dbg_flags & 1u))) {
 					const uint32_t idx = base | x;
 					cur[idx] = D[r];
 					if (run.mirror_out) cur[idx ^ mirror_x] = D[r];
@@ -369,17 +372,20 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 		}
 	}
 	if (score_out && w == 0 && tid == 0) *score_out = D[0];
-	if (P.dbg && w == 0 && tid == 0) {
-		unsigned long long* d = P.dbg + (size_t)run.pad * 8;
+	if (DBG && P.dbg && w == 0 && tid == 0) {
+		unsigned long long* d = P.dbg + (size_t)run.pad * 48;
 		d[0] = t_issued - t_start; d[1] = t_loaded - t_start; d[2] = t_loop - t_loaded; d[3] = __builtin_readcyclecounter() - t_loop; d[4] = ncols; d[5] = 1;
 	}
 }
 
-template <int LR>
+// DBG: timing experiments (WHAMD_SLOT_SKIP switches parts off -- results invalid) and in-kernel cycle stamps (WHAMD_SLOT_STAMPS);
+// the production instantiation carries none of it (a single wave issues one VALU instruction per ~8 cycles -- measured,
+// scripts/micro/issue_rate.hip -- so every instruction on the column chain counts).
+template <int LR, bool DBG>
 __global__ __launch_bounds__(512) void slot_run(DevProblem P, SlotRun run, const uint32_t* __restrict__ prev, uint32_t* __restrict__ cur,
                                                 uint32_t* __restrict__ score_out) {
 	touch_kernel_arguments<sizeof(DevProblem) + sizeof(SlotRun) + 24>();
-	slot_run_body<LR>(P, run, prev, cur, blockIdx.x, score_out);
+	slot_run_body<LR, DBG>(P, run, prev, cur, blockIdx.x, score_out);
 }
 
 // One launch = the next run of SEVERAL independent jobs (connected components of one table): blockIdx.y selects the entry.
@@ -395,5 +401,5 @@ __global__ __launch_bounds__(512) void slot_batch(DevProblem P, const SlotBatchE
 	}
 	const SlotRun run = e->run;
 	if (blockIdx.x >= (1u << (run.g - run.half)) || threadIdx.x >= run.threads) return;
-	slot_run_body<LR>(P, run, e->prev, e->cur, blockIdx.x, e->score_out);
+	slot_run_body<LR, false>(P, run, e->prev, e->cur, blockIdx.x, e->score_out);
 }
