@@ -133,6 +133,15 @@ struct DeviceTable::Impl {
 	std::vector<SuperStep> schedule;
 	std::vector<ResBatchEntry> entries;
 	ResBatchEntry* d_entries = nullptr;
+	// chunked speculative backtrace (kernels_backtrace.h) of a table made of slot runs
+	bool use_chunks = false;
+	std::vector<BtChunk> chunks;
+	BtChunk* d_chunks = nullptr;
+	uint32_t* d_unit_x = nullptr;
+	uint32_t* d_guess = nullptr;
+	uint32_t* d_bt_counters = nullptr;
+	uint32_t n_spec = 0;
+	size_t chunk_lds = 0;
 	// slot runs (slots.h): the default forward path of a single individual
 	SlotPlan splan;
 	bool use_slots = false;
@@ -478,6 +487,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 				su.g = run.g; su.L = run.L; su.n_ends = run.n_ends; su.threads = run.threads;
 				su.bt_lo = run.rec_lo; su.bt_hi = run.rec_hi; su.half = run.half; su.blob_words = slot_blob_words[st.index];
 				su.f_exit = m.splan.f_exit[st.index];
+				for (uint32_t j = 0; j < su.f_exit && j < 32; ++j) su.exit_pos[j] = (uint8_t)slot_pos(run.out_pos, m.splan.exit_slot[st.index][j]);
 				su.lr = run.lr;
 				for (uint32_t j = 0; j < su.f_exit && j < 32; ++j) su.exit_slot[j] = m.splan.exit_slot[st.index][j];
 				static_assert(sizeof(SlotBtUnit) == sizeof(BtUnit), "unit headers share one array");
@@ -496,12 +506,48 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		job.unit_count = (uint32_t)m.units.size() - job.unit_off;
 		}
 	}
+	// ---- chunks of the speculative backtrace: a new chunk starts at every BT_CHUNK_RUNS-th slot run (single job only)
+	m.use_chunks = false;
+	m.chunks.clear();
+	m.n_spec = 0;
+	for (SlotRun& run : m.splan.runs) run.spec_id = 0;
+	if (m.use_slots && m.jobs.size() == 1 && !getenv("WHAMD_BT_SEQUENTIAL") && m.units.size() > 2u * BT_CHUNK_RUNS) {
+		m.use_chunks = true;
+		BtChunk cur{0, 0, 0, 0};
+		uint32_t runs_in_chunk = 0;
+		for (uint32_t u = 0; u < m.units.size(); ++u) {
+			const bool is_run = m.units[u].kind == 2;
+			if (is_run && runs_in_chunk >= (uint32_t)BT_CHUNK_RUNS && u > 0) {
+				m.chunks.push_back(cur);
+				cur = BtChunk{u, 0, ++m.n_spec, 0};
+				runs_in_chunk = 0;
+				// the run of unit u leaves the seed: units are the job's steps in reverse order
+				const Step& st = m.plan.steps[m.jobs[0].steps[m.jobs[0].steps.size() - 1 - u]];
+				m.splan.runs[st.index].spec_id = m.n_spec;
+			}
+			runs_in_chunk += is_run;
+			++cur.unit_count;
+		}
+		m.chunks.push_back(cur);
+		void *d_chunks = nullptr;
+		HIP_TRY(up(&d_chunks, m.chunks.data(), m.chunks.size() * sizeof(BtChunk)));
+		m.d_chunks = (BtChunk*)d_chunks;
+		HIP_TRY(alloc((void**)&m.d_unit_x, m.units.size() * 4));
+		HIP_TRY(alloc((void**)&m.d_guess, m.chunks.size() * 4));
+		HIP_TRY(alloc((void**)&m.d_bt_counters, 16));
+		void* d_spec = nullptr;
+		HIP_TRY(alloc(&d_spec, ((size_t)m.n_spec + 1) * 8));
+		m.dp.spec_keys = (unsigned long long*)d_spec;
+	} else {
+		m.dp.spec_keys = nullptr;
+	}
 	HIP_TRY(up((void**)&m.d_units, m.units.data(), m.units.size() * sizeof(BtUnit)));
 	{
 		uint32_t max_stage = 0;
 		for (const ResSegment& sgm : m.plan.segments) max_stage = std::max(max_stage, sgm.stage_words);
 		for (const SlotRun& run : m.splan.runs) max_stage = std::max(max_stage, (run.n_ends * run.threads + 7) / 8);
 		m.bt_lds = (size_t)2 * RES_MAXCOLS * 128 + 512 + 16 + (size_t)BT_CELLS * 4 + (size_t)RES_MAXCOLS * 4 + (size_t)max_stage * 8 + 16;
+		m.chunk_lds = (size_t)(32 + 4 + BT_CELLS + SLOT_MAXCOLS * 8 + 32) * 4 + (size_t)max_stage * 8 + 16;
 	}
 	void* d_rtab = nullptr;
 	const bool ped_plan = !m.plan.ped_columns.empty();
@@ -781,6 +827,7 @@ whamd_status_t DeviceTable::enqueue_some_unguarded(const Problem& p, Solution& s
 		}
 		for (const Impl::Lane& lane : m.lanes) HIP_TRY(hipMemsetAsync(lane.d_keys, 0xFF, m.key_entries * 8, m.stream));
 		HIP_TRY(hipMemsetAsync(m.dp.last_keys, 0xFF, (size_t)MAX_T * 8, m.stream));
+		if (m.use_chunks) HIP_TRY(hipMemsetAsync(m.dp.spec_keys, 0xFF, ((size_t)m.n_spec + 1) * 8, m.stream));
 		HIP_TRY(hipEventRecord(m.ev0, m.stream));
 		if (!m.plan.ped_columns.empty()) {
 			const uint32_t entries = (uint32_t)m.plan.ped_columns.size() * PED_TABLE;
@@ -819,6 +866,12 @@ whamd_status_t DeviceTable::enqueue_some_unguarded(const Problem& p, Solution& s
 	if (m.next_super < m.schedule.size()) return WHAMD_OK;
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(m.ev1, m.stream));
+	if (m.use_chunks) {
+		hipLaunchKernelGGL(backtrace_chunks, dim3((uint32_t)m.chunks.size()), dim3(256), m.chunk_lds, m.stream, m.dp, m.d_units, m.d_chunks,
+		                   (uint32_t)m.chunks.size(), 0u, m.d_path_index, m.d_path_trans, m.d_score, m.d_unit_x, m.d_guess, m.d_bt_counters);
+		hipLaunchKernelGGL(backtrace_chunks, dim3(1), dim3(256), m.chunk_lds, m.stream, m.dp, m.d_units, m.d_chunks,
+		                   (uint32_t)m.chunks.size(), 1u, m.d_path_index, m.d_path_trans, m.d_score, m.d_unit_x, m.d_guess, m.d_bt_counters);
+	} else
 	hipLaunchKernelGGL(backtrace_kernel, dim3((uint32_t)m.jobs.size()), dim3(1024), m.bt_lds, m.stream, m.dp, m.d_units, m.d_btjobs,
 	                   m.d_path_index, m.d_path_trans, m.d_score);
 	HIP_TRY(hipGetLastError());
@@ -854,6 +907,11 @@ whamd_status_t DeviceTable::wait(const Problem& p, Solution& s, whamd_solve_stat
 	st.backtrace_ms = f12;
 	st.total_ms = f03;
 	st.forward_launches = launches;
+	if (m.use_chunks && getenv("WHAMD_BT_STATS")) {
+		uint32_t c[2] = {0, 0};
+		HIP_TRY(hipMemcpy(c, m.d_bt_counters, 8, hipMemcpyDeviceToHost));
+		fprintf(stderr, "[whamd backtrace] %zu chunks, %u guesses missed, %u units walked again (of %zu)\n", m.chunks.size(), c[0], c[1], m.units.size());
+	}
 	if (m.dp.dbg && m.use_slots) {
 		std::vector<unsigned long long> d(m.splan.runs.size() * 48);
 		HIP_TRY(hipMemcpy(d.data(), m.dp.dbg, d.size() * 8, hipMemcpyDeviceToHost));

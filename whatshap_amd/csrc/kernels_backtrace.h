@@ -11,7 +11,8 @@
 // P.last_keys), the walk starts at units[1].  == 0: the units are the steps of ONE connected component that ends before
 // the table does (its last column projects onto a single entry): the walk starts at units[0] with entry 0 and no score
 // is written.
-constexpr int BT_CELLS = 128;  // >= RES_MAXCOLS and >= SLOT_MAXENDS_RUN + 1
+constexpr int BT_CELLS = 128;
+constexpr int BT_CHUNK_RUNS = 16;   // slot runs per chunk of the speculative backtrace  // >= RES_MAXCOLS and >= SLOT_MAXENDS_RUN + 1
 
 __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtUnit* __restrict__ all_units, const BtJob* __restrict__ jobs,
                                                          uint32_t* __restrict__ path_index, uint32_t* __restrict__ path_trans,
@@ -352,4 +353,162 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 		unsigned long long* d = P.dbg + P.dbg_wg_off + 4 * 512 * 2;
 		d[0] = bt_load; d[1] = bt_walk; d[2] = bt_runs; d[3] = bt_a; d[4] = bt_b; d[5] = bt_c;
 	}
+}
+
+// ------------------------------------------------------------------------------------------------ chunked backtrace
+// The walk above is one dependent chain over the whole table (a run's record cannot be fetched before the path's
+// workgroup index in that run is known).  For a table made of slot runs the chain is cut into CHUNKS of consecutive
+// units: every chunk but the newest starts from a *guess* of the path's state at its end -- the minimum of the exit
+// column there, left by the forward pass (SlotRun::spec_id) -- and all chunks are walked at once, one workgroup each
+// (mode 0).  A second launch (mode 1, one workgroup) goes over the chunk boundaries newest to oldest: where the state
+// the true path arrives with equals the guess, the chunk's speculative walk IS the true path; where it does not, the
+// chunk is walked again from the true state until the path reaches a state the speculative walk went through at the
+// same unit boundary (from there on the two are identical) or the chunk ends.  By induction the result is exactly
+// the path the sequential walk finds; the guess only decides how much is walked twice.
+struct BtChunk {
+	uint32_t unit_off, unit_count;
+	uint32_t spec_id;   // 0: the newest chunk (units[0] is the table's last column, the optimum comes from P.last_keys)
+	uint32_t pad;
+};
+
+// One unit for the whole workgroup (256 threads): x = logical index of the path at the first column of the unit walked
+// before (later in the table); returns the index at this unit's first column.  Single individual only (no transmission).
+__device__ __forceinline__ uint32_t chunk_walk_unit(const DevProblem& P, const BtUnit* __restrict__ unit, uint32_t x, uint32_t* hdr, uint32_t* blob,
+                                                    uint32_t* cells, uint32_t* xshare, unsigned long long* stage,
+                                                    uint32_t* __restrict__ path_index, uint32_t* __restrict__ path_trans) {
+	const uint32_t tid = threadIdx.x, NT = blockDim.x;
+	__syncthreads();   // the previous unit's readers are done with the LDS areas
+	if (tid < 32) hdr[tid] = reinterpret_cast<const uint32_t*>(unit)[tid];
+	__syncthreads();
+	const uint32_t kind = hdr[0], c0 = hdr[1], ncols = hdr[2];
+	if (kind == 0) {
+		// one column through the column kernels' records (word layout: backtrace_kernel above)
+		const uint32_t cf = hdr[4], cmode = hdr[5], cnplanes = hdr[6], cebits = hdr[7], nsf = hdr[10], nse = hdr[11];
+		const unsigned long long cbt = ((unsigned long long)hdr[9] << 32) | hdr[8];
+		const uint32_t* segs = hdr[28] ? (hdr + 12) : (P.segs + P.cols[c0].seg_off);
+		const uint32_t y = cf >= 32 ? x : (x & ((1u << cf) - 1u));
+		uint32_t xp;
+		if (cmode == 0) {
+			const unsigned long long* planes = reinterpret_cast<const unsigned long long*>(P.bt + cbt);
+			const uint32_t words = 1u << (cf - 6);
+			uint32_t v = 0;
+			for (uint32_t p = 0; p < cnplanes; ++p) v |= (uint32_t)((planes[(size_t)p * words + (y >> 6)] >> (y & 63u)) & 1ull) << p;
+			const uint32_t e = v & ((1u << cebits) - 1u);
+			xp = deposit(y, segs, nsf) | deposit(e, segs + nsf, nse);
+		} else {
+			const uint32_t r = reinterpret_cast<const uint32_t*>(P.bt + cbt)[y] >> 4;
+			xp = r ^ (r >> 1);
+		}
+		if (tid == 0) { path_index[c0] = xp; path_trans[c0] = 0u; }
+		return xp;
+	}
+	// ---- slot run: blob (column slot lists + ending slots), physical exit index, record of the path's workgroup -> LDS
+	const uint32_t g = hdr[4], L = hdr[5], n_ends = hdr[6], threads = hdr[7], f_exit = hdr[12], lr = hdr[13];
+	const uint32_t* __restrict__ gblob = P.slot_blob + hdr[3];
+	for (uint32_t i = tid; i < hdr[11]; i += NT) blob[i] = gblob[i];
+	const uint8_t* exit_slot = reinterpret_cast<const uint8_t*>(hdr + 16);
+	uint32_t pexit = 0;
+	for (uint32_t j = 0; j < f_exit; ++j) pexit |= ((x >> j) & 1u) << exit_slot[j];
+	const uint32_t w = pexit >> L, lmask = (1u << L) - 1u;
+	const bool mirrored = hdr[10] && ((w >> (g - 1u)) & 1u);
+	const uint32_t wrec = mirrored ? (~w & ((1u << g) - 1u)) : w;
+	const uint32_t stage_words = n_ends * threads / 8u;
+	const unsigned long long* __restrict__ gst = reinterpret_cast<const unsigned long long*>(
+		P.bt + (((unsigned long long)hdr[9] << 32) | hdr[8]) + (size_t)wrec * n_ends * threads);
+	for (uint32_t i = tid; i < stage_words; i += NT) stage[i] = gst[i];
+	__syncthreads();
+	const SlotBtCol* bcols = reinterpret_cast<const SlotBtCol*>(blob);
+	if (tid < 64) {   // one wave follows the path: state S[k] = local index after undoing the ending reads k, k + 1, ...
+		const uint8_t* ends = reinterpret_cast<const uint8_t*>(blob + ncols * 8);
+		const uint8_t* stage8 = reinterpret_cast<const uint8_t*>(stage);
+		uint32_t l = pexit & lmask;
+		if (tid == 0) cells[n_ends] = l;
+		for (uint32_t k = n_ends; k-- > 0;) {
+			const uint32_t j = ends[k];
+			const uint32_t look = mirrored ? ((~l & lmask) | (1u << j)) : (l & ~(1u << j));
+			const uint32_t byte = stage8[k * threads + (look >> lr)];
+			l = (l & ~(1u << j)) | (((byte >> (look & ((1u << lr) - 1u))) & 1u) << j);
+			if (tid == 0) cells[k] = l;
+		}
+	}
+	__syncthreads();
+	// logical index of every column: lane j of a wave tests the slot of logical bit j, the ballot is the index
+	for (uint32_t c = tid >> 6; c < ncols; c += NT >> 6) {
+		const SlotBtCol& bc = bcols[c];
+		const uint32_t pc = (w << L) | cells[bc.kf];
+		const uint32_t j = tid & 63u;
+		const bool bit = j < bc.k && j < 28u && ((pc >> bc.slot[j < 28u ? j : 0u]) & 1u);
+		const uint32_t xl = (uint32_t)__ballot(bit);
+		if (j == 0) {
+			path_index[c0 + c] = xl;
+			path_trans[c0 + c] = 0u;
+			if (c == 0) xshare[0] = xl;
+		}
+	}
+	__syncthreads();
+	return xshare[0];
+}
+
+__global__ __launch_bounds__(256) void backtrace_chunks(DevProblem P, const BtUnit* __restrict__ units, const BtChunk* __restrict__ chunks,
+                                                         uint32_t n_chunks, uint32_t mode, uint32_t* __restrict__ path_index,
+                                                         uint32_t* __restrict__ path_trans, uint32_t* __restrict__ out_score,
+                                                         uint32_t* __restrict__ unit_x, uint32_t* __restrict__ guess, uint32_t* __restrict__ counters) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+	uint32_t* hdr = smem;                         // 32 words
+	uint32_t* xshare = hdr + 32;                  // 4 words
+	uint32_t* cells = xshare + 4;                 // BT_CELLS words
+	uint32_t* blob = cells + BT_CELLS;            // SLOT_MAXCOLS * 8 + 32 words
+	unsigned long long* stage = reinterpret_cast<unsigned long long*>(blob + SLOT_MAXCOLS * 8 + 32);
+	const uint32_t tid = threadIdx.x;
+	if (mode == 0) {
+		const BtChunk ch = chunks[blockIdx.x];
+		const BtUnit* __restrict__ cu = units + ch.unit_off;
+		uint32_t x, first = 0;
+		if (ch.spec_id == 0) {
+			// the table's last column: first (rank(x)) attaining the minimum (strict '<' scan, src/pedigreedptable.cpp:306-315)
+			const unsigned long long key = P.last_keys[0];
+			const uint32_t rlast = (uint32_t)(key >> 4) & 0x0FFFFFFFu;
+			x = rlast ^ (rlast >> 1);
+			if (tid == 0) {
+				out_score[0] = (uint32_t)(key >> 32);
+				path_index[P.n_cols - 1] = x;
+				path_trans[P.n_cols - 1] = 0u;
+				unit_x[ch.unit_off] = x;
+			}
+			first = 1;
+		} else {
+			// guess: the smallest entry of the column this chunk's newest run left (exit index -> logical exit index)
+			const uint32_t idx = (uint32_t)P.spec_keys[ch.spec_id - 1u];
+			const SlotBtUnit* su = reinterpret_cast<const SlotBtUnit*>(cu);
+			x = 0;
+			for (uint32_t j = 0; j < su->f_exit; ++j) x |= ((idx >> su->exit_pos[j]) & 1u) << j;
+			if (tid == 0) guess[blockIdx.x] = x;
+		}
+		for (uint32_t u = first; u < ch.unit_count; ++u) {
+			x = chunk_walk_unit(P, cu + u, x, hdr, blob, cells, xshare, stage, path_index, path_trans);
+			if (tid == 0) unit_x[ch.unit_off + u] = x;
+		}
+		return;
+	}
+	// ---- mode 1: boundaries newest to oldest
+	uint32_t missed = 0, rewalked = 0;
+	uint32_t entry = unit_x[chunks[0].unit_off + chunks[0].unit_count - 1u];   // the newest chunk started from the true optimum
+	for (uint32_t ci = 1; ci < n_chunks; ++ci) {
+		const BtChunk ch = chunks[ci];
+		const BtUnit* __restrict__ cu = units + ch.unit_off;
+		uint32_t x = entry;                                           // the true path's index at the first column of the unit walked before
+		entry = unit_x[ch.unit_off + ch.unit_count - 1u];             // where the speculative walk of this chunk arrived (true unless replaced below)
+		const SlotBtUnit* su = reinterpret_cast<const SlotBtUnit*>(cu);
+		const uint32_t fmask = su->f_exit >= 32u ? 0xFFFFFFFFu : ((1u << su->f_exit) - 1u);
+		if ((x & fmask) == (guess[ci] & fmask)) continue;             // the guess was the true state
+		++missed;
+		for (uint32_t u = 0; u < ch.unit_count; ++u) {
+			x = chunk_walk_unit(P, cu + u, x, hdr, blob, cells, xshare, stage, path_index, path_trans);
+			++rewalked;
+			const uint32_t was = unit_x[ch.unit_off + u];              // (never written by this launch before: every unit is visited once)
+			if (was == x) break;                                       // merged with the speculative walk: the rest is already the true path
+			if (u + 1u == ch.unit_count) entry = x;                    // walked to the chunk's end without merging
+		}
+	}
+	if (tid == 0) { counters[0] = missed; counters[1] = rewalked; }
 }

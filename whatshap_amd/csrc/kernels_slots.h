@@ -330,6 +330,7 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 #pragma unroll
 		for (int s = LR; s < SLOT_MAXSLOTS; ++s) base |= ((Pthr & occ) >> s & 1u) << pos[s];
 		const uint32_t mirror_x = run.mirror_out ? run.out_fullmask : 0u;
+		unsigned long long best_key = ~0ull;   // (value, exit index) of the smallest cell this thread stores (run.spec_id)
 		if ((occ & 3u) == 3u && pos[0] == 0u && pos[1] == 1u) {
 			// the reads of reg slots 0 and 1 are the two lowest bits of the exit index (the planner arranges that for reads
 			// that stay local in the next run): 4 cells = one 16-byte store
@@ -347,6 +348,10 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 				if (writes && !(DBG && (P.dbg_flags & 1u))) {
 					const uint32_t idx = base | x;
 					*reinterpret_cast<uint4*>(cur + idx) = make_uint4(D[r4], D[r4 + 1], D[r4 + 2], D[r4 + 3]);
+					if (run.spec_id) {
+#pragma unroll
+						for (int j = 0; j < 4; ++j) best_key = min(best_key, ((unsigned long long)D[r4 + j] << 32) | (idx + j));
+					}
 					if (run.mirror_out)   // the complement of a group of 4 is a group of 4 in reverse order
 						*reinterpret_cast<uint4*>(cur + ((idx ^ mirror_x) & ~3u)) = make_uint4(D[r4 + 3], D[r4 + 2], D[r4 + 1], D[r4]);
 				}
@@ -367,8 +372,20 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 					const uint32_t idx = base | x;
 					cur[idx] = D[r];
 					if (run.mirror_out) cur[idx ^ mirror_x] = D[r];
+					if (run.spec_id) best_key = min(best_key, ((unsigned long long)D[r] << 32) | idx);
 				}
 			}
+		}
+		if (run.spec_id) {
+			// Seed of the speculative backtrace (kernels_backtrace.h): the smallest entry of the exit column.  Any entry would
+			// keep the result exact (the walk from the seed is verified against the true path); the minimum is what the true
+			// path almost always runs through.  One atomic per wave, on a word of its own per boundary.
+#pragma unroll
+			for (int m = 1; m < 64; m <<= 1) {
+				const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)best_key, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(best_key >> 32), m);
+				best_key = min(best_key, ((unsigned long long)hi << 32) | lo);
+			}
+			if (lane == 0 && best_key != ~0ull) atomicMin(P.spec_keys + (run.spec_id - 1u), best_key);
 		}
 	}
 	if (score_out && w == 0 && tid == 0) *score_out = D[0];

@@ -224,7 +224,6 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 		d.symmetric = symmetric;
 		SlotRun run{};
 		run.c0 = c; run.ncols = d.ncols; run.g = g; run.L = L; run.lw = d.lw;
-		run.kind = 2;
 		run.ctrl_off = (uint32_t)plan.ctrl.size();
 		plan.ctrl.resize(plan.ctrl.size() + SLOT_CTRL_WORDS, 0);
 		for (uint32_t i = 0; i < d.ncols; ++i) {

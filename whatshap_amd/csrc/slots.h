@@ -79,7 +79,8 @@ struct SlotRun {
 	uint32_t in_occ, in_identity, in_half, in_mirror_pos;  // entry: occupied slots; 1: entry index == P & in_occ; the entering column was
 	                                 // written by a halved run: entries whose bit in_mirror_pos is set are read at index ^ in_fullmask
 	uint32_t in_fullmask, out_occ, mirror_out, out_fullmask;  // exit: occupied slots; 1: also store the mirror image (index ^ out_fullmask)
-	uint32_t kind, lr, ctrl_off, pad;   // lr: reg slots of this run (cells per thread = 2^lr); ctrl_off: the run's first word in slot_ctrl
+	uint32_t spec_id, lr, ctrl_off, pad;   // spec_id != 0: this run ends a backtrace chunk -- the kernel leaves (min value, index) of
+	                                 // its exit column in spec_keys[spec_id - 1] (kernels_backtrace.h, speculative walk); lr: reg slots of this run (cells per thread = 2^lr); ctrl_off: the run's first word in slot_ctrl
 	uint32_t in_pos[8];              // entry index bit of every occupied slot, one byte each (when !in_identity)
 	uint32_t out_pos[8];             // exit index bit of every occupied slot, one byte each
 	// (words, not byte arrays: the kernel reads them with static indices out of SGPRs; see slot_pos / slot_set_pos)
@@ -115,7 +116,7 @@ struct SlotBtUnit {
 	uint32_t bt_lo, bt_hi, half, blob_words;
 	uint32_t f_exit, lr, pad0[2];
 	uint8_t exit_slot[32];                 // [f_exit] slot of the read at bit j of the logical exit index
-	uint32_t pad1[8];
+	uint8_t exit_pos[32];                  // [f_exit] bit of the exit (exchange) index that holds bit j of the logical exit index
 };
 static_assert(sizeof(SlotBtUnit) == 128, "SlotBtUnit must stay 32 words");
 
