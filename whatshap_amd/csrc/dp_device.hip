@@ -137,7 +137,9 @@ struct DeviceTable::Impl {
 	bool use_chunks = false;
 	std::vector<BtChunk> chunks;
 	BtChunk* d_chunks = nullptr;
-	uint32_t* d_unit_x = nullptr;
+	uint32_t* d_unit_x = nullptr;   // [2][units]
+	uint32_t* d_path2 = nullptr;    // [2][columns]: speculative walks of the two orientations
+	uint8_t* d_sel = nullptr;
 	uint32_t* d_guess = nullptr;
 	uint32_t* d_bt_counters = nullptr;
 	uint32_t n_spec = 0;
@@ -532,7 +534,9 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		void *d_chunks = nullptr;
 		HIP_TRY(up(&d_chunks, m.chunks.data(), m.chunks.size() * sizeof(BtChunk)));
 		m.d_chunks = (BtChunk*)d_chunks;
-		HIP_TRY(alloc((void**)&m.d_unit_x, m.units.size() * 4));
+		HIP_TRY(alloc((void**)&m.d_unit_x, 2 * m.units.size() * 4));
+		HIP_TRY(alloc((void**)&m.d_path2, 2 * (size_t)n * 4));
+		HIP_TRY(alloc((void**)&m.d_sel, m.units.size() + 16));
 		HIP_TRY(alloc((void**)&m.d_guess, m.chunks.size() * 4));
 		HIP_TRY(alloc((void**)&m.d_bt_counters, 16));
 		void* d_spec = nullptr;
@@ -867,10 +871,12 @@ whamd_status_t DeviceTable::enqueue_some_unguarded(const Problem& p, Solution& s
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(m.ev1, m.stream));
 	if (m.use_chunks) {
-		hipLaunchKernelGGL(backtrace_chunks, dim3((uint32_t)m.chunks.size()), dim3(256), m.chunk_lds, m.stream, m.dp, m.d_units, m.d_chunks,
-		                   (uint32_t)m.chunks.size(), 0u, m.d_path_index, m.d_path_trans, m.d_score, m.d_unit_x, m.d_guess, m.d_bt_counters);
+		HIP_TRY(hipMemsetAsync(m.d_path_trans, 0, (size_t)n * 4, m.stream));   // single individual: no transmission values
+		hipLaunchKernelGGL(backtrace_chunks, dim3(2 * (uint32_t)m.chunks.size()), dim3(256), m.chunk_lds, m.stream, m.dp, m.d_units, m.d_chunks,
+		                   (uint32_t)m.chunks.size(), (uint32_t)m.units.size(), 0u, m.d_path2, m.d_path_trans, m.d_score, m.d_unit_x, m.d_guess, m.d_sel, m.d_bt_counters);
 		hipLaunchKernelGGL(backtrace_chunks, dim3(1), dim3(256), m.chunk_lds, m.stream, m.dp, m.d_units, m.d_chunks,
-		                   (uint32_t)m.chunks.size(), 1u, m.d_path_index, m.d_path_trans, m.d_score, m.d_unit_x, m.d_guess, m.d_bt_counters);
+		                   (uint32_t)m.chunks.size(), (uint32_t)m.units.size(), 1u, m.d_path2, m.d_path_trans, m.d_score, m.d_unit_x, m.d_guess, m.d_sel, m.d_bt_counters);
+		hipLaunchKernelGGL(backtrace_gather, dim3((uint32_t)m.units.size()), dim3(64), 0, m.stream, m.d_units, (uint32_t)m.units.size(), n, m.d_path2, m.d_sel, m.d_path_index);
 	} else
 	hipLaunchKernelGGL(backtrace_kernel, dim3((uint32_t)m.jobs.size()), dim3(1024), m.bt_lds, m.stream, m.dp, m.d_units, m.d_btjobs,
 	                   m.d_path_index, m.d_path_trans, m.d_score);

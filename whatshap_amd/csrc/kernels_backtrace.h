@@ -399,7 +399,7 @@ __device__ __forceinline__ uint32_t chunk_walk_unit(const DevProblem& P, const B
 			const uint32_t r = reinterpret_cast<const uint32_t*>(P.bt + cbt)[y] >> 4;
 			xp = r ^ (r >> 1);
 		}
-		if (tid == 0) { path_index[c0] = xp; path_trans[c0] = 0u; }
+		if (tid == 0) path_index[c0] = xp;
 		return xp;
 	}
 	// ---- slot run: blob (column slot lists + ending slots), physical exit index, record of the path's workgroup -> LDS
@@ -441,7 +441,6 @@ __device__ __forceinline__ uint32_t chunk_walk_unit(const DevProblem& P, const B
 		const uint32_t xl = (uint32_t)__ballot(bit);
 		if (j == 0) {
 			path_index[c0 + c] = xl;
-			path_trans[c0 + c] = 0u;
 			if (c == 0) xshare[0] = xl;
 		}
 	}
@@ -449,66 +448,97 @@ __device__ __forceinline__ uint32_t chunk_walk_unit(const DevProblem& P, const B
 	return xshare[0];
 }
 
+// mode 0: blockIdx.x = 2 * chunk + orientation.  The single-individual table is symmetric under complementing every read
+// (D[~x] == D[x]), so the minimum of an exit column is always attained twice, by a state and by its complement, and which of
+// the two the true path runs through is decided only at the table's last column: both are walked (into path buffer 0 / 1),
+// the verification picks the one the true path arrives at.  (The complement is NOT simply the complement path: ties break
+// differently for the two, the records hold both decisions -- slots.h.)
 __global__ __launch_bounds__(256) void backtrace_chunks(DevProblem P, const BtUnit* __restrict__ units, const BtChunk* __restrict__ chunks,
-                                                         uint32_t n_chunks, uint32_t mode, uint32_t* __restrict__ path_index,
+                                                         uint32_t n_chunks, uint32_t n_units, uint32_t mode, uint32_t* __restrict__ path2,
                                                          uint32_t* __restrict__ path_trans, uint32_t* __restrict__ out_score,
-                                                         uint32_t* __restrict__ unit_x, uint32_t* __restrict__ guess, uint32_t* __restrict__ counters) {
+                                                         uint32_t* __restrict__ unit_x2, uint32_t* __restrict__ guess, uint8_t* __restrict__ sel,
+                                                         uint32_t* __restrict__ counters) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
 	uint32_t* hdr = smem;                         // 32 words
 	uint32_t* xshare = hdr + 32;                  // 4 words
 	uint32_t* cells = xshare + 4;                 // BT_CELLS words
 	uint32_t* blob = cells + BT_CELLS;            // SLOT_MAXCOLS * 8 + 32 words
 	unsigned long long* stage = reinterpret_cast<unsigned long long*>(blob + SLOT_MAXCOLS * 8 + 32);
-	const uint32_t tid = threadIdx.x;
+	const uint32_t tid = threadIdx.x, n = P.n_cols;
 	if (mode == 0) {
-		const BtChunk ch = chunks[blockIdx.x];
+		const uint32_t ci = blockIdx.x >> 1, o = blockIdx.x & 1u;
+		const BtChunk ch = chunks[ci];
 		const BtUnit* __restrict__ cu = units + ch.unit_off;
+		uint32_t* __restrict__ path = path2 + (size_t)o * n;
+		uint32_t* __restrict__ unit_x = unit_x2 + (size_t)o * n_units;
 		uint32_t x, first = 0;
 		if (ch.spec_id == 0) {
+			if (o) return;
 			// the table's last column: first (rank(x)) attaining the minimum (strict '<' scan, src/pedigreedptable.cpp:306-315)
 			const unsigned long long key = P.last_keys[0];
 			const uint32_t rlast = (uint32_t)(key >> 4) & 0x0FFFFFFFu;
 			x = rlast ^ (rlast >> 1);
 			if (tid == 0) {
 				out_score[0] = (uint32_t)(key >> 32);
-				path_index[P.n_cols - 1] = x;
-				path_trans[P.n_cols - 1] = 0u;
+				path[n - 1] = x;
 				unit_x[ch.unit_off] = x;
 			}
 			first = 1;
 		} else {
-			// guess: the smallest entry of the column this chunk's newest run left (exit index -> logical exit index)
+			// guess: the smallest entry of the column this chunk's newest run left (exit index -> logical exit index), or its complement
 			const uint32_t idx = (uint32_t)P.spec_keys[ch.spec_id - 1u];
 			const SlotBtUnit* su = reinterpret_cast<const SlotBtUnit*>(cu);
 			x = 0;
 			for (uint32_t j = 0; j < su->f_exit; ++j) x |= ((idx >> su->exit_pos[j]) & 1u) << j;
-			if (tid == 0) guess[blockIdx.x] = x;
+			if (o) x ^= su->f_exit >= 32u ? 0xFFFFFFFFu : ((1u << su->f_exit) - 1u);
+			if (tid == 0 && o == 0) guess[ci] = x;
 		}
 		for (uint32_t u = first; u < ch.unit_count; ++u) {
-			x = chunk_walk_unit(P, cu + u, x, hdr, blob, cells, xshare, stage, path_index, path_trans);
+			x = chunk_walk_unit(P, cu + u, x, hdr, blob, cells, xshare, stage, path, path_trans);
 			if (tid == 0) unit_x[ch.unit_off + u] = x;
 		}
 		return;
 	}
-	// ---- mode 1: boundaries newest to oldest
+	// ---- mode 1: boundaries newest to oldest; sel[u] = path buffer that holds the true path of unit u
 	uint32_t missed = 0, rewalked = 0;
-	uint32_t entry = unit_x[chunks[0].unit_off + chunks[0].unit_count - 1u];   // the newest chunk started from the true optimum
+	const uint32_t* __restrict__ ux0 = unit_x2;
+	const uint32_t* __restrict__ ux1 = unit_x2 + n_units;
+	for (uint32_t u = tid; u < chunks[0].unit_count; u += blockDim.x) sel[chunks[0].unit_off + u] = 0;
+	uint32_t entry = ux0[chunks[0].unit_off + chunks[0].unit_count - 1u];   // the newest chunk started from the true optimum
 	for (uint32_t ci = 1; ci < n_chunks; ++ci) {
 		const BtChunk ch = chunks[ci];
 		const BtUnit* __restrict__ cu = units + ch.unit_off;
 		uint32_t x = entry;                                           // the true path's index at the first column of the unit walked before
-		entry = unit_x[ch.unit_off + ch.unit_count - 1u];             // where the speculative walk of this chunk arrived (true unless replaced below)
 		const SlotBtUnit* su = reinterpret_cast<const SlotBtUnit*>(cu);
 		const uint32_t fmask = su->f_exit >= 32u ? 0xFFFFFFFFu : ((1u << su->f_exit) - 1u);
-		if ((x & fmask) == (guess[ci] & fmask)) continue;             // the guess was the true state
-		++missed;
-		for (uint32_t u = 0; u < ch.unit_count; ++u) {
-			x = chunk_walk_unit(P, cu + u, x, hdr, blob, cells, xshare, stage, path_index, path_trans);
-			++rewalked;
-			const uint32_t was = unit_x[ch.unit_off + u];              // (never written by this launch before: every unit is visited once)
-			if (was == x) break;                                       // merged with the speculative walk: the rest is already the true path
-			if (u + 1u == ch.unit_count) entry = x;                    // walked to the chunk's end without merging
+		const uint32_t g0 = guess[ci] & fmask;
+		uint32_t from = 0;                                            // units [from, unit_count) come from buffer `o`
+		uint32_t o = 0;
+		if ((x & fmask) == g0) o = 0;
+		else if ((x & fmask) == (g0 ^ fmask)) o = 1;
+		else {
+			// neither: walk from the true state (into buffer 0) until the path reaches a state one of the two walks went through
+			++missed;
+			from = ch.unit_count;
+			for (uint32_t u = 0; u < ch.unit_count; ++u) {
+				x = chunk_walk_unit(P, cu + u, x, hdr, blob, cells, xshare, stage, path2, path_trans);
+				++rewalked;
+				const uint32_t w0 = ux0[ch.unit_off + u], w1 = ux1[ch.unit_off + u];   // (not written by this launch)
+				if (x == w0 || x == w1) { from = u + 1u; o = x == w0 ? 0u : 1u; break; }
+			}
 		}
+		for (uint32_t u = tid; u < ch.unit_count; u += blockDim.x) sel[ch.unit_off + u] = u < from ? (uint8_t)0 : (uint8_t)o;
+		entry = from == ch.unit_count ? x : (o ? ux1 : ux0)[ch.unit_off + ch.unit_count - 1u];
 	}
 	if (tid == 0) { counters[0] = missed; counters[1] = rewalked; }
+}
+
+// Gathers the final index path: unit u's columns from the path buffer the verification selected.
+__global__ __launch_bounds__(64) void backtrace_gather(const BtUnit* __restrict__ units, uint32_t n_units, uint32_t n_cols, const uint32_t* __restrict__ path2,
+                                                       const uint8_t* __restrict__ sel, uint32_t* __restrict__ path_index) {
+	const uint32_t u = blockIdx.x;
+	if (u >= n_units) return;
+	const uint32_t c0 = units[u].c0, ncols = units[u].ncols;
+	const uint32_t* __restrict__ src = path2 + (size_t)sel[u] * n_cols;
+	for (uint32_t c = threadIdx.x; c < ncols; c += blockDim.x) path_index[c0 + c] = src[c0 + c];
 }
