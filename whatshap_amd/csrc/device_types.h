@@ -51,7 +51,9 @@ struct DevProblem {
 	const SlotRow* slot_rows;    // per-column descriptors of the slot runs
 	const uint32_t* slot_blob;   // backtrace blobs of the slot runs (SlotBtUnit::blob_off)
 	const uint32_t* slot_ctrl;   // control bytes of the slot runs (SlotRun::ctrl_off)
-	unsigned long long* spec_keys;  // per backtrace chunk boundary: min over the exit column of (value << 32 | exit index), all-ones before
+	unsigned long long* spec_keys;  // [chunk boundary][spec_stride]: per wave of the boundary run, min over the cells it stored of
+	                                // (value << 32 | exit index); all-ones before
+	uint32_t spec_stride;
 	unsigned long long* dbg;  // optional cycle-counter dump (WHAMD_DEBUG_TIMING)
 	uint32_t dbg_wg_off;      // word offset of the per-workgroup start/end stamps inside dbg
 	uint32_t dbg_flags;       // experiments: bit 0 skip the slice store, bit 1 skip the record store (results invalid)

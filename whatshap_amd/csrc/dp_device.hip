@@ -539,8 +539,11 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		HIP_TRY(alloc((void**)&m.d_sel, m.units.size() + 16));
 		HIP_TRY(alloc((void**)&m.d_guess, m.chunks.size() * 4));
 		HIP_TRY(alloc((void**)&m.d_bt_counters, 16));
+		uint32_t stride = 64;
+		for (const SlotRun& run : m.splan.runs) if (run.spec_id) stride = std::max(stride, (run.threads >> 6) << (run.g - run.half));
+		m.dp.spec_stride = stride;
 		void* d_spec = nullptr;
-		HIP_TRY(alloc(&d_spec, ((size_t)m.n_spec + 1) * 8));
+		HIP_TRY(alloc(&d_spec, ((size_t)m.n_spec + 1) * stride * 8));
 		m.dp.spec_keys = (unsigned long long*)d_spec;
 	} else {
 		m.dp.spec_keys = nullptr;
@@ -780,13 +783,16 @@ void DeviceTable::Impl::launch_slot_run(const SlotBatchEntry& e, uint64_t& launc
 	const size_t lds = (size_t)2 * run.threads * (1u << run.lr) * 4 + (SLOT_MAXCOLS + 8) * 64 + 8 * 64 * 4 + SLOT_MAXCOLS * 64 * 4;   // wave-slot exchange + hot lines + per-wave A + lane sums
 	const dim3 grid(1u << (run.g - run.half)), block(run.threads);
 	const bool dbg = m.dp.dbg != nullptr || m.dp.dbg_flags != 0;
+	const bool spec = run.spec_id != 0 && m.use_chunks && !getenv("WHAMD_NO_SPEC_KERNEL");
+#define WHAMD_SLOT_LAUNCH(LRV, DBGV, SPECV) hipLaunchKernelGGL((slot_run<LRV, DBGV, SPECV>), grid, block, lds, m.stream, m.dp, run, e.prev, e.cur, e.score_out)
 	if (run.lr == 3) {
-		if (dbg) hipLaunchKernelGGL((slot_run<3, true>), grid, block, lds, m.stream, m.dp, run, e.prev, e.cur, e.score_out);
-		else hipLaunchKernelGGL((slot_run<3, false>), grid, block, lds, m.stream, m.dp, run, e.prev, e.cur, e.score_out);
+		if (dbg) { if (spec) WHAMD_SLOT_LAUNCH(3, true, true); else WHAMD_SLOT_LAUNCH(3, true, false); }
+		else { if (spec) WHAMD_SLOT_LAUNCH(3, false, true); else WHAMD_SLOT_LAUNCH(3, false, false); }
 	} else {
-		if (dbg) hipLaunchKernelGGL((slot_run<2, true>), grid, block, lds, m.stream, m.dp, run, e.prev, e.cur, e.score_out);
-		else hipLaunchKernelGGL((slot_run<2, false>), grid, block, lds, m.stream, m.dp, run, e.prev, e.cur, e.score_out);
+		if (dbg) { if (spec) WHAMD_SLOT_LAUNCH(2, true, true); else WHAMD_SLOT_LAUNCH(2, true, false); }
+		else { if (spec) WHAMD_SLOT_LAUNCH(2, false, true); else WHAMD_SLOT_LAUNCH(2, false, false); }
 	}
+#undef WHAMD_SLOT_LAUNCH
 	launches += 1;
 }
 
@@ -831,7 +837,7 @@ whamd_status_t DeviceTable::enqueue_some_unguarded(const Problem& p, Solution& s
 		}
 		for (const Impl::Lane& lane : m.lanes) HIP_TRY(hipMemsetAsync(lane.d_keys, 0xFF, m.key_entries * 8, m.stream));
 		HIP_TRY(hipMemsetAsync(m.dp.last_keys, 0xFF, (size_t)MAX_T * 8, m.stream));
-		if (m.use_chunks) HIP_TRY(hipMemsetAsync(m.dp.spec_keys, 0xFF, ((size_t)m.n_spec + 1) * 8, m.stream));
+		if (m.use_chunks) HIP_TRY(hipMemsetAsync(m.dp.spec_keys, 0xFF, ((size_t)m.n_spec + 1) * m.dp.spec_stride * 8, m.stream));
 		HIP_TRY(hipEventRecord(m.ev0, m.stream));
 		if (!m.plan.ped_columns.empty()) {
 			const uint32_t entries = (uint32_t)m.plan.ped_columns.size() * PED_TABLE;

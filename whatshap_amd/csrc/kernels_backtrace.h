@@ -486,7 +486,19 @@ __global__ __launch_bounds__(256) void backtrace_chunks(DevProblem P, const BtUn
 			first = 1;
 		} else {
 			// guess: the smallest entry of the column this chunk's newest run left (exit index -> logical exit index), or its complement
-			const uint32_t idx = (uint32_t)P.spec_keys[ch.spec_id - 1u];
+			const unsigned long long* __restrict__ cand = P.spec_keys + (size_t)(ch.spec_id - 1u) * P.spec_stride;
+			unsigned long long best = ~0ull;
+			for (uint32_t i = tid; i < P.spec_stride; i += blockDim.x) best = min(best, cand[i]);
+#pragma unroll
+			for (int m = 1; m < 64; m <<= 1) {
+				const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)best, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(best >> 32), m);
+				best = min(best, ((unsigned long long)hi << 32) | lo);
+			}
+			unsigned long long* red = reinterpret_cast<unsigned long long*>(cells);
+			if ((tid & 63u) == 0) red[tid >> 6] = best;
+			__syncthreads();
+			for (uint32_t i = 0; i < (blockDim.x >> 6); ++i) best = min(best, red[i]);
+			const uint32_t idx = (uint32_t)best;
 			const SlotBtUnit* su = reinterpret_cast<const SlotBtUnit*>(cu);
 			x = 0;
 			for (uint32_t j = 0; j < su->f_exit; ++j) x |= ((idx >> su->exit_pos[j]) & 1u) << j;

@@ -81,7 +81,7 @@ __device__ __forceinline__ void slot_touch_rows(const SlotRow* rows) {
 // byte s of a packed position table held in SGPRs (static s)
 __device__ __forceinline__ uint32_t slot_pos_dev(const uint32_t (&w)[8], int s) { return (w[s >> 2] >> ((s & 3) * 8)) & 31u; }
 
-template <int LR, bool DBG>
+template <int LR, bool DBG, bool SPEC>
 __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun& run, const uint32_t* __restrict__ prev,
                                               uint32_t* __restrict__ cur, const uint32_t w, uint32_t* score_out) {
 	constexpr int R = 1 << LR;
@@ -348,7 +348,7 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 				if (writes && !(DBG && (P.dbg_flags & 1u))) {
 					const uint32_t idx = base | x;
 					*reinterpret_cast<uint4*>(cur + idx) = make_uint4(D[r4], D[r4 + 1], D[r4 + 2], D[r4 + 3]);
-					if (run.spec_id) {
+					if (SPEC) {
 #pragma unroll
 						for (int j = 0; j < 4; ++j) best_key = min(best_key, ((unsigned long long)D[r4 + j] << 32) | (idx + j));
 					}
@@ -372,20 +372,21 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 					const uint32_t idx = base | x;
 					cur[idx] = D[r];
 					if (run.mirror_out) cur[idx ^ mirror_x] = D[r];
-					if (run.spec_id) best_key = min(best_key, ((unsigned long long)D[r] << 32) | idx);
+					if (SPEC) best_key = min(best_key, ((unsigned long long)D[r] << 32) | idx);
 				}
 			}
 		}
-		if (run.spec_id) {
+		if (SPEC && run.spec_id) {
 			// Seed of the speculative backtrace (kernels_backtrace.h): the smallest entry of the exit column.  Any entry would
 			// keep the result exact (the walk from the seed is verified against the true path); the minimum is what the true
-			// path almost always runs through.  One atomic per wave, on a word of its own per boundary.
+			// path almost always runs through.  One candidate per wave.
 #pragma unroll
 			for (int m = 1; m < 64; m <<= 1) {
 				const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)best_key, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(best_key >> 32), m);
 				best_key = min(best_key, ((unsigned long long)hi << 32) | lo);
 			}
-			if (lane == 0 && best_key != ~0ull) atomicMin(P.spec_keys + (run.spec_id - 1u), best_key);
+			// one plain store per wave (2048 atomics on one word would take ~25 us); the backtrace reduces the candidates
+			if (lane == 0) P.spec_keys[(size_t)(run.spec_id - 1u) * P.spec_stride + w * (threads >> 6) + wave] = best_key;
 		}
 	}
 	if (score_out && w == 0 && tid == 0) *score_out = D[0];
@@ -398,11 +399,13 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 // DBG: timing experiments (WHAMD_SLOT_SKIP switches parts off -- results invalid) and in-kernel cycle stamps (WHAMD_SLOT_STAMPS);
 // the production instantiation carries none of it (a single wave issues one VALU instruction per ~8 cycles -- measured,
 // scripts/micro/issue_rate.hip -- so every instruction on the column chain counts).
-template <int LR, bool DBG>
+// SPEC: the run ends a backtrace chunk and leaves the seed of the speculative walk (instantiated separately: the other runs
+// do not even carry the test).
+template <int LR, bool DBG, bool SPEC>
 __global__ __launch_bounds__(512) void slot_run(DevProblem P, SlotRun run, const uint32_t* __restrict__ prev, uint32_t* __restrict__ cur,
                                                 uint32_t* __restrict__ score_out) {
 	touch_kernel_arguments<sizeof(DevProblem) + sizeof(SlotRun) + 24>();
-	slot_run_body<LR, DBG>(P, run, prev, cur, blockIdx.x, score_out);
+	slot_run_body<LR, DBG, SPEC>(P, run, prev, cur, blockIdx.x, score_out);
 }
 
 // One launch = the next run of SEVERAL independent jobs (connected components of one table): blockIdx.y selects the entry.
@@ -418,5 +421,5 @@ __global__ __launch_bounds__(512) void slot_batch(DevProblem P, const SlotBatchE
 	}
 	const SlotRun run = e->run;
 	if (blockIdx.x >= (1u << (run.g - run.half)) || threadIdx.x >= run.threads) return;
-	slot_run_body<LR, false>(P, run, e->prev, e->cur, blockIdx.x, e->score_out);
+	slot_run_body<LR, false, false>(P, run, e->prev, e->cur, blockIdx.x, e->score_out);
 }
