@@ -275,12 +275,16 @@ whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uin
 	if (!out) return fail(WHAMD_ERR_INVALID, "out is NULL");
 	Problem p;
 	std::string msg;
+	const double tb0 = now_ms();
 	whamd_status_t st = build_problem(readset, recombcost, n_recombcost, pedigree, distrust_genotypes != 0, positions,
 	                                  n_positions, p, msg);
 	if (st != WHAMD_OK) return fail(st, msg);
 	const std::string mode(path ? path : "auto");
 	SlotPlan sp;
-	if ((mode == "auto" || mode == "slots") && plan_forward_slots(p, 11, 1, sp)) {
+	const double tp0 = now_ms();
+	const bool slots_ok = (mode == "auto" || mode == "slots") && plan_forward_slots(p, 11, 1, sp);
+	if (getenv("WHAMD_DEBUG_TIMING")) fprintf(stderr, "[whamd timing] plan_summarize: build_problem %.1f ms, plan_forward_slots %.1f ms\n", tp0 - tb0, now_ms() - tp0);
+	if (slots_ok) {
 		// slot runs (slots.h): every column in exactly one step, runs within their limits, slots consistent
 		whamd_plan_summary s{};
 		s.n_columns = p.n_cols;

@@ -281,14 +281,21 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 	p.f[n - 1] = 0;  // last column: everything is minimised out (global optimum, src/pedigreedptable.cpp:306-315)
 	p.fwd_mask[n - 1] = 0;
 
-	// ---- per-bit deltas and cost terms
+	// ---- per-bit deltas and cost terms.  Columns are independent: ranges of columns go to a few host threads, each with its
+	// own term list (concatenated in column order afterwards; the sums below are sums of integer-valued doubles, exact in any order)
 	p.delta.assign((size_t)p.col_ptr[n] * std::max<uint32_t>(p.n_ind, 1), 0);
 	p.term_ptr.assign((size_t)n * p.T + 1, 0);
 	p.terms.clear();
-	p.terms.reserve((size_t)n * p.T * 2);
-	double bound = 0.0;  // upper bound on any DP value, to rule out 32-bit wrap-around
+	struct RangeResult {
+		std::vector<CostTerm> terms;
+		double bound = 0.0;
+		uint64_t n_cells = 0, algorithmic_bytes = 0;
+		bool conflict = false;
+	};
+	auto terms_range = [&](uint32_t c_begin, uint32_t c_end, RangeResult& out) {
+	out.terms.reserve((size_t)(c_end - c_begin) * p.T * 2);
 	std::vector<uint32_t> R(p.n_ind), W(p.n_ind);
-	for (uint32_t c = 0; c < n; ++c) {
+	for (uint32_t c = c_begin; c < c_end; ++c) {
 		const ColumnEntry* col = p.col_begin(c);
 		const uint32_t kc = p.k[c];
 		std::fill(R.begin(), R.end(), 0u);
@@ -311,7 +318,7 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 		bool any = false;
 		for (uint32_t t = 0; t < p.T; ++t) {
 			const int8_t* map = p.h2p.data() + (size_t)t * p.n_ind * 2;
-			const size_t begin = p.terms.size();
+			const size_t begin = out.terms.size();
 			for (uint32_t a = 0; a < (1u << p.P); ++a) {  // src/pedigreecolumncostcomputer.cpp:25-49
 				bool compatible = true;
 				uint32_t acost = 0;
@@ -337,26 +344,54 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 				max_acost = std::max(max_acost, (double)acost);
 				// a term with the same L-dependence and a constant that is not smaller can never be the strict minimum
 				bool dominated = false;
-				for (size_t q = begin; q < p.terms.size(); ++q) {
-					if (p.terms[q].plus == term.plus && p.terms[q].minus == term.minus) {
-						if (term.c < p.terms[q].c) p.terms[q].c = term.c;
+				for (size_t q = begin; q < out.terms.size(); ++q) {
+					if (out.terms[q].plus == term.plus && out.terms[q].minus == term.minus) {
+						if (term.c < out.terms[q].c) out.terms[q].c = term.c;
 						dominated = true;
 						break;
 					}
 				}
-				if (!dominated) p.terms.push_back(term);
+				if (!dominated) out.terms.push_back(term);
 			}
-			if (p.terms.size() > begin) any = true;
-			p.term_ptr[(size_t)c * p.T + t + 1] = p.terms.size();
+			if (out.terms.size() > begin) any = true;
+			p.term_ptr[(size_t)c * p.T + t + 1] = out.terms.size();   // relative to the range; rebased below
 		}
 		if (!any) {  // every transmission value infeasible at every cell (src/pedigreedptable.cpp:301-303)
-			msg = "Error: Mendelian conflict";
-			return WHAMD_ERR_MENDELIAN_CONFLICT;
+			out.conflict = true;
+			return;
 		}
-		bound += wsum + max_acost + 2.0 * p.n_triples * (double)p.recomb[c];
+		out.bound += wsum + max_acost + 2.0 * p.n_triples * (double)p.recomb[c];
 		const uint64_t Tl = p.T;
-		p.n_cells += 1ull << kc;
-		p.algorithmic_bytes += (c > 0 ? 4 * Tl * (1ull << p.b[c]) : 0) + (c + 1 < n ? 12 * Tl * (1ull << p.f[c]) : 0) + 12ull * kc;
+		out.n_cells += 1ull << kc;
+		out.algorithmic_bytes += (c > 0 ? 4 * Tl * (1ull << p.b[c]) : 0) + (c + 1 < n ? 12 * Tl * (1ull << p.f[c]) : 0) + 12ull * kc;
+	}
+	};
+	double bound = 0.0;  // upper bound on any DP value, to rule out 32-bit wrap-around
+	{
+		uint32_t n_threads = std::min<uint32_t>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+		if (const char* e = getenv("WHAMD_PLAN_THREADS")) n_threads = (uint32_t)std::max(1, atoi(e));
+		n_threads = std::max(1u, std::min(n_threads, n / 8192u + 1u));
+		std::vector<RangeResult> parts(n_threads);
+		std::vector<uint32_t> bounds(n_threads + 1);
+		for (uint32_t t = 0; t <= n_threads; ++t) bounds[t] = (uint32_t)((uint64_t)n * t / n_threads);
+		if (n_threads == 1) terms_range(0, n, parts[0]);
+		else {
+			std::vector<std::thread> workers;
+			for (uint32_t t = 0; t < n_threads; ++t) workers.emplace_back([&, t]() { terms_range(bounds[t], bounds[t + 1], parts[t]); });
+			for (std::thread& w : workers) w.join();
+		}
+		for (uint32_t t = 0; t < n_threads; ++t) {
+			if (parts[t].conflict) {
+				msg = "Error: Mendelian conflict";
+				return WHAMD_ERR_MENDELIAN_CONFLICT;
+			}
+			const uint64_t base = p.terms.size();
+			for (size_t i = (size_t)bounds[t] * p.T + 1; i <= (size_t)bounds[t + 1] * p.T; ++i) p.term_ptr[i] += base;
+			p.terms.insert(p.terms.end(), parts[t].terms.begin(), parts[t].terms.end());
+			bound += parts[t].bound;
+			p.n_cells += parts[t].n_cells;
+			p.algorithmic_bytes += parts[t].algorithmic_bytes;
+		}
 	}
 	p.value_bound = bound;
 	if (bound >= 4294967295.0) {

@@ -9,6 +9,9 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <cstdio>
+#include <thread>
 
 #include "slots.h"
 
@@ -29,6 +32,7 @@ inline uint32_t parity32(uint32_t v) { return (uint32_t)__builtin_popcount(v) & 
 
 bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan& plan, int lr) {
 	lr = std::max(2, std::min(lr, SLOT_LR));
+	const auto tp0 = std::chrono::steady_clock::now();
 	plan = SlotPlan();
 	const uint32_t n = p.n_cols;
 	if (!(p.T == 1 && p.n_ind == 1 && p.value_bound < 1073741824.0)) return false;
@@ -40,10 +44,19 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 		const ColumnEntry* col = p.col_begin(c);
 		for (uint32_t j = 0; j < p.k[c]; ++j) last_col[col[j].read_id] = c;
 	}
+	std::vector<int32_t>& col_to_row = plan.col_to_row;
+	// rows and backtrace columns are indexed by COLUMN (row of column c = rows[c]; entries of columns outside runs stay unused):
+	// the ranges below write disjoint parts of them in place
+	plan.rows.resize(n);
+	plan.bt_cols.resize(n);
+	auto& rows_g = plan.rows;
+	auto& btc_g = plan.bt_cols;
+	// A run may start at ANY column (it reads the exchange column its predecessor left), so disjoint column ranges are
+	// planned independently -- in parallel -- and concatenated; a range boundary is just one more run boundary.
+	auto plan_range = [&](const uint32_t c_begin, const uint32_t c_end, SlotPlan& plan, std::vector<RunDraft>& drafts) {
 	std::vector<int8_t> slot_of(p.n_reads, -1);
-	std::vector<RunDraft> drafts;
-	uint32_t c = 0;
-	while (c < n) {
+	uint32_t c = c_begin;
+	while (c < c_end) {
 		auto column_step = [&]() { plan.steps.push_back(Step{0, c}); ++c; };
 		if (c + 1 >= n) { column_step(); continue; }   // the last column needs the global optimum (column_step_keys)
 		const uint32_t b0 = p.b[c];
@@ -103,13 +116,14 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 		};
 		for (uint32_t s = 0; s < nslots; ++s) if (cur[s] >= 0) slot_of[cur[s]] = (int8_t)s;
 		// ---- walk the columns
-		const size_t rows_mark = plan.rows.size(), ends_mark = plan.end_slots.size();
+		const size_t rows_mark = c, ends_mark = plan.end_slots.size();
 		std::vector<int32_t> started;   // reads that got their slot inside the run (marks to clear)
 		uint32_t c1 = c, n_ends = 0;
 		bool symmetric = true;
 		while (c1 < n && c1 - c < (uint32_t)SLOT_MAXCOLS) {
 			if (c1 + 1 == n) break;
 			if (c1 >= grid_end) break;
+			if (c1 >= c_end) break;
 			if (c1 > c && p.b[c1] == 0) break;
 			const ColumnEntry* col = p.col_begin(c1);
 			const uint32_t kc = p.k[c1], bc = c1 == c ? b0 : p.b[c1];
@@ -188,23 +202,19 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 				cur[slot_of[col[j].read_id]] = -1;
 			}
 			n_ends += en;
-			plan.col_to_row[c1] = (int32_t)plan.rows.size();
-			plan.rows.push_back(row);
-			plan.bt_cols.push_back(bc_rec);
+			col_to_row[c1] = (int32_t)c1;
+			rows_g[c1] = row;
+			btc_g[c1] = bc_rec;
 			++c1;
 		}
 		// a run whose bookkeeping stopped in the middle of a column: drop what that column appended
-		plan.rows.resize(rows_mark + (c1 - c));
-		plan.bt_cols.resize(rows_mark + (c1 - c));
 		{
 			size_t keep = 0;
-			for (size_t i = rows_mark; i < plan.rows.size(); ++i) keep += plan.rows[i].n_end;
+			for (size_t i = rows_mark; i < c1; ++i) keep += rows_g[i].n_end;
 			plan.end_slots.resize(ends_mark + keep);
 		}
 		if (c1 - c < 2) {   // not worth a launch of its own
-			for (uint32_t cc = c; cc < c1; ++cc) plan.col_to_row[cc] = -1;
-			plan.rows.resize(rows_mark);
-			plan.bt_cols.resize(rows_mark);
+			for (uint32_t cc = c; cc < c1; ++cc) col_to_row[cc] = -1;
 			plan.end_slots.resize(ends_mark);
 			release_marks();
 			for (int32_t r : started) slot_of[r] = -1;
@@ -216,7 +226,7 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 		{
 			const ColumnEntry* col = p.col_begin(c1 - 1);
 			for (uint32_t j = 0; j < p.k[c1 - 1]; ++j)
-				if ((p.fwd_mask[c1 - 1] >> j) & 1u) d.exit_read[plan.bt_cols[rows_mark + (c1 - 1 - c)].slot[j]] = (int32_t)col[j].read_id;
+				if ((p.fwd_mask[c1 - 1] >> j) & 1u) d.exit_read[btc_g[c1 - 1].slot[j]] = (int32_t)col[j].read_id;
 		}
 		release_marks();
 		for (int32_t r : started) slot_of[r] = -1;
@@ -227,14 +237,14 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 		run.ctrl_off = (uint32_t)plan.ctrl.size();
 		plan.ctrl.resize(plan.ctrl.size() + SLOT_CTRL_WORDS, 0);
 		for (uint32_t i = 0; i < d.ncols; ++i) {
-			const SlotRow& rw = plan.rows[rows_mark + i];
+			const SlotRow& rw = rows_g[rows_mark + i];
 			const uint32_t byte = rw.n_end | ((rw.n_end ? (rw.end[0].info & 31u) : 0u) << 2);
 			plan.ctrl[run.ctrl_off + (i >> 2)] |= byte << ((i & 3u) * 8u);
 		}
 		run.lr = (uint32_t)lr;
 		run.row_off = (uint32_t)rows_mark;
 		run.n_ends = 0;
-		for (size_t i = rows_mark; i < plan.rows.size(); ++i) run.n_ends += plan.rows[i].n_end;
+		for (size_t i = rows_mark; i < c1; ++i) run.n_ends += rows_g[i].n_end;
 		run.threads = 64u << d.lw;
 		run.has_prev = c > 0;   // a run that starts a connected component reads the single value the previous one projected onto
 		run.half = (use_symmetry > 0 && symmetric && g >= 1) ? 1u : 0u;
@@ -249,6 +259,44 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 		plan.n_run_columns += d.ncols;
 		c = c1;
 	}
+	};
+	std::vector<RunDraft> drafts;
+	const auto tp1 = std::chrono::steady_clock::now();
+	auto tp2 = tp1;
+	{
+		uint32_t n_threads = std::min<uint32_t>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+		if (const char* e = getenv("WHAMD_PLAN_THREADS")) n_threads = (uint32_t)std::max(1, atoi(e));
+		n_threads = std::max(1u, std::min(n_threads, n / 4096u + 1u));
+		std::vector<SlotPlan> parts(n_threads);
+		std::vector<std::vector<RunDraft>> part_drafts(n_threads);
+		std::vector<uint32_t> bounds(n_threads + 1);
+		for (uint32_t t = 0; t <= n_threads; ++t) bounds[t] = (uint32_t)((uint64_t)n * t / n_threads);
+		if (n_threads == 1) plan_range(0, n, parts[0], part_drafts[0]);
+		else {
+			std::vector<std::thread> workers;
+			for (uint32_t t = 0; t < n_threads; ++t)
+				workers.emplace_back([&, t]() {
+					const auto a = std::chrono::steady_clock::now();
+					plan_range(bounds[t], bounds[t + 1], parts[t], part_drafts[t]);
+					if (getenv("WHAMD_DEBUG_TIMING")) fprintf(stderr, "[whamd timing]   range %u: %.1f ms\n", t, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count());
+				});
+			for (std::thread& w : workers) w.join();
+		}
+		tp2 = std::chrono::steady_clock::now();
+		for (uint32_t t = 0; t < n_threads; ++t) {
+			const SlotPlan& q = parts[t];
+			const uint32_t run_base = (uint32_t)plan.runs.size();
+			const uint32_t end_base = (uint32_t)plan.end_slots.size(), ctrl_base = (uint32_t)plan.ctrl.size();
+			for (Step st : q.steps) { if (st.kind == 2) st.index += run_base; plan.steps.push_back(st); }
+			for (SlotRun run : q.runs) { run.ctrl_off += ctrl_base; plan.runs.push_back(run); }
+			for (uint32_t off : q.end_off) plan.end_off.push_back(off + end_base);
+			plan.end_slots.insert(plan.end_slots.end(), q.end_slots.begin(), q.end_slots.end());
+			plan.ctrl.insert(plan.ctrl.end(), q.ctrl.begin(), q.ctrl.end());
+			plan.n_run_columns += q.n_run_columns;
+			drafts.insert(drafts.end(), part_drafts[t].begin(), part_drafts[t].end());
+		}
+	}
+	const auto tp3 = std::chrono::steady_clock::now();
 	for (size_t si = 0; si < plan.steps.size(); ++si) {
 		const uint32_t c0 = plan.steps[si].kind == 2 ? plan.runs[plan.steps[si].index].c0 : plan.steps[si].index;
 		if (si == 0 || p.b[c0] == 0) plan.component_first_step.push_back((uint32_t)si);
@@ -329,6 +377,11 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 			B.out_fullmask = plan.f_exit[ri] >= 32 ? 0xFFFFFFFFu : ((1u << plan.f_exit[ri]) - 1u);
 			B.mirror_out = B.half;   // a per-column step reads every entry
 		}
+	}
+	if (getenv("WHAMD_DEBUG_TIMING")) {
+		auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+		fprintf(stderr, "[whamd timing] slot plan: setup %.1f ms, column ranges %.1f ms, concatenation %.1f ms, layouts %.1f ms\n",
+		        ms(tp0, tp1), ms(tp1, tp2), ms(tp2, tp3), ms(tp3, std::chrono::steady_clock::now()));
 	}
 	return true;
 }
