@@ -646,3 +646,41 @@ def test_two_ranks_on_the_device_path():
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "BLOCKS_OK" in res.stdout
+
+
+def test_shim_with_compiled_ingestion_on_plain_reference_objects():
+    """whatshap_amd.shim.table_factory on WhatsHap's OWN objects without the recording subclass: the compiled ingestion
+    (whatshap_amd/ingest, thisptr walk) feeds the device table; every return value of the PhasingAlgorithm interface equals
+    the reference PedigreeDPTable's on the same objects."""
+    from refobjects import reference_core, table_outputs
+    from whatshap_amd import ingest, shim
+    from whatshap_amd.synthetic import synthetic_block
+
+    ref = reference_core()
+    if ingest.load() is None:
+        pytest.skip("whatshap_amd/ingest not built")
+    for trio, coverage, n in ((False, 12, 400), (True, 9, 300)):
+        problem = synthetic_block(n, coverage, seed=77, trio=trio, distrust_genotypes=trio)
+        n_ind = problem.n_individuals
+        rs = ref.ReadSet()
+        ptr = problem.read_ptr
+        for r in range(problem.n_reads):
+            read = ref.Read(f"read{r}", 60, 0, int(problem.read_sample_id[r]))
+            for i in range(int(ptr[r]), int(ptr[r + 1])):
+                read.add_variant(int(problem.var_position[i]), int(problem.var_allele[i]), int(problem.var_quality[i]))
+            rs.add(read)
+        ids = ref.NumericSampleIds()
+        for numeric in range(n_ind):
+            assert ids[str(numeric)] == numeric
+        ped = ref.Pedigree(ids)   # plain: nothing recorded on the Python side
+        gl = None if problem.genotype_likelihoods is None else problem.genotype_likelihoods.reshape(n_ind, problem.n_variants, 3)
+        for i in range(n_ind):
+            ped.add_individual(str(i), [ref.Genotype([0, 1])] * problem.n_variants,
+                               None if gl is None else [ref.PhredGenotypeLikelihoods([float(x) for x in gl[i, v]]) for v in range(problem.n_variants)])
+        if trio:
+            ped.add_relationship("0", "1", "2")
+        recomb, positions = problem.recombcost.tolist(), problem.positions.tolist()
+        want = table_outputs(ref.PedigreeDPTable(rs, recomb, ped, problem.distrust_genotypes, positions))
+        table = shim.table_factory(ref)(rs, recomb, ped, problem.distrust_genotypes, positions)
+        assert type(table).__name__ == "_TableAdapter"   # the device table, not the fallback
+        assert table_outputs(table) == want

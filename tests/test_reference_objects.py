@@ -76,8 +76,17 @@ def test_shim_install_rebinds_a_phase_like_module():
     assert isinstance(rec, MirrorPedigree) and rec._ids == [0, 1, 2] and rec._triples == [(0, 1, 2)]
     assert [g.as_vector() for g in rec._genotypes[0]] == [[0, 1], [1, 1], [0, 0]]
     assert rec._gls[0][0].as_vector() == [10.0, 0.0, 20.0] and rec._gls[0][1] is None and rec._gls[1] == [None] * 3
-    with pytest.raises(TypeError):
-        phase.PedigreeDPTable(ref.ReadSet(), [1, 1, 1], ref.Pedigree(ids))  # a pedigree that was not recorded
+    from whatshap_amd import ingest
+
+    if ingest.load() is None:
+        with pytest.raises(TypeError):
+            phase.PedigreeDPTable(ref.ReadSet(), [1, 1, 1], ref.Pedigree(ids))  # a pedigree that was not recorded
+    else:
+        # with the compiled ingestion a plain reference Pedigree is read through thisptr: no recording needed (without a GPU
+        # the factory then falls back to the class it replaced, with a GPU it returns the device table)
+        plain = ref.Pedigree(ids)
+        plain.add_individual("father", gts)
+        assert phase.PedigreeDPTable(ref.ReadSet(), [1, 1, 1], plain) is not None
 
 
 def test_shim_falls_back_to_the_replaced_class_beyond_device_limits(monkeypatch):
@@ -116,3 +125,68 @@ def test_shim_falls_back_to_the_replaced_class_beyond_device_limits(monkeypatch)
     monkeypatch.setattr(core, "PedigreeDPTable", refusing(_native.WHAMD_ERR_UNSUPPORTED, "beyond the device path"))
     with pytest.raises(_native.SolverError):
         shim.table_factory(None)(rs, [1, 2], ped)
+
+
+def _compiled_ingestion():
+    from whatshap_amd import ingest
+    from whatshap_amd.ingest import build as ingest_build
+
+    reference_core()  # whatshap.core loaded (RTLD_GLOBAL) -- the C++ symbols the extension resolves against
+    if not ingest_build.available():
+        pytest.skip("whatshap_amd/ingest not built (reference tree absent when build() ran)")
+    mod = ingest.load()
+    assert mod is not None, "whamd_ingest was built but does not import"
+    return mod
+
+
+def _same_arrays(a, b):
+    for name in ("read_ptr", "var_position", "var_allele", "var_quality", "read_sample_id", "individual_id", "triple_ids",
+                 "genotype", "recombcost"):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+    assert a.n_variants == b.n_variants
+    if a.genotype_likelihoods is None:
+        assert b.genotype_likelihoods is None
+    else:
+        assert np.array_equal(a.genotype_likelihoods, b.genotype_likelihoods, equal_nan=True)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c.name for c in CASES])
+def test_compiled_ingestion_equals_python_walk(case):
+    """whatshap_amd.ingest (C++ against the reference's headers, thisptr walk as in readselect.pyx:14-15,244) produces the
+    arrays the Python-level walk of the same reference objects produces -- for the ReadSet and for the Pedigree, which is
+    opaque from Python (here the Python side needs the recording subclass, the compiled side does not)."""
+    from whatshap_amd.core import problem_from_reference_objects
+
+    mod = _compiled_ingestion()
+    ref = reference_core()
+    rs, ped = to_reference(case, ref)
+    want = problem_from_objects(rs, case.recombcost, ped.amd, case.distrust_genotypes, case.positions)
+    got = problem_from_reference_objects(mod, rs, case.recombcost, ped, case.distrust_genotypes, case.positions)
+    _same_arrays(want, got)
+
+
+def test_compiled_ingestion_on_a_plain_reference_pedigree_and_large_readset():
+    """No recording subclass at all: a plain whatshap.core.Pedigree (trio with likelihoods) and a 3 000-variant ReadSet."""
+    from refobjects import problem_to_reference
+    from whatshap_amd.core import problem_from_reference_objects
+    from whatshap_amd.synthetic import synthetic_block
+
+    mod = _compiled_ingestion()
+    ref = reference_core()
+    problem = synthetic_block(3000, 9, seed=5, trio=True, distrust_genotypes=True)
+    rs, recording = problem_to_reference(problem, ref)
+    ids = ref.NumericSampleIds()
+    for numeric in range(3):
+        assert ids[str(numeric)] == numeric
+    plain = ref.Pedigree(ids)
+    n_var = problem.n_variants
+    gl = problem.genotype_likelihoods.reshape(3, n_var, 3)
+    for i in range(3):
+        plain.add_individual(str(i), [ref.Genotype([0, 1])] * n_var,
+                             [ref.PhredGenotypeLikelihoods([float(x) for x in gl[i, v]]) for v in range(n_var)])
+    plain.add_relationship("0", "1", "2")
+    assert type(plain) is ref.Pedigree
+    got = problem_from_reference_objects(mod, rs, problem.recombcost.tolist(), plain, True, problem.positions.tolist())
+    want = problem_from_objects(rs, problem.recombcost.tolist(), recording.amd, True, problem.positions.tolist())
+    _same_arrays(want, got)
+    assert int(oracle.OracleTable(got).optimal_score()) == int(oracle.OracleTable(problem).optimal_score())

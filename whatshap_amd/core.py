@@ -429,6 +429,20 @@ def problem_from_objects(readset, recombcost, pedigree: Pedigree, distrust_genot
     )
 
 
+def problem_from_reference_objects(ingest, readset, recombcost, pedigree, distrust_genotypes: bool = False,
+                                   positions=None) -> _native.ProblemArrays:
+    """The same arrays from WhatsHap's OWN ``ReadSet`` / ``Pedigree`` objects through the compiled ingestion
+    (``whatshap_amd.ingest``): the C++ objects are walked through ``thisptr`` (``whatshap/readselect.pyx:14-15,244`` is the
+    precedent), no Python object is created per variant and the pedigree needs no recording subclass."""
+    read_ptr, pos, alle, qual, samples = ingest.flatten_readset(readset)
+    ids, triples, genotype, gl = ingest.flatten_pedigree(pedigree)
+    return _native.ProblemArrays(
+        read_ptr, pos, alle, qual, samples, ids, triples, genotype, gl, np.asarray(list(recombcost), dtype=np.uint32),
+        None if positions is None else np.asarray(list(positions), dtype=np.uint32), distrust_genotypes,
+        n_variants=genotype.shape[1] if genotype.ndim == 2 else 0,
+    )
+
+
 class PedigreeDPTable:
     """Drop-in for ``whatshap.core.PedigreeDPTable`` (core.pyx:364-416) running on an MI355X.
 
@@ -444,9 +458,11 @@ class PedigreeDPTable:
     """
 
     def __init__(self, readset, recombcost, pedigree: Pedigree, distrust_genotypes: bool = False, positions=None,
-                 *, device: int = 0, path: Optional[str] = None, split_blocks: bool = False, max_in_flight: int = 8):
+                 *, device: int = 0, path: Optional[str] = None, split_blocks: bool = False, max_in_flight: int = 8,
+                 problem: Optional[_native.ProblemArrays] = None):
         self.pedigree = pedigree
-        self._problem = problem_from_objects(readset, recombcost, pedigree, distrust_genotypes, positions)
+        # `problem`: the flat arrays are already there (compiled ingestion of reference objects, whatshap_amd.shim)
+        self._problem = problem if problem is not None else problem_from_objects(readset, recombcost, pedigree, distrust_genotypes, positions)
         self._tables: List[_native.NativeTable] = []
         self._blocks = None
         blocks = None

@@ -108,11 +108,22 @@ def table_factory(reference_core=None, fallback_table_class=None, **solver_optio
     reference raises them too."""
 
     def make(readset, recombcost, pedigree, distrust_genotypes=False, positions=None):
-        recorded = getattr(pedigree, "amd", pedigree)
-        if not isinstance(recorded, amd.Pedigree):
-            raise TypeError("the pedigree was not created through whatshap_amd.shim (no recorded individuals / trios)")
+        # WhatsHap's own objects: compiled ingestion (whatshap_amd/ingest) when it was built -- the C++ ReadSet / Pedigree are
+        # walked through thisptr, the pedigree needs no recording subclass; otherwise the objects' public Python API
+        from . import ingest as _ingest
+
+        compiled = _ingest.load() if reference_core is not None else None
+        problem = None
+        if compiled is not None and isinstance(readset, reference_core.ReadSet) and isinstance(pedigree, reference_core.Pedigree):
+            problem = amd.problem_from_reference_objects(compiled, readset, recombcost, pedigree, distrust_genotypes, positions)
+            recorded = getattr(pedigree, "amd", None)
+        else:
+            recorded = getattr(pedigree, "amd", pedigree)
+            if not isinstance(recorded, amd.Pedigree):
+                raise TypeError("the pedigree was not created through whatshap_amd.shim (no recorded individuals / trios) "
+                                "and the compiled ingestion (whatshap_amd/ingest/build.py) is not available")
         try:
-            table = amd.PedigreeDPTable(readset, recombcost, recorded, distrust_genotypes, positions, **solver_options)
+            table = amd.PedigreeDPTable(readset, recombcost, recorded, distrust_genotypes, positions, problem=problem, **solver_options)
         except RuntimeError as exc:
             status = getattr(exc, "status", None)
             if fallback_table_class is None or status not in _DEVICE_LIMIT_STATUSES:
