@@ -247,6 +247,15 @@ whamd_status_t whamd_debug_emulate_slot_plan(const whamd_readset_view* readset, 
  * mirror of ReadSet.sort(); not part of the DP path. */
 uint64_t whamd_read_sort_hash(const char* name, int source_id);
 
+/* Read selection (whatshap/readselect.pyx:218-255 readselection(readset, max_cov, preferred_source_ids, bridging)):
+ * selected_out[r] = 1 for every read the reference would return, 0 otherwise.  Host code (a priority queue; SURVEY.md
+ * section 8 row f2); ties are resolved as the reference resolves them under CPython 3.10 / libstdc++ (readselect.cpp).
+ * read_source_id: [n_reads] Read::getSourceID, may be NULL when n_preferred == 0.  A read with fewer than two variants
+ * is WHAMD_ERR_INVALID (the reference raises ValueError).  Uses var_position and var_quality of the view. */
+whamd_status_t whamd_readselection(const whamd_readset_view* readset, const int32_t* read_source_id,
+                                   const int32_t* preferred_source_ids, size_t n_preferred, uint32_t max_cov, int bridging,
+                                   uint8_t* selected_out, uint64_t* n_selected);
+
 #ifdef __cplusplus
 }
 #endif

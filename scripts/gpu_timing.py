@@ -1,4 +1,4 @@
-"""Timing probe: resident vs column path at the BASELINE shapes (optionally with WHAMD_DEBUG_TIMING=1)."""
+"""Timing probe: resident vs column path at the BASELINE shapes (optionally with WHAMD_DEBUG_STAMPS=1)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from whatshap_amd import _native

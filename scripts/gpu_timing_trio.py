@@ -1,4 +1,4 @@
-"""Timing probe for the trio (config 4) shape: in-kernel cycle split (WHAMD_DEBUG_TIMING) and slice-size sweep."""
+"""Timing probe for the trio (config 4) shape: in-kernel cycle split (WHAMD_DEBUG_STAMPS) and slice-size sweep."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from whatshap_amd import _native

@@ -243,6 +243,11 @@ def lib() -> C.CDLL:
     ]
     L.whamd_read_sort_hash.restype = C.c_uint64
     L.whamd_read_sort_hash.argtypes = [C.c_char_p, C.c_int]
+    L.whamd_readselection.restype = C.c_int
+    L.whamd_readselection.argtypes = [
+        C.POINTER(ReadSetView), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_size_t, C.c_uint32, C.c_int,
+        C.POINTER(C.c_uint8), C.POINTER(C.c_uint64),
+    ]
     if L.whamd_abi_version() != 1:
         raise ImportError("libwhatshap_amd.so has an unexpected ABI version")
     _lib = L
@@ -257,6 +262,7 @@ EXPORTED_SYMBOLS = [
     "whamd_dptable_get_super_reads", "whamd_dptable_get_optimal_partitioning", "whamd_dptable_get_index_path",
     "whamd_dptable_get_stats", "whamd_dptable_set_option", "whamd_read_sort_hash", "whamd_plan_summarize",
     "whamd_dptable_enqueue", "whamd_dptable_wait", "whamd_dptable_enqueue_many", "whamd_debug_emulate_slot_plan",
+    "whamd_readselection",
 ]
 
 
@@ -386,6 +392,30 @@ def emulate_slot_plan(problem: ProblemArrays, n_columns: int, slot_l: int = 11, 
 
 def device_count() -> int:
     return int(lib().whamd_device_count())
+
+
+def readselection(read_ptr, var_position, var_quality, max_cov: int, read_source_id=None, preferred_source_ids=None,
+                  bridging: bool = True) -> np.ndarray:
+    """whamd_readselection on flat arrays: boolean mask [n_reads] of the selected reads."""
+    read_ptr = np.ascontiguousarray(read_ptr, dtype=np.uint64)
+    if read_ptr.size == 0:
+        read_ptr = np.zeros(1, dtype=np.uint64)
+    var_position = np.ascontiguousarray(var_position, dtype=np.int32)
+    var_quality = np.ascontiguousarray(var_quality, dtype=np.uint32)
+    n_reads = read_ptr.size - 1
+    assert var_position.size == var_quality.size == int(read_ptr[-1])
+    view = ReadSetView(n_reads, _ptr(read_ptr, C.c_uint64), _ptr(var_position, C.c_int32), None, _ptr(var_quality, C.c_uint32), None)
+    preferred = np.ascontiguousarray(sorted(preferred_source_ids) if preferred_source_ids is not None else [], dtype=np.int32)
+    sources = None
+    if preferred.size:
+        sources = np.ascontiguousarray(read_source_id, dtype=np.int32)
+        assert sources.size == n_reads
+    selected = np.zeros(max(n_reads, 1), dtype=np.uint8)
+    count = C.c_uint64()
+    _check(lib().whamd_readselection(C.byref(view), None if sources is None else _ptr(sources, C.c_int32),
+                                     _ptr(preferred, C.c_int32) if preferred.size else None, preferred.size,
+                                     C.c_uint32(int(max_cov)), C.c_int(1 if bridging else 0), _ptr(selected, C.c_uint8), C.byref(count)))
+    return selected[:n_reads].astype(bool)
 
 
 def read_sort_hash(name: str, source_id: int) -> int:

@@ -42,6 +42,11 @@ double now_ms() {
 
 }  // namespace
 
+namespace whamd {
+// for the host-only entry points that live in other files (readselect.cpp)
+void set_last_error(const std::string& msg) { g_last_error = msg; }
+}
+
 extern "C" {
 
 int whamd_abi_version(void) { return WHAMD_ABI_VERSION; }

@@ -446,7 +446,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		final_job.final = true;
 		std::vector<Impl::Job> component_jobs;
 		const std::vector<uint32_t>& first = m.plan.component_first_step;
-		const bool split = m.max_lanes > 1 && first.size() > 1 && !getenv("WHAMD_DEBUG_TIMING");
+		const bool split = m.max_lanes > 1 && first.size() > 1 && !getenv("WHAMD_DEBUG_STAMPS");
 		if (!split) {
 			for (uint32_t si = 0; si < m.plan.steps.size(); ++si) final_job.steps.push_back(si);
 		} else {
@@ -682,14 +682,14 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		fprintf(stderr, "[whamd timing] upload: plan %.1f ms, descriptors + copies %.1f ms, backtrace arena (%.2f GB) %.1f ms, rest %.1f ms\n",
 		        ms(tu0, tu1), ms(tu1, tu2), (double)bt / 1e9, ms(tu2, tu3), ms(tu3, std::chrono::steady_clock::now()));
 	}
-	if (getenv("WHAMD_DEBUG_TIMING")) {
+	if (getenv("WHAMD_DEBUG_STAMPS") && !m.use_slots) {   // in-kernel cycle stamps of the LDS-resident runs (WHAMD_DEBUG_TIMING: host phases only)
 		void* d_dbg = nullptr;
 		const size_t dbg_bytes = (m.plan.segments.size() + 1) * 64 + 4 * 512 * 16 + 64;
 		HIP_TRY(alloc(&d_dbg, dbg_bytes));
 		HIP_TRY(hipMemset(d_dbg, 0, dbg_bytes));
 		m.dp.dbg = (unsigned long long*)d_dbg;
 		m.dp.dbg_wg_off = (uint32_t)((m.plan.segments.size() + 1) * 8);
-		m.dp.dbg_flags = (uint32_t)atoi(getenv("WHAMD_DEBUG_TIMING"));
+		m.dp.dbg_flags = (uint32_t)atoi(getenv("WHAMD_DEBUG_STAMPS"));
 	}
 	if (getenv("WHAMD_SLOT_STAMPS") && m.use_slots) {   // in-kernel cycle stamps of workgroup 0 / wave 0 of every slot run
 		void* d_dbg = nullptr;

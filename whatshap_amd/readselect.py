@@ -1,0 +1,59 @@
+"""``readselection`` -- the drop-in for ``whatshap.readselect.readselection`` (``whatshap/readselect.pyx:218-255``; its
+caller is ``whatshap/cli/phase.py:157-170`` ``select_reads``), SURVEY.md section 8 row (f2): the step that prunes a
+ReadSet to the coverage the DP can afford, directly upstream of ``PedigreeDPTable``.
+
+Host code behind the C ABI (``whamd_readselection``, ``whatshap_amd/csrc/readselect.cpp``): the algorithm is a priority
+queue whose scores change after every pick, there is nothing for the GPU in it.  It returns the same *set* of read
+indices as the reference, ties included (the C++ replays the iteration orders of the reference's Python sets).
+"""
+from typing import Iterable, Optional, Set
+
+import numpy as np
+
+from . import _native
+
+
+def _flat(readset):
+    """(read_ptr, positions, qualities) of our ReadSet mirror or of a reference ReadSet."""
+    from . import core
+
+    if isinstance(readset, core.ReadSet):
+        read_ptr, pos, _alle, qual, _samples = core._flatten_readset(readset)
+        return read_ptr, pos, qual
+    from . import ingest
+
+    compiled = ingest.load()
+    if compiled is not None:
+        try:
+            read_ptr, pos, _alle, qual, _samples = compiled.flatten_readset(readset)
+            return read_ptr, pos, qual
+        except TypeError:
+            pass
+    read_ptr = [0]
+    pos, qual = [], []
+    for read in readset:
+        for v in read:
+            pos.append(v.position)
+            qual.append(v.quality)
+        read_ptr.append(len(pos))
+    return np.asarray(read_ptr, dtype=np.uint64), np.asarray(pos, dtype=np.int32), np.asarray(qual, dtype=np.uint32)
+
+
+def readselection(readset, max_cov: int, preferred_source_ids: Optional[Iterable[int]] = None, bridging: bool = True) -> Set[int]:
+    """Indices of the reads to keep so that no variant is covered more than ``max_cov`` times.
+
+    Same signature, result and error as ``whatshap.readselect.readselection``: reads that cover fewer than two variants
+    raise ``ValueError`` (``readselect.pyx:236-239``).
+    """
+    read_ptr, pos, qual = _flat(readset)
+    sources = None
+    if preferred_source_ids is not None:
+        preferred_source_ids = set(int(s) for s in preferred_source_ids)
+        sources = np.asarray([read.source_id for read in readset], dtype=np.int32)
+    try:
+        mask = _native.readselection(read_ptr, pos, qual, max_cov, sources, preferred_source_ids, bridging)
+    except _native.SolverError as e:
+        if e.status == _native.WHAMD_ERR_INVALID:
+            raise ValueError(str(e)) from None
+        raise
+    return set(np.flatnonzero(mask).tolist())
