@@ -197,6 +197,10 @@ whamd_status_t whamd_dptable_get_stats(const whamd_dptable* table, whamd_solve_s
  *                   "column" (one launch per column, the general path) | "column_keys"
  *   "slot_l"        preferred number of local slots of a slot run (slot_r + 6 .. slot_r + 9: 1 .. 8 waves per workgroup)
  *   "slot_r"        reg slots of a slot run: "2" (4 cells per thread, default) or "3" (8 cells per thread)
+ *   "arena_limit_bytes"  upper bound of the backtrace arena (default: what free HBM allows).  A table whose records need
+ *                   more is solved in windows: the forward pass keeps the projection column at every window boundary and
+ *                   the steps of every window but the newest are run a second time right before their records are walked
+ *                   (same result, up to twice the forward time, any table length).
  *   "resident_l"    preferred log2 slice size of the run kernels
  *   "resident_fold" "0" disables folding of columns without an ending read
  *   "symmetry"      single individual: D[~x] == D[x], so a run may compute half of its workgroups only: "0" never,

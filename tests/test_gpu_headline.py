@@ -66,3 +66,68 @@ def test_full_size_every_path_and_symmetry_setting_agree(kw):
     for path, symmetry in VARIANTS[1:]:
         got = solve(p, path, symmetry)
         assert got == base, (path, symmetry, first_difference(base, got))
+    # windowed solve (arena capped at a fraction of the ~13 / ~6.5 GB the records need): same answer
+    got = solve(p, "auto", "1", arena_limit_bytes=3 << 30)
+    assert got == base, ("windowed", first_difference(base, got))
+
+
+# ---- windowed solve: the backtrace arena capped far below what the table's records need (tables beyond HBM)
+WINDOW_CASES = [
+    # kwargs of synthetic_block, path, arena limit in bytes
+    (dict(n_variants=3000, coverage=12, seed=11), "auto", 1 << 17),
+    (dict(n_variants=3000, coverage=12, seed=11), "resident", 1 << 17),
+    (dict(n_variants=3000, coverage=12, seed=11), "column", 1 << 18),
+    (dict(n_variants=20000, coverage=16, seed=12), "auto", 64 << 20),
+]
+
+
+@pytest.mark.parametrize("kw,path,limit", WINDOW_CASES, ids=str)
+def test_windowed_solve_equals_the_unrestricted_solve(kw, path, limit):
+    p = synthetic_block(**kw)
+    t = _native.NativeTable(p, solve=False, path=path)
+    t.solve()
+    base = table_solution(t)
+    base_launches = t.stats()["forward_launches"]
+    t.close()
+    t = _native.NativeTable(p, solve=False, path=path)
+    t.set_option("arena_limit_bytes", str(limit))
+    t.solve()
+    got = table_solution(t)
+    launches = t.stats()["forward_launches"]
+    t.solve()                       # a second solve of the same table replays the same program
+    again = table_solution(t)
+    t.close()
+    assert got == base, first_difference(base, got)
+    assert again == base
+    assert launches > base_launches, "the arena limit did not force a windowed solve"
+
+
+def test_windowed_trio_equals_the_unrestricted_solve():
+    p = synthetic_block(n_variants=1500, coverage=5, seed=21, trio=True)
+    base = solve(p, "auto", "1")
+    for limit in (1 << 20, 1 << 17):
+        got = solve(p, "auto", "1", arena_limit_bytes=limit)
+        assert got == base, (limit, first_difference(base, got))
+
+
+def test_windowed_table_of_many_connected_components():
+    """Connected components are jobs of their own in an unrestricted solve; a windowed solve runs them as one job."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    from gpu_multiblock import chromosome
+
+    whole = chromosome(12, 11, seed=7, max_len=150)
+    want = table_solution(oracle.OracleTable(whole))
+    for limit in (1 << 22, 1 << 16):
+        got = solve(whole, "auto", "1", arena_limit_bytes=limit)
+        assert got == want, (limit, first_difference(want, got))
+
+
+def test_unit_larger_than_the_arena_is_unsupported():
+    p = synthetic_block(n_variants=400, coverage=12, seed=14)
+    t = _native.NativeTable(p, solve=False)
+    t.set_option("arena_limit_bytes", "256")
+    with pytest.raises(_native.SolverError) as e:
+        t.solve()
+    assert e.value.status == _native.WHAMD_ERR_UNSUPPORTED
+    t.close()

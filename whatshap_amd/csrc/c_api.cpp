@@ -270,6 +270,11 @@ whamd_status_t whamd_dptable_set_option(whamd_dptable* t, const char* key, const
 		t->uploaded = false;
 		return WHAMD_OK;
 	}
+	if (k == "arena_limit_bytes") {
+		t->device.set_arena_limit(std::strtoull(value, nullptr, 10));
+		t->uploaded = false;
+		return WHAMD_OK;
+	}
 	return fail(WHAMD_ERR_INVALID, "unknown option '" + k + "'");
 }
 

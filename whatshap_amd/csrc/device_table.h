@@ -45,6 +45,9 @@ public:
 	// Lanes over which the connected components of a single-individual table are spread (default 32, 1 = off); the
 	// lanes advance in lockstep, their runs go out as batched launches; next upload().
 	void set_lanes(int n);
+	// Upper bound of the backtrace arena in bytes (0 = whatever free HBM allows).  A table whose records need more is
+	// solved in windows (the forward pass of every window but the newest runs twice); next upload().
+	void set_arena_limit(uint64_t bytes);
 
 private:
 	whamd_status_t enqueue_some_unguarded(const Problem& p, Solution& s, uint64_t budget, bool& done, std::string& msg);

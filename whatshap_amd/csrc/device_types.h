@@ -54,13 +54,14 @@ struct DevProblem {
 	unsigned long long* spec_keys;  // [chunk boundary][spec_stride]: per wave of the boundary run, min over the cells it stored of
 	                                // (value << 32 | exit index); all-ones before
 	uint32_t spec_stride;
-	unsigned long long* dbg;  // optional cycle-counter dump (WHAMD_DEBUG_TIMING)
+	unsigned long long* dbg;  // optional cycle-counter dump (WHAMD_DEBUG_STAMPS / WHAMD_SLOT_STAMPS)
 	uint32_t dbg_wg_off;      // word offset of the per-workgroup start/end stamps inside dbg
 	uint32_t dbg_flags;       // experiments: bit 0 skip the slice store, bit 1 skip the record store (results invalid)
 	uint32_t n_cols;
 	uint32_t T;
 	uint32_t tbits;         // 2 * triples
 	uint32_t n_ind;
+	uint32_t* bt_state;     // windowed solve (DeviceTable::Impl::Window): (x, transmission value) at the oldest column walked so far
 };
 
 }  // namespace whamd

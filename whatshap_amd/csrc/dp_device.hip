@@ -127,6 +127,10 @@ struct DeviceTable::Impl {
 		size_t lds = 0;
 		bool sym = false;  // some run of the batch takes part in the complement symmetry
 		std::vector<Single> singles;
+		// windowed solve: restore the kept column of boundary ck_load into this step's input before it runs; keep this
+		// step's output as boundary ck_save; walk window bt_window after it
+		int32_t ck_load = -1, ck_save = -1, bt_window = -1;
+		uint32_t* io[2] = {nullptr, nullptr};   // input / output exchange buffer of the step (single lane)
 	};
 	std::vector<Job> jobs;
 	std::vector<Lane> lanes;
@@ -155,6 +159,22 @@ struct DeviceTable::Impl {
 	uint32_t* d_job_scores = nullptr;
 	int max_lanes = 32;
 	size_t next_super = 0;  // cursor of the resumable enqueue
+	// Windowed solve (backtrace arena larger than what HBM can hold): the steps are cut into WINDOWS whose records fit the
+	// arena one at a time.  Pass 1 runs the whole forward pass (records of all windows but the last are written and
+	// dropped) and keeps the exchange column at every window boundary; then, newest window first, the window's steps
+	// are run again from the kept column -- this time its records survive until its units have been walked.  Twice the
+	// forward work, any table length.  Offsets into the arena are window-relative.
+	struct Window {
+		uint32_t step_lo = 0, step_hi = 0;   // positions in the job's step list
+		uint32_t unit_off = 0, unit_count = 0;
+	};
+	uint64_t arena_limit = 0;   // option arena_limit_bytes (0: what hipMemGetInfo leaves)
+	bool windowed = false;
+	std::vector<Window> windows;
+	uint8_t* d_checkpoints = nullptr;   // [windows - 1] exchange columns
+	size_t checkpoint_bytes = 0;
+	uint32_t* d_bt_state = nullptr;     // (x, transmission) the walk of a window hands to the next older one
+	BtJob* d_window_jobs = nullptr;
 
 	void launch_column_step(const Problem& p, const Step& step, const Lane& lane, const uint32_t* prev, uint32_t* cur, uint64_t& launches);
 	void launch_run(const ResBatchEntry& e, uint32_t step_index, uint64_t& launches);
@@ -166,10 +186,12 @@ struct DeviceTable::Impl {
 		schedule.clear();
 		entries.clear();
 		slot_entries.clear();
+		windows.clear();
 	}
 
 	void release() {
 		release_lanes();
+		windowed = false;
 		for (void* a : allocations) (void)hipFree(a);
 		allocations.clear();
 		if (h_pinned) (void)hipHostFree(h_pinned);
@@ -242,6 +264,7 @@ void DeviceTable::set_fold(bool v) { impl_->fold = v; }
 void DeviceTable::set_slot_l(int l) { impl_->slot_l = std::max(8, std::min(l, 12)); }
 void DeviceTable::set_slot_lr(int lr) { impl_->slot_lr = lr >= 3 ? 3 : 2; }
 
+void DeviceTable::set_arena_limit(uint64_t bytes) { impl_->arena_limit = bytes; }
 void DeviceTable::set_symmetry(int level) { impl_->symmetry = level < 0 ? 0 : (level > 2 ? 2 : level); }
 
 whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& msg) {
@@ -326,6 +349,28 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	uint64_t bt = 0, seg_bt = 0;
 	size_t seg_cursor = 0, slot_cursor = 0;
 	uint32_t max_f = 0, max_keys_f = 0;
+	size_t free_b = 0, total_b = 0;
+	HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+	// what the arena may take: free HBM minus the descriptors (~1 KiB per column), exchange buffers and slack
+	const uint64_t reserve = (3ull << 30) + (uint64_t)n * 1024ull;
+	uint64_t arena_cap = free_b > reserve ? free_b - reserve : 0;
+	if (m.arena_limit) arena_cap = std::min<uint64_t>(arena_cap, m.arena_limit);
+	std::vector<uint32_t> window_first_col;   // first column of every window after the first
+	uint64_t bt_max = 0;
+	auto open_unit = [&](uint32_t c, uint64_t bytes) -> bool {   // a backtrace unit of `bytes` starts at column c
+		if (bytes + 16 > arena_cap) return false;
+		if (bt + bytes + 16 > arena_cap) {
+			bt_max = std::max(bt_max, bt);
+			bt = 0;
+			window_first_col.push_back(c);
+		}
+		return true;
+	};
+	auto unit_too_large = [&](uint32_t c) {
+		msg = "the backtrace record of the unit at column " + std::to_string(c) + " alone does not fit in the arena (" + std::to_string(arena_cap >> 20) +
+		      " MiB of " + std::to_string(free_b >> 20) + " MiB free HBM)";
+		return WHAMD_ERR_UNSUPPORTED;
+	};
 	for (uint32_t c = 0; c < n; ++c) {
 		DevColumn& d = m.cols[c];
 		d.k = p.k[c];
@@ -349,6 +394,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 			d.res_idx = (uint32_t)m.splan.col_to_row[c];
 			if (slot_cursor < m.splan.runs.size() && m.splan.runs[slot_cursor].c0 == c) {  // first column of a slot run
 				SlotRun& run = m.splan.runs[slot_cursor];
+				if (!open_unit(c, (uint64_t)run.n_ends * run.threads * (1ull << (run.g - run.half)))) return unit_too_large(c);
 				run.rec_lo = (uint32_t)bt;
 				run.rec_hi = (uint32_t)(bt >> 32);
 				seg_bt = bt;
@@ -362,6 +408,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 			d.res_idx = (uint32_t)m.plan.col_to_res[c];
 			if (seg_cursor < m.plan.segments.size() && m.plan.segments[seg_cursor].c0 == c) {  // first column of a run
 				ResSegment& sgm = m.plan.segments[seg_cursor];
+				if (!open_unit(c, (uint64_t)sgm.stage_words * (1ull << sgm.g) * 8ull)) return unit_too_large(c);
 				sgm.bt_lo = (uint32_t)bt;
 				sgm.bt_hi = (uint32_t)(bt >> 32);
 				seg_bt = bt;
@@ -372,16 +419,20 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		} else {
 			const bool fused_ok = !force_keys && !d.is_last && d.f >= 6 && d.ebits <= (uint32_t)QMAX;
 			d.mode = fused_ok ? 0u : 1u;
-			if (d.mode == 0) bt += (uint64_t)d.nplanes * p.T * (1ull << (d.f - 6)) * 8ull;
-			else { bt += (uint64_t)p.T * (1ull << d.f) * 4ull; max_keys_f = std::max(max_keys_f, d.f); }
+			const uint64_t bytes = d.mode == 0 ? (uint64_t)d.nplanes * p.T * (1ull << (d.f - 6)) * 8ull : (uint64_t)p.T * (1ull << d.f) * 4ull;
+			if (!open_unit(c, bytes)) return unit_too_large(c);
+			d.bt_off = bt;
+			bt += bytes;
+			if (d.mode != 0) max_keys_f = std::max(max_keys_f, d.f);
 		}
 		bt = (bt + 15ull) & ~15ull;
 		max_f = std::max(max_f, d.f);
 	}
+	bt = bt_max = std::max(bt_max, bt);
 	m.bt_bytes = bt;
-	size_t free_b = 0, total_b = 0;
-	HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-	const uint64_t need = bt + 2ull * (1ull << max_f) * p.T * 4ull + (1ull << max_keys_f) * p.T * 8ull;
+	m.windowed = !window_first_col.empty();
+	m.checkpoint_bytes = (size_t)(1ull << max_f) * p.T * 4;
+	const uint64_t need = bt + (2ull + window_first_col.size()) * (1ull << max_f) * p.T * 4ull + (1ull << max_keys_f) * p.T * 8ull;
 	if (need + (1ull << 30) > free_b) {
 		msg = "backtrace arena of " + std::to_string(need >> 20) + " MiB does not fit in free HBM (" + std::to_string(free_b >> 20) + " MiB)";
 		return WHAMD_ERR_UNSUPPORTED;
@@ -446,7 +497,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		final_job.final = true;
 		std::vector<Impl::Job> component_jobs;
 		const std::vector<uint32_t>& first = m.plan.component_first_step;
-		const bool split = m.max_lanes > 1 && first.size() > 1 && !getenv("WHAMD_DEBUG_STAMPS");
+		const bool split = m.max_lanes > 1 && first.size() > 1 && !getenv("WHAMD_DEBUG_STAMPS") && !m.windowed;
 		if (!split) {
 			for (uint32_t si = 0; si < m.plan.steps.size(); ++si) final_job.steps.push_back(si);
 		} else {
@@ -508,12 +559,48 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		job.unit_count = (uint32_t)m.units.size() - job.unit_off;
 		}
 	}
+	// ---- windows (see Impl::Window): the single job's steps cut where the arena offsets start over
+	if (m.windowed) {
+		const std::vector<uint32_t>& steps = m.jobs[0].steps;
+		const uint32_t n_steps = (uint32_t)steps.size();
+		auto first_col = [&](uint32_t pos) {
+			const Step& st = m.plan.steps[steps[pos]];
+			return st.kind == 0 ? st.index : (st.kind == 2 ? m.splan.runs[st.index].c0 : m.plan.segments[st.index].c0);
+		};
+		Impl::Window w;
+		size_t next = 0;
+		for (uint32_t pos = 0; pos < n_steps; ++pos) {
+			if (next < window_first_col.size() && first_col(pos) == window_first_col[next]) {
+				w.step_hi = pos;
+				m.windows.push_back(w);
+				w = Impl::Window();
+				w.step_lo = pos;
+				++next;
+			}
+		}
+		w.step_hi = n_steps;
+		m.windows.push_back(w);
+		if (next != window_first_col.size()) { msg = "internal error: a window does not start at a step"; return WHAMD_ERR_DEVICE; }
+		std::vector<BtJob> wjobs;
+		for (size_t wi = 0; wi < m.windows.size(); ++wi) {   // units are the steps in reverse order
+			Impl::Window& win = m.windows[wi];
+			win.unit_off = n_steps - win.step_hi;
+			win.unit_count = win.step_hi - win.step_lo;
+			wjobs.push_back(BtJob{win.unit_off, win.unit_count, wi + 1 == m.windows.size() ? 1u : 2u, 0u});
+		}
+		void* d_wjobs = nullptr;
+		HIP_TRY(up(&d_wjobs, wjobs.data(), wjobs.size() * sizeof(BtJob)));
+		m.d_window_jobs = (BtJob*)d_wjobs;
+		HIP_TRY(alloc((void**)&m.d_checkpoints, (m.windows.size() - 1) * m.checkpoint_bytes));
+		HIP_TRY(alloc((void**)&m.d_bt_state, 16));
+		if (getenv("WHAMD_DEBUG_TIMING")) fprintf(stderr, "[whamd timing] windowed solve: %zu windows, arena %.2f GB\n", m.windows.size(), (double)bt / 1e9);
+	}
 	// ---- chunks of the speculative backtrace: a new chunk starts at every BT_CHUNK_RUNS-th slot run (single job only)
 	m.use_chunks = false;
 	m.chunks.clear();
 	m.n_spec = 0;
 	for (SlotRun& run : m.splan.runs) run.spec_id = 0;
-	if (m.use_slots && m.jobs.size() == 1 && !getenv("WHAMD_BT_SEQUENTIAL") && m.units.size() > 2u * BT_CHUNK_RUNS) {
+	if (m.use_slots && m.jobs.size() == 1 && !m.windowed && !getenv("WHAMD_BT_SEQUENTIAL") && m.units.size() > 2u * BT_CHUNK_RUNS) {
 		m.use_chunks = true;
 		BtChunk cur{0, 0, 0, 0};
 		uint32_t runs_in_chunk = 0;
@@ -622,6 +709,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 					e.prev = lane.d_pr[c.flip];
 					e.cur = lane.d_pr[c.flip ^ 1];
 					e.score_out = (last && !job.final) ? m.d_job_scores + job_id : nullptr;
+					ss.io[0] = lane.d_pr[c.flip]; ss.io[1] = lane.d_pr[c.flip ^ 1];
 					ss.lds = std::max<size_t>(ss.lds, (size_t)2 * e.run.threads * (1u << e.run.lr) * 4 + (SLOT_MAXCOLS + 8) * 64 + 8 * 64 * 4 + SLOT_MAXCOLS * 64 * 4);
 					ss.grid_x = std::max(ss.grid_x, 1u << (e.run.g - e.run.half));
 					ss.threads = std::max(ss.threads, e.run.threads);
@@ -635,6 +723,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 					e.prev = lane.d_pr[c.flip];
 					e.cur = lane.d_pr[c.flip ^ 1];
 					e.score_out = (last && !job.final) ? m.d_job_scores + job_id : nullptr;
+					ss.io[0] = lane.d_pr[c.flip]; ss.io[1] = lane.d_pr[c.flip ^ 1];
 					const size_t lds = e.sg.kind == 1
 						? ((((size_t)e.sg.ncols * (PED_LDSWORDS + PED_TABLE) + (size_t)e.sg.n_terms * 2 + 3) & ~(size_t)3) * 4 + 2 * ((size_t)16 << e.sg.max_l) + (size_t)e.sg.stage_words * 8)
 						: ((size_t)e.sg.ncols * (64 + RES_TABLE) * 4 + 2 * ((size_t)4 << e.sg.max_l) + (size_t)e.sg.stage_words * 8);
@@ -646,12 +735,31 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 					++ss.entry_count;
 				} else {
 					ss.singles.push_back(Impl::Single{(uint32_t)li, si, c.flip, first, (last && !job.final) ? (int32_t)job_id : -1});
+					ss.io[0] = lane.d_pr[c.flip]; ss.io[1] = lane.d_pr[c.flip ^ 1];
 				}
 				c.flip ^= 1;
 				if (last) { ++c.job_i; c.step_i = 0; } else ++c.step_i;
 			}
 			if (!ss.entry_count && ss.singles.empty()) break;
 			m.schedule.push_back(std::move(ss));
+		}
+		if (m.windowed) {
+			// one lane, one job: super-step i is step i.  Pass 1 = the schedule as it is, plus the kept columns and the
+			// walk of the newest window; then every older window again, newest first.
+			if (m.schedule.size() != m.jobs[0].steps.size()) { msg = "internal error: windowed schedule"; return WHAMD_ERR_DEVICE; }
+			const size_t nw = m.windows.size();
+			for (size_t wi = 0; wi + 1 < nw; ++wi) m.schedule[m.windows[wi].step_hi - 1].ck_save = (int32_t)wi;
+			m.schedule.back().bt_window = (int32_t)(nw - 1);
+			for (size_t wi = nw - 1; wi-- > 0;) {
+				const Impl::Window& win = m.windows[wi];
+				for (uint32_t pos = win.step_lo; pos < win.step_hi; ++pos) {
+					Impl::SuperStep again = m.schedule[pos];
+					again.ck_save = -1;
+					again.ck_load = (pos == win.step_lo && wi > 0) ? (int32_t)(wi - 1) : -1;
+					again.bt_window = pos + 1 == win.step_hi ? (int32_t)wi : -1;
+					m.schedule.push_back(std::move(again));
+				}
+			}
 		}
 		void* d_entries = nullptr;
 		HIP_TRY(up(&d_entries, m.entries.data(), m.entries.size() * sizeof(ResBatchEntry)));
@@ -674,6 +782,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	m.dp.bt = (uint8_t*)d_bt;
 	m.dp.keys = (unsigned long long*)d_keys;
 	m.dp.last_keys = (unsigned long long*)d_last_keys;
+	m.dp.bt_state = m.windowed ? m.d_bt_state : nullptr;
 	m.dp.res_cols = (const ResColumn*)d_rcol;
 	m.dp.res_bt = (const ResBacktrace*)d_rbt;
 	m.dp.dbg = nullptr;
@@ -838,6 +947,7 @@ whamd_status_t DeviceTable::enqueue_some_unguarded(const Problem& p, Solution& s
 		for (const Impl::Lane& lane : m.lanes) HIP_TRY(hipMemsetAsync(lane.d_keys, 0xFF, m.key_entries * 8, m.stream));
 		HIP_TRY(hipMemsetAsync(m.dp.last_keys, 0xFF, (size_t)MAX_T * 8, m.stream));
 		if (m.use_chunks) HIP_TRY(hipMemsetAsync(m.dp.spec_keys, 0xFF, ((size_t)m.n_spec + 1) * m.dp.spec_stride * 8, m.stream));
+		if (m.windowed) HIP_TRY(hipMemsetAsync(m.d_path_trans, 0, (size_t)n * 4, m.stream));
 		HIP_TRY(hipEventRecord(m.ev0, m.stream));
 		if (!m.plan.ped_columns.empty()) {
 			const uint32_t entries = (uint32_t)m.plan.ped_columns.size() * PED_TABLE;
@@ -850,6 +960,7 @@ whamd_status_t DeviceTable::enqueue_some_unguarded(const Problem& p, Solution& s
 	uint64_t launches = 0;
 	while (m.next_super < m.schedule.size() && launches < budget) {
 		const Impl::SuperStep& ss = m.schedule[m.next_super++];
+		if (ss.ck_load >= 0) HIP_TRY(hipMemcpyAsync(ss.io[0], m.d_checkpoints + (size_t)ss.ck_load * m.checkpoint_bytes, m.checkpoint_bytes, hipMemcpyDeviceToDevice, m.stream));
 		if (m.use_slots) {
 			if (ss.entry_count == 1) m.launch_slot_run(m.slot_entries[ss.entry_off], launches);
 			else if (ss.entry_count > 1) {
@@ -871,6 +982,10 @@ whamd_status_t DeviceTable::enqueue_some_unguarded(const Problem& p, Solution& s
 			if (sg.score_job >= 0)
 				HIP_TRY(hipMemcpyAsync(m.d_job_scores + sg.score_job, lane.d_pr[sg.flip ^ 1], 4, hipMemcpyDeviceToDevice, m.stream));
 		}
+		if (ss.ck_save >= 0) HIP_TRY(hipMemcpyAsync(m.d_checkpoints + (size_t)ss.ck_save * m.checkpoint_bytes, ss.io[1], m.checkpoint_bytes, hipMemcpyDeviceToDevice, m.stream));
+		if (ss.bt_window >= 0)
+			hipLaunchKernelGGL(backtrace_kernel, dim3(1), dim3(1024), m.bt_lds, m.stream, m.dp, m.d_units, m.d_window_jobs + ss.bt_window,
+			                   m.d_path_index, m.d_path_trans, m.d_score);
 	}
 	m.launches += launches;
 	if (m.next_super < m.schedule.size()) return WHAMD_OK;
@@ -883,7 +998,7 @@ whamd_status_t DeviceTable::enqueue_some_unguarded(const Problem& p, Solution& s
 		hipLaunchKernelGGL(backtrace_chunks, dim3(1), dim3(256), m.chunk_lds, m.stream, m.dp, m.d_units, m.d_chunks,
 		                   (uint32_t)m.chunks.size(), (uint32_t)m.units.size(), 1u, m.d_path2, m.d_path_trans, m.d_score, m.d_unit_x, m.d_guess, m.d_sel, m.d_bt_counters);
 		hipLaunchKernelGGL(backtrace_gather, dim3((uint32_t)m.units.size()), dim3(64), 0, m.stream, m.d_units, (uint32_t)m.units.size(), n, m.d_path2, m.d_sel, m.d_path_index);
-	} else
+	} else if (!m.windowed)   // (windowed: every window was walked right after its steps)
 	hipLaunchKernelGGL(backtrace_kernel, dim3((uint32_t)m.jobs.size()), dim3(1024), m.bt_lds, m.stream, m.dp, m.d_units, m.d_btjobs,
 	                   m.d_path_index, m.d_path_trans, m.d_score);
 	HIP_TRY(hipGetLastError());

@@ -29,9 +29,13 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 	unsigned long long* stage = reinterpret_cast<unsigned long long*>(tsarr + RES_MAXCOLS);
 	const uint32_t lane = threadIdx.x, NT = blockDim.x;
 	const uint32_t n = P.n_cols, T = P.T;
-	const uint32_t u_first = with_last_column ? 1u : 0u;
+	const uint32_t u_first = with_last_column == 1u ? 1u : 0u;
 	uint32_t x = 0, tprev = 0;
-	if (with_last_column) {
+	if (with_last_column == 2u) {   // windowed solve: continue where the walk of the next newer window stopped
+		x = P.bt_state[0];
+		tprev = P.bt_state[1];
+	}
+	if (with_last_column == 1u) {
 		// optimum of the last column: first (rank(x), i) attaining the minimum (strict '<' scan, :306-315)
 		unsigned long long bestk = ~0ull;
 		uint32_t t = 0;
@@ -348,6 +352,10 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 			tprev = xshare[1];
 			if (P.dbg) { bt_load += tb1 - tb0; bt_walk += __builtin_readcyclecounter() - tb1; bt_runs++; }
 		}
+	}
+	if (P.bt_state && lane == 0) {
+		P.bt_state[0] = x;
+		P.bt_state[1] = tprev;
 	}
 	if (P.dbg && lane == 0) {
 		unsigned long long* d = P.dbg + P.dbg_wg_off + 4 * 512 * 2;

@@ -186,7 +186,8 @@ static_assert(sizeof(BtUnit) == 128, "BtUnit must stay 32 words");
 // One backtrace job (blockIdx.x of backtrace_kernel): a contiguous range of units, newest first.
 struct BtJob {
 	uint32_t unit_off, unit_count;
-	uint32_t with_last_column;  // 1: units[0] is the table's last column (optimum from the key scratch); 0: start at entry 0
+	uint32_t with_last_column;  // 1: units[0] is the table's last column (optimum from the key scratch); 0: start at entry 0;
+	                            // 2: start from DevProblem::bt_state (windowed solve)
 	uint32_t pad;
 };
 
