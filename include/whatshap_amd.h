@@ -260,6 +260,34 @@ whamd_status_t whamd_readselection(const whamd_readset_view* readset, const int3
                                    const int32_t* preferred_source_ids, size_t n_preferred, uint32_t max_cov, int bridging,
                                    uint8_t* selected_out, uint64_t* n_selected);
 
+/* ---- GenotypeDPTable -----------------------------------------------------------------
+ * Replaces  cppclass GenotypeDPTable (whatshap/cpp.pxd:118-121; src/genotypedptable.cpp):
+ *     GenotypeDPTable(ReadSet*, vector[unsigned int] recombcost, Pedigree* pedigree, vector[unsigned int]* positions)
+ *     vector[long double] get_genotype_likelihoods(unsigned int individual_id, unsigned int position)
+ * One call = constructor (the whole forward-backward pass) + get_genotype_likelihoods for every individual and column.
+ * The pedigree view must carry genotype_likelihoods: here they are the genotype PRIORS (probabilities of 0/0, 0/1, 1/1;
+ * the reference asserts they are present, src/transitionprobabilitycomputer.cpp:66); its `genotype` codes are not used.
+ * gl_out: [n_individuals][n_columns][3], every triple sums to 1.  n_columns = n_positions, or the number of distinct
+ * read positions when positions is NULL; gl_capacity (in doubles) must be at least n_individuals * n_columns * 3.
+ * Arithmetic is f64 (the reference: long double): results agree to a relative tolerance (~1e-12), not bit for bit. */
+typedef struct whamd_genotype_stats {
+	uint64_t n_columns;
+	uint64_t n_cells;        /* sum_c 2^k_c */
+	uint64_t launches;
+	double backward_ms;      /* HIP events: backward pass that leaves the kept columns */
+	double forward_ms;       /* HIP events: windows (backward recompute + forward + normalisation) */
+	double total_ms;
+	double host_prepare_ms;  /* wall: flattening + model tables + upload + solve + download, minus total_ms */
+	uint32_t window;         /* columns per window */
+	uint32_t max_coverage;
+	uint32_t transmissions;
+	uint32_t pad;
+} whamd_genotype_stats;
+whamd_status_t whamd_genotype_likelihoods(const whamd_readset_view* readset, const uint32_t* recombcost, size_t n_recombcost,
+                                          const whamd_pedigree_view* pedigree, const uint32_t* positions, size_t n_positions,
+                                          int device, uint32_t window, double* gl_out, size_t gl_capacity,
+                                          whamd_genotype_stats* stats_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,113 @@
+"""GPU (-m gpu): GenotypeDPTable on the device against the REAL reference class
+(whatshap.core.GenotypeDPTable, built into oracle/_ref/cy) and against the CPU restatement.  The reference computes in
+long double, the device in f64: agreement to rtol 1e-9 (observed ~1e-13)."""
+import numpy as np
+import pytest
+
+from genotype_cases import random_case, reference_likelihoods
+from oracle import genotype_oracle
+from refobjects import reference_core
+from test_genotype_oracle import REFERENCE_VECTORS, _matrix_problem
+from whatshap_amd import _native, core
+from whatshap_amd.genotype import GenotypeDPTable
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 1e-9, 1e-13
+
+
+def device_likelihoods(problem, window=0):
+    n_columns = problem.positions.size if problem.positions is not None else np.unique(problem.var_position).size
+    gl, stats = _native.genotype_likelihoods(problem, int(n_columns), window=window)
+    return gl, stats
+
+
+@pytest.mark.parametrize("lines,want", REFERENCE_VECTORS, ids=["exact1", "exact2", "exact3"])
+def test_known_answers_of_the_reference_tests(lines, want):
+    gl, _ = device_likelihoods(_matrix_problem(lines))
+    assert np.allclose(gl[0], want, rtol=1e-9)
+
+
+@pytest.mark.parametrize("mode,n_cases", [("single", 40), ("trio", 25), ("quartet", 8)])
+def test_small_random_cases_vs_restatement_and_reference(mode, n_cases):
+    ref = reference_core()
+    for seed in range(n_cases):
+        p = random_case(7000 + 100 * len(mode) + seed, n_variants=8, n_reads=10 if mode == "single" else 8, max_len=4, mode=mode,
+                        max_coverage=6 if mode == "single" else 4, uniform_prior=seed % 3 == 0)
+        want = reference_likelihoods(p, ref)
+        oracle_gl = np.asarray(genotype_oracle.genotype_likelihoods(p), dtype=np.float64)
+        for window in (0, 1, 3):
+            got, _ = device_likelihoods(p, window)
+            assert np.allclose(got, want, rtol=RTOL, atol=ATOL), (mode, seed, window, np.abs(got - want).max())
+            assert np.allclose(got, oracle_gl, rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(mode="single", n_variants=300, n_reads=900, max_len=12, max_coverage=12),
+    dict(mode="single", n_variants=120, n_reads=500, max_len=9, max_coverage=15, phred=(0, 60)),
+    dict(mode="trio", n_variants=200, n_reads=500, max_len=8, max_coverage=9),
+    dict(mode="quartet", n_variants=60, n_reads=150, max_len=6, max_coverage=7),
+], ids=str)
+def test_larger_cases_vs_the_reference_class(kw):
+    ref = reference_core()
+    p = random_case(99, **kw)
+    want = reference_likelihoods(p, ref)
+    for window in (0, 7):
+        got, stats = device_likelihoods(p, window)
+        assert np.allclose(got, want, rtol=RTOL, atol=ATOL), (window, np.abs(got - want).max())
+        assert np.allclose(got.sum(axis=2), 1.0)
+    assert stats["n_columns"] == kw["n_variants"]
+
+
+def test_many_reads_starting_and_ending_in_one_column():
+    """Columns in which more reads start / end than a thread loops over: the split (atomic) accumulation path."""
+    ref = reference_core()
+    rng = np.random.default_rng(5)
+    read_ptr, pos, alle, qual = [0], [], [], []
+    for r in range(9):                      # nine reads over the same three variants, then three over the next two
+        for v in (10, 20, 30):
+            pos.append(v); alle.append(int(rng.integers(0, 2))); qual.append(int(rng.integers(5, 30)))
+        read_ptr.append(len(pos))
+    for r in range(3):
+        for v in (40, 50):
+            pos.append(v); alle.append(int(rng.integers(0, 2))); qual.append(int(rng.integers(5, 30)))
+        read_ptr.append(len(pos))
+    n_var = 5
+    gl = rng.random((1, n_var, 3)) + 0.1
+    gl /= gl.sum(axis=2, keepdims=True)
+    p = _native.ProblemArrays(np.asarray(read_ptr, dtype=np.uint64), np.asarray(pos, dtype=np.int32), np.asarray(alle, dtype=np.uint8),
+                              np.asarray(qual, dtype=np.uint32), np.zeros(12, dtype=np.int32), np.asarray([0], dtype=np.uint32),
+                              np.zeros(0, dtype=np.uint32), np.ones((1, n_var), dtype=np.uint8), gl, np.full(n_var, 7, dtype=np.uint32), None, False,
+                              n_variants=n_var)
+    want = reference_likelihoods(p, ref)
+    got, _ = device_likelihoods(p)
+    assert np.allclose(got, want, rtol=RTOL, atol=ATOL), np.abs(got - want).max()
+
+
+def test_python_class_mirrors_the_reference_constructor():
+    """whatshap_amd.genotype.GenotypeDPTable with the mirror ReadSet / Pedigree (tests/test_genotyping.py:66-95)."""
+    from helpers import string_to_readset
+
+    readset = string_to_readset("11\n 01", None, scale_quality=10)
+    positions = readset.get_positions()
+    ids = core.NumericSampleIds()
+    pedigree = core.Pedigree(ids)
+    pedigree.add_individual("individual0", [core.Genotype([0, 1])] * len(positions),
+                            [core.PhredGenotypeLikelihoods([1 / 3, 1 / 3, 1 / 3])] * len(positions))
+    table = GenotypeDPTable(ids, readset, [1] * len(positions), pedigree)
+    want = REFERENCE_VECTORS[0][1]
+    for c in range(len(positions)):
+        got = table.get_genotype_likelihoods("individual0", c)
+        assert np.allclose(got.as_vector(), want[c], rtol=1e-9)
+    assert table.get_stats()["n_columns"] == 3
+
+
+def test_empty_readset_and_missing_priors():
+    ids = core.NumericSampleIds()
+    pedigree = core.Pedigree(ids)
+    pedigree.add_individual("individual0", [core.Genotype([0, 1])] * 2, [None, None])
+    GenotypeDPTable(ids, core.ReadSet(), [1, 1], pedigree)   # tests/test_genotyping.py:54-62: nothing to do, no error
+    from helpers import string_to_readset
+
+    readset = string_to_readset("11\n01", None, scale_quality=10)
+    with pytest.raises(_native.SolverError, match="priors"):
+        GenotypeDPTable(ids, readset, [1, 1], pedigree)

@@ -81,6 +81,25 @@ class SolveStats(C.Structure):
         return {name: getattr(self, name) for name, _ in self._fields_}
 
 
+class GenotypeStats(C.Structure):
+    _fields_ = [
+        ("n_columns", C.c_uint64),
+        ("n_cells", C.c_uint64),
+        ("launches", C.c_uint64),
+        ("backward_ms", C.c_double),
+        ("forward_ms", C.c_double),
+        ("total_ms", C.c_double),
+        ("host_prepare_ms", C.c_double),
+        ("window", C.c_uint32),
+        ("max_coverage", C.c_uint32),
+        ("transmissions", C.c_uint32),
+        ("pad", C.c_uint32),
+    ]
+
+    def as_dict(self) -> dict:
+        return {name: getattr(self, name) for name, _ in self._fields_ if name != "pad"}
+
+
 def _ptr(arr: Optional[np.ndarray], ctype):
     if arr is None:
         return C.cast(None, C.POINTER(ctype))
@@ -243,6 +262,11 @@ def lib() -> C.CDLL:
     ]
     L.whamd_read_sort_hash.restype = C.c_uint64
     L.whamd_read_sort_hash.argtypes = [C.c_char_p, C.c_int]
+    L.whamd_genotype_likelihoods.restype = C.c_int
+    L.whamd_genotype_likelihoods.argtypes = [
+        C.POINTER(ReadSetView), C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(PedigreeView), C.POINTER(C.c_uint32), C.c_size_t,
+        C.c_int, C.c_uint32, C.POINTER(C.c_double), C.c_size_t, C.POINTER(GenotypeStats),
+    ]
     L.whamd_readselection.restype = C.c_int
     L.whamd_readselection.argtypes = [
         C.POINTER(ReadSetView), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_size_t, C.c_uint32, C.c_int,
@@ -262,7 +286,7 @@ EXPORTED_SYMBOLS = [
     "whamd_dptable_get_super_reads", "whamd_dptable_get_optimal_partitioning", "whamd_dptable_get_index_path",
     "whamd_dptable_get_stats", "whamd_dptable_set_option", "whamd_read_sort_hash", "whamd_plan_summarize",
     "whamd_dptable_enqueue", "whamd_dptable_wait", "whamd_dptable_enqueue_many", "whamd_debug_emulate_slot_plan",
-    "whamd_readselection",
+    "whamd_readselection", "whamd_genotype_likelihoods",
 ]
 
 
@@ -416,6 +440,17 @@ def readselection(read_ptr, var_position, var_quality, max_cov: int, read_source
                                      _ptr(preferred, C.c_int32) if preferred.size else None, preferred.size,
                                      C.c_uint32(int(max_cov)), C.c_int(1 if bridging else 0), _ptr(selected, C.c_uint8), C.byref(count)))
     return selected[:n_reads].astype(bool)
+
+
+def genotype_likelihoods(problem: ProblemArrays, n_columns: int, device: int = 0, window: int = 0):
+    """whamd_genotype_likelihoods: (likelihoods [individuals, columns, 3], stats dict)."""
+    n_ind = problem.n_individuals
+    gl = np.zeros((n_ind, int(n_columns), 3), dtype=np.float64)
+    stats = GenotypeStats()
+    a = problem.call_args()
+    _check(lib().whamd_genotype_likelihoods(a[0], a[1], a[2], a[3], a[5], a[6], C.c_int(int(device)), C.c_uint32(int(window)),
+                                            _ptr(gl, C.c_double), C.c_size_t(max(gl.size, 1) if gl.size else 0), C.byref(stats)))
+    return gl, stats.as_dict()
 
 
 def read_sort_hash(name: str, source_id: int) -> int:

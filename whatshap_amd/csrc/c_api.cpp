@@ -8,6 +8,7 @@
 #include <string>
 
 #include "device_table.h"
+#include "genotype.h"
 #include "problem.h"
 #include "resident.h"
 #include "slots.h"
@@ -443,6 +444,36 @@ whamd_status_t whamd_debug_emulate_slot_plan(const whamd_readset_view* readset, 
 // ReadSet.sort() orders reads exactly like the reference built against the same libstdc++.
 uint64_t whamd_read_sort_hash(const char* name, int source_id) {
 	return (uint64_t)(std::hash<std::string>()(std::string(name)) ^ std::hash<int>()(source_id));
+}
+
+whamd_status_t whamd_genotype_likelihoods(const whamd_readset_view* readset, const uint32_t* recombcost, size_t n_recombcost,
+                                          const whamd_pedigree_view* pedigree, const uint32_t* positions, size_t n_positions,
+                                          int device, uint32_t window, double* gl_out, size_t gl_capacity,
+                                          whamd_genotype_stats* stats_out) {
+	const double t0 = now_ms();
+	Problem p;
+	std::string msg;
+	whamd_status_t st = build_problem(readset, recombcost, n_recombcost, pedigree, false, positions, n_positions, p, msg, /*columns_only=*/true);
+	if (st != WHAMD_OK) return fail(st, msg);
+	const size_t need = (size_t)p.n_ind * p.n_cols * 3;
+	if (need && (!gl_out || gl_capacity < need)) return fail(WHAMD_ERR_INVALID, "gl_out holds fewer than individuals * columns * 3 values");
+	GenotypeModel model;
+	st = build_genotype_model(p, model, msg);
+	if (st != WHAMD_OK) return fail(st, msg);
+	std::vector<double> gl;
+	GenotypeStats gs;
+	st = genotype_solve_device(p, model, device, window, gl, gs, msg);
+	if (st != WHAMD_OK) return fail(st, msg);
+	if (need) std::memcpy(gl_out, gl.data(), need * sizeof(double));
+	if (stats_out) {
+		whamd_genotype_stats o{};
+		o.n_columns = gs.n_columns; o.n_cells = gs.n_cells; o.launches = gs.launches;
+		o.backward_ms = gs.backward_ms; o.forward_ms = gs.forward_ms; o.total_ms = gs.total_ms;
+		o.host_prepare_ms = (now_ms() - t0) - gs.total_ms;
+		o.window = gs.window; o.max_coverage = gs.max_coverage; o.transmissions = gs.transmissions;
+		*stats_out = o;
+	}
+	return WHAMD_OK;
 }
 
 }  // extern "C"

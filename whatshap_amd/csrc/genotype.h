@@ -1,0 +1,39 @@
+// genotype.h -- GenotypeDPTable: the forward-backward genotyper that shares the phasing
+// path's columns, indexing scheme and pedigree partitions (src/genotypedptable.cpp:16-451) -- sum-product instead of
+// min-plus, no backtrace, no ties.  Device path: genotype_device.hip; f64 arithmetic (the reference computes in long double,
+// so parity is to a relative tolerance, not bit-exact).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "problem.h"
+
+namespace whamd {
+
+struct GenotypeStats {
+	uint64_t n_columns = 0, n_cells = 0;   // sum_c 2^k_c
+	uint64_t launches = 0;
+	double backward_ms = 0, forward_ms = 0, total_ms = 0;   // HIP events: checkpoint pass / windows (recompute + forward) / all
+	uint32_t window = 0;                   // columns per window (backward columns kept at window ends, recomputed inside)
+	uint32_t max_coverage = 0, transmissions = 0;
+};
+
+// Per-column model of the genotyper, built on the host from a Problem (columns_only):
+//   transition_bern  [n_cols][2 * triples + 1]  normalised Bernoulli terms: P(i -> j) = bern[popcount(i ^ j)]
+//                    (TransitionProbabilityComputer, src/transitionprobabilitycomputer.cpp:22-45)
+//   allele_prior     [n_cols][T][A]             P(allele assignment a | transmission value i) from the genotype priors
+//                    (:48-90: product of the individuals' priors, divided by the multiplicity of the genotype vector, normalised)
+//   error_prob       [entries]                  10^(-phred / 10), 0.9999 for phred 0 (src/genotypecolumncostcomputer.cpp:26-48)
+struct GenotypeModel {
+	uint32_t A = 0;                 // allele assignments = 2^P
+	std::vector<double> transition_bern, allele_prior, error_prob;
+	std::vector<uint8_t> genotype_index;   // [T][A][n_ind]: allele0 + allele1 of individual under (i, a)  (:376-383)
+};
+whamd_status_t build_genotype_model(const Problem& p, GenotypeModel& m, std::string& msg);
+
+// gl_out: [n_ind][n_cols][3] genotype likelihoods (0/0, 0/1, 1/1), each triple normalised to sum 1
+// (GenotypeDPTable::get_genotype_likelihoods, src/genotypedptable.cpp:444-451).
+whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, int device, uint32_t window_hint,
+                                     std::vector<double>& gl_out, GenotypeStats& st, std::string& msg);
+
+}  // namespace whamd

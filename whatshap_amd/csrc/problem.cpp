@@ -84,7 +84,7 @@ bool build_partitions(Problem& p, std::string& msg) {
 
 whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recombcost, size_t n_recombcost,
                              const whamd_pedigree_view* ped, bool distrust, const uint32_t* positions,
-                             size_t n_positions, Problem& p, std::string& msg) {
+                             size_t n_positions, Problem& p, std::string& msg, bool columns_only) {
 	if (!rs || !ped) {
 		msg = "null readset or pedigree view";
 		return WHAMD_ERR_INVALID;
@@ -281,6 +281,7 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 	p.f[n - 1] = 0;  // last column: everything is minimised out (global optimum, src/pedigreedptable.cpp:306-315)
 	p.fwd_mask[n - 1] = 0;
 
+	if (columns_only) return WHAMD_OK;   // the genotyping path (genotype.cpp) has its own per-column model
 	// ---- per-bit deltas and cost terms.  Columns are independent: ranges of columns go to a few host threads, each with its
 	// own term list (concatenated in column order afterwards; the sums below are sums of integer-valued doubles, exact in any order)
 	p.delta.assign((size_t)p.col_ptr[n] * std::max<uint32_t>(p.n_ind, 1), 0);

@@ -82,7 +82,7 @@ struct Problem {
 // Builds the problem; on failure returns a status != WHAMD_OK and sets msg.
 whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recombcost, size_t n_recombcost,
                              const whamd_pedigree_view* ped, bool distrust, const uint32_t* positions,
-                             size_t n_positions, Problem& out, std::string& msg);
+                             size_t n_positions, Problem& out, std::string& msg, bool columns_only = false);
 
 // Host part of get_super_reads (src/pedigreedptable.cpp:344-388 + get_alleles,
 // src/pedigreecolumncostcomputer.cpp:117-175) and get_optimal_partitioning (:391-406) from a finished path.
