@@ -55,3 +55,21 @@ REFERENCE_VECTORS = [
 def test_known_answers_of_the_reference_tests(lines, want):
     got = np.asarray(genotype_oracle.genotype_likelihoods(_matrix_problem(lines)), dtype=np.float64)[0]
     assert np.allclose(got, want, rtol=1e-9)
+
+
+def golden_cases():
+    from helpers import load_golden, problem_from_json
+
+    for case in load_golden("genotype_cases.json")["cases"]:
+        yield case["name"], problem_from_json(case["problem"]), np.asarray([[[float(x) for x in col] for col in ind] for ind in case["likelihoods"]])
+
+
+def test_restatement_equals_the_committed_golden_vectors():
+    """tests/golden/genotype_cases.json (generated from the reference class by make_genotype_golden.py): usable where
+    neither /root/reference nor the built reference modules exist."""
+    n = 0
+    for name, problem, want in golden_cases():
+        got = np.asarray(genotype_oracle.genotype_likelihoods(problem), dtype=np.float64)
+        assert np.allclose(got, want, rtol=1e-12, atol=1e-15), name
+        n += 1
+    assert n == 6

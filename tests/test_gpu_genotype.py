@@ -111,3 +111,52 @@ def test_empty_readset_and_missing_priors():
     readset = string_to_readset("11\n01", None, scale_quality=10)
     with pytest.raises(_native.SolverError, match="priors"):
         GenotypeDPTable(ids, readset, [1, 1], pedigree)
+
+
+def test_shim_runs_the_reference_objects_through_the_device():
+    """whatshap.cli.genotype's call (cli/genotype.py:357-368) with WhatsHap's OWN ReadSet / Pedigree objects, rebound through
+    shim.install_genotype: same likelihoods as the reference class, returned as the reference's PhredGenotypeLikelihoods."""
+    import types
+
+    from whatshap_amd import shim
+
+    ref = reference_core()
+    module = types.SimpleNamespace(Pedigree=ref.Pedigree, GenotypeDPTable=ref.GenotypeDPTable)
+    previous = shim.install_genotype(module, ref)
+    assert previous[1] is ref.GenotypeDPTable
+    p = random_case(4242, n_variants=40, n_reads=120, max_len=7, mode="trio", max_coverage=9)
+    rs = ref.ReadSet()
+    for r in range(p.n_reads):
+        read = ref.Read(f"read{r}", 60, 0, int(p.read_sample_id[r]))
+        for i in range(int(p.read_ptr[r]), int(p.read_ptr[r + 1])):
+            read.add_variant(int(p.var_position[i]), int(p.var_allele[i]), int(p.var_quality[i]))
+        rs.add(read)
+    ids = ref.NumericSampleIds()
+    for name in ("0", "1", "2"):
+        ids[name]
+    gl = p.genotype_likelihoods.reshape(3, p.n_variants, 3)
+    peds = []
+    for cls in (module.Pedigree, ref.Pedigree):
+        ped = cls(ids)
+        for i in range(3):
+            ped.add_individual(str(i), [ref.Genotype([0, 1])] * p.n_variants,
+                               [ref.PhredGenotypeLikelihoods([float(x) for x in gl[i, v]]) for v in range(p.n_variants)])
+        ped.add_relationship("0", "1", "2")
+        peds.append(ped)
+    positions = [int(x) for x in p.positions]
+    recomb = [int(x) for x in p.recombcost]
+    ours = module.GenotypeDPTable(ids, rs, recomb, peds[0], positions)
+    theirs = ref.GenotypeDPTable(ids, rs, recomb, peds[1], positions)
+    for name in ("0", "1", "2"):
+        for c in range(len(positions)):
+            a, b = ours.get_genotype_likelihoods(name, c), theirs.get_genotype_likelihoods(name, c)
+            assert type(a) is type(b)
+            assert np.allclose(list(a), list(b), rtol=RTOL, atol=ATOL)
+
+
+def test_committed_golden_vectors():
+    from test_genotype_oracle import golden_cases
+
+    for name, problem, want in golden_cases():
+        got, _ = device_likelihoods(problem)
+        assert np.allclose(got, want, rtol=RTOL, atol=ATOL), (name, np.abs(got - want).max())

@@ -21,7 +21,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 
@@ -59,6 +61,12 @@ struct GenoDev {
 	const uint8_t* gidx;     // [T][A][n_ind]
 	const int8_t* h2p;       // [T][n_ind][2]
 	uint32_t T, A, P, n_ind, nb, n_cols;
+	// Product slots: founders first, in partition order (slot p = the haplotype that IS partition p), then the two
+	// haplotypes of every child.  slot_of[individual * 2 + haplotype]; child_part[i][q] = partition child slot q joins under
+	// transmission value i.
+	uint32_t n_child_slots;
+	uint8_t slot_of[2 * MAX_IND];
+	uint8_t child_part[MAX_T][4];
 };
 
 // what a block stages in LDS for its column
@@ -71,6 +79,8 @@ struct GenoShared {
 	uint8_t ind[MAX_COVERAGE + 7], allele[MAX_COVERAGE + 7];
 	uint8_t gidx[MAX_T * GENO_MAXA * MAX_IND];
 	int8_t h2p[MAX_T * MAX_IND * 2];
+	uint8_t slot_of[2 * MAX_IND + 4];     // (copies of the kernel arguments: indexed per thread, which arguments cannot be)
+	uint8_t child_part[MAX_T][4];
 };
 
 __device__ __forceinline__ void geno_stage(const GenoDev& G, uint32_t c, uint32_t k, GenoShared& S) {
@@ -81,37 +91,87 @@ __device__ __forceinline__ void geno_stage(const GenoDev& G, uint32_t c, uint32_
 	for (uint32_t i = tid; i < G.T * G.A * G.n_ind; i += GENO_BLOCK) S.gidx[i] = G.gidx[i];
 	for (uint32_t i = tid; i < G.T * G.n_ind * 2; i += GENO_BLOCK) S.h2p[i] = G.h2p[i];
 	if (tid < G.nb) S.bern[tid] = G.bern[(size_t)c * G.nb + tid];
+	if (tid == 64) {   // (static indices: the arguments stay in scalar registers)
+#pragma unroll
+		for (int q = 0; q < 2 * MAX_IND; ++q) S.slot_of[q] = G.slot_of[q];
+	}
+	if (tid == 128) {
+#pragma unroll
+		for (int q = 0; q < MAX_T; ++q) {
+#pragma unroll
+			for (int r = 0; r < 4; ++r) S.child_part[q][r] = G.child_part[q][r];
+		}
+	}
 }
 
-// 1 / (sum of the per-block sums of a stored column), the same in every thread of every reader
-__device__ __forceinline__ double geno_inverse_total(const double* partials, uint32_t n_blocks, double* red) {
-	double v = 0.0;
-	for (uint32_t i = threadIdx.x; i < n_blocks; i += GENO_BLOCK) v += partials[i];
-	for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-	if ((threadIdx.x & 63u) == 0) red[threadIdx.x >> 6] = v;
-	__syncthreads();
-	double total = 0.0;
-	for (int w = 0; w < GENO_BLOCK / 64; ++w) total += red[w];
-	__syncthreads();
-	return total > 0.0 ? 1.0 / total : 0.0;
+constexpr uint32_t GENO_GROUP_BITS = 7;      // reads per lookup table
+constexpr uint32_t GENO_GROUP = 1u << GENO_GROUP_BITS;
+constexpr int GENO_MAXSLOTS = 8;             // 2 * individuals (P <= 4: at most a quartet)
+
+// Lookup tables of the column in LDS: for every group of 7 reads and every setting of their bits, the product over the
+// group's reads of the emission factors, per product slot and allele:  tab[(group * 128 + bits) * E + slot * 2 + allele],
+// E = 4 * individuals.  A read r with bit b belongs to haplotype b ^ 1 of its individual (bit 0 <-> "entry_in_partition1",
+// src/genotypecolumncostcomputer.cpp:61) and contributes (allele == allele_r ? 1 - e_r : e_r).
+__device__ __forceinline__ void geno_build_tables(const GenoDev& G, const GenoShared& S, uint32_t k, double* tab) {
+	const uint32_t E = 4u * G.n_ind, groups = (k + GENO_GROUP_BITS - 1u) / GENO_GROUP_BITS;
+	for (uint32_t idx = threadIdx.x; idx < groups * GENO_GROUP; idx += GENO_BLOCK) {
+		double v[GENO_MAXSLOTS][2];   // the entry in registers: static indices, the slot of a read is matched with selects
+#pragma unroll
+		for (int q = 0; q < GENO_MAXSLOTS; ++q) v[q][0] = v[q][1] = 1.0;
+		const uint32_t g = idx >> GENO_GROUP_BITS, bits = idx & (GENO_GROUP - 1u);
+#pragma unroll
+		for (uint32_t jj = 0; jj < GENO_GROUP_BITS; ++jj) {
+			const uint32_t j = g * GENO_GROUP_BITS + jj;
+			const uint32_t al = j < k ? S.allele[j] : 2u;
+			const uint32_t hap = ((bits >> jj) & 1u) ^ 1u;
+			const uint32_t slot = al > 1u ? 0xFFu : (uint32_t)S.slot_of[S.ind[j < k ? j : 0u] * 2u + hap];   // BLANK: no slot
+			const double pe = S.pe[j < k ? j : 0u], ok = 1.0 - pe;
+			const double m0 = al == 0u ? ok : pe, m1 = al == 0u ? pe : ok;
+#pragma unroll
+			for (int q = 0; q < GENO_MAXSLOTS; ++q) {
+				v[q][0] *= slot == (uint32_t)q ? m0 : 1.0;
+				v[q][1] *= slot == (uint32_t)q ? m1 : 1.0;
+			}
+		}
+		double* e = tab + (size_t)idx * E;
+#pragma unroll
+		for (int q = 0; q < GENO_MAXSLOTS; ++q)
+			if ((uint32_t)q * 2u < E) *reinterpret_cast<double2*>(e + q * 2) = make_double2(v[q][0], v[q][1]);
+	}
 }
 
-// W_i(x) of one cell (see the header of this file): the reads of the column in LDS
-__device__ __forceinline__ void geno_partition_products(const GenoDev& G, const GenoShared& S, uint32_t k, uint32_t x, uint32_t i, double (&W)[4][2]) {
+// V[slot][allele] of one cell: the product of its groups' table entries
+__device__ __forceinline__ void geno_cell_products(const GenoDev& G, uint32_t k, uint32_t x, const double* tab, double (&V)[GENO_MAXSLOTS][2]) {
+	const uint32_t E = 4u * G.n_ind, groups = (k + GENO_GROUP_BITS - 1u) / GENO_GROUP_BITS;
 #pragma unroll
-	for (int p = 0; p < 4; ++p) W[p][0] = W[p][1] = 1.0;
-	for (uint32_t j = 0; j < k; ++j) {
-		const uint32_t al = S.allele[j];
-		if (al > 1u) continue;                       // BLANK
-		const uint32_t bit = (x >> j) & 1u;
-		// bit 0 <-> "entry_in_partition1" (src/genotypecolumncostcomputer.cpp:61): haplotype 1 of the read's individual
-		const uint32_t part = (uint32_t)S.h2p[((size_t)i * G.n_ind + S.ind[j]) * 2 + (bit ^ 1u)];
-		const double pe = S.pe[j], ok = 1.0 - pe;
-		const double m0 = al == 0u ? ok : pe, m1 = al == 0u ? pe : ok;   // factor for "the partition carries allele 0 / 1"
+	for (int q = 0; q < GENO_MAXSLOTS; ++q) V[q][0] = V[q][1] = 1.0;
+	for (uint32_t g = 0; g < groups; ++g) {
+		const double* e = tab + ((size_t)g * GENO_GROUP + ((x >> (g * GENO_GROUP_BITS)) & (GENO_GROUP - 1u))) * E;
 #pragma unroll
-		for (int p = 0; p < 4; ++p) {
-			W[p][0] *= part == (uint32_t)p ? m0 : 1.0;
-			W[p][1] *= part == (uint32_t)p ? m1 : 1.0;
+		for (int q = 0; q < GENO_MAXSLOTS; ++q) {
+			if ((uint32_t)q * 2u < E) {
+				const double2 v = *reinterpret_cast<const double2*>(e + q * 2);
+				V[q][0] *= v.x;
+				V[q][1] *= v.y;
+			}
+		}
+	}
+}
+
+// W_i[p][allele]: the founder haplotype that is partition p times the child haplotypes that join it under transmission value i
+__device__ __forceinline__ void geno_partition_products(const GenoDev& G, const GenoShared& S, const double (&V)[GENO_MAXSLOTS][2], uint32_t i, double (&W)[4][2]) {
+#pragma unroll
+	for (int p = 0; p < 4; ++p) { W[p][0] = V[p][0]; W[p][1] = V[p][1]; }   // (slots >= P hold children or ones)
+#pragma unroll
+	for (int q = 0; q < 4; ++q) {
+		if ((uint32_t)q < G.n_child_slots) {
+			const uint32_t part = S.child_part[i][q];
+			const double c0 = V[4 + q][0], c1 = V[4 + q][1];   // children exist only below two founders: P == 4, child slot q is V[4 + q]
+#pragma unroll
+			for (int p = 0; p < 4; ++p) {
+				W[p][0] *= part == (uint32_t)p ? c0 : 1.0;
+				W[p][1] *= part == (uint32_t)p ? c1 : 1.0;
+			}
 		}
 	}
 }
@@ -144,52 +204,86 @@ __device__ __forceinline__ uint32_t geno_pdep(uint32_t v, uint32_t mask) {
 	return r;
 }
 
+// per-column parameters the host knows: passed by value, nothing on the kernels' critical path loads them
+struct GenoCol {
+	uint32_t c, k, b, f, fmask, loop_bits, use_atomics, pad;
+};
+
+// the per-thread sum of the partials of a stored column (issued early; reduced by geno_inverse_finish)
+__device__ __forceinline__ double geno_partials_begin(const double* partials, uint32_t n_blocks) {
+	double v = 0.0;
+	for (uint32_t i = threadIdx.x; i < n_blocks; i += GENO_BLOCK) v += partials[i];
+	return v;
+}
+__device__ __forceinline__ double geno_inverse_finish(double v, double* red) {
+	for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+	if ((threadIdx.x & 63u) == 0) red[threadIdx.x >> 6] = v;
+	__syncthreads();
+	double total = 0.0;
+	for (int w = 0; w < GENO_BLOCK / 64; ++w) total += red[w];
+	__syncthreads();
+	return total > 0.0 ? 1.0 / total : 0.0;
+}
+
+// Thread mapping of both column kernels: thread = (projection entry, transmission value i); the T threads of an entry are
+// neighbouring lanes.  A thread loops over at most 4 cells of its entry (the reads that start / end in the column).
+
 // Backward step of column c: reads B_c (`in`, null for the last column), writes B_{c-1} (`out`, 2^b_c x T) and the per-block sums.
 template <int T>
-__global__ __launch_bounds__(GENO_BLOCK) void geno_backward(GenoDev G, uint32_t c, const double* __restrict__ in, const double* __restrict__ in_partials,
-                                                           uint32_t in_blocks, double* __restrict__ out, double* __restrict__ out_partials, uint32_t use_atomics) {
+__global__ __launch_bounds__(GENO_BLOCK) void geno_backward(GenoDev G, GenoCol C, const double* __restrict__ in, const double* __restrict__ in_partials,
+                                                           uint32_t in_blocks, double* __restrict__ out, double* __restrict__ out_partials) {
 	__shared__ GenoShared S;
-	const uint32_t k = G.k[c], b = G.b[c], fmask = G.fwd_mask[c];
-	geno_stage(G, c, k, S);
-	__syncthreads();
-	const double inv = in ? geno_inverse_total(in_partials, in_blocks, &S.red[0][0]) : 1.0;
-	const uint32_t nfree = k - b, loop_bits = nfree < GENO_LOOP_BITS ? nfree : GENO_LOOP_BITS;
-	const uint64_t n_threads = 1ull << (k - loop_bits);
+	extern __shared__ __attribute__((aligned(16))) double geno_tab[];
+	const uint32_t k = C.k, b = C.b, fmask = C.fmask, loop_bits = C.loop_bits;
+	// every global load of the kernel is issued here, before the first barrier: one memory round trip on the critical path
+	// (the column's scale -- the reciprocal of the sum of its partials -- is linear in the result and applied at the end)
+	const double psum = in ? geno_partials_begin(in_partials, in_blocks) : 0.0;
+	const uint64_t n_entries = 1ull << (k - loop_bits);
 	const uint64_t t = (uint64_t)blockIdx.x * GENO_BLOCK + threadIdx.x;
-	double acc[T];
+	const uint64_t entry = t / T;
+	const uint32_t i = (uint32_t)(t % T);
+	const bool active = entry < n_entries;
+	const uint32_t y = (uint32_t)entry & ((1u << b) - 1u), chunk = (uint32_t)(entry >> b);
+	double beta_raw[1u << GENO_LOOP_BITS];
 #pragma unroll
-	for (int j = 0; j < T; ++j) acc[j] = 0.0;
-	uint32_t y = 0;
-	if (t < n_threads) {
-		y = (uint32_t)t & ((1u << b) - 1u);
-		const uint32_t chunk = (uint32_t)(t >> b);
-		for (uint32_t e = 0; e < (1u << loop_bits); ++e) {
+	for (uint32_t e = 0; e < (1u << GENO_LOOP_BITS); ++e) {
+		beta_raw[e] = 1.0;
+		if (in && active && e < (1u << loop_bits)) beta_raw[e] = in[(size_t)geno_pext(y | (((chunk << loop_bits) | e) << b), fmask) * T + i];
+	}
+	geno_stage(G, C.c, k, S);
+	__syncthreads();
+	geno_build_tables(G, S, k, geno_tab);
+	__syncthreads();
+	double partial = 0.0;   // sum over this thread's cells of beta * sum_a prior * cost, for its transmission value i
+	if (active) {
+#pragma unroll
+		for (uint32_t e = 0; e < (1u << GENO_LOOP_BITS); ++e) {
+			if (e >= (1u << loop_bits)) break;
 			const uint32_t x = y | (((chunk << loop_bits) | e) << b);
-			const uint32_t yf = in ? geno_pext(x, fmask) : 0u;
-#pragma unroll
-			for (int i = 0; i < T; ++i) {
-				const double beta = in ? in[(size_t)yf * T + i] * inv : 1.0;
-				double W[4][2];
-				geno_partition_products(G, S, k, x, (uint32_t)i, W);
-				double s = 0.0;
-				for (uint32_t a = 0; a < G.A; ++a) s += S.prior[i * G.A + a] * geno_assignment_cost(W, G.P, a);
-				s *= beta;
-#pragma unroll
-				for (int j = 0; j < T; ++j) acc[j] += s * S.bern[__popc((uint32_t)(i ^ j))];
-			}
-		}
-		if (use_atomics) {
-#pragma unroll
-			for (int j = 0; j < T; ++j) atomicAdd(out + (size_t)y * T + j, acc[j]);
-		} else {
-#pragma unroll
-			for (int j = 0; j < T; ++j) out[(size_t)y * T + j] = acc[j];
+			const double beta = beta_raw[e];
+			double V[GENO_MAXSLOTS][2], W[4][2];
+			geno_cell_products(G, k, x, geno_tab, V);
+			geno_partition_products(G, S, V, i, W);
+			double s = 0.0;
+			for (uint32_t a = 0; a < G.A; ++a) s += S.prior[i * G.A + a] * geno_assignment_cost(W, G.P, a);
+			partial += s * beta;
 		}
 	}
-	// per-block sum of what was written
-	double v = 0.0;
+	// out[y][j] = sum_i partial_i * P(j -> i): thread i of the entry produces j = i from its neighbours' partials
+	double acc = 0.0;
+	const uint32_t lane = threadIdx.x & 63u, base = lane & ~(uint32_t)(T - 1);
 #pragma unroll
-	for (int j = 0; j < T; ++j) v += acc[j];
+	for (int ii = 0; ii < T; ++ii) {
+		const double other = T == 1 ? partial : __shfl(partial, (int)(base + ii));
+		acc += other * S.bern[__popc((uint32_t)ii ^ i)];
+	}
+	const double inv = in ? geno_inverse_finish(psum, &S.red[0][0]) : 1.0;
+	acc *= inv;
+	if (active) {
+		if (C.use_atomics) atomicAdd(out + (size_t)y * T + i, acc);
+		else out[(size_t)y * T + i] = acc;
+	} else acc = 0.0;
+	double v = acc;
 	for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
 	__syncthreads();
 	if ((threadIdx.x & 63u) == 0) S.red[threadIdx.x >> 6][0] = v;
@@ -205,83 +299,106 @@ __global__ __launch_bounds__(GENO_BLOCK) void geno_backward(GenoDev G, uint32_t 
 // (`out`, null for the last column) with its per-block sums, and the per-block sums of the normalisation and of the genotype
 // likelihood numerators (gl_partials[block][1 + 3 * individuals]).
 template <int T>
-__global__ __launch_bounds__(GENO_BLOCK) void geno_forward(GenoDev G, uint32_t c, const double* __restrict__ prev, const double* __restrict__ prev_partials,
+__global__ __launch_bounds__(GENO_BLOCK) void geno_forward(GenoDev G, GenoCol C, const double* __restrict__ prev, const double* __restrict__ prev_partials,
                                                           uint32_t prev_blocks, const double* __restrict__ beta, const double* __restrict__ beta_partials,
                                                           uint32_t beta_blocks, double* __restrict__ out, double* __restrict__ out_partials,
-                                                          double* __restrict__ gl_partials, uint32_t use_atomics) {
+                                                          double* __restrict__ gl_partials) {
 	__shared__ GenoShared S;
-	const uint32_t k = G.k[c], b = G.b[c], f = out ? G.f[c] : 0u, fmask = out ? G.fwd_mask[c] : 0u;
-	geno_stage(G, c, k, S);
-	__syncthreads();
-	const double inv_prev = prev ? geno_inverse_total(prev_partials, prev_blocks, &S.red[0][0]) : 1.0;
-	const double inv_beta = beta ? geno_inverse_total(beta_partials, beta_blocks, &S.red[0][0]) : 1.0;
+	extern __shared__ __attribute__((aligned(16))) double geno_tab[];
+	const uint32_t k = C.k, b = C.b, f = C.f, fmask = C.fmask, loop_bits = C.loop_bits;   // (last column: f = 0, fmask = 0)
+	const double psum_prev = prev ? geno_partials_begin(prev_partials, prev_blocks) : 0.0;
+	const double psum_beta = beta ? geno_partials_begin(beta_partials, beta_blocks) : 0.0;
 	const uint32_t kmask = k >= 32u ? 0xFFFFFFFFu : ((1u << k) - 1u), endmask = kmask & ~fmask;
-	const uint32_t nfree = k - f, loop_bits = nfree < GENO_LOOP_BITS ? nfree : GENO_LOOP_BITS;
-	const uint64_t n_threads = 1ull << (k - loop_bits);
+	const uint64_t n_entries = 1ull << (k - loop_bits);
 	const uint64_t t = (uint64_t)blockIdx.x * GENO_BLOCK + threadIdx.x;
+	const uint64_t entry = t / T;
+	const uint32_t i = (uint32_t)(t % T);
 	const uint32_t n_gl = 1u + 3u * G.n_ind;
-	double gl[GENO_MAXGL];
+	// all global loads up front (see geno_backward); the two scales are applied at the end
+	const bool active = entry < n_entries;
+	const uint32_t yf0 = (uint32_t)entry & ((1u << f) - 1u), chunk0 = (uint32_t)(entry >> f);
+	const uint32_t xf0 = geno_pdep(yf0, fmask);
+	const double bt_raw = (beta && active) ? beta[(size_t)yf0 * T + i] : 1.0;
+	double prev_raw[1u << GENO_LOOP_BITS][T];
 #pragma unroll
-	for (int q = 0; q < GENO_MAXGL; ++q) gl[q] = 0.0;
-	double acc[T];
+	for (uint32_t e = 0; e < (1u << GENO_LOOP_BITS); ++e) {
+		const uint32_t x = xf0 | geno_pdep((chunk0 << loop_bits) | e, endmask);
+		const bool use = prev && active && e < (1u << loop_bits);
 #pragma unroll
-	for (int i = 0; i < T; ++i) acc[i] = 0.0;
-	if (t < n_threads) {
-		const uint32_t yf = (uint32_t)t & ((1u << f) - 1u), chunk = (uint32_t)(t >> f);
-		const uint32_t xf = geno_pdep(yf, fmask);
-		// the genotype likelihood the true B_c of the LAST window column may be absent (last column of the table): beta = 1
-		for (uint32_t e = 0; e < (1u << loop_bits); ++e) {
+		for (int j = 0; j < T; ++j) prev_raw[e][j] = use ? prev[(size_t)(x & ((1u << b) - 1u)) * T + j] : 0.0;
+	}
+	geno_stage(G, C.c, k, S);
+	__syncthreads();
+	geno_build_tables(G, S, k, geno_tab);
+	__syncthreads();
+	double fa[GENO_MAXA];   // per allele assignment: sum over this thread's cells of forward * backward (its transmission value)
+#pragma unroll
+	for (int a = 0; a < GENO_MAXA; ++a) fa[a] = 0.0;
+	double acc = 0.0;
+	if (active) {
+		const uint32_t chunk = chunk0, xf = xf0;
+		const double bt = bt_raw;
+#pragma unroll
+		for (uint32_t e = 0; e < (1u << GENO_LOOP_BITS); ++e) {
+			if (e >= (1u << loop_bits)) break;
 			const uint32_t x = xf | geno_pdep((chunk << loop_bits) | e, endmask);
-			const uint32_t yb = x & ((1u << b) - 1u);
+			double sum_prev = 1.0;
+			if (prev) {
+				sum_prev = 0.0;
 #pragma unroll
-			for (int i = 0; i < T; ++i) {
-				double sum_prev = 1.0;
-				if (prev) {
-					sum_prev = 0.0;
-#pragma unroll
-					for (int j = 0; j < T; ++j) sum_prev += prev[(size_t)yb * T + j] * S.bern[__popc((uint32_t)(i ^ j))];
-					sum_prev *= inv_prev;
-				}
-				const double bt = beta ? beta[(size_t)yf * T + i] * inv_beta : 1.0;
-				double W[4][2];
-				geno_partition_products(G, S, k, x, (uint32_t)i, W);
-				for (uint32_t a = 0; a < G.A; ++a) {
-					const double fw = sum_prev * geno_assignment_cost(W, G.P, a) * S.prior[i * G.A + a];
-					const double fb = fw * bt;
-					acc[i] += fw;
-					gl[0] += fb;
-					const uint8_t* gi = S.gidx + ((size_t)i * G.A + a) * G.n_ind;
-#pragma unroll
-					for (int s = 0; s < MAX_IND; ++s) {
-						if ((uint32_t)s < G.n_ind) {
-							const uint32_t g = gi[s];
-							gl[1 + 3 * s + 0] += g == 0u ? fb : 0.0;
-							gl[1 + 3 * s + 1] += g == 1u ? fb : 0.0;
-							gl[1 + 3 * s + 2] += g == 2u ? fb : 0.0;
-						}
-					}
-				}
+				for (int j = 0; j < T; ++j) sum_prev += prev_raw[e][j] * S.bern[__popc((uint32_t)j ^ i)];
 			}
-		}
-		if (out) {
-			if (use_atomics) {
+			double V[GENO_MAXSLOTS][2], W[4][2];
+			geno_cell_products(G, k, x, geno_tab, V);
+			geno_partition_products(G, S, V, i, W);
 #pragma unroll
-				for (int i = 0; i < T; ++i) atomicAdd(out + (size_t)yf * T + i, acc[i]);
-			} else {
-#pragma unroll
-				for (int i = 0; i < T; ++i) out[(size_t)yf * T + i] = acc[i];
+			for (int a = 0; a < GENO_MAXA; ++a) {
+				if ((uint32_t)a < G.A) {
+					const double fw = sum_prev * geno_assignment_cost(W, G.P, (uint32_t)a) * S.prior[i * G.A + a];
+					acc += fw;
+					fa[a] += fw * bt;
+				}
 			}
 		}
 	}
-	// per-block sums: the written column (slot n_gl) and the likelihood numerators
-	double total_out = 0.0;
+	{
+		const double inv_prev = prev ? geno_inverse_finish(psum_prev, &S.red[0][0]) : 1.0;
+		const double inv_beta = beta ? geno_inverse_finish(psum_beta, &S.red[0][0]) : 1.0;
+		acc *= inv_prev;
+		const double both = inv_prev * inv_beta;
 #pragma unroll
-	for (int i = 0; i < T; ++i) total_out += acc[i];
+		for (int a = 0; a < GENO_MAXA; ++a) fa[a] *= both;
+		if (active && out) {
+			if (C.use_atomics) atomicAdd(out + (size_t)yf0 * T + i, acc);
+			else out[(size_t)yf0 * T + i] = acc;
+		}
+	}
+	// marginalise this thread's assignments over the genotypes (src/genotypedptable.cpp:376-383), once per thread
+	double gl[GENO_MAXGL];
+#pragma unroll
+	for (int q = 0; q < GENO_MAXGL; ++q) gl[q] = 0.0;
+#pragma unroll
+	for (int a = 0; a < GENO_MAXA; ++a) {
+		if ((uint32_t)a < G.A) {
+			gl[0] += fa[a];
+			const uint8_t* gi = S.gidx + ((size_t)i * G.A + a) * G.n_ind;
+#pragma unroll
+			for (int s = 0; s < 4; ++s) {
+				if ((uint32_t)s < G.n_ind) {
+					const uint32_t g = gi[s];
+					gl[1 + 3 * s + 0] += g == 0u ? fa[a] : 0.0;
+					gl[1 + 3 * s + 1] += g == 1u ? fa[a] : 0.0;
+					gl[1 + 3 * s + 2] += g == 2u ? fa[a] : 0.0;
+				}
+			}
+		}
+	}
+	// per-block sums: the likelihood numerators (slots 0 .. n_gl - 1) and the written column (slot n_gl)
 	__syncthreads();
 #pragma unroll
-	for (int q = 0; q <= GENO_MAXGL; ++q) {
-		if ((uint32_t)q <= n_gl) {   // (wave-uniform)
-			double v = (uint32_t)q == n_gl ? total_out : gl[q < GENO_MAXGL ? q : 0];
+	for (int q = 0; q <= 13; ++q) {   // 1 + 3 * 4 individuals + the column sum
+		if ((uint32_t)q <= n_gl) {    // (wave-uniform)
+			double v = (uint32_t)q == n_gl ? acc : gl[q < GENO_MAXGL ? q : 0];
 			for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
 			if ((threadIdx.x & 63u) == 0) S.red[threadIdx.x >> 6][q] = v;
 		}
@@ -313,9 +430,9 @@ __global__ __launch_bounds__(64) void geno_finish(const double* __restrict__ gl_
 	}
 }
 
-uint32_t blocks_for(uint32_t k, uint32_t proj) {   // grid of a column kernel: 2^(k - min(k - proj, LOOP)) threads
+uint32_t blocks_for(uint32_t k, uint32_t proj, uint32_t T) {   // grid of a column kernel: 2^(k - min(k - proj, LOOP)) entries x T threads
 	const uint32_t nfree = k - proj, loop_bits = std::min(nfree, GENO_LOOP_BITS);
-	const uint64_t threads = 1ull << (k - loop_bits);
+	const uint64_t threads = (1ull << (k - loop_bits)) * T;
 	return (uint32_t)((threads + GENO_BLOCK - 1) / GENO_BLOCK);
 }
 
@@ -347,16 +464,22 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 		st.n_cells += 1ull << p.k[c];
 	}
 	st.max_coverage = max_k;
-	uint32_t K = window_hint ? window_hint : (uint32_t)std::ceil(std::sqrt((double)n));
+	const size_t buf_doubles = ((size_t)1 << max_proj) * T;
+	const uint32_t max_blocks = (uint32_t)(((((size_t)1 << max_k) * T) + GENO_BLOCK - 1) / GENO_BLOCK);
+	const uint32_t n_gl = 1 + 3 * ni;
+	size_t free_b = 0, total_b = 0;
+	GENO_TRY(hipMemGetInfo(&free_b, &total_b));
+	// Window = how many backward columns are kept at once.  If all of them fit in a quarter of the free memory there is one
+	// window and no column is computed twice; otherwise the reference's scheme: sqrt(n) kept columns, the rest recomputed.
+	uint32_t K = window_hint;
+	if (!K) {
+		const double per_column = (double)buf_doubles * 8 + (double)max_blocks * 8 * (1 + n_gl);
+		K = per_column * n <= 0.25 * (double)free_b ? n : (uint32_t)std::ceil(std::sqrt((double)n));
+	}
 	K = std::max(1u, std::min(K, n));
 	st.window = K;
 	const uint32_t n_windows = (n + K - 1) / K;
-	const size_t buf_doubles = ((size_t)1 << max_proj) * T;
-	const uint32_t max_blocks = (uint32_t)((((size_t)1 << max_k) + GENO_BLOCK - 1) / GENO_BLOCK);
-	const uint32_t n_gl = 1 + 3 * ni;
 	{
-		size_t free_b = 0, total_b = 0;
-		GENO_TRY(hipMemGetInfo(&free_b, &total_b));
 		const double need = (double)(buf_doubles * 8 + (size_t)max_blocks * 8) * (n_windows + K + 4.0) + (double)K * max_blocks * n_gl * 8 + (double)p.entries.size() * 10 + (double)n * (64 + 8.0 * T * m.A);
 		if (need + (double)(1ull << 30) > (double)free_b) {
 			msg = "genotyping buffers of " + std::to_string((uint64_t)(need / 1048576.0)) + " MiB do not fit in free HBM";
@@ -391,8 +514,8 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 	for (size_t e = 0; e < p.entries.size(); ++e) { ent_ind[e] = p.entries[e].sample; ent_allele[e] = p.entries[e].allele; }
 	std::vector<uint32_t> fw_blocks(n), bw_blocks(n);
 	for (uint32_t c = 0; c < n; ++c) {
-		fw_blocks[c] = blocks_for(p.k[c], c + 1 < n ? p.f[c] : 0u);
-		bw_blocks[c] = blocks_for(p.k[c], p.b[c]);
+		fw_blocks[c] = blocks_for(p.k[c], c + 1 < n ? p.f[c] : 0u, T);
+		bw_blocks[c] = blocks_for(p.k[c], p.b[c], T);
 	}
 	GenoDev G{};
 	void *d_col_ptr, *d_ind, *d_allele, *d_pe, *d_k, *d_b, *d_f, *d_fmask, *d_bern, *d_prior, *d_gidx, *d_h2p, *d_fwb;
@@ -413,19 +536,44 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 	G.k = (const uint8_t*)d_k; G.b = (const uint8_t*)d_b; G.f = (const uint8_t*)d_f; G.fwd_mask = (const uint32_t*)d_fmask;
 	G.bern = (const double*)d_bern; G.prior = (const double*)d_prior; G.gidx = (const uint8_t*)d_gidx; G.h2p = (const int8_t*)d_h2p;
 	G.T = T; G.A = m.A; G.P = p.P; G.n_ind = ni; G.nb = 2 * p.n_triples + 1; G.n_cols = n;
+	{
+		// founders are the individuals whose two haplotypes ARE partitions (h2p does not depend on the transmission value)
+		std::vector<uint8_t> is_child(ni, 0);
+		for (uint32_t t3 = 0; t3 < p.n_triples; ++t3) is_child[p.triples[t3][2]] = 1;
+		uint32_t child_slots = 0;
+		for (uint32_t s = 0; s < ni; ++s) {
+			if (!is_child[s]) {
+				G.slot_of[2 * s] = (uint8_t)p.h2p[(size_t)s * 2];
+				G.slot_of[2 * s + 1] = (uint8_t)p.h2p[(size_t)s * 2 + 1];
+			} else {
+				if (p.P != 4 || child_slots + 2 > 4) { cleanup(); msg = "unsupported pedigree shape for device genotyping"; return WHAMD_ERR_UNSUPPORTED; }
+				for (uint32_t h = 0; h < 2; ++h) {
+					G.slot_of[2 * s + h] = (uint8_t)(p.P + child_slots + h);
+					for (uint32_t i = 0; i < T; ++i) G.child_part[i][child_slots + h] = (uint8_t)p.h2p[((size_t)i * ni + s) * 2 + h];
+				}
+				child_slots += 2;
+			}
+		}
+		G.n_child_slots = child_slots;
+	}
+	const size_t table_bytes = (size_t)((max_k + GENO_GROUP_BITS - 1) / GENO_GROUP_BITS) * GENO_GROUP * 4 * ni * sizeof(double);
 	// ---- buffers: every column buffer carries its per-block sums
 	struct Buf { double* v = nullptr; double* partials = nullptr; uint32_t blocks = 0; };
-	auto make_buf = [&](Buf& bf) -> hipError_t {
-		hipError_t e = alloc((void**)&bf.v, buf_doubles * 8);
-		if (e == hipSuccess) e = alloc((void**)&bf.partials, (size_t)max_blocks * 8);
-		return e;
-	};
 	Buf alpha[2], pp[2];
 	std::vector<Buf> ckpt(n_windows), wstore(K);
-	for (Buf& bf : alpha) GENO_DEV(make_buf(bf));
-	for (Buf& bf : pp) GENO_DEV(make_buf(bf));
-	for (Buf& bf : ckpt) GENO_DEV(make_buf(bf));
-	for (Buf& bf : wstore) GENO_DEV(make_buf(bf));
+	{
+		// one slab for all of them (tens of thousands of hipMalloc calls would take seconds)
+		const size_t count = 4 + (size_t)n_windows + K;
+		double *slab_v = nullptr, *slab_p = nullptr;
+		GENO_DEV(alloc((void**)&slab_v, count * buf_doubles * 8));
+		GENO_DEV(alloc((void**)&slab_p, count * (size_t)max_blocks * 8));
+		size_t next = 0;
+		auto take = [&](Buf& bf) { bf.v = slab_v + next * buf_doubles; bf.partials = slab_p + next * max_blocks; ++next; };
+		for (Buf& bf : alpha) take(bf);
+		for (Buf& bf : pp) take(bf);
+		for (Buf& bf : ckpt) take(bf);
+		for (Buf& bf : wstore) take(bf);
+	}
 	double *d_glpart = nullptr, *d_gl = nullptr;
 	GENO_DEV(alloc((void**)&d_glpart, (size_t)K * max_blocks * n_gl * 8));
 	GENO_DEV(alloc((void**)&d_gl, gl_out.size() * 8));
@@ -436,20 +584,22 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 	auto backward = [&](uint32_t c, const Buf* in, Buf& out) -> hipError_t {
 		const uint32_t blocks = bw_blocks[c];
 		const uint32_t atomics = (uint32_t)p.k[c] - p.b[c] > GENO_LOOP_BITS ? 1u : 0u;
+		const GenoCol C{c, p.k[c], p.b[c], p.f[c], p.fwd_mask[c], std::min<uint32_t>((uint32_t)p.k[c] - p.b[c], GENO_LOOP_BITS), atomics, 0u};
 		if (atomics) { hipError_t e = hipMemsetAsync(out.v, 0, ((size_t)T << p.b[c]) * 8, stream); if (e != hipSuccess) return e; }
 		out.blocks = blocks;
 		const double* iv = in ? in->v : nullptr;
 		const double* ip = in ? in->partials : nullptr;
 		const uint32_t ib = in ? in->blocks : 0u;
-		if (T == 1) hipLaunchKernelGGL(geno_backward<1>, dim3(blocks), dim3(GENO_BLOCK), 0, stream, G, c, iv, ip, ib, out.v, out.partials, atomics);
-		else if (T == 4) hipLaunchKernelGGL(geno_backward<4>, dim3(blocks), dim3(GENO_BLOCK), 0, stream, G, c, iv, ip, ib, out.v, out.partials, atomics);
-		else hipLaunchKernelGGL(geno_backward<16>, dim3(blocks), dim3(GENO_BLOCK), 0, stream, G, c, iv, ip, ib, out.v, out.partials, atomics);
+		if (T == 1) hipLaunchKernelGGL(geno_backward<1>, dim3(blocks), dim3(GENO_BLOCK), table_bytes, stream, G, C, iv, ip, ib, out.v, out.partials);
+		else if (T == 4) hipLaunchKernelGGL(geno_backward<4>, dim3(blocks), dim3(GENO_BLOCK), table_bytes, stream, G, C, iv, ip, ib, out.v, out.partials);
+		else hipLaunchKernelGGL(geno_backward<16>, dim3(blocks), dim3(GENO_BLOCK), table_bytes, stream, G, C, iv, ip, ib, out.v, out.partials);
 		++launches;
 		return hipGetLastError();
 	};
+	const auto t_enqueue0 = std::chrono::steady_clock::now();
 	GENO_DEV(hipEventRecord(ev[0], stream));
-	// ---- pass 1: B_{c-1} for c = n-1 .. 1, kept where c - 1 is the last column of a window
-	{
+	// ---- pass 1: B_{c-1} for c = n-1 .. 1, kept where c - 1 is the last column of a window (nothing to keep with one window)
+	if (n_windows > 1) {
 		const Buf* in = nullptr;
 		uint32_t flip = 0;
 		for (uint32_t c = n - 1; c >= 1; --c) {
@@ -485,9 +635,11 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 			const double *bv = beta ? beta->v : nullptr, *bpart = beta ? beta->partials : nullptr;
 			const uint32_t bb = beta ? beta->blocks : 0u;
 			double* ov = last ? nullptr : out.v;
-			if (T == 1) hipLaunchKernelGGL(geno_forward<1>, dim3(blocks), dim3(GENO_BLOCK), 0, stream, G, c, pv, ppart, pb, bv, bpart, bb, ov, out.partials, glp, atomics);
-			else if (T == 4) hipLaunchKernelGGL(geno_forward<4>, dim3(blocks), dim3(GENO_BLOCK), 0, stream, G, c, pv, ppart, pb, bv, bpart, bb, ov, out.partials, glp, atomics);
-			else hipLaunchKernelGGL(geno_forward<16>, dim3(blocks), dim3(GENO_BLOCK), 0, stream, G, c, pv, ppart, pb, bv, bpart, bb, ov, out.partials, glp, atomics);
+			const uint32_t fc = last ? 0u : p.f[c], fm = last ? 0u : p.fwd_mask[c];
+			const GenoCol C{c, p.k[c], p.b[c], fc, fm, std::min<uint32_t>((uint32_t)p.k[c] - fc, GENO_LOOP_BITS), atomics, 0u};
+			if (T == 1) hipLaunchKernelGGL(geno_forward<1>, dim3(blocks), dim3(GENO_BLOCK), table_bytes, stream, G, C, pv, ppart, pb, bv, bpart, bb, ov, out.partials, glp);
+			else if (T == 4) hipLaunchKernelGGL(geno_forward<4>, dim3(blocks), dim3(GENO_BLOCK), table_bytes, stream, G, C, pv, ppart, pb, bv, bpart, bb, ov, out.partials, glp);
+			else hipLaunchKernelGGL(geno_forward<16>, dim3(blocks), dim3(GENO_BLOCK), table_bytes, stream, G, C, pv, ppart, pb, bv, bpart, bb, ov, out.partials, glp);
 			++launches;
 			GENO_DEV(hipGetLastError());
 			prev_alpha = &out;
@@ -498,6 +650,12 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 		GENO_DEV(hipGetLastError());
 	}
 	GENO_DEV(hipEventRecord(ev[2], stream));
+	if (getenv("WHAMD_DEBUG_TIMING")) {
+		const double enq = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enqueue0).count();
+		GENO_DEV(hipStreamSynchronize(stream));
+		const double all = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enqueue0).count();
+		fprintf(stderr, "[whamd timing] genotype: %llu launches submitted in %.1f ms (host), stream drained after %.1f ms\n", (unsigned long long)launches, enq, all);
+	}
 	GENO_DEV(hipMemcpyAsync(gl_out.data(), d_gl, gl_out.size() * 8, hipMemcpyDeviceToHost, stream));
 	GENO_DEV(hipStreamSynchronize(stream));
 	float ms01 = 0, ms12 = 0, ms02 = 0;

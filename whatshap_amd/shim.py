@@ -147,3 +147,72 @@ def install(phase_module, reference_core=None, **solver_options):
     # keep the binding we replace: inputs beyond the device path's limits fall back to it (table_factory)
     phase_module.PedigreeDPTable = table_factory(reference_core, fallback_table_class=previous[1], **solver_options)
     return previous
+
+
+# ------------------------------------------------------------------------------------------------ whatshap genotype
+class _GenotypeAdapter:
+    """``get_genotype_likelihoods(sample_id, pos)`` returning the reference's ``PhredGenotypeLikelihoods`` when the reference
+    module was handed in (``whatshap/cli/genotype.py:369-383`` passes the result on to ``determine_genotype`` and into the
+    variant table)."""
+
+    def __init__(self, table, reference_core):
+        self._table = table
+        self._ref = reference_core
+
+    def get_genotype_likelihoods(self, sample_id, pos):
+        gl = self._table.get_genotype_likelihoods(sample_id, pos)
+        if self._ref is None:
+            return gl
+        return self._ref.PhredGenotypeLikelihoods(gl.as_vector())
+
+    def get_stats(self):
+        return self._table.get_stats()
+
+
+def genotype_table_factory(reference_core=None, fallback_table_class=None, **options):
+    """Callable with the constructor signature of the reference's ``GenotypeDPTable`` (core.pyx:581-597):
+    ``(numeric_sample_ids, readset, recombcost, pedigree, positions=None)``.  Same rules as ``table_factory``: WhatsHap's
+    own objects go through the compiled ingestion (or a recorded pedigree); an input beyond the device path's limits is
+    logged and handed to ``fallback_table_class``."""
+    from . import genotype as _genotype
+
+    def make(numeric_sample_ids, readset, recombcost, pedigree, positions=None):
+        from . import ingest as _ingest
+
+        compiled = _ingest.load() if reference_core is not None else None
+        problem = None
+        if compiled is not None and isinstance(readset, reference_core.ReadSet) and isinstance(pedigree, reference_core.Pedigree):
+            problem = amd.problem_from_reference_objects(compiled, readset, recombcost, pedigree, False, positions)
+            recorded = pedigree
+        else:
+            recorded = getattr(pedigree, "amd", pedigree)
+            if not isinstance(recorded, amd.Pedigree):
+                raise TypeError("the pedigree was not created through whatshap_amd.shim and the compiled ingestion is not available")
+        try:
+            table = _genotype.GenotypeDPTable(numeric_sample_ids, readset, recombcost, recorded, positions, problem=problem, **options)
+        except RuntimeError as exc:
+            status = getattr(exc, "status", None)
+            if fallback_table_class is None or status not in _DEVICE_LIMIT_STATUSES:
+                raise
+            import logging
+
+            logging.getLogger("whatshap_amd").warning(
+                "device path refused this genotyping table (%s); using the reference GenotypeDPTable", exc)
+            return fallback_table_class(numeric_sample_ids, readset, recombcost, pedigree, positions)
+        return _GenotypeAdapter(table, reference_core)
+
+    return make
+
+
+def install_genotype(genotype_module, reference_core=None, **options):
+    """Rebinds ``GenotypeDPTable`` (and ``Pedigree``, unless the compiled ingestion makes the recording subclass unnecessary)
+    in ``genotype_module`` (normally ``whatshap.cli.genotype``, which binds them at ``:20-30`` and uses them at ``:357-368``).
+    Returns the previous bindings."""
+    from . import ingest as _ingest
+
+    previous = (genotype_module.Pedigree, genotype_module.GenotypeDPTable)
+    if reference_core is None or _ingest.load() is None:
+        ref_pedigree = reference_core.Pedigree if reference_core is not None else genotype_module.Pedigree
+        genotype_module.Pedigree = recording_pedigree_class(ref_pedigree)
+    genotype_module.GenotypeDPTable = genotype_table_factory(reference_core, fallback_table_class=previous[1], **options)
+    return previous
