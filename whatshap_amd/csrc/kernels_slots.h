@@ -57,27 +57,6 @@ typedef const __attribute__((address_space(4))) slot_u32x16* slot_cptr16;
 typedef const __attribute__((address_space(4))) slot_u32x2* slot_cptr2;
 template <class T>
 __device__ __forceinline__ slot_cptr8 slot_scalar_ptr(const T* p) { return (slot_cptr8)(unsigned long long)p; }
-// the hot line of a column (SlotRow), one s_load_dwordx16
-__device__ __forceinline__ slot_u32x16 slot_load_hot(const SlotRow* row) { return *(slot_cptr16)(unsigned long long)row; }
-
-// Pulls the hot lines of the next 32 rows into the scalar cache: 32 independent scalar loads in flight at once (their
-// results are not used: one destination register, one wait inside the statement, so the compiler never sees a pending
-// load).  The column loop's own loads then hit.  Rows beyond the run exist (SLOT_ROW_PAD).
-__device__ __forceinline__ void slot_touch_rows(const SlotRow* rows) {
-	uint32_t sink;
-	asm volatile(
-		"s_load_dword %0, %1, 0x0\n\ts_load_dword %0, %1, 0x100\n\ts_load_dword %0, %1, 0x200\n\ts_load_dword %0, %1, 0x300\n\t"
-		"s_load_dword %0, %1, 0x400\n\ts_load_dword %0, %1, 0x500\n\ts_load_dword %0, %1, 0x600\n\ts_load_dword %0, %1, 0x700\n\t"
-		"s_load_dword %0, %1, 0x800\n\ts_load_dword %0, %1, 0x900\n\ts_load_dword %0, %1, 0xa00\n\ts_load_dword %0, %1, 0xb00\n\t"
-		"s_load_dword %0, %1, 0xc00\n\ts_load_dword %0, %1, 0xd00\n\ts_load_dword %0, %1, 0xe00\n\ts_load_dword %0, %1, 0xf00\n\t"
-		"s_load_dword %0, %1, 0x1000\n\ts_load_dword %0, %1, 0x1100\n\ts_load_dword %0, %1, 0x1200\n\ts_load_dword %0, %1, 0x1300\n\t"
-		"s_load_dword %0, %1, 0x1400\n\ts_load_dword %0, %1, 0x1500\n\ts_load_dword %0, %1, 0x1600\n\ts_load_dword %0, %1, 0x1700\n\t"
-		"s_load_dword %0, %1, 0x1800\n\ts_load_dword %0, %1, 0x1900\n\ts_load_dword %0, %1, 0x1a00\n\ts_load_dword %0, %1, 0x1b00\n\t"
-		"s_load_dword %0, %1, 0x1c00\n\ts_load_dword %0, %1, 0x1d00\n\ts_load_dword %0, %1, 0x1e00\n\ts_load_dword %0, %1, 0x1f00\n\t"
-		"s_waitcnt lgkmcnt(0)"
-		: "=&s"(sink) : "s"(rows) : "memory");
-}
-
 // byte s of a packed position table held in SGPRs (static s)
 __device__ __forceinline__ uint32_t slot_pos_dev(const uint32_t (&w)[8], int s) { return (w[s >> 2] >> ((s & 3) * 8)) & 31u; }
 
