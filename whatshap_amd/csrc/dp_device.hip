@@ -143,6 +143,7 @@ struct DeviceTable::Impl {
 	BtChunk* d_chunks = nullptr;
 	uint32_t* d_unit_x = nullptr;   // [2][units]
 	uint32_t* d_path2 = nullptr;    // [2][columns]: speculative walks of the two orientations
+	uint32_t* d_trans2 = nullptr;   // [2][columns]: their transmission values
 	uint8_t* d_sel = nullptr;
 	uint32_t* d_guess = nullptr;
 	uint32_t* d_bt_counters = nullptr;
@@ -600,19 +601,67 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	m.chunks.clear();
 	m.n_spec = 0;
 	for (SlotRun& run : m.splan.runs) run.spec_id = 0;
-	if (m.use_slots && m.jobs.size() == 1 && !m.windowed && !getenv("WHAMD_BT_SEQUENTIAL") && m.units.size() > 2u * BT_CHUNK_RUNS) {
+	const bool trio_runs = !m.use_slots && !m.plan.ped_columns.empty();   // LDS-resident trio runs (kernels_trio.h)
+	if (trio_runs) for (ResSegment& sgm : m.plan.segments) sgm.in_mirror_bit = 0;   // (trio runs have no mirror: the field carries the spec id)
+	if ((m.use_slots || trio_runs) && m.jobs.size() == 1 && !m.windowed && !getenv("WHAMD_BT_SEQUENTIAL") && m.units.size() > 2u * BT_CHUNK_RUNS) {
 		m.use_chunks = true;
-		BtChunk cur{0, 0, 0, 0};
+		// orientation generators (BtChunk): per founder the index bits of its reads in the projection column a chunk starts from
+		std::vector<uint32_t> founder_tflip;   // founder rank -> transmission bits it flips; individual -> founder rank
+		std::vector<int> founder_rank(std::max<uint32_t>(p.n_ind, 1), -1);
+		{
+			std::vector<uint8_t> is_child(std::max<uint32_t>(p.n_ind, 1), 0);
+			for (uint32_t t3 = 0; t3 < p.n_triples; ++t3) is_child[p.triples[t3][2]] = 1;
+			for (uint32_t s = 0; s < p.n_ind; ++s) {
+				if (is_child[s]) continue;
+				uint32_t tf = 0;
+				for (uint32_t t3 = 0; t3 < p.n_triples; ++t3) {
+					if (p.triples[t3][0] == s) tf |= 1u << (2 * t3);
+					if (p.triples[t3][1] == s) tf |= 1u << (2 * t3 + 1);
+				}
+				founder_rank[s] = (int)founder_tflip.size();
+				founder_tflip.push_back(tf);
+			}
+		}
+		auto orientations = [&](BtChunk& ch, uint32_t unit) {
+			// the chunk starts from the projection column of the LAST column of unit `unit`'s step: bit j = j-th forwarded read
+			const BtUnit& bu = m.units[unit];
+			const uint32_t c_last = bu.c0 + bu.ncols - 1;
+			ch.n_orient = 1; ch.flip[0] = ch.flip[1] = 0;
+			if (p.n_triples == 0 && p.n_ind <= 1) {
+				const uint32_t fb = p.f[c_last];
+				ch.flip[0] = fb >= 28 ? 0x0FFFFFFFu : ((1u << fb) - 1u);
+				ch.n_orient = 2;
+				return;
+			}
+			if (founder_tflip.size() != 2) return;   // other pedigree shapes: one guess (still exact, more walked twice)
+			const ColumnEntry* col = p.col_begin(c_last);
+			uint32_t bit = 0;
+			for (uint32_t j = 0; j < p.k[c_last]; ++j) {
+				if (!((p.fwd_mask[c_last] >> j) & 1u)) continue;
+				const int fr = founder_rank[col[j].sample];
+				if (fr >= 0) ch.flip[fr] |= 1u << bit;
+				++bit;
+			}
+			ch.flip[0] |= founder_tflip[0] << 28;
+			ch.flip[1] |= founder_tflip[1] << 28;
+			ch.n_orient = 4;
+		};
+		BtChunk cur{};
+		cur.n_orient = 1;   // the newest chunk starts from the table's optimum
 		uint32_t runs_in_chunk = 0;
 		for (uint32_t u = 0; u < m.units.size(); ++u) {
-			const bool is_run = m.units[u].kind == 2;
+			const bool is_run = m.units[u].kind == 2 || (trio_runs && m.units[u].kind == 1);
 			if (is_run && runs_in_chunk >= (uint32_t)BT_CHUNK_RUNS && u > 0) {
 				m.chunks.push_back(cur);
-				cur = BtChunk{u, 0, ++m.n_spec, 0};
+				cur = BtChunk{};
+				cur.unit_off = u;
+				cur.spec_id = ++m.n_spec;
+				orientations(cur, u);
 				runs_in_chunk = 0;
 				// the run of unit u leaves the seed: units are the job's steps in reverse order
 				const Step& st = m.plan.steps[m.jobs[0].steps[m.jobs[0].steps.size() - 1 - u]];
-				m.splan.runs[st.index].spec_id = m.n_spec;
+				if (trio_runs) m.plan.segments[st.index].in_mirror_bit = m.n_spec;
+				else m.splan.runs[st.index].spec_id = m.n_spec;
 			}
 			runs_in_chunk += is_run;
 			++cur.unit_count;
@@ -621,13 +670,15 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		void *d_chunks = nullptr;
 		HIP_TRY(up(&d_chunks, m.chunks.data(), m.chunks.size() * sizeof(BtChunk)));
 		m.d_chunks = (BtChunk*)d_chunks;
-		HIP_TRY(alloc((void**)&m.d_unit_x, 2 * m.units.size() * 4));
-		HIP_TRY(alloc((void**)&m.d_path2, 2 * (size_t)n * 4));
+		HIP_TRY(alloc((void**)&m.d_unit_x, BT_ORIENT * m.units.size() * 4));
+		HIP_TRY(alloc((void**)&m.d_path2, BT_ORIENT * (size_t)n * 4));
+		HIP_TRY(alloc((void**)&m.d_trans2, BT_ORIENT * (size_t)n * 4));
 		HIP_TRY(alloc((void**)&m.d_sel, m.units.size() + 16));
 		HIP_TRY(alloc((void**)&m.d_guess, m.chunks.size() * 4));
 		HIP_TRY(alloc((void**)&m.d_bt_counters, 16));
 		uint32_t stride = 64;
 		for (const SlotRun& run : m.splan.runs) if (run.spec_id) stride = std::max(stride, (run.threads >> 6) << (run.g - run.half));
+		if (trio_runs) for (const ResSegment& sgm : m.plan.segments) if (sgm.in_mirror_bit) stride = std::max(stride, (sgm.threads >> 6) << sgm.g);
 		m.dp.spec_stride = stride;
 		void* d_spec = nullptr;
 		HIP_TRY(alloc(&d_spec, ((size_t)m.n_spec + 1) * stride * 8));
@@ -641,7 +692,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		for (const ResSegment& sgm : m.plan.segments) max_stage = std::max(max_stage, sgm.stage_words);
 		for (const SlotRun& run : m.splan.runs) max_stage = std::max(max_stage, (run.n_ends * run.threads + 7) / 8);
 		m.bt_lds = (size_t)2 * RES_MAXCOLS * 128 + 512 + 16 + (size_t)BT_CELLS * 4 + (size_t)RES_MAXCOLS * 4 + (size_t)max_stage * 8 + 16;
-		m.chunk_lds = (size_t)(32 + 4 + BT_CELLS + SLOT_MAXCOLS * 8 + 32) * 4 + (size_t)max_stage * 8 + 16;
+		m.chunk_lds = (size_t)(32 + 4 + BT_CELLS + BT_CHUNK_BLOB) * 4 + (size_t)max_stage * 8 + 16;
 	}
 	void* d_rtab = nullptr;
 	const bool ped_plan = !m.plan.ped_columns.empty();
@@ -824,6 +875,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(backtrace_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment_ped<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment_ped<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((resident_segment_ped<false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 	return WHAMD_OK;
 }
 
@@ -873,6 +925,7 @@ void DeviceTable::Impl::launch_run(const ResBatchEntry& e, uint32_t step_index, 
 		const size_t words = ((size_t)sg.ncols * (PED_LDSWORDS + PED_TABLE) + (size_t)sg.n_terms * 2 + 3) & ~(size_t)3;
 		const size_t lds_ped = words * 4 + 2 * ((size_t)16 << sg.max_l) + (size_t)sg.stage_words * 8;
 		if (m.dp.dbg) hipLaunchKernelGGL(resident_segment_ped<true>, dim3(1u << sg.g), dim3(sg.threads), lds_ped, m.stream, m.dp, sg, e.prev, e.cur);
+		else if (sg.in_mirror_bit && m.use_chunks) hipLaunchKernelGGL((resident_segment_ped<false, true>), dim3(1u << sg.g), dim3(sg.threads), lds_ped, m.stream, m.dp, sg, e.prev, e.cur);
 		else hipLaunchKernelGGL(resident_segment_ped<false>, dim3(1u << sg.g), dim3(sg.threads), lds_ped, m.stream, m.dp, sg, e.prev, e.cur);
 	} else {
 		const size_t lds = (size_t)sg.ncols * (64 + RES_TABLE) * 4 + 2 * ((size_t)4 << sg.max_l) + (size_t)sg.stage_words * 8;
@@ -992,12 +1045,12 @@ whamd_status_t DeviceTable::enqueue_some_unguarded(const Problem& p, Solution& s
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(m.ev1, m.stream));
 	if (m.use_chunks) {
-		HIP_TRY(hipMemsetAsync(m.d_path_trans, 0, (size_t)n * 4, m.stream));   // single individual: no transmission values
-		hipLaunchKernelGGL(backtrace_chunks, dim3(2 * (uint32_t)m.chunks.size()), dim3(256), m.chunk_lds, m.stream, m.dp, m.d_units, m.d_chunks,
-		                   (uint32_t)m.chunks.size(), (uint32_t)m.units.size(), 0u, m.d_path2, m.d_path_trans, m.d_score, m.d_unit_x, m.d_guess, m.d_sel, m.d_bt_counters);
+		hipLaunchKernelGGL(backtrace_chunks, dim3(BT_ORIENT * (uint32_t)m.chunks.size()), dim3(256), m.chunk_lds, m.stream, m.dp, m.d_units, m.d_chunks,
+		                   (uint32_t)m.chunks.size(), (uint32_t)m.units.size(), 0u, m.d_path2, m.d_trans2, m.d_score, m.d_unit_x, m.d_guess, m.d_sel, m.d_bt_counters);
 		hipLaunchKernelGGL(backtrace_chunks, dim3(1), dim3(256), m.chunk_lds, m.stream, m.dp, m.d_units, m.d_chunks,
-		                   (uint32_t)m.chunks.size(), (uint32_t)m.units.size(), 1u, m.d_path2, m.d_path_trans, m.d_score, m.d_unit_x, m.d_guess, m.d_sel, m.d_bt_counters);
-		hipLaunchKernelGGL(backtrace_gather, dim3((uint32_t)m.units.size()), dim3(64), 0, m.stream, m.d_units, (uint32_t)m.units.size(), n, m.d_path2, m.d_sel, m.d_path_index);
+		                   (uint32_t)m.chunks.size(), (uint32_t)m.units.size(), 1u, m.d_path2, m.d_trans2, m.d_score, m.d_unit_x, m.d_guess, m.d_sel, m.d_bt_counters);
+		hipLaunchKernelGGL(backtrace_gather, dim3((uint32_t)m.units.size()), dim3(64), 0, m.stream, m.d_units, (uint32_t)m.units.size(), n, m.d_path2, m.d_trans2, m.d_sel,
+		                   m.d_path_index, m.d_path_trans);
 	} else if (!m.windowed)   // (windowed: every window was walked right after its steps)
 	hipLaunchKernelGGL(backtrace_kernel, dim3((uint32_t)m.jobs.size()), dim3(1024), m.bt_lds, m.stream, m.dp, m.d_units, m.d_btjobs,
 	                   m.d_path_index, m.d_path_trans, m.d_score);

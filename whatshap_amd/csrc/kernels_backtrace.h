@@ -12,6 +12,7 @@
 // the table does (its last column projects onto a single entry): the walk starts at units[0] with entry 0 and no score
 // is written.
 constexpr int BT_CELLS = 128;
+constexpr int BT_CHUNK_BLOB = RES_MAXCOLS * 32;   // words of the chunk walker's per-unit descriptor area (>= SLOT_MAXCOLS * 8 + 32)
 constexpr int BT_CHUNK_RUNS = 16;   // slot runs per chunk of the speculative backtrace  // >= RES_MAXCOLS and >= SLOT_MAXENDS_RUN + 1
 
 __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtUnit* __restrict__ all_units, const BtJob* __restrict__ jobs,
@@ -373,42 +374,124 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 // chunk is walked again from the true state until the path reaches a state the speculative walk went through at the
 // same unit boundary (from there on the two are identical) or the chunk ends.  By induction the result is exactly
 // the path the sequential walk finds; the guess only decides how much is walked twice.
+// Orientations.  The minimum of a projection column is attained by every image of a state under the table's symmetries:
+// relabelling the two haplotypes of a FOUNDER (complement the bits of its reads, and flip the transmission bits of the trios
+// it is a parent of) leaves every cost unchanged.  A single individual has one such generator (all bits), a trio or a quartet
+// two (father, mother): 2 or 4 equally good guesses, and which of them the true path runs through is decided only at the
+// table's last column -- all of them are walked (path buffers 0 .. 3), the verification picks.  (An image's walk is NOT the
+// image of the walk: ties break differently, the records hold every decision.)
+constexpr uint32_t BT_ORIENT = 4;
 struct BtChunk {
 	uint32_t unit_off, unit_count;
 	uint32_t spec_id;   // 0: the newest chunk (units[0] is the table's last column, the optimum comes from P.last_keys)
-	uint32_t pad;
+	uint32_t n_orient;  // 1, 2 or 4
+	uint32_t flip[2];   // packed-state XOR of generator 1 / 2 at this chunk's entry (index bits | transmission bits << 28)
+	uint32_t pad[2];
 };
+__device__ __forceinline__ uint32_t bt_orient(const BtChunk& ch, uint32_t state, uint32_t o) {
+	return state ^ ((o & 1u) ? ch.flip[0] : 0u) ^ ((o & 2u) ? ch.flip[1] : 0u);
+}
 
-// One unit for the whole workgroup (256 threads): x = logical index of the path at the first column of the unit walked
-// before (later in the table); returns the index at this unit's first column.  Single individual only (no transmission).
-__device__ __forceinline__ uint32_t chunk_walk_unit(const DevProblem& P, const BtUnit* __restrict__ unit, uint32_t x, uint32_t* hdr, uint32_t* blob,
+// State of the walk between units, packed into one word: logical index of the path at the first column of the unit walked
+// before (bits 0..27) | transmission value handed down (bits 28..31; 0 for a single individual).
+constexpr uint32_t BT_STATE_XMASK = 0x0FFFFFFFu;
+
+// One unit for the whole workgroup (256 threads): takes the packed state at the first column of the unit walked before (later
+// in the table), returns the packed state at this unit's first column.  Column steps (any T), slot runs (T = 1), trio runs.
+__device__ __forceinline__ uint32_t chunk_walk_unit(const DevProblem& P, const BtUnit* __restrict__ unit, uint32_t state, uint32_t* hdr, uint32_t* blob,
                                                     uint32_t* cells, uint32_t* xshare, unsigned long long* stage,
                                                     uint32_t* __restrict__ path_index, uint32_t* __restrict__ path_trans) {
 	const uint32_t tid = threadIdx.x, NT = blockDim.x;
+	const uint32_t x = state & BT_STATE_XMASK, tprev = state >> 28;
 	__syncthreads();   // the previous unit's readers are done with the LDS areas
 	if (tid < 32) hdr[tid] = reinterpret_cast<const uint32_t*>(unit)[tid];
 	__syncthreads();
 	const uint32_t kind = hdr[0], c0 = hdr[1], ncols = hdr[2];
 	if (kind == 0) {
 		// one column through the column kernels' records (word layout: backtrace_kernel above)
+		const uint32_t T = P.T;
 		const uint32_t cf = hdr[4], cmode = hdr[5], cnplanes = hdr[6], cebits = hdr[7], nsf = hdr[10], nse = hdr[11];
 		const unsigned long long cbt = ((unsigned long long)hdr[9] << 32) | hdr[8];
 		const uint32_t* segs = hdr[28] ? (hdr + 12) : (P.segs + P.cols[c0].seg_off);
 		const uint32_t y = cf >= 32 ? x : (x & ((1u << cf) - 1u));
-		uint32_t xp;
+		uint32_t xp, aj;
 		if (cmode == 0) {
 			const unsigned long long* planes = reinterpret_cast<const unsigned long long*>(P.bt + cbt);
 			const uint32_t words = 1u << (cf - 6);
 			uint32_t v = 0;
-			for (uint32_t p = 0; p < cnplanes; ++p) v |= (uint32_t)((planes[(size_t)p * words + (y >> 6)] >> (y & 63u)) & 1ull) << p;
+			for (uint32_t p = 0; p < cnplanes; ++p) v |= (uint32_t)((planes[(size_t)(p * T + tprev) * words + (y >> 6)] >> (y & 63u)) & 1ull) << p;
 			const uint32_t e = v & ((1u << cebits) - 1u);
+			aj = v >> cebits;
 			xp = deposit(y, segs, nsf) | deposit(e, segs + nsf, nse);
 		} else {
-			const uint32_t r = reinterpret_cast<const uint32_t*>(P.bt + cbt)[y] >> 4;
+			const uint32_t raw = reinterpret_cast<const uint32_t*>(P.bt + cbt)[(size_t)y * T + tprev];
+			const uint32_t r = raw >> 4;
 			xp = r ^ (r >> 1);
+			aj = raw & 15u;
 		}
-		if (tid == 0) path_index[c0] = xp;
-		return xp;
+		if (tid == 0) { path_index[c0] = xp; path_trans[c0] = tprev; }
+		return xp | (aj << 28);
+	}
+	if (kind == 1) {
+		// ---- LDS-resident run of a trio (kernels_trio.h): per-column parameters (ResBacktrace, 32 words each) and the record of the
+		// workgroup the path runs through -> LDS; one wave follows the argmins column by column (every column carries the
+		// transmission argmin).  Same record semantics as the walk in backtrace_kernel.
+		const uint32_t g = hdr[4], Lf_last = hdr[5], stage_words = hdr[6], n_wext = hdr[7];
+		const uint32_t yexit = x & ((1u << (Lf_last + g)) - 1u);
+		uint32_t w = 0;
+		for (uint32_t i = 0; i < n_wext; ++i) {
+			const uint32_t r = hdr[12 + i];
+			w |= ((yexit >> (r & 31u)) & ((1u << ((r >> 16) & 31u)) - 1u)) << ((r >> 8) & 31u);
+		}
+		const uint32_t* __restrict__ grecs = reinterpret_cast<const uint32_t*>(P.res_bt + hdr[3]);
+		for (uint32_t i = tid; i < ncols * 32u; i += NT) blob[i] = grecs[i];
+		const unsigned long long* __restrict__ gst = reinterpret_cast<const unsigned long long*>(
+			P.bt + (((unsigned long long)hdr[9] << 32) | hdr[8])) + (size_t)w * stage_words;
+		for (uint32_t i = tid; i < stage_words; i += NT) stage[i] = gst[i];
+		__syncthreads();
+		if (tid < 64) {
+			uint32_t l = 0;
+			for (uint32_t i = 0; i < hdr[10]; ++i) {
+				const uint32_t r = hdr[18 + i];
+				l |= ((yexit >> (r & 31u)) & ((1u << ((r >> 16) & 31u)) - 1u)) << ((r >> 8) & 31u);
+			}
+			const uint8_t* stage8 = reinterpret_cast<const uint8_t*>(stage);
+			uint32_t tcur = tprev;
+			for (uint32_t ci = ncols; ci-- > 0;) {
+				const uint32_t* rb = blob + ci * 32u;   // Lf, ebits, layout (2 for a trio column), stage_off | nwords, epos0, epos1, epos2
+				const uint32_t lout = l & ((1u << rb[0]) - 1u), eb = rb[1];
+				const uint32_t fld = stage8[rb[3] * 8u + lout * 4u + tcur] & 31u;   // ending-read bits | argj << 3
+				uint32_t cell = lout, bits = 0;
+				for (uint32_t q = 0; q < eb && q < 3u; ++q) {
+					cell = insert_zero(cell, rb[5 + q]);
+					bits |= ((fld >> q) & 1u) << rb[5 + q];
+				}
+				cell |= bits;
+				if (tid == 0) { cells[ci] = cell; cells[64 + ci] = tcur; }
+				tcur = fld >> 3;
+				l = cell;
+			}
+			if (tid == 0) xshare[1] = tcur;
+		}
+		__syncthreads();
+		if (tid < ncols) {   // logical index of column tid: deposits of the workgroup index and of the local cell
+			const uint32_t* rb = blob + tid * 32u;
+			const uint32_t cell = cells[tid], ng = rb[8], nl = rb[9];
+			uint32_t xl = 0;
+			for (uint32_t i = 0; i < ng; ++i) {
+				const uint32_t r = rb[10 + i];
+				xl |= ((w >> (r & 31u)) & ((1u << ((r >> 16) & 31u)) - 1u)) << ((r >> 8) & 31u);
+			}
+			for (uint32_t i = 0; i < nl; ++i) {
+				const uint32_t r = rb[18 + i];
+				xl |= ((cell >> (r & 31u)) & ((1u << ((r >> 16) & 31u)) - 1u)) << ((r >> 8) & 31u);
+			}
+			path_index[c0 + tid] = xl;
+			path_trans[c0 + tid] = cells[64 + tid];
+			if (tid == 0) xshare[0] = xl;
+		}
+		__syncthreads();
+		return xshare[0] | (xshare[1] << 28);
 	}
 	// ---- slot run: blob (column slot lists + ending slots), physical exit index, record of the path's workgroup -> LDS
 	const uint32_t g = hdr[4], L = hdr[5], n_ends = hdr[6], threads = hdr[7], f_exit = hdr[12], lr = hdr[13];
@@ -449,6 +532,7 @@ __device__ __forceinline__ uint32_t chunk_walk_unit(const DevProblem& P, const B
 		const uint32_t xl = (uint32_t)__ballot(bit);
 		if (j == 0) {
 			path_index[c0 + c] = xl;
+			path_trans[c0 + c] = 0u;
 			if (c == 0) xshare[0] = xl;
 		}
 	}
@@ -463,35 +547,61 @@ __device__ __forceinline__ uint32_t chunk_walk_unit(const DevProblem& P, const B
 // differently for the two, the records hold both decisions -- slots.h.)
 __global__ __launch_bounds__(256) void backtrace_chunks(DevProblem P, const BtUnit* __restrict__ units, const BtChunk* __restrict__ chunks,
                                                          uint32_t n_chunks, uint32_t n_units, uint32_t mode, uint32_t* __restrict__ path2,
-                                                         uint32_t* __restrict__ path_trans, uint32_t* __restrict__ out_score,
+                                                         uint32_t* __restrict__ trans2, uint32_t* __restrict__ out_score,
                                                          uint32_t* __restrict__ unit_x2, uint32_t* __restrict__ guess, uint8_t* __restrict__ sel,
                                                          uint32_t* __restrict__ counters) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
 	uint32_t* hdr = smem;                         // 32 words
 	uint32_t* xshare = hdr + 32;                  // 4 words
 	uint32_t* cells = xshare + 4;                 // BT_CELLS words
-	uint32_t* blob = cells + BT_CELLS;            // SLOT_MAXCOLS * 8 + 32 words
-	unsigned long long* stage = reinterpret_cast<unsigned long long*>(blob + SLOT_MAXCOLS * 8 + 32);
+	uint32_t* blob = cells + BT_CELLS;            // BT_CHUNK_BLOB words: slot blob, or the ResBacktrace records of a trio run
+	unsigned long long* stage = reinterpret_cast<unsigned long long*>(blob + BT_CHUNK_BLOB);
 	const uint32_t tid = threadIdx.x, n = P.n_cols;
 	if (mode == 0) {
-		const uint32_t ci = blockIdx.x >> 1, o = blockIdx.x & 1u;
+		const uint32_t ci = blockIdx.x / BT_ORIENT, o = blockIdx.x % BT_ORIENT;
 		const BtChunk ch = chunks[ci];
+		if (o >= ch.n_orient) return;
 		const BtUnit* __restrict__ cu = units + ch.unit_off;
 		uint32_t* __restrict__ path = path2 + (size_t)o * n;
+		uint32_t* __restrict__ ptrans = trans2 + (size_t)o * n;
 		uint32_t* __restrict__ unit_x = unit_x2 + (size_t)o * n_units;
 		uint32_t x, first = 0;
 		if (ch.spec_id == 0) {
 			if (o) return;
-			// the table's last column: first (rank(x)) attaining the minimum (strict '<' scan, src/pedigreedptable.cpp:306-315)
-			const unsigned long long key = P.last_keys[0];
+			// the table's last column: first (rank(x), i) attaining the minimum (strict '<' scan, src/pedigreedptable.cpp:306-315)
+			unsigned long long key = ~0ull;
+			uint32_t t_last = 0;
+			for (uint32_t i = 0; i < P.T; ++i) {
+				const unsigned long long k2 = P.last_keys[i];
+				if ((k2 >> 4) < (key >> 4)) { key = k2; t_last = i; }
+			}
 			const uint32_t rlast = (uint32_t)(key >> 4) & 0x0FFFFFFFu;
-			x = rlast ^ (rlast >> 1);
+			x = (rlast ^ (rlast >> 1)) | (((uint32_t)key & 15u) << 28);   // index of the last column | the argj it hands down
 			if (tid == 0) {
-				out_score[0] = (uint32_t)(key >> 32);
-				path[n - 1] = x;
+				out_score[0] = key == ~0ull ? 0xFFFFFFFFu : (uint32_t)(key >> 32);
+				path[n - 1] = x & BT_STATE_XMASK;
+				ptrans[n - 1] = t_last;
 				unit_x[ch.unit_off] = x;
 			}
 			first = 1;
+		} else if (cu->kind == 1u) {
+			// trio: the smallest entry (y, t) of the projection column this chunk's newest run left (key = value << 32 | y * 4 + t)
+			const unsigned long long* __restrict__ cand = P.spec_keys + (size_t)(ch.spec_id - 1u) * P.spec_stride;
+			unsigned long long best = ~0ull;
+			for (uint32_t i = tid; i < P.spec_stride; i += blockDim.x) best = min(best, cand[i]);
+#pragma unroll
+			for (int m = 1; m < 64; m <<= 1) {
+				const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)best, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(best >> 32), m);
+				best = min(best, ((unsigned long long)hi << 32) | lo);
+			}
+			unsigned long long* red = reinterpret_cast<unsigned long long*>(cells);
+			if ((tid & 63u) == 0) red[tid >> 6] = best;
+			__syncthreads();
+			for (uint32_t i = 0; i < (blockDim.x >> 6); ++i) best = min(best, red[i]);
+			const uint32_t idx = (uint32_t)best;
+			x = (idx >> 2) | ((idx & 3u) << 28);
+			if (tid == 0 && o == 0) guess[ci] = x;
+			x = bt_orient(ch, x, o);
 		} else {
 			// guess: the smallest entry of the column this chunk's newest run left (exit index -> logical exit index), or its complement
 			const unsigned long long* __restrict__ cand = P.spec_keys + (size_t)(ch.spec_id - 1u) * P.spec_stride;
@@ -510,55 +620,64 @@ __global__ __launch_bounds__(256) void backtrace_chunks(DevProblem P, const BtUn
 			const SlotBtUnit* su = reinterpret_cast<const SlotBtUnit*>(cu);
 			x = 0;
 			for (uint32_t j = 0; j < su->f_exit; ++j) x |= ((idx >> su->exit_pos[j]) & 1u) << j;
-			if (o) x ^= su->f_exit >= 32u ? 0xFFFFFFFFu : ((1u << su->f_exit) - 1u);
 			if (tid == 0 && o == 0) guess[ci] = x;
+			x = bt_orient(ch, x, o);
 		}
 		for (uint32_t u = first; u < ch.unit_count; ++u) {
-			x = chunk_walk_unit(P, cu + u, x, hdr, blob, cells, xshare, stage, path, path_trans);
+			x = chunk_walk_unit(P, cu + u, x, hdr, blob, cells, xshare, stage, path, ptrans);
 			if (tid == 0) unit_x[ch.unit_off + u] = x;
 		}
 		return;
 	}
 	// ---- mode 1: boundaries newest to oldest; sel[u] = path buffer that holds the true path of unit u
 	uint32_t missed = 0, rewalked = 0;
-	const uint32_t* __restrict__ ux0 = unit_x2;
-	const uint32_t* __restrict__ ux1 = unit_x2 + n_units;
 	for (uint32_t u = tid; u < chunks[0].unit_count; u += blockDim.x) sel[chunks[0].unit_off + u] = 0;
-	uint32_t entry = ux0[chunks[0].unit_off + chunks[0].unit_count - 1u];   // the newest chunk started from the true optimum
+	uint32_t entry = unit_x2[chunks[0].unit_off + chunks[0].unit_count - 1u];   // the newest chunk started from the true optimum
 	for (uint32_t ci = 1; ci < n_chunks; ++ci) {
 		const BtChunk ch = chunks[ci];
 		const BtUnit* __restrict__ cu = units + ch.unit_off;
-		uint32_t x = entry;                                           // the true path's index at the first column of the unit walked before
+		uint32_t x = entry;                                           // the true path's state at the first column of the unit walked before
 		const SlotBtUnit* su = reinterpret_cast<const SlotBtUnit*>(cu);
-		const uint32_t fmask = su->f_exit >= 32u ? 0xFFFFFFFFu : ((1u << su->f_exit) - 1u);
-		const uint32_t g0 = guess[ci] & fmask;
+		// the part of the state the chunk's first unit looks at: the low f bits of the index (+ the transmission value)
+		const uint32_t fbits = cu->kind == 1u ? cu->g + cu->Lf_last : su->f_exit;
+		const uint32_t imask = fbits >= 28u ? BT_STATE_XMASK : ((1u << fbits) - 1u);
+		const uint32_t fmask = imask | ~BT_STATE_XMASK;
+		const uint32_t g0 = guess[ci];
 		uint32_t from = 0;                                            // units [from, unit_count) come from buffer `o`
-		uint32_t o = 0;
-		if ((x & fmask) == g0) o = 0;
-		else if ((x & fmask) == (g0 ^ fmask)) o = 1;
-		else {
-			// neither: walk from the true state (into buffer 0) until the path reaches a state one of the two walks went through
+		uint32_t o = BT_ORIENT;
+		for (uint32_t q = 0; q < ch.n_orient; ++q)
+			if (o == BT_ORIENT && ((x ^ bt_orient(ch, g0, q)) & fmask) == 0u) o = q;
+		if (o == BT_ORIENT) {
+			// none of the guesses: walk from the true state (into buffer 0) until the path reaches a state one of the walks went through
 			++missed;
+			o = 0;
 			from = ch.unit_count;
 			for (uint32_t u = 0; u < ch.unit_count; ++u) {
-				x = chunk_walk_unit(P, cu + u, x, hdr, blob, cells, xshare, stage, path2, path_trans);
+				x = chunk_walk_unit(P, cu + u, x, hdr, blob, cells, xshare, stage, path2, trans2);
 				++rewalked;
-				const uint32_t w0 = ux0[ch.unit_off + u], w1 = ux1[ch.unit_off + u];   // (not written by this launch)
-				if (x == w0 || x == w1) { from = u + 1u; o = x == w0 ? 0u : 1u; break; }
+				uint32_t hit = BT_ORIENT;
+				for (uint32_t q = 0; q < ch.n_orient; ++q)
+					if (hit == BT_ORIENT && x == unit_x2[(size_t)q * n_units + ch.unit_off + u]) hit = q;   // (not written by this launch)
+				if (hit != BT_ORIENT) { from = u + 1u; o = hit; break; }
 			}
 		}
 		for (uint32_t u = tid; u < ch.unit_count; u += blockDim.x) sel[ch.unit_off + u] = u < from ? (uint8_t)0 : (uint8_t)o;
-		entry = from == ch.unit_count ? x : (o ? ux1 : ux0)[ch.unit_off + ch.unit_count - 1u];
+		entry = from == ch.unit_count ? x : unit_x2[(size_t)o * n_units + ch.unit_off + ch.unit_count - 1u];
 	}
 	if (tid == 0) { counters[0] = missed; counters[1] = rewalked; }
 }
 
 // Gathers the final index path: unit u's columns from the path buffer the verification selected.
 __global__ __launch_bounds__(64) void backtrace_gather(const BtUnit* __restrict__ units, uint32_t n_units, uint32_t n_cols, const uint32_t* __restrict__ path2,
-                                                       const uint8_t* __restrict__ sel, uint32_t* __restrict__ path_index) {
+                                                       const uint32_t* __restrict__ trans2, const uint8_t* __restrict__ sel,
+                                                       uint32_t* __restrict__ path_index, uint32_t* __restrict__ path_trans) {
 	const uint32_t u = blockIdx.x;
 	if (u >= n_units) return;
 	const uint32_t c0 = units[u].c0, ncols = units[u].ncols;
 	const uint32_t* __restrict__ src = path2 + (size_t)sel[u] * n_cols;
-	for (uint32_t c = threadIdx.x; c < ncols; c += blockDim.x) path_index[c0 + c] = src[c0 + c];
+	const uint32_t* __restrict__ tsrc = trans2 + (size_t)sel[u] * n_cols;
+	for (uint32_t c = threadIdx.x; c < ncols; c += blockDim.x) {
+		path_index[c0 + c] = src[c0 + c];
+		path_trans[c0 + c] = tsrc[c0 + c];
+	}
 }

@@ -142,7 +142,10 @@ __device__ __forceinline__ void ped_column(const uint32_t* lw, const int32_t* tb
 // With two waves per SIMD (2^15 cells x 4 values = 2048 waves on 1024 SIMDs) nothing but the lane's own instruction
 // stream hides LDS latency, so a column issues its LDS reads in two batches: everything addressed by (column, lane),
 // then the table entries and previous-slice rows addressed by the cell index.
-template <bool DBG>
+// SPEC: the run ends a backtrace chunk (ResSegment::in_mirror_bit carries the chunk's spec id for trio runs, which have no
+// mirror) and leaves, per wave, the smallest entry (value << 32 | y * 4 + t) of the projection column it writes -- the seed of
+// the speculative walk (kernels_backtrace.h).
+template <bool DBG, bool SPEC = false>
 __global__ __launch_bounds__(1024) void resident_segment_ped(DevProblem P, ResSegment sg, const uint32_t* __restrict__ prev,
                                                               uint32_t* __restrict__ cur) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -258,7 +261,26 @@ __global__ __launch_bounds__(1024) void resident_segment_ped(DevProblem P, ResSe
 	const unsigned long long t_cols = DBG ? __builtin_readcyclecounter() : 0ull;
 	const uint32_t wout = deposit_args(w, sg.out_grid, sg.n_out_grid);
 	uint4* c4 = reinterpret_cast<uint4*>(cur);
-	for (uint32_t l = tid; l < (1u << sg.Lf_last); l += NT) c4[wout | deposit_args(l, sg.out_local, sg.n_out_local)] = bufP[l];
+	unsigned long long best_key = ~0ull;
+	for (uint32_t l = tid; l < (1u << sg.Lf_last); l += NT) {
+		const uint32_t y = wout | deposit_args(l, sg.out_local, sg.n_out_local);
+		const uint4 v = bufP[l];
+		c4[y] = v;
+		if (SPEC) {
+			best_key = min(best_key, ((unsigned long long)v.x << 32) | (y * 4u + 0u));
+			best_key = min(best_key, ((unsigned long long)v.y << 32) | (y * 4u + 1u));
+			best_key = min(best_key, ((unsigned long long)v.z << 32) | (y * 4u + 2u));
+			best_key = min(best_key, ((unsigned long long)v.w << 32) | (y * 4u + 3u));
+		}
+	}
+	if (SPEC && sg.in_mirror_bit) {
+#pragma unroll
+		for (int m = 1; m < 64; m <<= 1) {
+			const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)best_key, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(best_key >> 32), m);
+			best_key = min(best_key, ((unsigned long long)hi << 32) | lo);
+		}
+		if ((tid & 63u) == 0) P.spec_keys[(size_t)(sg.in_mirror_bit - 1u) * P.spec_stride + w * (NT >> 6) + (tid >> 6)] = best_key;
+	}
 	unsigned long long* grec = reinterpret_cast<unsigned long long*>(P.bt + (((unsigned long long)sg.bt_hi << 32) | sg.bt_lo)) + (size_t)w * sg.stage_words;
 	const unsigned long long* st64 = reinterpret_cast<const unsigned long long*>(stage);
 	for (uint32_t i = tid; i < sg.stage_words; i += NT) grec[i] = st64[i];
