@@ -605,46 +605,48 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	if (trio_runs) for (ResSegment& sgm : m.plan.segments) sgm.in_mirror_bit = 0;   // (trio runs have no mirror: the field carries the spec id)
 	if ((m.use_slots || trio_runs) && m.jobs.size() == 1 && !m.windowed && !getenv("WHAMD_BT_SEQUENTIAL") && m.units.size() > 2u * BT_CHUNK_RUNS) {
 		m.use_chunks = true;
-		// orientation generators (BtChunk): per founder the index bits of its reads in the projection column a chunk starts from
-		std::vector<uint32_t> founder_tflip;   // founder rank -> transmission bits it flips; individual -> founder rank
-		std::vector<int> founder_rank(std::max<uint32_t>(p.n_ind, 1), -1);
-		{
-			std::vector<uint8_t> is_child(std::max<uint32_t>(p.n_ind, 1), 0);
-			for (uint32_t t3 = 0; t3 < p.n_triples; ++t3) is_child[p.triples[t3][2]] = 1;
+		// orientation generators (BtChunk): per individual the transmission bits its relabelling flips -- a founder those of the
+		// trios it is a parent of, a child both of its own trio (exact where genotypes are heterozygous); individuals that are
+		// both, or pedigrees with more than BT_GENERATORS individuals, get no generator (still exact, more walked twice)
+		std::vector<int> generator_of(std::max<uint32_t>(p.n_ind, 1), -1);
+		std::vector<uint32_t> generator_tflip;
+		if (p.n_ind >= 2 && p.n_ind <= BT_GENERATORS) {
 			for (uint32_t s = 0; s < p.n_ind; ++s) {
-				if (is_child[s]) continue;
-				uint32_t tf = 0;
+				uint32_t as_parent = 0, as_child = 0;
 				for (uint32_t t3 = 0; t3 < p.n_triples; ++t3) {
-					if (p.triples[t3][0] == s) tf |= 1u << (2 * t3);
-					if (p.triples[t3][1] == s) tf |= 1u << (2 * t3 + 1);
+					if (p.triples[t3][0] == s) as_parent |= 1u << (2 * t3);
+					if (p.triples[t3][1] == s) as_parent |= 1u << (2 * t3 + 1);
+					if (p.triples[t3][2] == s) as_child |= 3u << (2 * t3);
 				}
-				founder_rank[s] = (int)founder_tflip.size();
-				founder_tflip.push_back(tf);
+				if (as_parent && as_child) continue;
+				if (!as_parent && !as_child) continue;   // unrelated individual of a multi-sample table
+				generator_of[s] = (int)generator_tflip.size();
+				generator_tflip.push_back(as_parent | as_child);
 			}
 		}
 		auto orientations = [&](BtChunk& ch, uint32_t unit) {
 			// the chunk starts from the projection column of the LAST column of unit `unit`'s step: bit j = j-th forwarded read
 			const BtUnit& bu = m.units[unit];
 			const uint32_t c_last = bu.c0 + bu.ncols - 1;
-			ch.n_orient = 1; ch.flip[0] = ch.flip[1] = 0;
+			ch.n_orient = 1;
+			for (uint32_t q = 0; q < BT_GENERATORS; ++q) ch.flip[q] = 0;
 			if (p.n_triples == 0 && p.n_ind <= 1) {
 				const uint32_t fb = p.f[c_last];
 				ch.flip[0] = fb >= 28 ? 0x0FFFFFFFu : ((1u << fb) - 1u);
 				ch.n_orient = 2;
 				return;
 			}
-			if (founder_tflip.size() != 2) return;   // other pedigree shapes: one guess (still exact, more walked twice)
+			if (generator_tflip.empty()) return;
 			const ColumnEntry* col = p.col_begin(c_last);
 			uint32_t bit = 0;
 			for (uint32_t j = 0; j < p.k[c_last]; ++j) {
 				if (!((p.fwd_mask[c_last] >> j) & 1u)) continue;
-				const int fr = founder_rank[col[j].sample];
-				if (fr >= 0) ch.flip[fr] |= 1u << bit;
+				const int gq = generator_of[col[j].sample];
+				if (gq >= 0) ch.flip[gq] |= 1u << bit;
 				++bit;
 			}
-			ch.flip[0] |= founder_tflip[0] << 28;
-			ch.flip[1] |= founder_tflip[1] << 28;
-			ch.n_orient = 4;
+			for (size_t q = 0; q < generator_tflip.size(); ++q) ch.flip[q] |= generator_tflip[q] << 28;
+			ch.n_orient = 1u << generator_tflip.size();
 		};
 		BtChunk cur{};
 		cur.n_orient = 1;   // the newest chunk starts from the table's optimum
@@ -1088,9 +1090,9 @@ whamd_status_t DeviceTable::wait(const Problem& p, Solution& s, whamd_solve_stat
 	st.total_ms = f03;
 	st.forward_launches = launches;
 	if (m.use_chunks && getenv("WHAMD_BT_STATS")) {
-		uint32_t c[2] = {0, 0};
-		HIP_TRY(hipMemcpy(c, m.d_bt_counters, 8, hipMemcpyDeviceToHost));
-		fprintf(stderr, "[whamd backtrace] %zu chunks, %u guesses missed, %u units walked again (of %zu)\n", m.chunks.size(), c[0], c[1], m.units.size());
+		uint32_t c[3] = {0, 0, 0};
+		HIP_TRY(hipMemcpy(c, m.d_bt_counters, 12, hipMemcpyDeviceToHost));
+		fprintf(stderr, "[whamd backtrace] %zu chunks, %u guesses missed (%u of them only in the transmission value), %u units walked again (of %zu)\n", m.chunks.size(), c[0], c[2], c[1], m.units.size());
 	}
 	if (m.dp.dbg && m.use_slots) {
 		std::vector<unsigned long long> d(m.splan.runs.size() * 48);

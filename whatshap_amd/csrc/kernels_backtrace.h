@@ -377,19 +377,25 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 // Orientations.  The minimum of a projection column is attained by every image of a state under the table's symmetries:
 // relabelling the two haplotypes of a FOUNDER (complement the bits of its reads, and flip the transmission bits of the trios
 // it is a parent of) leaves every cost unchanged.  A single individual has one such generator (all bits), a trio or a quartet
-// two (father, mother): 2 or 4 equally good guesses, and which of them the true path runs through is decided only at the
-// table's last column -- all of them are walked (path buffers 0 .. 3), the verification picks.  (An image's walk is NOT the
-// image of the walk: ties break differently, the records hold every decision.)
-constexpr uint32_t BT_ORIENT = 4;
+// two (father, mother); which image the true path runs through is decided only at the table's last column -- all of them are
+// walked (one path buffer each), the verification picks.  (An image's walk is NOT the image of the walk: ties break
+// differently, the records hold every decision.)
+// Where every genotype is heterozygous (the synthetic benchmarks; long stretches of real data) complementing a CHILD's reads
+// together with both of its transmission bits is a symmetry too: the child then carries its parents' other haplotypes, which
+// hold the complementary alleles.  It is not exact in general -- a guess only has to be right often, the verification keeps the
+// result exact -- so children are generators as well: up to 4 generators (a quartet), 16 guesses per chunk.
+constexpr uint32_t BT_GENERATORS = 4;
+constexpr uint32_t BT_ORIENT = 1u << BT_GENERATORS;
 struct BtChunk {
 	uint32_t unit_off, unit_count;
 	uint32_t spec_id;   // 0: the newest chunk (units[0] is the table's last column, the optimum comes from P.last_keys)
-	uint32_t n_orient;  // 1, 2 or 4
-	uint32_t flip[2];   // packed-state XOR of generator 1 / 2 at this chunk's entry (index bits | transmission bits << 28)
-	uint32_t pad[2];
+	uint32_t n_orient;  // 2^generators in use
+	uint32_t flip[BT_GENERATORS];   // packed-state XOR of each generator at this chunk's entry (index bits | transmission bits << 28)
 };
 __device__ __forceinline__ uint32_t bt_orient(const BtChunk& ch, uint32_t state, uint32_t o) {
-	return state ^ ((o & 1u) ? ch.flip[0] : 0u) ^ ((o & 2u) ? ch.flip[1] : 0u);
+#pragma unroll
+	for (uint32_t q = 0; q < BT_GENERATORS; ++q) state ^= ((o >> q) & 1u) ? ch.flip[q] : 0u;
+	return state;
 }
 
 // State of the walk between units, packed into one word: logical index of the path at the first column of the unit walked
@@ -630,7 +636,7 @@ __global__ __launch_bounds__(256) void backtrace_chunks(DevProblem P, const BtUn
 		return;
 	}
 	// ---- mode 1: boundaries newest to oldest; sel[u] = path buffer that holds the true path of unit u
-	uint32_t missed = 0, rewalked = 0;
+	uint32_t missed = 0, rewalked = 0, index_only = 0;
 	for (uint32_t u = tid; u < chunks[0].unit_count; u += blockDim.x) sel[chunks[0].unit_off + u] = 0;
 	uint32_t entry = unit_x2[chunks[0].unit_off + chunks[0].unit_count - 1u];   // the newest chunk started from the true optimum
 	for (uint32_t ci = 1; ci < n_chunks; ++ci) {
@@ -648,6 +654,8 @@ __global__ __launch_bounds__(256) void backtrace_chunks(DevProblem P, const BtUn
 		for (uint32_t q = 0; q < ch.n_orient; ++q)
 			if (o == BT_ORIENT && ((x ^ bt_orient(ch, g0, q)) & fmask) == 0u) o = q;
 		if (o == BT_ORIENT) {
+			for (uint32_t q = 0; q < ch.n_orient; ++q)
+				if (((x ^ bt_orient(ch, g0, q)) & imask) == 0u) { ++index_only; break; }
 			// none of the guesses: walk from the true state (into buffer 0) until the path reaches a state one of the walks went through
 			++missed;
 			o = 0;
@@ -664,7 +672,7 @@ __global__ __launch_bounds__(256) void backtrace_chunks(DevProblem P, const BtUn
 		for (uint32_t u = tid; u < ch.unit_count; u += blockDim.x) sel[ch.unit_off + u] = u < from ? (uint8_t)0 : (uint8_t)o;
 		entry = from == ch.unit_count ? x : unit_x2[(size_t)o * n_units + ch.unit_off + ch.unit_count - 1u];
 	}
-	if (tid == 0) { counters[0] = missed; counters[1] = rewalked; }
+	if (tid == 0) { counters[0] = missed; counters[1] = rewalked; counters[2] = index_only; }
 }
 
 // Gathers the final index path: unit u's columns from the path buffer the verification selected.
