@@ -143,7 +143,8 @@ struct DeviceTable::Impl {
 	BtChunk* d_chunks = nullptr;
 	uint32_t* d_unit_x = nullptr;   // [2][units]
 	uint32_t* d_path2 = nullptr;    // [2][columns]: speculative walks of the two orientations
-	uint32_t* d_trans2 = nullptr;   // [2][columns]: their transmission values
+	uint32_t* d_trans2 = nullptr;   // [orientations][columns]: their transmission values
+	uint32_t n_orient_max = 1;      // most orientations any chunk has (2 for a single individual, 8 for a trio)
 	uint8_t* d_sel = nullptr;
 	uint32_t* d_guess = nullptr;
 	uint32_t* d_bt_counters = nullptr;
@@ -672,9 +673,11 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		void *d_chunks = nullptr;
 		HIP_TRY(up(&d_chunks, m.chunks.data(), m.chunks.size() * sizeof(BtChunk)));
 		m.d_chunks = (BtChunk*)d_chunks;
-		HIP_TRY(alloc((void**)&m.d_unit_x, BT_ORIENT * m.units.size() * 4));
-		HIP_TRY(alloc((void**)&m.d_path2, BT_ORIENT * (size_t)n * 4));
-		HIP_TRY(alloc((void**)&m.d_trans2, BT_ORIENT * (size_t)n * 4));
+		m.n_orient_max = 1;
+		for (const BtChunk& ch : m.chunks) m.n_orient_max = std::max(m.n_orient_max, ch.n_orient);
+		HIP_TRY(alloc((void**)&m.d_unit_x, (size_t)m.n_orient_max * m.units.size() * 4));
+		HIP_TRY(alloc((void**)&m.d_path2, (size_t)m.n_orient_max * n * 4));
+		HIP_TRY(alloc((void**)&m.d_trans2, (size_t)m.n_orient_max * n * 4));
 		HIP_TRY(alloc((void**)&m.d_sel, m.units.size() + 16));
 		HIP_TRY(alloc((void**)&m.d_guess, m.chunks.size() * 4));
 		HIP_TRY(alloc((void**)&m.d_bt_counters, 16));
@@ -1047,10 +1050,10 @@ whamd_status_t DeviceTable::enqueue_some_unguarded(const Problem& p, Solution& s
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(m.ev1, m.stream));
 	if (m.use_chunks) {
-		hipLaunchKernelGGL(backtrace_chunks, dim3(BT_ORIENT * (uint32_t)m.chunks.size()), dim3(256), m.chunk_lds, m.stream, m.dp, m.d_units, m.d_chunks,
-		                   (uint32_t)m.chunks.size(), (uint32_t)m.units.size(), 0u, m.d_path2, m.d_trans2, m.d_score, m.d_unit_x, m.d_guess, m.d_sel, m.d_bt_counters);
+		hipLaunchKernelGGL(backtrace_chunks, dim3(m.n_orient_max * (uint32_t)m.chunks.size()), dim3(256), m.chunk_lds, m.stream, m.dp, m.d_units, m.d_chunks,
+		                   (uint32_t)m.chunks.size(), (uint32_t)m.units.size(), 0u, m.n_orient_max, m.d_path2, m.d_trans2, m.d_score, m.d_unit_x, m.d_guess, m.d_sel, m.d_bt_counters);
 		hipLaunchKernelGGL(backtrace_chunks, dim3(1), dim3(256), m.chunk_lds, m.stream, m.dp, m.d_units, m.d_chunks,
-		                   (uint32_t)m.chunks.size(), (uint32_t)m.units.size(), 1u, m.d_path2, m.d_trans2, m.d_score, m.d_unit_x, m.d_guess, m.d_sel, m.d_bt_counters);
+		                   (uint32_t)m.chunks.size(), (uint32_t)m.units.size(), 1u, m.n_orient_max, m.d_path2, m.d_trans2, m.d_score, m.d_unit_x, m.d_guess, m.d_sel, m.d_bt_counters);
 		hipLaunchKernelGGL(backtrace_gather, dim3((uint32_t)m.units.size()), dim3(64), 0, m.stream, m.d_units, (uint32_t)m.units.size(), n, m.d_path2, m.d_trans2, m.d_sel,
 		                   m.d_path_index, m.d_path_trans);
 	} else if (!m.windowed)   // (windowed: every window was walked right after its steps)

@@ -552,7 +552,7 @@ __device__ __forceinline__ uint32_t chunk_walk_unit(const DevProblem& P, const B
 // the verification picks the one the true path arrives at.  (The complement is NOT simply the complement path: ties break
 // differently for the two, the records hold both decisions -- slots.h.)
 __global__ __launch_bounds__(256) void backtrace_chunks(DevProblem P, const BtUnit* __restrict__ units, const BtChunk* __restrict__ chunks,
-                                                         uint32_t n_chunks, uint32_t n_units, uint32_t mode, uint32_t* __restrict__ path2,
+                                                         uint32_t n_chunks, uint32_t n_units, uint32_t mode, uint32_t n_orient_max, uint32_t* __restrict__ path2,
                                                          uint32_t* __restrict__ trans2, uint32_t* __restrict__ out_score,
                                                          uint32_t* __restrict__ unit_x2, uint32_t* __restrict__ guess, uint8_t* __restrict__ sel,
                                                          uint32_t* __restrict__ counters) {
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256) void backtrace_chunks(DevProblem P, const BtUn
 	unsigned long long* stage = reinterpret_cast<unsigned long long*>(blob + BT_CHUNK_BLOB);
 	const uint32_t tid = threadIdx.x, n = P.n_cols;
 	if (mode == 0) {
-		const uint32_t ci = blockIdx.x / BT_ORIENT, o = blockIdx.x % BT_ORIENT;
+		const uint32_t ci = blockIdx.x / n_orient_max, o = blockIdx.x % n_orient_max;   // (the grid is n_chunks x the most orientations any chunk has)
 		const BtChunk ch = chunks[ci];
 		if (o >= ch.n_orient) return;
 		const BtUnit* __restrict__ cu = units + ch.unit_off;
