@@ -67,7 +67,7 @@ void plan_forward(const Problem& p, bool resident, int l_pref, bool fold, Reside
 	const bool single = p.T == 1 && p.n_ind == 1 && p.value_bound < 1073741824.0;
 	const bool ped = p.T == (uint32_t)PED_T && p.n_ind == (uint32_t)PED_NIND && p.n_triples == 1;
 	const bool eligible = resident && (single || ped);
-	if (ped && l_pref > 7) l_pref = 7;  // trio slices hold T values per entry and every entry is much more work (7 measured best)
+	if (ped && l_pref > 7) l_pref = 7;  // trio slices hold T values per entry and every entry is much more work (7 measured best: 8 -> 109 ms, 9 -> 154 ms forward on configs[3])  // trio slices hold T values per entry and every entry is much more work (7 measured best)
 	std::vector<uint32_t> last_col;
 	if (eligible) {
 		last_col.assign(p.n_reads, 0);
