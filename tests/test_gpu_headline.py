@@ -131,3 +131,37 @@ def test_unit_larger_than_the_arena_is_unsupported():
         t.solve()
     assert e.value.status == _native.WHAMD_ERR_UNSUPPORTED
     t.close()
+
+
+def test_full_size_trio_chunked_backtrace_equals_the_sequential_walk(monkeypatch):
+    """BASELINE configs[3] (trio, 100 000 columns, coverage 15) at full size: the chunked speculative backtrace (8 orientations
+    per chunk) and the sequential walk (WHAMD_BT_SEQUENTIAL, read when the table is uploaded) return the same cost, index path,
+    transmission vector, partitioning and superreads; so does a windowed solve."""
+    p = synthetic_block(n_variants=100000, coverage=15, seed=4, trio=True)
+    chunked = solve(p, "auto", "1")
+    monkeypatch.setenv("WHAMD_BT_SEQUENTIAL", "1")
+    sequential = solve(p, "auto", "1")
+    monkeypatch.delenv("WHAMD_BT_SEQUENTIAL")
+    assert chunked == sequential, first_difference(sequential, chunked)
+    windowed = solve(p, "auto", "1", arena_limit_bytes=1 << 30)
+    assert windowed == sequential, first_difference(sequential, windowed)
+
+
+def test_trio_with_many_recombination_events_chunked_vs_sequential_vs_oracle(monkeypatch):
+    """The benchmark's trio never recombines (constant transmission vector).  With a recombination cost of 1 the optimal path
+    switches transmission values all the time: the packed (index, transmission value) states, the transmission flips of the
+    orientations and the argj chain of the chunk walker are all exercised, against the sequential walk and the oracle."""
+    base = synthetic_block(n_variants=1400, coverage=12, seed=9, trio=True, error_rate=0.12)
+    p = _native.ProblemArrays(base.read_ptr, base.var_position, base.var_allele, base.var_quality, base.read_sample_id, base.individual_id,
+                              base.triple_ids, base.genotype.reshape(3, -1), None, np.ones_like(base.recombcost), base.positions, False,
+                              n_variants=base.n_variants)
+    want = table_solution(oracle.OracleTable(p))
+    assert len(set(want["transmission"])) > 1
+    switches = int(np.count_nonzero(np.diff(np.asarray(want["transmission"]))))
+    assert switches > 20, switches
+    chunked = solve(p, "auto", "1")
+    monkeypatch.setenv("WHAMD_BT_SEQUENTIAL", "1")
+    sequential = solve(p, "auto", "1")
+    monkeypatch.delenv("WHAMD_BT_SEQUENTIAL")
+    assert sequential == want, first_difference(want, sequential)
+    assert chunked == want, first_difference(want, chunked)
