@@ -298,13 +298,34 @@ __global__ __launch_bounds__(GENO_BLOCK) void geno_backward(GenoDev G, GenoCol C
 // Forward step of column c: reads A_{c-1} (`prev`, null for column 0) and B_c (`beta`, null for the last column), writes A_c
 // (`out`, null for the last column) with its per-block sums, and the per-block sums of the normalisation and of the genotype
 // likelihood numerators (gl_partials[block][1 + 3 * individuals]).
-template <int T>
-__global__ __launch_bounds__(GENO_BLOCK) void geno_forward(GenoDev G, GenoCol C, const double* __restrict__ prev, const double* __restrict__ prev_partials,
-                                                          uint32_t prev_blocks, const double* __restrict__ beta, const double* __restrict__ beta_partials,
-                                                          uint32_t beta_blocks, double* __restrict__ out, double* __restrict__ out_partials,
-                                                          double* __restrict__ gl_partials) {
+// MODE 0: all of it (windowed solve).  When every column fits in memory the forward chain runs BESIDE the backward chain
+// instead of after it (two streams, half as many dependent launches): MODE 1 writes A_c only, and MODE 2 -- one launch for
+// a batch of columns, blockIdx.y = column, arguments from a device array -- combines the stored A_{c-1} and B_c into the
+// likelihood sums (every column is independent there).
+struct GenoFwdArgs {
+	GenoCol C;
+	const double* prev; const double* prev_partials;
+	const double* beta; const double* beta_partials;
+	double* out; double* out_partials;
+	double* gl_partials;
+	uint32_t prev_blocks, beta_blocks, n_blocks, pad;
+};
+
+template <int T, int MODE>
+__global__ __launch_bounds__(GENO_BLOCK) void geno_forward(GenoDev G, GenoFwdArgs by_value, const GenoFwdArgs* __restrict__ batch) {
 	__shared__ GenoShared S;
 	extern __shared__ __attribute__((aligned(16))) double geno_tab[];
+	const GenoFwdArgs A = MODE == 2 ? batch[blockIdx.y] : by_value;
+	if (MODE == 2 && blockIdx.x >= A.n_blocks) return;
+	const GenoCol C = A.C;
+	const double* __restrict__ prev = A.prev;
+	const double* __restrict__ prev_partials = A.prev_partials;
+	const double* __restrict__ beta = MODE == 1 ? nullptr : A.beta;
+	const double* __restrict__ beta_partials = A.beta_partials;
+	double* __restrict__ out = MODE == 2 ? nullptr : A.out;
+	double* __restrict__ out_partials = A.out_partials;
+	double* __restrict__ gl_partials = A.gl_partials;
+	const uint32_t prev_blocks = A.prev_blocks, beta_blocks = A.beta_blocks;
 	const uint32_t k = C.k, b = C.b, f = C.f, fmask = C.fmask, loop_bits = C.loop_bits;   // (last column: f = 0, fmask = 0)
 	const double psum_prev = prev ? geno_partials_begin(prev_partials, prev_blocks) : 0.0;
 	const double psum_beta = beta ? geno_partials_begin(beta_partials, beta_blocks) : 0.0;
@@ -356,7 +377,7 @@ __global__ __launch_bounds__(GENO_BLOCK) void geno_forward(GenoDev G, GenoCol C,
 				if ((uint32_t)a < G.A) {
 					const double fw = sum_prev * geno_assignment_cost(W, G.P, (uint32_t)a) * S.prior[i * G.A + a];
 					acc += fw;
-					fa[a] += fw * bt;
+					if (MODE != 1) fa[a] += fw * bt;
 				}
 			}
 		}
@@ -372,6 +393,19 @@ __global__ __launch_bounds__(GENO_BLOCK) void geno_forward(GenoDev G, GenoCol C,
 			if (C.use_atomics) atomicAdd(out + (size_t)yf0 * T + i, acc);
 			else out[(size_t)yf0 * T + i] = acc;
 		}
+	}
+	if (MODE == 1) {   // A_c only: the per-block sum of what was written
+		double v = acc;
+		for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+		__syncthreads();
+		if ((threadIdx.x & 63u) == 0) S.red[threadIdx.x >> 6][0] = v;
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			double total = 0.0;
+			for (int w = 0; w < GENO_BLOCK / 64; ++w) total += S.red[w][0];
+			out_partials[blockIdx.x] = total;
+		}
+		return;
 	}
 	// marginalise this thread's assignments over the genotypes (src/genotypedptable.cpp:376-383), once per thread
 	double gl[GENO_MAXGL];
@@ -474,7 +508,7 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 	uint32_t K = window_hint;
 	if (!K) {
 		const double per_column = (double)buf_doubles * 8 + (double)max_blocks * 8 * (1 + n_gl);
-		K = per_column * n <= 0.25 * (double)free_b ? n : (uint32_t)std::ceil(std::sqrt((double)n));
+		K = 2.0 * per_column * n <= 0.4 * (double)free_b ? n : (uint32_t)std::ceil(std::sqrt((double)n));   // (backward AND forward columns kept)
 	}
 	K = std::max(1u, std::min(K, n));
 	st.window = K;
@@ -560,10 +594,10 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 	// ---- buffers: every column buffer carries its per-block sums
 	struct Buf { double* v = nullptr; double* partials = nullptr; uint32_t blocks = 0; };
 	Buf alpha[2], pp[2];
-	std::vector<Buf> ckpt(n_windows), wstore(K);
+	std::vector<Buf> ckpt(n_windows), wstore(K), astore(n_windows == 1 ? K : 0);   // astore: the forward columns of the two-chain mode
 	{
 		// one slab for all of them (tens of thousands of hipMalloc calls would take seconds)
-		const size_t count = 4 + (size_t)n_windows + K;
+		const size_t count = 4 + (size_t)n_windows + K + astore.size();
 		double *slab_v = nullptr, *slab_p = nullptr;
 		GENO_DEV(alloc((void**)&slab_v, count * buf_doubles * 8));
 		GENO_DEV(alloc((void**)&slab_p, count * (size_t)max_blocks * 8));
@@ -573,9 +607,10 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 		for (Buf& bf : pp) take(bf);
 		for (Buf& bf : ckpt) take(bf);
 		for (Buf& bf : wstore) take(bf);
+		for (Buf& bf : astore) take(bf);
 	}
 	double *d_glpart = nullptr, *d_gl = nullptr;
-	GENO_DEV(alloc((void**)&d_glpart, (size_t)K * max_blocks * n_gl * 8));
+	GENO_DEV(alloc((void**)&d_glpart, (size_t)std::min<uint32_t>(K, n_windows == 1 ? 1024u : K) * max_blocks * n_gl * 8));
 	GENO_DEV(alloc((void**)&d_gl, gl_out.size() * 8));
 	hipEvent_t ev[3];
 	for (hipEvent_t& e : ev) GENO_DEV(hipEventCreate(&e));
@@ -611,6 +646,83 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 		}
 	}
 	GENO_DEV(hipEventRecord(ev[1], stream));
+	auto fwd_args = [&](uint32_t c, const Buf* prev_alpha, const Buf* beta, Buf* out, double* glp) {
+		const bool last = c + 1 == n;
+		const uint32_t fc = last ? 0u : p.f[c], fm = last ? 0u : p.fwd_mask[c];
+		const uint32_t atomics = (!last && out && (uint32_t)p.k[c] - fc > GENO_LOOP_BITS) ? 1u : 0u;
+		GenoFwdArgs a{};
+		a.C = GenoCol{c, p.k[c], p.b[c], fc, fm, std::min<uint32_t>((uint32_t)p.k[c] - fc, GENO_LOOP_BITS), atomics, 0u};
+		a.prev = prev_alpha ? prev_alpha->v : nullptr; a.prev_partials = prev_alpha ? prev_alpha->partials : nullptr;
+		a.prev_blocks = prev_alpha ? prev_alpha->blocks : 0u;
+		a.beta = beta ? beta->v : nullptr; a.beta_partials = beta ? beta->partials : nullptr; a.beta_blocks = beta ? beta->blocks : 0u;
+		a.out = (last || !out) ? nullptr : out->v; a.out_partials = out ? out->partials : nullptr;
+		a.gl_partials = glp;
+		a.n_blocks = fw_blocks[c];
+		return a;
+	};
+	auto launch_forward = [&](const GenoFwdArgs& a, int mode, hipStream_t on) -> hipError_t {
+		if (a.C.use_atomics) { hipError_t e = hipMemsetAsync(a.out, 0, ((size_t)T << a.C.f) * 8, on); if (e != hipSuccess) return e; }
+		const dim3 grid(a.n_blocks), block(GENO_BLOCK);
+#define GENO_FWD(TT) do { if (mode == 0) hipLaunchKernelGGL((geno_forward<TT, 0>), grid, block, table_bytes, on, G, a, (const GenoFwdArgs*)nullptr); \
+		                     else hipLaunchKernelGGL((geno_forward<TT, 1>), grid, block, table_bytes, on, G, a, (const GenoFwdArgs*)nullptr); } while (0)
+		if (T == 1) GENO_FWD(1); else if (T == 4) GENO_FWD(4); else GENO_FWD(16);
+#undef GENO_FWD
+		++launches;
+		return hipGetLastError();
+	};
+	if (n_windows == 1) {
+		// ---- everything fits: the backward chain (this stream) and the forward chain of the A columns (a second stream) run side
+		// by side -- they meet only in the likelihood sums, which one batched launch per 1024 columns computes afterwards
+		hipStream_t stream2 = nullptr;
+		GENO_DEV(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+		hipEvent_t ev_start, ev_fwd;
+		GENO_DEV(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
+		GENO_DEV(hipEventCreateWithFlags(&ev_fwd, hipEventDisableTiming));
+		GENO_DEV(hipEventRecord(ev_start, stream));
+		GENO_DEV(hipStreamWaitEvent(stream2, ev_start, 0));   // (uploads happened on `stream`)
+		// interleave the submissions so that neither hardware queue runs dry
+		uint32_t cb = n - 1, cf = 0;
+		while (cb >= 1 || cf + 1 < n) {
+			if (cb >= 1) {
+				GENO_DEV(backward(cb, cb == n - 1 ? nullptr : &wstore[cb], wstore[cb - 1]));
+				--cb;
+			}
+			if (cf + 1 < n) {
+				astore[cf].blocks = fw_blocks[cf];
+				GENO_DEV(launch_forward(fwd_args(cf, cf ? &astore[cf - 1] : nullptr, nullptr, &astore[cf], nullptr), 1, stream2));
+				++cf;
+			}
+		}
+		GENO_DEV(hipEventRecord(ev_fwd, stream2));
+		GENO_DEV(hipStreamWaitEvent(stream, ev_fwd, 0));
+		GENO_DEV(hipEventRecord(ev[1], stream));
+		constexpr uint32_t BATCH = 1024;
+		std::vector<GenoFwdArgs> batch(n);
+		for (uint32_t c = 0; c < n; ++c)
+			batch[c] = fwd_args(c, c ? &astore[c - 1] : nullptr, c + 1 < n ? &wstore[c] : nullptr, nullptr, d_glpart + (size_t)(c % BATCH) * max_blocks * n_gl);
+		void* d_batch = nullptr;
+		GENO_DEV(up(&d_batch, batch.data(), batch.size() * sizeof(GenoFwdArgs)));
+		for (uint32_t c0 = 0; c0 < n; c0 += BATCH) {
+			const uint32_t cols = std::min(BATCH, n - c0);
+			uint32_t gx = 1;
+			for (uint32_t c = c0; c < c0 + cols; ++c) gx = std::max(gx, fw_blocks[c]);
+			const dim3 grid(gx, cols), block(GENO_BLOCK);
+			const GenoFwdArgs none{};
+			const GenoFwdArgs* bp = (const GenoFwdArgs*)d_batch + c0;
+			if (T == 1) hipLaunchKernelGGL((geno_forward<1, 2>), grid, block, table_bytes, stream, G, none, bp);
+			else if (T == 4) hipLaunchKernelGGL((geno_forward<4, 2>), grid, block, table_bytes, stream, G, none, bp);
+			else hipLaunchKernelGGL((geno_forward<16, 2>), grid, block, table_bytes, stream, G, none, bp);
+			++launches;
+			GENO_DEV(hipGetLastError());
+			hipLaunchKernelGGL(geno_finish, dim3(cols), dim3(64), 0, stream, d_glpart, (const uint32_t*)d_fwb, c0, max_blocks, ni, n, d_gl);
+			++launches;
+			GENO_DEV(hipGetLastError());
+		}
+		GENO_DEV(hipStreamSynchronize(stream));
+		(void)hipEventDestroy(ev_start);
+		(void)hipEventDestroy(ev_fwd);
+		(void)hipStreamDestroy(stream2);
+	} else {
 	// ---- windows: recompute the backward columns of the window, then the forward pass through it
 	uint32_t aflip = 0;
 	const Buf* prev_alpha = nullptr;
@@ -623,31 +735,16 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 		}
 		for (uint32_t c = lo; c < hi; ++c) {
 			const Buf* beta = c == hi - 1 ? last_beta : &wstore[c - lo];
-			const bool last = c + 1 == n;
 			Buf& out = alpha[aflip];
-			const uint32_t blocks = fw_blocks[c];
-			const uint32_t atomics = (!last && (uint32_t)p.k[c] - p.f[c] > GENO_LOOP_BITS) ? 1u : 0u;
-			if (atomics) GENO_DEV(hipMemsetAsync(out.v, 0, ((size_t)T << p.f[c]) * 8, stream));
-			out.blocks = blocks;
-			double* glp = d_glpart + (size_t)(c - lo) * max_blocks * n_gl;
-			const double *pv = prev_alpha ? prev_alpha->v : nullptr, *ppart = prev_alpha ? prev_alpha->partials : nullptr;
-			const uint32_t pb = prev_alpha ? prev_alpha->blocks : 0u;
-			const double *bv = beta ? beta->v : nullptr, *bpart = beta ? beta->partials : nullptr;
-			const uint32_t bb = beta ? beta->blocks : 0u;
-			double* ov = last ? nullptr : out.v;
-			const uint32_t fc = last ? 0u : p.f[c], fm = last ? 0u : p.fwd_mask[c];
-			const GenoCol C{c, p.k[c], p.b[c], fc, fm, std::min<uint32_t>((uint32_t)p.k[c] - fc, GENO_LOOP_BITS), atomics, 0u};
-			if (T == 1) hipLaunchKernelGGL(geno_forward<1>, dim3(blocks), dim3(GENO_BLOCK), table_bytes, stream, G, C, pv, ppart, pb, bv, bpart, bb, ov, out.partials, glp);
-			else if (T == 4) hipLaunchKernelGGL(geno_forward<4>, dim3(blocks), dim3(GENO_BLOCK), table_bytes, stream, G, C, pv, ppart, pb, bv, bpart, bb, ov, out.partials, glp);
-			else hipLaunchKernelGGL(geno_forward<16>, dim3(blocks), dim3(GENO_BLOCK), table_bytes, stream, G, C, pv, ppart, pb, bv, bpart, bb, ov, out.partials, glp);
-			++launches;
-			GENO_DEV(hipGetLastError());
+			out.blocks = fw_blocks[c];
+			GENO_DEV(launch_forward(fwd_args(c, prev_alpha, beta, &out, d_glpart + (size_t)(c - lo) * max_blocks * n_gl), 0, stream));
 			prev_alpha = &out;
 			aflip ^= 1u;
 		}
 		hipLaunchKernelGGL(geno_finish, dim3(hi - lo), dim3(64), 0, stream, d_glpart, (const uint32_t*)d_fwb, lo, max_blocks, ni, n, d_gl);
 		++launches;
 		GENO_DEV(hipGetLastError());
+	}
 	}
 	GENO_DEV(hipEventRecord(ev[2], stream));
 	if (getenv("WHAMD_DEBUG_TIMING")) {
