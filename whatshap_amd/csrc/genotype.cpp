@@ -3,7 +3,6 @@
 #include "genotype.h"
 
 #include <cmath>
-#include <map>
 
 namespace whamd {
 
@@ -21,10 +20,12 @@ whamd_status_t build_genotype_model(const Problem& p, GenotypeModel& m, std::str
 	}
 	// ---- error probabilities of the column entries (get_phred_probability, src/genotypecolumncostcomputer.cpp:26-48)
 	m.error_prob.resize(p.entries.size());
+	double small[256];   // (the reference keeps the same table, :27-35)
+	small[0] = (double)0.9999L;
+	for (int q = 1; q < 256; ++q) small[q] = (double)powl(10.0L, -(long double)q / 10.0L);
 	for (size_t e = 0; e < p.entries.size(); ++e) {
 		const uint32_t q = p.entries[e].phred;
-		const long double pr = q == 0 ? 0.9999L : (q < 256 ? powl(10.0L, -(long double)q / 10.0L) : powl(10.0L, -(long double)(int)q / 10.0L));
-		m.error_prob[e] = (double)pr;
+		m.error_prob[e] = q < 256 ? small[q] : (double)powl(10.0L, -(long double)(int)q / 10.0L);
 	}
 	// ---- genotype of every individual under (transmission value, allele assignment)
 	m.genotype_index.assign((size_t)T * A * std::max<uint32_t>(ni, 1), 0);
@@ -62,7 +63,7 @@ whamd_status_t build_genotype_model(const Problem& p, GenotypeModel& m, std::str
 						return WHAMD_ERR_INVALID;   // the reference asserts gls != nullptr (:66)
 					}
 			for (uint32_t i = 0; i < T; ++i) {
-				std::map<uint32_t, uint32_t> count;
+				uint32_t count[81] = {0};   // genotype vectors in base 3: at most 4 individuals (P <= 4)
 				for (uint32_t a = 0; a < A; ++a) {
 					long double pr = 1.0L;
 					uint32_t k = 0;
