@@ -165,3 +165,15 @@ def test_trio_with_many_recombination_events_chunked_vs_sequential_vs_oracle(mon
     monkeypatch.delenv("WHAMD_BT_SEQUENTIAL")
     assert sequential == want, first_difference(want, sequential)
     assert chunked == want, first_difference(want, chunked)
+
+
+@pytest.mark.parametrize("kw", [dict(n_variants=1200, coverage=9, seed=61, trio=True, distrust_genotypes=True),
+                                dict(n_variants=1500, coverage=12, seed=62, trio=True, step=3),
+                                dict(n_variants=900, coverage=6, seed=63, trio=True, error_rate=0.2, drop_rate=0.3)], ids=str)
+def test_trio_tables_long_enough_for_chunks_vs_oracle(kw):
+    """Trio tables of several dozen runs (the chunked backtrace with its eight orientations is on) against the oracle:
+    distrusted genotypes (more terms than registers: the pool path), a step-3 read layout, noisy data with many BLANK entries."""
+    p = synthetic_block(**kw)
+    want = table_solution(oracle.OracleTable(p))
+    got = solve(p, "auto", "1")
+    assert got == want, first_difference(want, got)
