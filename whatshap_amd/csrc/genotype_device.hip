@@ -61,6 +61,8 @@ struct GenoDev {
 	const uint8_t* gidx;     // [T][A][n_ind]
 	const int8_t* h2p;       // [T][n_ind][2]
 	uint32_t T, A, P, n_ind, nb, n_cols;
+	const double* tables;     // lookup tables of every column, written once per solve by geno_tables (table_stride doubles per column)
+	uint32_t table_stride, pad_t;
 	// Product slots: founders first, in partition order (slot p = the haplotype that IS partition p), then the two
 	// haplotypes of every child.  slot_of[individual * 2 + haplotype]; child_part[i][q] = partition child slot q joins under
 	// transmission value i.
@@ -108,36 +110,52 @@ constexpr uint32_t GENO_GROUP_BITS = 7;      // reads per lookup table
 constexpr uint32_t GENO_GROUP = 1u << GENO_GROUP_BITS;
 constexpr int GENO_MAXSLOTS = 8;             // 2 * individuals (P <= 4: at most a quartet)
 
-// Lookup tables of the column in LDS: for every group of 7 reads and every setting of their bits, the product over the
+// Lookup tables of a column (global memory, geno_tables): for every group of 7 reads and every setting of their bits, the product over the
 // group's reads of the emission factors, per product slot and allele:  tab[(group * 128 + bits) * E + slot * 2 + allele],
 // E = 4 * individuals.  A read r with bit b belongs to haplotype b ^ 1 of its individual (bit 0 <-> "entry_in_partition1",
 // src/genotypecolumncostcomputer.cpp:61) and contributes (allele == allele_r ? 1 - e_r : e_r).
-__device__ __forceinline__ void geno_build_tables(const GenoDev& G, const GenoShared& S, uint32_t k, double* tab) {
+// One launch for ALL columns (blockIdx.y = column): building a column's tables inside its own step kernel cost 2.9 us of
+// every 10.7 us dependent launch; here it is a few hundred microseconds of fully parallel work per solve.
+__global__ __launch_bounds__(GENO_BLOCK) void geno_tables(GenoDev G, double* __restrict__ tables) {
+	const uint32_t c = blockIdx.y, k = G.k[c];
 	const uint32_t E = 4u * G.n_ind, groups = (k + GENO_GROUP_BITS - 1u) / GENO_GROUP_BITS;
-	for (uint32_t idx = threadIdx.x; idx < groups * GENO_GROUP; idx += GENO_BLOCK) {
-		double v[GENO_MAXSLOTS][2];   // the entry in registers: static indices, the slot of a read is matched with selects
+	const uint32_t idx = blockIdx.x * GENO_BLOCK + threadIdx.x;
+	if (idx >= groups * GENO_GROUP) return;
+	const uint64_t e0 = G.col_ptr[c];
+	double v[GENO_MAXSLOTS][2];   // the entry in registers: static indices, the slot of a read is matched with selects
 #pragma unroll
-		for (int q = 0; q < GENO_MAXSLOTS; ++q) v[q][0] = v[q][1] = 1.0;
-		const uint32_t g = idx >> GENO_GROUP_BITS, bits = idx & (GENO_GROUP - 1u);
+	for (int q = 0; q < GENO_MAXSLOTS; ++q) v[q][0] = v[q][1] = 1.0;
+	const uint32_t g = idx >> GENO_GROUP_BITS, bits = idx & (GENO_GROUP - 1u);
 #pragma unroll
-		for (uint32_t jj = 0; jj < GENO_GROUP_BITS; ++jj) {
-			const uint32_t j = g * GENO_GROUP_BITS + jj;
-			const uint32_t al = j < k ? S.allele[j] : 2u;
-			const uint32_t hap = ((bits >> jj) & 1u) ^ 1u;
-			const uint32_t slot = al > 1u ? 0xFFu : (uint32_t)S.slot_of[S.ind[j < k ? j : 0u] * 2u + hap];   // BLANK: no slot
-			const double pe = S.pe[j < k ? j : 0u], ok = 1.0 - pe;
-			const double m0 = al == 0u ? ok : pe, m1 = al == 0u ? pe : ok;
+	for (uint32_t jj = 0; jj < GENO_GROUP_BITS; ++jj) {
+		const uint32_t j = g * GENO_GROUP_BITS + jj;
+		if (j >= k) break;
+		const uint32_t al = G.ent_allele[e0 + j];
+		if (al > 1u) continue;   // BLANK
+		const uint32_t key = (uint32_t)G.ent_ind[e0 + j] * 2u + (((bits >> jj) & 1u) ^ 1u);   // individual * 2 + haplotype
+		uint32_t slot = 0;
 #pragma unroll
-			for (int q = 0; q < GENO_MAXSLOTS; ++q) {
-				v[q][0] *= slot == (uint32_t)q ? m0 : 1.0;
-				v[q][1] *= slot == (uint32_t)q ? m1 : 1.0;
-			}
+		for (int q = 0; q < 2 * MAX_IND; ++q) slot = key == (uint32_t)q ? (uint32_t)G.slot_of[q] : slot;
+		const double pe = G.ent_pe[e0 + j], ok = 1.0 - pe;
+		const double m0 = al == 0u ? ok : pe, m1 = al == 0u ? pe : ok;
+#pragma unroll
+		for (int q = 0; q < GENO_MAXSLOTS; ++q) {
+			v[q][0] *= slot == (uint32_t)q ? m0 : 1.0;
+			v[q][1] *= slot == (uint32_t)q ? m1 : 1.0;
 		}
-		double* e = tab + (size_t)idx * E;
-#pragma unroll
-		for (int q = 0; q < GENO_MAXSLOTS; ++q)
-			if ((uint32_t)q * 2u < E) *reinterpret_cast<double2*>(e + q * 2) = make_double2(v[q][0], v[q][1]);
 	}
+	double* e = tables + (size_t)c * G.table_stride + (size_t)idx * E;
+#pragma unroll
+	for (int q = 0; q < GENO_MAXSLOTS; ++q)
+		if ((uint32_t)q * 2u < E) *reinterpret_cast<double2*>(e + q * 2) = make_double2(v[q][0], v[q][1]);
+}
+
+// The column's tables, global -> LDS: one coalesced copy in the same barrier phase as the staging of the column's reads
+__device__ __forceinline__ void geno_copy_tables(const GenoDev& G, uint32_t c, uint32_t k, double* lds) {
+	const uint32_t E = 4u * G.n_ind, groups = (k + GENO_GROUP_BITS - 1u) / GENO_GROUP_BITS;
+	const double2* __restrict__ src = reinterpret_cast<const double2*>(G.tables + (size_t)c * G.table_stride);
+	double2* dst = reinterpret_cast<double2*>(lds);
+	for (uint32_t i = threadIdx.x; i < groups * GENO_GROUP * E / 2u; i += GENO_BLOCK) dst[i] = src[i];
 }
 
 // V[slot][allele] of one cell: the product of its groups' table entries
@@ -250,19 +268,17 @@ __global__ __launch_bounds__(GENO_BLOCK) void geno_backward(GenoDev G, GenoCol C
 		beta_raw[e] = 1.0;
 		if (in && active && e < (1u << loop_bits)) beta_raw[e] = in[(size_t)geno_pext(y | (((chunk << loop_bits) | e) << b), fmask) * T + i];
 	}
+	geno_copy_tables(G, C.c, k, geno_tab);
 	geno_stage(G, C.c, k, S);
-	__syncthreads();
-	geno_build_tables(G, S, k, geno_tab);
 	__syncthreads();
 	double partial = 0.0;   // sum over this thread's cells of beta * sum_a prior * cost, for its transmission value i
 	if (active) {
 #pragma unroll
 		for (uint32_t e = 0; e < (1u << GENO_LOOP_BITS); ++e) {
 			if (e >= (1u << loop_bits)) break;
-			const uint32_t x = y | (((chunk << loop_bits) | e) << b);
 			const double beta = beta_raw[e];
 			double V[GENO_MAXSLOTS][2], W[4][2];
-			geno_cell_products(G, k, x, geno_tab, V);
+			geno_cell_products(G, k, y | (((chunk << loop_bits) | e) << b), geno_tab, V);
 			geno_partition_products(G, S, V, i, W);
 			double s = 0.0;
 			for (uint32_t a = 0; a < G.A; ++a) s += S.prior[i * G.A + a] * geno_assignment_cost(W, G.P, a);
@@ -348,21 +364,19 @@ __global__ __launch_bounds__(GENO_BLOCK) void geno_forward(GenoDev G, GenoFwdArg
 #pragma unroll
 		for (int j = 0; j < T; ++j) prev_raw[e][j] = use ? prev[(size_t)(x & ((1u << b) - 1u)) * T + j] : 0.0;
 	}
+	geno_copy_tables(G, C.c, k, geno_tab);
 	geno_stage(G, C.c, k, S);
-	__syncthreads();
-	geno_build_tables(G, S, k, geno_tab);
 	__syncthreads();
 	double fa[GENO_MAXA];   // per allele assignment: sum over this thread's cells of forward * backward (its transmission value)
 #pragma unroll
 	for (int a = 0; a < GENO_MAXA; ++a) fa[a] = 0.0;
 	double acc = 0.0;
 	if (active) {
-		const uint32_t chunk = chunk0, xf = xf0;
 		const double bt = bt_raw;
 #pragma unroll
 		for (uint32_t e = 0; e < (1u << GENO_LOOP_BITS); ++e) {
 			if (e >= (1u << loop_bits)) break;
-			const uint32_t x = xf | geno_pdep((chunk << loop_bits) | e, endmask);
+			const uint32_t x = xf0 | geno_pdep((chunk0 << loop_bits) | e, endmask);
 			double sum_prev = 1.0;
 			if (prev) {
 				sum_prev = 0.0;
@@ -514,7 +528,8 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 	st.window = K;
 	const uint32_t n_windows = (n + K - 1) / K;
 	{
-		const double need = (double)(buf_doubles * 8 + (size_t)max_blocks * 8) * (n_windows + K + 4.0) + (double)K * max_blocks * n_gl * 8 + (double)p.entries.size() * 10 + (double)n * (64 + 8.0 * T * m.A);
+		const double need = (double)(buf_doubles * 8 + (size_t)max_blocks * 8) * (n_windows + K + 4.0) + (double)K * max_blocks * n_gl * 8 + (double)p.entries.size() * 10 + (double)n * (64 + 8.0 * T * m.A)
+		                    + (double)n * ((max_k + GENO_GROUP_BITS - 1) / GENO_GROUP_BITS) * GENO_GROUP * 4 * ni * 8.0;
 		if (need + (double)(1ull << 30) > (double)free_b) {
 			msg = "genotyping buffers of " + std::to_string((uint64_t)(need / 1048576.0)) + " MiB do not fit in free HBM";
 			return WHAMD_ERR_UNSUPPORTED;
@@ -590,7 +605,13 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 		}
 		G.n_child_slots = child_slots;
 	}
-	const size_t table_bytes = (size_t)((max_k + GENO_GROUP_BITS - 1) / GENO_GROUP_BITS) * GENO_GROUP * 4 * ni * sizeof(double);
+	// lookup tables of all columns (geno_tables): one launch before the chains start
+	const uint32_t max_groups = (max_k + GENO_GROUP_BITS - 1) / GENO_GROUP_BITS;
+	G.table_stride = std::max(1u, max_groups) * GENO_GROUP * 4 * ni;
+	double* d_tables = nullptr;
+	GENO_DEV(alloc((void**)&d_tables, (size_t)n * G.table_stride * sizeof(double)));
+	G.tables = d_tables;
+	const size_t table_bytes = (size_t)G.table_stride * sizeof(double);   // the step kernels copy their column's tables into LDS
 	// ---- buffers: every column buffer carries its per-block sums
 	struct Buf { double* v = nullptr; double* partials = nullptr; uint32_t blocks = 0; };
 	Buf alpha[2], pp[2];
@@ -633,6 +654,11 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 	};
 	const auto t_enqueue0 = std::chrono::steady_clock::now();
 	GENO_DEV(hipEventRecord(ev[0], stream));
+	if (max_groups) {
+		hipLaunchKernelGGL(geno_tables, dim3((max_groups * GENO_GROUP + GENO_BLOCK - 1) / GENO_BLOCK, n), dim3(GENO_BLOCK), 0, stream, G, d_tables);
+		++launches;
+		GENO_DEV(hipGetLastError());
+	}
 	// ---- pass 1: B_{c-1} for c = n-1 .. 1, kept where c - 1 is the last column of a window (nothing to keep with one window)
 	if (n_windows > 1) {
 		const Buf* in = nullptr;
