@@ -288,6 +288,10 @@ whamd_status_t whamd_genotype_likelihoods(const whamd_readset_view* readset, con
                                           int device, uint32_t window, double* gl_out, size_t gl_capacity,
                                           whamd_genotype_stats* stats_out);
 
+/* whamd_genotype_likelihoods keeps its column store (tens of GB for long inputs) allocated between calls, one block per
+ * device, because mapping that much fresh device memory takes seconds; this returns the blocks that are not in use. */
+void whamd_release_caches(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -286,7 +286,7 @@ EXPORTED_SYMBOLS = [
     "whamd_dptable_get_super_reads", "whamd_dptable_get_optimal_partitioning", "whamd_dptable_get_index_path",
     "whamd_dptable_get_stats", "whamd_dptable_set_option", "whamd_read_sort_hash", "whamd_plan_summarize",
     "whamd_dptable_enqueue", "whamd_dptable_wait", "whamd_dptable_enqueue_many", "whamd_debug_emulate_slot_plan",
-    "whamd_readselection", "whamd_genotype_likelihoods",
+    "whamd_readselection", "whamd_genotype_likelihoods", "whamd_release_caches",
 ]
 
 
@@ -451,6 +451,12 @@ def genotype_likelihoods(problem: ProblemArrays, n_columns: int, device: int = 0
     _check(lib().whamd_genotype_likelihoods(a[0], a[1], a[2], a[3], a[5], a[6], C.c_int(int(device)), C.c_uint32(int(window)),
                                             _ptr(gl, C.c_double), C.c_size_t(max(gl.size, 1) if gl.size else 0), C.byref(stats)))
     return gl, stats.as_dict()
+
+
+def release_caches() -> None:
+    """whamd_release_caches: frees the device memory the genotyping path keeps between calls."""
+    lib().whamd_release_caches.restype = None
+    lib().whamd_release_caches()
 
 
 def read_sort_hash(name: str, source_id: int) -> int:

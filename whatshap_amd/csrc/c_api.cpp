@@ -476,4 +476,6 @@ whamd_status_t whamd_genotype_likelihoods(const whamd_readset_view* readset, con
 	return WHAMD_OK;
 }
 
+void whamd_release_caches(void) { genotype_release_cache(); }
+
 }  // extern "C"

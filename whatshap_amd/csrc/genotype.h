@@ -36,4 +36,7 @@ whamd_status_t build_genotype_model(const Problem& p, GenotypeModel& m, std::str
 whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, int device, uint32_t window_hint,
                                      std::vector<double>& gl_out, GenotypeStats& st, std::string& msg);
 
+// Frees the device memory genotype_solve_device keeps between calls (one column store per device).
+void genotype_release_cache();
+
 }  // namespace whamd

@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 
 #include "genotype.h"
 
@@ -486,6 +487,29 @@ uint32_t blocks_for(uint32_t k, uint32_t proj, uint32_t T) {   // grid of a colu
 
 }  // namespace
 
+// The column store (tens of GB) is kept between calls, one block per device: mapping that much fresh device memory took 3 - 4 s
+// in about one call out of four (hipMalloc right after the hipFree of the previous call), reusing the block costs nothing.
+// A call that finds the block in use (another thread) or too small allocates its own.  genotype_release_cache() frees them.
+namespace {
+struct SlabCache { void* ptr = nullptr; size_t bytes = 0; bool in_use = false; };
+SlabCache g_slab[16];
+std::mutex g_slab_mutex;
+}  // namespace
+
+void genotype_release_cache() {
+	std::lock_guard<std::mutex> lock(g_slab_mutex);
+	int current = 0;
+	(void)hipGetDevice(&current);
+	for (int d = 0; d < 16; ++d) {
+		if (g_slab[d].ptr && !g_slab[d].in_use) {
+			(void)hipSetDevice(d);
+			(void)hipFree(g_slab[d].ptr);
+			g_slab[d] = SlabCache();
+		}
+	}
+	(void)hipSetDevice(current);
+}
+
 whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, int device, uint32_t window_hint,
                                      std::vector<double>& gl_out, GenotypeStats& st, std::string& msg) {
 	const uint32_t n = p.n_cols, T = p.T, ni = p.n_ind;
@@ -517,6 +541,10 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 	const uint32_t n_gl = 1 + 3 * ni;
 	size_t free_b = 0, total_b = 0;
 	GENO_TRY(hipMemGetInfo(&free_b, &total_b));
+	{   // the block kept from an earlier call is available to this one
+		std::lock_guard<std::mutex> lock(g_slab_mutex);
+		if (device < 16 && !g_slab[device].in_use) free_b += g_slab[device].bytes;
+	}
 	// Window = how many backward columns are kept at once.  If all of them fit in a quarter of the free memory there is one
 	// window and no column is computed twice; otherwise the reference's scheme: sqrt(n) kept columns, the rest recomputed.
 	uint32_t K = window_hint;
@@ -535,11 +563,18 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 			return WHAMD_ERR_UNSUPPORTED;
 		}
 	}
+	const auto t_phase0 = std::chrono::steady_clock::now();
+	auto phase_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_phase0).count(); };
 	hipStream_t stream = nullptr;
 	GENO_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
 	std::vector<void*> allocations;
+	bool slab_from_cache = false;
 	auto cleanup = [&]() {
 		for (void* a : allocations) (void)hipFree(a);
+		if (slab_from_cache) {
+			std::lock_guard<std::mutex> lock(g_slab_mutex);
+			g_slab[device].in_use = false;
+		}
 		if (stream) (void)hipStreamDestroy(stream);
 	};
 	auto fail = [&](hipError_t e, const char* what) {
@@ -620,7 +655,21 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 		// one slab for all of them (tens of thousands of hipMalloc calls would take seconds)
 		const size_t count = 4 + (size_t)n_windows + K + astore.size();
 		double *slab_v = nullptr, *slab_p = nullptr;
-		GENO_DEV(alloc((void**)&slab_v, count * buf_doubles * 8));
+		{
+			const size_t want = count * buf_doubles * 8;
+			std::lock_guard<std::mutex> lock(g_slab_mutex);
+			SlabCache& sc = g_slab[device < 16 ? device : 0];
+			if (device < 16 && !sc.in_use && !getenv("WHAMD_GENOTYPE_NO_CACHE")) {
+				if (sc.bytes < want) {
+					if (sc.ptr) (void)hipFree(sc.ptr);
+					sc = SlabCache();
+					if (hipMalloc(&sc.ptr, want) == hipSuccess) sc.bytes = want;
+					else { sc = SlabCache(); (void)hipGetLastError(); }
+				}
+				if (sc.ptr) { sc.in_use = true; slab_from_cache = true; slab_v = (double*)sc.ptr; }
+			}
+		}
+		if (!slab_v) GENO_DEV(alloc((void**)&slab_v, count * buf_doubles * 8));
 		GENO_DEV(alloc((void**)&slab_p, count * (size_t)max_blocks * 8));
 		size_t next = 0;
 		auto take = [&](Buf& bf) { bf.v = slab_v + next * buf_doubles; bf.partials = slab_p + next * max_blocks; ++next; };
@@ -652,6 +701,7 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 		++launches;
 		return hipGetLastError();
 	};
+	const double ms_allocated = phase_ms();
 	const auto t_enqueue0 = std::chrono::steady_clock::now();
 	GENO_DEV(hipEventRecord(ev[0], stream));
 	if (max_groups) {
@@ -790,7 +840,11 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 	st.total_ms = ms02;
 	st.launches = launches;
 	for (hipEvent_t& e : ev) (void)hipEventDestroy(e);
+	const double ms_done = phase_ms();
 	cleanup();
+	if (getenv("WHAMD_DEBUG_TIMING"))
+		fprintf(stderr, "[whamd timing] genotype phases (wall): allocations + uploads %.1f ms, submission + device %.1f ms, freeing %.1f ms\n",
+		        ms_allocated, ms_done - ms_allocated, phase_ms() - ms_done);
 #undef GENO_DEV
 	return WHAMD_OK;
 }
