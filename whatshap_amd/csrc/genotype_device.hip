@@ -556,7 +556,7 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 	st.window = K;
 	const uint32_t n_windows = (n + K - 1) / K;
 	{
-		const double need = (double)(buf_doubles * 8 + (size_t)max_blocks * 8) * (n_windows + K + 4.0) + (double)K * max_blocks * n_gl * 8 + (double)p.entries.size() * 10 + (double)n * (64 + 8.0 * T * m.A)
+		const double need = (double)(buf_doubles * 8 + (size_t)max_blocks * 8) * (n_windows + 2.0 * K + 4.0) + (double)K * max_blocks * n_gl * 8 + (double)p.entries.size() * 10 + (double)n * (64 + 8.0 * T * m.A)
 		                    + (double)n * ((max_k + GENO_GROUP_BITS - 1) / GENO_GROUP_BITS) * GENO_GROUP * 4 * ni * 8.0;
 		if (need + (double)(1ull << 30) > (double)free_b) {
 			msg = "genotyping buffers of " + std::to_string((uint64_t)(need / 1048576.0)) + " MiB do not fit in free HBM";
@@ -650,10 +650,10 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 	// ---- buffers: every column buffer carries its per-block sums
 	struct Buf { double* v = nullptr; double* partials = nullptr; uint32_t blocks = 0; };
 	Buf alpha[2], pp[2];
-	std::vector<Buf> ckpt(n_windows), wstore(K), astore(n_windows == 1 ? K : 0);   // astore: the forward columns of the two-chain mode
+	std::vector<Buf> ckpt(n_windows), wstore(n_windows == 1 ? K : 2 * (size_t)K), astore(n_windows == 1 ? K : 0);   // windowed: two halves, recompute of window w + 1 beside the forward pass of window w   // astore: the forward columns of the two-chain mode
 	{
 		// one slab for all of them (tens of thousands of hipMalloc calls would take seconds)
-		const size_t count = 4 + (size_t)n_windows + K + astore.size();
+		const size_t count = 4 + (size_t)n_windows + wstore.size() + astore.size();
 		double *slab_v = nullptr, *slab_p = nullptr;
 		{
 			const size_t want = count * buf_doubles * 8;
@@ -686,18 +686,19 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 	for (hipEvent_t& e : ev) GENO_DEV(hipEventCreate(&e));
 	uint64_t launches = 0;
 	// one backward step: column c, B_c in `in` (null: last column) -> B_{c-1} in `out`
-	auto backward = [&](uint32_t c, const Buf* in, Buf& out) -> hipError_t {
+	auto backward = [&](uint32_t c, const Buf* in, Buf& out, hipStream_t on = nullptr) -> hipError_t {
+		if (!on) on = stream;
 		const uint32_t blocks = bw_blocks[c];
 		const uint32_t atomics = (uint32_t)p.k[c] - p.b[c] > GENO_LOOP_BITS ? 1u : 0u;
 		const GenoCol C{c, p.k[c], p.b[c], p.f[c], p.fwd_mask[c], std::min<uint32_t>((uint32_t)p.k[c] - p.b[c], GENO_LOOP_BITS), atomics, 0u};
-		if (atomics) { hipError_t e = hipMemsetAsync(out.v, 0, ((size_t)T << p.b[c]) * 8, stream); if (e != hipSuccess) return e; }
+		if (atomics) { hipError_t e = hipMemsetAsync(out.v, 0, ((size_t)T << p.b[c]) * 8, on); if (e != hipSuccess) return e; }
 		out.blocks = blocks;
 		const double* iv = in ? in->v : nullptr;
 		const double* ip = in ? in->partials : nullptr;
 		const uint32_t ib = in ? in->blocks : 0u;
-		if (T == 1) hipLaunchKernelGGL(geno_backward<1>, dim3(blocks), dim3(GENO_BLOCK), table_bytes, stream, G, C, iv, ip, ib, out.v, out.partials);
-		else if (T == 4) hipLaunchKernelGGL(geno_backward<4>, dim3(blocks), dim3(GENO_BLOCK), table_bytes, stream, G, C, iv, ip, ib, out.v, out.partials);
-		else hipLaunchKernelGGL(geno_backward<16>, dim3(blocks), dim3(GENO_BLOCK), table_bytes, stream, G, C, iv, ip, ib, out.v, out.partials);
+		if (T == 1) hipLaunchKernelGGL(geno_backward<1>, dim3(blocks), dim3(GENO_BLOCK), table_bytes, on, G, C, iv, ip, ib, out.v, out.partials);
+		else if (T == 4) hipLaunchKernelGGL(geno_backward<4>, dim3(blocks), dim3(GENO_BLOCK), table_bytes, on, G, C, iv, ip, ib, out.v, out.partials);
+		else hipLaunchKernelGGL(geno_backward<16>, dim3(blocks), dim3(GENO_BLOCK), table_bytes, on, G, C, iv, ip, ib, out.v, out.partials);
 		++launches;
 		return hipGetLastError();
 	};
@@ -799,18 +800,41 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 		(void)hipEventDestroy(ev_fwd);
 		(void)hipStreamDestroy(stream2);
 	} else {
-	// ---- windows: recompute the backward columns of the window, then the forward pass through it
+	// ---- windows: the backward columns of window w + 1 are recomputed on a second stream (into the other half of the window
+	// store) while the forward pass runs through window w
+	hipStream_t stream2 = nullptr;
+	GENO_DEV(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+	hipEvent_t ev_back[2], ev_fwd[2], ev_pass1;
+	for (hipEvent_t& e : ev_back) GENO_DEV(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+	for (hipEvent_t& e : ev_fwd) GENO_DEV(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+	GENO_DEV(hipEventCreateWithFlags(&ev_pass1, hipEventDisableTiming));
+	GENO_DEV(hipEventRecord(ev_pass1, stream));
+	GENO_DEV(hipStreamWaitEvent(stream2, ev_pass1, 0));   // the kept columns (and the uploads) are complete
+	auto recompute = [&](uint32_t w) -> hipError_t {      // B_c for the columns of window w but its last, on stream2
+		const uint32_t lo = w * K, hi = std::min(n, lo + K);
+		Buf* half = wstore.data() + (size_t)(w & 1u) * K;
+		const Buf* last_beta = hi == n ? nullptr : &ckpt[w];   // B_{hi-1}
+		for (uint32_t c = hi - 1; c > lo; --c) {
+			const Buf* in = c == hi - 1 ? last_beta : &half[c - lo];
+			hipError_t e = backward(c, in, half[c - 1 - lo], stream2);
+			if (e != hipSuccess) return e;
+		}
+		return hipEventRecord(ev_back[w & 1u], stream2);
+	};
+	GENO_DEV(recompute(0));
 	uint32_t aflip = 0;
 	const Buf* prev_alpha = nullptr;
 	for (uint32_t w = 0; w < n_windows; ++w) {
 		const uint32_t lo = w * K, hi = std::min(n, lo + K);
-		const Buf* last_beta = hi == n ? nullptr : &ckpt[w];   // B_{hi-1}
-		for (uint32_t c = hi - 1; c > lo; --c) {
-			const Buf* in = c == hi - 1 ? last_beta : &wstore[c - lo];
-			GENO_DEV(backward(c, in, wstore[c - 1 - lo]));
+		const Buf* half = wstore.data() + (size_t)(w & 1u) * K;
+		const Buf* last_beta = hi == n ? nullptr : &ckpt[w];
+		GENO_DEV(hipStreamWaitEvent(stream, ev_back[w & 1u], 0));
+		if (w + 1 < n_windows) {
+			if (w >= 1) GENO_DEV(hipStreamWaitEvent(stream2, ev_fwd[(w - 1) & 1u], 0));   // the forward pass of window w - 1 is done with that half
+			GENO_DEV(recompute(w + 1));
 		}
 		for (uint32_t c = lo; c < hi; ++c) {
-			const Buf* beta = c == hi - 1 ? last_beta : &wstore[c - lo];
+			const Buf* beta = c == hi - 1 ? last_beta : &half[c - lo];
 			Buf& out = alpha[aflip];
 			out.blocks = fw_blocks[c];
 			GENO_DEV(launch_forward(fwd_args(c, prev_alpha, beta, &out, d_glpart + (size_t)(c - lo) * max_blocks * n_gl), 0, stream));
@@ -820,7 +844,14 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 		hipLaunchKernelGGL(geno_finish, dim3(hi - lo), dim3(64), 0, stream, d_glpart, (const uint32_t*)d_fwb, lo, max_blocks, ni, n, d_gl);
 		++launches;
 		GENO_DEV(hipGetLastError());
+		GENO_DEV(hipEventRecord(ev_fwd[w & 1u], stream));
 	}
+	GENO_DEV(hipStreamSynchronize(stream));
+	GENO_DEV(hipStreamSynchronize(stream2));
+	for (hipEvent_t& e : ev_back) (void)hipEventDestroy(e);
+	for (hipEvent_t& e : ev_fwd) (void)hipEventDestroy(e);
+	(void)hipEventDestroy(ev_pass1);
+	(void)hipStreamDestroy(stream2);
 	}
 	GENO_DEV(hipEventRecord(ev[2], stream));
 	if (getenv("WHAMD_DEBUG_TIMING")) {
