@@ -73,3 +73,20 @@ def test_restatement_equals_the_committed_golden_vectors():
         assert np.allclose(got, want, rtol=1e-12, atol=1e-15), name
         n += 1
     assert n == 6
+
+
+def test_device_path_fails_loudly_without_a_gpu_and_checks_its_input_first():
+    """No CPU fallback: with valid input and no visible device the C ABI reports WHAMD_ERR_DEVICE; missing priors are an input
+    error before any device is touched (the reference asserts them, src/transitionprobabilitycomputer.cpp:66)."""
+    from whatshap_amd import _native
+
+    p = _matrix_problem(["11", " 01"])
+    if _native.device_count() == 0:
+        with pytest.raises(_native.SolverError) as e:
+            _native.genotype_likelihoods(p, 3)
+        assert e.value.status == _native.WHAMD_ERR_DEVICE and "no CPU fallback" in str(e.value)
+    no_priors = _native.ProblemArrays(p.read_ptr, p.var_position, p.var_allele, p.var_quality, p.read_sample_id, p.individual_id, p.triple_ids,
+                                      p.genotype.reshape(1, -1), None, p.recombcost, None, False, n_variants=p.n_variants)
+    with pytest.raises(_native.SolverError) as e:
+        _native.genotype_likelihoods(no_priors, 3)
+    assert e.value.status == _native.WHAMD_ERR_INVALID and "priors" in str(e.value)
