@@ -246,6 +246,17 @@ whamd_status_t whamd_debug_emulate_slot_plan(const whamd_readset_view* readset, 
                                             const uint32_t* positions, size_t n_positions, int slot_l, int symmetry,
                                             uint32_t* index_out, uint32_t* score_out, uint64_t* n_run_columns_out);
 
+/* The same diagnostic for a pedigree table with one or two trios (T = 4 / 16): the pedigree slot plan (one (cell,
+ * transmission value) per lane, cost forms split into per-workgroup / per-wave / per-lane tables, butterfly min-plus
+ * step, one record byte per lane and column) executed on the CPU as kernels_pedslots.h does it.  slot_l <= 0: the
+ * default number of local slots, else that many.  transmission_out[n_columns]: index_path[c].inheritance_value.
+ * WHAMD_ERR_UNSUPPORTED when the table is not eligible for pedigree slot runs. */
+whamd_status_t whamd_debug_emulate_pedslot_plan(const whamd_readset_view* readset, const uint32_t* recombcost, size_t n_recombcost,
+                                               const whamd_pedigree_view* pedigree, int distrust_genotypes,
+                                               const uint32_t* positions, size_t n_positions, int slot_l,
+                                               uint32_t* index_out, uint32_t* transmission_out, uint32_t* score_out,
+                                               uint64_t* n_run_columns_out);
+
 /* The tie-break hash of ReadSet::sort (src/readset.h:39-66,76-82): std::hash<std::string>(name) ^
  * std::hash<int>(source_id) of the libstdc++ this library is built against.  Used by the Python
  * mirror of ReadSet.sort(); not part of the DP path. */

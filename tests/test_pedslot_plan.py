@@ -1,0 +1,73 @@
+"""CPU: the pedigree slot plan (whatshap_amd/csrc/slot_plan.cpp on a table with one or two trios) checked against the
+oracle without a GPU.  `whamd_debug_emulate_pedslot_plan` executes the plan the way kernels_pedslots.h does -- cost forms
+split into per-workgroup / per-wave / per-lane tables, one (cell, transmission value) per lane, the butterfly min-plus
+step over the previous transmission value, pair decisions of the ending reads, one record byte per lane and column, the
+column-by-column walk -- and cost, index path and transmission path must equal the oracle's."""
+import random
+
+import numpy as np
+import pytest
+
+import oracle
+from whatshap_amd import _native
+from whatshap_amd.synthetic import random_small_instance, synthetic_block
+
+
+def agrees(problem, **kw):
+    o = oracle.OracleTable(problem)
+    want_idx, want_trans = o.index_path()
+    idx, trans, score, run_columns = _native.emulate_pedslot_plan(problem, o.n_columns, **kw)
+    ok = score == o.optimal_score() and bool((idx == want_idx).all()) and bool((trans == want_trans).all())
+    return ok, run_columns
+
+
+@pytest.mark.parametrize("mode", ["trio", "quartet"])
+def test_random_tie_heavy_instances(mode):
+    rng = random.Random(5 if mode == "trio" else 6)
+    eligible = with_runs = 0
+    for i in range(400):
+        p = random_small_instance(rng, mode=mode, allow_conflict=False)
+        try:
+            ok, run_columns = agrees(p, slot_l=0 if i % 2 else (4 if mode == "trio" else 2))
+        except _native.SolverError as e:
+            assert e.status == _native.WHAMD_ERR_UNSUPPORTED   # genotypes not trusted: more than 4 forms per value
+            continue
+        eligible += 1
+        with_runs += run_columns > 0
+        assert ok, i
+    assert eligible > 80 and with_runs > 80, (eligible, with_runs)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_synthetic_trio_blocks(seed):
+    for kw in (dict(coverage=7 + seed % 3), dict(coverage=8, step=1), dict(coverage=7, mixed_genotypes=True), dict(coverage=9, step=3)):
+        base = synthetic_block(n_variants=90, seed=seed, trio=True, **kw)
+        ties = _native.ProblemArrays(base.read_ptr, base.var_position, base.var_allele, (1 + (base.var_quality % 2)).astype(np.uint32),
+                                     base.read_sample_id, base.individual_id, base.triple_ids, base.genotype.reshape(base.individual_id.size, -1), base.genotype_likelihoods,
+                                     (base.recombcost % 3).astype(np.uint32), base.positions, base.distrust_genotypes, n_variants=base.n_variants)
+        for p in (base, ties):
+            for slot_l in (0, 5, 6):
+                ok, run_columns = agrees(p, slot_l=slot_l)
+                assert ok, (seed, kw, slot_l)
+                assert run_columns > 0.7 * p.n_variants, (kw, run_columns)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_synthetic_quartet_blocks(seed):
+    for kw in (dict(coverage=6 + seed), dict(coverage=7, mixed_genotypes=True)):
+        p = synthetic_block(n_variants=70, seed=10 + seed, quartet=True, **kw)
+        for slot_l in (0, 3):
+            ok, run_columns = agrees(p, slot_l=slot_l)
+            assert ok, (seed, kw, slot_l)
+            assert run_columns > 0.6 * p.n_variants, (kw, run_columns)
+
+
+def test_not_for_a_single_individual_or_untrusted_genotypes():
+    single = synthetic_block(n_variants=40, coverage=6, seed=1)
+    with pytest.raises(_native.SolverError) as e:
+        _native.emulate_pedslot_plan(single, 40)
+    assert e.value.status == _native.WHAMD_ERR_UNSUPPORTED
+    distrust = synthetic_block(n_variants=40, coverage=6, seed=1, trio=True, distrust_genotypes=True)
+    with pytest.raises(_native.SolverError) as e:
+        _native.emulate_pedslot_plan(distrust, 40)
+    assert e.value.status == _native.WHAMD_ERR_UNSUPPORTED

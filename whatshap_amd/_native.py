@@ -260,6 +260,11 @@ def lib() -> C.CDLL:
         C.POINTER(ReadSetView), C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(PedigreeView), C.c_int,
         C.POINTER(C.c_uint32), C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
     ]
+    L.whamd_debug_emulate_pedslot_plan.restype = C.c_int
+    L.whamd_debug_emulate_pedslot_plan.argtypes = [
+        C.POINTER(ReadSetView), C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(PedigreeView), C.c_int,
+        C.POINTER(C.c_uint32), C.c_size_t, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
+    ]
     L.whamd_read_sort_hash.restype = C.c_uint64
     L.whamd_read_sort_hash.argtypes = [C.c_char_p, C.c_int]
     L.whamd_genotype_likelihoods.restype = C.c_int
@@ -286,6 +291,7 @@ EXPORTED_SYMBOLS = [
     "whamd_dptable_get_super_reads", "whamd_dptable_get_optimal_partitioning", "whamd_dptable_get_index_path",
     "whamd_dptable_get_stats", "whamd_dptable_set_option", "whamd_read_sort_hash", "whamd_plan_summarize",
     "whamd_dptable_enqueue", "whamd_dptable_wait", "whamd_dptable_enqueue_many", "whamd_debug_emulate_slot_plan",
+    "whamd_debug_emulate_pedslot_plan",
     "whamd_readselection", "whamd_genotype_likelihoods", "whamd_release_caches",
 ]
 
@@ -412,6 +418,18 @@ def emulate_slot_plan(problem: ProblemArrays, n_columns: int, slot_l: int = 11, 
     _check(lib().whamd_debug_emulate_slot_plan(*problem.call_args(), C.c_int(slot_l), C.c_int(symmetry), _ptr(idx, C.c_uint32),
                                                C.byref(score), C.byref(ncols)))
     return idx[:n_columns], int(score.value), int(ncols.value)
+
+
+def emulate_pedslot_plan(problem: ProblemArrays, n_columns: int, slot_l: int = 0):
+    """Host-only diagnostic of the pedigree slot plan (whamd_debug_emulate_pedslot_plan):
+    (index path, transmission path, optimal score, columns inside runs)."""
+    idx = np.zeros(max(n_columns, 1), dtype=np.uint32)
+    trans = np.zeros(max(n_columns, 1), dtype=np.uint32)
+    score = C.c_uint32()
+    ncols = C.c_uint64()
+    _check(lib().whamd_debug_emulate_pedslot_plan(*problem.call_args(), C.c_int(slot_l), _ptr(idx, C.c_uint32), _ptr(trans, C.c_uint32),
+                                                  C.byref(score), C.byref(ncols)))
+    return idx[:n_columns], trans[:n_columns], int(score.value), int(ncols.value)
 
 
 def device_count() -> int:

@@ -293,7 +293,7 @@ whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uin
 	const std::string mode(path ? path : "auto");
 	SlotPlan sp;
 	const double tp0 = now_ms();
-	const bool slots_ok = (mode == "auto" || mode == "slots") && plan_forward_slots(p, 11, 1, sp);
+	const bool slots_ok = (mode == "auto" || mode == "slots") && p.T == 1 && plan_forward_slots(p, 11, 1, sp);
 	if (getenv("WHAMD_DEBUG_TIMING")) fprintf(stderr, "[whamd timing] plan_summarize: build_problem %.1f ms, plan_forward_slots %.1f ms\n", tp0 - tb0, now_ms() - tp0);
 	if (slots_ok) {
 		// slot runs (slots.h): every column in exactly one step, runs within their limits, slots consistent
@@ -430,11 +430,33 @@ whamd_status_t whamd_debug_emulate_slot_plan(const whamd_readset_view* readset, 
 	                                  n_positions, p, msg);
 	if (st != WHAMD_OK) return fail(st, msg);
 	SlotPlan sp;
-	if (!plan_forward_slots(p, slot_l, symmetry, sp, lr)) return fail(WHAMD_ERR_UNSUPPORTED, "slot runs apply to a single individual only");
+	if (p.T != 1 || !plan_forward_slots(p, slot_l, symmetry, sp, lr)) return fail(WHAMD_ERR_UNSUPPORTED, "slot runs apply to a single individual only");
 	std::vector<uint32_t> path;
 	uint32_t score = 0;
 	if (!emulate_slot_plan(p, sp, path, score, msg)) return fail(WHAMD_ERR_INVALID, "slot plan inconsistent: " + msg);
 	if (index_out && !path.empty()) std::memcpy(index_out, path.data(), path.size() * sizeof(uint32_t));
+	if (score_out) *score_out = score;
+	if (n_run_columns_out) *n_run_columns_out = sp.n_run_columns;
+	return WHAMD_OK;
+}
+
+whamd_status_t whamd_debug_emulate_pedslot_plan(const whamd_readset_view* readset, const uint32_t* recombcost, size_t n_recombcost,
+                                               const whamd_pedigree_view* pedigree, int distrust_genotypes, const uint32_t* positions,
+                                               size_t n_positions, int slot_l, uint32_t* index_out, uint32_t* transmission_out,
+                                               uint32_t* score_out, uint64_t* n_run_columns_out) {
+	Problem p;
+	std::string msg;
+	whamd_status_t st = build_problem(readset, recombcost, n_recombcost, pedigree, distrust_genotypes != 0, positions,
+	                                  n_positions, p, msg);
+	if (st != WHAMD_OK) return fail(st, msg);
+	SlotPlan sp;
+	if (p.T == 1 || !plan_forward_slots(p, slot_l > 0 ? -slot_l : 0, 0, sp) || !sp.ped)
+		return fail(WHAMD_ERR_UNSUPPORTED, "pedigree slot runs apply to tables with one or two trios whose columns need at most 4 cost forms per transmission value");
+	std::vector<uint32_t> path, trans;
+	uint32_t score = 0;
+	if (!emulate_pedslot_plan(p, sp, path, trans, score, msg)) return fail(WHAMD_ERR_INVALID, "pedigree slot plan inconsistent: " + msg);
+	if (index_out && !path.empty()) std::memcpy(index_out, path.data(), path.size() * sizeof(uint32_t));
+	if (transmission_out && !trans.empty()) std::memcpy(transmission_out, trans.data(), trans.size() * sizeof(uint32_t));
 	if (score_out) *score_out = score;
 	if (n_run_columns_out) *n_run_columns_out = sp.n_run_columns;
 	return WHAMD_OK;

@@ -299,7 +299,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	const bool force_keys = m.path == "column_keys";
 	const bool want_resident = m.path == "auto" || m.path == "resident";
 	const auto tu0 = std::chrono::steady_clock::now();
-	m.use_slots = (m.path == "auto" || m.path == "slots") && plan_forward_slots(p, m.slot_l, m.symmetry, m.splan, m.slot_lr);
+	m.use_slots = (m.path == "auto" || m.path == "slots") && p.T == 1 && plan_forward_slots(p, m.slot_l, m.symmetry, m.splan, m.slot_lr);
 	if (m.use_slots) {
 		// the driver below walks plan.steps / plan.component_first_step; slot runs are steps of kind 2
 		m.plan = ResidentPlan();

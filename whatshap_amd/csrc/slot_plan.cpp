@@ -31,14 +31,23 @@ inline uint32_t parity32(uint32_t v) { return (uint32_t)__builtin_popcount(v) & 
 }  // namespace
 
 bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan& plan, int lr) {
-	lr = std::max(2, std::min(lr, SLOT_LR));
 	const auto tp0 = std::chrono::steady_clock::now();
 	plan = SlotPlan();
 	const uint32_t n = p.n_cols;
-	if (!(p.T == 1 && p.n_ind == 1 && p.value_bound < 1073741824.0)) return false;
+	// pedigree tables (one or two trios): a lane holds ONE (cell, transmission value); no reg slots, 6 - TB lane slots
+	const bool ped = p.T > 1;
+	const uint32_t TB = p.T == 4 ? 2u : (p.T == 16 ? 4u : 0u);
+	if (ped && (TB == 0 || p.n_ind < 3)) return false;
+	if (!ped && !(p.T == 1 && p.n_ind == 1)) return false;
+	if (!(p.value_bound < 1073741824.0)) return false;
+	plan.ped = ped;
+	lr = ped ? 0 : std::max(2, std::min(lr, SLOT_LR));
+	const int n_lane = ped ? 6 - (int)TB : SLOT_LANE;
 	plan.col_to_row.assign(n, -1);
-	const int LMIN = lr + SLOT_LANE, LMAX = lr + SLOT_LANE + SLOT_LWMAX;
+	const int LMIN = lr + n_lane, LMAX = lr + n_lane + SLOT_LWMAX;
+	if (ped) l_pref = l_pref < 0 ? -l_pref : LMAX;
 	l_pref = std::max(LMIN, std::min(l_pref, LMAX));
+	const uint32_t max_run_cols = ped ? (uint32_t)PSLOT_MAXCOLS : (uint32_t)SLOT_MAXCOLS;
 	std::vector<uint32_t> last_col(p.n_reads, 0);
 	for (uint32_t c = 0; c < n; ++c) {
 		const ColumnEntry* col = p.col_begin(c);
@@ -47,9 +56,10 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 	std::vector<int32_t>& col_to_row = plan.col_to_row;
 	// rows and backtrace columns are indexed by COLUMN (row of column c = rows[c]; entries of columns outside runs stay unused):
 	// the ranges below write disjoint parts of them in place
-	plan.rows.resize(n);
+	if (ped) plan.prows.resize(n); else plan.rows.resize(n);
 	plan.bt_cols.resize(n);
 	auto& rows_g = plan.rows;
+	auto& prows_g = plan.prows;
 	auto& btc_g = plan.bt_cols;
 	// A run may start at ANY column (it reads the exchange column its predecessor left), so disjoint column ranges are
 	// planned independently -- in parallel -- and concatenated; a range boundary is just one more run boundary.
@@ -120,7 +130,8 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 		std::vector<int32_t> started;   // reads that got their slot inside the run (marks to clear)
 		uint32_t c1 = c, n_ends = 0;
 		bool symmetric = true;
-		while (c1 < n && c1 - c < (uint32_t)SLOT_MAXCOLS) {
+		uint32_t run_forms = 2;   // pedigree runs: NF = 2 or 4 forms per transmission value
+		while (c1 < n && c1 - c < max_run_cols) {
 			if (c1 + 1 == n) break;
 			if (c1 >= grid_end) break;
 			if (c1 >= c_end) break;
@@ -133,7 +144,16 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 			for (uint32_t s = 0; s < L; ++s) n_free += cur[s] < 0;
 			if (n_new > n_free) break;
 			bool ok = true;
-			for (uint32_t j = 0; j < kc && ok; ++j) ok = std::abs(p.delta[(size_t)p.col_ptr[c1] + j]) < SLOT_DELTA_LIMIT;
+			if (!ped) for (uint32_t j = 0; j < kc && ok; ++j) ok = std::abs(p.delta[(size_t)p.col_ptr[c1] + j]) < SLOT_DELTA_LIMIT;
+			if (ped) {
+				// at most PSLOT_MAXFORMS forms per transmission value; the run's tables grow with the widest column (NF 2 -> 4)
+				uint32_t most = 0;
+				for (uint32_t t = 0; t < p.T; ++t) most = std::max<uint32_t>(most, (uint32_t)(p.term_end(c1, t) - p.term_begin(c1, t)));
+				if (most > (uint32_t)PSLOT_MAXFORMS) break;
+				const uint32_t nf = std::max(run_forms, most > 2 ? 4u : 2u);
+				if ((c1 - c + 1) * p.T * nf > (uint32_t)PSLOT_FORMWORDS) break;
+				run_forms = nf;
+			}
 			for (uint32_t j = 0; j < bc && ok; ++j) ok = slot_of[col[j].read_id] >= 0;   // every shared read is tracked
 			if (!ok) break;
 			// reads that start here take the lowest free local slots
@@ -146,31 +166,43 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 					started.push_back((int32_t)col[j].read_id);
 				}
 			}
-			const int32_t* dl = p.delta.data() + (size_t)p.col_ptr[c1];   // n_ind == 1
+			const int32_t* dl = p.delta.data() + (size_t)p.col_ptr[c1] * p.n_ind;   // [individual][bit]; n_ind == 1 unless ped
 			SlotRow row{};
+			PedSlotRow prow{};
 			SlotBtCol bc_rec{};
-			uint32_t Cp = RES_ABSENT, Cm = RES_ABSENT, Cc = INF;
-			for (uint64_t q = p.term_begin(c1, 0); q < p.term_end(c1, 0); ++q) {
-				const CostTerm& t = p.terms[q];
-				if (t.plus) Cp = t.c;
-				else if (t.minus) Cm = t.c;
-				else Cc = std::min(Cc, t.c);
-			}
-			row.K = Cp + Cm;
-			row.Cc = Cc;
-			row.Cp = Cp;
-			uint32_t dsum = 0;
 			bc_rec.k = (uint8_t)kc;
 			bc_rec.kf = (uint8_t)n_ends;
-			for (uint32_t j = 0; j < kc; ++j) {
-				const int s = slot_of[col[j].read_id];
-				row.dslot[s] = dl[j];
-				dsum += (uint32_t)dl[j];
-				bc_rec.slot[j] = (uint8_t)s;
-			}
-			for (int s = 0; s < lr; ++s) row.dreg[s] = row.dslot[s];
-			for (int s = 0; s < SLOT_LANE; ++s) row.dlane[s] = row.dslot[lr + s];
-			{   // cost(~x) == cost(x)  <=>  Cp + (sum of all deltas) == Cm, or no orientation term at all
+			if (ped) {
+				// the cost forms stay where build_problem left them (DevProblem::terms); the row only says which read sits where
+				prow.recomb = p.recomb[c1];
+				for (uint32_t j = 0; j < kc; ++j) {
+					const int s = slot_of[col[j].read_id];
+					prow.dslot[s] = dl[(size_t)col[j].sample * kc + j];
+					prow.ind[s] = col[j].sample;
+					bc_rec.slot[j] = (uint8_t)s;
+				}
+				symmetric = false;
+			} else {
+				uint32_t Cp = RES_ABSENT, Cm = RES_ABSENT, Cc = INF;
+				for (uint64_t q = p.term_begin(c1, 0); q < p.term_end(c1, 0); ++q) {
+					const CostTerm& t = p.terms[q];
+					if (t.plus) Cp = t.c;
+					else if (t.minus) Cm = t.c;
+					else Cc = std::min(Cc, t.c);
+				}
+				row.K = Cp + Cm;
+				row.Cc = Cc;
+				row.Cp = Cp;
+				uint32_t dsum = 0;
+				for (uint32_t j = 0; j < kc; ++j) {
+					const int s = slot_of[col[j].read_id];
+					row.dslot[s] = dl[j];
+					dsum += (uint32_t)dl[j];
+					bc_rec.slot[j] = (uint8_t)s;
+				}
+				for (int s = 0; s < lr; ++s) row.dreg[s] = row.dslot[s];
+				for (int s = 0; s < SLOT_LANE; ++s) row.dlane[s] = row.dslot[lr + s];
+				// cost(~x) == cost(x)  <=>  Cp + (sum of all deltas) == Cm, or no orientation term at all
 				const bool both_absent = Cp == RES_ABSENT && Cm == RES_ABSENT;
 				if (!both_absent && (Cp == RES_ABSENT || Cm == RES_ABSENT || Cp + dsum != Cm)) symmetric = false;
 			}
@@ -191,11 +223,19 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 				}
 				row.end[en].info = (uint32_t)s | (qmask << 8) | (mflip << 24);
 				row.end[en].M = M;
+				if (ped) {   // (the kernel's cell index has no reg bits: M as it is)
+					if (en == 0) { prow.info0 = (uint32_t)s; prow.M0 = M; }
+					else if (en == 1) { prow.info1 = (uint32_t)s; prow.M1 = M; }
+					else { prow.info2 = (uint32_t)s; prow.M2 = M; }
+					bc_rec.slot[25 + en] = (uint8_t)s;   // the backtrace walks column by column: ending slots of the column, in order
+				}
 				plan.end_slots.push_back((uint8_t)s);
 				++en;
 			}
 			if (!ok) break;
 			row.n_end = en;
+			prow.n_end = en;
+			if (ped) bc_rec.pad[0] = (uint8_t)en;
 			// after the projection the ended reads' slots are free again
 			for (uint32_t j = 0; j < kc; ++j) {
 				if ((p.fwd_mask[c1] >> j) & 1u) continue;
@@ -203,14 +243,14 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 			}
 			n_ends += en;
 			col_to_row[c1] = (int32_t)c1;
-			rows_g[c1] = row;
+			if (ped) prows_g[c1] = prow; else rows_g[c1] = row;
 			btc_g[c1] = bc_rec;
 			++c1;
 		}
 		// a run whose bookkeeping stopped in the middle of a column: drop what that column appended
 		{
 			size_t keep = 0;
-			for (size_t i = rows_mark; i < c1; ++i) keep += rows_g[i].n_end;
+			for (size_t i = rows_mark; i < c1; ++i) keep += ped ? prows_g[i].n_end : rows_g[i].n_end;
 			plan.end_slots.resize(ends_mark + keep);
 		}
 		if (c1 - c < 2) {   // not worth a launch of its own
@@ -237,14 +277,26 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 		run.ctrl_off = (uint32_t)plan.ctrl.size();
 		plan.ctrl.resize(plan.ctrl.size() + SLOT_CTRL_WORDS, 0);
 		for (uint32_t i = 0; i < d.ncols; ++i) {
-			const SlotRow& rw = rows_g[rows_mark + i];
-			const uint32_t byte = rw.n_end | ((rw.n_end ? (rw.end[0].info & 31u) : 0u) << 2);
+			const uint32_t ne = ped ? prows_g[rows_mark + i].n_end : rows_g[rows_mark + i].n_end;
+			const uint32_t s0 = ped ? prows_g[rows_mark + i].info0 : (rows_g[rows_mark + i].end[0].info & 31u);
+			const uint32_t byte = ne | ((ne ? (s0 & 31u) : 0u) << 2);
 			plan.ctrl[run.ctrl_off + (i >> 2)] |= byte << ((i & 3u) * 8u);
 		}
 		run.lr = (uint32_t)lr;
 		run.row_off = (uint32_t)rows_mark;
 		run.n_ends = 0;
-		for (size_t i = rows_mark; i < c1; ++i) run.n_ends += rows_g[i].n_end;
+		for (size_t i = rows_mark; i < c1; ++i) run.n_ends += ped ? prows_g[i].n_end : rows_g[i].n_end;
+		if (ped) {
+			PedSlotExtra ex{};
+			ex.tb = TB;
+			ex.nf = 2;   // (recomputed: run_forms may have grown for a column that was dropped again)
+			for (uint32_t i = 0; i < d.ncols; ++i)
+				for (uint32_t t = 0; t < p.T; ++t) if (p.term_end(c + i, t) - p.term_begin(c + i, t) > 2) ex.nf = 4;
+			ex.fwn = d.ncols * p.T * ex.nf;
+			ex.arow = (ex.fwn + 3u) & ~3u;
+			ex.rec_words = ((d.ncols + 3u) / 4u) * (64u << d.lw);
+			plan.pextra.push_back(ex);
+		}
 		run.threads = 64u << d.lw;
 		run.has_prev = c > 0;   // a run that starts a connected component reads the single value the previous one projected onto
 		run.half = (use_symmetry > 0 && symmetric && g >= 1) ? 1u : 0u;
@@ -289,6 +341,7 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 			const uint32_t end_base = (uint32_t)plan.end_slots.size(), ctrl_base = (uint32_t)plan.ctrl.size();
 			for (Step st : q.steps) { if (st.kind == 2) st.index += run_base; plan.steps.push_back(st); }
 			for (SlotRun run : q.runs) { run.ctrl_off += ctrl_base; plan.runs.push_back(run); }
+			plan.pextra.insert(plan.pextra.end(), q.pextra.begin(), q.pextra.end());
 			for (uint32_t off : q.end_off) plan.end_off.push_back(off + end_base);
 			plan.end_slots.insert(plan.end_slots.end(), q.end_slots.begin(), q.end_slots.end());
 			plan.ctrl.insert(plan.ctrl.end(), q.ctrl.begin(), q.ctrl.end());
@@ -300,6 +353,24 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 	for (size_t si = 0; si < plan.steps.size(); ++si) {
 		const uint32_t c0 = plan.steps[si].kind == 2 ? plan.runs[plan.steps[si].index].c0 : plan.steps[si].index;
 		if (si == 0 || p.b[c0] == 0) plan.component_first_step.push_back((uint32_t)si);
+	}
+	if (ped) {
+		// a table that mostly falls back to per-column steps (genotypes not trusted: up to 16 forms per value) is better off
+		// with the LDS-resident trio runs / the per-column kernels
+		if (plan.n_run_columns * 2 < n) return false;
+		// where each run's tables (G, W, S of slots.h) live in the table array
+		uint64_t words = 0;
+		for (size_t ri = 0; ri < plan.runs.size(); ++ri) {
+			const SlotRun& run = plan.runs[ri];
+			PedSlotExtra& ex = plan.pextra[ri];
+			ex.g_lo = (uint32_t)words;
+			ex.g_hi = (uint32_t)(words >> 32);
+			const uint64_t gsz = ((uint64_t)1 << run.g) * ex.fwn;
+			ex.w_off = (uint32_t)gsz;
+			ex.s_off = (uint32_t)(gsz + ((uint64_t)1 << run.lw) * ex.fwn);
+			words += (uint64_t)ex.s_off + (uint64_t)run.ncols * 64u * ex.nf;
+		}
+		plan.table_words = words;
 	}
 	// ---- entry / exit layouts.  Exit index of a run in LOGICAL order: bit j = j-th continuing read of its last column.
 	plan.f_exit.assign(plan.runs.size(), 0);

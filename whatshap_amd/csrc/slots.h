@@ -93,6 +93,39 @@ inline void slot_set_pos(uint32_t (&w)[8], uint32_t s, uint32_t pos) {
 }
 static_assert(sizeof(SlotRun) == 160, "SlotRun layout");
 
+// ---- pedigree slot runs (T = 4 or 16 transmission values; kernels_pedslots.h) -------------------------------------
+// Same slots, same run / exchange machinery; a cell holds T values, ONE (cell, transmission value) per lane: the
+// transmission value in lane bits 0 .. TB-1 (TB = 2 trio, 4 quartet), 6 - TB lane slots, up to 3 wave slots, no reg slots.
+// The min-plus step over the previous transmission value j (src/pedigreedptable.cpp:264-300) is a butterfly of DPP moves
+// over the TB low lane bits (popcount(i ^ j) * recomb is separable per bit; low bits first gives the lowest j on ties).
+// The cost of a cell is the minimum over at most NF *forms* per transmission value (one per allele assignment that
+// survives, PedigreeColumnCostComputer::get_cost): form a = c_a + sum over the set bits of x of sigma_a(individual) * d_bit.
+// Every form splits over the slot classes, and the three parts are TABLES computed once per table at create time
+// (pedslot_tables, full-chip width): G[workgroup] (constant + grid slots), W[wave], S[lane]; a run's prologue is then
+// pure copies (A = G + W per wave into LDS) and a column costs two small LDS reads, NF adds and NF - 1 minima per lane.
+constexpr int PSLOT_MAXCOLS = 32;      // columns per run
+constexpr int PSLOT_MAXFORMS = 4;      // forms per transmission value a run can hold (NF = 2 or 4)
+constexpr int PSLOT_FORMWORDS = 1024;  // ncols * T * NF of one run (one row per wave in LDS)
+struct PedSlotRow {
+	// ---- hot: copied to LDS by the run kernel (8 words)
+	uint32_t recomb;
+	uint32_t M0;                     // first ending read: physical CELL-index bits of the reads logically above it
+	uint32_t info1, M1, info2, M2;   // further ending reads (rare): slot in the low byte of info
+	uint32_t n_end, info0;
+	// ---- cold: read by pedslot_tables only
+	int32_t dslot[SLOT_MAXSLOTS];    // delta of the read in every slot at this column (0: free slot, BLANK entry)
+	uint8_t ind[SLOT_MAXSLOTS + 2];  // individual of the read in every slot
+	uint32_t pad[7];
+};
+static_assert(sizeof(PedSlotRow) == 192, "PedSlotRow must stay 48 words");
+// Per run, next to its SlotRun (kernel argument by value).
+struct PedSlotExtra {
+	uint32_t tb, nf, fwn, arow;      // log2 T; forms per value; ncols * T * NF; fwn rounded up to 4 (row stride of A in LDS)
+	uint32_t g_lo, g_hi, w_off, s_off;   // word offsets into the table array: G [2^g][fwn]; W and S relative to G: [2^lw][fwn], [ncols][64][NF]
+	uint32_t rec_words, pad[3];      // record of one workgroup: one byte per thread and column, 4 columns per word: ceil(ncols / 4) * threads words
+};
+static_assert(sizeof(PedSlotExtra) == 48, "PedSlotExtra layout");
+
 struct SlotBatchEntry {
 	SlotRun run;
 	const uint32_t* prev;
@@ -147,15 +180,28 @@ struct SlotPlan {
 	std::vector<int32_t> col_to_row;         // [n_cols] index into rows or -1
 	std::vector<uint32_t> component_first_step;
 	uint64_t n_run_columns = 0;
+	// pedigree tables (T > 1): rows of the run columns (indexed by column, like `rows`), per-run extras, words of all tables
+	bool ped = false;
+	std::vector<PedSlotRow, NoInitAllocator<PedSlotRow>> prows;
+	std::vector<PedSlotExtra> pextra;
+	uint64_t table_words = 0;
 };
 
 // Plans the forward pass of a single-individual table with slot runs wherever they apply (per-column steps elsewhere).
-// Returns false if the table is not eligible (pedigree, values beyond 2^30): the caller uses plan_forward().
+// Returns false if the table is not eligible (values beyond 2^30; a pedigree other than one or two trios, or one whose
+// columns mostly need more than PSLOT_MAXFORMS forms per transmission value): the caller uses plan_forward().
 // use_symmetry: 0 never halve, >= 1 halve every run whose columns are symmetric and that has a grid slot.
+// A table with T = 4 or 16 gets pedigree slot runs (plan.ped; l_pref and lr are then ignored unless l_pref < 0: -l_pref
+// local slots, for tests).
 bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan& plan, int lr = 2);
 
 // Host-only diagnostic (slot_emulate.cpp): executes `plan` cell by cell the way the kernels do.  For planner tests on
 // small inputs; never part of a solve.
 bool emulate_slot_plan(const Problem& p, const SlotPlan& plan, std::vector<uint32_t>& path_index, uint32_t& score, std::string& msg);
+// The same for a pedigree plan (pedslot_emulate.cpp): tables, butterfly min-plus, byte records, walk -- as kernels_pedslots.h does it.
+bool emulate_pedslot_plan(const Problem& p, const SlotPlan& plan, std::vector<uint32_t>& path_index, std::vector<uint32_t>& path_trans,
+                          uint32_t& score, std::string& msg);
+// Host restatement of one table entry (pedslot_tables computes the same on the device): kind 0 G, 1 W, 2 S.
+uint32_t pedslot_table_entry(const Problem& p, const SlotPlan& plan, uint32_t run_index, int kind, uint32_t unit, uint32_t c, uint32_t t, uint32_t f);
 
 }  // namespace whamd

@@ -41,9 +41,12 @@ def uniform_recombination_costs(positions, recombrate: float = 1.26) -> np.ndarr
 
 def synthetic_block(n_variants: int, coverage: int, seed: int, step: int = 2, trio: bool = False,
                     distrust_genotypes: bool = False, error_rate: float = 0.02, drop_rate: float = 0.10,
-                    n_columns_limit: Optional[int] = None) -> ProblemArrays:
+                    n_columns_limit: Optional[int] = None, quartet: bool = False,
+                    mixed_genotypes: bool = False) -> ProblemArrays:
     """One connected phasing block.  ``n_columns_limit`` keeps only the first columns of the SAME
-    ReadSet (reads are clipped to the prefix), for bounded CPU-baseline samples."""
+    ReadSet (reads are clipped to the prefix), for bounded CPU-baseline samples.
+    ``quartet``: two trios sharing their parents (T = 16), reads round-robin over the four individuals.
+    ``mixed_genotypes`` (pedigrees): Mendelian-consistent random genotypes instead of all-heterozygous ones."""
     rng = np.random.default_rng(seed)
     n = int(n_variants)
     hap = rng.integers(0, 2, size=n, dtype=np.uint8)  # haplotype 0; haplotype 1 is its complement
@@ -85,15 +88,25 @@ def synthetic_block(n_variants: int, coverage: int, seed: int, step: int = 2, tr
     n_cols = n if n_columns_limit is None else min(n, n_columns_limit)
     positions = (1000 * (np.arange(n_cols, dtype=np.int64) + 1)).astype(np.uint32)
     var_position = (1000 * (var_idx + 1)).astype(np.int32)
-    if trio:
-        sample = (np.arange(n_reads) % 3).astype(np.int32)  # father, mother, child round-robin
-        individual_id = np.array([0, 1, 2], dtype=np.uint32)
-        triples = np.array([0, 1, 2], dtype=np.uint32)
-        genotype = np.ones((3, n_cols), dtype=np.uint8)
+    if trio or quartet:
+        n_ind = 4 if quartet else 3
+        sample = (np.arange(n_reads) % n_ind).astype(np.int32)  # father, mother, child (, second child) round-robin
+        individual_id = np.arange(n_ind, dtype=np.uint32)
+        triples = np.array([0, 1, 2, 0, 1, 3] if quartet else [0, 1, 2], dtype=np.uint32)
+        genotype = np.ones((n_ind, n_cols), dtype=np.uint8)
+        if mixed_genotypes:
+            grng = np.random.default_rng(seed + 7919)
+            fa = grng.integers(0, 2, size=(2, n_cols))
+            mo = grng.integers(0, 2, size=(2, n_cols))
+            genotype[0] = fa.sum(axis=0)
+            genotype[1] = mo.sum(axis=0)
+            cols = np.arange(n_cols)
+            for child in range(2, n_ind):
+                genotype[child] = fa[grng.integers(0, 2, size=n_cols), cols] + mo[grng.integers(0, 2, size=n_cols), cols]
         recomb = np.zeros(n_cols, dtype=np.uint32)
         if n_cols > 1:
             recomb[1:] = round(centimorgen_to_phred(1000 * 1e-6 * 1.26))
-        gl = np.tile(np.array([30.0, 0.0, 30.0]), (3, n_cols, 1)) if distrust_genotypes else None
+        gl = np.tile(np.array([30.0, 0.0, 30.0]), (n_ind, n_cols, 1)) if distrust_genotypes else None
     else:
         sample = np.zeros(n_reads, dtype=np.int32)
         individual_id = np.array([0], dtype=np.uint32)
