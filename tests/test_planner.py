@@ -55,9 +55,17 @@ def test_column_path_request_has_no_runs_and_trios_get_their_own_runs():
     assert s["invariants_ok"] == 1 and s["n_runs"] > 0 and s["n_resident_columns"] >= 580
     assert s["n_folded_columns"] == 0          # the transmission argmin is recorded on every column
     assert s["max_workgroups"] >= 32 and s["max_lds_bytes"] <= 160 * 1024
-    quartet = random_small_instance(random.Random(3), mode="quartet", allow_conflict=False)
-    s = _native.plan_summary(quartet)
-    assert s["n_runs"] == 0 and s["invariants_ok"] == 1  # two trios: per-column kernels
+    assert s["max_workgroups"] == 256 and s["max_run_columns"] >= 12   # pedigree slot runs: 7 local + 8 grid slots
+    s = _native.plan_summary(trio, "resident")   # the LDS-resident trio runs remain selectable
+    assert s["invariants_ok"] == 1 and s["n_runs"] > 0 and s["n_resident_columns"] >= 580
+    quartet = synthetic_block(n_variants=400, coverage=12, seed=7, quartet=True, mixed_genotypes=True)
+    s = _native.plan_summary(quartet)   # two trios: pedigree slot runs with T = 16 (2 lane slots + 3 wave slots)
+    assert s["invariants_ok"] == 1 and s["n_runs"] > 0 and s["n_resident_columns"] >= 300 and s["max_workgroups"] == 128
+    s = _native.plan_summary(quartet, "column")
+    assert s["n_runs"] == 0 and s["invariants_ok"] == 1
+    distrust = synthetic_block(n_variants=300, coverage=10, seed=8, trio=True, distrust_genotypes=True)
+    s = _native.plan_summary(distrust)   # 9 cost forms per transmission value: not for the pedigree slot runs
+    assert s["invariants_ok"] == 1 and s["n_runs"] > 0 and s["max_workgroups"] <= 64
 
 
 @pytest.mark.parametrize("seed", range(6))

@@ -293,7 +293,7 @@ whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uin
 	const std::string mode(path ? path : "auto");
 	SlotPlan sp;
 	const double tp0 = now_ms();
-	const bool slots_ok = (mode == "auto" || mode == "slots") && p.T == 1 && plan_forward_slots(p, 11, 1, sp);
+	const bool slots_ok = (mode == "auto" || mode == "slots") && plan_forward_slots(p, 11, 1, sp);
 	if (getenv("WHAMD_DEBUG_TIMING")) fprintf(stderr, "[whamd timing] plan_summarize: build_problem %.1f ms, plan_forward_slots %.1f ms\n", tp0 - tb0, now_ms() - tp0);
 	if (slots_ok) {
 		// slot runs (slots.h): every column in exactly one step, runs within their limits, slots consistent
@@ -309,12 +309,18 @@ whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uin
 		for (size_t si = 0; si < sp.steps.size(); ++si) {
 			const Step& step = sp.steps[si];
 			const uint32_t c0 = step.kind == 2 ? sp.runs[step.index].c0 : step.index;
-			if (si == 0 || p.b[c0] == 0) { ok = ok && kc < sp.component_first_step.size() && sp.component_first_step[kc] == si; ++kc; }
+			if (!sp.ped && (si == 0 || p.b[c0] == 0)) { ok = ok && kc < sp.component_first_step.size() && sp.component_first_step[kc] == si; ++kc; }
 			ok = ok && c0 == expect;
 			if (step.kind == 0) { expect = c0 + 1; ok = ok && sp.col_to_row[c0] < 0; continue; }
 			const SlotRun& run = sp.runs[step.index];
 			expect = c0 + run.ncols;
-			ok = ok && step.kind == 2 && run.ncols >= 2 && run.ncols <= (uint32_t)SLOT_MAXCOLS && run.g <= (uint32_t)SLOT_GMAX;
+			ok = ok && step.kind == 2 && run.ncols >= 2 && run.ncols <= (uint32_t)(sp.ped ? PSLOT_MAXCOLS : SLOT_MAXCOLS) && run.g <= (uint32_t)SLOT_GMAX;
+			if (sp.ped) {
+				const PedSlotExtra& ex = sp.pextra[step.index];
+				ok = ok && sp.pextra.size() == sp.runs.size() && run.lr == 0 && !run.half && (1u << ex.tb) == p.T && run.L == 6u - ex.tb + run.lw;
+				ok = ok && (ex.nf == 2 || ex.nf == 4) && ex.fwn == run.ncols * p.T * ex.nf && ex.fwn <= (uint32_t)PSLOT_FORMWORDS && ex.rec_words == ((run.ncols + 3) / 4) * run.threads;
+				ok = ok && run.lw <= (uint32_t)SLOT_LWMAX && run.threads == (64u << run.lw);
+			} else
 			ok = ok && run.lr >= 2 && run.lr <= (uint32_t)SLOT_LR && run.L == run.lr + (uint32_t)SLOT_LANE + run.lw && run.lw <= (uint32_t)SLOT_LWMAX && run.threads == (64u << run.lw);
 			ok = ok && run.L + run.g <= (uint32_t)SLOT_MAXSLOTS && run.n_ends <= (uint32_t)SLOT_MAXENDS_RUN && (!run.half || run.g >= 1);
 			uint32_t ends = 0;
@@ -322,26 +328,36 @@ whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uin
 				const uint32_t c = c0 + i;
 				if (c + 1 >= p.n_cols) { ok = false; break; }   // the last column never runs inside a run
 				ok = ok && sp.col_to_row[c] == (int32_t)(run.row_off + i) && (i == 0 || p.b[c] != 0);
-				const SlotRow& row = sp.rows[run.row_off + i];
+				const uint32_t row_n_end = sp.ped ? sp.prows[run.row_off + i].n_end : sp.rows[run.row_off + i].n_end;
 				const SlotBtCol& bc = sp.bt_cols[run.row_off + i];
-				ok = ok && bc.k == p.k[c] && bc.kf == ends && row.n_end == (uint32_t)p.k[c] - p.f[c] && row.n_end <= (uint32_t)SLOT_MAXEND;
+				ok = ok && bc.k == p.k[c] && bc.kf == ends && row_n_end == (uint32_t)p.k[c] - p.f[c] && row_n_end <= (uint32_t)SLOT_MAXEND;
+				if (sp.ped) for (uint32_t t = 0; t < p.T; ++t) ok = ok && p.term_end(c, t) - p.term_begin(c, t) <= sp.pextra[step.index].nf;
 				uint32_t used = 0;
 				for (uint32_t j = 0; j < bc.k; ++j) {   // distinct slots, ending reads local
 					ok = ok && bc.slot[j] < run.L + run.g && !((used >> bc.slot[j]) & 1u);
 					used |= 1u << bc.slot[j];
 					if (!((p.fwd_mask[c] >> j) & 1u)) ok = ok && bc.slot[j] < run.L;
 				}
-				for (uint32_t q = 0; q < row.n_end; ++q) ok = ok && sp.end_slots[sp.end_off[step.index] + ends + q] == (row.end[q].info & 255u);
-				ends += row.n_end;
+				for (uint32_t q = 0; q < row_n_end; ++q) {
+					const uint32_t es = sp.ped ? (uint32_t)bc.slot[25 + q] : (sp.rows[run.row_off + i].end[q].info & 255u);
+					ok = ok && sp.end_slots[sp.end_off[step.index] + ends + q] == es;
+				}
+				ends += row_n_end;
 			}
 			ok = ok && ends == run.n_ends;
 			s.max_run_columns = std::max<uint64_t>(s.max_run_columns, run.ncols);
 			s.max_workgroups = std::max<uint64_t>(s.max_workgroups, 1ull << (run.g - run.half));
-			s.max_lds_bytes = std::max<uint64_t>(s.max_lds_bytes, 2ull * run.threads * (1u << run.lr) * 4 + (SLOT_MAXCOLS + 8) * 64 + 8 * 64 * 4 + SLOT_MAXCOLS * 64 * 4);
+			if (sp.ped) {
+				const PedSlotExtra& ex = sp.pextra[step.index];
+				s.max_lds_bytes = std::max<uint64_t>(s.max_lds_bytes, (2ull * run.threads + (PSLOT_MAXCOLS + 4) * 8 + (uint64_t)(run.threads >> 6) * (ex.arow + 4u * p.T * ex.nf) + (uint64_t)(run.ncols + 4) * 64 * ex.nf) * 4);
+				s.backtrace_bytes += ((uint64_t)ex.rec_words * 4) << run.g;
+			} else {
+				s.max_lds_bytes = std::max<uint64_t>(s.max_lds_bytes, 2ull * run.threads * (1u << run.lr) * 4 + (SLOT_MAXCOLS + 8) * 64 + 8 * 64 * 4 + SLOT_MAXCOLS * 64 * 4);
+				s.backtrace_bytes += (uint64_t)run.n_ends * run.threads * (1ull << (run.g - run.half));
+			}
 			if (run.half) s.n_halved_runs++;
 			s.n_resident_columns += run.ncols;
 			s.n_vectorised_columns += run.ncols;
-			s.backtrace_bytes += (uint64_t)run.n_ends * run.threads * (1ull << (run.g - run.half));
 		}
 		ok = ok && expect == p.n_cols && kc == sp.component_first_step.size();
 		s.invariants_ok = ok ? 1 : 0;

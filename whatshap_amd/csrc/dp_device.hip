@@ -45,6 +45,7 @@ namespace {
 #include "kernels_resident.h"
 #include "kernels_trio.h"
 #include "kernels_slots.h"
+#include "kernels_pedslots.h"
 #include "kernels_backtrace.h"
 
 // ---------------------------------------------------------------------------------------------- launch tables
@@ -155,8 +156,9 @@ struct DeviceTable::Impl {
 	bool use_slots = false;
 	int slot_l = 11;            // preferred number of local slots (lr + 6 .. lr + 9)
 	int slot_lr = 2;            // reg slots: 4 cells per thread -> 8 waves per workgroup at 11 local slots (two waves per SIMD)
-	std::vector<SlotBatchEntry> slot_entries;
+	std::vector<SlotBatchEntry> slot_entries;   // (pedigree runs: `pad` holds the run's index into splan.pextra)
 	SlotBatchEntry* d_slot_entries = nullptr;
+	uint64_t table_bytes = 0;   // pedigree slot runs: cost-form tables
 	BtJob* d_btjobs = nullptr;
 	uint32_t* d_job_scores = nullptr;
 	int max_lanes = 32;
@@ -299,7 +301,12 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	const bool force_keys = m.path == "column_keys";
 	const bool want_resident = m.path == "auto" || m.path == "resident";
 	const auto tu0 = std::chrono::steady_clock::now();
-	m.use_slots = (m.path == "auto" || m.path == "slots") && p.T == 1 && plan_forward_slots(p, m.slot_l, m.symmetry, m.splan, m.slot_lr);
+	size_t free_b = 0, total_b = 0;
+	HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+	m.use_slots = (m.path == "auto" || m.path == "slots") && plan_forward_slots(p, m.slot_l, m.symmetry, m.splan, m.slot_lr);
+	// pedigree slot runs keep their cost-form tables in HBM (slots.h): at most a quarter of what is free, else the older paths
+	if (m.use_slots && m.splan.ped && m.splan.table_words * 4ull > free_b / 4) m.use_slots = false;
+	m.table_bytes = m.use_slots && m.splan.ped ? m.splan.table_words * 4ull : 0ull;
 	if (m.use_slots) {
 		// the driver below walks plan.steps / plan.component_first_step; slot runs are steps of kind 2
 		m.plan = ResidentPlan();
@@ -351,10 +358,14 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	uint64_t bt = 0, seg_bt = 0;
 	size_t seg_cursor = 0, slot_cursor = 0;
 	uint32_t max_f = 0, max_keys_f = 0;
-	size_t free_b = 0, total_b = 0;
-	HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-	// what the arena may take: free HBM minus the descriptors (~1 KiB per column), exchange buffers and slack
-	const uint64_t reserve = (3ull << 30) + (uint64_t)n * 1024ull;
+	// what the arena may take: free HBM minus the descriptors (~1 KiB per column), exchange buffers, tables and slack
+	const uint64_t reserve = (3ull << 30) + (uint64_t)n * 1024ull + m.table_bytes;
+	const bool ped_slots = m.use_slots && m.splan.ped;
+	auto slot_record_bytes = [&](size_t ri) -> uint64_t {   // record of one slot run: only launched workgroups write
+		const SlotRun& run = m.splan.runs[ri];
+		if (ped_slots) return (uint64_t)m.splan.pextra[ri].rec_words * 4ull << run.g;
+		return (uint64_t)run.n_ends * run.threads * (1ull << (run.g - run.half));
+	};
 	uint64_t arena_cap = free_b > reserve ? free_b - reserve : 0;
 	if (m.arena_limit) arena_cap = std::min<uint64_t>(arena_cap, m.arena_limit);
 	std::vector<uint32_t> window_first_col;   // first column of every window after the first
@@ -396,11 +407,11 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 			d.res_idx = (uint32_t)m.splan.col_to_row[c];
 			if (slot_cursor < m.splan.runs.size() && m.splan.runs[slot_cursor].c0 == c) {  // first column of a slot run
 				SlotRun& run = m.splan.runs[slot_cursor];
-				if (!open_unit(c, (uint64_t)run.n_ends * run.threads * (1ull << (run.g - run.half)))) return unit_too_large(c);
+				if (!open_unit(c, slot_record_bytes(slot_cursor))) return unit_too_large(c);
 				run.rec_lo = (uint32_t)bt;
 				run.rec_hi = (uint32_t)(bt >> 32);
 				seg_bt = bt;
-				bt += (uint64_t)run.n_ends * run.threads * (1ull << (run.g - run.half));   // only launched workgroups write
+				bt += slot_record_bytes(slot_cursor);
 				max_f = std::max(max_f, run.L + run.g);   // entry / exit indices in physical order need 2^(L + g) entries
 				++slot_cursor;
 			}
@@ -490,6 +501,15 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	void* d_sctrl = nullptr;
 	HIP_TRY(up(&d_sctrl, m.splan.ctrl.data(), m.splan.ctrl.size() * sizeof(uint32_t)));
 	m.dp.slot_ctrl = (const uint32_t*)d_sctrl;
+	void *d_prows = nullptr, *d_pruns = nullptr, *d_pextra = nullptr, *d_ptab = nullptr;
+	if (ped_slots) {
+		HIP_TRY(up(&d_prows, m.splan.prows.data(), m.splan.prows.size() * sizeof(PedSlotRow)));
+		HIP_TRY(up(&d_pruns, m.splan.runs.data(), m.splan.runs.size() * sizeof(SlotRun)));
+		HIP_TRY(up(&d_pextra, m.splan.pextra.data(), m.splan.pextra.size() * sizeof(PedSlotExtra)));
+		HIP_TRY(alloc(&d_ptab, m.table_bytes));
+	}
+	m.dp.pslot_rows = (const PedSlotRow*)d_prows;
+	m.dp.pslot_tab = (const uint32_t*)d_ptab;
 	m.dp.slot_rows = (const SlotRow*)d_srows;
 	m.dp.slot_blob = (const uint32_t*)d_sblob;
 	// ---- jobs (see Impl::Job): connected components made of runs only get their own job
@@ -538,12 +558,13 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 			} else if (st.kind == 2) {
 				const SlotRun& run = m.splan.runs[st.index];
 				SlotBtUnit su{};
-				su.kind = 2; su.c0 = run.c0; su.ncols = run.ncols; su.blob_off = slot_blob_off[st.index];
+				su.kind = ped_slots ? 3 : 2; su.c0 = run.c0; su.ncols = run.ncols; su.blob_off = slot_blob_off[st.index];
 				su.g = run.g; su.L = run.L; su.n_ends = run.n_ends; su.threads = run.threads;
 				su.bt_lo = run.rec_lo; su.bt_hi = run.rec_hi; su.half = run.half; su.blob_words = slot_blob_words[st.index];
 				su.f_exit = m.splan.f_exit[st.index];
 				for (uint32_t j = 0; j < su.f_exit && j < 32; ++j) su.exit_pos[j] = (uint8_t)slot_pos(run.out_pos, m.splan.exit_slot[st.index][j]);
 				su.lr = run.lr;
+				if (ped_slots) { su.n_ends = m.splan.pextra[st.index].rec_words; su.lr = m.splan.pextra[st.index].tb; }   // kind 3: words of one workgroup's record, log2 T
 				for (uint32_t j = 0; j < su.f_exit && j < 32; ++j) su.exit_slot[j] = m.splan.exit_slot[st.index][j];
 				static_assert(sizeof(SlotBtUnit) == sizeof(BtUnit), "unit headers share one array");
 				std::memcpy(&u, &su, sizeof u);
@@ -653,7 +674,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		cur.n_orient = 1;   // the newest chunk starts from the table's optimum
 		uint32_t runs_in_chunk = 0;
 		for (uint32_t u = 0; u < m.units.size(); ++u) {
-			const bool is_run = m.units[u].kind == 2 || (trio_runs && m.units[u].kind == 1);
+			const bool is_run = m.units[u].kind == 2 || m.units[u].kind == 3 || (trio_runs && m.units[u].kind == 1);
 			if (is_run && runs_in_chunk >= (uint32_t)BT_CHUNK_RUNS && u > 0) {
 				m.chunks.push_back(cur);
 				cur = BtChunk{};
@@ -695,7 +716,8 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	{
 		uint32_t max_stage = 0;
 		for (const ResSegment& sgm : m.plan.segments) max_stage = std::max(max_stage, sgm.stage_words);
-		for (const SlotRun& run : m.splan.runs) max_stage = std::max(max_stage, (run.n_ends * run.threads + 7) / 8);
+		for (size_t ri = 0; ri < m.splan.runs.size(); ++ri)
+			max_stage = std::max(max_stage, ped_slots ? m.splan.pextra[ri].rec_words / 2u : (m.splan.runs[ri].n_ends * m.splan.runs[ri].threads + 7) / 8);
 		m.bt_lds = (size_t)2 * RES_MAXCOLS * 128 + 512 + 16 + (size_t)BT_CELLS * 4 + (size_t)RES_MAXCOLS * 4 + (size_t)max_stage * 8 + 16;
 		m.chunk_lds = (size_t)(32 + 4 + BT_CELLS + BT_CHUNK_BLOB) * 4 + (size_t)max_stage * 8 + 16;
 	}
@@ -767,6 +789,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 					e.score_out = (last && !job.final) ? m.d_job_scores + job_id : nullptr;
 					ss.io[0] = lane.d_pr[c.flip]; ss.io[1] = lane.d_pr[c.flip ^ 1];
 					ss.lds = std::max<size_t>(ss.lds, (size_t)2 * e.run.threads * (1u << e.run.lr) * 4 + (SLOT_MAXCOLS + 8) * 64 + 8 * 64 * 4 + SLOT_MAXCOLS * 64 * 4);
+					e.pad = step.index;
 					ss.grid_x = std::max(ss.grid_x, 1u << (e.run.g - e.run.half));
 					ss.threads = std::max(ss.threads, e.run.threads);
 					m.slot_entries.push_back(e);
@@ -829,8 +852,22 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		HIP_TRY(up(&d_btjobs, btjobs.data(), btjobs.size() * sizeof(BtJob)));
 		m.d_btjobs = (BtJob*)d_btjobs;
 	}
-	HIP_TRY(hipStreamSynchronize(m.stream));
 	m.dp.cols = m.d_cols;
+	m.dp.term_ptr = (const uint32_t*)d_term_ptr;
+	m.dp.terms = (const DevTerm*)d_terms;
+	if (ped_slots) {
+		// the cost-form tables of every run (slots.h), once per table: blockIdx.y = run
+		uint32_t most = 0;
+		for (size_t ri = 0; ri < m.splan.runs.size(); ++ri)
+			most = std::max<uint32_t>(most, (m.splan.pextra[ri].fwn << m.splan.runs[ri].g) + (m.splan.pextra[ri].fwn << m.splan.runs[ri].lw) + m.splan.runs[ri].ncols * 64u * m.splan.pextra[ri].nf);
+		const uint32_t bx = std::max(1u, std::min(1024u, (most + 255u) / 256u));
+		for (size_t r0 = 0; r0 < m.splan.runs.size(); r0 += 32768) {   // (gridDim.y <= 65535)
+			const uint32_t ny = (uint32_t)std::min<size_t>(32768, m.splan.runs.size() - r0);
+			hipLaunchKernelGGL(pedslot_tables, dim3(bx, ny), dim3(256), 0, m.stream, m.dp, (const SlotRun*)d_pruns + r0, (const PedSlotExtra*)d_pextra + r0, (uint32_t*)d_ptab);
+		}
+		HIP_TRY(hipGetLastError());
+	}
+	HIP_TRY(hipStreamSynchronize(m.stream));
 	m.dp.delta = (const int32_t*)d_delta;
 	m.dp.term_ptr = (const uint32_t*)d_term_ptr;
 	m.dp.terms = (const DevTerm*)d_terms;
@@ -881,6 +918,12 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment_ped<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment_ped<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((resident_segment_ped<false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, 4, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, 4, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, 2, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, 2, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, 4, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, 4, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 	return WHAMD_OK;
 }
 
@@ -947,10 +990,25 @@ void DeviceTable::Impl::launch_run(const ResBatchEntry& e, uint32_t step_index, 
 void DeviceTable::Impl::launch_slot_run(const SlotBatchEntry& e, uint64_t& launches) {
 	Impl& m = *this;
 	const SlotRun& run = e.run;
+	const bool spec = run.spec_id != 0 && m.use_chunks && !getenv("WHAMD_NO_SPEC_KERNEL");
+	if (m.splan.ped) {
+		const PedSlotExtra& ex = m.splan.pextra[e.pad];
+		const uint32_t T = 1u << ex.tb;
+		// wave-slot exchange + hot lines + per-wave A rows + S (four columns of slack behind the rows: lines are requested ahead)
+		const size_t lds_ped = ((size_t)2 * run.threads + (PSLOT_MAXCOLS + 4) * 8 + (size_t)(run.threads >> 6) * (ex.arow + 4u * T * ex.nf) + (size_t)(run.ncols + 4) * 64 * ex.nf) * 4;
+		const dim3 grid(1u << run.g), block(run.threads);
+#define WHAMD_PSLOT_LAUNCH(TBV, NFV, SPECV) hipLaunchKernelGGL((pedslot_run<TBV, NFV, SPECV>), grid, block, lds_ped, m.stream, m.dp, run, ex, e.prev, e.cur)
+		if (ex.tb == 2 && ex.nf == 2) { if (spec) WHAMD_PSLOT_LAUNCH(2, 2, true); else WHAMD_PSLOT_LAUNCH(2, 2, false); }
+		else if (ex.tb == 2) { if (spec) WHAMD_PSLOT_LAUNCH(2, 4, true); else WHAMD_PSLOT_LAUNCH(2, 4, false); }
+		else if (ex.nf == 2) { if (spec) WHAMD_PSLOT_LAUNCH(4, 2, true); else WHAMD_PSLOT_LAUNCH(4, 2, false); }
+		else { if (spec) WHAMD_PSLOT_LAUNCH(4, 4, true); else WHAMD_PSLOT_LAUNCH(4, 4, false); }
+#undef WHAMD_PSLOT_LAUNCH
+		launches += 1;
+		return;
+	}
 	const size_t lds = (size_t)2 * run.threads * (1u << run.lr) * 4 + (SLOT_MAXCOLS + 8) * 64 + 8 * 64 * 4 + SLOT_MAXCOLS * 64 * 4;   // wave-slot exchange + hot lines + per-wave A + lane sums
 	const dim3 grid(1u << (run.g - run.half)), block(run.threads);
 	const bool dbg = m.dp.dbg != nullptr || m.dp.dbg_flags != 0;
-	const bool spec = run.spec_id != 0 && m.use_chunks && !getenv("WHAMD_NO_SPEC_KERNEL");
 #define WHAMD_SLOT_LAUNCH(LRV, DBGV, SPECV) hipLaunchKernelGGL((slot_run<LRV, DBGV, SPECV>), grid, block, lds, m.stream, m.dp, run, e.prev, e.cur, e.score_out)
 	if (run.lr == 3) {
 		if (dbg) { if (spec) WHAMD_SLOT_LAUNCH(3, true, true); else WHAMD_SLOT_LAUNCH(3, true, false); }

@@ -15,6 +15,28 @@ constexpr int BT_CELLS = 128;
 constexpr int BT_CHUNK_BLOB = RES_MAXCOLS * 32;   // words of the chunk walker's per-unit descriptor area (>= SLOT_MAXCOLS * 8 + 32)
 constexpr int BT_CHUNK_RUNS = 16;   // slot runs per chunk of the speculative backtrace  // >= RES_MAXCOLS and >= SLOT_MAXENDS_RUN + 1
 
+// One pedigree slot run (slots.h, kernels_pedslots.h) for the calling wave: the record holds one byte per (lane, column) =
+// argj | ending-read decisions << 4, four columns per word.  Walks the columns newest first from local cell `l` and
+// transmission value `tcur` (src/pedigreedptable.cpp:151-172: the ending reads of the column are undone in reverse order at
+// the side-0 lane of each pair, then the lane of the complete cell holds the transmission value of the column before).
+// cells[c] / cells[64 + c]: local cell and transmission value of the path at column c; returns the value handed down.
+__device__ __forceinline__ uint32_t pedslot_walk(const SlotBtCol* bcols, const uint8_t* stage8, uint32_t ncols, uint32_t threads, uint32_t tb,
+                                                uint32_t l, uint32_t tcur, uint32_t* cells, bool writer) {
+	for (uint32_t ci = ncols; ci-- > 0;) {
+		const SlotBtCol& bc = bcols[ci];
+		const uint32_t base = (ci >> 2) * threads * 4u + (ci & 3u);
+		for (uint32_t e = bc.pad[0]; e-- > 0;) {
+			const uint32_t slot = bc.slot[25u + e];
+			const uint32_t look = l & ~(1u << slot);
+			const uint32_t byte = stage8[base + ((look << tb) | tcur) * 4u];
+			l = look | (((byte >> (4u + e)) & 1u) << slot);
+		}
+		if (writer) { cells[ci] = l; cells[64u + ci] = tcur; }
+		tcur = stage8[base + ((l << tb) | tcur) * 4u] & 15u;
+	}
+	return tcur;
+}
+
 __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtUnit* __restrict__ all_units, const BtJob* __restrict__ jobs,
                                                          uint32_t* __restrict__ path_index, uint32_t* __restrict__ path_trans,
                                                          uint32_t* __restrict__ out_score) {
@@ -69,7 +91,7 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 		const uint32_t* h1 = hdr + (u_first & 3u) * 32;
 		const uint32_t* __restrict__ g1 = reinterpret_cast<const uint32_t*>(P.res_bt + h1[3]);
 		for (uint32_t i = lane; i < h1[2] * 32; i += NT) recs0[(u_first & 1u) * RES_MAXCOLS * 32 + i] = g1[i];
-	} else if (n_units > u_first && hdr[(u_first & 3u) * 32] == 2u) {
+	} else if (n_units > u_first && (hdr[(u_first & 3u) * 32] == 2u || hdr[(u_first & 3u) * 32] == 3u)) {
 		const uint32_t* h1 = hdr + (u_first & 3u) * 32;
 		const uint32_t* __restrict__ g1 = P.slot_blob + h1[3];
 		for (uint32_t i = lane; i < h1[11]; i += NT) recs0[(u_first & 1u) * RES_MAXCOLS * 32 + i] = g1[i];
@@ -86,7 +108,7 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 		const bool hload = lane < 32 && ui + 2 < n_units;
 		if (hload) hv = reinterpret_cast<const uint32_t*>(units + ui + 2)[lane];
 		const uint32_t* hn = hdr + ((ui + 1) & 3u) * 32;
-		const bool next_run = ui + 1 < n_units && hn[0] == 1u, next_slots = ui + 1 < n_units && hn[0] == 2u;
+		const bool next_run = ui + 1 < n_units && hn[0] == 1u, next_slots = ui + 1 < n_units && (hn[0] == 2u || hn[0] == 3u);
 		const uint32_t nrec = next_run ? hn[2] * 32 : (next_slots ? hn[11] : 0u);
 		const uint32_t* __restrict__ gnext = next_slots ? P.slot_blob + hn[3] : reinterpret_cast<const uint32_t*>(P.res_bt + (next_run ? hn[3] : 0u));
 		uint32_t slot_w = 0, slot_l = 0;
@@ -128,6 +150,23 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 			}
 			tprev = aj;
 			x = xp;
+		} else if (kind == 3) {
+			// ---- pedigree slot run: physical exit index from the logical one, the record of the path's workgroup -> LDS
+			const uint32_t L = h[5], rec_words = h[6], f_exit = h[12];
+			const uint8_t* exit_slot = reinterpret_cast<const uint8_t*>(h + 16);
+			uint32_t pexit = 0;
+			for (uint32_t j = 0; j < f_exit; ++j) pexit |= ((x >> j) & 1u) << exit_slot[j];
+			slot_w = pexit >> L;
+			slot_l = pexit & ((1u << L) - 1u);
+			const uint32_t stage_words = rec_words / 2u;
+			const unsigned long long* __restrict__ gst = reinterpret_cast<const unsigned long long*>(
+				P.bt + (((unsigned long long)h[9] << 32) | h[8]) + (size_t)slot_w * rec_words * 4u);
+			unsigned long long sv[2];
+#pragma unroll
+			for (int u = 0; u < 2; ++u) { const uint32_t i = u * NT + lane; sv[u] = i < stage_words ? gst[i] : 0ull; }
+#pragma unroll
+			for (int u = 0; u < 2; ++u) { const uint32_t i = u * NT + lane; if (i < stage_words) stage[i] = sv[u]; }
+			for (uint32_t i = 2 * NT + lane; i < stage_words; i += NT) stage[i] = gst[i];
 		} else if (kind == 2) {
 			// ---- slot run (slots.h): physical exit index from the logical one, then the record of the workgroup the path
 			// runs through (the complement workgroup's when that half was not computed) -> LDS
@@ -211,6 +250,26 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 					path_trans[c0 + lane] = 0u;
 				}
 				if (lane == 0) { xshare[0] = xl; xshare[1] = 0u; }
+			}
+			__syncthreads();
+			x = xshare[0];
+			tprev = xshare[1];
+		}
+		if (kind == 3) {
+			if (lane < 64) {   // one wave follows the path
+				const uint32_t L = h[5], threads = h[7], tb = h[13];
+				const SlotBtCol* bcols = reinterpret_cast<const SlotBtCol*>(recs);
+				const uint32_t thand = pedslot_walk(bcols, reinterpret_cast<const uint8_t*>(stage), ncols, threads, tb, slot_l, tprev, cells, lane == 0);
+				__builtin_amdgcn_wave_barrier();
+				uint32_t xl = 0;
+				if (lane < ncols) {
+					const SlotBtCol& bc = bcols[lane];
+					const uint32_t pc = (slot_w << L) | cells[lane];
+					for (uint32_t j = 0; j < bc.k; ++j) xl |= ((pc >> bc.slot[j]) & 1u) << j;
+					path_index[c0 + lane] = xl;
+					path_trans[c0 + lane] = cells[64u + lane];
+				}
+				if (lane == 0) { xshare[0] = xl; xshare[1] = thand; }
 			}
 			__syncthreads();
 			x = xshare[0];
@@ -499,6 +558,40 @@ __device__ __forceinline__ uint32_t chunk_walk_unit(const DevProblem& P, const B
 		__syncthreads();
 		return xshare[0] | (xshare[1] << 28);
 	}
+	if (kind == 3) {
+		// ---- pedigree slot run: blob (column slot lists), physical exit index, record of the path's workgroup -> LDS
+		const uint32_t L = hdr[5], rec_words = hdr[6], threads = hdr[7], f_exit = hdr[12], tb = hdr[13];
+		const uint32_t* __restrict__ gblob = P.slot_blob + hdr[3];
+		for (uint32_t i = tid; i < hdr[11]; i += NT) blob[i] = gblob[i];
+		const uint8_t* exit_slot = reinterpret_cast<const uint8_t*>(hdr + 16);
+		uint32_t pexit = 0;
+		for (uint32_t j = 0; j < f_exit; ++j) pexit |= ((x >> j) & 1u) << exit_slot[j];
+		const uint32_t w = pexit >> L;
+		const unsigned long long* __restrict__ gst = reinterpret_cast<const unsigned long long*>(
+			P.bt + (((unsigned long long)hdr[9] << 32) | hdr[8]) + (size_t)w * rec_words * 4u);
+		for (uint32_t i = tid; i < rec_words / 2u; i += NT) stage[i] = gst[i];
+		__syncthreads();
+		const SlotBtCol* bcols = reinterpret_cast<const SlotBtCol*>(blob);
+		if (tid < 64) {
+			const uint32_t thand = pedslot_walk(bcols, reinterpret_cast<const uint8_t*>(stage), ncols, threads, tb, pexit & ((1u << L) - 1u), tprev, cells, tid == 0);
+			if (tid == 0) xshare[1] = thand;
+		}
+		__syncthreads();
+		for (uint32_t c = tid >> 6; c < ncols; c += NT >> 6) {
+			const SlotBtCol& bc = bcols[c];
+			const uint32_t pc = (w << L) | cells[c];
+			const uint32_t j = tid & 63u;
+			const bool bit = j < bc.k && j < 25u && ((pc >> bc.slot[j < 25u ? j : 0u]) & 1u);
+			const uint32_t xl = (uint32_t)__ballot(bit);
+			if (j == 0) {
+				path_index[c0 + c] = xl;
+				path_trans[c0 + c] = cells[64u + c];
+				if (c == 0) xshare[0] = xl;
+			}
+		}
+		__syncthreads();
+		return xshare[0] | (xshare[1] << 28);
+	}
 	// ---- slot run: blob (column slot lists + ending slots), physical exit index, record of the path's workgroup -> LDS
 	const uint32_t g = hdr[4], L = hdr[5], n_ends = hdr[6], threads = hdr[7], f_exit = hdr[12], lr = hdr[13];
 	const uint32_t* __restrict__ gblob = P.slot_blob + hdr[3];
@@ -590,6 +683,27 @@ __global__ __launch_bounds__(256) void backtrace_chunks(DevProblem P, const BtUn
 				unit_x[ch.unit_off] = x;
 			}
 			first = 1;
+		} else if (cu->kind == 3u) {
+			// pedigree slot run: the smallest entry of the exit column (key = value << 32 | exit index * T + t)
+			const unsigned long long* __restrict__ cand = P.spec_keys + (size_t)(ch.spec_id - 1u) * P.spec_stride;
+			unsigned long long best = ~0ull;
+			for (uint32_t i = tid; i < P.spec_stride; i += blockDim.x) best = min(best, cand[i]);
+#pragma unroll
+			for (int m = 1; m < 64; m <<= 1) {
+				const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)best, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(best >> 32), m);
+				best = min(best, ((unsigned long long)hi << 32) | lo);
+			}
+			unsigned long long* red = reinterpret_cast<unsigned long long*>(cells);
+			if ((tid & 63u) == 0) red[tid >> 6] = best;
+			__syncthreads();
+			for (uint32_t i = 0; i < (blockDim.x >> 6); ++i) best = min(best, red[i]);
+			const SlotBtUnit* su = reinterpret_cast<const SlotBtUnit*>(cu);
+			const uint32_t idx = (uint32_t)best >> su->lr, tt = (uint32_t)best & ((1u << su->lr) - 1u);   // (lr holds log2 T for these units)
+			x = 0;
+			for (uint32_t j = 0; j < su->f_exit; ++j) x |= ((idx >> su->exit_pos[j]) & 1u) << j;
+			x |= tt << 28;
+			if (tid == 0 && o == 0) guess[ci] = x;
+			x = bt_orient(ch, x, o);
 		} else if (cu->kind == 1u) {
 			// trio: the smallest entry (y, t) of the projection column this chunk's newest run left (key = value << 32 | y * 4 + t)
 			const unsigned long long* __restrict__ cand = P.spec_keys + (size_t)(ch.spec_id - 1u) * P.spec_stride;

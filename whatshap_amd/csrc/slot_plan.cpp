@@ -352,7 +352,8 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 	const auto tp3 = std::chrono::steady_clock::now();
 	for (size_t si = 0; si < plan.steps.size(); ++si) {
 		const uint32_t c0 = plan.steps[si].kind == 2 ? plan.runs[plan.steps[si].index].c0 : plan.steps[si].index;
-		if (si == 0 || p.b[c0] == 0) plan.component_first_step.push_back((uint32_t)si);
+		// (a pedigree table is ONE job: across a column no read spans the T transmission values still couple the two sides)
+		if (!ped && (si == 0 || p.b[c0] == 0)) plan.component_first_step.push_back((uint32_t)si);
 	}
 	if (ped) {
 		// a table that mostly falls back to per-column steps (genotypes not trusted: up to 16 forms per value) is better off
