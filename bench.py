@@ -15,6 +15,11 @@ Workloads (BASELINE.json `configs`):
 `python bench.py --gpus N` starts its N ranks itself (one process per GPU through torch.distributed.run on
 127.0.0.1) when it was not already launched by torchrun, and fails loudly when fewer than N devices are visible.
 
+At N = 1 with no workload flags the line also carries `configs`: the other single-GPU workloads of BASELINE.json
+(configs[1] 50 000 x coverage 15, configs[3] trio, three configs[4] blocks in flight) plus an irregular read layout
+(Poisson starts, geometric lengths: the planner's typical case rather than its best) and a quartet, each measured by a child
+`bench.py --workload NAME --sub` with its own value / ms_per_step / steps / roofline.frac / cpu_baseline sample.
+
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
   roofline      counter-based: the fraction of the chip's VALU issue slots the dominant kernel uses (the binding roof of
                 this integer min-plus path; no MFMA), next to the LDS-pipe and MEASURED HBM fractions.  The counters
@@ -44,6 +49,16 @@ CLOCK_GHZ = 2.4          # max shader clock
 N_SIMD = 1024            # 256 CUs x 4 SIMD-32
 N_CU = 256
 CONFIG4_BLOCKS, CONFIG4_VARIANTS, CONFIG4_SEED0 = 24, 100000, 100
+# named single-GPU workloads: flags they stand for
+WORKLOADS = {
+    "config1": dict(variants=50000, coverage=15),                                  # BASELINE configs[1]
+    "config2": dict(variants=200000, coverage=20),                                 # BASELINE configs[2] (the headline)
+    "config3": dict(trio=True, variants=100000, coverage=15),                      # BASELINE configs[3]
+    "blocks3": dict(variants=100000, coverage=20, blocks=3, in_flight=3),          # three configs[4] blocks in flight on one GPU
+    "irregular": dict(irregular=True, variants=100000, coverage=20),               # Poisson starts, geometric lengths (mean 16), coverage capped
+    "quartet": dict(quartet=True, variants=50000, coverage=13),                    # two trios sharing parents, T = 16
+}
+EXTRA_CONFIGS = ["config1", "config3", "blocks3", "irregular", "quartet"]
 
 
 def parse_args():
@@ -57,6 +72,13 @@ def parse_args():
     ap.add_argument("--blocks-per-gpu", type=int, default=None, help="weak-scaling mode: every rank gets this many blocks")
     ap.add_argument("--in-flight", type=int, default=4, help="blocks a rank keeps in flight at once")
     ap.add_argument("--trio", action="store_true", help="configs[3]-shaped workload (trio PedMEC, coverage 15) instead")
+    ap.add_argument("--quartet", action="store_true", help="two trios sharing their parents (T = 16), coverage 13")
+    ap.add_argument("--irregular", action="store_true", help="irregular read layout (whatshap_amd.synthetic.irregular_block, seed 7)")
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="a named workload (sets the flags above)")
+    ap.add_argument("--configs", default="auto", choices=["auto", "on", "off"],
+                    help="append the other single-GPU workloads as `configs` (auto: N=1 and no workload flags)")
+    ap.add_argument("--sub", action="store_true", help=argparse.SUPPRESS)   # child of the `configs` array: short counters, short CPU sample, no torch
+    ap.add_argument("--oversubscribe", action="store_true", help="allow more ranks than devices (rank r uses device r %% visible; tests)")
     ap.add_argument("--path", default="auto")
     ap.add_argument("--option", action="append", default=[], help="key=value passed to whamd_dptable_set_option")
     ap.add_argument("--cpu-baseline-columns", type=int, default=-1,
@@ -78,22 +100,44 @@ def resolve_workload(args, world):
     cov = args.coverage
     if args.trio and args.coverage == 20:
         cov = args.coverage = 15
+    if args.quartet and args.coverage == 20:
+        cov = args.coverage = 13
     if args.blocks_per_gpu is not None:
         v = args.variants or 200000
         blocks = [(3 + b, v) for b in range(world * args.blocks_per_gpu)]
         return blocks, "weak", f"{args.blocks_per_gpu} block(s) of {v} SNVs per GPU"
     if world == 1 and args.blocks is None:
-        v = args.variants or (100000 if args.trio else 200000)
+        v = args.variants or (100000 if args.trio else (50000 if args.quartet else 200000))
         tag = ""
         if not args.trio and v == 200000 and cov == 20:
             tag = " (BASELINE configs[2])"
         if args.trio and v == 100000 and cov == 15:
             tag = " (BASELINE configs[3])"
-        return [(4 if args.trio else 3, v)], "weak", f"1 block of {v} SNVs{tag}"
+        if args.irregular:
+            return [(7, v)], "weak", f"1 block of {v} SNVs, irregular read layout (Poisson starts, geometric lengths of mean {0.8 * cov:.0f}, seed 7)"
+        return [(4 if args.trio else (5 if args.quartet else 3), v)], "weak", f"1 block of {v} SNVs{tag}"
     n = args.blocks or CONFIG4_BLOCKS
     v = args.variants or CONFIG4_VARIANTS
     tag = " (BASELINE configs[4])" if (n == CONFIG4_BLOCKS and v == CONFIG4_VARIANTS and cov == 20 and not args.trio) else ""
     return [(CONFIG4_SEED0 + b, v) for b in range(n)], "strong", f"{n} independent blocks x {v} SNVs, LPT over {world} GPU(s){tag}"
+
+
+def build_block(args, seed, n_variants, n_columns_limit=None):
+    """The seeded block of the selected workload (optionally only its first columns: the CPU-baseline samples)."""
+    from whatshap_amd.synthetic import clip_to_columns, irregular_block, synthetic_block
+
+    if args.irregular:
+        p = irregular_block(n_variants, args.coverage, seed=seed)
+        return p if n_columns_limit is None else clip_to_columns(p, n_columns_limit)
+    return synthetic_block(n_variants, args.coverage, seed=seed, trio=args.trio, quartet=args.quartet, n_columns_limit=n_columns_limit)
+
+
+def workload_flags(args):
+    out = []
+    for flag in ("trio", "quartet", "irregular"):
+        if getattr(args, flag):
+            out.append("--" + flag)
+    return out
 
 
 def apply_options(table, args):
@@ -120,11 +164,10 @@ def reference_seconds(args, seed, n_columns):
     """Constructor + the three getters of the compiled reference (oracle/_ref; the C restatement if it is absent) on the
     first `n_columns` columns of the seeded ReadSet; single thread."""
     import oracle
-    from whatshap_amd.synthetic import synthetic_block
 
     kind = "reference" if oracle.have_reference() else "port"
     table_cls = oracle.ReferenceTable if kind == "reference" else oracle.OracleTable
-    problem = synthetic_block(args.variants_for_cpu, args.coverage, seed=seed, trio=args.trio, n_columns_limit=n_columns)
+    problem = build_block(args, seed, args.variants_for_cpu, n_columns_limit=n_columns)
     t0 = time.perf_counter()
     table = table_cls(problem)
     score = table.optimal_score()
@@ -142,7 +185,7 @@ def cpu_baseline(args, seed):
     if n_cpu < 0:
         tb, cb, _, _ = reference_seconds(args, seed, ramp + 24)
         per_col = max((tb - ta) / max(cb - ca, 1), 1e-6)
-        n_cpu = int(max(24, min(args.variants_for_cpu - ramp - 8, 15.0 / per_col)))
+        n_cpu = int(max(24, min(args.variants_for_cpu - ramp - 8, (4.0 if args.sub else 15.0) / per_col)))
     tc, cc, score, _ = reference_seconds(args, seed, ramp + 8 + n_cpu)
     steady_cols, steady_s = cc - ca, max(tc - ta, 1e-9)
     info = cpu_info()
@@ -151,7 +194,7 @@ def cpu_baseline(args, seed):
         "unit": "variant-columns/s",
         "cores": 1,
         "kind": kind,
-        "sample": f"columns {ca}..{cc} of the same seeded ReadSet (coverage {args.coverage}{', trio' if args.trio else ''}; all at full "
+        "sample": f"columns {ca}..{cc} of the same seeded ReadSet (coverage {args.coverage}{', trio' if args.trio else ''}{', quartet' if args.quartet else ''}{', irregular layout' if args.irregular else ''}; all at full "
                   f"coverage: the {ramp}-column ramp is timed separately and subtracted), constructor + 3 getters, {steady_s:.1f} s of "
                   f"{tc:.1f} s wall, optimal cost of the prefix {score}",
         "seconds": tc + ta,
@@ -165,7 +208,7 @@ def cpu_baseline_procs(args, procs):
     ramp = 2 * args.coverage
     cols = 16
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-sample-worker", str(cols), "--coverage", str(args.coverage),
-           "--variants", str(args.variants_for_cpu)] + (["--trio"] if args.trio else [])
+           "--variants", str(args.variants_for_cpu)] + workload_flags(args)
     t0 = time.perf_counter()
     children = [subprocess.Popen(cmd + ["--blocks", str(CONFIG4_SEED0 + i)], stdout=subprocess.PIPE, text=True) for i in range(procs)]
     rates = []
@@ -208,13 +251,15 @@ def run_pmc_passes(args, kernel_substring, keep_dir):
     if not os.path.exists(rocprof):
         return None, "rocprofv3 not found"
     inner = [sys.executable, os.path.abspath(__file__), "--pmc-inner", "--variants", str(args.pmc_variants), "--coverage", str(args.coverage),
-             "--path", args.path, "--steps", "1", "--warmup", "1"] + (["--trio"] if args.trio else [])
+             "--path", args.path, "--steps", "1", "--warmup", "1", "--configs", "off"] + workload_flags(args)
+    if args.blocks:
+        inner += ["--blocks", str(args.blocks), "--in-flight", str(args.in_flight)]
     for kv in args.option:
         inner += ["--option", kv]
     env = dict(os.environ, TMPDIR="/tmp")
     averages, counts, notes = {}, {}, []
     os.makedirs(keep_dir, exist_ok=True)
-    for name, counters in PMC_PASSES:
+    for name, counters in (PMC_PASSES[:1] if args.sub else PMC_PASSES):
         out_dir = tempfile.mkdtemp(prefix=f"whamd_pmc_{name}_", dir="/tmp")
         cmd = [rocprof, "--kernel-trace", "--pmc"] + counters.split() + ["--output-format", "csv", "-d", out_dir, "-o", "p", "--"] + inner
         try:
@@ -309,7 +354,7 @@ def self_launch(args):
     from whatshap_amd import _native
 
     visible = _native.device_count()
-    if visible < args.gpus:
+    if visible < args.gpus and not args.oversubscribe:
         raise SystemExit(f"bench.py --gpus {args.gpus}: only {visible} HIP device(s) visible; refusing to run fewer ranks than asked for")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -321,10 +366,62 @@ def self_launch(args):
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
+def dominant_kernel(args):
+    if args.path in ("column", "column_keys"):
+        return "column_step_fused"
+    if args.trio or args.quartet:
+        return "resident_segment_ped" if args.path == "resident" else "pedslot_run"
+    return "resident_segment" if args.path == "resident" else "slot_run"
+
+
+def run_extra_configs(args):
+    """The other single-GPU workloads, one child process each (own tables, own counters, own CPU sample)."""
+    out = []
+    for name in EXTRA_CONFIGS:
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--sub", "--steps", str(max(2, min(args.steps, 3))), "--warmup", "1",
+               "--configs", "off", "--pmc", args.pmc, "--pmc-keep", os.path.join(args.pmc_keep, name)]
+        if args.cpu_baseline_columns == 0:
+            cmd += ["--cpu-baseline-columns", "0"]
+        t0 = time.perf_counter()
+        try:
+            res = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+            line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+            if res.returncode != 0 or not line:
+                out.append({"name": name, "error": f"rc={res.returncode} {res.stderr[-300:]}"})
+                continue
+            full = json.loads(line[-1])
+        except Exception as exc:  # noqa: BLE001 -- the headline must come out whatever a child does
+            out.append({"name": name, "error": repr(exc)})
+            continue
+        roof = full.get("roofline", {})
+        entry = {
+            "name": name,
+            "workload": full["config"]["workload"],
+            "value": full["value"],
+            "unit": full["unit"],
+            "ms_per_step": full["ms_per_step"],
+            "steps": full["steps"],
+            "bipartition_costs_per_s": full["bipartition_costs_per_s"],
+            "optimal_cost_checksum": full["config"]["optimal_cost_checksum"],
+            "forward_launches_per_step": full["rank0"]["forward_launches_per_step"],
+            "roofline": {k: roof.get(k) for k in ("bound", "kernel", "frac", "avg_launch_us", "peak", "unit", "pmc_note")},
+            "wall_s": time.perf_counter() - t0,
+        }
+        if "cpu_baseline" in full:
+            entry["cpu_baseline"] = {k: full["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind", "sample")}
+            entry["speedup_vs_cpu_baseline_device_only"] = full["value"] / full["cpu_baseline"]["value"]
+        out.append(entry)
+    return out
+
+
 def main():
     args = parse_args()
     if args.cpu_sample_worker:
         return cpu_sample_worker(args)
+    explicit = any(a in sys.argv[1:] for a in ("--workload", "--trio", "--quartet", "--irregular", "--variants", "--coverage", "--blocks", "--blocks-per-gpu", "--path", "--option"))
+    if args.workload:
+        for key, value in WORKLOADS[args.workload].items():
+            setattr(args, key, value)
     import __graft_entry__ as entry
 
     if not os.path.exists(os.path.join(ROOT, "whatshap_amd", "libwhatshap_amd.so")):
@@ -338,33 +435,40 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
-    import torch  # device selection, synchronisation and the rendezvous only
-
     from whatshap_amd import _native
     from whatshap_amd.blocks import assign_blocks, block_weight
-    from whatshap_amd.synthetic import synthetic_block
 
-    if not torch.cuda.is_available() or _native.device_count() < 1:
+    child = args.sub or args.pmc_inner   # children of this script: every table waits on its own stream, torch is not needed
+    torch = None
+    if not child:
+        import torch  # device selection, synchronisation and the rendezvous only
+
+    visible = _native.device_count()
+    if visible < 1 or (torch is not None and not torch.cuda.is_available()):
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    if local_rank >= _native.device_count():
-        raise SystemExit(f"rank {rank}: device {local_rank} requested, {_native.device_count()} visible")
-    torch.cuda.set_device(local_rank)
+    device = local_rank % visible if args.oversubscribe else local_rank
+    if device >= visible:
+        raise SystemExit(f"rank {rank}: device {local_rank} requested, {visible} visible")
+    if torch is not None:
+        torch.cuda.set_device(device)
     dist = None
     if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run (also with one rank, to exercise the path)
         import torch.distributed as dist
 
+        # gloo: the data path has no collective (north_star: host-side work queue, no RCCL); the rendezvous only carries the
+        # barrier, the max-over-ranks time and the per-rank checksums -- host tensors
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="gloo")
 
     blocks, scaling, workload = resolve_workload(args, world)
-    T = 4 if args.trio else 1
+    T = 4 if args.trio else (16 if args.quartet else 1)
     weights = [block_weight(v, args.coverage, T) for _, v in blocks]
     mine = assign_blocks(weights, world)[rank]
     tables = []
     for b in mine:
         seed, v = blocks[b]
-        problem = synthetic_block(v, args.coverage, seed=seed, trio=args.trio)
-        t = _native.NativeTable(problem, device=local_rank, path=None if args.path == "auto" else args.path, solve=False)
+        problem = build_block(args, seed, v)
+        t = _native.NativeTable(problem, device=device, path=None if args.path == "auto" else args.path, solve=False)
         apply_options(t, args)
         tables.append(t)
 
@@ -378,10 +482,12 @@ def main():
                 t.wait()
 
     def sync():
-        torch.cuda.synchronize()
+        if torch is not None:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if torch is not None:
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -404,14 +510,22 @@ def main():
     stats = [t.stats() for t in tables]
     totals = [float(sum(s["n_columns"] for s in stats)), float(sum(s["n_costs"] for s in stats)), float(sum(t.optimal_score() for t in tables))]
     per_rank_checksums = [int(totals[2])]
+    # what a SCALE record can be audited with: which rank ran which blocks on which device, and for how long
+    print(f"[bench rank {rank}/{world}] device {device}, blocks {[blocks[b][0] for b in mine]} (seeds), {len(mine)} table(s), "
+          f"{elapsed:.3f} s for {args.steps} step(s), cost checksum {int(totals[2])}", file=sys.stderr, flush=True)
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        import torch as _torch
+
+        tmax = _torch.tensor([elapsed], dtype=_torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         gathered = [None] * world
-        dist.all_gather_object(gathered, totals)
+        dist.all_gather_object(gathered, totals + [float(device)])
         per_rank_checksums = [int(g[2]) for g in gathered]
+        per_rank_devices = [int(g[3]) for g in gathered]
         totals = [sum(g[i] for g in gathered) for i in range(3)]
+    else:
+        per_rank_devices = [device]
     cols_job, costs_job = totals[0], totals[1]
 
     if rank == 0:
@@ -419,13 +533,16 @@ def main():
         bytes_rank = sum(s["algorithmic_bytes"] for s in stats)
         bytes_per_launch = bytes_rank / max(launches / args.steps, 1)
         column_path = args.path in ("column", "column_keys")
-        kernel = ("column_step_fused" if column_path else ("resident_segment_ped" if args.trio else
-                  ("resident_segment" if args.path == "resident" else "slot_run")))
+        kernel = dominant_kernel(args)
+        kind = "synthetic trio PedMEC" if args.trio else ("synthetic quartet PedMEC (two trios sharing parents)" if args.quartet else "synthetic diploid single-individual")
         out = {
             "metric": "variant-columns/sec at max-coverage %d (bipartition-costs/sec reported alongside)" % args.coverage,
             "value": cols_job * args.steps / elapsed,
             "unit": "variant-columns/s",
             "bipartition_costs_per_s": costs_job * args.steps / elapsed,
+            "bipartition_costs_note": ("sum over columns of 2^k_c * T (SURVEY.md 8d metric 2), credited in full: for a single individual the "
+                                       "kernels EVALUATE only half of them, the other half follows from the complement symmetry D[~x] = D[x]")
+                                      if T == 1 else "sum over columns of 2^k_c * T (SURVEY.md 8d metric 2); every one is evaluated",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -436,9 +553,11 @@ def main():
             "dtype": "u32",
             "data": "synthetic",
             "config": {
-                "workload": ("synthetic trio PedMEC" if args.trio else "synthetic diploid single-individual") + f", max-coverage {args.coverage}: " + workload,
+                "workload": kind + f", max-coverage {args.coverage}: " + workload,
                 "blocks": len(blocks),
                 "blocks_per_rank": [len(r) for r in assign_blocks(weights, world)],
+                "block_seeds_per_rank": [[blocks[b][0] for b in r] for r in assign_blocks(weights, world)],
+                "device_per_rank": per_rank_devices,
                 "blocks_in_flight_per_gpu": min(args.in_flight, len(mine)),
                 "max_coverage": args.coverage,
                 "transmission_values": T,
@@ -446,16 +565,17 @@ def main():
                 "options": args.option,
                 "optimal_cost_checksum": int(totals[2]),
                 "optimal_cost_checksum_per_rank": per_rank_checksums,
+                "rendezvous": "gloo (barrier, max-over-ranks time, checksums; no collective on the data path)" if dist is not None else "none",
             },
             "rank0": {"forward_ms_per_step": fwd_ms / args.steps, "backtrace_ms_per_step": bt_ms / args.steps,
                       "forward_launches_per_step": launches / args.steps},
         }
         # ---- a fresh table end to end (host-inclusive): create + solve + getters
-        if world == 1:
+        if world == 1 and not args.sub:
             seed, v = blocks[mine[0]]
-            problem = synthetic_block(v, args.coverage, seed=seed, trio=args.trio)
+            problem = build_block(args, seed, v)
             te0 = time.perf_counter()
-            fresh = _native.NativeTable(problem, device=local_rank, path=None if args.path == "auto" else args.path, solve=False)
+            fresh = _native.NativeTable(problem, device=device, path=None if args.path == "auto" else args.path, solve=False)
             apply_options(fresh, args)
             te1 = time.perf_counter()
             fresh.solve()
@@ -487,6 +607,11 @@ def main():
         procs = args.cpu_baseline_procs if args.cpu_baseline_procs >= 0 else (os.cpu_count() or 1)
         if world == 1 and procs > 0:
             out["cpu_baseline_all_cores"] = cpu_baseline_procs(args, procs)
+        # ---- the other single-GPU workloads of BASELINE.json (+ an irregular layout, + a quartet)
+        if args.configs == "on" or (args.configs == "auto" and world == 1 and not explicit and not args.sub):
+            for t in tables:
+                t.release_device()
+            out["configs"] = run_extra_configs(args)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -17,7 +17,7 @@ def _bench():
 
 
 def _args(**kw):
-    base = dict(coverage=20, trio=False, blocks=None, blocks_per_gpu=None, variants=None, pmc_variants=8000)
+    base = dict(coverage=20, trio=False, quartet=False, irregular=False, blocks=None, blocks_per_gpu=None, variants=None, pmc_variants=8000, sub=False)
     base.update(kw)
     return types.SimpleNamespace(**base)
 
@@ -34,6 +34,36 @@ def test_workload_follows_baseline_configs():
     assert len(blocks) == 6 and scaling == "weak"
     blocks, _, text = b.resolve_workload(_args(trio=True), 1)
     assert blocks == [(4, 100000)] and "configs[3]" in text
+    # the named workloads of the `configs` array
+    assert set(b.EXTRA_CONFIGS) <= set(b.WORKLOADS) and "config2" not in b.EXTRA_CONFIGS   # the headline is not measured twice
+    blocks, _, text = b.resolve_workload(_args(**b.WORKLOADS["config1"]), 1)
+    assert blocks == [(3, 50000)]
+    blocks, scaling, text = b.resolve_workload(_args(**{k: v for k, v in b.WORKLOADS["blocks3"].items() if k != "in_flight"}), 1)
+    assert [v for _, v in blocks] == [100000] * 3 and [s for s, _ in blocks] == [100, 101, 102]
+    blocks, _, text = b.resolve_workload(_args(**b.WORKLOADS["irregular"]), 1)
+    assert blocks == [(7, 100000)] and "irregular" in text
+    a = _args(**b.WORKLOADS["quartet"])
+    blocks, _, text = b.resolve_workload(a, 1)
+    assert blocks == [(5, 50000)] and a.coverage == 13
+    assert b.dominant_kernel(_args(trio=True, path="auto")) == "pedslot_run" and b.dominant_kernel(_args(path="auto")) == "slot_run"
+    assert b.dominant_kernel(_args(trio=True, path="resident")) == "resident_segment_ped"
+
+
+def test_irregular_workload_is_seeded_and_clips_to_a_prefix():
+    import numpy as np
+
+    from whatshap_amd.synthetic import clip_to_columns, irregular_block
+
+    p, q = irregular_block(3000, 12, seed=7), irregular_block(3000, 12, seed=7)
+    assert (p.read_ptr == q.read_ptr).all() and (p.var_position == q.var_position).all() and (p.var_allele == q.var_allele).all()
+    lengths = np.diff(p.read_ptr)
+    assert lengths.min() >= 2 and lengths.std() > 2          # geometric lengths, not one length
+    prefix = clip_to_columns(p, 100)
+    assert prefix.n_variants == 100 and prefix.var_position.max() <= prefix.positions[-1] and np.diff(prefix.read_ptr).min() >= 2
+    from whatshap_amd import _native
+
+    s = _native.plan_summary(p)
+    assert s["invariants_ok"] == 1 and s["max_coverage"] <= 12 and s["n_resident_columns"] > 0.9 * 3000
 
 
 def test_gpus_without_devices_is_refused():

@@ -105,9 +105,10 @@ def test_windowed_solve_equals_the_unrestricted_solve(kw, path, limit):
 def test_windowed_trio_equals_the_unrestricted_solve():
     p = synthetic_block(n_variants=1500, coverage=5, seed=21, trio=True)
     base = solve(p, "auto", "1")
-    for limit in (1 << 20, 1 << 17):
-        got = solve(p, "auto", "1", arena_limit_bytes=limit)
-        assert got == base, (limit, first_difference(base, got))
+    for path in ("auto", "resident"):
+        for limit in (1 << 20, 1 << 17):
+            got = solve(p, path, "1", arena_limit_bytes=limit)
+            assert got == base, (path, limit, first_difference(base, got))
 
 
 def test_windowed_table_of_many_connected_components():
@@ -175,5 +176,6 @@ def test_trio_tables_long_enough_for_chunks_vs_oracle(kw):
     distrusted genotypes (more terms than registers: the pool path), a step-3 read layout, noisy data with many BLANK entries."""
     p = synthetic_block(**kw)
     want = table_solution(oracle.OracleTable(p))
-    got = solve(p, "auto", "1")
-    assert got == want, first_difference(want, got)
+    for path in ("auto", "resident"):   # pedigree slot runs (where the cost forms fit), LDS-resident trio runs
+        got = solve(p, path, "1")
+        assert got == want, (path, first_difference(want, got))

@@ -311,7 +311,7 @@ def test_irregular_trio_reads_vs_oracle(seed):
     scattered over the index, recombination costs vary per column; both device paths must equal the oracle."""
     p = _irregular_problem(seed, 260, True, 12)
     want = table_solution(oracle.OracleTable(p))
-    for path in ("auto", "column"):
+    for path in ("auto", "resident", "column"):   # pedigree slot runs, LDS-resident trio runs, per-column kernels
         got = native_solution(p, path)
         assert got == want, (path, first_difference(want, got))
     s = _native.plan_summary(p)
@@ -467,10 +467,11 @@ def test_resident_kernel_variants_trio(seed):
     }
     for name, p in variants.items():
         want = table_solution(oracle.OracleTable(p))
-        for path in ("auto", "column"):
+        for path in ("auto", "resident", "column"):
             got = native_solution(p, path)
             assert got == want, (name, path, first_difference(want, got))
         assert _native.plan_summary(p)["n_resident_columns"] > 200, name
+        assert _native.plan_summary(p, "resident")["n_resident_columns"] > 200, name
     # weights so large that the per-individual sums leave the 24-bit range of the term evaluation: the planner must keep
     # those columns away from the run kernel, and the result must still be exact
     small = synthetic_block(n_variants=40, coverage=10, seed=seed, trio=True)
@@ -646,6 +647,33 @@ def test_two_ranks_on_the_device_path():
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "BLOCKS_OK" in res.stdout
+
+
+def test_bench_with_two_ranks_on_one_device_matches_a_single_rank():
+    """`bench.py --gpus 2` (both ranks on device 0: --oversubscribe) at reduced size: gloo rendezvous, LPT assignment of the
+    blocks, no collective on the data path -- the per-rank cost checksums must add up to a single-rank solve of the same
+    blocks, every block on exactly one rank."""
+    import json, os, subprocess, sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--variants", "4000", "--blocks", "6", "--coverage", "14", "--steps", "1", "--warmup", "1", "--pmc", "off", "--cpu-baseline-columns", "0"]
+    lines = []
+    for gpus in (1, 2):
+        res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--oversubscribe"] + common,
+                             capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        lines.append(json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]))
+        if gpus == 2:
+            assert res.stderr.count("[bench rank") == 2   # every rank reports its device, blocks and wall time
+    one, two = lines
+    assert one["config"]["blocks"] == two["config"]["blocks"] == 6 and two["n_gpus"] == 2 and two["scaling"] == "strong"
+    assert sorted(sum(two["config"]["block_seeds_per_rank"], [])) == sorted(sum(one["config"]["block_seeds_per_rank"], []))
+    assert len(two["config"]["optimal_cost_checksum_per_rank"]) == 2 and all(c > 0 for c in two["config"]["optimal_cost_checksum_per_rank"])
+    assert sum(two["config"]["optimal_cost_checksum_per_rank"]) == one["config"]["optimal_cost_checksum"] == two["config"]["optimal_cost_checksum"]
+    assert "gloo" in two["config"]["rendezvous"]
+    # per-rank checksums against single-rank solves of exactly those blocks
+    for seeds, checksum in zip(two["config"]["block_seeds_per_rank"], two["config"]["optimal_cost_checksum_per_rank"]):
+        assert checksum == sum(_native.NativeTable(synthetic_block(4000, 14, seed=s)).optimal_score() for s in seeds)
 
 
 def test_shim_with_compiled_ingestion_on_plain_reference_objects():

@@ -1,0 +1,112 @@
+"""GPU (-m gpu): the pedigree slot runs (kernels_pedslots.h; T = 4 and T = 16) through the C ABI against the oracle --
+synthetic quartets and double trios at coverage 9-11 over several hundred columns, Mendelian-consistent mixed genotypes,
+tie-heavy weights, many recombination events, irregular read layouts, the windowed solve, and the older paths they
+replaced (LDS-resident trio runs, per-column kernels) on the same inputs.  Bit-exact (integer path)."""
+import numpy as np
+import pytest
+
+import oracle
+from helpers import first_difference, native_solution, table_solution
+from whatshap_amd import _native
+from whatshap_amd.synthetic import synthetic_block
+
+pytestmark = pytest.mark.gpu
+
+
+def _with(p, quality=None, recomb=None):
+    return _native.ProblemArrays(p.read_ptr, p.var_position, p.var_allele, p.var_quality if quality is None else quality, p.read_sample_id,
+                                 p.individual_id, p.triple_ids, p.genotype.reshape(p.n_individuals, p.n_variants), None,
+                                 p.recombcost if recomb is None else recomb, p.positions, False, n_variants=p.n_variants)
+
+
+def solve(problem, path="auto", **options):
+    t = _native.NativeTable(problem, solve=False, path=path)
+    for k, v in options.items():
+        t.set_option(k, str(v))
+    t.solve()
+    out = table_solution(t)
+    stats = t.stats()
+    t.close()
+    return out, stats
+
+
+QUARTETS = [
+    dict(n_variants=320, coverage=9, seed=71, quartet=True),
+    dict(n_variants=300, coverage=10, seed=72, quartet=True, mixed_genotypes=True),
+    dict(n_variants=300, coverage=11, seed=73, quartet=True, step=1),
+    dict(n_variants=400, coverage=8, seed=74, quartet=True, error_rate=0.15, drop_rate=0.3),
+    dict(n_variants=300, coverage=9, seed=75, two_trios=True),
+    dict(n_variants=300, coverage=10, seed=76, two_trios=True, mixed_genotypes=True),
+]
+
+
+@pytest.mark.parametrize("kw", QUARTETS, ids=str)
+def test_quartets_and_double_trios_vs_oracle(kw):
+    """T = 16 at coverage >= 9 over >= 300 columns (the table is long enough for the chunked backtrace with its
+    orientations): pedigree slot runs == oracle == per-column kernels, with far fewer launches."""
+    p = synthetic_block(**kw)
+    want = table_solution(oracle.OracleTable(p))
+    got, stats = solve(p)
+    assert got == want, first_difference(want, got)
+    col, col_stats = solve(p, "column")
+    assert col == want, first_difference(want, col)
+    assert stats["forward_launches"] * 2 < col_stats["forward_launches"], (stats["forward_launches"], col_stats["forward_launches"])
+
+
+@pytest.mark.parametrize("kw", [dict(n_variants=500, coverage=10, seed=81, quartet=True), dict(n_variants=600, coverage=11, seed=82, trio=True),
+                                dict(n_variants=400, coverage=9, seed=83, two_trios=True, mixed_genotypes=True)], ids=str)
+def test_tie_heavy_weights_and_cheap_recombination(kw):
+    """Two-valued weights and recombination costs of 0 / 1 / 2: nearly every minimum is a tie (Gray-rank rule between the
+    cells of a pair, lowest previous transmission value in the butterfly) and the optimal path switches transmission values."""
+    b = synthetic_block(**kw)
+    p = _with(b, quality=(1 + (b.var_quality % 2)).astype(np.uint32), recomb=(b.recombcost % 3).astype(np.uint32))
+    want = table_solution(oracle.OracleTable(p))
+    got, _ = solve(p)
+    assert got == want, first_difference(want, got)
+    if kw.get("trio"):
+        res, _ = solve(p, "resident")
+        assert res == want, first_difference(want, res)
+
+
+def test_many_recombination_events_in_a_quartet():
+    b = synthetic_block(n_variants=700, coverage=10, seed=85, quartet=True, error_rate=0.12)
+    p = _with(b, recomb=np.ones_like(b.recombcost))
+    want = table_solution(oracle.OracleTable(p))
+    assert len(set(want["transmission"])) > 2
+    got, _ = solve(p)
+    assert got == want, first_difference(want, got)
+
+
+@pytest.mark.parametrize("slot_l", [4, 5, 6])
+def test_fewer_local_slots(slot_l):
+    """Narrower workgroups (1 - 4 waves): more grid slots, other exchange layouts, other wave-slot / lane-slot splits."""
+    p = synthetic_block(n_variants=260, coverage=10, seed=86, trio=True, mixed_genotypes=True)
+    want = table_solution(oracle.OracleTable(p))
+    got, _ = solve(p, slot_l=slot_l)
+    assert got == want, first_difference(want, got)
+
+
+def test_windowed_quartet_equals_the_unrestricted_solve():
+    p = synthetic_block(n_variants=1500, coverage=7, seed=87, quartet=True)
+    base, st0 = solve(p)
+    for limit in (1 << 21, 1 << 18):
+        got, st = solve(p, arena_limit_bytes=limit)
+        assert got == base, (limit, first_difference(base, got))
+        assert st["forward_launches"] > st0["forward_launches"], "the arena limit did not force a windowed solve"
+
+
+def test_untrusted_genotypes_fall_back_to_the_older_runs():
+    """9 cost forms per transmission value do not fit the form tables: the planner declines, the LDS-resident trio runs take over."""
+    p = synthetic_block(n_variants=400, coverage=9, seed=88, trio=True, distrust_genotypes=True)
+    want = table_solution(oracle.OracleTable(p))
+    got, _ = solve(p)
+    assert got == want, first_difference(want, got)
+
+
+def test_full_size_trio_old_and_new_runs_agree():
+    """BASELINE configs[3] at full size: pedigree slot runs == LDS-resident trio runs on every output."""
+    p = synthetic_block(n_variants=100000, coverage=15, seed=4, trio=True)
+    new, st_new = solve(p)
+    old, st_old = solve(p, "resident")
+    assert new == old, first_difference(old, new)
+    assert st_new["total_ms"] < st_old["total_ms"]

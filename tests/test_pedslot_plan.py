@@ -62,6 +62,16 @@ def test_synthetic_quartet_blocks(seed):
             assert run_columns > 0.6 * p.n_variants, (kw, run_columns)
 
 
+@pytest.mark.parametrize("seed", range(2))
+def test_two_unrelated_trios_need_four_forms_per_value(seed):
+    """Six individuals, four founders: 2^4 allele assignments, two children's constraints leave 4 -- the NF = 4 tables."""
+    for kw in (dict(coverage=6), dict(coverage=8, mixed_genotypes=True)):
+        p = synthetic_block(n_variants=60, seed=20 + seed, two_trios=True, **kw)
+        ok, run_columns = agrees(p)
+        assert ok, (seed, kw)
+        assert run_columns > 0.6 * p.n_variants, (kw, run_columns)
+
+
 def test_not_for_a_single_individual_or_untrusted_genotypes():
     single = synthetic_block(n_variants=40, coverage=6, seed=1)
     with pytest.raises(_native.SolverError) as e:

@@ -154,7 +154,8 @@ struct DeviceTable::Impl {
 	// slot runs (slots.h): the default forward path of a single individual
 	SlotPlan splan;
 	bool use_slots = false;
-	int slot_l = 11;            // preferred number of local slots (lr + 6 .. lr + 9)
+	int slot_l = 11;            // preferred number of local slots (lr + 6 .. lr + 9; pedigree runs: 6 - log2 T .. + 3, only when set explicitly)
+	bool slot_l_set = false;
 	int slot_lr = 2;            // reg slots: 4 cells per thread -> 8 waves per workgroup at 11 local slots (two waves per SIMD)
 	std::vector<SlotBatchEntry> slot_entries;   // (pedigree runs: `pad` holds the run's index into splan.pextra)
 	SlotBatchEntry* d_slot_entries = nullptr;
@@ -265,7 +266,7 @@ void DeviceTable::set_l_pref(int l) { impl_->l_pref = std::max(4, std::min(l, RE
 void DeviceTable::set_lanes(int n) { impl_->max_lanes = n < 1 ? 1 : (n > 64 ? 64 : n); }
 
 void DeviceTable::set_fold(bool v) { impl_->fold = v; }
-void DeviceTable::set_slot_l(int l) { impl_->slot_l = std::max(8, std::min(l, 12)); }
+void DeviceTable::set_slot_l(int l) { impl_->slot_l = std::max(2, std::min(l, 12)); impl_->slot_l_set = true; }
 void DeviceTable::set_slot_lr(int lr) { impl_->slot_lr = lr >= 3 ? 3 : 2; }
 
 void DeviceTable::set_arena_limit(uint64_t bytes) { impl_->arena_limit = bytes; }
@@ -303,7 +304,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	const auto tu0 = std::chrono::steady_clock::now();
 	size_t free_b = 0, total_b = 0;
 	HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-	m.use_slots = (m.path == "auto" || m.path == "slots") && plan_forward_slots(p, m.slot_l, m.symmetry, m.splan, m.slot_lr);
+	m.use_slots = (m.path == "auto" || m.path == "slots") && plan_forward_slots(p, p.T > 1 ? (m.slot_l_set ? -m.slot_l : 0) : std::max(8, m.slot_l), m.symmetry, m.splan, m.slot_lr);
 	// pedigree slot runs keep their cost-form tables in HBM (slots.h): at most a quarter of what is free, else the older paths
 	if (m.use_slots && m.splan.ped && m.splan.table_words * 4ull > free_b / 4) m.use_slots = false;
 	m.table_bytes = m.use_slots && m.splan.ped ? m.splan.table_words * 4ull : 0ull;
@@ -325,6 +326,8 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 				const SlotRun& r = m.splan.runs[st.index];
 				fprintf(stderr, "[plan] slot run c0=%u ncols=%u g=%u L=%u half=%u ends=%u has_prev=%u in_identity=%u in_half=%u mirror_pos=%u in_occ=%x out_occ=%x mirror_out=%u\n",
 				        r.c0, r.ncols, r.g, r.L, r.half, r.n_ends, r.has_prev, r.in_identity, r.in_half, r.in_mirror_pos, r.in_occ, r.out_occ, r.mirror_out);
+				if (m.splan.ped) fprintf(stderr, "[plan]   pedigree run: T=%u forms per value=%u table words=%u record words per workgroup=%u\n", 1u << m.splan.pextra[st.index].tb,
+				                         m.splan.pextra[st.index].nf, m.splan.pextra[st.index].s_off + r.ncols * 64u * m.splan.pextra[st.index].nf, m.splan.pextra[st.index].rec_words);
 				continue;
 			}
 			const ResSegment& sgm = m.plan.segments[st.index];

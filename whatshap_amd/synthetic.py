@@ -42,10 +42,11 @@ def uniform_recombination_costs(positions, recombrate: float = 1.26) -> np.ndarr
 def synthetic_block(n_variants: int, coverage: int, seed: int, step: int = 2, trio: bool = False,
                     distrust_genotypes: bool = False, error_rate: float = 0.02, drop_rate: float = 0.10,
                     n_columns_limit: Optional[int] = None, quartet: bool = False,
-                    mixed_genotypes: bool = False) -> ProblemArrays:
+                    mixed_genotypes: bool = False, two_trios: bool = False) -> ProblemArrays:
     """One connected phasing block.  ``n_columns_limit`` keeps only the first columns of the SAME
     ReadSet (reads are clipped to the prefix), for bounded CPU-baseline samples.
     ``quartet``: two trios sharing their parents (T = 16), reads round-robin over the four individuals.
+    ``two_trios``: two unrelated trios in one table (T = 16, six individuals, four founders: up to 4 cost forms per value).
     ``mixed_genotypes`` (pedigrees): Mendelian-consistent random genotypes instead of all-heterozygous ones."""
     rng = np.random.default_rng(seed)
     n = int(n_variants)
@@ -88,21 +89,22 @@ def synthetic_block(n_variants: int, coverage: int, seed: int, step: int = 2, tr
     n_cols = n if n_columns_limit is None else min(n, n_columns_limit)
     positions = (1000 * (np.arange(n_cols, dtype=np.int64) + 1)).astype(np.uint32)
     var_position = (1000 * (var_idx + 1)).astype(np.int32)
-    if trio or quartet:
-        n_ind = 4 if quartet else 3
+    if trio or quartet or two_trios:
+        n_ind = 6 if two_trios else (4 if quartet else 3)
         sample = (np.arange(n_reads) % n_ind).astype(np.int32)  # father, mother, child (, second child) round-robin
         individual_id = np.arange(n_ind, dtype=np.uint32)
-        triples = np.array([0, 1, 2, 0, 1, 3] if quartet else [0, 1, 2], dtype=np.uint32)
+        triples = np.array([0, 1, 2, 3, 4, 5] if two_trios else ([0, 1, 2, 0, 1, 3] if quartet else [0, 1, 2]), dtype=np.uint32)
         genotype = np.ones((n_ind, n_cols), dtype=np.uint8)
         if mixed_genotypes:
             grng = np.random.default_rng(seed + 7919)
-            fa = grng.integers(0, 2, size=(2, n_cols))
-            mo = grng.integers(0, 2, size=(2, n_cols))
-            genotype[0] = fa.sum(axis=0)
-            genotype[1] = mo.sum(axis=0)
             cols = np.arange(n_cols)
-            for child in range(2, n_ind):
-                genotype[child] = fa[grng.integers(0, 2, size=n_cols), cols] + mo[grng.integers(0, 2, size=n_cols), cols]
+            for fam in range(0, n_ind, 3) if two_trios else (0,):
+                fa = grng.integers(0, 2, size=(2, n_cols))
+                mo = grng.integers(0, 2, size=(2, n_cols))
+                genotype[fam] = fa.sum(axis=0)
+                genotype[fam + 1] = mo.sum(axis=0)
+                for child in range(fam + 2, fam + 3 if two_trios else n_ind):
+                    genotype[child] = fa[grng.integers(0, 2, size=n_cols), cols] + mo[grng.integers(0, 2, size=n_cols), cols]
         recomb = np.zeros(n_cols, dtype=np.uint32)
         if n_cols > 1:
             recomb[1:] = round(centimorgen_to_phred(1000 * 1e-6 * 1.26))
@@ -116,6 +118,85 @@ def synthetic_block(n_variants: int, coverage: int, seed: int, step: int = 2, tr
         gl = np.tile(np.array([30.0, 0.0, 30.0]), (1, n_cols, 1)) if distrust_genotypes else None
     return ProblemArrays(read_ptr, var_position, allele, quality, sample, individual_id, triples, genotype, gl,
                          recomb, positions, distrust_genotypes, n_variants=n_cols)
+
+
+def irregular_block(n_variants: int, coverage: int, seed: int, mean_length: Optional[float] = None,
+                    error_rate: float = 0.02, drop_rate: float = 0.10) -> ProblemArrays:
+    """A single-individual block whose read layout is NOT the planner's best case: reads start at random (Poisson
+    number of new reads per variant), lengths are geometric (mean ``mean_length`` variants, default 0.8 * coverage, at
+    least 2), and a read that would push the physical coverage of any column it spans beyond ``coverage`` is not
+    generated (what read selection guarantees, whatshap/readselect.pyx:140-145).  Same allele / quality / BLANK model as
+    ``synthetic_block``.  bench.py's irregular-layout line uses seed 7."""
+    rng = np.random.default_rng(seed)
+    n = int(n_variants)
+    mean_len = float(mean_length) if mean_length else 0.8 * coverage
+    lam = 1.15 * coverage / mean_len          # a little more than the cap admits: the cap binds most of the time
+    n_new = rng.poisson(lam, size=n)
+    cov = np.zeros(n + 1, dtype=np.int32)      # difference array of the physical coverage
+    active_end: List[int] = []
+    starts, ends = [], []
+    p_stop = 1.0 / max(mean_len - 1.0, 1.0)
+    running = 0
+    import heapq
+    for i in range(n - 1):
+        while active_end and active_end[0] <= i:
+            heapq.heappop(active_end)
+        running = len(active_end)
+        for _ in range(int(n_new[i])):
+            if running >= coverage:
+                break
+            length = 2 + int(rng.geometric(p_stop)) - 1
+            e = min(i + length, n)
+            if e - i < 2:
+                continue
+            starts.append(i)
+            ends.append(e)
+            heapq.heappush(active_end, e)
+            running += 1
+    starts = np.asarray(starts, dtype=np.int64)
+    ends = np.asarray(ends, dtype=np.int64)
+    order = np.argsort(starts, kind="stable")
+    starts, ends = starts[order], ends[order]
+    n_reads = starts.size
+    hap = rng.integers(0, 2, size=n, dtype=np.uint8)
+    lengths = ends - starts
+    read_of = np.repeat(np.arange(n_reads), lengths)
+    offs = np.arange(lengths.sum()) - np.repeat(np.cumsum(lengths) - lengths, lengths)
+    var_idx = np.repeat(starts, lengths) + offs
+    read_hap = rng.integers(0, 2, size=n_reads, dtype=np.uint8)
+    allele = hap[var_idx] ^ read_hap[read_of]
+    allele = (allele ^ (rng.random(allele.size) < error_rate).astype(np.uint8)).astype(np.uint8)
+    quality = rng.integers(5, 41, size=allele.size, dtype=np.uint32)
+    interior = (offs > 0) & (offs < np.repeat(lengths, lengths) - 1)
+    keepv = ~(interior & (rng.random(allele.size) < drop_rate))
+    read_of, var_idx, allele, quality = read_of[keepv], var_idx[keepv], allele[keepv], quality[keepv]
+    counts = np.bincount(read_of, minlength=n_reads)
+    read_ptr = np.zeros(n_reads + 1, dtype=np.uint64)
+    read_ptr[1:] = np.cumsum(counts)
+    positions = (1000 * (np.arange(n, dtype=np.int64) + 1)).astype(np.uint32)
+    return ProblemArrays(read_ptr, (1000 * (var_idx + 1)).astype(np.int32), allele, quality, np.zeros(n_reads, dtype=np.int32),
+                         np.array([0], dtype=np.uint32), np.zeros(0, dtype=np.uint32), np.ones((1, n), dtype=np.uint8), None,
+                         np.ones(n, dtype=np.uint32), positions, False, n_variants=n)
+
+
+def clip_to_columns(p: ProblemArrays, n_columns: int) -> ProblemArrays:
+    """The first ``n_columns`` columns of a block: reads are clipped to the prefix, reads left with fewer than two
+    variants are dropped (bounded CPU-baseline samples of a workload without its own prefix option)."""
+    n_columns = int(min(n_columns, p.n_variants))
+    limit = int(p.positions[n_columns - 1])
+    lengths = np.diff(p.read_ptr).astype(np.int64)
+    read_of = np.repeat(np.arange(p.n_reads), lengths)
+    keep = p.var_position <= limit
+    counts = np.bincount(read_of[keep], minlength=p.n_reads)
+    ok = counts >= 2
+    keep &= ok[read_of]
+    read_ptr = np.zeros(int(ok.sum()) + 1, dtype=np.uint64)
+    read_ptr[1:] = np.cumsum(counts[ok])
+    n_ind = p.individual_id.size
+    gl = None if p.genotype_likelihoods is None else p.genotype_likelihoods.reshape(n_ind, p.n_variants, 3)[:, :n_columns]
+    return ProblemArrays(read_ptr, p.var_position[keep], p.var_allele[keep], p.var_quality[keep], p.read_sample_id[ok], p.individual_id,
+                         p.triple_ids, p.genotype.reshape(n_ind, p.n_variants)[:, :n_columns], gl, p.recombcost[:n_columns],
+                         p.positions[:n_columns], p.distrust_genotypes, n_variants=n_columns)
 
 
 def random_small_instance(rng: random.Random, mode: Optional[str] = None, max_variants: int = 9,
