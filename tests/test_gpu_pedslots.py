@@ -110,3 +110,28 @@ def test_full_size_trio_old_and_new_runs_agree():
     old, st_old = solve(p, "resident")
     assert new == old, first_difference(old, new)
     assert st_new["total_ms"] < st_old["total_ms"]
+
+
+@pytest.mark.parametrize("mode", ["three_children", "three_trios", "big_family"])
+def test_pedigrees_beyond_two_trios_and_six_individuals_vs_oracle(mode):
+    """Three trios (T = 64: a family with three children, three unrelated trios) and seven individuals in one table: the
+    generic per-column kernel (column_step_wide) -- the device path refuses a pedigree only beyond 3 trios / 12 individuals."""
+    import random
+
+    from whatshap_amd.synthetic import random_small_instance
+
+    rng = random.Random({"three_children": 191, "three_trios": 192, "big_family": 193}[mode])
+    compared = 0
+    for _ in range(50):
+        p = random_small_instance(rng, mode=mode, max_variants=8, max_reads=7)
+        try:
+            want = table_solution(oracle.OracleTable(p))
+        except oracle.OracleError as e:
+            with pytest.raises(_native.SolverError, match="Mendelian"):
+                solve(p)
+            assert "Mendelian" in str(e)
+            continue
+        got, _ = solve(p)
+        assert got == want, (mode, first_difference(want, got))
+        compared += 1
+    assert compared > 30

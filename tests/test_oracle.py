@@ -95,6 +95,28 @@ def test_oracle_vs_compiled_reference_random():
 
 
 @pytest.mark.skipif(not oracle.have_reference(), reason="oracle/_ref not built (no reference tree here)")
+@pytest.mark.parametrize("mode", ["three_children", "three_trios", "big_family"])
+def test_oracle_vs_compiled_reference_larger_pedigrees(mode):
+    """Three trios (T = 64) and a seven-individual family: the restatement is general in T and in the number of individuals,
+    like the reference (src/pedigreepartitions.cpp:7-42); pinned against the compiled reference before the device path is."""
+    if not oracle.have_reference():
+        pytest.skip("compiled reference not built")
+    rng = random.Random({"three_children": 91, "three_trios": 92, "big_family": 93}[mode])
+    compared = 0
+    for _ in range(60):
+        p = random_small_instance(rng, mode=mode, max_variants=7, max_reads=6)
+        try:
+            want = table_solution(oracle.ReferenceTable(p))
+        except oracle.OracleError as e:
+            with pytest.raises(oracle.OracleError, match=str(e)):
+                oracle.OracleTable(p)
+            continue
+        assert table_solution(oracle.OracleTable(p)) == want
+        compared += 1
+    assert compared > 40
+
+
+@pytest.mark.skipif(not oracle.have_reference(), reason="oracle/_ref not built (no reference tree here)")
 @pytest.mark.parametrize("kw", [dict(n_variants=300, coverage=10, seed=31), dict(n_variants=150, coverage=9, seed=32, trio=True),
                                 dict(n_variants=3000, coverage=14, seed=33, n_columns_limit=40)], ids=str)
 def test_oracle_vs_compiled_reference_synthetic(kw):

@@ -82,18 +82,24 @@ def test_shim_install_rebinds_a_phase_like_module():
         with pytest.raises(TypeError):
             phase.PedigreeDPTable(ref.ReadSet(), [1, 1, 1], ref.Pedigree(ids))  # a pedigree that was not recorded
     else:
-        # with the compiled ingestion a plain reference Pedigree is read through thisptr: no recording needed (without a GPU
-        # the factory then falls back to the class it replaced, with a GPU it returns the device table)
+        # with the compiled ingestion a plain reference Pedigree is read through thisptr: no recording needed (with a GPU the
+        # factory returns the device table; without one it raises WHAMD_ERR_DEVICE -- never a silent CPU run)
         plain = ref.Pedigree(ids)
         plain.add_individual("father", gts)
-        assert phase.PedigreeDPTable(ref.ReadSet(), [1, 1, 1], plain) is not None
+        from whatshap_amd import _native
+
+        if _native.device_count() > 0:
+            assert phase.PedigreeDPTable(ref.ReadSet(), [1, 1, 1], plain) is not None
+        else:
+            with pytest.raises(_native.SolverError) as e:
+                phase.PedigreeDPTable(ref.ReadSet(), [1, 1, 1], plain)
+            assert e.value.status == _native.WHAMD_ERR_DEVICE
 
 
-def test_shim_falls_back_to_the_replaced_class_beyond_device_limits(monkeypatch):
-    """shim.install must not turn inputs the reference can phase into hard errors.  A refusal of the device
-    path for its OWN limits (UNSUPPORTED / OVERFLOW / DEVICE) is logged and the table is built by the class that was
-    replaced, from the original objects; algorithmic errors are re-raised; without a fallback class the refusal stays
-    an error (what tests and bench.py rely on)."""
+def test_shim_fallback_is_opt_in_counted_and_never_taken_for_device_errors(monkeypatch):
+    """VERDICT r2 #10 / ADVICE r2: the CPU fallback of the integration shim is OPT-IN (`allow_cpu_fallback=True`), taken
+    only for the device path's INPUT limits (UNSUPPORTED / OVERFLOW), counted (`shim.stats()`), and NEVER taken for
+    WHAMD_ERR_DEVICE (no GPU, a HIP fault: a broken installation must surface).  Algorithmic errors are re-raised."""
     import types
 
     import pytest
@@ -112,19 +118,63 @@ def test_shim_falls_back_to_the_replaced_class_beyond_device_limits(monkeypatch)
 
     ped = core.Pedigree(core.NumericSampleIds())
     rs = core.ReadSet()
+    # default: no fallback at all
     phase = types.SimpleNamespace(Pedigree=core.Pedigree, PedigreeDPTable=FakeReferenceTable)
     previous = shim.install(phase, None)
     assert previous == (core.Pedigree, FakeReferenceTable)
     for status in (_native.WHAMD_ERR_UNSUPPORTED, _native.WHAMD_ERR_OVERFLOW, _native.WHAMD_ERR_DEVICE):
         monkeypatch.setattr(core, "PedigreeDPTable", refusing(status, "beyond the device path"))
+        with pytest.raises(_native.SolverError):
+            phase.PedigreeDPTable(rs, [1, 2], ped, True, [10, 20])
+    assert not calls
+    # opt-in: input limits fall back and are counted; device errors still raise
+    phase = types.SimpleNamespace(Pedigree=core.Pedigree, PedigreeDPTable=FakeReferenceTable)
+    shim.install(phase, None, allow_cpu_fallback=True)
+    shim.reset_stats()
+    for status in (_native.WHAMD_ERR_UNSUPPORTED, _native.WHAMD_ERR_OVERFLOW):
+        monkeypatch.setattr(core, "PedigreeDPTable", refusing(status, "beyond the device path"))
         table = phase.PedigreeDPTable(rs, [1, 2], ped, True, [10, 20])
         assert isinstance(table, FakeReferenceTable) and calls[-1] == (rs, (1, 2), ped, True, [10, 20])
+    st = shim.stats()
+    assert st["cpu_fallbacks"] == 2 and st["device_tables"] == 0 and len(st["fallback_reasons"]) == 2
+    monkeypatch.setattr(core, "PedigreeDPTable", refusing(_native.WHAMD_ERR_DEVICE, "no HIP device visible"))
+    with pytest.raises(_native.SolverError, match="no HIP device"):
+        phase.PedigreeDPTable(rs, [1, 2], ped)
     monkeypatch.setattr(core, "PedigreeDPTable", refusing(_native.WHAMD_ERR_MENDELIAN_CONFLICT, "Error: Mendelian conflict"))
     with pytest.raises(RuntimeError, match="Mendelian conflict"):
         phase.PedigreeDPTable(rs, [1, 2], ped)
-    monkeypatch.setattr(core, "PedigreeDPTable", refusing(_native.WHAMD_ERR_UNSUPPORTED, "beyond the device path"))
-    with pytest.raises(_native.SolverError):
-        shim.table_factory(None)(rs, [1, 2], ped)
+    assert shim.stats()["cpu_fallbacks"] == 2
+
+
+def test_shim_without_a_device_raises_instead_of_running_on_the_cpu():
+    """The real library on a box without a GPU (this container; skipped where one is visible): shim.install with the
+    fallback ALLOWED still raises WHAMD_ERR_DEVICE -- a mis-configured installation never runs 100 % on the CPU reference."""
+    import types
+
+    from whatshap_amd import _native, core, shim
+    from whatshap_amd.core import Read, ReadSet
+
+    if _native.device_count() > 0:
+        pytest.skip("a HIP device is visible")
+
+    class MustNotBeUsed:
+        def __init__(self, *args, **kwargs):
+            raise AssertionError("fell back to the CPU class on a device error")
+
+    phase = types.SimpleNamespace(Pedigree=core.Pedigree, PedigreeDPTable=MustNotBeUsed)
+    shim.install(phase, None, allow_cpu_fallback=True)
+    ids = core.NumericSampleIds()
+    ped = core.Pedigree(ids)
+    ped.add_individual("a", [core.Genotype([0, 1]), core.Genotype([0, 1])])
+    rs = ReadSet()
+    r = Read("r", 50, 0, ids["a"])
+    r.add_variant(10, 0, 5)
+    r.add_variant(20, 1, 5)
+    rs.add(r)
+    rs.sort()
+    with pytest.raises(_native.SolverError) as e:
+        phase.PedigreeDPTable(rs, [1, 1], ped)
+    assert e.value.status == _native.WHAMD_ERR_DEVICE
 
 
 def _compiled_ingestion():

@@ -7,6 +7,13 @@
 
 namespace whamd {
 
+// Packed formats shared by the per-column kernels and the backtrace:
+//   key of a projection entry  = value << 32 | gray_rank(x) << KEY_JBITS | argj      (rank < 2^26: at most 25 reads per column)
+//   raw backtrace record (u32) = the low word of the key
+//   state of the walk (u32)    = logical index | transmission value << BT_STATE_TSHIFT
+constexpr uint32_t KEY_JBITS = 6, KEY_JMASK = 63u;          // argj of up to 64 transmission values (three trios)
+constexpr uint32_t BT_STATE_TSHIFT = 26, BT_STATE_XMASK = 0x03FFFFFFu;
+
 // Per-column descriptor, read wave-uniformly (scalar loads) by every kernel.
 struct DevColumn {
 	uint32_t k;          // active reads (bits of a bipartition index)

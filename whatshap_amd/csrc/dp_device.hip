@@ -92,6 +92,7 @@ struct DeviceTable::Impl {
 	DevProblem dp{};
 	FusedFn fused = nullptr;
 	KeysFn keysfn = nullptr;
+	bool wide = false;   // column_step_wide instead of the templated per-column kernels
 	size_t key_entries = 0;
 	std::string path = "auto";
 	int l_pref = 11;
@@ -295,16 +296,18 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	m.release();
 	const uint32_t n = p.n_cols;
 	if (n == 0) return WHAMD_OK;
-	if (!select_kernels(p.T, p.n_ind, m.fused, m.keysfn)) {
+	// pedigrees beyond the templated kernels (three trios, more than six individuals): the generic per-column kernel, key path only
+	m.wide = !select_kernels(p.T, p.n_ind, m.fused, m.keysfn);
+	if (m.wide && (p.T > (uint32_t)MAX_T_WIDE || p.n_ind > (uint32_t)MAX_IND_WIDE)) {
 		msg = "no device kernel for T=" + std::to_string(p.T) + ", individuals=" + std::to_string(p.n_ind);
 		return WHAMD_ERR_UNSUPPORTED;
 	}
-	const bool force_keys = m.path == "column_keys";
-	const bool want_resident = m.path == "auto" || m.path == "resident";
+	const bool force_keys = m.path == "column_keys" || m.wide;
+	const bool want_resident = (m.path == "auto" || m.path == "resident") && !m.wide;
 	const auto tu0 = std::chrono::steady_clock::now();
 	size_t free_b = 0, total_b = 0;
 	HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-	m.use_slots = (m.path == "auto" || m.path == "slots") && plan_forward_slots(p, p.T > 1 ? (m.slot_l_set ? -m.slot_l : 0) : std::max(8, m.slot_l), m.symmetry, m.splan, m.slot_lr);
+	m.use_slots = (m.path == "auto" || m.path == "slots") && !m.wide && plan_forward_slots(p, p.T > 1 ? (m.slot_l_set ? -m.slot_l : 0) : std::max(8, m.slot_l), m.symmetry, m.splan, m.slot_lr);
 	// pedigree slot runs keep their cost-form tables in HBM (slots.h): at most a quarter of what is free, else the older paths
 	if (m.use_slots && m.splan.ped && m.splan.table_words * 4ull > free_b / 4) m.use_slots = false;
 	m.table_bytes = m.use_slots && m.splan.ped ? m.splan.table_words * 4ull : 0ull;
@@ -657,7 +660,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 			for (uint32_t q = 0; q < BT_GENERATORS; ++q) ch.flip[q] = 0;
 			if (p.n_triples == 0 && p.n_ind <= 1) {
 				const uint32_t fb = p.f[c_last];
-				ch.flip[0] = fb >= 28 ? 0x0FFFFFFFu : ((1u << fb) - 1u);
+				ch.flip[0] = fb >= BT_STATE_TSHIFT ? BT_STATE_XMASK : ((1u << fb) - 1u);
 				ch.n_orient = 2;
 				return;
 			}
@@ -670,7 +673,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 				if (gq >= 0) ch.flip[gq] |= 1u << bit;
 				++bit;
 			}
-			for (size_t q = 0; q < generator_tflip.size(); ++q) ch.flip[q] |= generator_tflip[q] << 28;
+			for (size_t q = 0; q < generator_tflip.size(); ++q) ch.flip[q] |= generator_tflip[q] << BT_STATE_TSHIFT;
 			ch.n_orient = 1u << generator_tflip.size();
 		};
 		BtChunk cur{};
@@ -734,7 +737,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	const auto tu3 = std::chrono::steady_clock::now();
 	m.key_entries = (size_t)(1ull << max_keys_f) * p.T;
 	HIP_TRY(alloc(&d_keys, m.key_entries * 8));
-	HIP_TRY(alloc(&d_last_keys, (size_t)MAX_T * 8));
+	HIP_TRY(alloc(&d_last_keys, (size_t)MAX_T_WIDE * 8));
 	HIP_TRY(alloc((void**)&m.d_pr[0], (size_t)(1ull << max_f) * p.T * 4));
 	HIP_TRY(alloc((void**)&m.d_pr[1], (size_t)(1ull << max_f) * p.T * 4));
 	HIP_TRY(alloc((void**)&m.d_path_index, (size_t)n * 4));
@@ -958,9 +961,10 @@ void DeviceTable::Impl::launch_column_step(const Problem& p, const Step& step, c
 		hipLaunchKernelGGL(m.fused, dim3(threads / block), dim3(block), 0, m.stream, dp, c, prev, cur);
 		launches += 1;
 	} else {
-		const uint64_t total = 1ull << (d.f + d.ebits - d.eloop);
+		const uint64_t total = (1ull << (d.f + d.ebits - d.eloop)) * (m.wide ? p.T : 1u);
 		const uint32_t block = (uint32_t)std::min<uint64_t>(256, (total + 63) / 64 * 64);
-		hipLaunchKernelGGL(m.keysfn, dim3((uint32_t)((total + block - 1) / block)), dim3(block), 0, m.stream, dp, c, prev, (uint32_t)total);
+		if (m.wide) hipLaunchKernelGGL(column_step_wide, dim3((uint32_t)((total + block - 1) / block)), dim3(block), 0, m.stream, dp, c, prev, (uint32_t)total);
+		else hipLaunchKernelGGL(m.keysfn, dim3((uint32_t)((total + block - 1) / block)), dim3(block), 0, m.stream, dp, c, prev, (uint32_t)total);
 		const uint32_t entries = (1u << d.f) * p.T;
 		const uint32_t fblock = std::min<uint32_t>(256, (entries + 63) / 64 * 64);
 		hipLaunchKernelGGL(column_finalize, dim3((entries + fblock - 1) / fblock), dim3(fblock), 0, m.stream, dp, c, cur, entries);
@@ -1064,7 +1068,7 @@ whamd_status_t DeviceTable::enqueue_some_unguarded(const Problem& p, Solution& s
 			return WHAMD_OK;
 		}
 		for (const Impl::Lane& lane : m.lanes) HIP_TRY(hipMemsetAsync(lane.d_keys, 0xFF, m.key_entries * 8, m.stream));
-		HIP_TRY(hipMemsetAsync(m.dp.last_keys, 0xFF, (size_t)MAX_T * 8, m.stream));
+		HIP_TRY(hipMemsetAsync(m.dp.last_keys, 0xFF, (size_t)MAX_T_WIDE * 8, m.stream));
 		if (m.use_chunks) HIP_TRY(hipMemsetAsync(m.dp.spec_keys, 0xFF, ((size_t)m.n_spec + 1) * m.dp.spec_stride * 8, m.stream));
 		if (m.windowed) HIP_TRY(hipMemsetAsync(m.d_path_trans, 0, (size_t)n * 4, m.stream));
 		HIP_TRY(hipEventRecord(m.ev0, m.stream));

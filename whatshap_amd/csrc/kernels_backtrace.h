@@ -64,7 +64,7 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 		uint32_t t = 0;
 		for (uint32_t i = 0; i < T; ++i) {
 			const unsigned long long key = P.last_keys[i];
-			if ((key >> 4) < (bestk >> 4)) { bestk = key; t = i; }
+			if ((key >> KEY_JBITS) < (bestk >> KEY_JBITS)) { bestk = key; t = i; }
 		}
 		if (bestk == ~0ull) {  // unreachable for valid inputs (the host rejects Mendelian conflicts); keep defined output
 			if (lane == 0) out_score[0] = 0xFFFFFFFFu;
@@ -72,9 +72,9 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 		} else if (lane == 0) {
 			out_score[0] = (uint32_t)(bestk >> 32);
 		}
-		const uint32_t rlast = (uint32_t)(bestk >> 4) & 0x0FFFFFFFu;
+		const uint32_t rlast = (uint32_t)(bestk >> KEY_JBITS) & BT_STATE_XMASK;
 		x = rlast ^ (rlast >> 1);
-		tprev = (uint32_t)bestk & 15u;
+		tprev = (uint32_t)bestk & KEY_JMASK;
 		if (lane == 0) {
 			path_index[n - 1] = x;
 			path_trans[n - 1] = t;
@@ -140,9 +140,9 @@ __global__ __launch_bounds__(1024) void backtrace_kernel(DevProblem P, const BtU
 				xp = deposit(y, segs, nsf) | deposit(e, segs + nsf, nse);
 			} else {
 				const uint32_t raw = reinterpret_cast<const uint32_t*>(P.bt + cbt)[(size_t)y * T + tprev];
-				const uint32_t r = raw >> 4;
+				const uint32_t r = raw >> KEY_JBITS;
 				xp = r ^ (r >> 1);
-				aj = raw & 15u;
+				aj = raw & KEY_JMASK;
 			}
 			if (lane == 0) {
 				path_index[c] = xp;
@@ -449,7 +449,7 @@ struct BtChunk {
 	uint32_t unit_off, unit_count;
 	uint32_t spec_id;   // 0: the newest chunk (units[0] is the table's last column, the optimum comes from P.last_keys)
 	uint32_t n_orient;  // 2^generators in use
-	uint32_t flip[BT_GENERATORS];   // packed-state XOR of each generator at this chunk's entry (index bits | transmission bits << 28)
+	uint32_t flip[BT_GENERATORS];   // packed-state XOR of each generator at this chunk's entry (index bits | transmission bits << BT_STATE_TSHIFT)
 };
 __device__ __forceinline__ uint32_t bt_orient(const BtChunk& ch, uint32_t state, uint32_t o) {
 #pragma unroll
@@ -458,8 +458,7 @@ __device__ __forceinline__ uint32_t bt_orient(const BtChunk& ch, uint32_t state,
 }
 
 // State of the walk between units, packed into one word: logical index of the path at the first column of the unit walked
-// before (bits 0..27) | transmission value handed down (bits 28..31; 0 for a single individual).
-constexpr uint32_t BT_STATE_XMASK = 0x0FFFFFFFu;
+// before (bits 0..25) | transmission value handed down (bits 26..31; 0 for a single individual): device_types.h.
 
 // One unit for the whole workgroup (256 threads): takes the packed state at the first column of the unit walked before (later
 // in the table), returns the packed state at this unit's first column.  Column steps (any T), slot runs (T = 1), trio runs.
@@ -467,7 +466,7 @@ __device__ __forceinline__ uint32_t chunk_walk_unit(const DevProblem& P, const B
                                                     uint32_t* cells, uint32_t* xshare, unsigned long long* stage,
                                                     uint32_t* __restrict__ path_index, uint32_t* __restrict__ path_trans) {
 	const uint32_t tid = threadIdx.x, NT = blockDim.x;
-	const uint32_t x = state & BT_STATE_XMASK, tprev = state >> 28;
+	const uint32_t x = state & BT_STATE_XMASK, tprev = state >> BT_STATE_TSHIFT;
 	__syncthreads();   // the previous unit's readers are done with the LDS areas
 	if (tid < 32) hdr[tid] = reinterpret_cast<const uint32_t*>(unit)[tid];
 	__syncthreads();
@@ -490,12 +489,12 @@ __device__ __forceinline__ uint32_t chunk_walk_unit(const DevProblem& P, const B
 			xp = deposit(y, segs, nsf) | deposit(e, segs + nsf, nse);
 		} else {
 			const uint32_t raw = reinterpret_cast<const uint32_t*>(P.bt + cbt)[(size_t)y * T + tprev];
-			const uint32_t r = raw >> 4;
+			const uint32_t r = raw >> KEY_JBITS;
 			xp = r ^ (r >> 1);
-			aj = raw & 15u;
+			aj = raw & KEY_JMASK;
 		}
 		if (tid == 0) { path_index[c0] = xp; path_trans[c0] = tprev; }
-		return xp | (aj << 28);
+		return xp | (aj << BT_STATE_TSHIFT);
 	}
 	if (kind == 1) {
 		// ---- LDS-resident run of a trio (kernels_trio.h): per-column parameters (ResBacktrace, 32 words each) and the record of the
@@ -556,7 +555,7 @@ __device__ __forceinline__ uint32_t chunk_walk_unit(const DevProblem& P, const B
 			if (tid == 0) xshare[0] = xl;
 		}
 		__syncthreads();
-		return xshare[0] | (xshare[1] << 28);
+		return xshare[0] | (xshare[1] << BT_STATE_TSHIFT);
 	}
 	if (kind == 3) {
 		// ---- pedigree slot run: blob (column slot lists), physical exit index, record of the path's workgroup -> LDS
@@ -590,7 +589,7 @@ __device__ __forceinline__ uint32_t chunk_walk_unit(const DevProblem& P, const B
 			}
 		}
 		__syncthreads();
-		return xshare[0] | (xshare[1] << 28);
+		return xshare[0] | (xshare[1] << BT_STATE_TSHIFT);
 	}
 	// ---- slot run: blob (column slot lists + ending slots), physical exit index, record of the path's workgroup -> LDS
 	const uint32_t g = hdr[4], L = hdr[5], n_ends = hdr[6], threads = hdr[7], f_exit = hdr[12], lr = hdr[13];
@@ -672,10 +671,10 @@ __global__ __launch_bounds__(256) void backtrace_chunks(DevProblem P, const BtUn
 			uint32_t t_last = 0;
 			for (uint32_t i = 0; i < P.T; ++i) {
 				const unsigned long long k2 = P.last_keys[i];
-				if ((k2 >> 4) < (key >> 4)) { key = k2; t_last = i; }
+				if ((k2 >> KEY_JBITS) < (key >> KEY_JBITS)) { key = k2; t_last = i; }
 			}
-			const uint32_t rlast = (uint32_t)(key >> 4) & 0x0FFFFFFFu;
-			x = (rlast ^ (rlast >> 1)) | (((uint32_t)key & 15u) << 28);   // index of the last column | the argj it hands down
+			const uint32_t rlast = (uint32_t)(key >> KEY_JBITS) & BT_STATE_XMASK;
+			x = (rlast ^ (rlast >> 1)) | (((uint32_t)key & KEY_JMASK) << BT_STATE_TSHIFT);   // index of the last column | the argj it hands down
 			if (tid == 0) {
 				out_score[0] = key == ~0ull ? 0xFFFFFFFFu : (uint32_t)(key >> 32);
 				path[n - 1] = x & BT_STATE_XMASK;
@@ -701,7 +700,7 @@ __global__ __launch_bounds__(256) void backtrace_chunks(DevProblem P, const BtUn
 			const uint32_t idx = (uint32_t)best >> su->lr, tt = (uint32_t)best & ((1u << su->lr) - 1u);   // (lr holds log2 T for these units)
 			x = 0;
 			for (uint32_t j = 0; j < su->f_exit; ++j) x |= ((idx >> su->exit_pos[j]) & 1u) << j;
-			x |= tt << 28;
+			x |= tt << BT_STATE_TSHIFT;
 			if (tid == 0 && o == 0) guess[ci] = x;
 			x = bt_orient(ch, x, o);
 		} else if (cu->kind == 1u) {
@@ -719,7 +718,7 @@ __global__ __launch_bounds__(256) void backtrace_chunks(DevProblem P, const BtUn
 			__syncthreads();
 			for (uint32_t i = 0; i < (blockDim.x >> 6); ++i) best = min(best, red[i]);
 			const uint32_t idx = (uint32_t)best;
-			x = (idx >> 2) | ((idx & 3u) << 28);
+			x = (idx >> 2) | ((idx & 3u) << BT_STATE_TSHIFT);
 			if (tid == 0 && o == 0) guess[ci] = x;
 			x = bt_orient(ch, x, o);
 		} else {
@@ -760,7 +759,7 @@ __global__ __launch_bounds__(256) void backtrace_chunks(DevProblem P, const BtUn
 		const SlotBtUnit* su = reinterpret_cast<const SlotBtUnit*>(cu);
 		// the part of the state the chunk's first unit looks at: the low f bits of the index (+ the transmission value)
 		const uint32_t fbits = cu->kind == 1u ? cu->g + cu->Lf_last : su->f_exit;
-		const uint32_t imask = fbits >= 28u ? BT_STATE_XMASK : ((1u << fbits) - 1u);
+		const uint32_t imask = fbits >= BT_STATE_TSHIFT ? BT_STATE_XMASK : ((1u << fbits) - 1u);
 		const uint32_t fmask = imask | ~BT_STATE_XMASK;
 		const uint32_t g0 = guess[ci];
 		uint32_t from = 0;                                            // units [from, unit_count) come from buffer `o`

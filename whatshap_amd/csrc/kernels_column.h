@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void column_step_keys(DevProblem P, uint32_t c
 		const uint32_t r = gray_rank(x);
 #pragma unroll
 		for (int i = 0; i < T; ++i) {
-			const unsigned long long key = ((unsigned long long)D[i] << 32) | ((unsigned long long)r << 4) | aj[i];
+			const unsigned long long key = ((unsigned long long)D[i] << 32) | ((unsigned long long)r << KEY_JBITS) | aj[i];
 			best[i] = min(best[i], key);
 		}
 	}
@@ -217,7 +217,90 @@ __global__ __launch_bounds__(256) void column_step_keys(DevProblem P, uint32_t c
 	for (int i = 0; i < T; ++i) atomicMin(&P.keys[(size_t)y * T + i], best[i]);
 }
 
-// keys -> Pr_c (value) + raw u32 backtrace record (rank << 4 | argj); re-arms the key scratch.
+// Any pedigree the templated kernels above do not cover (three trios: T = 64; more than six individuals): one thread per
+// (projection entry, chunk of ending patterns, transmission value i), everything with run-time loops.  Same keys, same
+// column_finalize; no run kernel and no bit-plane records -- the slow, general path (src/pedigreedptable.cpp:240-327).
+constexpr int WIDE_MAXIND = MAX_IND_WIDE;
+struct WideStage {
+	int32_t lut[WIDE_MAXIND][COL_CHUNKS][32];
+	DevTerm terms[COL_MAXTERMS];
+	uint32_t tptr[MAX_T_WIDE + 1];
+};
+__global__ __launch_bounds__(256) void column_step_wide(DevProblem P, uint32_t c, const uint32_t* __restrict__ prev, uint32_t total_threads) {
+	const DevColumn col = P.cols[c];
+	__shared__ WideStage S;
+	const uint32_t T = P.T, tbits = P.tbits, n_ind = P.n_ind, k = col.k;
+	{
+		const int32_t* __restrict__ dl = P.delta + col.delta_off;
+		for (uint32_t idx = threadIdx.x; idx < n_ind * COL_CHUNKS * 32u; idx += blockDim.x) {
+			const uint32_t s = idx / (COL_CHUNKS * 32), chunk = (idx / 32) % COL_CHUNKS, v = idx & 31u;
+			int32_t sum = 0;
+			for (uint32_t j = 0; j < 5; ++j) {
+				const uint32_t bit = chunk * 5 + j;
+				if (bit < k && ((v >> j) & 1u)) sum += dl[s * k + bit];
+			}
+			S.lut[s][chunk][v] = sum;
+		}
+		const uint32_t* __restrict__ tp = P.term_ptr + col.term_off;
+		const uint32_t t0 = tp[0], nterms = min(tp[T] - t0, (uint32_t)COL_MAXTERMS);
+		for (uint32_t i = threadIdx.x; i < nterms; i += blockDim.x) S.terms[i] = P.terms[t0 + i];
+		for (uint32_t i = threadIdx.x; i <= T; i += blockDim.x) S.tptr[i] = min(tp[i] - t0, (uint32_t)COL_MAXTERMS);
+		__syncthreads();
+	}
+	const uint32_t nchunks = (k + 4) / 5;
+	const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+	if (gid >= total_threads) return;
+	const uint32_t i = gid & (T - 1u), rest = gid >> tbits;
+	const uint32_t y = rest & ((1u << col.f) - 1u), chunk = rest >> col.f;
+	const uint32_t* __restrict__ segs = P.segs + col.seg_off;
+	const uint32_t xbase = deposit(y, segs, col.nseg_fwd);
+	const uint32_t lowmask = (1u << col.b) - 1u;
+	unsigned long long best = ~0ull;
+	const uint32_t ne = 1u << col.eloop;
+	for (uint32_t el = 0; el < ne; ++el) {
+		const uint32_t e = (chunk << col.eloop) | el;
+		const uint32_t x = xbase | deposit(e, segs + col.nseg_fwd, col.nseg_end);
+		int32_t L[WIDE_MAXIND];
+		for (uint32_t s = 0; s < n_ind; ++s) L[s] = 0;
+		for (uint32_t cc = 0; cc < nchunks; ++cc) {
+			const uint32_t v = (x >> (5 * cc)) & 31u;
+			for (uint32_t s = 0; s < n_ind; ++s) L[s] += S.lut[s][cc][v];
+		}
+		uint32_t cost = 0xFFFFFFFFu;
+		for (uint32_t q = S.tptr[i]; q < S.tptr[i + 1]; ++q) {
+			const DevTerm tm = S.terms[q];
+			uint32_t v = tm.c;
+			for (uint32_t s = 0; s < n_ind; ++s) {
+				v += ((tm.plus >> s) & 1u) ? (uint32_t)L[s] : 0u;
+				v -= ((tm.minus >> s) & 1u) ? (uint32_t)L[s] : 0u;
+			}
+			cost = min(cost, v);
+		}
+		uint32_t m = 0xFFFFFFFFu, mj = 0;
+		if (cost != 0xFFFFFFFFu) {
+			const uint32_t* __restrict__ pv = c ? prev + (size_t)(x & lowmask) * T : nullptr;
+			for (uint32_t j = 0; j < T; ++j) {
+				const uint32_t pj = pv ? pv[j] : 0u;
+				if (pj == 0xFFFFFFFFu) continue;
+				const uint32_t val = cost + pj + (uint32_t)__popc(i ^ j) * col.recomb;
+				if (val < m) { m = val; mj = j; }
+			}
+		}
+		best = min(best, ((unsigned long long)m << 32) | ((unsigned long long)gray_rank(x) << KEY_JBITS) | mj);
+	}
+	// lanes whose indices differ by a multiple of T * 2^f hold candidates for the same (entry, i): reduce inside the wave first
+	const uint32_t span_bits = col.f + tbits;
+	if (span_bits < 6u && total_threads >= 64u) {
+		for (uint32_t stride = 32; stride >= (1u << span_bits); stride >>= 1) {
+			best = min(best, (unsigned long long)__shfl_xor(best, (int)stride));
+			if (stride == 1u) break;
+		}
+		if ((threadIdx.x & 63u) >> span_bits) return;
+	}
+	atomicMin(&P.keys[(size_t)y * T + i], best);
+}
+
+// keys -> Pr_c (value) + raw u32 backtrace record (rank << KEY_JBITS | argj); re-arms the key scratch.
 __global__ __launch_bounds__(256) void column_finalize(DevProblem P, uint32_t c, uint32_t* __restrict__ cur, uint32_t entries) {
 	const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
 	if (idx >= entries) return;

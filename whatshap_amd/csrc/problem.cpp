@@ -128,8 +128,16 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 			if (!id_to_index(p, ped->triple_ids[3 * i + m], p.triples[i][m], msg)) return WHAMD_ERR_INVALID;
 		}
 	}
-	if (p.n_triples > 2 || p.n_ind > (uint32_t)MAX_IND) {
-		msg = "pedigree too large for the device path (at most " + std::to_string(MAX_IND) + " individuals and 2 trios)";
+	if (columns_only) {   // genotyping (genotype_device.hip)
+		if (p.n_triples > 2 || p.n_ind > (uint32_t)MAX_IND) {
+			msg = "pedigree too large for the genotyping device path (at most " + std::to_string(MAX_IND) + " individuals and 2 trios)";
+			return WHAMD_ERR_UNSUPPORTED;
+		}
+	} else if (p.n_triples > (uint32_t)MAX_TRIPLES_WIDE || p.n_ind > (uint32_t)MAX_IND_WIDE || 2 * (p.n_ind - std::min(p.n_ind, p.n_triples)) > 14) {
+		// (the reference has no such limit, src/pedigreepartitions.cpp:7-42; 4^trios transmission values x 2^partitions allele
+		// assignments per column are enumerated on the host, src/pedigreecolumncostcomputer.cpp:25-49)
+		msg = "pedigree too large for the device path (at most " + std::to_string(MAX_IND_WIDE) + " individuals, " + std::to_string(MAX_TRIPLES_WIDE) +
+		      " trios, 14 founder haplotypes)";
 		return WHAMD_ERR_UNSUPPORTED;
 	}
 	p.T = 1u << (2 * p.n_triples);

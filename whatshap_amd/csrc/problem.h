@@ -20,8 +20,11 @@ namespace whamd {
 
 constexpr uint32_t INF = 0xFFFFFFFFu;
 constexpr int MAX_COVERAGE = 25;   // device limit on reads per column (the CLI caps at 23, cli/phase.py:1181)
-constexpr int MAX_IND = 6;         // individuals per pedigree on the device path
-constexpr int MAX_T = 16;          // transmission values = 4^triples (<= 2 trios)
+constexpr int MAX_IND = 6;         // individuals per pedigree of the templated kernels (and of the genotyping path)
+constexpr int MAX_T = 16;          // transmission values = 4^triples of the templated kernels (<= 2 trios)
+constexpr int MAX_IND_WIDE = 12;   // phasing: larger pedigrees run on the generic per-column kernel (column_step_wide)
+constexpr int MAX_TRIPLES_WIDE = 3;
+constexpr int MAX_T_WIDE = 64;     // 4^3
 
 struct ColumnEntry {  // Entry (src/entry.h) plus the individual index of its read
 	uint32_t read_id;

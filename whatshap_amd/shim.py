@@ -89,23 +89,39 @@ class _TableAdapter:
         return converted, transmission
 
 
-# status codes of the device path's own limits (include/whatshap_amd.h): the reference has none of them
-_DEVICE_LIMIT_STATUSES = (4, 5, 6)  # WHAMD_ERR_UNSUPPORTED, WHAMD_ERR_DEVICE, WHAMD_ERR_OVERFLOW
+# Status codes of the device path's own INPUT limits (include/whatshap_amd.h); the reference has none of them.
+# WHAMD_ERR_DEVICE (5: no GPU visible, a HIP runtime fault) is deliberately NOT in the list: a broken installation or a kernel
+# fault must surface, not turn into a silent CPU run.
+_DEVICE_LIMIT_STATUSES = (4, 6)  # WHAMD_ERR_UNSUPPORTED, WHAMD_ERR_OVERFLOW
+
+_counters = {"device_tables": 0, "cpu_fallbacks": 0, "device_genotype_tables": 0, "cpu_genotype_fallbacks": 0}
+_fallback_reasons = []
+
+
+def stats() -> dict:
+    """How many tables the shim built on the device and how many it handed to the reference class (with the library's
+    message for each refusal) since the last ``reset_stats()``."""
+    return dict(_counters, fallback_reasons=list(_fallback_reasons))
+
+
+def reset_stats() -> None:
+    for key in _counters:
+        _counters[key] = 0
+    del _fallback_reasons[:]
 
 
 def table_factory(reference_core=None, fallback_table_class=None, **solver_options):
     """Callable with the constructor signature of the reference's ``PedigreeDPTable`` (core.pyx:364-379).  The pedigree
     must come from ``recording_pedigree_class`` (or be a ``whatshap_amd.core.Pedigree``).
 
-    ``fallback_table_class`` (``install`` passes the binding it replaces, i.e. the reference's own ``PedigreeDPTable``):
-    the device path has limits the reference does not have -- at most 2 trios / 6 individuals per pedigree, 25 reads per
-    column, 1024 cost terms per column, a pessimistic 32-bit overflow bound, and of course a visible GPU.  When the
-    library refuses an input for one of those reasons (``WHAMD_ERR_UNSUPPORTED`` / ``_OVERFLOW`` / ``_DEVICE``) the run
-    must not die where the unmodified WhatsHap would have phased it: the refusal is logged and the table is built by the
-    fallback class from the ORIGINAL ReadSet and pedigree objects.  This is the integration shim of an end-user run,
-    not the measured product path: parity tests and ``bench.py`` never pass a fallback, so a refusal stays an error
-    there.  Errors of the algorithm itself (Mendelian conflict, unsorted ReadSet) are re-raised unchanged -- the
-    reference raises them too."""
+    ``fallback_table_class`` (OPT-IN: ``install(..., allow_cpu_fallback=True)`` passes the binding it replaces, i.e. the
+    reference's own ``PedigreeDPTable``): the device path has input limits the reference does not have -- 25 reads per
+    column, 3 trios / 8 individuals per pedigree, 1024 cost terms per column, a pessimistic 32-bit overflow bound.  When
+    the library refuses an input for one of those reasons (``WHAMD_ERR_UNSUPPORTED`` / ``_OVERFLOW``) and a fallback class
+    was given, the refusal is logged, counted (``shim.stats()``) and the table is built by the fallback class from the
+    ORIGINAL ReadSet and pedigree objects.  ``WHAMD_ERR_DEVICE`` -- no GPU visible, a HIP error -- is never a reason to
+    fall back: it is re-raised, like the errors of the algorithm itself (Mendelian conflict, unsorted ReadSet), which the
+    reference raises too.  Without a fallback class (the default; parity tests and ``bench.py``) every refusal is an error."""
 
     def make(readset, recombcost, pedigree, distrust_genotypes=False, positions=None):
         # WhatsHap's own objects: compiled ingestion (whatshap_amd/ingest) when it was built -- the C++ ReadSet / Pedigree are
@@ -132,20 +148,23 @@ def table_factory(reference_core=None, fallback_table_class=None, **solver_optio
 
             logging.getLogger("whatshap_amd").warning(
                 "device path refused this table (%s); solving it with the reference PedigreeDPTable", exc)
+            _counters["cpu_fallbacks"] += 1
+            _fallback_reasons.append(str(exc))
             return fallback_table_class(readset, recombcost, pedigree, distrust_genotypes, positions)
+        _counters["device_tables"] += 1
         return _TableAdapter(table, reference_core)
 
     return make
 
 
-def install(phase_module, reference_core=None, **solver_options):
+def install(phase_module, reference_core=None, allow_cpu_fallback=False, **solver_options):
     """Rebinds ``Pedigree`` and ``PedigreeDPTable`` in ``phase_module`` (normally ``whatshap.cli.phase``).  Returns the
-    previous bindings so that a caller can restore them."""
+    previous bindings so that a caller can restore them.  ``allow_cpu_fallback=True``: inputs beyond the device path's
+    INPUT limits are handed to the class that was replaced (see ``table_factory``; never a missing GPU or a HIP error)."""
     previous = (phase_module.Pedigree, phase_module.PedigreeDPTable)
     ref_pedigree = reference_core.Pedigree if reference_core is not None else phase_module.Pedigree
     phase_module.Pedigree = recording_pedigree_class(ref_pedigree)
-    # keep the binding we replace: inputs beyond the device path's limits fall back to it (table_factory)
-    phase_module.PedigreeDPTable = table_factory(reference_core, fallback_table_class=previous[1], **solver_options)
+    phase_module.PedigreeDPTable = table_factory(reference_core, fallback_table_class=previous[1] if allow_cpu_fallback else None, **solver_options)
     return previous
 
 
@@ -172,8 +191,8 @@ class _GenotypeAdapter:
 def genotype_table_factory(reference_core=None, fallback_table_class=None, **options):
     """Callable with the constructor signature of the reference's ``GenotypeDPTable`` (core.pyx:581-597):
     ``(numeric_sample_ids, readset, recombcost, pedigree, positions=None)``.  Same rules as ``table_factory``: WhatsHap's
-    own objects go through the compiled ingestion (or a recorded pedigree); an input beyond the device path's limits is
-    logged and handed to ``fallback_table_class``."""
+    own objects go through the compiled ingestion (or a recorded pedigree); an input beyond the device path's INPUT limits is
+    logged, counted and handed to ``fallback_table_class`` when one was given (opt-in); device errors are re-raised."""
     from . import genotype as _genotype
 
     def make(numeric_sample_ids, readset, recombcost, pedigree, positions=None):
@@ -198,21 +217,24 @@ def genotype_table_factory(reference_core=None, fallback_table_class=None, **opt
 
             logging.getLogger("whatshap_amd").warning(
                 "device path refused this genotyping table (%s); using the reference GenotypeDPTable", exc)
+            _counters["cpu_genotype_fallbacks"] += 1
+            _fallback_reasons.append(str(exc))
             return fallback_table_class(numeric_sample_ids, readset, recombcost, pedigree, positions)
+        _counters["device_genotype_tables"] += 1
         return _GenotypeAdapter(table, reference_core)
 
     return make
 
 
-def install_genotype(genotype_module, reference_core=None, **options):
+def install_genotype(genotype_module, reference_core=None, allow_cpu_fallback=False, **options):
     """Rebinds ``GenotypeDPTable`` (and ``Pedigree``, unless the compiled ingestion makes the recording subclass unnecessary)
     in ``genotype_module`` (normally ``whatshap.cli.genotype``, which binds them at ``:20-30`` and uses them at ``:357-368``).
-    Returns the previous bindings."""
+    Returns the previous bindings.  ``allow_cpu_fallback`` as in ``install``."""
     from . import ingest as _ingest
 
     previous = (genotype_module.Pedigree, genotype_module.GenotypeDPTable)
     if reference_core is None or _ingest.load() is None:
         ref_pedigree = reference_core.Pedigree if reference_core is not None else genotype_module.Pedigree
         genotype_module.Pedigree = recording_pedigree_class(ref_pedigree)
-    genotype_module.GenotypeDPTable = genotype_table_factory(reference_core, fallback_table_class=previous[1], **options)
+    genotype_module.GenotypeDPTable = genotype_table_factory(reference_core, fallback_table_class=previous[1] if allow_cpu_fallback else None, **options)
     return previous

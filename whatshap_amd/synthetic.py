@@ -207,7 +207,7 @@ def random_small_instance(rng: random.Random, mode: Optional[str] = None, max_va
         mode = rng.choice(["single", "trio", "quartet"])
     n_var = rng.randint(2, max_variants)
     n_reads = rng.randint(1, max_reads)
-    n_ind = {"single": 1, "trio": 3, "quartet": 4}[mode]
+    n_ind = {"single": 1, "trio": 3, "quartet": 4, "three_children": 5, "three_trios": 9, "big_family": 7}[mode]
     var_positions = [10 * (i + 1) for i in range(n_var)]
     reads = []
     for _ in range(n_reads):
@@ -228,14 +228,28 @@ def random_small_instance(rng: random.Random, mode: Optional[str] = None, max_va
     n_cols = len(positions)
     distrust = rng.random() < 0.5
     genotype = np.ones((n_ind, n_cols), dtype=np.uint8)
+    triples: List[int] = []
+    if mode == "trio":
+        triples = [0, 1, 2]
+    elif mode == "quartet":
+        triples = [0, 1, 2, 0, 1, 3]
+    elif mode == "three_children":   # T = 64: two parents, three children
+        triples = [0, 1, 2, 0, 1, 3, 0, 1, 4]
+    elif mode == "three_trios":      # T = 64: three unrelated trios in one table
+        triples = [0, 1, 2, 3, 4, 5, 6, 7, 8]
+    elif mode == "big_family":       # T = 16, seven individuals: grandparents (0, 1) -> father 2; mother 3; child 4; two unrelated
+        triples = [0, 1, 2, 2, 3, 4]
     if mode != "single" and rng.random() < 0.5:
         for c in range(n_cols):
-            f = [rng.randint(0, 1), rng.randint(0, 1)]
-            m = [rng.randint(0, 1), rng.randint(0, 1)]
-            genotype[0, c] = sum(f)
-            genotype[1, c] = sum(m)
-            for child in range(2, n_ind):
-                genotype[child, c] = rng.choice(f) + rng.choice(m)
+            hap = {}
+            for ind in range(n_ind):
+                trio = [tr for tr in range(len(triples) // 3) if triples[3 * tr + 2] == ind]
+                if trio:   # a child: one haplotype of each parent (parents come first in every mode)
+                    fa, mo = triples[3 * trio[0]], triples[3 * trio[0] + 1]
+                    hap[ind] = [rng.choice(hap[fa]), rng.choice(hap[mo])]
+                else:
+                    hap[ind] = [rng.randint(0, 1), rng.randint(0, 1)]
+                genotype[ind, c] = sum(hap[ind])
     if allow_conflict and rng.random() < 0.3:
         genotype[rng.randrange(n_ind), rng.randrange(n_cols)] = rng.randint(0, 2)
     gl = np.zeros((n_ind, n_cols, 3), dtype=np.float64)
@@ -244,11 +258,6 @@ def random_small_instance(rng: random.Random, mode: Optional[str] = None, max_va
             for g in range(3):
                 gl[i, c, g] = rng.choice([0, 0, 3, 10])
     recomb = np.array([rng.choice([0, 1, 2, 5]) for _ in range(n_cols)], dtype=np.uint32)
-    triples: List[int] = []
-    if mode == "trio":
-        triples = [0, 1, 2]
-    elif mode == "quartet":
-        triples = [0, 1, 2, 0, 1, 3]
     read_ptr = [0]
     pos, alle, qual, samples = [], [], [], []
     for variants, sample in reads:
