@@ -100,6 +100,10 @@ typedef struct whamd_solve_stats {
 	double host_finish_ms;       /* wall: superreads + partitioning on the host */
 	uint32_t max_coverage;       /* max_c k_c */
 	uint32_t transmissions;      /* T = 4^triples */
+	uint32_t bt_chunks;          /* chunked speculative backtrace: chunks walked at once (0: the sequential walk was used) */
+	uint32_t bt_missed;          /*   chunks whose true entry state was none of the guesses */
+	uint32_t bt_rewalked;        /*   units walked again from the true state */
+	uint32_t pad;
 } whamd_solve_stats;
 
 /* Library / device introspection. */

@@ -240,3 +240,25 @@ def test_compiled_ingestion_on_a_plain_reference_pedigree_and_large_readset():
     want = problem_from_objects(rs, problem.recombcost.tolist(), recording.amd, True, problem.positions.tolist())
     _same_arrays(want, got)
     assert int(oracle.OracleTable(got).optimal_score()) == int(oracle.OracleTable(problem).optimal_score())
+
+
+def test_ingest_refuses_the_objects_of_another_whatshap_release(monkeypatch):
+    """whamd_ingest reads C++ objects through thisptr with the class layouts of the release it was built against
+    (recorded by build.py); with a different installed release load() declines (public-API walk instead), version stubs of
+    builds without metadata ('0+oracle') are not compared."""
+    import sys
+    import types
+    import warnings
+
+    from whatshap_amd import ingest
+
+    assert ingest._same_release("2.8", "2.8.1") and not ingest._same_release("2.8", "2.9.dev1+g0")
+    assert ingest._is_release("2.8") and not ingest._is_release("0+oracle") and not ingest._is_release(None)
+    _compiled_ingestion()   # built and loadable here
+    monkeypatch.setattr(ingest, "_module", None)
+    monkeypatch.setattr(ingest, "_tried", False)
+    monkeypatch.setitem(sys.modules, "whatshap", types.SimpleNamespace(__version__="1.7"))
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        assert ingest.load() is None
+    assert any("built against WhatsHap" in str(w.message) for w in caught)

@@ -75,10 +75,14 @@ class SolveStats(C.Structure):
         ("host_finish_ms", C.c_double),
         ("max_coverage", C.c_uint32),
         ("transmissions", C.c_uint32),
+        ("bt_chunks", C.c_uint32),
+        ("bt_missed", C.c_uint32),
+        ("bt_rewalked", C.c_uint32),
+        ("pad", C.c_uint32),
     ]
 
     def as_dict(self) -> dict:
-        return {name: getattr(self, name) for name, _ in self._fields_}
+        return {name: getattr(self, name) for name, _ in self._fields_ if name != "pad"}
 
 
 class GenotypeStats(C.Structure):
@@ -468,6 +472,9 @@ def genotype_likelihoods(problem: ProblemArrays, n_columns: int, device: int = 0
     a = problem.call_args()
     _check(lib().whamd_genotype_likelihoods(a[0], a[1], a[2], a[3], a[5], a[6], C.c_int(int(device)), C.c_uint32(int(window)),
                                             _ptr(gl, C.c_double), C.c_size_t(max(gl.size, 1) if gl.size else 0), C.byref(stats)))
+    if int(stats.n_columns) != int(n_columns):
+        # the library strides its output by ITS column count: a different count here would silently mis-align every individual after the first
+        raise SolverError(WHAMD_ERR_INVALID, f"genotype_likelihoods: caller assumed {n_columns} columns, the library found {int(stats.n_columns)}")
     return gl, stats.as_dict()
 
 

@@ -1157,10 +1157,14 @@ whamd_status_t DeviceTable::wait(const Problem& p, Solution& s, whamd_solve_stat
 	st.backtrace_ms = f12;
 	st.total_ms = f03;
 	st.forward_launches = launches;
-	if (m.use_chunks && getenv("WHAMD_BT_STATS")) {
+	st.bt_chunks = st.bt_missed = st.bt_rewalked = 0;
+	if (m.use_chunks) {
 		uint32_t c[3] = {0, 0, 0};
 		HIP_TRY(hipMemcpy(c, m.d_bt_counters, 12, hipMemcpyDeviceToHost));
-		fprintf(stderr, "[whamd backtrace] %zu chunks, %u guesses missed (%u of them only in the transmission value), %u units walked again (of %zu)\n", m.chunks.size(), c[0], c[2], c[1], m.units.size());
+		st.bt_chunks = (uint32_t)m.chunks.size();
+		st.bt_missed = c[0];
+		st.bt_rewalked = c[1];
+		if (getenv("WHAMD_BT_STATS")) fprintf(stderr, "[whamd backtrace] %zu chunks, %u guesses missed (%u of them only in the transmission value), %u units walked again (of %zu)\n", m.chunks.size(), c[0], c[2], c[1], m.units.size());
 	}
 	if (m.dp.dbg && m.use_slots) {
 		std::vector<unsigned long long> d(m.splan.runs.size() * 48);

@@ -21,4 +21,36 @@ def load():
         _module = importlib.import_module("whatshap_amd.ingest.whamd_ingest")
     except ImportError:
         _module = None
+        return None
+    # The extension reads the C++ objects of whatshap.core through thisptr with the class layouts of the headers it was built
+    # against (build.py records that WhatsHap version): refuse to walk the objects of a different WhatsHap.
+    import os
+
+    built_for = None
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "whamd_ingest.built_for")) as f:
+            built_for = f.read().strip()
+    except OSError:
+        pass
+    installed = getattr(sys.modules.get("whatshap"), "__version__", None)
+    if built_for not in (None, "unknown") and _is_release(installed) and not _same_release(built_for, installed):
+        import warnings
+
+        warnings.warn(f"whatshap_amd.ingest was built against WhatsHap {built_for} but {installed} is loaded: using the objects' "
+                      "public Python API instead of the compiled walk", RuntimeWarning)
+        _module = None
     return _module
+
+
+def _is_release(v) -> bool:
+    """'2.8', '2.8.1', '2.9.dev3+g1234' -- not the '0+oracle' / '0.1.dev...' stubs of builds without version metadata."""
+    import re
+
+    return bool(v) and re.match(r"[1-9]\d*\.\d+", v) is not None
+
+
+def _same_release(a: str, b: str) -> bool:
+    """Versions agree on major.minor."""
+    def key(v):
+        return tuple(v.replace("+", ".").split(".")[:2])
+    return key(a) == key(b)

@@ -42,7 +42,24 @@ def build(force=False):
     subprocess.check_call(["g++", "-std=c++11", "-O2", "-fPIC", "-shared", "-w", "-Werror=return-type",
                            "-I" + os.path.join(REFERENCE, "src"), "-I" + HERE, "-I" + sysconfig.get_paths()["include"],
                            "-o", target(), cpp])
+    with open(os.path.join(HERE, "whamd_ingest.built_for"), "w") as f:   # read by load(): class layouts are per WhatsHap release
+        f.write(reference_version() + "\n")
     return available()
+
+
+def reference_version():
+    """Release of the tree the extension is built against: the newest heading of its CHANGES.rst ('v2.8 (2025-06-08)')."""
+    import re
+
+    try:
+        with open(os.path.join(REFERENCE, "CHANGES.rst")) as f:
+            for line in f:
+                m = re.match(r"v(\d+\.\d+)", line)
+                if m:
+                    return m.group(1)
+    except OSError:
+        pass
+    return "unknown"
 
 
 if __name__ == "__main__":

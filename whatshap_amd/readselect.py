@@ -6,11 +6,29 @@ Host code behind the C ABI (``whamd_readselection``, ``whatshap_amd/csrc/readsel
 queue whose scores change after every pick, there is nothing for the GPU in it.  It returns the same *set* of read
 indices as the reference, ties included (the C++ replays the iteration orders of the reference's Python sets).
 """
+import sys
+import warnings
 from typing import Iterable, Optional, Set
 
 import numpy as np
 
 from . import _native
+
+# Which read wins a tie depends, in the reference, on the layout of CPython `set`s and of a libstdc++ unordered_set; the C++
+# side replays CPython 3.8 - 3.12's setobject.c (unchanged across those versions) and was validated against the built
+# reference under CPython 3.10 (tests/test_readselect.py).  Outside that range the selection is still a valid one -- same
+# coverage bound, same scores -- but tie order is not guaranteed to match an installed WhatsHap.
+_VALIDATED_PYTHONS = ((3, 8), (3, 12))
+_warned = False
+
+
+def _check_interpreter():
+    global _warned
+    if _warned or _VALIDATED_PYTHONS[0] <= sys.version_info[:2] <= _VALIDATED_PYTHONS[1]:
+        return
+    _warned = True
+    warnings.warn(f"whatshap_amd.readselect: tie order was validated for CPython {_VALIDATED_PYTHONS[0]} .. {_VALIDATED_PYTHONS[1]}, "
+                  f"this is {sys.version_info[:2]}: the selected set may differ from whatshap.readselect's on ties", RuntimeWarning, stacklevel=3)
 
 
 def _flat(readset):
@@ -45,6 +63,7 @@ def readselection(readset, max_cov: int, preferred_source_ids: Optional[Iterable
     Same signature, result and error as ``whatshap.readselect.readselection``: reads that cover fewer than two variants
     raise ``ValueError`` (``readselect.pyx:236-239``).
     """
+    _check_interpreter()
     read_ptr, pos, qual = _flat(readset)
     sources = None
     if preferred_source_ids is not None:
