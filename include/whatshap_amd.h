@@ -296,7 +296,7 @@ typedef struct whamd_genotype_stats {
 	uint32_t window;         /* columns per window */
 	uint32_t max_coverage;
 	uint32_t transmissions;
-	uint32_t pad;
+	uint32_t slot_runs;      /* launches per chain of the run-fused path (genotype_slots.hip); 0: the per-column kernels ran */
 } whamd_genotype_stats;
 whamd_status_t whamd_genotype_likelihoods(const whamd_readset_view* readset, const uint32_t* recombcost, size_t n_recombcost,
                                           const whamd_pedigree_view* pedigree, const uint32_t* positions, size_t n_positions,

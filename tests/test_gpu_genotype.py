@@ -35,7 +35,7 @@ def test_small_random_cases_vs_restatement_and_reference(mode, n_cases):
                         max_coverage=6 if mode == "single" else 4, uniform_prior=seed % 3 == 0)
         want = reference_likelihoods(p, ref)
         oracle_gl = np.asarray(genotype_oracle.genotype_likelihoods(p), dtype=np.float64)
-        for window in (0, 1, 3):
+        for window in (0, 1, 3):   # 0: the run-fused path where every column fits a run; a forced window: the per-column kernels
             got, _ = device_likelihoods(p, window)
             assert np.allclose(got, want, rtol=RTOL, atol=ATOL), (mode, seed, window, np.abs(got - want).max())
             assert np.allclose(got, oracle_gl, rtol=RTOL, atol=ATOL)
@@ -55,7 +55,37 @@ def test_larger_cases_vs_the_reference_class(kw):
         got, stats = device_likelihoods(p, window)
         assert np.allclose(got, want, rtol=RTOL, atol=ATOL), (window, np.abs(got - want).max())
         assert np.allclose(got.sum(axis=2), 1.0)
+        assert (stats["slot_runs"] > 0) == (window == 0), stats   # both device paths were exercised
     assert stats["n_columns"] == kw["n_variants"]
+
+
+def _synthetic_genotyping_problem(n_variants, coverage, seed, **kw):
+    """A synthetic phasing block (whatshap_amd.synthetic) with random genotype priors: long tables at a steady coverage."""
+    from whatshap_amd.synthetic import synthetic_block
+
+    b = synthetic_block(n_variants, coverage, seed=seed, **kw)
+    rng = np.random.default_rng(seed)
+    gl = rng.random((b.n_individuals, b.n_variants, 3)) + 0.05
+    gl /= gl.sum(axis=2, keepdims=True)
+    return _native.ProblemArrays(b.read_ptr, b.var_position, b.var_allele, b.var_quality, b.read_sample_id, b.individual_id, b.triple_ids,
+                                 b.genotype.reshape(b.n_individuals, -1), gl, b.recombcost, b.positions, False, n_variants=b.n_variants)
+
+
+@pytest.mark.parametrize("kw", [dict(n_variants=6000, coverage=11, seed=3), dict(n_variants=1500, coverage=9, seed=4, trio=True)], ids=str)
+def test_no_drift_over_thousands_of_columns(kw):
+    """f64 on the device against the long-double reference class over thousands of normalised columns (the runs
+    rescale once per launch, the reference once per column): still rtol 1e-9 at the far end of the table, on both device paths."""
+    ref = reference_core()
+    p = _synthetic_genotyping_problem(**kw)
+    want = reference_likelihoods(p, ref)
+    got, stats = device_likelihoods(p)
+    assert stats["slot_runs"] > 100, stats
+    assert np.allclose(got, want, rtol=RTOL, atol=ATOL), np.abs(got - want).max()
+    tail = slice(-50, None)
+    assert np.allclose(got[:, tail], want[:, tail], rtol=RTOL, atol=ATOL)
+    old, old_stats = device_likelihoods(p, window=256)
+    assert old_stats["slot_runs"] == 0
+    assert np.allclose(old, want, rtol=RTOL, atol=ATOL), np.abs(old - want).max()
 
 
 def test_many_reads_starting_and_ending_in_one_column():

@@ -97,7 +97,7 @@ class GenotypeStats(C.Structure):
         ("window", C.c_uint32),
         ("max_coverage", C.c_uint32),
         ("transmissions", C.c_uint32),
-        ("pad", C.c_uint32),
+        ("slot_runs", C.c_uint32),
     ]
 
     def as_dict(self) -> dict:

@@ -287,11 +287,48 @@ whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uin
 	Problem p;
 	std::string msg;
 	const double tb0 = now_ms();
-	whamd_status_t st = build_problem(readset, recombcost, n_recombcost, pedigree, distrust_genotypes != 0, positions,
-	                                  n_positions, p, msg);
-	if (st != WHAMD_OK) return fail(st, msg);
 	const std::string mode(path ? path : "auto");
+	whamd_status_t st = build_problem(readset, recombcost, n_recombcost, pedigree, distrust_genotypes != 0, positions,
+	                                  n_positions, p, msg, /*columns_only=*/mode == "genotype_slots");
+	if (st != WHAMD_OK) return fail(st, msg);
 	SlotPlan sp;
+	if (mode == "genotype_slots") {
+		// the run plan of the genotyping path (genotype_slots.hip): every column must lie in a run, or the per-column kernels take over
+		whamd_plan_summary s{};
+		s.n_columns = p.n_cols;
+		s.max_coverage = p.max_k;
+		if (plan_forward_slots(p, 0, 0, sp, 0, /*genotype_mode=*/true)) {
+			s.n_steps = sp.steps.size();
+			s.n_runs = sp.runs.size();
+			bool ok = true;
+			uint32_t expect = 0;
+			for (const Step& step : sp.steps) {
+				if (step.kind != 2) {
+					if (getenv("WHAMD_DEBUG_PLAN")) fprintf(stderr, "[plan] genotype: column %u outside runs (k=%u b=%u f=%u, next k=%u)\n", step.index, p.k[step.index], p.b[step.index], p.f[step.index], step.index + 1 < p.n_cols ? p.k[step.index + 1] : 0);
+					ok = ok && step.index == expect; expect = step.index + 1; continue;
+				}
+				const SlotRun& run = sp.runs[step.index];
+				ok = ok && run.c0 == expect && run.lr == 0 && !run.half && run.ncols >= 1 && run.ncols <= (uint32_t)PSLOT_MAXCOLS;
+				expect = run.c0 + run.ncols;
+				s.n_resident_columns += run.ncols;
+				s.max_run_columns = std::max<uint64_t>(s.max_run_columns, run.ncols);
+				s.max_workgroups = std::max<uint64_t>(s.max_workgroups, 1ull << run.g);
+				uint32_t starts = 0, ends = 0;
+				for (uint32_t i = 0; i < run.ncols; ++i) {
+					const PedSlotRow& pr = sp.prows[run.c0 + i];
+					const uint32_t c = run.c0 + i;
+					ok = ok && pr.pad[0] == (uint32_t)p.k[c] - (i == 0 ? p.b[run.c0] : p.b[c]) && pr.pad[1] == starts;
+					ok = ok && pr.n_end == (c + 1 == p.n_cols ? 0u : (uint32_t)p.k[c] - p.f[c]) && sp.bt_cols[c].kf == ends;
+					starts += pr.pad[0];
+					ends += pr.n_end;
+				}
+			}
+			ok = ok && expect == p.n_cols;
+			s.invariants_ok = ok ? 1 : 0;
+		}
+		*out = s;
+		return WHAMD_OK;
+	}
 	const double tp0 = now_ms();
 	const bool slots_ok = (mode == "auto" || mode == "slots") && plan_forward_slots(p, 11, 1, sp);
 	if (getenv("WHAMD_DEBUG_TIMING")) fprintf(stderr, "[whamd timing] plan_summarize: build_problem %.1f ms, plan_forward_slots %.1f ms\n", tp0 - tb0, now_ms() - tp0);
@@ -508,7 +545,7 @@ whamd_status_t whamd_genotype_likelihoods(const whamd_readset_view* readset, con
 		o.n_columns = gs.n_columns; o.n_cells = gs.n_cells; o.launches = gs.launches;
 		o.backward_ms = gs.backward_ms; o.forward_ms = gs.forward_ms; o.total_ms = gs.total_ms;
 		o.host_prepare_ms = (now_ms() - t0) - gs.total_ms;
-		o.window = gs.window; o.max_coverage = gs.max_coverage; o.transmissions = gs.transmissions;
+		o.window = gs.window; o.max_coverage = gs.max_coverage; o.transmissions = gs.transmissions; o.slot_runs = gs.slot_runs;
 		*stats_out = o;
 	}
 	return WHAMD_OK;

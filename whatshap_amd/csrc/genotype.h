@@ -16,6 +16,7 @@ struct GenotypeStats {
 	double backward_ms = 0, forward_ms = 0, total_ms = 0;   // HIP events: checkpoint pass / windows (recompute + forward) / all
 	uint32_t window = 0;                   // columns per window (backward columns kept at window ends, recomputed inside)
 	uint32_t max_coverage = 0, transmissions = 0;
+	uint32_t slot_runs = 0;                // run-fused path: launches per chain (0: per-column kernels)
 };
 
 // Per-column model of the genotyper, built on the host from a Problem (columns_only):
@@ -35,6 +36,11 @@ whamd_status_t build_genotype_model(const Problem& p, GenotypeModel& m, std::str
 // (GenotypeDPTable::get_genotype_likelihoods, src/genotypedptable.cpp:444-451).
 whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, int device, uint32_t window_hint,
                                      std::vector<double>& gl_out, GenotypeStats& st, std::string& msg);
+
+// The run-fused path (genotype_slots.hip): slot runs with sums instead of minima, both chains side by side, one combine launch.
+// `used` = false (and WHAMD_OK): the table is not eligible, take genotype_solve_device's per-column kernels.
+whamd_status_t genotype_solve_slots(const Problem& p, const GenotypeModel& m, int device, std::vector<double>& gl_out, GenotypeStats& st,
+                                    bool& used, std::string& msg);
 
 // Frees the device memory genotype_solve_device keeps between calls (one column store per device).
 void genotype_release_cache();

@@ -529,6 +529,17 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 	}
 	if (T != 1 && T != 4 && T != 16) { msg = "unsupported number of transmission values"; return WHAMD_ERR_UNSUPPORTED; }
 	GENO_TRY(hipSetDevice(device));
+	// the run-fused path wherever it applies (no forced window, every column in a run, stores fit in HBM)
+	if (!window_hint && !getenv("WHAMD_GENOTYPE_COLUMNS")) {
+		bool used = false;
+		const whamd_status_t sst = genotype_solve_slots(p, m, device, gl_out, st, used, msg);
+		if (sst != WHAMD_OK) return sst;
+		if (used) return WHAMD_OK;
+		gl_out.assign((size_t)ni * n * 3, 0.0);
+		st = GenotypeStats();
+		st.n_columns = n;
+		st.transmissions = T;
+	}
 	uint32_t max_k = 0, max_proj = 0;
 	for (uint32_t c = 0; c < n; ++c) {
 		max_k = std::max<uint32_t>(max_k, p.k[c]);

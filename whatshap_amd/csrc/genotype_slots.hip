@@ -1,0 +1,592 @@
+// genotype_slots.hip -- run-fused device path of GenotypeDPTable (genotype.h; src/genotypedptable.cpp:200-441): the slot runs of
+// slots.h with SUMS instead of minima -- no records, no ties.
+//
+// One launch = one run of consecutive columns (the planner of the phasing path in genotype_mode: one (cell, transmission
+// value) per lane, 6 - log2 T lane slots, up to 3 wave slots, the reads that stay through the run select the workgroup).
+//   forward chain  (src/genotypedptable.cpp:292-441): a lane holds A_{c-1}[back(x)][i]; per column: transition over the
+//       previous transmission value (butterfly over the low lane bits: P(j -> i) is a product over the bits of i ^ j), store the
+//       transitioned value, multiply by S_i(x) = sum_a prior_c(i, a) * cost_i(x, a), sum out the reads that END in the column;
+//   backward chain (:200-289), the same runs walked from their last column to their first: a lane holds B_c[fwd(x)][i];
+//       per column: store it, multiply by S_i(x), sum out the reads that START in the column, transition;
+//   combine: ONE full-chip launch over (column, cell) after both chains: the genotype-likelihood sums
+//       L_c[individual][genotype] = sum over x, i, a of stored forward * prior * cost * stored backward (:376-383), per-block partial
+//       sums, then the normalisation of every column.  Any constant factor on a whole stored column cancels there, so the
+//       chains rescale freely: every run divides what it hands on by the total of what it received.
+// cost_i(x, a) = prod_p W_i(x)[p][a_p]; W splits over the slot classes into TABLES computed once per solve at full-chip width
+// (geno_slot_tables): G[workgroup], V[wave], S[lane] per (column, transmission value): a column costs two LDS reads of 2P doubles
+// and 2P multiplications per lane for W, then 2^(P+1) - 2 multiplications for the products of all assignments.
+// The two chains are independent until the combine: they run on two streams side by side.
+// Arithmetic is f64 (the reference: long double): parity to a relative tolerance (tests/test_gpu_genotype.py, rtol 1e-9).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "genotype.h"
+#include "slots.h"
+
+namespace whamd {
+
+namespace {
+
+constexpr int GS_MAXLOCAL = 12;      // local slots of a run (<= 6 lane + 3 wave)
+constexpr int GS_MAXA = 16;          // allele assignments (P <= 4)
+constexpr int GS_MAXGL = 1 + 3 * 4;  // normaliser + 3 genotypes of up to 4 individuals
+
+// Per column: which reads end / start in it (local slots, the order does not matter for sums) and which slots hold a read.
+struct GsCol {
+	uint32_t active;                 // slots (local and grid) that hold a read in this column
+	uint8_t n_end, n_start, first_of_table, last_of_table;
+	uint8_t end_slot[GS_MAXLOCAL], start_slot[GS_MAXLOCAL];
+};
+static_assert(sizeof(GsCol) == 32, "GsCol layout");
+// Per column: the read in every slot (tables kernel and combine kernel only).
+struct GsRow {
+	double pe[SLOT_MAXSLOTS];        // error probability of the read's entry (src/genotypecolumncostcomputer.cpp:26-48)
+	uint8_t ind[SLOT_MAXSLOTS + 2];
+	uint8_t allele[SLOT_MAXSLOTS + 2];   // 0 REF, 1 ALT, 2 BLANK
+};
+// Per run.
+struct GsRun {
+	uint32_t c0, ncols, g, L, lw, threads, has_prev, has_next;
+	uint32_t in_occ, in_identity, out_occ, pad0;
+	uint32_t in_pos[8], out_pos[8];      // entry / exit index bit of every slot (SlotRun)
+	unsigned long long tab_off;          // tables of the run: G [2^g][ncols][T][E], V [2^lw][ncols][T][E], S [ncols][64][E]  (doubles, E = 2 P)
+	unsigned long long store_off;        // the run's columns in the two column stores: [ncols][2^g * threads] doubles
+	uint32_t v_off, s_off;               // V and S relative to tab_off
+	uint32_t part_in_f, part_out_f, part_in_b, part_out_b;   // first per-wave partial sum of the exchange columns read / written (forward, backward)
+	uint32_t n_part_in_f, n_part_in_b;   // how many
+};
+struct GsDev {
+	const GsCol* cols;        // by column
+	const GsRow* rows;        // by column
+	const double* prior;      // [n_cols][T][A]
+	const double* rho;        // [n_cols]: P(one transmission bit differs) / P(it does not)  (src/transitionprobabilitycomputer.cpp:22-45)
+	const uint8_t* gidx;      // [T][A][n_ind]
+	const int8_t* h2p;        // [T][n_ind][2]
+	double* tab;
+	double* fstore;           // forward column store
+	double* bstore;           // backward column store
+	double* partials;         // per-wave sums of the exchange columns
+	uint32_t T, A, P, n_ind, n_cols, pad;
+};
+
+__device__ __forceinline__ uint32_t gs_uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t gs_pos(const uint32_t (&w)[8], uint32_t s) { return (w[s >> 2] >> ((s & 3u) * 8u)) & 31u; }
+
+// ---- tables: blockIdx.y = run; one thread per (kind, unit, column, transmission value), E = 2 P outputs each
+__global__ __launch_bounds__(256) void geno_slot_tables(GsDev G, const GsRun* __restrict__ runs) {
+	const GsRun run = runs[blockIdx.y];
+	const uint32_t T = G.T, P = G.P, E = 2u * P, tb = 31u - (uint32_t)__clz((int)T), nls = 6u - tb;
+	const uint32_t per_unit = run.ncols * T;   // entries per workgroup / wave
+	const uint32_t n_g = per_unit << run.g, n_v = per_unit << run.lw, n_s = run.ncols * 64u;
+	double* __restrict__ out = G.tab + run.tab_off;
+	for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n_g + n_v + n_s; idx += gridDim.x * blockDim.x) {
+		uint32_t kind, unit, c, i, s0, s1, bits;
+		if (idx < n_g + n_v) {
+			kind = idx < n_g ? 0u : 1u;
+			const uint32_t r = kind ? idx - n_g : idx;
+			unit = r / per_unit; c = (r % per_unit) / T; i = r % T;
+			if (kind == 0u) { s0 = run.L; s1 = run.L + run.g; } else { s0 = nls; s1 = run.L; }
+			bits = unit;
+		} else {
+			kind = 2u;
+			const uint32_t r = idx - n_g - n_v;
+			c = r >> 6; unit = r & 63u; i = unit & (T - 1u);
+			s0 = 0; s1 = nls; bits = unit >> tb;
+		}
+		const GsRow& row = G.rows[run.c0 + c];
+		const uint32_t active = G.cols[run.c0 + c].active;
+		double w[8];
+#pragma unroll
+		for (int q = 0; q < 8; ++q) w[q] = 1.0;
+		for (uint32_t s = s0; s < s1; ++s) {
+			if (!((active >> s) & 1u)) continue;
+			const uint32_t al = row.allele[s];
+			if (al > 1u) continue;   // BLANK
+			const uint32_t hap = ((bits >> (s - s0)) & 1u) ^ 1u;   // bit 0 <-> haplotype 1 (src/genotypecolumncostcomputer.cpp:61)
+			const uint32_t part = (uint32_t)G.h2p[((size_t)i * G.n_ind + row.ind[s]) * 2u + hap];
+			const double pe = row.pe[s], ok = 1.0 - pe;
+#pragma unroll
+			for (int q = 0; q < 8; ++q) {
+				const uint32_t p = (uint32_t)q >> 1, a = (uint32_t)q & 1u;
+				w[q] *= (p == part) ? (a == al ? ok : pe) : 1.0;
+			}
+		}
+		// (the same index arithmetic in the kernels: entry = ((unit * ncols + c) * T + i) * E for G / V, (c * 64 + lane) * E for S)
+		double* e = kind == 0u ? out + ((size_t)(unit * run.ncols + c) * T + i) * E
+		          : (kind == 1u ? out + run.v_off + ((size_t)(unit * run.ncols + c) * T + i) * E : out + run.s_off + ((size_t)c * 64u + unit) * E);
+#pragma unroll
+		for (int q = 0; q < 8; ++q) if ((uint32_t)q < E) e[q] = w[q];
+	}
+}
+
+// value of lane (l ^ mask), f64
+__device__ __forceinline__ double gs_lane_xor(double v, uint32_t mask) { return __shfl_xor(v, (int)mask); }
+
+template <int P>
+__device__ __forceinline__ void gs_products(const double (&W)[2 * P], double (&prod)[1 << P]) {
+	// prod[a] = prod_p W[p][a_p], built bit by bit: 2^(P+1) - 2 multiplications
+	prod[0] = W[0]; prod[1] = W[1];
+#pragma unroll
+	for (int p = 1; p < P; ++p) {
+#pragma unroll
+		for (int a = (1 << p) - 1; a >= 0; --a) {
+			prod[a | (1 << p)] = prod[a] * W[2 * p + 1];
+			prod[a] = prod[a] * W[2 * p];
+		}
+	}
+}
+
+// One run, forward (DIR 0) or backward (DIR 1).  LDS: exchange 2 x [threads] doubles | A [waves][ncols][T][E] | S [ncols][64][E] |
+// prior [ncols][T][A] | rho [ncols] | GsCol [ncols] | reduction scratch.
+template <int TB, int P, int DIR>
+__global__ __launch_bounds__(512) void geno_slot_run(GsDev G, GsRun run, const double* __restrict__ prev, double* __restrict__ cur) {
+	constexpr uint32_t T = 1u << TB, E = 2u * P, A = 1u << P;
+	constexpr int NLS = 6 - TB;
+	extern __shared__ __attribute__((aligned(16))) double gs_smem[];
+	const uint32_t w = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = gs_uni(tid >> 6);
+	const uint32_t threads = run.threads, ncols = run.ncols, L = run.L, nwaves = threads >> 6;
+	const uint32_t i = lane & (T - 1u);
+	const uint32_t lcell = tid >> TB, Pcell = (w << L) | lcell;
+	double* xbuf = gs_smem;
+	double* a_lds = xbuf + 2u * threads;
+	double* s_lds = a_lds + (size_t)nwaves * ncols * T * E;
+	double* pr_lds = s_lds + (size_t)ncols * 64u * E;
+	double* rho_lds = pr_lds + (size_t)ncols * T * A;
+	double* red = rho_lds + ((ncols + 1u) & ~1u);
+	GsCol* col_lds = reinterpret_cast<GsCol*>(red + 16);
+	const double* __restrict__ tabG = G.tab + run.tab_off;
+	// ---- prologue: tables, priors, descriptors, the entering value, the scale of the entering column
+	{
+		const uint32_t per_wave = ncols * T * E;   // A = G[w] * V[wave]
+		const double* __restrict__ g = tabG + (size_t)w * per_wave;
+		const double* __restrict__ v = tabG + run.v_off + (size_t)wave * per_wave;
+		for (uint32_t q = lane; q < per_wave; q += 64u) a_lds[(size_t)wave * per_wave + q] = g[q] * v[q];
+		const double2* __restrict__ s2 = reinterpret_cast<const double2*>(tabG + run.s_off);
+		for (uint32_t q = tid; q < ncols * 32u * E; q += threads) reinterpret_cast<double2*>(s_lds)[q] = s2[q];
+		const double* __restrict__ pr = G.prior + (size_t)run.c0 * T * A;
+		for (uint32_t q = tid; q < ncols * T * A; q += threads) pr_lds[q] = pr[q];
+		for (uint32_t q = tid; q < ncols; q += threads) rho_lds[q] = G.rho[run.c0 + q];
+		const uint4* __restrict__ cg = reinterpret_cast<const uint4*>(G.cols + run.c0);
+		for (uint32_t q = tid; q < ncols * 2u; q += threads) reinterpret_cast<uint4*>(col_lds)[q] = cg[q];
+	}
+	const bool from_other = DIR == 0 ? run.has_prev != 0u : run.has_next != 0u;
+	double val = 1.0;   // forward: column 0 starts from 1 (:313, `prev ? ... : 1`); backward: B of the last column is 1
+	double psum = 0.0;
+	if (from_other) {
+		// forward reads the exchange column in its ENTRY layout, backward in its EXIT layout (the same index space: the reads that
+		// continue across the boundary)
+		const uint32_t occ = DIR == 0 ? run.in_occ : run.out_occ;
+		uint32_t idx = 0;
+		if (DIR == 0 && run.in_identity) idx = Pcell & occ;
+		else {
+#pragma unroll
+			for (int s = 0; s < SLOT_MAXSLOTS; ++s) idx |= (((Pcell & occ) >> s) & 1u) << (DIR == 0 ? gs_pos(run.in_pos, s) : gs_pos(run.out_pos, s));
+		}
+		val = prev[(size_t)idx * T + i];
+		const uint32_t p0 = DIR == 0 ? run.part_in_f : run.part_in_b, np = DIR == 0 ? run.n_part_in_f : run.n_part_in_b;
+		for (uint32_t q = tid; q < np; q += threads) psum += G.partials[p0 + q];
+	}
+	// total of the entering column (every thread ends up with the same number): wave sums, then across the waves
+	for (int off = 32; off > 0; off >>= 1) psum += __shfl_xor(psum, off);
+	if (lane == 0) red[wave] = psum;
+	__syncthreads();
+	double inv = 1.0;
+	if (from_other) {
+		double total = 0.0;
+		for (uint32_t q = 0; q < nwaves; ++q) total += red[q];
+		inv = total > 0.0 ? 1.0 / total : 1.0;
+	}
+	double* __restrict__ store = (DIR == 0 ? G.fstore : G.bstore) + run.store_off + (size_t)w * threads + tid;
+	const size_t col_stride = (size_t)threads << run.g;
+	uint32_t xsel = 0;
+	auto sum_out = [&](uint32_t slot) {   // both lanes of a pair end up with the pair's sum
+		double other;
+		if (slot < (uint32_t)NLS) other = gs_lane_xor(val, 1u << (slot + TB));
+		else {
+			double* xb = xbuf + xsel * threads;
+			xb[tid] = val;
+			__syncthreads();
+			other = xb[tid ^ (64u << (slot - NLS))];
+			xsel ^= 1u;
+		}
+		val += other;
+	};
+	auto transition = [&](double rho) {   // sum over the other transmission value of val * P(. -> .): one fused multiply-add per bit
+#pragma unroll
+		for (int s = 0; s < TB; ++s) val = fma(rho, gs_lane_xor(val, 1u << s), val);
+	};
+	auto cell_sum = [&](uint32_t ci) -> double {   // S_i(x) of this lane's cell in column ci
+		const double* ap = a_lds + ((size_t)(wave * ncols + ci) * T + i) * E;
+		const double* sp = s_lds + ((size_t)ci * 64u + lane) * E;
+		double W[E];
+#pragma unroll
+		for (uint32_t q = 0; q < E; q += 2) {
+			const double2 av = *reinterpret_cast<const double2*>(ap + q), sv = *reinterpret_cast<const double2*>(sp + q);
+			W[q] = av.x * sv.x; W[q + 1] = av.y * sv.y;
+		}
+		double prod[A];
+		gs_products<P>(W, prod);
+		const double* pp = pr_lds + ((size_t)ci * T + i) * A;
+		double s = 0.0;
+#pragma unroll
+		for (uint32_t a = 0; a < A; ++a) s = fma(pp[a], prod[a], s);
+		return s;
+	};
+	if (DIR == 0) {
+		for (uint32_t ci = 0; ci < ncols; ++ci) {
+			const GsCol& cd = col_lds[ci];
+			const uint32_t n_end = gs_uni(cd.n_end), first = gs_uni(cd.first_of_table);
+			if (!first) transition(rho_lds[ci]);
+			store[(size_t)ci * col_stride] = val;   // sum_j A_{c-1}[back(x)][j] P(j -> i): what the likelihood sums need
+			val *= cell_sum(ci);
+			for (uint32_t e = 0; e < n_end; ++e) sum_out(gs_uni(cd.end_slot[e]));
+		}
+	} else {
+		for (uint32_t ci = ncols; ci-- > 0;) {
+			const GsCol& cd = col_lds[ci];
+			const uint32_t n_start = gs_uni(cd.n_start), first = gs_uni(cd.first_of_table);
+			store[(size_t)ci * col_stride] = val;   // B_c[fwd(x)][i]
+			if (first) break;                       // (B_{-1} is never needed, :200-289 stops at column 1)
+			val *= cell_sum(ci);
+			for (uint32_t e = 0; e < n_start; ++e) sum_out(gs_uni(cd.start_slot[e]));
+			transition(rho_lds[ci]);
+		}
+	}
+	// ---- exit: hand on what was received times 1 / (total received), and the per-wave sums of what is handed on
+	const bool to_other = DIR == 0 ? run.has_next != 0u : run.has_prev != 0u;
+	if (to_other) {
+		const uint32_t occ = DIR == 0 ? run.out_occ : run.in_occ;
+		const uint32_t localmask = (1u << L) - 1u;
+		const bool writes = (lcell & ~occ & localmask) == 0u;   // representatives: free-slot bits zero
+		uint32_t idx = 0;
+		if (DIR == 1 && run.in_identity) idx = Pcell & occ;
+		else {
+#pragma unroll
+			for (int s = 0; s < SLOT_MAXSLOTS; ++s) idx |= (((Pcell & occ) >> s) & 1u) << (DIR == 0 ? gs_pos(run.out_pos, s) : gs_pos(run.in_pos, s));
+		}
+		const double outv = val * inv;
+		if (writes) cur[(size_t)idx * T + i] = outv;
+		double ps = writes ? outv : 0.0;
+		for (int off = 32; off > 0; off >>= 1) ps += __shfl_xor(ps, off);
+		if (lane == 0) G.partials[(DIR == 0 ? run.part_out_f : run.part_out_b) + w * nwaves + wave] = ps;
+	}
+}
+
+// ---- combine: blockIdx.y = column, blockIdx.x = 256-thread block of the column's lanes (workgroup-major, as the chains stored them)
+struct GsCombineCol {
+	unsigned long long tab_off, store_off;   // the column's run
+	uint32_t v_off, s_off;
+	uint32_t ci, ncols, g, L, threads, n_blocks;
+};
+template <int TB, int P>
+__global__ __launch_bounds__(256) void geno_slot_combine(GsDev G, const GsCombineCol* __restrict__ ccols, uint32_t c_first, uint32_t max_blocks,
+                                                          double* __restrict__ gl_partials) {
+	constexpr uint32_t T = 1u << TB, E = 2u * P, A = 1u << P;
+	const uint32_t c = c_first + blockIdx.y;
+	const GsCombineCol cc = ccols[c];
+	if (blockIdx.x >= cc.n_blocks) return;
+	__shared__ double red[4][GS_MAXGL];
+	__shared__ uint8_t gidx_lds[16 * GS_MAXA * 4];
+	const uint32_t n_ind = G.n_ind, n_gl = 1u + 3u * n_ind;
+	for (uint32_t q = threadIdx.x; q < T * A * n_ind; q += 256u) gidx_lds[q] = G.gidx[q];
+	const uint32_t gt = blockIdx.x * 256u + threadIdx.x;   // lane of the column: workgroup * threads + tid
+	const uint32_t w = gt / cc.threads, tid = gt % cc.threads, lane = tid & 63u, wave = tid >> 6;
+	const uint32_t i = lane & (T - 1u), lcell = tid >> TB;
+	const GsCol cd = G.cols[c];
+	const uint32_t localmask = (1u << cc.L) - 1u;
+	const bool counts = w < (1u << cc.g) && (lcell & ~cd.active & localmask) == 0u;   // one lane per DISTINCT cell: free-slot bits zero
+	double gl[GS_MAXGL];
+#pragma unroll
+	for (int q = 0; q < GS_MAXGL; ++q) gl[q] = 0.0;
+	__syncthreads();
+	if (counts) {
+		const size_t at = cc.store_off + (size_t)cc.ci * ((size_t)cc.threads << cc.g) + gt;
+		const double fb = G.fstore[at] * G.bstore[at];
+		const double* __restrict__ tab = G.tab + cc.tab_off;
+		const double* gp = tab + ((size_t)(w * cc.ncols + cc.ci) * T + i) * E;
+		const double* vp = tab + cc.v_off + ((size_t)(wave * cc.ncols + cc.ci) * T + i) * E;
+		const double* sp = tab + cc.s_off + ((size_t)cc.ci * 64u + lane) * E;
+		double W[E];
+#pragma unroll
+		for (uint32_t q = 0; q < E; ++q) W[q] = gp[q] * vp[q] * sp[q];
+		double prod[A];
+		gs_products<P>(W, prod);
+		const double* __restrict__ pp = G.prior + ((size_t)c * T + i) * A;
+#pragma unroll
+		for (uint32_t a = 0; a < A; ++a) {
+			const double fa = fb * pp[a] * prod[a];
+			gl[0] += fa;
+			const uint8_t* gi = gidx_lds + ((size_t)i * A + a) * n_ind;
+#pragma unroll
+			for (int s = 0; s < 4; ++s) {
+				if ((uint32_t)s < n_ind) {
+					const uint32_t g = gi[s];
+					gl[1 + 3 * s + 0] += g == 0u ? fa : 0.0;
+					gl[1 + 3 * s + 1] += g == 1u ? fa : 0.0;
+					gl[1 + 3 * s + 2] += g == 2u ? fa : 0.0;
+				}
+			}
+		}
+	}
+#pragma unroll
+	for (int q = 0; q < GS_MAXGL; ++q) {
+		if ((uint32_t)q < n_gl) {
+			double v = gl[q];
+			for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+			if ((threadIdx.x & 63u) == 0) red[threadIdx.x >> 6][q] = v;
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x < n_gl)
+		gl_partials[((size_t)blockIdx.y * max_blocks + blockIdx.x) * n_gl + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// normalised genotype likelihoods of a batch of columns: block = column (src/genotypedptable.cpp:444-451)
+__global__ __launch_bounds__(64) void geno_slot_finish(const double* __restrict__ gl_partials, const GsCombineCol* __restrict__ ccols, uint32_t c_first,
+                                                       uint32_t max_blocks, uint32_t n_ind, uint32_t n_cols, double* __restrict__ gl_out) {
+	const uint32_t c = c_first + blockIdx.x, n_gl = 1u + 3u * n_ind, nb = ccols[c].n_blocks;
+	__shared__ double tot[GS_MAXGL];
+	const double* p = gl_partials + (size_t)blockIdx.x * max_blocks * n_gl;
+	if (threadIdx.x < n_gl) {
+		double v = 0.0;
+		for (uint32_t blk = 0; blk < nb; ++blk) v += p[(size_t)blk * n_gl + threadIdx.x];
+		tot[threadIdx.x] = v;
+	}
+	__syncthreads();
+	if (threadIdx.x >= 1 && threadIdx.x < n_gl) {
+		const uint32_t s = (threadIdx.x - 1) / 3, g = (threadIdx.x - 1) % 3;
+		gl_out[((size_t)s * n_cols + c) * 3 + g] = tot[threadIdx.x] / tot[0];
+	}
+}
+
+struct Cleanup {
+	std::vector<void*> allocations;
+	std::vector<hipStream_t> streams;
+	std::vector<hipEvent_t> events;
+	~Cleanup() {
+		for (hipEvent_t e : events) (void)hipEventDestroy(e);
+		for (hipStream_t s : streams) (void)hipStreamDestroy(s);
+		for (void* a : allocations) (void)hipFree(a);
+	}
+};
+
+}  // namespace
+
+// Returns WHAMD_OK with `used` = false when the table is not eligible (the caller takes the per-column kernels): a pedigree the
+// planner does not cover, a column that fits no run, stores that do not fit in HBM.
+whamd_status_t genotype_solve_slots(const Problem& p, const GenotypeModel& m, int device, std::vector<double>& gl_out, GenotypeStats& st,
+                                    bool& used, std::string& msg) {
+	used = false;
+	const uint32_t n = p.n_cols, T = p.T, ni = p.n_ind;
+	if (n < 2 || ni == 0 || ni > 4 || !(p.P == 2 || p.P == 4) || !(T == 1 || T == 4 || T == 16) || (T == 1) != (p.P == 2)) return WHAMD_OK;
+	int l_pref = 0;
+	if (const char* e = getenv("WHAMD_GENO_SLOT_L")) l_pref = atoi(e);
+	SlotPlan plan;
+	if (!plan_forward_slots(p, l_pref > 0 ? -l_pref : 0, 0, plan, 0, /*genotype_mode=*/true)) return WHAMD_OK;
+	for (const Step& s : plan.steps) if (s.kind != 2) return WHAMD_OK;   // a column no run can take
+	const uint32_t tb = T == 1 ? 0u : (T == 4 ? 2u : 4u), E = 2u * p.P, A = m.A;
+#define GS_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { msg = std::string(#expr) + " failed: " + hipGetErrorString(e_); return WHAMD_ERR_DEVICE; } } while (0)
+	GS_TRY(hipSetDevice(device));
+	const size_t n_runs = plan.runs.size();
+	// ---- host descriptors
+	std::vector<GsCol> cols(n);
+	std::vector<GsRow> rows(n);
+	std::vector<GsRun> runs(n_runs);
+	std::vector<GsCombineCol> ccols(n);
+	unsigned long long tab_words = 0, store_words = 0;
+	uint32_t n_partials = 0, max_f = 0, max_blocks = 1;
+	size_t max_lds = 0;
+	for (size_t ri = 0; ri < n_runs; ++ri) {
+		const SlotRun& sr = plan.runs[ri];
+		GsRun& r = runs[ri];
+		r.c0 = sr.c0; r.ncols = sr.ncols; r.g = sr.g; r.L = sr.L; r.lw = sr.lw; r.threads = sr.threads;
+		r.has_prev = sr.c0 > 0 ? 1u : 0u;
+		r.has_next = sr.c0 + sr.ncols < n ? 1u : 0u;
+		r.in_occ = sr.in_occ; r.in_identity = sr.in_identity; r.out_occ = sr.out_occ;
+		std::memcpy(r.in_pos, sr.in_pos, sizeof r.in_pos);
+		std::memcpy(r.out_pos, sr.out_pos, sizeof r.out_pos);
+		const unsigned long long per_unit = (unsigned long long)sr.ncols * T * E;
+		r.tab_off = tab_words;
+		r.v_off = (uint32_t)(per_unit << sr.g);
+		r.s_off = r.v_off + (uint32_t)(per_unit << sr.lw);
+		tab_words += (unsigned long long)r.s_off + (unsigned long long)sr.ncols * 64u * E;
+		r.store_off = store_words;
+		store_words += (unsigned long long)sr.ncols * ((unsigned long long)sr.threads << sr.g);
+		max_f = std::max(max_f, sr.L + sr.g);
+		const uint32_t nw = (sr.threads >> 6) << sr.g;   // per-wave partial sums of what the run hands on, one set per direction
+		r.part_out_f = n_partials; n_partials += nw;
+		r.part_out_b = n_partials; n_partials += nw;
+		const uint32_t blocks = (uint32_t)((((size_t)sr.threads << sr.g) + 255u) / 256u);
+		max_blocks = std::max(max_blocks, blocks);
+		const size_t waves = sr.threads >> 6;
+		max_lds = std::max(max_lds, ((size_t)2 * sr.threads + waves * sr.ncols * T * E + (size_t)sr.ncols * 64 * E + (size_t)sr.ncols * T * A + ((sr.ncols + 1) & ~1u) + 16) * 8 + (size_t)sr.ncols * sizeof(GsCol));
+		for (uint32_t ci = 0; ci < sr.ncols; ++ci) {
+			const uint32_t c = sr.c0 + ci;
+			const PedSlotRow& pr = plan.prows[c];
+			const SlotBtCol& bc = plan.bt_cols[c];
+			GsCol& cd = cols[c];
+			GsRow& rw = rows[c];
+			std::memset(&cd, 0, sizeof cd);
+			std::memset(&rw, 0, sizeof rw);
+			const ColumnEntry* col = p.col_begin(c);
+			for (uint32_t j = 0; j < p.k[c]; ++j) {
+				const uint32_t s = bc.slot[j];
+				cd.active |= 1u << s;
+				rw.pe[s] = m.error_prob[p.col_ptr[c] + j];
+				rw.ind[s] = col[j].sample;
+				rw.allele[s] = col[j].allele;
+			}
+			cd.first_of_table = c == 0;
+			cd.last_of_table = c + 1 == n;
+			if (pr.n_end > (uint32_t)GS_MAXLOCAL || pr.pad[0] > (uint32_t)GS_MAXLOCAL) return WHAMD_OK;
+			cd.n_end = (uint8_t)pr.n_end;
+			for (uint32_t e = 0; e < pr.n_end; ++e) cd.end_slot[e] = plan.end_slots[plan.end_off[ri] + bc.kf + e];
+			cd.n_start = (uint8_t)pr.pad[0];
+			for (uint32_t e = 0; e < pr.pad[0]; ++e) cd.start_slot[e] = plan.start_slots[plan.start_off[ri] + pr.pad[1] + e];
+			GsCombineCol& cc = ccols[c];
+			cc.tab_off = r.tab_off; cc.store_off = r.store_off; cc.v_off = r.v_off; cc.s_off = r.s_off;
+			cc.ci = ci; cc.ncols = sr.ncols; cc.g = sr.g; cc.L = sr.L; cc.threads = sr.threads; cc.n_blocks = blocks;
+		}
+	}
+	for (size_t ri = 0; ri < n_runs; ++ri) {   // the partial sums a run reads are the ones its neighbour writes
+		GsRun& r = runs[ri];
+		if (ri > 0) { r.part_in_f = runs[ri - 1].part_out_f; r.n_part_in_f = (plan.runs[ri - 1].threads >> 6) << plan.runs[ri - 1].g; }
+		if (ri + 1 < n_runs) { r.part_in_b = runs[ri + 1].part_out_b; r.n_part_in_b = (plan.runs[ri + 1].threads >> 6) << plan.runs[ri + 1].g; }
+	}
+	size_t free_b = 0, total_b = 0;
+	GS_TRY(hipMemGetInfo(&free_b, &total_b));
+	const uint32_t n_gl = 1 + 3 * ni;
+	constexpr uint32_t BATCH = 512;
+	const double need = (double)tab_words * 8 + 2.0 * (double)store_words * 8 + (double)BATCH * max_blocks * n_gl * 8 + 4.0 * ((double)(1ull << max_f) * T * 8) +
+	                    (double)n * (sizeof(GsCol) + sizeof(GsRow) + sizeof(GsCombineCol) + 8.0 * T * A + 8);
+	if (max_lds > 150 * 1024 || need + (double)(2ull << 30) > 0.8 * (double)free_b) return WHAMD_OK;   // (the per-column path windows its stores)
+	used = true;
+	gl_out.assign((size_t)ni * n * 3, 0.0);
+	st = GenotypeStats();
+	st.n_columns = n;
+	st.transmissions = T;
+	st.window = n;
+	for (uint32_t c = 0; c < n; ++c) { st.n_cells += 1ull << p.k[c]; st.max_coverage = std::max<uint32_t>(st.max_coverage, p.k[c]); }
+	Cleanup keep;
+	hipStream_t sf = nullptr, sb = nullptr;
+	GS_TRY(hipStreamCreateWithFlags(&sf, hipStreamNonBlocking)); keep.streams.push_back(sf);
+	GS_TRY(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking)); keep.streams.push_back(sb);
+	auto alloc = [&](void** dptr, size_t bytes) -> hipError_t {
+		hipError_t e = hipMalloc(dptr, std::max<size_t>(bytes, 16));
+		if (e == hipSuccess) keep.allocations.push_back(*dptr);
+		return e;
+	};
+	auto up = [&](void** dptr, const void* src, size_t bytes) -> hipError_t {
+		hipError_t e = alloc(dptr, bytes);
+		if (e == hipSuccess && bytes) e = hipMemcpyAsync(*dptr, src, bytes, hipMemcpyHostToDevice, sf);
+		return e;
+	};
+	std::vector<double> rho(n, 0.0);
+	const uint32_t nb = 2 * p.n_triples + 1;
+	if (T > 1) for (uint32_t c = 0; c < n; ++c) rho[c] = m.transition_bern[(size_t)c * nb + 1] / m.transition_bern[(size_t)c * nb];
+	GsDev G{};
+	void *d_cols, *d_rows, *d_prior, *d_rho, *d_gidx, *d_h2p, *d_runs, *d_ccols, *d_tab, *d_fs, *d_bs, *d_part, *d_glpart, *d_gl;
+	double* d_x[4];
+	GS_TRY(up(&d_cols, cols.data(), cols.size() * sizeof(GsCol)));
+	GS_TRY(up(&d_rows, rows.data(), rows.size() * sizeof(GsRow)));
+	GS_TRY(up(&d_prior, m.allele_prior.data(), m.allele_prior.size() * 8));
+	GS_TRY(up(&d_rho, rho.data(), rho.size() * 8));
+	GS_TRY(up(&d_gidx, m.genotype_index.data(), m.genotype_index.size()));
+	GS_TRY(up(&d_h2p, p.h2p.data(), p.h2p.size()));
+	GS_TRY(up(&d_runs, runs.data(), runs.size() * sizeof(GsRun)));
+	GS_TRY(up(&d_ccols, ccols.data(), ccols.size() * sizeof(GsCombineCol)));
+	GS_TRY(alloc(&d_tab, (size_t)tab_words * 8));
+	GS_TRY(alloc(&d_fs, (size_t)store_words * 8));
+	GS_TRY(alloc(&d_bs, (size_t)store_words * 8));
+	GS_TRY(alloc(&d_part, (size_t)n_partials * 8));
+	GS_TRY(alloc(&d_glpart, (size_t)BATCH * max_blocks * n_gl * 8));
+	GS_TRY(alloc(&d_gl, gl_out.size() * 8));
+	for (double*& x : d_x) GS_TRY(alloc((void**)&x, ((size_t)1 << max_f) * T * 8));
+	G.cols = (const GsCol*)d_cols; G.rows = (const GsRow*)d_rows; G.prior = (const double*)d_prior; G.rho = (const double*)d_rho;
+	G.gidx = (const uint8_t*)d_gidx; G.h2p = (const int8_t*)d_h2p; G.tab = (double*)d_tab; G.fstore = (double*)d_fs; G.bstore = (double*)d_bs;
+	G.partials = (double*)d_part; G.T = T; G.A = A; G.P = p.P; G.n_ind = ni; G.n_cols = n;
+	hipEvent_t ev[4];
+	for (hipEvent_t& e : ev) { GS_TRY(hipEventCreate(&e)); keep.events.push_back(e); }
+	using RunFn = void (*)(GsDev, GsRun, const double*, double*);
+	RunFn fwd = nullptr, bwd = nullptr;
+	if (tb == 0) { fwd = geno_slot_run<0, 2, 0>; bwd = geno_slot_run<0, 2, 1>; }
+	else if (tb == 2) { fwd = geno_slot_run<2, 4, 0>; bwd = geno_slot_run<2, 4, 1>; }
+	else { fwd = geno_slot_run<4, 4, 0>; bwd = geno_slot_run<4, 4, 1>; }
+	GS_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	GS_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	uint64_t launches = 0;
+	GS_TRY(hipEventRecord(ev[0], sf));
+	{
+		uint32_t most = 0;
+		for (const GsRun& r : runs) most = std::max<uint32_t>(most, ((r.ncols * T) << r.g) + ((r.ncols * T) << r.lw) + r.ncols * 64u);
+		const uint32_t bx = std::max(1u, std::min(256u, (most + 255u) / 256u));
+		for (size_t r0 = 0; r0 < n_runs; r0 += 32768) {
+			const uint32_t ny = (uint32_t)std::min<size_t>(32768, n_runs - r0);
+			hipLaunchKernelGGL(geno_slot_tables, dim3(bx, ny), dim3(256), 0, sf, G, (const GsRun*)d_runs + r0);
+			++launches;
+		}
+		GS_TRY(hipGetLastError());
+	}
+	GS_TRY(hipEventRecord(ev[1], sf));
+	GS_TRY(hipStreamWaitEvent(sb, ev[1], 0));   // uploads and tables are complete
+	auto lds_of = [&](const GsRun& r) {
+		const size_t waves = r.threads >> 6;
+		return ((size_t)2 * r.threads + waves * r.ncols * T * E + (size_t)r.ncols * 64 * E + (size_t)r.ncols * T * A + ((r.ncols + 1) & ~1u) + 16) * 8 + (size_t)r.ncols * sizeof(GsCol);
+	};
+	// the two chains, submissions interleaved so that neither hardware queue runs dry
+	size_t rf = 0, rb = n_runs;
+	while (rf < n_runs || rb > 0) {
+		if (rf < n_runs) {
+			const GsRun& r = runs[rf];
+			hipLaunchKernelGGL(fwd, dim3(1u << r.g), dim3(r.threads), lds_of(r), sf, G, r, (const double*)d_x[rf & 1], d_x[(rf & 1) ^ 1]);
+			++rf; ++launches;
+		}
+		if (rb > 0) {
+			--rb;
+			const GsRun& r = runs[rb];
+			hipLaunchKernelGGL(bwd, dim3(1u << r.g), dim3(r.threads), lds_of(r), sb, G, r, (const double*)d_x[2 + (rb & 1)], d_x[2 + ((rb & 1) ^ 1)]);
+			++launches;
+		}
+	}
+	GS_TRY(hipGetLastError());
+	GS_TRY(hipEventRecord(ev[2], sb));
+	GS_TRY(hipStreamWaitEvent(sf, ev[2], 0));
+	GS_TRY(hipEventRecord(ev[2], sf));
+	for (uint32_t c0 = 0; c0 < n; c0 += BATCH) {
+		const uint32_t ncol = std::min(BATCH, n - c0);
+		uint32_t gx = 1;
+		for (uint32_t c = c0; c < c0 + ncol; ++c) gx = std::max(gx, ccols[c].n_blocks);
+		if (tb == 0) hipLaunchKernelGGL((geno_slot_combine<0, 2>), dim3(gx, ncol), dim3(256), 0, sf, G, (const GsCombineCol*)d_ccols, c0, max_blocks, (double*)d_glpart);
+		else if (tb == 2) hipLaunchKernelGGL((geno_slot_combine<2, 4>), dim3(gx, ncol), dim3(256), 0, sf, G, (const GsCombineCol*)d_ccols, c0, max_blocks, (double*)d_glpart);
+		else hipLaunchKernelGGL((geno_slot_combine<4, 4>), dim3(gx, ncol), dim3(256), 0, sf, G, (const GsCombineCol*)d_ccols, c0, max_blocks, (double*)d_glpart);
+		hipLaunchKernelGGL(geno_slot_finish, dim3(ncol), dim3(64), 0, sf, (const double*)d_glpart, (const GsCombineCol*)d_ccols, c0, max_blocks, ni, n, (double*)d_gl);
+		launches += 2;
+	}
+	GS_TRY(hipGetLastError());
+	GS_TRY(hipEventRecord(ev[3], sf));
+	GS_TRY(hipMemcpyAsync(gl_out.data(), d_gl, gl_out.size() * 8, hipMemcpyDeviceToHost, sf));
+	GS_TRY(hipStreamSynchronize(sf));
+	GS_TRY(hipStreamSynchronize(sb));
+	float t_tab = 0, t_chain = 0, t_all = 0;
+	GS_TRY(hipEventElapsedTime(&t_tab, ev[0], ev[1]));
+	GS_TRY(hipEventElapsedTime(&t_chain, ev[1], ev[2]));
+	GS_TRY(hipEventElapsedTime(&t_all, ev[0], ev[3]));
+	st.backward_ms = t_chain;              // the two chains side by side
+	st.forward_ms = t_all - t_chain;       // tables + combine
+	st.total_ms = t_all;
+	st.launches = launches;
+	st.slot_runs = (uint32_t)n_runs;
+	if (getenv("WHAMD_DEBUG_TIMING"))
+		fprintf(stderr, "[whamd timing] genotype slot runs: %zu runs (%.1f columns per run), tables %.2f ms, chains %.2f ms, combine %.2f ms; tables %.1f MB, stores 2 x %.1f MB\n",
+		        n_runs, (double)n / n_runs, t_tab, t_chain, t_all - t_chain - t_tab, tab_words * 8e-6, store_words * 8e-6);
+#undef GS_TRY
+	return WHAMD_OK;
+}
+
+}  // namespace whamd

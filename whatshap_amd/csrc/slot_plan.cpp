@@ -30,16 +30,17 @@ inline uint32_t parity32(uint32_t v) { return (uint32_t)__builtin_popcount(v) & 
 
 }  // namespace
 
-bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan& plan, int lr) {
+bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan& plan, int lr, bool genotype_mode) {
 	const auto tp0 = std::chrono::steady_clock::now();
 	plan = SlotPlan();
 	const uint32_t n = p.n_cols;
 	// pedigree tables (one or two trios): a lane holds ONE (cell, transmission value); no reg slots, 6 - TB lane slots
-	const bool ped = p.T > 1;
+	const bool ped = p.T > 1 || genotype_mode;   // (one value per lane; genotype_mode also for a single individual)
 	const uint32_t TB = p.T == 4 ? 2u : (p.T == 16 ? 4u : 0u);
-	if (ped && (TB == 0 || p.n_ind < 3)) return false;
+	if (ped && !genotype_mode && (TB == 0 || p.n_ind < 3)) return false;
+	if (genotype_mode && p.T != 1 && TB == 0) return false;
 	if (!ped && !(p.T == 1 && p.n_ind == 1)) return false;
-	if (!(p.value_bound < 1073741824.0)) return false;
+	if (!genotype_mode && !(p.value_bound < 1073741824.0)) return false;
 	plan.ped = ped;
 	lr = ped ? 0 : std::max(2, std::min(lr, SLOT_LR));
 	const int n_lane = ped ? 6 - (int)TB : SLOT_LANE;
@@ -68,7 +69,7 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 	uint32_t c = c_begin;
 	while (c < c_end) {
 		auto column_step = [&]() { plan.steps.push_back(Step{0, c}); ++c; };
-		if (c + 1 >= n) { column_step(); continue; }   // the last column needs the global optimum (column_step_keys)
+		if (c + 1 >= n && !genotype_mode) { column_step(); continue; }   // the last column needs the global optimum (column_step_keys)
 		const uint32_t b0 = p.b[c];
 		const ColumnEntry* first = p.col_begin(c);
 		// ---- shape of the run: local slots L, grid slots g
@@ -79,6 +80,7 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 		}
 		const uint32_t L = std::min<uint32_t>((uint32_t)l_pref, std::max<uint32_t>((uint32_t)LMIN, kmax));
 		uint32_t g = kmax > L ? kmax - L : 0;
+		if (genotype_mode) g = std::min(g, b0);   // (a short run while the coverage ramps up rather than a column the run kernels cannot take)
 		if (g > b0 || g > (uint32_t)SLOT_GMAX || p.k[c] > L + g) { column_step(); continue; }
 		// grid reads: the g entering reads that end last (ties: the younger read)
 		std::vector<uint32_t> order(b0);
@@ -88,6 +90,12 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 			if (ea != eb) return ea > eb;
 			return a > bb;
 		});
+		if (genotype_mode) {
+			// g was sized for the columns ahead; a grid read must outlive this column, or the run would be empty (every column has
+			// to lie in a run here): fewer grid slots if the reads allow it
+			while (g > 0 && c + 1 < n && last_col[first[order[g - 1]].read_id] <= c) --g;
+			if (p.k[c] > L + g) { column_step(); continue; }
+		}
 		RunDraft d;
 		d.c0 = c; d.g = g; d.L = L; d.lw = L - (uint32_t)LMIN;
 		const uint32_t nslots = L + g;
@@ -126,26 +134,27 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 		};
 		for (uint32_t s = 0; s < nslots; ++s) if (cur[s] >= 0) slot_of[cur[s]] = (int8_t)s;
 		// ---- walk the columns
-		const size_t rows_mark = c, ends_mark = plan.end_slots.size();
+		const size_t rows_mark = c, ends_mark = plan.end_slots.size(), starts_mark = plan.start_slots.size();
 		std::vector<int32_t> started;   // reads that got their slot inside the run (marks to clear)
 		uint32_t c1 = c, n_ends = 0;
 		bool symmetric = true;
 		uint32_t run_forms = 2;   // pedigree runs: NF = 2 or 4 forms per transmission value
 		while (c1 < n && c1 - c < max_run_cols) {
-			if (c1 + 1 == n) break;
-			if (c1 >= grid_end) break;
+			if (c1 + 1 == n && !genotype_mode) break;
+			if (c1 >= grid_end && !(genotype_mode && c1 + 1 == n)) break;   // (genotyping: nothing follows the last column, its reads need not be summed out)
 			if (c1 >= c_end) break;
 			if (c1 > c && p.b[c1] == 0) break;
 			const ColumnEntry* col = p.col_begin(c1);
 			const uint32_t kc = p.k[c1], bc = c1 == c ? b0 : p.b[c1];
 			const uint32_t n_new = kc - bc, n_end = kc - p.f[c1];
-			if (n_end > (uint32_t)SLOT_MAXEND || n_ends + n_end > (uint32_t)SLOT_MAXENDS_RUN) break;
+			if (!genotype_mode && (n_end > (uint32_t)SLOT_MAXEND || n_ends + n_end > (uint32_t)SLOT_MAXENDS_RUN)) break;
+			if (genotype_mode && n_ends + n_end > 250u) break;
 			uint32_t n_free = 0;
 			for (uint32_t s = 0; s < L; ++s) n_free += cur[s] < 0;
 			if (n_new > n_free) break;
 			bool ok = true;
 			if (!ped) for (uint32_t j = 0; j < kc && ok; ++j) ok = std::abs(p.delta[(size_t)p.col_ptr[c1] + j]) < SLOT_DELTA_LIMIT;
-			if (ped) {
+			if (ped && !genotype_mode) {
 				// at most PSLOT_MAXFORMS forms per transmission value; the run's tables grow with the widest column (NF 2 -> 4)
 				uint32_t most = 0;
 				for (uint32_t t = 0; t < p.T; ++t) most = std::max<uint32_t>(most, (uint32_t)(p.term_end(c1, t) - p.term_begin(c1, t)));
@@ -164,9 +173,10 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 					cur[s] = (int32_t)col[j].read_id;
 					slot_of[col[j].read_id] = (int8_t)s;
 					started.push_back((int32_t)col[j].read_id);
+					if (genotype_mode) plan.start_slots.push_back((uint8_t)s);
 				}
 			}
-			const int32_t* dl = p.delta.data() + (size_t)p.col_ptr[c1] * p.n_ind;   // [individual][bit]; n_ind == 1 unless ped
+			const int32_t* dl = genotype_mode ? nullptr : p.delta.data() + (size_t)p.col_ptr[c1] * p.n_ind;   // [individual][bit]; n_ind == 1 unless ped
 			SlotRow row{};
 			PedSlotRow prow{};
 			SlotBtCol bc_rec{};
@@ -177,7 +187,7 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 				prow.recomb = p.recomb[c1];
 				for (uint32_t j = 0; j < kc; ++j) {
 					const int s = slot_of[col[j].read_id];
-					prow.dslot[s] = dl[(size_t)col[j].sample * kc + j];
+					if (!genotype_mode) prow.dslot[s] = dl[(size_t)col[j].sample * kc + j];
 					prow.ind[s] = col[j].sample;
 					bc_rec.slot[j] = (uint8_t)s;
 				}
@@ -210,6 +220,7 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 			uint32_t en = 0;
 			for (uint32_t j = 0; j < kc; ++j) {
 				if ((p.fwd_mask[c1] >> j) & 1u) continue;
+				if (genotype_mode && c1 + 1 == n) break;   // (the last column of the table: nothing is summed out)
 				const int s = slot_of[col[j].read_id];
 				if (s >= (int)L) { ok = false; break; }   // a grid read would end (excluded by grid_end)
 				uint32_t M = 0;
@@ -221,9 +232,11 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 					if (s < lr) bit ^= ((r >> s) & 1u) & mflip;
 					qmask |= bit << r;
 				}
-				row.end[en].info = (uint32_t)s | (qmask << 8) | (mflip << 24);
-				row.end[en].M = M;
-				if (ped) {   // (the kernel's cell index has no reg bits: M as it is)
+				if (en < (uint32_t)SLOT_MAXEND) {
+					row.end[en].info = (uint32_t)s | (qmask << 8) | (mflip << 24);
+					row.end[en].M = M;
+				}
+				if (ped && !genotype_mode) {   // (the kernel's cell index has no reg bits: M as it is)
 					if (en == 0) { prow.info0 = (uint32_t)s; prow.M0 = M; }
 					else if (en == 1) { prow.info1 = (uint32_t)s; prow.M1 = M; }
 					else { prow.info2 = (uint32_t)s; prow.M2 = M; }
@@ -236,6 +249,10 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 			row.n_end = en;
 			prow.n_end = en;
 			if (ped) bc_rec.pad[0] = (uint8_t)en;
+			if (genotype_mode) {
+				prow.pad[0] = n_new;
+				prow.pad[1] = (uint32_t)(plan.start_slots.size() - starts_mark) - n_new;
+			}
 			// after the projection the ended reads' slots are free again
 			for (uint32_t j = 0; j < kc; ++j) {
 				if ((p.fwd_mask[c1] >> j) & 1u) continue;
@@ -252,10 +269,16 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 			size_t keep = 0;
 			for (size_t i = rows_mark; i < c1; ++i) keep += ped ? prows_g[i].n_end : rows_g[i].n_end;
 			plan.end_slots.resize(ends_mark + keep);
+			if (genotype_mode) {
+				size_t keep_starts = 0;
+				for (size_t i = rows_mark; i < c1; ++i) keep_starts += prows_g[i].pad[0];
+				plan.start_slots.resize(starts_mark + keep_starts);
+			}
 		}
-		if (c1 - c < 2) {   // not worth a launch of its own
+		if (c1 - c < (genotype_mode ? 1u : 2u)) {   // not worth a launch of its own
 			for (uint32_t cc = c; cc < c1; ++cc) col_to_row[cc] = -1;
 			plan.end_slots.resize(ends_mark);
+			plan.start_slots.resize(starts_mark);
 			release_marks();
 			for (int32_t r : started) slot_of[r] = -1;
 			column_step();
@@ -290,7 +313,7 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 			PedSlotExtra ex{};
 			ex.tb = TB;
 			ex.nf = 2;   // (recomputed: run_forms may have grown for a column that was dropped again)
-			for (uint32_t i = 0; i < d.ncols; ++i)
+			for (uint32_t i = 0; i < d.ncols && !genotype_mode; ++i)
 				for (uint32_t t = 0; t < p.T; ++t) if (p.term_end(c + i, t) - p.term_begin(c + i, t) > 2) ex.nf = 4;
 			ex.fwn = d.ncols * p.T * ex.nf;
 			ex.arow = (ex.fwn + 3u) & ~3u;
@@ -307,6 +330,7 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 		plan.steps.push_back(Step{2, (uint32_t)plan.runs.size()});
 		plan.runs.push_back(run);
 		plan.end_off.push_back((uint32_t)ends_mark);
+		plan.start_off.push_back((uint32_t)starts_mark);
 		drafts.push_back(d);
 		plan.n_run_columns += d.ncols;
 		c = c1;
@@ -343,6 +367,8 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 			for (SlotRun run : q.runs) { run.ctrl_off += ctrl_base; plan.runs.push_back(run); }
 			plan.pextra.insert(plan.pextra.end(), q.pextra.begin(), q.pextra.end());
 			for (uint32_t off : q.end_off) plan.end_off.push_back(off + end_base);
+			for (uint32_t off : q.start_off) plan.start_off.push_back(off + (uint32_t)plan.start_slots.size());
+			plan.start_slots.insert(plan.start_slots.end(), q.start_slots.begin(), q.start_slots.end());
 			plan.end_slots.insert(plan.end_slots.end(), q.end_slots.begin(), q.end_slots.end());
 			plan.ctrl.insert(plan.ctrl.end(), q.ctrl.begin(), q.ctrl.end());
 			plan.n_run_columns += q.n_run_columns;
@@ -355,7 +381,7 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 		// (a pedigree table is ONE job: across a column no read spans the T transmission values still couple the two sides)
 		if (!ped && (si == 0 || p.b[c0] == 0)) plan.component_first_step.push_back((uint32_t)si);
 	}
-	if (ped) {
+	if (ped && !genotype_mode) {
 		// a table that mostly falls back to per-column steps (genotypes not trusted: up to 16 forms per value) is better off
 		// with the LDS-resident trio runs / the per-column kernels
 		if (plan.n_run_columns * 2 < n) return false;

@@ -182,6 +182,10 @@ struct SlotPlan {
 	uint64_t n_run_columns = 0;
 	// pedigree tables (T > 1): rows of the run columns (indexed by column, like `rows`), per-run extras, words of all tables
 	bool ped = false;
+	// genotype_mode: per run (start_off) the local slot of every read that STARTS inside the run, forward order; per column
+	// PedSlotRow::pad[0] = reads starting in the column, pad[1] = how many started in earlier columns of the run
+	std::vector<uint8_t> start_slots;
+	std::vector<uint32_t> start_off;
 	std::vector<PedSlotRow, NoInitAllocator<PedSlotRow>> prows;
 	std::vector<PedSlotExtra> pextra;
 	uint64_t table_words = 0;
@@ -193,7 +197,10 @@ struct SlotPlan {
 // use_symmetry: 0 never halve, >= 1 halve every run whose columns are symmetric and that has a grid slot.
 // A table with T = 4 or 16 gets pedigree slot runs (plan.ped; l_pref and lr are then ignored unless l_pref < 0: -l_pref
 // local slots, for tests).
-bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan& plan, int lr = 2);
+// genotype_mode (genotype_slots.hip): the same one-value-per-lane layout for the forward-backward genotyper, for any T in {1, 4, 16}
+// (T = 1: six lane slots); only the slot assignment, the ending reads (prows / ctrl / bt_cols) and the exchange layouts are
+// planned -- no cost forms (Problem::terms is not needed), no tables.
+bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan& plan, int lr = 2, bool genotype_mode = false);
 
 // Host-only diagnostic (slot_emulate.cpp): executes `plan` cell by cell the way the kernels do.  For planner tests on
 // small inputs; never part of a solve.
