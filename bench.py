@@ -57,8 +57,10 @@ WORKLOADS = {
     "blocks3": dict(variants=100000, coverage=20, blocks=3, in_flight=3),          # three configs[4] blocks in flight on one GPU
     "irregular": dict(irregular=True, variants=100000, coverage=20),               # Poisson starts, geometric lengths (mean 16), coverage capped
     "quartet": dict(quartet=True, variants=50000, coverage=13),                    # two trios sharing parents, T = 16
+    "genotype": dict(genotype=True, variants=50000, coverage=15),                  # GenotypeDPTable, single individual
+    "genotype_trio": dict(genotype=True, trio=True, variants=20000, coverage=15),  # GenotypeDPTable, trio
 }
-EXTRA_CONFIGS = ["config1", "config3", "blocks3", "irregular", "quartet"]
+EXTRA_CONFIGS = ["config1", "config3", "blocks3", "irregular", "quartet", "genotype", "genotype_trio"]
 
 
 def parse_args():
@@ -74,6 +76,7 @@ def parse_args():
     ap.add_argument("--trio", action="store_true", help="configs[3]-shaped workload (trio PedMEC, coverage 15) instead")
     ap.add_argument("--quartet", action="store_true", help="two trios sharing their parents (T = 16), coverage 13")
     ap.add_argument("--irregular", action="store_true", help="irregular read layout (whatshap_amd.synthetic.irregular_block, seed 7)")
+    ap.add_argument("--genotype", action="store_true", help="the genotyping row: GenotypeDPTable (forward-backward, f64) instead of the phasing table")
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="a named workload (sets the flags above)")
     ap.add_argument("--configs", default="auto", choices=["auto", "on", "off"],
                     help="append the other single-GPU workloads as `configs` (auto: N=1 and no workload flags)")
@@ -134,7 +137,7 @@ def build_block(args, seed, n_variants, n_columns_limit=None):
 
 def workload_flags(args):
     out = []
-    for flag in ("trio", "quartet", "irregular"):
+    for flag in ("trio", "quartet", "irregular", "genotype"):
         if getattr(args, flag):
             out.append("--" + flag)
     return out
@@ -259,7 +262,10 @@ def run_pmc_passes(args, kernel_substring, keep_dir):
     env = dict(os.environ, TMPDIR="/tmp")
     averages, counts, notes = {}, {}, []
     os.makedirs(keep_dir, exist_ok=True)
-    for name, counters in (PMC_PASSES[:1] if args.sub else PMC_PASSES):
+    passes = PMC_PASSES[:1] if args.sub else PMC_PASSES
+    if args.genotype:   # how many of the VALU instructions are f64 (they hold a SIMD for 4 cycles, not 2)
+        passes = list(passes) + [("f64", "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64")]
+    for name, counters in passes:
         out_dir = tempfile.mkdtemp(prefix=f"whamd_pmc_{name}_", dir="/tmp")
         cmd = [rocprof, "--kernel-trace", "--pmc"] + counters.split() + ["--output-format", "csv", "-d", out_dir, "-o", "p", "--"] + inner
         try:
@@ -326,6 +332,12 @@ def roofline_from_counters(pmc, avg_launch_us, kernel, bytes_per_launch_model, a
         out["achieved"] = valu / cycles
         out["frac"] = out["achieved"] / out["peak"]
         out["valu_issue_frac"] = out["frac"]
+    f64 = [pmc.get(k) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")]
+    if valu is not None and any(x is not None for x in f64):
+        n64 = sum(x for x in f64 if x is not None)
+        out["f64_instructions_per_launch"] = n64
+        # SIMD-cycles the VALU instructions occupy (2 per wave64 instruction, 4 when it is f64) over the SIMD-cycles of the launch
+        out["valu_busy_frac_f64_weighted"] = (2.0 * valu + 2.0 * n64) / (N_SIMD * cycles)
     fetch_kb, write_kb = pmc.get("FETCH_SIZE"), pmc.get("WRITE_SIZE")
     if fetch_kb is not None and write_kb is not None:
         # MI355X_MICROARCH.md "HBM": gfx950's FETCH_SIZE reports half of a wide coalesced read stream -> doubled; WRITE_SIZE as is
@@ -364,6 +376,104 @@ def self_launch(args):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def with_uniform_priors(p):
+    """Genotype priors 1/3, 1/3, 1/3 for every individual and column: what `whatshap genotype` passes when it has none."""
+    import numpy as np
+    from whatshap_amd import _native
+
+    n_ind, n_var = p.n_individuals, p.n_variants
+    gl = np.full((n_ind, n_var, 3), 1.0 / 3.0)
+    return _native.ProblemArrays(p.read_ptr, p.var_position, p.var_allele, p.var_quality, p.read_sample_id, p.individual_id, p.triple_ids,
+                                 p.genotype.reshape(n_ind, n_var), gl, p.recombcost, p.positions, False, n_variants=n_var)
+
+
+def genotype_main(args):
+    """`--genotype`: the genotyping row.  A step = one whamd_genotype_likelihoods call from host arrays
+    (constructor + every likelihood of the reference class, whatshap/core.pyx:581-602); `value` = columns / the HIP-event
+    time of a step (tables + both chains + combine; inputs uploaded before the events start, like the phasing line);
+    `end_to_end` = columns / the wall time of the call.  roofline: the run kernel's VALU issue fraction (f64 instructions
+    occupy a SIMD for 4 cycles instead of 2: `f64_weighted_frac`) and the combine kernel's measured HBM fraction."""
+    import numpy as np
+    from whatshap_amd import _native
+
+    if _native.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if args.trio and args.coverage == 20:
+        args.coverage = 15
+    v = args.variants or (20000 if args.trio else 50000)
+    seed = 4 if args.trio else 2
+    problem = with_uniform_priors(build_block(args, seed, v))
+    n = int(problem.positions.size)
+    for _ in range(args.warmup):
+        _native.genotype_likelihoods(problem, n)
+    if args.pmc_inner:
+        _native.genotype_likelihoods(problem, n)
+        return
+    wall, dev, stats = [], [], None
+    for _ in range(args.steps):
+        t0 = time.perf_counter()
+        gl, stats = _native.genotype_likelihoods(problem, n)
+        wall.append(time.perf_counter() - t0)
+        dev.append(stats["total_ms"] / 1e3)
+    dev_s, wall_s = float(np.median(dev)), float(np.median(wall))
+    T = 4 if args.trio else 1
+    out = {
+        "metric": "variant-columns/sec of GenotypeDPTable (forward-backward + every genotype likelihood) at max-coverage %d" % args.coverage,
+        "value": n / dev_s, "unit": "variant-columns/s", "cells_per_s": stats["n_cells"] * T / dev_s,
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dev_s * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"synthetic {'trio' if args.trio else 'single individual'}, {n} SNVs, max-coverage {args.coverage}, uniform genotype priors, GenotypeDPTable",
+                   "transmission_values": stats["transmissions"], "slot_runs_per_chain": stats["slot_runs"], "launches": stats["launches"],
+                   "optimal_cost_checksum": int(round(float(gl[:, :, 1].sum()) * 1e6)),   # (sum of the heterozygous likelihoods x 1e6: a fingerprint of the output)
+                   "value_is": "median over the steps of columns / HIP-event time of one call (tables + both chains + combine)"},
+        "rank0": {"forward_ms_per_step": stats["backward_ms"], "backtrace_ms_per_step": stats["forward_ms"], "forward_launches_per_step": float(stats["launches"]),
+                  "note": "forward_ms = the two chains side by side, backtrace_ms = tables + combine (the fields of the phasing line reused)"},
+        "end_to_end": {"value": n / wall_s, "unit": "variant-columns/s", "ms_per_step": wall_s * 1e3,
+                       "what": "whamd_genotype_likelihoods from host arrays: flatten + model + plan + upload + device + download (wall, median)"},
+        "bipartition_costs_per_s": stats["n_cells"] * T / dev_s,
+    }
+    kernel = "geno_slot_run" if stats["slot_runs"] else "geno_forward"
+    avg_launch_us = stats["backward_ms"] * 1e3 / max(stats["slot_runs"], 1) if stats["slot_runs"] else stats["total_ms"] * 1e3 / max(stats["launches"], 1)
+    pmc, pmc_note = None, "skipped"
+    if args.pmc in ("on", "auto"):
+        _native.release_caches()
+        try:
+            pmc, pmc_note = run_pmc_passes(args, kernel, args.pmc_keep)
+        except Exception as exc:  # noqa: BLE001
+            pmc_note = repr(exc)
+    roof = roofline_from_counters(pmc, avg_launch_us, kernel, 0.0, args)
+    roof.pop("hbm_model_ratio", None)
+    roof.pop("hbm_model_note", None)
+    roof["pmc_note"] = pmc_note
+    roof["launch_time_note"] = "chain time / runs per chain (the two chains run side by side on two streams: a launch's own duration is at most this)"
+    out["roofline"] = roof
+    if args.cpu_baseline_columns != 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from genotype_cases import reference_likelihoods
+        from oracle import build_cython_ref
+
+        if build_cython_ref.available():
+            ref = build_cython_ref.import_reference()
+            ramp = 2 * args.coverage
+            cols = args.cpu_baseline_columns if args.cpu_baseline_columns > 0 else (12 if args.trio else (150 if args.sub else 400))
+            times = {}
+            for c in (ramp, ramp + cols):   # steady-state columns = the difference of two prefixes of the same ReadSet
+                prefix = with_uniform_priors(build_block(args, seed, v, n_columns_limit=c))
+                t0 = time.perf_counter()
+                want = reference_likelihoods(prefix, ref)
+                times[c] = time.perf_counter() - t0
+            got, _ = _native.genotype_likelihoods(prefix, int(prefix.positions.size))
+            steady = max(times[ramp + cols] - times[ramp], 1e-9)
+            out["cpu_baseline"] = {"value": cols / steady, "unit": "variant-columns/s", "cores": 1, "kind": "reference",
+                                   "sample": f"{cols} steady-state columns (prefix of {ramp + cols} minus prefix of {ramp} columns of the same ReadSet), whatshap.core.GenotypeDPTable "
+                                             f"constructor + every get_genotype_likelihoods (long double), {times[ramp + cols]:.1f} s",
+                                   "host": cpu_info()}
+            out["parity_prefix_max_abs_diff"] = float(np.abs(got - want).max())
+            out["speedup_vs_cpu_baseline_device_only"] = out["value"] / out["cpu_baseline"]["value"]
+            out["speedup_vs_cpu_baseline"] = out["end_to_end"]["value"] / out["cpu_baseline"]["value"]
+    print(json.dumps(out), flush=True)
 
 
 def dominant_kernel(args):
@@ -418,7 +528,7 @@ def main():
     args = parse_args()
     if args.cpu_sample_worker:
         return cpu_sample_worker(args)
-    explicit = any(a in sys.argv[1:] for a in ("--workload", "--trio", "--quartet", "--irregular", "--variants", "--coverage", "--blocks", "--blocks-per-gpu", "--path", "--option"))
+    explicit = any(a in sys.argv[1:] for a in ("--workload", "--trio", "--quartet", "--irregular", "--genotype", "--variants", "--coverage", "--blocks", "--blocks-per-gpu", "--path", "--option"))
     if args.workload:
         for key, value in WORKLOADS[args.workload].items():
             setattr(args, key, value)
@@ -426,6 +536,8 @@ def main():
 
     if not os.path.exists(os.path.join(ROOT, "whatshap_amd", "libwhatshap_amd.so")):
         entry.build()
+    if args.genotype:
+        return genotype_main(args)
     if args.gpus > 1 and "RANK" not in os.environ:
         return self_launch(args)
 

@@ -55,7 +55,10 @@ def test_larger_cases_vs_the_reference_class(kw):
         got, stats = device_likelihoods(p, window)
         assert np.allclose(got, want, rtol=RTOL, atol=ATOL), (window, np.abs(got - want).max())
         assert np.allclose(got.sum(axis=2), 1.0)
-        assert (stats["slot_runs"] > 0) == (window == 0), stats   # both device paths were exercised
+        # both device paths were exercised: the run-fused one whenever every column fits a run (the planner says), never under a forced window
+        plan = _native.plan_summary(p, "genotype_slots")
+        eligible = plan["invariants_ok"] == 1 and plan["n_resident_columns"] == plan["n_columns"]
+        assert (stats["slot_runs"] > 0) == (window == 0 and eligible), (stats, plan)
     assert stats["n_columns"] == kw["n_variants"]
 
 

@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "device_table.h"
+#include "genotype.h"
 
 namespace whamd {
 
@@ -307,6 +308,10 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	const auto tu0 = std::chrono::steady_clock::now();
 	size_t free_b = 0, total_b = 0;
 	HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+	if (free_b < total_b / 2) {   // a genotyping call of this process may be holding its column store (genotype.h): give it back first
+		genotype_release_cache();
+		HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+	}
 	m.use_slots = (m.path == "auto" || m.path == "slots") && !m.wide && plan_forward_slots(p, p.T > 1 ? (m.slot_l_set ? -m.slot_l : 0) : std::max(8, m.slot_l), m.symmetry, m.splan, m.slot_lr);
 	// pedigree slot runs keep their cost-form tables in HBM (slots.h): at most a quarter of what is free, else the older paths
 	if (m.use_slots && m.splan.ped && m.splan.table_words * 4ull > free_b / 4) m.use_slots = false;

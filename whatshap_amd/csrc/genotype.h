@@ -44,5 +44,12 @@ whamd_status_t genotype_solve_slots(const Problem& p, const GenotypeModel& m, in
 
 // Frees the device memory genotype_solve_device keeps between calls (one column store per device).
 void genotype_release_cache();
+// The column store kept between calls (mapping tens of GB of fresh device memory took seconds in one call out of four):
+// acquire returns the cached block of `device` grown to `bytes` and marks it in use, or nullptr (in use by another call,
+// allocation failed, caching disabled) -- the caller then allocates its own.  release marks it idle again; a block larger than
+// a quarter of the device's memory is freed instead of kept (a later phasing solve sizes its arena from what is free).
+void* genotype_slab_acquire(int device, size_t bytes);
+void genotype_slab_release(int device);
+size_t genotype_slab_idle_bytes(int device);
 
 }  // namespace whamd

@@ -496,6 +496,39 @@ SlabCache g_slab[16];
 std::mutex g_slab_mutex;
 }  // namespace
 
+void* genotype_slab_acquire(int device, size_t bytes) {
+	if (device < 0 || device >= 16 || getenv("WHAMD_GENOTYPE_NO_CACHE")) return nullptr;
+	std::lock_guard<std::mutex> lock(g_slab_mutex);
+	SlabCache& sc = g_slab[device];
+	if (sc.in_use) return nullptr;
+	if (sc.bytes < bytes) {
+		if (sc.ptr) (void)hipFree(sc.ptr);
+		sc = SlabCache();
+		if (hipMalloc(&sc.ptr, bytes) == hipSuccess) sc.bytes = bytes;
+		else { sc = SlabCache(); (void)hipGetLastError(); return nullptr; }
+	}
+	sc.in_use = true;
+	return sc.ptr;
+}
+
+void genotype_slab_release(int device) {
+	if (device < 0 || device >= 16) return;
+	std::lock_guard<std::mutex> lock(g_slab_mutex);
+	SlabCache& sc = g_slab[device];
+	sc.in_use = false;
+	size_t free_b = 0, total_b = 0;
+	if (sc.ptr && hipMemGetInfo(&free_b, &total_b) == hipSuccess && sc.bytes > total_b / 4) {
+		(void)hipFree(sc.ptr);
+		sc = SlabCache();
+	}
+}
+
+size_t genotype_slab_idle_bytes(int device) {
+	if (device < 0 || device >= 16) return 0;
+	std::lock_guard<std::mutex> lock(g_slab_mutex);
+	return g_slab[device].in_use ? 0 : g_slab[device].bytes;
+}
+
 void genotype_release_cache() {
 	std::lock_guard<std::mutex> lock(g_slab_mutex);
 	int current = 0;
@@ -552,10 +585,7 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 	const uint32_t n_gl = 1 + 3 * ni;
 	size_t free_b = 0, total_b = 0;
 	GENO_TRY(hipMemGetInfo(&free_b, &total_b));
-	{   // the block kept from an earlier call is available to this one
-		std::lock_guard<std::mutex> lock(g_slab_mutex);
-		if (device < 16 && !g_slab[device].in_use) free_b += g_slab[device].bytes;
-	}
+	free_b += genotype_slab_idle_bytes(device);   // the block kept from an earlier call is available to this one
 	// Window = how many backward columns are kept at once.  If all of them fit in a quarter of the free memory there is one
 	// window and no column is computed twice; otherwise the reference's scheme: sqrt(n) kept columns, the rest recomputed.
 	uint32_t K = window_hint;
@@ -579,13 +609,14 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 	hipStream_t stream = nullptr;
 	GENO_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
 	std::vector<void*> allocations;
+	std::vector<hipStream_t> extra_streams;   // the second chain's stream and every event: owned by cleanup(), whichever way the call ends
+	std::vector<hipEvent_t> all_events;
 	bool slab_from_cache = false;
 	auto cleanup = [&]() {
+		for (hipEvent_t e : all_events) (void)hipEventDestroy(e);
+		for (hipStream_t s2 : extra_streams) (void)hipStreamDestroy(s2);
 		for (void* a : allocations) (void)hipFree(a);
-		if (slab_from_cache) {
-			std::lock_guard<std::mutex> lock(g_slab_mutex);
-			g_slab[device].in_use = false;
-		}
+		if (slab_from_cache) genotype_slab_release(device);
 		if (stream) (void)hipStreamDestroy(stream);
 	};
 	auto fail = [&](hipError_t e, const char* what) {
@@ -658,6 +689,18 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 	GENO_DEV(alloc((void**)&d_tables, (size_t)n * G.table_stride * sizeof(double)));
 	G.tables = d_tables;
 	const size_t table_bytes = (size_t)G.table_stride * sizeof(double);   // the step kernels copy their column's tables into LDS
+	if (table_bytes + sizeof(GenoShared) > 160 * 1024) {   // (a quartet beyond coverage ~35: never reached below the 25-read limit, but never a bare launch failure)
+		cleanup();
+		msg = "lookup tables of " + std::to_string(table_bytes >> 10) + " KiB per column do not fit in LDS";
+		return WHAMD_ERR_UNSUPPORTED;
+	}
+	if (table_bytes + sizeof(GenoShared) > 64 * 1024) {   // more than 64 KiB of LDS needs the opt-in on every kernel that asks for it
+		const void* fns[] = {(const void*)geno_backward<1>, (const void*)geno_backward<4>, (const void*)geno_backward<16>,
+		                     (const void*)geno_forward<1, 0>, (const void*)geno_forward<1, 1>, (const void*)geno_forward<1, 2>,
+		                     (const void*)geno_forward<4, 0>, (const void*)geno_forward<4, 1>, (const void*)geno_forward<4, 2>,
+		                     (const void*)geno_forward<16, 0>, (const void*)geno_forward<16, 1>, (const void*)geno_forward<16, 2>};
+		for (const void* fn : fns) GENO_DEV(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)sizeof(GenoShared)));
+	}
 	// ---- buffers: every column buffer carries its per-block sums
 	struct Buf { double* v = nullptr; double* partials = nullptr; uint32_t blocks = 0; };
 	Buf alpha[2], pp[2];
@@ -666,20 +709,8 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 		// one slab for all of them (tens of thousands of hipMalloc calls would take seconds)
 		const size_t count = 4 + (size_t)n_windows + wstore.size() + astore.size();
 		double *slab_v = nullptr, *slab_p = nullptr;
-		{
-			const size_t want = count * buf_doubles * 8;
-			std::lock_guard<std::mutex> lock(g_slab_mutex);
-			SlabCache& sc = g_slab[device < 16 ? device : 0];
-			if (device < 16 && !sc.in_use && !getenv("WHAMD_GENOTYPE_NO_CACHE")) {
-				if (sc.bytes < want) {
-					if (sc.ptr) (void)hipFree(sc.ptr);
-					sc = SlabCache();
-					if (hipMalloc(&sc.ptr, want) == hipSuccess) sc.bytes = want;
-					else { sc = SlabCache(); (void)hipGetLastError(); }
-				}
-				if (sc.ptr) { sc.in_use = true; slab_from_cache = true; slab_v = (double*)sc.ptr; }
-			}
-		}
+		slab_v = (double*)genotype_slab_acquire(device, count * buf_doubles * 8);
+		slab_from_cache = slab_v != nullptr;
 		if (!slab_v) GENO_DEV(alloc((void**)&slab_v, count * buf_doubles * 8));
 		GENO_DEV(alloc((void**)&slab_p, count * (size_t)max_blocks * 8));
 		size_t next = 0;
@@ -694,7 +725,7 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 	GENO_DEV(alloc((void**)&d_glpart, (size_t)std::min<uint32_t>(K, n_windows == 1 ? 1024u : K) * max_blocks * n_gl * 8));
 	GENO_DEV(alloc((void**)&d_gl, gl_out.size() * 8));
 	hipEvent_t ev[3];
-	for (hipEvent_t& e : ev) GENO_DEV(hipEventCreate(&e));
+	for (hipEvent_t& e : ev) { GENO_DEV(hipEventCreate(&e)); all_events.push_back(e); }
 	uint64_t launches = 0;
 	// one backward step: column c, B_c in `in` (null: last column) -> B_{c-1} in `out`
 	auto backward = [&](uint32_t c, const Buf* in, Buf& out, hipStream_t on = nullptr) -> hipError_t {
@@ -763,9 +794,12 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 		// by side -- they meet only in the likelihood sums, which one batched launch per 1024 columns computes afterwards
 		hipStream_t stream2 = nullptr;
 		GENO_DEV(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+		extra_streams.push_back(stream2);
 		hipEvent_t ev_start, ev_fwd;
 		GENO_DEV(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
+		all_events.push_back(ev_start);
 		GENO_DEV(hipEventCreateWithFlags(&ev_fwd, hipEventDisableTiming));
+		all_events.push_back(ev_fwd);
 		GENO_DEV(hipEventRecord(ev_start, stream));
 		GENO_DEV(hipStreamWaitEvent(stream2, ev_start, 0));   // (uploads happened on `stream`)
 		// interleave the submissions so that neither hardware queue runs dry
@@ -807,18 +841,17 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 			GENO_DEV(hipGetLastError());
 		}
 		GENO_DEV(hipStreamSynchronize(stream));
-		(void)hipEventDestroy(ev_start);
-		(void)hipEventDestroy(ev_fwd);
-		(void)hipStreamDestroy(stream2);
 	} else {
 	// ---- windows: the backward columns of window w + 1 are recomputed on a second stream (into the other half of the window
 	// store) while the forward pass runs through window w
 	hipStream_t stream2 = nullptr;
 	GENO_DEV(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+	extra_streams.push_back(stream2);
 	hipEvent_t ev_back[2], ev_fwd[2], ev_pass1;
-	for (hipEvent_t& e : ev_back) GENO_DEV(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-	for (hipEvent_t& e : ev_fwd) GENO_DEV(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+	for (hipEvent_t& e : ev_back) { GENO_DEV(hipEventCreateWithFlags(&e, hipEventDisableTiming)); all_events.push_back(e); }
+	for (hipEvent_t& e : ev_fwd) { GENO_DEV(hipEventCreateWithFlags(&e, hipEventDisableTiming)); all_events.push_back(e); }
 	GENO_DEV(hipEventCreateWithFlags(&ev_pass1, hipEventDisableTiming));
+	all_events.push_back(ev_pass1);
 	GENO_DEV(hipEventRecord(ev_pass1, stream));
 	GENO_DEV(hipStreamWaitEvent(stream2, ev_pass1, 0));   // the kept columns (and the uploads) are complete
 	auto recompute = [&](uint32_t w) -> hipError_t {      // B_c for the columns of window w but its last, on stream2
@@ -859,10 +892,6 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 	}
 	GENO_DEV(hipStreamSynchronize(stream));
 	GENO_DEV(hipStreamSynchronize(stream2));
-	for (hipEvent_t& e : ev_back) (void)hipEventDestroy(e);
-	for (hipEvent_t& e : ev_fwd) (void)hipEventDestroy(e);
-	(void)hipEventDestroy(ev_pass1);
-	(void)hipStreamDestroy(stream2);
 	}
 	GENO_DEV(hipEventRecord(ev[2], stream));
 	if (getenv("WHAMD_DEBUG_TIMING")) {
@@ -881,7 +910,6 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 	st.forward_ms = ms12;
 	st.total_ms = ms02;
 	st.launches = launches;
-	for (hipEvent_t& e : ev) (void)hipEventDestroy(e);
 	const double ms_done = phase_ms();
 	cleanup();
 	if (getenv("WHAMD_DEBUG_TIMING"))

@@ -59,8 +59,10 @@ struct GsRun {
 	unsigned long long store_off;        // the run's columns in the two column stores: [ncols][2^g * threads] doubles
 	uint32_t v_off, s_off;               // V and S relative to tab_off
 	uint32_t part_in_f, part_out_f, part_in_b, part_out_b;   // first per-wave partial sum of the exchange columns read / written (forward, backward)
-	uint32_t n_part_in_f, n_part_in_b;   // how many
+	uint32_t n_part_in_f, n_part_in_b;   // how many (0: this run does not rescale -- only every GS_RESCALE-th run does)
+	uint32_t emit_f, emit_b;             // 1: the neighbour rescales, leave the per-wave sums of what is handed on
 };
+constexpr uint32_t GS_RESCALE = 4;       // runs between two rescalings of a chain (a run shrinks the values by ~1e-10 at most: far from 1e-308)
 struct GsDev {
 	const GsCol* cols;        // by column
 	const GsRow* rows;        // by column
@@ -125,8 +127,21 @@ __global__ __launch_bounds__(256) void geno_slot_tables(GsDev G, const GsRun* __
 	}
 }
 
-// value of lane (l ^ mask), f64
-__device__ __forceinline__ double gs_lane_xor(double v, uint32_t mask) { return __shfl_xor(v, (int)mask); }
+// value of lane (l ^ mask), f64; mask is wave-uniform.  Masks inside a row of 16 lanes are DPP moves (no LDS crossbar round trip).
+template <int CTRL>
+__device__ __forceinline__ double gs_dpp(double v) {
+	const unsigned long long u = __double_as_longlong(v);
+	const uint32_t lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)u, CTRL, 0xF, 0xF, true);
+	const uint32_t hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(u >> 32), CTRL, 0xF, 0xF, true);
+	return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double gs_lane_xor(double v, uint32_t mask) {
+	if (mask == 1u) return gs_dpp<0xB1>(v);                       // quad_perm [1,0,3,2]
+	if (mask == 2u) return gs_dpp<0x4E>(v);                       // quad_perm [2,3,0,1]
+	if (mask == 4u) return gs_dpp<0x1B>(gs_dpp<0x141>(v));        // row_half_mirror (i ^ 7), quad_perm [3,2,1,0] (i ^ 3)
+	if (mask == 8u) return gs_dpp<0x141>(gs_dpp<0x140>(v));       // row_mirror (i ^ 15), row_half_mirror (i ^ 7)
+	return __shfl_xor(v, (int)mask);
+}
 
 template <int P>
 __device__ __forceinline__ void gs_products(const double (&W)[2 * P], double (&prod)[1 << P]) {
@@ -189,15 +204,18 @@ __global__ __launch_bounds__(512) void geno_slot_run(GsDev G, GsRun run, const d
 			for (int s = 0; s < SLOT_MAXSLOTS; ++s) idx |= (((Pcell & occ) >> s) & 1u) << (DIR == 0 ? gs_pos(run.in_pos, s) : gs_pos(run.out_pos, s));
 		}
 		val = prev[(size_t)idx * T + i];
-		const uint32_t p0 = DIR == 0 ? run.part_in_f : run.part_in_b, np = DIR == 0 ? run.n_part_in_f : run.n_part_in_b;
-		for (uint32_t q = tid; q < np; q += threads) psum += G.partials[p0 + q];
 	}
-	// total of the entering column (every thread ends up with the same number): wave sums, then across the waves
-	for (int off = 32; off > 0; off >>= 1) psum += __shfl_xor(psum, off);
-	if (lane == 0) red[wave] = psum;
+	// total of the entering column when this run rescales (every thread ends up with the same number): wave sums, then across the waves
+	const uint32_t np = DIR == 0 ? run.n_part_in_f : run.n_part_in_b;
+	if (np) {
+		const uint32_t p0 = DIR == 0 ? run.part_in_f : run.part_in_b;
+		for (uint32_t q = tid; q < np; q += threads) psum += G.partials[p0 + q];
+		for (int off = 32; off > 0; off >>= 1) psum += __shfl_xor(psum, off);
+		if (lane == 0) red[wave] = psum;
+	}
 	__syncthreads();
 	double inv = 1.0;
-	if (from_other) {
+	if (np) {
 		double total = 0.0;
 		for (uint32_t q = 0; q < nwaves; ++q) total += red[q];
 		inv = total > 0.0 ? 1.0 / total : 1.0;
@@ -272,9 +290,11 @@ __global__ __launch_bounds__(512) void geno_slot_run(GsDev G, GsRun run, const d
 		}
 		const double outv = val * inv;
 		if (writes) cur[(size_t)idx * T + i] = outv;
-		double ps = writes ? outv : 0.0;
-		for (int off = 32; off > 0; off >>= 1) ps += __shfl_xor(ps, off);
-		if (lane == 0) G.partials[(DIR == 0 ? run.part_out_f : run.part_out_b) + w * nwaves + wave] = ps;
+		if (DIR == 0 ? run.emit_f : run.emit_b) {
+			double ps = writes ? outv : 0.0;
+			for (int off = 32; off > 0; off >>= 1) ps += __shfl_xor(ps, off);
+			if (lane == 0) G.partials[(DIR == 0 ? run.part_out_f : run.part_out_b) + w * nwaves + wave] = ps;
+		}
 	}
 }
 
@@ -284,6 +304,7 @@ struct GsCombineCol {
 	uint32_t v_off, s_off;
 	uint32_t ci, ncols, g, L, threads, n_blocks;
 };
+constexpr uint32_t GS_COMBINE_LANES = 4;   // lanes of a column one thread of the combine kernel goes through (one reduction for all of them)
 template <int TB, int P>
 __global__ __launch_bounds__(256) void geno_slot_combine(GsDev G, const GsCombineCol* __restrict__ ccols, uint32_t c_first, uint32_t max_blocks,
                                                           double* __restrict__ gl_partials) {
@@ -295,20 +316,33 @@ __global__ __launch_bounds__(256) void geno_slot_combine(GsDev G, const GsCombin
 	__shared__ uint8_t gidx_lds[16 * GS_MAXA * 4];
 	const uint32_t n_ind = G.n_ind, n_gl = 1u + 3u * n_ind;
 	for (uint32_t q = threadIdx.x; q < T * A * n_ind; q += 256u) gidx_lds[q] = G.gidx[q];
-	const uint32_t gt = blockIdx.x * 256u + threadIdx.x;   // lane of the column: workgroup * threads + tid
-	const uint32_t w = gt / cc.threads, tid = gt % cc.threads, lane = tid & 63u, wave = tid >> 6;
-	const uint32_t i = lane & (T - 1u), lcell = tid >> TB;
 	const GsCol cd = G.cols[c];
 	const uint32_t localmask = (1u << cc.L) - 1u;
-	const bool counts = w < (1u << cc.g) && (lcell & ~cd.active & localmask) == 0u;   // one lane per DISTINCT cell: free-slot bits zero
+	const uint32_t n_lanes = cc.threads << cc.g;
+	const double* __restrict__ tab = G.tab + cc.tab_off;
+	const size_t col_at = cc.store_off + (size_t)cc.ci * n_lanes;
+	// all the loads of the thread's lanes first: one memory round trip
+	double fv[GS_COMBINE_LANES], bv[GS_COMBINE_LANES];
+	bool counts[GS_COMBINE_LANES];
+#pragma unroll
+	for (uint32_t j = 0; j < GS_COMBINE_LANES; ++j) {
+		const uint32_t gt = (blockIdx.x * GS_COMBINE_LANES + j) * 256u + threadIdx.x;   // lane of the column: workgroup * threads + tid
+		const uint32_t lcell = (gt % cc.threads) >> TB;
+		counts[j] = gt < n_lanes && (lcell & ~cd.active & localmask) == 0u;   // one lane per DISTINCT cell: free-slot bits zero
+		fv[j] = counts[j] ? G.fstore[col_at + gt] : 0.0;
+		bv[j] = counts[j] ? G.bstore[col_at + gt] : 0.0;
+	}
 	double gl[GS_MAXGL];
 #pragma unroll
 	for (int q = 0; q < GS_MAXGL; ++q) gl[q] = 0.0;
 	__syncthreads();
-	if (counts) {
-		const size_t at = cc.store_off + (size_t)cc.ci * ((size_t)cc.threads << cc.g) + gt;
-		const double fb = G.fstore[at] * G.bstore[at];
-		const double* __restrict__ tab = G.tab + cc.tab_off;
+#pragma unroll
+	for (uint32_t j = 0; j < GS_COMBINE_LANES; ++j) {
+		if (!counts[j]) continue;
+		const uint32_t gt = (blockIdx.x * GS_COMBINE_LANES + j) * 256u + threadIdx.x;
+		const uint32_t w = gt / cc.threads, tid = gt % cc.threads, lane = tid & 63u, wave = tid >> 6;
+		const uint32_t i = lane & (T - 1u);
+		const double fb = fv[j] * bv[j];
 		const double* gp = tab + ((size_t)(w * cc.ncols + cc.ci) * T + i) * E;
 		const double* vp = tab + cc.v_off + ((size_t)(wave * cc.ncols + cc.ci) * T + i) * E;
 		const double* sp = tab + cc.s_off + ((size_t)cc.ci * 64u + lane) * E;
@@ -324,12 +358,12 @@ __global__ __launch_bounds__(256) void geno_slot_combine(GsDev G, const GsCombin
 			gl[0] += fa;
 			const uint8_t* gi = gidx_lds + ((size_t)i * A + a) * n_ind;
 #pragma unroll
-			for (int s = 0; s < 4; ++s) {
-				if ((uint32_t)s < n_ind) {
-					const uint32_t g = gi[s];
-					gl[1 + 3 * s + 0] += g == 0u ? fa : 0.0;
-					gl[1 + 3 * s + 1] += g == 1u ? fa : 0.0;
-					gl[1 + 3 * s + 2] += g == 2u ? fa : 0.0;
+			for (int s2 = 0; s2 < 4; ++s2) {
+				if ((uint32_t)s2 < n_ind) {
+					const uint32_t g = gi[s2];
+					gl[1 + 3 * s2 + 0] += g == 0u ? fa : 0.0;
+					gl[1 + 3 * s2 + 1] += g == 1u ? fa : 0.0;
+					gl[1 + 3 * s2 + 2] += g == 2u ? fa : 0.0;
 				}
 			}
 		}
@@ -369,7 +403,9 @@ struct Cleanup {
 	std::vector<void*> allocations;
 	std::vector<hipStream_t> streams;
 	std::vector<hipEvent_t> events;
+	int slab_device = -1;
 	~Cleanup() {
+		if (slab_device >= 0) genotype_slab_release(slab_device);
 		for (hipEvent_t e : events) (void)hipEventDestroy(e);
 		for (hipStream_t s : streams) (void)hipStreamDestroy(s);
 		for (void* a : allocations) (void)hipFree(a);
@@ -422,7 +458,7 @@ whamd_status_t genotype_solve_slots(const Problem& p, const GenotypeModel& m, in
 		const uint32_t nw = (sr.threads >> 6) << sr.g;   // per-wave partial sums of what the run hands on, one set per direction
 		r.part_out_f = n_partials; n_partials += nw;
 		r.part_out_b = n_partials; n_partials += nw;
-		const uint32_t blocks = (uint32_t)((((size_t)sr.threads << sr.g) + 255u) / 256u);
+		const uint32_t blocks = (uint32_t)((((size_t)sr.threads << sr.g) + 256u * GS_COMBINE_LANES - 1u) / (256u * GS_COMBINE_LANES));
 		max_blocks = std::max(max_blocks, blocks);
 		const size_t waves = sr.threads >> 6;
 		max_lds = std::max(max_lds, ((size_t)2 * sr.threads + waves * sr.ncols * T * E + (size_t)sr.ncols * 64 * E + (size_t)sr.ncols * T * A + ((sr.ncols + 1) & ~1u) + 16) * 8 + (size_t)sr.ncols * sizeof(GsCol));
@@ -454,13 +490,20 @@ whamd_status_t genotype_solve_slots(const Problem& p, const GenotypeModel& m, in
 			cc.ci = ci; cc.ncols = sr.ncols; cc.g = sr.g; cc.L = sr.L; cc.threads = sr.threads; cc.n_blocks = blocks;
 		}
 	}
-	for (size_t ri = 0; ri < n_runs; ++ri) {   // the partial sums a run reads are the ones its neighbour writes
+	for (size_t ri = 0; ri < n_runs; ++ri) {   // the partial sums a run reads are the ones its neighbour writes; every GS_RESCALE-th run of a chain rescales
 		GsRun& r = runs[ri];
-		if (ri > 0) { r.part_in_f = runs[ri - 1].part_out_f; r.n_part_in_f = (plan.runs[ri - 1].threads >> 6) << plan.runs[ri - 1].g; }
-		if (ri + 1 < n_runs) { r.part_in_b = runs[ri + 1].part_out_b; r.n_part_in_b = (plan.runs[ri + 1].threads >> 6) << plan.runs[ri + 1].g; }
+		if (ri > 0 && ri % GS_RESCALE == 0) {
+			r.part_in_f = runs[ri - 1].part_out_f; r.n_part_in_f = (plan.runs[ri - 1].threads >> 6) << plan.runs[ri - 1].g;
+			runs[ri - 1].emit_f = 1;
+		}
+		if (ri + 1 < n_runs && (n_runs - 1 - ri) % GS_RESCALE == 0) {
+			r.part_in_b = runs[ri + 1].part_out_b; r.n_part_in_b = (plan.runs[ri + 1].threads >> 6) << plan.runs[ri + 1].g;
+			runs[ri + 1].emit_b = 1;
+		}
 	}
 	size_t free_b = 0, total_b = 0;
 	GS_TRY(hipMemGetInfo(&free_b, &total_b));
+	free_b += genotype_slab_idle_bytes(device);   // the column store kept from an earlier call is available to this one
 	const uint32_t n_gl = 1 + 3 * ni;
 	constexpr uint32_t BATCH = 512;
 	const double need = (double)tab_words * 8 + 2.0 * (double)store_words * 8 + (double)BATCH * max_blocks * n_gl * 8 + 4.0 * ((double)(1ull << max_f) * T * 8) +
@@ -502,8 +545,10 @@ whamd_status_t genotype_solve_slots(const Problem& p, const GenotypeModel& m, in
 	GS_TRY(up(&d_runs, runs.data(), runs.size() * sizeof(GsRun)));
 	GS_TRY(up(&d_ccols, ccols.data(), ccols.size() * sizeof(GsCombineCol)));
 	GS_TRY(alloc(&d_tab, (size_t)tab_words * 8));
-	GS_TRY(alloc(&d_fs, (size_t)store_words * 8));
-	GS_TRY(alloc(&d_bs, (size_t)store_words * 8));
+	d_fs = genotype_slab_acquire(device, 2 * (size_t)store_words * 8);   // both column stores in the block kept between calls
+	if (d_fs) keep.slab_device = device;
+	else GS_TRY(alloc(&d_fs, 2 * (size_t)store_words * 8));
+	d_bs = (double*)d_fs + store_words;
 	GS_TRY(alloc(&d_part, (size_t)n_partials * 8));
 	GS_TRY(alloc(&d_glpart, (size_t)BATCH * max_blocks * n_gl * 8));
 	GS_TRY(alloc(&d_gl, gl_out.size() * 8));
