@@ -157,8 +157,10 @@ __device__ __forceinline__ void gs_products(const double (&W)[2 * P], double (&p
 	}
 }
 
-// One run, forward (DIR 0) or backward (DIR 1).  LDS: exchange 2 x [threads] doubles | A [waves][ncols][T][E] | S [ncols][64][E] |
-// prior [ncols][T][A] | rho [ncols] | GsCol [ncols] | reduction scratch.
+// One run, forward (DIR 0) or backward (DIR 1).  LDS: exchange 2 x [threads] doubles | A [waves][ncols][T][E] | prior [ncols][T][A] |
+// rho [ncols] | reduction scratch | GsCol [ncols].  The lane part S of W is the same for every workgroup of every run that
+// shares the column: each lane reads its 2 P doubles per column straight from the table (L2), one column ahead of their use --
+// copying the run's whole S table into LDS up front was most of a launch (57 KB per workgroup for a trio).
 template <int TB, int P, int DIR>
 __global__ __launch_bounds__(512) void geno_slot_run(GsDev G, GsRun run, const double* __restrict__ prev, double* __restrict__ cur) {
 	constexpr uint32_t T = 1u << TB, E = 2u * P, A = 1u << P;
@@ -170,8 +172,7 @@ __global__ __launch_bounds__(512) void geno_slot_run(GsDev G, GsRun run, const d
 	const uint32_t lcell = tid >> TB, Pcell = (w << L) | lcell;
 	double* xbuf = gs_smem;
 	double* a_lds = xbuf + 2u * threads;
-	double* s_lds = a_lds + (size_t)nwaves * ncols * T * E;
-	double* pr_lds = s_lds + (size_t)ncols * 64u * E;
+	double* pr_lds = a_lds + (size_t)nwaves * ncols * T * E;
 	double* rho_lds = pr_lds + (size_t)ncols * T * A;
 	double* red = rho_lds + ((ncols + 1u) & ~1u);
 	GsCol* col_lds = reinterpret_cast<GsCol*>(red + 16);
@@ -181,9 +182,20 @@ __global__ __launch_bounds__(512) void geno_slot_run(GsDev G, GsRun run, const d
 		const uint32_t per_wave = ncols * T * E;   // A = G[w] * V[wave]
 		const double* __restrict__ g = tabG + (size_t)w * per_wave;
 		const double* __restrict__ v = tabG + run.v_off + (size_t)wave * per_wave;
-		for (uint32_t q = lane; q < per_wave; q += 64u) a_lds[(size_t)wave * per_wave + q] = g[q] * v[q];
-		const double2* __restrict__ s2 = reinterpret_cast<const double2*>(tabG + run.s_off);
-		for (uint32_t q = tid; q < ncols * 32u * E; q += threads) reinterpret_cast<double2*>(s_lds)[q] = s2[q];
+		for (uint32_t q0 = 0; q0 < per_wave; q0 += 512u) {   // eight loads in flight per lane before the first is used
+			double gv[8], vv[8];
+#pragma unroll
+			for (uint32_t u = 0; u < 8; ++u) {
+				const uint32_t q = q0 + u * 64u + lane;
+				gv[u] = q < per_wave ? g[q] : 0.0;
+				vv[u] = q < per_wave ? v[q] : 0.0;
+			}
+#pragma unroll
+			for (uint32_t u = 0; u < 8; ++u) {
+				const uint32_t q = q0 + u * 64u + lane;
+				if (q < per_wave) a_lds[(size_t)wave * per_wave + q] = gv[u] * vv[u];
+			}
+		}
 		const double* __restrict__ pr = G.prior + (size_t)run.c0 * T * A;
 		for (uint32_t q = tid; q < ncols * T * A; q += threads) pr_lds[q] = pr[q];
 		for (uint32_t q = tid; q < ncols; q += threads) rho_lds[q] = G.rho[run.c0 + q];
@@ -239,14 +251,19 @@ __global__ __launch_bounds__(512) void geno_slot_run(GsDev G, GsRun run, const d
 #pragma unroll
 		for (int s = 0; s < TB; ++s) val = fma(rho, gs_lane_xor(val, 1u << s), val);
 	};
-	auto cell_sum = [&](uint32_t ci) -> double {   // S_i(x) of this lane's cell in column ci
+	const double2* __restrict__ tabS = reinterpret_cast<const double2*>(tabG + run.s_off) + (size_t)lane * (E / 2u);
+	auto load_s = [&](uint32_t ci, double (&sv)[E]) {   // the lane part of W for column ci (global: the same 64 entries for everybody, L2-resident)
+		const double2* sp = tabS + (size_t)ci * 32u * E;
+#pragma unroll
+		for (uint32_t q = 0; q < E; q += 2) { const double2 t2 = sp[q / 2u]; sv[q] = t2.x; sv[q + 1] = t2.y; }
+	};
+	auto cell_sum = [&](uint32_t ci, const double (&sv)[E]) -> double {   // S_i(x) of this lane's cell in column ci
 		const double* ap = a_lds + ((size_t)(wave * ncols + ci) * T + i) * E;
-		const double* sp = s_lds + ((size_t)ci * 64u + lane) * E;
 		double W[E];
 #pragma unroll
 		for (uint32_t q = 0; q < E; q += 2) {
-			const double2 av = *reinterpret_cast<const double2*>(ap + q), sv = *reinterpret_cast<const double2*>(sp + q);
-			W[q] = av.x * sv.x; W[q + 1] = av.y * sv.y;
+			const double2 av = *reinterpret_cast<const double2*>(ap + q);
+			W[q] = av.x * sv[q]; W[q + 1] = av.y * sv[q + 1];
 		}
 		double prod[A];
 		gs_products<P>(W, prod);
@@ -256,24 +273,33 @@ __global__ __launch_bounds__(512) void geno_slot_run(GsDev G, GsRun run, const d
 		for (uint32_t a = 0; a < A; ++a) s = fma(pp[a], prod[a], s);
 		return s;
 	};
+	double s_cur[E], s_next[E];
 	if (DIR == 0) {
+		load_s(0, s_cur);
 		for (uint32_t ci = 0; ci < ncols; ++ci) {
 			const GsCol& cd = col_lds[ci];
 			const uint32_t n_end = gs_uni(cd.n_end), first = gs_uni(cd.first_of_table);
+			load_s(ci + 1 < ncols ? ci + 1 : ci, s_next);
 			if (!first) transition(rho_lds[ci]);
 			store[(size_t)ci * col_stride] = val;   // sum_j A_{c-1}[back(x)][j] P(j -> i): what the likelihood sums need
-			val *= cell_sum(ci);
+			val *= cell_sum(ci, s_cur);
 			for (uint32_t e = 0; e < n_end; ++e) sum_out(gs_uni(cd.end_slot[e]));
+#pragma unroll
+			for (uint32_t q = 0; q < E; ++q) s_cur[q] = s_next[q];
 		}
 	} else {
+		load_s(ncols - 1u, s_cur);
 		for (uint32_t ci = ncols; ci-- > 0;) {
 			const GsCol& cd = col_lds[ci];
 			const uint32_t n_start = gs_uni(cd.n_start), first = gs_uni(cd.first_of_table);
+			load_s(ci ? ci - 1 : 0u, s_next);
 			store[(size_t)ci * col_stride] = val;   // B_c[fwd(x)][i]
 			if (first) break;                       // (B_{-1} is never needed, :200-289 stops at column 1)
-			val *= cell_sum(ci);
+			val *= cell_sum(ci, s_cur);
 			for (uint32_t e = 0; e < n_start; ++e) sum_out(gs_uni(cd.start_slot[e]));
 			transition(rho_lds[ci]);
+#pragma unroll
+			for (uint32_t q = 0; q < E; ++q) s_cur[q] = s_next[q];
 		}
 	}
 	// ---- exit: hand on what was received times 1 / (total received), and the per-wave sums of what is handed on
@@ -304,98 +330,96 @@ struct GsCombineCol {
 	uint32_t v_off, s_off;
 	uint32_t ci, ncols, g, L, threads, n_blocks;
 };
-constexpr uint32_t GS_COMBINE_LANES = 4;   // lanes of a column one thread of the combine kernel goes through (one reduction for all of them)
+constexpr uint32_t GS_COMBINE_LANES = 8;   // lanes of a column one thread of the combine kernel goes through (one reduction for all of them)
+// Per lane only U(x, i, a) = forward * backward * prod_p W_i(x)[p][a_p] is formed and summed over the cells x -- the prior and the
+// genotype of every individual depend on (i, a) alone, they are applied to the T x A sums of a column by geno_slot_finish.
+// A thread's lanes share lane & 63, hence the transmission value i: it accumulates A numbers; the block reduces them over the
+// lanes with the same i and leaves u_partials[column][block][i][a].
 template <int TB, int P>
 __global__ __launch_bounds__(256) void geno_slot_combine(GsDev G, const GsCombineCol* __restrict__ ccols, uint32_t c_first, uint32_t max_blocks,
-                                                          double* __restrict__ gl_partials) {
+                                                          double* __restrict__ u_partials) {
 	constexpr uint32_t T = 1u << TB, E = 2u * P, A = 1u << P;
 	const uint32_t c = c_first + blockIdx.y;
 	const GsCombineCol cc = ccols[c];
 	if (blockIdx.x >= cc.n_blocks) return;
-	__shared__ double red[4][GS_MAXGL];
-	__shared__ uint8_t gidx_lds[16 * GS_MAXA * 4];
-	const uint32_t n_ind = G.n_ind, n_gl = 1u + 3u * n_ind;
-	for (uint32_t q = threadIdx.x; q < T * A * n_ind; q += 256u) gidx_lds[q] = G.gidx[q];
+	__shared__ double red[4][T * A];
 	const GsCol cd = G.cols[c];
 	const uint32_t localmask = (1u << cc.L) - 1u;
 	const uint32_t n_lanes = cc.threads << cc.g;
 	const double* __restrict__ tab = G.tab + cc.tab_off;
 	const size_t col_at = cc.store_off + (size_t)cc.ci * n_lanes;
+	const uint32_t lane = threadIdx.x & 63u, i = lane & (T - 1u);
 	// all the loads of the thread's lanes first: one memory round trip
-	double fv[GS_COMBINE_LANES], bv[GS_COMBINE_LANES];
-	bool counts[GS_COMBINE_LANES];
+	double fb[GS_COMBINE_LANES];
 #pragma unroll
 	for (uint32_t j = 0; j < GS_COMBINE_LANES; ++j) {
 		const uint32_t gt = (blockIdx.x * GS_COMBINE_LANES + j) * 256u + threadIdx.x;   // lane of the column: workgroup * threads + tid
 		const uint32_t lcell = (gt % cc.threads) >> TB;
-		counts[j] = gt < n_lanes && (lcell & ~cd.active & localmask) == 0u;   // one lane per DISTINCT cell: free-slot bits zero
-		fv[j] = counts[j] ? G.fstore[col_at + gt] : 0.0;
-		bv[j] = counts[j] ? G.bstore[col_at + gt] : 0.0;
+		const bool counts = gt < n_lanes && (lcell & ~cd.active & localmask) == 0u;   // one lane per DISTINCT cell: free-slot bits zero
+		fb[j] = counts ? G.fstore[col_at + gt] * G.bstore[col_at + gt] : 0.0;
 	}
-	double gl[GS_MAXGL];
+	double sw[E];   // the lane part of W is the same for all of the thread's lanes
+	{
+		const double* sp = tab + cc.s_off + ((size_t)cc.ci * 64u + lane) * E;
 #pragma unroll
-	for (int q = 0; q < GS_MAXGL; ++q) gl[q] = 0.0;
-	__syncthreads();
+		for (uint32_t q = 0; q < E; ++q) sw[q] = sp[q];
+	}
+	double acc[A];
+#pragma unroll
+	for (uint32_t a = 0; a < A; ++a) acc[a] = 0.0;
 #pragma unroll
 	for (uint32_t j = 0; j < GS_COMBINE_LANES; ++j) {
-		if (!counts[j]) continue;
 		const uint32_t gt = (blockIdx.x * GS_COMBINE_LANES + j) * 256u + threadIdx.x;
-		const uint32_t w = gt / cc.threads, tid = gt % cc.threads, lane = tid & 63u, wave = tid >> 6;
-		const uint32_t i = lane & (T - 1u);
-		const double fb = fv[j] * bv[j];
+		if (gt >= n_lanes) continue;   // (wave-uniform: whole waves lie inside or outside the column)
+		const uint32_t w = gt / cc.threads, wave = (gt % cc.threads) >> 6;
 		const double* gp = tab + ((size_t)(w * cc.ncols + cc.ci) * T + i) * E;
 		const double* vp = tab + cc.v_off + ((size_t)(wave * cc.ncols + cc.ci) * T + i) * E;
-		const double* sp = tab + cc.s_off + ((size_t)cc.ci * 64u + lane) * E;
 		double W[E];
 #pragma unroll
-		for (uint32_t q = 0; q < E; ++q) W[q] = gp[q] * vp[q] * sp[q];
+		for (uint32_t q = 0; q < E; ++q) W[q] = gp[q] * vp[q] * sw[q];
 		double prod[A];
 		gs_products<P>(W, prod);
-		const double* __restrict__ pp = G.prior + ((size_t)c * T + i) * A;
 #pragma unroll
-		for (uint32_t a = 0; a < A; ++a) {
-			const double fa = fb * pp[a] * prod[a];
-			gl[0] += fa;
-			const uint8_t* gi = gidx_lds + ((size_t)i * A + a) * n_ind;
-#pragma unroll
-			for (int s2 = 0; s2 < 4; ++s2) {
-				if ((uint32_t)s2 < n_ind) {
-					const uint32_t g = gi[s2];
-					gl[1 + 3 * s2 + 0] += g == 0u ? fa : 0.0;
-					gl[1 + 3 * s2 + 1] += g == 1u ? fa : 0.0;
-					gl[1 + 3 * s2 + 2] += g == 2u ? fa : 0.0;
-				}
-			}
-		}
+		for (uint32_t a = 0; a < A; ++a) acc[a] = fma(fb[j], prod[a], acc[a]);
 	}
+	// sum over the lanes with the same transmission value: the lane bits above the TB low ones, then the four waves
 #pragma unroll
-	for (int q = 0; q < GS_MAXGL; ++q) {
-		if ((uint32_t)q < n_gl) {
-			double v = gl[q];
-			for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-			if ((threadIdx.x & 63u) == 0) red[threadIdx.x >> 6][q] = v;
-		}
+	for (uint32_t a = 0; a < A; ++a) {
+		double v = acc[a];
+#pragma unroll
+		for (int bit = TB; bit < 6; ++bit) v += gs_lane_xor(v, 1u << bit);
+		if (lane < T) red[threadIdx.x >> 6][lane * A + a] = v;
 	}
 	__syncthreads();
-	if (threadIdx.x < n_gl)
-		gl_partials[((size_t)blockIdx.y * max_blocks + blockIdx.x) * n_gl + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+	if (threadIdx.x < T * A)
+		u_partials[((size_t)blockIdx.y * max_blocks + blockIdx.x) * (T * A) + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-// normalised genotype likelihoods of a batch of columns: block = column (src/genotypedptable.cpp:444-451)
-__global__ __launch_bounds__(64) void geno_slot_finish(const double* __restrict__ gl_partials, const GsCombineCol* __restrict__ ccols, uint32_t c_first,
-                                                       uint32_t max_blocks, uint32_t n_ind, uint32_t n_cols, double* __restrict__ gl_out) {
-	const uint32_t c = c_first + blockIdx.x, n_gl = 1u + 3u * n_ind, nb = ccols[c].n_blocks;
+// normalised genotype likelihoods of a batch of columns: block = column.  L_c[individual][genotype] = sum over (i, a) with that
+// genotype of prior_c(i, a) * U_c[i][a]  (src/genotypedptable.cpp:376-383, :444-451)
+__global__ __launch_bounds__(256) void geno_slot_finish(GsDev G, const double* __restrict__ u_partials, const GsCombineCol* __restrict__ ccols, uint32_t c_first,
+                                                        uint32_t max_blocks, double* __restrict__ gl_out) {
+	const uint32_t c = c_first + blockIdx.x, TA = G.T * G.A, n_ind = G.n_ind, n_gl = 1u + 3u * n_ind, nb = ccols[c].n_blocks;
+	__shared__ double u[16 * GS_MAXA];
 	__shared__ double tot[GS_MAXGL];
-	const double* p = gl_partials + (size_t)blockIdx.x * max_blocks * n_gl;
+	const double* p = u_partials + (size_t)blockIdx.x * max_blocks * TA;
+	if (threadIdx.x < TA) {
+		double v = 0.0;
+		for (uint32_t blk = 0; blk < nb; ++blk) v += p[(size_t)blk * TA + threadIdx.x];
+		u[threadIdx.x] = v * G.prior[(size_t)c * TA + threadIdx.x];
+	}
+	__syncthreads();
 	if (threadIdx.x < n_gl) {
 		double v = 0.0;
-		for (uint32_t blk = 0; blk < nb; ++blk) v += p[(size_t)blk * n_gl + threadIdx.x];
+		const uint32_t s = threadIdx.x ? (threadIdx.x - 1) / 3 : 0, g = threadIdx.x ? (threadIdx.x - 1) % 3 : 0;
+		for (uint32_t q = 0; q < TA; ++q)
+			if (threadIdx.x == 0 || G.gidx[(size_t)q * n_ind + s] == g) v += u[q];
 		tot[threadIdx.x] = v;
 	}
 	__syncthreads();
 	if (threadIdx.x >= 1 && threadIdx.x < n_gl) {
 		const uint32_t s = (threadIdx.x - 1) / 3, g = (threadIdx.x - 1) % 3;
-		gl_out[((size_t)s * n_cols + c) * 3 + g] = tot[threadIdx.x] / tot[0];
+		gl_out[((size_t)s * G.n_cols + c) * 3 + g] = tot[threadIdx.x] / tot[0];
 	}
 }
 
@@ -461,7 +485,7 @@ whamd_status_t genotype_solve_slots(const Problem& p, const GenotypeModel& m, in
 		const uint32_t blocks = (uint32_t)((((size_t)sr.threads << sr.g) + 256u * GS_COMBINE_LANES - 1u) / (256u * GS_COMBINE_LANES));
 		max_blocks = std::max(max_blocks, blocks);
 		const size_t waves = sr.threads >> 6;
-		max_lds = std::max(max_lds, ((size_t)2 * sr.threads + waves * sr.ncols * T * E + (size_t)sr.ncols * 64 * E + (size_t)sr.ncols * T * A + ((sr.ncols + 1) & ~1u) + 16) * 8 + (size_t)sr.ncols * sizeof(GsCol));
+		max_lds = std::max(max_lds, ((size_t)2 * sr.threads + waves * sr.ncols * T * E + (size_t)sr.ncols * T * A + ((sr.ncols + 1) & ~1u) + 16) * 8 + (size_t)sr.ncols * sizeof(GsCol));
 		for (uint32_t ci = 0; ci < sr.ncols; ++ci) {
 			const uint32_t c = sr.c0 + ci;
 			const PedSlotRow& pr = plan.prows[c];
@@ -504,9 +528,8 @@ whamd_status_t genotype_solve_slots(const Problem& p, const GenotypeModel& m, in
 	size_t free_b = 0, total_b = 0;
 	GS_TRY(hipMemGetInfo(&free_b, &total_b));
 	free_b += genotype_slab_idle_bytes(device);   // the column store kept from an earlier call is available to this one
-	const uint32_t n_gl = 1 + 3 * ni;
 	constexpr uint32_t BATCH = 512;
-	const double need = (double)tab_words * 8 + 2.0 * (double)store_words * 8 + (double)BATCH * max_blocks * n_gl * 8 + 4.0 * ((double)(1ull << max_f) * T * 8) +
+	const double need = (double)tab_words * 8 + 2.0 * (double)store_words * 8 + (double)BATCH * max_blocks * T * A * 8 + 4.0 * ((double)(1ull << max_f) * T * 8) +
 	                    (double)n * (sizeof(GsCol) + sizeof(GsRow) + sizeof(GsCombineCol) + 8.0 * T * A + 8);
 	if (max_lds > 150 * 1024 || need + (double)(2ull << 30) > 0.8 * (double)free_b) return WHAMD_OK;   // (the per-column path windows its stores)
 	used = true;
@@ -550,7 +573,7 @@ whamd_status_t genotype_solve_slots(const Problem& p, const GenotypeModel& m, in
 	else GS_TRY(alloc(&d_fs, 2 * (size_t)store_words * 8));
 	d_bs = (double*)d_fs + store_words;
 	GS_TRY(alloc(&d_part, (size_t)n_partials * 8));
-	GS_TRY(alloc(&d_glpart, (size_t)BATCH * max_blocks * n_gl * 8));
+	GS_TRY(alloc(&d_glpart, (size_t)BATCH * max_blocks * T * A * 8));
 	GS_TRY(alloc(&d_gl, gl_out.size() * 8));
 	for (double*& x : d_x) GS_TRY(alloc((void**)&x, ((size_t)1 << max_f) * T * 8));
 	G.cols = (const GsCol*)d_cols; G.rows = (const GsRow*)d_rows; G.prior = (const double*)d_prior; G.rho = (const double*)d_rho;
@@ -582,7 +605,7 @@ whamd_status_t genotype_solve_slots(const Problem& p, const GenotypeModel& m, in
 	GS_TRY(hipStreamWaitEvent(sb, ev[1], 0));   // uploads and tables are complete
 	auto lds_of = [&](const GsRun& r) {
 		const size_t waves = r.threads >> 6;
-		return ((size_t)2 * r.threads + waves * r.ncols * T * E + (size_t)r.ncols * 64 * E + (size_t)r.ncols * T * A + ((r.ncols + 1) & ~1u) + 16) * 8 + (size_t)r.ncols * sizeof(GsCol);
+		return ((size_t)2 * r.threads + waves * r.ncols * T * E + (size_t)r.ncols * T * A + ((r.ncols + 1) & ~1u) + 16) * 8 + (size_t)r.ncols * sizeof(GsCol);
 	};
 	// the two chains, submissions interleaved so that neither hardware queue runs dry
 	size_t rf = 0, rb = n_runs;
@@ -610,7 +633,7 @@ whamd_status_t genotype_solve_slots(const Problem& p, const GenotypeModel& m, in
 		if (tb == 0) hipLaunchKernelGGL((geno_slot_combine<0, 2>), dim3(gx, ncol), dim3(256), 0, sf, G, (const GsCombineCol*)d_ccols, c0, max_blocks, (double*)d_glpart);
 		else if (tb == 2) hipLaunchKernelGGL((geno_slot_combine<2, 4>), dim3(gx, ncol), dim3(256), 0, sf, G, (const GsCombineCol*)d_ccols, c0, max_blocks, (double*)d_glpart);
 		else hipLaunchKernelGGL((geno_slot_combine<4, 4>), dim3(gx, ncol), dim3(256), 0, sf, G, (const GsCombineCol*)d_ccols, c0, max_blocks, (double*)d_glpart);
-		hipLaunchKernelGGL(geno_slot_finish, dim3(ncol), dim3(64), 0, sf, (const double*)d_glpart, (const GsCombineCol*)d_ccols, c0, max_blocks, ni, n, (double*)d_gl);
+		hipLaunchKernelGGL(geno_slot_finish, dim3(ncol), dim3(256), 0, sf, G, (const double*)d_glpart, (const GsCombineCol*)d_ccols, c0, max_blocks, (double*)d_gl);
 		launches += 2;
 	}
 	GS_TRY(hipGetLastError());
