@@ -261,6 +261,44 @@ whamd_status_t whamd_debug_emulate_pedslot_plan(const whamd_readset_view* readse
                                                uint32_t* index_out, uint32_t* transmission_out, uint32_t* score_out,
                                                uint64_t* n_run_columns_out);
 
+/* ---- PedMecHeuristic: the beam-search sibling of PedigreeDPTable behind the same Python API -------------
+ * Replaces cpp.PedMecHeuristic (whatshap/cpp.pxd:260-268; src/pedmecheuristic.h:56-120): constructor arguments of
+ * whatshap/core.pyx:674-689 (row_limit, allow_mutations; verbosity has no counterpart), solve() is part of _create as the
+ * wrapper's getters all call it first (core.pyx:695).  The ReadSet must be sorted (whatshap/cli/phase.py:590 sorts it) and
+ * the pedigree's individuals must carry the ids 0 .. n-1 in insertion order (the reference mixes ids, indices and ranks,
+ * src/pedmecheuristic.cpp:49-82).  One persistent single-workgroup kernel per table (csrc/heuristic_device.hip); every
+ * decision of the beam equals the reference's (float scores restated operation by operation). */
+typedef struct whamd_heuristic whamd_heuristic; /* opaque */
+typedef struct whamd_heuristic_stats {
+	uint64_t n_columns, n_reads;
+	uint64_t max_solutions;      /* widest column of the beam */
+	uint64_t total_solutions;    /* sum over the columns */
+	double device_ms;            /* HIP events around the kernel */
+	double host_prepare_ms;      /* flattening + per-column bookkeeping + upload (wall) */
+	double host_finish_ms;       /* allele votes + phasing per column (wall) */
+	uint32_t n_samples, row_limit;
+} whamd_heuristic_stats;
+whamd_status_t whamd_pedmec_heuristic_create(const whamd_readset_view* readset, const uint32_t* recombcost, size_t n_recombcost,
+                                             const whamd_pedigree_view* pedigree, int distrust_genotypes,
+                                             const uint32_t* positions, size_t n_positions, uint32_t row_limit, int allow_mutations,
+                                             int device, whamd_heuristic** out);
+/* HOST-ONLY DIAGNOSTIC: the same solver source run with one CPU thread (csrc/heuristic_host.cpp), for the CPU test-suite to
+ * compare with the compiled reference; never what the drop-in class calls. */
+whamd_status_t whamd_debug_pedmec_heuristic_create_host(const whamd_readset_view* readset, const uint32_t* recombcost, size_t n_recombcost,
+                                                        const whamd_pedigree_view* pedigree, int distrust_genotypes,
+                                                        const uint32_t* positions, size_t n_positions, uint32_t row_limit, int allow_mutations,
+                                                        whamd_heuristic** out);
+uint64_t whamd_pedmec_heuristic_column_count(const whamd_heuristic* h);
+uint32_t whamd_pedmec_heuristic_sample_count(const whamd_heuristic* h);
+uint32_t whamd_pedmec_heuristic_read_count(const whamd_heuristic* h);
+/* score: getOptScore (the reference never assigns it: 0); bipartition[reads]: getOptBipartition bits; transmission[columns]:
+ * getOptTransmission; haplotypes / mutated [samples][2][columns]: getOptHaplotypes / getMutations; sample_ids[samples]: the
+ * global ids getSuperReads gives its reads; positions[columns].  NULL pointers are skipped. */
+whamd_status_t whamd_pedmec_heuristic_get(const whamd_heuristic* h, float* score, uint8_t* bipartition, uint32_t* transmission,
+                                          int8_t* haplotypes, uint8_t* mutated, uint32_t* sample_ids, uint32_t* positions);
+whamd_status_t whamd_pedmec_heuristic_get_stats(const whamd_heuristic* h, whamd_heuristic_stats* stats_out);
+void whamd_pedmec_heuristic_destroy(whamd_heuristic* h);
+
 /* The tie-break hash of ReadSet::sort (src/readset.h:39-66,76-82): std::hash<std::string>(name) ^
  * std::hash<int>(source_id) of the libstdc++ this library is built against.  Used by the Python
  * mirror of ReadSet.sort(); not part of the DP path. */

@@ -186,6 +186,97 @@ class ReferenceTable(_Table):
         return float(self._load().whref_ctor_seconds(self._h))
 
 
+class ReferenceHeuristic:
+    """The compiled reference's PedMecHeuristic (src/pedmecheuristic.cpp + oracle/ref_driver.cpp), solved at construction.
+    ``problem`` as for the tables (reads sorted, individuals in ascending sample-id order)."""
+
+    _lib = None
+
+    @classmethod
+    def _load(cls):
+        if cls._lib is None:
+            if not os.path.exists(REFERENCE_LIB):
+                raise OracleError(f"{REFERENCE_LIB} is not built (make -C oracle)")
+            L = C.CDLL(REFERENCE_LIB)
+            H = C.c_void_p
+            L.whref_heuristic_create.restype = C.c_int
+            L.whref_heuristic_create.argtypes = [C.POINTER(ReadSetView), C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(PedigreeView), C.c_int,
+                                                 C.POINTER(C.c_uint32), C.c_size_t, C.c_uint32, C.c_int, C.POINTER(H)]
+            L.whref_heuristic_error.restype = C.c_char_p
+            L.whref_heuristic_error.argtypes = [H]
+            for name in ("column_count", "sample_count"):
+                getattr(L, "whref_heuristic_" + name).restype = C.c_uint32
+                getattr(L, "whref_heuristic_" + name).argtypes = [H]
+            L.whref_heuristic_solve_seconds.restype = C.c_double
+            L.whref_heuristic_solve_seconds.argtypes = [H]
+            L.whref_heuristic_score.restype = C.c_float
+            L.whref_heuristic_score.argtypes = [H]
+            L.whref_heuristic_bipartition.restype = None
+            L.whref_heuristic_bipartition.argtypes = [H, C.POINTER(C.c_uint8)]
+            L.whref_heuristic_transmission.restype = None
+            L.whref_heuristic_transmission.argtypes = [H, C.POINTER(C.c_uint32)]
+            L.whref_heuristic_haplotypes.restype = None
+            L.whref_heuristic_haplotypes.argtypes = [H, C.POINTER(C.c_int8), C.POINTER(C.c_uint8)]
+            L.whref_heuristic_destroy.restype = None
+            L.whref_heuristic_destroy.argtypes = [H]
+            cls._lib = L
+        return cls._lib
+
+    def __init__(self, problem: ProblemArrays, row_limit: int = 256, allow_mutations: bool = True):
+        L = self._load()
+        self._h = C.c_void_p()
+        self._problem = problem
+        status = L.whref_heuristic_create(*problem.call_args(), C.c_uint32(int(row_limit)), C.c_int(1 if allow_mutations else 0), C.byref(self._h))
+        if status != 0:
+            message = L.whref_heuristic_error(self._h).decode("utf-8", "replace")
+            self.close()
+            raise OracleError(message)
+        self.n_columns = int(L.whref_heuristic_column_count(self._h))
+        self.n_samples = int(L.whref_heuristic_sample_count(self._h))
+        self.n_reads = problem.n_reads
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._load().whref_heuristic_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def score(self) -> float:
+        return float(self._load().whref_heuristic_score(self._h))
+
+    def solve_seconds(self) -> float:
+        return float(self._load().whref_heuristic_solve_seconds(self._h))
+
+    def bipartition(self):
+        out = np.zeros(max(self.n_reads, 1), dtype=np.uint8)
+        self._load().whref_heuristic_bipartition(self._h, _ptr(out, C.c_uint8))
+        return out[:self.n_reads]
+
+    def transmission(self):
+        out = np.zeros(max(self.n_columns, 1), dtype=np.uint32)
+        self._load().whref_heuristic_transmission(self._h, _ptr(out, C.c_uint32))
+        return out[:self.n_columns]
+
+    def haplotypes(self):
+        """(alleles [samples][2][columns] int8, mutated [samples][2][columns] 0/1)"""
+        haps = np.zeros((max(self.n_samples, 1), 2, max(self.n_columns, 1)), dtype=np.int8)
+        mut = np.zeros((max(self.n_samples, 1), 2, max(self.n_columns, 1)), dtype=np.uint8)
+        self._load().whref_heuristic_haplotypes(self._h, haps.ctypes.data_as(C.POINTER(C.c_int8)), _ptr(mut, C.c_uint8))
+        return haps[:self.n_samples, :, :self.n_columns], mut[:self.n_samples, :, :self.n_columns]
+
+
+def heuristic_tuple(h):
+    """(score, bipartition, transmission, haplotypes, mutations) in comparable form."""
+    haps, mut = h.haplotypes()
+    return {"score": h.score(), "bipartition": h.bipartition().tolist(), "transmission": h.transmission().tolist(),
+            "haplotypes": haps.tolist(), "mutated": mut.tolist()}
+
+
 def solution_tuple(table):
     """(cost, index path, transmission vector, partitioning, superreads) in comparable form."""
     a0, a1, q, tv, sid = table.super_reads()

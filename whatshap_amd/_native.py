@@ -104,6 +104,23 @@ class GenotypeStats(C.Structure):
         return {name: getattr(self, name) for name, _ in self._fields_ if name != "pad"}
 
 
+class HeuristicStats(C.Structure):
+    _fields_ = [
+        ("n_columns", C.c_uint64),
+        ("n_reads", C.c_uint64),
+        ("max_solutions", C.c_uint64),
+        ("total_solutions", C.c_uint64),
+        ("device_ms", C.c_double),
+        ("host_prepare_ms", C.c_double),
+        ("host_finish_ms", C.c_double),
+        ("n_samples", C.c_uint32),
+        ("row_limit", C.c_uint32),
+    ]
+
+    def as_dict(self) -> dict:
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
 def _ptr(arr: Optional[np.ndarray], ctype):
     if arr is None:
         return C.cast(None, C.POINTER(ctype))
@@ -269,6 +286,25 @@ def lib() -> C.CDLL:
         C.POINTER(ReadSetView), C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(PedigreeView), C.c_int,
         C.POINTER(C.c_uint32), C.c_size_t, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
     ]
+    heur_args = [C.POINTER(ReadSetView), C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(PedigreeView), C.c_int,
+                 C.POINTER(C.c_uint32), C.c_size_t, C.c_uint32, C.c_int]
+    L.whamd_pedmec_heuristic_create.restype = C.c_int
+    L.whamd_pedmec_heuristic_create.argtypes = heur_args + [C.c_int, C.POINTER(C.c_void_p)]
+    L.whamd_debug_pedmec_heuristic_create_host.restype = C.c_int
+    L.whamd_debug_pedmec_heuristic_create_host.argtypes = heur_args + [C.POINTER(C.c_void_p)]
+    L.whamd_pedmec_heuristic_column_count.restype = C.c_uint64
+    L.whamd_pedmec_heuristic_column_count.argtypes = [C.c_void_p]
+    L.whamd_pedmec_heuristic_sample_count.restype = C.c_uint32
+    L.whamd_pedmec_heuristic_sample_count.argtypes = [C.c_void_p]
+    L.whamd_pedmec_heuristic_read_count.restype = C.c_uint32
+    L.whamd_pedmec_heuristic_read_count.argtypes = [C.c_void_p]
+    L.whamd_pedmec_heuristic_get.restype = C.c_int
+    L.whamd_pedmec_heuristic_get.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_int8),
+                                             C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.whamd_pedmec_heuristic_get_stats.restype = C.c_int
+    L.whamd_pedmec_heuristic_get_stats.argtypes = [C.c_void_p, C.POINTER(HeuristicStats)]
+    L.whamd_pedmec_heuristic_destroy.restype = None
+    L.whamd_pedmec_heuristic_destroy.argtypes = [C.c_void_p]
     L.whamd_read_sort_hash.restype = C.c_uint64
     L.whamd_read_sort_hash.argtypes = [C.c_char_p, C.c_int]
     L.whamd_genotype_likelihoods.restype = C.c_int
@@ -295,7 +331,9 @@ EXPORTED_SYMBOLS = [
     "whamd_dptable_get_super_reads", "whamd_dptable_get_optimal_partitioning", "whamd_dptable_get_index_path",
     "whamd_dptable_get_stats", "whamd_dptable_set_option", "whamd_read_sort_hash", "whamd_plan_summarize",
     "whamd_dptable_enqueue", "whamd_dptable_wait", "whamd_dptable_enqueue_many", "whamd_debug_emulate_slot_plan",
-    "whamd_debug_emulate_pedslot_plan",
+    "whamd_debug_emulate_pedslot_plan", "whamd_pedmec_heuristic_create", "whamd_debug_pedmec_heuristic_create_host",
+    "whamd_pedmec_heuristic_column_count", "whamd_pedmec_heuristic_sample_count", "whamd_pedmec_heuristic_read_count",
+    "whamd_pedmec_heuristic_get", "whamd_pedmec_heuristic_get_stats", "whamd_pedmec_heuristic_destroy",
     "whamd_readselection", "whamd_genotype_likelihoods", "whamd_release_caches",
 ]
 
@@ -434,6 +472,37 @@ def emulate_pedslot_plan(problem: ProblemArrays, n_columns: int, slot_l: int = 0
     _check(lib().whamd_debug_emulate_pedslot_plan(*problem.call_args(), C.c_int(slot_l), _ptr(idx, C.c_uint32), _ptr(trans, C.c_uint32),
                                                   C.byref(score), C.byref(ncols)))
     return idx[:n_columns], trans[:n_columns], int(score.value), int(ncols.value)
+
+
+def pedmec_heuristic(problem: ProblemArrays, row_limit: int = 256, allow_mutations: bool = True, device: int = 0, host_diagnostic: bool = False) -> dict:
+    """whamd_pedmec_heuristic_create + _get: the beam search of PedMecHeuristic (constructor + solve) and everything its getters
+    return.  host_diagnostic: the same solver source on one CPU thread (tests only)."""
+    L = lib()
+    h = C.c_void_p()
+    a = problem.call_args()
+    if host_diagnostic:
+        _check(L.whamd_debug_pedmec_heuristic_create_host(*a, C.c_uint32(int(row_limit)), C.c_int(1 if allow_mutations else 0), C.byref(h)))
+    else:
+        _check(L.whamd_pedmec_heuristic_create(*a, C.c_uint32(int(row_limit)), C.c_int(1 if allow_mutations else 0), C.c_int(int(device)), C.byref(h)))
+    try:
+        n = int(L.whamd_pedmec_heuristic_column_count(h))
+        ns = int(L.whamd_pedmec_heuristic_sample_count(h))
+        nr = int(L.whamd_pedmec_heuristic_read_count(h))
+        score = C.c_float()
+        bip = np.zeros(max(nr, 1), dtype=np.uint8)
+        trans = np.zeros(max(n, 1), dtype=np.uint32)
+        haps = np.zeros((max(ns, 1), 2, max(n, 1)), dtype=np.int8)
+        mut = np.zeros((max(ns, 1), 2, max(n, 1)), dtype=np.uint8)
+        sid = np.zeros(max(ns, 1), dtype=np.uint32)
+        pos = np.zeros(max(n, 1), dtype=np.uint32)
+        _check(L.whamd_pedmec_heuristic_get(h, C.byref(score), _ptr(bip, C.c_uint8), _ptr(trans, C.c_uint32), haps.ctypes.data_as(C.POINTER(C.c_int8)),
+                                            _ptr(mut, C.c_uint8), _ptr(sid, C.c_uint32), _ptr(pos, C.c_uint32)))
+        stats = HeuristicStats()
+        _check(L.whamd_pedmec_heuristic_get_stats(h, C.byref(stats)))
+    finally:
+        L.whamd_pedmec_heuristic_destroy(h)
+    return {"score": float(score.value), "bipartition": bip[:nr], "transmission": trans[:n], "haplotypes": haps[:ns, :, :n], "mutated": mut[:ns, :, :n],
+            "sample_ids": sid[:ns], "positions": pos[:n], "stats": stats.as_dict()}
 
 
 def device_count() -> int:

@@ -9,6 +9,7 @@
 
 #include "device_table.h"
 #include "genotype.h"
+#include "heuristic.h"
 #include "problem.h"
 #include "resident.h"
 #include "slots.h"
@@ -514,6 +515,79 @@ whamd_status_t whamd_debug_emulate_pedslot_plan(const whamd_readset_view* readse
 	if (n_run_columns_out) *n_run_columns_out = sp.n_run_columns;
 	return WHAMD_OK;
 }
+
+}  // extern "C"
+
+struct whamd_heuristic {
+	whamd::HeurPlan plan;
+	whamd::HeurResult result;
+	whamd_heuristic_stats stats{};
+};
+
+namespace {
+whamd_status_t heuristic_create_common(const whamd_readset_view* readset, const uint32_t* recombcost, size_t n_recombcost, const whamd_pedigree_view* pedigree,
+                                       int distrust_genotypes, const uint32_t* positions, size_t n_positions, uint32_t row_limit, int allow_mutations,
+                                       int device, bool on_host, whamd_heuristic** out) {
+	if (!out) return fail(WHAMD_ERR_INVALID, "out is NULL");
+	*out = nullptr;
+	const double t0 = now_ms();
+	std::unique_ptr<whamd_heuristic> h(new whamd_heuristic());
+	std::string msg;
+	whamd_status_t st = whamd::build_heuristic_plan(readset, recombcost, n_recombcost, pedigree, distrust_genotypes != 0, positions, n_positions, row_limit,
+	                                                allow_mutations != 0, h->plan, msg);
+	if (st != WHAMD_OK) return fail(st, msg);
+	const double t1 = now_ms();
+	st = on_host ? whamd::heuristic_solve_host(h->plan, h->result, msg) : whamd::heuristic_solve_device(h->plan, device, h->result, msg);
+	if (st != WHAMD_OK) return fail(st, msg);
+	const double t2 = now_ms();
+	whamd::heuristic_finish(h->plan, h->result);
+	h->stats.n_columns = h->plan.n_cols; h->stats.n_reads = h->plan.n_reads; h->stats.max_solutions = h->result.max_solutions;
+	h->stats.total_solutions = h->result.total_solutions; h->stats.device_ms = h->result.device_ms;
+	h->stats.host_prepare_ms = (t1 - t0) + ((t2 - t1) - h->result.device_ms); h->stats.host_finish_ms = now_ms() - t2;
+	h->stats.n_samples = h->plan.n_samples; h->stats.row_limit = h->plan.row_limit;
+	*out = h.release();
+	return WHAMD_OK;
+}
+}  // namespace
+
+extern "C" {
+
+whamd_status_t whamd_pedmec_heuristic_create(const whamd_readset_view* readset, const uint32_t* recombcost, size_t n_recombcost,
+                                             const whamd_pedigree_view* pedigree, int distrust_genotypes, const uint32_t* positions, size_t n_positions,
+                                             uint32_t row_limit, int allow_mutations, int device, whamd_heuristic** out) {
+	return heuristic_create_common(readset, recombcost, n_recombcost, pedigree, distrust_genotypes, positions, n_positions, row_limit, allow_mutations, device, false, out);
+}
+
+whamd_status_t whamd_debug_pedmec_heuristic_create_host(const whamd_readset_view* readset, const uint32_t* recombcost, size_t n_recombcost,
+                                                        const whamd_pedigree_view* pedigree, int distrust_genotypes, const uint32_t* positions,
+                                                        size_t n_positions, uint32_t row_limit, int allow_mutations, whamd_heuristic** out) {
+	return heuristic_create_common(readset, recombcost, n_recombcost, pedigree, distrust_genotypes, positions, n_positions, row_limit, allow_mutations, 0, true, out);
+}
+
+uint64_t whamd_pedmec_heuristic_column_count(const whamd_heuristic* h) { return h ? h->plan.n_cols : 0; }
+uint32_t whamd_pedmec_heuristic_sample_count(const whamd_heuristic* h) { return h ? h->plan.n_samples : 0; }
+uint32_t whamd_pedmec_heuristic_read_count(const whamd_heuristic* h) { return h ? h->plan.n_reads : 0; }
+
+whamd_status_t whamd_pedmec_heuristic_get(const whamd_heuristic* h, float* score, uint8_t* bipartition, uint32_t* transmission, int8_t* haplotypes,
+                                          uint8_t* mutated, uint32_t* sample_ids, uint32_t* positions) {
+	if (!h) return fail(WHAMD_ERR_INVALID, "null argument");
+	if (score) *score = h->result.score;
+	if (bipartition && !h->result.bipartition.empty()) std::memcpy(bipartition, h->result.bipartition.data(), h->result.bipartition.size());
+	if (transmission && !h->result.transmission.empty()) std::memcpy(transmission, h->result.transmission.data(), h->result.transmission.size() * 4);
+	if (haplotypes && !h->result.haplotypes.empty()) std::memcpy(haplotypes, h->result.haplotypes.data(), h->result.haplotypes.size());
+	if (mutated && !h->result.mutated.empty()) std::memcpy(mutated, h->result.mutated.data(), h->result.mutated.size());
+	if (sample_ids && !h->plan.sample_global_id.empty()) std::memcpy(sample_ids, h->plan.sample_global_id.data(), h->plan.sample_global_id.size() * 4);
+	if (positions && !h->plan.positions.empty()) std::memcpy(positions, h->plan.positions.data(), h->plan.positions.size() * 4);
+	return WHAMD_OK;
+}
+
+whamd_status_t whamd_pedmec_heuristic_get_stats(const whamd_heuristic* h, whamd_heuristic_stats* stats_out) {
+	if (!h || !stats_out) return fail(WHAMD_ERR_INVALID, "null argument");
+	*stats_out = h->stats;
+	return WHAMD_OK;
+}
+
+void whamd_pedmec_heuristic_destroy(whamd_heuristic* h) { delete h; }
 
 // std::hash tie-break of ReadSet::sort (src/readset.h:52-55,78-82): exported so that the Python mirror of
 // ReadSet.sort() orders reads exactly like the reference built against the same libstdc++.

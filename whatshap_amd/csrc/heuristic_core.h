@@ -1,0 +1,510 @@
+// heuristic_core.h -- the PedMecHeuristic solver (heuristic.h), written ONCE against a small execution interface and
+// instantiated twice: as a persistent single-workgroup HIP kernel (heuristic_device.hip) and single-threaded on the host
+// (heuristic_host.cpp, CPU diagnostic).  The includer defines, before including this file:
+//   HEUR_FN                         function qualifier (__device__ / nothing)
+//   HEUR_SHARED                     storage of block-shared scratch (__shared__ / static)
+//   HEUR_TID, HEUR_NT               index of the calling thread, number of threads (a power of two <= 1024)
+//   HEUR_SYNC()                     barrier of all threads (also orders their global-memory accesses)
+//   heur_cas32(p, cmp, val) -> old  heur_min32(p, v)  heur_min64(p, v)  heur_add32(p, v) -> old     atomics
+//   heur_load32(p)  heur_load64(p)  loads of words other threads changed with atomics (device: past the CU's L1, which the
+//                                   atomics -- performed in L2 -- do not update)
+//
+// Restates src/pedmecheuristic.cpp:123-409 (solve) and :420-622 (updateSolution, getRecombinationCost, getMutationCost,
+// getOptPhasing, addBalance, extendSolutions, filterSolutions).  MecScore is float (src/mecheader.h): every score operation
+// below is the reference's, in its order, in IEEE single precision with contraction OFF -- the beam's decisions (which
+// duplicate wins, which copy is kept, where the pruning threshold falls) are then the reference's.
+#pragma once
+#include <cstdint>
+
+#pragma clang fp contract(off)
+
+namespace whamd {
+
+constexpr uint32_t HEUR_MAXS = 8;          // samples of one table
+constexpr uint32_t HEUR_EMPTY = 0xFFFFFFFFu;
+
+// One pool of solutions (structure of arrays); two of them are used alternately.
+struct HeurPool {
+	float* score;      // [cap]
+	float* mut;        // [cap] mutationScore
+	uint32_t* trans;   // [cap]
+	uint32_t* bt;      // [cap] btRow
+	uint32_t* bits;    // [cap][nw] bipartition over the column's active reads (kept reads first, then the new ones)
+	float* bal;        // [cap][2 S][w_max]
+};
+
+struct HeurDev {
+	// ---- plan (heuristic.h HeurPlan)
+	uint32_t n_cols, n_samples, n_trios, tm_bits, row_limit, distrust, w_max, nw;
+	uint32_t trios[3 * HEUR_MAXS];
+	const float* recomb; const float* mutation;
+	const int8_t* genotype;
+	const uint32_t* start_index;
+	const uint32_t *window, *n_kept, *kept_off, *n_new, *new_off, *kept;
+	const uint32_t* new_sample; const int32_t* new_equal_to; const uint8_t *new_seen, *new_useful;
+	const unsigned long long* new_bal_off; const float* new_balance;
+	// ---- state
+	HeurPool pool[2];
+	uint32_t cap;
+	uint32_t* pbits;               // [cap][nw] projected bipartitions
+	uint32_t* table;               // [tsz] hash slots: a member of the slot's group
+	uint32_t* lead;                // [tsz] smallest member index
+	unsigned long long* best;      // [tsz] min (sortable score << 32 | index)
+	uint32_t tsz;
+	uint32_t* slot;                // [cap]
+	uint32_t* rank;                // [cap] scan results
+	uint32_t* aux;                 // [cap] per-solution scratch (mode / count / source index)
+	float* val;                    // [cap] score + mutationScore of the pruning
+	// ---- records (backtrace): per column `stride` words per solution: btRow, trans, bits of the new reads
+	uint32_t* arena; unsigned long long arena_words;
+	unsigned long long* col_off; uint32_t* col_count;
+	// ---- results
+	uint8_t* opt_bipart; uint32_t* opt_trans;
+	unsigned long long* stats;     // [0] status (0 ok, 1 pool overflow, 2 arena overflow), [1] widest column, [2] sum of the column sizes
+};
+
+HEUR_FN inline uint32_t heur_sortable(float f) {
+	uint32_t u = __builtin_bit_cast(uint32_t, f);
+	return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+HEUR_FN inline float heur_unsortable(uint32_t k) {
+	const uint32_t u = k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu);
+	return __builtin_bit_cast(float, u);
+}
+HEUR_FN inline float heur_abs(float x) { return x < 0 ? -x : x; }           // std::abs (sign of zero irrelevant below)
+HEUR_FN inline float heur_min(float a, float b) { return b < a ? b : a; }    // std::min
+HEUR_FN inline float heur_max(float a, float b) { return a < b ? b : a; }    // std::max
+HEUR_FN inline uint32_t heur_popc(uint32_t v) { return (uint32_t)__builtin_popcount(v); }
+
+// A balance matrix [2 S][w_max] with one row seen as (row + add): what addBalance leaves behind, without materialising it.
+struct HeurBalView {
+	const float* bal; uint32_t w_max; uint32_t over_row; const float* add;
+	HEUR_FN inline float at(uint32_t row, uint32_t i) const {
+		const float v = bal[(size_t)row * w_max + i];
+		return row == over_row ? v + add[i] : v;
+	}
+};
+
+// addBalance (src/pedmecheuristic.cpp:566-586): the penalty only (the caller adds `add` to the row afterwards)
+HEUR_FN inline float heur_add_balance(const float* basis, const float* co, const float* add, uint32_t w, bool distrust, const int8_t* target) {
+	float penalty = 0;
+	for (uint32_t i = 0; i < w; ++i) {
+		if (distrust) {
+			if (basis[i] * add[i] < 0) penalty += heur_min(heur_abs(basis[i]), heur_abs(add[i]));
+		} else if (target[i] == 1) {
+			if (add[i] <= 0) penalty += heur_min(-add[i], heur_max(basis[i] - co[i], (float)0));
+			else penalty += heur_min(add[i], heur_max(co[i] - basis[i], (float)0));
+		} else {
+			penalty += heur_abs(add[i]) * (float)(int)(add[i] * (float)(target[i] - 1) < 0);
+		}
+	}
+	return penalty;
+}
+
+// getMutationCost (:438-468)
+HEUR_FN inline float heur_mutation_cost(const HeurDev& D, const HeurBalView& B, uint32_t t, uint32_t p, bool allow_flips, uint32_t ahead, uint32_t w) {
+	float cost = 0.0f;
+	const float mc = D.mutation[p];
+	const uint32_t last = ahead < w - 1u ? ahead : w - 1u;
+	for (uint32_t i = 0; i <= last; ++i) {
+		for (uint32_t k = 0; k < D.n_trios; ++k) {
+			const uint32_t m2c = (t >> (2 * k)) & 1u, f2c = (t >> (2 * k + 1)) & 1u;
+			const uint32_t t0 = D.trios[3 * k], t1 = D.trios[3 * k + 1], t2 = D.trios[3 * k + 2];
+			const float cm = B.at(2 * t2, i), cf = B.at(2 * t2 + 1, i), m = B.at(2 * t0 + m2c, i), f = B.at(2 * t1 + f2c, i);
+			if (allow_flips) {
+				if (cm * m < 0) cost += heur_min(mc, heur_min(heur_abs(cm), heur_abs(m)));
+				if (cf * f < 0) cost += heur_min(mc, heur_min(heur_abs(cf), heur_abs(f)));
+			} else {
+				cost += (float)(int)(cm * m < 0) * mc;
+				cost += (float)(int)(cf * f < 0) * mc;
+			}
+		}
+	}
+	return cost;
+}
+
+// getOptPhasing (:471-563).  firsts[2 S]; returns the minimal cost; opt_phase[S] (0 = 0|0, 1 = 0|1, 2 = 1|0, 3 = 1|1) and
+// mutated[2 S] of the first combination attaining it when the pointers are given.
+HEUR_FN inline float heur_opt_phasing(const HeurDev& D, const float* firsts, uint32_t t, uint32_t p, uint8_t* opt_phase, uint8_t* mutated) {
+	const uint32_t S = D.n_samples;
+	float pc[HEUR_MAXS][5];
+	uint8_t phases[HEUR_MAXS][4], n_ph[HEUR_MAXS], v[HEUR_MAXS];
+	const float mc = D.mutation[p];
+	for (uint32_t s = 0; s < S; ++s) {
+		const float a0 = firsts[2 * s], a1 = firsts[2 * s + 1];
+		pc[s][0] = (a0 * (float)(int)(a0 > 0) + a1 * (float)(int)(a1 > 0));
+		pc[s][1] = (-a0 * (float)(int)(a0 < 0) + a1 * (float)(int)(a1 > 0));
+		pc[s][2] = (a0 * (float)(int)(a0 > 0) - a1 * (float)(int)(a1 < 0));
+		pc[s][3] = (-a0 * (float)(int)(a0 < 0) - a1 * (float)(int)(a1 < 0));
+		float mx = pc[s][0];   // std::max_element: the first of the largest
+		for (int q = 1; q < 4; ++q) if (mx < pc[s][q]) mx = pc[s][q];
+		pc[s][4] = mx;
+		n_ph[s] = 0;
+		if (D.distrust) {
+			for (uint8_t q = 0; q < 4; ++q) if (pc[s][q] < pc[s][4] + (float)2 * mc) phases[s][n_ph[s]++] = q;
+		} else {
+			const int8_t g = D.genotype[(size_t)s * D.n_cols + p];
+			if (g == 0) phases[s][n_ph[s]++] = 0;
+			else if (g == 2) phases[s][n_ph[s]++] = 3;
+			else { phases[s][n_ph[s]++] = 1; phases[s][n_ph[s]++] = 2; }
+		}
+		v[s] = 0;
+	}
+	float min_cost = __builtin_inff();
+	while (v[S - 1] < n_ph[S - 1]) {
+		float cost = 0.0f;
+		uint8_t mut[2 * HEUR_MAXS];
+		for (uint32_t s = 0; s < 2 * S; ++s) mut[s] = 0;
+		for (uint32_t k = 0; k < D.n_trios; ++k) {
+			const uint32_t m2c = (t >> (2 * k)) & 1u, f2c = (t >> (2 * k + 1)) & 1u;
+			const uint32_t t0 = D.trios[3 * k], t1 = D.trios[3 * k + 1], t2 = D.trios[3 * k + 2];
+			const int acm = phases[t2][v[t2]] & 1, acf = (phases[t2][v[t2]] & 2) >> 1;
+			const int am = (phases[t0][v[t0]] & (1 + m2c)) >> m2c, af = (phases[t1][v[t1]] & (1 + f2c)) >> f2c;
+			cost += (float)(int)(am != acm) * mc;
+			cost += (float)(int)(af != acf) * mc;
+			mut[2 * t2] = am != acm;
+			mut[2 * t2 + 1] = af != acf;
+		}
+		for (uint32_t s = 0; s < S; ++s) cost += pc[s][phases[s][v[s]]];
+		if (cost < min_cost) {
+			min_cost = cost;
+			if (opt_phase) for (uint32_t s = 0; s < S; ++s) opt_phase[s] = phases[s][v[s]];
+			if (mutated) for (uint32_t s = 0; s < 2 * S; ++s) mutated[s] = mut[s];
+		}
+		v[0]++;
+		for (uint32_t j = 0; j + 1 < S; ++j)
+			if (v[j] >= n_ph[j]) { v[j] = 0; v[j + 1]++; }
+	}
+	return min_cost;
+}
+
+// ---- block-wide primitives --------------------------------------------------------------------------------------------
+// Exclusive prefix sums of in[0 .. n) into out (may alias in); returns the total.  Every thread must call it.
+HEUR_FN inline uint32_t heur_scan(const uint32_t* in, uint32_t* out, uint32_t n) {
+	HEUR_SHARED uint32_t tmp[1024];
+	HEUR_SHARED uint32_t carry;
+	const uint32_t tid = HEUR_TID, nt = HEUR_NT;
+	if (tid == 0) carry = 0;
+	HEUR_SYNC();
+	for (uint32_t base = 0; base < n; base += nt) {
+		const uint32_t i = base + tid;
+		const uint32_t mine = i < n ? in[i] : 0u;
+		tmp[tid] = mine;
+		HEUR_SYNC();
+		for (uint32_t off = 1; off < nt; off <<= 1) {   // Hillis-Steele inclusive scan
+			const uint32_t add = tid >= off ? tmp[tid - off] : 0u;
+			HEUR_SYNC();
+			tmp[tid] += add;
+			HEUR_SYNC();
+		}
+		const uint32_t incl = tmp[tid], c = carry;
+		if (i < n) out[i] = c + incl - mine;
+		HEUR_SYNC();
+		if (tid == nt - 1) carry = c + incl;
+		HEUR_SYNC();
+	}
+	return carry;
+}
+
+// The k-th smallest (0-based) of the sortable keys of val[0 .. n): radix select, four 8-bit passes.
+HEUR_FN inline uint32_t heur_select(const float* val, uint32_t n, uint32_t k) {
+	HEUR_SHARED uint32_t hist[256];
+	HEUR_SHARED uint32_t sh_prefix, sh_k;
+	const uint32_t tid = HEUR_TID, nt = HEUR_NT;
+	uint32_t prefix = 0, mask = 0;
+	if (tid == 0) sh_k = k;
+	for (int pass = 3; pass >= 0; --pass) {
+		for (uint32_t b = tid; b < 256u; b += nt) hist[b] = 0;
+		HEUR_SYNC();
+		for (uint32_t i = tid; i < n; i += nt) {
+			const uint32_t key = heur_sortable(val[i]);
+			if ((key & mask) == prefix) heur_add32(&hist[(key >> (8 * pass)) & 255u], 1u);
+		}
+		HEUR_SYNC();
+		if (tid == 0) {
+			uint32_t kk = sh_k, b = 0;
+			while (b < 255u && kk >= hist[b]) { kk -= hist[b]; ++b; }
+			sh_k = kk;
+			sh_prefix = prefix | (b << (8 * pass));
+		}
+		HEUR_SYNC();
+		prefix = sh_prefix;
+		mask |= 0xFFu << (8 * pass);
+		HEUR_SYNC();
+	}
+	return prefix;
+}
+
+HEUR_FN inline void heur_copy_solution(const HeurDev& D, const HeurPool& src, uint32_t i, const HeurPool& dst, uint32_t j, uint32_t w) {
+	dst.score[j] = src.score[i]; dst.mut[j] = src.mut[i]; dst.trans[j] = src.trans[i]; dst.bt[j] = src.bt[i];
+	for (uint32_t q = 0; q < D.nw; ++q) dst.bits[(size_t)j * D.nw + q] = src.bits[(size_t)i * D.nw + q];
+	const size_t rows = 2u * D.n_samples;
+	for (uint32_t r = 0; r < rows; ++r)
+		for (uint32_t x = 0; x < w; ++x) dst.bal[((size_t)j * rows + r) * D.w_max + x] = src.bal[((size_t)i * rows + r) * D.w_max + x];
+}
+
+// filterSolutions (:604-622): pool[cur] (count) -> pool[cur ^ 1]; returns the new count.
+HEUR_FN inline uint32_t heur_filter(const HeurDev& D, uint32_t cur, uint32_t count, uint32_t w) {
+	const uint32_t tid = HEUR_TID, nt = HEUR_NT;
+	const HeurPool& src = D.pool[cur];
+	const HeurPool& dst = D.pool[cur ^ 1u];
+	for (uint32_t i = tid; i < count; i += nt) D.val[i] = src.score[i] + src.mut[i];
+	HEUR_SYNC();
+	const float lowest = heur_unsortable(heur_select(D.val, count, 0));
+	const float too_high = count > D.row_limit ? heur_unsortable(heur_select(D.val, count, D.row_limit)) : __builtin_inff();
+	for (uint32_t i = tid; i < count; i += nt) D.aux[i] = (D.val[i] < too_high || D.val[i] == lowest) ? 1u : 0u;
+	HEUR_SYNC();
+	uint32_t kept = heur_scan(D.aux, D.rank, count);
+	if (kept > HEUR_MAX_ROW_LIMIT) kept = HEUR_MAX_ROW_LIMIT;   // `kept.size() < MAX_ROW_LIMIT`: the first 65535 in order
+	for (uint32_t i = tid; i < count; i += nt)
+		if (D.aux[i] && D.rank[i] < kept) heur_copy_solution(D, src, i, dst, D.rank[i], w);
+	HEUR_SYNC();
+	return kept;
+}
+
+HEUR_FN inline uint32_t heur_get_bit(const uint32_t* bits, uint32_t b) { return (bits[b >> 5] >> (b & 31u)) & 1u; }
+
+// ---- the solver: src/pedmecheuristic.cpp:123-358 ------------------------------------------------------------------------
+HEUR_FN inline void heur_solve(const HeurDev& D) {
+	const uint32_t tid = HEUR_TID, nt = HEUR_NT;
+	const uint32_t S = D.n_samples, rows = 2u * S, nw = D.nw, wm = D.w_max, T = 1u << D.tm_bits;
+	uint32_t cur = 0, count = 1, w_prev = 1;
+	unsigned long long arena_used = 0, widest = 0, total = 0;
+	// lastCol = { empty bipartition, transmission 0, score 0, balances (1, 0) }  (:151)
+	if (tid == 0) { D.pool[0].score[0] = 0.0f; D.pool[0].mut[0] = 0.0f; D.pool[0].trans[0] = 0; D.pool[0].bt[0] = 0; }
+	for (uint32_t x = tid; x < rows * wm; x += nt) D.pool[0].bal[x] = 0.0f;
+	for (uint32_t x = tid; x < nw; x += nt) D.pool[0].bits[x] = 0;
+	HEUR_SYNC();
+	for (uint32_t p = 0; p < D.n_cols; ++p) {
+		const uint32_t w = D.window[p], nk = D.n_kept[p], nn = D.n_new[p];
+		const uint32_t* kept = D.kept + D.kept_off[p];
+		// ================= projection onto the reads that continue, duplicates merged into their first occurrence (:170-197)
+		{
+			const HeurPool& src = D.pool[cur];
+			const HeurPool& dst = D.pool[cur ^ 1u];
+			uint32_t tsz = 64;
+			while (tsz < 2u * count) tsz <<= 1;
+			for (uint32_t x = tid; x < tsz; x += nt) { D.table[x] = HEUR_EMPTY; D.lead[x] = HEUR_EMPTY; D.best[x] = ~0ull; }
+			for (uint32_t i = tid; i < count; i += nt) {
+				uint32_t* pb = D.pbits + (size_t)i * nw;
+				for (uint32_t q = 0; q < nw; ++q) pb[q] = 0;
+				const uint32_t* sb = src.bits + (size_t)i * nw;
+				for (uint32_t a = 0; a < nk; ++a) pb[a >> 5] |= heur_get_bit(sb, kept[a]) << (a & 31u);
+			}
+			HEUR_SYNC();
+			for (uint32_t i = tid; i < count; i += nt) {
+				const uint32_t* pb = D.pbits + (size_t)i * nw;
+				const uint32_t tr = src.trans[i];
+				uint32_t h = tr * 0x9E3779B1u + 0x7F4A7C15u;
+				for (uint32_t q = 0; q < nw; ++q) { h ^= pb[q]; h *= 0x85EBCA6Bu; h ^= h >> 13; }
+				uint32_t pos = h & (tsz - 1u);
+				for (;;) {
+					uint32_t other = heur_load32(&D.table[pos]);
+					if (other == HEUR_EMPTY) {
+						other = heur_cas32(&D.table[pos], HEUR_EMPTY, i);
+						if (other == HEUR_EMPTY) break;   // this solution is the slot's group from now on
+					}
+					bool same = src.trans[other] == tr;
+					const uint32_t* ob = D.pbits + (size_t)other * nw;
+					for (uint32_t q = 0; q < nw && same; ++q) same = ob[q] == pb[q];
+					if (same) break;
+					pos = (pos + 1u) & (tsz - 1u);
+				}
+				D.slot[i] = pos;
+				heur_min32(&D.lead[pos], i);
+				// updateSolution (:420-432): a later duplicate replaces the kept one only if strictly better
+				heur_min64(&D.best[pos], ((unsigned long long)heur_sortable(src.score[i]) << 32) | i);
+			}
+			HEUR_SYNC();
+			for (uint32_t i = tid; i < count; i += nt) D.aux[i] = heur_load32(&D.lead[D.slot[i]]) == i ? 1u : 0u;
+			HEUR_SYNC();
+			const uint32_t n2 = heur_scan(D.aux, D.rank, count);
+			for (uint32_t i = tid; i < count; i += nt) {
+				if (!D.aux[i]) continue;
+				const uint32_t j = D.rank[i], win = (uint32_t)heur_load64(&D.best[D.slot[i]]);
+				dst.score[j] = src.score[win]; dst.mut[j] = 0.0f; dst.trans[j] = src.trans[i]; dst.bt[j] = win;
+				for (uint32_t q = 0; q < nw; ++q) dst.bits[(size_t)j * nw + q] = D.pbits[(size_t)i * nw + q];
+				// balances of the winner without their first position, extended with zeros to the column's window (:204-206, :425-431)
+				for (uint32_t r = 0; r < rows; ++r) {
+					const float* sb = src.bal + ((size_t)win * rows + r) * wm;
+					float* db = dst.bal + ((size_t)j * rows + r) * wm;
+					for (uint32_t x = 0; x < w; ++x) db[x] = x + 1u < w_prev ? sb[x + 1u] : 0.0f;
+				}
+			}
+			HEUR_SYNC();
+			cur ^= 1u;
+			count = n2;
+		}
+		// ================= the reads that start here, one after the other (:240-297)
+		for (uint32_t q = 0; q < nn; ++q) {
+			const uint32_t nr = D.new_off[p] + q;
+			const int32_t eq = D.new_equal_to[nr];
+			const uint32_t bitpos = nk + q;
+			const HeurPool& P = D.pool[cur];
+			if (eq >= 0) {   // identical to an earlier read of the column: same side, no branching (:247-250)
+				for (uint32_t i = tid; i < count; i += nt) {
+					uint32_t* b = P.bits + (size_t)i * nw;
+					if (heur_get_bit(b, nk + (uint32_t)eq)) b[bitpos >> 5] |= 1u << (bitpos & 31u);
+				}
+				HEUR_SYNC();
+				continue;
+			}
+			const uint32_t s = D.new_sample[nr];
+			const bool seen = D.new_seen[nr] != 0;
+			const float* add = D.new_balance + D.new_bal_off[nr];
+			const int8_t* target = D.genotype + (size_t)s * D.n_cols + p;
+			if ((unsigned long long)count * 2ull > D.cap) { if (tid == 0) D.stats[0] = 1; return; }
+			// pass 1: both placements of the read scored per solution; aux = 0 keep side 0, 1 keep side 1, 2 keep both
+			for (uint32_t i = tid; i < count; i += nt) {
+				const float* bal = P.bal + (size_t)i * rows * wm;
+				const float* b0 = bal + (size_t)(2 * s) * wm;
+				const float* b1 = bal + (size_t)(2 * s + 1) * wm;
+				bool useful;
+				if (D.distrust) {
+					useful = false;
+					for (uint32_t j = 0; j < w && !useful; ++j) {
+						const float s0 = b0[j], s1 = b1[j];
+						useful = (add[j] != 0 && s0 * s1 < 0) || ((add[j] + s0) * s0 <= 0 && (add[j] + s1) * s1 <= 0);
+					}
+				} else useful = D.new_useful[nr] != 0;
+				const uint32_t tr = P.trans[i];
+				const float sc = P.score[i];
+				float sc1 = 0, mu1 = 0;
+				if (seen) {
+					sc1 = sc + heur_add_balance(b1, b0, add, w, D.distrust != 0, target);
+					mu1 = heur_mutation_cost(D, HeurBalView{bal, wm, 2 * s + 1, add}, tr, p, true, 5, w);
+				}
+				const float sc0 = sc + heur_add_balance(b0, b1, add, w, D.distrust != 0, target);
+				const float mu0 = heur_mutation_cost(D, HeurBalView{bal, wm, 2 * s, add}, tr, p, true, 5, w);
+				uint32_t mode = 0;
+				if (seen) mode = useful ? 2u : ((sc0 + mu0 > sc1 + mu1) ? 1u : 0u);
+				D.aux[i] = mode;
+				// (scores of both sides kept for pass 2: val = side 1's score, rank slot reused below for its mutation score)
+				D.val[i] = sc1;
+				D.slot[i] = __builtin_bit_cast(uint32_t, mu1);
+				P.score[i] = mode == 1u ? sc1 : sc0;
+				P.mut[i] = mode == 1u ? mu1 : mu0;
+			}
+			HEUR_SYNC();
+			for (uint32_t i = tid; i < count; i += nt) D.rank[i] = D.aux[i] == 2u ? 1u : 0u;
+			HEUR_SYNC();
+			const uint32_t n_app = heur_scan(D.rank, D.rank, count);
+			// pass 2: the copies (side 1) behind the existing solutions in their order, then the read joins its side in place
+			for (uint32_t i = tid; i < count; i += nt) {
+				if (D.aux[i] != 2u) continue;
+				const uint32_t j = count + D.rank[i];
+				heur_copy_solution(D, P, i, P, j, w);
+				P.score[j] = D.val[i];
+				P.mut[j] = __builtin_bit_cast(float, D.slot[i]);
+				float* row = P.bal + ((size_t)j * rows + 2 * s + 1) * wm;
+				for (uint32_t x = 0; x < w; ++x) row[x] += add[x];
+				P.bits[(size_t)j * nw + (bitpos >> 5)] |= 1u << (bitpos & 31u);
+			}
+			HEUR_SYNC();
+			for (uint32_t i = tid; i < count; i += nt) {
+				const uint32_t side = D.aux[i] == 1u ? 1u : 0u;
+				float* row = P.bal + ((size_t)i * rows + 2 * s + side) * wm;
+				for (uint32_t x = 0; x < w; ++x) row[x] += add[x];
+				if (side) P.bits[(size_t)i * nw + (bitpos >> 5)] |= 1u << (bitpos & 31u);
+			}
+			HEUR_SYNC();
+			count += n_app;
+			if (count > D.row_limit) { count = heur_filter(D, cur, count, w); cur ^= 1u; }
+		}
+		// ================= other transmission values where they pay for themselves (:299-303, :588-602)
+		{
+			const HeurPool& P = D.pool[cur];
+			const float rc1 = D.recomb[p];
+			for (uint32_t i = tid; i < count; i += nt) {
+				const float* bal = P.bal + (size_t)i * rows * wm;
+				const HeurBalView B{bal, wm, HEUR_EMPTY, nullptr};
+				const uint32_t tr = P.trans[i];
+				const float mu = heur_mutation_cost(D, B, tr, p, false, 0, w);
+				P.mut[i] = mu;
+				uint32_t n_ext = 0;
+				if (mu > 0) {
+					for (uint32_t t = 0; t < T; ++t) {
+						if (t == tr) continue;
+						const float rc = rc1 * (float)heur_popc(tr ^ t);
+						if (rc >= mu) continue;
+						const float m2 = heur_mutation_cost(D, B, t, p, false, 0, w);
+						if (m2 + rc >= mu) continue;
+						++n_ext;
+					}
+				}
+				D.aux[i] = n_ext;
+			}
+			HEUR_SYNC();
+			const uint32_t n_app = heur_scan(D.aux, D.rank, count);
+			if ((unsigned long long)count + n_app > D.cap) { if (tid == 0) D.stats[0] = 1; return; }
+			for (uint32_t i = tid; i < count; i += nt) {
+				if (!D.aux[i]) continue;
+				const float* bal = P.bal + (size_t)i * rows * wm;
+				const HeurBalView B{bal, wm, HEUR_EMPTY, nullptr};
+				const uint32_t tr = P.trans[i];
+				const float mu = P.mut[i], sc = P.score[i];
+				uint32_t j = count + D.rank[i];
+				for (uint32_t t = 0; t < T; ++t) {
+					if (t == tr) continue;
+					const float rc = rc1 * (float)heur_popc(tr ^ t);
+					if (rc >= mu) continue;
+					const float m2 = heur_mutation_cost(D, B, t, p, false, 0, w);
+					if (m2 + rc >= mu) continue;
+					heur_copy_solution(D, P, i, P, j, w);
+					P.trans[j] = t; P.score[j] = sc + rc; P.mut[j] = m2;
+					++j;
+				}
+			}
+			HEUR_SYNC();
+			count += n_app;
+			if (count > D.row_limit) { count = heur_filter(D, cur, count, w); cur ^= 1u; }
+		}
+		// ================= the column's own phasing cost (:306-313), then the backtrace record of the column (:315-330)
+		{
+			const HeurPool& P = D.pool[cur];
+			const uint32_t nwn = (nn + 31u) >> 5, stride = 2u + nwn;
+			if (arena_used + (unsigned long long)count * stride > D.arena_words) { if (tid == 0) D.stats[0] = 2; return; }
+			uint32_t* rec = D.arena + arena_used;
+			for (uint32_t i = tid; i < count; i += nt) {
+				float firsts[2 * HEUR_MAXS];
+				for (uint32_t r = 0; r < rows; ++r) firsts[r] = P.bal[((size_t)i * rows + r) * wm];
+				P.score[i] += heur_opt_phasing(D, firsts, P.trans[i], p, nullptr, nullptr);
+				uint32_t* e = rec + (size_t)i * stride;
+				e[0] = P.bt[i];
+				e[1] = P.trans[i];
+				const uint32_t* b = P.bits + (size_t)i * nw;
+				for (uint32_t q = 0; q < nwn; ++q) e[2 + q] = 0;
+				for (uint32_t q = 0; q < nn; ++q) e[2 + (q >> 5)] |= heur_get_bit(b, nk + q) << (q & 31u);
+			}
+			if (tid == 0) { D.col_off[p] = arena_used; D.col_count[p] = count; }
+			arena_used += (unsigned long long)count * stride;
+			if (count > widest) widest = count;
+			total += count;
+			HEUR_SYNC();
+		}
+		w_prev = w;
+	}
+	// ================= best solution of the last column: the first with the smallest score (:332-341), then the walk back (:343-359)
+	{
+		const HeurPool& P = D.pool[cur];
+		if (tid == 0) D.best[0] = ~0ull;
+		HEUR_SYNC();
+		for (uint32_t i = tid; i < count; i += nt) heur_min64(&D.best[0], ((unsigned long long)heur_sortable(P.score[i]) << 32) | i);
+		HEUR_SYNC();
+		if (tid == 0) {
+			uint32_t ri = (uint32_t)heur_load64(&D.best[0]);
+			for (uint32_t p = D.n_cols; p-- > 0;) {
+				const uint32_t nn = D.n_new[p], nwn = (nn + 31u) >> 5, stride = 2u + nwn;
+				const uint32_t* e = D.arena + D.col_off[p] + (size_t)ri * stride;
+				for (uint32_t q = 0; q < nn; ++q) D.opt_bipart[D.start_index[p] + q] = (uint8_t)((e[2 + (q >> 5)] >> (q & 31u)) & 1u);
+				D.opt_trans[p] = e[1];
+				ri = e[0];
+			}
+			D.stats[1] = widest;
+			D.stats[2] = total;
+		}
+		HEUR_SYNC();
+	}
+}
+
+}  // namespace whamd

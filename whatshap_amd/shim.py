@@ -157,6 +157,49 @@ def table_factory(reference_core=None, fallback_table_class=None, **solver_optio
     return make
 
 
+def heuristic_factory(reference_core=None, fallback_class=None):
+    """Callable with the constructor signature of the reference's ``PedMecHeuristic`` (core.pyx:675): ``(readset, recombcost,
+    pedigree, row_limit=256, distrust_genotypes=False, positions=None, allow_mutations=True, verbosity=0)``.  Same rules as
+    ``table_factory``: compiled ingestion or a recorded pedigree; input-limit refusals go to ``fallback_class`` when one was given."""
+    from . import heuristic as _heuristic
+
+    def make(readset, recombcost, pedigree, row_limit=256, distrust_genotypes=False, positions=None, allow_mutations=True, verbosity=0):
+        from . import ingest as _ingest
+
+        compiled = _ingest.load() if reference_core is not None else None
+        problem = None
+        if compiled is not None and isinstance(readset, reference_core.ReadSet) and isinstance(pedigree, reference_core.Pedigree):
+            problem = amd.problem_from_reference_objects(compiled, readset, recombcost, pedigree, distrust_genotypes, positions)
+            recorded = pedigree
+        else:
+            recorded = getattr(pedigree, "amd", pedigree)
+            if not isinstance(recorded, amd.Pedigree):
+                raise TypeError("the pedigree was not created through whatshap_amd.shim and the compiled ingestion is not available")
+        try:
+            solver = _heuristic.PedMecHeuristic(readset, recombcost, recorded, row_limit, distrust_genotypes, positions, allow_mutations, verbosity, problem=problem)
+        except RuntimeError as exc:
+            status = getattr(exc, "status", None)
+            if fallback_class is None or status not in _DEVICE_LIMIT_STATUSES:
+                raise
+            import logging
+
+            logging.getLogger("whatshap_amd").warning("device path refused this table (%s); solving it with the reference PedMecHeuristic", exc)
+            _counters["cpu_fallbacks"] += 1
+            _fallback_reasons.append(str(exc))
+            return fallback_class(readset, recombcost, pedigree, row_limit, distrust_genotypes, positions, allow_mutations, verbosity)
+        _counters["device_tables"] += 1
+        return _HeuristicAdapter(solver, reference_core)
+
+    return make
+
+
+class _HeuristicAdapter(_TableAdapter):
+    """``get_super_reads`` as the reference's own objects (through ``_TableAdapter``), plus ``get_mutations``."""
+
+    def get_mutations(self):
+        return self._table.get_mutations()
+
+
 def install(phase_module, reference_core=None, allow_cpu_fallback=False, **solver_options):
     """Rebinds ``Pedigree`` and ``PedigreeDPTable`` in ``phase_module`` (normally ``whatshap.cli.phase``).  Returns the
     previous bindings so that a caller can restore them.  ``allow_cpu_fallback=True``: inputs beyond the device path's
@@ -165,6 +208,8 @@ def install(phase_module, reference_core=None, allow_cpu_fallback=False, **solve
     ref_pedigree = reference_core.Pedigree if reference_core is not None else phase_module.Pedigree
     phase_module.Pedigree = recording_pedigree_class(ref_pedigree)
     phase_module.PedigreeDPTable = table_factory(reference_core, fallback_table_class=previous[1] if allow_cpu_fallback else None, **solver_options)
+    if hasattr(phase_module, "PedMecHeuristic"):   # `--algorithm heuristic` (whatshap/cli/phase.py:589-603)
+        phase_module.PedMecHeuristic = heuristic_factory(reference_core, phase_module.PedMecHeuristic if allow_cpu_fallback else None)
     return previous
 
 
