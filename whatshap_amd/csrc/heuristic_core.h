@@ -6,6 +6,7 @@
 //   HEUR_TID, HEUR_NT               index of the calling thread, number of threads (a power of two <= 1024)
 //   HEUR_SYNC()                     barrier of all threads (also orders their global-memory accesses)
 //   heur_cas32(p, cmp, val) -> old  heur_min32(p, v)  heur_min64(p, v)  heur_add32(p, v) -> old     atomics
+//   heur_block_inclusive(v, tmp)    inclusive prefix sum of one value per thread over the block (tmp: 32 shared words; ends with a barrier)
 //   heur_load32(p)  heur_load64(p)  loads of words other threads changed with atomics (device: past the CU's L1, which the
 //                                   atomics -- performed in L2 -- do not update)
 //
@@ -181,7 +182,7 @@ HEUR_FN inline float heur_opt_phasing(const HeurDev& D, const float* firsts, uin
 // ---- block-wide primitives --------------------------------------------------------------------------------------------
 // Exclusive prefix sums of in[0 .. n) into out (may alias in); returns the total.  Every thread must call it.
 HEUR_FN inline uint32_t heur_scan(const uint32_t* in, uint32_t* out, uint32_t n) {
-	HEUR_SHARED uint32_t tmp[1024];
+	HEUR_SHARED uint32_t tmp[32];
 	HEUR_SHARED uint32_t carry;
 	const uint32_t tid = HEUR_TID, nt = HEUR_NT;
 	if (tid == 0) carry = 0;
@@ -189,15 +190,8 @@ HEUR_FN inline uint32_t heur_scan(const uint32_t* in, uint32_t* out, uint32_t n)
 	for (uint32_t base = 0; base < n; base += nt) {
 		const uint32_t i = base + tid;
 		const uint32_t mine = i < n ? in[i] : 0u;
-		tmp[tid] = mine;
-		HEUR_SYNC();
-		for (uint32_t off = 1; off < nt; off <<= 1) {   // Hillis-Steele inclusive scan
-			const uint32_t add = tid >= off ? tmp[tid - off] : 0u;
-			HEUR_SYNC();
-			tmp[tid] += add;
-			HEUR_SYNC();
-		}
-		const uint32_t incl = tmp[tid], c = carry;
+		const uint32_t incl = heur_block_inclusive(mine, tmp);
+		const uint32_t c = carry;
 		if (i < n) out[i] = c + incl - mine;
 		HEUR_SYNC();
 		if (tid == nt - 1) carry = c + incl;
@@ -206,13 +200,14 @@ HEUR_FN inline uint32_t heur_scan(const uint32_t* in, uint32_t* out, uint32_t n)
 	return carry;
 }
 
-// The k-th smallest (0-based) of the sortable keys of val[0 .. n): radix select, four 8-bit passes.
+// The k-th smallest (0-based) of the sortable keys of val[0 .. n): radix select, four 8-bit passes; the bucket of a pass is found
+// with a block-wide prefix sum over the 256 counters.
 HEUR_FN inline uint32_t heur_select(const float* val, uint32_t n, uint32_t k) {
 	HEUR_SHARED uint32_t hist[256];
+	HEUR_SHARED uint32_t tmp[32];
 	HEUR_SHARED uint32_t sh_prefix, sh_k;
 	const uint32_t tid = HEUR_TID, nt = HEUR_NT;
-	uint32_t prefix = 0, mask = 0;
-	if (tid == 0) sh_k = k;
+	uint32_t prefix = 0, mask = 0, kk = k;
 	for (int pass = 3; pass >= 0; --pass) {
 		for (uint32_t b = tid; b < 256u; b += nt) hist[b] = 0;
 		HEUR_SYNC();
@@ -221,14 +216,18 @@ HEUR_FN inline uint32_t heur_select(const float* val, uint32_t n, uint32_t k) {
 			if ((key & mask) == prefix) heur_add32(&hist[(key >> (8 * pass)) & 255u], 1u);
 		}
 		HEUR_SYNC();
-		if (tid == 0) {
-			uint32_t kk = sh_k, b = 0;
-			while (b < 255u && kk >= hist[b]) { kk -= hist[b]; ++b; }
-			sh_k = kk;
-			sh_prefix = prefix | (b << (8 * pass));
+		// bucket b with  sum(hist[0 .. b)) <= kk < sum(hist[0 .. b])
+		uint32_t carry = 0;
+		for (uint32_t base = 0; base < 256u; base += nt) {   // (one round when the block has >= 256 threads)
+			const uint32_t b = base + tid;
+			const uint32_t mine = b < 256u ? hist[b] : 0u;
+			const uint32_t incl = carry + heur_block_inclusive(mine, tmp);
+			if (b < 256u && incl - mine <= kk && kk < incl) { sh_prefix = prefix | (b << (8 * pass)); sh_k = kk - (incl - mine); }
+			HEUR_SYNC();
+			if (nt < 256u) { if (tid == nt - 1) tmp[0] = incl; HEUR_SYNC(); carry = tmp[0]; HEUR_SYNC(); }
 		}
-		HEUR_SYNC();
 		prefix = sh_prefix;
+		kk = sh_k;
 		mask |= 0xFFu << (8 * pass);
 		HEUR_SYNC();
 	}
@@ -250,7 +249,16 @@ HEUR_FN inline uint32_t heur_filter(const HeurDev& D, uint32_t cur, uint32_t cou
 	const HeurPool& dst = D.pool[cur ^ 1u];
 	for (uint32_t i = tid; i < count; i += nt) D.val[i] = src.score[i] + src.mut[i];
 	HEUR_SYNC();
-	const float lowest = heur_unsortable(heur_select(D.val, count, 0));
+	HEUR_SHARED uint32_t sh_low;
+	if (tid == 0) sh_low = 0xFFFFFFFFu;
+	HEUR_SYNC();
+	{
+		uint32_t low = 0xFFFFFFFFu;
+		for (uint32_t i = tid; i < count; i += nt) { const uint32_t key = heur_sortable(D.val[i]); low = key < low ? key : low; }
+		heur_min32(&sh_low, low);
+	}
+	HEUR_SYNC();
+	const float lowest = heur_unsortable(sh_low);
 	const float too_high = count > D.row_limit ? heur_unsortable(heur_select(D.val, count, D.row_limit)) : __builtin_inff();
 	for (uint32_t i = tid; i < count; i += nt) D.aux[i] = (D.val[i] < too_high || D.val[i] == lowest) ? 1u : 0u;
 	HEUR_SYNC();

@@ -24,6 +24,30 @@ __device__ __forceinline__ uint32_t heur_cas32(uint32_t* p, uint32_t cmp, uint32
 __device__ __forceinline__ void heur_min32(uint32_t* p, uint32_t v) { atomicMin(p, v); }
 __device__ __forceinline__ void heur_min64(unsigned long long* p, unsigned long long v) { atomicMin(p, v); }
 __device__ __forceinline__ uint32_t heur_add32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
+// inclusive prefix sum over the block: shuffles inside a wavefront, one pass over the wave totals (three barriers instead of 2 log n)
+__device__ __forceinline__ uint32_t heur_block_inclusive(uint32_t v, uint32_t* tmp) {
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = (blockDim.x + 63u) >> 6;
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) {
+		const uint32_t u = (uint32_t)__shfl_up((int)v, off);
+		if (lane >= (uint32_t)off) v += u;
+	}
+	if (lane == 63u) tmp[wave] = v;
+	__syncthreads();
+	if (wave == 0) {
+		uint32_t t = lane < n_waves ? tmp[lane] : 0u;
+#pragma unroll
+		for (int off = 1; off < 16; off <<= 1) {
+			const uint32_t u = (uint32_t)__shfl_up((int)t, off);
+			if (lane >= (uint32_t)off) t += u;
+		}
+		if (lane < n_waves) tmp[lane] = t;
+	}
+	__syncthreads();
+	if (wave > 0) v += tmp[wave - 1u];
+	__syncthreads();
+	return v;
+}
 __device__ __forceinline__ uint32_t heur_load32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned long long heur_load64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 }  // namespace whamd
@@ -115,7 +139,11 @@ whamd_status_t heuristic_solve_device(const HeurPlan& pl, int device, HeurResult
 		D.arena = (uint32_t*)arena; D.arena_words = arena_words;
 		HEUR_TRY(hipMemset(D.stats, 0, 64));
 		HEUR_TRY(hipEventRecord(ev0, nullptr));
-		hipLaunchKernelGGL(heuristic_kernel, dim3(1), dim3(1024), 0, nullptr, D);
+		// as many threads as the beam usually has solutions (a barrier costs with the number of waves): 2 x row_limit, 128 .. 1024
+		uint32_t block = 128;
+		while (block < 1024u && block < 2u * pl.row_limit) block <<= 1;
+		if (const char* e = getenv("WHAMD_HEURISTIC_THREADS")) block = (uint32_t)std::max(64, std::min(1024, atoi(e)));
+		hipLaunchKernelGGL(heuristic_kernel, dim3(1), dim3(block), 0, nullptr, D);
 		HEUR_TRY(hipEventRecord(ev1, nullptr));
 		hipError_t e = hipDeviceSynchronize();
 		if (e == hipSuccess) e = hipMemcpy(stats, D.stats, sizeof stats, hipMemcpyDeviceToHost);

@@ -17,6 +17,7 @@ static inline uint32_t heur_cas32(uint32_t* p, uint32_t cmp, uint32_t val) { con
 static inline void heur_min32(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
 static inline void heur_min64(unsigned long long* p, unsigned long long v) { if (v < *p) *p = v; }
 static inline uint32_t heur_add32(uint32_t* p, uint32_t v) { const uint32_t old = *p; *p = old + v; return old; }
+static inline uint32_t heur_block_inclusive(uint32_t v, uint32_t*) { return v; }   // one thread: its own value
 static inline uint32_t heur_load32(const uint32_t* p) { return *p; }
 static inline unsigned long long heur_load64(const unsigned long long* p) { return *p; }
 }  // namespace whamd
