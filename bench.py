@@ -59,8 +59,9 @@ WORKLOADS = {
     "quartet": dict(quartet=True, variants=50000, coverage=13),                    # two trios sharing parents, T = 16
     "genotype": dict(genotype=True, variants=50000, coverage=15),                  # GenotypeDPTable, single individual
     "genotype_trio": dict(genotype=True, trio=True, variants=20000, coverage=15),  # GenotypeDPTable, trio
+    "heuristic": dict(heuristic=True, variants=8000, coverage=30),                 # PedMecHeuristic, coverage beyond the exact DP
 }
-EXTRA_CONFIGS = ["config1", "config3", "blocks3", "irregular", "quartet", "genotype", "genotype_trio"]
+EXTRA_CONFIGS = ["config1", "config3", "blocks3", "irregular", "quartet", "genotype", "genotype_trio", "heuristic"]
 
 
 def parse_args():
@@ -77,6 +78,7 @@ def parse_args():
     ap.add_argument("--quartet", action="store_true", help="two trios sharing their parents (T = 16), coverage 13")
     ap.add_argument("--irregular", action="store_true", help="irregular read layout (whatshap_amd.synthetic.irregular_block, seed 7)")
     ap.add_argument("--genotype", action="store_true", help="the genotyping row: GenotypeDPTable (forward-backward, f64) instead of the phasing table")
+    ap.add_argument("--heuristic", action="store_true", help="the PedMecHeuristic row: beam search at a coverage the exact DP cannot afford (row limit 256)")
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="a named workload (sets the flags above)")
     ap.add_argument("--configs", default="auto", choices=["auto", "on", "off"],
                     help="append the other single-GPU workloads as `configs` (auto: N=1 and no workload flags)")
@@ -137,7 +139,7 @@ def build_block(args, seed, n_variants, n_columns_limit=None):
 
 def workload_flags(args):
     out = []
-    for flag in ("trio", "quartet", "irregular", "genotype"):
+    for flag in ("trio", "quartet", "irregular", "genotype", "heuristic"):
         if getattr(args, flag):
             out.append("--" + flag)
     return out
@@ -476,6 +478,72 @@ def genotype_main(args):
     print(json.dumps(out), flush=True)
 
 
+def heuristic_main(args):
+    """`--heuristic`: PedMecHeuristic.  A step = one solve (constructor + solve() of the reference class); `value` =
+    columns / HIP-event time of the persistent kernel; the CPU baseline is the compiled reference's solve() on a prefix of the same
+    ReadSet, and every output of that prefix is compared (`identical_to_reference`)."""
+    from whatshap_amd import _native
+
+    if _native.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if args.coverage == 20:
+        args.coverage = 30
+    v = args.variants or 8000
+    row_limit = 256
+    problem = build_block(args, 3, v)
+    for _ in range(args.warmup):
+        _native.pedmec_heuristic(problem, row_limit=row_limit)
+    if args.pmc_inner:
+        _native.pedmec_heuristic(problem, row_limit=row_limit)
+        return
+    dev, wall, got = [], [], None
+    for _ in range(args.steps):
+        t0 = time.perf_counter()
+        got = _native.pedmec_heuristic(problem, row_limit=row_limit)
+        wall.append(time.perf_counter() - t0)
+        dev.append(got["stats"]["device_ms"] / 1e3)
+    dev_s, wall_s = sorted(dev)[len(dev) // 2], sorted(wall)[len(wall) // 2]
+    out = {
+        "metric": "variant-columns/sec of PedMecHeuristic.solve at max-coverage %d, row limit %d" % (args.coverage, row_limit),
+        "value": v / dev_s, "unit": "variant-columns/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dev_s * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "bipartition_costs_per_s": got["stats"]["total_solutions"] / dev_s,
+        "bipartition_costs_note": "partial solutions of the beam scored per second (sum over the columns of the beam's width), not table cells",
+        "config": {"workload": f"synthetic single individual, {v} SNVs, max-coverage {args.coverage}, PedMecHeuristic row limit {row_limit}",
+                   "optimal_cost_checksum": int(got["bipartition"].sum()) * 1000003 + int(got["transmission"].sum()), "widest_column": got["stats"]["max_solutions"]},
+        "rank0": {"forward_ms_per_step": dev_s * 1e3, "backtrace_ms_per_step": 0.0, "forward_launches_per_step": 1.0},
+        "end_to_end": {"value": v / wall_s, "unit": "variant-columns/s", "what": "whamd_pedmec_heuristic_create from host arrays (plan + upload + kernel + phasing), wall"},
+    }
+    pmc, pmc_note = None, "skipped"
+    if args.pmc in ("on", "auto"):
+        try:
+            pmc, pmc_note = run_pmc_passes(args, "heuristic_kernel", args.pmc_keep)
+        except Exception as exc:  # noqa: BLE001
+            pmc_note = repr(exc)
+    roof = roofline_from_counters(pmc, dev_s * 1e6, "heuristic_kernel", 0.0, args)
+    roof.pop("hbm_model_ratio", None)
+    roof.pop("hbm_model_note", None)
+    roof["pmc_note"] = pmc_note
+    roof["shape_note"] = "ONE persistent workgroup (a chain over columns and reads; the beam is the only parallelism): the chip-wide fraction is bounded by 1 / 256 CUs"
+    out["roofline"] = roof
+    if args.cpu_baseline_columns != 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle
+        from heuristic_cases import result_tuple
+
+        if oracle.have_reference():
+            cols = args.cpu_baseline_columns if args.cpu_baseline_columns > 0 else (2000 if args.sub else 6000)
+            prefix = build_block(args, 3, v, n_columns_limit=min(cols, v))
+            ref = oracle.ReferenceHeuristic(prefix, row_limit=row_limit)
+            mine = _native.pedmec_heuristic(prefix, row_limit=row_limit)
+            out["cpu_baseline"] = {"value": prefix.n_variants / ref.solve_seconds(), "unit": "variant-columns/s", "cores": 1, "kind": "reference",
+                                   "sample": f"PedMecHeuristic::solve() of the compiled reference on the first {prefix.n_variants} columns of the same ReadSet, {ref.solve_seconds():.2f} s",
+                                   "host": cpu_info()}
+            out["identical_to_reference"] = result_tuple(mine) == oracle.heuristic_tuple(ref)
+            out["speedup_vs_cpu_baseline_device_only"] = out["value"] / out["cpu_baseline"]["value"]
+    print(json.dumps(out), flush=True)
+
+
 def dominant_kernel(args):
     if args.path in ("column", "column_keys"):
         return "column_step_fused"
@@ -528,7 +596,7 @@ def main():
     args = parse_args()
     if args.cpu_sample_worker:
         return cpu_sample_worker(args)
-    explicit = any(a in sys.argv[1:] for a in ("--workload", "--trio", "--quartet", "--irregular", "--genotype", "--variants", "--coverage", "--blocks", "--blocks-per-gpu", "--path", "--option"))
+    explicit = any(a in sys.argv[1:] for a in ("--workload", "--trio", "--quartet", "--irregular", "--genotype", "--heuristic", "--variants", "--coverage", "--blocks", "--blocks-per-gpu", "--path", "--option"))
     if args.workload:
         for key, value in WORKLOADS[args.workload].items():
             setattr(args, key, value)
@@ -538,6 +606,8 @@ def main():
         entry.build()
     if args.genotype:
         return genotype_main(args)
+    if args.heuristic:
+        return heuristic_main(args)
     if args.gpus > 1 and "RANK" not in os.environ:
         return self_launch(args)
 

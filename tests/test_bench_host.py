@@ -17,7 +17,7 @@ def _bench():
 
 
 def _args(**kw):
-    base = dict(coverage=20, trio=False, quartet=False, irregular=False, genotype=False, blocks=None, blocks_per_gpu=None, variants=None, pmc_variants=8000, sub=False)
+    base = dict(coverage=20, trio=False, quartet=False, irregular=False, genotype=False, heuristic=False, blocks=None, blocks_per_gpu=None, variants=None, pmc_variants=8000, sub=False)
     base.update(kw)
     return types.SimpleNamespace(**base)
 
