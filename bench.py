@@ -779,6 +779,13 @@ def main():
                 pmc_note = repr(exc)
         out["roofline"] = roofline_from_counters(pmc, avg_launch_us, kernel, bytes_per_launch, args)
         out["roofline"]["pmc_note"] = pmc_note
+        # work-based bound: the fewest VALU lane-operations the algorithm needs per evaluated (cell, transmission value) of a
+        # column -- single individual: A, K - A, min3, accumulate + ending reads = 5, half of the cells by symmetry; trio (NF = 2): 2 adds + min,
+        # 2 x 6 butterfly, accumulate, ending reads = 19; quartet 31 -- issued at the chip's 512 wave-instructions per cycle, over the forward time
+        ops = {1: 5.0, 4: 19.0, 16: 31.0}[T]
+        evaluated = costs_job / world * (0.5 if T == 1 else 1.0)
+        out["roofline"]["work_bound_frac"] = (evaluated * ops / 64.0 / (N_SIMD / 2.0) / (CLOCK_GHZ * 1e9)) / max(fwd_ms / args.steps * 1e-3, 1e-12)
+        out["roofline"]["work_bound_note"] = f"{ops:g} VALU lane-operations per evaluated cell-value of a column at 512 wave-instructions/cycle, over the forward time of a step"
         # ---- CPU baseline (rank 0, N = 1 only)
         args.variants_for_cpu = blocks[0][1]
         if world == 1 and args.cpu_baseline_columns != 0:
