@@ -58,6 +58,7 @@ struct DevProblem {
 	const SlotRow* slot_rows;    // per-column descriptors of the slot runs
 	const uint32_t* slot_blob;   // backtrace blobs of the slot runs (SlotBtUnit::blob_off)
 	const uint32_t* slot_ctrl;   // control bytes of the slot runs (SlotRun::ctrl_off)
+	const uint32_t* slot_tab;    // per-run tables of the single-individual slot runs (SlotRun::tab_g / tab_w / tab_sl)
 	const PedSlotRow* pslot_rows;   // pedigree slot runs: per-column descriptors (indexed by column)
 	const uint32_t* pslot_tab;      // pedigree slot runs: the cost-form tables G / W / S of every run (PedSlotExtra offsets)
 	unsigned long long* spec_keys;  // [chunk boundary][spec_stride]: per wave of the boundary run, min over the cells it stored of

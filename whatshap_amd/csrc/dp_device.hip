@@ -512,6 +512,24 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	void* d_sctrl = nullptr;
 	HIP_TRY(up(&d_sctrl, m.splan.ctrl.data(), m.splan.ctrl.size() * sizeof(uint32_t)));
 	m.dp.slot_ctrl = (const uint32_t*)d_sctrl;
+	// single-individual slot runs: the prologue's tables (SlotRun::tab_g / tab_w / tab_sl), built on the device below
+	void *d_sruns = nullptr, *d_stab = nullptr;
+	uint64_t slot_tab_words = 0;
+	if (m.use_slots && !ped_slots) {
+		for (SlotRun& run : m.splan.runs) {
+			auto pad4 = [](uint64_t v) { return (v + 3ull) & ~3ull; };
+			run.tab_g = (uint32_t)slot_tab_words;
+			slot_tab_words += pad4((uint64_t)run.ncols << (run.g - run.half));
+			run.tab_w = (uint32_t)slot_tab_words;
+			slot_tab_words += pad4((uint64_t)run.ncols * (run.threads >> 6));
+			run.tab_sl = (uint32_t)slot_tab_words;
+			slot_tab_words += (uint64_t)run.ncols * 64u;
+		}
+		if (slot_tab_words >= 0xFFFFFFFFull) { msg = "slot-run tables exceed 32-bit offsets"; return WHAMD_ERR_UNSUPPORTED; }
+		HIP_TRY(up(&d_sruns, m.splan.runs.data(), m.splan.runs.size() * sizeof(SlotRun)));
+		HIP_TRY(alloc(&d_stab, slot_tab_words * 4));
+	}
+	m.dp.slot_tab = (const uint32_t*)d_stab;
 	void *d_prows = nullptr, *d_pruns = nullptr, *d_pextra = nullptr, *d_ptab = nullptr;
 	if (ped_slots) {
 		HIP_TRY(up(&d_prows, m.splan.prows.data(), m.splan.prows.size() * sizeof(PedSlotRow)));
@@ -875,6 +893,16 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		for (size_t r0 = 0; r0 < m.splan.runs.size(); r0 += 32768) {   // (gridDim.y <= 65535)
 			const uint32_t ny = (uint32_t)std::min<size_t>(32768, m.splan.runs.size() - r0);
 			hipLaunchKernelGGL(pedslot_tables, dim3(bx, ny), dim3(256), 0, m.stream, m.dp, (const SlotRun*)d_pruns + r0, (const PedSlotExtra*)d_pextra + r0, (uint32_t*)d_ptab);
+		}
+		HIP_TRY(hipGetLastError());
+	}
+	if (m.use_slots && !ped_slots && !m.splan.runs.empty()) {
+		uint32_t most = 0;
+		for (const SlotRun& run : m.splan.runs) most = std::max<uint32_t>(most, (run.ncols << (run.g - run.half)) + run.ncols * ((run.threads >> 6) + 64u));
+		const uint32_t bx = std::max(1u, std::min(64u, (most + 255u) / 256u));
+		for (size_t r0 = 0; r0 < m.splan.runs.size(); r0 += 32768) {
+			const uint32_t ny = (uint32_t)std::min<size_t>(32768, m.splan.runs.size() - r0);
+			hipLaunchKernelGGL(slot_tables, dim3(bx, ny), dim3(256), 0, m.stream, m.dp, (const SlotRun*)d_sruns + r0, (uint32_t*)d_stab);
 		}
 		HIP_TRY(hipGetLastError());
 	}

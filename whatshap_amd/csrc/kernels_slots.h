@@ -76,15 +76,19 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 
 	// ---- prologue: ONE batch of global loads, issued before anything waits (vector loads return in order, so the first
 	// consumers below wait only for what was issued first).
-	// (1) lane c of every wave fetches the cold part of column c (slots 8 .. 25 and Cp, five 16-byte loads) to prepare
-	//     A = Cp + (deltas of the set grid / wave slots) of that column
-	uint4 cold[5];
+	// (1) lane c of every wave fetches A of column c = Cp + (deltas of the set grid slots: table G of this workgroup) + (deltas of
+	//     the set wave slots: table W of this wave) -- slot_tables built both at create time; the cold part of SlotRow (80 bytes per
+	//     lane, an 18-slot loop) is no longer touched by a run
+	uint32_t a_g, a_w;
 	{
 		const uint32_t cl = lane < ncols ? lane : 0u;
-		const uint4* __restrict__ cq = reinterpret_cast<const uint4*>(rows + cl) + 10;   // dwords 40 .. 59: dslot[8 .. 25], Cp, pad
-#pragma unroll
-		for (int q = 0; q < 5; ++q) cold[q] = cq[q];
+		a_g = P.slot_tab[run.tab_g + w * ncols + cl];
+		a_w = P.slot_tab[run.tab_w + wave * ncols + cl];
 	}
+	//     ... and the lane part of S(column, lane), table SL: the same for every workgroup, 16 bytes per thread
+	const uint4* __restrict__ sl_src = reinterpret_cast<const uint4*>(P.slot_tab + run.tab_sl);
+	uint4 sl_piece = make_uint4(0, 0, 0, 0);
+	if (tid < ncols * 16u) sl_piece = sl_src[tid];
 	// (2) one 16-byte piece of the hot lines per thread (they go to LDS below)
 	uint4 hot_piece = make_uint4(0, 0, 0, 0);
 	if (tid < ncols * 4u) hot_piece = reinterpret_cast<const uint4*>(rows + (tid >> 2))[tid & 3u];
@@ -135,47 +139,21 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 	if (tid < ncols * 4u) reinterpret_cast<uint4*>(hot_lds)[tid] = hot_piece;
 	for (uint32_t i = tid + run.threads; i < ncols * 4u; i += run.threads)   // narrow workgroups, long runs
 		reinterpret_cast<uint4*>(hot_lds)[i] = reinterpret_cast<const uint4*>(rows + (i >> 2))[i & 3u];
-	uint32_t Avec;
-	{
-		const uint32_t Pu = (w << L) | (wave << (6 + LR));   // the wave-uniform part of the physical index
-		const uint32_t dv[20] = {cold[0].x, cold[0].y, cold[0].z, cold[0].w, cold[1].x, cold[1].y, cold[1].z, cold[1].w, cold[2].x, cold[2].y,
-		                         cold[2].z, cold[2].w, cold[3].x, cold[3].y, cold[3].z, cold[3].w, cold[4].x, cold[4].y, cold[4].z, cold[4].w};
-		uint32_t acc = dv[18];   // Cp
-#pragma unroll
-		for (int s2 = LR + 6; s2 < SLOT_MAXSLOTS; ++s2) acc += dv[s2 - 8] & (0u - ((Pu >> s2) & 1u));   // slots >= L + g: bit and delta are 0
-		Avec = acc;
-	}
+	const uint32_t Avec = a_g + a_w;
 	// ... and so does A of every column, one 64-entry row per wave: a VALU -> SGPR transfer (v_readlane, v_readfirstlane)
 	// costs ~35 cycles of issue, so nothing on the column chain goes that way.  What steers control flow (does a read end in
 	// this column, in which slot) comes from the run's control bytes, loaded once into SGPRs.
 	uint32_t* a_lds = hot_lds + (SLOT_MAXCOLS + 8) * 16 + wave * 64u;
 	a_lds[lane] = Avec;
 	uint32_t* sl_lds = hot_lds + (SLOT_MAXCOLS + 8) * 16 + 8 * 64;   // [column][lane]: lane part of S, the same for every wave
+	if (tid < ncols * 16u) reinterpret_cast<uint4*>(sl_lds)[tid] = sl_piece;
+	for (uint32_t i = tid + run.threads; i < ncols * 16u; i += run.threads) reinterpret_cast<uint4*>(sl_lds)[i] = sl_src[i];   // narrow workgroups, long runs
 	slot_u32x16 ctrlq = *(slot_cptr16)(unsigned long long)(P.slot_ctrl + run.ctrl_off);
 	uint8_t* __restrict__ rec = P.bt + (((unsigned long long)run.rec_hi << 32) | run.rec_lo) + (size_t)w * run.n_ends * run.threads + tid;
 	const uint32_t threads = run.threads;
 	const uint32_t xwords = threads * R;   // one exchange buffer
 	uint32_t xsel = 0;
 	const unsigned long long t_issued = (DBG && P.dbg) ? __builtin_readcyclecounter() : 0ull;
-	__syncthreads();
-	// The lane part of S(column, lane) = sum of the deltas of the lane slots whose bit is set in `lane` does not depend on the
-	// wave: the waves share the columns (wave v: columns v, v + #waves, ...) and leave the sums in LDS -- one 4-byte read per
-	// column and thread on the chain instead of six multiply-adds fed by six broadcast words.
-	{
-		int32_t lanebit[SLOT_LANE];
-#pragma unroll
-		for (int j = 0; j < SLOT_LANE; ++j) lanebit[j] = (int32_t)((lane >> j) & 1u);
-		const uint32_t nw = threads >> 6;
-		for (uint32_t c = wave; c < ncols; c += nw) {
-			const uint4* hl = reinterpret_cast<const uint4*>(hot_lds + c * 16u);
-			const uint4 b = hl[1], cc = hl[2];
-			const uint32_t dl[SLOT_LANE] = {b.y, b.z, b.w, cc.x, cc.y, cc.z};
-			uint32_t acc = 0;
-#pragma unroll
-			for (int j = 0; j < SLOT_LANE; ++j) acc += (uint32_t)__mul24(lanebit[j], (int32_t)dl[j]);   // |delta| < 2^22
-			sl_lds[c * 64u + lane] = acc;
-		}
-	}
 	__syncthreads();
 	uint32_t D[R];
 #pragma unroll
@@ -372,6 +350,35 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 	if (DBG && P.dbg && w == 0 && tid == 0) {
 		unsigned long long* d = P.dbg + (size_t)run.pad * 48;
 		d[0] = t_issued - t_start; d[1] = t_loaded - t_start; d[2] = t_loop - t_loaded; d[3] = __builtin_readcyclecounter() - t_loop; d[4] = ncols; d[5] = 1;
+	}
+}
+
+// The per-run tables of the prologue (SlotRun::tab_g / tab_w / tab_sl), once per table at create time: blockIdx.y = run.
+__global__ __launch_bounds__(256) void slot_tables(DevProblem P, const SlotRun* __restrict__ runs, uint32_t* __restrict__ tab) {
+	const SlotRun& run = runs[blockIdx.y];
+	const uint32_t ncols = run.ncols, L = run.L, lr = run.lr, nwg = 1u << (run.g - run.half), nwaves = run.threads >> 6;
+	const uint32_t n_g = nwg * ncols, n_w = nwaves * ncols, n_sl = ncols * 64u;
+	const SlotRow* __restrict__ rows = P.slot_rows + run.row_off;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_g + n_w + n_sl; i += gridDim.x * blockDim.x) {
+		if (i < n_g) {
+			const uint32_t w = i / ncols, c = i % ncols;
+			const SlotRow& row = rows[c];
+			uint32_t acc = row.Cp;
+			for (uint32_t s = L; s < L + run.g; ++s) acc += (uint32_t)row.dslot[s] & (0u - ((w >> (s - L)) & 1u));
+			tab[run.tab_g + i] = acc;
+		} else if (i < n_g + n_w) {
+			const uint32_t q = i - n_g, wave = q / ncols, c = q % ncols;
+			const SlotRow& row = rows[c];
+			uint32_t acc = 0;
+			for (uint32_t s = lr + 6u; s < L; ++s) acc += (uint32_t)row.dslot[s] & (0u - ((wave >> (s - lr - 6u)) & 1u));
+			tab[run.tab_w + q] = acc;
+		} else {
+			const uint32_t q = i - n_g - n_w, c = q >> 6, lane = q & 63u;
+			const SlotRow& row = rows[c];
+			uint32_t acc = 0;
+			for (uint32_t j = 0; j < (uint32_t)SLOT_LANE; ++j) acc += (uint32_t)row.dlane[j] & (0u - ((lane >> j) & 1u));
+			tab[run.tab_sl + q] = acc;
+		}
 	}
 }
 

@@ -86,12 +86,16 @@ struct SlotRun {
 	uint32_t in_pos[8];              // entry index bit of every occupied slot, one byte each (when !in_identity)
 	uint32_t out_pos[8];             // exit index bit of every occupied slot, one byte each
 	// (words, not byte arrays: the kernel reads them with static indices out of SGPRs; see slot_pos / slot_set_pos)
+	// Single-individual runs: what the prologue used to compute per launch from the cold part of SlotRow is a table built once
+	// at create time (slot_tables): G [launched workgroups][ncols] = Cp + deltas of the set grid slots, W [waves][ncols] = deltas
+	// of the set wave slots, SL [ncols][64] = deltas of the set lane slots.  Word offsets into DevProblem::slot_tab.
+	uint32_t tab_g, tab_w, tab_sl, tab_pad;
 };
 inline uint32_t slot_pos(const uint32_t (&w)[8], uint32_t s) { return (w[s >> 2] >> ((s & 3u) * 8u)) & 255u; }
 inline void slot_set_pos(uint32_t (&w)[8], uint32_t s, uint32_t pos) {
 	w[s >> 2] = (w[s >> 2] & ~(255u << ((s & 3u) * 8u))) | (pos << ((s & 3u) * 8u));
 }
-static_assert(sizeof(SlotRun) == 160, "SlotRun layout");
+static_assert(sizeof(SlotRun) == 176, "SlotRun layout");
 
 // ---- pedigree slot runs (T = 4 or 16 transmission values; kernels_pedslots.h) -------------------------------------
 // Same slots, same run / exchange machinery; a cell holds T values, ONE (cell, transmission value) per lane: the
