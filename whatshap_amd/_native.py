@@ -451,9 +451,11 @@ def plan_summary(problem: ProblemArrays, path: str = "auto") -> dict:
 
 def emulate_slot_plan(problem: ProblemArrays, n_columns: int, slot_l: int = 11, symmetry: int = 1, slot_r: int = 2):
     """Host-only planner diagnostic (whamd_debug_emulate_slot_plan): (index path, optimal score, columns inside runs).
-    slot_r: reg slots per thread (2 or 3; passed as slot_l + 100 for 3)."""
+    slot_r: reg slots per thread (1, 2 or 3; passed as slot_l + 100 for 3, + 200 for 1)."""
     if slot_r >= 3:
         slot_l += 100
+    elif slot_r <= 1:
+        slot_l += 200
     idx = np.zeros(max(n_columns, 1), dtype=np.uint32)
     score = C.c_uint32()
     ncols = C.c_uint64()

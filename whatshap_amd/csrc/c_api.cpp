@@ -359,7 +359,7 @@ whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uin
 				ok = ok && (ex.nf == 2 || ex.nf == 4) && ex.fwn == run.ncols * p.T * ex.nf && ex.fwn <= (uint32_t)PSLOT_FORMWORDS && ex.rec_words == ((run.ncols + 3) / 4) * run.threads;
 				ok = ok && run.lw <= (uint32_t)SLOT_LWMAX && run.threads == (64u << run.lw);
 			} else
-			ok = ok && run.lr >= 2 && run.lr <= (uint32_t)SLOT_LR && run.L == run.lr + (uint32_t)SLOT_LANE + run.lw && run.lw <= (uint32_t)SLOT_LWMAX && run.threads == (64u << run.lw);
+			ok = ok && run.lr >= 1 && run.lr <= (uint32_t)SLOT_LR && run.L == run.lr + (uint32_t)SLOT_LANE + run.lw && run.lw <= (uint32_t)SLOT_LWMAX && run.threads == (64u << run.lw);
 			ok = ok && run.L + run.g <= (uint32_t)SLOT_MAXSLOTS && run.n_ends <= (uint32_t)SLOT_MAXENDS_RUN && (!run.half || run.g >= 1);
 			uint32_t ends = 0;
 			for (uint32_t i = 0; i < run.ncols && ok; ++i) {
@@ -476,8 +476,8 @@ whamd_status_t whamd_debug_emulate_slot_plan(const whamd_readset_view* readset, 
                                             const whamd_pedigree_view* pedigree, int distrust_genotypes, const uint32_t* positions,
                                             size_t n_positions, int slot_l, int symmetry, uint32_t* index_out, uint32_t* score_out,
                                             uint64_t* n_run_columns_out) {
-	const int lr = slot_l >= 100 ? 3 : 2;   // slot_l + 100: 8 cells per thread
-	if (slot_l >= 100) slot_l -= 100;
+	const int lr = slot_l >= 200 ? 1 : slot_l >= 100 ? 3 : 2;   // slot_l + 100: 8 cells per thread, + 200: 2 cells per thread
+	if (slot_l >= 100) slot_l -= slot_l >= 200 ? 200 : 100;
 	Problem p;
 	std::string msg;
 	whamd_status_t st = build_problem(readset, recombcost, n_recombcost, pedigree, distrust_genotypes != 0, positions,

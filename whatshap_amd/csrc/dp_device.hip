@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -71,6 +72,78 @@ bool select_kernels(uint32_t T, uint32_t n_ind, FusedFn& ff, KeysFn& kf) {
 	return false;
 }
 
+// ---------------------------------------------------------------------------------------------- pinned staging of the create path
+// hipMemcpyAsync from pageable memory goes through the runtime's own small staging buffers: ~5 GB/s measured for the ~100 MB of
+// descriptors of a configs[2] table, 20 ms of a 58 ms create.  The create path copies its large arrays into ONE process-wide pinned
+// area with a few host threads and sends them from there (the copies overlap the host work that follows).  One upload() at a
+// time owns the area; it grows to what the largest table so far needed (at most STAGE_MAX; larger uploads go in rounds).
+struct UploadStage {
+	std::mutex mu;
+	char* base = nullptr;
+	size_t cap = 0, want = 0;
+	bool broken = false;   // hipHostMalloc failed once: pageable copies from then on
+};
+UploadStage g_stage;
+constexpr size_t STAGE_MAX = (size_t)1 << 30, STAGE_MIN_COPY = (size_t)256 << 10, STAGE_GRAIN = (size_t)16 << 20;
+
+struct StageSession {
+	std::unique_lock<std::mutex> lock;
+	hipStream_t stream;
+	size_t used = 0, total = 0;
+	bool pending = false;
+	const bool enabled;
+	explicit StageSession(hipStream_t s) : lock(g_stage.mu), stream(s), enabled(getenv("WHAMD_NO_PINNED_STAGE") == nullptr) {}
+	~StageSession() {
+		if (pending) (void)hipStreamSynchronize(stream);
+		g_stage.want = std::max(g_stage.want, std::min(total, STAGE_MAX));
+	}
+	bool ensure(size_t bytes) {   // area empty (nothing pending): make it hold `bytes`, or everything the largest table so far staged
+		const size_t need = (std::max(std::min(bytes, STAGE_MAX), g_stage.want) + STAGE_GRAIN - 1) / STAGE_GRAIN * STAGE_GRAIN;
+		if (g_stage.cap >= need) return true;
+		if (g_stage.base) (void)hipHostFree(g_stage.base);
+		g_stage.base = nullptr;
+		g_stage.cap = 0;
+		void* ptr = nullptr;
+		if (hipHostMalloc(&ptr, need, hipHostMallocPortable) != hipSuccess) {
+			(void)hipGetLastError();
+			g_stage.broken = true;
+			return false;
+		}
+		g_stage.base = (char*)ptr;
+		g_stage.cap = need;
+		return true;
+	}
+	hipError_t copy(void* dst, const void* src, size_t bytes) {
+		if (!enabled || g_stage.broken || bytes < STAGE_MIN_COPY) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream);
+		total += (bytes + 255) & ~(size_t)255;
+		size_t done = 0;
+		while (done < bytes) {
+			if (!pending && used == 0 && !ensure(bytes - done)) return hipMemcpyAsync((char*)dst + done, (const char*)src + done, bytes - done, hipMemcpyHostToDevice, stream);
+			const size_t chunk = std::min(bytes - done, g_stage.cap - used);
+			if (chunk == 0) {   // area full: wait for what is in flight, start over
+				hipError_t e = hipStreamSynchronize(stream);
+				if (e != hipSuccess) return e;
+				pending = false;
+				used = 0;
+				continue;
+			}
+			char* at = g_stage.base + used;
+			const char* from = (const char*)src + done;
+			parallel_ranges(chunk, host_threads(chunk, (size_t)2 << 20), [&](uint64_t b0, uint64_t b1, uint32_t) { std::memcpy(at + b0, from + b0, b1 - b0); });
+			hipError_t e = hipMemcpyAsync((char*)dst + done, at, chunk, hipMemcpyHostToDevice, stream);
+			if (e != hipSuccess) return e;
+			pending = true;
+			used += (chunk + 255) & ~(size_t)255;
+			done += chunk;
+		}
+		return hipSuccess;
+	}
+	void finish() {   // after the caller synchronised the stream
+		pending = false;
+		used = 0;
+	}
+};
+
 }  // namespace
 
 // ================================================================================================ DeviceTable
@@ -88,7 +161,7 @@ struct DeviceTable::Impl {
 	BtUnit* d_units = nullptr;
 	std::vector<BtUnit> units;
 	size_t bt_lds = 0;
-	std::vector<DevColumn> cols;
+	RawVec<DevColumn> cols;
 	ResidentPlan plan;
 	DevProblem dp{};
 	FusedFn fused = nullptr;
@@ -269,7 +342,7 @@ void DeviceTable::set_lanes(int n) { impl_->max_lanes = n < 1 ? 1 : (n > 64 ? 64
 
 void DeviceTable::set_fold(bool v) { impl_->fold = v; }
 void DeviceTable::set_slot_l(int l) { impl_->slot_l = std::max(2, std::min(l, 12)); impl_->slot_l_set = true; }
-void DeviceTable::set_slot_lr(int lr) { impl_->slot_lr = lr >= 3 ? 3 : 2; }
+void DeviceTable::set_slot_lr(int lr) { impl_->slot_lr = lr >= 3 ? 3 : (lr <= 1 ? 1 : 2); }
 
 void DeviceTable::set_arena_limit(uint64_t bytes) { impl_->arena_limit = bytes; }
 void DeviceTable::set_symmetry(int level) { impl_->symmetry = level < 0 ? 0 : (level > 2 ? 2 : level); }
@@ -303,6 +376,9 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		msg = "no device kernel for T=" + std::to_string(p.T) + ", individuals=" + std::to_string(p.n_ind);
 		return WHAMD_ERR_UNSUPPORTED;
 	}
+	// ... and a column with more allele-assignment terms than the templated kernels stage in LDS (genotypes not trusted, seven and more
+	// individuals): the generic kernel reads them from global memory
+	for (uint32_t c = 0; c < p.n_cols && !m.wide; ++c) m.wide = p.term_end(c, p.T - 1) - p.term_begin(c, 0) > (uint64_t)COL_MAXTERMS;
 	const bool force_keys = m.path == "column_keys" || m.wide;
 	const bool want_resident = (m.path == "auto" || m.path == "resident") && !m.wide;
 	const auto tu0 = std::chrono::steady_clock::now();
@@ -350,18 +426,20 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	}
 	const uint32_t tbits = 2 * p.n_triples;
 	const uint32_t ni = std::max<uint32_t>(p.n_ind, 1);
+	const bool timing = getenv("WHAMD_DEBUG_TIMING") != nullptr;
+	auto lap_t = std::chrono::steady_clock::now();
+	auto ulap = [&](const char* what) {
+		if (!timing) return;
+		const auto now = std::chrono::steady_clock::now();
+		fprintf(stderr, "[whamd timing]   upload: %s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - lap_t).count());
+		lap_t = now;
+	};
 	// ---- descriptors
-	m.cols.assign(n, DevColumn{});
+	m.cols.resize(n);
 	std::vector<uint32_t> segs;
-	std::vector<uint32_t> term_ptr32((size_t)n * (p.T + 1));
+	RawVec<uint32_t> term_ptr32((size_t)n * (p.T + 1));
 	std::vector<DevTerm> terms(p.terms.size());
 	for (size_t i = 0; i < p.terms.size(); ++i) terms[i] = DevTerm{p.terms[i].c, p.terms[i].plus, p.terms[i].minus};
-	for (uint32_t c = 0; c < n; ++c) {
-		if (p.term_end(c, p.T - 1) - p.term_begin(c, 0) > (uint64_t)COL_MAXTERMS) {
-			msg = "more than " + std::to_string(COL_MAXTERMS) + " allele-assignment terms in one column: pedigree too complex for the device path";
-			return WHAMD_ERR_UNSUPPORTED;
-		}
-	}
 	if (p.terms.size() >= 0xFFFFFFFFull || (uint64_t)p.col_ptr[n] * ni >= 0xFFFFFFFFull) {
 		msg = "problem too large for 32-bit device offsets";
 		return WHAMD_ERR_UNSUPPORTED;
@@ -395,23 +473,34 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		      " MiB of " + std::to_string(free_b >> 20) + " MiB free HBM)";
 		return WHAMD_ERR_UNSUPPORTED;
 	};
+	// what a column's descriptor holds by itself: a few host threads; the offsets that run through the table (segment lists,
+	// backtrace records, windows) follow in column order
+	parallel_ranges(n, host_threads(n, 16384), [&](uint64_t c0, uint64_t c1, uint32_t) {
+		for (uint32_t c = (uint32_t)c0; c < (uint32_t)c1; ++c) {
+			DevColumn d{};
+			d.k = p.k[c];
+			d.b = p.b[c];
+			d.f = p.f[c];
+			d.recomb = p.recomb[c];
+			d.delta_off = (uint32_t)(p.col_ptr[c] * ni);
+			d.term_off = (uint32_t)((size_t)c * (p.T + 1));
+			for (uint32_t t = 0; t <= p.T; ++t) term_ptr32[(size_t)c * (p.T + 1) + t] = (uint32_t)p.term_ptr[(size_t)c * p.T + t];
+			d.ebits = d.k - d.f;
+			d.is_last = (c + 1 == n);
+			d.eloop = std::min<uint32_t>(d.ebits, QMAX);
+			d.nplanes = d.ebits + tbits;
+			m.cols[c] = d;
+		}
+	});
 	for (uint32_t c = 0; c < n; ++c) {
 		DevColumn& d = m.cols[c];
-		d.k = p.k[c];
-		d.b = p.b[c];
-		d.f = p.f[c];
-		d.recomb = p.recomb[c];
-		d.delta_off = (uint32_t)(p.col_ptr[c] * ni);
-		d.term_off = (uint32_t)((size_t)c * (p.T + 1));
-		for (uint32_t t = 0; t <= p.T; ++t) term_ptr32[(size_t)c * (p.T + 1) + t] = (uint32_t)p.term_ptr[(size_t)c * p.T + t];
+		const bool in_slot_run = m.use_slots && m.splan.col_to_row[c] >= 0;   // (the run kernels read none of the per-column arrays)
 		d.seg_off = (uint32_t)segs.size();
 		const uint32_t kmask = d.k >= 32 ? 0xFFFFFFFFu : ((1u << d.k) - 1u);
-		append_segments(p.fwd_mask[c], segs, d.nseg_fwd);
-		append_segments(kmask & ~p.fwd_mask[c], segs, d.nseg_end);
-		d.ebits = d.k - d.f;
-		d.is_last = (c + 1 == n);
-		d.eloop = std::min<uint32_t>(d.ebits, QMAX);
-		d.nplanes = d.ebits + tbits;
+		if (!in_slot_run) {
+			append_segments(p.fwd_mask[c], segs, d.nseg_fwd);
+			append_segments(kmask & ~p.fwd_mask[c], segs, d.nseg_end);
+		}
 		d.bt_off = bt;
 		if (m.use_slots && m.splan.col_to_row[c] >= 0) {
 			d.mode = 3;
@@ -452,6 +541,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		bt = (bt + 15ull) & ~15ull;
 		max_f = std::max(max_f, d.f);
 	}
+	ulap("column descriptors (host)");
 	bt = bt_max = std::max(bt_max, bt);
 	m.bt_bytes = bt;
 	m.windowed = !window_first_col.empty();
@@ -462,6 +552,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		return WHAMD_ERR_UNSUPPORTED;
 	}
 	// ---- allocate + upload
+	StageSession stage(m.stream);
 	auto alloc = [&](void** dptr, size_t bytes) -> hipError_t {
 		hipError_t e = hipMalloc(dptr, std::max<size_t>(bytes, 16));
 		if (e == hipSuccess) m.allocations.push_back(*dptr);
@@ -470,7 +561,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	auto up = [&](void** dptr, const void* src, size_t bytes) -> hipError_t {
 		hipError_t e = alloc(dptr, bytes);
 		if (e != hipSuccess) return e;
-		if (bytes) e = hipMemcpyAsync(*dptr, src, bytes, hipMemcpyHostToDevice, m.stream);
+		if (bytes) e = stage.copy(*dptr, src, bytes);
 		return e;
 	};
 	std::vector<int32_t> delta_fallback;
@@ -491,6 +582,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	HIP_TRY(up(&d_pterm, m.plan.ped_terms.data(), m.plan.ped_terms.size() * sizeof(PedTerm)));
 	m.dp.ped_cols = (const PedColumn*)d_pcol;
 	m.dp.ped_terms = (const PedTerm*)d_pterm;
+	ulap("column arrays: allocations + copies");
 	// slot runs: per-column descriptors and the backtrace blobs ([ncols] SlotBtCol + ending slots per run)
 	std::vector<uint32_t> slot_blob;
 	std::vector<uint32_t> slot_blob_off(m.splan.runs.size(), 0), slot_blob_words(m.splan.runs.size(), 0);
@@ -505,9 +597,11 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		if (run.n_ends) std::memcpy(slot_blob.data() + at, m.splan.end_slots.data() + m.splan.end_off[ri], run.n_ends);
 		slot_blob_words[ri] = (uint32_t)(slot_blob.size() - slot_blob_off[ri]);
 	}
+	ulap("slot backtrace blobs (host)");
 	void *d_srows = nullptr, *d_sblob = nullptr;
 	if (!m.splan.rows.empty()) m.splan.rows.resize(m.splan.rows.size() + SLOT_ROW_PAD);   // the kernel's scalar-cache warm-up touches a fixed number of rows
 	HIP_TRY(up(&d_srows, m.splan.rows.data(), m.splan.rows.size() * sizeof(SlotRow)));
+	ulap("slot rows: allocation + copy");
 	HIP_TRY(up(&d_sblob, slot_blob.data(), slot_blob.size() * sizeof(uint32_t)));
 	void* d_sctrl = nullptr;
 	HIP_TRY(up(&d_sctrl, m.splan.ctrl.data(), m.splan.ctrl.size() * sizeof(uint32_t)));
@@ -527,7 +621,9 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		}
 		if (slot_tab_words >= 0xFFFFFFFFull) { msg = "slot-run tables exceed 32-bit offsets"; return WHAMD_ERR_UNSUPPORTED; }
 		HIP_TRY(up(&d_sruns, m.splan.runs.data(), m.splan.runs.size() * sizeof(SlotRun)));
+		ulap("slot blobs, control words, runs: allocations + copies");
 		HIP_TRY(alloc(&d_stab, slot_tab_words * 4));
+		ulap("slot tables: allocation");
 	}
 	m.dp.slot_tab = (const uint32_t*)d_stab;
 	void *d_prows = nullptr, *d_pruns = nullptr, *d_pextra = nullptr, *d_ptab = nullptr;
@@ -541,6 +637,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	m.dp.pslot_tab = (const uint32_t*)d_ptab;
 	m.dp.slot_rows = (const SlotRow*)d_srows;
 	m.dp.slot_blob = (const uint32_t*)d_sblob;
+	ulap("slot rows / blobs / control words: allocations + copies");
 	// ---- jobs (see Impl::Job): connected components made of runs only get their own job
 	m.release_lanes();
 	{
@@ -755,6 +852,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	HIP_TRY(alloc(&d_rtab, m.plan.columns.size() * (ped_plan ? PED_TABLE : RES_TABLE) * sizeof(int32_t)));
 	m.dp.res_tables = ped_plan ? nullptr : (int32_t*)d_rtab;
 	m.dp.ped_tables = ped_plan ? (int32_t*)d_rtab : nullptr;
+	ulap("jobs, backtrace units, schedule");
 	const auto tu2 = std::chrono::steady_clock::now();
 	HIP_TRY(alloc(&d_bt, bt));
 	const auto tu3 = std::chrono::steady_clock::now();
@@ -907,6 +1005,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		HIP_TRY(hipGetLastError());
 	}
 	HIP_TRY(hipStreamSynchronize(m.stream));
+	stage.finish();
 	m.dp.delta = (const int32_t*)d_delta;
 	m.dp.term_ptr = (const uint32_t*)d_term_ptr;
 	m.dp.terms = (const DevTerm*)d_terms;
@@ -1053,6 +1152,9 @@ void DeviceTable::Impl::launch_slot_run(const SlotBatchEntry& e, uint64_t& launc
 	if (run.lr == 3) {
 		if (dbg) { if (spec) WHAMD_SLOT_LAUNCH(3, true, true); else WHAMD_SLOT_LAUNCH(3, true, false); }
 		else { if (spec) WHAMD_SLOT_LAUNCH(3, false, true); else WHAMD_SLOT_LAUNCH(3, false, false); }
+	} else if (run.lr == 1) {
+		if (dbg) { if (spec) WHAMD_SLOT_LAUNCH(1, true, true); else WHAMD_SLOT_LAUNCH(1, true, false); }
+		else { if (spec) WHAMD_SLOT_LAUNCH(1, false, true); else WHAMD_SLOT_LAUNCH(1, false, false); }
 	} else {
 		if (dbg) { if (spec) WHAMD_SLOT_LAUNCH(2, true, true); else WHAMD_SLOT_LAUNCH(2, true, false); }
 		else { if (spec) WHAMD_SLOT_LAUNCH(2, false, true); else WHAMD_SLOT_LAUNCH(2, false, false); }
@@ -1120,7 +1222,8 @@ whamd_status_t DeviceTable::enqueue_some_unguarded(const Problem& p, Solution& s
 		if (m.use_slots) {
 			if (ss.entry_count == 1) m.launch_slot_run(m.slot_entries[ss.entry_off], launches);
 			else if (ss.entry_count > 1) {
-				if (m.slot_lr == 3) hipLaunchKernelGGL(slot_batch<3>, dim3(ss.grid_x, ss.entry_count), dim3(ss.threads), ss.lds, m.stream, m.dp, m.d_slot_entries + ss.entry_off);
+				if (m.slot_lr == 1) hipLaunchKernelGGL(slot_batch<1>, dim3(ss.grid_x, ss.entry_count), dim3(ss.threads), ss.lds, m.stream, m.dp, m.d_slot_entries + ss.entry_off);
+				else if (m.slot_lr == 3) hipLaunchKernelGGL(slot_batch<3>, dim3(ss.grid_x, ss.entry_count), dim3(ss.threads), ss.lds, m.stream, m.dp, m.d_slot_entries + ss.entry_off);
 				else hipLaunchKernelGGL(slot_batch<2>, dim3(ss.grid_x, ss.entry_count), dim3(ss.threads), ss.lds, m.stream, m.dp, m.d_slot_entries + ss.entry_off);
 				launches += 1;
 			}

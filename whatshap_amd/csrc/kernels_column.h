@@ -242,11 +242,16 @@ __global__ __launch_bounds__(256) void column_step_wide(DevProblem P, uint32_t c
 			S.lut[s][chunk][v] = sum;
 		}
 		const uint32_t* __restrict__ tp = P.term_ptr + col.term_off;
-		const uint32_t t0 = tp[0], nterms = min(tp[T] - t0, (uint32_t)COL_MAXTERMS);
-		for (uint32_t i = threadIdx.x; i < nterms; i += blockDim.x) S.terms[i] = P.terms[t0 + i];
-		for (uint32_t i = threadIdx.x; i <= T; i += blockDim.x) S.tptr[i] = min(tp[i] - t0, (uint32_t)COL_MAXTERMS);
+		// (a column with more terms than the stage holds -- nine individuals with untrusted genotypes: 3^6 per transmission value --
+		// reads them from global memory)
+		const uint32_t t0 = tp[0], nterms = tp[T] - t0;
+		if (nterms <= (uint32_t)COL_MAXTERMS)
+			for (uint32_t i = threadIdx.x; i < nterms; i += blockDim.x) S.terms[i] = P.terms[t0 + i];
+		for (uint32_t i = threadIdx.x; i <= T; i += blockDim.x) S.tptr[i] = tp[i] - t0;
 		__syncthreads();
 	}
+	const uint32_t term_count = S.tptr[T];
+	const DevTerm* __restrict__ col_terms = term_count <= (uint32_t)COL_MAXTERMS ? S.terms : P.terms + P.term_ptr[col.term_off];
 	const uint32_t nchunks = (k + 4) / 5;
 	const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
 	if (gid >= total_threads) return;
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(256) void column_step_wide(DevProblem P, uint32_t c
 		}
 		uint32_t cost = 0xFFFFFFFFu;
 		for (uint32_t q = S.tptr[i]; q < S.tptr[i + 1]; ++q) {
-			const DevTerm tm = S.terms[q];
+			const DevTerm tm = col_terms[q];
 			uint32_t v = tm.c;
 			for (uint32_t s = 0; s < n_ind; ++s) {
 				v += ((tm.plus >> s) & 1u) ? (uint32_t)L[s] : 0u;

@@ -108,6 +108,10 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 				const uint4 t = *reinterpret_cast<const uint4*>(prev + base + 4 * q);
 				Draw[4 * q] = t.x; Draw[4 * q + 1] = t.y; Draw[4 * q + 2] = t.z; Draw[4 * q + 3] = t.w;
 			}
+			if (R == 2) {   // two cells per thread: one 8-byte load
+				const uint2 t = *reinterpret_cast<const uint2*>(prev + base);
+				Draw[0] = t.x; Draw[R - 1] = t.y;
+			}
 		} else {
 			// any layout (the writer's order inside this workgroup's block; logical order after a per-column step): index bit by
 			// bit, tables in SGPRs, static slot indices
@@ -182,7 +186,7 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 	// cell arithmetic as they are; only what steers control flow (n_end, the ending read's slot) becomes scalar.
 	auto column = [&](const HotLine& h, const uint32_t ci, const uint32_t ctrl) {
 		const uint32_t K = h.a.x, Cc = h.a.y;
-		const uint32_t dr[SLOT_LR] = {h.a.z, h.a.w, h.d2};
+		const uint32_t dr[SLOT_LR + 1] = {h.a.z, h.a.w, h.d2, 0u};
 		const uint32_t A = h.A;
 		uint32_t Ar[R];
 		Ar[0] = A;
@@ -199,7 +203,7 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 			uint32_t takes;
 			if (slot < (uint32_t)LR) {
 				if (slot == 0) takes = slot_end_reg<LR, 0>(D, qthr, qmask);
-				else if (slot == 1) takes = slot_end_reg<LR, 1>(D, qthr, qmask);
+				else if (LR > 1 && slot == 1) takes = slot_end_reg<LR, (LR > 1 ? 1 : 0)>(D, qthr, qmask);
 				else if (LR > 2 && slot == 2) takes = slot_end_reg<LR, (LR > 2 ? 2 : 0)>(D, qthr, qmask);
 				else takes = slot_end_reg<LR, (LR > 3 ? 3 : 0)>(D, qthr, qmask);
 			} else if (slot < (uint32_t)(LR + SLOT_LANE)) {
@@ -215,6 +219,7 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 				uint4* mine = reinterpret_cast<uint4*>(xb + tid * R);
 #pragma unroll
 				for (int q4 = 0; q4 < R / 4; ++q4) mine[q4] = make_uint4(D[4 * q4], D[4 * q4 + 1], D[4 * q4 + 2], D[4 * q4 + 3]);
+				if (R == 2) *reinterpret_cast<uint2*>(mine) = make_uint2(D[0], D[R - 1]);
 				__syncthreads();
 				const uint32_t ptid = tid ^ (64u << (slot - LR - SLOT_LANE));
 				const uint4* theirs = reinterpret_cast<const uint4*>(xb + ptid * R);
@@ -223,6 +228,10 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 				for (int q4 = 0; q4 < R / 4; ++q4) {
 					const uint4 t = theirs[q4];
 					other[4 * q4] = t.x; other[4 * q4 + 1] = t.y; other[4 * q4 + 2] = t.z; other[4 * q4 + 3] = t.w;
+				}
+				if (R == 2) {
+					const uint2 t = *reinterpret_cast<const uint2*>(theirs);
+					other[0] = t.x; other[R - 1] = t.y;
 				}
 				takes = slot_end_partner<LR>(D, other, qthr, qmask);
 				xsel ^= 1u;
@@ -288,7 +297,14 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 		for (int s = LR; s < SLOT_MAXSLOTS; ++s) base |= ((Pthr & occ) >> s & 1u) << pos[s];
 		const uint32_t mirror_x = run.mirror_out ? run.out_fullmask : 0u;
 		unsigned long long best_key = ~0ull;   // (value, exit index) of the smallest cell this thread stores (run.spec_id)
-		if ((occ & 3u) == 3u && pos[0] == 0u && pos[1] == 1u) {
+		if (R == 2 && (occ & 1u) && pos[0] == 0u) {
+			// two cells per thread, the read of the reg slot is the lowest bit of the exit index: one 8-byte store
+			if (thread_writes && !(DBG && (P.dbg_flags & 1u))) {
+				*reinterpret_cast<uint2*>(cur + base) = make_uint2(D[0], D[R - 1]);
+				if (SPEC) best_key = min(min(best_key, ((unsigned long long)D[0] << 32) | base), ((unsigned long long)D[R - 1] << 32) | (base + 1u));
+				if (run.mirror_out) *reinterpret_cast<uint2*>(cur + ((base ^ mirror_x) & ~1u)) = make_uint2(D[R - 1], D[0]);
+			}
+		} else if (R >= 4 && (occ & 3u) == 3u && pos[0] == 0u && pos[1] == 1u) {
 			// the reads of reg slots 0 and 1 are the two lowest bits of the exit index (the planner arranges that for reads
 			// that stay local in the next run): 4 cells = one 16-byte store
 #pragma unroll

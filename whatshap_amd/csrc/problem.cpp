@@ -3,7 +3,9 @@
 #include "problem.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -90,22 +92,44 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 		return WHAMD_ERR_INVALID;
 	}
 	// ---- copy the views
+	const bool timing = getenv("WHAMD_DEBUG_TIMING") != nullptr;
+	auto lap_t = std::chrono::steady_clock::now();
+	auto lap = [&](const char* what) {
+		if (!timing) return;
+		const auto now = std::chrono::steady_clock::now();
+		fprintf(stderr, "[whamd timing]   flatten: %s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - lap_t).count());
+		lap_t = now;
+	};
 	p.n_reads = rs->n_reads;
 	const uint64_t nnz = rs->n_reads ? rs->read_ptr[rs->n_reads] : 0;
 	p.read_ptr.assign(rs->n_reads + 1, 0);
 	if (rs->n_reads) std::copy(rs->read_ptr, rs->read_ptr + rs->n_reads + 1, p.read_ptr.begin());
-	p.var_position.assign(rs->var_position, rs->var_position + nnz);
-	p.var_allele.assign(rs->var_allele, rs->var_allele + nnz);
-	p.var_quality.assign(rs->var_quality, rs->var_quality + nnz);
-	for (uint64_t i = 0; i < nnz; ++i) {
+	p.var_position.resize(nnz);
+	p.var_allele.resize(nnz);
+	p.var_quality.resize(nnz);
+	{
 		// Entry::BLANK (2) inside a read is accepted and skipped by the reference (pedigreecolumncostcomputer.cpp:69-70,
 		// 93-94), exactly like the BLANK entries ColumnIterator inserts; only EQUAL_SCORES (3) and beyond reach its
 		// assert(false) (:71-72, asserts are live in the reference's build)
-		if (p.var_allele[i] > WHAMD_ALLELE_BLANK) {
-			msg = "read allele must be 0 (REF), 1 (ALT) or 2 (BLANK)";
-			return WHAMD_ERR_INVALID;
+		const uint32_t n_threads = host_threads(nnz, 1u << 18);
+		std::vector<uint8_t> bad(n_threads, 0);
+		parallel_ranges(nnz, n_threads, [&](uint64_t i0, uint64_t i1, uint32_t t) {
+			if (i1 <= i0) return;
+			std::memcpy(p.var_position.data() + i0, rs->var_position + i0, (i1 - i0) * sizeof(int32_t));
+			std::memcpy(p.var_allele.data() + i0, rs->var_allele + i0, (i1 - i0) * sizeof(uint8_t));
+			std::memcpy(p.var_quality.data() + i0, rs->var_quality + i0, (i1 - i0) * sizeof(uint32_t));
+			uint8_t worst = 0;
+			for (uint64_t i = i0; i < i1; ++i) worst = std::max(worst, rs->var_allele[i]);
+			bad[t] = worst > WHAMD_ALLELE_BLANK;
+		});
+		for (uint8_t v : bad) {
+			if (v) {
+				msg = "read allele must be 0 (REF), 1 (ALT) or 2 (BLANK)";
+				return WHAMD_ERR_INVALID;
+			}
 		}
 	}
+	lap("copies of the read arrays");
 	p.n_ind = ped->n_individuals;
 	p.n_triples = ped->n_triples;
 	p.n_variants = ped->n_variants;
@@ -153,44 +177,71 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 	}
 	p.n_cols = (uint32_t)p.positions.size();
 	const uint32_t n = p.n_cols;
-	std::unordered_map<uint32_t, uint32_t> position_map;  // later duplicates win, as position_map[pos] = i does
-	position_map.reserve(n * 2 + 1);
-	for (uint32_t i = 0; i < n; ++i) position_map[p.positions[i]] = i;
-	std::vector<uint32_t> first_col(p.n_reads), last_col(p.n_reads);
-	int pos = 0;
-	for (uint32_t r = 0; r < p.n_reads; ++r) {
-		const uint64_t lo = p.read_ptr[r], hi = p.read_ptr[r + 1];
-		if (hi <= lo) {  // Read::firstPosition (src/read.cpp:75-78)
-			msg = "No variants present";
-			return WHAMD_ERR_INVALID;
+	lap("pedigree + positions");
+	// positions -> columns: binary search in the (strictly increasing) position list; a list that is not -- rejected below, after
+	// the reads, as before -- goes through the map the reference builds (later duplicates win, as position_map[pos] = i does)
+	bool positions_increase = true;
+	for (uint32_t i = 1; i < n && positions_increase; ++i) positions_increase = p.positions[i - 1] < p.positions[i];
+	std::unordered_map<uint32_t, uint32_t> position_map;
+	if (!positions_increase) {
+		position_map.reserve(n * 2 + 1);
+		for (uint32_t i = 0; i < n; ++i) position_map[p.positions[i]] = i;
+	}
+	auto column_of = [&](uint32_t position, uint32_t& col) -> bool {
+		if (positions_increase) {
+			const auto it = std::lower_bound(p.positions.begin(), p.positions.end(), position);
+			if (it == p.positions.end() || *it != position) return false;
+			col = (uint32_t)(it - p.positions.begin());
+			return true;
 		}
-		if (p.var_position[lo] < pos) {
-			msg = "ColumnIterator: reads in ReadSet are not sorted.";
-			return WHAMD_ERR_UNSORTED;
-		}
-		for (uint64_t i = lo + 1; i < hi; ++i) {  // Read::isSorted (src/read.cpp:210-218): strictly increasing
-			if (!(p.var_position[i - 1] < p.var_position[i])) {
-				msg = "ColumnIterator: encountered read with unsorted variants.";
-				return WHAMD_ERR_UNSORTED;
+		const auto it = position_map.find(position);
+		if (it == position_map.end()) return false;
+		col = it->second;
+		return true;
+	};
+	p.read_first_col.resize(p.n_reads);
+	p.read_last_col.resize(p.n_reads);
+	std::vector<uint32_t>&first_col = p.read_first_col, &last_col = p.read_last_col;
+	{
+		// the reads are independent but for the order test against the previous read's first position; the first failing read
+		// (lowest index) decides the error, as in the sequential scan of the constructor
+		struct ReadError { uint32_t read = 0xFFFFFFFFu; whamd_status_t status = WHAMD_OK; std::string msg; };
+		const uint32_t n_threads = positions_increase ? host_threads(p.n_reads, 1u << 14) : 1u;
+		std::vector<ReadError> errors(n_threads);
+		const uint64_t* ptr = rs->read_ptr;
+		const int32_t* vp = rs->var_position;
+		parallel_ranges(p.n_reads, n_threads, [&](uint64_t r0, uint64_t r1, uint32_t t) {
+			auto fail_read = [&](uint32_t r, whamd_status_t st, std::string m) { errors[t].read = r; errors[t].status = st; errors[t].msg = std::move(m); };
+			for (uint32_t r = (uint32_t)r0; r < (uint32_t)r1; ++r) {
+				const uint64_t lo = ptr[r], hi = ptr[r + 1];
+				if (hi <= lo || hi > nnz) return fail_read(r, WHAMD_ERR_INVALID, "No variants present");  // Read::firstPosition (src/read.cpp:75-78)
+				// (an earlier read without variants fails first: this read's predecessor can be taken as valid)
+				const int pos = r == 0 ? 0 : ((ptr[r] > ptr[r - 1] && ptr[r] <= nnz) ? vp[ptr[r - 1]] : 0);
+				if (vp[lo] < pos) return fail_read(r, WHAMD_ERR_UNSORTED, "ColumnIterator: reads in ReadSet are not sorted.");
+				for (uint64_t i = lo + 1; i < hi; ++i) {  // Read::isSorted (src/read.cpp:210-218): strictly increasing
+					if (!(vp[i - 1] < vp[i])) return fail_read(r, WHAMD_ERR_UNSORTED, "ColumnIterator: encountered read with unsorted variants.");
+				}
+				uint32_t fc = 0, lc = 0;
+				if (vp[lo] < 0 || !column_of((uint32_t)vp[lo], fc) || !column_of((uint32_t)vp[hi - 1], lc) || fc > lc) {
+					// the reference asserts here (src/columniterator.cpp:36-39) and aborts the process
+					return fail_read(r, WHAMD_ERR_INVALID, "read " + std::to_string(r) + " starts or ends at a position that is not in the position list");
+				}
+				first_col[r] = fc;
+				last_col[r] = lc;
+			}
+		});
+		for (const ReadError& e : errors) {   // ranges are in read order
+			if (e.status != WHAMD_OK) {
+				msg = e.msg;
+				return e.status;
 			}
 		}
-		auto fi = position_map.find((uint32_t)p.var_position[lo]);
-		auto li = position_map.find((uint32_t)p.var_position[hi - 1]);
-		if (p.var_position[lo] < 0 || fi == position_map.end() || li == position_map.end() || fi->second > li->second) {
-			// the reference asserts here (src/columniterator.cpp:36-39) and aborts the process
-			msg = "read " + std::to_string(r) + " starts or ends at a position that is not in the position list";
-			return WHAMD_ERR_INVALID;
-		}
-		first_col[r] = fi->second;
-		last_col[r] = li->second;
-		pos = p.var_position[lo];
 	}
-	for (uint32_t i = 1; i < n; ++i) {
-		if (!(p.positions[i - 1] < p.positions[i])) {
-			msg = "positions must be strictly increasing";
-			return WHAMD_ERR_INVALID;
-		}
+	if (!positions_increase) {
+		msg = "positions must be strictly increasing";
+		return WHAMD_ERR_INVALID;
 	}
+	lap("position map + read validation");
 	// read -> individual (src/pedigreedptable.cpp:32-34)
 	p.read_source.resize(p.n_reads);
 	for (uint32_t r = 0; r < p.n_reads; ++r) {
@@ -222,94 +273,59 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 	if (!build_partitions(p, msg)) return WHAMD_ERR_INVALID;
 	if (n == 0) return WHAMD_OK;
 
-	// ---- columns (ColumnIterator::get_next, src/columniterator.cpp:91-139): read r is active in
-	// columns first_col[r]..last_col[r]; entries in read-index order; BLANK where the read has no variant.
+	// ---- columns (ColumnIterator::get_next, src/columniterator.cpp:91-139): read r is active in columns first_col[r]..last_col[r];
+	// entries in read-index order; BLANK where the read has no variant.  The reads are sorted by their first position, so the reads
+	// that start at column c are a contiguous range [start_idx[c], start_idx[c + 1]) and the coverage is a difference array.
+	std::vector<uint32_t> start_idx(n + 2, 0);
 	p.col_ptr.assign(n + 1, 0);
-	for (uint32_t r = 0; r < p.n_reads; ++r) {
-		for (uint32_t c = first_col[r]; c <= last_col[r]; ++c) p.col_ptr[c + 1]++;
-	}
-	for (uint32_t c = 0; c < n; ++c) {
-		if (p.col_ptr[c + 1] > (uint64_t)MAX_COVERAGE) {
-			msg = "coverage " + std::to_string(p.col_ptr[c + 1]) + " at column " + std::to_string(c) + " exceeds the device limit of " + std::to_string(MAX_COVERAGE);
-			return WHAMD_ERR_UNSUPPORTED;
-		}
-		p.col_ptr[c + 1] += p.col_ptr[c];
-	}
-	p.entries.resize(p.col_ptr[n]);
 	{
-		std::vector<uint64_t> fill(p.col_ptr.begin(), p.col_ptr.end() - 1);
+		std::vector<int64_t> diff(n + 1, 0);
 		for (uint32_t r = 0; r < p.n_reads; ++r) {
-			uint64_t v = p.read_ptr[r];
-			for (uint32_t c = first_col[r]; c <= last_col[r]; ++c) {
-				const int cpos = (int)p.positions[c];
-				while (p.var_position[v] < cpos) ++v;
-				ColumnEntry& e = p.entries[fill[c]++];
-				e.read_id = r;
-				e.sample = (uint8_t)p.read_source[r];
-				if (p.var_position[v] == cpos) {
-					e.allele = p.var_allele[v];
-					e.phred = p.var_quality[v];
-				} else {
-					e.allele = WHAMD_ALLELE_BLANK;
-					e.phred = 0;
-				}
+			start_idx[first_col[r] + 1]++;
+			diff[first_col[r]]++;
+			diff[last_col[r] + 1]--;
+		}
+		for (uint32_t c = 0; c <= n; ++c) start_idx[c + 1] += start_idx[c];
+		int64_t cov = 0;
+		for (uint32_t c = 0; c < n; ++c) {
+			cov += diff[c];
+			if (cov > (int64_t)MAX_COVERAGE) {
+				msg = "coverage " + std::to_string(cov) + " at column " + std::to_string(c) + " exceeds the device limit of " + std::to_string(MAX_COVERAGE);
+				return WHAMD_ERR_UNSUPPORTED;
 			}
+			p.col_ptr[c + 1] = p.col_ptr[c] + (uint64_t)cov;
 		}
 	}
-	// ---- ColumnIndexingScheme: k, backward width b, forward mask / width f
+	lap("column pointers");
+	// ---- one pass per range of columns (a few host threads): the column's entries, ColumnIndexingScheme (k, backward width b, forward
+	// mask / width f: src/columnindexingscheme.cpp:19-33 is a merge of two sorted id lists -- here the reads that continue are known
+	// from their last column), then the per-bit deltas and the cost terms.  Each range keeps its own term list (concatenated in column
+	// order afterwards; the sums are sums of integer-valued doubles, exact in any order).
+	p.entries.resize(p.col_ptr[n]);
 	p.k.resize(n);
 	p.b.resize(n);
 	p.f.resize(n);
-	p.fwd_mask.assign(n, 0);
-	for (uint32_t c = 0; c < n; ++c) {
-		const ColumnEntry* cur = p.col_begin(c);
-		const uint32_t kc = (uint32_t)(p.col_ptr[c + 1] - p.col_ptr[c]);
-		p.k[c] = (uint8_t)kc;
-		p.max_k = std::max(p.max_k, kc);
-		uint32_t bw = 0;
-		if (c > 0) {  // merge of the two sorted id lists (src/columnindexingscheme.cpp:19-33)
-			const ColumnEntry* prev = p.col_begin(c - 1);
-			const uint32_t kp = p.k[c - 1];
-			uint32_t i = 0, j = 0, mask = 0;
-			while (i < kp && j < kc) {
-				if (prev[i].read_id == cur[j].read_id) {
-					mask |= 1u << i;
-					++bw; ++i; ++j;
-				} else if (prev[i].read_id < cur[j].read_id) ++i; else ++j;
-			}
-			p.fwd_mask[c - 1] = mask;
-			p.f[c - 1] = (uint8_t)bw;
-			// shared reads are exactly the low bw bits of column c (they started earlier than any new read)
-			for (uint32_t q = 0; q < bw; ++q) {
-				if (q >= kc) { msg = "internal: shared reads are not a prefix"; return WHAMD_ERR_INVALID; }
-			}
-		}
-		p.b[c] = (uint8_t)bw;
+	p.fwd_mask.resize(n);
+	if (!columns_only) {
+		p.delta.resize((size_t)p.col_ptr[n] * std::max<uint32_t>(p.n_ind, 1));
+		p.term_ptr.assign((size_t)n * p.T + 1, 0);
+		p.terms.clear();
 	}
-	p.f[n - 1] = 0;  // last column: everything is minimised out (global optimum, src/pedigreedptable.cpp:306-315)
-	p.fwd_mask[n - 1] = 0;
-
-	if (columns_only) return WHAMD_OK;   // the genotyping path (genotype.cpp) has its own per-column model
-	// ---- per-bit deltas and cost terms.  Columns are independent: ranges of columns go to a few host threads, each with its
-	// own term list (concatenated in column order afterwards; the sums below are sums of integer-valued doubles, exact in any order)
-	p.delta.assign((size_t)p.col_ptr[n] * std::max<uint32_t>(p.n_ind, 1), 0);
-	p.term_ptr.assign((size_t)n * p.T + 1, 0);
-	p.terms.clear();
 	struct RangeResult {
 		std::vector<CostTerm> terms;
 		double bound = 0.0;
 		uint64_t n_cells = 0, algorithmic_bytes = 0;
+		uint32_t max_k = 0;
 		bool conflict = false;
 	};
-	auto terms_range = [&](uint32_t c_begin, uint32_t c_end, RangeResult& out) {
-	out.terms.reserve((size_t)(c_end - c_begin) * p.T * 2);
-	std::vector<uint32_t> R(p.n_ind), W(p.n_ind);
-	for (uint32_t c = c_begin; c < c_end; ++c) {
+	// deltas and cost terms of column c (its entries and indexing scheme are in place); false: Mendelian conflict
+	auto column_terms = [&](uint32_t c, RangeResult& out, std::vector<uint32_t>& R, std::vector<uint32_t>& W) -> bool {
 		const ColumnEntry* col = p.col_begin(c);
 		const uint32_t kc = p.k[c];
 		std::fill(R.begin(), R.end(), 0u);
 		std::fill(W.begin(), W.end(), 0u);
 		int32_t* dl = p.delta.data() + (size_t)p.col_ptr[c] * p.n_ind;
+		std::fill(dl, dl + (size_t)kc * p.n_ind, 0);
 		double wsum = 0.0;
 		for (uint32_t j = 0; j < kc; ++j) {
 			const ColumnEntry& e = col[j];
@@ -367,28 +383,73 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 		}
 		if (!any) {  // every transmission value infeasible at every cell (src/pedigreedptable.cpp:301-303)
 			out.conflict = true;
-			return;
+			return false;
 		}
 		out.bound += wsum + max_acost + 2.0 * p.n_triples * (double)p.recomb[c];
 		const uint64_t Tl = p.T;
 		out.n_cells += 1ull << kc;
 		out.algorithmic_bytes += (c > 0 ? 4 * Tl * (1ull << p.b[c]) : 0) + (c + 1 < n ? 12 * Tl * (1ull << p.f[c]) : 0) + 12ull * kc;
-	}
+		return true;
+	};
+	struct ActiveRead { uint32_t read, last; uint64_t v; };
+	auto columns_range = [&](uint32_t c_begin, uint32_t c_end, RangeResult& out) {
+		if (c_begin >= c_end) return;
+		out.terms.reserve(columns_only ? 0 : (size_t)(c_end - c_begin) * p.T * 2);
+		std::vector<uint32_t> R(p.n_ind), W(p.n_ind);
+		std::vector<ActiveRead> act;
+		act.reserve(64);
+		// the reads that started before the range and are still active at its first column
+		for (uint32_t r = 0; r < start_idx[c_begin]; ++r) {
+			if (last_col[r] < c_begin) continue;
+			const int32_t* lo = p.var_position.data() + p.read_ptr[r];
+			const int32_t* hi = p.var_position.data() + p.read_ptr[r + 1];
+			act.push_back(ActiveRead{r, last_col[r], (uint64_t)(std::lower_bound(lo, hi, (int32_t)p.positions[c_begin]) - p.var_position.data())});
+		}
+		for (uint32_t c = c_begin; c < c_end; ++c) {
+			size_t w = 0;
+			for (size_t i = 0; i < act.size(); ++i) {
+				if (act[i].last >= c) act[w++] = act[i];
+			}
+			act.resize(w);
+			const uint32_t shared = (uint32_t)w;   // they started earlier than any new read: the low bits of the column's index
+			for (uint32_t r = start_idx[c]; r < start_idx[c + 1]; ++r) act.push_back(ActiveRead{r, last_col[r], p.read_ptr[r]});
+			const uint32_t kc = (uint32_t)act.size();
+			ColumnEntry* col = p.entries.data() + p.col_ptr[c];
+			const int cpos = (int)p.positions[c];
+			uint32_t mask = 0;
+			for (uint32_t j = 0; j < kc; ++j) {
+				ActiveRead& a = act[j];
+				while (p.var_position[a.v] < cpos) ++a.v;
+				ColumnEntry& e = col[j];
+				e.read_id = a.read;
+				e.sample = (uint8_t)p.read_source[a.read];
+				if (p.var_position[a.v] == cpos) {
+					e.allele = p.var_allele[a.v];
+					e.phred = p.var_quality[a.v];
+				} else {
+					e.allele = WHAMD_ALLELE_BLANK;
+					e.phred = 0;
+				}
+				if (a.last > c) mask |= 1u << j;
+			}
+			p.k[c] = (uint8_t)kc;
+			p.b[c] = (uint8_t)shared;
+			p.fwd_mask[c] = mask;   // last column: everything is minimised out (global optimum, src/pedigreedptable.cpp:306-315)
+			p.f[c] = (uint8_t)__builtin_popcount(mask);
+			out.max_k = std::max(out.max_k, kc);
+			if (!columns_only && !column_terms(c, out, R, W)) return;
+		}
 	};
 	double bound = 0.0;  // upper bound on any DP value, to rule out 32-bit wrap-around
 	{
-		uint32_t n_threads = std::min<uint32_t>(std::max(1u, std::thread::hardware_concurrency()), 16u);
-		if (const char* e = getenv("WHAMD_PLAN_THREADS")) n_threads = (uint32_t)std::max(1, atoi(e));
-		n_threads = std::max(1u, std::min(n_threads, n / 8192u + 1u));
+		const uint32_t n_threads = host_threads(n, 8192);
 		std::vector<RangeResult> parts(n_threads);
 		std::vector<uint32_t> bounds(n_threads + 1);
 		for (uint32_t t = 0; t <= n_threads; ++t) bounds[t] = (uint32_t)((uint64_t)n * t / n_threads);
-		if (n_threads == 1) terms_range(0, n, parts[0]);
-		else {
-			std::vector<std::thread> workers;
-			for (uint32_t t = 0; t < n_threads; ++t) workers.emplace_back([&, t]() { terms_range(bounds[t], bounds[t + 1], parts[t]); });
-			for (std::thread& w : workers) w.join();
-		}
+		parallel_ranges(n, n_threads, [&](uint64_t c0, uint64_t c1, uint32_t t) { columns_range((uint32_t)c0, (uint32_t)c1, parts[t]); });
+		for (uint32_t t = 0; t < n_threads; ++t) p.max_k = std::max(p.max_k, parts[t].max_k);
+		lap("column entries, indexing scheme, deltas + cost terms");
+		if (columns_only) return WHAMD_OK;   // the genotyping path (genotype.cpp) has its own per-column model
 		for (uint32_t t = 0; t < n_threads; ++t) {
 			if (parts[t].conflict) {
 				msg = "Error: Mendelian conflict";
@@ -402,6 +463,7 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 			p.algorithmic_bytes += parts[t].algorithmic_bytes;
 		}
 	}
+	lap("term lists joined");
 	p.value_bound = bound;
 	if (bound >= 4294967295.0) {
 		msg = "costs may exceed 32 bits (upper bound " + std::to_string(bound) + "); the reference's unsigned arithmetic wraps there and results are undefined";
@@ -489,7 +551,7 @@ whamd_status_t finish_solution(const Problem& p, Solution& s, std::string& msg) 
 	s.allele1.assign((size_t)p.n_ind * n, 0);
 	s.quality.assign((size_t)p.n_ind * n, 0);
 	s.partition.assign(p.n_reads, 1);
-	const uint32_t n_threads = n < 20000 ? 1u : std::min<uint32_t>(8, std::max<uint32_t>(1, std::thread::hardware_concurrency()));
+	const uint32_t n_threads = n < 20000 ? 1u : host_threads(n, 8192);
 	if (n_threads == 1) return finish_columns(p, s, 0, n, msg);
 	std::vector<std::thread> workers;
 	std::vector<whamd_status_t> status(n_threads, WHAMD_OK);

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/whatshap_amd.h"
+#include "host_parallel.h"
 
 namespace whamd {
 
@@ -47,10 +48,11 @@ struct Problem {
 	// ---- inputs (copied from the views)
 	uint32_t n_reads = 0;
 	std::vector<uint64_t> read_ptr;
-	std::vector<int32_t> var_position;
-	std::vector<uint8_t> var_allele;
-	std::vector<uint32_t> var_quality;
+	RawVec<int32_t> var_position;   // (RawVec: sized without being zero-filled, host_parallel.h)
+	RawVec<uint8_t> var_allele;
+	RawVec<uint32_t> var_quality;
 	std::vector<uint32_t> read_source;
+	std::vector<uint32_t> read_first_col, read_last_col;   // [n_reads] columns of a read's first and last variant
 	uint32_t n_ind = 0, n_triples = 0, n_variants = 0;
 	std::vector<uint32_t> individual_id;
 	std::vector<std::array<uint32_t, 3>> triples;  // by individual index
@@ -65,14 +67,14 @@ struct Problem {
 	uint32_t T = 1, P = 0;
 	std::vector<int8_t> h2p;  // [T][n_ind][2]
 	std::vector<uint64_t> col_ptr;  // [n_cols + 1]
-	std::vector<ColumnEntry> entries;
+	RawVec<ColumnEntry> entries;
 	std::vector<uint8_t> k, b, f;        // per column
 	std::vector<uint32_t> fwd_mask;      // per column: bits of reads that continue into the next column
 	// cost terms per (column, transmission value)
 	std::vector<uint64_t> term_ptr;  // [n_cols * T + 1] offsets into terms
 	std::vector<CostTerm> terms;
 	// per column and individual: signed per-bit deltas d (REF +q, ALT -q, BLANK 0) of L_s(x) - R_s
-	std::vector<int32_t> delta;  // [col_ptr[c] * n_ind ... ): for column c, delta[(col_ptr[c] * n_ind) + s * k_c + bit]
+	RawVec<int32_t> delta;  // [col_ptr[c] * n_ind ... ): for column c, delta[(col_ptr[c] * n_ind) + s * k_c + bit]
 	uint32_t max_k = 0;
 	uint64_t n_cells = 0, algorithmic_bytes = 0;
 	double value_bound = 0.0;  // upper bound on every finite DP value

@@ -42,22 +42,22 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 	if (!ped && !(p.T == 1 && p.n_ind == 1)) return false;
 	if (!genotype_mode && !(p.value_bound < 1073741824.0)) return false;
 	plan.ped = ped;
-	lr = ped ? 0 : std::max(2, std::min(lr, SLOT_LR));
+	lr = ped ? 0 : std::max(1, std::min(lr, SLOT_LR));
 	const int n_lane = ped ? 6 - (int)TB : SLOT_LANE;
 	plan.col_to_row.assign(n, -1);
 	const int LMIN = lr + n_lane, LMAX = lr + n_lane + SLOT_LWMAX;
 	if (ped) l_pref = l_pref < 0 ? -l_pref : LMAX;
 	l_pref = std::max(LMIN, std::min(l_pref, LMAX));
 	const uint32_t max_run_cols = ped ? (uint32_t)PSLOT_MAXCOLS : (uint32_t)SLOT_MAXCOLS;
-	std::vector<uint32_t> last_col(p.n_reads, 0);
-	for (uint32_t c = 0; c < n; ++c) {
-		const ColumnEntry* col = p.col_begin(c);
-		for (uint32_t j = 0; j < p.k[c]; ++j) last_col[col[j].read_id] = c;
-	}
+	const std::vector<uint32_t>& last_col = p.read_last_col;   // (problem.cpp)
 	std::vector<int32_t>& col_to_row = plan.col_to_row;
 	// rows and backtrace columns are indexed by COLUMN (row of column c = rows[c]; entries of columns outside runs stay unused):
 	// the ranges below write disjoint parts of them in place
-	if (ped) plan.prows.resize(n); else plan.rows.resize(n);
+	if (ped) plan.prows.resize(n);
+	else {
+		plan.rows.reserve((size_t)n + SLOT_ROW_PAD);   // (the driver appends the pad rows: no reallocation of 50 MB)
+		plan.rows.resize(n);
+	}
 	plan.bt_cols.resize(n);
 	auto& rows_g = plan.rows;
 	auto& prows_g = plan.prows;
@@ -340,9 +340,7 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 	const auto tp1 = std::chrono::steady_clock::now();
 	auto tp2 = tp1;
 	{
-		uint32_t n_threads = std::min<uint32_t>(std::max(1u, std::thread::hardware_concurrency()), 16u);
-		if (const char* e = getenv("WHAMD_PLAN_THREADS")) n_threads = (uint32_t)std::max(1, atoi(e));
-		n_threads = std::max(1u, std::min(n_threads, n / 4096u + 1u));
+		const uint32_t n_threads = host_threads(n, 4096);
 		std::vector<SlotPlan> parts(n_threads);
 		std::vector<std::vector<RunDraft>> part_drafts(n_threads);
 		std::vector<uint32_t> bounds(n_threads + 1);
@@ -402,7 +400,8 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 	// ---- entry / exit layouts.  Exit index of a run in LOGICAL order: bit j = j-th continuing read of its last column.
 	plan.f_exit.assign(plan.runs.size(), 0);
 	plan.exit_slot.assign(plan.runs.size(), std::vector<uint8_t>());
-	for (size_t ri = 0; ri < plan.runs.size(); ++ri) {
+	parallel_ranges(plan.runs.size(), host_threads(plan.runs.size(), 512), [&](uint64_t r_begin, uint64_t r_end, uint32_t) {
+	for (size_t ri = r_begin; ri < r_end; ++ri) {
 		const SlotRun& run = plan.runs[ri];
 		const uint32_t cl = run.c0 + run.ncols - 1;
 		const SlotBtCol& bc = plan.bt_cols[run.row_off + run.ncols - 1];
@@ -410,7 +409,10 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 			if ((p.fwd_mask[cl] >> j) & 1u) plan.exit_slot[ri].push_back(bc.slot[j]);
 		plan.f_exit[ri] = (uint32_t)plan.exit_slot[ri].size();
 	}
-	for (size_t si = 0; si < plan.steps.size(); ++si) {
+	});
+	// (step si writes the exit side of its own run and the entry side of the next one: steps are independent)
+	parallel_ranges(plan.steps.size(), host_threads(plan.steps.size(), 512), [&](uint64_t s_begin, uint64_t s_end, uint32_t) {
+	for (size_t si = s_begin; si < s_end; ++si) {
 		if (plan.steps[si].kind != 2) continue;
 		const uint32_t ri = plan.steps[si].index;
 		SlotRun& B = plan.runs[ri];
@@ -476,6 +478,7 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 			B.mirror_out = B.half;   // a per-column step reads every entry
 		}
 	}
+	});
 	if (getenv("WHAMD_DEBUG_TIMING")) {
 		auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
 		fprintf(stderr, "[whamd timing] slot plan: setup %.1f ms, column ranges %.1f ms, concatenation %.1f ms, layouts %.1f ms\n",

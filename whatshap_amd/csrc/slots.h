@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "problem.h"
+#include "host_parallel.h"
 #include "resident.h"
 
 namespace whamd {
@@ -159,16 +160,9 @@ struct SlotBtUnit {
 };
 static_assert(sizeof(SlotBtUnit) == 128, "SlotBtUnit must stay 32 words");
 
-// std::vector whose resize() leaves trivially constructible elements uninitialised (the planner assigns every row it uses;
-// value-initialising 58 MB of rows was a third of its time).
+// (rows and backtrace columns: vectors that are sized without being written, on huge pages -- host_parallel.h)
 template <class T>
-struct NoInitAllocator : std::allocator<T> {
-	template <class U> struct rebind { using other = NoInitAllocator<U>; };
-	NoInitAllocator() = default;
-	template <class U> NoInitAllocator(const NoInitAllocator<U>&) {}
-	template <class U> void construct(U* ptr) noexcept { ::new (static_cast<void*>(ptr)) U; }
-	template <class U, class... A> void construct(U* ptr, A&&... a) { ::new (static_cast<void*>(ptr)) U(std::forward<A>(a)...); }
-};
+using NoInitAllocator = NoInitAlloc<T>;
 
 struct SlotPlan {
 	std::vector<Step> steps;                 // kind 0: per-column step (index = column), kind 2: slot run (index into runs)
