@@ -6,7 +6,10 @@ from whatshap_amd import _native
 from whatshap_amd.synthetic import synthetic_block
 
 p = synthetic_block(int(sys.argv[1]) if len(sys.argv) > 1 else 20000, 20, seed=3)
-for skip, options in ((0, ()), (3, ()), (11, ()), (27, ()), (0, (("slot_r", "3"),)), (11, (("slot_r", "3"),))):
+VARIANTS = ((0, ()), (3, ()), (11, ()), (27, ()), (0, (("slot_r", "3"),)), (11, (("slot_r", "3"),)), (0, (("slot_r", "1"),)), (11, (("slot_r", "1"),)))
+if len(sys.argv) > 2:
+    VARIANTS = tuple(VARIANTS[int(i)] for i in sys.argv[2].split(","))
+for skip, options in VARIANTS:
     os.environ["WHAMD_SLOT_SKIP"] = str(skip)
     t = _native.NativeTable(p, solve=False)
     for k, v in options:

@@ -138,6 +138,7 @@ struct StageSession {
 		}
 		return hipSuccess;
 	}
+	void expect(size_t bytes) { g_stage.want = std::max(g_stage.want, std::min(bytes, STAGE_MAX)); }   // before the first copy: one allocation
 	void finish() {   // after the caller synchronised the stream
 		pending = false;
 		used = 0;
@@ -569,6 +570,10 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	size_t delta_count = (size_t)p.col_ptr[n] * p.n_ind;
 	if (p.n_ind == 0) { delta_fallback.assign(std::max<size_t>(p.col_ptr[n], 1), 0); delta_src = delta_fallback.data(); delta_count = delta_fallback.size(); }
 	void *d_delta, *d_term_ptr, *d_terms, *d_segs, *d_bt, *d_keys, *d_last_keys, *d_rcol, *d_rbt;
+	stage.expect(m.cols.size() * sizeof(DevColumn) + delta_count * sizeof(int32_t) + term_ptr32.size() * 4 + terms.size() * sizeof(DevTerm) + segs.size() * 4 +
+	             m.plan.columns.size() * (sizeof(ResColumn) + sizeof(ResBacktrace) + sizeof(PedColumn)) + m.plan.ped_terms.size() * sizeof(PedTerm) +
+	             (m.splan.rows.size() + SLOT_ROW_PAD) * sizeof(SlotRow) + m.splan.prows.size() * sizeof(PedSlotRow) + m.splan.bt_cols.size() * (sizeof(SlotBtCol) + 8) +
+	             m.splan.runs.size() * (sizeof(SlotRun) + sizeof(PedSlotExtra) + sizeof(BtUnit) + 64) + ((size_t)8 << 20));
 	HIP_TRY(up((void**)&m.d_cols, m.cols.data(), m.cols.size() * sizeof(DevColumn)));
 	HIP_TRY(up(&d_delta, delta_src, delta_count * sizeof(int32_t)));
 	HIP_TRY(up(&d_term_ptr, term_ptr32.data(), term_ptr32.size() * sizeof(uint32_t)));
