@@ -41,7 +41,8 @@ def test_golden_vectors():
 
 @pytest.mark.parametrize("kw,row_limit", [(dict(n_variants=3000, coverage=30, seed=11), 256), (dict(n_variants=2000, coverage=24, seed=12, trio=True), 256),
                                           (dict(n_variants=1500, coverage=18, seed=13, quartet=True, error_rate=0.08), 128),
-                                          (dict(n_variants=1200, coverage=40, seed=14, error_rate=0.1), 1024)], ids=str)
+                                          (dict(n_variants=1200, coverage=40, seed=14, error_rate=0.1), 1024),
+                                          (dict(n_variants=400, coverage=70, seed=15, error_rate=0.05), 64)], ids=str)
 def test_coverages_the_exact_dp_cannot_afford(kw, row_limit):
     """Thousands of columns at coverage 18 - 40 (the exact table stops at 25 reads per column): the use the solver exists for."""
     p = synthetic_block(**kw)
@@ -49,6 +50,14 @@ def test_coverages_the_exact_dp_cannot_afford(kw, row_limit):
     got = device(p, row_limit)
     assert result_tuple(got) == want
     assert got["stats"]["max_solutions"] >= min(row_limit, 16)
+
+
+def test_fewer_threads_than_solutions(monkeypatch):
+    """One wavefront for a beam of hundreds of solutions (WHAMD_HEURISTIC_THREADS): every phase loops over the beam in rounds."""
+    p = synthetic_block(n_variants=800, coverage=26, seed=16, trio=True)
+    want = oracle.heuristic_tuple(oracle.ReferenceHeuristic(p, row_limit=128))
+    monkeypatch.setenv("WHAMD_HEURISTIC_THREADS", "64")
+    assert result_tuple(device(p, 128)) == want
 
 
 def test_drop_in_class_and_shim():

@@ -19,19 +19,27 @@
 
 #pragma clang fp contract(off)
 
+#ifndef HEUR_STAMP            // cycle stamps per phase of a column (device, WHAMD_HEURISTIC_STAMPS): stats[8 + phase] += cycles since the last stamp
+#define HEUR_STAMP(D, phase)
+#define HEUR_STAMP_BEGIN(D)
+#endif
+
 namespace whamd {
 
 constexpr uint32_t HEUR_MAXS = 8;          // samples of one table
 constexpr uint32_t HEUR_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t HEUR_LDS_BEAM = 1024;   // beams up to this size: hash table of the projection (2 x as many slots) and projected bipartitions in LDS
 
-// One pool of solutions (structure of arrays); two of them are used alternately.
+// One pool of solutions (structure of arrays); two of them are used alternately.  Every array has the SOLUTION index innermost:
+// the threads of a wavefront work on consecutive solutions, so each of their loads and stores is one contiguous piece of memory
+// (with the solution outermost every access of a wave touched 64 cache lines -- three quarters of the kernel's time).
 struct HeurPool {
 	float* score;      // [cap]
 	float* mut;        // [cap] mutationScore
 	uint32_t* trans;   // [cap]
 	uint32_t* bt;      // [cap] btRow
-	uint32_t* bits;    // [cap][nw] bipartition over the column's active reads (kept reads first, then the new ones)
-	float* bal;        // [cap][2 S][w_max]
+	uint32_t* bits;    // [nw][cap] bipartition over the column's active reads (kept reads first, then the new ones)
+	float* bal;        // [2 S][w_max][cap]
 };
 
 struct HeurDev {
@@ -47,7 +55,7 @@ struct HeurDev {
 	// ---- state
 	HeurPool pool[2];
 	uint32_t cap;
-	uint32_t* pbits;               // [cap][nw] projected bipartitions
+	uint32_t* pbits;               // [nw][cap] projected bipartitions (beams of up to HEUR_LDS_BEAM solutions keep them in LDS)
 	uint32_t* table;               // [tsz] hash slots: a member of the slot's group
 	uint32_t* lead;                // [tsz] smallest member index
 	unsigned long long* best;      // [tsz] min (sortable score << 32 | index)
@@ -77,30 +85,15 @@ HEUR_FN inline float heur_min(float a, float b) { return b < a ? b : a; }    // 
 HEUR_FN inline float heur_max(float a, float b) { return a < b ? b : a; }    // std::max
 HEUR_FN inline uint32_t heur_popc(uint32_t v) { return (uint32_t)__builtin_popcount(v); }
 
-// A balance matrix [2 S][w_max] with one row seen as (row + add): what addBalance leaves behind, without materialising it.
+// The balance matrix [2 S][w_max] of ONE solution (bal points at its element (0, 0); consecutive elements are `cap` apart) with
+// one row seen as (row + add): what addBalance leaves behind, without materialising it.
 struct HeurBalView {
-	const float* bal; uint32_t w_max; uint32_t over_row; const float* add;
+	const float* bal; size_t cap; uint32_t w_max; uint32_t over_row; const float* add;
 	HEUR_FN inline float at(uint32_t row, uint32_t i) const {
-		const float v = bal[(size_t)row * w_max + i];
+		const float v = bal[((size_t)row * w_max + i) * cap];
 		return row == over_row ? v + add[i] : v;
 	}
 };
-
-// addBalance (src/pedmecheuristic.cpp:566-586): the penalty only (the caller adds `add` to the row afterwards)
-HEUR_FN inline float heur_add_balance(const float* basis, const float* co, const float* add, uint32_t w, bool distrust, const int8_t* target) {
-	float penalty = 0;
-	for (uint32_t i = 0; i < w; ++i) {
-		if (distrust) {
-			if (basis[i] * add[i] < 0) penalty += heur_min(heur_abs(basis[i]), heur_abs(add[i]));
-		} else if (target[i] == 1) {
-			if (add[i] <= 0) penalty += heur_min(-add[i], heur_max(basis[i] - co[i], (float)0));
-			else penalty += heur_min(add[i], heur_max(co[i] - basis[i], (float)0));
-		} else {
-			penalty += heur_abs(add[i]) * (float)(int)(add[i] * (float)(target[i] - 1) < 0);
-		}
-	}
-	return penalty;
-}
 
 // getMutationCost (:438-468)
 HEUR_FN inline float heur_mutation_cost(const HeurDev& D, const HeurBalView& B, uint32_t t, uint32_t p, bool allow_flips, uint32_t ahead, uint32_t w) {
@@ -234,12 +227,39 @@ HEUR_FN inline uint32_t heur_select(const float* val, uint32_t n, uint32_t k) {
 	return prefix;
 }
 
+// Copies / updates of one row of a balance matrix (elements `st` apart), eight elements at a time: all loads of a batch are issued
+// before the first store (source and destination may be the same pool, which the compiler must assume to alias -- element by element
+// every load would wait for the previous store, a full memory round trip per element).
+constexpr uint32_t HEUR_BATCH = 8;
+// dst[x] = x + shift < n_src ? src[x + shift] : 0   for x < w
+HEUR_FN inline void heur_copy_row(float* dst, const float* src, size_t st, uint32_t w, uint32_t shift, uint32_t n_src) {
+	for (uint32_t x0 = 0; x0 < w; x0 += HEUR_BATCH) {
+		float t[HEUR_BATCH];
+#pragma unroll
+		for (uint32_t u = 0; u < HEUR_BATCH; ++u) t[u] = (x0 + u < w && x0 + u + shift < n_src) ? src[(size_t)(x0 + u + shift) * st] : 0.0f;
+#pragma unroll
+		for (uint32_t u = 0; u < HEUR_BATCH; ++u) if (x0 + u < w) dst[(size_t)(x0 + u) * st] = t[u];
+	}
+}
+// row[x] += add[x]   for x < w
+HEUR_FN inline void heur_add_row(float* row, size_t st, const float* add, uint32_t w) {
+	for (uint32_t x0 = 0; x0 < w; x0 += HEUR_BATCH) {
+		float t[HEUR_BATCH];
+#pragma unroll
+		for (uint32_t u = 0; u < HEUR_BATCH; ++u) t[u] = x0 + u < w ? row[(size_t)(x0 + u) * st] + add[x0 + u] : 0.0f;
+#pragma unroll
+		for (uint32_t u = 0; u < HEUR_BATCH; ++u) if (x0 + u < w) row[(size_t)(x0 + u) * st] = t[u];
+	}
+}
+
 HEUR_FN inline void heur_copy_solution(const HeurDev& D, const HeurPool& src, uint32_t i, const HeurPool& dst, uint32_t j, uint32_t w) {
-	dst.score[j] = src.score[i]; dst.mut[j] = src.mut[i]; dst.trans[j] = src.trans[i]; dst.bt[j] = src.bt[i];
-	for (uint32_t q = 0; q < D.nw; ++q) dst.bits[(size_t)j * D.nw + q] = src.bits[(size_t)i * D.nw + q];
-	const size_t rows = 2u * D.n_samples;
-	for (uint32_t r = 0; r < rows; ++r)
-		for (uint32_t x = 0; x < w; ++x) dst.bal[((size_t)j * rows + r) * D.w_max + x] = src.bal[((size_t)i * rows + r) * D.w_max + x];
+	const float sc = src.score[i], mu = src.mut[i];
+	const uint32_t tr = src.trans[i], bt = src.bt[i];
+	dst.score[j] = sc; dst.mut[j] = mu; dst.trans[j] = tr; dst.bt[j] = bt;
+	const size_t cap = D.cap;
+	for (uint32_t q = 0; q < D.nw; ++q) dst.bits[q * cap + j] = src.bits[q * cap + i];
+	const uint32_t rows = 2u * D.n_samples;
+	for (uint32_t r = 0; r < rows; ++r) heur_copy_row(dst.bal + (size_t)r * D.w_max * cap + j, src.bal + (size_t)r * D.w_max * cap + i, cap, w, 0, w);
 }
 
 // filterSolutions (:604-622): pool[cur] (count) -> pool[cur ^ 1]; returns the new count.
@@ -270,7 +290,8 @@ HEUR_FN inline uint32_t heur_filter(const HeurDev& D, uint32_t cur, uint32_t cou
 	return kept;
 }
 
-HEUR_FN inline uint32_t heur_get_bit(const uint32_t* bits, uint32_t b) { return (bits[b >> 5] >> (b & 31u)) & 1u; }
+// bit b of solution i's bipartition (bits: [nw][cap])
+HEUR_FN inline uint32_t heur_get_bit(const uint32_t* bits, size_t cap, uint32_t i, uint32_t b) { return (bits[(b >> 5) * cap + i] >> (b & 31u)) & 1u; }
 
 // ---- the solver: src/pedmecheuristic.cpp:123-358 ------------------------------------------------------------------------
 HEUR_FN inline void heur_solve(const HeurDev& D) {
@@ -280,9 +301,11 @@ HEUR_FN inline void heur_solve(const HeurDev& D) {
 	unsigned long long arena_used = 0, widest = 0, total = 0;
 	// lastCol = { empty bipartition, transmission 0, score 0, balances (1, 0) }  (:151)
 	if (tid == 0) { D.pool[0].score[0] = 0.0f; D.pool[0].mut[0] = 0.0f; D.pool[0].trans[0] = 0; D.pool[0].bt[0] = 0; }
-	for (uint32_t x = tid; x < rows * wm; x += nt) D.pool[0].bal[x] = 0.0f;
-	for (uint32_t x = tid; x < nw; x += nt) D.pool[0].bits[x] = 0;
+	const size_t cap = D.cap;
+	for (uint32_t x = tid; x < rows * wm; x += nt) D.pool[0].bal[x * cap] = 0.0f;
+	for (uint32_t x = tid; x < nw; x += nt) D.pool[0].bits[x * cap] = 0;
 	HEUR_SYNC();
+	HEUR_STAMP_BEGIN(D);
 	for (uint32_t p = 0; p < D.n_cols; ++p) {
 		const uint32_t w = D.window[p], nk = D.n_kept[p], nn = D.n_new[p];
 		const uint32_t* kept = D.kept + D.kept_off[p];
@@ -292,54 +315,75 @@ HEUR_FN inline void heur_solve(const HeurDev& D) {
 			const HeurPool& dst = D.pool[cur ^ 1u];
 			uint32_t tsz = 64;
 			while (tsz < 2u * count) tsz <<= 1;
-			for (uint32_t x = tid; x < tsz; x += nt) { D.table[x] = HEUR_EMPTY; D.lead[x] = HEUR_EMPTY; D.best[x] = ~0ull; }
-			for (uint32_t i = tid; i < count; i += nt) {
-				uint32_t* pb = D.pbits + (size_t)i * nw;
-				for (uint32_t q = 0; q < nw; ++q) pb[q] = 0;
-				const uint32_t* sb = src.bits + (size_t)i * nw;
-				for (uint32_t a = 0; a < nk; ++a) pb[a >> 5] |= heur_get_bit(sb, kept[a]) << (a & 31u);
-			}
-			HEUR_SYNC();
-			for (uint32_t i = tid; i < count; i += nt) {
-				const uint32_t* pb = D.pbits + (size_t)i * nw;
-				const uint32_t tr = src.trans[i];
-				uint32_t h = tr * 0x9E3779B1u + 0x7F4A7C15u;
-				for (uint32_t q = 0; q < nw; ++q) { h ^= pb[q]; h *= 0x85EBCA6Bu; h ^= h >> 13; }
-				uint32_t pos = h & (tsz - 1u);
-				for (;;) {
-					uint32_t other = heur_load32(&D.table[pos]);
-					if (other == HEUR_EMPTY) {
-						other = heur_cas32(&D.table[pos], HEUR_EMPTY, i);
-						if (other == HEUR_EMPTY) break;   // this solution is the slot's group from now on
+			// the usual beam: hash table and projected bipartitions in LDS (its atomics do not leave the CU)
+			HEUR_SHARED uint32_t sh_table[2 * HEUR_LDS_BEAM], sh_lead[2 * HEUR_LDS_BEAM], sh_pbits[2 * HEUR_LDS_BEAM];
+			HEUR_SHARED unsigned long long sh_best[2 * HEUR_LDS_BEAM];
+			HEUR_SHARED uint32_t sh_kept[64], sh_trans[HEUR_LDS_BEAM];
+			const bool in_lds = count <= HEUR_LDS_BEAM && nw <= 2u;
+			if (nw <= 2u) for (uint32_t a = tid; a < nk; a += nt) sh_kept[a] = kept[a];   // (read by every thread below: past the first barrier)
+			// (a generic lambda, instantiated for the LDS arrays and for the global ones: with pointers chosen at run time every access
+			// would be a FLAT instruction -- measured: the probe loop alone took a third of the column)
+			uint32_t n2 = 0;
+			auto project = [&](uint32_t* table, uint32_t* lead, unsigned long long* best, uint32_t* pbits, uint32_t* trans_stage, const uint32_t* ptrans, const size_t pst) {
+				for (uint32_t x = tid; x < tsz; x += nt) { table[x] = HEUR_EMPTY; lead[x] = HEUR_EMPTY; best[x] = ~0ull; }
+				HEUR_SYNC();
+				HEUR_STAMP(D, 7);
+				for (uint32_t i = tid; i < count; i += nt) {
+					if (trans_stage) trans_stage[i] = src.trans[i];
+					if (nw <= 2u) {   // both words in registers: bit a of the projection = bit kept[a] of the solution
+						const unsigned long long sb = (unsigned long long)src.bits[i] | (nw > 1u ? (unsigned long long)src.bits[cap + i] << 32 : 0ull);
+						unsigned long long pb = 0;
+						for (uint32_t a = 0; a < nk; ++a) pb |= ((sb >> sh_kept[a]) & 1ull) << a;
+						pbits[i] = (uint32_t)pb;
+						if (nw > 1u) pbits[pst + i] = (uint32_t)(pb >> 32);
+					} else {
+						for (uint32_t q = 0; q < nw; ++q) pbits[q * pst + i] = 0;
+						for (uint32_t a = 0; a < nk; ++a) pbits[(a >> 5) * pst + i] |= heur_get_bit(src.bits, cap, i, kept[a]) << (a & 31u);
 					}
-					bool same = src.trans[other] == tr;
-					const uint32_t* ob = D.pbits + (size_t)other * nw;
-					for (uint32_t q = 0; q < nw && same; ++q) same = ob[q] == pb[q];
-					if (same) break;
-					pos = (pos + 1u) & (tsz - 1u);
 				}
-				D.slot[i] = pos;
-				heur_min32(&D.lead[pos], i);
-				// updateSolution (:420-432): a later duplicate replaces the kept one only if strictly better
-				heur_min64(&D.best[pos], ((unsigned long long)heur_sortable(src.score[i]) << 32) | i);
-			}
-			HEUR_SYNC();
-			for (uint32_t i = tid; i < count; i += nt) D.aux[i] = heur_load32(&D.lead[D.slot[i]]) == i ? 1u : 0u;
-			HEUR_SYNC();
-			const uint32_t n2 = heur_scan(D.aux, D.rank, count);
-			for (uint32_t i = tid; i < count; i += nt) {
-				if (!D.aux[i]) continue;
-				const uint32_t j = D.rank[i], win = (uint32_t)heur_load64(&D.best[D.slot[i]]);
-				dst.score[j] = src.score[win]; dst.mut[j] = 0.0f; dst.trans[j] = src.trans[i]; dst.bt[j] = win;
-				for (uint32_t q = 0; q < nw; ++q) dst.bits[(size_t)j * nw + q] = D.pbits[(size_t)i * nw + q];
-				// balances of the winner without their first position, extended with zeros to the column's window (:204-206, :425-431)
-				for (uint32_t r = 0; r < rows; ++r) {
-					const float* sb = src.bal + ((size_t)win * rows + r) * wm;
-					float* db = dst.bal + ((size_t)j * rows + r) * wm;
-					for (uint32_t x = 0; x < w; ++x) db[x] = x + 1u < w_prev ? sb[x + 1u] : 0.0f;
+				HEUR_SYNC();
+				HEUR_STAMP(D, 8);
+				for (uint32_t i = tid; i < count; i += nt) {
+					const uint32_t tr = ptrans[i];
+					const unsigned long long score_key = ((unsigned long long)heur_sortable(src.score[i]) << 32) | i;
+					uint32_t h = tr * 0x9E3779B1u + 0x7F4A7C15u;
+					for (uint32_t q = 0; q < nw; ++q) { h ^= pbits[q * pst + i]; h *= 0x85EBCA6Bu; h ^= h >> 13; }
+					h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;   // full avalanche: the newest reads are the HIGH bits of the bipartition
+					uint32_t pos = h & (tsz - 1u);
+					for (;;) {
+						uint32_t other = heur_load32(&table[pos]);
+						if (other == HEUR_EMPTY) {
+							other = heur_cas32(&table[pos], HEUR_EMPTY, i);
+							if (other == HEUR_EMPTY) break;   // this solution is the slot's group from now on
+						}
+						bool same = ptrans[other] == tr;
+						for (uint32_t q = 0; q < nw && same; ++q) same = pbits[q * pst + other] == pbits[q * pst + i];
+						if (same) break;
+						pos = (pos + 1u) & (tsz - 1u);
+					}
+					D.slot[i] = pos;
+					heur_min32(&lead[pos], i);
+					// updateSolution (:420-432): a later duplicate replaces the kept one only if strictly better
+					heur_min64(&best[pos], score_key);
 				}
-			}
+				HEUR_SYNC();
+				HEUR_STAMP(D, 0);
+				for (uint32_t i = tid; i < count; i += nt) D.aux[i] = heur_load32(&lead[D.slot[i]]) == i ? 1u : 0u;
+				HEUR_SYNC();
+				n2 = heur_scan(D.aux, D.rank, count);
+				for (uint32_t i = tid; i < count; i += nt) {
+					if (!D.aux[i]) continue;
+					const uint32_t j = D.rank[i], win = (uint32_t)heur_load64(&best[D.slot[i]]);
+					dst.score[j] = src.score[win]; dst.mut[j] = 0.0f; dst.trans[j] = src.trans[i]; dst.bt[j] = win;
+					for (uint32_t q = 0; q < nw; ++q) dst.bits[q * cap + j] = pbits[q * pst + i];
+					// balances of the winner without their first position, extended with zeros to the column's window (:204-206, :425-431)
+					for (uint32_t r = 0; r < rows; ++r) heur_copy_row(dst.bal + (size_t)r * wm * cap + j, src.bal + (size_t)r * wm * cap + win, cap, w, 1, w_prev);
+				}
+			};
+			if (in_lds) project(sh_table, sh_lead, sh_best, sh_pbits, sh_trans, sh_trans, (size_t)HEUR_LDS_BEAM);
+			else project(D.table, D.lead, D.best, D.pbits, nullptr, src.trans, cap);
 			HEUR_SYNC();
+			HEUR_STAMP(D, 1);
 			cur ^= 1u;
 			count = n2;
 		}
@@ -351,8 +395,7 @@ HEUR_FN inline void heur_solve(const HeurDev& D) {
 			const HeurPool& P = D.pool[cur];
 			if (eq >= 0) {   // identical to an earlier read of the column: same side, no branching (:247-250)
 				for (uint32_t i = tid; i < count; i += nt) {
-					uint32_t* b = P.bits + (size_t)i * nw;
-					if (heur_get_bit(b, nk + (uint32_t)eq)) b[bitpos >> 5] |= 1u << (bitpos & 31u);
+					if (heur_get_bit(P.bits, cap, i, nk + (uint32_t)eq)) P.bits[(bitpos >> 5) * cap + i] |= 1u << (bitpos & 31u);
 				}
 				HEUR_SYNC();
 				continue;
@@ -364,26 +407,48 @@ HEUR_FN inline void heur_solve(const HeurDev& D) {
 			if ((unsigned long long)count * 2ull > D.cap) { if (tid == 0) D.stats[0] = 1; return; }
 			// pass 1: both placements of the read scored per solution; aux = 0 keep side 0, 1 keep side 1, 2 keep both
 			for (uint32_t i = tid; i < count; i += nt) {
-				const float* bal = P.bal + (size_t)i * rows * wm;
-				const float* b0 = bal + (size_t)(2 * s) * wm;
-				const float* b1 = bal + (size_t)(2 * s + 1) * wm;
-				bool useful;
-				if (D.distrust) {
-					useful = false;
-					for (uint32_t j = 0; j < w && !useful; ++j) {
-						const float s0 = b0[j], s1 = b1[j];
-						useful = (add[j] != 0 && s0 * s1 < 0) || ((add[j] + s0) * s0 <= 0 && (add[j] + s1) * s1 <= 0);
+				const float* bal = P.bal + i;
+				const float* b0 = bal + (size_t)(2 * s) * wm * cap;
+				const float* b1 = bal + (size_t)(2 * s + 1) * wm * cap;
+				// addBalance (src/pedmecheuristic.cpp:566-586; the penalty only, the rows are updated in pass 2) of the read on either
+				// haplotype, and the "useful" test of the untrusted-genotype mode (:256-258), in ONE pass over the two rows, eight positions at a time (all loads of a batch before the arithmetic that waits for them); each penalty is
+				// accumulated in the reference's order
+				bool useful = D.distrust ? false : D.new_useful[nr] != 0;
+				float pen0 = 0, pen1 = 0;
+				for (uint32_t x0 = 0; x0 < w; x0 += HEUR_BATCH) {
+					float v0[HEUR_BATCH], v1[HEUR_BATCH];
+#pragma unroll
+					for (uint32_t u = 0; u < HEUR_BATCH; ++u) {
+						v0[u] = x0 + u < w ? b0[(size_t)(x0 + u) * cap] : 0.0f;
+						v1[u] = x0 + u < w ? b1[(size_t)(x0 + u) * cap] : 0.0f;
 					}
-				} else useful = D.new_useful[nr] != 0;
+#pragma unroll
+					for (uint32_t u = 0; u < HEUR_BATCH; ++u) {
+						if (x0 + u >= w) continue;
+						const float a = add[x0 + u], s0 = v0[u], s1 = v1[u];
+						if (D.distrust) {
+							useful = useful || (a != 0 && s0 * s1 < 0) || ((a + s0) * s0 <= 0 && (a + s1) * s1 <= 0);
+							if (s0 * a < 0) pen0 += heur_min(heur_abs(s0), heur_abs(a));
+							if (s1 * a < 0) pen1 += heur_min(heur_abs(s1), heur_abs(a));
+						} else if (target[x0 + u] == 1) {
+							if (a <= 0) { pen0 += heur_min(-a, heur_max(s0 - s1, (float)0)); pen1 += heur_min(-a, heur_max(s1 - s0, (float)0)); }
+							else { pen0 += heur_min(a, heur_max(s1 - s0, (float)0)); pen1 += heur_min(a, heur_max(s0 - s1, (float)0)); }
+						} else {
+							const float t = heur_abs(a) * (float)(int)(a * (float)(target[x0 + u] - 1) < 0);
+							pen0 += t;
+							pen1 += t;
+						}
+					}
+				}
 				const uint32_t tr = P.trans[i];
 				const float sc = P.score[i];
 				float sc1 = 0, mu1 = 0;
 				if (seen) {
-					sc1 = sc + heur_add_balance(b1, b0, add, w, D.distrust != 0, target);
-					mu1 = heur_mutation_cost(D, HeurBalView{bal, wm, 2 * s + 1, add}, tr, p, true, 5, w);
+					sc1 = sc + pen1;
+					mu1 = heur_mutation_cost(D, HeurBalView{bal, cap, wm, 2 * s + 1, add}, tr, p, true, 5, w);
 				}
-				const float sc0 = sc + heur_add_balance(b0, b1, add, w, D.distrust != 0, target);
-				const float mu0 = heur_mutation_cost(D, HeurBalView{bal, wm, 2 * s, add}, tr, p, true, 5, w);
+				const float sc0 = sc + pen0;
+				const float mu0 = heur_mutation_cost(D, HeurBalView{bal, cap, wm, 2 * s, add}, tr, p, true, 5, w);
 				uint32_t mode = 0;
 				if (seen) mode = useful ? 2u : ((sc0 + mu0 > sc1 + mu1) ? 1u : 0u);
 				D.aux[i] = mode;
@@ -394,6 +459,7 @@ HEUR_FN inline void heur_solve(const HeurDev& D) {
 				P.mut[i] = mode == 1u ? mu1 : mu0;
 			}
 			HEUR_SYNC();
+			HEUR_STAMP(D, 2);
 			for (uint32_t i = tid; i < count; i += nt) D.rank[i] = D.aux[i] == 2u ? 1u : 0u;
 			HEUR_SYNC();
 			const uint32_t n_app = heur_scan(D.rank, D.rank, count);
@@ -404,28 +470,27 @@ HEUR_FN inline void heur_solve(const HeurDev& D) {
 				heur_copy_solution(D, P, i, P, j, w);
 				P.score[j] = D.val[i];
 				P.mut[j] = __builtin_bit_cast(float, D.slot[i]);
-				float* row = P.bal + ((size_t)j * rows + 2 * s + 1) * wm;
-				for (uint32_t x = 0; x < w; ++x) row[x] += add[x];
-				P.bits[(size_t)j * nw + (bitpos >> 5)] |= 1u << (bitpos & 31u);
+				heur_add_row(P.bal + (size_t)(2 * s + 1) * wm * cap + j, cap, add, w);
+				P.bits[(bitpos >> 5) * cap + j] |= 1u << (bitpos & 31u);
 			}
 			HEUR_SYNC();
 			for (uint32_t i = tid; i < count; i += nt) {
 				const uint32_t side = D.aux[i] == 1u ? 1u : 0u;
-				float* row = P.bal + ((size_t)i * rows + 2 * s + side) * wm;
-				for (uint32_t x = 0; x < w; ++x) row[x] += add[x];
-				if (side) P.bits[(size_t)i * nw + (bitpos >> 5)] |= 1u << (bitpos & 31u);
+				heur_add_row(P.bal + (size_t)(2 * s + side) * wm * cap + i, cap, add, w);
+				if (side) P.bits[(bitpos >> 5) * cap + i] |= 1u << (bitpos & 31u);
 			}
 			HEUR_SYNC();
 			count += n_app;
+			HEUR_STAMP(D, 3);
 			if (count > D.row_limit) { count = heur_filter(D, cur, count, w); cur ^= 1u; }
+			HEUR_STAMP(D, 4);
 		}
 		// ================= other transmission values where they pay for themselves (:299-303, :588-602)
 		{
 			const HeurPool& P = D.pool[cur];
 			const float rc1 = D.recomb[p];
 			for (uint32_t i = tid; i < count; i += nt) {
-				const float* bal = P.bal + (size_t)i * rows * wm;
-				const HeurBalView B{bal, wm, HEUR_EMPTY, nullptr};
+				const HeurBalView B{P.bal + i, cap, wm, HEUR_EMPTY, nullptr};
 				const uint32_t tr = P.trans[i];
 				const float mu = heur_mutation_cost(D, B, tr, p, false, 0, w);
 				P.mut[i] = mu;
@@ -447,8 +512,7 @@ HEUR_FN inline void heur_solve(const HeurDev& D) {
 			if ((unsigned long long)count + n_app > D.cap) { if (tid == 0) D.stats[0] = 1; return; }
 			for (uint32_t i = tid; i < count; i += nt) {
 				if (!D.aux[i]) continue;
-				const float* bal = P.bal + (size_t)i * rows * wm;
-				const HeurBalView B{bal, wm, HEUR_EMPTY, nullptr};
+				const HeurBalView B{P.bal + i, cap, wm, HEUR_EMPTY, nullptr};
 				const uint32_t tr = P.trans[i];
 				const float mu = P.mut[i], sc = P.score[i];
 				uint32_t j = count + D.rank[i];
@@ -466,6 +530,7 @@ HEUR_FN inline void heur_solve(const HeurDev& D) {
 			HEUR_SYNC();
 			count += n_app;
 			if (count > D.row_limit) { count = heur_filter(D, cur, count, w); cur ^= 1u; }
+			HEUR_STAMP(D, 5);
 		}
 		// ================= the column's own phasing cost (:306-313), then the backtrace record of the column (:315-330)
 		{
@@ -475,20 +540,20 @@ HEUR_FN inline void heur_solve(const HeurDev& D) {
 			uint32_t* rec = D.arena + arena_used;
 			for (uint32_t i = tid; i < count; i += nt) {
 				float firsts[2 * HEUR_MAXS];
-				for (uint32_t r = 0; r < rows; ++r) firsts[r] = P.bal[((size_t)i * rows + r) * wm];
+				for (uint32_t r = 0; r < rows; ++r) firsts[r] = P.bal[(size_t)r * wm * cap + i];
 				P.score[i] += heur_opt_phasing(D, firsts, P.trans[i], p, nullptr, nullptr);
 				uint32_t* e = rec + (size_t)i * stride;
 				e[0] = P.bt[i];
 				e[1] = P.trans[i];
-				const uint32_t* b = P.bits + (size_t)i * nw;
 				for (uint32_t q = 0; q < nwn; ++q) e[2 + q] = 0;
-				for (uint32_t q = 0; q < nn; ++q) e[2 + (q >> 5)] |= heur_get_bit(b, nk + q) << (q & 31u);
+				for (uint32_t q = 0; q < nn; ++q) e[2 + (q >> 5)] |= heur_get_bit(P.bits, cap, i, nk + q) << (q & 31u);
 			}
 			if (tid == 0) { D.col_off[p] = arena_used; D.col_count[p] = count; }
 			arena_used += (unsigned long long)count * stride;
 			if (count > widest) widest = count;
 			total += count;
 			HEUR_SYNC();
+			HEUR_STAMP(D, 6);
 		}
 		w_prev = w;
 	}

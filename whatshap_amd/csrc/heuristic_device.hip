@@ -19,6 +19,10 @@
 #define HEUR_TID threadIdx.x
 #define HEUR_NT blockDim.x
 #define HEUR_SYNC() __syncthreads()
+#ifdef WHAMD_HEURISTIC_STAMPS
+#define HEUR_STAMP_BEGIN(D) do { if (threadIdx.x == 0) (D).stats[7] = __builtin_readcyclecounter(); } while (0)
+#define HEUR_STAMP(D, phase) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); (D).stats[8 + (phase)] += now_ - (D).stats[7]; (D).stats[7] = now_; } } while (0)
+#endif
 namespace whamd {
 __device__ __forceinline__ uint32_t heur_cas32(uint32_t* p, uint32_t cmp, uint32_t val) { return atomicCAS(p, cmp, val); }
 __device__ __forceinline__ void heur_min32(uint32_t* p, uint32_t v) { atomicMin(p, v); }
@@ -120,7 +124,7 @@ whamd_status_t heuristic_solve_device(const HeurPlan& pl, int device, HeurResult
 	HEUR_TRY(alloc((void**)&D.aux, cap * 4)); HEUR_TRY(alloc((void**)&D.val, cap * 4));
 	HEUR_TRY(alloc((void**)&D.col_off, (size_t)pl.n_cols * 8)); HEUR_TRY(alloc((void**)&D.col_count, (size_t)pl.n_cols * 4));
 	HEUR_TRY(alloc((void**)&D.opt_bipart, std::max<size_t>(pl.n_reads, 1))); HEUR_TRY(alloc((void**)&D.opt_trans, (size_t)pl.n_cols * 4));
-	HEUR_TRY(alloc((void**)&D.stats, 64));
+	HEUR_TRY(alloc((void**)&D.stats, 256));
 	HEUR_TRY(hipMemset(D.opt_bipart, 0, std::max<size_t>(pl.n_reads, 1)));
 	hipEvent_t ev0, ev1;
 	HEUR_TRY(hipEventCreate(&ev0));
@@ -129,7 +133,7 @@ whamd_status_t heuristic_solve_device(const HeurPlan& pl, int device, HeurResult
 	unsigned long long stride_sum = 0;
 	for (uint32_t p = 0; p < pl.n_cols; ++p) stride_sum += 2 + ((pl.n_new[p] + 31) >> 5);
 	unsigned long long arena_words = stride_sum * std::min<uint64_t>(cap, (uint64_t)pl.row_limit * 4u * T) + 1024;
-	unsigned long long stats[4] = {0, 0, 0, 0};
+	unsigned long long stats[32] = {0};
 	whamd_status_t status = WHAMD_OK;
 	for (;;) {
 		HEUR_TRY(hipMemGetInfo(&free_b, &total_b));
@@ -137,7 +141,7 @@ whamd_status_t heuristic_solve_device(const HeurPlan& pl, int device, HeurResult
 		void* arena = nullptr;
 		HEUR_TRY(hipMalloc(&arena, arena_words * 4));
 		D.arena = (uint32_t*)arena; D.arena_words = arena_words;
-		HEUR_TRY(hipMemset(D.stats, 0, 64));
+		HEUR_TRY(hipMemset(D.stats, 0, 256));
 		HEUR_TRY(hipEventRecord(ev0, nullptr));
 		// as many threads as the beam usually has solutions (a barrier costs with the number of waves): 2 x row_limit, 128 .. 1024
 		uint32_t block = 128;
@@ -153,6 +157,10 @@ whamd_status_t heuristic_solve_device(const HeurPlan& pl, int device, HeurResult
 		if (stats[0] == 1) { msg = "PedMecHeuristic: more tied solutions than the device pools hold (" + std::to_string(cap) + ")"; status = WHAMD_ERR_UNSUPPORTED; }
 		break;
 	}
+#ifdef WHAMD_HEURISTIC_STAMPS
+	fprintf(stderr, "[whamd heuristic stamps] cycles: hash %llu, project-copy %llu, read pass 1 %llu, read pass 2 %llu, filter %llu, transmissions %llu, phasing + record %llu; hash parts: init %llu, gather %llu\n",
+	        stats[8], stats[9], stats[10], stats[11], stats[12], stats[13], stats[14], stats[15], stats[16]);
+#endif
 	if (status == WHAMD_OK) {
 		float ms = 0;
 		(void)hipEventElapsedTime(&ms, ev0, ev1);
