@@ -28,6 +28,7 @@ namespace whamd {
 
 constexpr uint32_t HEUR_MAXS = 8;          // samples of one table
 constexpr uint32_t HEUR_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t HEUR_LDS_SCRATCH = 1024;   // beams up to this size: the per-solution scratch words (flags, ranks, slots, pruning values) in LDS
 constexpr uint32_t HEUR_LDS_BEAM = 1024;   // beams up to this size: hash table of the projection (2 x as many slots) and projected bipartitions in LDS
 
 // One pool of solutions (structure of arrays); two of them are used alternately.  Every array has the SOLUTION index innermost:
@@ -263,29 +264,29 @@ HEUR_FN inline void heur_copy_solution(const HeurDev& D, const HeurPool& src, ui
 }
 
 // filterSolutions (:604-622): pool[cur] (count) -> pool[cur ^ 1]; returns the new count.
-HEUR_FN inline uint32_t heur_filter(const HeurDev& D, uint32_t cur, uint32_t count, uint32_t w) {
+HEUR_FN inline uint32_t heur_filter(const HeurDev& D, uint32_t cur, uint32_t count, uint32_t w, float* val, uint32_t* aux, uint32_t* rank) {
 	const uint32_t tid = HEUR_TID, nt = HEUR_NT;
 	const HeurPool& src = D.pool[cur];
 	const HeurPool& dst = D.pool[cur ^ 1u];
-	for (uint32_t i = tid; i < count; i += nt) D.val[i] = src.score[i] + src.mut[i];
+	for (uint32_t i = tid; i < count; i += nt) val[i] = src.score[i] + src.mut[i];
 	HEUR_SYNC();
 	HEUR_SHARED uint32_t sh_low;
 	if (tid == 0) sh_low = 0xFFFFFFFFu;
 	HEUR_SYNC();
 	{
 		uint32_t low = 0xFFFFFFFFu;
-		for (uint32_t i = tid; i < count; i += nt) { const uint32_t key = heur_sortable(D.val[i]); low = key < low ? key : low; }
+		for (uint32_t i = tid; i < count; i += nt) { const uint32_t key = heur_sortable(val[i]); low = key < low ? key : low; }
 		heur_min32(&sh_low, low);
 	}
 	HEUR_SYNC();
 	const float lowest = heur_unsortable(sh_low);
-	const float too_high = count > D.row_limit ? heur_unsortable(heur_select(D.val, count, D.row_limit)) : __builtin_inff();
-	for (uint32_t i = tid; i < count; i += nt) D.aux[i] = (D.val[i] < too_high || D.val[i] == lowest) ? 1u : 0u;
+	const float too_high = count > D.row_limit ? heur_unsortable(heur_select(val, count, D.row_limit)) : __builtin_inff();
+	for (uint32_t i = tid; i < count; i += nt) aux[i] = (val[i] < too_high || val[i] == lowest) ? 1u : 0u;
 	HEUR_SYNC();
-	uint32_t kept = heur_scan(D.aux, D.rank, count);
+	uint32_t kept = heur_scan(aux, rank, count);
 	if (kept > HEUR_MAX_ROW_LIMIT) kept = HEUR_MAX_ROW_LIMIT;   // `kept.size() < MAX_ROW_LIMIT`: the first 65535 in order
 	for (uint32_t i = tid; i < count; i += nt)
-		if (D.aux[i] && D.rank[i] < kept) heur_copy_solution(D, src, i, dst, D.rank[i], w);
+		if (aux[i] && rank[i] < kept) heur_copy_solution(D, src, i, dst, rank[i], w);
 	HEUR_SYNC();
 	return kept;
 }
@@ -302,6 +303,15 @@ HEUR_FN inline void heur_solve(const HeurDev& D) {
 	// lastCol = { empty bipartition, transmission 0, score 0, balances (1, 0) }  (:151)
 	if (tid == 0) { D.pool[0].score[0] = 0.0f; D.pool[0].mut[0] = 0.0f; D.pool[0].trans[0] = 0; D.pool[0].bt[0] = 0; }
 	const size_t cap = D.cap;
+	// per-solution scratch of the phases: in LDS while the beam is small (every phase between two barriers otherwise starts with a
+	// round trip to L2 for a word the same thread wrote a phase earlier).  The stages below are generic lambdas instantiated for the
+	// LDS arrays and for the global ones -- pointers chosen at run time would turn every access into a FLAT instruction.
+	HEUR_SHARED uint32_t sh_aux[HEUR_LDS_SCRATCH], sh_rank[HEUR_LDS_SCRATCH], sh_slot[HEUR_LDS_SCRATCH];
+	HEUR_SHARED float sh_val[HEUR_LDS_SCRATCH];
+	auto filter = [&](uint32_t pool, uint32_t n, uint32_t w) -> uint32_t {
+		if (n <= HEUR_LDS_SCRATCH) return heur_filter(D, pool, n, w, sh_val, sh_aux, sh_rank);
+		return heur_filter(D, pool, n, w, D.val, D.aux, D.rank);
+	};
 	for (uint32_t x = tid; x < rows * wm; x += nt) D.pool[0].bal[x * cap] = 0.0f;
 	for (uint32_t x = tid; x < nw; x += nt) D.pool[0].bits[x * cap] = 0;
 	HEUR_SYNC();
@@ -324,7 +334,8 @@ HEUR_FN inline void heur_solve(const HeurDev& D) {
 			// (a generic lambda, instantiated for the LDS arrays and for the global ones: with pointers chosen at run time every access
 			// would be a FLAT instruction -- measured: the probe loop alone took a third of the column)
 			uint32_t n2 = 0;
-			auto project = [&](uint32_t* table, uint32_t* lead, unsigned long long* best, uint32_t* pbits, uint32_t* trans_stage, const uint32_t* ptrans, const size_t pst) {
+			auto project = [&](uint32_t* table, uint32_t* lead, unsigned long long* best, uint32_t* pbits, uint32_t* trans_stage, const uint32_t* ptrans, const size_t pst,
+			                   uint32_t* aux, uint32_t* rank, uint32_t* slot) {
 				for (uint32_t x = tid; x < tsz; x += nt) { table[x] = HEUR_EMPTY; lead[x] = HEUR_EMPTY; best[x] = ~0ull; }
 				HEUR_SYNC();
 				HEUR_STAMP(D, 7);
@@ -361,27 +372,28 @@ HEUR_FN inline void heur_solve(const HeurDev& D) {
 						if (same) break;
 						pos = (pos + 1u) & (tsz - 1u);
 					}
-					D.slot[i] = pos;
+					slot[i] = pos;
 					heur_min32(&lead[pos], i);
 					// updateSolution (:420-432): a later duplicate replaces the kept one only if strictly better
 					heur_min64(&best[pos], score_key);
 				}
 				HEUR_SYNC();
 				HEUR_STAMP(D, 0);
-				for (uint32_t i = tid; i < count; i += nt) D.aux[i] = heur_load32(&lead[D.slot[i]]) == i ? 1u : 0u;
+				for (uint32_t i = tid; i < count; i += nt) aux[i] = heur_load32(&lead[slot[i]]) == i ? 1u : 0u;
 				HEUR_SYNC();
-				n2 = heur_scan(D.aux, D.rank, count);
+				n2 = heur_scan(aux, rank, count);
 				for (uint32_t i = tid; i < count; i += nt) {
-					if (!D.aux[i]) continue;
-					const uint32_t j = D.rank[i], win = (uint32_t)heur_load64(&best[D.slot[i]]);
+					if (!aux[i]) continue;
+					const uint32_t j = rank[i], win = (uint32_t)heur_load64(&best[slot[i]]);
 					dst.score[j] = src.score[win]; dst.mut[j] = 0.0f; dst.trans[j] = src.trans[i]; dst.bt[j] = win;
 					for (uint32_t q = 0; q < nw; ++q) dst.bits[q * cap + j] = pbits[q * pst + i];
 					// balances of the winner without their first position, extended with zeros to the column's window (:204-206, :425-431)
 					for (uint32_t r = 0; r < rows; ++r) heur_copy_row(dst.bal + (size_t)r * wm * cap + j, src.bal + (size_t)r * wm * cap + win, cap, w, 1, w_prev);
 				}
 			};
-			if (in_lds) project(sh_table, sh_lead, sh_best, sh_pbits, sh_trans, sh_trans, (size_t)HEUR_LDS_BEAM);
-			else project(D.table, D.lead, D.best, D.pbits, nullptr, src.trans, cap);
+			if (in_lds && count <= HEUR_LDS_SCRATCH) project(sh_table, sh_lead, sh_best, sh_pbits, sh_trans, sh_trans, (size_t)HEUR_LDS_BEAM, sh_aux, sh_rank, sh_slot);
+			else if (in_lds) project(sh_table, sh_lead, sh_best, sh_pbits, sh_trans, sh_trans, (size_t)HEUR_LDS_BEAM, D.aux, D.rank, D.slot);
+			else project(D.table, D.lead, D.best, D.pbits, nullptr, src.trans, cap, D.aux, D.rank, D.slot);
 			HEUR_SYNC();
 			HEUR_STAMP(D, 1);
 			cur ^= 1u;
@@ -405,131 +417,143 @@ HEUR_FN inline void heur_solve(const HeurDev& D) {
 			const float* add = D.new_balance + D.new_bal_off[nr];
 			const int8_t* target = D.genotype + (size_t)s * D.n_cols + p;
 			if ((unsigned long long)count * 2ull > D.cap) { if (tid == 0) D.stats[0] = 1; return; }
-			// pass 1: both placements of the read scored per solution; aux = 0 keep side 0, 1 keep side 1, 2 keep both
-			for (uint32_t i = tid; i < count; i += nt) {
-				const float* bal = P.bal + i;
-				const float* b0 = bal + (size_t)(2 * s) * wm * cap;
-				const float* b1 = bal + (size_t)(2 * s + 1) * wm * cap;
-				// addBalance (src/pedmecheuristic.cpp:566-586; the penalty only, the rows are updated in pass 2) of the read on either
-				// haplotype, and the "useful" test of the untrusted-genotype mode (:256-258), in ONE pass over the two rows, eight positions at a time (all loads of a batch before the arithmetic that waits for them); each penalty is
-				// accumulated in the reference's order
-				bool useful = D.distrust ? false : D.new_useful[nr] != 0;
-				float pen0 = 0, pen1 = 0;
-				for (uint32_t x0 = 0; x0 < w; x0 += HEUR_BATCH) {
-					float v0[HEUR_BATCH], v1[HEUR_BATCH];
+			uint32_t n_app = 0;
+			auto place = [&](uint32_t* aux, uint32_t* rank, uint32_t* slot, float* val) {
+				// pass 1: both placements of the read scored per solution; aux = 0 keep side 0, 1 keep side 1, 2 keep both
+				for (uint32_t i = tid; i < count; i += nt) {
+					const float* bal = P.bal + i;
+					const float* b0 = bal + (size_t)(2 * s) * wm * cap;
+					const float* b1 = bal + (size_t)(2 * s + 1) * wm * cap;
+					// addBalance (src/pedmecheuristic.cpp:566-586; the penalty only, the rows are updated in pass 2) of the read on either
+					// haplotype, and the "useful" test of the untrusted-genotype mode (:256-258), in ONE pass over the two rows, eight positions
+					// at a time (all loads of a batch before the arithmetic that waits for them); each penalty is accumulated in the reference's order
+					bool useful = D.distrust ? false : D.new_useful[nr] != 0;
+					float pen0 = 0, pen1 = 0;
+					for (uint32_t x0 = 0; x0 < w; x0 += HEUR_BATCH) {
+						float v0[HEUR_BATCH], v1[HEUR_BATCH];
 #pragma unroll
-					for (uint32_t u = 0; u < HEUR_BATCH; ++u) {
-						v0[u] = x0 + u < w ? b0[(size_t)(x0 + u) * cap] : 0.0f;
-						v1[u] = x0 + u < w ? b1[(size_t)(x0 + u) * cap] : 0.0f;
-					}
+						for (uint32_t u = 0; u < HEUR_BATCH; ++u) {
+							v0[u] = x0 + u < w ? b0[(size_t)(x0 + u) * cap] : 0.0f;
+							v1[u] = x0 + u < w ? b1[(size_t)(x0 + u) * cap] : 0.0f;
+						}
 #pragma unroll
-					for (uint32_t u = 0; u < HEUR_BATCH; ++u) {
-						if (x0 + u >= w) continue;
-						const float a = add[x0 + u], s0 = v0[u], s1 = v1[u];
-						if (D.distrust) {
-							useful = useful || (a != 0 && s0 * s1 < 0) || ((a + s0) * s0 <= 0 && (a + s1) * s1 <= 0);
-							if (s0 * a < 0) pen0 += heur_min(heur_abs(s0), heur_abs(a));
-							if (s1 * a < 0) pen1 += heur_min(heur_abs(s1), heur_abs(a));
-						} else if (target[x0 + u] == 1) {
-							if (a <= 0) { pen0 += heur_min(-a, heur_max(s0 - s1, (float)0)); pen1 += heur_min(-a, heur_max(s1 - s0, (float)0)); }
-							else { pen0 += heur_min(a, heur_max(s1 - s0, (float)0)); pen1 += heur_min(a, heur_max(s0 - s1, (float)0)); }
-						} else {
-							const float t = heur_abs(a) * (float)(int)(a * (float)(target[x0 + u] - 1) < 0);
-							pen0 += t;
-							pen1 += t;
+						for (uint32_t u = 0; u < HEUR_BATCH; ++u) {
+							if (x0 + u >= w) continue;
+							const float a = add[x0 + u], s0 = v0[u], s1 = v1[u];
+							if (D.distrust) {
+								useful = useful || (a != 0 && s0 * s1 < 0) || ((a + s0) * s0 <= 0 && (a + s1) * s1 <= 0);
+								if (s0 * a < 0) pen0 += heur_min(heur_abs(s0), heur_abs(a));
+								if (s1 * a < 0) pen1 += heur_min(heur_abs(s1), heur_abs(a));
+							} else if (target[x0 + u] == 1) {
+								if (a <= 0) { pen0 += heur_min(-a, heur_max(s0 - s1, (float)0)); pen1 += heur_min(-a, heur_max(s1 - s0, (float)0)); }
+								else { pen0 += heur_min(a, heur_max(s1 - s0, (float)0)); pen1 += heur_min(a, heur_max(s0 - s1, (float)0)); }
+							} else {
+								const float t = heur_abs(a) * (float)(int)(a * (float)(target[x0 + u] - 1) < 0);
+								pen0 += t;
+								pen1 += t;
+							}
 						}
 					}
+					const uint32_t tr = P.trans[i];
+					const float sc = P.score[i];
+					float sc1 = 0, mu1 = 0;
+					if (seen) {
+						sc1 = sc + pen1;
+						mu1 = heur_mutation_cost(D, HeurBalView{bal, cap, wm, 2 * s + 1, add}, tr, p, true, 5, w);
+					}
+					const float sc0 = sc + pen0;
+					const float mu0 = heur_mutation_cost(D, HeurBalView{bal, cap, wm, 2 * s, add}, tr, p, true, 5, w);
+					uint32_t mode = 0;
+					if (seen) mode = useful ? 2u : ((sc0 + mu0 > sc1 + mu1) ? 1u : 0u);
+					aux[i] = mode;
+					// (scores of both sides kept for pass 2: val = side 1's score, rank slot reused below for its mutation score)
+					val[i] = sc1;
+					slot[i] = __builtin_bit_cast(uint32_t, mu1);
+					P.score[i] = mode == 1u ? sc1 : sc0;
+					P.mut[i] = mode == 1u ? mu1 : mu0;
 				}
-				const uint32_t tr = P.trans[i];
-				const float sc = P.score[i];
-				float sc1 = 0, mu1 = 0;
-				if (seen) {
-					sc1 = sc + pen1;
-					mu1 = heur_mutation_cost(D, HeurBalView{bal, cap, wm, 2 * s + 1, add}, tr, p, true, 5, w);
+				HEUR_SYNC();
+				HEUR_STAMP(D, 2);
+				for (uint32_t i = tid; i < count; i += nt) rank[i] = aux[i] == 2u ? 1u : 0u;
+				HEUR_SYNC();
+				n_app = heur_scan(rank, rank, count);
+				// pass 2: the copies (side 1) behind the existing solutions in their order, then the read joins its side in place
+				for (uint32_t i = tid; i < count; i += nt) {
+					if (aux[i] != 2u) continue;
+					const uint32_t j = count + rank[i];
+					heur_copy_solution(D, P, i, P, j, w);
+					P.score[j] = val[i];
+					P.mut[j] = __builtin_bit_cast(float, slot[i]);
+					heur_add_row(P.bal + (size_t)(2 * s + 1) * wm * cap + j, cap, add, w);
+					P.bits[(bitpos >> 5) * cap + j] |= 1u << (bitpos & 31u);
 				}
-				const float sc0 = sc + pen0;
-				const float mu0 = heur_mutation_cost(D, HeurBalView{bal, cap, wm, 2 * s, add}, tr, p, true, 5, w);
-				uint32_t mode = 0;
-				if (seen) mode = useful ? 2u : ((sc0 + mu0 > sc1 + mu1) ? 1u : 0u);
-				D.aux[i] = mode;
-				// (scores of both sides kept for pass 2: val = side 1's score, rank slot reused below for its mutation score)
-				D.val[i] = sc1;
-				D.slot[i] = __builtin_bit_cast(uint32_t, mu1);
-				P.score[i] = mode == 1u ? sc1 : sc0;
-				P.mut[i] = mode == 1u ? mu1 : mu0;
-			}
-			HEUR_SYNC();
-			HEUR_STAMP(D, 2);
-			for (uint32_t i = tid; i < count; i += nt) D.rank[i] = D.aux[i] == 2u ? 1u : 0u;
-			HEUR_SYNC();
-			const uint32_t n_app = heur_scan(D.rank, D.rank, count);
-			// pass 2: the copies (side 1) behind the existing solutions in their order, then the read joins its side in place
-			for (uint32_t i = tid; i < count; i += nt) {
-				if (D.aux[i] != 2u) continue;
-				const uint32_t j = count + D.rank[i];
-				heur_copy_solution(D, P, i, P, j, w);
-				P.score[j] = D.val[i];
-				P.mut[j] = __builtin_bit_cast(float, D.slot[i]);
-				heur_add_row(P.bal + (size_t)(2 * s + 1) * wm * cap + j, cap, add, w);
-				P.bits[(bitpos >> 5) * cap + j] |= 1u << (bitpos & 31u);
-			}
-			HEUR_SYNC();
-			for (uint32_t i = tid; i < count; i += nt) {
-				const uint32_t side = D.aux[i] == 1u ? 1u : 0u;
-				heur_add_row(P.bal + (size_t)(2 * s + side) * wm * cap + i, cap, add, w);
-				if (side) P.bits[(bitpos >> 5) * cap + i] |= 1u << (bitpos & 31u);
-			}
-			HEUR_SYNC();
+				HEUR_SYNC();
+				for (uint32_t i = tid; i < count; i += nt) {
+					const uint32_t side = aux[i] == 1u ? 1u : 0u;
+					heur_add_row(P.bal + (size_t)(2 * s + side) * wm * cap + i, cap, add, w);
+					if (side) P.bits[(bitpos >> 5) * cap + i] |= 1u << (bitpos & 31u);
+				}
+				HEUR_SYNC();
+			};
+			if (count <= HEUR_LDS_SCRATCH) place(sh_aux, sh_rank, sh_slot, sh_val);
+			else place(D.aux, D.rank, D.slot, D.val);
 			count += n_app;
 			HEUR_STAMP(D, 3);
-			if (count > D.row_limit) { count = heur_filter(D, cur, count, w); cur ^= 1u; }
+			if (count > D.row_limit) { count = filter(cur, count, w); cur ^= 1u; }
 			HEUR_STAMP(D, 4);
 		}
 		// ================= other transmission values where they pay for themselves (:299-303, :588-602)
 		{
 			const HeurPool& P = D.pool[cur];
 			const float rc1 = D.recomb[p];
-			for (uint32_t i = tid; i < count; i += nt) {
-				const HeurBalView B{P.bal + i, cap, wm, HEUR_EMPTY, nullptr};
-				const uint32_t tr = P.trans[i];
-				const float mu = heur_mutation_cost(D, B, tr, p, false, 0, w);
-				P.mut[i] = mu;
-				uint32_t n_ext = 0;
-				if (mu > 0) {
+			uint32_t n_app = 0;
+			bool overflow = false;
+			auto transmit = [&](uint32_t* aux, uint32_t* rank) {
+				for (uint32_t i = tid; i < count; i += nt) {
+					const HeurBalView B{P.bal + i, cap, wm, HEUR_EMPTY, nullptr};
+					const uint32_t tr = P.trans[i];
+					const float mu = heur_mutation_cost(D, B, tr, p, false, 0, w);
+					P.mut[i] = mu;
+					uint32_t n_ext = 0;
+					if (mu > 0) {
+						for (uint32_t t = 0; t < T; ++t) {
+							if (t == tr) continue;
+							const float rc = rc1 * (float)heur_popc(tr ^ t);
+							if (rc >= mu) continue;
+							const float m2 = heur_mutation_cost(D, B, t, p, false, 0, w);
+							if (m2 + rc >= mu) continue;
+							++n_ext;
+						}
+					}
+					aux[i] = n_ext;
+				}
+				HEUR_SYNC();
+				n_app = heur_scan(aux, rank, count);
+				if ((unsigned long long)count + n_app > D.cap) { if (tid == 0) D.stats[0] = 1; overflow = true; return; }
+				for (uint32_t i = tid; i < count; i += nt) {
+					if (!aux[i]) continue;
+					const HeurBalView B{P.bal + i, cap, wm, HEUR_EMPTY, nullptr};
+					const uint32_t tr = P.trans[i];
+					const float mu = P.mut[i], sc = P.score[i];
+					uint32_t j = count + rank[i];
 					for (uint32_t t = 0; t < T; ++t) {
 						if (t == tr) continue;
 						const float rc = rc1 * (float)heur_popc(tr ^ t);
 						if (rc >= mu) continue;
 						const float m2 = heur_mutation_cost(D, B, t, p, false, 0, w);
 						if (m2 + rc >= mu) continue;
-						++n_ext;
+						heur_copy_solution(D, P, i, P, j, w);
+						P.trans[j] = t; P.score[j] = sc + rc; P.mut[j] = m2;
+						++j;
 					}
 				}
-				D.aux[i] = n_ext;
-			}
-			HEUR_SYNC();
-			const uint32_t n_app = heur_scan(D.aux, D.rank, count);
-			if ((unsigned long long)count + n_app > D.cap) { if (tid == 0) D.stats[0] = 1; return; }
-			for (uint32_t i = tid; i < count; i += nt) {
-				if (!D.aux[i]) continue;
-				const HeurBalView B{P.bal + i, cap, wm, HEUR_EMPTY, nullptr};
-				const uint32_t tr = P.trans[i];
-				const float mu = P.mut[i], sc = P.score[i];
-				uint32_t j = count + D.rank[i];
-				for (uint32_t t = 0; t < T; ++t) {
-					if (t == tr) continue;
-					const float rc = rc1 * (float)heur_popc(tr ^ t);
-					if (rc >= mu) continue;
-					const float m2 = heur_mutation_cost(D, B, t, p, false, 0, w);
-					if (m2 + rc >= mu) continue;
-					heur_copy_solution(D, P, i, P, j, w);
-					P.trans[j] = t; P.score[j] = sc + rc; P.mut[j] = m2;
-					++j;
-				}
-			}
-			HEUR_SYNC();
+				HEUR_SYNC();
+			};
+			if (count <= HEUR_LDS_SCRATCH) transmit(sh_aux, sh_rank);
+			else transmit(D.aux, D.rank);
+			if (overflow) return;
 			count += n_app;
-			if (count > D.row_limit) { count = heur_filter(D, cur, count, w); cur ^= 1u; }
+			if (count > D.row_limit) { count = filter(cur, count, w); cur ^= 1u; }
 			HEUR_STAMP(D, 5);
 		}
 		// ================= the column's own phasing cost (:306-313), then the backtrace record of the column (:315-330)

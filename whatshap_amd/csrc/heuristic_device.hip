@@ -60,7 +60,8 @@ __device__ __forceinline__ unsigned long long heur_load64(const unsigned long lo
 namespace whamd {
 
 namespace {
-__global__ __launch_bounds__(1024) void heuristic_kernel(HeurDev D) { heur_solve(D); }
+template <int MAXT>
+__global__ __launch_bounds__(MAXT) void heuristic_kernel(HeurDev D) { heur_solve(D); }
 }  // namespace
 
 whamd_status_t heuristic_solve_device(const HeurPlan& pl, int device, HeurResult& out, std::string& msg) {
@@ -147,7 +148,10 @@ whamd_status_t heuristic_solve_device(const HeurPlan& pl, int device, HeurResult
 		uint32_t block = 128;
 		while (block < 1024u && block < 2u * pl.row_limit) block <<= 1;
 		if (const char* e = getenv("WHAMD_HEURISTIC_THREADS")) block = (uint32_t)std::max(64, std::min(1024, atoi(e)));
-		hipLaunchKernelGGL(heuristic_kernel, dim3(1), dim3(block), 0, nullptr, D);
+		// (compiled twice: up to 512 threads a thread may hold 256 VGPRs -- at the 128 of a 1024-thread workgroup the batches of the row
+		// copies spill to scratch memory)
+		if (block <= 512u) hipLaunchKernelGGL(heuristic_kernel<512>, dim3(1), dim3(block), 0, nullptr, D);
+		else hipLaunchKernelGGL(heuristic_kernel<1024>, dim3(1), dim3(block), 0, nullptr, D);
 		HEUR_TRY(hipEventRecord(ev1, nullptr));
 		hipError_t e = hipDeviceSynchronize();
 		if (e == hipSuccess) e = hipMemcpy(stats, D.stats, sizeof stats, hipMemcpyDeviceToHost);
