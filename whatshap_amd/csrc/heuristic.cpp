@@ -168,6 +168,7 @@ whamd_status_t build_heuristic_plan(const whamd_readset_view* rs, const uint32_t
 			pl.new_useful.push_back(useful ? 1 : 0);
 			pl.new_bal_off.push_back(pl.new_balance.size());
 			pl.new_balance.insert(pl.new_balance.end(), balances[i].begin(), balances[i].end());
+			for (uint32_t j = 0; j < w; ++j) pl.new_target.push_back((int32_t)pl.genotype[(size_t)s * n + p + j]);
 			seen[s] = 1;
 		}
 		active.swap(next);

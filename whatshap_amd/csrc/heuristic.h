@@ -42,6 +42,9 @@ struct HeurPlan {
 	std::vector<uint8_t> new_seen, new_useful; // sample seen before this read (:261, :291); "useful" of the trusted-genotype mode (:256-258)
 	std::vector<uint64_t> new_bal_off;         // into new_balance: window[p] floats
 	std::vector<float> new_balance;
+	std::vector<int32_t> new_target;           // parallel to new_balance: the sample's genotype at the window's positions (0 / 1 / 2), as words --
+	                                           // the solver reads them as wave-uniform scalars next to the balances (a byte per position
+	                                           // out of `genotype` was a dependent memory round trip per position on the device)
 	// for the final phasing (host, :361-406)
 	std::vector<uint32_t> sample_global_id;    // [n_samples]
 	std::vector<uint32_t> positions;           // [n_cols]

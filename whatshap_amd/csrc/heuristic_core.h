@@ -16,6 +16,7 @@
 // duplicate wins, which copy is kept, where the pruning threshold falls) are then the reference's.
 #pragma once
 #include <cstdint>
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -52,7 +53,7 @@ struct HeurDev {
 	const uint32_t* start_index;
 	const uint32_t *window, *n_kept, *kept_off, *n_new, *new_off, *kept;
 	const uint32_t* new_sample; const int32_t* new_equal_to; const uint8_t *new_seen, *new_useful;
-	const unsigned long long* new_bal_off; const float* new_balance;
+	const unsigned long long* new_bal_off; const float* new_balance; const int32_t* new_target;
 	// ---- state
 	HeurPool pool[2];
 	uint32_t cap;
@@ -234,7 +235,16 @@ HEUR_FN inline uint32_t heur_select(const float* val, uint32_t n, uint32_t k) {
 constexpr uint32_t HEUR_BATCH = 8;
 // dst[x] = x + shift < n_src ? src[x + shift] : 0   for x < w
 HEUR_FN inline void heur_copy_row(float* dst, const float* src, size_t st, uint32_t w, uint32_t shift, uint32_t n_src) {
-	for (uint32_t x0 = 0; x0 < w; x0 += HEUR_BATCH) {
+	uint32_t x0 = 0;
+	const uint32_t n_full = w < n_src - (n_src < shift ? n_src : shift) ? w : n_src - (n_src < shift ? n_src : shift);   // positions with a source
+	for (; x0 + HEUR_BATCH <= n_full; x0 += HEUR_BATCH) {   // whole batches inside the source: no per-element tests
+		float t[HEUR_BATCH];
+#pragma unroll
+		for (uint32_t u = 0; u < HEUR_BATCH; ++u) t[u] = src[(size_t)(x0 + u + shift) * st];
+#pragma unroll
+		for (uint32_t u = 0; u < HEUR_BATCH; ++u) dst[(size_t)(x0 + u) * st] = t[u];
+	}
+	for (; x0 < w; x0 += HEUR_BATCH) {
 		float t[HEUR_BATCH];
 #pragma unroll
 		for (uint32_t u = 0; u < HEUR_BATCH; ++u) t[u] = (x0 + u < w && x0 + u + shift < n_src) ? src[(size_t)(x0 + u + shift) * st] : 0.0f;
@@ -244,7 +254,18 @@ HEUR_FN inline void heur_copy_row(float* dst, const float* src, size_t st, uint3
 }
 // row[x] += add[x]   for x < w
 HEUR_FN inline void heur_add_row(float* row, size_t st, const float* add, uint32_t w) {
-	for (uint32_t x0 = 0; x0 < w; x0 += HEUR_BATCH) {
+	uint32_t x0 = 0;
+	for (; x0 + HEUR_BATCH <= w; x0 += HEUR_BATCH) {
+		float t[HEUR_BATCH];
+#pragma unroll
+		for (uint32_t u = 0; u < HEUR_BATCH; ++u) t[u] = row[(size_t)(x0 + u) * st];
+		float a[HEUR_BATCH];
+#pragma unroll
+		for (uint32_t u = 0; u < HEUR_BATCH; ++u) a[u] = add[x0 + u];
+#pragma unroll
+		for (uint32_t u = 0; u < HEUR_BATCH; ++u) row[(size_t)(x0 + u) * st] = t[u] + a[u];
+	}
+	for (; x0 < w; x0 += HEUR_BATCH) {
 		float t[HEUR_BATCH];
 #pragma unroll
 		for (uint32_t u = 0; u < HEUR_BATCH; ++u) t[u] = x0 + u < w ? row[(size_t)(x0 + u) * st] + add[x0 + u] : 0.0f;
@@ -415,7 +436,7 @@ HEUR_FN inline void heur_solve(const HeurDev& D) {
 			const uint32_t s = D.new_sample[nr];
 			const bool seen = D.new_seen[nr] != 0;
 			const float* add = D.new_balance + D.new_bal_off[nr];
-			const int8_t* target = D.genotype + (size_t)s * D.n_cols + p;
+			const int32_t* target = D.new_target + D.new_bal_off[nr];   // genotype of sample s at the window's positions
 			if ((unsigned long long)count * 2ull > D.cap) { if (tid == 0) D.stats[0] = 1; return; }
 			uint32_t n_app = 0;
 			auto place = [&](uint32_t* aux, uint32_t* rank, uint32_t* slot, float* val) {
@@ -429,31 +450,40 @@ HEUR_FN inline void heur_solve(const HeurDev& D) {
 					// at a time (all loads of a batch before the arithmetic that waits for them); each penalty is accumulated in the reference's order
 					bool useful = D.distrust ? false : D.new_useful[nr] != 0;
 					float pen0 = 0, pen1 = 0;
-					for (uint32_t x0 = 0; x0 < w; x0 += HEUR_BATCH) {
-						float v0[HEUR_BATCH], v1[HEUR_BATCH];
+					auto batch = [&](const uint32_t x0, auto whole) {   // whole batches carry no per-position tests
+						constexpr bool WHOLE = decltype(whole)::value;
+						// (the read's balance and the genotype of the position are loaded with the batch as well: fetched where they are used,
+						// each was one more dependent round trip per position)
+						float v0[HEUR_BATCH], v1[HEUR_BATCH], av[HEUR_BATCH];
+						int32_t tv[HEUR_BATCH];
 #pragma unroll
 						for (uint32_t u = 0; u < HEUR_BATCH; ++u) {
-							v0[u] = x0 + u < w ? b0[(size_t)(x0 + u) * cap] : 0.0f;
-							v1[u] = x0 + u < w ? b1[(size_t)(x0 + u) * cap] : 0.0f;
+							v0[u] = (WHOLE || x0 + u < w) ? b0[(size_t)(x0 + u) * cap] : 0.0f;
+							v1[u] = (WHOLE || x0 + u < w) ? b1[(size_t)(x0 + u) * cap] : 0.0f;
+							av[u] = (WHOLE || x0 + u < w) ? add[x0 + u] : 0.0f;
+							tv[u] = (WHOLE || x0 + u < w) ? target[x0 + u] : 0;
 						}
 #pragma unroll
 						for (uint32_t u = 0; u < HEUR_BATCH; ++u) {
-							if (x0 + u >= w) continue;
-							const float a = add[x0 + u], s0 = v0[u], s1 = v1[u];
+							if (!WHOLE && x0 + u >= w) continue;
+							const float a = av[u], s0 = v0[u], s1 = v1[u];
 							if (D.distrust) {
 								useful = useful || (a != 0 && s0 * s1 < 0) || ((a + s0) * s0 <= 0 && (a + s1) * s1 <= 0);
 								if (s0 * a < 0) pen0 += heur_min(heur_abs(s0), heur_abs(a));
 								if (s1 * a < 0) pen1 += heur_min(heur_abs(s1), heur_abs(a));
-							} else if (target[x0 + u] == 1) {
+							} else if (tv[u] == 1) {
 								if (a <= 0) { pen0 += heur_min(-a, heur_max(s0 - s1, (float)0)); pen1 += heur_min(-a, heur_max(s1 - s0, (float)0)); }
 								else { pen0 += heur_min(a, heur_max(s1 - s0, (float)0)); pen1 += heur_min(a, heur_max(s0 - s1, (float)0)); }
 							} else {
-								const float t = heur_abs(a) * (float)(int)(a * (float)(target[x0 + u] - 1) < 0);
+								const float t = heur_abs(a) * (float)(int)(a * (float)(tv[u] - 1) < 0);
 								pen0 += t;
 								pen1 += t;
 							}
 						}
-					}
+					};
+					uint32_t xb = 0;
+					for (; xb + HEUR_BATCH <= w; xb += HEUR_BATCH) batch(xb, std::true_type{});
+					if (xb < w) batch(xb, std::false_type{});
 					const uint32_t tr = P.trans[i];
 					const float sc = P.score[i];
 					float sc1 = 0, mu1 = 0;

@@ -112,7 +112,7 @@ whamd_status_t heuristic_solve_device(const HeurPlan& pl, int device, HeurResult
 	HEUR_UP(kept_off, pl.kept_off, const uint32_t*); HEUR_UP(n_new, pl.n_new, const uint32_t*); HEUR_UP(new_off, pl.new_off, const uint32_t*);
 	HEUR_UP(kept, pl.kept, const uint32_t*); HEUR_UP(new_sample, pl.new_sample, const uint32_t*); HEUR_UP(new_equal_to, pl.new_equal_to, const int32_t*);
 	HEUR_UP(new_seen, pl.new_seen, const uint8_t*); HEUR_UP(new_useful, pl.new_useful, const uint8_t*);
-	HEUR_UP(new_bal_off, pl.new_bal_off, const unsigned long long*); HEUR_UP(new_balance, pl.new_balance, const float*);
+	HEUR_UP(new_bal_off, pl.new_bal_off, const unsigned long long*); HEUR_UP(new_balance, pl.new_balance, const float*); HEUR_UP(new_target, pl.new_target, const int32_t*);
 #undef HEUR_UP
 	for (int q = 0; q < 2; ++q) {
 		HEUR_TRY(alloc((void**)&D.pool[q].score, cap * 4)); HEUR_TRY(alloc((void**)&D.pool[q].mut, cap * 4));

@@ -59,7 +59,7 @@ whamd_status_t heuristic_solve_host(const HeurPlan& pl, HeurResult& out, std::st
 	D.recomb = pl.recomb.data(); D.mutation = pl.mutation.data(); D.genotype = pl.genotype.data(); D.start_index = pl.start_index.data();
 	D.window = pl.window.data(); D.n_kept = pl.n_kept.data(); D.kept_off = pl.kept_off.data(); D.n_new = pl.n_new.data(); D.new_off = pl.new_off.data();
 	D.kept = pl.kept.data(); D.new_sample = pl.new_sample.data(); D.new_equal_to = pl.new_equal_to.data(); D.new_seen = pl.new_seen.data();
-	D.new_useful = pl.new_useful.data(); D.new_bal_off = reinterpret_cast<const unsigned long long*>(pl.new_bal_off.data()); D.new_balance = pl.new_balance.data();
+	D.new_useful = pl.new_useful.data(); D.new_bal_off = reinterpret_cast<const unsigned long long*>(pl.new_bal_off.data()); D.new_balance = pl.new_balance.data(); D.new_target = pl.new_target.data();
 	D.cap = cap; D.pbits = pbits.data(); D.table = table.data(); D.lead = lead.data(); D.best = best.data(); D.tsz = tsz;
 	D.slot = slot.data(); D.rank = rank.data(); D.aux = aux.data(); D.val = val.data();
 	D.arena = arena.data(); D.arena_words = arena_words; D.col_off = col_off.data(); D.col_count = col_count.data();
