@@ -252,6 +252,22 @@ HEUR_FN inline void heur_copy_row(float* dst, const float* src, size_t st, uint3
 		for (uint32_t u = 0; u < HEUR_BATCH; ++u) if (x0 + u < w) dst[(size_t)(x0 + u) * st] = t[u];
 	}
 }
+// the same for the two rows of one sample at once (rows come in pairs: haplotype 0 / 1): sixteen loads in flight per batch
+HEUR_FN inline void heur_copy_row_pair(float* dst, const float* src, size_t st, size_t row_st, uint32_t w, uint32_t shift, uint32_t n_src) {
+	uint32_t x0 = 0;
+	const uint32_t n_full = w < n_src - (n_src < shift ? n_src : shift) ? w : n_src - (n_src < shift ? n_src : shift);
+	for (; x0 + HEUR_BATCH <= n_full; x0 += HEUR_BATCH) {
+		float t[HEUR_BATCH], u2[HEUR_BATCH];
+#pragma unroll
+		for (uint32_t u = 0; u < HEUR_BATCH; ++u) { t[u] = src[(size_t)(x0 + u + shift) * st]; u2[u] = src[row_st + (size_t)(x0 + u + shift) * st]; }
+#pragma unroll
+		for (uint32_t u = 0; u < HEUR_BATCH; ++u) { dst[(size_t)(x0 + u) * st] = t[u]; dst[row_st + (size_t)(x0 + u) * st] = u2[u]; }
+	}
+	if (x0 < w) {
+		heur_copy_row(dst + (size_t)x0 * st, src + (size_t)x0 * st, st, w - x0, shift, n_src > x0 ? n_src - x0 : 0u);
+		heur_copy_row(dst + row_st + (size_t)x0 * st, src + row_st + (size_t)x0 * st, st, w - x0, shift, n_src > x0 ? n_src - x0 : 0u);
+	}
+}
 // row[x] += add[x]   for x < w
 HEUR_FN inline void heur_add_row(float* row, size_t st, const float* add, uint32_t w) {
 	uint32_t x0 = 0;
@@ -281,7 +297,7 @@ HEUR_FN inline void heur_copy_solution(const HeurDev& D, const HeurPool& src, ui
 	const size_t cap = D.cap;
 	for (uint32_t q = 0; q < D.nw; ++q) dst.bits[q * cap + j] = src.bits[q * cap + i];
 	const uint32_t rows = 2u * D.n_samples;
-	for (uint32_t r = 0; r < rows; ++r) heur_copy_row(dst.bal + (size_t)r * D.w_max * cap + j, src.bal + (size_t)r * D.w_max * cap + i, cap, w, 0, w);
+	for (uint32_t r = 0; r < rows; r += 2) heur_copy_row_pair(dst.bal + (size_t)r * D.w_max * cap + j, src.bal + (size_t)r * D.w_max * cap + i, cap, (size_t)D.w_max * cap, w, 0, w);
 }
 
 // filterSolutions (:604-622): pool[cur] (count) -> pool[cur ^ 1]; returns the new count.
@@ -409,7 +425,7 @@ HEUR_FN inline void heur_solve(const HeurDev& D) {
 					dst.score[j] = src.score[win]; dst.mut[j] = 0.0f; dst.trans[j] = src.trans[i]; dst.bt[j] = win;
 					for (uint32_t q = 0; q < nw; ++q) dst.bits[q * cap + j] = pbits[q * pst + i];
 					// balances of the winner without their first position, extended with zeros to the column's window (:204-206, :425-431)
-					for (uint32_t r = 0; r < rows; ++r) heur_copy_row(dst.bal + (size_t)r * wm * cap + j, src.bal + (size_t)r * wm * cap + win, cap, w, 1, w_prev);
+					for (uint32_t r = 0; r < rows; r += 2) heur_copy_row_pair(dst.bal + (size_t)r * wm * cap + j, src.bal + (size_t)r * wm * cap + win, cap, (size_t)wm * cap, w, 1, w_prev);
 				}
 			};
 			if (in_lds && count <= HEUR_LDS_SCRATCH) project(sh_table, sh_lead, sh_best, sh_pbits, sh_trans, sh_trans, (size_t)HEUR_LDS_BEAM, sh_aux, sh_rank, sh_slot);
@@ -538,11 +554,43 @@ HEUR_FN inline void heur_solve(const HeurDev& D) {
 			const float rc1 = D.recomb[p];
 			uint32_t n_app = 0;
 			bool overflow = false;
+			// getMutationCost of a transmission value without flips looks at the FIRST position only (:438-468 with ahead = 0): per trio the
+			// child's two balances and both haplotypes of either parent -- six words, loaded once per solution and kept in registers for
+			// every transmission value tried (fetched inside heur_mutation_cost they were four dependent round trips per value and trio)
+			constexpr uint32_t TRIO_CACHE = 3;
+			const bool cached = D.n_trios <= TRIO_CACHE;
+			struct TrioFirsts { float v[TRIO_CACHE][6]; };
+			auto load_firsts = [&](uint32_t i, TrioFirsts& c) {
+#pragma unroll
+				for (uint32_t k = 0; k < TRIO_CACHE; ++k) {
+					if (k >= D.n_trios) continue;
+					const uint32_t t0 = D.trios[3 * k], t1 = D.trios[3 * k + 1], t2 = D.trios[3 * k + 2];
+					const float* b = P.bal + i;
+					c.v[k][0] = b[(size_t)(2 * t2) * wm * cap]; c.v[k][1] = b[(size_t)(2 * t2 + 1) * wm * cap];
+					c.v[k][2] = b[(size_t)(2 * t0) * wm * cap]; c.v[k][3] = b[(size_t)(2 * t0 + 1) * wm * cap];
+					c.v[k][4] = b[(size_t)(2 * t1) * wm * cap]; c.v[k][5] = b[(size_t)(2 * t1 + 1) * wm * cap];
+				}
+			};
+			const float mc1 = D.mutation[p];
+			auto cost_of = [&](uint32_t i, const TrioFirsts& c, uint32_t t) -> float {
+				if (!cached) return heur_mutation_cost(D, HeurBalView{P.bal + i, cap, wm, HEUR_EMPTY, nullptr}, t, p, false, 0, w);
+				float cost = 0.0f;
+#pragma unroll
+				for (uint32_t k = 0; k < TRIO_CACHE; ++k) {
+					if (k >= D.n_trios) continue;
+					const uint32_t m2c = (t >> (2 * k)) & 1u, f2c = (t >> (2 * k + 1)) & 1u;
+					const float cm = c.v[k][0], cf = c.v[k][1], m = m2c ? c.v[k][3] : c.v[k][2], f = f2c ? c.v[k][5] : c.v[k][4];
+					cost += (float)(int)(cm * m < 0) * mc1;
+					cost += (float)(int)(cf * f < 0) * mc1;
+				}
+				return cost;
+			};
 			auto transmit = [&](uint32_t* aux, uint32_t* rank) {
 				for (uint32_t i = tid; i < count; i += nt) {
-					const HeurBalView B{P.bal + i, cap, wm, HEUR_EMPTY, nullptr};
+					TrioFirsts c;
+					if (cached) load_firsts(i, c);
 					const uint32_t tr = P.trans[i];
-					const float mu = heur_mutation_cost(D, B, tr, p, false, 0, w);
+					const float mu = cost_of(i, c, tr);
 					P.mut[i] = mu;
 					uint32_t n_ext = 0;
 					if (mu > 0) {
@@ -550,7 +598,7 @@ HEUR_FN inline void heur_solve(const HeurDev& D) {
 							if (t == tr) continue;
 							const float rc = rc1 * (float)heur_popc(tr ^ t);
 							if (rc >= mu) continue;
-							const float m2 = heur_mutation_cost(D, B, t, p, false, 0, w);
+							const float m2 = cost_of(i, c, t);
 							if (m2 + rc >= mu) continue;
 							++n_ext;
 						}
@@ -562,7 +610,8 @@ HEUR_FN inline void heur_solve(const HeurDev& D) {
 				if ((unsigned long long)count + n_app > D.cap) { if (tid == 0) D.stats[0] = 1; overflow = true; return; }
 				for (uint32_t i = tid; i < count; i += nt) {
 					if (!aux[i]) continue;
-					const HeurBalView B{P.bal + i, cap, wm, HEUR_EMPTY, nullptr};
+					TrioFirsts c;
+					if (cached) load_firsts(i, c);
 					const uint32_t tr = P.trans[i];
 					const float mu = P.mut[i], sc = P.score[i];
 					uint32_t j = count + rank[i];
@@ -570,7 +619,7 @@ HEUR_FN inline void heur_solve(const HeurDev& D) {
 						if (t == tr) continue;
 						const float rc = rc1 * (float)heur_popc(tr ^ t);
 						if (rc >= mu) continue;
-						const float m2 = heur_mutation_cost(D, B, t, p, false, 0, w);
+						const float m2 = cost_of(i, c, t);
 						if (m2 + rc >= mu) continue;
 						heur_copy_solution(D, P, i, P, j, w);
 						P.trans[j] = t; P.score[j] = sc + rc; P.mut[j] = m2;
