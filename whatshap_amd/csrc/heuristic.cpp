@@ -178,4 +178,16 @@ whamd_status_t build_heuristic_plan(const whamd_readset_view* rs, const uint32_t
 	return WHAMD_OK;
 }
 
+std::vector<HeurColMeta> heuristic_col_meta(const HeurPlan& pl) {
+	std::vector<HeurColMeta> out(pl.n_cols);
+	for (uint32_t p = 0; p < pl.n_cols; ++p) out[p] = HeurColMeta{pl.window[p], pl.n_kept[p], pl.kept_off[p], pl.n_new[p], pl.new_off[p], {0, 0, 0}};
+	return out;
+}
+
+std::vector<HeurReadMeta> heuristic_read_meta(const HeurPlan& pl) {
+	std::vector<HeurReadMeta> out(pl.new_sample.size());
+	for (size_t r = 0; r < out.size(); ++r) out[r] = HeurReadMeta{pl.new_sample[r], pl.new_equal_to[r], pl.new_seen[r], pl.new_useful[r], pl.new_bal_off[r], {0, 0}};
+	return out;
+}
+
 }  // namespace whamd

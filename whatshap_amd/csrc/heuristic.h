@@ -55,6 +55,12 @@ struct HeurPlan {
 	std::vector<uint32_t> read_sample;         // rank per read
 };
 
+// What the solver reads per column / per starting read, one 32-byte record each (the device kernel fetches a record with one scalar
+// load; as separate arrays they were five dependent loads and ten kernel-argument registers).
+struct HeurColMeta { uint32_t window, n_kept, kept_off, n_new, new_off, pad[3]; };
+struct HeurReadMeta { uint32_t sample; int32_t equal_to; uint32_t seen, useful; uint64_t bal_off; uint32_t pad[2]; };
+static_assert(sizeof(HeurColMeta) == 32 && sizeof(HeurReadMeta) == 32, "one scalar load each");
+
 struct HeurResult {
 	float score = 0.0f;                        // getOptScore(): the reference never assigns it, it stays 0 (:19, :338-346)
 	std::vector<uint8_t> bipartition;          // [n_reads] getOptBipartition() bits
@@ -65,6 +71,8 @@ struct HeurResult {
 	double device_ms = 0.0;
 };
 
+std::vector<HeurColMeta> heuristic_col_meta(const struct HeurPlan& plan);
+std::vector<HeurReadMeta> heuristic_read_meta(const struct HeurPlan& plan);
 whamd_status_t build_heuristic_plan(const whamd_readset_view* rs, const uint32_t* recombcost, size_t n_recombcost, const whamd_pedigree_view* ped,
                                     bool distrust, const uint32_t* positions, size_t n_positions, uint32_t row_limit, bool allow_mutations,
                                     HeurPlan& plan, std::string& msg);

@@ -44,28 +44,24 @@ struct HeurPool {
 	float* bal;        // [2 S][w_max][cap]
 };
 
+// Everything the kernel is handed, small enough to stay in scalar registers (as one pointer per array -- 45 of them -- the structure
+// took 125 SGPRs and the compiler kept it in VGPR lanes: a v_readlane in front of most memory instructions).
 struct HeurDev {
 	// ---- plan (heuristic.h HeurPlan)
 	uint32_t n_cols, n_samples, n_trios, tm_bits, row_limit, distrust, w_max, nw;
-	uint32_t trios[3 * HEUR_MAXS];
+	uint32_t cap, tsz;             // solutions a pool holds; hash slots allocated
+	const uint32_t* trios;         // [3 n_trios] sample ranks: mother-side parent, father-side parent, child (heuristic.h)
 	const float* recomb; const float* mutation;
 	const int8_t* genotype;
 	const uint32_t* start_index;
-	const uint32_t *window, *n_kept, *kept_off, *n_new, *new_off, *kept;
-	const uint32_t* new_sample; const int32_t* new_equal_to; const uint8_t *new_seen, *new_useful;
-	const unsigned long long* new_bal_off; const float* new_balance; const int32_t* new_target;
-	// ---- state
-	HeurPool pool[2];
-	uint32_t cap;
-	uint32_t* pbits;               // [nw][cap] projected bipartitions (beams of up to HEUR_LDS_BEAM solutions keep them in LDS)
-	uint32_t* table;               // [tsz] hash slots: a member of the slot's group
-	uint32_t* lead;                // [tsz] smallest member index
-	unsigned long long* best;      // [tsz] min (sortable score << 32 | index)
-	uint32_t tsz;
-	uint32_t* slot;                // [cap]
-	uint32_t* rank;                // [cap] scan results
-	uint32_t* aux;                 // [cap] per-solution scratch (mode / count / source index)
-	float* val;                    // [cap] score + mutationScore of the pruning
+	const HeurColMeta* col;        // [n_cols]
+	const uint32_t* kept;
+	const HeurReadMeta* reads;     // per starting read
+	const float* new_balance; const int32_t* new_target;
+	// ---- state: one block of words per pool / for the scratch arrays / for the hash table (heur_pool and the accessors below)
+	uint32_t* pool_words[2];       // score | mut | trans | bt | bits [nw] | bal [2 S][w_max], each [cap]
+	uint32_t* scratch;             // slot | rank | aux | val | pbits [nw], each [cap]
+	uint32_t* hash;                // table [tsz] | lead [tsz] | best [tsz] (64-bit)
 	// ---- records (backtrace): per column `stride` words per solution: btRow, trans, bits of the new reads
 	uint32_t* arena; unsigned long long arena_words;
 	unsigned long long* col_off; uint32_t* col_count;
@@ -73,6 +69,22 @@ struct HeurDev {
 	uint8_t* opt_bipart; uint32_t* opt_trans;
 	unsigned long long* stats;     // [0] status (0 ok, 1 pool overflow, 2 arena overflow), [1] widest column, [2] sum of the column sizes
 };
+constexpr size_t heur_pool_words(uint32_t cap, uint32_t nw, uint32_t n_samples, uint32_t w_max) { return (size_t)cap * (4u + nw + 2u * n_samples * w_max); }
+constexpr size_t heur_scratch_words(uint32_t cap, uint32_t nw) { return (size_t)cap * (4u + nw); }
+constexpr size_t heur_hash_words(uint32_t tsz) { return (size_t)tsz * 4u; }
+HEUR_FN inline HeurPool heur_pool(const HeurDev& D, uint32_t q) {
+	uint32_t* b = q ? D.pool_words[1] : D.pool_words[0];
+	const size_t cap = D.cap;
+	return HeurPool{reinterpret_cast<float*>(b), reinterpret_cast<float*>(b + cap), b + 2 * cap, b + 3 * cap, b + 4 * cap, reinterpret_cast<float*>(b + (4 + D.nw) * cap)};
+}
+HEUR_FN inline uint32_t* heur_slot(const HeurDev& D) { return D.scratch; }                                  // [cap] hash slot / side-1 mutation score
+HEUR_FN inline uint32_t* heur_rank(const HeurDev& D) { return D.scratch + (size_t)D.cap; }                  // [cap] scan results
+HEUR_FN inline uint32_t* heur_aux(const HeurDev& D) { return D.scratch + 2 * (size_t)D.cap; }               // [cap] flags / counts
+HEUR_FN inline float* heur_val(const HeurDev& D) { return reinterpret_cast<float*>(D.scratch + 3 * (size_t)D.cap); }   // [cap] pruning values
+HEUR_FN inline uint32_t* heur_pbits(const HeurDev& D) { return D.scratch + 4 * (size_t)D.cap; }             // [nw][cap] projected bipartitions
+HEUR_FN inline uint32_t* heur_table(const HeurDev& D) { return D.hash; }                                    // [tsz] a member of the slot's group
+HEUR_FN inline uint32_t* heur_lead(const HeurDev& D) { return D.hash + D.tsz; }                             // [tsz] smallest member index
+HEUR_FN inline unsigned long long* heur_best(const HeurDev& D) { return reinterpret_cast<unsigned long long*>(D.hash + 2 * (size_t)D.tsz); }   // [tsz] min (score, index)
 
 HEUR_FN inline uint32_t heur_sortable(float f) {
 	uint32_t u = __builtin_bit_cast(uint32_t, f);
@@ -303,8 +315,8 @@ HEUR_FN inline void heur_copy_solution(const HeurDev& D, const HeurPool& src, ui
 // filterSolutions (:604-622): pool[cur] (count) -> pool[cur ^ 1]; returns the new count.
 HEUR_FN inline uint32_t heur_filter(const HeurDev& D, uint32_t cur, uint32_t count, uint32_t w, float* val, uint32_t* aux, uint32_t* rank) {
 	const uint32_t tid = HEUR_TID, nt = HEUR_NT;
-	const HeurPool& src = D.pool[cur];
-	const HeurPool& dst = D.pool[cur ^ 1u];
+	const HeurPool src = heur_pool(D, cur);
+	const HeurPool dst = heur_pool(D, cur ^ 1u);
 	for (uint32_t i = tid; i < count; i += nt) val[i] = src.score[i] + src.mut[i];
 	HEUR_SYNC();
 	HEUR_SHARED uint32_t sh_low;
@@ -338,7 +350,8 @@ HEUR_FN inline void heur_solve(const HeurDev& D) {
 	uint32_t cur = 0, count = 1, w_prev = 1;
 	unsigned long long arena_used = 0, widest = 0, total = 0;
 	// lastCol = { empty bipartition, transmission 0, score 0, balances (1, 0) }  (:151)
-	if (tid == 0) { D.pool[0].score[0] = 0.0f; D.pool[0].mut[0] = 0.0f; D.pool[0].trans[0] = 0; D.pool[0].bt[0] = 0; }
+	const HeurPool first = heur_pool(D, 0);
+	if (tid == 0) { first.score[0] = 0.0f; first.mut[0] = 0.0f; first.trans[0] = 0; first.bt[0] = 0; }
 	const size_t cap = D.cap;
 	// per-solution scratch of the phases: in LDS while the beam is small (every phase between two barriers otherwise starts with a
 	// round trip to L2 for a word the same thread wrote a phase earlier).  The stages below are generic lambdas instantiated for the
@@ -347,19 +360,20 @@ HEUR_FN inline void heur_solve(const HeurDev& D) {
 	HEUR_SHARED float sh_val[HEUR_LDS_SCRATCH];
 	auto filter = [&](uint32_t pool, uint32_t n, uint32_t w) -> uint32_t {
 		if (n <= HEUR_LDS_SCRATCH) return heur_filter(D, pool, n, w, sh_val, sh_aux, sh_rank);
-		return heur_filter(D, pool, n, w, D.val, D.aux, D.rank);
+		return heur_filter(D, pool, n, w, heur_val(D), heur_aux(D), heur_rank(D));
 	};
-	for (uint32_t x = tid; x < rows * wm; x += nt) D.pool[0].bal[x * cap] = 0.0f;
-	for (uint32_t x = tid; x < nw; x += nt) D.pool[0].bits[x * cap] = 0;
+	for (uint32_t x = tid; x < rows * wm; x += nt) first.bal[x * cap] = 0.0f;
+	for (uint32_t x = tid; x < nw; x += nt) first.bits[x * cap] = 0;
 	HEUR_SYNC();
 	HEUR_STAMP_BEGIN(D);
 	for (uint32_t p = 0; p < D.n_cols; ++p) {
-		const uint32_t w = D.window[p], nk = D.n_kept[p], nn = D.n_new[p];
-		const uint32_t* kept = D.kept + D.kept_off[p];
+		const HeurColMeta cm = D.col[p];
+		const uint32_t w = cm.window, nk = cm.n_kept, nn = cm.n_new;
+		const uint32_t* kept = D.kept + cm.kept_off;
 		// ================= projection onto the reads that continue, duplicates merged into their first occurrence (:170-197)
 		{
-			const HeurPool& src = D.pool[cur];
-			const HeurPool& dst = D.pool[cur ^ 1u];
+			const HeurPool src = heur_pool(D, cur);
+			const HeurPool dst = heur_pool(D, cur ^ 1u);
 			uint32_t tsz = 64;
 			while (tsz < 2u * count) tsz <<= 1;
 			// the usual beam: hash table and projected bipartitions in LDS (its atomics do not leave the CU)
@@ -429,8 +443,8 @@ HEUR_FN inline void heur_solve(const HeurDev& D) {
 				}
 			};
 			if (in_lds && count <= HEUR_LDS_SCRATCH) project(sh_table, sh_lead, sh_best, sh_pbits, sh_trans, sh_trans, (size_t)HEUR_LDS_BEAM, sh_aux, sh_rank, sh_slot);
-			else if (in_lds) project(sh_table, sh_lead, sh_best, sh_pbits, sh_trans, sh_trans, (size_t)HEUR_LDS_BEAM, D.aux, D.rank, D.slot);
-			else project(D.table, D.lead, D.best, D.pbits, nullptr, src.trans, cap, D.aux, D.rank, D.slot);
+			else if (in_lds) project(sh_table, sh_lead, sh_best, sh_pbits, sh_trans, sh_trans, (size_t)HEUR_LDS_BEAM, heur_aux(D), heur_rank(D), heur_slot(D));
+			else project(heur_table(D), heur_lead(D), heur_best(D), heur_pbits(D), nullptr, src.trans, cap, heur_aux(D), heur_rank(D), heur_slot(D));
 			HEUR_SYNC();
 			HEUR_STAMP(D, 1);
 			cur ^= 1u;
@@ -438,10 +452,11 @@ HEUR_FN inline void heur_solve(const HeurDev& D) {
 		}
 		// ================= the reads that start here, one after the other (:240-297)
 		for (uint32_t q = 0; q < nn; ++q) {
-			const uint32_t nr = D.new_off[p] + q;
-			const int32_t eq = D.new_equal_to[nr];
+			const uint32_t nr = cm.new_off + q;
+			const HeurReadMeta rm = D.reads[nr];
+			const int32_t eq = rm.equal_to;
 			const uint32_t bitpos = nk + q;
-			const HeurPool& P = D.pool[cur];
+			const HeurPool P = heur_pool(D, cur);
 			if (eq >= 0) {   // identical to an earlier read of the column: same side, no branching (:247-250)
 				for (uint32_t i = tid; i < count; i += nt) {
 					if (heur_get_bit(P.bits, cap, i, nk + (uint32_t)eq)) P.bits[(bitpos >> 5) * cap + i] |= 1u << (bitpos & 31u);
@@ -449,10 +464,10 @@ HEUR_FN inline void heur_solve(const HeurDev& D) {
 				HEUR_SYNC();
 				continue;
 			}
-			const uint32_t s = D.new_sample[nr];
-			const bool seen = D.new_seen[nr] != 0;
-			const float* add = D.new_balance + D.new_bal_off[nr];
-			const int32_t* target = D.new_target + D.new_bal_off[nr];   // genotype of sample s at the window's positions
+			const uint32_t s = rm.sample;
+			const bool seen = rm.seen != 0;
+			const float* add = D.new_balance + rm.bal_off;
+			const int32_t* target = D.new_target + rm.bal_off;   // genotype of sample s at the window's positions
 			if ((unsigned long long)count * 2ull > D.cap) { if (tid == 0) D.stats[0] = 1; return; }
 			uint32_t n_app = 0;
 			auto place = [&](uint32_t* aux, uint32_t* rank, uint32_t* slot, float* val) {
@@ -464,7 +479,7 @@ HEUR_FN inline void heur_solve(const HeurDev& D) {
 					// addBalance (src/pedmecheuristic.cpp:566-586; the penalty only, the rows are updated in pass 2) of the read on either
 					// haplotype, and the "useful" test of the untrusted-genotype mode (:256-258), in ONE pass over the two rows, eight positions
 					// at a time (all loads of a batch before the arithmetic that waits for them); each penalty is accumulated in the reference's order
-					bool useful = D.distrust ? false : D.new_useful[nr] != 0;
+					bool useful = D.distrust ? false : rm.useful != 0;
 					float pen0 = 0, pen1 = 0;
 					auto batch = [&](const uint32_t x0, auto whole) {   // whole batches carry no per-position tests
 						constexpr bool WHOLE = decltype(whole)::value;
@@ -542,7 +557,7 @@ HEUR_FN inline void heur_solve(const HeurDev& D) {
 				HEUR_SYNC();
 			};
 			if (count <= HEUR_LDS_SCRATCH) place(sh_aux, sh_rank, sh_slot, sh_val);
-			else place(D.aux, D.rank, D.slot, D.val);
+			else place(heur_aux(D), heur_rank(D), heur_slot(D), heur_val(D));
 			count += n_app;
 			HEUR_STAMP(D, 3);
 			if (count > D.row_limit) { count = filter(cur, count, w); cur ^= 1u; }
@@ -550,7 +565,7 @@ HEUR_FN inline void heur_solve(const HeurDev& D) {
 		}
 		// ================= other transmission values where they pay for themselves (:299-303, :588-602)
 		{
-			const HeurPool& P = D.pool[cur];
+			const HeurPool P = heur_pool(D, cur);
 			const float rc1 = D.recomb[p];
 			uint32_t n_app = 0;
 			bool overflow = false;
@@ -629,7 +644,7 @@ HEUR_FN inline void heur_solve(const HeurDev& D) {
 				HEUR_SYNC();
 			};
 			if (count <= HEUR_LDS_SCRATCH) transmit(sh_aux, sh_rank);
-			else transmit(D.aux, D.rank);
+			else transmit(heur_aux(D), heur_rank(D));
 			if (overflow) return;
 			count += n_app;
 			if (count > D.row_limit) { count = filter(cur, count, w); cur ^= 1u; }
@@ -637,7 +652,7 @@ HEUR_FN inline void heur_solve(const HeurDev& D) {
 		}
 		// ================= the column's own phasing cost (:306-313), then the backtrace record of the column (:315-330)
 		{
-			const HeurPool& P = D.pool[cur];
+			const HeurPool P = heur_pool(D, cur);
 			const uint32_t nwn = (nn + 31u) >> 5, stride = 2u + nwn;
 			if (arena_used + (unsigned long long)count * stride > D.arena_words) { if (tid == 0) D.stats[0] = 2; return; }
 			uint32_t* rec = D.arena + arena_used;
@@ -662,15 +677,16 @@ HEUR_FN inline void heur_solve(const HeurDev& D) {
 	}
 	// ================= best solution of the last column: the first with the smallest score (:332-341), then the walk back (:343-359)
 	{
-		const HeurPool& P = D.pool[cur];
-		if (tid == 0) D.best[0] = ~0ull;
+		const HeurPool P = heur_pool(D, cur);
+		unsigned long long* best = heur_best(D);
+		if (tid == 0) best[0] = ~0ull;
 		HEUR_SYNC();
-		for (uint32_t i = tid; i < count; i += nt) heur_min64(&D.best[0], ((unsigned long long)heur_sortable(P.score[i]) << 32) | i);
+		for (uint32_t i = tid; i < count; i += nt) heur_min64(&best[0], ((unsigned long long)heur_sortable(P.score[i]) << 32) | i);
 		HEUR_SYNC();
 		if (tid == 0) {
-			uint32_t ri = (uint32_t)heur_load64(&D.best[0]);
+			uint32_t ri = (uint32_t)heur_load64(&best[0]);
 			for (uint32_t p = D.n_cols; p-- > 0;) {
-				const uint32_t nn = D.n_new[p], nwn = (nn + 31u) >> 5, stride = 2u + nwn;
+				const uint32_t nn = D.col[p].n_new, nwn = (nn + 31u) >> 5, stride = 2u + nwn;
 				const uint32_t* e = D.arena + D.col_off[p] + (size_t)ri * stride;
 				for (uint32_t q = 0; q < nn; ++q) D.opt_bipart[D.start_index[p] + q] = (uint8_t)((e[2 + (q >> 5)] >> (q & 31u)) & 1u);
 				D.opt_trans[p] = e[1];

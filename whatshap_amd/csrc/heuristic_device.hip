@@ -104,25 +104,19 @@ whamd_status_t heuristic_solve_device(const HeurPlan& pl, int device, HeurResult
 	HeurDev D{};
 	D.n_cols = pl.n_cols; D.n_samples = pl.n_samples; D.n_trios = pl.n_trios; D.tm_bits = pl.tm_bits; D.row_limit = pl.row_limit;
 	D.distrust = pl.distrust; D.w_max = pl.w_max; D.nw = pl.nw;
-	for (size_t q = 0; q < pl.trios.size(); ++q) D.trios[q] = pl.trios[q];
+	const std::vector<HeurColMeta> col_meta = heuristic_col_meta(pl);
+	const std::vector<HeurReadMeta> read_meta = heuristic_read_meta(pl);
 	void* d = nullptr;
 #define HEUR_UP(field, vec, type) HEUR_TRY(up(&d, (vec).data(), (vec).size() * sizeof((vec)[0]))); D.field = (type)d
+	HEUR_UP(trios, pl.trios, const uint32_t*);
 	HEUR_UP(recomb, pl.recomb, const float*); HEUR_UP(mutation, pl.mutation, const float*); HEUR_UP(genotype, pl.genotype, const int8_t*);
-	HEUR_UP(start_index, pl.start_index, const uint32_t*); HEUR_UP(window, pl.window, const uint32_t*); HEUR_UP(n_kept, pl.n_kept, const uint32_t*);
-	HEUR_UP(kept_off, pl.kept_off, const uint32_t*); HEUR_UP(n_new, pl.n_new, const uint32_t*); HEUR_UP(new_off, pl.new_off, const uint32_t*);
-	HEUR_UP(kept, pl.kept, const uint32_t*); HEUR_UP(new_sample, pl.new_sample, const uint32_t*); HEUR_UP(new_equal_to, pl.new_equal_to, const int32_t*);
-	HEUR_UP(new_seen, pl.new_seen, const uint8_t*); HEUR_UP(new_useful, pl.new_useful, const uint8_t*);
-	HEUR_UP(new_bal_off, pl.new_bal_off, const unsigned long long*); HEUR_UP(new_balance, pl.new_balance, const float*); HEUR_UP(new_target, pl.new_target, const int32_t*);
+	HEUR_UP(start_index, pl.start_index, const uint32_t*); HEUR_UP(col, col_meta, const HeurColMeta*); HEUR_UP(kept, pl.kept, const uint32_t*);
+	HEUR_UP(reads, read_meta, const HeurReadMeta*); HEUR_UP(new_balance, pl.new_balance, const float*); HEUR_UP(new_target, pl.new_target, const int32_t*);
 #undef HEUR_UP
-	for (int q = 0; q < 2; ++q) {
-		HEUR_TRY(alloc((void**)&D.pool[q].score, cap * 4)); HEUR_TRY(alloc((void**)&D.pool[q].mut, cap * 4));
-		HEUR_TRY(alloc((void**)&D.pool[q].trans, cap * 4)); HEUR_TRY(alloc((void**)&D.pool[q].bt, cap * 4));
-		HEUR_TRY(alloc((void**)&D.pool[q].bits, cap * pl.nw * 4)); HEUR_TRY(alloc((void**)&D.pool[q].bal, cap * rows * pl.w_max * 4));
-	}
 	D.cap = (uint32_t)cap; D.tsz = tsz;
-	HEUR_TRY(alloc((void**)&D.pbits, cap * pl.nw * 4)); HEUR_TRY(alloc((void**)&D.table, (size_t)tsz * 4)); HEUR_TRY(alloc((void**)&D.lead, (size_t)tsz * 4));
-	HEUR_TRY(alloc((void**)&D.best, (size_t)tsz * 8)); HEUR_TRY(alloc((void**)&D.slot, cap * 4)); HEUR_TRY(alloc((void**)&D.rank, cap * 4));
-	HEUR_TRY(alloc((void**)&D.aux, cap * 4)); HEUR_TRY(alloc((void**)&D.val, cap * 4));
+	for (int q = 0; q < 2; ++q) HEUR_TRY(alloc((void**)&D.pool_words[q], heur_pool_words(D.cap, pl.nw, pl.n_samples, pl.w_max) * 4));
+	HEUR_TRY(alloc((void**)&D.scratch, heur_scratch_words(D.cap, pl.nw) * 4));
+	HEUR_TRY(alloc((void**)&D.hash, heur_hash_words(tsz) * 4));
 	HEUR_TRY(alloc((void**)&D.col_off, (size_t)pl.n_cols * 8)); HEUR_TRY(alloc((void**)&D.col_count, (size_t)pl.n_cols * 4));
 	HEUR_TRY(alloc((void**)&D.opt_bipart, std::max<size_t>(pl.n_reads, 1))); HEUR_TRY(alloc((void**)&D.opt_trans, (size_t)pl.n_cols * 4));
 	HEUR_TRY(alloc((void**)&D.stats, 256));

@@ -34,34 +34,27 @@ whamd_status_t heuristic_solve_host(const HeurPlan& pl, HeurResult& out, std::st
 	// small inputs only: capacity for a beam that never prunes below 2^12 solutions
 	const uint32_t T = 1u << pl.tm_bits;
 	const uint32_t cap = std::min<uint32_t>(HEUR_MAX_ROW_LIMIT, std::max<uint32_t>(pl.row_limit, 4096u)) * std::max(2u, T);
-	const size_t rows = 2u * pl.n_samples;
-	std::vector<float> score[2], mut[2], bal[2], val(cap);
-	std::vector<uint32_t> trans[2], bt[2], bits[2], pbits((size_t)cap * pl.nw), slot(cap), rank(cap), aux(cap);
 	HeurDev D{};
-	for (int q = 0; q < 2; ++q) {
-		score[q].assign(cap, 0); mut[q].assign(cap, 0); trans[q].assign(cap, 0); bt[q].assign(cap, 0);
-		bits[q].assign((size_t)cap * pl.nw, 0); bal[q].assign((size_t)cap * rows * pl.w_max, 0);
-		D.pool[q] = HeurPool{score[q].data(), mut[q].data(), trans[q].data(), bt[q].data(), bits[q].data(), bal[q].data()};
-	}
+	D.n_cols = pl.n_cols; D.n_samples = pl.n_samples; D.n_trios = pl.n_trios; D.tm_bits = pl.tm_bits; D.row_limit = pl.row_limit;
+	D.distrust = pl.distrust; D.w_max = pl.w_max; D.nw = pl.nw;
 	uint32_t tsz = 64;
 	while (tsz < 2u * cap) tsz <<= 1;
-	std::vector<uint32_t> table(tsz), lead(tsz);
-	std::vector<unsigned long long> best(tsz);
+	D.cap = cap; D.tsz = tsz;
+	std::vector<uint32_t> pool0(heur_pool_words(cap, pl.nw, pl.n_samples, pl.w_max), 0), pool1(pool0.size(), 0), scratch(heur_scratch_words(cap, pl.nw), 0);
+	std::vector<unsigned long long> hash(heur_hash_words(tsz) / 2 + 1, 0);   // (64-bit elements: the `best` part is aligned)
+	D.pool_words[0] = pool0.data(); D.pool_words[1] = pool1.data(); D.scratch = scratch.data(); D.hash = reinterpret_cast<uint32_t*>(hash.data());
 	unsigned long long arena_words = 0;
 	for (uint32_t p = 0; p < pl.n_cols; ++p) arena_words += (unsigned long long)(2 + ((pl.n_new[p] + 31) >> 5));
 	arena_words *= cap;
 	arena_words = std::min<unsigned long long>(arena_words, 1ull << 28);
 	std::vector<uint32_t> arena(arena_words), col_count(pl.n_cols);
 	std::vector<unsigned long long> col_off(pl.n_cols), stats(4, 0);
-	D.n_cols = pl.n_cols; D.n_samples = pl.n_samples; D.n_trios = pl.n_trios; D.tm_bits = pl.tm_bits; D.row_limit = pl.row_limit;
-	D.distrust = pl.distrust; D.w_max = pl.w_max; D.nw = pl.nw;
-	for (size_t q = 0; q < pl.trios.size(); ++q) D.trios[q] = pl.trios[q];
+	const std::vector<HeurColMeta> col_meta = heuristic_col_meta(pl);
+	const std::vector<HeurReadMeta> read_meta = heuristic_read_meta(pl);
+	D.trios = pl.trios.data();
 	D.recomb = pl.recomb.data(); D.mutation = pl.mutation.data(); D.genotype = pl.genotype.data(); D.start_index = pl.start_index.data();
-	D.window = pl.window.data(); D.n_kept = pl.n_kept.data(); D.kept_off = pl.kept_off.data(); D.n_new = pl.n_new.data(); D.new_off = pl.new_off.data();
-	D.kept = pl.kept.data(); D.new_sample = pl.new_sample.data(); D.new_equal_to = pl.new_equal_to.data(); D.new_seen = pl.new_seen.data();
-	D.new_useful = pl.new_useful.data(); D.new_bal_off = reinterpret_cast<const unsigned long long*>(pl.new_bal_off.data()); D.new_balance = pl.new_balance.data(); D.new_target = pl.new_target.data();
-	D.cap = cap; D.pbits = pbits.data(); D.table = table.data(); D.lead = lead.data(); D.best = best.data(); D.tsz = tsz;
-	D.slot = slot.data(); D.rank = rank.data(); D.aux = aux.data(); D.val = val.data();
+	D.col = col_meta.data(); D.kept = pl.kept.data(); D.reads = read_meta.data();
+	D.new_balance = pl.new_balance.data(); D.new_target = pl.new_target.data();
 	D.arena = arena.data(); D.arena_words = arena_words; D.col_off = col_off.data(); D.col_count = col_count.data();
 	D.opt_bipart = out.bipartition.data(); D.opt_trans = out.transmission.data(); D.stats = stats.data();
 	heur_solve(D);
@@ -90,7 +83,7 @@ void heuristic_finish(const HeurPlan& pl, HeurResult& out) {
 		}
 	HeurDev D{};
 	D.n_cols = n; D.n_samples = S; D.n_trios = pl.n_trios; D.distrust = pl.distrust;
-	for (size_t q = 0; q < pl.trios.size(); ++q) D.trios[q] = pl.trios[q];
+	D.trios = pl.trios.data();
 	D.mutation = pl.mutation.data(); D.genotype = pl.genotype.data();
 	for (uint32_t p = 0; p < n; ++p) {
 		uint8_t phase[HEUR_MAXS] = {0}, mut[2 * HEUR_MAXS] = {0};
