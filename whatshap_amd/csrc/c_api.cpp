@@ -390,7 +390,7 @@ whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uin
 				s.max_lds_bytes = std::max<uint64_t>(s.max_lds_bytes, (2ull * run.threads + (PSLOT_MAXCOLS + 4) * 8 + (uint64_t)(run.threads >> 6) * (ex.arow + 4u * p.T * ex.nf) + (uint64_t)(run.ncols + 4) * 64 * ex.nf) * 4);
 				s.backtrace_bytes += ((uint64_t)ex.rec_words * 4) << run.g;
 			} else {
-				s.max_lds_bytes = std::max<uint64_t>(s.max_lds_bytes, 2ull * run.threads * (1u << run.lr) * 4 + (SLOT_MAXCOLS + 8) * 64 + 8 * 64 * 4 + SLOT_MAXCOLS * 64 * 4);
+				s.max_lds_bytes = std::max<uint64_t>(s.max_lds_bytes, 2ull * run.threads * (1u << run.lr) * 4 + (SLOT_MAXCOLS + 8) * 64 + 8 * 64 * 4 + (SLOT_MAXCOLS + 8) * 64 * 4);
 				s.backtrace_bytes += (uint64_t)run.n_ends * run.threads * (1ull << (run.g - run.half));
 			}
 			if (run.half) s.n_halved_runs++;

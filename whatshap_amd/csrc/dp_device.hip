@@ -920,7 +920,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 					e.cur = lane.d_pr[c.flip ^ 1];
 					e.score_out = (last && !job.final) ? m.d_job_scores + job_id : nullptr;
 					ss.io[0] = lane.d_pr[c.flip]; ss.io[1] = lane.d_pr[c.flip ^ 1];
-					ss.lds = std::max<size_t>(ss.lds, (size_t)2 * e.run.threads * (1u << e.run.lr) * 4 + (SLOT_MAXCOLS + 8) * 64 + 8 * 64 * 4 + SLOT_MAXCOLS * 64 * 4);
+					ss.lds = std::max<size_t>(ss.lds, (size_t)2 * e.run.threads * (1u << e.run.lr) * 4 + (SLOT_MAXCOLS + 8) * 64 + 8 * 64 * 4 + (SLOT_MAXCOLS + 8) * 64 * 4);
 					e.pad = step.index;
 					ss.grid_x = std::max(ss.grid_x, 1u << (e.run.g - e.run.half));
 					ss.threads = std::max(ss.threads, e.run.threads);
@@ -1150,7 +1150,7 @@ void DeviceTable::Impl::launch_slot_run(const SlotBatchEntry& e, uint64_t& launc
 		launches += 1;
 		return;
 	}
-	const size_t lds = (size_t)2 * run.threads * (1u << run.lr) * 4 + (SLOT_MAXCOLS + 8) * 64 + 8 * 64 * 4 + SLOT_MAXCOLS * 64 * 4;   // wave-slot exchange + hot lines + per-wave A + lane sums
+	const size_t lds = (size_t)2 * run.threads * (1u << run.lr) * 4 + (SLOT_MAXCOLS + 8) * 64 + 8 * 64 * 4 + (SLOT_MAXCOLS + 8) * 64 * 4;   // wave-slot exchange + hot lines + per-wave A + lane sums
 	const dim3 grid(1u << (run.g - run.half)), block(run.threads);
 	const bool dbg = m.dp.dbg != nullptr || m.dp.dbg_flags != 0;
 #define WHAMD_SLOT_LAUNCH(LRV, DBGV, SPECV) hipLaunchKernelGGL((slot_run<LRV, DBGV, SPECV>), grid, block, lds, m.stream, m.dp, run, e.prev, e.cur, e.score_out)

@@ -140,28 +140,32 @@ __global__ __launch_bounds__(512) void pedslot_run(DevProblem P, SlotRun run, Pe
 		if (i < n_s4) reinterpret_cast<uint4*>(s_lds)[i] = sp[u];
 	}
 	for (uint32_t i = 2u * threads + tid; i < n_s4; i += threads) reinterpret_cast<uint4*>(s_lds)[i] = tabS[i];
-	slot_u32x8 ctrlq = *(slot_cptr8)(unsigned long long)(P.slot_ctrl + run.ctrl_off);   // one control byte per column (PSLOT_MAXCOLS = 32)
+	// one control byte per column (PSLOT_MAXCOLS = 32): the eight words sit in the lanes of ONE vector register, a trip fetches its word
+	// with a v_readlane (as a queue of SGPRs rotated by scalar moves it cost nine instructions per trip, kernels_slots.h)
+	const uint32_t ctrl_v = P.slot_ctrl[run.ctrl_off + (lane & 7u)];
 	uint32_t* __restrict__ rec = reinterpret_cast<uint32_t*>(P.bt + (((unsigned long long)run.rec_hi << 32) | run.rec_lo)) + (size_t)w * ex.rec_words + tid;
 	uint32_t xsel = 0;
 	uint32_t tbit[TB > 0 ? TB : 1];
 #pragma unroll
 	for (int s = 0; s < TB; ++s) tbit[s] = (t >> s) & 1u;
-	// (the control words must have arrived BEFORE the loop: scalar loads share the LDS counter and return out of order, a pending
-	// one would turn every counted wait of the column loop into a full drain)
-	asm volatile("" ::"s"(ctrlq[0]), "s"(ctrlq[1]), "s"(ctrlq[2]), "s"(ctrlq[3]), "s"(ctrlq[4]), "s"(ctrlq[5]), "s"(ctrlq[6]), "s"(ctrlq[7]));
 	__syncthreads();
 
 	// What a column needs from LDS, requested ahead (LDS returns in order): {recomb, M0} of the hot line (wave-uniform words in
 	// VECTOR registers, see kernels_slots.h), the lane's NF entries of A and of S.
 	struct Line { uint2 h; uint32_t a[NF]; uint32_t s[NF]; };
 	const uint32_t a_base = wave * (ex.arow + 4u * T * NF) + t * NF;
-	auto load_line = [&](uint32_t c) -> Line {
+	// (lines are requested in column order: three running word offsets advance by a constant per request -- kernels_slots.h; the one of
+	// the hot line starts from an opaque move so that the compiler does not learn that its loads are wave-uniform)
+	uint32_t hot_at = 0, a_at = a_base, s_at = lane * NF;
+	asm volatile("" : "+v"(hot_at));
+	auto load_line = [&](uint32_t) -> Line {   // (the argument documents which column a call site requests: always the next one)
 		Line ln;
-		uint32_t off = c * 8u;
-		asm volatile("" : "+v"(off));
-		ln.h = *reinterpret_cast<const uint2*>(hot_lds + off);
-		const uint32_t* ap = a_lds + a_base + c * (T * NF);
-		const uint32_t* spn = s_lds + (c * 64u + lane) * NF;
+		ln.h = *reinterpret_cast<const uint2*>(hot_lds + hot_at);
+		const uint32_t* ap = a_lds + a_at;
+		const uint32_t* spn = s_lds + s_at;
+		hot_at += 8u;
+		a_at += T * NF;
+		s_at += 64u * NF;
 		if (NF == 2) {
 			const uint2 av = *reinterpret_cast<const uint2*>(ap), sv = *reinterpret_cast<const uint2*>(spn);
 			ln.a[0] = av.x; ln.a[1] = av.y; ln.s[0] = sv.x; ln.s[1] = sv.y;
@@ -230,8 +234,7 @@ __global__ __launch_bounds__(512) void pedslot_run(DevProblem P, SlotRun run, Pe
 		// four columns per trip (one control word, one record word); every line is requested three columns ahead
 		Line h0 = load_line(0), h1 = load_line(1), h2 = load_line(2), h3;
 		for (uint32_t ci = 0; ci < ncols; ci += 4u) {
-			const uint32_t cw = ctrlq[0];
-			ctrlq = __builtin_shufflevector(ctrlq, ctrlq, 1, 2, 3, 4, 5, 6, 7, 0);
+			const uint32_t cw = (uint32_t)__builtin_amdgcn_readlane((int)ctrl_v, (int)(ci >> 2));
 			recacc = 0;
 			h3 = load_line(ci + 3u);      // (lines beyond the run may be read: the LDS areas have room, the values are not used)
 			column(h0, ci, cw & 255u, 0);

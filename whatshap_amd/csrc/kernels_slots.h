@@ -152,7 +152,9 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 	uint32_t* sl_lds = hot_lds + (SLOT_MAXCOLS + 8) * 16 + 8 * 64;   // [column][lane]: lane part of S, the same for every wave
 	if (tid < ncols * 16u) reinterpret_cast<uint4*>(sl_lds)[tid] = sl_piece;
 	for (uint32_t i = tid + run.threads; i < ncols * 16u; i += run.threads) reinterpret_cast<uint4*>(sl_lds)[i] = sl_src[i];   // narrow workgroups, long runs
-	slot_u32x16 ctrlq = *(slot_cptr16)(unsigned long long)(P.slot_ctrl + run.ctrl_off);
+	// the run's 16 control words (one byte per column), one per lane: the word of a trip is fetched with ONE v_readlane (a queue of 16
+	// SGPRs rotated with scalar moves was 17 instructions per trip of four columns -- an eighth of a plain column's instructions)
+	const uint32_t ctrl_v = P.slot_ctrl[run.ctrl_off + (lane & 15u)];
 	uint8_t* __restrict__ rec = P.bt + (((unsigned long long)run.rec_hi << 32) | run.rec_lo) + (size_t)w * run.n_ends * run.threads + tid;
 	const uint32_t threads = run.threads;
 	const uint32_t xwords = threads * R;   // one exchange buffer
@@ -168,18 +170,21 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 	// What a column needs from LDS, requested one column ahead: {K, Cc, dreg0, dreg1} (+ dreg2), {info0, M0} of the first ending
 	// read (wave-uniform words in VECTOR registers: operands of the cell arithmetic as they are) and the thread's own A.
 	struct HotLine { uint4 a; uint32_t d2; uint2 e; uint32_t A; };
-	auto load_hot = [&](uint32_t c) -> HotLine {
-		// (offsets go through an opaque move: the compiler must not learn that these loads are wave-uniform, or it selects
-		// scalar instructions for what is derived from them and pays a v_readfirstlane for every operand)
-		uint32_t off = c * 16u;
-		asm volatile("" : "+v"(off));
+	// The lines are requested in column order, so three running word offsets (hot line, A of the wave, lane sum) advance by a constant
+	// per request: three adds instead of rebuilding each address from the column number (5 vector + 3 scalar instructions of the ~34 a
+	// plain column took).  They start from an opaque move: the compiler must not learn that the hot-line loads are wave-uniform, or it
+	// selects scalar instructions for what is derived from them and pays a v_readfirstlane for every operand.
+	uint32_t hot_at = 0, a_at = 0, sl_at = lane;
+	asm volatile("" : "+v"(hot_at), "+v"(a_at), "+v"(sl_at));
+	auto load_hot = [&](uint32_t) -> HotLine {   // (the argument documents which column a call site requests: always the next one)
 		HotLine h;
-		h.a = *reinterpret_cast<const uint4*>(hot_lds + off);
-		h.d2 = LR > 2 ? hot_lds[off + 4u] : 0u;
-		h.e = *reinterpret_cast<const uint2*>(hot_lds + off + 12u);
-		uint32_t aoff = c & 63u;
-		asm volatile("" : "+v"(aoff));
-		h.A = a_lds[aoff] + sl_lds[(c & 63u) * 64u + lane];
+		h.a = *reinterpret_cast<const uint4*>(hot_lds + hot_at);
+		h.d2 = LR > 2 ? hot_lds[hot_at + 4u] : 0u;
+		h.e = *reinterpret_cast<const uint2*>(hot_lds + hot_at + 12u);
+		h.A = a_lds[a_at] + sl_lds[sl_at];
+		hot_at += 16u;
+		a_at += 1u;
+		sl_at += 64u;
 		return h;
 	};
 	// One column for the calling thread's cells.  The hot words are wave-uniform values in VECTOR registers: operands of the
@@ -197,9 +202,8 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 		const uint32_t n_end = (DBG && (P.dbg_flags & 8u)) ? 0u : (ctrl & 3u);
 		// one ending read: `slot` is a scalar (control flow), info / M are wave-uniform vector values
 		auto ending = [&](const uint32_t info, const uint32_t M, const uint32_t slot) {
-			const uint32_t qmask = (info >> 8) & 0xFFFFu, mflip = (info >> 24) & 1u;
+			const uint32_t qmask = (info >> 8) & 0xFFFFu;   // (lane / wave slots: the side term of the parity is folded into M by the planner)
 			uint32_t qthr = (uint32_t)__popc(Pthr & M) & 1u;
-			if (slot >= (uint32_t)LR) qthr ^= ((Pthr >> slot) & 1u) & mflip;
 			uint32_t takes;
 			if (slot < (uint32_t)LR) {
 				if (slot == 0) takes = slot_end_reg<LR, 0>(D, qthr, qmask);
@@ -265,10 +269,8 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 		// in order, the waits count down) and no register is copied
 		HotLine h0 = load_hot(0), h1 = load_hot(1), h2 = load_hot(2), h3;
 		for (uint32_t ci = 0; ci < nc; ci += 4u) {
-			// control word of columns ci .. ci + 3: the head of the queue of 16 words held in SGPRs (rotated with scalar moves;
-			// a dynamically indexed register array would go through VGPRs or scratch)
-			const uint32_t cw = ctrlq[0];
-			ctrlq = __builtin_shufflevector(ctrlq, ctrlq, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 0);
+			// control word of columns ci .. ci + 3
+			const uint32_t cw = (uint32_t)__builtin_amdgcn_readlane((int)ctrl_v, (int)(ci >> 2));
 			h3 = load_hot(ci + 3u);        // (lines beyond the run may be read: the LDS areas have room, the values are not used)
 			column(h0, ci, cw & 255u);
 			if (ci + 1u >= nc) break;

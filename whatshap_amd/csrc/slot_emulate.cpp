@@ -107,7 +107,7 @@ bool emulate_slot_plan(const Problem& p, const SlotPlan& plan, std::vector<uint3
 				for (uint32_t P = 0; P < ncell; ++P) {
 					const uint32_t Pthr = P & ~(R - 1u), r = P & (R - 1u);
 					uint32_t qthr = (uint32_t)__builtin_popcount(Pthr & M) & 1u;
-					if (slot >= LRr) qthr ^= bit(Pthr, slot) & mflip;
+					(void)mflip;   // (lane / wave slots: folded into M by the planner)
 					const uint32_t qq = qthr ^ bit(qmask, r);
 					const uint32_t other = D[P ^ (1u << slot)];
 					const uint32_t w = P >> L, tid = (P & ((1u << L) - 1u)) >> LRr;

@@ -234,7 +234,9 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 				}
 				if (en < (uint32_t)SLOT_MAXEND) {
 					row.end[en].info = (uint32_t)s | (qmask << 8) | (mflip << 24);
-					row.end[en].M = M;
+					// (a read in a lane / wave slot: the kernel's parity also takes (side & mflip) -- the side is bit s of the thread's index,
+					// which is not in M, so it is folded into the mask: one AND + popcount instead of a shift, two ANDs, a select and a XOR)
+					row.end[en].M = s >= lr ? M ^ (mflip << s) : M;
 				}
 				if (ped && !genotype_mode) {   // (the kernel's cell index has no reg bits: M as it is)
 					if (en == 0) { prow.info0 = (uint32_t)s; prow.M0 = M; }
