@@ -86,6 +86,52 @@ struct UploadStage {
 UploadStage g_stage;
 constexpr size_t STAGE_MAX = (size_t)1 << 30, STAGE_MIN_COPY = (size_t)256 << 10, STAGE_GRAIN = (size_t)16 << 20;
 
+// ---------------------------------------------------------------------------------------------- one arena kept between tables
+// hipFree + hipMalloc of a 13 GB backtrace arena per table stalls for up to a second every few tables (measured: create 26 ms,
+// 26 ms, 26 ms, 997 ms).  The arena of the table closed last stays allocated (one block per process); the next table takes it when it
+// is large enough and not wastefully large, otherwise it is freed first.  Counted as free memory when a table sizes its arena.
+struct ArenaCache {
+	std::mutex mu;
+	void* ptr = nullptr;
+	size_t bytes = 0;
+	int device = -1;
+};
+ArenaCache g_arena;
+size_t arena_idle_bytes(int device) {
+	std::lock_guard<std::mutex> lock(g_arena.mu);
+	return g_arena.ptr && g_arena.device == device ? g_arena.bytes : 0;
+}
+void* arena_take(int device, size_t need, size_t& got) {   // nullptr: nothing suitable (a cached block that does not fit is freed)
+	std::lock_guard<std::mutex> lock(g_arena.mu);
+	if (!g_arena.ptr) return nullptr;
+	void* ptr = g_arena.ptr;
+	const size_t bytes = g_arena.bytes;
+	const bool fits = g_arena.device == device && bytes >= need && bytes <= 2 * need + ((size_t)1 << 30);
+	g_arena.ptr = nullptr;
+	g_arena.bytes = 0;
+	if (!fits) {
+		int cur = 0;
+		(void)hipGetDevice(&cur);
+		(void)hipSetDevice(g_arena.device);
+		(void)hipFree(ptr);
+		(void)hipSetDevice(cur);
+		return nullptr;
+	}
+	got = bytes;
+	return ptr;
+}
+void arena_give(int device, void* ptr, size_t bytes) {   // called with `device` current
+	if (!ptr) return;
+	std::lock_guard<std::mutex> lock(g_arena.mu);
+	if (!g_arena.ptr && bytes >= ((size_t)256 << 20) && getenv("WHAMD_NO_ARENA_CACHE") == nullptr) {
+		g_arena.ptr = ptr;
+		g_arena.bytes = bytes;
+		g_arena.device = device;
+		return;
+	}
+	(void)hipFree(ptr);
+}
+
 struct StageSession {
 	std::unique_lock<std::mutex> lock;
 	hipStream_t stream;
@@ -154,6 +200,8 @@ struct DeviceTable::Impl {
 	hipStream_t stream = nullptr;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
 	std::vector<void*> allocations;
+	void* d_arena = nullptr;    // the backtrace arena: not in `allocations`, handed to the arena cache on release
+	size_t arena_bytes = 0;
 	DevColumn* d_cols = nullptr;
 	uint32_t* d_pr[2] = {nullptr, nullptr};
 	uint32_t* d_path_index = nullptr;
@@ -275,6 +323,10 @@ struct DeviceTable::Impl {
 		windowed = false;
 		for (void* a : allocations) (void)hipFree(a);
 		allocations.clear();
+		if (d_arena && stream) (void)hipStreamSynchronize(stream);   // (hipFree used to wait for the table's last kernels)
+		arena_give(device, d_arena, arena_bytes);
+		d_arena = nullptr;
+		arena_bytes = 0;
 		if (h_pinned) (void)hipHostFree(h_pinned);
 		h_pinned = nullptr;
 		d_cols = nullptr;
@@ -389,6 +441,12 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		genotype_release_cache();
 		HIP_TRY(hipMemGetInfo(&free_b, &total_b));
 	}
+	if (free_b < total_b / 4) {   // tight: the arena kept from the previous table goes back as well
+		size_t none = 0;
+		(void)arena_take(device, ~(size_t)0 >> 2, none);
+		HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+	}
+	free_b += arena_idle_bytes(device);   // (taken below, or freed before this table's own arena is allocated)
 	m.use_slots = (m.path == "auto" || m.path == "slots") && !m.wide && plan_forward_slots(p, p.T > 1 ? (m.slot_l_set ? -m.slot_l : 0) : std::max(8, m.slot_l), m.symmetry, m.splan, m.slot_lr);
 	// pedigree slot runs keep their cost-form tables in HBM (slots.h): at most a quarter of what is free, else the older paths
 	if (m.use_slots && m.splan.ped && m.splan.table_words * 4ull > free_b / 4) m.use_slots = false;
@@ -859,7 +917,16 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	m.dp.ped_tables = ped_plan ? (int32_t*)d_rtab : nullptr;
 	ulap("jobs, backtrace units, schedule");
 	const auto tu2 = std::chrono::steady_clock::now();
-	HIP_TRY(alloc(&d_bt, bt));
+	{
+		size_t got = 0;
+		d_bt = arena_take(device, bt, got);
+		if (!d_bt) {
+			HIP_TRY(hipMalloc(&d_bt, std::max<size_t>(bt, 16)));
+			got = std::max<size_t>(bt, 16);
+		}
+		m.d_arena = d_bt;
+		m.arena_bytes = got;
+	}
 	const auto tu3 = std::chrono::steady_clock::now();
 	m.key_entries = (size_t)(1ull << max_keys_f) * p.T;
 	HIP_TRY(alloc(&d_keys, m.key_entries * 8));
@@ -1365,6 +1432,18 @@ whamd_status_t DeviceTable::wait(const Problem& p, Solution& s, whamd_solve_stat
 		        (double)b / std::max<unsigned long long>(cols, 1), (double)c2 / m.plan.segments.size(), f01, f01 * 1e3 / m.plan.segments.size());
 	}
 	return WHAMD_OK;
+}
+
+void dptable_release_arena_cache() {
+	std::lock_guard<std::mutex> lock(g_arena.mu);
+	if (!g_arena.ptr) return;
+	int cur = 0;
+	(void)hipGetDevice(&cur);
+	(void)hipSetDevice(g_arena.device);
+	(void)hipFree(g_arena.ptr);
+	(void)hipSetDevice(cur);
+	g_arena.ptr = nullptr;
+	g_arena.bytes = 0;
 }
 
 }  // namespace whamd

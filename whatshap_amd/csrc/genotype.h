@@ -44,6 +44,9 @@ whamd_status_t genotype_solve_slots(const Problem& p, const GenotypeModel& m, in
 
 // Frees the device memory genotype_solve_device keeps between calls (one column store per device).
 void genotype_release_cache();
+// The phasing tables' counterpart (dp_device.hip): one backtrace arena kept between tables; a genotyping call that finds the device
+// more than half full gives it back first.
+void dptable_release_arena_cache();
 // The column store kept between calls (mapping tens of GB of fresh device memory took seconds in one call out of four):
 // acquire returns the cached block of `device` grown to `bytes` and marks it in use, or nullptr (in use by another call,
 // allocation failed, caching disabled) -- the caller then allocates its own.  release marks it idle again; a block larger than

@@ -585,6 +585,10 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 	const uint32_t n_gl = 1 + 3 * ni;
 	size_t free_b = 0, total_b = 0;
 	GENO_TRY(hipMemGetInfo(&free_b, &total_b));
+	if (free_b < total_b / 2) {   // a phasing table of this process may have left its arena in the cache (dp_device.hip)
+		dptable_release_arena_cache();
+		GENO_TRY(hipMemGetInfo(&free_b, &total_b));
+	}
 	free_b += genotype_slab_idle_bytes(device);   // the block kept from an earlier call is available to this one
 	// Window = how many backward columns are kept at once.  If all of them fit in a quarter of the free memory there is one
 	// window and no column is computed twice; otherwise the reference's scheme: sqrt(n) kept columns, the rest recomputed.

@@ -527,6 +527,10 @@ whamd_status_t genotype_solve_slots(const Problem& p, const GenotypeModel& m, in
 	}
 	size_t free_b = 0, total_b = 0;
 	GS_TRY(hipMemGetInfo(&free_b, &total_b));
+	if (free_b < total_b / 2) {   // a phasing table of this process may have left its arena in the cache (dp_device.hip)
+		dptable_release_arena_cache();
+		GS_TRY(hipMemGetInfo(&free_b, &total_b));
+	}
 	free_b += genotype_slab_idle_bytes(device);   // the column store kept from an earlier call is available to this one
 	constexpr uint32_t BATCH = 512;
 	const double need = (double)tab_words * 8 + 2.0 * (double)store_words * 8 + (double)BATCH * max_blocks * T * A * 8 + 4.0 * ((double)(1ull << max_f) * T * 8) +
