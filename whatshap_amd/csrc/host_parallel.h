@@ -5,8 +5,12 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
+#include <cstdio>
+#include <cstring>
 #include <memory>
 #include <new>
+#include <pthread.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <thread>
 #include <vector>
@@ -21,6 +25,56 @@ inline uint32_t host_threads(uint64_t n_items, uint64_t grain) {
 	return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_threads, n_items / std::max<uint64_t>(grain, 1) + 1));
 }
 
+// The CPUs of the NUMA node the calling thread runs on (intersected with what the process may use), or an empty set.  Workers are
+// bound to that set: on the two-socket host of the MI355X box unbound workers landed on both sockets, away from the arrays the caller
+// allocated -- the flattener's pass took 16.9 ms on 8 threads, 5.3 ms with the process held to one node (measured with taskset).
+inline const cpu_set_t* caller_node_cpus() {
+	struct Nodes {
+		std::vector<cpu_set_t> sets;      // per node
+		std::vector<int> node_of_cpu;
+		Nodes() {
+			if (getenv("WHAMD_NO_AFFINITY")) return;
+			cpu_set_t allowed;
+			CPU_ZERO(&allowed);
+			if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return;
+			node_of_cpu.assign(CPU_SETSIZE, -1);
+			for (int node = 0; node < 64; ++node) {
+				char path[96];
+				snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+				FILE* f = fopen(path, "r");
+				if (!f) break;
+				char text[4096];
+				const bool got = fgets(text, sizeof text, f) != nullptr;
+				fclose(f);
+				cpu_set_t set;
+				CPU_ZERO(&set);
+				if (got) {
+					for (char* tok = strtok(text, ",\n"); tok; tok = strtok(nullptr, ",\n")) {   // "0-63,128-191"
+						int lo = 0, hi = 0;
+						const int fields = sscanf(tok, "%d-%d", &lo, &hi);
+						if (fields == 1) hi = lo;
+						if (fields < 1) continue;
+						for (int c = lo; c <= hi && c < CPU_SETSIZE; ++c)
+							if (c >= 0 && CPU_ISSET(c, &allowed)) { CPU_SET(c, &set); node_of_cpu[c] = node; }
+					}
+				}
+				sets.push_back(set);
+			}
+			if (sets.size() < 2) sets.clear();   // one node: nothing to choose
+		}
+	};
+	static const Nodes nodes;   // (strtok above runs once, under the static's initialisation lock)
+	if (nodes.sets.empty()) return nullptr;
+	// ONE node per process, the one the first caller ran on: the arrays of later tables are then touched where the earlier ones were
+	static const int chosen = [] {
+		const int cpu = sched_getcpu();
+		return cpu >= 0 && cpu < (int)nodes.node_of_cpu.size() ? nodes.node_of_cpu[cpu] : -1;
+	}();
+	if (chosen < 0) return nullptr;
+	const cpu_set_t* set = &nodes.sets[chosen];
+	return CPU_COUNT(set) > 0 ? set : nullptr;
+}
+
 // fn(begin, end, t) for n_threads contiguous ranges of [0, n); the calling thread takes the last range.
 template <class F>
 inline void parallel_ranges(uint64_t n, uint32_t n_threads, F&& fn) {
@@ -28,11 +82,22 @@ inline void parallel_ranges(uint64_t n, uint32_t n_threads, F&& fn) {
 		fn((uint64_t)0, n, 0u);
 		return;
 	}
+	const cpu_set_t* node_cpus = caller_node_cpus();
+	// (the calling thread takes the last range: it joins the workers on their node for the duration)
+	cpu_set_t caller_mask;
+	const bool rebind = node_cpus && pthread_getaffinity_np(pthread_self(), sizeof caller_mask, &caller_mask) == 0 &&
+	                    pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), node_cpus) == 0;
 	std::vector<std::thread> workers;
 	workers.reserve(n_threads - 1);
-	for (uint32_t t = 0; t + 1 < n_threads; ++t) workers.emplace_back([&fn, n, n_threads, t]() { fn(n * t / n_threads, n * (t + 1) / n_threads, t); });
+	for (uint32_t t = 0; t + 1 < n_threads; ++t) {
+		workers.emplace_back([&fn, n, n_threads, t, node_cpus]() {
+			if (node_cpus) (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), node_cpus);
+			fn(n * t / n_threads, n * (t + 1) / n_threads, t);
+		});
+	}
 	fn(n * (n_threads - 1) / n_threads, n, n_threads - 1);
 	for (std::thread& w : workers) w.join();
+	if (rebind) (void)pthread_setaffinity_np(pthread_self(), sizeof caller_mask, &caller_mask);
 }
 
 // Allocator of the create path's large arrays: the value-less construct() default-initialises (resize() of a vector of trivial

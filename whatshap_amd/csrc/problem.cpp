@@ -553,14 +553,9 @@ whamd_status_t finish_solution(const Problem& p, Solution& s, std::string& msg) 
 	s.partition.assign(p.n_reads, 1);
 	const uint32_t n_threads = n < 20000 ? 1u : host_threads(n, 8192);
 	if (n_threads == 1) return finish_columns(p, s, 0, n, msg);
-	std::vector<std::thread> workers;
 	std::vector<whamd_status_t> status(n_threads, WHAMD_OK);
 	std::vector<std::string> messages(n_threads);
-	for (uint32_t w = 0; w < n_threads; ++w) {
-		const uint32_t c0 = (uint32_t)((uint64_t)n * w / n_threads), c1 = (uint32_t)((uint64_t)n * (w + 1) / n_threads);
-		workers.emplace_back([&, w, c0, c1] { status[w] = finish_columns(p, s, c0, c1, messages[w]); });
-	}
-	for (auto& t : workers) t.join();
+	parallel_ranges(n, n_threads, [&](uint64_t c0, uint64_t c1, uint32_t w) { status[w] = finish_columns(p, s, (uint32_t)c0, (uint32_t)c1, messages[w]); });
 	for (uint32_t w = 0; w < n_threads; ++w) {
 		if (status[w] != WHAMD_OK) {
 			msg = messages[w];

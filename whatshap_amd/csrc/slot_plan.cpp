@@ -347,17 +347,7 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 		std::vector<std::vector<RunDraft>> part_drafts(n_threads);
 		std::vector<uint32_t> bounds(n_threads + 1);
 		for (uint32_t t = 0; t <= n_threads; ++t) bounds[t] = (uint32_t)((uint64_t)n * t / n_threads);
-		if (n_threads == 1) plan_range(0, n, parts[0], part_drafts[0]);
-		else {
-			std::vector<std::thread> workers;
-			for (uint32_t t = 0; t < n_threads; ++t)
-				workers.emplace_back([&, t]() {
-					const auto a = std::chrono::steady_clock::now();
-					plan_range(bounds[t], bounds[t + 1], parts[t], part_drafts[t]);
-					if (getenv("WHAMD_DEBUG_TIMING")) fprintf(stderr, "[whamd timing]   range %u: %.1f ms\n", t, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count());
-				});
-			for (std::thread& w : workers) w.join();
-		}
+		parallel_ranges(n, n_threads, [&](uint64_t, uint64_t, uint32_t t) { plan_range(bounds[t], bounds[t + 1], parts[t], part_drafts[t]); });
 		tp2 = std::chrono::steady_clock::now();
 		for (uint32_t t = 0; t < n_threads; ++t) {
 			const SlotPlan& q = parts[t];
