@@ -75,6 +75,7 @@ struct GsDev {
 	double* bstore;           // backward column store
 	double* partials;         // per-wave sums of the exchange columns
 	uint32_t T, A, P, n_ind, n_cols, pad;
+	unsigned long long* dbg;  // -DWHAMD_GENO_STAMPS: cycle sums of the run kernel's phases (wave 0 of workgroup 0)
 };
 
 __device__ __forceinline__ uint32_t gs_uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -167,6 +168,12 @@ __global__ __launch_bounds__(512) void geno_slot_run(GsDev G, GsRun run, const d
 	constexpr int NLS = 6 - TB;
 	extern __shared__ __attribute__((aligned(16))) double gs_smem[];
 	const uint32_t w = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = gs_uni(tid >> 6);
+#ifdef WHAMD_GENO_STAMPS
+	const unsigned long long st0 = __builtin_readcyclecounter();
+#define GS_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && G.dbg) atomicAdd(&G.dbg[DIR * 8 + (k)], __builtin_readcyclecounter() - st0); } while (0)
+#else
+#define GS_STAMP(k)
+#endif
 	const uint32_t threads = run.threads, ncols = run.ncols, L = run.L, nwaves = threads >> 6;
 	const uint32_t i = lane & (T - 1u);
 	const uint32_t lcell = tid >> TB, Pcell = (w << L) | lcell;
@@ -202,6 +209,7 @@ __global__ __launch_bounds__(512) void geno_slot_run(GsDev G, GsRun run, const d
 		const uint4* __restrict__ cg = reinterpret_cast<const uint4*>(G.cols + run.c0);
 		for (uint32_t q = tid; q < ncols * 2u; q += threads) reinterpret_cast<uint4*>(col_lds)[q] = cg[q];
 	}
+	GS_STAMP(0);   // prologue loads issued and staged
 	const bool from_other = DIR == 0 ? run.has_prev != 0u : run.has_next != 0u;
 	double val = 1.0;   // forward: column 0 starts from 1 (:313, `prev ? ... : 1`); backward: B of the last column is 1
 	double psum = 0.0;
@@ -226,6 +234,7 @@ __global__ __launch_bounds__(512) void geno_slot_run(GsDev G, GsRun run, const d
 		if (lane == 0) red[wave] = psum;
 	}
 	__syncthreads();
+	GS_STAMP(1);   // entering value loaded, partial sums reduced, barrier
 	double inv = 1.0;
 	if (np) {
 		double total = 0.0;
@@ -302,6 +311,7 @@ __global__ __launch_bounds__(512) void geno_slot_run(GsDev G, GsRun run, const d
 			for (uint32_t q = 0; q < E; ++q) s_cur[q] = s_next[q];
 		}
 	}
+	GS_STAMP(2);   // column loop
 	// ---- exit: hand on what was received times 1 / (total received), and the per-wave sums of what is handed on
 	const bool to_other = DIR == 0 ? run.has_next != 0u : run.has_prev != 0u;
 	if (to_other) {
@@ -322,6 +332,11 @@ __global__ __launch_bounds__(512) void geno_slot_run(GsDev G, GsRun run, const d
 			if (lane == 0) G.partials[(DIR == 0 ? run.part_out_f : run.part_out_b) + w * nwaves + wave] = ps;
 		}
 	}
+	GS_STAMP(3);   // exit
+#ifdef WHAMD_GENO_STAMPS
+	if (blockIdx.x == 0 && threadIdx.x == 0 && G.dbg) { atomicAdd(&G.dbg[DIR * 8 + 6], 1ull); atomicAdd(&G.dbg[DIR * 8 + 7], (unsigned long long)ncols); }
+#endif
+#undef GS_STAMP
 }
 
 // ---- combine: blockIdx.y = column, blockIdx.x = 256-thread block of the column's lanes (workgroup-major, as the chains stored them)
@@ -582,6 +597,10 @@ whamd_status_t genotype_solve_slots(const Problem& p, const GenotypeModel& m, in
 	for (double*& x : d_x) GS_TRY(alloc((void**)&x, ((size_t)1 << max_f) * T * 8));
 	G.cols = (const GsCol*)d_cols; G.rows = (const GsRow*)d_rows; G.prior = (const double*)d_prior; G.rho = (const double*)d_rho;
 	G.gidx = (const uint8_t*)d_gidx; G.h2p = (const int8_t*)d_h2p; G.tab = (double*)d_tab; G.fstore = (double*)d_fs; G.bstore = (double*)d_bs;
+	G.dbg = nullptr;
+#ifdef WHAMD_GENO_STAMPS
+	{ void* d_dbg = nullptr; GS_TRY(alloc(&d_dbg, 128)); GS_TRY(hipMemset(d_dbg, 0, 128)); G.dbg = (unsigned long long*)d_dbg; }
+#endif
 	G.partials = (double*)d_part; G.T = T; G.A = A; G.P = p.P; G.n_ind = ni; G.n_cols = n;
 	hipEvent_t ev[4];
 	for (hipEvent_t& e : ev) { GS_TRY(hipEventCreate(&e)); keep.events.push_back(e); }
@@ -645,6 +664,17 @@ whamd_status_t genotype_solve_slots(const Problem& p, const GenotypeModel& m, in
 	GS_TRY(hipMemcpyAsync(gl_out.data(), d_gl, gl_out.size() * 8, hipMemcpyDeviceToHost, sf));
 	GS_TRY(hipStreamSynchronize(sf));
 	GS_TRY(hipStreamSynchronize(sb));
+#ifdef WHAMD_GENO_STAMPS
+	{
+		unsigned long long d[16];
+		GS_TRY(hipMemcpy(d, G.dbg, sizeof d, hipMemcpyDeviceToHost));
+		for (int dir = 0; dir < 2; ++dir) {
+			const double runs = (double)std::max<unsigned long long>(d[dir * 8 + 6], 1);
+			fprintf(stderr, "[whamd geno stamps] %s: %llu runs, %.1f columns each; cycles since kernel start (wave 0 / workgroup 0): staged %.0f, entered + reduced %.0f, loop done %.0f, exit %.0f\n",
+			        dir ? "backward" : "forward", d[dir * 8 + 6], d[dir * 8 + 7] / runs, d[dir * 8 + 0] / runs, d[dir * 8 + 1] / runs, d[dir * 8 + 2] / runs, d[dir * 8 + 3] / runs);
+		}
+	}
+#endif
 	float t_tab = 0, t_chain = 0, t_all = 0;
 	GS_TRY(hipEventElapsedTime(&t_tab, ev[0], ev[1]));
 	GS_TRY(hipEventElapsedTime(&t_chain, ev[1], ev[2]));
