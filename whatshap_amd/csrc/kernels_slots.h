@@ -4,9 +4,11 @@
 // One launch = one run of consecutive columns.  Workgroup w, wave v, lane l and register r of a thread hold the cell
 // with physical index P = (w << L) | (v << (6 + LR)) | (l << LR) | r for the whole run; a column adds its closed-form
 // cost to every cell, an ending read is minimised out where it sits (registers / cross-lane move / LDS exchange
-// between two waves), a starting read just begins to contribute its delta.  Per-column constants are wave-uniform:
-// they arrive through the scalar cache (s_load) into SGPRs, the workgroup- and wave-dependent part of S is prepared
-// for all columns of the run at once by the lanes of the wave (lane c: column c) and picked up with v_readlane.
+// between two waves), a starting read just begins to contribute its delta.  Per-column constants are wave-uniform: the
+// hot lines of the run's columns are staged in LDS by the prologue and read back three columns ahead (wave-uniform words in
+// VECTOR registers); the workgroup- and wave-dependent part of S and the lane sums come from tables built once per table
+// (slot_tables); what steers control flow -- does a read end in this column, in which slot -- is one control byte per column,
+// sixteen words in the lanes of one register, fetched per trip of four columns with a v_readlane.
 //
 // Restates compute_column of the reference (src/pedigreedptable.cpp:177-335) for T = 1: cost per cell (:262-283 with
 // PedigreeColumnCostComputer::get_cost), strict-'<' projection with Gray-code visiting order (:306-327) as the tie

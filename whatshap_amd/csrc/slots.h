@@ -47,12 +47,10 @@ constexpr int SLOT_MAXEND = 3;       // reads that may end in one column of a ru
 constexpr int SLOT_MAXENDS_RUN = 96; // ending reads per run (one record byte per thread each)
 constexpr int32_t SLOT_DELTA_LIMIT = 1 << 22;  // |delta| of every read in a run (24-bit multiply-add of the lane part)
 
-// Per-column descriptor of a run, 64 dwords.  The first 32 ("hot") are fetched by every wave with scalar loads once per
-// column; the rest ("cold") is read in the prologue only (lane c of a wave reads column c).
+// Per-column descriptor of a run, 64 dwords.  The first 16 ("hot") are what a run reads per column: the prologue copies the
+// hot lines of its columns into LDS (kernels_slots.h).  The rest ("cold") is read once per table, by slot_tables.
 struct SlotRow {
-	// ---- hot: ONE 64-byte line that every wave fetches through the scalar cache (s_load_dwordx16) one column ahead.
-	// Every dword is read by the kernel: a dword that is loaded but never read lets the register allocator reuse its
-	// SGPR while the load is in flight, which forces a wait right after the load.
+	// ---- hot: ONE 64-byte line per column
 	uint32_t K;                      // Cp + Cm (mod 2^32; an absent term is RES_ABSENT, resident.h)
 	uint32_t Cc;                     // constant term (INF if none)
 	int32_t dreg[SLOT_LR];           // deltas of the reg slots (0 for a slot the run does not have)
