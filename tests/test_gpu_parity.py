@@ -143,6 +143,29 @@ def test_many_reads_ending_at_once():
         assert native_solution(p, path) == want
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_four_to_seven_reads_ending_in_one_column_of_a_run(seed):
+    """Inside a slot run (not as a per-column step): the third and later ending reads of a column come out of the row's second line."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_slot_plan import _reads_problem
+
+    rng = np.random.default_rng(40 + seed)
+    n = 40
+    reads = []
+    for stop in (9, 17, 26, 33):
+        for q in range(4 + seed):
+            reads.append((int(stop - 2 - rng.integers(0, 5)), stop))
+    for first in range(0, n - 6, 3):
+        reads.append((first, min(n - 1, first + int(rng.integers(5, 12)))))
+    p = _reads_problem(reads, n, seed)
+    want = table_solution(oracle.OracleTable(p))
+    summary = _native.plan_summary(p)
+    assert summary["n_resident_columns"] >= n - 2, summary
+    for path in PATHS:
+        assert native_solution(p, path) == want, (path, first_difference(want, native_solution(p, path)))
+
+
 @pytest.mark.parametrize("kw", [dict(n_variants=50000, coverage=15, seed=2), dict(n_variants=200000, coverage=20, seed=3)], ids=str)
 def test_full_size_properties_single_individual(kw):
     """BASELINE configs 2 and 3 at full size (50 000 x coverage 15; 200 000 x coverage 20): the reported optimum

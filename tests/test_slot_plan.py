@@ -66,3 +66,37 @@ def test_connected_components_and_pedigrees():
     with pytest.raises(_native.SolverError) as e:
         _native.emulate_slot_plan(trio, 50)
     assert e.value.status == _native.WHAMD_ERR_UNSUPPORTED
+
+
+def _reads_problem(reads, n_variants, seed):
+    """A single-individual problem from explicit reads [(first variant, last variant)], alleles / qualities seeded."""
+    rng = np.random.default_rng(seed)
+    reads = sorted(reads)
+    ptr, pos, allele, qual = [0], [], [], []
+    for first, last in reads:
+        for v in range(first, last + 1):
+            pos.append(100 * (v + 1)); allele.append(int(rng.integers(0, 2))); qual.append(int(rng.integers(1, 4)))
+        ptr.append(len(pos))
+    return _native.ProblemArrays(np.array(ptr, dtype=np.uint64), np.array(pos, dtype=np.int32), np.array(allele, dtype=np.uint8), np.array(qual, dtype=np.uint32),
+                                 np.zeros(len(reads), dtype=np.int32), np.array([0], dtype=np.uint32), np.zeros(0, dtype=np.uint32),
+                                 np.ones((1, n_variants), dtype=np.uint8), None, np.zeros(n_variants, dtype=np.uint32),
+                                 np.array([100 * (v + 1) for v in range(n_variants)], dtype=np.uint32), False, n_variants=n_variants)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_many_reads_ending_in_one_column(seed):
+    """Four to eight reads whose last variant is the same column (an irregular layout does that in every tenth run): the run
+    continues through it (SLOT_MAXEND = 8; the third and later ending reads come out of the row's second line)."""
+    rng = np.random.default_rng(40 + seed)
+    n = 40
+    reads = []
+    for stop in (9, 17, 26, 33):           # columns where 4 + seed reads end at once
+        for q in range(4 + seed):
+            reads.append((int(stop - 2 - rng.integers(0, 5)), stop))
+    for first in range(0, n - 6, 3):       # a background of staggered reads
+        reads.append((first, min(n - 1, first + int(rng.integers(5, 12)))))
+    p = _reads_problem(reads, n, seed)
+    for slot_l, slot_r in ((10, 2), (9, 2), (11, 3), (9, 1)):
+        ok, run_columns = agrees(p, slot_l=slot_l, slot_r=slot_r)
+        assert ok, (seed, slot_l, slot_r)
+        assert run_columns >= n - 2, run_columns

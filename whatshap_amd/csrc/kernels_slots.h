@@ -256,9 +256,12 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 				uint32_t s1;
 				asm volatile("s_nop 0\n\tv_readfirstlane_b32 %0, %1" : "=s"(s1) : "v"(e1.x));
 				ending(e1.x, e1.y, s1 & 255u);
-				if (n_end > 2u) {   // the third lies in the row's second line
-					const slot_u32x2 e2 = *(slot_cptr2)((unsigned long long)(rows + ci) + 64);
-					ending(e2[0], e2[1], e2[0] & 255u);
+				if (n_end > 2u) {   // the third and later lie in the row's second line; a control byte of 3 says "three or more"
+					const uint32_t total = *(const __attribute__((address_space(4))) uint32_t*)((unsigned long long)(rows + ci) + 44);
+					for (uint32_t e = 2; e < total; ++e) {
+						const slot_u32x2 ex = *(slot_cptr2)((unsigned long long)(rows + ci) + 48 + 8 * e);
+						ending(ex[0], ex[1], ex[0] & 255u);
+					}
 				}
 			}
 		}

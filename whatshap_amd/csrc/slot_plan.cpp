@@ -147,7 +147,7 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 			const ColumnEntry* col = p.col_begin(c1);
 			const uint32_t kc = p.k[c1], bc = c1 == c ? b0 : p.b[c1];
 			const uint32_t n_new = kc - bc, n_end = kc - p.f[c1];
-			if (!genotype_mode && (n_end > (uint32_t)SLOT_MAXEND || n_ends + n_end > (uint32_t)SLOT_MAXENDS_RUN)) break;
+			if (!genotype_mode && (n_end > (uint32_t)(ped ? PSLOT_MAXEND : SLOT_MAXEND) || n_ends + n_end > (uint32_t)SLOT_MAXENDS_RUN)) break;
 			if (genotype_mode && n_ends + n_end > 250u) break;
 			uint32_t n_free = 0;
 			for (uint32_t s = 0; s < L; ++s) n_free += cur[s] < 0;
@@ -304,7 +304,7 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 		for (uint32_t i = 0; i < d.ncols; ++i) {
 			const uint32_t ne = ped ? prows_g[rows_mark + i].n_end : rows_g[rows_mark + i].n_end;
 			const uint32_t s0 = ped ? prows_g[rows_mark + i].info0 : (rows_g[rows_mark + i].end[0].info & 31u);
-			const uint32_t byte = ne | ((ne ? (s0 & 31u) : 0u) << 2);
+			const uint32_t byte = std::min(ne, 3u) | ((ne ? (s0 & 31u) : 0u) << 2);   // (3: three or more, the kernel reads the row's count)
 			plan.ctrl[run.ctrl_off + (i >> 2)] |= byte << ((i & 3u) * 8u);
 		}
 		run.lr = (uint32_t)lr;

@@ -43,7 +43,8 @@ constexpr int SLOT_LWMAX = 3;        // wave slots (at most 8 waves per workgrou
 constexpr int SLOT_GMAX = 12;        // grid slots
 constexpr int SLOT_MAXSLOTS = 26;    // local + grid slots of one run (device limit: 25 reads per column)
 constexpr int SLOT_MAXCOLS = 64;     // columns per run: lane c of every wave prepares column c in the prologue
-constexpr int SLOT_MAXEND = 3;       // reads that may end in one column of a run
+constexpr int SLOT_MAXEND = 8;       // reads that may end in one column of a run (pedigree runs: PSLOT_MAXEND)
+constexpr int PSLOT_MAXEND = 3;      // ... of a pedigree run (PedSlotRow holds three)
 constexpr int SLOT_MAXENDS_RUN = 96; // ending reads per run (one record byte per thread each)
 constexpr int32_t SLOT_DELTA_LIMIT = 1 << 22;  // |delta| of every read in a run (24-bit multiply-add of the lane part)
 
@@ -60,14 +61,15 @@ struct SlotRow {
 		uint32_t info;               // slot | qmask << 8 | mflip << 24 (qmask bit r: reg-slot part of the tie-break parity of cell r,
 		                             //  including (side & mflip) when the ending read itself sits in a reg slot)
 		uint32_t M;                  // physical index bits of the reads logically above the ending read
-	} end[SLOT_MAXEND];              // ascending logical position; end[2] lies in the next line (three reads ending at once are rare)
-	uint32_t pad2[14];
+	} end[SLOT_MAXEND];              // ascending logical position; end[2] and later lie in the next line (three and more reads ending at
+	                                 // once: rare in a regular layout, every tenth run of an irregular one -- the kernel fetches them with scalar loads)
+	uint32_t pad2[4];
 	// ---- cold (128-byte aligned: lane c fetches its column with wide loads)
 	int32_t dslot[SLOT_MAXSLOTS];    // delta of every slot at this column (0: free slot, BLANK entry)
 	uint32_t Cp;
 	uint32_t pad3[5];
 };
-static_assert(SLOT_LR == 3 && SLOT_LANE == 6 && SLOT_MAXEND == 3, "hot layout of SlotRow: 2 + 3 + 6 + 1 + 4 dwords in the first line");
+static_assert(SLOT_LR == 3 && SLOT_LANE == 6 && SLOT_MAXEND == 8, "hot layout of SlotRow: 2 + 3 + 6 + 1 + 4 dwords in the first line, six more ending reads in the second");
 static_assert(sizeof(SlotRow) == 256, "SlotRow must stay 64 dwords");
 constexpr int SLOT_CTRL_WORDS = 16;  // control bytes of a run's columns (SLOT_MAXCOLS bytes)
 constexpr int SLOT_ROW_PAD = 64;     // rows appended to the array: the kernel touches a fixed number of rows to warm the scalar cache
