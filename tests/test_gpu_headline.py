@@ -196,3 +196,22 @@ def test_long_tie_heavy_table_chunked_backtrace_vs_oracle():
     assert stats["bt_chunks"] >= 150, stats
     assert got == want, first_difference(want, got)
     assert stats["bt_missed"] > 0 and stats["bt_rewalked"] >= stats["bt_missed"], stats   # the miss branch was exercised
+
+
+def test_irregular_layout_chunked_backtrace_vs_oracle():
+    """The irregular read layout of the bench (Poisson starts, geometric lengths) at a coverage the oracle affords: columns in which
+    four and more reads end lie inside runs, the table is long enough for tens of backtrace chunks, two-valued weights make ties."""
+    from whatshap_amd.synthetic import irregular_block
+
+    b = irregular_block(12000, 13, seed=7)
+    p = _native.ProblemArrays(b.read_ptr, b.var_position, b.var_allele, (1 + (b.var_quality % 2)).astype(np.uint32), b.read_sample_id, b.individual_id,
+                              b.triple_ids, b.genotype.reshape(1, -1), None, b.recombcost, b.positions, False, n_variants=b.n_variants)
+    summary = _native.plan_summary(p)
+    assert summary["n_resident_columns"] > 0.99 * p.n_variants, summary   # (three ending reads per column was the limit: 2.6 % outside runs)
+    want = table_solution(oracle.OracleTable(p))
+    t = _native.NativeTable(p)
+    got = table_solution(t)
+    stats = t.stats()
+    t.close()
+    assert stats["bt_chunks"] >= 20, stats
+    assert got == want, first_difference(want, got)
