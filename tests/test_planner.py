@@ -123,3 +123,51 @@ def test_components_are_found_and_no_run_spans_one():
     assert _native.plan_summary(single)["n_components"] == 1
     trio = synthetic_block(n_variants=300, coverage=9, seed=3, trio=True)
     assert _native.plan_summary(trio)["n_components"] == 0  # coupled through the transmission vector: never split
+
+
+def _chain_problem(n_reads, edit=None, positions=None):
+    """n_reads reads of three variants each, read r at variants r, r + 1, r + 2 (positions 10 * (v + 1)); `edit(ptr, pos)` may damage it."""
+    import numpy as np
+
+    ptr = np.arange(0, 3 * (n_reads + 1), 3, dtype=np.uint64)
+    pos = (10 * (np.arange(n_reads)[:, None] + np.arange(3)[None, :] + 1)).astype(np.int32).reshape(-1)
+    if edit:
+        edit(ptr, pos)
+    n_var = n_reads + 2
+    return _native.ProblemArrays(ptr, pos, np.zeros(pos.size, dtype=np.uint8), np.ones(pos.size, dtype=np.uint32), np.zeros(n_reads, dtype=np.int32),
+                                 np.array([0], dtype=np.uint32), np.zeros(0, dtype=np.uint32), np.ones((1, n_var), dtype=np.uint8), None,
+                                 np.ones(n_var, dtype=np.uint32), positions, False, n_variants=n_var)
+
+
+def test_validation_of_the_parallel_flattener_reports_the_first_failing_read():
+    """build_problem validates the reads on several host threads (40 000 reads: three ranges); the error is the one the reference's
+    sequential constructor would raise -- that of the FIRST failing read (src/columniterator.cpp:22-41), whichever range finds what."""
+    import numpy as np
+
+    n = 40000
+
+    def late_unsorted_variants_early_unsorted_reads(ptr, pos):
+        pos[3 * 30000 + 1] = pos[3 * 30000]          # read 30 000: variants not strictly increasing
+        pos[3 * 100: 3 * 100 + 3] -= 500             # read 100 starts before read 99
+    with pytest.raises(_native.SolverError, match="reads in ReadSet are not sorted"):
+        _native.plan_summary(_chain_problem(n, late_unsorted_variants_early_unsorted_reads))
+
+    def only_late(ptr, pos):
+        pos[3 * 30000 + 1] = pos[3 * 30000]
+    with pytest.raises(_native.SolverError, match="encountered read with unsorted variants"):
+        _native.plan_summary(_chain_problem(n, only_late))
+
+    def read_without_variants(ptr, pos):
+        ptr[20001] = ptr[20000]                       # read 20 000 is empty (the next one takes its variants)
+    with pytest.raises(_native.SolverError, match="No variants present"):
+        _native.plan_summary(_chain_problem(n, read_without_variants))
+
+    positions = (10 * (np.arange(n + 2) + 1)).astype(np.uint32)
+    missing = np.delete(positions, 777)               # a position some read starts / ends at is not in the list
+    with pytest.raises(_native.SolverError, match="not in the position list"):
+        _native.plan_summary(_chain_problem(n, None, missing))
+    swapped = positions.copy()
+    swapped[[5000, 5001]] = swapped[[5001, 5000]]
+    with pytest.raises(_native.SolverError, match="not in the position list|strictly increasing"):
+        _native.plan_summary(_chain_problem(n, None, swapped))
+    assert _native.plan_summary(_chain_problem(n, None, positions))["n_columns"] == n + 2
