@@ -72,17 +72,21 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 		if (c + 1 >= n && !genotype_mode) { column_step(); continue; }   // the last column needs the global optimum (column_step_keys)
 		const uint32_t b0 = p.b[c];
 		const ColumnEntry* first = p.col_begin(c);
-		// ---- shape of the run: local slots L, grid slots g
-		uint32_t kmax = 0;
-		for (uint32_t cc = c; cc < std::min(n, c + 6); ++cc) {
+		// ---- shape of the run: local slots L, grid slots g.  A grid read must outlive the run, a starting read needs a free local slot:
+		// few grid slots end the run when the coverage grows, many end it when the first of them does.  The widest column of the next
+		// 1 .. 12 columns gives the candidates for g; each is probed (slot counts only) and the one with the longest run is planned.
+		constexpr uint32_t LOOK = 12;
+		uint32_t kmax_at[LOOK], n_look = 0;
+		for (uint32_t cc = c; cc < std::min(n, c + LOOK); ++cc) {
 			if (cc > c && p.b[cc] == 0) break;
-			kmax = std::max<uint32_t>(kmax, p.k[cc]);
+			kmax_at[n_look] = std::max<uint32_t>(n_look ? kmax_at[n_look - 1] : 0u, p.k[cc]);
+			++n_look;
 		}
+		const uint32_t kmax = kmax_at[std::min<uint32_t>(n_look, genotype_mode || ped ? 6u : LOOK) - 1];
 		const uint32_t L = std::min<uint32_t>((uint32_t)l_pref, std::max<uint32_t>((uint32_t)LMIN, kmax));
 		uint32_t g = kmax > L ? kmax - L : 0;
 		if (genotype_mode) g = std::min(g, b0);   // (a short run while the coverage ramps up rather than a column the run kernels cannot take)
-		if (g > b0 || g > (uint32_t)SLOT_GMAX || p.k[c] > L + g) { column_step(); continue; }
-		// grid reads: the g entering reads that end last (ties: the younger read)
+		// the entering reads by the column they end in, latest first (ties: the younger read): the first g of them are the grid reads
 		std::vector<uint32_t> order(b0);
 		for (uint32_t j = 0; j < b0; ++j) order[j] = j;
 		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t bb) {
@@ -90,6 +94,33 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 			if (ea != eb) return ea > eb;
 			return a > bb;
 		});
+		if (!genotype_mode && !ped) {
+			auto probe = [&](uint32_t gg) -> uint32_t {   // columns a run with gg grid slots would take (the walk below, counts only)
+				uint32_t grid_end = 0xFFFFFFFFu;
+				for (uint32_t i = 0; i < gg; ++i) grid_end = std::min(grid_end, last_col[first[order[i]].read_id]);
+				uint32_t n_free = L - (b0 - gg), ends = 0, c1 = c;
+				for (; c1 < n && c1 - c < max_run_cols; ++c1) {
+					if (c1 + 1 == n || c1 >= grid_end || c1 >= c_end || (c1 > c && p.b[c1] == 0)) break;
+					const uint32_t kc = p.k[c1], bc = c1 == c ? b0 : p.b[c1], n_new = kc - bc, n_end = kc - p.f[c1];
+					if (n_end > (uint32_t)SLOT_MAXEND || ends + n_end > (uint32_t)SLOT_MAXENDS_RUN || n_new > n_free) break;
+					n_free = n_free - n_new + n_end;
+					ends += n_end;
+				}
+				return c1 - c;
+			};
+			uint32_t best_g = 0xFFFFFFFFu, best_len = 0, last_g = 0xFFFFFFFFu;
+			for (uint32_t q = 0; q < n_look; ++q) {
+				const uint32_t gg = kmax_at[q] > L ? kmax_at[q] - L : 0;
+				if (gg == last_g) continue;
+				last_g = gg;
+				if (gg > b0 || gg > (uint32_t)SLOT_GMAX || p.k[c] > L + gg || b0 - gg > L) continue;
+				const uint32_t len = probe(gg);
+				if (len > best_len) { best_len = len; best_g = gg; }
+			}
+			if (best_g == 0xFFFFFFFFu) { column_step(); continue; }
+			g = best_g;
+		}
+		if (g > b0 || g > (uint32_t)SLOT_GMAX || p.k[c] > L + g) { column_step(); continue; }
 		if (genotype_mode) {
 			// g was sized for the columns ahead; a grid read must outlive this column, or the run would be empty (every column has
 			// to lie in a run here): fewer grid slots if the reads allow it
