@@ -82,7 +82,7 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 			kmax_at[n_look] = std::max<uint32_t>(n_look ? kmax_at[n_look - 1] : 0u, p.k[cc]);
 			++n_look;
 		}
-		const uint32_t kmax = kmax_at[std::min<uint32_t>(n_look, genotype_mode || ped ? 6u : LOOK) - 1];
+		const uint32_t kmax = kmax_at[std::min<uint32_t>(n_look, genotype_mode ? 6u : LOOK) - 1];
 		const uint32_t L = std::min<uint32_t>((uint32_t)l_pref, std::max<uint32_t>((uint32_t)LMIN, kmax));
 		uint32_t g = kmax > L ? kmax - L : 0;
 		if (genotype_mode) g = std::min(g, b0);   // (a short run while the coverage ramps up rather than a column the run kernels cannot take)
@@ -94,7 +94,7 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 			if (ea != eb) return ea > eb;
 			return a > bb;
 		});
-		if (!genotype_mode && !ped) {
+		if (!genotype_mode) {
 			auto probe = [&](uint32_t gg) -> uint32_t {   // columns a run with gg grid slots would take (the walk below, counts only)
 				uint32_t grid_end = 0xFFFFFFFFu;
 				for (uint32_t i = 0; i < gg; ++i) grid_end = std::min(grid_end, last_col[first[order[i]].read_id]);
@@ -102,7 +102,7 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 				for (; c1 < n && c1 - c < max_run_cols; ++c1) {
 					if (c1 + 1 == n || c1 >= grid_end || c1 >= c_end || (c1 > c && p.b[c1] == 0)) break;
 					const uint32_t kc = p.k[c1], bc = c1 == c ? b0 : p.b[c1], n_new = kc - bc, n_end = kc - p.f[c1];
-					if (n_end > (uint32_t)SLOT_MAXEND || ends + n_end > (uint32_t)SLOT_MAXENDS_RUN || n_new > n_free) break;
+					if (n_end > (uint32_t)(ped ? PSLOT_MAXEND : SLOT_MAXEND) || ends + n_end > (uint32_t)SLOT_MAXENDS_RUN || n_new > n_free) break;
 					n_free = n_free - n_new + n_end;
 					ends += n_end;
 				}
