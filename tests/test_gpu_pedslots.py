@@ -135,3 +135,29 @@ def test_pedigrees_beyond_two_trios_and_six_individuals_vs_oracle(mode):
         assert got == want, (mode, first_difference(want, got))
         compared += 1
     assert compared > 30
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_four_reads_ending_in_one_column_of_a_pedigree_run(seed):
+    """The fourth ending read of a column (PSLOT_MAXEND = 4) comes out of the row with scalar loads; its decision is bit 7 of the
+    lane's record byte, its slot sits next to the count in the backtrace column."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_pedslot_plan import _trio_reads_problem
+
+    rng = np.random.default_rng(60 + seed)
+    n = 36
+    reads = []
+    for stop in (8, 15, 23, 30):
+        for q in range(4):
+            reads.append((int(stop - 2 - rng.integers(0, 4)), stop))
+    for first in range(0, n - 6, 4):
+        reads.append((first, min(n - 1, first + int(rng.integers(5, 10)))))
+    p = _trio_reads_problem(reads, n, seed)
+    want = table_solution(oracle.OracleTable(p))
+    assert _native.plan_summary(p)["n_resident_columns"] >= n - 5
+    for path in ("auto", "resident", "column"):
+        got, _ = solve(p, path)
+        assert got == want, (path, first_difference(want, got))

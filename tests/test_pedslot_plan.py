@@ -81,3 +81,38 @@ def test_not_for_a_single_individual_or_untrusted_genotypes():
     with pytest.raises(_native.SolverError) as e:
         _native.emulate_pedslot_plan(distrust, 40)
     assert e.value.status == _native.WHAMD_ERR_UNSUPPORTED
+
+
+def _trio_reads_problem(reads, n_variants, seed):
+    """A trio problem from explicit reads [(first variant, last variant)], samples round-robin, alleles / qualities seeded."""
+    rng = np.random.default_rng(seed)
+    reads = sorted(reads)
+    ptr, pos, allele, qual = [0], [], [], []
+    for first, last in reads:
+        for v in range(first, last + 1):
+            pos.append(100 * (v + 1)); allele.append(int(rng.integers(0, 2))); qual.append(int(rng.integers(1, 4)))
+        ptr.append(len(pos))
+    samples = np.arange(len(reads), dtype=np.int32) % 3
+    return _native.ProblemArrays(np.array(ptr, dtype=np.uint64), np.array(pos, dtype=np.int32), np.array(allele, dtype=np.uint8), np.array(qual, dtype=np.uint32),
+                                 samples, np.array([0, 1, 2], dtype=np.uint32), np.array([0, 1, 2], dtype=np.uint32),
+                                 np.ones((3, n_variants), dtype=np.uint8), None, np.array([0] + [int(rng.integers(1, 6)) for _ in range(n_variants - 1)], dtype=np.uint32),
+                                 np.array([100 * (v + 1) for v in range(n_variants)], dtype=np.uint32), False, n_variants=n_variants)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_four_reads_ending_in_one_column_of_a_pedigree_run(seed):
+    """PSLOT_MAXEND = 4: the fourth decision bit of a lane's record byte, the fourth ending read's slot next to the count in the
+    backtrace column; the run continues through such a column."""
+    rng = np.random.default_rng(60 + seed)
+    n = 36
+    reads = []
+    for stop in (8, 15, 23, 30):
+        for q in range(4):
+            reads.append((int(stop - 2 - rng.integers(0, 4)), stop))
+    for first in range(0, n - 6, 4):
+        reads.append((first, min(n - 1, first + int(rng.integers(5, 10)))))
+    p = _trio_reads_problem(reads, n, seed)
+    for slot_l in (0, 5, 6):
+        ok, run_columns = agrees(p, slot_l=slot_l)
+        assert ok, (seed, slot_l)
+        assert run_columns >= n - 5, run_columns

@@ -368,7 +368,7 @@ whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uin
 				ok = ok && sp.col_to_row[c] == (int32_t)(run.row_off + i) && (i == 0 || p.b[c] != 0);
 				const uint32_t row_n_end = sp.ped ? sp.prows[run.row_off + i].n_end : sp.rows[run.row_off + i].n_end;
 				const SlotBtCol& bc = sp.bt_cols[run.row_off + i];
-				ok = ok && bc.k == p.k[c] && bc.kf == ends && row_n_end == (uint32_t)p.k[c] - p.f[c] && row_n_end <= (uint32_t)SLOT_MAXEND;
+				ok = ok && bc.k == p.k[c] && bc.kf == ends && row_n_end == (uint32_t)p.k[c] - p.f[c] && row_n_end <= (uint32_t)(sp.ped ? PSLOT_MAXEND : SLOT_MAXEND);
 				if (sp.ped) for (uint32_t t = 0; t < p.T; ++t) ok = ok && p.term_end(c, t) - p.term_begin(c, t) <= sp.pextra[step.index].nf;
 				uint32_t used = 0;
 				for (uint32_t j = 0; j < bc.k; ++j) {   // distinct slots, ending reads local
@@ -377,7 +377,7 @@ whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uin
 					if (!((p.fwd_mask[c] >> j) & 1u)) ok = ok && bc.slot[j] < run.L;
 				}
 				for (uint32_t q = 0; q < row_n_end; ++q) {
-					const uint32_t es = sp.ped ? (uint32_t)bc.slot[25 + q] : (sp.rows[run.row_off + i].end[q].info & 255u);
+					const uint32_t es = sp.ped ? (uint32_t)(q < 3u ? bc.slot[25 + q] : bc.pad[1]) : (sp.rows[run.row_off + i].end[q].info & 255u);
 					ok = ok && sp.end_slots[sp.end_off[step.index] + ends + q] == es;
 				}
 				ends += row_n_end;

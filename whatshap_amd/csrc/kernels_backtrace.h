@@ -26,7 +26,7 @@ __device__ __forceinline__ uint32_t pedslot_walk(const SlotBtCol* bcols, const u
 		const SlotBtCol& bc = bcols[ci];
 		const uint32_t base = (ci >> 2) * threads * 4u + (ci & 3u);
 		for (uint32_t e = bc.pad[0]; e-- > 0;) {
-			const uint32_t slot = bc.slot[25u + e];
+			const uint32_t slot = e < 3u ? bc.slot[25u + e] : bc.pad[1];
 			const uint32_t look = l & ~(1u << slot);
 			const uint32_t byte = stage8[base + ((look << tb) | tcur) * 4u];
 			l = look | (((byte >> (4u + e)) & 1u) << slot);

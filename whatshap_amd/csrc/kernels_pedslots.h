@@ -225,6 +225,14 @@ __global__ __launch_bounds__(512) void pedslot_run(DevProblem P, SlotRun run, Pe
 					uint32_t s2;
 					asm volatile("s_nop 0\n\tv_readfirstlane_b32 %0, %1" : "=s"(s2) : "v"(e2.x));
 					ending(e2.y, s2 & 255u, 2u);
+					// a control byte of 3 says "three or more": the fourth (PSLOT_MAXEND) comes out of the row itself
+					const PedSlotRow* __restrict__ grow = P.pslot_rows + run.row_off + ci;
+					const uint32_t total = *(const __attribute__((address_space(4))) uint32_t*)(unsigned long long)(&grow->n_end);
+					if (total > 3u) {
+						const uint32_t s3 = *(const __attribute__((address_space(4))) uint32_t*)(unsigned long long)(&grow->pad[2]);
+						const uint32_t m3 = *(const __attribute__((address_space(4))) uint32_t*)(unsigned long long)(&grow->pad[3]);
+						ending(m3, s3 & 255u, 3u);
+					}
 				}
 			}
 		}

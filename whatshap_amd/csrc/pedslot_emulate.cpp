@@ -162,8 +162,8 @@ bool emulate_pedslot_plan(const Problem& p, const SlotPlan& plan, std::vector<ui
 				}
 			}
 			for (uint32_t q = 0; q < row.n_end; ++q) {
-				const uint32_t slot = (q == 0 ? row.info0 : (q == 1 ? row.info1 : row.info2)) & 255u;
-				const uint32_t M = q == 0 ? row.M0 : (q == 1 ? row.M1 : row.M2);
+				const uint32_t slot = (q == 0 ? row.info0 : (q == 1 ? row.info1 : (q == 2 ? row.info2 : row.pad[2]))) & 255u;
+				const uint32_t M = q == 0 ? row.M0 : (q == 1 ? row.M1 : (q == 2 ? row.M2 : row.pad[3]));
 				if (slot >= L) { msg = "an ending read sits in a grid slot"; return false; }
 				V = D;
 				for (uint32_t P = 0; P < ncell; ++P) {
@@ -222,7 +222,7 @@ bool emulate_pedslot_plan(const Problem& p, const SlotPlan& plan, std::vector<ui
 		for (uint32_t ci = run.ncols; ci-- > 0;) {
 			const SlotBtCol& bc = plan.bt_cols[run.row_off + ci];
 			for (uint32_t e = bc.pad[0]; e-- > 0;) {
-				const uint32_t slot = bc.slot[25 + e];
+				const uint32_t slot = e < 3u ? bc.slot[25 + e] : bc.pad[1];
 				const uint32_t look = l & ~(1u << slot);
 				l = look | (((rec_byte(ci, look, tcur) >> (4u + e)) & 1u) << slot);
 			}

@@ -272,8 +272,10 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 				if (ped && !genotype_mode) {   // (the kernel's cell index has no reg bits: M as it is)
 					if (en == 0) { prow.info0 = (uint32_t)s; prow.M0 = M; }
 					else if (en == 1) { prow.info1 = (uint32_t)s; prow.M1 = M; }
-					else { prow.info2 = (uint32_t)s; prow.M2 = M; }
-					bc_rec.slot[25 + en] = (uint8_t)s;   // the backtrace walks column by column: ending slots of the column, in order
+					else if (en == 2) { prow.info2 = (uint32_t)s; prow.M2 = M; }
+					else { prow.pad[2] = (uint32_t)s; prow.pad[3] = M; }
+					// the backtrace walks column by column: ending slots of the column, in order (the fourth next to the count)
+					if (en < 3) bc_rec.slot[25 + en] = (uint8_t)s; else bc_rec.pad[1] = (uint8_t)s;
 				}
 				plan.end_slots.push_back((uint8_t)s);
 				++en;

@@ -44,7 +44,7 @@ constexpr int SLOT_GMAX = 12;        // grid slots
 constexpr int SLOT_MAXSLOTS = 26;    // local + grid slots of one run (device limit: 25 reads per column)
 constexpr int SLOT_MAXCOLS = 64;     // columns per run: lane c of every wave prepares column c in the prologue
 constexpr int SLOT_MAXEND = 8;       // reads that may end in one column of a run (pedigree runs: PSLOT_MAXEND)
-constexpr int PSLOT_MAXEND = 3;      // ... of a pedigree run (PedSlotRow holds three)
+constexpr int PSLOT_MAXEND = 4;      // ... of a pedigree run (four decision bits next to the transmission argument in a lane's record byte)
 constexpr int SLOT_MAXENDS_RUN = 96; // ending reads per run (one record byte per thread each)
 constexpr int32_t SLOT_DELTA_LIMIT = 1 << 22;  // |delta| of every read in a run (24-bit multiply-add of the lane part)
 
@@ -120,7 +120,8 @@ struct PedSlotRow {
 	// ---- cold: read by pedslot_tables only
 	int32_t dslot[SLOT_MAXSLOTS];    // delta of the read in every slot at this column (0: free slot, BLANK entry)
 	uint8_t ind[SLOT_MAXSLOTS + 2];  // individual of the read in every slot
-	uint32_t pad[7];
+	uint32_t pad[7];                 // genotype mode: [0] reads starting here, [1] starts before it in the run; phasing: [2], [3] = info3, M3 (a
+	                                 // fourth ending read: fetched from the row with scalar loads, its slot for the backtrace in SlotBtCol::pad[1])
 };
 static_assert(sizeof(PedSlotRow) == 192, "PedSlotRow must stay 48 words");
 // Per run, next to its SlotRun (kernel argument by value).
