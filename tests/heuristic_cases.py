@@ -41,6 +41,7 @@ SYNTHETIC = [
     (dict(n_variants=300, coverage=16, seed=7, trio=True, error_rate=0.1), 256),
     (dict(n_variants=250, coverage=14, seed=8, trio=True, mixed_genotypes=True), 128),
     (dict(n_variants=500, coverage=26, seed=9, error_rate=0.05), 256),          # beyond the exact DP's 25 reads per column
+    (dict(n_variants=160, coverage=70, seed=10, error_rate=0.05), 32),          # three words per bipartition
 ]
 
 
