@@ -95,9 +95,16 @@ inline void parallel_ranges(uint64_t n, uint32_t n_threads, F&& fn) {
 			fn(n * t / n_threads, n * (t + 1) / n_threads, t);
 		});
 	}
+	struct Finish {   // also on the way out of an exception in the caller's own range (std::bad_alloc): join, give the caller its mask back
+		std::vector<std::thread>& workers;
+		const bool rebind;
+		const cpu_set_t& mask;
+		~Finish() {
+			for (std::thread& w : workers) if (w.joinable()) w.join();
+			if (rebind) (void)pthread_setaffinity_np(pthread_self(), sizeof mask, &mask);
+		}
+	} finish{workers, rebind, caller_mask};
 	fn(n * (n_threads - 1) / n_threads, n, n_threads - 1);
-	for (std::thread& w : workers) w.join();
-	if (rebind) (void)pthread_setaffinity_np(pthread_self(), sizeof caller_mask, &caller_mask);
 }
 
 // Allocator of the create path's large arrays: the value-less construct() default-initialises (resize() of a vector of trivial
