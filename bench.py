@@ -55,13 +55,16 @@ WORKLOADS = {
     "config2": dict(variants=200000, coverage=20),                                 # BASELINE configs[2] (the headline)
     "config3": dict(trio=True, variants=100000, coverage=15),                      # BASELINE configs[3]
     "blocks3": dict(variants=100000, coverage=20, blocks=3, in_flight=3),          # three configs[4] blocks in flight on one GPU
+    "blocks24": dict(variants=100000, coverage=20, blocks=24, in_flight=24),       # BASELINE configs[4] on ONE GPU: all 24 blocks as one group of launches
+    "config1_x24": dict(variants=50000, coverage=15, blocks=24, in_flight=24),     # 24 tables at `whatshap phase`'s default coverage (24 chromosomes) on one GPU
+    "config3_x8": dict(trio=True, variants=100000, coverage=15, blocks=8, in_flight=8),  # eight trio tables (families / chromosomes) on one GPU
     "irregular": dict(irregular=True, variants=100000, coverage=20),               # Poisson starts, geometric lengths (mean 16), coverage capped
     "quartet": dict(quartet=True, variants=50000, coverage=13),                    # two trios sharing parents, T = 16
     "genotype": dict(genotype=True, variants=50000, coverage=15),                  # GenotypeDPTable, single individual
     "genotype_trio": dict(genotype=True, trio=True, variants=20000, coverage=15),  # GenotypeDPTable, trio
     "heuristic": dict(heuristic=True, variants=8000, coverage=30),                 # PedMecHeuristic, coverage beyond the exact DP
 }
-EXTRA_CONFIGS = ["config1", "config3", "blocks3", "irregular", "quartet", "genotype", "genotype_trio", "heuristic"]
+EXTRA_CONFIGS = ["config1", "config1_x24", "config3", "config3_x8", "blocks3", "blocks24", "irregular", "quartet", "genotype", "genotype_trio", "heuristic"]
 
 
 def parse_args():
@@ -165,7 +168,14 @@ def cpu_info():
     return {"nproc": os.cpu_count(), "model": model}
 
 
-def reference_seconds(args, seed, n_columns):
+def solution_tuple(table):
+    """Everything the drop-in class hands back (whatshap/core.pyx:364-416): cost, index path, transmission vector, partitioning, superreads."""
+    a0, a1, q, tv, sid = table.super_reads()
+    idx, tv2 = table.index_path()
+    return (int(table.optimal_score()), idx.tolist(), tv.tolist(), tv2.tolist(), table.partitioning().tolist(), a0.tolist(), a1.tolist(), q.tolist(), sid.tolist())
+
+
+def reference_seconds(args, seed, n_columns, want_solution=False):
     """Constructor + the three getters of the compiled reference (oracle/_ref; the C restatement if it is absent) on the
     first `n_columns` columns of the seeded ReadSet; single thread."""
     import oracle
@@ -178,7 +188,10 @@ def reference_seconds(args, seed, n_columns):
     score = table.optimal_score()
     table.super_reads()
     table.partitioning()
-    return time.perf_counter() - t0, table.n_columns, score, kind
+    seconds = time.perf_counter() - t0
+    if want_solution:
+        return seconds, table.n_columns, score, kind, solution_tuple(table), problem
+    return seconds, table.n_columns, score, kind
 
 
 def cpu_baseline(args, seed):
@@ -191,10 +204,20 @@ def cpu_baseline(args, seed):
         tb, cb, _, _ = reference_seconds(args, seed, ramp + 24)
         per_col = max((tb - ta) / max(cb - ca, 1), 1e-6)
         n_cpu = int(max(24, min(args.variants_for_cpu - ramp - 8, (4.0 if args.sub else 15.0) / per_col)))
-    tc, cc, score, _ = reference_seconds(args, seed, ramp + 8 + n_cpu)
+    tc, cc, score, _, want, prefix = reference_seconds(args, seed, ramp + 8 + n_cpu, want_solution=True)
     steady_cols, steady_s = cc - ca, max(tc - ta, 1e-9)
     info = cpu_info()
+    # the parity bit of this line: the SAME prefix on the device (the product path, through the C ABI), full tuple compared
+    from whatshap_amd import _native
+
+    mine = _native.NativeTable(prefix, device=args.device_for_parity, path=None if args.path == "auto" else args.path, solve=False)
+    apply_options(mine, args)
+    mine.solve()
+    identical = solution_tuple(mine) == want
+    mine.close()
     return {
+        "identical_to_reference": bool(identical),
+        "identical_what": f"cost, index path, transmission vector, partitioning and superreads (alleles + qualities) of the first {cc} columns: device vs the {kind}",
         "value": steady_cols / steady_s,
         "unit": "variant-columns/s",
         "cores": 1,
@@ -544,19 +567,19 @@ def heuristic_main(args):
     print(json.dumps(out), flush=True)
 
 
-def dominant_kernel(args):
+def dominant_kernel(args, grouped=False):
     if args.path in ("column", "column_keys"):
         return "column_step_fused"
     if args.trio or args.quartet:
-        return "resident_segment_ped" if args.path == "resident" else "pedslot_run"
-    return "resident_segment" if args.path == "resident" else "slot_run"
+        return "resident_segment_ped" if args.path == "resident" else ("pedslot_group" if grouped else "pedslot_run")
+    return "resident_segment" if args.path == "resident" else ("slot_group" if grouped else "slot_run")
 
 
 def run_extra_configs(args):
     """The other single-GPU workloads, one child process each (own tables, own counters, own CPU sample)."""
     out = []
     for name in EXTRA_CONFIGS:
-        cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--sub", "--steps", str(max(2, min(args.steps, 3))), "--warmup", "1",
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--sub", "--steps", "10", "--warmup", "2",
                "--configs", "off", "--pmc", args.pmc, "--pmc-keep", os.path.join(args.pmc_keep, name)]
         if args.cpu_baseline_columns == 0:
             cmd += ["--cpu-baseline-columns", "0"]
@@ -578,7 +601,13 @@ def run_extra_configs(args):
             "value": full["value"],
             "unit": full["unit"],
             "ms_per_step": full["ms_per_step"],
+            "ms_per_step_min": full.get("ms_per_step_min"),
+            "ms_per_step_median": full.get("ms_per_step_median"),
             "steps": full["steps"],
+            "warmup": full["warmup"],
+            "tables_in_flight": full["config"].get("blocks_in_flight_per_gpu"),
+            "tables_per_launch": full["config"].get("tables_per_launch"),
+            "identical_to_reference": full.get("identical_to_reference"),
             "bipartition_costs_per_s": full["bipartition_costs_per_s"],
             "optimal_cost_checksum": full["config"]["optimal_cost_checksum"],
             "forward_launches_per_step": full["rank0"]["forward_launches_per_step"],
@@ -680,13 +709,24 @@ def main():
     t0 = time.perf_counter()
     fwd_ms = bt_ms = 0.0
     launches = 0
+    step_s = []
+    grouped = False
     for _ in range(args.steps):
+        ts = time.perf_counter()
         step()
-        for t in tables:
-            s = t.stats()
-            fwd_ms += s["forward_ms"]
-            bt_ms += s["backtrace_ms"]
-            launches += s["forward_launches"]
+        step_s.append(time.perf_counter() - ts)
+        for start in range(0, len(tables), args.in_flight):
+            st = [t.stats() for t in tables[start:start + args.in_flight]]
+            if st[0]["group_tables"] > 1:
+                # the tables of the window shared their launches (enqueue_many -> one slot_group launch per super-step): every table
+                # reports the group's forward time and the launches it took part in
+                grouped = True
+                fwd_ms += max(x["forward_ms"] for x in st)
+                launches += max(x["forward_launches"] for x in st)
+            else:
+                fwd_ms += sum(x["forward_ms"] for x in st)
+                launches += sum(x["forward_launches"] for x in st)
+            bt_ms += sum(x["backtrace_ms"] for x in st)
     sync()
     elapsed = time.perf_counter() - t0
     stats = [t.stats() for t in tables]
@@ -715,7 +755,7 @@ def main():
         bytes_rank = sum(s["algorithmic_bytes"] for s in stats)
         bytes_per_launch = bytes_rank / max(launches / args.steps, 1)
         column_path = args.path in ("column", "column_keys")
-        kernel = dominant_kernel(args)
+        kernel = dominant_kernel(args, grouped)
         kind = "synthetic trio PedMEC" if args.trio else ("synthetic quartet PedMEC (two trios sharing parents)" if args.quartet else "synthetic diploid single-individual")
         out = {
             "metric": "variant-columns/sec at max-coverage %d (bipartition-costs/sec reported alongside)" % args.coverage,
@@ -729,6 +769,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_min": min(step_s) * 1e3,
+            "ms_per_step_median": sorted(step_s)[len(step_s) // 2] * 1e3,
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,
@@ -741,6 +783,7 @@ def main():
                 "block_seeds_per_rank": [[blocks[b][0] for b in r] for r in assign_blocks(weights, world)],
                 "device_per_rank": per_rank_devices,
                 "blocks_in_flight_per_gpu": min(args.in_flight, len(mine)),
+                "tables_per_launch": (min(args.in_flight, len(mine)) if grouped else 1),
                 "max_coverage": args.coverage,
                 "transmission_values": T,
                 "path": args.path,
@@ -805,8 +848,11 @@ def main():
         out["roofline"]["work_bound_note"] = f"{ops:g} VALU lane-operations per evaluated cell-value of a column at 512 wave-instructions/cycle, over the forward time of a step"
         # ---- CPU baseline (rank 0, N = 1 only)
         args.variants_for_cpu = blocks[0][1]
+        args.device_for_parity = device
         if world == 1 and args.cpu_baseline_columns != 0:
             out["cpu_baseline"] = cpu_baseline(args, blocks[0][0])
+            out["identical_to_reference"] = out["cpu_baseline"].pop("identical_to_reference")
+            out["identical_what"] = out["cpu_baseline"].pop("identical_what")
             out["speedup_vs_cpu_baseline_device_only"] = out["value"] / out["cpu_baseline"]["value"]
             if "end_to_end" in out:
                 out["speedup_vs_cpu_baseline"] = out["end_to_end"]["value"] / out["cpu_baseline"]["value"]
@@ -819,6 +865,12 @@ def main():
                 t.release_device()
             out["configs"] = run_extra_configs(args)
         print(json.dumps(out), flush=True)
+        parity = [out.get("identical_to_reference")] + [c.get("identical_to_reference") for c in out.get("configs", [])]
+        if any(x is False for x in parity):
+            print("bench.py: a device solution differs from the reference's (identical_to_reference: false)", file=sys.stderr, flush=True)
+            if dist is not None:
+                dist.destroy_process_group()
+            sys.exit(3)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -103,7 +103,8 @@ typedef struct whamd_solve_stats {
 	uint32_t bt_chunks;          /* chunked speculative backtrace: chunks walked at once (0: the sequential walk was used) */
 	uint32_t bt_missed;          /*   chunks whose true entry state was none of the guesses */
 	uint32_t bt_rewalked;        /*   units walked again from the true state */
-	uint32_t pad;
+	uint32_t group_tables;       /* tables that shared this solve's forward launches (whamd_dptable_enqueue_many groups tables of one device;
+	                              * 1: the table ran alone).  forward_ms / forward_launches then describe the GROUP's launches. */
 } whamd_solve_stats;
 
 /* Library / device introspection. */

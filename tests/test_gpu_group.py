@@ -1,0 +1,132 @@
+"""GPU (-m gpu): several tables as ONE sequence of launches (whamd_dptable_enqueue_many -> DeviceTable::enqueue_group,
+slot_group / pedslot_group): every table of a batched solve must give exactly what it gives alone -- cost, index path,
+transmission vector, partitioning, superreads with qualities -- and what the oracle gives.
+
+Independent tables are what `whatshap phase` produces per chromosome x family (whatshap/cli/phase.py:467,486,604); the tie rules
+being pinned are src/pedigreedptable.cpp:264-300 (lowest j) and :306-327 (Gray order).
+"""
+import numpy as np
+import pytest
+
+import oracle
+from helpers import first_difference, table_solution
+from whatshap_amd import _native
+from whatshap_amd.synthetic import irregular_block, synthetic_block
+
+pytestmark = pytest.mark.gpu
+
+
+def two_valued(problem, seed):
+    """Qualities from {5, 10}: nearly every minimum is attained more than once (the tie rules carry the result)."""
+    rng = np.random.default_rng(seed)
+    q = rng.choice(np.array([5, 10], dtype=np.uint32), size=problem.var_quality.size)
+    return _native.ProblemArrays(problem.read_ptr, problem.var_position, problem.var_allele, q, problem.read_sample_id, problem.individual_id,
+                                 problem.triple_ids, problem.genotype, problem.genotype_likelihoods, problem.recombcost, problem.positions,
+                                 problem.distrust_genotypes, n_variants=problem.n_variants)
+
+
+def the_24_tables():
+    """24 DIFFERENT tables: widths from 1 to 16 workgroups, lengths from 300 to 4000 columns (some longer than two backtrace chunks, so
+    their runs leave speculative seeds inside the group kernel), regular and irregular layouts, tie-heavy weights, trios, a quartet."""
+    out = []
+    for i, (cov, n) in enumerate([(15, 4000), (15, 3000), (14, 2500), (13, 1800), (12, 900), (12, 400), (11, 350), (10, 300)]):
+        out.append(("single", synthetic_block(n_variants=n, coverage=cov, seed=40 + i)))
+    for i, (cov, n) in enumerate([(15, 3000), (14, 2000), (12, 600), (12, 450)]):
+        out.append(("irregular", irregular_block(n, cov, seed=60 + i)))
+    for i, (cov, n) in enumerate([(14, 2200), (12, 500), (11, 400)]):
+        out.append(("ties", two_valued(synthetic_block(n_variants=n, coverage=cov, seed=70 + i), 170 + i)))
+    for i, (cov, n) in enumerate([(13, 2500), (12, 1500), (10, 420), (9, 380), (9, 300)]):
+        out.append(("trio", synthetic_block(n_variants=n, coverage=cov, seed=80 + i, trio=True)))
+    out.append(("trio ties", two_valued(synthetic_block(n_variants=400, coverage=9, seed=88, trio=True), 188)))
+    out.append(("quartet", synthetic_block(n_variants=1200, coverage=11, seed=90, quartet=True)))
+    out.append(("quartet", synthetic_block(n_variants=300, coverage=8, seed=91, quartet=True)))
+    out.append(("single", synthetic_block(n_variants=700, coverage=9, seed=92)))
+    assert len(out) == 24
+    return out
+
+
+ORACLE_ON = range(24)   # (the CPU restatement needs ~25 s for all of them)
+
+
+@pytest.fixture(scope="module")
+def tables_and_alone():
+    cases = the_24_tables()
+    alone = []
+    for _, p in cases:
+        t = _native.NativeTable(p)
+        alone.append(table_solution(t))
+        t.close()
+    return cases, alone
+
+
+def test_24_different_tables_batched_equal_one_by_one_and_the_oracle(tables_and_alone):
+    cases, alone = tables_and_alone
+    tables = [_native.NativeTable(p, solve=False) for _, p in cases]
+    _native.enqueue_many(tables)
+    for t in tables:
+        t.wait()
+    for i, t in enumerate(tables):
+        got = table_solution(t)
+        assert got == alone[i], (i, cases[i][0], first_difference(alone[i], got))
+    assert any(t.stats()["bt_chunks"] > 0 for t in tables), "no table of the batch went through the chunked backtrace"
+    for i in ORACLE_ON:
+        want = table_solution(oracle.OracleTable(cases[i][1]))
+        assert alone[i] == want, (i, cases[i][0], first_difference(want, alone[i]))
+    # a second solve of the same batch (buffers re-armed on the group's stream) and of a reversed, smaller batch
+    _native.enqueue_many(tables)
+    for t in tables:
+        t.wait()
+    for i, t in enumerate(tables):
+        assert table_solution(t) == alone[i], (i, "second batched solve")
+    some = [tables[i] for i in (23, 17, 9, 0)]
+    _native.enqueue_many(some)
+    for t in some:
+        t.wait()
+    for t, i in zip(some, (23, 17, 9, 0)):
+        assert table_solution(t) == alone[i], (i, "reordered batch")
+    # ... and a table of the batch solved alone afterwards
+    tables[3].solve()
+    assert table_solution(tables[3]) == alone[3]
+    for t in tables:
+        t.close()
+
+
+def test_batch_with_tables_outside_the_group(tables_and_alone):
+    """Per-column and LDS-resident tables keep their own streams next to a group; a table with connected components brings several
+    runs per super-step into the group launch."""
+    cases, alone = tables_and_alone
+    picks = (4, 6, 17, 22)
+    tables = [_native.NativeTable(cases[i][1], solve=False, path=("column" if i == 6 else ("resident" if i == 17 else None))) for i in picks]
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    from gpu_multiblock import chromosome
+
+    comp = chromosome(9, 11, seed=6, max_len=150)
+    comp_alone = table_solution(_native.NativeTable(comp))
+    tables.append(_native.NativeTable(comp, solve=False))
+    _native.enqueue_many(tables)
+    for t in tables:
+        t.wait()
+    for t, i in zip(tables, picks):
+        assert table_solution(t) == alone[i], (i, first_difference(alone[i], table_solution(t)))
+    assert table_solution(tables[-1]) == comp_alone
+    assert comp_alone == table_solution(oracle.OracleTable(comp))
+    for t in tables:
+        t.close()
+
+
+def test_full_width_tables_batched():
+    """Three coverage-20 tables (256 workgroups each) in one launch per super-step: more workgroups than the chip holds at once."""
+    ps = [synthetic_block(n_variants=200000, coverage=20, seed=3 + i, n_columns_limit=1500 + 200 * i) for i in range(3)]
+    alone = []
+    for p in ps:
+        t = _native.NativeTable(p)
+        alone.append(table_solution(t))
+        t.close()
+    tables = [_native.NativeTable(p, solve=False) for p in ps]
+    _native.enqueue_many(tables)
+    for t in tables:
+        t.wait()
+    for t, a in zip(tables, alone):
+        assert table_solution(t) == a, first_difference(a, table_solution(t))
+        t.close()

@@ -78,7 +78,7 @@ class SolveStats(C.Structure):
         ("bt_chunks", C.c_uint32),
         ("bt_missed", C.c_uint32),
         ("bt_rewalked", C.c_uint32),
-        ("pad", C.c_uint32),
+        ("group_tables", C.c_uint32),
     ]
 
     def as_dict(self) -> dict:

@@ -123,20 +123,50 @@ whamd_status_t whamd_dptable_enqueue_many(whamd_dptable* const* tables, size_t n
 		whamd_status_t st = begin_enqueue(tables[i]);
 		if (st != WHAMD_OK) return st;
 	}
-	// round robin over the tables, a few launches each: their streams fill up side by side
-	constexpr uint64_t SLICE = 16;
-	std::vector<uint8_t> done(n_tables, 0);
-	size_t open = n_tables;
 	std::string msg;
-	while (open) {
+	// Tables on slot runs (the default path) of one device advance TOGETHER: one launch per super-step serves all of them
+	// (DeviceTable::enqueue_group).  Everything else -- other paths, windowed tables, a device with a single table -- keeps its own
+	// stream; those submissions are interleaved round robin below.
+	std::vector<size_t> rest;
+	{
+		std::vector<std::pair<int, size_t>> eligible;   // (device, position)
 		for (size_t i = 0; i < n_tables; ++i) {
+			if (tables[i]->device.group_eligible(tables[i]->problem)) eligible.emplace_back(tables[i]->device_index, i);
+			else rest.push_back(i);
+		}
+		std::stable_sort(eligible.begin(), eligible.end(), [](const std::pair<int, size_t>& a, const std::pair<int, size_t>& b) { return a.first < b.first; });
+		for (size_t a = 0; a < eligible.size();) {
+			size_t b = a;
+			while (b < eligible.size() && eligible[b].first == eligible[a].first) ++b;
+			if (b - a == 1) { rest.push_back(eligible[a].second); a = b; continue; }
+			std::vector<DeviceTable*> devs;
+			std::vector<const Problem*> probs;
+			std::vector<Solution*> sols;
+			for (size_t q = a; q < b; ++q) {
+				whamd_dptable* t = tables[eligible[q].second];
+				devs.push_back(&t->device); probs.push_back(&t->problem); sols.push_back(&t->solution);
+			}
+			const whamd_status_t st = DeviceTable::enqueue_group(devs.data(), probs.data(), sols.data(), devs.size(), msg);
+			if (st != WHAMD_OK) return fail(st, msg);   // (the group has rewound itself; tables of earlier groups stay in flight)
+			for (size_t q = a; q < b; ++q) tables[eligible[q].second]->in_flight = true;
+			a = b;
+		}
+		std::sort(rest.begin(), rest.end());
+	}
+	// round robin over the remaining tables, a few launches each: their streams fill up side by side
+	constexpr uint64_t SLICE = 16;
+	std::vector<uint8_t> done(n_tables, 1);
+	for (size_t i : rest) done[i] = 0;
+	size_t open = rest.size();
+	while (open) {
+		for (size_t i : rest) {
 			if (done[i]) continue;
 			bool finished = false;
 			whamd_status_t st = tables[i]->device.enqueue_some(tables[i]->problem, tables[i]->solution, SLICE, finished, msg);
 			if (st != WHAMD_OK) {
 				// the failing table has rewound itself; the others must not keep half-submitted schedules either: tables
 				// whose submission is complete stay in flight (collect them with whamd_dptable_wait), the rest is aborted
-				for (size_t j = 0; j < n_tables; ++j)
+				for (size_t j : rest)
 					if (j != i && !done[j]) tables[j]->device.abort_enqueue();
 				return fail(st, msg);
 			}

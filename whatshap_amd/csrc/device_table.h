@@ -25,6 +25,11 @@ public:
 	// Resumable enqueue(): at most `budget` forward launches per call; `done` once backtrace and downloads are submitted.
 	whamd_status_t enqueue_some(const Problem& p, Solution& s, uint64_t budget, bool& done, std::string& msg);
 	whamd_status_t wait(const Problem& p, Solution& s, whamd_solve_stats& st, std::string& msg);
+	// Several tables of ONE device as one sequence of launches (see dp_device.hip, "group solve"): every table must be group_eligible().
+	// Afterwards each table is in flight exactly as after enqueue(): collect with wait().
+	static whamd_status_t enqueue_group(DeviceTable* const* tables, const Problem* const* problems, Solution* const* solutions, size_t n_tables, std::string& msg);
+	bool group_eligible(const Problem& p) const;
+	int device_index() const;
 	// Drops a partially submitted solve (enqueue_some that has not reported `done`): drains the stream, rewinds the cursor.
 	void abort_enqueue();
 	// Frees the device buffers, the stream and the events; the next upload() recreates them.

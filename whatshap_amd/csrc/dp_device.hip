@@ -198,7 +198,9 @@ struct StageSession {
 struct DeviceTable::Impl {
 	int device = 0;
 	hipStream_t stream = nullptr;
+	hipStream_t run_stream = nullptr;   // where the forward steps of the solve being submitted go: `stream`, or the stream of the group's first table (enqueue_group)
 	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+	hipEvent_t ev_group = nullptr;      // group solve: "the forward pass of every table of the group is submitted up to here"
 	std::vector<void*> allocations;
 	void* d_arena = nullptr;    // the backtrace arena: not in `allocations`, handed to the arena cache on release
 	size_t arena_bytes = 0;
@@ -223,6 +225,7 @@ struct DeviceTable::Impl {
 	int symmetry = 1;  // single individual: compute only half of a run, the rest is its mirror image (plan_forward)
 	uint64_t bt_bytes = 0;
 	uint64_t launches = 0;
+	uint32_t group_tables = 1;  // tables that shared the forward launches of the solve in flight (enqueue_group)
 	bool enqueue_open = false;  // resumable enqueue (enqueue_some)
 	uint32_t* h_pinned = nullptr;  // [2 n + 1 + jobs]: path index, path transmission, score of the final job, scores of the others
 	// A job is a sequence of forward steps with its own backtrace.  Job 0 ("final") is the last connected component (it
@@ -308,6 +311,9 @@ struct DeviceTable::Impl {
 	void launch_column_step(const Problem& p, const Step& step, const Lane& lane, const uint32_t* prev, uint32_t* cur, uint64_t& launches);
 	void launch_run(const ResBatchEntry& e, uint32_t step_index, uint64_t& launches);
 	void launch_slot_run(const SlotBatchEntry& e, uint64_t& launches);
+	whamd_status_t begin_solve(const Problem& p, Solution& s, std::string& msg);
+	whamd_status_t submit_singles(const Problem& p, const SuperStep& ss, uint64_t& launches, std::string& msg);
+	whamd_status_t submit_tail(const Problem& p, std::string& msg);
 
 	void release_lanes() {
 		lanes.clear();
@@ -346,6 +352,7 @@ DeviceTable::~DeviceTable() {
 		if (impl_->ev1) (void)hipEventDestroy(impl_->ev1);
 		if (impl_->ev2) (void)hipEventDestroy(impl_->ev2);
 		if (impl_->ev3) (void)hipEventDestroy(impl_->ev3);
+		if (impl_->ev_group) (void)hipEventDestroy(impl_->ev_group);
 		if (impl_->stream) (void)hipStreamDestroy(impl_->stream);
 		delete impl_;
 	}
@@ -355,7 +362,7 @@ void DeviceTable::release_device() {
 	Impl& m = *impl_;
 	(void)hipSetDevice(m.device);
 	m.release();
-	for (hipEvent_t* e : {&m.ev0, &m.ev1, &m.ev2, &m.ev3}) {
+	for (hipEvent_t* e : {&m.ev0, &m.ev1, &m.ev2, &m.ev3, &m.ev_group}) {
 		if (*e) (void)hipEventDestroy(*e);
 		*e = nullptr;
 	}
@@ -419,6 +426,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		HIP_TRY(hipEventCreate(&m.ev1));
 		HIP_TRY(hipEventCreate(&m.ev2));
 		HIP_TRY(hipEventCreate(&m.ev3));
+		HIP_TRY(hipEventCreateWithFlags(&m.ev_group, hipEventDisableTiming));
 	}
 	m.release();
 	const uint32_t n = p.n_cols;
@@ -987,8 +995,20 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 					e.cur = lane.d_pr[c.flip ^ 1];
 					e.score_out = (last && !job.final) ? m.d_job_scores + job_id : nullptr;
 					ss.io[0] = lane.d_pr[c.flip]; ss.io[1] = lane.d_pr[c.flip ^ 1];
+					if (m.splan.ped) {
+						const PedSlotExtra& pex = m.splan.pextra[step.index];
+						ss.lds = std::max<size_t>(ss.lds, ((size_t)2 * e.run.threads + (PSLOT_MAXCOLS + 4) * 8 + (size_t)(e.run.threads >> 6) * (pex.arow + 4u * p.T * pex.nf) + (size_t)(e.run.ncols + 4) * 64 * pex.nf) * 4);
+					} else
 					ss.lds = std::max<size_t>(ss.lds, (size_t)2 * e.run.threads * (1u << e.run.lr) * 4 + (SLOT_MAXCOLS + 8) * 64 + 8 * 64 * 4 + (SLOT_MAXCOLS + 8) * 64 * 4);
 					e.pad = step.index;
+					// the owning table's arrays: a group launch (slot_group / pedslot_group) serves runs of several tables
+					if (ped_slots) e.ex = m.splan.pextra[step.index];
+					e.tab = ped_slots ? (const uint32_t*)d_ptab : (const uint32_t*)d_stab;
+					e.rows = ped_slots ? (const void*)d_prows : (const void*)d_srows;
+					e.ctrl = (const uint32_t*)d_sctrl;
+					e.bt = (uint8_t*)d_bt;
+					e.spec_keys = m.dp.spec_keys;
+					e.spec_stride = m.dp.spec_stride;
 					ss.grid_x = std::max(ss.grid_x, 1u << (e.run.g - e.run.half));
 					ss.threads = std::max(ss.threads, e.run.threads);
 					m.slot_entries.push_back(e);
@@ -1134,6 +1154,10 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, 2, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, 4, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, 4, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_group<2, 2>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_group<2, 4>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_group<4, 2>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_group<4, 4>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 	return WHAMD_OK;
 }
 
@@ -1162,16 +1186,16 @@ void DeviceTable::Impl::launch_column_step(const Problem& p, const Step& step, c
 	if (d.mode == 0) {
 		const uint32_t threads = 1u << d.f;
 		const uint32_t block = std::min<uint32_t>(256, threads);
-		hipLaunchKernelGGL(m.fused, dim3(threads / block), dim3(block), 0, m.stream, dp, c, prev, cur);
+		hipLaunchKernelGGL(m.fused, dim3(threads / block), dim3(block), 0, m.run_stream, dp, c, prev, cur);
 		launches += 1;
 	} else {
 		const uint64_t total = (1ull << (d.f + d.ebits - d.eloop)) * (m.wide ? p.T : 1u);
 		const uint32_t block = (uint32_t)std::min<uint64_t>(256, (total + 63) / 64 * 64);
-		if (m.wide) hipLaunchKernelGGL(column_step_wide, dim3((uint32_t)((total + block - 1) / block)), dim3(block), 0, m.stream, dp, c, prev, (uint32_t)total);
-		else hipLaunchKernelGGL(m.keysfn, dim3((uint32_t)((total + block - 1) / block)), dim3(block), 0, m.stream, dp, c, prev, (uint32_t)total);
+		if (m.wide) hipLaunchKernelGGL(column_step_wide, dim3((uint32_t)((total + block - 1) / block)), dim3(block), 0, m.run_stream, dp, c, prev, (uint32_t)total);
+		else hipLaunchKernelGGL(m.keysfn, dim3((uint32_t)((total + block - 1) / block)), dim3(block), 0, m.run_stream, dp, c, prev, (uint32_t)total);
 		const uint32_t entries = (1u << d.f) * p.T;
 		const uint32_t fblock = std::min<uint32_t>(256, (entries + 63) / 64 * 64);
-		hipLaunchKernelGGL(column_finalize, dim3((entries + fblock - 1) / fblock), dim3(fblock), 0, m.stream, dp, c, cur, entries);
+		hipLaunchKernelGGL(column_finalize, dim3((entries + fblock - 1) / fblock), dim3(fblock), 0, m.run_stream, dp, c, cur, entries);
 		launches += 2;
 	}
 }
@@ -1183,16 +1207,16 @@ void DeviceTable::Impl::launch_run(const ResBatchEntry& e, uint32_t step_index, 
 	if (sg.kind == 1) {
 		const size_t words = ((size_t)sg.ncols * (PED_LDSWORDS + PED_TABLE) + (size_t)sg.n_terms * 2 + 3) & ~(size_t)3;
 		const size_t lds_ped = words * 4 + 2 * ((size_t)16 << sg.max_l) + (size_t)sg.stage_words * 8;
-		if (m.dp.dbg) hipLaunchKernelGGL(resident_segment_ped<true>, dim3(1u << sg.g), dim3(sg.threads), lds_ped, m.stream, m.dp, sg, e.prev, e.cur);
-		else if (sg.in_mirror_bit && m.use_chunks) hipLaunchKernelGGL((resident_segment_ped<false, true>), dim3(1u << sg.g), dim3(sg.threads), lds_ped, m.stream, m.dp, sg, e.prev, e.cur);
-		else hipLaunchKernelGGL(resident_segment_ped<false>, dim3(1u << sg.g), dim3(sg.threads), lds_ped, m.stream, m.dp, sg, e.prev, e.cur);
+		if (m.dp.dbg) hipLaunchKernelGGL(resident_segment_ped<true>, dim3(1u << sg.g), dim3(sg.threads), lds_ped, m.run_stream, m.dp, sg, e.prev, e.cur);
+		else if (sg.in_mirror_bit && m.use_chunks) hipLaunchKernelGGL((resident_segment_ped<false, true>), dim3(1u << sg.g), dim3(sg.threads), lds_ped, m.run_stream, m.dp, sg, e.prev, e.cur);
+		else hipLaunchKernelGGL(resident_segment_ped<false>, dim3(1u << sg.g), dim3(sg.threads), lds_ped, m.run_stream, m.dp, sg, e.prev, e.cur);
 	} else {
 		const size_t lds = (size_t)sg.ncols * (64 + RES_TABLE) * 4 + 2 * ((size_t)4 << sg.max_l) + (size_t)sg.stage_words * 8;
 		const bool sym = sg.half || sg.in_half || sg.mirror_out;
 		const dim3 grid(1u << (sg.g - sg.half)), block(sg.threads);
-		if (m.dp.dbg) hipLaunchKernelGGL((resident_segment<true, true>), grid, block, lds, m.stream, m.dp, sg, e.prev, e.cur, e.score_out);
-		else if (sym) hipLaunchKernelGGL((resident_segment<false, true>), grid, block, lds, m.stream, m.dp, sg, e.prev, e.cur, e.score_out);
-		else hipLaunchKernelGGL((resident_segment<false, false>), grid, block, lds, m.stream, m.dp, sg, e.prev, e.cur, e.score_out);
+		if (m.dp.dbg) hipLaunchKernelGGL((resident_segment<true, true>), grid, block, lds, m.run_stream, m.dp, sg, e.prev, e.cur, e.score_out);
+		else if (sym) hipLaunchKernelGGL((resident_segment<false, true>), grid, block, lds, m.run_stream, m.dp, sg, e.prev, e.cur, e.score_out);
+		else hipLaunchKernelGGL((resident_segment<false, false>), grid, block, lds, m.run_stream, m.dp, sg, e.prev, e.cur, e.score_out);
 	}
 	launches += 1;
 }
@@ -1208,7 +1232,7 @@ void DeviceTable::Impl::launch_slot_run(const SlotBatchEntry& e, uint64_t& launc
 		// wave-slot exchange + hot lines + per-wave A rows + S (four columns of slack behind the rows: lines are requested ahead)
 		const size_t lds_ped = ((size_t)2 * run.threads + (PSLOT_MAXCOLS + 4) * 8 + (size_t)(run.threads >> 6) * (ex.arow + 4u * T * ex.nf) + (size_t)(run.ncols + 4) * 64 * ex.nf) * 4;
 		const dim3 grid(1u << run.g), block(run.threads);
-#define WHAMD_PSLOT_LAUNCH(TBV, NFV, SPECV) hipLaunchKernelGGL((pedslot_run<TBV, NFV, SPECV>), grid, block, lds_ped, m.stream, m.dp, run, ex, e.prev, e.cur)
+#define WHAMD_PSLOT_LAUNCH(TBV, NFV, SPECV) hipLaunchKernelGGL((pedslot_run<TBV, NFV, SPECV>), grid, block, lds_ped, m.run_stream, m.dp, run, ex, e.prev, e.cur)
 		if (ex.tb == 2 && ex.nf == 2) { if (spec) WHAMD_PSLOT_LAUNCH(2, 2, true); else WHAMD_PSLOT_LAUNCH(2, 2, false); }
 		else if (ex.tb == 2) { if (spec) WHAMD_PSLOT_LAUNCH(2, 4, true); else WHAMD_PSLOT_LAUNCH(2, 4, false); }
 		else if (ex.nf == 2) { if (spec) WHAMD_PSLOT_LAUNCH(4, 2, true); else WHAMD_PSLOT_LAUNCH(4, 2, false); }
@@ -1220,7 +1244,7 @@ void DeviceTable::Impl::launch_slot_run(const SlotBatchEntry& e, uint64_t& launc
 	const size_t lds = (size_t)2 * run.threads * (1u << run.lr) * 4 + (SLOT_MAXCOLS + 8) * 64 + 8 * 64 * 4 + (SLOT_MAXCOLS + 8) * 64 * 4;   // wave-slot exchange + hot lines + per-wave A + lane sums
 	const dim3 grid(1u << (run.g - run.half)), block(run.threads);
 	const bool dbg = m.dp.dbg != nullptr || m.dp.dbg_flags != 0;
-#define WHAMD_SLOT_LAUNCH(LRV, DBGV, SPECV) hipLaunchKernelGGL((slot_run<LRV, DBGV, SPECV>), grid, block, lds, m.stream, m.dp, run, e.prev, e.cur, e.score_out)
+#define WHAMD_SLOT_LAUNCH(LRV, DBGV, SPECV) hipLaunchKernelGGL((slot_run<LRV, DBGV, SPECV>), grid, block, lds, m.run_stream, m.dp, run, e.prev, e.cur, e.score_out)
 	if (run.lr == 3) {
 		if (dbg) { if (spec) WHAMD_SLOT_LAUNCH(3, true, true); else WHAMD_SLOT_LAUNCH(3, true, false); }
 		else { if (spec) WHAMD_SLOT_LAUNCH(3, false, true); else WHAMD_SLOT_LAUNCH(3, false, false); }
@@ -1257,69 +1281,47 @@ void DeviceTable::abort_enqueue() {
 	m.next_super = 0;
 }
 
-whamd_status_t DeviceTable::enqueue_some_unguarded(const Problem& p, Solution& s, uint64_t budget, bool& done, std::string& msg) {
-	Impl& m = *impl_;
+// The preamble of a solve on m.run_stream: path buffers, key re-arm, the start event, the lookup tables of the LDS-resident paths.
+whamd_status_t DeviceTable::Impl::begin_solve(const Problem& p, Solution& s, std::string& msg) {
+	Impl& m = *this;
 	const uint32_t n = p.n_cols;
-	done = false;
-	if (n) HIP_TRY(hipSetDevice(m.device));
-	if (!m.enqueue_open) {
-		m.enqueue_open = true;
-		s.path_index.assign(n, 0);
-		s.path_trans.assign(n, 0);
-		m.launches = 0;
-		m.next_super = 0;
-		if (n == 0) {  // src/pedigreedptable.cpp:88-92
-			s.optimal_score = 0;
-			m.enqueue_open = false;
-			done = true;
-			return WHAMD_OK;
-		}
-		for (const Impl::Lane& lane : m.lanes) HIP_TRY(hipMemsetAsync(lane.d_keys, 0xFF, m.key_entries * 8, m.stream));
-		HIP_TRY(hipMemsetAsync(m.dp.last_keys, 0xFF, (size_t)MAX_T_WIDE * 8, m.stream));
-		if (m.use_chunks) HIP_TRY(hipMemsetAsync(m.dp.spec_keys, 0xFF, ((size_t)m.n_spec + 1) * m.dp.spec_stride * 8, m.stream));
-		if (m.windowed) HIP_TRY(hipMemsetAsync(m.d_path_trans, 0, (size_t)n * 4, m.stream));
-		HIP_TRY(hipEventRecord(m.ev0, m.stream));
-		if (!m.plan.ped_columns.empty()) {
-			const uint32_t entries = (uint32_t)m.plan.ped_columns.size() * PED_TABLE;
-			hipLaunchKernelGGL(ped_tables, dim3((entries + 255) / 256), dim3(256), 0, m.stream, m.dp.ped_cols, (uint32_t)m.plan.ped_columns.size(), m.dp.ped_tables);
-		} else if (!m.use_slots && !m.plan.columns.empty()) {
-			const uint32_t entries = (uint32_t)m.plan.columns.size() * RES_TABLE;
-			hipLaunchKernelGGL(resident_tables, dim3((entries + 255) / 256), dim3(256), 0, m.stream, m.dp.res_cols, (uint32_t)m.plan.columns.size(), m.dp.res_tables);
-		}
+	s.path_index.assign(n, 0);
+	s.path_trans.assign(n, 0);
+	m.launches = 0;
+	m.next_super = 0;
+	if (n == 0) return WHAMD_OK;
+	for (const Impl::Lane& lane : m.lanes) HIP_TRY(hipMemsetAsync(lane.d_keys, 0xFF, m.key_entries * 8, m.run_stream));
+	HIP_TRY(hipMemsetAsync(m.dp.last_keys, 0xFF, (size_t)MAX_T_WIDE * 8, m.run_stream));
+	if (m.use_chunks) HIP_TRY(hipMemsetAsync(m.dp.spec_keys, 0xFF, ((size_t)m.n_spec + 1) * m.dp.spec_stride * 8, m.run_stream));
+	if (m.windowed) HIP_TRY(hipMemsetAsync(m.d_path_trans, 0, (size_t)n * 4, m.run_stream));
+	HIP_TRY(hipEventRecord(m.ev0, m.run_stream));
+	if (!m.plan.ped_columns.empty()) {
+		const uint32_t entries = (uint32_t)m.plan.ped_columns.size() * PED_TABLE;
+		hipLaunchKernelGGL(ped_tables, dim3((entries + 255) / 256), dim3(256), 0, m.run_stream, m.dp.ped_cols, (uint32_t)m.plan.ped_columns.size(), m.dp.ped_tables);
+	} else if (!m.use_slots && !m.plan.columns.empty()) {
+		const uint32_t entries = (uint32_t)m.plan.columns.size() * RES_TABLE;
+		hipLaunchKernelGGL(resident_tables, dim3((entries + 255) / 256), dim3(256), 0, m.run_stream, m.dp.res_cols, (uint32_t)m.plan.columns.size(), m.dp.res_tables);
 	}
-	uint64_t launches = 0;
-	while (m.next_super < m.schedule.size() && launches < budget) {
-		const Impl::SuperStep& ss = m.schedule[m.next_super++];
-		if (ss.ck_load >= 0) HIP_TRY(hipMemcpyAsync(ss.io[0], m.d_checkpoints + (size_t)ss.ck_load * m.checkpoint_bytes, m.checkpoint_bytes, hipMemcpyDeviceToDevice, m.stream));
-		if (m.use_slots) {
-			if (ss.entry_count == 1) m.launch_slot_run(m.slot_entries[ss.entry_off], launches);
-			else if (ss.entry_count > 1) {
-				if (m.slot_lr == 1) hipLaunchKernelGGL(slot_batch<1>, dim3(ss.grid_x, ss.entry_count), dim3(ss.threads), ss.lds, m.stream, m.dp, m.d_slot_entries + ss.entry_off);
-				else if (m.slot_lr == 3) hipLaunchKernelGGL(slot_batch<3>, dim3(ss.grid_x, ss.entry_count), dim3(ss.threads), ss.lds, m.stream, m.dp, m.d_slot_entries + ss.entry_off);
-				else hipLaunchKernelGGL(slot_batch<2>, dim3(ss.grid_x, ss.entry_count), dim3(ss.threads), ss.lds, m.stream, m.dp, m.d_slot_entries + ss.entry_off);
-				launches += 1;
-			}
-		} else if (ss.entry_count == 1) {
-			m.launch_run(m.entries[ss.entry_off], 0, launches);
-		} else if (ss.entry_count > 1) {
-			if (ss.sym) hipLaunchKernelGGL(resident_batch<true>, dim3(ss.grid_x, ss.entry_count), dim3(ss.threads), ss.lds, m.stream, m.dp, m.d_entries + ss.entry_off);
-			else hipLaunchKernelGGL(resident_batch<false>, dim3(ss.grid_x, ss.entry_count), dim3(ss.threads), ss.lds, m.stream, m.dp, m.d_entries + ss.entry_off);
-			launches += 1;
-		}
-		for (const Impl::Single& sg : ss.singles) {
-			const Impl::Lane& lane = m.lanes[sg.lane];
-			if (sg.zero_prev) HIP_TRY(hipMemsetAsync(lane.d_pr[sg.flip], 0, 4 * (size_t)p.T, m.stream));
-			m.launch_column_step(p, m.plan.steps[sg.step], lane, lane.d_pr[sg.flip], lane.d_pr[sg.flip ^ 1], launches);
-			if (sg.score_job >= 0)
-				HIP_TRY(hipMemcpyAsync(m.d_job_scores + sg.score_job, lane.d_pr[sg.flip ^ 1], 4, hipMemcpyDeviceToDevice, m.stream));
-		}
-		if (ss.ck_save >= 0) HIP_TRY(hipMemcpyAsync(m.d_checkpoints + (size_t)ss.ck_save * m.checkpoint_bytes, ss.io[1], m.checkpoint_bytes, hipMemcpyDeviceToDevice, m.stream));
-		if (ss.bt_window >= 0)
-			hipLaunchKernelGGL(backtrace_kernel, dim3(1), dim3(1024), m.bt_lds, m.stream, m.dp, m.d_units, m.d_window_jobs + ss.bt_window,
-			                   m.d_path_index, m.d_path_trans, m.d_score);
+	return WHAMD_OK;
+}
+
+// The per-column steps of one super-step (each a launch of its own on m.run_stream).
+whamd_status_t DeviceTable::Impl::submit_singles(const Problem& p, const SuperStep& ss, uint64_t& launches, std::string& msg) {
+	Impl& m = *this;
+	for (const Impl::Single& sg : ss.singles) {
+		const Impl::Lane& lane = m.lanes[sg.lane];
+		if (sg.zero_prev) HIP_TRY(hipMemsetAsync(lane.d_pr[sg.flip], 0, 4 * (size_t)p.T, m.run_stream));
+		m.launch_column_step(p, m.plan.steps[sg.step], lane, lane.d_pr[sg.flip], lane.d_pr[sg.flip ^ 1], launches);
+		if (sg.score_job >= 0)
+			HIP_TRY(hipMemcpyAsync(m.d_job_scores + sg.score_job, lane.d_pr[sg.flip ^ 1], 4, hipMemcpyDeviceToDevice, m.run_stream));
 	}
-	m.launches += launches;
-	if (m.next_super < m.schedule.size()) return WHAMD_OK;
+	return WHAMD_OK;
+}
+
+// Everything after the forward pass, on the table's OWN stream: backtrace, downloads, events.
+whamd_status_t DeviceTable::Impl::submit_tail(const Problem& p, std::string& msg) {
+	Impl& m = *this;
+	const uint32_t n = p.n_cols;
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(m.ev1, m.stream));
 	if (m.use_chunks) {
@@ -1341,8 +1343,174 @@ whamd_status_t DeviceTable::enqueue_some_unguarded(const Problem& p, Solution& s
 	if (m.jobs.size() > 1)
 		HIP_TRY(hipMemcpyAsync(m.h_pinned + 2 * (size_t)n + 1, m.d_job_scores + 1, (m.jobs.size() - 1) * 4, hipMemcpyDeviceToHost, m.stream));
 	HIP_TRY(hipEventRecord(m.ev3, m.stream));
+	return WHAMD_OK;
+}
+
+whamd_status_t DeviceTable::enqueue_some_unguarded(const Problem& p, Solution& s, uint64_t budget, bool& done, std::string& msg) {
+	Impl& m = *impl_;
+	const uint32_t n = p.n_cols;
+	done = false;
+	if (n) HIP_TRY(hipSetDevice(m.device));
+	if (!m.enqueue_open) {
+		m.enqueue_open = true;
+		m.run_stream = m.stream;
+		m.group_tables = 1;
+		const whamd_status_t st = m.begin_solve(p, s, msg);
+		if (st != WHAMD_OK) return st;
+		if (n == 0) {  // src/pedigreedptable.cpp:88-92
+			s.optimal_score = 0;
+			m.enqueue_open = false;
+			done = true;
+			return WHAMD_OK;
+		}
+	}
+	uint64_t launches = 0;
+	while (m.next_super < m.schedule.size() && launches < budget) {
+		const Impl::SuperStep& ss = m.schedule[m.next_super++];
+		if (ss.ck_load >= 0) HIP_TRY(hipMemcpyAsync(ss.io[0], m.d_checkpoints + (size_t)ss.ck_load * m.checkpoint_bytes, m.checkpoint_bytes, hipMemcpyDeviceToDevice, m.stream));
+		if (m.use_slots) {
+			if (ss.entry_count == 1) m.launch_slot_run(m.slot_entries[ss.entry_off], launches);
+			else if (ss.entry_count > 1) {
+				if (m.slot_lr == 1) hipLaunchKernelGGL(slot_batch<1>, dim3(ss.grid_x, ss.entry_count), dim3(ss.threads), ss.lds, m.stream, m.dp, m.d_slot_entries + ss.entry_off);
+				else if (m.slot_lr == 3) hipLaunchKernelGGL(slot_batch<3>, dim3(ss.grid_x, ss.entry_count), dim3(ss.threads), ss.lds, m.stream, m.dp, m.d_slot_entries + ss.entry_off);
+				else hipLaunchKernelGGL(slot_batch<2>, dim3(ss.grid_x, ss.entry_count), dim3(ss.threads), ss.lds, m.stream, m.dp, m.d_slot_entries + ss.entry_off);
+				launches += 1;
+			}
+		} else if (ss.entry_count == 1) {
+			m.launch_run(m.entries[ss.entry_off], 0, launches);
+		} else if (ss.entry_count > 1) {
+			if (ss.sym) hipLaunchKernelGGL(resident_batch<true>, dim3(ss.grid_x, ss.entry_count), dim3(ss.threads), ss.lds, m.stream, m.dp, m.d_entries + ss.entry_off);
+			else hipLaunchKernelGGL(resident_batch<false>, dim3(ss.grid_x, ss.entry_count), dim3(ss.threads), ss.lds, m.stream, m.dp, m.d_entries + ss.entry_off);
+			launches += 1;
+		}
+		const whamd_status_t st = m.submit_singles(p, ss, launches, msg);
+		if (st != WHAMD_OK) return st;
+		if (ss.ck_save >= 0) HIP_TRY(hipMemcpyAsync(m.d_checkpoints + (size_t)ss.ck_save * m.checkpoint_bytes, ss.io[1], m.checkpoint_bytes, hipMemcpyDeviceToDevice, m.stream));
+		if (ss.bt_window >= 0)
+			hipLaunchKernelGGL(backtrace_kernel, dim3(1), dim3(1024), m.bt_lds, m.stream, m.dp, m.d_units, m.d_window_jobs + ss.bt_window,
+			                   m.d_path_index, m.d_path_trans, m.d_score);
+	}
+	m.launches += launches;
+	if (m.next_super < m.schedule.size()) return WHAMD_OK;
+	const whamd_status_t st = m.submit_tail(p, msg);
+	if (st != WHAMD_OK) return st;
 	m.enqueue_open = false;
 	done = true;
+	return WHAMD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- group solve
+// Several independent tables as ONE sequence of launches (whamd_dptable_enqueue_many): super-step k of the group = step k of every
+// member that still has one; the runs of all members go out as one slot_group / pedslot_group launch per kernel variant
+// (blockIdx.y = member), on the stream of the group's first table; per-column steps follow as launches of their own.  When the
+// forward pass is submitted every member's own stream waits for it (one event) and runs that table's backtrace and downloads --
+// those overlap across the members -- so whamd_dptable_wait works per table as before.
+bool DeviceTable::group_eligible(const Problem& p) const {
+	const Impl& m = *impl_;
+	if (p.n_cols == 0 || !m.use_slots || m.windowed || m.enqueue_open || m.dp.dbg || m.dp.dbg_flags) return false;
+	if (!m.splan.ped && m.slot_lr != 2) return false;   // (the group kernel exists for the default four cells per thread)
+	return getenv("WHAMD_NO_GROUP") == nullptr;
+}
+
+int DeviceTable::device_index() const { return impl_->device; }
+
+whamd_status_t DeviceTable::enqueue_group(DeviceTable* const* tables, const Problem* const* problems, Solution* const* solutions, size_t n_tables, std::string& msg) {
+	if (n_tables == 0) return WHAMD_OK;
+	Impl& lead = *tables[0]->impl_;
+	HIP_TRY(hipSetDevice(lead.device));
+	auto abort_all = [&]() {
+		(void)hipStreamSynchronize(lead.stream);
+		(void)hipGetLastError();
+		for (size_t i = 0; i < n_tables; ++i) {
+			Impl& m = *tables[i]->impl_;
+			(void)hipStreamSynchronize(m.stream);
+			m.enqueue_open = false;
+			m.next_super = 0;
+			m.run_stream = m.stream;
+		}
+	};
+	size_t max_steps = 0;
+	for (size_t i = 0; i < n_tables; ++i) {
+		Impl& m = *tables[i]->impl_;
+		m.enqueue_open = true;
+		m.run_stream = lead.stream;
+		m.group_tables = (uint32_t)n_tables;
+		const whamd_status_t st = m.begin_solve(*problems[i], *solutions[i], msg);
+		if (st != WHAMD_OK) { abort_all(); return st; }
+		max_steps = std::max(max_steps, m.schedule.size());
+	}
+	// kernel variants: 0 single individual (four cells per thread); 1 .. 4 pedigree runs (TB, NF) = (2,2) (2,4) (4,2) (4,4)
+	struct Batch { SlotGroupArgs args; uint32_t grid_x = 0, threads = 0; size_t lds = 0; };
+	std::vector<Batch> batches(5);
+	auto flush = [&](int variant) {
+		Batch& b = batches[variant];
+		if (!b.args.n) return;
+		const dim3 grid(b.grid_x, b.args.n), block(b.threads);
+		switch (variant) {
+			case 0: hipLaunchKernelGGL(slot_group<2>, grid, block, b.lds, lead.stream, b.args); break;
+			case 1: hipLaunchKernelGGL((pedslot_group<2, 2>), grid, block, b.lds, lead.stream, b.args); break;
+			case 2: hipLaunchKernelGGL((pedslot_group<2, 4>), grid, block, b.lds, lead.stream, b.args); break;
+			case 3: hipLaunchKernelGGL((pedslot_group<4, 2>), grid, block, b.lds, lead.stream, b.args); break;
+			default: hipLaunchKernelGGL((pedslot_group<4, 4>), grid, block, b.lds, lead.stream, b.args); break;
+		}
+		b.args.n = 0;
+		b.grid_x = b.threads = 0;
+		b.lds = 0;
+	};
+	std::vector<uint64_t> table_launches(n_tables, 0);
+	std::vector<uint8_t> counted(n_tables * 5, 0);
+	const auto t_submit0 = std::chrono::steady_clock::now();
+	for (size_t k = 0; k < max_steps; ++k) {
+		std::fill(counted.begin(), counted.end(), 0);
+		for (size_t i = 0; i < n_tables; ++i) {
+			Impl& m = *tables[i]->impl_;
+			if (k >= m.schedule.size()) continue;
+			const Impl::SuperStep& ss = m.schedule[k];
+			for (uint32_t q = 0; q < ss.entry_count; ++q) {
+				const SlotBatchEntry& he = m.slot_entries[ss.entry_off + q];
+				const int variant = m.splan.ped ? 1 + (he.ex.tb == 4 ? 2 : 0) + (he.ex.nf == 4 ? 1 : 0) : 0;
+				Batch& b = batches[variant];
+				if (b.args.n == (uint32_t)SLOT_GROUP_MAX) {
+					flush(variant);
+					for (size_t j = 0; j < n_tables; ++j) if (counted[j * 5 + variant]) { table_launches[j] += 1; counted[j * 5 + variant] = 0; }
+				}
+				b.args.entry[b.args.n++] = m.d_slot_entries + ss.entry_off + q;
+				b.grid_x = std::max(b.grid_x, 1u << (he.run.g - he.run.half));
+				b.threads = std::max(b.threads, he.run.threads);
+				b.lds = std::max(b.lds, ss.lds);
+				counted[i * 5 + variant] = 1;
+			}
+		}
+		for (int v = 0; v < 5; ++v) {
+			flush(v);
+			for (size_t j = 0; j < n_tables; ++j) if (counted[j * 5 + v]) table_launches[j] += 1;
+		}
+		for (size_t i = 0; i < n_tables; ++i) {
+			Impl& m = *tables[i]->impl_;
+			if (k >= m.schedule.size() || m.schedule[k].singles.empty()) continue;
+			const whamd_status_t st = m.submit_singles(*problems[i], m.schedule[k], table_launches[i], msg);
+			if (st != WHAMD_OK) { abort_all(); return st; }
+		}
+	}
+	if (getenv("WHAMD_DEBUG_TIMING"))
+		fprintf(stderr, "[whamd timing] group of %zu tables: %zu super-steps submitted in %.2f ms (host)\n", n_tables, max_steps,
+		        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_submit0).count());
+	if (hipGetLastError() != hipSuccess || hipEventRecord(lead.ev_group, lead.stream) != hipSuccess) {
+		msg = "group launch failed";
+		abort_all();
+		return WHAMD_ERR_DEVICE;
+	}
+	for (size_t i = 0; i < n_tables; ++i) {
+		Impl& m = *tables[i]->impl_;
+		m.launches = table_launches[i];
+		m.next_super = m.schedule.size();
+		whamd_status_t st = WHAMD_OK;
+		if (m.stream != lead.stream && hipStreamWaitEvent(m.stream, lead.ev_group, 0) != hipSuccess) { msg = "hipStreamWaitEvent failed"; st = WHAMD_ERR_DEVICE; }
+		if (st == WHAMD_OK) st = m.submit_tail(*problems[i], msg);
+		if (st != WHAMD_OK) { abort_all(); return st; }
+		m.enqueue_open = false;
+		m.run_stream = m.stream;
+	}
 	return WHAMD_OK;
 }
 
@@ -1365,6 +1533,7 @@ whamd_status_t DeviceTable::wait(const Problem& p, Solution& s, whamd_solve_stat
 	st.backtrace_ms = f12;
 	st.total_ms = f03;
 	st.forward_launches = launches;
+	st.group_tables = m.group_tables;
 	st.bt_chunks = st.bt_missed = st.bt_rewalked = 0;
 	if (m.use_chunks) {
 		uint32_t c[3] = {0, 0, 0};

@@ -7,11 +7,13 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <memory>
 #include <new>
 #include <pthread.h>
 #include <sched.h>
 #include <sys/mman.h>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -76,6 +78,9 @@ inline const cpu_set_t* caller_node_cpus() {
 }
 
 // fn(begin, end, t) for n_threads contiguous ranges of [0, n); the calling thread takes the last range.
+// Exception-safe: the guard that joins the workers and gives the caller its affinity mask back exists BEFORE the first worker does; a
+// worker that cannot be started (std::system_error: EAGAIN under a pids limit) leaves its range and the following ones to the caller;
+// an exception inside a worker's fn is carried to the caller and rethrown after the join (the C ABI turns it into a status).
 template <class F>
 inline void parallel_ranges(uint64_t n, uint32_t n_threads, F&& fn) {
 	if (n_threads <= 1) {
@@ -88,14 +93,8 @@ inline void parallel_ranges(uint64_t n, uint32_t n_threads, F&& fn) {
 	const bool rebind = node_cpus && pthread_getaffinity_np(pthread_self(), sizeof caller_mask, &caller_mask) == 0 &&
 	                    pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), node_cpus) == 0;
 	std::vector<std::thread> workers;
-	workers.reserve(n_threads - 1);
-	for (uint32_t t = 0; t + 1 < n_threads; ++t) {
-		workers.emplace_back([&fn, n, n_threads, t, node_cpus]() {
-			if (node_cpus) (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), node_cpus);
-			fn(n * t / n_threads, n * (t + 1) / n_threads, t);
-		});
-	}
-	struct Finish {   // also on the way out of an exception in the caller's own range (std::bad_alloc): join, give the caller its mask back
+	std::vector<std::exception_ptr> failed(n_threads);
+	struct Finish {   // on every way out: join, give the caller its mask back
 		std::vector<std::thread>& workers;
 		const bool rebind;
 		const cpu_set_t& mask;
@@ -103,8 +102,30 @@ inline void parallel_ranges(uint64_t n, uint32_t n_threads, F&& fn) {
 			for (std::thread& w : workers) if (w.joinable()) w.join();
 			if (rebind) (void)pthread_setaffinity_np(pthread_self(), sizeof mask, &mask);
 		}
-	} finish{workers, rebind, caller_mask};
-	fn(n * (n_threads - 1) / n_threads, n, n_threads - 1);
+	};
+	{
+		Finish finish{workers, rebind, caller_mask};
+		workers.reserve(n_threads - 1);
+		uint32_t started = 0;
+		for (; started + 1 < n_threads; ++started) {
+			const uint32_t t = started;
+			try {
+				workers.emplace_back([&fn, &failed, n, n_threads, t, node_cpus]() {
+					if (node_cpus) (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), node_cpus);
+					try {
+						fn(n * t / n_threads, n * (t + 1) / n_threads, t);
+					} catch (...) {
+						failed[t] = std::current_exception();
+					}
+				});
+			} catch (const std::system_error&) {
+				break;   // no more threads to be had: the caller runs what is left
+			}
+		}
+		for (uint32_t t = started; t < n_threads; ++t) fn(n * t / n_threads, t + 1 == n_threads ? n : n * (t + 1) / n_threads, t);
+	}
+	for (const std::exception_ptr& e : failed)
+		if (e) std::rethrow_exception(e);
 }
 
 // Allocator of the create path's large arrays: the value-less construct() default-initialises (resize() of a vector of trivial

@@ -73,13 +73,12 @@ __device__ __forceinline__ uint32_t pslot_lane_xor(uint32_t v) {
 __device__ __forceinline__ uint32_t pslot_sat_add(uint32_t a, uint32_t b) { return __builtin_elementwise_add_sat(a, b); }
 
 template <int TB, int NF, bool SPEC>
-__global__ __launch_bounds__(512) void pedslot_run(DevProblem P, SlotRun run, PedSlotExtra ex, const uint32_t* __restrict__ prev,
-                                                   uint32_t* __restrict__ cur) {
+__device__ __forceinline__ void pedslot_run_body(const DevProblem& P, const SlotRun& run, const PedSlotExtra& ex, const uint32_t* __restrict__ prev,
+                                                 uint32_t* __restrict__ cur, const uint32_t w) {
 	constexpr uint32_t T = 1u << TB;
 	constexpr int NLS = 6 - TB;   // lane slots
-	touch_kernel_arguments<sizeof(DevProblem) + sizeof(SlotRun) + sizeof(PedSlotExtra) + 16>();
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-	const uint32_t w = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u;
 	const uint32_t wave = uni(tid >> 6);
 	const uint32_t threads = run.threads, ncols = run.ncols, L = run.L;
 	const uint32_t t = lane & (T - 1u);
@@ -285,4 +284,22 @@ __global__ __launch_bounds__(512) void pedslot_run(DevProblem P, SlotRun run, Pe
 			if (lane == 0) P.spec_keys[(size_t)(run.spec_id - 1u) * P.spec_stride + w * (threads >> 6) + wave] = best_key;
 		}
 	}
+}
+
+template <int TB, int NF, bool SPEC>
+__global__ __launch_bounds__(512) void pedslot_run(DevProblem P, SlotRun run, PedSlotExtra ex, const uint32_t* __restrict__ prev,
+                                                   uint32_t* __restrict__ cur) {
+	touch_kernel_arguments<sizeof(DevProblem) + sizeof(SlotRun) + sizeof(PedSlotExtra) + 16>();
+	pedslot_run_body<TB, NF, SPEC>(P, run, ex, prev, cur, blockIdx.x);
+}
+
+// One launch = the next run of SEVERAL pedigree tables (see slot_group, kernels_slots.h): blockIdx.y selects the table's entry.
+template <int TB, int NF>
+__global__ __launch_bounds__(512) void pedslot_group(SlotGroupArgs args) {
+	const SlotBatchEntry e = slot_scalar_copy(args.entry[blockIdx.y]);
+	const SlotRun& run = e.run;
+	if (blockIdx.x >= (1u << run.g) || threadIdx.x >= run.threads) return;
+	const DevProblem P = slot_entry_problem(e, true);
+	if (run.spec_id) pedslot_run_body<TB, NF, true>(P, run, e.ex, e.prev, e.cur, blockIdx.x);
+	else pedslot_run_body<TB, NF, false>(P, run, e.ex, e.prev, e.cur, blockIdx.x);
 }

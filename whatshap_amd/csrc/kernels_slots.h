@@ -432,3 +432,44 @@ __global__ __launch_bounds__(512) void slot_batch(DevProblem P, const SlotBatchE
 	if (blockIdx.x >= (1u << (run.g - run.half)) || threadIdx.x >= run.threads) return;
 	slot_run_body<LR, false, false>(P, run, e->prev, e->cur, blockIdx.x, e->score_out);
 }
+
+// A wave-uniform record in global memory, copied through the CONSTANT address space: the loads become s_load_dwordx16 (a pointer that was
+// itself loaded from memory is not a noalias kernel argument -- through the generic address space the compiler fetches the record with
+// vector loads and a v_readfirstlane per word, ~35 cycles each).
+template <class T>
+__device__ __forceinline__ T slot_scalar_copy(const T* __restrict__ p) {
+	static_assert(sizeof(T) % 4 == 0, "whole words");
+	T out;
+	uint32_t* w = reinterpret_cast<uint32_t*>(&out);
+	const __attribute__((address_space(4))) uint32_t* src = (const __attribute__((address_space(4))) uint32_t*)(unsigned long long)p;
+#pragma unroll
+	for (uint32_t i = 0; i < sizeof(T) / 4; ++i) w[i] = src[i];
+	return out;
+}
+
+// The arrays of the table an entry belongs to, as the DevProblem the run bodies read (unused fields fold away).
+__device__ __forceinline__ DevProblem slot_entry_problem(const SlotBatchEntry& e, bool ped) {
+	DevProblem P{};
+	if (ped) { P.pslot_tab = e.tab; P.pslot_rows = reinterpret_cast<const PedSlotRow*>(e.rows); }
+	else { P.slot_tab = e.tab; P.slot_rows = reinterpret_cast<const SlotRow*>(e.rows); }
+	P.slot_ctrl = e.ctrl;
+	P.bt = e.bt;
+	P.spec_keys = e.spec_keys;
+	P.spec_stride = e.spec_stride;
+	return P;
+}
+
+// One launch = the next run of SEVERAL TABLES (whamd_dptable_enqueue_many: independent tables advance in lockstep on one stream):
+// blockIdx.y selects the table's entry, blockIdx.x the workgroup of that run.  The launch boundary between two dependent launches
+// (~2.5 us) and the prologue's round trips are then paid once per super-step of the whole group instead of once per table, and a
+// narrow table (coverage 15: 8 workgroups) no longer leaves the other 248 CUs idle.  Runs that end a backtrace chunk leave their
+// seed (SPEC) -- a wave-uniform branch between the two instantiations, not a test on the column chain.
+template <int LR>
+__global__ __launch_bounds__(512) void slot_group(SlotGroupArgs args) {
+	const SlotBatchEntry e = slot_scalar_copy(args.entry[blockIdx.y]);
+	const SlotRun& run = e.run;
+	if (blockIdx.x >= (1u << (run.g - run.half)) || threadIdx.x >= run.threads) return;
+	const DevProblem P = slot_entry_problem(e, false);
+	if (run.spec_id) slot_run_body<LR, false, true>(P, run, e.prev, e.cur, blockIdx.x, e.score_out);
+	else slot_run_body<LR, false, false>(P, run, e.prev, e.cur, blockIdx.x, e.score_out);
+}

@@ -375,13 +375,19 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 	const auto tp1 = std::chrono::steady_clock::now();
 	auto tp2 = tp1;
 	{
-		const uint32_t n_threads = host_threads(n, 4096);
-		std::vector<SlotPlan> parts(n_threads);
-		std::vector<std::vector<RunDraft>> part_drafts(n_threads);
-		std::vector<uint32_t> bounds(n_threads + 1);
-		for (uint32_t t = 0; t <= n_threads; ++t) bounds[t] = (uint32_t)((uint64_t)n * t / n_threads);
-		parallel_ranges(n, n_threads, [&](uint64_t, uint64_t, uint32_t t) { plan_range(bounds[t], bounds[t + 1], parts[t], part_drafts[t]); });
+		// The ranges planned independently become run boundaries: they follow from the INPUT alone (fixed pieces of ~PLAN_PIECE columns), not
+		// from how many host threads this machine has -- the same table gets the same runs, launches and record layout everywhere.
+		constexpr uint32_t PLAN_PIECE = 8192;
+		const uint32_t n_pieces = std::max<uint32_t>(1, n / PLAN_PIECE);
+		std::vector<SlotPlan> parts(n_pieces);
+		std::vector<std::vector<RunDraft>> part_drafts(n_pieces);
+		std::vector<uint32_t> bounds(n_pieces + 1);
+		for (uint32_t t = 0; t <= n_pieces; ++t) bounds[t] = (uint32_t)((uint64_t)n * t / n_pieces);
+		parallel_ranges(n_pieces, host_threads(n_pieces, 1), [&](uint64_t q0, uint64_t q1, uint32_t) {
+			for (uint64_t q = q0; q < q1; ++q) plan_range(bounds[q], bounds[q + 1], parts[q], part_drafts[q]);
+		});
 		tp2 = std::chrono::steady_clock::now();
+		const uint32_t n_threads = n_pieces;
 		for (uint32_t t = 0; t < n_threads; ++t) {
 			const SlotPlan& q = parts[t];
 			const uint32_t run_base = (uint32_t)plan.runs.size();

@@ -132,14 +132,33 @@ struct PedSlotExtra {
 };
 static_assert(sizeof(PedSlotExtra) == 48, "PedSlotExtra layout");
 
+// One run as a record in device memory: what slot_batch (the runs of ONE table's jobs) and slot_group / pedslot_group (the runs of
+// SEVERAL tables, one launch per super-step of the whole group) read instead of kernel arguments.  The entry carries the owning table's
+// arrays, so that a launch does not need a per-table DevProblem.
 struct SlotBatchEntry {
 	SlotRun run;
+	PedSlotExtra ex;                 // pedigree runs (zero otherwise)
 	const uint32_t* prev;
 	uint32_t* cur;
 	uint32_t* score_out;             // non-null: the run ends a connected component, its single exit value goes here
-	uint64_t pad;
+	uint64_t pad;                    // host side: index of the run in the plan
+	const uint32_t* tab;             // DevProblem::slot_tab / pslot_tab of the owning table
+	const void* rows;                // DevProblem::slot_rows / pslot_rows
+	const uint32_t* ctrl;            // DevProblem::slot_ctrl
+	uint8_t* bt;                     // the table's backtrace arena
+	unsigned long long* spec_keys;   // DevProblem::spec_keys
+	uint32_t spec_stride, pad2;
+	uint64_t pad3[2];
 };
-static_assert(sizeof(SlotBatchEntry) % 16 == 0, "entries are fetched with wide scalar loads");
+static_assert(sizeof(SlotBatchEntry) == 320 && sizeof(SlotBatchEntry) % 64 == 0, "entries are fetched with wide scalar loads, whole 64-byte lines");
+
+// Kernel argument of a group launch: blockIdx.y selects the entry (a pointer into the owning table's own entry array -- the arrays are
+// built once per table at create time; a group launch only passes which of them take part).
+constexpr int SLOT_GROUP_MAX = 120;
+struct SlotGroupArgs {
+	uint32_t n, pad;
+	const SlotBatchEntry* entry[SLOT_GROUP_MAX];
+};
 
 // Backtrace side of a run's column: which slot holds the read of every logical bit, and how many ending reads of the
 // run lie in earlier columns (the path's state at this column = the state after undoing every later ending read).
