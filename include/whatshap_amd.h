@@ -234,6 +234,7 @@ typedef struct whamd_plan_summary {
 	uint64_t n_halved_runs;       /* runs that launch only half of their workgroups (complement symmetry) */
 	uint32_t max_coverage;
 	uint32_t invariants_ok;       /* 1 if the internal consistency checks passed */
+	uint64_t n_yform_runs;        /* slot runs that compute in Y form (one absolute difference per cell-column; slots.h) */
 } whamd_plan_summary;
 whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uint32_t* recombcost, size_t n_recombcost,
                                     const whamd_pedigree_view* pedigree, int distrust_genotypes,

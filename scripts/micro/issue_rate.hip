@@ -32,20 +32,20 @@ int main() {
 	unsigned long long* out; unsigned int* sink;
 	hipMalloc(&out, 4096 * 8); hipMalloc(&sink, 4096 * 1024 * 4);
 	const char* names[5] = {"dependent v_add chain", "3 independent v_add + xor", "dependent s_add chain", "VALU/SALU alternating", "dependent min3/sub chain"};
-	for (int threads : {64, 256, 512, 1024}) {
+	for (int grid : {256, 512}) for (int threads : {64, 256, 512, 1024}) {
 		for (int mode = 0; mode < 5; ++mode) {
 			for (int rep = 0; rep < 2; ++rep) {
-				if (mode == 0) hipLaunchKernelGGL(probe<0>, dim3(256), dim3(threads), 0, 0, out, sink, 1u);
-				if (mode == 1) hipLaunchKernelGGL(probe<1>, dim3(256), dim3(threads), 0, 0, out, sink, 1u);
-				if (mode == 2) hipLaunchKernelGGL(probe<2>, dim3(256), dim3(threads), 0, 0, out, sink, 1u);
-				if (mode == 3) hipLaunchKernelGGL(probe<3>, dim3(256), dim3(threads), 0, 0, out, sink, 1u);
-				if (mode == 4) hipLaunchKernelGGL(probe<4>, dim3(256), dim3(threads), 0, 0, out, sink, 1u);
+				if (mode == 0) hipLaunchKernelGGL(probe<0>, dim3(grid), dim3(threads), 0, 0, out, sink, 1u);
+				if (mode == 1) hipLaunchKernelGGL(probe<1>, dim3(grid), dim3(threads), 0, 0, out, sink, 1u);
+				if (mode == 2) hipLaunchKernelGGL(probe<2>, dim3(grid), dim3(threads), 0, 0, out, sink, 1u);
+				if (mode == 3) hipLaunchKernelGGL(probe<3>, dim3(grid), dim3(threads), 0, 0, out, sink, 1u);
+				if (mode == 4) hipLaunchKernelGGL(probe<4>, dim3(grid), dim3(threads), 0, 0, out, sink, 1u);
 				hipDeviceSynchronize();
 			}
 			std::vector<unsigned long long> h(256);
 			hipMemcpy(h.data(), out, 256 * 8, hipMemcpyDeviceToHost);
 			double sum = 0; for (auto v : h) sum += (double)v;
-			printf("%4d threads/WG (%d waves/SIMD)  %-28s %.2f cycles per instruction (wave 0 of each WG)\n", threads, threads / 256 ? threads / 256 : 1, names[mode], sum / 256 / (64 * 16 * 4));
+			printf("grid %d %4d threads/WG (%d waves/SIMD per WG)  %-28s %.2f cycles per instruction (wave 0 of each WG)\n", grid, threads, threads / 256 ? threads / 256 : 1, names[mode], sum / 256 / (64 * 16 * 4));
 		}
 	}
 	return 0;

@@ -69,6 +69,7 @@ def test_24_different_tables_batched_equal_one_by_one_and_the_oracle(tables_and_
         got = table_solution(t)
         assert got == alone[i], (i, cases[i][0], first_difference(alone[i], got))
     assert any(t.stats()["bt_chunks"] > 0 for t in tables), "no table of the batch went through the chunked backtrace"
+    assert all(t.stats()["group_tables"] == 24 for t in tables), "the batch did not share its launches"
     for i in ORACLE_ON:
         want = table_solution(oracle.OracleTable(cases[i][1]))
         assert alone[i] == want, (i, cases[i][0], first_difference(want, alone[i]))
@@ -115,8 +116,10 @@ def test_batch_with_tables_outside_the_group(tables_and_alone):
         t.close()
 
 
-def test_full_width_tables_batched():
-    """Three coverage-20 tables (256 workgroups each) in one launch per super-step: more workgroups than the chip holds at once."""
+def test_full_width_tables_batched(monkeypatch):
+    """Three coverage-20 tables (256 workgroups each) in one launch per super-step: more workgroups than the chip holds at once
+    (enqueue_many would keep so few wide tables on their own streams: WHAMD_GROUP_ALWAYS forces the shared launches)."""
+    monkeypatch.setenv("WHAMD_GROUP_ALWAYS", "1")
     ps = [synthetic_block(n_variants=200000, coverage=20, seed=3 + i, n_columns_limit=1500 + 200 * i) for i in range(3)]
     alone = []
     for p in ps:
@@ -128,5 +131,6 @@ def test_full_width_tables_batched():
     for t in tables:
         t.wait()
     for t, a in zip(tables, alone):
+        assert t.stats()["group_tables"] == 3
         assert table_solution(t) == a, first_difference(a, table_solution(t))
         t.close()

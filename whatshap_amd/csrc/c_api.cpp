@@ -138,7 +138,16 @@ whamd_status_t whamd_dptable_enqueue_many(whamd_dptable* const* tables, size_t n
 		for (size_t a = 0; a < eligible.size();) {
 			size_t b = a;
 			while (b < eligible.size() && eligible[b].first == eligible[a].first) ++b;
-			if (b - a == 1) { rest.push_back(eligible[a].second); a = b; continue; }
+			// up to four tables that fill the chip by themselves (>= 128 workgroups per launch) do better on their own streams: their
+			// launches drift against each other, one table's boundary and prologue under another's columns (5.4 M columns/s for three
+			// coverage-20 tables against 3.5 M in lockstep); many tables, or narrow ones, share their launches
+			bool wide = true;
+			for (size_t q = a; q < b; ++q) wide = wide && tables[eligible[q].second]->device.widest_launch() >= 128;
+			if (b - a == 1 || (b - a <= 4 && wide && !getenv("WHAMD_GROUP_ALWAYS"))) {
+				for (size_t q = a; q < b; ++q) rest.push_back(eligible[q].second);
+				a = b;
+				continue;
+			}
 			std::vector<DeviceTable*> devs;
 			std::vector<const Problem*> probs;
 			std::vector<Solution*> sols;
@@ -420,10 +429,11 @@ whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uin
 				s.max_lds_bytes = std::max<uint64_t>(s.max_lds_bytes, (2ull * run.threads + (PSLOT_MAXCOLS + 4) * 8 + (uint64_t)(run.threads >> 6) * (ex.arow + 4u * p.T * ex.nf) + (uint64_t)(run.ncols + 4) * 64 * ex.nf) * 4);
 				s.backtrace_bytes += ((uint64_t)ex.rec_words * 4) << run.g;
 			} else {
-				s.max_lds_bytes = std::max<uint64_t>(s.max_lds_bytes, 2ull * run.threads * (1u << run.lr) * 4 + (SLOT_MAXCOLS + 8) * 64 + 8 * 64 * 4 + (SLOT_MAXCOLS + 8) * 64 * 4);
+				s.max_lds_bytes = std::max<uint64_t>(s.max_lds_bytes, slot_run_lds_bytes(run.threads, run.lr, run.ncols));
 				s.backtrace_bytes += (uint64_t)run.n_ends * run.threads * (1ull << (run.g - run.half));
 			}
 			if (run.half) s.n_halved_runs++;
+			if (run.yflags & 1u) s.n_yform_runs++;
 			s.n_resident_columns += run.ncols;
 			s.n_vectorised_columns += run.ncols;
 		}

@@ -30,6 +30,7 @@ public:
 	static whamd_status_t enqueue_group(DeviceTable* const* tables, const Problem* const* problems, Solution* const* solutions, size_t n_tables, std::string& msg);
 	bool group_eligible(const Problem& p) const;
 	int device_index() const;
+	uint32_t widest_launch() const;   // workgroups of the widest launch of the schedule
 	// Drops a partially submitted solve (enqueue_some that has not reported `done`): drains the stream, rewinds the cursor.
 	void abort_enqueue();
 	// Frees the device buffers, the stream and the events; the next upload() recreates them.

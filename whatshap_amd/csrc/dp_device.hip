@@ -226,6 +226,7 @@ struct DeviceTable::Impl {
 	uint64_t bt_bytes = 0;
 	uint64_t launches = 0;
 	uint32_t group_tables = 1;  // tables that shared the forward launches of the solve in flight (enqueue_group)
+	uint32_t max_grid_x = 1;    // widest launch of the schedule, in workgroups
 	bool enqueue_open = false;  // resumable enqueue (enqueue_some)
 	uint32_t* h_pinned = nullptr;  // [2 n + 1 + jobs]: path index, path transmission, score of the final job, scores of the others
 	// A job is a sequence of forward steps with its own backtrace.  Job 0 ("final") is the last connected component (it
@@ -316,6 +317,7 @@ struct DeviceTable::Impl {
 	whamd_status_t submit_tail(const Problem& p, std::string& msg);
 
 	void release_lanes() {
+		max_grid_x = 1;
 		lanes.clear();
 		jobs.clear();
 		schedule.clear();
@@ -999,7 +1001,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 						const PedSlotExtra& pex = m.splan.pextra[step.index];
 						ss.lds = std::max<size_t>(ss.lds, ((size_t)2 * e.run.threads + (PSLOT_MAXCOLS + 4) * 8 + (size_t)(e.run.threads >> 6) * (pex.arow + 4u * p.T * pex.nf) + (size_t)(e.run.ncols + 4) * 64 * pex.nf) * 4);
 					} else
-					ss.lds = std::max<size_t>(ss.lds, (size_t)2 * e.run.threads * (1u << e.run.lr) * 4 + (SLOT_MAXCOLS + 8) * 64 + 8 * 64 * 4 + (SLOT_MAXCOLS + 8) * 64 * 4);
+					ss.lds = std::max<size_t>(ss.lds, slot_run_lds_bytes(e.run.threads, e.run.lr, e.run.ncols));
 					e.pad = step.index;
 					// the owning table's arrays: a group launch (slot_group / pedslot_group) serves runs of several tables
 					if (ped_slots) e.ex = m.splan.pextra[step.index];
@@ -1009,6 +1011,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 					e.bt = (uint8_t*)d_bt;
 					e.spec_keys = m.dp.spec_keys;
 					e.spec_stride = m.dp.spec_stride;
+					if (const char* skip = getenv("WHAMD_SLOT_SKIP")) e.pad2 = (uint32_t)atoi(skip);   // (timing experiments in a group launch)
 					ss.grid_x = std::max(ss.grid_x, 1u << (e.run.g - e.run.half));
 					ss.threads = std::max(ss.threads, e.run.threads);
 					m.slot_entries.push_back(e);
@@ -1241,7 +1244,7 @@ void DeviceTable::Impl::launch_slot_run(const SlotBatchEntry& e, uint64_t& launc
 		launches += 1;
 		return;
 	}
-	const size_t lds = (size_t)2 * run.threads * (1u << run.lr) * 4 + (SLOT_MAXCOLS + 8) * 64 + 8 * 64 * 4 + (SLOT_MAXCOLS + 8) * 64 * 4;   // wave-slot exchange + hot lines + per-wave A + lane sums
+	const size_t lds = slot_run_lds_bytes(run.threads, run.lr, run.ncols);   // wave-slot exchange + hot lines + per-wave A + lane sums
 	const dim3 grid(1u << (run.g - run.half)), block(run.threads);
 	const bool dbg = m.dp.dbg != nullptr || m.dp.dbg_flags != 0;
 #define WHAMD_SLOT_LAUNCH(LRV, DBGV, SPECV) hipLaunchKernelGGL((slot_run<LRV, DBGV, SPECV>), grid, block, lds, m.run_stream, m.dp, run, e.prev, e.cur, e.score_out)
@@ -1251,6 +1254,11 @@ void DeviceTable::Impl::launch_slot_run(const SlotBatchEntry& e, uint64_t& launc
 	} else if (run.lr == 1) {
 		if (dbg) { if (spec) WHAMD_SLOT_LAUNCH(1, true, true); else WHAMD_SLOT_LAUNCH(1, true, false); }
 		else { if (spec) WHAMD_SLOT_LAUNCH(1, false, true); else WHAMD_SLOT_LAUNCH(1, false, false); }
+	} else if (run.yflags & 1u) {   // Y-form run (slot_plan.cpp): one instruction per cell-column
+#define WHAMD_SLOT_LAUNCH_Y(DBGV, SPECV) hipLaunchKernelGGL((slot_run<2, DBGV, SPECV, true>), grid, block, lds, m.run_stream, m.dp, run, e.prev, e.cur, e.score_out)
+		if (dbg) { if (spec) WHAMD_SLOT_LAUNCH_Y(true, true); else WHAMD_SLOT_LAUNCH_Y(true, false); }
+		else { if (spec) WHAMD_SLOT_LAUNCH_Y(false, true); else WHAMD_SLOT_LAUNCH_Y(false, false); }
+#undef WHAMD_SLOT_LAUNCH_Y
 	} else {
 		if (dbg) { if (spec) WHAMD_SLOT_LAUNCH(2, true, true); else WHAMD_SLOT_LAUNCH(2, true, false); }
 		else { if (spec) WHAMD_SLOT_LAUNCH(2, false, true); else WHAMD_SLOT_LAUNCH(2, false, false); }
@@ -1407,19 +1415,40 @@ whamd_status_t DeviceTable::enqueue_some_unguarded(const Problem& p, Solution& s
 // those overlap across the members -- so whamd_dptable_wait works per table as before.
 bool DeviceTable::group_eligible(const Problem& p) const {
 	const Impl& m = *impl_;
-	if (p.n_cols == 0 || !m.use_slots || m.windowed || m.enqueue_open || m.dp.dbg || m.dp.dbg_flags) return false;
+	if (p.n_cols == 0 || !m.use_slots || m.windowed || m.enqueue_open || m.dp.dbg || (m.dp.dbg_flags && m.splan.ped)) return false;
 	if (!m.splan.ped && m.slot_lr != 2) return false;   // (the group kernel exists for the default four cells per thread)
 	return getenv("WHAMD_NO_GROUP") == nullptr;
 }
 
 int DeviceTable::device_index() const { return impl_->device; }
+uint32_t DeviceTable::widest_launch() const { return impl_->max_grid_x; }
 
 whamd_status_t DeviceTable::enqueue_group(DeviceTable* const* tables, const Problem* const* problems, Solution* const* solutions, size_t n_tables, std::string& msg) {
 	if (n_tables == 0) return WHAMD_OK;
-	Impl& lead = *tables[0]->impl_;
-	HIP_TRY(hipSetDevice(lead.device));
+	HIP_TRY(hipSetDevice(tables[0]->impl_->device));
+	// ---- parts.  Tables that advance in lockstep are all in the same phase at the same time: every workgroup waits in its prologue
+	// together, then they all compete for the issue slots together -- three full-width tables in ONE launch per super-step take 17 us
+	// where three tables on their own streams, drifting against each other, take 11 (whamd_dptable_enqueue_many therefore keeps up to
+	// four full-width tables on their own streams).  A group can be cut into PARTS, each a group of its own on the stream of its first
+	// table, submitted round robin; measured on 24 full-width tables that is no gain over one part (6.30 M columns/s with 1 part,
+	// 6.23 / 6.15 / 5.75 / 6.06 / 5.98 with 2 / 3 / 4 / 6 / 8: profiles/r04/), so one part is the default and WHAMD_GROUP_PARTS the experiment.
+	uint64_t width = 0;
+	for (size_t i = 0; i < n_tables; ++i) width += tables[i]->impl_->max_grid_x;
+	size_t n_parts = 1;
+	if (const char* e = getenv("WHAMD_GROUP_PARTS")) n_parts = (size_t)std::max(1, atoi(e));
+	n_parts = std::min(n_parts, n_tables);
+	const bool tight = width > 768 && !getenv("WHAMD_GROUP_LOOSE");   // more than three workgroups per CU: the variants held to 80 SGPRs (four workgroups per CU)
+	struct Batch { SlotGroupArgs args; uint32_t grid_x = 0, threads = 0; size_t lds = 0; };
+	struct Part {
+		std::vector<size_t> members;   // positions in `tables`
+		Impl* lead = nullptr;
+		std::vector<Batch> batches;    // per kernel variant: 0 single individual (four cells per thread); 1 .. 4 pedigree runs (TB, NF) = (2,2) (2,4) (4,2) (4,4)
+	};
+	std::vector<Part> parts(n_parts);
+	for (size_t i = 0; i < n_tables; ++i) parts[i % n_parts].members.push_back(i);
+	for (Part& part : parts) { part.lead = tables[part.members[0]]->impl_; part.batches.resize(5); }
 	auto abort_all = [&]() {
-		(void)hipStreamSynchronize(lead.stream);
+		for (Part& part : parts) (void)hipStreamSynchronize(part.lead->stream);
 		(void)hipGetLastError();
 		for (size_t i = 0; i < n_tables; ++i) {
 			Impl& m = *tables[i]->impl_;
@@ -1430,28 +1459,31 @@ whamd_status_t DeviceTable::enqueue_group(DeviceTable* const* tables, const Prob
 		}
 	};
 	size_t max_steps = 0;
-	for (size_t i = 0; i < n_tables; ++i) {
-		Impl& m = *tables[i]->impl_;
-		m.enqueue_open = true;
-		m.run_stream = lead.stream;
-		m.group_tables = (uint32_t)n_tables;
-		const whamd_status_t st = m.begin_solve(*problems[i], *solutions[i], msg);
-		if (st != WHAMD_OK) { abort_all(); return st; }
-		max_steps = std::max(max_steps, m.schedule.size());
-	}
-	// kernel variants: 0 single individual (four cells per thread); 1 .. 4 pedigree runs (TB, NF) = (2,2) (2,4) (4,2) (4,4)
-	struct Batch { SlotGroupArgs args; uint32_t grid_x = 0, threads = 0; size_t lds = 0; };
-	std::vector<Batch> batches(5);
-	auto flush = [&](int variant) {
-		Batch& b = batches[variant];
+	for (Part& part : parts)
+		for (size_t i : part.members) {
+			Impl& m = *tables[i]->impl_;
+			m.enqueue_open = true;
+			m.run_stream = part.lead->stream;
+			m.group_tables = (uint32_t)part.members.size();
+			const whamd_status_t st = m.begin_solve(*problems[i], *solutions[i], msg);
+			if (st != WHAMD_OK) { abort_all(); return st; }
+			max_steps = std::max(max_steps, m.schedule.size());
+		}
+	auto flush = [&](Part& part, int variant) {
+		Batch& b = part.batches[variant];
 		if (!b.args.n) return;
 		const dim3 grid(b.grid_x, b.args.n), block(b.threads);
+		hipStream_t stream = part.lead->stream;
 		switch (variant) {
-			case 0: hipLaunchKernelGGL(slot_group<2>, grid, block, b.lds, lead.stream, b.args); break;
-			case 1: hipLaunchKernelGGL((pedslot_group<2, 2>), grid, block, b.lds, lead.stream, b.args); break;
-			case 2: hipLaunchKernelGGL((pedslot_group<2, 4>), grid, block, b.lds, lead.stream, b.args); break;
-			case 3: hipLaunchKernelGGL((pedslot_group<4, 2>), grid, block, b.lds, lead.stream, b.args); break;
-			default: hipLaunchKernelGGL((pedslot_group<4, 4>), grid, block, b.lds, lead.stream, b.args); break;
+			case 0:
+				if (part.lead->dp.dbg_flags) hipLaunchKernelGGL((slot_group<2, true, false>), grid, block, b.lds, stream, b.args);
+				else if (tight) hipLaunchKernelGGL((slot_group<2, false, true>), grid, block, b.lds, stream, b.args);
+				else hipLaunchKernelGGL((slot_group<2, false, false>), grid, block, b.lds, stream, b.args);
+				break;
+			case 1: hipLaunchKernelGGL((pedslot_group<2, 2>), grid, block, b.lds, stream, b.args); break;
+			case 2: hipLaunchKernelGGL((pedslot_group<2, 4>), grid, block, b.lds, stream, b.args); break;
+			case 3: hipLaunchKernelGGL((pedslot_group<4, 2>), grid, block, b.lds, stream, b.args); break;
+			default: hipLaunchKernelGGL((pedslot_group<4, 4>), grid, block, b.lds, stream, b.args); break;
 		}
 		b.args.n = 0;
 		b.grid_x = b.threads = 0;
@@ -1461,55 +1493,56 @@ whamd_status_t DeviceTable::enqueue_group(DeviceTable* const* tables, const Prob
 	std::vector<uint8_t> counted(n_tables * 5, 0);
 	const auto t_submit0 = std::chrono::steady_clock::now();
 	for (size_t k = 0; k < max_steps; ++k) {
-		std::fill(counted.begin(), counted.end(), 0);
-		for (size_t i = 0; i < n_tables; ++i) {
-			Impl& m = *tables[i]->impl_;
-			if (k >= m.schedule.size()) continue;
-			const Impl::SuperStep& ss = m.schedule[k];
-			for (uint32_t q = 0; q < ss.entry_count; ++q) {
-				const SlotBatchEntry& he = m.slot_entries[ss.entry_off + q];
-				const int variant = m.splan.ped ? 1 + (he.ex.tb == 4 ? 2 : 0) + (he.ex.nf == 4 ? 1 : 0) : 0;
-				Batch& b = batches[variant];
-				if (b.args.n == (uint32_t)SLOT_GROUP_MAX) {
-					flush(variant);
-					for (size_t j = 0; j < n_tables; ++j) if (counted[j * 5 + variant]) { table_launches[j] += 1; counted[j * 5 + variant] = 0; }
+		for (Part& part : parts) {
+			for (size_t i : part.members) std::fill(counted.begin() + i * 5, counted.begin() + i * 5 + 5, 0);
+			for (size_t i : part.members) {
+				Impl& m = *tables[i]->impl_;
+				if (k >= m.schedule.size()) continue;
+				const Impl::SuperStep& ss = m.schedule[k];
+				for (uint32_t q = 0; q < ss.entry_count; ++q) {
+					const SlotBatchEntry& he = m.slot_entries[ss.entry_off + q];
+					const int variant = m.splan.ped ? 1 + (he.ex.tb == 4 ? 2 : 0) + (he.ex.nf == 4 ? 1 : 0) : 0;
+					Batch& b = part.batches[variant];
+					if (b.args.n == (uint32_t)SLOT_GROUP_MAX) {
+						flush(part, variant);
+						for (size_t j : part.members) if (counted[j * 5 + variant]) { table_launches[j] += 1; counted[j * 5 + variant] = 0; }
+					}
+					b.args.entry[b.args.n++] = m.d_slot_entries + ss.entry_off + q;
+					b.grid_x = std::max(b.grid_x, 1u << (he.run.g - he.run.half));
+					b.threads = std::max(b.threads, he.run.threads);
+					b.lds = std::max(b.lds, ss.lds);
+					counted[i * 5 + variant] = 1;
 				}
-				b.args.entry[b.args.n++] = m.d_slot_entries + ss.entry_off + q;
-				b.grid_x = std::max(b.grid_x, 1u << (he.run.g - he.run.half));
-				b.threads = std::max(b.threads, he.run.threads);
-				b.lds = std::max(b.lds, ss.lds);
-				counted[i * 5 + variant] = 1;
 			}
-		}
-		for (int v = 0; v < 5; ++v) {
-			flush(v);
-			for (size_t j = 0; j < n_tables; ++j) if (counted[j * 5 + v]) table_launches[j] += 1;
-		}
-		for (size_t i = 0; i < n_tables; ++i) {
-			Impl& m = *tables[i]->impl_;
-			if (k >= m.schedule.size() || m.schedule[k].singles.empty()) continue;
-			const whamd_status_t st = m.submit_singles(*problems[i], m.schedule[k], table_launches[i], msg);
-			if (st != WHAMD_OK) { abort_all(); return st; }
+			for (int v = 0; v < 5; ++v) {
+				flush(part, v);
+				for (size_t j : part.members) if (counted[j * 5 + v]) table_launches[j] += 1;
+			}
+			for (size_t i : part.members) {
+				Impl& m = *tables[i]->impl_;
+				if (k >= m.schedule.size() || m.schedule[k].singles.empty()) continue;
+				const whamd_status_t st = m.submit_singles(*problems[i], m.schedule[k], table_launches[i], msg);
+				if (st != WHAMD_OK) { abort_all(); return st; }
+			}
 		}
 	}
 	if (getenv("WHAMD_DEBUG_TIMING"))
-		fprintf(stderr, "[whamd timing] group of %zu tables: %zu super-steps submitted in %.2f ms (host)\n", n_tables, max_steps,
+		fprintf(stderr, "[whamd timing] group of %zu tables in %zu part(s): %zu super-steps submitted in %.2f ms (host)\n", n_tables, n_parts, max_steps,
 		        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_submit0).count());
-	if (hipGetLastError() != hipSuccess || hipEventRecord(lead.ev_group, lead.stream) != hipSuccess) {
-		msg = "group launch failed";
-		abort_all();
-		return WHAMD_ERR_DEVICE;
-	}
-	for (size_t i = 0; i < n_tables; ++i) {
-		Impl& m = *tables[i]->impl_;
-		m.launches = table_launches[i];
-		m.next_super = m.schedule.size();
-		whamd_status_t st = WHAMD_OK;
-		if (m.stream != lead.stream && hipStreamWaitEvent(m.stream, lead.ev_group, 0) != hipSuccess) { msg = "hipStreamWaitEvent failed"; st = WHAMD_ERR_DEVICE; }
-		if (st == WHAMD_OK) st = m.submit_tail(*problems[i], msg);
-		if (st != WHAMD_OK) { abort_all(); return st; }
-		m.enqueue_open = false;
-		m.run_stream = m.stream;
+	if (hipGetLastError() != hipSuccess) { msg = "group launch failed"; abort_all(); return WHAMD_ERR_DEVICE; }
+	for (Part& part : parts) {
+		if (hipEventRecord(part.lead->ev_group, part.lead->stream) != hipSuccess) { msg = "hipEventRecord failed"; abort_all(); return WHAMD_ERR_DEVICE; }
+		for (size_t i : part.members) {
+			Impl& m = *tables[i]->impl_;
+			m.launches = table_launches[i];
+			m.next_super = m.schedule.size();
+			whamd_status_t st = WHAMD_OK;
+			if (m.stream != part.lead->stream && hipStreamWaitEvent(m.stream, part.lead->ev_group, 0) != hipSuccess) { msg = "hipStreamWaitEvent failed"; st = WHAMD_ERR_DEVICE; }
+			if (st == WHAMD_OK) st = m.submit_tail(*problems[i], msg);
+			if (st != WHAMD_OK) { abort_all(); return st; }
+			m.enqueue_open = false;
+			m.run_stream = m.stream;
+		}
 	}
 	return WHAMD_OK;
 }

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(512) void pedslot_run(DevProblem P, SlotRun run, Pe
 
 // One launch = the next run of SEVERAL pedigree tables (see slot_group, kernels_slots.h): blockIdx.y selects the table's entry.
 template <int TB, int NF>
-__global__ __launch_bounds__(512) void pedslot_group(SlotGroupArgs args) {
+__global__ __launch_bounds__(512, NF == 2 ? 8 : 4) void pedslot_group(SlotGroupArgs args) {   // (NF = 2: four workgroups per CU -- at most 80 SGPRs, 64 VGPRs)
 	const SlotBatchEntry e = slot_scalar_copy(args.entry[blockIdx.y]);
 	const SlotRun& run = e.run;
 	if (blockIdx.x >= (1u << run.g) || threadIdx.x >= run.threads) return;

@@ -90,6 +90,9 @@ bool emulate_slot_plan(const Problem& p, const SlotPlan& plan, std::vector<uint3
 				D[P] = pr[idx];
 			}
 		}
+		// Y form (slot_plan.cpp): the cells hold Y = B - 2 D; the row's first four words are Kr[0..3], the tables are doubled and biased
+		const bool yf = run.yflags & 1u;
+		if (yf && !(run.yflags & 2u)) for (uint32_t P = 0; P < ncell; ++P) D[P] = run.base_in - 2u * D[P];
 		uint32_t k_end = 0;
 		for (uint32_t ci = 0; ci < run.ncols; ++ci) {
 			const SlotRow& row = plan.rows[run.row_off + ci];
@@ -97,6 +100,13 @@ bool emulate_slot_plan(const Problem& p, const SlotPlan& plan, std::vector<uint3
 				uint32_t A = row.Cp;
 				for (uint32_t s = LRr + SLOT_LANE; s < nslots; ++s) if (bit(P, s)) A += (uint32_t)row.dslot[s];
 				for (uint32_t s = 0; s < (uint32_t)SLOT_LANE; ++s) if (bit(P, LRr + s)) A += (uint32_t)row.dlane[s];
+				if (yf) {
+					if (LRr != 2) { msg = "a Y-form run must have two reg slots"; return false; }
+					const uint32_t kr[4] = {row.K, row.Cc, (uint32_t)row.dreg[0], (uint32_t)row.dreg[1]};
+					const uint32_t x0 = 2u * A + SLOT_YBIAS, k = kr[P & 3u];   // (A of the thread's cell 0: reg-slot bits not added)
+					D[P] += x0 > k ? x0 - k : k - x0;
+					continue;
+				}
 				for (uint32_t s = 0; s < LRr; ++s) if (bit(P, s)) A += (uint32_t)row.dreg[s];
 				D[P] += std::min(std::min(A, row.K - A), row.Cc);
 			}
@@ -111,14 +121,22 @@ bool emulate_slot_plan(const Problem& p, const SlotPlan& plan, std::vector<uint3
 					const uint32_t qq = qthr ^ bit(qmask, r);
 					const uint32_t other = D[P ^ (1u << slot)];
 					const uint32_t w = P >> L, tid = (P & ((1u << L) - 1u)) >> LRr;
-					if (other < D[P] + qq) records[st.index][((size_t)w * run.n_ends + k_end) * threads + tid] |= (uint8_t)(1u << r);
-					D2[P] = std::min(D[P], other);
+					const bool takes = yf ? (D[P] < other + qq) : (other < D[P] + qq);   // Y form: the larger Y is the smaller D
+					if (takes) records[st.index][((size_t)w * run.n_ends + k_end) * threads + tid] |= (uint8_t)(1u << r);
+					D2[P] = yf ? std::max(D[P], other) : std::min(D[P], other);
 				}
 				D.swap(D2);
 				++k_end;
 			}
 		}
 		// exit
+		if (yf && !(run.yflags & 4u)) {
+			for (uint32_t P = 0; P < ncell; ++P) {
+				if ((run.base_out - D[P]) & 1u) { msg = "Y-form exit: B - Y is odd"; return false; }
+				if (D[P] > run.base_out) { msg = "Y-form exit: Y exceeds its base"; return false; }
+				D[P] = (run.base_out - D[P]) >> 1;
+			}
+		}
 		const uint32_t out_size = run.out_fullmask + 1u;
 		nx.assign(out_size ? out_size : 1u, 0xDEADBEEFu);
 		const uint32_t localmask = (1u << L) - 1u;

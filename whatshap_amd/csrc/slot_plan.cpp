@@ -338,7 +338,11 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 			const uint32_t ne = ped ? prows_g[rows_mark + i].n_end : rows_g[rows_mark + i].n_end;
 			const uint32_t s0 = ped ? prows_g[rows_mark + i].info0 : (rows_g[rows_mark + i].end[0].info & 31u);
 			const uint32_t byte = std::min(ne, 3u) | ((ne ? (s0 & 31u) : 0u) << 2);   // (3: three or more, the kernel reads the row's count)
-			plan.ctrl[run.ctrl_off + (i >> 2)] |= byte << ((i & 3u) * 8u);
+			if (ped) plan.ctrl[run.ctrl_off + (i >> 2)] |= byte << ((i & 3u) * 8u);
+			else {   // single individual: 16 bits per column, the first ending read's qmask (tie parity of the thread's cells) next to its slot
+				const uint32_t qm = ne ? ((rows_g[rows_mark + i].end[0].info >> 8) & 255u) : 0u;
+				plan.ctrl[run.ctrl_off + (i >> 1)] |= (byte | (qm << 7)) << ((i & 1u) * 16u);
+			}
 		}
 		run.lr = (uint32_t)lr;
 		run.row_off = (uint32_t)rows_mark;
@@ -409,6 +413,59 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 		const uint32_t c0 = plan.steps[si].kind == 2 ? plan.runs[plan.steps[si].index].c0 : plan.steps[si].index;
 		// (a pedigree table is ONE job: across a column no read spans the T transmission values still couple the two sides)
 		if (!ped && (si == 0 || p.b[c0] == 0)) plan.component_first_step.push_back((uint32_t)si);
+	}
+	// ---- Y form (kernels_slots.h).  A run whose columns all have both orientation terms and no constant one -- every column of a
+	// `whatshap phase` table with trusted genotypes: only heterozygous variants are phased -- computes with Y = B_c - 2 D instead of D, where
+	// B_c is the same for every cell of column c (the prefix sum below): min(A, K - A) = (K - |2A - K|) / 2, so a cell-column is ONE absolute
+	// difference accumulated into Y (v_sad_u32) instead of subtract, min3, add; minima become maxima, the tie rule keeps its form.
+	// Between two such runs the exchange column stays in Y form; at any other neighbour the run converts (D = (B - Y) / 2 exactly).
+	if (!ped && lr == 2 && !getenv("WHAMD_NO_YFORM")) {
+		std::vector<uint8_t> pure(n, 0);
+		std::vector<uint64_t> B((size_t)n + 1, 0);   // B[c + 1] = base after column c
+		for (uint32_t c = 0; c < n; ++c) {
+			uint64_t kstar = 0;
+			uint32_t Cp = RES_ABSENT, Cm = RES_ABSENT, Cc = INF;
+			uint64_t dabs = 0, ub = ~0ull;
+			const int32_t* dl = p.delta.data() + (size_t)p.col_ptr[c];
+			for (uint32_t j = 0; j < p.k[c]; ++j) dabs += (uint64_t)std::abs((int64_t)dl[j]);
+			for (uint64_t q = p.term_begin(c, 0); q < p.term_end(c, 0); ++q) {
+				const CostTerm& t = p.terms[q];
+				if (t.plus) Cp = t.c; else if (t.minus) Cm = t.c; else Cc = std::min(Cc, t.c);
+				ub = std::min<uint64_t>(ub, (uint64_t)t.c + ((t.plus || t.minus) ? dabs : 0));
+			}
+			pure[c] = Cp != RES_ABSENT && Cm != RES_ABSENT && Cc == INF;
+			kstar = pure[c] ? (uint64_t)(uint32_t)(Cp + Cm) : 2 * (ub == ~0ull ? 0 : ub);   // (2 D grows by at most this much in column c)
+			B[c + 1] = B[c] + kstar;
+		}
+		if (B[n] < 0xFFFFFFF0ull) {
+			std::vector<uint8_t> yrun(plan.runs.size(), 0);
+			for (size_t ri = 0; ri < plan.runs.size(); ++ri) {
+				const SlotRun& run = plan.runs[ri];
+				bool ok = run.lr == 2;
+				for (uint32_t i = 0; i < run.ncols && ok; ++i) ok = pure[run.c0 + i];
+				yrun[ri] = ok;
+			}
+			for (size_t si = 0; si < plan.steps.size(); ++si) {
+				if (plan.steps[si].kind != 2 || !yrun[plan.steps[si].index]) continue;
+				SlotRun& run = plan.runs[plan.steps[si].index];
+				auto y_neighbour = [&](size_t sj) { return plan.steps[sj].kind == 2 && yrun[plan.steps[sj].index]; };
+				// (a step that starts a connected component reads one value of the previous component, or starts from cost 0 as a job of its own)
+				const bool in = si > 0 && p.b[run.c0] != 0 && y_neighbour(si - 1);
+				bool out = false;
+				if (si + 1 < plan.steps.size() && y_neighbour(si + 1)) out = p.b[plan.runs[plan.steps[si + 1].index].c0] != 0;
+				run.yflags = 1u | (in ? 2u : 0u) | (out ? 4u : 0u);
+				run.base_in = (uint32_t)B[run.c0];
+				run.base_out = (uint32_t)B[run.c0 + run.ncols];
+				for (uint32_t i = 0; i < run.ncols; ++i) {
+					SlotRow& row = plan.rows[run.row_off + i];
+					const uint32_t K = row.K, d0 = (uint32_t)row.dreg[0], d1 = (uint32_t)row.dreg[1];
+					row.K = K + SLOT_YBIAS;                                  // Kr[0]
+					row.Cc = K - 2u * d0 + SLOT_YBIAS;                       // Kr[1]
+					row.dreg[0] = (int32_t)(K - 2u * d1 + SLOT_YBIAS);       // Kr[2]
+					row.dreg[1] = (int32_t)(K - 2u * (d0 + d1) + SLOT_YBIAS);   // Kr[3]
+				}
+			}
+		}
 	}
 	if (ped && !genotype_mode) {
 		// a table that mostly falls back to per-column steps (genotypes not trusted: up to 16 forms per value) is better off

@@ -52,6 +52,8 @@ constexpr int32_t SLOT_DELTA_LIMIT = 1 << 22;  // |delta| of every read in a run
 // hot lines of its columns into LDS (kernels_slots.h).  The rest ("cold") is read once per table, by slot_tables.
 struct SlotRow {
 	// ---- hot: ONE 64-byte line per column
+	// (rows of a Y-form run -- SlotRun::yflags -- hold Kr[0..3] in the first four words instead: Kr[r] = K - 2 * (sum of the reg-slot
+	//  deltas set in r) + SLOT_YBIAS; the planner rewrites them once the runs are known, see slot_plan.cpp "Y form")
 	uint32_t K;                      // Cp + Cm (mod 2^32; an absent term is RES_ABSENT, resident.h)
 	uint32_t Cc;                     // constant term (INF if none)
 	int32_t dreg[SLOT_LR];           // deltas of the reg slots (0 for a slot the run does not have)
@@ -71,7 +73,9 @@ struct SlotRow {
 };
 static_assert(SLOT_LR == 3 && SLOT_LANE == 6 && SLOT_MAXEND == 8, "hot layout of SlotRow: 2 + 3 + 6 + 1 + 4 dwords in the first line, six more ending reads in the second");
 static_assert(sizeof(SlotRow) == 256, "SlotRow must stay 64 dwords");
-constexpr int SLOT_CTRL_WORDS = 16;  // control bytes of a run's columns (SLOT_MAXCOLS bytes)
+constexpr int SLOT_CTRL_WORDS = 32;  // control words of a run: single individual 16 bits per column (n_end | slot of the first ending read << 2 | its
+                                     // qmask << 7), SLOT_MAXCOLS columns; pedigree runs one byte per column (n_end | slot << 2), PSLOT_MAXCOLS columns
+constexpr uint32_t SLOT_YBIAS = 0x80000000u;   // Y-form rows and tables: both operands of the absolute difference carry this bias (unsigned compare)
 constexpr int SLOT_ROW_PAD = 64;     // rows appended to the array: the kernel touches a fixed number of rows to warm the scalar cache
 
 // One run, passed to the kernel by value.
@@ -91,12 +95,22 @@ struct SlotRun {
 	// at create time (slot_tables): G [launched workgroups][ncols] = Cp + deltas of the set grid slots, W [waves][ncols] = deltas
 	// of the set wave slots, SL [ncols][64] = deltas of the set lane slots.  Word offsets into DevProblem::slot_tab.
 	uint32_t tab_g, tab_w, tab_sl, tab_pad;
+	// Y-form runs (kernels_slots.h, "Y form"): yflags bit 0 the run computes in Y form, bit 1 the entering column is already in Y form,
+	// bit 2 the exit column stays in Y form; base_in / base_out: the column-uniform base B at the run's entry and exit.
+	uint32_t yflags, base_in, base_out, ypad;
 };
+// Dynamic LDS of a single-individual run: wave-slot exchange 2 x [threads][cells] | hot lines [ncols + 8][16] | A [8 waves][64] | lane sums
+// [ncols + 8][64] (eight lines of slack: lines are requested up to six columns ahead).  Sized by the run's own length -- at 22 columns
+// 28 KB instead of the 41 KB of SLOT_MAXCOLS columns -- so that FOUR workgroups of 512 threads fit a CU (160 KB) when several tables
+// share a launch (slot_group).
+inline size_t slot_run_lds_bytes(uint32_t threads, uint32_t lr, uint32_t ncols) {
+	return (size_t)2 * threads * ((size_t)1 << lr) * 4 + (size_t)(ncols + 8) * 64 + 8 * 64 * 4 + (size_t)(ncols + 8) * 64 * 4;
+}
 inline uint32_t slot_pos(const uint32_t (&w)[8], uint32_t s) { return (w[s >> 2] >> ((s & 3u) * 8u)) & 255u; }
 inline void slot_set_pos(uint32_t (&w)[8], uint32_t s, uint32_t pos) {
 	w[s >> 2] = (w[s >> 2] & ~(255u << ((s & 3u) * 8u))) | (pos << ((s & 3u) * 8u));
 }
-static_assert(sizeof(SlotRun) == 176, "SlotRun layout");
+static_assert(sizeof(SlotRun) == 192, "SlotRun layout");
 
 // ---- pedigree slot runs (T = 4 or 16 transmission values; kernels_pedslots.h) -------------------------------------
 // Same slots, same run / exchange machinery; a cell holds T values, ONE (cell, transmission value) per lane: the
@@ -148,9 +162,9 @@ struct SlotBatchEntry {
 	uint8_t* bt;                     // the table's backtrace arena
 	unsigned long long* spec_keys;   // DevProblem::spec_keys
 	uint32_t spec_stride, pad2;
-	uint64_t pad3[2];
+	uint64_t pad3[8];
 };
-static_assert(sizeof(SlotBatchEntry) == 320 && sizeof(SlotBatchEntry) % 64 == 0, "entries are fetched with wide scalar loads, whole 64-byte lines");
+static_assert(sizeof(SlotBatchEntry) == 384 && sizeof(SlotBatchEntry) % 64 == 0, "entries are fetched with wide scalar loads, whole 64-byte lines");
 
 // Kernel argument of a group launch: blockIdx.y selects the entry (a pointer into the owning table's own entry array -- the arrays are
 // built once per table at create time; a group launch only passes which of them take part).
