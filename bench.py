@@ -63,8 +63,9 @@ WORKLOADS = {
     "genotype": dict(genotype=True, variants=50000, coverage=15),                  # GenotypeDPTable, single individual
     "genotype_trio": dict(genotype=True, trio=True, variants=20000, coverage=15),  # GenotypeDPTable, trio
     "heuristic": dict(heuristic=True, variants=8000, coverage=30),                 # PedMecHeuristic, coverage beyond the exact DP
+    "heuristic_x32": dict(heuristic=True, variants=8000, coverage=30, blocks=32),  # 32 PedMecHeuristic tables in ONE launch (one persistent workgroup each)
 }
-EXTRA_CONFIGS = ["config1", "config1_x24", "config3", "config3_x8", "blocks3", "blocks24", "irregular", "quartet", "genotype", "genotype_trio", "heuristic"]
+EXTRA_CONFIGS = ["config1", "config1_x24", "config3", "config3_x8", "blocks3", "blocks24", "irregular", "quartet", "genotype", "genotype_trio", "heuristic", "heuristic_x32"]
 
 
 def parse_args():
@@ -99,6 +100,7 @@ def parse_args():
     ap.add_argument("--pmc-keep", default=os.path.join(ROOT, "gpurun_out", "pmc_live"), help="where the filtered counter CSVs are kept")
     ap.add_argument("--pmc-inner", action="store_true", help=argparse.SUPPRESS)     # the profiled child: solve and exit
     ap.add_argument("--cpu-sample-worker", type=int, default=0, help=argparse.SUPPRESS)  # child of --cpu-baseline-procs
+    ap.add_argument("--heuristic-cpu-worker", type=int, default=0, help=argparse.SUPPRESS)  # child of the batched heuristic entry
     return ap.parse_args()
 
 
@@ -502,9 +504,11 @@ def genotype_main(args):
 
 
 def heuristic_main(args):
-    """`--heuristic`: PedMecHeuristic.  A step = one solve (constructor + solve() of the reference class); `value` =
-    columns / HIP-event time of the persistent kernel; the CPU baseline is the compiled reference's solve() on a prefix of the same
-    ReadSet, and every output of that prefix is compared (`identical_to_reference`)."""
+    """`--heuristic`: PedMecHeuristic.  A step = one solve (constructor + solve() of the reference class) of every table of
+    the workload -- `--blocks B` tables go out as ONE launch with one persistent workgroup each (whamd_pedmec_heuristic_enqueue_many);
+    `value` = columns of all tables / HIP-event time of the launch; the CPU baseline is the compiled reference's solve() on a prefix of the
+    same ReadSet (and, for several tables, the same on `nproc` concurrent processes: independent tables are the reference's only
+    parallelism), and every output of that prefix is compared (`identical_to_reference`)."""
     from whatshap_amd import _native
 
     if _native.device_count() < 1:
@@ -512,30 +516,41 @@ def heuristic_main(args):
     if args.coverage == 20:
         args.coverage = 30
     v = args.variants or 8000
+    n_tables = args.blocks or 1
     row_limit = 256
-    problem = build_block(args, 3, v)
+    problems = [build_block(args, 3 + i, v) for i in range(n_tables)]
+
+    def solve_all():
+        if n_tables == 1:
+            return [_native.pedmec_heuristic(problems[0], row_limit=row_limit)]
+        return _native.pedmec_heuristic_many(problems, row_limit=row_limit)
+
     for _ in range(args.warmup):
-        _native.pedmec_heuristic(problem, row_limit=row_limit)
+        solve_all()
     if args.pmc_inner:
-        _native.pedmec_heuristic(problem, row_limit=row_limit)
+        solve_all()
         return
     dev, wall, got = [], [], None
     for _ in range(args.steps):
         t0 = time.perf_counter()
-        got = _native.pedmec_heuristic(problem, row_limit=row_limit)
+        got = solve_all()
         wall.append(time.perf_counter() - t0)
-        dev.append(got["stats"]["device_ms"] / 1e3)
+        dev.append(got[0]["stats"]["device_ms"] / 1e3)
     dev_s, wall_s = sorted(dev)[len(dev) // 2], sorted(wall)[len(wall) // 2]
+    cols = v * n_tables
     out = {
         "metric": "variant-columns/sec of PedMecHeuristic.solve at max-coverage %d, row limit %d" % (args.coverage, row_limit),
-        "value": v / dev_s, "unit": "variant-columns/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dev_s * 1e3,
+        "value": cols / dev_s, "unit": "variant-columns/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dev_s * 1e3,
+        "ms_per_step_min": min(dev) * 1e3, "ms_per_step_median": dev_s * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "bipartition_costs_per_s": got["stats"]["total_solutions"] / dev_s,
+        "bipartition_costs_per_s": sum(g["stats"]["total_solutions"] for g in got) / dev_s,
         "bipartition_costs_note": "partial solutions of the beam scored per second (sum over the columns of the beam's width), not table cells",
-        "config": {"workload": f"synthetic single individual, {v} SNVs, max-coverage {args.coverage}, PedMecHeuristic row limit {row_limit}",
-                   "optimal_cost_checksum": int(got["bipartition"].sum()) * 1000003 + int(got["transmission"].sum()), "widest_column": got["stats"]["max_solutions"]},
+        "config": {"workload": f"synthetic single individual, {n_tables} table(s) x {v} SNVs, max-coverage {args.coverage}, PedMecHeuristic row limit {row_limit}"
+                               + (", ONE launch with one persistent workgroup per table" if n_tables > 1 else ""),
+                   "optimal_cost_checksum": sum(int(g["bipartition"].sum()) * 1000003 + int(g["transmission"].sum()) for g in got),
+                   "widest_column": max(g["stats"]["max_solutions"] for g in got), "blocks_in_flight_per_gpu": n_tables, "tables_per_launch": n_tables},
         "rank0": {"forward_ms_per_step": dev_s * 1e3, "backtrace_ms_per_step": 0.0, "forward_launches_per_step": 1.0},
-        "end_to_end": {"value": v / wall_s, "unit": "variant-columns/s", "what": "whamd_pedmec_heuristic_create from host arrays (plan + upload + kernel + phasing), wall"},
+        "end_to_end": {"value": cols / wall_s, "unit": "variant-columns/s", "what": "plans + upload + kernel + phasing of every table from host arrays, wall"},
     }
     pmc, pmc_note = None, "skipped"
     if args.pmc in ("on", "auto"):
@@ -547,7 +562,8 @@ def heuristic_main(args):
     roof.pop("hbm_model_ratio", None)
     roof.pop("hbm_model_note", None)
     roof["pmc_note"] = pmc_note
-    roof["shape_note"] = "ONE persistent workgroup (a chain over columns and reads; the beam is the only parallelism): the chip-wide fraction is bounded by 1 / 256 CUs"
+    roof["shape_note"] = (f"{n_tables} persistent workgroup(s), one per table (a chain over columns and reads; the beam is the only parallelism inside a table): "
+                          f"the chip-wide fraction is bounded by {n_tables} / 256 CUs")
     out["roofline"] = roof
     if args.cpu_baseline_columns != 0:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -555,8 +571,8 @@ def heuristic_main(args):
         from heuristic_cases import result_tuple
 
         if oracle.have_reference():
-            cols = args.cpu_baseline_columns if args.cpu_baseline_columns > 0 else (2000 if args.sub else 6000)
-            prefix = build_block(args, 3, v, n_columns_limit=min(cols, v))
+            cols_cpu = args.cpu_baseline_columns if args.cpu_baseline_columns > 0 else (2000 if args.sub else 6000)
+            prefix = build_block(args, 3, v, n_columns_limit=min(cols_cpu, v))
             ref = oracle.ReferenceHeuristic(prefix, row_limit=row_limit)
             mine = _native.pedmec_heuristic(prefix, row_limit=row_limit)
             out["cpu_baseline"] = {"value": prefix.n_variants / ref.solve_seconds(), "unit": "variant-columns/s", "cores": 1, "kind": "reference",
@@ -564,7 +580,34 @@ def heuristic_main(args):
                                    "host": cpu_info()}
             out["identical_to_reference"] = result_tuple(mine) == oracle.heuristic_tuple(ref)
             out["speedup_vs_cpu_baseline_device_only"] = out["value"] / out["cpu_baseline"]["value"]
+            if n_tables > 1:
+                # the honest comparison for independent tables: the reference on every host core at once, one table prefix per process
+                procs = os.cpu_count() or 1
+                cmd = [sys.executable, os.path.abspath(__file__), "--heuristic-cpu-worker", str(min(1500, v)), "--coverage", str(args.coverage), "--variants", str(v)]
+                t0 = time.perf_counter()
+                children = [subprocess.Popen(cmd + ["--blocks", str(3 + (i % n_tables))], stdout=subprocess.PIPE, text=True) for i in range(procs)]
+                rates = []
+                for ch in children:
+                    o, _ = ch.communicate(timeout=900)
+                    if ch.returncode == 0 and o.strip():
+                        rates.append(float(o.strip().splitlines()[-1]))
+                out["cpu_baseline_all_cores"] = {"value": sum(rates), "unit": "variant-columns/s", "cores": len(rates), "kind": "reference",
+                                                 "sample": f"{len(rates)} concurrent single-thread processes, each PedMecHeuristic::solve() on the first {min(1500, v)} columns of one of the "
+                                                           f"{n_tables} ReadSets, {time.perf_counter() - t0:.1f} s wall", "host": cpu_info()}
+                out["speedup_vs_cpu_all_cores_device_only"] = out["value"] / max(sum(rates), 1e-9)
     print(json.dumps(out), flush=True)
+    if out.get("identical_to_reference") is False:
+        sys.exit(3)
+
+
+def heuristic_cpu_worker(args):
+    """Child of heuristic_main: the compiled reference's solve() on a prefix of one seeded ReadSet; prints columns/s."""
+    import oracle
+
+    args.coverage = 30 if args.coverage == 20 else args.coverage
+    prefix = build_block(args, args.blocks or 3, args.variants or 8000, n_columns_limit=args.heuristic_cpu_worker)
+    ref = oracle.ReferenceHeuristic(prefix, row_limit=256)
+    print(prefix.n_variants / ref.solve_seconds())
 
 
 def dominant_kernel(args, grouped=False):
@@ -625,6 +668,8 @@ def main():
     args = parse_args()
     if args.cpu_sample_worker:
         return cpu_sample_worker(args)
+    if args.heuristic_cpu_worker:
+        return heuristic_cpu_worker(args)
     explicit = any(a in sys.argv[1:] for a in ("--workload", "--trio", "--quartet", "--irregular", "--genotype", "--heuristic", "--variants", "--coverage", "--blocks", "--blocks-per-gpu", "--path", "--option"))
     if args.workload:
         for key, value in WORKLOADS[args.workload].items():
@@ -689,8 +734,7 @@ def main():
         for start in range(0, len(tables), args.in_flight):
             window = tables[start:start + args.in_flight]
             _native.enqueue_many(window)
-            for t in window:
-                t.wait()
+            _native.wait_many(window)
 
     def sync():
         if torch is not None:

@@ -126,6 +126,10 @@ whamd_status_t whamd_dptable_release_device(whamd_dptable* table);
  * to submit the next).  Collect every table with whamd_dptable_wait.  No reference counterpart (the reference solves
  * blocks one after the other, cli/phase.py:604). */
 whamd_status_t whamd_dptable_enqueue_many(whamd_dptable* const* tables, size_t n_tables);
+/* whamd_dptable_wait for several tables: every table's device side is collected, then the host side of all of them (superreads and
+ * partitioning: what get_super_reads / get_optimal_partitioning compute, src/pedigreedptable.cpp:344-406) runs on a few host threads at
+ * once.  Returns the first failure; every table has left the "in flight" state afterwards. */
+whamd_status_t whamd_dptable_wait_many(whamd_dptable* const* tables, size_t n_tables);
 
 /*
  * Replaces PedigreeDPTable::PedigreeDPTable (src/pedigreedptable.cpp:15-37), split in two so that
@@ -268,8 +272,8 @@ whamd_status_t whamd_debug_emulate_pedslot_plan(const whamd_readset_view* readse
  * whatshap/core.pyx:674-689 (row_limit, allow_mutations; verbosity has no counterpart), solve() is part of _create as the
  * wrapper's getters all call it first (core.pyx:695).  The ReadSet must be sorted (whatshap/cli/phase.py:590 sorts it) and
  * the pedigree's individuals must carry the ids 0 .. n-1 in insertion order (the reference mixes ids, indices and ranks,
- * src/pedmecheuristic.cpp:49-82).  One persistent single-workgroup kernel per table (csrc/heuristic_device.hip); every
- * decision of the beam equals the reference's (float scores restated operation by operation). */
+ * src/pedmecheuristic.cpp:49-82).  One persistent workgroup per table (csrc/heuristic_device.hip), any number of tables per launch
+ * (whamd_pedmec_heuristic_enqueue_many); every decision of the beam equals the reference's (float scores restated operation by operation). */
 typedef struct whamd_heuristic whamd_heuristic; /* opaque */
 typedef struct whamd_heuristic_stats {
 	uint64_t n_columns, n_reads;
@@ -284,6 +288,24 @@ whamd_status_t whamd_pedmec_heuristic_create(const whamd_readset_view* readset, 
                                              const whamd_pedigree_view* pedigree, int distrust_genotypes,
                                              const uint32_t* positions, size_t n_positions, uint32_t row_limit, int allow_mutations,
                                              int device, whamd_heuristic** out);
+/* Several tables at once, asynchronously: every job is what whamd_pedmec_heuristic_create takes.  _enqueue_many builds the plans (a few
+ * host threads), uploads them and submits ONE launch whose grid is the tables -- one persistent workgroup each, on a stream of the batch's
+ * own -- and returns with out[i] in flight; whamd_pedmec_heuristic_wait(out[i]) collects (the first wait on any handle of a batch collects
+ * the whole batch; the getters fail on a handle still in flight).  Independent tables are what `whatshap phase --algorithm heuristic`
+ * produces per chromosome x family (whatshap/cli/phase.py:467,486,589-603).  The input arrays are only read during _enqueue_many. */
+typedef struct whamd_heuristic_job {
+	const whamd_readset_view* readset;
+	const uint32_t* recombcost;
+	size_t n_recombcost;
+	const whamd_pedigree_view* pedigree;
+	int distrust_genotypes;
+	const uint32_t* positions;
+	size_t n_positions;
+	uint32_t row_limit;
+	int allow_mutations;
+} whamd_heuristic_job;
+whamd_status_t whamd_pedmec_heuristic_enqueue_many(const whamd_heuristic_job* jobs, size_t n_jobs, int device, whamd_heuristic** out);
+whamd_status_t whamd_pedmec_heuristic_wait(whamd_heuristic* h);
 /* HOST-ONLY DIAGNOSTIC: the same solver source run with one CPU thread (csrc/heuristic_host.cpp), for the CPU test-suite to
  * compare with the compiled reference; never what the drop-in class calls. */
 whamd_status_t whamd_debug_pedmec_heuristic_create_host(const whamd_readset_view* readset, const uint32_t* recombcost, size_t n_recombcost,
@@ -343,8 +365,10 @@ whamd_status_t whamd_genotype_likelihoods(const whamd_readset_view* readset, con
                                           int device, uint32_t window, double* gl_out, size_t gl_capacity,
                                           whamd_genotype_stats* stats_out);
 
-/* whamd_genotype_likelihoods keeps its column store (tens of GB for long inputs) allocated between calls, one block per
- * device, because mapping that much fresh device memory takes seconds; this returns the blocks that are not in use. */
+/* Everything the library keeps between calls goes back to the driver: the column store of whamd_genotype_likelihoods (tens of GB for long
+ * inputs, one block per device: mapping that much fresh device memory takes seconds), the backtrace arena of the table closed last
+ * (commonly > 10 GB), the pinned upload staging area of whamd_dptable_create (up to 1 GiB of host memory) and the device buffers of
+ * the PedMecHeuristic solves.  Blocks in use are not touched. */
 void whamd_release_caches(void);
 
 #ifdef __cplusplus

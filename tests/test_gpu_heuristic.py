@@ -99,3 +99,33 @@ def test_drop_in_class_and_shim():
     shim.install(phase, None)
     rebound = phase.PedMecHeuristic(rs, recomb, ped, 64, distrust_genotypes=False, positions=[int(x) for x in p.positions])
     assert rebound.get_super_reads()[1] == transmission and rebound.get_optimal_partitioning() == solver.get_optimal_partitioning()
+
+
+def test_32_tables_in_one_launch_equal_single_solves_and_the_reference():
+    """whamd_pedmec_heuristic_enqueue_many: 32 different tables (single individuals, trios, a quartet; coverages 12 - 40; row limits
+    per batch) as ONE launch with one persistent workgroup each -- every output equals the table solved alone and the compiled reference's."""
+    specs = []
+    for i in range(20):
+        specs.append(dict(n_variants=300 + 40 * i, coverage=18 + (i % 5) * 4, seed=200 + i, error_rate=0.03 + 0.01 * (i % 4)))
+    for i in range(9):
+        specs.append(dict(n_variants=250 + 50 * i, coverage=12 + 2 * (i % 4), seed=230 + i, trio=True))
+    specs += [dict(n_variants=300, coverage=12, seed=240, quartet=True), dict(n_variants=500, coverage=40, seed=241, error_rate=0.1),
+              dict(n_variants=200, coverage=16, seed=242, trio=True, distrust_genotypes=True)]
+    assert len(specs) == 32
+    problems = [synthetic_block(**kw) for kw in specs]
+    for row_limit in (64, 256):
+        got = _native.pedmec_heuristic_many(problems, row_limit=row_limit)
+        assert len(got) == 32
+        for i, (p, g) in enumerate(zip(problems, got)):
+            if i % 4 == 0 or row_limit == 64:
+                want = oracle.heuristic_tuple(oracle.ReferenceHeuristic(p, row_limit=row_limit))
+                assert result_tuple(g) == want, (row_limit, specs[i])
+            if i % 8 == 1:
+                assert result_tuple(g) == result_tuple(device(p, row_limit)), (row_limit, specs[i])
+    # a second batch reuses the device buffers of the first (the per-process pool), with another order and size
+    again = _native.pedmec_heuristic_many(problems[::-3], row_limit=64)
+    first = _native.pedmec_heuristic_many(problems, row_limit=64)
+    for g, f in zip(again, first[::-3]):
+        assert result_tuple(g) == result_tuple(f)
+    _native.release_caches()
+    assert result_tuple(device(problems[0], 64)) == result_tuple(first[0])

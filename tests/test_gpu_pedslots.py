@@ -161,3 +161,33 @@ def test_four_reads_ending_in_one_column_of_a_pedigree_run(seed):
     for path in ("auto", "resident", "column"):
         got, _ = solve(p, path)
         assert got == want, (path, first_difference(want, got))
+
+
+FULL_WIDTH = [
+    # BASELINE configs[3] itself (trio, coverage 15, seed 4): 30 columns of ramp, then > 40 full-width pedslot_run launches of 14 columns
+    # (256 workgroups x 8 waves, 3 wave slots + grid slots), long enough for the chunked backtrace with its eight orientations
+    ("trio coverage 15", dict(n_variants=100000, coverage=15, seed=4, trio=True, n_columns_limit=640)),
+    # the bench's quartet (two trios sharing parents, T = 16, coverage 13, seed 5)
+    ("quartet coverage 13", dict(n_variants=50000, coverage=13, seed=5, quartet=True, n_columns_limit=280)),
+]
+
+
+@pytest.mark.parametrize("name,kw", FULL_WIDTH, ids=[n for n, _ in FULL_WIDTH])
+@pytest.mark.parametrize("ties", [False, True], ids=["weights as generated", "two-valued weights"])
+def test_full_width_pedigree_runs_vs_oracle(name, kw, ties):
+    """The pedigree configurations of the bench line at FULL width against the oracle (the reference does ~100 columns/s on this
+    shape): lowest-j rule of the min-plus step (src/pedigreedptable.cpp:264-300) and the Gray-order rule of the projection (:306-327),
+    on the slot runs (`auto`) and on the per-column kernels."""
+    p = synthetic_block(**kw)
+    if ties:
+        rng = np.random.default_rng(7)
+        p = _with(p, quality=rng.choice(np.array([4, 8], dtype=np.uint32), size=p.var_quality.size),
+                  recomb=rng.choice(np.array([0, 1, 2, 12], dtype=np.uint32), size=p.recombcost.size))
+    want = table_solution(oracle.OracleTable(p))
+    got, stats = solve(p)
+    assert got == want, (name, first_difference(want, got))
+    assert stats["forward_launches"] <= p.n_variants // 8, "the table did not run on pedigree slot runs"
+    if not ties and name.startswith("trio"):
+        assert stats["bt_chunks"] >= 2, "the table did not go through the chunked backtrace"
+    col, _ = solve(p, "column")
+    assert col == want, (name, "column", first_difference(want, col))

@@ -121,6 +121,12 @@ class HeuristicStats(C.Structure):
         return {name: getattr(self, name) for name, _ in self._fields_}
 
 
+class HeuristicJob(C.Structure):
+    _fields_ = [("readset", C.POINTER(ReadSetView)), ("recombcost", C.POINTER(C.c_uint32)), ("n_recombcost", C.c_size_t),
+                ("pedigree", C.POINTER(PedigreeView)), ("distrust_genotypes", C.c_int), ("positions", C.POINTER(C.c_uint32)),
+                ("n_positions", C.c_size_t), ("row_limit", C.c_uint32), ("allow_mutations", C.c_int)]
+
+
 def _ptr(arr: Optional[np.ndarray], ctype):
     if arr is None:
         return C.cast(None, C.POINTER(ctype))
@@ -245,6 +251,8 @@ def lib() -> C.CDLL:
     L.whamd_dptable_wait.argtypes = [H]
     L.whamd_dptable_enqueue_many.restype = C.c_int
     L.whamd_dptable_enqueue_many.argtypes = [C.POINTER(H), C.c_size_t]
+    L.whamd_dptable_wait_many.restype = C.c_int
+    L.whamd_dptable_wait_many.argtypes = [C.POINTER(H), C.c_size_t]
     L.whamd_dptable_release_device.restype = C.c_int
     L.whamd_dptable_release_device.argtypes = [H]
     L.whamd_dptable_destroy.restype = None
@@ -292,6 +300,10 @@ def lib() -> C.CDLL:
     L.whamd_pedmec_heuristic_create.argtypes = heur_args + [C.c_int, C.POINTER(C.c_void_p)]
     L.whamd_debug_pedmec_heuristic_create_host.restype = C.c_int
     L.whamd_debug_pedmec_heuristic_create_host.argtypes = heur_args + [C.POINTER(C.c_void_p)]
+    L.whamd_pedmec_heuristic_enqueue_many.restype = C.c_int
+    L.whamd_pedmec_heuristic_enqueue_many.argtypes = [C.POINTER(HeuristicJob), C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
+    L.whamd_pedmec_heuristic_wait.restype = C.c_int
+    L.whamd_pedmec_heuristic_wait.argtypes = [C.c_void_p]
     L.whamd_pedmec_heuristic_column_count.restype = C.c_uint64
     L.whamd_pedmec_heuristic_column_count.argtypes = [C.c_void_p]
     L.whamd_pedmec_heuristic_sample_count.restype = C.c_uint32
@@ -330,8 +342,9 @@ EXPORTED_SYMBOLS = [
     "whamd_dptable_read_count", "whamd_dptable_positions", "whamd_dptable_get_optimal_score",
     "whamd_dptable_get_super_reads", "whamd_dptable_get_optimal_partitioning", "whamd_dptable_get_index_path",
     "whamd_dptable_get_stats", "whamd_dptable_set_option", "whamd_read_sort_hash", "whamd_plan_summarize",
-    "whamd_dptable_enqueue", "whamd_dptable_wait", "whamd_dptable_enqueue_many", "whamd_debug_emulate_slot_plan",
+    "whamd_dptable_enqueue", "whamd_dptable_wait", "whamd_dptable_enqueue_many", "whamd_dptable_wait_many", "whamd_debug_emulate_slot_plan",
     "whamd_debug_emulate_pedslot_plan", "whamd_pedmec_heuristic_create", "whamd_debug_pedmec_heuristic_create_host",
+    "whamd_pedmec_heuristic_enqueue_many", "whamd_pedmec_heuristic_wait",
     "whamd_pedmec_heuristic_column_count", "whamd_pedmec_heuristic_sample_count", "whamd_pedmec_heuristic_read_count",
     "whamd_pedmec_heuristic_get", "whamd_pedmec_heuristic_get_stats", "whamd_pedmec_heuristic_destroy",
     "whamd_readselection", "whamd_genotype_likelihoods", "whamd_release_caches",
@@ -358,6 +371,15 @@ def enqueue_many(tables) -> None:
         return
     arr = (C.c_void_p * len(tables))(*[t._h.value for t in tables])
     _check(lib().whamd_dptable_enqueue_many(arr, len(tables)))
+
+
+def wait_many(tables) -> None:
+    """whamd_dptable_wait_many: collects several tables in flight; their host-side result extraction runs on a few threads at once."""
+    tables = list(tables)
+    if not tables:
+        return
+    arr = (C.c_void_p * len(tables))(*[t._h.value for t in tables])
+    _check(lib().whamd_dptable_wait_many(arr, len(tables)))
 
 
 class NativeTable:
@@ -476,6 +498,25 @@ def emulate_pedslot_plan(problem: ProblemArrays, n_columns: int, slot_l: int = 0
     return idx[:n_columns], trans[:n_columns], int(score.value), int(ncols.value)
 
 
+def _heuristic_result(L, h) -> dict:
+    n = int(L.whamd_pedmec_heuristic_column_count(h))
+    ns = int(L.whamd_pedmec_heuristic_sample_count(h))
+    nr = int(L.whamd_pedmec_heuristic_read_count(h))
+    score = C.c_float()
+    bip = np.zeros(max(nr, 1), dtype=np.uint8)
+    trans = np.zeros(max(n, 1), dtype=np.uint32)
+    haps = np.zeros((max(ns, 1), 2, max(n, 1)), dtype=np.int8)
+    mut = np.zeros((max(ns, 1), 2, max(n, 1)), dtype=np.uint8)
+    sid = np.zeros(max(ns, 1), dtype=np.uint32)
+    pos = np.zeros(max(n, 1), dtype=np.uint32)
+    _check(L.whamd_pedmec_heuristic_get(h, C.byref(score), _ptr(bip, C.c_uint8), _ptr(trans, C.c_uint32), haps.ctypes.data_as(C.POINTER(C.c_int8)),
+                                        _ptr(mut, C.c_uint8), _ptr(sid, C.c_uint32), _ptr(pos, C.c_uint32)))
+    stats = HeuristicStats()
+    _check(L.whamd_pedmec_heuristic_get_stats(h, C.byref(stats)))
+    return {"score": float(score.value), "bipartition": bip[:nr], "transmission": trans[:n], "haplotypes": haps[:ns, :, :n], "mutated": mut[:ns, :, :n],
+            "sample_ids": sid[:ns], "positions": pos[:n], "stats": stats.as_dict()}
+
+
 def pedmec_heuristic(problem: ProblemArrays, row_limit: int = 256, allow_mutations: bool = True, device: int = 0, host_diagnostic: bool = False) -> dict:
     """whamd_pedmec_heuristic_create + _get: the beam search of PedMecHeuristic (constructor + solve) and everything its getters
     return.  host_diagnostic: the same solver source on one CPU thread (tests only)."""
@@ -487,24 +528,62 @@ def pedmec_heuristic(problem: ProblemArrays, row_limit: int = 256, allow_mutatio
     else:
         _check(L.whamd_pedmec_heuristic_create(*a, C.c_uint32(int(row_limit)), C.c_int(1 if allow_mutations else 0), C.c_int(int(device)), C.byref(h)))
     try:
-        n = int(L.whamd_pedmec_heuristic_column_count(h))
-        ns = int(L.whamd_pedmec_heuristic_sample_count(h))
-        nr = int(L.whamd_pedmec_heuristic_read_count(h))
-        score = C.c_float()
-        bip = np.zeros(max(nr, 1), dtype=np.uint8)
-        trans = np.zeros(max(n, 1), dtype=np.uint32)
-        haps = np.zeros((max(ns, 1), 2, max(n, 1)), dtype=np.int8)
-        mut = np.zeros((max(ns, 1), 2, max(n, 1)), dtype=np.uint8)
-        sid = np.zeros(max(ns, 1), dtype=np.uint32)
-        pos = np.zeros(max(n, 1), dtype=np.uint32)
-        _check(L.whamd_pedmec_heuristic_get(h, C.byref(score), _ptr(bip, C.c_uint8), _ptr(trans, C.c_uint32), haps.ctypes.data_as(C.POINTER(C.c_int8)),
-                                            _ptr(mut, C.c_uint8), _ptr(sid, C.c_uint32), _ptr(pos, C.c_uint32)))
-        stats = HeuristicStats()
-        _check(L.whamd_pedmec_heuristic_get_stats(h, C.byref(stats)))
+        return _heuristic_result(L, h)
     finally:
         L.whamd_pedmec_heuristic_destroy(h)
-    return {"score": float(score.value), "bipartition": bip[:nr], "transmission": trans[:n], "haplotypes": haps[:ns, :, :n], "mutated": mut[:ns, :, :n],
-            "sample_ids": sid[:ns], "positions": pos[:n], "stats": stats.as_dict()}
+
+
+class HeuristicBatch:
+    """whamd_pedmec_heuristic_enqueue_many: several tables in ONE launch (one persistent workgroup each) on a stream of the batch's own;
+    `results()` waits and returns one dict per table (as pedmec_heuristic)."""
+
+    def __init__(self, problems, row_limit: int = 256, allow_mutations: bool = True, device: int = 0):
+        L = lib()
+        problems = list(problems)
+        self._L = L
+        self._n = len(problems)
+        self._handles = (C.c_void_p * max(self._n, 1))()
+        jobs = (HeuristicJob * max(self._n, 1))()
+        for i, p in enumerate(problems):   # (the problems outlive the call: the arrays are only read during _enqueue_many)
+            jobs[i].readset = C.pointer(p.readset_view)
+            jobs[i].recombcost = _ptr(p.recombcost, C.c_uint32)
+            jobs[i].n_recombcost = p.recombcost.size
+            jobs[i].pedigree = C.pointer(p.pedigree_view)
+            jobs[i].distrust_genotypes = 1 if p.distrust_genotypes else 0
+            jobs[i].positions = _ptr(p.positions, C.c_uint32)
+            jobs[i].n_positions = 0 if p.positions is None else p.positions.size
+            jobs[i].row_limit = int(row_limit)
+            jobs[i].allow_mutations = 1 if allow_mutations else 0
+        if self._n:
+            _check(L.whamd_pedmec_heuristic_enqueue_many(jobs, self._n, C.c_int(int(device)), self._handles))
+
+    def results(self):
+        out = []
+        try:
+            for i in range(self._n):
+                _check(self._L.whamd_pedmec_heuristic_wait(self._handles[i]))
+                out.append(_heuristic_result(self._L, self._handles[i]))
+        finally:
+            self.close()
+        return out
+
+    def close(self):
+        for i in range(self._n):
+            if self._handles[i]:
+                self._L.whamd_pedmec_heuristic_destroy(self._handles[i])
+                self._handles[i] = None
+        self._n = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def pedmec_heuristic_many(problems, row_limit: int = 256, allow_mutations: bool = True, device: int = 0):
+    """Several tables through one batched launch; one result dict per table."""
+    return HeuristicBatch(problems, row_limit, allow_mutations, device).results()
 
 
 def device_count() -> int:

@@ -97,13 +97,14 @@ def split_independent_blocks(problem: ProblemArrays) -> List[Tuple[ProblemArrays
 
 
 def solve_blocks(problems: Sequence[ProblemArrays], device: int = 0, path=None, max_in_flight: int = 8,
-                 release: bool = True, devices: Sequence[int] = None, weights: Sequence[float] = None):
+                 release: bool = True, devices: Sequence[int] = None, weights: Sequence[float] = None, create_threads: int = 4):
     """Host-side work queue (BASELINE north_star: "independent phasing blocks shard across the GPUs of one node via a
     host-side work queue"; scheduling precedent: whatshap/polyphase/algorithm.py:101-128).
 
-    One device (``devices`` None): solves independent blocks ``max_in_flight`` at a time, each on its own stream with
-    interleaved launch sequences (``whamd_dptable_enqueue_many``), so that blocks -- which cannot fill 256 CUs on their
-    own -- overlap.
+    One device (``devices`` None): solves independent blocks ``max_in_flight`` at a time through
+    ``whamd_dptable_enqueue_many`` -- tables on slot runs share their launches (one launch per super-step serves the whole
+    window: a coverage-15 table alone is 8 workgroups on 256 CUs), up to four full-width tables keep their own streams --
+    while ``create_threads`` host threads build the tables of the next window.
 
     Several devices (``devices=[0, 1, ...]``; an index may repeat: two workers on one device): the blocks are assigned
     longest-processing-time-first to the least loaded device (``assign_blocks``; ``weights`` defaults to the number of
@@ -113,19 +114,31 @@ def solve_blocks(problems: Sequence[ProblemArrays], device: int = 0, path=None, 
 
     Returns the solved tables in input order; with ``release`` their device buffers and streams are freed as soon as
     the solution is on the host."""
-    from ._native import NativeTable, device_count, enqueue_many
+    from ._native import NativeTable, device_count, enqueue_many, wait_many
 
     problems = list(problems)
     if devices is None:
+        # create (flatten + plan + upload: host work, the C library releases the GIL) of the NEXT window runs on a few threads while the
+        # device solves the current one; the windows' host-side result extraction runs in parallel as well (wait_many)
+        from concurrent.futures import ThreadPoolExecutor
+
+        windows = [problems[start:start + max_in_flight] for start in range(0, len(problems), max_in_flight)]
         tables = []
-        for start in range(0, len(problems), max_in_flight):
-            window = [NativeTable(sub, device=device, path=path, solve=False) for sub in problems[start:start + max_in_flight]]
-            enqueue_many(window)
-            for t in window:
-                t.wait()
+        with ThreadPoolExecutor(max_workers=max(1, min(create_threads, max_in_flight))) as pool:
+            def create(window):
+                return list(pool.map(lambda sub: NativeTable(sub, device=device, path=path, solve=False), window))
+
+            ready = create(windows[0]) if windows else []
+            for wi in range(len(windows)):
+                window = ready
+                enqueue_many(window)
+                pending = [pool.submit(NativeTable, sub, device, path, False) for sub in windows[wi + 1]] if wi + 1 < len(windows) else []
+                wait_many(window)
                 if release:
-                    t.release_device()
-            tables.extend(window)
+                    for t in window:
+                        t.release_device()
+                tables.extend(window)
+                ready = [f.result() for f in pending]
         return tables
 
     import threading
@@ -144,7 +157,7 @@ def solve_blocks(problems: Sequence[ProblemArrays], device: int = 0, path=None, 
         try:
             share = shares[slot]
             solved = solve_blocks([problems[b] for b in share], device=devices[slot], path=path,
-                                  max_in_flight=max_in_flight, release=release)
+                                  max_in_flight=max_in_flight, release=release, create_threads=create_threads)
             for b, t in zip(share, solved):
                 out[b] = t
         except BaseException as exc:  # noqa: BLE001 -- re-raised in the caller's thread

@@ -10,6 +10,7 @@
 #include "device_table.h"
 #include "genotype.h"
 #include "heuristic.h"
+#include "host_parallel.h"
 #include "problem.h"
 #include "resident.h"
 #include "slots.h"
@@ -202,6 +203,41 @@ whamd_status_t whamd_dptable_wait(whamd_dptable* t) {
 	t->stats.host_finish_ms = now_ms() - t0;
 	t->solved = true;
 	return WHAMD_OK;
+}
+
+whamd_status_t whamd_dptable_wait_many(whamd_dptable* const* tables, size_t n_tables) {
+	if (!tables && n_tables) return fail(WHAMD_ERR_INVALID, "tables is NULL");
+	for (size_t i = 0; i < n_tables; ++i) {
+		if (!tables[i]) return fail(WHAMD_ERR_INVALID, "table is NULL");
+		if (!tables[i]->in_flight) return fail(WHAMD_ERR_INVALID, "whamd_dptable_enqueue has not run");
+	}
+	// the device side of every table first (stream by stream: paths and scores arrive in pinned buffers) ...
+	whamd_status_t first = WHAMD_OK;
+	std::string first_msg;
+	std::vector<uint8_t> ok(n_tables, 0);
+	for (size_t i = 0; i < n_tables; ++i) {
+		whamd_dptable* t = tables[i];
+		t->in_flight = false;
+		std::string msg;
+		const whamd_status_t st = t->device.wait(t->problem, t->solution, t->stats, msg);
+		if (st != WHAMD_OK) { if (first == WHAMD_OK) { first = st; first_msg = msg; } continue; }
+		ok[i] = 1;
+	}
+	// ... then the host side (superreads, partitioning: get_super_reads / get_optimal_partitioning of the reference) of all of them at once
+	std::vector<whamd_status_t> status(n_tables, WHAMD_OK);
+	std::vector<std::string> messages(n_tables);
+	parallel_ranges(n_tables, host_threads(n_tables, 1), [&](uint64_t i0, uint64_t i1, uint32_t) {
+		for (uint64_t i = i0; i < i1; ++i) {
+			if (!ok[i]) continue;
+			const double t0 = now_ms();
+			status[i] = finish_solution(tables[i]->problem, tables[i]->solution, messages[i]);
+			tables[i]->stats.host_finish_ms = now_ms() - t0;
+			tables[i]->solved = status[i] == WHAMD_OK;
+		}
+	});
+	for (size_t i = 0; i < n_tables && first == WHAMD_OK; ++i)
+		if (status[i] != WHAMD_OK) { first = status[i]; first_msg = messages[i]; }
+	return first == WHAMD_OK ? WHAMD_OK : fail(first, first_msg);
 }
 
 whamd_status_t whamd_dptable_solve(whamd_dptable* t) {
@@ -558,18 +594,109 @@ whamd_status_t whamd_debug_emulate_pedslot_plan(const whamd_readset_view* readse
 
 }  // extern "C"
 
+// A batch in flight is shared by its handles: the first whamd_pedmec_heuristic_wait on any of them collects all of them.
+struct whamd_heuristic;
+struct HeuristicBatchState {
+	whamd::HeurBatch batch;
+	std::vector<whamd_heuristic*> members;
+	bool collected = false;
+	whamd_status_t status = WHAMD_OK;
+	std::string message;
+	double t_enqueued = 0.0;
+};
+
 struct whamd_heuristic {
 	whamd::HeurPlan plan;
 	whamd::HeurResult result;
 	whamd_heuristic_stats stats{};
+	std::shared_ptr<HeuristicBatchState> batch;   // non-null while in flight
+	bool finished = false;
 };
 
 namespace {
+whamd_status_t heuristic_collect(whamd_heuristic* h) {
+	if (h->finished) return WHAMD_OK;
+	if (!h->batch) return fail(WHAMD_ERR_INVALID, "whamd_pedmec_heuristic_enqueue has not run");
+	std::shared_ptr<HeuristicBatchState> st = h->batch;
+	if (!st->collected) {
+		st->collected = true;
+		std::vector<whamd::HeurResult> results(st->members.size());
+		st->status = st->batch.wait(results.data(), st->message);
+		if (st->status == WHAMD_OK) {
+			const double t_done = now_ms();
+			// allele votes + phasing per column (host, src/pedmecheuristic.cpp:361-406) of all tables at once
+			whamd::parallel_ranges(st->members.size(), whamd::host_threads(st->members.size(), 1), [&](uint64_t i0, uint64_t i1, uint32_t) {
+				for (uint64_t i = i0; i < i1; ++i) {
+					whamd_heuristic* m = st->members[i];
+					const double t0 = now_ms();
+					m->result = std::move(results[i]);
+					whamd::heuristic_finish(m->plan, m->result);
+					m->stats.max_solutions = m->result.max_solutions;
+					m->stats.total_solutions = m->result.total_solutions;
+					m->stats.device_ms = m->result.device_ms;
+					m->stats.host_prepare_ms += std::max(0.0, (t_done - st->t_enqueued) - m->result.device_ms);
+					m->stats.host_finish_ms = now_ms() - t0;
+				}
+			});
+		}
+		for (whamd_heuristic* m : st->members) { m->finished = st->status == WHAMD_OK; m->batch.reset(); }
+	}
+	if (st->status != WHAMD_OK) return fail(st->status, st->message);
+	return WHAMD_OK;
+}
+
+whamd_status_t heuristic_enqueue_jobs(const whamd_heuristic_job* jobs, size_t n_jobs, int device, whamd_heuristic** out) {
+	if (!out || (!jobs && n_jobs)) return fail(WHAMD_ERR_INVALID, "null argument");
+	for (size_t i = 0; i < n_jobs; ++i) out[i] = nullptr;
+	std::vector<std::unique_ptr<whamd_heuristic>> hs(n_jobs);
+	std::vector<whamd_status_t> status(n_jobs, WHAMD_OK);
+	std::vector<std::string> messages(n_jobs);
+	std::vector<double> prepare_ms(n_jobs, 0.0);
+	// the plans (flattening + the per-column bookkeeping of solve() that does not depend on the beam): a few host threads
+	whamd::parallel_ranges(n_jobs, whamd::host_threads(n_jobs, 1), [&](uint64_t i0, uint64_t i1, uint32_t) {
+		for (uint64_t i = i0; i < i1; ++i) {
+			const double t0 = now_ms();
+			hs[i].reset(new whamd_heuristic());
+			const whamd_heuristic_job& j = jobs[i];
+			status[i] = whamd::build_heuristic_plan(j.readset, j.recombcost, j.n_recombcost, j.pedigree, j.distrust_genotypes != 0, j.positions, j.n_positions,
+			                                        j.row_limit, j.allow_mutations != 0, hs[i]->plan, messages[i]);
+			prepare_ms[i] = now_ms() - t0;
+		}
+	});
+	for (size_t i = 0; i < n_jobs; ++i) if (status[i] != WHAMD_OK) return fail(status[i], messages[i]);
+	std::shared_ptr<HeuristicBatchState> st(new HeuristicBatchState());
+	std::vector<const whamd::HeurPlan*> plans(n_jobs);
+	for (size_t i = 0; i < n_jobs; ++i) plans[i] = &hs[i]->plan;
+	std::string msg;
+	st->t_enqueued = now_ms();
+	const whamd_status_t es = st->batch.enqueue(plans.data(), n_jobs, device, msg);
+	if (es != WHAMD_OK) return fail(es, msg);
+	for (size_t i = 0; i < n_jobs; ++i) {
+		whamd_heuristic* h = hs[i].get();
+		h->stats.n_columns = h->plan.n_cols; h->stats.n_reads = h->plan.n_reads; h->stats.n_samples = h->plan.n_samples; h->stats.row_limit = h->plan.row_limit;
+		h->stats.host_prepare_ms = prepare_ms[i];
+		h->batch = st;
+		st->members.push_back(h);
+	}
+	for (size_t i = 0; i < n_jobs; ++i) out[i] = hs[i].release();
+	return WHAMD_OK;
+}
+
 whamd_status_t heuristic_create_common(const whamd_readset_view* readset, const uint32_t* recombcost, size_t n_recombcost, const whamd_pedigree_view* pedigree,
                                        int distrust_genotypes, const uint32_t* positions, size_t n_positions, uint32_t row_limit, int allow_mutations,
                                        int device, bool on_host, whamd_heuristic** out) {
 	if (!out) return fail(WHAMD_ERR_INVALID, "out is NULL");
 	*out = nullptr;
+	if (!on_host) {
+		whamd_heuristic_job job{readset, recombcost, n_recombcost, pedigree, distrust_genotypes, positions, n_positions, row_limit, allow_mutations};
+		whamd_heuristic* h = nullptr;
+		whamd_status_t st = heuristic_enqueue_jobs(&job, 1, device, &h);
+		if (st != WHAMD_OK) return st;
+		st = heuristic_collect(h);
+		if (st != WHAMD_OK) { delete h; return st; }
+		*out = h;
+		return WHAMD_OK;
+	}
 	const double t0 = now_ms();
 	std::unique_ptr<whamd_heuristic> h(new whamd_heuristic());
 	std::string msg;
@@ -577,7 +704,7 @@ whamd_status_t heuristic_create_common(const whamd_readset_view* readset, const 
 	                                                allow_mutations != 0, h->plan, msg);
 	if (st != WHAMD_OK) return fail(st, msg);
 	const double t1 = now_ms();
-	st = on_host ? whamd::heuristic_solve_host(h->plan, h->result, msg) : whamd::heuristic_solve_device(h->plan, device, h->result, msg);
+	st = whamd::heuristic_solve_host(h->plan, h->result, msg);
 	if (st != WHAMD_OK) return fail(st, msg);
 	const double t2 = now_ms();
 	whamd::heuristic_finish(h->plan, h->result);
@@ -585,6 +712,7 @@ whamd_status_t heuristic_create_common(const whamd_readset_view* readset, const 
 	h->stats.total_solutions = h->result.total_solutions; h->stats.device_ms = h->result.device_ms;
 	h->stats.host_prepare_ms = (t1 - t0) + ((t2 - t1) - h->result.device_ms); h->stats.host_finish_ms = now_ms() - t2;
 	h->stats.n_samples = h->plan.n_samples; h->stats.row_limit = h->plan.row_limit;
+	h->finished = true;
 	*out = h.release();
 	return WHAMD_OK;
 }
@@ -596,6 +724,15 @@ whamd_status_t whamd_pedmec_heuristic_create(const whamd_readset_view* readset, 
                                              const whamd_pedigree_view* pedigree, int distrust_genotypes, const uint32_t* positions, size_t n_positions,
                                              uint32_t row_limit, int allow_mutations, int device, whamd_heuristic** out) {
 	return heuristic_create_common(readset, recombcost, n_recombcost, pedigree, distrust_genotypes, positions, n_positions, row_limit, allow_mutations, device, false, out);
+}
+
+whamd_status_t whamd_pedmec_heuristic_enqueue_many(const whamd_heuristic_job* jobs, size_t n_jobs, int device, whamd_heuristic** out) {
+	return heuristic_enqueue_jobs(jobs, n_jobs, device, out);
+}
+
+whamd_status_t whamd_pedmec_heuristic_wait(whamd_heuristic* h) {
+	if (!h) return fail(WHAMD_ERR_INVALID, "null argument");
+	return heuristic_collect(h);
 }
 
 whamd_status_t whamd_debug_pedmec_heuristic_create_host(const whamd_readset_view* readset, const uint32_t* recombcost, size_t n_recombcost,
@@ -611,6 +748,7 @@ uint32_t whamd_pedmec_heuristic_read_count(const whamd_heuristic* h) { return h 
 whamd_status_t whamd_pedmec_heuristic_get(const whamd_heuristic* h, float* score, uint8_t* bipartition, uint32_t* transmission, int8_t* haplotypes,
                                           uint8_t* mutated, uint32_t* sample_ids, uint32_t* positions) {
 	if (!h) return fail(WHAMD_ERR_INVALID, "null argument");
+	if (!h->finished) return fail(WHAMD_ERR_INVALID, "the solve is still in flight: call whamd_pedmec_heuristic_wait first");
 	if (score) *score = h->result.score;
 	if (bipartition && !h->result.bipartition.empty()) std::memcpy(bipartition, h->result.bipartition.data(), h->result.bipartition.size());
 	if (transmission && !h->result.transmission.empty()) std::memcpy(transmission, h->result.transmission.data(), h->result.transmission.size() * 4);
@@ -627,7 +765,12 @@ whamd_status_t whamd_pedmec_heuristic_get_stats(const whamd_heuristic* h, whamd_
 	return WHAMD_OK;
 }
 
-void whamd_pedmec_heuristic_destroy(whamd_heuristic* h) { delete h; }
+void whamd_pedmec_heuristic_destroy(whamd_heuristic* h) {
+	if (h && h->batch) {   // still in flight: the batch reads this handle's plan -- collect it first (the other members keep their results)
+		(void)heuristic_collect(h);
+	}
+	delete h;
+}
 
 // std::hash tie-break of ReadSet::sort (src/readset.h:52-55,78-82): exported so that the Python mirror of
 // ReadSet.sort() orders reads exactly like the reference built against the same libstdc++.
@@ -665,6 +808,10 @@ whamd_status_t whamd_genotype_likelihoods(const whamd_readset_view* readset, con
 	return WHAMD_OK;
 }
 
-void whamd_release_caches(void) { genotype_release_cache(); }
+void whamd_release_caches(void) {
+	genotype_release_cache();
+	whamd::heuristic_release_cache();
+	whamd::dptable_release_caches();
+}
 
 }  // extern "C"

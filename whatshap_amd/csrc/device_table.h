@@ -61,4 +61,7 @@ private:
 	Impl* impl_;
 };
 
+// process-wide caches of the device driver (the arena of the table closed last, the pinned upload staging area): whamd_release_caches
+void dptable_release_caches();
+
 }  // namespace whamd

@@ -1648,4 +1648,14 @@ void dptable_release_arena_cache() {
 	g_arena.bytes = 0;
 }
 
+// whamd_release_caches: the kept backtrace arena AND the pinned upload staging area go back to the driver.
+void dptable_release_caches() {
+	dptable_release_arena_cache();
+	std::lock_guard<std::mutex> lock(g_stage.mu);
+	if (g_stage.base) (void)hipHostFree(g_stage.base);
+	g_stage.base = nullptr;
+	g_stage.cap = 0;
+	g_stage.want = 0;
+}
+
 }  // namespace whamd

@@ -78,6 +78,23 @@ whamd_status_t build_heuristic_plan(const whamd_readset_view* rs, const uint32_t
                                     HeurPlan& plan, std::string& msg);
 // the beam search: bipartition + transmission (device: heuristic_device.hip; host diagnostic: heuristic_host.cpp)
 whamd_status_t heuristic_solve_device(const HeurPlan& plan, int device, HeurResult& out, std::string& msg);
+// Several tables of one device in flight (heuristic_device.hip): enqueue() uploads the plans and submits ONE launch whose grid is the
+// tables (one persistent workgroup each) on the batch's own stream and returns; wait() collects every table (and runs a table again whose
+// records outgrew their arena).  The plans must outlive the batch.
+class HeurBatch {
+public:
+	HeurBatch();
+	~HeurBatch();
+	HeurBatch(const HeurBatch&) = delete;
+	HeurBatch& operator=(const HeurBatch&) = delete;
+	whamd_status_t enqueue(const HeurPlan* const* plans, size_t n, int device, std::string& msg);
+	whamd_status_t wait(HeurResult* outs, std::string& msg);   // outs[n]
+	struct Impl;
+private:
+	Impl* impl_;
+};
+// gives the device buffers kept between solves back to the driver (whamd_release_caches)
+void heuristic_release_cache();
 whamd_status_t heuristic_solve_host(const HeurPlan& plan, HeurResult& out, std::string& msg);
 // allele votes of the final bipartition and the optimal phasing per column (host, src/pedmecheuristic.cpp:361-406)
 void heuristic_finish(const HeurPlan& plan, HeurResult& out);

@@ -11,6 +11,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
 
 #include "heuristic.h"
 
@@ -62,118 +66,324 @@ namespace whamd {
 namespace {
 template <int MAXT>
 __global__ __launch_bounds__(MAXT) void heuristic_kernel(HeurDev D) { heur_solve(D); }
+
+// One launch = SEVERAL tables, one persistent workgroup each (blockIdx.x selects the table's descriptor): independent chromosomes /
+// families run side by side on as many CUs -- the beam of one table cannot use more than one.
+template <int MAXT>
+__global__ __launch_bounds__(MAXT) void heuristic_kernel_many(const HeurDev* __restrict__ tables) {
+	HeurDev D;   // (copied through the constant address space: wave-uniform scalar loads, the descriptor ends up in SGPRs like a kernel argument)
+	{
+		static_assert(sizeof(HeurDev) % 4 == 0, "whole words");
+		uint32_t* w = reinterpret_cast<uint32_t*>(&D);
+		const __attribute__((address_space(4))) uint32_t* src = (const __attribute__((address_space(4))) uint32_t*)(unsigned long long)(tables + blockIdx.x);
+#pragma unroll
+		for (uint32_t i = 0; i < sizeof(HeurDev) / 4; ++i) w[i] = src[i];
+	}
+	heur_solve(D);
+}
+
+// ---- device buffers kept between calls.  A solve used to hipMalloc ~20 arrays and hipFree them again (each a driver round trip, the
+// large ones hundreds of microseconds); blocks are now taken from and given back to a per-process pool, rounded to size classes so
+// that the tables of one run reuse each other's.  whamd_release_caches() empties it.
+struct DevBlock { void* ptr; size_t bytes; int device; };
+struct DevPool {
+	std::mutex mu;
+	std::vector<DevBlock> idle;
+	size_t idle_bytes = 0;
+};
+DevPool g_pool;
+constexpr size_t POOL_KEEP = (size_t)12 << 30;   // most bytes kept idle
+size_t pool_class(size_t bytes) {
+	bytes = std::max<size_t>(bytes, 256);
+	size_t p = 256;
+	while (p < bytes) p <<= 1;
+	const size_t step = std::max<size_t>(p / 8, 256);   // eight classes per power of two: at most 12.5 % over
+	return (bytes + step - 1) / step * step;
+}
+hipError_t pool_take(int device, size_t bytes, void** out, size_t* got) {
+	const size_t want = pool_class(bytes);
+	{
+		std::lock_guard<std::mutex> lock(g_pool.mu);
+		for (size_t i = 0; i < g_pool.idle.size(); ++i) {
+			if (g_pool.idle[i].device != device || g_pool.idle[i].bytes != want) continue;
+			*out = g_pool.idle[i].ptr;
+			*got = want;
+			g_pool.idle_bytes -= want;
+			g_pool.idle[i] = g_pool.idle.back();
+			g_pool.idle.pop_back();
+			return hipSuccess;
+		}
+	}
+	*got = want;
+	return hipMalloc(out, want);
+}
+void pool_give(int device, void* ptr, size_t bytes) {
+	if (!ptr) return;
+	{
+		std::lock_guard<std::mutex> lock(g_pool.mu);
+		if (g_pool.idle_bytes + bytes <= POOL_KEEP) {
+			g_pool.idle.push_back(DevBlock{ptr, bytes, device});
+			g_pool.idle_bytes += bytes;
+			return;
+		}
+	}
+	(void)hipFree(ptr);
+}
 }  // namespace
 
-whamd_status_t heuristic_solve_device(const HeurPlan& pl, int device, HeurResult& out, std::string& msg) {
-	out = HeurResult();
-	out.bipartition.assign(pl.n_reads, 0);
-	out.transmission.assign(pl.n_cols, 0);
-	if (pl.n_cols == 0) return WHAMD_OK;
+void heuristic_release_cache() {
+	std::vector<DevBlock> blocks;
+	{
+		std::lock_guard<std::mutex> lock(g_pool.mu);
+		blocks.swap(g_pool.idle);
+		g_pool.idle_bytes = 0;
+	}
+	int cur = 0;
+	(void)hipGetDevice(&cur);
+	for (const DevBlock& b : blocks) { (void)hipSetDevice(b.device); (void)hipFree(b.ptr); }
+	(void)hipSetDevice(cur);
+}
+
+// Several tables in flight: everything between "plans built" and "bipartitions on the host".
+struct HeurBatch::Impl {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	struct Job {
+		const HeurPlan* plan = nullptr;
+		HeurDev D{};
+		std::vector<std::pair<void*, size_t>> blocks;   // pool blocks (pointer, class size)
+		void* arena = nullptr; size_t arena_bytes = 0;
+		unsigned long long arena_words = 0;
+		uint64_t cap = 0;
+		uint32_t block = 128;
+		bool done = false;
+		unsigned long long stats[32] = {0};
+	};
+	std::vector<Job> jobs;
+	HeurDev* d_tables = nullptr; size_t d_tables_bytes = 0;
+	bool launched = false;
+	~Impl() {
+		(void)hipSetDevice(device);
+		if (stream) (void)hipStreamSynchronize(stream);
+		for (Job& j : jobs) {
+			for (auto& b : j.blocks) pool_give(device, b.first, b.second);
+			pool_give(device, j.arena, j.arena_bytes);
+		}
+		pool_give(device, d_tables, d_tables_bytes);
+		if (ev0) (void)hipEventDestroy(ev0);
+		if (ev1) (void)hipEventDestroy(ev1);
+		if (stream) (void)hipStreamDestroy(stream);
+	}
+};
+
+HeurBatch::HeurBatch() : impl_(new Impl()) {}
+HeurBatch::~HeurBatch() { delete impl_; }
+
+#define HEUR_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { msg = std::string(#expr) + " failed: " + hipGetErrorString(e_); return WHAMD_ERR_DEVICE; } } while (0)
+
+// Launches every job that is not done yet: one launch per workgroup size (the kernel is compiled for 512 and for 1024 threads).
+static whamd_status_t heur_launch_pending(HeurBatch::Impl& m, std::string& msg) {
+	std::vector<HeurDev> host;
+	std::vector<size_t> which;
+	size_t written = 0;   // descriptors of this round's launches: consecutive parts of d_tables (a later launch must not overwrite an earlier one's)
+	for (uint32_t block : {128u, 256u, 512u, 1024u}) {
+		host.clear();
+		which.clear();
+		for (size_t i = 0; i < m.jobs.size(); ++i)
+			if (!m.jobs[i].done && m.jobs[i].block == block) { host.push_back(m.jobs[i].D); which.push_back(i); }
+		if (host.empty()) continue;
+		if (host.size() == 1) {   // a single table: descriptor by value (kernel arguments)
+			if (block <= 512u) hipLaunchKernelGGL(heuristic_kernel<512>, dim3(1), dim3(block), 0, m.stream, host[0]);
+			else hipLaunchKernelGGL(heuristic_kernel<1024>, dim3(1), dim3(block), 0, m.stream, host[0]);
+			continue;
+		}
+		HeurDev* dst = m.d_tables + written;
+		written += host.size();
+		HEUR_TRY(hipMemcpyAsync(dst, host.data(), host.size() * sizeof(HeurDev), hipMemcpyHostToDevice, m.stream));
+		HEUR_TRY(hipStreamSynchronize(m.stream));   // (`host` is pageable and dies with this scope)
+		if (block <= 512u) hipLaunchKernelGGL(heuristic_kernel_many<512>, dim3((uint32_t)host.size()), dim3(block), 0, m.stream, dst);
+		else hipLaunchKernelGGL(heuristic_kernel_many<1024>, dim3((uint32_t)host.size()), dim3(block), 0, m.stream, dst);
+	}
+	HEUR_TRY(hipGetLastError());
+	return WHAMD_OK;
+}
+
+whamd_status_t HeurBatch::enqueue(const HeurPlan* const* plans, size_t n, int device, std::string& msg) {
+	Impl& m = *impl_;
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
 		msg = "no HIP device visible: the whatshap_amd device path needs an MI355X (gfx950); there is no CPU fallback";
 		return WHAMD_ERR_DEVICE;
 	}
 	if (device < 0 || device >= ndev) { msg = "device index " + std::to_string(device) + " out of range (" + std::to_string(ndev) + " visible)"; return WHAMD_ERR_DEVICE; }
-#define HEUR_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { msg = std::string(#expr) + " failed: " + hipGetErrorString(e_); for (void* a : allocations) (void)hipFree(a); return WHAMD_ERR_DEVICE; } } while (0)
-	std::vector<void*> allocations;
+	m.device = device;
 	HEUR_TRY(hipSetDevice(device));
+	HEUR_TRY(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
+	HEUR_TRY(hipEventCreate(&m.ev0));
+	HEUR_TRY(hipEventCreate(&m.ev1));
 	size_t free_b = 0, total_b = 0;
 	HEUR_TRY(hipMemGetInfo(&free_b, &total_b));
-	const uint32_t T = 1u << pl.tm_bits;
-	const size_t rows = 2u * pl.n_samples;
-	// worst case of the beam: the pruning keeps every solution that ties with the best one, up to 65535 (filterSolutions), a read doubles
-	// them, the transmission values multiply them by 4^trios.  Sized for that when it fits in a third of the free memory, else for
-	// 16 x row_limit (an overflow is reported, never silently pruned differently).
-	const size_t per_solution = rows * pl.w_max * 4 + (size_t)pl.nw * 8 + 48;
-	uint64_t cap = (uint64_t)HEUR_MAX_ROW_LIMIT * std::max(2u, T);
-	if (2 * cap * per_solution > free_b / 3) cap = std::max<uint64_t>((uint64_t)pl.row_limit * 16u * std::max(2u, T), 4096);
-	if (2 * cap * per_solution > free_b / 3) { msg = "PedMecHeuristic: the solution pools do not fit in device memory"; return WHAMD_ERR_UNSUPPORTED; }
-	uint32_t tsz = 64;
-	while (tsz < 2 * cap) tsz <<= 1;
-	auto alloc = [&](void** dptr, size_t bytes) -> hipError_t {
-		hipError_t e = hipMalloc(dptr, std::max<size_t>(bytes, 16));
-		if (e == hipSuccess) allocations.push_back(*dptr);
-		return e;
-	};
-	auto up = [&](void** dptr, const void* src, size_t bytes) -> hipError_t {
-		hipError_t e = alloc(dptr, bytes);
-		if (e == hipSuccess && bytes) e = hipMemcpy(*dptr, src, bytes, hipMemcpyHostToDevice);
-		return e;
-	};
-	HeurDev D{};
-	D.n_cols = pl.n_cols; D.n_samples = pl.n_samples; D.n_trios = pl.n_trios; D.tm_bits = pl.tm_bits; D.row_limit = pl.row_limit;
-	D.distrust = pl.distrust; D.w_max = pl.w_max; D.nw = pl.nw;
-	const std::vector<HeurColMeta> col_meta = heuristic_col_meta(pl);
-	const std::vector<HeurReadMeta> read_meta = heuristic_read_meta(pl);
-	void* d = nullptr;
-#define HEUR_UP(field, vec, type) HEUR_TRY(up(&d, (vec).data(), (vec).size() * sizeof((vec)[0]))); D.field = (type)d
-	HEUR_UP(trios, pl.trios, const uint32_t*);
-	HEUR_UP(recomb, pl.recomb, const float*); HEUR_UP(mutation, pl.mutation, const float*); HEUR_UP(genotype, pl.genotype, const int8_t*);
-	HEUR_UP(start_index, pl.start_index, const uint32_t*); HEUR_UP(col, col_meta, const HeurColMeta*); HEUR_UP(kept, pl.kept, const uint32_t*);
-	HEUR_UP(reads, read_meta, const HeurReadMeta*); HEUR_UP(new_balance, pl.new_balance, const float*); HEUR_UP(new_target, pl.new_target, const int32_t*);
-#undef HEUR_UP
-	D.cap = (uint32_t)cap; D.tsz = tsz;
-	for (int q = 0; q < 2; ++q) HEUR_TRY(alloc((void**)&D.pool_words[q], heur_pool_words(D.cap, pl.nw, pl.n_samples, pl.w_max) * 4));
-	HEUR_TRY(alloc((void**)&D.scratch, heur_scratch_words(D.cap, pl.nw) * 4));
-	HEUR_TRY(alloc((void**)&D.hash, heur_hash_words(tsz) * 4));
-	HEUR_TRY(alloc((void**)&D.col_off, (size_t)pl.n_cols * 8)); HEUR_TRY(alloc((void**)&D.col_count, (size_t)pl.n_cols * 4));
-	HEUR_TRY(alloc((void**)&D.opt_bipart, std::max<size_t>(pl.n_reads, 1))); HEUR_TRY(alloc((void**)&D.opt_trans, (size_t)pl.n_cols * 4));
-	HEUR_TRY(alloc((void**)&D.stats, 256));
-	HEUR_TRY(hipMemset(D.opt_bipart, 0, std::max<size_t>(pl.n_reads, 1)));
-	hipEvent_t ev0, ev1;
-	HEUR_TRY(hipEventCreate(&ev0));
-	HEUR_TRY(hipEventCreate(&ev1));
-	// the backtrace arena: sized for 4 x row_limit x 4^trios solutions per column first, regrown on overflow while memory allows
-	unsigned long long stride_sum = 0;
-	for (uint32_t p = 0; p < pl.n_cols; ++p) stride_sum += 2 + ((pl.n_new[p] + 31) >> 5);
-	unsigned long long arena_words = stride_sum * std::min<uint64_t>(cap, (uint64_t)pl.row_limit * 4u * T) + 1024;
-	unsigned long long stats[32] = {0};
-	whamd_status_t status = WHAMD_OK;
-	for (;;) {
-		HEUR_TRY(hipMemGetInfo(&free_b, &total_b));
-		if (arena_words * 4 > free_b / 2) { msg = "PedMecHeuristic: the backtrace records do not fit in device memory"; status = WHAMD_ERR_UNSUPPORTED; break; }
-		void* arena = nullptr;
-		HEUR_TRY(hipMalloc(&arena, arena_words * 4));
-		D.arena = (uint32_t*)arena; D.arena_words = arena_words;
-		HEUR_TRY(hipMemset(D.stats, 0, 256));
-		HEUR_TRY(hipEventRecord(ev0, nullptr));
+	{
+		std::lock_guard<std::mutex> lock(g_pool.mu);
+		free_b += g_pool.idle_bytes;   // (reused below, or freed by the allocator's callers when memory is short)
+	}
+	const size_t budget = free_b / 3 / std::max<size_t>(n, 1);   // what one table's pools may take
+	m.jobs.resize(n);
+	{
+		size_t got = 0;
+		void* ptr = nullptr;
+		HEUR_TRY(pool_take(device, (n + 1) * sizeof(HeurDev), &ptr, &got));
+		m.d_tables = (HeurDev*)ptr; m.d_tables_bytes = got;
+	}
+	for (size_t ji = 0; ji < n; ++ji) {
+		const HeurPlan& pl = *plans[ji];
+		Impl::Job& job = m.jobs[ji];
+		job.plan = &pl;
+		if (pl.n_cols == 0) { job.done = true; continue; }
+		const uint32_t T = 1u << pl.tm_bits;
+		const size_t rows = 2u * pl.n_samples;
+		// worst case of the beam: the pruning keeps every solution that ties with the best one, up to 65535 (filterSolutions), a read doubles
+		// them, the transmission values multiply them by 4^trios.  Sized for that when it fits in the table's share of the free memory, else
+		// for 16 x row_limit (an overflow is reported, never silently pruned differently).
+		const size_t per_solution = rows * pl.w_max * 4 + (size_t)pl.nw * 8 + 48;
+		const uint64_t full_cap = (uint64_t)HEUR_MAX_ROW_LIMIT * std::max(2u, T);
+		uint64_t cap = full_cap;
+		if (2 * cap * per_solution > budget) cap = std::min<uint64_t>(full_cap, std::max<uint64_t>((uint64_t)pl.row_limit * 16u * std::max(2u, T), 4096));
+		if (2 * cap * per_solution > budget) { msg = "PedMecHeuristic: the solution pools do not fit in device memory"; return WHAMD_ERR_UNSUPPORTED; }
+		job.cap = cap;
+		uint32_t tsz = 64;
+		while (tsz < 2 * cap) tsz <<= 1;
+		auto alloc = [&](void** dptr, size_t bytes) -> hipError_t {
+			size_t got = 0;
+			hipError_t e = pool_take(device, std::max<size_t>(bytes, 16), dptr, &got);
+			if (e == hipSuccess) job.blocks.emplace_back(*dptr, got);
+			return e;
+		};
+		// the small read-only arrays of the plan travel as ONE block (one allocation, one copy)
+		HeurDev& D = job.D;
+		D.n_cols = pl.n_cols; D.n_samples = pl.n_samples; D.n_trios = pl.n_trios; D.tm_bits = pl.tm_bits; D.row_limit = pl.row_limit;
+		D.distrust = pl.distrust; D.w_max = pl.w_max; D.nw = pl.nw;
+		const std::vector<HeurColMeta> col_meta = heuristic_col_meta(pl);
+		const std::vector<HeurReadMeta> read_meta = heuristic_read_meta(pl);
+		struct Piece { const void* src; size_t bytes; size_t off; };
+		std::vector<Piece> pieces;
+		size_t total = 0;
+		auto piece = [&](const void* src, size_t bytes) { const size_t off = total; pieces.push_back(Piece{src, bytes, off}); total += (bytes + 255) & ~(size_t)255; return off; };
+		const size_t o_trios = piece(pl.trios.data(), pl.trios.size() * 4), o_recomb = piece(pl.recomb.data(), pl.recomb.size() * 4);
+		const size_t o_mut = piece(pl.mutation.data(), pl.mutation.size() * 4), o_geno = piece(pl.genotype.data(), pl.genotype.size());
+		const size_t o_start = piece(pl.start_index.data(), pl.start_index.size() * 4), o_col = piece(col_meta.data(), col_meta.size() * sizeof(HeurColMeta));
+		const size_t o_kept = piece(pl.kept.data(), pl.kept.size() * 4), o_reads = piece(read_meta.data(), read_meta.size() * sizeof(HeurReadMeta));
+		const size_t o_bal = piece(pl.new_balance.data(), pl.new_balance.size() * 4), o_target = piece(pl.new_target.data(), pl.new_target.size() * 4);
+		std::vector<char> staged(std::max<size_t>(total, 16), 0);
+		for (const Piece& pc : pieces) if (pc.bytes) std::memcpy(staged.data() + pc.off, pc.src, pc.bytes);
+		char* base = nullptr;
+		HEUR_TRY(alloc((void**)&base, staged.size()));
+		HEUR_TRY(hipMemcpyAsync(base, staged.data(), staged.size(), hipMemcpyHostToDevice, m.stream));
+		HEUR_TRY(hipStreamSynchronize(m.stream));   // (`staged` is pageable)
+		D.trios = (const uint32_t*)(base + o_trios); D.recomb = (const float*)(base + o_recomb); D.mutation = (const float*)(base + o_mut);
+		D.genotype = (const int8_t*)(base + o_geno); D.start_index = (const uint32_t*)(base + o_start); D.col = (const HeurColMeta*)(base + o_col);
+		D.kept = (const uint32_t*)(base + o_kept); D.reads = (const HeurReadMeta*)(base + o_reads); D.new_balance = (const float*)(base + o_bal);
+		D.new_target = (const int32_t*)(base + o_target);
+		D.cap = (uint32_t)cap; D.tsz = tsz;
+		for (int q = 0; q < 2; ++q) HEUR_TRY(alloc((void**)&D.pool_words[q], heur_pool_words(D.cap, pl.nw, pl.n_samples, pl.w_max) * 4));
+		HEUR_TRY(alloc((void**)&D.scratch, heur_scratch_words(D.cap, pl.nw) * 4));
+		HEUR_TRY(alloc((void**)&D.hash, heur_hash_words(tsz) * 4));
+		// col_off | col_count | opt_trans | opt_bipart | stats: one block
+		const size_t b_off = 0, b_count = (size_t)pl.n_cols * 8, b_trans = b_count + (((size_t)pl.n_cols * 4 + 7) & ~(size_t)7), b_bip = b_trans + (((size_t)pl.n_cols * 4 + 7) & ~(size_t)7);
+		const size_t b_stats = b_bip + ((std::max<size_t>(pl.n_reads, 1) + 255) & ~(size_t)255), b_total = b_stats + 256;
+		char* res = nullptr;
+		HEUR_TRY(alloc((void**)&res, b_total));
+		D.col_off = (unsigned long long*)(res + b_off); D.col_count = (uint32_t*)(res + b_count); D.opt_trans = (uint32_t*)(res + b_trans);
+		D.opt_bipart = (uint8_t*)(res + b_bip); D.stats = (unsigned long long*)(res + b_stats);
+		HEUR_TRY(hipMemsetAsync(res + b_bip, 0, b_total - b_bip, m.stream));
+		// the backtrace arena: sized for 4 x row_limit x 4^trios solutions per column first, regrown on overflow while memory allows
+		unsigned long long stride_sum = 0;
+		for (uint32_t p = 0; p < pl.n_cols; ++p) stride_sum += 2 + ((pl.n_new[p] + 31) >> 5);
+		job.arena_words = stride_sum * std::min<uint64_t>(cap, (uint64_t)pl.row_limit * 4u * T) + 1024;
+		if (job.arena_words * 4 > free_b / 2 / std::max<size_t>(n, 1)) { msg = "PedMecHeuristic: the backtrace records do not fit in device memory"; return WHAMD_ERR_UNSUPPORTED; }
+		HEUR_TRY(pool_take(device, job.arena_words * 4, &job.arena, &job.arena_bytes));
+		D.arena = (uint32_t*)job.arena; D.arena_words = job.arena_words;
 		// as many threads as the beam usually has solutions (a barrier costs with the number of waves): 2 x row_limit, 128 .. 1024
 		uint32_t block = 128;
 		while (block < 1024u && block < 2u * pl.row_limit) block <<= 1;
-		if (const char* e = getenv("WHAMD_HEURISTIC_THREADS")) block = (uint32_t)std::max(64, std::min(1024, atoi(e)));
-		// (compiled twice: up to 512 threads a thread may hold 256 VGPRs -- at the 128 of a 1024-thread workgroup the batches of the row
-		// copies spill to scratch memory)
-		if (block <= 512u) hipLaunchKernelGGL(heuristic_kernel<512>, dim3(1), dim3(block), 0, nullptr, D);
-		else hipLaunchKernelGGL(heuristic_kernel<1024>, dim3(1), dim3(block), 0, nullptr, D);
-		HEUR_TRY(hipEventRecord(ev1, nullptr));
-		hipError_t e = hipDeviceSynchronize();
-		if (e == hipSuccess) e = hipMemcpy(stats, D.stats, sizeof stats, hipMemcpyDeviceToHost);
-		(void)hipFree(arena);
-		if (e != hipSuccess) { msg = std::string("heuristic kernel failed: ") + hipGetErrorString(e); status = WHAMD_ERR_DEVICE; break; }
-		if (stats[0] == 2) { arena_words *= 4; continue; }
-		if (stats[0] == 1) { msg = "PedMecHeuristic: more tied solutions than the device pools hold (" + std::to_string(cap) + ")"; status = WHAMD_ERR_UNSUPPORTED; }
-		break;
+		if (const char* e = getenv("WHAMD_HEURISTIC_THREADS")) { block = 128; const uint32_t want = (uint32_t)std::max(64, std::min(1024, atoi(e))); while (block < want) block <<= 1; }
+		job.block = block;
+	}
+	HEUR_TRY(hipEventRecord(m.ev0, m.stream));
+	const whamd_status_t st = heur_launch_pending(m, msg);
+	if (st != WHAMD_OK) return st;
+	HEUR_TRY(hipEventRecord(m.ev1, m.stream));
+	m.launched = true;
+	return WHAMD_OK;
+}
+
+whamd_status_t HeurBatch::wait(HeurResult* outs, std::string& msg) {
+	Impl& m = *impl_;
+	HEUR_TRY(hipSetDevice(m.device));
+	float ms_total = 0;
+	for (;;) {
+		hipError_t e = hipStreamSynchronize(m.stream);
+		if (e != hipSuccess) { msg = std::string("heuristic kernel failed: ") + hipGetErrorString(e); return WHAMD_ERR_DEVICE; }
+		float ms = 0;
+		(void)hipEventElapsedTime(&ms, m.ev0, m.ev1);
+		ms_total += ms;
+		bool again = false;
+		for (Impl::Job& job : m.jobs) {
+			if (job.done) continue;
+			HEUR_TRY(hipMemcpy(job.stats, job.D.stats, sizeof job.stats, hipMemcpyDeviceToHost));
+			if (job.stats[0] == 2) {   // the records outgrew the arena: four times the room, this table once more
+				pool_give(m.device, job.arena, job.arena_bytes);
+				job.arena = nullptr;
+				job.arena_words *= 4;
+				size_t free_b = 0, total_b = 0;
+				HEUR_TRY(hipMemGetInfo(&free_b, &total_b));
+				if (job.arena_words * 4 > free_b / 2) { msg = "PedMecHeuristic: the backtrace records do not fit in device memory"; return WHAMD_ERR_UNSUPPORTED; }
+				HEUR_TRY(pool_take(m.device, job.arena_words * 4, &job.arena, &job.arena_bytes));
+				job.D.arena = (uint32_t*)job.arena; job.D.arena_words = job.arena_words;
+				HEUR_TRY(hipMemsetAsync(job.D.stats, 0, 256, m.stream));
+				HEUR_TRY(hipMemsetAsync(job.D.opt_bipart, 0, std::max<size_t>(job.plan->n_reads, 1), m.stream));
+				again = true;
+				continue;
+			}
+			if (job.stats[0] == 1) { msg = "PedMecHeuristic: more tied solutions than the device pools hold (" + std::to_string(job.cap) + ")"; return WHAMD_ERR_UNSUPPORTED; }
+			job.done = true;
+		}
+		if (!again) break;
+		HEUR_TRY(hipEventRecord(m.ev0, m.stream));
+		const whamd_status_t st = heur_launch_pending(m, msg);
+		if (st != WHAMD_OK) return st;
+		HEUR_TRY(hipEventRecord(m.ev1, m.stream));
 	}
 #ifdef WHAMD_HEURISTIC_STAMPS
-	fprintf(stderr, "[whamd heuristic stamps] cycles: hash %llu, project-copy %llu, read pass 1 %llu, read pass 2 %llu, filter %llu, transmissions %llu, phasing + record %llu; hash parts: init %llu, gather %llu\n",
-	        stats[8], stats[9], stats[10], stats[11], stats[12], stats[13], stats[14], stats[15], stats[16]);
+	for (const Impl::Job& job : m.jobs)
+		fprintf(stderr, "[whamd heuristic stamps] cycles: hash %llu, project-copy %llu, read pass 1 %llu, read pass 2 %llu, filter %llu, transmissions %llu, phasing + record %llu; hash parts: init %llu, gather %llu\n",
+		        job.stats[8], job.stats[9], job.stats[10], job.stats[11], job.stats[12], job.stats[13], job.stats[14], job.stats[15], job.stats[16]);
 #endif
-	if (status == WHAMD_OK) {
-		float ms = 0;
-		(void)hipEventElapsedTime(&ms, ev0, ev1);
-		out.device_ms = ms;
-		out.max_solutions = stats[1];
-		out.total_solutions = stats[2];
-		hipError_t e = hipMemcpy(out.transmission.data(), D.opt_trans, (size_t)pl.n_cols * 4, hipMemcpyDeviceToHost);
-		if (e == hipSuccess && pl.n_reads) e = hipMemcpy(out.bipartition.data(), D.opt_bipart, pl.n_reads, hipMemcpyDeviceToHost);
-		if (e != hipSuccess) { msg = std::string("download failed: ") + hipGetErrorString(e); status = WHAMD_ERR_DEVICE; }
+	for (size_t ji = 0; ji < m.jobs.size(); ++ji) {
+		const Impl::Job& job = m.jobs[ji];
+		const HeurPlan& pl = *job.plan;
+		HeurResult& out = outs[ji];
+		out = HeurResult();
+		out.bipartition.assign(pl.n_reads, 0);
+		out.transmission.assign(pl.n_cols, 0);
+		if (pl.n_cols == 0) continue;
+		out.device_ms = ms_total;   // (the launch all tables of the batch shared)
+		out.max_solutions = job.stats[1];
+		out.total_solutions = job.stats[2];
+		HEUR_TRY(hipMemcpy(out.transmission.data(), job.D.opt_trans, (size_t)pl.n_cols * 4, hipMemcpyDeviceToHost));
+		if (pl.n_reads) HEUR_TRY(hipMemcpy(out.bipartition.data(), job.D.opt_bipart, pl.n_reads, hipMemcpyDeviceToHost));
 	}
-	(void)hipEventDestroy(ev0);
-	(void)hipEventDestroy(ev1);
-	for (void* a : allocations) (void)hipFree(a);
+	return WHAMD_OK;
+}
 #undef HEUR_TRY
-	return status;
+
+whamd_status_t heuristic_solve_device(const HeurPlan& pl, int device, HeurResult& out, std::string& msg) {
+	HeurBatch batch;
+	const HeurPlan* plans[1] = {&pl};
+	whamd_status_t st = batch.enqueue(plans, 1, device, msg);
+	if (st != WHAMD_OK) return st;
+	return batch.wait(&out, msg);
 }
 
 }  // namespace whamd
