@@ -91,6 +91,24 @@ def test_no_drift_over_thousands_of_columns(kw):
     assert np.allclose(old, want, rtol=RTOL, atol=ATOL), np.abs(old - want).max()
 
 
+@pytest.mark.parametrize("kw,window_bytes", [(dict(n_variants=5000, coverage=11, seed=5), 24 << 20), (dict(n_variants=1200, coverage=9, seed=6, trio=True), 4 << 20),
+                                             (dict(n_variants=1200, coverage=9, seed=6, trio=True), 3 << 19)], ids=str)
+def test_windowed_run_path_is_identical_to_the_unwindowed_one(kw, window_bytes, monkeypatch):
+    """Column stores larger than their budget (WHAMD_GENO_WINDOW_BYTES stands in for HBM): the runs are cut into windows, the forward
+    columns of every window but the newest are recomputed from the kept exchange column (src/genotypedptable.cpp:116-157,159-195,324 keeps
+    sqrt(n) columns for the same reason).  Same operations in the same order: the likelihoods are the SAME doubles, and they equal the
+    reference class's to rtol 1e-9."""
+    p = _synthetic_genotyping_problem(**kw)
+    whole, stats = device_likelihoods(p)
+    assert stats["slot_runs"] > 50 and stats["window"] == p.n_variants
+    monkeypatch.setenv("WHAMD_GENO_WINDOW_BYTES", str(window_bytes))
+    windowed, wstats = device_likelihoods(p)
+    assert wstats["slot_runs"] == stats["slot_runs"] and wstats["window"] < p.n_variants // 3, wstats
+    assert np.array_equal(windowed, whole), np.abs(windowed - whole).max()
+    want = reference_likelihoods(p, reference_core())
+    assert np.allclose(windowed, want, rtol=RTOL, atol=ATOL), np.abs(windowed - want).max()
+
+
 def test_many_reads_starting_and_ending_in_one_column():
     """Columns in which more reads start / end than a thread loops over: the split (atomic) accumulation path."""
     ref = reference_core()

@@ -241,6 +241,7 @@ __global__ __launch_bounds__(512) void geno_slot_run(GsDev G, GsRun run, const d
 		for (uint32_t q = 0; q < nwaves; ++q) total += red[q];
 		inv = total > 0.0 ? 1.0 / total : 1.0;
 	}
+	const bool keep = DIR == 1 || G.fstore != nullptr;   // (windowed solve, first pass of the forward chain: only the exchange columns survive)
 	double* __restrict__ store = (DIR == 0 ? G.fstore : G.bstore) + run.store_off + (size_t)w * threads + tid;
 	const size_t col_stride = (size_t)threads << run.g;
 	uint32_t xsel = 0;
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(512) void geno_slot_run(GsDev G, GsRun run, const d
 			const uint32_t n_end = gs_uni(cd.n_end), first = gs_uni(cd.first_of_table);
 			load_s(ci + 1 < ncols ? ci + 1 : ci, s_next);
 			if (!first) transition(rho_lds[ci]);
-			store[(size_t)ci * col_stride] = val;   // sum_j A_{c-1}[back(x)][j] P(j -> i): what the likelihood sums need
+			if (keep) store[(size_t)ci * col_stride] = val;   // sum_j A_{c-1}[back(x)][j] P(j -> i): what the likelihood sums need
 			val *= cell_sum(ci, s_cur);
 			for (uint32_t e = 0; e < n_end; ++e) sum_out(gs_uni(cd.end_slot[e]));
 #pragma unroll
@@ -548,20 +549,60 @@ whamd_status_t genotype_solve_slots(const Problem& p, const GenotypeModel& m, in
 	}
 	free_b += genotype_slab_idle_bytes(device);   // the column store kept from an earlier call is available to this one
 	constexpr uint32_t BATCH = 512;
-	const double need = (double)tab_words * 8 + 2.0 * (double)store_words * 8 + (double)BATCH * max_blocks * T * A * 8 + 4.0 * ((double)(1ull << max_f) * T * 8) +
-	                    (double)n * (sizeof(GsCol) + sizeof(GsRow) + sizeof(GsCombineCol) + 8.0 * T * A + 8);
-	if (max_lds > 150 * 1024 || need + (double)(2ull << 30) > 0.8 * (double)free_b) return WHAMD_OK;   // (the per-column path windows its stores)
+	const double fixed = (double)tab_words * 8 + (double)BATCH * max_blocks * T * A * 8 + 4.0 * ((double)(1ull << max_f) * T * 8) +
+	                     (double)n * (sizeof(GsCol) + sizeof(GsRow) + sizeof(GsCombineCol) + 8.0 * T * A + 8);
+	if (max_lds > 150 * 1024) return WHAMD_OK;
+	// ---- windows.  The column stores are what grows with the table (a trio at coverage 15: 2 MiB per column and chain).  When both do not fit,
+	// the runs are cut into WINDOWS (the reference keeps sqrt(n) columns and recomputes, src/genotypedptable.cpp:116-157,159-195,324): pass 1
+	// runs the whole forward chain keeping only the exchange column at every window boundary (and the columns of the newest window); then,
+	// newest window first, the forward columns of a window are recomputed from its kept exchange column, the backward chain runs through the
+	// window, and the window's likelihoods are formed.  Two sets of window stores: the recomputation of window w - 1 runs beside the backward
+	// chain and the combine of window w.  One more forward pass, any table length.
+	struct GsWindow { size_t r0, r1; unsigned long long words; uint32_t c0, c1; };
+	std::vector<GsWindow> windows;
+	{
+		const double room = 0.8 * (double)free_b - fixed - (double)(2ull << 30);
+		unsigned long long budget_words = ~0ull;   // per store
+		if (2.0 * (double)store_words * 8 > room) budget_words = room > 0 ? (unsigned long long)(room / 4.0 / 8.0) : 0ull;
+		if (const char* e = getenv("WHAMD_GENO_WINDOW_BYTES")) budget_words = std::min<unsigned long long>(budget_words, std::strtoull(e, nullptr, 10) / 8);
+		GsWindow cur{0, 0, 0, 0, 0};
+		for (size_t ri = 0; ri < n_runs; ++ri) {
+			const unsigned long long words = (unsigned long long)plan.runs[ri].ncols * ((unsigned long long)plan.runs[ri].threads << plan.runs[ri].g);
+			if (words > budget_words) return WHAMD_OK;   // a single run beyond the budget: the per-column path
+			if (cur.words + words > budget_words) {
+				cur.r1 = ri;
+				windows.push_back(cur);
+				cur = GsWindow{ri, ri, 0, 0, 0};
+			}
+			runs[ri].store_off = cur.words;   // (relative to the window's stores)
+			cur.words += words;
+		}
+		cur.r1 = n_runs;
+		windows.push_back(cur);
+		for (GsWindow& wdw : windows) {
+			wdw.c0 = plan.runs[wdw.r0].c0;
+			wdw.c1 = plan.runs[wdw.r1 - 1].c0 + plan.runs[wdw.r1 - 1].ncols;
+			for (uint32_t c = wdw.c0; c < wdw.c1; ++c) ccols[c].store_off = runs[0].store_off;   // (set per column below)
+		}
+		for (size_t ri = 0; ri < n_runs; ++ri)
+			for (uint32_t ci = 0; ci < plan.runs[ri].ncols; ++ci) ccols[plan.runs[ri].c0 + ci].store_off = runs[ri].store_off;
+	}
+	const size_t n_windows = windows.size();
+	unsigned long long window_words = 0;
+	for (const GsWindow& wdw : windows) window_words = std::max(window_words, wdw.words);
+	const size_t n_sets = n_windows > 1 ? 2 : 1;   // (fstore, bstore) pairs
 	used = true;
 	gl_out.assign((size_t)ni * n * 3, 0.0);
 	st = GenotypeStats();
 	st.n_columns = n;
 	st.transmissions = T;
-	st.window = n;
+	st.window = n_windows > 1 ? windows[0].c1 - windows[0].c0 : n;
 	for (uint32_t c = 0; c < n; ++c) { st.n_cells += 1ull << p.k[c]; st.max_coverage = std::max<uint32_t>(st.max_coverage, p.k[c]); }
 	Cleanup keep;
-	hipStream_t sf = nullptr, sb = nullptr;
+	hipStream_t sf = nullptr, sb = nullptr, sc = nullptr;
 	GS_TRY(hipStreamCreateWithFlags(&sf, hipStreamNonBlocking)); keep.streams.push_back(sf);
 	GS_TRY(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking)); keep.streams.push_back(sb);
+	GS_TRY(hipStreamCreateWithFlags(&sc, hipStreamNonBlocking)); keep.streams.push_back(sc);
 	auto alloc = [&](void** dptr, size_t bytes) -> hipError_t {
 		hipError_t e = hipMalloc(dptr, std::max<size_t>(bytes, 16));
 		if (e == hipSuccess) keep.allocations.push_back(*dptr);
@@ -587,10 +628,13 @@ whamd_status_t genotype_solve_slots(const Problem& p, const GenotypeModel& m, in
 	GS_TRY(up(&d_runs, runs.data(), runs.size() * sizeof(GsRun)));
 	GS_TRY(up(&d_ccols, ccols.data(), ccols.size() * sizeof(GsCombineCol)));
 	GS_TRY(alloc(&d_tab, (size_t)tab_words * 8));
-	d_fs = genotype_slab_acquire(device, 2 * (size_t)store_words * 8);   // both column stores in the block kept between calls
+	d_fs = genotype_slab_acquire(device, 2 * n_sets * (size_t)window_words * 8);   // the column stores in the block kept between calls
 	if (d_fs) keep.slab_device = device;
-	else GS_TRY(alloc(&d_fs, 2 * (size_t)store_words * 8));
-	d_bs = (double*)d_fs + store_words;
+	else GS_TRY(alloc(&d_fs, 2 * n_sets * (size_t)window_words * 8));
+	d_bs = (double*)d_fs + n_sets * window_words;
+	void* d_check = nullptr;   // the forward exchange column entering every window but the first
+	const size_t check_bytes = ((size_t)1 << max_f) * T * 8;
+	if (n_windows > 1) GS_TRY(alloc(&d_check, (n_windows - 1) * check_bytes));
 	GS_TRY(alloc(&d_part, (size_t)n_partials * 8));
 	GS_TRY(alloc(&d_glpart, (size_t)BATCH * max_blocks * T * A * 8));
 	GS_TRY(alloc(&d_gl, gl_out.size() * 8));
@@ -630,40 +674,123 @@ whamd_status_t genotype_solve_slots(const Problem& p, const GenotypeModel& m, in
 		const size_t waves = r.threads >> 6;
 		return ((size_t)2 * r.threads + waves * r.ncols * T * E + (size_t)r.ncols * T * A + ((r.ncols + 1) & ~1u) + 16) * 8 + (size_t)r.ncols * sizeof(GsCol);
 	};
-	// the two chains, submissions interleaved so that neither hardware queue runs dry
-	size_t rf = 0, rb = n_runs;
-	while (rf < n_runs || rb > 0) {
-		if (rf < n_runs) {
-			const GsRun& r = runs[rf];
-			hipLaunchKernelGGL(fwd, dim3(1u << r.g), dim3(r.threads), lds_of(r), sf, G, r, (const double*)d_x[rf & 1], d_x[(rf & 1) ^ 1]);
-			++rf; ++launches;
+	auto with_stores = [&](size_t set, bool forward_keeps) {
+		GsDev g = G;
+		g.fstore = forward_keeps ? (double*)d_fs + set * window_words : nullptr;
+		g.bstore = (double*)d_bs + set * window_words;
+		return g;
+	};
+	auto launch_fwd = [&](size_t ri, const GsDev& g) {
+		const GsRun& r = runs[ri];
+		hipLaunchKernelGGL(fwd, dim3(1u << r.g), dim3(r.threads), lds_of(r), sf, g, r, (const double*)d_x[ri & 1], d_x[(ri & 1) ^ 1]);
+		++launches;
+	};
+	auto launch_bwd = [&](size_t ri, const GsDev& g) {
+		const GsRun& r = runs[ri];
+		hipLaunchKernelGGL(bwd, dim3(1u << r.g), dim3(r.threads), lds_of(r), sb, g, r, (const double*)d_x[2 + (ri & 1)], d_x[2 + ((ri & 1) ^ 1)]);
+		++launches;
+	};
+	auto launch_combine = [&](const GsWindow& wdw, const GsDev& g, hipStream_t stream) {
+		for (uint32_t c0 = wdw.c0; c0 < wdw.c1; c0 += BATCH) {
+			const uint32_t ncol = std::min(BATCH, wdw.c1 - c0);
+			uint32_t gx = 1;
+			for (uint32_t c = c0; c < c0 + ncol; ++c) gx = std::max(gx, ccols[c].n_blocks);
+			if (tb == 0) hipLaunchKernelGGL((geno_slot_combine<0, 2>), dim3(gx, ncol), dim3(256), 0, stream, g, (const GsCombineCol*)d_ccols, c0, max_blocks, (double*)d_glpart);
+			else if (tb == 2) hipLaunchKernelGGL((geno_slot_combine<2, 4>), dim3(gx, ncol), dim3(256), 0, stream, g, (const GsCombineCol*)d_ccols, c0, max_blocks, (double*)d_glpart);
+			else hipLaunchKernelGGL((geno_slot_combine<4, 4>), dim3(gx, ncol), dim3(256), 0, stream, g, (const GsCombineCol*)d_ccols, c0, max_blocks, (double*)d_glpart);
+			hipLaunchKernelGGL(geno_slot_finish, dim3(ncol), dim3(256), 0, stream, g, (const double*)d_glpart, (const GsCombineCol*)d_ccols, c0, max_blocks, (double*)d_gl);
+			launches += 2;
 		}
-		if (rb > 0) {
-			--rb;
-			const GsRun& r = runs[rb];
-			hipLaunchKernelGGL(bwd, dim3(1u << r.g), dim3(r.threads), lds_of(r), sb, G, r, (const double*)d_x[2 + (rb & 1)], d_x[2 + ((rb & 1) ^ 1)]);
-			++launches;
+	};
+	if (n_windows == 1) {
+		// the two chains, submissions interleaved so that neither hardware queue runs dry.  (WHAMD_GENO_PIECES = k forms the likelihood sums of
+		// a k-th of the table on a third stream as soon as both chains have passed it, beside the rest of the chains.  Measured: no gain --
+		// the combine streams the stores at 3 TB/s and the chains slow down by what it saves: trio of 20 000 columns, chains 37 -> 54 ms,
+		// combine 24 -> 6 ms.  One piece after the chains is the default.)
+		const GsDev g = with_stores(0, true);
+		size_t n_pieces = 1;
+		if (const char* e = getenv("WHAMD_GENO_PIECES")) n_pieces = std::max<size_t>(1, std::min<size_t>((size_t)atoi(e), std::max<size_t>(1, n_runs / 64)));
+		auto piece_lo = [&](size_t k) { return n_runs * k / n_pieces; };
+		std::vector<hipEvent_t> pf(n_pieces), pb(n_pieces);
+		for (size_t k = 0; k < n_pieces; ++k)
+			for (hipEvent_t* e : {&pf[k], &pb[k]}) { GS_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming)); keep.events.push_back(*e); }
+		size_t rf = 0, rb = n_runs, kf = 0, kb = n_pieces;
+		while (rf < n_runs || rb > 0) {
+			if (rf < n_runs) {
+				launch_fwd(rf++, g);
+				if (rf == piece_lo(kf + 1)) { GS_TRY(hipEventRecord(pf[kf], sf)); ++kf; }
+			}
+			if (rb > 0) {
+				launch_bwd(--rb, g);
+				if (rb == piece_lo(kb - 1)) { --kb; GS_TRY(hipEventRecord(pb[kb], sb)); }
+			}
 		}
-	}
-	GS_TRY(hipGetLastError());
-	GS_TRY(hipEventRecord(ev[2], sb));
-	GS_TRY(hipStreamWaitEvent(sf, ev[2], 0));
-	GS_TRY(hipEventRecord(ev[2], sf));
-	for (uint32_t c0 = 0; c0 < n; c0 += BATCH) {
-		const uint32_t ncol = std::min(BATCH, n - c0);
-		uint32_t gx = 1;
-		for (uint32_t c = c0; c < c0 + ncol; ++c) gx = std::max(gx, ccols[c].n_blocks);
-		if (tb == 0) hipLaunchKernelGGL((geno_slot_combine<0, 2>), dim3(gx, ncol), dim3(256), 0, sf, G, (const GsCombineCol*)d_ccols, c0, max_blocks, (double*)d_glpart);
-		else if (tb == 2) hipLaunchKernelGGL((geno_slot_combine<2, 4>), dim3(gx, ncol), dim3(256), 0, sf, G, (const GsCombineCol*)d_ccols, c0, max_blocks, (double*)d_glpart);
-		else hipLaunchKernelGGL((geno_slot_combine<4, 4>), dim3(gx, ncol), dim3(256), 0, sf, G, (const GsCombineCol*)d_ccols, c0, max_blocks, (double*)d_glpart);
-		hipLaunchKernelGGL(geno_slot_finish, dim3(ncol), dim3(256), 0, sf, G, (const double*)d_glpart, (const GsCombineCol*)d_ccols, c0, max_blocks, (double*)d_gl);
-		launches += 2;
+		GS_TRY(hipGetLastError());
+		GS_TRY(hipEventRecord(ev[2], sb));
+		GS_TRY(hipStreamWaitEvent(sf, ev[2], 0));
+		GS_TRY(hipEventRecord(ev[2], sf));
+		// pieces in the order both chains have passed them: from the middle outwards
+		std::vector<size_t> order;
+		for (size_t d = 0; order.size() < n_pieces; ++d) {
+			const size_t mid = n_pieces / 2;
+			if (d == 0) { order.push_back(mid); continue; }
+			if (mid >= d) order.push_back(mid - d);
+			if (mid + d < n_pieces) order.push_back(mid + d);
+		}
+		for (size_t k : order) {
+			GS_TRY(hipStreamWaitEvent(sc, pf[k], 0));
+			GS_TRY(hipStreamWaitEvent(sc, pb[k], 0));
+			const size_t r0 = piece_lo(k), r1 = piece_lo(k + 1);
+			GsWindow piece{r0, r1, 0, plan.runs[r0].c0, plan.runs[r1 - 1].c0 + plan.runs[r1 - 1].ncols};
+			launch_combine(piece, g, sc);
+		}
+		hipEvent_t done = nullptr;
+		GS_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming)); keep.events.push_back(done);
+		GS_TRY(hipEventRecord(done, sc));
+		GS_TRY(hipStreamWaitEvent(sf, done, 0));
+	} else {
+		// pass 1: the whole forward chain; only the newest window keeps its columns; the exchange column entering every window is kept
+		const size_t last = n_windows - 1;
+		std::vector<hipEvent_t> ef(n_windows), eb(n_windows), ec(n_windows);
+		for (size_t w = 0; w < n_windows; ++w)
+			for (hipEvent_t* e : {&ef[w], &eb[w], &ec[w]}) { GS_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming)); keep.events.push_back(*e); }
+		for (size_t w = 0; w < n_windows; ++w) {
+			const GsWindow& wdw = windows[w];
+			if (w > 0) GS_TRY(hipMemcpyAsync((char*)d_check + (w - 1) * check_bytes, d_x[wdw.r0 & 1], check_bytes, hipMemcpyDeviceToDevice, sf));
+			const GsDev g = with_stores(w % 2, w == last);
+			for (size_t ri = wdw.r0; ri < wdw.r1; ++ri) launch_fwd(ri, g);
+		}
+		GS_TRY(hipGetLastError());
+		GS_TRY(hipEventRecord(ef[last], sf));
+		// newest window first: (recompute the forward columns,) backward chain, likelihoods -- forward of window w - 1 beside backward / combine of w
+		for (size_t w = n_windows; w-- > 0;) {
+			const GsWindow& wdw = windows[w];
+			const GsDev g = with_stores(w % 2, true);
+			if (w != last) {
+				if (w + 2 < n_windows) GS_TRY(hipStreamWaitEvent(sf, ec[w + 2], 0));   // the stores of this set are free again
+				if (w > 0) GS_TRY(hipMemcpyAsync(d_x[wdw.r0 & 1], (char*)d_check + (w - 1) * check_bytes, check_bytes, hipMemcpyDeviceToDevice, sf));
+				for (size_t ri = wdw.r0; ri < wdw.r1; ++ri) launch_fwd(ri, g);
+				GS_TRY(hipEventRecord(ef[w], sf));
+			}
+			GS_TRY(hipStreamWaitEvent(sb, ef[w], 0));
+			if (w + 2 < n_windows) GS_TRY(hipStreamWaitEvent(sb, ec[w + 2], 0));
+			for (size_t ri = wdw.r1; ri-- > wdw.r0;) launch_bwd(ri, g);
+			GS_TRY(hipEventRecord(eb[w], sb));
+			GS_TRY(hipStreamWaitEvent(sc, eb[w], 0));
+			launch_combine(wdw, g, sc);
+			GS_TRY(hipEventRecord(ec[w], sc));
+			GS_TRY(hipGetLastError());
+		}
+		GS_TRY(hipEventRecord(ev[2], sb));
+		GS_TRY(hipStreamWaitEvent(sf, ec[0], 0));
+		GS_TRY(hipStreamWaitEvent(sf, ec[n_windows > 1 ? 1 : 0], 0));
 	}
 	GS_TRY(hipGetLastError());
 	GS_TRY(hipEventRecord(ev[3], sf));
 	GS_TRY(hipMemcpyAsync(gl_out.data(), d_gl, gl_out.size() * 8, hipMemcpyDeviceToHost, sf));
 	GS_TRY(hipStreamSynchronize(sf));
 	GS_TRY(hipStreamSynchronize(sb));
+	GS_TRY(hipStreamSynchronize(sc));
 #ifdef WHAMD_GENO_STAMPS
 	{
 		unsigned long long d[16];
@@ -685,8 +812,8 @@ whamd_status_t genotype_solve_slots(const Problem& p, const GenotypeModel& m, in
 	st.launches = launches;
 	st.slot_runs = (uint32_t)n_runs;
 	if (getenv("WHAMD_DEBUG_TIMING"))
-		fprintf(stderr, "[whamd timing] genotype slot runs: %zu runs (%.1f columns per run), tables %.2f ms, chains %.2f ms, combine %.2f ms; tables %.1f MB, stores 2 x %.1f MB\n",
-		        n_runs, (double)n / n_runs, t_tab, t_chain, t_all - t_chain - t_tab, tab_words * 8e-6, store_words * 8e-6);
+		fprintf(stderr, "[whamd timing] genotype slot runs: %zu runs (%.1f columns per run), %zu window(s), tables %.2f ms, chains %.2f ms, combine %.2f ms; tables %.1f MB, stores %zu x %.1f MB\n",
+		        n_runs, (double)n / n_runs, n_windows, t_tab, t_chain, t_all - t_chain - t_tab, tab_words * 8e-6, 2 * n_sets, window_words * 8e-6);
 #undef GS_TRY
 	return WHAMD_OK;
 }
