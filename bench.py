@@ -57,6 +57,7 @@ WORKLOADS = {
     "blocks3": dict(variants=100000, coverage=20, blocks=3, in_flight=3),          # three configs[4] blocks in flight on one GPU
     "blocks24": dict(variants=100000, coverage=20, blocks=24, in_flight=24),       # BASELINE configs[4] on ONE GPU: all 24 blocks as one group of launches
     "config1_x24": dict(variants=50000, coverage=15, blocks=24, in_flight=24),     # 24 tables at `whatshap phase`'s default coverage (24 chromosomes) on one GPU
+    "config3_distrust": dict(trio=True, distrust=True, variants=100000, coverage=15),   # configs[3]'s ReadSet, genotypes not trusted (16 allele assignments per value)
     "config3_x8": dict(trio=True, variants=100000, coverage=15, blocks=8, in_flight=8),  # eight trio tables (families / chromosomes) on one GPU
     "irregular": dict(irregular=True, variants=100000, coverage=20),               # Poisson starts, geometric lengths (mean 16), coverage capped
     "quartet": dict(quartet=True, variants=50000, coverage=13),                    # two trios sharing parents, T = 16
@@ -65,7 +66,7 @@ WORKLOADS = {
     "heuristic": dict(heuristic=True, variants=8000, coverage=30),                 # PedMecHeuristic, coverage beyond the exact DP
     "heuristic_x32": dict(heuristic=True, variants=8000, coverage=30, blocks=32),  # 32 PedMecHeuristic tables in ONE launch (one persistent workgroup each)
 }
-EXTRA_CONFIGS = ["config1", "config1_x24", "config3", "config3_x8", "blocks3", "blocks24", "irregular", "quartet", "genotype", "genotype_trio", "heuristic", "heuristic_x32"]
+EXTRA_CONFIGS = ["config1", "config1_x24", "config3", "config3_distrust", "config3_x8", "blocks3", "blocks24", "irregular", "quartet", "genotype", "genotype_trio", "heuristic", "heuristic_x32"]
 
 
 def parse_args():
@@ -80,6 +81,7 @@ def parse_args():
     ap.add_argument("--in-flight", type=int, default=4, help="blocks a rank keeps in flight at once")
     ap.add_argument("--trio", action="store_true", help="configs[3]-shaped workload (trio PedMEC, coverage 15) instead")
     ap.add_argument("--quartet", action="store_true", help="two trios sharing their parents (T = 16), coverage 13")
+    ap.add_argument("--distrust", action="store_true", help="distrust_genotypes=True: every allele assignment of an individual is allowed, priced by its genotype likelihood")
     ap.add_argument("--irregular", action="store_true", help="irregular read layout (whatshap_amd.synthetic.irregular_block, seed 7)")
     ap.add_argument("--genotype", action="store_true", help="the genotyping row: GenotypeDPTable (forward-backward, f64) instead of the phasing table")
     ap.add_argument("--heuristic", action="store_true", help="the PedMecHeuristic row: beam search at a coverage the exact DP cannot afford (row limit 256)")
@@ -139,12 +141,12 @@ def build_block(args, seed, n_variants, n_columns_limit=None):
     if args.irregular:
         p = irregular_block(n_variants, args.coverage, seed=seed)
         return p if n_columns_limit is None else clip_to_columns(p, n_columns_limit)
-    return synthetic_block(n_variants, args.coverage, seed=seed, trio=args.trio, quartet=args.quartet, n_columns_limit=n_columns_limit)
+    return synthetic_block(n_variants, args.coverage, seed=seed, trio=args.trio, quartet=args.quartet, distrust_genotypes=args.distrust, n_columns_limit=n_columns_limit)
 
 
 def workload_flags(args):
     out = []
-    for flag in ("trio", "quartet", "irregular", "genotype", "heuristic"):
+    for flag in ("trio", "quartet", "distrust", "irregular", "genotype", "heuristic"):
         if getattr(args, flag):
             out.append("--" + flag)
     return out
@@ -224,7 +226,7 @@ def cpu_baseline(args, seed):
         "unit": "variant-columns/s",
         "cores": 1,
         "kind": kind,
-        "sample": f"columns {ca}..{cc} of the same seeded ReadSet (coverage {args.coverage}{', trio' if args.trio else ''}{', quartet' if args.quartet else ''}{', irregular layout' if args.irregular else ''}; all at full "
+        "sample": f"columns {ca}..{cc} of the same seeded ReadSet (coverage {args.coverage}{', trio' if args.trio else ''}{', genotypes not trusted' if args.distrust else ''}{', quartet' if args.quartet else ''}{', irregular layout' if args.irregular else ''}; all at full "
                   f"coverage: the {ramp}-column ramp is timed separately and subtracted), constructor + 3 getters, {steady_s:.1f} s of "
                   f"{tc:.1f} s wall, optimal cost of the prefix {score}",
         "seconds": tc + ta,
@@ -670,7 +672,7 @@ def main():
         return cpu_sample_worker(args)
     if args.heuristic_cpu_worker:
         return heuristic_cpu_worker(args)
-    explicit = any(a in sys.argv[1:] for a in ("--workload", "--trio", "--quartet", "--irregular", "--genotype", "--heuristic", "--variants", "--coverage", "--blocks", "--blocks-per-gpu", "--path", "--option"))
+    explicit = any(a in sys.argv[1:] for a in ("--workload", "--trio", "--quartet", "--distrust", "--irregular", "--genotype", "--heuristic", "--variants", "--coverage", "--blocks", "--blocks-per-gpu", "--path", "--option"))
     if args.workload:
         for key, value in WORKLOADS[args.workload].items():
             setattr(args, key, value)
@@ -800,7 +802,7 @@ def main():
         bytes_per_launch = bytes_rank / max(launches / args.steps, 1)
         column_path = args.path in ("column", "column_keys")
         kernel = dominant_kernel(args, grouped)
-        kind = "synthetic trio PedMEC" if args.trio else ("synthetic quartet PedMEC (two trios sharing parents)" if args.quartet else "synthetic diploid single-individual")
+        kind = ("synthetic trio PedMEC, genotypes not trusted" if args.distrust else "synthetic trio PedMEC") if args.trio else ("synthetic quartet PedMEC (two trios sharing parents)" if args.quartet else "synthetic diploid single-individual")
         out = {
             "metric": "variant-columns/sec at max-coverage %d (bipartition-costs/sec reported alongside)" % args.coverage,
             "value": cols_job * args.steps / elapsed,

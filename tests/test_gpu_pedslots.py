@@ -95,12 +95,23 @@ def test_windowed_quartet_equals_the_unrestricted_solve():
         assert st["forward_launches"] > st0["forward_launches"], "the arena limit did not force a windowed solve"
 
 
-def test_untrusted_genotypes_fall_back_to_the_older_runs():
-    """9 cost forms per transmission value do not fit the form tables: the planner declines, the LDS-resident trio runs take over."""
-    p = synthetic_block(n_variants=400, coverage=9, seed=88, trio=True, distrust_genotypes=True)
+@pytest.mark.parametrize("kw", [dict(n_variants=400, coverage=9, seed=88, trio=True, distrust_genotypes=True),
+                                dict(n_variants=700, coverage=12, seed=89, trio=True, distrust_genotypes=True, mixed_genotypes=True),
+                                # full width: BASELINE configs[3]'s ReadSet with the genotypes not trusted, >= 25 launches of 256 workgroups
+                                dict(n_variants=100000, coverage=15, seed=4, trio=True, distrust_genotypes=True, n_columns_limit=430)], ids=str)
+def test_untrusted_genotypes_on_pedigree_runs_vs_oracle(kw):
+    """Up to 15 cost forms per transmission value (src/pedigreecolumncostcomputer.cpp:14-50,101-114): pedslot_run<2, 16> == oracle ==
+    the LDS-resident trio runs it replaces in the default dispatch == the per-column kernels."""
+    p = synthetic_block(**kw)
     want = table_solution(oracle.OracleTable(p))
-    got, _ = solve(p)
+    got, stats = solve(p)
     assert got == want, first_difference(want, got)
+    assert stats["forward_launches"] <= p.n_variants // 6, "the table did not run on pedigree slot runs"
+    old, _ = solve(p, "resident")
+    assert old == want, first_difference(want, old)
+    if p.n_variants <= 700:
+        col, _ = solve(p, "column")
+        assert col == want, first_difference(want, col)
 
 
 def test_full_size_trio_old_and_new_runs_agree():

@@ -72,15 +72,23 @@ def test_two_unrelated_trios_need_four_forms_per_value(seed):
         assert run_columns > 0.6 * p.n_variants, (kw, run_columns)
 
 
-def test_not_for_a_single_individual_or_untrusted_genotypes():
+def test_not_for_a_single_individual():
     single = synthetic_block(n_variants=40, coverage=6, seed=1)
     with pytest.raises(_native.SolverError) as e:
         _native.emulate_pedslot_plan(single, 40)
     assert e.value.status == _native.WHAMD_ERR_UNSUPPORTED
-    distrust = synthetic_block(n_variants=40, coverage=6, seed=1, trio=True, distrust_genotypes=True)
-    with pytest.raises(_native.SolverError) as e:
-        _native.emulate_pedslot_plan(distrust, 40)
-    assert e.value.status == _native.WHAMD_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("kw", [dict(n_variants=60, coverage=6, seed=1, trio=True, distrust_genotypes=True),
+                                dict(n_variants=300, coverage=8, seed=2, trio=True, distrust_genotypes=True),
+                                dict(n_variants=200, coverage=9, seed=3, trio=True, distrust_genotypes=True, mixed_genotypes=True)], ids=str)
+def test_untrusted_genotypes_of_a_trio_on_sixteen_forms(kw):
+    """Genotypes not trusted: up to 15 distinct cost forms per transmission value (16 allele assignments, src/pedigreecolumncostcomputer.cpp:14-50)
+    -- runs with NF = 16: plan, tables, records and walk emulated on the CPU equal the oracle."""
+    p = synthetic_block(**kw)
+    ok, run_columns = agrees(p)
+    assert ok, kw
+    assert run_columns > 0.8 * p.n_variants, (kw, run_columns)
 
 
 def _trio_reads_problem(reads, n_variants, seed):

@@ -431,7 +431,7 @@ whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uin
 			if (sp.ped) {
 				const PedSlotExtra& ex = sp.pextra[step.index];
 				ok = ok && sp.pextra.size() == sp.runs.size() && run.lr == 0 && !run.half && (1u << ex.tb) == p.T && run.L == 6u - ex.tb + run.lw;
-				ok = ok && (ex.nf == 2 || ex.nf == 4) && ex.fwn == run.ncols * p.T * ex.nf && ex.fwn <= (uint32_t)PSLOT_FORMWORDS && ex.rec_words == ((run.ncols + 3) / 4) * run.threads;
+				ok = ok && (ex.nf == 2 || ex.nf == 4 || (ex.nf == 16 && ex.tb == 2)) && ex.fwn == run.ncols * p.T * ex.nf && ex.fwn <= (uint32_t)PSLOT_FORMWORDS && ex.rec_words == ((run.ncols + 3) / 4) * run.threads;
 				ok = ok && run.lw <= (uint32_t)SLOT_LWMAX && run.threads == (64u << run.lw);
 			} else
 			ok = ok && run.lr >= 1 && run.lr <= (uint32_t)SLOT_LR && run.L == run.lr + (uint32_t)SLOT_LANE + run.lw && run.lw <= (uint32_t)SLOT_LWMAX && run.threads == (64u << run.lw);

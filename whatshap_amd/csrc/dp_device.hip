@@ -1157,6 +1157,9 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, 2, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, 4, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, 4, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, 16, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, 16, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_group<2, 16>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_group<2, 2>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_group<2, 4>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_group<4, 2>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1236,7 +1239,8 @@ void DeviceTable::Impl::launch_slot_run(const SlotBatchEntry& e, uint64_t& launc
 		const size_t lds_ped = ((size_t)2 * run.threads + (PSLOT_MAXCOLS + 4) * 8 + (size_t)(run.threads >> 6) * (ex.arow + 4u * T * ex.nf) + (size_t)(run.ncols + 4) * 64 * ex.nf) * 4;
 		const dim3 grid(1u << run.g), block(run.threads);
 #define WHAMD_PSLOT_LAUNCH(TBV, NFV, SPECV) hipLaunchKernelGGL((pedslot_run<TBV, NFV, SPECV>), grid, block, lds_ped, m.run_stream, m.dp, run, ex, e.prev, e.cur)
-		if (ex.tb == 2 && ex.nf == 2) { if (spec) WHAMD_PSLOT_LAUNCH(2, 2, true); else WHAMD_PSLOT_LAUNCH(2, 2, false); }
+		if (ex.tb == 2 && ex.nf == 16) { if (spec) WHAMD_PSLOT_LAUNCH(2, 16, true); else WHAMD_PSLOT_LAUNCH(2, 16, false); }
+		else if (ex.tb == 2 && ex.nf == 2) { if (spec) WHAMD_PSLOT_LAUNCH(2, 2, true); else WHAMD_PSLOT_LAUNCH(2, 2, false); }
 		else if (ex.tb == 2) { if (spec) WHAMD_PSLOT_LAUNCH(2, 4, true); else WHAMD_PSLOT_LAUNCH(2, 4, false); }
 		else if (ex.nf == 2) { if (spec) WHAMD_PSLOT_LAUNCH(4, 2, true); else WHAMD_PSLOT_LAUNCH(4, 2, false); }
 		else { if (spec) WHAMD_PSLOT_LAUNCH(4, 4, true); else WHAMD_PSLOT_LAUNCH(4, 4, false); }
@@ -1442,11 +1446,12 @@ whamd_status_t DeviceTable::enqueue_group(DeviceTable* const* tables, const Prob
 	struct Part {
 		std::vector<size_t> members;   // positions in `tables`
 		Impl* lead = nullptr;
-		std::vector<Batch> batches;    // per kernel variant: 0 single individual (four cells per thread); 1 .. 4 pedigree runs (TB, NF) = (2,2) (2,4) (4,2) (4,4)
+		std::vector<Batch> batches;    // per kernel variant: 0 single individual (four cells per thread); 1 .. 5 pedigree runs (TB, NF) = (2,2) (2,4) (4,2) (4,4) (2,16)
 	};
 	std::vector<Part> parts(n_parts);
 	for (size_t i = 0; i < n_tables; ++i) parts[i % n_parts].members.push_back(i);
-	for (Part& part : parts) { part.lead = tables[part.members[0]]->impl_; part.batches.resize(5); }
+	constexpr int NV = 6;   // kernel variants
+	for (Part& part : parts) { part.lead = tables[part.members[0]]->impl_; part.batches.resize(NV); }
 	auto abort_all = [&]() {
 		for (Part& part : parts) (void)hipStreamSynchronize(part.lead->stream);
 		(void)hipGetLastError();
@@ -1483,40 +1488,41 @@ whamd_status_t DeviceTable::enqueue_group(DeviceTable* const* tables, const Prob
 			case 1: hipLaunchKernelGGL((pedslot_group<2, 2>), grid, block, b.lds, stream, b.args); break;
 			case 2: hipLaunchKernelGGL((pedslot_group<2, 4>), grid, block, b.lds, stream, b.args); break;
 			case 3: hipLaunchKernelGGL((pedslot_group<4, 2>), grid, block, b.lds, stream, b.args); break;
-			default: hipLaunchKernelGGL((pedslot_group<4, 4>), grid, block, b.lds, stream, b.args); break;
+			case 4: hipLaunchKernelGGL((pedslot_group<4, 4>), grid, block, b.lds, stream, b.args); break;
+			default: hipLaunchKernelGGL((pedslot_group<2, 16>), grid, block, b.lds, stream, b.args); break;
 		}
 		b.args.n = 0;
 		b.grid_x = b.threads = 0;
 		b.lds = 0;
 	};
 	std::vector<uint64_t> table_launches(n_tables, 0);
-	std::vector<uint8_t> counted(n_tables * 5, 0);
+	std::vector<uint8_t> counted(n_tables * NV, 0);
 	const auto t_submit0 = std::chrono::steady_clock::now();
 	for (size_t k = 0; k < max_steps; ++k) {
 		for (Part& part : parts) {
-			for (size_t i : part.members) std::fill(counted.begin() + i * 5, counted.begin() + i * 5 + 5, 0);
+			for (size_t i : part.members) std::fill(counted.begin() + i * NV, counted.begin() + i * NV + NV, 0);
 			for (size_t i : part.members) {
 				Impl& m = *tables[i]->impl_;
 				if (k >= m.schedule.size()) continue;
 				const Impl::SuperStep& ss = m.schedule[k];
 				for (uint32_t q = 0; q < ss.entry_count; ++q) {
 					const SlotBatchEntry& he = m.slot_entries[ss.entry_off + q];
-					const int variant = m.splan.ped ? 1 + (he.ex.tb == 4 ? 2 : 0) + (he.ex.nf == 4 ? 1 : 0) : 0;
+					const int variant = m.splan.ped ? (he.ex.nf == 16 ? 5 : 1 + (he.ex.tb == 4 ? 2 : 0) + (he.ex.nf == 4 ? 1 : 0)) : 0;
 					Batch& b = part.batches[variant];
 					if (b.args.n == (uint32_t)SLOT_GROUP_MAX) {
 						flush(part, variant);
-						for (size_t j : part.members) if (counted[j * 5 + variant]) { table_launches[j] += 1; counted[j * 5 + variant] = 0; }
+						for (size_t j : part.members) if (counted[j * NV + variant]) { table_launches[j] += 1; counted[j * NV + variant] = 0; }
 					}
 					b.args.entry[b.args.n++] = m.d_slot_entries + ss.entry_off + q;
 					b.grid_x = std::max(b.grid_x, 1u << (he.run.g - he.run.half));
 					b.threads = std::max(b.threads, he.run.threads);
 					b.lds = std::max(b.lds, ss.lds);
-					counted[i * 5 + variant] = 1;
+					counted[i * NV + variant] = 1;
 				}
 			}
-			for (int v = 0; v < 5; ++v) {
+			for (int v = 0; v < NV; ++v) {
 				flush(part, v);
-				for (size_t j : part.members) if (counted[j * 5 + v]) table_launches[j] += 1;
+				for (size_t j : part.members) if (counted[j * NV + v]) table_launches[j] += 1;
 			}
 			for (size_t i : part.members) {
 				Impl& m = *tables[i]->impl_;

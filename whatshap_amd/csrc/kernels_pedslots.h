@@ -169,9 +169,12 @@ __device__ __forceinline__ void pedslot_run_body(const DevProblem& P, const Slot
 			const uint2 av = *reinterpret_cast<const uint2*>(ap), sv = *reinterpret_cast<const uint2*>(spn);
 			ln.a[0] = av.x; ln.a[1] = av.y; ln.s[0] = sv.x; ln.s[1] = sv.y;
 		} else {
-			const uint4 av = *reinterpret_cast<const uint4*>(ap), sv = *reinterpret_cast<const uint4*>(spn);
-			ln.a[0] = av.x; ln.a[1] = av.y; ln.a[NF > 2 ? 2 : 0] = av.z; ln.a[NF > 2 ? 3 : 0] = av.w;
-			ln.s[0] = sv.x; ln.s[1] = sv.y; ln.s[NF > 2 ? 2 : 0] = sv.z; ln.s[NF > 2 ? 3 : 0] = sv.w;
+#pragma unroll
+			for (int q = 0; q < NF / 4; ++q) {   // NF = 4: one 16-byte read each; NF = 16: four
+				const uint4 av = reinterpret_cast<const uint4*>(ap)[q], sv = reinterpret_cast<const uint4*>(spn)[q];
+				ln.a[4 * q] = av.x; ln.a[4 * q + 1] = av.y; ln.a[NF > 2 ? 4 * q + 2 : 0] = av.z; ln.a[NF > 2 ? 4 * q + 3 : 0] = av.w;
+				ln.s[4 * q] = sv.x; ln.s[4 * q + 1] = sv.y; ln.s[NF > 2 ? 4 * q + 2 : 0] = sv.z; ln.s[NF > 2 ? 4 * q + 3 : 0] = sv.w;
+			}
 		}
 		return ln;
 	};
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(512) void pedslot_run(DevProblem P, SlotRun run, Pe
 
 // One launch = the next run of SEVERAL pedigree tables (see slot_group, kernels_slots.h): blockIdx.y selects the table's entry.
 template <int TB, int NF>
-__global__ __launch_bounds__(512, NF == 2 ? 8 : 4) void pedslot_group(SlotGroupArgs args) {   // (NF = 2: four workgroups per CU -- at most 80 SGPRs, 64 VGPRs)
+__global__ __launch_bounds__(512, NF == 2 ? 8 : (NF == 4 ? 4 : 2)) void pedslot_group(SlotGroupArgs args) {   // (NF = 2: four workgroups per CU -- at most 80 SGPRs, 64 VGPRs)
 	const SlotBatchEntry e = slot_scalar_copy(args.entry[blockIdx.y]);
 	const SlotRun& run = e.run;
 	if (blockIdx.x >= (1u << run.g) || threadIdx.x >= run.threads) return;

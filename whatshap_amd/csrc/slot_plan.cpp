@@ -189,8 +189,11 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 				// at most PSLOT_MAXFORMS forms per transmission value; the run's tables grow with the widest column (NF 2 -> 4)
 				uint32_t most = 0;
 				for (uint32_t t = 0; t < p.T; ++t) most = std::max<uint32_t>(most, (uint32_t)(p.term_end(c1, t) - p.term_begin(c1, t)));
-				if (most > (uint32_t)PSLOT_MAXFORMS) break;
-				const uint32_t nf = std::max(run_forms, most > 2 ? 4u : 2u);
+				if (most > (uint32_t)PSLOT_MAXFORMS || (most > 4u && TB != 2u)) {   // (sixteen forms: the trio kernel only)
+					if (getenv("WHAMD_DEBUG_PLAN")) fprintf(stderr, "[plan] column %u: %u cost forms per transmission value: no pedigree run\n", c1, most);
+					break;
+				}
+				const uint32_t nf = std::max(run_forms, most > 4 ? 16u : (most > 2 ? 4u : 2u));
 				if ((c1 - c + 1) * p.T * nf > (uint32_t)PSLOT_FORMWORDS) break;
 				run_forms = nf;
 			}
@@ -353,7 +356,10 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 			ex.tb = TB;
 			ex.nf = 2;   // (recomputed: run_forms may have grown for a column that was dropped again)
 			for (uint32_t i = 0; i < d.ncols && !genotype_mode; ++i)
-				for (uint32_t t = 0; t < p.T; ++t) if (p.term_end(c + i, t) - p.term_begin(c + i, t) > 2) ex.nf = 4;
+				for (uint32_t t = 0; t < p.T; ++t) {
+					const uint32_t cnt = (uint32_t)(p.term_end(c + i, t) - p.term_begin(c + i, t));
+					ex.nf = std::max(ex.nf, cnt > 4 ? 16u : (cnt > 2 ? 4u : 2u));
+				}
 			ex.fwn = d.ncols * p.T * ex.nf;
 			ex.arow = (ex.fwn + 3u) & ~3u;
 			ex.rec_words = ((d.ncols + 3u) / 4u) * (64u << d.lw);

@@ -123,7 +123,8 @@ static_assert(sizeof(SlotRun) == 192, "SlotRun layout");
 // (pedslot_tables, full-chip width): G[workgroup] (constant + grid slots), W[wave], S[lane]; a run's prologue is then
 // pure copies (A = G + W per wave into LDS) and a column costs two small LDS reads, NF adds and NF - 1 minima per lane.
 constexpr int PSLOT_MAXCOLS = 32;      // columns per run
-constexpr int PSLOT_MAXFORMS = 4;      // forms per transmission value a run can hold (NF = 2 or 4)
+constexpr int PSLOT_MAXFORMS = 16;     // forms per transmission value a run can hold: NF = 2, 4, or 16 (a trio with untrusted genotypes:
+                                       // 16 allele assignments, up to 15 distinct forms per value once the genotype likelihoods differ)
 constexpr int PSLOT_FORMWORDS = 1024;  // ncols * T * NF of one run (one row per wave in LDS)
 struct PedSlotRow {
 	// ---- hot: copied to LDS by the run kernel (8 words)
