@@ -26,6 +26,7 @@
 #include <string>
 #include <vector>
 
+#include "device_pool.h"
 #include "device_table.h"
 #include "genotype.h"
 
@@ -77,95 +78,240 @@ bool select_kernels(uint32_t T, uint32_t n_ind, FusedFn& ff, KeysFn& kf) {
 // descriptors of a configs[2] table, 20 ms of a 58 ms create.  The create path copies its large arrays into ONE process-wide pinned
 // area with a few host threads and sends them from there (the copies overlap the host work that follows).  One upload() at a
 // time owns the area; it grows to what the largest table so far needed (at most STAGE_MAX; larger uploads go in rounds).
+// ---------------------------------------------------------------------------------------------- device_pool.h
+struct DevPool {
+	std::mutex mu;
+	struct Block { void* ptr; size_t bytes; int device; };
+	std::vector<Block> idle;
+	size_t idle_bytes = 0;
+};
+DevPool g_pool;
+constexpr size_t POOL_KEEP = (size_t)24 << 30;   // most bytes kept idle
+size_t pool_class(size_t bytes) {
+	bytes = std::max<size_t>(bytes, 256);
+	size_t p = 256;
+	while (p < bytes) p <<= 1;
+	const size_t step = std::max<size_t>(p / 8, 256);
+	return (bytes + step - 1) / step * step;
+}
+
+// A table's stream and events, and its pinned download buffer, come from pools as well: creating and destroying them per table (a stream,
+// five events, hipHostMalloc / hipHostFree of the path buffer) was as expensive as the whole create of a coverage-15 table
+// (24 tables: create 103 ms on 8 threads, close 110 ms).
+struct StreamSet { hipStream_t stream = nullptr; hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; int device = -1; };
+struct HostBlock { void* ptr; size_t bytes; };
+struct MiscPool {
+	std::mutex mu;
+	std::vector<StreamSet> streams;
+	std::vector<HostBlock> pinned;
+	size_t pinned_bytes = 0;
+};
+MiscPool g_misc;
+bool streamset_take(int device, StreamSet& out) {
+	{
+		std::lock_guard<std::mutex> lock(g_misc.mu);
+		for (size_t i = 0; i < g_misc.streams.size(); ++i) {
+			if (g_misc.streams[i].device != device) continue;
+			out = g_misc.streams[i];
+			g_misc.streams[i] = g_misc.streams.back();
+			g_misc.streams.pop_back();
+			return true;
+		}
+	}
+	out = StreamSet();
+	out.device = device;
+	if (hipStreamCreateWithFlags(&out.stream, hipStreamNonBlocking) != hipSuccess) return false;
+	for (int k = 0; k < 5; ++k)
+		if ((k < 4 ? hipEventCreate(&out.ev[k]) : hipEventCreateWithFlags(&out.ev[k], hipEventDisableTiming)) != hipSuccess) return false;
+	return true;
+}
+void streamset_give(const StreamSet& ss) {   // (the stream is idle: the caller synchronised it)
+	if (!ss.stream) return;
+	std::lock_guard<std::mutex> lock(g_misc.mu);
+	if (g_misc.streams.size() < 256) { g_misc.streams.push_back(ss); return; }
+	for (hipEvent_t e : ss.ev) if (e) (void)hipEventDestroy(e);
+	(void)hipStreamDestroy(ss.stream);
+}
+hipError_t pinned_take(size_t bytes, void** out, size_t* got) {
+	const size_t want = pool_class(bytes);
+	*got = want;
+	{
+		std::lock_guard<std::mutex> lock(g_misc.mu);
+		for (size_t i = 0; i < g_misc.pinned.size(); ++i) {
+			if (g_misc.pinned[i].bytes != want) continue;
+			*out = g_misc.pinned[i].ptr;
+			g_misc.pinned_bytes -= want;
+			g_misc.pinned[i] = g_misc.pinned.back();
+			g_misc.pinned.pop_back();
+			return hipSuccess;
+		}
+	}
+	return hipHostMalloc(out, want, hipHostMallocPortable);
+}
+void pinned_give(void* ptr, size_t bytes) {
+	if (!ptr) return;
+	{
+		std::lock_guard<std::mutex> lock(g_misc.mu);
+		if (g_misc.pinned_bytes + bytes <= ((size_t)1 << 30)) { g_misc.pinned.push_back(HostBlock{ptr, bytes}); g_misc.pinned_bytes += bytes; return; }
+	}
+	(void)hipHostFree(ptr);
+}
+void misc_pool_release() {
+	std::vector<StreamSet> streams;
+	std::vector<HostBlock> pinned;
+	{
+		std::lock_guard<std::mutex> lock(g_misc.mu);
+		streams.swap(g_misc.streams);
+		pinned.swap(g_misc.pinned);
+		g_misc.pinned_bytes = 0;
+	}
+	int cur = 0;
+	(void)hipGetDevice(&cur);
+	for (const StreamSet& ss : streams) {
+		(void)hipSetDevice(ss.device);
+		for (hipEvent_t e : ss.ev) if (e) (void)hipEventDestroy(e);
+		(void)hipStreamDestroy(ss.stream);
+	}
+	(void)hipSetDevice(cur);
+	for (const HostBlock& b : pinned) (void)hipHostFree(b.ptr);
+}
+
 struct UploadStage {
 	std::mutex mu;
-	char* base = nullptr;
-	size_t cap = 0, want = 0;
+	struct Area { char* base = nullptr; size_t cap = 0; bool busy = false; };
+	std::vector<Area> areas;   // a few pinned areas: tables created by several host threads at once (blocks.solve_blocks) do not wait for each other
+	size_t want = 0;
 	bool broken = false;   // hipHostMalloc failed once: pageable copies from then on
 };
 UploadStage g_stage;
-constexpr size_t STAGE_MAX = (size_t)1 << 30, STAGE_MIN_COPY = (size_t)256 << 10, STAGE_GRAIN = (size_t)16 << 20;
+constexpr size_t STAGE_MAX = (size_t)1 << 30, STAGE_MIN_COPY = (size_t)256 << 10, STAGE_GRAIN = (size_t)16 << 20, STAGE_AREAS = 8;
 
-// ---------------------------------------------------------------------------------------------- one arena kept between tables
+// ---------------------------------------------------------------------------------------------- arenas kept between tables
 // hipFree + hipMalloc of a 13 GB backtrace arena per table stalls for up to a second every few tables (measured: create 26 ms,
-// 26 ms, 26 ms, 997 ms).  The arena of the table closed last stays allocated (one block per process); the next table takes it when it
-// is large enough and not wastefully large, otherwise it is freed first.  Counted as free memory when a table sizes its arena.
+// 26 ms, 26 ms, 997 ms; 24 tables of 100 000 columns created and released one after the other: 50 - 100 ms each).  The arenas of closed
+// tables stay allocated (a few blocks per process, at most 40 % of the device); the next table takes the smallest one that is large enough
+// and not wastefully large.  Counted as free memory when a table sizes its arena; given back when memory is tight.
 struct ArenaCache {
 	std::mutex mu;
-	void* ptr = nullptr;
-	size_t bytes = 0;
-	int device = -1;
+	struct Block { void* ptr; size_t bytes; int device; };
+	std::vector<Block> blocks;
 };
 ArenaCache g_arena;
+constexpr size_t ARENA_BLOCKS = 32;
 size_t arena_idle_bytes(int device) {
 	std::lock_guard<std::mutex> lock(g_arena.mu);
-	return g_arena.ptr && g_arena.device == device ? g_arena.bytes : 0;
+	size_t sum = 0;
+	for (const ArenaCache::Block& b : g_arena.blocks) if (b.device == device) sum += b.bytes;
+	return sum;
 }
-void* arena_take(int device, size_t need, size_t& got) {   // nullptr: nothing suitable (a cached block that does not fit is freed)
-	std::lock_guard<std::mutex> lock(g_arena.mu);
-	if (!g_arena.ptr) return nullptr;
-	void* ptr = g_arena.ptr;
-	const size_t bytes = g_arena.bytes;
-	const bool fits = g_arena.device == device && bytes >= need && bytes <= 2 * need + ((size_t)1 << 30);
-	g_arena.ptr = nullptr;
-	g_arena.bytes = 0;
-	if (!fits) {
-		int cur = 0;
-		(void)hipGetDevice(&cur);
-		(void)hipSetDevice(g_arena.device);
-		(void)hipFree(ptr);
-		(void)hipSetDevice(cur);
-		return nullptr;
+void arena_free_block(const ArenaCache::Block& b) {
+	int cur = 0;
+	(void)hipGetDevice(&cur);
+	(void)hipSetDevice(b.device);
+	(void)hipFree(b.ptr);
+	(void)hipSetDevice(cur);
+}
+// nullptr: nothing suitable.  `make_room`: the caller is about to hipMalloc `need` bytes -- blocks that do not fit are freed first.
+void* arena_take(int device, size_t need, size_t& got, bool make_room = true) {
+	std::vector<ArenaCache::Block> drop;
+	void* out = nullptr;
+	{
+		std::lock_guard<std::mutex> lock(g_arena.mu);
+		size_t best = g_arena.blocks.size();
+		for (size_t i = 0; i < g_arena.blocks.size(); ++i) {
+			const ArenaCache::Block& b = g_arena.blocks[i];
+			if (b.device != device || b.bytes < need || b.bytes > 2 * need + ((size_t)1 << 30)) continue;
+			if (best == g_arena.blocks.size() || b.bytes < g_arena.blocks[best].bytes) best = i;
+		}
+		if (best != g_arena.blocks.size()) {
+			out = g_arena.blocks[best].ptr;
+			got = g_arena.blocks[best].bytes;
+			g_arena.blocks[best] = g_arena.blocks.back();
+			g_arena.blocks.pop_back();
+		} else if (make_room) {
+			// nothing fits: the allocation that follows must not fail because of idle blocks -- free them when they are needed
+			size_t free_b = 0, total_b = 0;
+			if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + ((size_t)4 << 30)) drop.swap(g_arena.blocks);
+		}
 	}
-	got = bytes;
-	return ptr;
+	for (const ArenaCache::Block& b : drop) arena_free_block(b);
+	return out;
 }
 void arena_give(int device, void* ptr, size_t bytes) {   // called with `device` current
 	if (!ptr) return;
-	std::lock_guard<std::mutex> lock(g_arena.mu);
-	if (!g_arena.ptr && bytes >= ((size_t)256 << 20) && getenv("WHAMD_NO_ARENA_CACHE") == nullptr) {
-		g_arena.ptr = ptr;
-		g_arena.bytes = bytes;
-		g_arena.device = device;
-		return;
+	{
+		std::lock_guard<std::mutex> lock(g_arena.mu);
+		size_t idle = 0, total_b = 0, free_b = 0;
+		for (const ArenaCache::Block& b : g_arena.blocks) idle += b.bytes;
+		const bool room = hipMemGetInfo(&free_b, &total_b) == hipSuccess && idle + bytes <= total_b / 5 * 2;
+		if (room && g_arena.blocks.size() < ARENA_BLOCKS && bytes >= ((size_t)32 << 20) && getenv("WHAMD_NO_ARENA_CACHE") == nullptr) {
+			g_arena.blocks.push_back(ArenaCache::Block{ptr, bytes, device});
+			return;
+		}
 	}
 	(void)hipFree(ptr);
 }
 
 struct StageSession {
-	std::unique_lock<std::mutex> lock;
 	hipStream_t stream;
 	size_t used = 0, total = 0;
 	bool pending = false;
 	const bool enabled;
-	explicit StageSession(hipStream_t s) : lock(g_stage.mu), stream(s), enabled(getenv("WHAMD_NO_PINNED_STAGE") == nullptr) {}
+	int slot = -1;          // the area this session owns (g_stage.areas), -1: none (pageable copies)
+	char* base = nullptr;
+	size_t cap = 0;
+	explicit StageSession(hipStream_t s) : stream(s), enabled(getenv("WHAMD_NO_PINNED_STAGE") == nullptr) {
+		std::lock_guard<std::mutex> lock(g_stage.mu);
+		size_t best = g_stage.areas.size();
+		for (size_t i = 0; i < g_stage.areas.size(); ++i)
+			if (!g_stage.areas[i].busy && (best == g_stage.areas.size() || g_stage.areas[i].cap > g_stage.areas[best].cap)) best = i;
+		if (best == g_stage.areas.size() && g_stage.areas.size() < STAGE_AREAS) { g_stage.areas.emplace_back(); best = g_stage.areas.size() - 1; }
+		if (best != g_stage.areas.size()) {
+			slot = (int)best;
+			g_stage.areas[best].busy = true;
+			base = g_stage.areas[best].base;
+			cap = g_stage.areas[best].cap;
+		}
+	}
 	~StageSession() {
 		if (pending) (void)hipStreamSynchronize(stream);
+		std::lock_guard<std::mutex> lock(g_stage.mu);
 		g_stage.want = std::max(g_stage.want, std::min(total, STAGE_MAX));
+		if (slot >= 0) {
+			g_stage.areas[slot].base = base;
+			g_stage.areas[slot].cap = cap;
+			g_stage.areas[slot].busy = false;
+		}
 	}
 	bool ensure(size_t bytes) {   // area empty (nothing pending): make it hold `bytes`, or everything the largest table so far staged
-		const size_t need = (std::max(std::min(bytes, STAGE_MAX), g_stage.want) + STAGE_GRAIN - 1) / STAGE_GRAIN * STAGE_GRAIN;
-		if (g_stage.cap >= need) return true;
-		if (g_stage.base) (void)hipHostFree(g_stage.base);
-		g_stage.base = nullptr;
-		g_stage.cap = 0;
+		if (slot < 0) return false;
+		size_t want = 0;
+		{
+			std::lock_guard<std::mutex> lock(g_stage.mu);
+			want = g_stage.want;
+		}
+		const size_t need = (std::max(std::min(bytes, STAGE_MAX), want) + STAGE_GRAIN - 1) / STAGE_GRAIN * STAGE_GRAIN;
+		if (cap >= need) return true;
+		if (base) (void)hipHostFree(base);
+		base = nullptr;
+		cap = 0;
 		void* ptr = nullptr;
 		if (hipHostMalloc(&ptr, need, hipHostMallocPortable) != hipSuccess) {
 			(void)hipGetLastError();
 			g_stage.broken = true;
 			return false;
 		}
-		g_stage.base = (char*)ptr;
-		g_stage.cap = need;
+		base = (char*)ptr;
+		cap = need;
 		return true;
 	}
 	hipError_t copy(void* dst, const void* src, size_t bytes) {
-		if (!enabled || g_stage.broken || bytes < STAGE_MIN_COPY) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream);
+		if (!enabled || g_stage.broken || slot < 0 || bytes < STAGE_MIN_COPY) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream);
 		total += (bytes + 255) & ~(size_t)255;
 		size_t done = 0;
 		while (done < bytes) {
 			if (!pending && used == 0 && !ensure(bytes - done)) return hipMemcpyAsync((char*)dst + done, (const char*)src + done, bytes - done, hipMemcpyHostToDevice, stream);
-			const size_t chunk = std::min(bytes - done, g_stage.cap - used);
+			const size_t chunk = std::min(bytes - done, cap - used);
 			if (chunk == 0) {   // area full: wait for what is in flight, start over
 				hipError_t e = hipStreamSynchronize(stream);
 				if (e != hipSuccess) return e;
@@ -173,7 +319,7 @@ struct StageSession {
 				used = 0;
 				continue;
 			}
-			char* at = g_stage.base + used;
+			char* at = base + used;
 			const char* from = (const char*)src + done;
 			parallel_ranges(chunk, host_threads(chunk, (size_t)2 << 20), [&](uint64_t b0, uint64_t b1, uint32_t) { std::memcpy(at + b0, from + b0, b1 - b0); });
 			hipError_t e = hipMemcpyAsync((char*)dst + done, at, chunk, hipMemcpyHostToDevice, stream);
@@ -184,7 +330,10 @@ struct StageSession {
 		}
 		return hipSuccess;
 	}
-	void expect(size_t bytes) { g_stage.want = std::max(g_stage.want, std::min(bytes, STAGE_MAX)); }   // before the first copy: one allocation
+	void expect(size_t bytes) {   // before the first copy: one allocation
+		std::lock_guard<std::mutex> lock(g_stage.mu);
+		g_stage.want = std::max(g_stage.want, std::min(bytes, STAGE_MAX));
+	}
 	void finish() {   // after the caller synchronised the stream
 		pending = false;
 		used = 0;
@@ -192,6 +341,53 @@ struct StageSession {
 };
 
 }  // namespace
+
+hipError_t devpool_take(int device, size_t bytes, void** out, size_t* got) {
+	const size_t want = pool_class(bytes);
+	*got = want;
+	{
+		std::lock_guard<std::mutex> lock(g_pool.mu);
+		for (size_t i = 0; i < g_pool.idle.size(); ++i) {
+			if (g_pool.idle[i].device != device || g_pool.idle[i].bytes != want) continue;
+			*out = g_pool.idle[i].ptr;
+			g_pool.idle_bytes -= want;
+			g_pool.idle[i] = g_pool.idle.back();
+			g_pool.idle.pop_back();
+			return hipSuccess;
+		}
+	}
+	hipError_t e = hipMalloc(out, want);
+	if (e != hipSuccess) {   // out of memory with idle blocks around: give them back and try once more
+		(void)hipGetLastError();
+		devpool_release();
+		e = hipMalloc(out, want);
+	}
+	return e;
+}
+void devpool_give(int device, void* ptr, size_t bytes) {
+	if (!ptr) return;
+	{
+		std::lock_guard<std::mutex> lock(g_pool.mu);
+		if (g_pool.idle_bytes + bytes <= POOL_KEEP && bytes <= ((size_t)2 << 30)) {
+			g_pool.idle.push_back(DevPool::Block{ptr, bytes, device});
+			g_pool.idle_bytes += bytes;
+			return;
+		}
+	}
+	(void)hipFree(ptr);
+}
+void devpool_release() {
+	std::vector<DevPool::Block> blocks;
+	{
+		std::lock_guard<std::mutex> lock(g_pool.mu);
+		blocks.swap(g_pool.idle);
+		g_pool.idle_bytes = 0;
+	}
+	int cur = 0;
+	(void)hipGetDevice(&cur);
+	for (const DevPool::Block& b : blocks) { (void)hipSetDevice(b.device); (void)hipFree(b.ptr); }
+	(void)hipSetDevice(cur);
+}
 
 // ================================================================================================ DeviceTable
 
@@ -201,7 +397,7 @@ struct DeviceTable::Impl {
 	hipStream_t run_stream = nullptr;   // where the forward steps of the solve being submitted go: `stream`, or the stream of the group's first table (enqueue_group)
 	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
 	hipEvent_t ev_group = nullptr;      // group solve: "the forward pass of every table of the group is submitted up to here"
-	std::vector<void*> allocations;
+	std::vector<std::pair<void*, size_t>> allocations;   // (pointer, size class) of device_pool.h
 	void* d_arena = nullptr;    // the backtrace arena: not in `allocations`, handed to the arena cache on release
 	size_t arena_bytes = 0;
 	DevColumn* d_cols = nullptr;
@@ -228,6 +424,7 @@ struct DeviceTable::Impl {
 	uint32_t group_tables = 1;  // tables that shared the forward launches of the solve in flight (enqueue_group)
 	uint32_t max_grid_x = 1;    // widest launch of the schedule, in workgroups
 	bool enqueue_open = false;  // resumable enqueue (enqueue_some)
+	size_t h_pinned_bytes = 0;
 	uint32_t* h_pinned = nullptr;  // [2 n + 1 + jobs]: path index, path transmission, score of the final job, scores of the others
 	// A job is a sequence of forward steps with its own backtrace.  Job 0 ("final") is the last connected component (it
 	// ends with the table's last column, whose optimum comes from the key scratch); every other job is one earlier
@@ -329,13 +526,13 @@ struct DeviceTable::Impl {
 	void release() {
 		release_lanes();
 		windowed = false;
-		for (void* a : allocations) (void)hipFree(a);
+		if (stream && (!allocations.empty() || d_arena)) (void)hipStreamSynchronize(stream);   // (hipFree used to wait for the table's last kernels)
+		for (auto& a : allocations) devpool_give(device, a.first, a.second);
 		allocations.clear();
-		if (d_arena && stream) (void)hipStreamSynchronize(stream);   // (hipFree used to wait for the table's last kernels)
 		arena_give(device, d_arena, arena_bytes);
 		d_arena = nullptr;
 		arena_bytes = 0;
-		if (h_pinned) (void)hipHostFree(h_pinned);
+		pinned_give(h_pinned, h_pinned_bytes);
 		h_pinned = nullptr;
 		d_cols = nullptr;
 		d_units = nullptr;
@@ -348,14 +545,7 @@ DeviceTable::DeviceTable() : impl_(new Impl()) {}
 
 DeviceTable::~DeviceTable() {
 	if (impl_) {
-		(void)hipSetDevice(impl_->device);
-		impl_->release();
-		if (impl_->ev0) (void)hipEventDestroy(impl_->ev0);
-		if (impl_->ev1) (void)hipEventDestroy(impl_->ev1);
-		if (impl_->ev2) (void)hipEventDestroy(impl_->ev2);
-		if (impl_->ev3) (void)hipEventDestroy(impl_->ev3);
-		if (impl_->ev_group) (void)hipEventDestroy(impl_->ev_group);
-		if (impl_->stream) (void)hipStreamDestroy(impl_->stream);
+		release_device();
 		delete impl_;
 	}
 }
@@ -363,13 +553,15 @@ DeviceTable::~DeviceTable() {
 void DeviceTable::release_device() {
 	Impl& m = *impl_;
 	(void)hipSetDevice(m.device);
-	m.release();
-	for (hipEvent_t* e : {&m.ev0, &m.ev1, &m.ev2, &m.ev3, &m.ev_group}) {
-		if (*e) (void)hipEventDestroy(*e);
-		*e = nullptr;
+	m.release();   // (synchronises the stream before anything is handed back)
+	if (m.stream) {
+		(void)hipStreamSynchronize(m.stream);
+		StreamSet ss;
+		ss.stream = m.stream; ss.ev[0] = m.ev0; ss.ev[1] = m.ev1; ss.ev[2] = m.ev2; ss.ev[3] = m.ev3; ss.ev[4] = m.ev_group; ss.device = m.device;
+		streamset_give(ss);
 	}
-	if (m.stream) (void)hipStreamDestroy(m.stream);
-	m.stream = nullptr;
+	m.stream = m.run_stream = nullptr;
+	m.ev0 = m.ev1 = m.ev2 = m.ev3 = m.ev_group = nullptr;
 }
 
 int DeviceTable::device_count() {
@@ -422,13 +614,10 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		return WHAMD_ERR_DEVICE;
 	}
 	HIP_TRY(hipSetDevice(device));
-	if (!m.stream) HIP_TRY(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
-	if (!m.ev0) {
-		HIP_TRY(hipEventCreate(&m.ev0));
-		HIP_TRY(hipEventCreate(&m.ev1));
-		HIP_TRY(hipEventCreate(&m.ev2));
-		HIP_TRY(hipEventCreate(&m.ev3));
-		HIP_TRY(hipEventCreateWithFlags(&m.ev_group, hipEventDisableTiming));
+	if (!m.stream) {
+		StreamSet ss;
+		if (!streamset_take(device, ss)) { msg = "could not create the table's stream and events"; return WHAMD_ERR_DEVICE; }
+		m.stream = ss.stream; m.ev0 = ss.ev[0]; m.ev1 = ss.ev[1]; m.ev2 = ss.ev[2]; m.ev3 = ss.ev[3]; m.ev_group = ss.ev[4];
 	}
 	m.release();
 	const uint32_t n = p.n_cols;
@@ -451,9 +640,9 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		genotype_release_cache();
 		HIP_TRY(hipMemGetInfo(&free_b, &total_b));
 	}
-	if (free_b < total_b / 4) {   // tight: the arena kept from the previous table goes back as well
-		size_t none = 0;
-		(void)arena_take(device, ~(size_t)0 >> 2, none);
+	if (free_b < total_b / 4) {   // tight: the arenas and buffers kept from closed tables go back as well
+		dptable_release_arena_cache();
+		devpool_release();
 		HIP_TRY(hipMemGetInfo(&free_b, &total_b));
 	}
 	free_b += arena_idle_bytes(device);   // (taken below, or freed before this table's own arena is allocated)
@@ -623,8 +812,9 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	// ---- allocate + upload
 	StageSession stage(m.stream);
 	auto alloc = [&](void** dptr, size_t bytes) -> hipError_t {
-		hipError_t e = hipMalloc(dptr, std::max<size_t>(bytes, 16));
-		if (e == hipSuccess) m.allocations.push_back(*dptr);
+		size_t got = 0;
+		hipError_t e = devpool_take(device, std::max<size_t>(bytes, 16), dptr, &got);
+		if (e == hipSuccess) m.allocations.emplace_back(*dptr, got);
 		return e;
 	};
 	auto up = [&](void** dptr, const void* src, size_t bytes) -> hipError_t {
@@ -946,7 +1136,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	HIP_TRY(alloc((void**)&m.d_path_index, (size_t)n * 4));
 	HIP_TRY(alloc((void**)&m.d_path_trans, (size_t)n * 4));
 	HIP_TRY(alloc((void**)&m.d_score, 16));
-	HIP_TRY(hipHostMalloc((void**)&m.h_pinned, (2 * (size_t)n + 4 + m.jobs.size()) * sizeof(uint32_t), hipHostMallocDefault));
+	HIP_TRY(pinned_take((2 * (size_t)n + 4 + m.jobs.size()) * sizeof(uint32_t), (void**)&m.h_pinned, &m.h_pinned_bytes));
 	HIP_TRY(alloc((void**)&m.d_job_scores, (m.jobs.size() + 1) * 4));
 	{   // lanes: longest job first to the least loaded lane; lane 0 always runs the final job
 		// at most 1 GiB of private exchange buffers (coverage 23: 64 MiB per lane)
@@ -1643,24 +1833,26 @@ whamd_status_t DeviceTable::wait(const Problem& p, Solution& s, whamd_solve_stat
 }
 
 void dptable_release_arena_cache() {
-	std::lock_guard<std::mutex> lock(g_arena.mu);
-	if (!g_arena.ptr) return;
-	int cur = 0;
-	(void)hipGetDevice(&cur);
-	(void)hipSetDevice(g_arena.device);
-	(void)hipFree(g_arena.ptr);
-	(void)hipSetDevice(cur);
-	g_arena.ptr = nullptr;
-	g_arena.bytes = 0;
+	std::vector<ArenaCache::Block> blocks;
+	{
+		std::lock_guard<std::mutex> lock(g_arena.mu);
+		blocks.swap(g_arena.blocks);
+	}
+	for (const ArenaCache::Block& b : blocks) arena_free_block(b);
 }
 
 // whamd_release_caches: the kept backtrace arena AND the pinned upload staging area go back to the driver.
 void dptable_release_caches() {
 	dptable_release_arena_cache();
+	devpool_release();
+	misc_pool_release();
 	std::lock_guard<std::mutex> lock(g_stage.mu);
-	if (g_stage.base) (void)hipHostFree(g_stage.base);
-	g_stage.base = nullptr;
-	g_stage.cap = 0;
+	for (UploadStage::Area& a : g_stage.areas) {
+		if (a.busy) continue;   // (an upload in flight on another thread keeps its area)
+		if (a.base) (void)hipHostFree(a.base);
+		a.base = nullptr;
+		a.cap = 0;
+	}
 	g_stage.want = 0;
 }
 

@@ -16,6 +16,7 @@
 #include <utility>
 #include <vector>
 
+#include "device_pool.h"
 #include "heuristic.h"
 
 #define HEUR_FN __device__
@@ -82,67 +83,9 @@ __global__ __launch_bounds__(MAXT) void heuristic_kernel_many(const HeurDev* __r
 	heur_solve(D);
 }
 
-// ---- device buffers kept between calls.  A solve used to hipMalloc ~20 arrays and hipFree them again (each a driver round trip, the
-// large ones hundreds of microseconds); blocks are now taken from and given back to a per-process pool, rounded to size classes so
-// that the tables of one run reuse each other's.  whamd_release_caches() empties it.
-struct DevBlock { void* ptr; size_t bytes; int device; };
-struct DevPool {
-	std::mutex mu;
-	std::vector<DevBlock> idle;
-	size_t idle_bytes = 0;
-};
-DevPool g_pool;
-constexpr size_t POOL_KEEP = (size_t)12 << 30;   // most bytes kept idle
-size_t pool_class(size_t bytes) {
-	bytes = std::max<size_t>(bytes, 256);
-	size_t p = 256;
-	while (p < bytes) p <<= 1;
-	const size_t step = std::max<size_t>(p / 8, 256);   // eight classes per power of two: at most 12.5 % over
-	return (bytes + step - 1) / step * step;
-}
-hipError_t pool_take(int device, size_t bytes, void** out, size_t* got) {
-	const size_t want = pool_class(bytes);
-	{
-		std::lock_guard<std::mutex> lock(g_pool.mu);
-		for (size_t i = 0; i < g_pool.idle.size(); ++i) {
-			if (g_pool.idle[i].device != device || g_pool.idle[i].bytes != want) continue;
-			*out = g_pool.idle[i].ptr;
-			*got = want;
-			g_pool.idle_bytes -= want;
-			g_pool.idle[i] = g_pool.idle.back();
-			g_pool.idle.pop_back();
-			return hipSuccess;
-		}
-	}
-	*got = want;
-	return hipMalloc(out, want);
-}
-void pool_give(int device, void* ptr, size_t bytes) {
-	if (!ptr) return;
-	{
-		std::lock_guard<std::mutex> lock(g_pool.mu);
-		if (g_pool.idle_bytes + bytes <= POOL_KEEP) {
-			g_pool.idle.push_back(DevBlock{ptr, bytes, device});
-			g_pool.idle_bytes += bytes;
-			return;
-		}
-	}
-	(void)hipFree(ptr);
-}
 }  // namespace
 
-void heuristic_release_cache() {
-	std::vector<DevBlock> blocks;
-	{
-		std::lock_guard<std::mutex> lock(g_pool.mu);
-		blocks.swap(g_pool.idle);
-		g_pool.idle_bytes = 0;
-	}
-	int cur = 0;
-	(void)hipGetDevice(&cur);
-	for (const DevBlock& b : blocks) { (void)hipSetDevice(b.device); (void)hipFree(b.ptr); }
-	(void)hipSetDevice(cur);
-}
+void heuristic_release_cache() { devpool_release(); }
 
 // Several tables in flight: everything between "plans built" and "bipartitions on the host".
 struct HeurBatch::Impl {
@@ -167,10 +110,10 @@ struct HeurBatch::Impl {
 		(void)hipSetDevice(device);
 		if (stream) (void)hipStreamSynchronize(stream);
 		for (Job& j : jobs) {
-			for (auto& b : j.blocks) pool_give(device, b.first, b.second);
-			pool_give(device, j.arena, j.arena_bytes);
+			for (auto& b : j.blocks) devpool_give(device, b.first, b.second);
+			devpool_give(device, j.arena, j.arena_bytes);
 		}
-		pool_give(device, d_tables, d_tables_bytes);
+		devpool_give(device, d_tables, d_tables_bytes);
 		if (ev0) (void)hipEventDestroy(ev0);
 		if (ev1) (void)hipEventDestroy(ev1);
 		if (stream) (void)hipStreamDestroy(stream);
@@ -224,16 +167,12 @@ whamd_status_t HeurBatch::enqueue(const HeurPlan* const* plans, size_t n, int de
 	HEUR_TRY(hipEventCreate(&m.ev1));
 	size_t free_b = 0, total_b = 0;
 	HEUR_TRY(hipMemGetInfo(&free_b, &total_b));
-	{
-		std::lock_guard<std::mutex> lock(g_pool.mu);
-		free_b += g_pool.idle_bytes;   // (reused below, or freed by the allocator's callers when memory is short)
-	}
 	const size_t budget = free_b / 3 / std::max<size_t>(n, 1);   // what one table's pools may take
 	m.jobs.resize(n);
 	{
 		size_t got = 0;
 		void* ptr = nullptr;
-		HEUR_TRY(pool_take(device, (n + 1) * sizeof(HeurDev), &ptr, &got));
+		HEUR_TRY(devpool_take(device, (n + 1) * sizeof(HeurDev), &ptr, &got));
 		m.d_tables = (HeurDev*)ptr; m.d_tables_bytes = got;
 	}
 	for (size_t ji = 0; ji < n; ++ji) {
@@ -256,7 +195,7 @@ whamd_status_t HeurBatch::enqueue(const HeurPlan* const* plans, size_t n, int de
 		while (tsz < 2 * cap) tsz <<= 1;
 		auto alloc = [&](void** dptr, size_t bytes) -> hipError_t {
 			size_t got = 0;
-			hipError_t e = pool_take(device, std::max<size_t>(bytes, 16), dptr, &got);
+			hipError_t e = devpool_take(device, std::max<size_t>(bytes, 16), dptr, &got);
 			if (e == hipSuccess) job.blocks.emplace_back(*dptr, got);
 			return e;
 		};
@@ -302,7 +241,7 @@ whamd_status_t HeurBatch::enqueue(const HeurPlan* const* plans, size_t n, int de
 		for (uint32_t p = 0; p < pl.n_cols; ++p) stride_sum += 2 + ((pl.n_new[p] + 31) >> 5);
 		job.arena_words = stride_sum * std::min<uint64_t>(cap, (uint64_t)pl.row_limit * 4u * T) + 1024;
 		if (job.arena_words * 4 > free_b / 2 / std::max<size_t>(n, 1)) { msg = "PedMecHeuristic: the backtrace records do not fit in device memory"; return WHAMD_ERR_UNSUPPORTED; }
-		HEUR_TRY(pool_take(device, job.arena_words * 4, &job.arena, &job.arena_bytes));
+		HEUR_TRY(devpool_take(device, job.arena_words * 4, &job.arena, &job.arena_bytes));
 		D.arena = (uint32_t*)job.arena; D.arena_words = job.arena_words;
 		// as many threads as the beam usually has solutions (a barrier costs with the number of waves): 2 x row_limit, 128 .. 1024
 		uint32_t block = 128;
@@ -333,13 +272,13 @@ whamd_status_t HeurBatch::wait(HeurResult* outs, std::string& msg) {
 			if (job.done) continue;
 			HEUR_TRY(hipMemcpy(job.stats, job.D.stats, sizeof job.stats, hipMemcpyDeviceToHost));
 			if (job.stats[0] == 2) {   // the records outgrew the arena: four times the room, this table once more
-				pool_give(m.device, job.arena, job.arena_bytes);
+				devpool_give(m.device, job.arena, job.arena_bytes);
 				job.arena = nullptr;
 				job.arena_words *= 4;
 				size_t free_b = 0, total_b = 0;
 				HEUR_TRY(hipMemGetInfo(&free_b, &total_b));
 				if (job.arena_words * 4 > free_b / 2) { msg = "PedMecHeuristic: the backtrace records do not fit in device memory"; return WHAMD_ERR_UNSUPPORTED; }
-				HEUR_TRY(pool_take(m.device, job.arena_words * 4, &job.arena, &job.arena_bytes));
+				HEUR_TRY(devpool_take(m.device, job.arena_words * 4, &job.arena, &job.arena_bytes));
 				job.D.arena = (uint32_t*)job.arena; job.D.arena_words = job.arena_words;
 				HEUR_TRY(hipMemsetAsync(job.D.stats, 0, 256, m.stream));
 				HEUR_TRY(hipMemsetAsync(job.D.opt_bipart, 0, std::max<size_t>(job.plan->n_reads, 1), m.stream));
