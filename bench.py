@@ -361,6 +361,12 @@ def roofline_from_counters(pmc, avg_launch_us, kernel, bytes_per_launch_model, a
         out["achieved"] = valu / cycles
         out["frac"] = out["achieved"] / out["peak"]
         out["valu_issue_frac"] = out["frac"]
+    act = pmc.get("SQ_ACTIVE_INST_VALU")
+    if act is not None:
+        # measured, not modelled: SQ_ACTIVE_INST_VALU counts quad-cycles in which a SIMD's vector ALU is held by an instruction (the guide: SQ_WAVE_CYCLES /
+        # SQ_ACTIVE_INST_* count quad-cycles).  Simple adds hold it for one, v_sad_u32 / v_min3_u32 / v_max_u32 for nearly two (scripts/micro/op_rates.hip)
+        out["valu_active_frac"] = 4.0 * act / (N_SIMD * cycles)
+        out["valu_active_note"] = "4 x SQ_ACTIVE_INST_VALU (quad-cycles) / (1024 SIMDs x launch cycles): the share of the launch in which the vector ALUs are held"
     f64 = [pmc.get(k) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")]
     if valu is not None and any(x is not None for x in f64):
         n64 = sum(x for x in f64 if x is not None)
@@ -658,7 +664,7 @@ def run_extra_configs(args):
             "bipartition_costs_per_s": full["bipartition_costs_per_s"],
             "optimal_cost_checksum": full["config"]["optimal_cost_checksum"],
             "forward_launches_per_step": full["rank0"]["forward_launches_per_step"],
-            "roofline": {k: roof.get(k) for k in ("bound", "kernel", "frac", "avg_launch_us", "peak", "unit", "pmc_note")},
+            "roofline": {k: roof.get(k) for k in ("bound", "kernel", "frac", "valu_active_frac", "work_bound_frac", "avg_launch_us", "peak", "unit", "pmc_note")},
             "wall_s": time.perf_counter() - t0,
         }
         if "cpu_baseline" in full:
@@ -921,6 +927,10 @@ def main():
         # column -- single individual: A, K - A, min3, accumulate + ending reads = 5, half of the cells by symmetry; trio (NF = 2): 2 adds + min,
         # 2 x 6 butterfly, accumulate, ending reads = 19; quartet 31 -- issued at the chip's 512 wave-instructions per cycle, over the forward time
         ops = {1: 5.0, 4: 19.0, 16: 31.0}[T]
+        if T == 1 and args.path == "auto" and not args.distrust:
+            # Y-form runs: one absolute-difference-accumulate per evaluated cell-column, a quarter of the add that forms the thread's
+            # operand, and per ending read (0.5 per column) compare, shift-in and maximum on each pair: 1 + 0.25 + 1.5 = 2.75
+            ops = 2.75
         evaluated = costs_job / world * (0.5 if T == 1 else 1.0)
         out["roofline"]["work_bound_frac"] = (evaluated * ops / 64.0 / (N_SIMD / 2.0) / (CLOCK_GHZ * 1e9)) / max(fwd_ms / args.steps * 1e-3, 1e-12)
         out["roofline"]["work_bound_note"] = f"{ops:g} VALU lane-operations per evaluated cell-value of a column at 512 wave-instructions/cycle, over the forward time of a step"

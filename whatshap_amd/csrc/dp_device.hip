@@ -1232,6 +1232,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 				if (last) { ++c.job_i; c.step_i = 0; } else ++c.step_i;
 			}
 			if (!ss.entry_count && ss.singles.empty()) break;
+			m.max_grid_x = std::max(m.max_grid_x, ss.grid_x * std::max(1u, ss.entry_count));
 			m.schedule.push_back(std::move(ss));
 		}
 		if (m.windowed) {
