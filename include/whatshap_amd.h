@@ -57,7 +57,8 @@ typedef enum whamd_status_t {
 	WHAMD_ERR_UNSORTED = 3,          /* ColumnIterator sortedness errors */
 	WHAMD_ERR_UNSUPPORTED = 4,       /* outside the limits of the device path (coverage > 23, ...) */
 	WHAMD_ERR_DEVICE = 5,            /* HIP runtime error / no device / extension missing */
-	WHAMD_ERR_OVERFLOW = 6           /* costs could exceed 32 bits; reference behaviour undefined there */
+	WHAMD_ERR_OVERFLOW = 6,          /* costs could exceed 32 bits; reference behaviour undefined there */
+	WHAMD_ERR_HOST = 7               /* a host-side failure inside the library: out of memory, no thread could be started (message says what) */
 } whamd_status_t;
 
 /* View of a ReadSet (src/readset.h:14-26, src/read.h:10-83).  Reads in ReadSet order; the

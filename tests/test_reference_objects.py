@@ -59,9 +59,13 @@ def test_shim_install_rebinds_a_phase_like_module():
     from whatshap_amd.core import Pedigree as MirrorPedigree
 
     ref = reference_core()
-    phase = types.SimpleNamespace(Pedigree=ref.Pedigree, PedigreeDPTable=ref.PedigreeDPTable)
+    phase = types.SimpleNamespace(Pedigree=ref.Pedigree, PedigreeDPTable=ref.PedigreeDPTable, PedMecHeuristic=ref.PedMecHeuristic)
     previous = shim.install(phase, ref)
     assert previous == (ref.Pedigree, ref.PedigreeDPTable)
+    assert phase.PedMecHeuristic is not ref.PedMecHeuristic and previous.bindings["PedMecHeuristic"] is ref.PedMecHeuristic
+    previous.restore()   # every rebound name goes back, the heuristic factory included
+    assert (phase.Pedigree, phase.PedigreeDPTable, phase.PedMecHeuristic) == (ref.Pedigree, ref.PedigreeDPTable, ref.PedMecHeuristic)
+    previous = shim.install(phase, ref)
     assert issubclass(phase.Pedigree, ref.Pedigree) and phase.Pedigree is not ref.Pedigree
     ids = ref.NumericSampleIds()
     ped = phase.Pedigree(ids)  # what create_pedigree() does (cli/phase.py:901-935)

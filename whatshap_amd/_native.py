@@ -24,6 +24,7 @@ WHAMD_ERR_UNSORTED = 3
 WHAMD_ERR_UNSUPPORTED = 4
 WHAMD_ERR_DEVICE = 5
 WHAMD_ERR_OVERFLOW = 6
+WHAMD_ERR_HOST = 7
 GT_OTHER = 255
 
 

@@ -5,6 +5,8 @@
 #include <cstring>
 #include <functional>
 #include <memory>
+#include <new>
+#include <stdexcept>
 #include <string>
 
 #include "device_table.h"
@@ -39,6 +41,21 @@ whamd_status_t fail(whamd_status_t st, const std::string& msg) {
 	return st;
 }
 
+// No C++ exception crosses the C boundary: std::bad_alloc of the flatten / plan vectors, std::system_error of a worker thread that could not
+// be started, anything a worker carried over (host_parallel.h) become WHAMD_ERR_HOST with the exception's message.
+template <class F>
+whamd_status_t guarded(F&& body) {
+	try {
+		return body();
+	} catch (const std::bad_alloc&) {
+		return fail(WHAMD_ERR_HOST, "out of host memory");
+	} catch (const std::exception& e) {
+		return fail(WHAMD_ERR_HOST, std::string("host-side failure: ") + e.what());
+	} catch (...) {
+		return fail(WHAMD_ERR_HOST, "host-side failure (unknown exception)");
+	}
+}
+
 double now_ms() {
 	return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -62,6 +79,7 @@ whamd_status_t whamd_dptable_create(const whamd_readset_view* readset, const uin
                                     size_t n_recombcost, const whamd_pedigree_view* pedigree,
                                     int distrust_genotypes, const uint32_t* positions, size_t n_positions,
                                     int device, whamd_dptable** out) {
+	return guarded([&]() -> whamd_status_t {
 	if (!out) return fail(WHAMD_ERR_INVALID, "out is NULL");
 	*out = nullptr;
 	const double t0 = now_ms();
@@ -80,6 +98,7 @@ whamd_status_t whamd_dptable_create(const whamd_readset_view* readset, const uin
 	t->stats.host_prepare_ms = now_ms() - t0;
 	*out = t.release();
 	return WHAMD_OK;
+	});
 }
 
 namespace {
@@ -109,6 +128,7 @@ whamd_status_t begin_enqueue(whamd_dptable* t) {
 }  // namespace
 
 whamd_status_t whamd_dptable_enqueue(whamd_dptable* t) {
+	return guarded([&]() -> whamd_status_t {
 	whamd_status_t st = begin_enqueue(t);
 	if (st != WHAMD_OK) return st;
 	std::string msg;
@@ -116,9 +136,11 @@ whamd_status_t whamd_dptable_enqueue(whamd_dptable* t) {
 	if (st != WHAMD_OK) return fail(st, msg);
 	t->in_flight = true;
 	return WHAMD_OK;
+	});
 }
 
 whamd_status_t whamd_dptable_enqueue_many(whamd_dptable* const* tables, size_t n_tables) {
+	return guarded([&]() -> whamd_status_t {
 	if (!tables && n_tables) return fail(WHAMD_ERR_INVALID, "tables is NULL");
 	for (size_t i = 0; i < n_tables; ++i) {
 		whamd_status_t st = begin_enqueue(tables[i]);
@@ -188,9 +210,11 @@ whamd_status_t whamd_dptable_enqueue_many(whamd_dptable* const* tables, size_t n
 		}
 	}
 	return WHAMD_OK;
+	});
 }
 
 whamd_status_t whamd_dptable_wait(whamd_dptable* t) {
+	return guarded([&]() -> whamd_status_t {
 	if (!t) return fail(WHAMD_ERR_INVALID, "table is NULL");
 	if (!t->in_flight) return fail(WHAMD_ERR_INVALID, "whamd_dptable_enqueue has not run");
 	t->in_flight = false;
@@ -203,9 +227,11 @@ whamd_status_t whamd_dptable_wait(whamd_dptable* t) {
 	t->stats.host_finish_ms = now_ms() - t0;
 	t->solved = true;
 	return WHAMD_OK;
+	});
 }
 
 whamd_status_t whamd_dptable_wait_many(whamd_dptable* const* tables, size_t n_tables) {
+	return guarded([&]() -> whamd_status_t {
 	if (!tables && n_tables) return fail(WHAMD_ERR_INVALID, "tables is NULL");
 	for (size_t i = 0; i < n_tables; ++i) {
 		if (!tables[i]) return fail(WHAMD_ERR_INVALID, "table is NULL");
@@ -238,12 +264,15 @@ whamd_status_t whamd_dptable_wait_many(whamd_dptable* const* tables, size_t n_ta
 	for (size_t i = 0; i < n_tables && first == WHAMD_OK; ++i)
 		if (status[i] != WHAMD_OK) { first = status[i]; first_msg = messages[i]; }
 	return first == WHAMD_OK ? WHAMD_OK : fail(first, first_msg);
+	});
 }
 
 whamd_status_t whamd_dptable_solve(whamd_dptable* t) {
+	return guarded([&]() -> whamd_status_t {
 	whamd_status_t st = whamd_dptable_enqueue(t);
 	if (st != WHAMD_OK) return st;
 	return whamd_dptable_wait(t);
+	});
 }
 
 whamd_status_t whamd_dptable_release_device(whamd_dptable* t) {
@@ -359,6 +388,7 @@ whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uin
                                     const whamd_pedigree_view* pedigree, int distrust_genotypes,
                                     const uint32_t* positions, size_t n_positions, const char* path,
                                     whamd_plan_summary* out) {
+	return guarded([&]() -> whamd_status_t {
 	if (!out) return fail(WHAMD_ERR_INVALID, "out is NULL");
 	Problem p;
 	std::string msg;
@@ -546,12 +576,14 @@ whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uin
 	s.invariants_ok = ok ? 1 : 0;
 	*out = s;
 	return WHAMD_OK;
+	});
 }
 
 whamd_status_t whamd_debug_emulate_slot_plan(const whamd_readset_view* readset, const uint32_t* recombcost, size_t n_recombcost,
                                             const whamd_pedigree_view* pedigree, int distrust_genotypes, const uint32_t* positions,
                                             size_t n_positions, int slot_l, int symmetry, uint32_t* index_out, uint32_t* score_out,
                                             uint64_t* n_run_columns_out) {
+	return guarded([&]() -> whamd_status_t {
 	const int lr = slot_l >= 200 ? 1 : slot_l >= 100 ? 3 : 2;   // slot_l + 100: 8 cells per thread, + 200: 2 cells per thread
 	if (slot_l >= 100) slot_l -= slot_l >= 200 ? 200 : 100;
 	Problem p;
@@ -568,12 +600,14 @@ whamd_status_t whamd_debug_emulate_slot_plan(const whamd_readset_view* readset, 
 	if (score_out) *score_out = score;
 	if (n_run_columns_out) *n_run_columns_out = sp.n_run_columns;
 	return WHAMD_OK;
+	});
 }
 
 whamd_status_t whamd_debug_emulate_pedslot_plan(const whamd_readset_view* readset, const uint32_t* recombcost, size_t n_recombcost,
                                                const whamd_pedigree_view* pedigree, int distrust_genotypes, const uint32_t* positions,
                                                size_t n_positions, int slot_l, uint32_t* index_out, uint32_t* transmission_out,
                                                uint32_t* score_out, uint64_t* n_run_columns_out) {
+	return guarded([&]() -> whamd_status_t {
 	Problem p;
 	std::string msg;
 	whamd_status_t st = build_problem(readset, recombcost, n_recombcost, pedigree, distrust_genotypes != 0, positions,
@@ -590,6 +624,7 @@ whamd_status_t whamd_debug_emulate_pedslot_plan(const whamd_readset_view* readse
 	if (score_out) *score_out = score;
 	if (n_run_columns_out) *n_run_columns_out = sp.n_run_columns;
 	return WHAMD_OK;
+	});
 }
 
 }  // extern "C"
@@ -723,22 +758,30 @@ extern "C" {
 whamd_status_t whamd_pedmec_heuristic_create(const whamd_readset_view* readset, const uint32_t* recombcost, size_t n_recombcost,
                                              const whamd_pedigree_view* pedigree, int distrust_genotypes, const uint32_t* positions, size_t n_positions,
                                              uint32_t row_limit, int allow_mutations, int device, whamd_heuristic** out) {
+	return guarded([&]() -> whamd_status_t {
 	return heuristic_create_common(readset, recombcost, n_recombcost, pedigree, distrust_genotypes, positions, n_positions, row_limit, allow_mutations, device, false, out);
+	});
 }
 
 whamd_status_t whamd_pedmec_heuristic_enqueue_many(const whamd_heuristic_job* jobs, size_t n_jobs, int device, whamd_heuristic** out) {
+	return guarded([&]() -> whamd_status_t {
 	return heuristic_enqueue_jobs(jobs, n_jobs, device, out);
+	});
 }
 
 whamd_status_t whamd_pedmec_heuristic_wait(whamd_heuristic* h) {
+	return guarded([&]() -> whamd_status_t {
 	if (!h) return fail(WHAMD_ERR_INVALID, "null argument");
 	return heuristic_collect(h);
+	});
 }
 
 whamd_status_t whamd_debug_pedmec_heuristic_create_host(const whamd_readset_view* readset, const uint32_t* recombcost, size_t n_recombcost,
                                                         const whamd_pedigree_view* pedigree, int distrust_genotypes, const uint32_t* positions,
                                                         size_t n_positions, uint32_t row_limit, int allow_mutations, whamd_heuristic** out) {
+	return guarded([&]() -> whamd_status_t {
 	return heuristic_create_common(readset, recombcost, n_recombcost, pedigree, distrust_genotypes, positions, n_positions, row_limit, allow_mutations, 0, true, out);
+	});
 }
 
 uint64_t whamd_pedmec_heuristic_column_count(const whamd_heuristic* h) { return h ? h->plan.n_cols : 0; }
@@ -782,6 +825,7 @@ whamd_status_t whamd_genotype_likelihoods(const whamd_readset_view* readset, con
                                           const whamd_pedigree_view* pedigree, const uint32_t* positions, size_t n_positions,
                                           int device, uint32_t window, double* gl_out, size_t gl_capacity,
                                           whamd_genotype_stats* stats_out) {
+	return guarded([&]() -> whamd_status_t {
 	const double t0 = now_ms();
 	Problem p;
 	std::string msg;
@@ -806,6 +850,7 @@ whamd_status_t whamd_genotype_likelihoods(const whamd_readset_view* readset, con
 		*stats_out = o;
 	}
 	return WHAMD_OK;
+	});
 }
 
 void whamd_release_caches(void) {

@@ -200,17 +200,35 @@ class _HeuristicAdapter(_TableAdapter):
         return self._table.get_mutations()
 
 
+class _Previous(tuple):
+    """What ``install`` replaced: unpacks as ``(Pedigree, PedigreeDPTable)`` like the tuple earlier versions returned, and
+    ``restore()`` puts EVERY rebound name back -- ``PedMecHeuristic`` included."""
+
+    def __new__(cls, module, bindings):
+        self = super().__new__(cls, (bindings["Pedigree"], bindings["PedigreeDPTable"]))
+        self._module = module
+        self.bindings = dict(bindings)
+        return self
+
+    def restore(self):
+        for name, value in self.bindings.items():
+            setattr(self._module, name, value)
+
+
 def install(phase_module, reference_core=None, allow_cpu_fallback=False, **solver_options):
-    """Rebinds ``Pedigree`` and ``PedigreeDPTable`` in ``phase_module`` (normally ``whatshap.cli.phase``).  Returns the
-    previous bindings so that a caller can restore them.  ``allow_cpu_fallback=True``: inputs beyond the device path's
-    INPUT limits are handed to the class that was replaced (see ``table_factory``; never a missing GPU or a HIP error)."""
-    previous = (phase_module.Pedigree, phase_module.PedigreeDPTable)
+    """Rebinds ``Pedigree``, ``PedigreeDPTable`` and (where the module has it) ``PedMecHeuristic`` in ``phase_module`` (normally
+    ``whatshap.cli.phase``).  Returns the previous bindings: a tuple ``(Pedigree, PedigreeDPTable)`` with ``.restore()`` (all three
+    names) and ``.bindings`` (dict).  ``allow_cpu_fallback`` defaults to **False**: an input beyond the device path's INPUT limits
+    (more than 25 reads in a column, more than three trios) raises instead of silently running on the class that was replaced; with
+    ``True`` such inputs are handed to that class (see ``table_factory``; never a missing GPU or a HIP error)."""
+    bindings = {"Pedigree": phase_module.Pedigree, "PedigreeDPTable": phase_module.PedigreeDPTable}
     ref_pedigree = reference_core.Pedigree if reference_core is not None else phase_module.Pedigree
     phase_module.Pedigree = recording_pedigree_class(ref_pedigree)
-    phase_module.PedigreeDPTable = table_factory(reference_core, fallback_table_class=previous[1] if allow_cpu_fallback else None, **solver_options)
+    phase_module.PedigreeDPTable = table_factory(reference_core, fallback_table_class=bindings["PedigreeDPTable"] if allow_cpu_fallback else None, **solver_options)
     if hasattr(phase_module, "PedMecHeuristic"):   # `--algorithm heuristic` (whatshap/cli/phase.py:589-603)
-        phase_module.PedMecHeuristic = heuristic_factory(reference_core, phase_module.PedMecHeuristic if allow_cpu_fallback else None)
-    return previous
+        bindings["PedMecHeuristic"] = phase_module.PedMecHeuristic
+        phase_module.PedMecHeuristic = heuristic_factory(reference_core, bindings["PedMecHeuristic"] if allow_cpu_fallback else None)
+    return _Previous(phase_module, bindings)
 
 
 # ------------------------------------------------------------------------------------------------ whatshap genotype
