@@ -55,8 +55,8 @@ WORKLOADS = {
     "config2": dict(variants=200000, coverage=20),                                 # BASELINE configs[2] (the headline)
     "config3": dict(trio=True, variants=100000, coverage=15),                      # BASELINE configs[3]
     "blocks3": dict(variants=100000, coverage=20, blocks=3, in_flight=3),          # three configs[4] blocks in flight on one GPU
-    "blocks24": dict(variants=100000, coverage=20, blocks=24, in_flight=24),       # BASELINE configs[4] on ONE GPU: all 24 blocks as one group of launches
-    "config1_x24": dict(variants=50000, coverage=15, blocks=24, in_flight=24),     # 24 tables at `whatshap phase`'s default coverage (24 chromosomes) on one GPU
+    "blocks24": dict(variants=100000, coverage=20, blocks=24, in_flight=24, option=["shared_launches=1"]),       # BASELINE configs[4] on ONE GPU: all 24 blocks as one group of launches
+    "config1_x24": dict(variants=50000, coverage=15, blocks=24, in_flight=24, option=["shared_launches=1"]),     # 24 tables at `whatshap phase`'s default coverage (24 chromosomes) on one GPU
     "config3_distrust": dict(trio=True, distrust=True, variants=100000, coverage=15),   # configs[3]'s ReadSet, genotypes not trusted (16 allele assignments per value)
     "config3_x8": dict(trio=True, variants=100000, coverage=15, blocks=8, in_flight=8),  # eight trio tables (families / chromosomes) on one GPU
     "irregular": dict(irregular=True, variants=100000, coverage=20),               # Poisson starts, geometric lengths (mean 16), coverage capped
@@ -150,6 +150,10 @@ def workload_flags(args):
         if getattr(args, flag):
             out.append("--" + flag)
     return out
+
+
+def option_dict(args):
+    return dict(kv.partition("=")[::2] for kv in args.option)
 
 
 def apply_options(table, args):
@@ -734,8 +738,7 @@ def main():
     for b in mine:
         seed, v = blocks[b]
         problem = build_block(args, seed, v)
-        t = _native.NativeTable(problem, device=device, path=None if args.path == "auto" else args.path, solve=False)
-        apply_options(t, args)
+        t = _native.NativeTable(problem, device=device, path=None if args.path == "auto" else args.path, solve=False, options=option_dict(args))
         tables.append(t)
 
     def step():

@@ -134,3 +134,54 @@ def test_full_width_tables_batched(monkeypatch):
         assert t.stats()["group_tables"] == 3
         assert table_solution(t) == a, first_difference(a, table_solution(t))
         t.close()
+
+
+def test_enqueue_many_rejects_a_table_listed_twice_and_takes_an_empty_list():
+    p = synthetic_block(n_variants=300, coverage=9, seed=1)
+    a, b = _native.NativeTable(p, solve=False), _native.NativeTable(p, solve=False)
+    with pytest.raises(_native.SolverError) as e:
+        _native.enqueue_many([a, b, a])
+    assert e.value.status == _native.WHAMD_ERR_INVALID
+    _native.enqueue_many([])
+    _native.wait_many([])
+    _native.enqueue_many([a, b])   # the refused call left nothing in flight
+    _native.wait_many([a, b])
+    assert table_solution(a) == table_solution(b) == table_solution(oracle.OracleTable(p))
+    a.close(); b.close()
+
+
+def test_shared_launches_layout_eight_cells_per_thread_vs_oracle(monkeypatch):
+    """Tables created with the option shared_launches = 1 (whamd_dptable_create_with_options; what blocks.solve_blocks passes for windows
+    of more than four tables): wide single-individual tables take eight cells per thread and twelve local slots (Y form with Kr[0..7]), narrow
+    ones and pedigrees keep their layout.  Every table equals the oracle -- alone and sharing launches with the others."""
+    cases = [synthetic_block(n_variants=200000, coverage=20, seed=3, n_columns_limit=420),       # 300+ full-width columns of BASELINE configs[2]
+             synthetic_block(n_variants=100000, coverage=20, seed=100, n_columns_limit=900),     # a configs[4] block, several backtrace chunks
+             two_valued(synthetic_block(n_variants=1200, coverage=19, seed=7), 77),              # tie-heavy
+             irregular_block(1500, 20, seed=9),
+             synthetic_block(n_variants=2000, coverage=18, seed=8),
+             synthetic_block(n_variants=3000, coverage=15, seed=5),                              # narrow: keeps four cells per thread
+             synthetic_block(n_variants=600, coverage=12, seed=6, trio=True)]
+    want = [table_solution(oracle.OracleTable(p)) for p in cases]
+    opts = {"shared_launches": "1"}
+    for p, w in zip(cases, want):   # alone
+        t = _native.NativeTable(p, options=opts)
+        assert table_solution(t) == w, first_difference(w, table_solution(t))
+        t.close()
+    tables = [_native.NativeTable(p, solve=False, options=opts) for p in cases]
+    _native.enqueue_many(tables)
+    _native.wait_many(tables)
+    for t, w in zip(tables, want):
+        assert t.stats()["group_tables"] == len(cases)
+        assert table_solution(t) == w, first_difference(w, table_solution(t))
+    launches = [t.stats()["forward_launches"] for t in tables]
+    plain = _native.NativeTable(cases[0], solve=False)
+    plain.solve()
+    assert launches[0] <= plain.stats()["forward_launches"], "twelve local slots did not give longer runs"
+    plain.close()
+    for t in tables:
+        t.close()
+    # the explicit options, and eleven local slots (256-thread workgroups)
+    for extra in ({"slot_r": "3", "slot_l": "12"}, {"slot_r": "3", "slot_l": "11"}, {"slot_r": "3", "slot_l": "10", "symmetry": "0"}):
+        t = _native.NativeTable(cases[0], options=extra)
+        assert table_solution(t) == want[0], (extra, first_difference(want[0], table_solution(t)))
+        t.close()

@@ -244,6 +244,11 @@ def lib() -> C.CDLL:
         C.POINTER(ReadSetView), C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(PedigreeView), C.c_int,
         C.POINTER(C.c_uint32), C.c_size_t, C.c_int, C.POINTER(H),
     ]
+    L.whamd_dptable_create_with_options.restype = C.c_int
+    L.whamd_dptable_create_with_options.argtypes = [
+        C.POINTER(ReadSetView), C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(PedigreeView), C.c_int,
+        C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_size_t, C.c_int, C.POINTER(H),
+    ]
     L.whamd_dptable_solve.restype = C.c_int
     L.whamd_dptable_solve.argtypes = [H]
     L.whamd_dptable_enqueue.restype = C.c_int
@@ -338,7 +343,7 @@ def lib() -> C.CDLL:
 
 # every symbol include/whatshap_amd.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = [
-    "whamd_abi_version", "whamd_device_count", "whamd_last_error", "whamd_dptable_create", "whamd_dptable_solve",
+    "whamd_abi_version", "whamd_device_count", "whamd_last_error", "whamd_dptable_create", "whamd_dptable_create_with_options", "whamd_dptable_solve",
     "whamd_dptable_release_device", "whamd_dptable_destroy", "whamd_dptable_column_count", "whamd_dptable_individual_count",
     "whamd_dptable_read_count", "whamd_dptable_positions", "whamd_dptable_get_optimal_score",
     "whamd_dptable_get_super_reads", "whamd_dptable_get_optimal_partitioning", "whamd_dptable_get_index_path",
@@ -386,16 +391,22 @@ def wait_many(tables) -> None:
 class NativeTable:
     """Thin RAII wrapper of whamd_dptable: create -> (set_option) -> solve -> getters."""
 
-    def __init__(self, problem: ProblemArrays, device: int = 0, path: Optional[str] = None, solve: bool = True):
+    def __init__(self, problem: ProblemArrays, device: int = 0, path: Optional[str] = None, solve: bool = True, options: Optional[dict] = None):
         L = lib()
         self._h = C.c_void_p()
         self._problem = problem  # keep the arrays alive while create() reads them
-        _check(L.whamd_dptable_create(*problem.call_args(), C.c_int(device), C.byref(self._h)))
+        opts = dict(options or {})
+        if path is not None:
+            opts["path"] = path
+        if opts:   # applied before the plan is made: one upload
+            keys = (C.c_char_p * len(opts))(*[str(k).encode() for k in opts])
+            values = (C.c_char_p * len(opts))(*[str(v).encode() for v in opts.values()])
+            _check(L.whamd_dptable_create_with_options(*problem.call_args(), keys, values, C.c_size_t(len(opts)), C.c_int(device), C.byref(self._h)))
+        else:
+            _check(L.whamd_dptable_create(*problem.call_args(), C.c_int(device), C.byref(self._h)))
         self.n_columns = int(L.whamd_dptable_column_count(self._h))
         self.n_individuals = int(L.whamd_dptable_individual_count(self._h))
         self.n_reads = int(L.whamd_dptable_read_count(self._h))
-        if path is not None:
-            self.set_option("path", path)
         if solve:
             self.solve()
 

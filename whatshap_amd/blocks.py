@@ -125,14 +125,17 @@ def solve_blocks(problems: Sequence[ProblemArrays], device: int = 0, path=None, 
         windows = [problems[start:start + max_in_flight] for start in range(0, len(problems), max_in_flight)]
         tables = []
         with ThreadPoolExecutor(max_workers=max(1, min(create_threads, max_in_flight))) as pool:
+            def options_of(window):   # more than four tables per window share their launches: the library picks the layout for that
+                return {"shared_launches": "1"} if len(window) > 4 else None
+
             def create(window):
-                return list(pool.map(lambda sub: NativeTable(sub, device=device, path=path, solve=False), window))
+                return list(pool.map(lambda sub: NativeTable(sub, device=device, path=path, solve=False, options=options_of(window)), window))
 
             ready = create(windows[0]) if windows else []
             for wi in range(len(windows)):
                 window = ready
                 enqueue_many(window)
-                pending = [pool.submit(NativeTable, sub, device, path, False) for sub in windows[wi + 1]] if wi + 1 < len(windows) else []
+                pending = [pool.submit(NativeTable, sub, device, path, False, options_of(windows[wi + 1])) for sub in windows[wi + 1]] if wi + 1 < len(windows) else []
                 wait_many(window)
                 if release:
                     for t in window:

@@ -75,13 +75,15 @@ int whamd_device_count(void) { return DeviceTable::device_count(); }
 
 const char* whamd_last_error(void) { return g_last_error.c_str(); }
 
-whamd_status_t whamd_dptable_create(const whamd_readset_view* readset, const uint32_t* recombcost,
-                                    size_t n_recombcost, const whamd_pedigree_view* pedigree,
-                                    int distrust_genotypes, const uint32_t* positions, size_t n_positions,
-                                    int device, whamd_dptable** out) {
-	return guarded([&]() -> whamd_status_t {
+namespace {
+whamd_status_t apply_option(whamd_dptable* t, const std::string& k, const char* value);   // (below: whamd_dptable_set_option)
+
+whamd_status_t create_table(const whamd_readset_view* readset, const uint32_t* recombcost, size_t n_recombcost, const whamd_pedigree_view* pedigree,
+                            int distrust_genotypes, const uint32_t* positions, size_t n_positions, const char* const* keys, const char* const* values,
+                            size_t n_options, int device, whamd_dptable** out) {
 	if (!out) return fail(WHAMD_ERR_INVALID, "out is NULL");
 	*out = nullptr;
+	if (n_options && (!keys || !values)) return fail(WHAMD_ERR_INVALID, "option arrays are NULL");
 	const double t0 = now_ms();
 	std::unique_ptr<whamd_dptable> t(new whamd_dptable());
 	std::string msg;
@@ -90,6 +92,11 @@ whamd_status_t whamd_dptable_create(const whamd_readset_view* readset, const uin
 	if (st != WHAMD_OK) return fail(st, msg);
 	const double t1 = now_ms();
 	t->device_index = device;
+	for (size_t i = 0; i < n_options; ++i) {   // before the (one) upload: the plan is made for them
+		if (!keys[i] || !values[i]) return fail(WHAMD_ERR_INVALID, "null option");
+		st = apply_option(t.get(), keys[i], values[i]);
+		if (st != WHAMD_OK) return st;
+	}
 	st = t->device.upload(t->problem, device, msg);
 	if (st != WHAMD_OK) return fail(st, msg);
 	if (getenv("WHAMD_DEBUG_TIMING"))
@@ -98,6 +105,25 @@ whamd_status_t whamd_dptable_create(const whamd_readset_view* readset, const uin
 	t->stats.host_prepare_ms = now_ms() - t0;
 	*out = t.release();
 	return WHAMD_OK;
+}
+}  // namespace
+
+whamd_status_t whamd_dptable_create(const whamd_readset_view* readset, const uint32_t* recombcost,
+                                    size_t n_recombcost, const whamd_pedigree_view* pedigree,
+                                    int distrust_genotypes, const uint32_t* positions, size_t n_positions,
+                                    int device, whamd_dptable** out) {
+	return guarded([&]() -> whamd_status_t {
+		return create_table(readset, recombcost, n_recombcost, pedigree, distrust_genotypes, positions, n_positions, nullptr, nullptr, 0, device, out);
+	});
+}
+
+whamd_status_t whamd_dptable_create_with_options(const whamd_readset_view* readset, const uint32_t* recombcost,
+                                                 size_t n_recombcost, const whamd_pedigree_view* pedigree,
+                                                 int distrust_genotypes, const uint32_t* positions, size_t n_positions,
+                                                 const char* const* keys, const char* const* values, size_t n_options,
+                                                 int device, whamd_dptable** out) {
+	return guarded([&]() -> whamd_status_t {
+		return create_table(readset, recombcost, n_recombcost, pedigree, distrust_genotypes, positions, n_positions, keys, values, n_options, device, out);
 	});
 }
 
@@ -142,6 +168,11 @@ whamd_status_t whamd_dptable_enqueue(whamd_dptable* t) {
 whamd_status_t whamd_dptable_enqueue_many(whamd_dptable* const* tables, size_t n_tables) {
 	return guarded([&]() -> whamd_status_t {
 	if (!tables && n_tables) return fail(WHAMD_ERR_INVALID, "tables is NULL");
+	{
+		std::vector<const whamd_dptable*> seen(tables, tables + n_tables);
+		std::sort(seen.begin(), seen.end());
+		if (std::adjacent_find(seen.begin(), seen.end()) != seen.end()) return fail(WHAMD_ERR_INVALID, "a table appears twice in the list");
+	}
 	for (size_t i = 0; i < n_tables; ++i) {
 		whamd_status_t st = begin_enqueue(tables[i]);
 		if (st != WHAMD_OK) return st;
@@ -338,9 +369,9 @@ whamd_status_t whamd_dptable_get_stats(const whamd_dptable* t, whamd_solve_stats
 	return WHAMD_OK;
 }
 
-whamd_status_t whamd_dptable_set_option(whamd_dptable* t, const char* key, const char* value) {
-	if (!t || !key || !value) return fail(WHAMD_ERR_INVALID, "null argument");
-	const std::string k(key), v(value);
+namespace {
+whamd_status_t apply_option(whamd_dptable* t, const std::string& k, const char* value) {
+	const std::string v(value);
 	if (k == "path") {
 		if (!t->device.set_path(v)) return fail(WHAMD_ERR_INVALID, "unknown path '" + v + "' (auto, slots, resident, column, column_keys)");
 		t->uploaded = false;  // descriptors are rebuilt at the next solve
@@ -376,12 +407,23 @@ whamd_status_t whamd_dptable_set_option(whamd_dptable* t, const char* key, const
 		t->uploaded = false;
 		return WHAMD_OK;
 	}
+	if (k == "shared_launches") {
+		t->device.set_shared_launches(v != "0");
+		t->uploaded = false;
+		return WHAMD_OK;
+	}
 	if (k == "arena_limit_bytes") {
 		t->device.set_arena_limit(std::strtoull(value, nullptr, 10));
 		t->uploaded = false;
 		return WHAMD_OK;
 	}
 	return fail(WHAMD_ERR_INVALID, "unknown option '" + k + "'");
+}
+}  // namespace
+
+whamd_status_t whamd_dptable_set_option(whamd_dptable* t, const char* key, const char* value) {
+	if (!t || !key || !value) return fail(WHAMD_ERR_INVALID, "null argument");
+	return apply_option(t, key, value);
 }
 
 whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uint32_t* recombcost, size_t n_recombcost,

@@ -54,6 +54,9 @@ public:
 	// Upper bound of the backtrace arena in bytes (0 = whatever free HBM allows).  A table whose records need more is
 	// solved in windows (the forward pass of every window but the newest runs twice); next upload().
 	void set_arena_limit(uint64_t bytes);
+	// The table will be solved together with many others (whamd_dptable_enqueue_many): a wide single-individual table then plans eight cells
+	// per thread and twelve local slots (half the wavefronts per table); next upload().
+	void set_shared_launches(bool v);
 
 private:
 	whamd_status_t enqueue_some_unguarded(const Problem& p, Solution& s, uint64_t budget, bool& done, std::string& msg);

@@ -482,11 +482,13 @@ struct DeviceTable::Impl {
 	int slot_l = 11;            // preferred number of local slots (lr + 6 .. lr + 9; pedigree runs: 6 - log2 T .. + 3, only when set explicitly)
 	bool slot_l_set = false;
 	int slot_lr = 2;            // reg slots: 4 cells per thread -> 8 waves per workgroup at 11 local slots (two waves per SIMD)
+	int slot_lr_used = 2;       // ... of the plan in use (the shared-launches layout takes 3)
 	std::vector<SlotBatchEntry> slot_entries;   // (pedigree runs: `pad` holds the run's index into splan.pextra)
 	SlotBatchEntry* d_slot_entries = nullptr;
 	uint64_t table_bytes = 0;   // pedigree slot runs: cost-form tables
 	BtJob* d_btjobs = nullptr;
 	uint32_t* d_job_scores = nullptr;
+	bool shared_hint = false;   // option shared_launches: the table will be solved together with many others (enqueue_many)
 	int max_lanes = 32;
 	size_t next_super = 0;  // cursor of the resumable enqueue
 	// Windowed solve (backtrace arena larger than what HBM can hold): the steps are cut into WINDOWS whose records fit the
@@ -599,6 +601,7 @@ void DeviceTable::set_slot_l(int l) { impl_->slot_l = std::max(2, std::min(l, 12
 void DeviceTable::set_slot_lr(int lr) { impl_->slot_lr = lr >= 3 ? 3 : (lr <= 1 ? 1 : 2); }
 
 void DeviceTable::set_arena_limit(uint64_t bytes) { impl_->arena_limit = bytes; }
+void DeviceTable::set_shared_launches(bool v) { impl_->shared_hint = v; }
 void DeviceTable::set_symmetry(int level) { impl_->symmetry = level < 0 ? 0 : (level > 2 ? 2 : level); }
 
 whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& msg) {
@@ -646,7 +649,13 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		HIP_TRY(hipMemGetInfo(&free_b, &total_b));
 	}
 	free_b += arena_idle_bytes(device);   // (taken below, or freed before this table's own arena is allocated)
-	m.use_slots = (m.path == "auto" || m.path == "slots") && !m.wide && plan_forward_slots(p, p.T > 1 ? (m.slot_l_set ? -m.slot_l : 0) : std::max(8, m.slot_l), m.symmetry, m.splan, m.slot_lr);
+	// A wide single-individual table (coverage >= 18: 128 and more workgroups per launch) that will share its launches with many others
+	// takes EIGHT cells per thread and twelve local slots: half the wavefronts per table and longer runs -- 24 coverage-20 tables
+	// 7.7 M columns/s instead of 6.4 M; alone the same table is slower that way (1.87 M against 2.26 M), and narrow tables gain nothing.
+	int slot_lr = m.slot_lr, slot_l = m.slot_l;
+	if (m.shared_hint && p.T == 1 && p.max_k >= 18 && !m.slot_l_set && m.slot_lr == 2) { slot_lr = 3; slot_l = 12; }
+	m.slot_lr_used = slot_lr;
+	m.use_slots = (m.path == "auto" || m.path == "slots") && !m.wide && plan_forward_slots(p, p.T > 1 ? (m.slot_l_set ? -m.slot_l : 0) : std::max(8, slot_l), m.symmetry, m.splan, slot_lr);
 	// pedigree slot runs keep their cost-form tables in HBM (slots.h): at most a quarter of what is free, else the older paths
 	if (m.use_slots && m.splan.ped && m.splan.table_words * 4ull > free_b / 4) m.use_slots = false;
 	m.table_bytes = m.use_slots && m.splan.ped ? m.splan.table_words * 4ull : 0ull;
@@ -1443,7 +1452,12 @@ void DeviceTable::Impl::launch_slot_run(const SlotBatchEntry& e, uint64_t& launc
 	const dim3 grid(1u << (run.g - run.half)), block(run.threads);
 	const bool dbg = m.dp.dbg != nullptr || m.dp.dbg_flags != 0;
 #define WHAMD_SLOT_LAUNCH(LRV, DBGV, SPECV) hipLaunchKernelGGL((slot_run<LRV, DBGV, SPECV>), grid, block, lds, m.run_stream, m.dp, run, e.prev, e.cur, e.score_out)
-	if (run.lr == 3) {
+	if (run.lr == 3 && (run.yflags & 1u)) {   // Y-form run, eight cells per thread
+#define WHAMD_SLOT_LAUNCH_Y3(DBGV, SPECV) hipLaunchKernelGGL((slot_run<3, DBGV, SPECV, true>), grid, block, lds, m.run_stream, m.dp, run, e.prev, e.cur, e.score_out)
+		if (dbg) { if (spec) WHAMD_SLOT_LAUNCH_Y3(true, true); else WHAMD_SLOT_LAUNCH_Y3(true, false); }
+		else { if (spec) WHAMD_SLOT_LAUNCH_Y3(false, true); else WHAMD_SLOT_LAUNCH_Y3(false, false); }
+#undef WHAMD_SLOT_LAUNCH_Y3
+	} else if (run.lr == 3) {
 		if (dbg) { if (spec) WHAMD_SLOT_LAUNCH(3, true, true); else WHAMD_SLOT_LAUNCH(3, true, false); }
 		else { if (spec) WHAMD_SLOT_LAUNCH(3, false, true); else WHAMD_SLOT_LAUNCH(3, false, false); }
 	} else if (run.lr == 1) {
@@ -1574,8 +1588,8 @@ whamd_status_t DeviceTable::enqueue_some_unguarded(const Problem& p, Solution& s
 		if (m.use_slots) {
 			if (ss.entry_count == 1) m.launch_slot_run(m.slot_entries[ss.entry_off], launches);
 			else if (ss.entry_count > 1) {
-				if (m.slot_lr == 1) hipLaunchKernelGGL(slot_batch<1>, dim3(ss.grid_x, ss.entry_count), dim3(ss.threads), ss.lds, m.stream, m.dp, m.d_slot_entries + ss.entry_off);
-				else if (m.slot_lr == 3) hipLaunchKernelGGL(slot_batch<3>, dim3(ss.grid_x, ss.entry_count), dim3(ss.threads), ss.lds, m.stream, m.dp, m.d_slot_entries + ss.entry_off);
+				if (m.slot_lr_used == 1) hipLaunchKernelGGL(slot_batch<1>, dim3(ss.grid_x, ss.entry_count), dim3(ss.threads), ss.lds, m.stream, m.dp, m.d_slot_entries + ss.entry_off);
+				else if (m.slot_lr_used == 3) hipLaunchKernelGGL(slot_batch<3>, dim3(ss.grid_x, ss.entry_count), dim3(ss.threads), ss.lds, m.stream, m.dp, m.d_slot_entries + ss.entry_off);
 				else hipLaunchKernelGGL(slot_batch<2>, dim3(ss.grid_x, ss.entry_count), dim3(ss.threads), ss.lds, m.stream, m.dp, m.d_slot_entries + ss.entry_off);
 				launches += 1;
 			}
@@ -1611,7 +1625,7 @@ whamd_status_t DeviceTable::enqueue_some_unguarded(const Problem& p, Solution& s
 bool DeviceTable::group_eligible(const Problem& p) const {
 	const Impl& m = *impl_;
 	if (p.n_cols == 0 || !m.use_slots || m.windowed || m.enqueue_open || m.dp.dbg || (m.dp.dbg_flags && m.splan.ped)) return false;
-	if (!m.splan.ped && m.slot_lr != 2) return false;   // (the group kernel exists for the default four cells per thread)
+	if (!m.splan.ped && m.slot_lr_used != 2 && m.slot_lr_used != 3) return false;   // (group kernels: four or eight cells per thread)
 	return getenv("WHAMD_NO_GROUP") == nullptr;
 }
 
@@ -1641,7 +1655,7 @@ whamd_status_t DeviceTable::enqueue_group(DeviceTable* const* tables, const Prob
 	};
 	std::vector<Part> parts(n_parts);
 	for (size_t i = 0; i < n_tables; ++i) parts[i % n_parts].members.push_back(i);
-	constexpr int NV = 6;   // kernel variants
+	constexpr int NV = 7;   // kernel variants (6: single individual, eight cells per thread)
 	for (Part& part : parts) { part.lead = tables[part.members[0]]->impl_; part.batches.resize(NV); }
 	auto abort_all = [&]() {
 		for (Part& part : parts) (void)hipStreamSynchronize(part.lead->stream);
@@ -1680,7 +1694,11 @@ whamd_status_t DeviceTable::enqueue_group(DeviceTable* const* tables, const Prob
 			case 2: hipLaunchKernelGGL((pedslot_group<2, 4>), grid, block, b.lds, stream, b.args); break;
 			case 3: hipLaunchKernelGGL((pedslot_group<4, 2>), grid, block, b.lds, stream, b.args); break;
 			case 4: hipLaunchKernelGGL((pedslot_group<4, 4>), grid, block, b.lds, stream, b.args); break;
-			default: hipLaunchKernelGGL((pedslot_group<2, 16>), grid, block, b.lds, stream, b.args); break;
+			case 5: hipLaunchKernelGGL((pedslot_group<2, 16>), grid, block, b.lds, stream, b.args); break;
+			default:
+				if (tight) hipLaunchKernelGGL((slot_group<3, false, true>), grid, block, b.lds, stream, b.args);
+				else hipLaunchKernelGGL((slot_group<3, false, false>), grid, block, b.lds, stream, b.args);
+				break;
 		}
 		b.args.n = 0;
 		b.grid_x = b.threads = 0;
@@ -1698,7 +1716,7 @@ whamd_status_t DeviceTable::enqueue_group(DeviceTable* const* tables, const Prob
 				const Impl::SuperStep& ss = m.schedule[k];
 				for (uint32_t q = 0; q < ss.entry_count; ++q) {
 					const SlotBatchEntry& he = m.slot_entries[ss.entry_off + q];
-					const int variant = m.splan.ped ? (he.ex.nf == 16 ? 5 : 1 + (he.ex.tb == 4 ? 2 : 0) + (he.ex.nf == 4 ? 1 : 0)) : 0;
+					const int variant = m.splan.ped ? (he.ex.nf == 16 ? 5 : 1 + (he.ex.tb == 4 ? 2 : 0) + (he.ex.nf == 4 ? 1 : 0)) : (he.run.lr == 3 ? 6 : 0);
 					Batch& b = part.batches[variant];
 					if (b.args.n == (uint32_t)SLOT_GROUP_MAX) {
 						flush(part, variant);

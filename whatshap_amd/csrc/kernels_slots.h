@@ -91,7 +91,7 @@ template <int LR, bool DBG, bool SPEC, bool YF = false>
 __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun& run, const uint32_t* __restrict__ prev,
                                               uint32_t* __restrict__ cur, const uint32_t w, uint32_t* score_out) {
 	constexpr int R = 1 << LR;
-	static_assert(!YF || LR == 2, "Y-form rows hold Kr[0..3]: four cells per thread");
+	static_assert(!YF || LR == 2 || LR == 3, "Y-form rows hold Kr[0 .. 2^LR): four or eight cells per thread");
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];   // wave-slot exchange: 2 x [threads][R]
 	const unsigned long long t_start = (DBG && P.dbg) ? __builtin_readcyclecounter() : 0ull;
 	const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -205,7 +205,7 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 
 	// What a column needs from LDS, requested one column ahead: {K, Cc, dreg0, dreg1} (+ dreg2), {info0, M0} of the first ending
 	// read (wave-uniform words in VECTOR registers: operands of the cell arithmetic as they are) and the thread's own A.
-	struct HotLine { uint4 a; uint32_t d2; uint2 e; uint32_t A; };
+	struct HotLine { uint4 a; uint4 b; uint32_t d2; uint2 e; uint32_t A; };   // (b: Kr[4..7] of a Y-form run with eight cells per thread)
 	// The lines are requested in column order, so three running word offsets (hot line, A of the wave, lane sum) advance by a constant
 	// per request: three adds instead of rebuilding each address from the column number (5 vector + 3 scalar instructions of the ~34 a
 	// plain column took).  They start from an opaque move: the compiler must not learn that the hot-line loads are wave-uniform, or it
@@ -220,7 +220,8 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 	auto load_hot = [&](const uint32_t k) -> HotLine {   // line k of the current trip (k = 0 .. 6: a line is requested three columns ahead)
 		HotLine h;
 		h.a = *reinterpret_cast<const uint4*>(hot_p + 16u * k);
-		h.d2 = LR > 2 ? hot_p[16u * k + 4u] : 0u;
+		h.d2 = (LR > 2 && !YF) ? hot_p[16u * k + 4u] : 0u;
+		if (YF && LR > 2) h.b = *reinterpret_cast<const uint4*>(hot_p + 16u * k + 4u);
 		h.e = *reinterpret_cast<const uint2*>(hot_p + 16u * k + 12u);
 		h.A = a_p[k] + sl_p[64u * k];
 		return h;
@@ -229,9 +230,9 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 	// cell arithmetic as they are; only what steers control flow (n_end, the ending read's slot) becomes scalar.
 	auto column = [&](const HotLine& h, const uint32_t ci, const uint32_t ctrl) {
 		if (YF) {
-			const uint32_t kr[4] = {h.a.x, h.a.y, h.a.z, h.a.w};
+			const uint32_t kr[8] = {h.a.x, h.a.y, h.a.z, h.a.w, h.b.x, h.b.y, h.b.z, h.b.w};
 #pragma unroll
-			for (int r = 0; r < R; ++r) D[r] = slot_y_sad(h.A, kr[r & 3], D[r]);
+			for (int r = 0; r < R; ++r) D[r] = slot_y_sad(h.A, kr[r & 7], D[r]);
 		} else {
 			const uint32_t K = h.a.x, Cc = h.a.y;
 			const uint32_t dr[SLOT_LR + 1] = {h.a.z, h.a.w, h.d2, 0u};
@@ -257,9 +258,12 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 				if (slot == 0) {
 #pragma unroll
 					for (int r = 0; r < R; ++r) other[r] = D[r ^ 1];
-				} else {
+				} else if (LR < 3 || slot == 1) {
 #pragma unroll
 					for (int r = 0; r < R; ++r) other[r] = D[r ^ (R > 2 ? 2 : 1)];
+				} else {
+#pragma unroll
+					for (int r = 0; r < R; ++r) other[r] = D[r ^ (R > 4 ? 4 : 1)];
 				}
 			} else if (slot < (uint32_t)(LR + SLOT_LANE)) {
 				const int src = (int)((lane ^ (1u << (slot - LR))) << 2);
@@ -267,11 +271,15 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 				for (int r = 0; r < R; ++r) other[r] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)D[r]);
 			} else {
 				uint32_t* xb = smem + xsel * xwords;
-				*reinterpret_cast<uint4*>(xb + tid * R) = make_uint4(D[0], D[1], D[R > 2 ? 2 : 0], D[R > 2 ? 3 : 0]);
+#pragma unroll
+				for (int q4 = 0; q4 < R / 4; ++q4) reinterpret_cast<uint4*>(xb + tid * R)[q4] = make_uint4(D[4 * q4], D[4 * q4 + 1], D[4 * q4 + 2], D[4 * q4 + 3]);
 				__syncthreads();
 				const uint32_t ptid = tid ^ (64u << (slot - LR - SLOT_LANE));
-				const uint4 t = *reinterpret_cast<const uint4*>(xb + ptid * R);
-				other[0] = t.x; other[1] = t.y; other[R > 2 ? 2 : 0] = t.z; other[R > 2 ? 3 : 0] = t.w;
+#pragma unroll
+				for (int q4 = 0; q4 < R / 4; ++q4) {
+					const uint4 t = reinterpret_cast<const uint4*>(xb + ptid * R)[q4];
+					other[4 * q4] = t.x; other[4 * q4 + 1] = t.y; other[4 * q4 + 2] = t.z; other[4 * q4 + 3] = t.w;
+				}
 			}
 			xsel ^= (uint32_t)(slot >= (uint32_t)(LR + SLOT_LANE));   // (outside the branches: a scalar update, no merge of branch values)
 			uint32_t takes = 0;
@@ -493,7 +501,7 @@ __global__ __launch_bounds__(256) void slot_tables(DevProblem P, const SlotRun* 
 			const uint32_t q = i - n_g - n_w, c = q >> 6, lane = q & 63u;
 			const SlotRow& row = rows[c];
 			uint32_t acc = 0;
-			for (uint32_t j = 0; j < (uint32_t)SLOT_LANE; ++j) acc += (uint32_t)row.dlane[j] & (0u - ((lane >> j) & 1u));
+			for (uint32_t j = 0; j < (uint32_t)SLOT_LANE; ++j) acc += (uint32_t)row.dslot[lr + j] & (0u - ((lane >> j) & 1u));   // (= dlane[j]; a Y-form row reuses those words)
 			tab[run.tab_sl + q] = acc << ysh;
 		}
 	}
@@ -524,7 +532,7 @@ __global__ __launch_bounds__(512) void slot_batch(DevProblem P, const SlotBatchE
 	}
 	const SlotRun run = e->run;
 	if (blockIdx.x >= (1u << (run.g - run.half)) || threadIdx.x >= run.threads) return;
-	if (LR == 2 && (run.yflags & 1u)) slot_run_body<2, false, false, true>(P, run, e->prev, e->cur, blockIdx.x, e->score_out);
+	if ((LR == 2 || LR == 3) && (run.yflags & 1u)) slot_run_body<(LR == 3 ? 3 : 2), false, false, true>(P, run, e->prev, e->cur, blockIdx.x, e->score_out);
 	else slot_run_body<LR, false, false>(P, run, e->prev, e->cur, blockIdx.x, e->score_out);
 }
 
@@ -563,15 +571,15 @@ __device__ __forceinline__ DevProblem slot_entry_problem(const SlotBatchEntry& e
 // launches that put more than three workgroups on a CU; the loose variant (101 SGPRs: three workgroups per CU) is 1.5 us faster per
 // launch when the group is a handful of narrow tables and every workgroup has a CU to itself.
 template <int LR, bool DBG = false, bool TIGHT = false>
-__global__ __launch_bounds__(512, TIGHT ? 8 : 2) void slot_group(SlotGroupArgs args) {
+__global__ __launch_bounds__(512, TIGHT ? (LR == 3 ? 6 : 8) : 2) void slot_group(SlotGroupArgs args) {
 	const SlotBatchEntry e = slot_scalar_copy(args.entry[blockIdx.y]);
 	const SlotRun& run = e.run;
 	if (blockIdx.x >= (1u << (run.g - run.half)) || threadIdx.x >= run.threads) return;
 	DevProblem P = slot_entry_problem(e, false);
 	if (DBG) P.dbg_flags = e.pad2;   // timing experiments (WHAMD_SLOT_SKIP: results invalid)
-	if (LR == 2 && (run.yflags & 1u)) {
-		if (run.spec_id) slot_run_body<2, DBG, true, true>(P, run, e.prev, e.cur, blockIdx.x, e.score_out);
-		else slot_run_body<2, DBG, false, true>(P, run, e.prev, e.cur, blockIdx.x, e.score_out);
+	if ((LR == 2 || LR == 3) && (run.yflags & 1u)) {
+		if (run.spec_id) slot_run_body<(LR == 3 ? 3 : 2), DBG, true, true>(P, run, e.prev, e.cur, blockIdx.x, e.score_out);
+		else slot_run_body<(LR == 3 ? 3 : 2), DBG, false, true>(P, run, e.prev, e.cur, blockIdx.x, e.score_out);
 	} else if (run.spec_id) slot_run_body<LR, DBG, true>(P, run, e.prev, e.cur, blockIdx.x, e.score_out);
 	else slot_run_body<LR, DBG, false>(P, run, e.prev, e.cur, blockIdx.x, e.score_out);
 }

@@ -99,11 +99,11 @@ bool emulate_slot_plan(const Problem& p, const SlotPlan& plan, std::vector<uint3
 			for (uint32_t P = 0; P < ncell; ++P) {
 				uint32_t A = row.Cp;
 				for (uint32_t s = LRr + SLOT_LANE; s < nslots; ++s) if (bit(P, s)) A += (uint32_t)row.dslot[s];
-				for (uint32_t s = 0; s < (uint32_t)SLOT_LANE; ++s) if (bit(P, LRr + s)) A += (uint32_t)row.dlane[s];
+				for (uint32_t s = 0; s < (uint32_t)SLOT_LANE; ++s) if (bit(P, LRr + s)) A += (uint32_t)row.dslot[LRr + s];   // (dlane duplicates these; a Y-form row reuses its words)
 				if (yf) {
-					if (LRr != 2) { msg = "a Y-form run must have two reg slots"; return false; }
-					const uint32_t kr[4] = {row.K, row.Cc, (uint32_t)row.dreg[0], (uint32_t)row.dreg[1]};
-					const uint32_t x0 = 2u * A + SLOT_YBIAS, k = kr[P & 3u];   // (A of the thread's cell 0: reg-slot bits not added)
+					if (LRr != 2 && LRr != 3) { msg = "a Y-form run has two or three reg slots"; return false; }
+					const uint32_t* kr = reinterpret_cast<const uint32_t*>(&row);   // Kr[0 .. 2^lr)
+					const uint32_t x0 = 2u * A + SLOT_YBIAS, k = kr[P & (R - 1u)];   // (A of the thread's cell 0: reg-slot bits not added)
 					D[P] += x0 > k ? x0 - k : k - x0;
 					continue;
 				}

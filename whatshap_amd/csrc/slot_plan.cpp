@@ -425,7 +425,7 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 	// B_c is the same for every cell of column c (the prefix sum below): min(A, K - A) = (K - |2A - K|) / 2, so a cell-column is ONE absolute
 	// difference accumulated into Y (v_sad_u32) instead of subtract, min3, add; minima become maxima, the tie rule keeps its form.
 	// Between two such runs the exchange column stays in Y form; at any other neighbour the run converts (D = (B - Y) / 2 exactly).
-	if (!ped && lr == 2 && !getenv("WHAMD_NO_YFORM")) {
+	if (!ped && (lr == 2 || lr == 3) && !getenv("WHAMD_NO_YFORM")) {
 		std::vector<uint8_t> pure(n, 0);
 		std::vector<uint64_t> B((size_t)n + 1, 0);   // B[c + 1] = base after column c
 		for (uint32_t c = 0; c < n; ++c) {
@@ -447,7 +447,7 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 			std::vector<uint8_t> yrun(plan.runs.size(), 0);
 			for (size_t ri = 0; ri < plan.runs.size(); ++ri) {
 				const SlotRun& run = plan.runs[ri];
-				bool ok = run.lr == 2;
+				bool ok = run.lr == 2 || run.lr == 3;
 				for (uint32_t i = 0; i < run.ncols && ok; ++i) ok = pure[run.c0 + i];
 				yrun[ri] = ok;
 			}
@@ -464,11 +464,15 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 				run.base_out = (uint32_t)B[run.c0 + run.ncols];
 				for (uint32_t i = 0; i < run.ncols; ++i) {
 					SlotRow& row = plan.rows[run.row_off + i];
-					const uint32_t K = row.K, d0 = (uint32_t)row.dreg[0], d1 = (uint32_t)row.dreg[1];
-					row.K = K + SLOT_YBIAS;                                  // Kr[0]
-					row.Cc = K - 2u * d0 + SLOT_YBIAS;                       // Kr[1]
-					row.dreg[0] = (int32_t)(K - 2u * d1 + SLOT_YBIAS);       // Kr[2]
-					row.dreg[1] = (int32_t)(K - 2u * (d0 + d1) + SLOT_YBIAS);   // Kr[3]
+					// Kr[r] = K - 2 * (sum of the reg-slot deltas set in r) + bias over the row's first 2^lr words (K, Cc, dreg[0..2], dlane[0..2]: the
+					// run kernel reads none of them in Y form; slot_tables takes the lane deltas from dslot)
+					const uint32_t K = row.K, dreg[3] = {(uint32_t)row.dreg[0], (uint32_t)row.dreg[1], (uint32_t)row.dreg[2]};
+					uint32_t* words = reinterpret_cast<uint32_t*>(&row);
+					for (uint32_t r = 0; r < (1u << run.lr); ++r) {
+						uint32_t dsum = 0;
+						for (uint32_t sb = 0; sb < run.lr; ++sb) if ((r >> sb) & 1u) dsum += dreg[sb];
+						words[r] = K - 2u * dsum + SLOT_YBIAS;
+					}
 				}
 			}
 		}
