@@ -259,6 +259,7 @@ whamd_status_t HeurBatch::enqueue(const HeurPlan* const* plans, size_t n, int de
 
 whamd_status_t HeurBatch::wait(HeurResult* outs, std::string& msg) {
 	Impl& m = *impl_;
+	if (!m.launched) { msg = "the batch was not enqueued"; return WHAMD_ERR_INVALID; }
 	HEUR_TRY(hipSetDevice(m.device));
 	float ms_total = 0;
 	for (;;) {

@@ -162,10 +162,9 @@ struct SlotBatchEntry {
 	const uint32_t* ctrl;            // DevProblem::slot_ctrl
 	uint8_t* bt;                     // the table's backtrace arena
 	unsigned long long* spec_keys;   // DevProblem::spec_keys
-	uint32_t spec_stride, pad2;
-	uint64_t pad3[8];
+	uint32_t spec_stride, pad2;      // pad2: WHAMD_SLOT_SKIP flags of a timing experiment (group launches)
 };
-static_assert(sizeof(SlotBatchEntry) == 384 && sizeof(SlotBatchEntry) % 64 == 0, "entries are fetched with wide scalar loads, whole 64-byte lines");
+static_assert(sizeof(SlotBatchEntry) == 320 && sizeof(SlotBatchEntry) % 64 == 0, "entries are fetched with wide scalar loads, whole 64-byte lines");
 
 // Kernel argument of a group launch: blockIdx.y selects the entry (a pointer into the owning table's own entry array -- the arrays are
 // built once per table at create time; a group launch only passes which of them take part).
