@@ -159,7 +159,9 @@ whamd_status_t whamd_dptable_create(const whamd_readset_view* readset, const uin
  * options (the keys of whamd_dptable_set_option) applied BEFORE the plan is made and uploaded: one upload instead of two.  What it is for: tables that will share their launches with many others (whamd_dptable_enqueue_many) do
  * better with eight cells per thread and twelve local slots when they are wide: "shared_launches" = "1" says so (the library applies the
  * layout to single-individual tables of coverage >= 18: half the wavefronts per table, 24 coverage-20 tables 7.7 M columns/s instead of
- * 6.4 M), while a table solved alone is faster with the default four cells (2.26 M against 1.87 M) and narrow tables gain nothing. */
+ * 6.4 M), while a table solved alone is faster with the default four cells (2.26 M against 1.87 M) and narrow tables gain nothing.
+ * "host_threads" = "n" (this call only): how many host threads the create may use -- a caller that creates many tables on threads of its
+ * own keeps each to a few. */
 whamd_status_t whamd_dptable_create_with_options(const whamd_readset_view* readset, const uint32_t* recombcost,
                                                  size_t n_recombcost, const whamd_pedigree_view* pedigree,
                                                  int distrust_genotypes, const uint32_t* positions, size_t n_positions,

@@ -7,7 +7,7 @@ from whatshap_amd.synthetic import synthetic_block
 n, cols, cov = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 problems = [synthetic_block(cols, cov, seed=100 + i) for i in range(n)]
 for rep in range(2):
-    for threads in (1, 4, 8, 16):
+    for threads in [int(x) for x in os.environ.get("WHAMD_E2E_THREADS", "1,4,8,16").split(",")]:
         t0 = time.perf_counter()
         with ThreadPoolExecutor(max_workers=threads) as pool:
             tables = list(pool.map(lambda p: _native.NativeTable(p, solve=False), problems))

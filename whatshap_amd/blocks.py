@@ -97,7 +97,7 @@ def split_independent_blocks(problem: ProblemArrays) -> List[Tuple[ProblemArrays
 
 
 def solve_blocks(problems: Sequence[ProblemArrays], device: int = 0, path=None, max_in_flight: int = 8,
-                 release: bool = True, devices: Sequence[int] = None, weights: Sequence[float] = None, create_threads: int = 4):
+                 release: bool = True, devices: Sequence[int] = None, weights: Sequence[float] = None, create_threads: int = 16):
     """Host-side work queue (BASELINE north_star: "independent phasing blocks shard across the GPUs of one node via a
     host-side work queue"; scheduling precedent: whatshap/polyphase/algorithm.py:101-128).
 
@@ -124,24 +124,35 @@ def solve_blocks(problems: Sequence[ProblemArrays], device: int = 0, path=None, 
 
         windows = [problems[start:start + max_in_flight] for start in range(0, len(problems), max_in_flight)]
         tables = []
-        with ThreadPoolExecutor(max_workers=max(1, min(create_threads, max_in_flight))) as pool:
-            def options_of(window):   # more than four tables per window share their launches: the library picks the layout for that
-                return {"shared_launches": "1"} if len(window) > 4 else None
+        n_workers = max(1, min(create_threads, max_in_flight))
+        with ThreadPoolExecutor(max_workers=n_workers) as pool:
+            def options_of(window):
+                opts = {}
+                if len(window) > 4:       # more than four tables per window share their launches: the library picks the layout for that
+                    opts["shared_launches"] = "1"
+                if n_workers > 1 and len(window) > 1:   # several creates at once: each keeps to two threads of its own (32 each would fight)
+                    opts["host_threads"] = "2"
+                return opts or None
 
-            def create(window):
-                return list(pool.map(lambda sub: NativeTable(sub, device=device, path=path, solve=False, options=options_of(window)), window))
+            def create(sub, opts):
+                return NativeTable(sub, device=device, path=path, solve=False, options=opts)
 
-            ready = create(windows[0]) if windows else []
+            def submit_window(window):
+                opts = options_of(window)
+                return [pool.submit(create, sub, opts) for sub in window]
+
+            pending = submit_window(windows[0]) if windows else []
+            releases = []
             for wi in range(len(windows)):
-                window = ready
+                window = [f.result() for f in pending]
                 enqueue_many(window)
-                pending = [pool.submit(NativeTable, sub, device, path, False, options_of(windows[wi + 1])) for sub in windows[wi + 1]] if wi + 1 < len(windows) else []
+                pending = submit_window(windows[wi + 1]) if wi + 1 < len(windows) else []   # built while the device solves this window
                 wait_many(window)
-                if release:
-                    for t in window:
-                        t.release_device()
+                if release:               # (stream synchronisation, buffers back to the pools: off the critical path)
+                    releases += [pool.submit(t.release_device) for t in window]
                 tables.extend(window)
-                ready = [f.result() for f in pending]
+            for f in releases:
+                f.result()
         return tables
 
     import threading

@@ -87,13 +87,19 @@ whamd_status_t create_table(const whamd_readset_view* readset, const uint32_t* r
 	const double t0 = now_ms();
 	std::unique_ptr<whamd_dptable> t(new whamd_dptable());
 	std::string msg;
+	// "host_threads": how many host threads THIS create may use (flatten, plan, staging copies); restored on every way out
+	struct ThreadsGuard { uint32_t saved = whamd::host_threads_override(); ~ThreadsGuard() { whamd::host_threads_override() = saved; } } threads_guard;
+	for (size_t i = 0; i < n_options; ++i) {
+		if (!keys[i] || !values[i]) return fail(WHAMD_ERR_INVALID, "null option");
+		if (std::string(keys[i]) == "host_threads") whamd::host_threads_override() = (uint32_t)std::max(0, std::atoi(values[i]));
+	}
 	whamd_status_t st = build_problem(readset, recombcost, n_recombcost, pedigree, distrust_genotypes != 0,
 	                                  positions, n_positions, t->problem, msg);
 	if (st != WHAMD_OK) return fail(st, msg);
 	const double t1 = now_ms();
 	t->device_index = device;
 	for (size_t i = 0; i < n_options; ++i) {   // before the (one) upload: the plan is made for them
-		if (!keys[i] || !values[i]) return fail(WHAMD_ERR_INVALID, "null option");
+		if (std::string(keys[i]) == "host_threads") continue;
 		st = apply_option(t.get(), keys[i], values[i]);
 		if (st != WHAMD_OK) return st;
 	}

@@ -1341,29 +1341,38 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	m.dp.T = p.T;
 	m.dp.tbits = tbits;
 	m.dp.n_ind = p.n_ind;
-	// kernels with more than 64 KiB of dynamic LDS need the opt-in on every device they run on
-	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_batch<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_batch<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(backtrace_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment_ped<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment_ped<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((resident_segment_ped<false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, 4, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, 4, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, 2, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, 2, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, 4, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, 4, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, 16, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, 16, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_group<2, 16>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_group<2, 2>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_group<2, 4>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_group<4, 2>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_group<4, 4>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	// kernels with more than 64 KiB of dynamic LDS need the opt-in on every device they run on -- once per process and device (23 driver calls
+	// per table were a tenth of a coverage-15 create when many tables are built at once)
+	{
+		static std::mutex attr_mu;
+		static unsigned long long attr_done = 0;   // bit = device
+		std::lock_guard<std::mutex> lock(attr_mu);
+		if (device >= 64 || !((attr_done >> device) & 1ull)) {
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_batch<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_batch<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(backtrace_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment_ped<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment_ped<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((resident_segment_ped<false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, 4, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, 4, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, 2, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, 2, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, 4, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, 4, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, 16, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, 16, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_group<2, 16>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_group<2, 2>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_group<2, 4>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_group<4, 2>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_group<4, 4>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+			if (device < 64) attr_done |= 1ull << device;
+		}
+	}
 	return WHAMD_OK;
 }
 

@@ -21,9 +21,16 @@ namespace whamd {
 
 // Host threads for `n_items` independent items, at least `grain` items per thread: min(hardware threads, 32), or what
 // WHAMD_PLAN_THREADS says (bench.py reports the create path at 8 threads and at the default).
+// (per calling thread: a create that runs beside many others -- blocks.solve_blocks builds a window's tables on a pool of host threads -- is told
+// to keep to a few threads of its own, option "host_threads" of whamd_dptable_create_with_options; 0 = no override)
+inline uint32_t& host_threads_override() {
+	static thread_local uint32_t value = 0;
+	return value;
+}
 inline uint32_t host_threads(uint64_t n_items, uint64_t grain) {
 	uint32_t n_threads = std::min<uint32_t>(std::max(1u, std::thread::hardware_concurrency()), 32u);
 	if (const char* e = getenv("WHAMD_PLAN_THREADS")) n_threads = (uint32_t)std::max(1, atoi(e));
+	if (host_threads_override()) n_threads = host_threads_override();
 	return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_threads, n_items / std::max<uint64_t>(grain, 1) + 1));
 }
 
