@@ -241,7 +241,6 @@ __global__ __launch_bounds__(512) void geno_slot_run(GsDev G, GsRun run, const d
 		for (uint32_t q = 0; q < nwaves; ++q) total += red[q];
 		inv = total > 0.0 ? 1.0 / total : 1.0;
 	}
-	const bool keep = DIR == 1 || G.fstore != nullptr;   // (windowed solve, first pass of the forward chain: only the exchange columns survive)
 	double* __restrict__ store = (DIR == 0 ? G.fstore : G.bstore) + run.store_off + (size_t)w * threads + tid;
 	const size_t col_stride = (size_t)threads << run.g;
 	uint32_t xsel = 0;
@@ -291,7 +290,7 @@ __global__ __launch_bounds__(512) void geno_slot_run(GsDev G, GsRun run, const d
 			const uint32_t n_end = gs_uni(cd.n_end), first = gs_uni(cd.first_of_table);
 			load_s(ci + 1 < ncols ? ci + 1 : ci, s_next);
 			if (!first) transition(rho_lds[ci]);
-			if (keep) store[(size_t)ci * col_stride] = val;   // sum_j A_{c-1}[back(x)][j] P(j -> i): what the likelihood sums need
+			store[(size_t)ci * col_stride] = val;   // sum_j A_{c-1}[back(x)][j] P(j -> i): what the likelihood sums need
 			val *= cell_sum(ci, s_cur);
 			for (uint32_t e = 0; e < n_end; ++e) sum_out(gs_uni(cd.end_slot[e]));
 #pragma unroll
@@ -602,7 +601,7 @@ whamd_status_t genotype_solve_slots(const Problem& p, const GenotypeModel& m, in
 	hipStream_t sf = nullptr, sb = nullptr, sc = nullptr;
 	GS_TRY(hipStreamCreateWithFlags(&sf, hipStreamNonBlocking)); keep.streams.push_back(sf);
 	GS_TRY(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking)); keep.streams.push_back(sb);
-	GS_TRY(hipStreamCreateWithFlags(&sc, hipStreamNonBlocking)); keep.streams.push_back(sc);
+	if (n_windows > 1 || getenv("WHAMD_GENO_PIECES")) { GS_TRY(hipStreamCreateWithFlags(&sc, hipStreamNonBlocking)); keep.streams.push_back(sc); }   // (likelihood sums beside the chains)
 	auto alloc = [&](void** dptr, size_t bytes) -> hipError_t {
 		hipError_t e = hipMalloc(dptr, std::max<size_t>(bytes, 16));
 		if (e == hipSuccess) keep.allocations.push_back(*dptr);
@@ -674,9 +673,9 @@ whamd_status_t genotype_solve_slots(const Problem& p, const GenotypeModel& m, in
 		const size_t waves = r.threads >> 6;
 		return ((size_t)2 * r.threads + waves * r.ncols * T * E + (size_t)r.ncols * T * A + ((r.ncols + 1) & ~1u) + 16) * 8 + (size_t)r.ncols * sizeof(GsCol);
 	};
-	auto with_stores = [&](size_t set, bool forward_keeps) {
+	auto with_stores = [&](size_t set) {
 		GsDev g = G;
-		g.fstore = forward_keeps ? (double*)d_fs + set * window_words : nullptr;
+		g.fstore = (double*)d_fs + set * window_words;
 		g.bstore = (double*)d_bs + set * window_words;
 		return g;
 	};
@@ -707,8 +706,9 @@ whamd_status_t genotype_solve_slots(const Problem& p, const GenotypeModel& m, in
 		// a k-th of the table on a third stream as soon as both chains have passed it, beside the rest of the chains.  Measured: no gain --
 		// the combine streams the stores at 3 TB/s and the chains slow down by what it saves: trio of 20 000 columns, chains 37 -> 54 ms,
 		// combine 24 -> 6 ms.  One piece after the chains is the default.)
-		const GsDev g = with_stores(0, true);
+		const GsDev g = with_stores(0);
 		size_t n_pieces = 1;
+		const bool third_stream = getenv("WHAMD_GENO_PIECES") != nullptr;
 		if (const char* e = getenv("WHAMD_GENO_PIECES")) n_pieces = std::max<size_t>(1, std::min<size_t>((size_t)atoi(e), std::max<size_t>(1, n_runs / 64)));
 		auto piece_lo = [&](size_t k) { return n_runs * k / n_pieces; };
 		std::vector<hipEvent_t> pf(n_pieces), pb(n_pieces);
@@ -737,19 +737,27 @@ whamd_status_t genotype_solve_slots(const Problem& p, const GenotypeModel& m, in
 			if (mid >= d) order.push_back(mid - d);
 			if (mid + d < n_pieces) order.push_back(mid + d);
 		}
+		// (one piece: on the forward chain's stream, which has just waited for the backward chain)
+		const hipStream_t cs = third_stream ? sc : sf;
 		for (size_t k : order) {
-			GS_TRY(hipStreamWaitEvent(sc, pf[k], 0));
-			GS_TRY(hipStreamWaitEvent(sc, pb[k], 0));
+			if (third_stream) {
+				GS_TRY(hipStreamWaitEvent(sc, pf[k], 0));
+				GS_TRY(hipStreamWaitEvent(sc, pb[k], 0));
+			}
 			const size_t r0 = piece_lo(k), r1 = piece_lo(k + 1);
 			GsWindow piece{r0, r1, 0, plan.runs[r0].c0, plan.runs[r1 - 1].c0 + plan.runs[r1 - 1].ncols};
-			launch_combine(piece, g, sc);
+			launch_combine(piece, g, cs);
 		}
-		hipEvent_t done = nullptr;
-		GS_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming)); keep.events.push_back(done);
-		GS_TRY(hipEventRecord(done, sc));
-		GS_TRY(hipStreamWaitEvent(sf, done, 0));
+		if (third_stream) {
+			hipEvent_t done = nullptr;
+			GS_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming)); keep.events.push_back(done);
+			GS_TRY(hipEventRecord(done, sc));
+			GS_TRY(hipStreamWaitEvent(sf, done, 0));
+		}
 	} else {
-		// pass 1: the whole forward chain; only the newest window keeps its columns; the exchange column entering every window is kept
+		// pass 1: the whole forward chain; the exchange column entering every window is kept.  Every window writes its columns into its set and
+		// only the newest window's survive: the store of the run kernel is unconditional (under a `keep` branch the counter wait at the join
+		// became a wait for the store itself, every column: 42 -> 48 ms for the chains of 50 000 columns)
 		const size_t last = n_windows - 1;
 		std::vector<hipEvent_t> ef(n_windows), eb(n_windows), ec(n_windows);
 		for (size_t w = 0; w < n_windows; ++w)
@@ -757,7 +765,7 @@ whamd_status_t genotype_solve_slots(const Problem& p, const GenotypeModel& m, in
 		for (size_t w = 0; w < n_windows; ++w) {
 			const GsWindow& wdw = windows[w];
 			if (w > 0) GS_TRY(hipMemcpyAsync((char*)d_check + (w - 1) * check_bytes, d_x[wdw.r0 & 1], check_bytes, hipMemcpyDeviceToDevice, sf));
-			const GsDev g = with_stores(w % 2, w == last);
+			const GsDev g = with_stores(w % 2);
 			for (size_t ri = wdw.r0; ri < wdw.r1; ++ri) launch_fwd(ri, g);
 		}
 		GS_TRY(hipGetLastError());
@@ -765,7 +773,7 @@ whamd_status_t genotype_solve_slots(const Problem& p, const GenotypeModel& m, in
 		// newest window first: (recompute the forward columns,) backward chain, likelihoods -- forward of window w - 1 beside backward / combine of w
 		for (size_t w = n_windows; w-- > 0;) {
 			const GsWindow& wdw = windows[w];
-			const GsDev g = with_stores(w % 2, true);
+			const GsDev g = with_stores(w % 2);
 			if (w != last) {
 				if (w + 2 < n_windows) GS_TRY(hipStreamWaitEvent(sf, ec[w + 2], 0));   // the stores of this set are free again
 				if (w > 0) GS_TRY(hipMemcpyAsync(d_x[wdw.r0 & 1], (char*)d_check + (w - 1) * check_bytes, check_bytes, hipMemcpyDeviceToDevice, sf));
@@ -790,7 +798,7 @@ whamd_status_t genotype_solve_slots(const Problem& p, const GenotypeModel& m, in
 	GS_TRY(hipMemcpyAsync(gl_out.data(), d_gl, gl_out.size() * 8, hipMemcpyDeviceToHost, sf));
 	GS_TRY(hipStreamSynchronize(sf));
 	GS_TRY(hipStreamSynchronize(sb));
-	GS_TRY(hipStreamSynchronize(sc));
+	if (sc) GS_TRY(hipStreamSynchronize(sc));
 #ifdef WHAMD_GENO_STAMPS
 	{
 		unsigned long long d[16];
