@@ -82,13 +82,39 @@ def test_not_for_a_single_individual():
 @pytest.mark.parametrize("kw", [dict(n_variants=60, coverage=6, seed=1, trio=True, distrust_genotypes=True),
                                 dict(n_variants=300, coverage=8, seed=2, trio=True, distrust_genotypes=True),
                                 dict(n_variants=200, coverage=9, seed=3, trio=True, distrust_genotypes=True, mixed_genotypes=True)], ids=str)
-def test_untrusted_genotypes_of_a_trio_on_sixteen_forms(kw):
-    """Genotypes not trusted: up to 15 distinct cost forms per transmission value (16 allele assignments, src/pedigreecolumncostcomputer.cpp:14-50)
-    -- runs with NF = 16: plan, tables, records and walk emulated on the CPU equal the oracle."""
+@pytest.mark.parametrize("factorised", [True, False], ids=["factorised", "sixteen-forms"])
+def test_untrusted_genotypes_of_a_trio_on_sixteen_forms(kw, factorised, monkeypatch):
+    """Genotypes not trusted: up to 15 distinct cost forms per transmission value (16 allele assignments, src/pedigreecolumncostcomputer.cpp:14-50).
+    Default: the FACTORISED line (slots.h PSLOT_FACT: the untransmitted alleles minimised out first, three sums + twelve constants, checked
+    against the generic term list when the problem is built); WHAMD_NO_PED_FACT: runs with NF = 16.  Plan, tables, records and walk emulated
+    on the CPU equal the oracle in both."""
+    if not factorised:
+        monkeypatch.setenv("WHAMD_NO_PED_FACT", "1")
     p = synthetic_block(**kw)
+    summary = _native.plan_summary(p, "slots")
+    assert summary["invariants_ok"] == 1
+    assert (summary["n_fact_runs"] == summary["n_runs"]) if factorised else (summary["n_fact_runs"] == 0), summary
     ok, run_columns = agrees(p)
     assert ok, kw
     assert run_columns > 0.8 * p.n_variants, (kw, run_columns)
+
+
+def test_factorised_lines_with_any_role_order_and_uneven_likelihoods():
+    """The child may be any of the three individuals: the roles (which founder transmits to which haplotype of the child, on which of the
+    founder's haplotypes the transmitted allele sits) are read off the haplotype-to-partition map, for genotype likelihoods that differ
+    per individual, genotype and column."""
+    rng = np.random.default_rng(5)
+    base = synthetic_block(n_variants=120, coverage=8, seed=11, trio=True, distrust_genotypes=True)
+    ids = [int(v) for v in base.individual_id]
+    for roles in ([0, 1, 2], [2, 0, 1], [1, 2, 0], [0, 2, 1]):   # (mother, father, child) as positions in individual_id
+        gl = rng.integers(0, 60, size=base.genotype_likelihoods.shape).astype(np.float64)
+        p = _native.ProblemArrays(base.read_ptr, base.var_position, base.var_allele, base.var_quality, base.read_sample_id, base.individual_id,
+                                  np.array([ids[r] for r in roles], dtype=np.uint32), base.genotype, gl, base.recombcost, base.positions, True,
+                                  n_variants=base.n_variants)
+        summary = _native.plan_summary(p, "slots")
+        assert summary["invariants_ok"] == 1 and summary["n_fact_runs"] == summary["n_runs"] > 0, (roles, summary)
+        ok, _ = agrees(p)
+        assert ok, roles
 
 
 def _trio_reads_problem(reads, n_variants, seed):

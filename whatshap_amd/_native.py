@@ -56,7 +56,7 @@ class PlanSummary(C.Structure):
     _fields_ = [(name, C.c_uint64) for name in (
         "n_columns", "n_steps", "n_runs", "n_resident_columns", "n_folded_columns", "n_vectorised_columns",
         "max_run_columns", "max_workgroups", "max_lds_bytes", "backtrace_bytes", "n_components", "n_halved_runs")] + [
-        ("max_coverage", C.c_uint32), ("invariants_ok", C.c_uint32), ("n_yform_runs", C.c_uint64)]
+        ("max_coverage", C.c_uint32), ("invariants_ok", C.c_uint32), ("n_yform_runs", C.c_uint64), ("n_fact_runs", C.c_uint64)]
 
     def as_dict(self) -> dict:
         return {name: getattr(self, name) for name, _ in self._fields_}

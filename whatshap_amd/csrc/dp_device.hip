@@ -678,7 +678,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 				fprintf(stderr, "[plan] slot run c0=%u ncols=%u g=%u L=%u half=%u ends=%u has_prev=%u in_identity=%u in_half=%u mirror_pos=%u in_occ=%x out_occ=%x mirror_out=%u\n",
 				        r.c0, r.ncols, r.g, r.L, r.half, r.n_ends, r.has_prev, r.in_identity, r.in_half, r.in_mirror_pos, r.in_occ, r.out_occ, r.mirror_out);
 				if (m.splan.ped) fprintf(stderr, "[plan]   pedigree run: T=%u forms per value=%u table words=%u record words per workgroup=%u\n", 1u << m.splan.pextra[st.index].tb,
-				                         m.splan.pextra[st.index].nf, m.splan.pextra[st.index].s_off + r.ncols * 64u * m.splan.pextra[st.index].nf, m.splan.pextra[st.index].rec_words);
+				                         m.splan.pextra[st.index].nf, m.splan.pextra[st.index].s_off + r.ncols * 64u * pslot_ns(m.splan.pextra[st.index].nf), m.splan.pextra[st.index].rec_words);
 				continue;
 			}
 			const ResSegment& sgm = m.plan.segments[st.index];
@@ -836,8 +836,8 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	const int32_t* delta_src = p.delta.data();
 	size_t delta_count = (size_t)p.col_ptr[n] * p.n_ind;
 	if (p.n_ind == 0) { delta_fallback.assign(std::max<size_t>(p.col_ptr[n], 1), 0); delta_src = delta_fallback.data(); delta_count = delta_fallback.size(); }
-	void *d_delta, *d_term_ptr, *d_terms, *d_segs, *d_bt, *d_keys, *d_last_keys, *d_rcol, *d_rbt;
-	stage.expect(m.cols.size() * sizeof(DevColumn) + delta_count * sizeof(int32_t) + term_ptr32.size() * 4 + terms.size() * sizeof(DevTerm) + segs.size() * 4 +
+	void *d_delta, *d_term_ptr, *d_terms, *d_segs, *d_bt, *d_keys, *d_last_keys, *d_rcol, *d_rbt, *d_fterms = nullptr;
+	stage.expect(m.cols.size() * sizeof(DevColumn) + delta_count * sizeof(int32_t) + term_ptr32.size() * 4 + (terms.size() + p.fterms.size()) * sizeof(DevTerm) + segs.size() * 4 +
 	             m.plan.columns.size() * (sizeof(ResColumn) + sizeof(ResBacktrace) + sizeof(PedColumn)) + m.plan.ped_terms.size() * sizeof(PedTerm) +
 	             (m.splan.rows.size() + SLOT_ROW_PAD) * sizeof(SlotRow) + m.splan.prows.size() * sizeof(PedSlotRow) + m.splan.bt_cols.size() * (sizeof(SlotBtCol) + 8) +
 	             m.splan.runs.size() * (sizeof(SlotRun) + sizeof(PedSlotExtra) + sizeof(BtUnit) + 64) + ((size_t)8 << 20));
@@ -845,6 +845,8 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	HIP_TRY(up(&d_delta, delta_src, delta_count * sizeof(int32_t)));
 	HIP_TRY(up(&d_term_ptr, term_ptr32.data(), term_ptr32.size() * sizeof(uint32_t)));
 	HIP_TRY(up(&d_terms, terms.data(), terms.size() * sizeof(DevTerm)));
+	static_assert(sizeof(CostTerm) == sizeof(DevTerm), "Problem::fterms is uploaded as it is");
+	if (!p.fterms.empty()) HIP_TRY(up(&d_fterms, p.fterms.data(), p.fterms.size() * sizeof(DevTerm)));   // factorised lines (pedslot_tables, PSLOT_FACT)
 	HIP_TRY(up(&d_segs, segs.data(), segs.size() * sizeof(uint32_t)));
 	HIP_TRY(up(&d_rcol, m.plan.columns.data(), m.plan.columns.size() * sizeof(ResColumn)));
 	HIP_TRY(up(&d_rbt, m.plan.backtrace.data(), m.plan.backtrace.size() * sizeof(ResBacktrace)));
@@ -1198,7 +1200,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 					ss.io[0] = lane.d_pr[c.flip]; ss.io[1] = lane.d_pr[c.flip ^ 1];
 					if (m.splan.ped) {
 						const PedSlotExtra& pex = m.splan.pextra[step.index];
-						ss.lds = std::max<size_t>(ss.lds, ((size_t)2 * e.run.threads + (PSLOT_MAXCOLS + 4) * 8 + (size_t)(e.run.threads >> 6) * (pex.arow + 4u * p.T * pex.nf) + (size_t)(e.run.ncols + 4) * 64 * pex.nf) * 4);
+						ss.lds = std::max<size_t>(ss.lds, pedslot_lds_bytes(e.run.threads, e.run.ncols, pex));
 					} else
 					ss.lds = std::max<size_t>(ss.lds, slot_run_lds_bytes(e.run.threads, e.run.lr, e.run.ncols));
 					e.pad = step.index;
@@ -1281,11 +1283,12 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		// the cost-form tables of every run (slots.h), once per table: blockIdx.y = run
 		uint32_t most = 0;
 		for (size_t ri = 0; ri < m.splan.runs.size(); ++ri)
-			most = std::max<uint32_t>(most, (m.splan.pextra[ri].fwn << m.splan.runs[ri].g) + (m.splan.pextra[ri].fwn << m.splan.runs[ri].lw) + m.splan.runs[ri].ncols * 64u * m.splan.pextra[ri].nf);
+			most = std::max<uint32_t>(most, (m.splan.pextra[ri].fwn << m.splan.runs[ri].g) + (m.splan.pextra[ri].fwn << m.splan.runs[ri].lw) + m.splan.runs[ri].ncols * (64u * pslot_ns(m.splan.pextra[ri].nf) + p.T * pslot_nk(m.splan.pextra[ri].nf)));
 		const uint32_t bx = std::max(1u, std::min(1024u, (most + 255u) / 256u));
 		for (size_t r0 = 0; r0 < m.splan.runs.size(); r0 += 32768) {   // (gridDim.y <= 65535)
 			const uint32_t ny = (uint32_t)std::min<size_t>(32768, m.splan.runs.size() - r0);
-			hipLaunchKernelGGL(pedslot_tables, dim3(bx, ny), dim3(256), 0, m.stream, m.dp, (const SlotRun*)d_pruns + r0, (const PedSlotExtra*)d_pextra + r0, (uint32_t*)d_ptab);
+			hipLaunchKernelGGL(pedslot_tables, dim3(bx, ny), dim3(256), 0, m.stream, m.dp, (const SlotRun*)d_pruns + r0, (const PedSlotExtra*)d_pextra + r0, (uint32_t*)d_ptab,
+			                   (const DevTerm*)d_fterms);
 		}
 		HIP_TRY(hipGetLastError());
 	}
@@ -1366,6 +1369,9 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, 16, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, 16, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_group<2, 16>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, PSLOT_FACT, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, PSLOT_FACT, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_group<2, PSLOT_FACT>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_group<2, 2>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_group<2, 4>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_group<4, 2>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1443,12 +1449,11 @@ void DeviceTable::Impl::launch_slot_run(const SlotBatchEntry& e, uint64_t& launc
 	const bool spec = run.spec_id != 0 && m.use_chunks && !getenv("WHAMD_NO_SPEC_KERNEL");
 	if (m.splan.ped) {
 		const PedSlotExtra& ex = m.splan.pextra[e.pad];
-		const uint32_t T = 1u << ex.tb;
-		// wave-slot exchange + hot lines + per-wave A rows + S (four columns of slack behind the rows: lines are requested ahead)
-		const size_t lds_ped = ((size_t)2 * run.threads + (PSLOT_MAXCOLS + 4) * 8 + (size_t)(run.threads >> 6) * (ex.arow + 4u * T * ex.nf) + (size_t)(run.ncols + 4) * 64 * ex.nf) * 4;
+		const size_t lds_ped = pedslot_lds_bytes(run.threads, run.ncols, ex);
 		const dim3 grid(1u << run.g), block(run.threads);
 #define WHAMD_PSLOT_LAUNCH(TBV, NFV, SPECV) hipLaunchKernelGGL((pedslot_run<TBV, NFV, SPECV>), grid, block, lds_ped, m.run_stream, m.dp, run, ex, e.prev, e.cur)
-		if (ex.tb == 2 && ex.nf == 16) { if (spec) WHAMD_PSLOT_LAUNCH(2, 16, true); else WHAMD_PSLOT_LAUNCH(2, 16, false); }
+		if (ex.tb == 2 && ex.nf == (uint32_t)PSLOT_FACT) { if (spec) WHAMD_PSLOT_LAUNCH(2, PSLOT_FACT, true); else WHAMD_PSLOT_LAUNCH(2, PSLOT_FACT, false); }
+		else if (ex.tb == 2 && ex.nf == 16) { if (spec) WHAMD_PSLOT_LAUNCH(2, 16, true); else WHAMD_PSLOT_LAUNCH(2, 16, false); }
 		else if (ex.tb == 2 && ex.nf == 2) { if (spec) WHAMD_PSLOT_LAUNCH(2, 2, true); else WHAMD_PSLOT_LAUNCH(2, 2, false); }
 		else if (ex.tb == 2) { if (spec) WHAMD_PSLOT_LAUNCH(2, 4, true); else WHAMD_PSLOT_LAUNCH(2, 4, false); }
 		else if (ex.nf == 2) { if (spec) WHAMD_PSLOT_LAUNCH(4, 2, true); else WHAMD_PSLOT_LAUNCH(4, 2, false); }
@@ -1664,7 +1669,7 @@ whamd_status_t DeviceTable::enqueue_group(DeviceTable* const* tables, const Prob
 	};
 	std::vector<Part> parts(n_parts);
 	for (size_t i = 0; i < n_tables; ++i) parts[i % n_parts].members.push_back(i);
-	constexpr int NV = 7;   // kernel variants (6: single individual, eight cells per thread)
+	constexpr int NV = 8;   // kernel variants (6: single individual, eight cells per thread; 7: trio, factorised lines)
 	for (Part& part : parts) { part.lead = tables[part.members[0]]->impl_; part.batches.resize(NV); }
 	auto abort_all = [&]() {
 		for (Part& part : parts) (void)hipStreamSynchronize(part.lead->stream);
@@ -1704,6 +1709,7 @@ whamd_status_t DeviceTable::enqueue_group(DeviceTable* const* tables, const Prob
 			case 3: hipLaunchKernelGGL((pedslot_group<4, 2>), grid, block, b.lds, stream, b.args); break;
 			case 4: hipLaunchKernelGGL((pedslot_group<4, 4>), grid, block, b.lds, stream, b.args); break;
 			case 5: hipLaunchKernelGGL((pedslot_group<2, 16>), grid, block, b.lds, stream, b.args); break;
+			case 7: hipLaunchKernelGGL((pedslot_group<2, PSLOT_FACT>), grid, block, b.lds, stream, b.args); break;
 			default:
 				if (tight) hipLaunchKernelGGL((slot_group<3, false, true>), grid, block, b.lds, stream, b.args);
 				else hipLaunchKernelGGL((slot_group<3, false, false>), grid, block, b.lds, stream, b.args);
@@ -1725,7 +1731,7 @@ whamd_status_t DeviceTable::enqueue_group(DeviceTable* const* tables, const Prob
 				const Impl::SuperStep& ss = m.schedule[k];
 				for (uint32_t q = 0; q < ss.entry_count; ++q) {
 					const SlotBatchEntry& he = m.slot_entries[ss.entry_off + q];
-					const int variant = m.splan.ped ? (he.ex.nf == 16 ? 5 : 1 + (he.ex.tb == 4 ? 2 : 0) + (he.ex.nf == 4 ? 1 : 0)) : (he.run.lr == 3 ? 6 : 0);
+					const int variant = m.splan.ped ? (he.ex.nf == (uint32_t)PSLOT_FACT ? 7 : (he.ex.nf == 16 ? 5 : 1 + (he.ex.tb == 4 ? 2 : 0) + (he.ex.nf == 4 ? 1 : 0))) : (he.run.lr == 3 ? 6 : 0);
 					Batch& b = part.batches[variant];
 					if (b.args.n == (uint32_t)SLOT_GROUP_MAX) {
 						flush(part, variant);

@@ -5,7 +5,8 @@
 //   D_c[x][i] = cost_{c,i}(x) (+) min_j ( Pr_{c-1}[x & lowmask][j] + popcount(i ^ j) * recomb_c ),  lowest j on ties (:264-300)
 //   Pr_c[y][i] = min over the cells x that project onto y, first in Gray-code order on ties (:306-327)
 // A lane holds ONE value: workgroup w, thread tid <-> cell (w << L) | (tid >> TB), transmission value tid & (T - 1).
-//   * cost: min over NF forms of A[wave][c][t][f] + S[c][lane][f] (tables of slots.h; absent forms are INF + 0);
+//   * cost: min over NF forms of A[wave][c][t][f] + S[c][lane][f] (tables of slots.h; absent forms are INF + 0); NF = PSLOT_FACT: the
+//     factorised line of a trio with untrusted genotypes -- three sums and twelve constants, slots.h;
 //   * min over j: butterfly over the TB low lane bits with DPP moves -- popcount(i ^ j) * recomb is a sum over the bits, bit s
 //     of the butterfly chooses between "j_s = i_s" (the value the lane holds) and "j_s != i_s" (the partner's + recomb); low
 //     bits first, and a tie keeps the candidate whose bit s is 0, so the surviving j is the lowest one;
@@ -14,32 +15,38 @@
 
 // ---- tables: G [2^g][fwn], W [2^lw][fwn], S [ncols][64][NF] per run; blockIdx.y = run
 __global__ __launch_bounds__(256) void pedslot_tables(DevProblem P, const SlotRun* __restrict__ runs, const PedSlotExtra* __restrict__ extras,
-                                                       uint32_t* __restrict__ tab) {
+                                                       uint32_t* __restrict__ tab, const DevTerm* __restrict__ fterms) {
 	const SlotRun& run = runs[blockIdx.y];
 	const PedSlotExtra& ex = extras[blockIdx.y];
-	const uint32_t TB = ex.tb, T = 1u << TB, NF = ex.nf, fwn = ex.fwn, L = run.L, nls = 6u - TB;
-	const uint32_t n_g = fwn << run.g, n_w = fwn << run.lw, n_s = run.ncols * 64u * NF;
+	const bool fact = ex.nf == (uint32_t)PSLOT_FACT;   // entries of the factorised line (Problem::fterms) instead of cost forms
+	const uint32_t TB = ex.tb, T = 1u << TB, NA = pslot_na(ex.nf), NS = pslot_ns(ex.nf), fwn = ex.fwn, L = run.L, nls = 6u - TB;
+	const uint32_t n_g = fwn << run.g, n_w = fwn << run.lw, n_s = run.ncols * 64u * NS, n_k = run.ncols * T * pslot_nk(ex.nf);
 	uint32_t* __restrict__ out = tab + (((unsigned long long)ex.g_hi << 32) | ex.g_lo);
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_g + n_w + n_s; i += gridDim.x * blockDim.x) {
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_g + n_w + n_s + n_k; i += gridDim.x * blockDim.x) {
 		uint32_t kind, unit, c, t, f;
+		if (i >= n_g + n_w + n_s) {   // K [c][t][12]: the constants of the factorised line (entries 4 .. 15 of the column's sixteen)
+			const uint32_t r = i - n_g - n_w - n_s;
+			out[i] = fterms[((size_t)run.c0 * T + r / PSLOT_NK) * 16u + 4u + r % PSLOT_NK].c;
+			continue;
+		}
 		if (i < n_g + n_w) {
 			kind = i < n_g ? 0u : 1u;
 			const uint32_t r = kind ? i - n_g : i;
 			unit = r / fwn;
 			const uint32_t q = r % fwn;   // [c][t][f]
-			c = q / (T * NF); t = (q / NF) % T; f = q % NF;
+			c = q / (T * NA); t = (q / NA) % T; f = q % NA;
 		} else {
 			kind = 2u;
 			const uint32_t r = i - n_g - n_w;   // [c][lane][f]
-			c = r / (64u * NF); unit = (r / NF) & 63u; f = r % NF;
+			c = r / (64u * NS); unit = (r / NS) & 63u; f = r % NS;
 			t = unit & (T - 1u);
 		}
 		const PedSlotRow& row = P.pslot_rows[run.row_off + c];
 		const DevColumn& col = P.cols[run.c0 + c];
 		const uint32_t q0 = P.term_ptr[col.term_off + t] + f, q1 = P.term_ptr[col.term_off + t + 1];
 		uint32_t acc = kind == 0u ? 0xFFFFFFFFu : 0u;   // absent form: INF + 0 + 0
-		if (q0 < q1) {
-			const DevTerm tm = P.terms[q0];
+		if (fact || q0 < q1) {
+			const DevTerm tm = fact ? fterms[((size_t)(run.c0 + c) * T + t) * 16u + f] : P.terms[q0];
 			acc = kind == 0u ? tm.c : 0u;
 			uint32_t s0, s1, bits;
 			if (kind == 0u) { s0 = L; s1 = L + run.g; bits = unit; }
@@ -52,7 +59,7 @@ __global__ __launch_bounds__(256) void pedslot_tables(DevProblem P, const SlotRu
 				else if ((tm.minus >> ind) & 1u) acc -= (uint32_t)row.dslot[s];
 			}
 		}
-		out[i] = acc;   // (W and S follow G at w_off = n_g and s_off = n_g + n_w)
+		out[i] = acc;   // (W and S follow G at w_off = n_g and s_off = n_g + n_w, K follows S)
 	}
 }
 
@@ -77,6 +84,8 @@ __device__ __forceinline__ void pedslot_run_body(const DevProblem& P, const Slot
                                                  uint32_t* __restrict__ cur, const uint32_t w) {
 	constexpr uint32_t T = 1u << TB;
 	constexpr int NLS = 6 - TB;   // lane slots
+	constexpr bool FACT = NF == PSLOT_FACT;          // the factorised line of a trio with untrusted genotypes (slots.h)
+	constexpr int NA = (int)pslot_na(NF), NS = (int)pslot_ns(NF), NK = (int)pslot_nk(NF);   // words per (column, value) of A, per (column, lane) of S, per (column, value) of K
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
 	const uint32_t tid = threadIdx.x, lane = tid & 63u;
 	const uint32_t wave = uni(tid >> 6);
@@ -84,10 +93,11 @@ __device__ __forceinline__ void pedslot_run_body(const DevProblem& P, const Slot
 	const uint32_t t = lane & (T - 1u);
 	const uint32_t lcell = tid >> TB;              // local cell index: wave << NLS | lane >> TB
 	const uint32_t Pcell = (w << L) | lcell;       // physical cell index
-	// LDS: wave-slot exchange 2 x [threads] | hot lines [PSLOT_MAXCOLS + 4][8] | A [waves][arow] | S [ncols + 4][64][NF]
+	// LDS: wave-slot exchange 2 x [threads] | hot lines [PSLOT_MAXCOLS + 4][8] | A [waves][arow] | S [ncols + 4][64][NS] | K [ncols + 4][T][NK]
 	uint32_t* hot_lds = smem + 2u * threads;
 	uint32_t* a_lds = hot_lds + (PSLOT_MAXCOLS + 4) * 8;
-	uint32_t* s_lds = a_lds + (threads >> 6) * (ex.arow + 4u * T * NF);
+	uint32_t* s_lds = a_lds + (threads >> 6) * (ex.arow + 4u * T * NA);
+	uint32_t* k_lds = s_lds + (ncols + 4u) * 64u * NS;
 	const uint32_t* __restrict__ tabG = P.pslot_tab + (((unsigned long long)ex.g_hi << 32) | ex.g_lo);
 	const PedSlotRow* __restrict__ rows = P.pslot_rows + run.row_off;
 
@@ -105,13 +115,16 @@ __device__ __forceinline__ void pedslot_run_body(const DevProblem& P, const Slot
 	}
 	// (3) S: the same for every workgroup
 	const uint4* __restrict__ tabS = reinterpret_cast<const uint4*>(tabG + ex.s_off);
-	const uint32_t n_s4 = ncols * 16u * NF;   // ncols * 64 * NF / 4
+	const uint32_t n_s4 = ncols * 16u * NS;   // ncols * 64 * NS / 4
 	uint4 sp[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
 #pragma unroll
 	for (int u = 0; u < 2; ++u) {
 		const uint32_t i = (uint32_t)u * threads + tid;
 		if (i < n_s4) sp[u] = tabS[i];
 	}
+	// (3b) K: the constants of the factorised lines, the same for every workgroup and wave (at most 32 * 4 * 12 words: one 16-byte piece per thread)
+	uint4 kp = make_uint4(0, 0, 0, 0);
+	if (FACT && tid < ncols * T * (NK / 4)) kp = reinterpret_cast<const uint4*>(tabG + ex.s_off + ncols * 64u * NS)[tid];
 	// (4) the entering value
 	uint32_t D = 0;
 	if (run.has_prev) {
@@ -126,7 +139,8 @@ __device__ __forceinline__ void pedslot_run_body(const DevProblem& P, const Slot
 		D = prev[(size_t)idx * T + t];
 	}
 	if (tid < ncols * 2u) reinterpret_cast<uint4*>(hot_lds)[tid] = hot_piece;
-	uint32_t* a_row = a_lds + wave * (ex.arow + 4u * T * NF);
+	if (FACT && tid < ncols * T * (NK / 4)) reinterpret_cast<uint4*>(k_lds)[tid] = kp;
+	uint32_t* a_row = a_lds + wave * (ex.arow + 4u * T * NA);
 #pragma unroll
 	for (int u = 0; u < 2; ++u) {
 		const uint32_t i = (uint32_t)u * 64u + lane;
@@ -151,11 +165,11 @@ __device__ __forceinline__ void pedslot_run_body(const DevProblem& P, const Slot
 
 	// What a column needs from LDS, requested ahead (LDS returns in order): {recomb, M0} of the hot line (wave-uniform words in
 	// VECTOR registers, see kernels_slots.h), the lane's NF entries of A and of S.
-	struct Line { uint2 h; uint32_t a[NF]; uint32_t s[NF]; };
-	const uint32_t a_base = wave * (ex.arow + 4u * T * NF) + t * NF;
+	struct Line { uint2 h; uint32_t a[NA]; uint32_t s[NS]; uint32_t k[NK > 0 ? NK : 1]; };
+	const uint32_t a_base = wave * (ex.arow + 4u * T * NA) + t * NA;
 	// (lines are requested in column order: three running word offsets advance by a constant per request -- kernels_slots.h; the one of
 	// the hot line starts from an opaque move so that the compiler does not learn that its loads are wave-uniform)
-	uint32_t hot_at = 0, a_at = a_base, s_at = lane * NF;
+	uint32_t hot_at = 0, a_at = a_base, s_at = lane * NS, k_at = t * NK;
 	asm volatile("" : "+v"(hot_at));
 	auto load_line = [&](uint32_t) -> Line {   // (the argument documents which column a call site requests: always the next one)
 		Line ln;
@@ -163,9 +177,17 @@ __device__ __forceinline__ void pedslot_run_body(const DevProblem& P, const Slot
 		const uint32_t* ap = a_lds + a_at;
 		const uint32_t* spn = s_lds + s_at;
 		hot_at += 8u;
-		a_at += T * NF;
-		s_at += 64u * NF;
-		if (NF == 2) {
+		a_at += T * NA;
+		s_at += 64u * NS;
+		if constexpr (FACT) {   // one 16-byte read of A, one of S, three of K
+			const uint4 av = *reinterpret_cast<const uint4*>(ap), sv = *reinterpret_cast<const uint4*>(spn);
+			ln.a[0] = av.x; ln.a[1] = av.y; ln.a[2] = av.z;
+			ln.s[0] = sv.x; ln.s[1] = sv.y; ln.s[2] = sv.z;
+			const uint4* kq = reinterpret_cast<const uint4*>(k_lds + k_at);
+			k_at += T * NK;
+#pragma unroll
+			for (int q = 0; q < 3; ++q) { const uint4 kv = kq[q]; ln.k[4 * q] = kv.x; ln.k[4 * q + 1] = kv.y; ln.k[4 * q + 2] = kv.z; ln.k[4 * q + 3] = kv.w; }
+		} else if (NF == 2) {
 			const uint2 av = *reinterpret_cast<const uint2*>(ap), sv = *reinterpret_cast<const uint2*>(spn);
 			ln.a[0] = av.x; ln.a[1] = av.y; ln.s[0] = sv.x; ln.s[1] = sv.y;
 		} else {
@@ -182,9 +204,19 @@ __device__ __forceinline__ void pedslot_run_body(const DevProblem& P, const Slot
 	auto column = [&](const Line& ln, const uint32_t ci, const uint32_t ctrl, const int sub) {
 		const uint32_t rc = ln.h.x;
 		// cost of this lane's (cell, transmission value)
-		uint32_t cost = ln.a[0] + ln.s[0];
+		uint32_t cost;
+		if constexpr (FACT) {   // (slots.h: the minimum over the sixteen allele assignments, the untransmitted alleles first; 19 operations)
+			const uint32_t X = ln.a[0] + ln.s[0], Y = ln.a[1] + ln.s[1], C = ln.a[2] + ln.s[2];
+			const uint32_t M0 = min(ln.k[0], ln.k[1] + X), M1 = min(ln.k[2], ln.k[3] - X);
+			const uint32_t F0 = min(ln.k[4], ln.k[5] + Y), F1 = min(ln.k[6], ln.k[7] - Y);
+			const uint32_t t00 = ln.k[8] + M0 + F0, t01 = ln.k[9] + C + M0 + F1;
+			const uint32_t t10 = ln.k[10] - C + M1 + F0, t11 = ln.k[11] + M1 + F1;
+			cost = min(min(t00, t01), min(t10, t11));
+		} else {
+			cost = ln.a[0] + ln.s[0];
 #pragma unroll
-		for (int f = 1; f < NF; ++f) cost = min(cost, ln.a[f] + ln.s[f]);
+			for (int f = 1; f < NF; ++f) cost = min(cost, ln.a[f] + ln.s[f]);
+		}
 		// min over the previous transmission value j, argmin = lowest j
 		uint32_t v = D, j = t;
 		if (TB >= 1) { const uint32_t pv = pslot_lane_xor<1>(v), pj = pslot_lane_xor<1>(j); const uint32_t cand = pslot_sat_add(pv, rc); const bool take = cand < pslot_sat_add(v, tbit[0]); v = take ? cand : v; j = take ? pj : j; }

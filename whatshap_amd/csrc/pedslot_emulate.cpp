@@ -50,9 +50,10 @@ uint32_t pedslot_table_entry(const Problem& p, const SlotPlan& plan, uint32_t ru
 	const PedSlotExtra& ex = plan.pextra[run_index];
 	const PedSlotRow& row = plan.prows[run.row_off + c];
 	const uint32_t col = run.c0 + c;
+	const bool fact = ex.nf == (uint32_t)PSLOT_FACT;   // entry f of the factorised line (Problem::fterms): always present
 	const uint64_t q = p.term_begin(col, t) + f;
-	if (q >= p.term_end(col, t)) return kind == 0 ? INF : 0u;   // absent form: INF + 0 + 0
-	const CostTerm& tm = p.terms[q];
+	if (!fact && q >= p.term_end(col, t)) return kind == 0 ? INF : 0u;   // absent form: INF + 0 + 0
+	const CostTerm& tm = fact ? p.fterms[((size_t)col * p.T + t) * 16 + f] : p.terms[q];
 	const uint32_t nls = 6u - ex.tb;
 	uint32_t acc = kind == 0 ? tm.c : 0u;
 	uint32_t s0, s1, bits;
@@ -152,6 +153,17 @@ bool emulate_pedslot_plan(const Problem& p, const SlotPlan& plan, std::vector<ui
 				for (uint32_t t = 0; t < T; ++t) {
 					const uint32_t tid = (l << TB) | t, lane = tid & 63u;
 					uint32_t cost = INF;
+					if (ex.nf == (uint32_t)PSLOT_FACT) {   // the factorised line, operation by operation as pedslot_run_body
+						uint32_t a[16], sl[4];
+						for (uint32_t f = 0; f < 4; ++f)
+							a[f] = pedslot_table_entry(p, plan, st.index, 0, w, ci, t, f) + pedslot_table_entry(p, plan, st.index, 1, wave, ci, t, f);
+						for (uint32_t f = 4; f < 16; ++f) a[f] = p.fterms[((size_t)(run.c0 + ci) * T + t) * 16 + f].c;   // K: the same for every cell
+						for (uint32_t f = 0; f < 4; ++f) sl[f] = pedslot_table_entry(p, plan, st.index, 2, lane, ci, t, f);
+						const uint32_t X = a[0] + sl[0], Y = a[1] + sl[1], C = a[2] + sl[2];
+						const uint32_t M0 = std::min(a[4], a[5] + X), M1 = std::min(a[6], a[7] - X);
+						const uint32_t F0 = std::min(a[8], a[9] + Y), F1 = std::min(a[10], a[11] - Y);
+						cost = std::min(std::min(a[12] + M0 + F0, a[13] + C + M0 + F1), std::min(a[14] - C + M1 + F0, a[15] + M1 + F1));
+					} else
 					for (uint32_t f = 0; f < ex.nf; ++f) {
 						const uint32_t a = pedslot_table_entry(p, plan, st.index, 0, w, ci, t, f) + pedslot_table_entry(p, plan, st.index, 1, wave, ci, t, f);
 						cost = std::min(cost, a + pedslot_table_entry(p, plan, st.index, 2, lane, ci, t, f));

@@ -42,6 +42,7 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 	if (!ped && !(p.T == 1 && p.n_ind == 1)) return false;
 	if (!genotype_mode && !(p.value_bound < 1073741824.0)) return false;
 	plan.ped = ped;
+	const bool fact = ped && !genotype_mode && TB == 2 && !p.fterms.empty();   // a trio with untrusted genotypes: factorised lines (PSLOT_FACT)
 	lr = ped ? 0 : std::max(1, std::min(lr, SLOT_LR));
 	const int n_lane = ped ? 6 - (int)TB : SLOT_LANE;
 	plan.col_to_row.assign(n, -1);
@@ -193,7 +194,7 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 					if (getenv("WHAMD_DEBUG_PLAN")) fprintf(stderr, "[plan] column %u: %u cost forms per transmission value: no pedigree run\n", c1, most);
 					break;
 				}
-				const uint32_t nf = std::max(run_forms, most > 4 ? 16u : (most > 2 ? 4u : 2u));
+				const uint32_t nf = fact ? pslot_na(PSLOT_FACT) : std::max(run_forms, most > 4 ? 16u : (most > 2 ? 4u : 2u));
 				if ((c1 - c + 1) * p.T * nf > (uint32_t)PSLOT_FORMWORDS) break;
 				run_forms = nf;
 			}
@@ -360,7 +361,8 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 					const uint32_t cnt = (uint32_t)(p.term_end(c + i, t) - p.term_begin(c + i, t));
 					ex.nf = std::max(ex.nf, cnt > 4 ? 16u : (cnt > 2 ? 4u : 2u));
 				}
-			ex.fwn = d.ncols * p.T * ex.nf;
+			if (fact) ex.nf = PSLOT_FACT;
+			ex.fwn = d.ncols * p.T * pslot_na(ex.nf);
 			ex.arow = (ex.fwn + 3u) & ~3u;
 			ex.rec_words = ((d.ncols + 3u) / 4u) * (64u << d.lw);
 			plan.pextra.push_back(ex);
@@ -491,7 +493,7 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 			const uint64_t gsz = ((uint64_t)1 << run.g) * ex.fwn;
 			ex.w_off = (uint32_t)gsz;
 			ex.s_off = (uint32_t)(gsz + ((uint64_t)1 << run.lw) * ex.fwn);
-			words += (uint64_t)ex.s_off + (uint64_t)run.ncols * 64u * ex.nf;
+			words += (uint64_t)ex.s_off + (uint64_t)run.ncols * 64u * pslot_ns(ex.nf) + (uint64_t)run.ncols * p.T * pslot_nk(ex.nf);
 		}
 		plan.table_words = words;
 	}

@@ -126,6 +126,16 @@ constexpr int PSLOT_MAXCOLS = 32;      // columns per run
 constexpr int PSLOT_MAXFORMS = 16;     // forms per transmission value a run can hold: NF = 2, 4, or 16 (a trio with untrusted genotypes:
                                        // 16 allele assignments, up to 15 distinct forms per value once the genotype likelihoods differ)
 constexpr int PSLOT_FORMWORDS = 1024;  // ncols * T * NF of one run (one row per wave in LDS)
+// NF = PSLOT_FACT: the FACTORISED line of a trio with untrusted genotypes (Problem::fterms): three signed sums {X_L, Y_L, C_L, 0} -- split
+// over workgroup / wave / lane like a form: G, W, S with four words per entry -- and twelve constants {kx[4], ky[4], cc[4]} per (column,
+// transmission value), the same for every cell: a fourth table K [ncols][T][12] behind S, staged once per workgroup.
+//   M_a = min(kx[2a], kx[2a+1] +- X_L),  F_b = min(ky[2b], ky[2b+1] +- Y_L),  cost = min over (a, b) of cc[2a+b] (+- C_L) + M_a + F_b
+// 19 operations per cell instead of 16 adds and 15 minima; a quarter of the per-wave and lane tables.
+constexpr int PSLOT_FACT = 1;
+constexpr uint32_t PSLOT_NK = 12;   // constants per (column, value) of a factorised line
+constexpr uint32_t pslot_na(uint32_t nf) { return nf == (uint32_t)PSLOT_FACT ? 4u : nf; }    // words per (column, value) of G / W / A
+constexpr uint32_t pslot_ns(uint32_t nf) { return nf == (uint32_t)PSLOT_FACT ? 4u : nf; }    // words per (column, lane) of S
+constexpr uint32_t pslot_nk(uint32_t nf) { return nf == (uint32_t)PSLOT_FACT ? PSLOT_NK : 0u; }   // words per (column, value) of K
 struct PedSlotRow {
 	// ---- hot: copied to LDS by the run kernel (8 words)
 	uint32_t recomb;
@@ -141,11 +151,17 @@ struct PedSlotRow {
 static_assert(sizeof(PedSlotRow) == 192, "PedSlotRow must stay 48 words");
 // Per run, next to its SlotRun (kernel argument by value).
 struct PedSlotExtra {
-	uint32_t tb, nf, fwn, arow;      // log2 T; forms per value; ncols * T * NF; fwn rounded up to 4 (row stride of A in LDS)
-	uint32_t g_lo, g_hi, w_off, s_off;   // word offsets into the table array: G [2^g][fwn]; W and S relative to G: [2^lw][fwn], [ncols][64][NF]
+	uint32_t tb, nf, fwn, arow;      // log2 T; forms per value (or PSLOT_FACT); ncols * T * pslot_na(nf); fwn rounded up to 4 (row stride of A in LDS)
+	uint32_t g_lo, g_hi, w_off, s_off;   // word offsets into the table array: G [2^g][fwn]; W and S relative to G: [2^lw][fwn], [ncols][64][pslot_ns(nf)] (then K [ncols][T][pslot_nk(nf)])
 	uint32_t rec_words, pad[3];      // record of one workgroup: one byte per thread and column, 4 columns per word: ceil(ncols / 4) * threads words
 };
 static_assert(sizeof(PedSlotExtra) == 48, "PedSlotExtra layout");
+// LDS of one pedigree run: wave-slot exchange 2 x [threads] | hot lines | A [waves][arow] | S [ncols][64][ns] | K [ncols][T][nk]  (four columns
+// of slack behind the rows of A, S and K: lines are requested ahead)
+inline size_t pedslot_lds_bytes(uint32_t threads, uint32_t ncols, const PedSlotExtra& ex) {
+	return ((size_t)2 * threads + (PSLOT_MAXCOLS + 4) * 8 + (size_t)(threads >> 6) * (ex.arow + (4u << ex.tb) * pslot_na(ex.nf)) + (size_t)(ncols + 4) * 64 * pslot_ns(ex.nf) +
+	        ((size_t)(ncols + 4) << ex.tb) * pslot_nk(ex.nf)) * 4;
+}
 
 // One run as a record in device memory: what slot_batch (the runs of ONE table's jobs) and slot_group / pedslot_group (the runs of
 // SEVERAL tables, one launch per super-step of the whole group) read instead of kernel arguments.  The entry carries the owning table's
