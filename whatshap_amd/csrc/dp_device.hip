@@ -705,8 +705,8 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	m.cols.resize(n);
 	std::vector<uint32_t> segs;
 	RawVec<uint32_t> term_ptr32((size_t)n * (p.T + 1));
-	std::vector<DevTerm> terms(p.terms.size());
-	for (size_t i = 0; i < p.terms.size(); ++i) terms[i] = DevTerm{p.terms[i].c, p.terms[i].plus, p.terms[i].minus};
+	static_assert(sizeof(CostTerm) == sizeof(DevTerm), "Problem::terms / fterms are uploaded as they are");
+	const RawVec<CostTerm>& terms = p.terms;
 	if (p.terms.size() >= 0xFFFFFFFFull || (uint64_t)p.col_ptr[n] * ni >= 0xFFFFFFFFull) {
 		msg = "problem too large for 32-bit device offsets";
 		return WHAMD_ERR_UNSUPPORTED;
@@ -845,7 +845,6 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	HIP_TRY(up(&d_delta, delta_src, delta_count * sizeof(int32_t)));
 	HIP_TRY(up(&d_term_ptr, term_ptr32.data(), term_ptr32.size() * sizeof(uint32_t)));
 	HIP_TRY(up(&d_terms, terms.data(), terms.size() * sizeof(DevTerm)));
-	static_assert(sizeof(CostTerm) == sizeof(DevTerm), "Problem::fterms is uploaded as it is");
 	if (!p.fterms.empty()) HIP_TRY(up(&d_fterms, p.fterms.data(), p.fterms.size() * sizeof(DevTerm)));   // factorised lines (pedslot_tables, PSLOT_FACT)
 	HIP_TRY(up(&d_segs, segs.data(), segs.size() * sizeof(uint32_t)));
 	HIP_TRY(up(&d_rcol, m.plan.columns.data(), m.plan.columns.size() * sizeof(ResColumn)));

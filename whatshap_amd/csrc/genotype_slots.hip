@@ -358,6 +358,7 @@ __global__ __launch_bounds__(256) void geno_slot_combine(GsDev G, const GsCombin
 	const GsCombineCol cc = ccols[c];
 	if (blockIdx.x >= cc.n_blocks) return;
 	__shared__ double red[4][T * A];
+	__shared__ __attribute__((aligned(16))) double gv[GS_COMBINE_LANES * 4u][T * E];   // G[workgroup] * V[wave] of the 32 (lane group, wave) pieces of this block
 	const GsCol cd = G.cols[c];
 	const uint32_t localmask = (1u << cc.L) - 1u;
 	const uint32_t n_lanes = cc.threads << cc.g;
@@ -379,6 +380,17 @@ __global__ __launch_bounds__(256) void geno_slot_combine(GsDev G, const GsCombin
 #pragma unroll
 		for (uint32_t q = 0; q < E; ++q) sw[q] = sp[q];
 	}
+	// the workgroup and wave parts of W: the same T x E numbers for the 64 lanes of a piece -- fetched once per block, coalesced, into LDS (as
+	// per-lane loads they were 2 E loads with four distinct addresses per piece and lane: the kernel waited on them, 24 ms for a trio's 42 GB)
+	for (uint32_t idx = threadIdx.x; idx < GS_COMBINE_LANES * 4u * T * E; idx += 256u) {
+		const uint32_t piece = idx / (T * E), q = idx % (T * E);
+		const uint32_t gt0 = ((blockIdx.x * GS_COMBINE_LANES + (piece >> 2)) * 4u + (piece & 3u)) * 64u;   // first lane of the piece
+		if (gt0 < n_lanes) {
+			const uint32_t w = gt0 / cc.threads, wave = (gt0 % cc.threads) >> 6;
+			gv[piece][q] = tab[((size_t)(w * cc.ncols + cc.ci) * T) * E + q] * tab[cc.v_off + ((size_t)(wave * cc.ncols + cc.ci) * T) * E + q];
+		}
+	}
+	__syncthreads();
 	double acc[A];
 #pragma unroll
 	for (uint32_t a = 0; a < A; ++a) acc[a] = 0.0;
@@ -386,12 +398,10 @@ __global__ __launch_bounds__(256) void geno_slot_combine(GsDev G, const GsCombin
 	for (uint32_t j = 0; j < GS_COMBINE_LANES; ++j) {
 		const uint32_t gt = (blockIdx.x * GS_COMBINE_LANES + j) * 256u + threadIdx.x;
 		if (gt >= n_lanes) continue;   // (wave-uniform: whole waves lie inside or outside the column)
-		const uint32_t w = gt / cc.threads, wave = (gt % cc.threads) >> 6;
-		const double* gp = tab + ((size_t)(w * cc.ncols + cc.ci) * T + i) * E;
-		const double* vp = tab + cc.v_off + ((size_t)(wave * cc.ncols + cc.ci) * T + i) * E;
+		const double2* gvp = reinterpret_cast<const double2*>(&gv[j * 4u + (threadIdx.x >> 6)][i * E]);
 		double W[E];
 #pragma unroll
-		for (uint32_t q = 0; q < E; ++q) W[q] = gp[q] * vp[q] * sw[q];
+		for (uint32_t q = 0; q < E; q += 2) { const double2 t2 = gvp[q / 2u]; W[q] = t2.x * sw[q]; W[q + 1] = t2.y * sw[q + 1]; }
 		double prod[A];
 		gs_products<P>(W, prod);
 #pragma unroll

@@ -325,39 +325,52 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 	// (h0, h1): (0,0) R, (1,1) W - R, (0,1) R + L, (1,0) W - R - L.  The minimum over a' and b' can be taken first:
 	//   min_{a,b} [ g_C[a+b] + cost_C(a,b) + min_{a'} (g_X[a+a'] + cost_X) + min_{b'} (g_Y[b+b'] + cost_Y) ].
 	// Which founder transmits to which haplotype of the child, and whether the transmitted allele sits on the founder's haplotype 0,
-	// is read off the haplotype-to-partition map of the transmission value; the construction is CHECKED against the generic term list of
-	// every (column, transmission value) -- same set of (L-dependence, smallest constant) -- and dropped for the table when it differs.
-	const bool want_fact = distrust && p.n_ind == 3 && p.P == 4 && p.T == 4 && !columns_only && !getenv("WHAMD_NO_PED_FACT");
-	if (want_fact) p.fterms.assign((size_t)n * p.T * 16, CostTerm{0, 0, 0});
-	auto factorised_terms = [&](uint32_t c, uint32_t t, const std::vector<uint32_t>& R, const std::vector<uint32_t>& W, const CostTerm* gen, size_t n_gen) -> bool {
+	// is read off the haplotype-to-partition map of the transmission value (FactRoles).  The construction is CHECKED, not trusted: for
+	// every (column, transmission value, allele assignment) the constant and the L-dependence it implies must equal the term the generic
+	// loop below computes; one difference and the table keeps the sixteen forms.
+	struct FactRoles {
+		int child = -1, X = -1, Y = -1;
+		bool oX = false, oY = false;              // the transmitted allele sits on the founder's haplotype 0
+		uint32_t bx = 0, bx2 = 0, by = 0, by2 = 0;   // allele bits: transmitted by X / X's other / transmitted by Y / Y's other
+		bool ok = false;
+	};
+	bool want_fact = distrust && p.n_ind == 3 && p.P == 4 && p.T == 4 && !columns_only && !getenv("WHAMD_NO_PED_FACT");
+	FactRoles roles[4];
+	for (uint32_t t = 0; t < 4 && want_fact; ++t) {
 		const int8_t* map = p.h2p.data() + (size_t)t * p.n_ind * 2;
 		const int8_t* map0 = p.h2p.data();
-		int child = -1;
+		FactRoles r;
+		int n_children = 0;
 		for (uint32_t s = 0; s < 3; ++s) {   // the child: the individual whose haplotypes change partition with the transmission value
 			bool varies = false;
 			for (uint32_t tt = 1; tt < p.T; ++tt) {
 				const int8_t* mt = p.h2p.data() + (size_t)tt * p.n_ind * 2;
 				varies = varies || mt[2 * s] != map0[2 * s] || mt[2 * s + 1] != map0[2 * s + 1];
 			}
-			if (varies) { if (child >= 0) return false; child = (int)s; }
+			if (varies) { r.child = (int)s; ++n_children; }
 		}
-		if (child < 0) return false;
-		int X = -1, Y = -1;
-		bool oX = false, oY = false;
-		for (uint32_t s = 0; s < 3; ++s) {
-			if ((int)s == child) continue;
+		int nx = 0, ny = 0;
+		for (uint32_t s = 0; s < 3 && n_children == 1; ++s) {
+			if ((int)s == r.child) continue;
 			for (int h = 0; h < 2; ++h) {
-				if (map[2 * s + h] == map[2 * child]) { if (X >= 0) return false; X = (int)s; oX = h == 0; }
-				if (map[2 * s + h] == map[2 * child + 1]) { if (Y >= 0) return false; Y = (int)s; oY = h == 0; }
+				if (map[2 * s + h] == map[2 * r.child]) { r.X = (int)s; r.oX = h == 0; r.bx = (uint32_t)map[2 * s + h]; r.bx2 = (uint32_t)map[2 * s + 1 - h]; ++nx; }
+				if (map[2 * s + h] == map[2 * r.child + 1]) { r.Y = (int)s; r.oY = h == 0; r.by = (uint32_t)map[2 * s + h]; r.by2 = (uint32_t)map[2 * s + 1 - h]; ++ny; }
 			}
 		}
-		if (X < 0 || Y < 0 || X == Y) return false;
+		r.ok = n_children == 1 && nx == 1 && ny == 1 && r.X != r.Y;
+		if (!r.ok) want_fact = false;
+		roles[t] = r;
+	}
+	if (want_fact) p.fterms.resize((size_t)n * p.T * 16);   // (every entry is written below)
+	// the sixteen entries of (c, t): three signed sums {X_L, Y_L, C_L, 0}, then kx[4], ky[4], cc[4]
+	auto factorised_line = [&](uint32_t c, uint32_t t, const std::vector<uint32_t>& R, const std::vector<uint32_t>& W) -> CostTerm* {
+		const FactRoles& r = roles[t];
 		auto g = [&](int s, uint32_t k) { return (uint32_t)(0.0 + p.gl[((size_t)s * p.n_variants + c) * 3 + k]); };   // (`cost += gls->get(genotype)` on an unsigned)
 		CostTerm* ft = p.fterms.data() + ((size_t)c * p.T + t) * 16;
 		auto signed_sum = [](int s, bool positive) { return positive ? CostTerm{0, 1u << s, 0} : CostTerm{0, 0, 1u << s}; };
-		ft[0] = signed_sum(X, oX);   // X_L = +-L_X: + when the transmitted allele is on X's haplotype 0
-		ft[1] = signed_sum(Y, oY);
-		ft[2] = signed_sum(child, true);
+		ft[0] = signed_sum(r.X, r.oX);   // X_L = +-L_X: + when the transmitted allele is on X's haplotype 0
+		ft[1] = signed_sum(r.Y, r.oY);
+		ft[2] = signed_sum(r.child, true);
 		ft[3] = CostTerm{0, 0, 0};
 		auto founder = [&](int s, bool o, CostTerm* k) {
 			k[0] = CostTerm{g(s, 0) + R[s], 0, 0};                       // a = 0, a' = 0
@@ -365,40 +378,24 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 			k[2] = CostTerm{g(s, 2) + W[s] - R[s], 0, 0};                // a = 1, a' = 1
 			k[3] = CostTerm{g(s, 1) + (o ? W[s] - R[s] : R[s]), 0, 0};    // a = 1, a' = 0: - X_L
 		};
-		founder(X, oX, ft + 4);
-		founder(Y, oY, ft + 8);
-		ft[12] = CostTerm{g(child, 0) + R[child], 0, 0};                 // (a, b) = (0, 0)
-		ft[13] = CostTerm{g(child, 1) + R[child], 0, 0};                 // (0, 1): + L_child
-		ft[14] = CostTerm{g(child, 1) + W[child] - R[child], 0, 0};      // (1, 0): - L_child
-		ft[15] = CostTerm{g(child, 2) + W[child] - R[child], 0, 0};      // (1, 1)
-		// ---- the check: expand into the 16 forms, merge equal L-dependences keeping the smallest constant, compare with the generic list
-		CostTerm ex[16];
-		size_t n_ex = 0;
-		for (uint32_t q = 0; q < 16; ++q) {
-			const uint32_t a = q & 1u, a2 = (q >> 1) & 1u, b = (q >> 2) & 1u, b2 = (q >> 3) & 1u;
-			CostTerm tm{0, 0, 0};
-			auto add_founder = [&](int s, bool o, const CostTerm* k, uint32_t tr, uint32_t other) {
-				tm.c += k[tr == 0 ? (other == 0 ? 0 : 1) : (other == 1 ? 2 : 3)].c;
-				if (tr == other) return;
-				const bool plus = (tr == 0) == o;   // (a, a') = (0, 1): + X_L = + L when o; (1, 0): - X_L
-				(plus ? tm.plus : tm.minus) |= 1u << s;
-			};
-			add_founder(X, oX, ft + 4, a, a2);
-			add_founder(Y, oY, ft + 8, b, b2);
-			tm.c += ft[12 + a * 2 + b].c;
-			if (a != b) (a == 0 ? tm.plus : tm.minus) |= 1u << child;
-			bool merged = false;
-			for (size_t i = 0; i < n_ex && !merged; ++i)
-				if (ex[i].plus == tm.plus && ex[i].minus == tm.minus) { ex[i].c = std::min(ex[i].c, tm.c); merged = true; }
-			if (!merged) ex[n_ex++] = tm;
-		}
-		if (n_ex != n_gen) return false;
-		for (size_t i = 0; i < n_ex; ++i) {
-			bool found = false;
-			for (size_t j = 0; j < n_gen && !found; ++j) found = gen[j].plus == ex[i].plus && gen[j].minus == ex[i].minus && gen[j].c == ex[i].c;
-			if (!found) return false;
-		}
-		return true;
+		founder(r.X, r.oX, ft + 4);
+		founder(r.Y, r.oY, ft + 8);
+		ft[12] = CostTerm{g(r.child, 0) + R[r.child], 0, 0};                   // (a, b) = (0, 0)
+		ft[13] = CostTerm{g(r.child, 1) + R[r.child], 0, 0};                   // (0, 1): + L_child
+		ft[14] = CostTerm{g(r.child, 1) + W[r.child] - R[r.child], 0, 0};      // (1, 0): - L_child
+		ft[15] = CostTerm{g(r.child, 2) + W[r.child] - R[r.child], 0, 0};      // (1, 1)
+		return ft;
+	};
+	// what the line implies for allele assignment `asg` (bits by partition, as the generic loop enumerates them)
+	auto factorised_form = [&](const CostTerm* ft, uint32_t t, uint32_t asg) -> CostTerm {
+		const FactRoles& r = roles[t];
+		const uint32_t a = (asg >> r.bx) & 1u, a2 = (asg >> r.bx2) & 1u, b = (asg >> r.by) & 1u, b2 = (asg >> r.by2) & 1u;
+		CostTerm tm{0, 0, 0};
+		tm.c = ft[4 + (a == 0 ? (a2 == 0 ? 0 : 1) : (a2 == 1 ? 2 : 3))].c + ft[8 + (b == 0 ? (b2 == 0 ? 0 : 1) : (b2 == 1 ? 2 : 3))].c + ft[12 + a * 2 + b].c;
+		if (a != a2) ((a == 0) == r.oX ? tm.plus : tm.minus) |= 1u << r.X;   // (a, a') = (0, 1): + X_L, which is + L_X when oX
+		if (b != b2) ((b == 0) == r.oY ? tm.plus : tm.minus) |= 1u << r.Y;
+		if (a != b) (a == 0 ? tm.plus : tm.minus) |= 1u << r.child;
+		return tm;
 	};
 	// deltas and cost terms of column c (its entries and indexing scheme are in place); false: Mendelian conflict
 	auto column_terms = [&](uint32_t c, RangeResult& out, std::vector<uint32_t>& R, std::vector<uint32_t>& W) -> bool {
@@ -426,6 +423,7 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 		for (uint32_t t = 0; t < p.T; ++t) {
 			const int8_t* map = p.h2p.data() + (size_t)t * p.n_ind * 2;
 			const size_t begin = out.terms.size();
+			const CostTerm* fline = (want_fact && out.fact_ok) ? factorised_line(c, t, R, W) : nullptr;
 			for (uint32_t a = 0; a < (1u << p.P); ++a) {  // src/pedigreecolumncostcomputer.cpp:25-49
 				bool compatible = true;
 				uint32_t acost = 0;
@@ -449,6 +447,10 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 				if (!compatible) continue;
 				term.c += acost;
 				max_acost = std::max(max_acost, (double)acost);
+				if (fline) {
+					const CostTerm pred = factorised_form(fline, t, a);
+					if (pred.c != term.c || pred.plus != term.plus || pred.minus != term.minus) { out.fact_ok = false; fline = nullptr; }
+				}
 				// a term with the same L-dependence and a constant that is not smaller can never be the strict minimum
 				bool dominated = false;
 				for (size_t q = begin; q < out.terms.size(); ++q) {
@@ -461,7 +463,6 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 				if (!dominated) out.terms.push_back(term);
 			}
 			if (out.terms.size() > begin) any = true;
-			if (want_fact && out.fact_ok) out.fact_ok = factorised_terms(c, t, R, W, out.terms.data() + begin, out.terms.size() - begin);
 			p.term_ptr[(size_t)c * p.T + t + 1] = out.terms.size();   // relative to the range; rebased below
 		}
 		if (!any) {  // every transmission value infeasible at every cell (src/pedigreedptable.cpp:301-303)
@@ -533,19 +534,26 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 		for (uint32_t t = 0; t < n_threads; ++t) p.max_k = std::max(p.max_k, parts[t].max_k);
 		lap("column entries, indexing scheme, deltas + cost terms");
 		if (columns_only) return WHAMD_OK;   // the genotyping path (genotype.cpp) has its own per-column model
+		std::vector<uint64_t> base(n_threads + 1, 0);
 		for (uint32_t t = 0; t < n_threads; ++t) {
 			if (parts[t].conflict) {
 				msg = "Error: Mendelian conflict";
 				return WHAMD_ERR_MENDELIAN_CONFLICT;
 			}
-			const uint64_t base = p.terms.size();
-			for (size_t i = (size_t)bounds[t] * p.T + 1; i <= (size_t)bounds[t + 1] * p.T; ++i) p.term_ptr[i] += base;
-			p.terms.insert(p.terms.end(), parts[t].terms.begin(), parts[t].terms.end());
+			base[t + 1] = base[t] + parts[t].terms.size();
 			bound += parts[t].bound;
 			if (!parts[t].fact_ok) p.fterms.clear();
 			p.n_cells += parts[t].n_cells;
 			p.algorithmic_bytes += parts[t].algorithmic_bytes;
 		}
+		// the term lists of the ranges, concatenated in column order (each range copies its own piece: 72 MB for an untrusted trio of 100 000 columns)
+		p.terms.resize(base[n_threads]);
+		parallel_ranges(n_threads, n_threads, [&](uint64_t t0, uint64_t t1, uint32_t) {
+			for (uint64_t t = t0; t < t1; ++t) {
+				for (size_t i = (size_t)bounds[t] * p.T + 1; i <= (size_t)bounds[t + 1] * p.T; ++i) p.term_ptr[i] += base[t];
+				if (!parts[t].terms.empty()) std::memcpy(p.terms.data() + base[t], parts[t].terms.data(), parts[t].terms.size() * sizeof(CostTerm));
+			}
+		});
 	}
 	lap("term lists joined");
 	p.value_bound = bound;

@@ -72,11 +72,11 @@ struct Problem {
 	std::vector<uint32_t> fwd_mask;      // per column: bits of reads that continue into the next column
 	// cost terms per (column, transmission value)
 	std::vector<uint64_t> term_ptr;  // [n_cols * T + 1] offsets into terms
-	std::vector<CostTerm> terms;
+	RawVec<CostTerm> terms;
 	// A trio whose genotypes are not trusted: the minimum over the 16 allele assignments of a transmission value factorises over the
 	// individuals (build_problem; kernels_pedslots.h PSLOT_FACT) -- 16 entries per (column, transmission value): three signed sums
 	// {L_X, L_Y, L_child, 0} and twelve constants.  Empty when the table is not of that shape.
-	std::vector<CostTerm> fterms;    // [n_cols * T * 16]
+	RawVec<CostTerm> fterms;         // [n_cols * T * 16]
 	// per column and individual: signed per-bit deltas d (REF +q, ALT -q, BLANK 0) of L_s(x) - R_s
 	RawVec<int32_t> delta;  // [col_ptr[c] * n_ind ... ): for column c, delta[(col_ptr[c] * n_ind) + s * k_c + bit]
 	uint32_t max_k = 0;
