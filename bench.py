@@ -907,7 +907,7 @@ def main():
                 t.release_device()
             problems = [build_block(args, *blocks[b]) for b in mine]
             best = None
-            for window in sorted({min(len(problems), w) for w in (6, 8, 12, args.in_flight)}):
+            for window in sorted({min(len(problems), w) for w in (8, 12, args.in_flight)}):
                 te0 = time.perf_counter()
                 solved = solve_blocks(problems, device=device, path=None if args.path == "auto" else args.path, max_in_flight=window, release=True, create_threads=16)
                 checksum = 0

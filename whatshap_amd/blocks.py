@@ -97,14 +97,19 @@ def split_independent_blocks(problem: ProblemArrays) -> List[Tuple[ProblemArrays
 
 
 def solve_blocks(problems: Sequence[ProblemArrays], device: int = 0, path=None, max_in_flight: int = 8,
-                 release: bool = True, devices: Sequence[int] = None, weights: Sequence[float] = None, create_threads: int = 16):
+                 release: bool = True, devices: Sequence[int] = None, weights: Sequence[float] = None, create_threads: int = 16,
+                 windows_on_device: int = 1, trace: list = None, eager_create: bool = False):
     """Host-side work queue (BASELINE north_star: "independent phasing blocks shard across the GPUs of one node via a
     host-side work queue"; scheduling precedent: whatshap/polyphase/algorithm.py:101-128).
 
     One device (``devices`` None): solves independent blocks ``max_in_flight`` at a time through
     ``whamd_dptable_enqueue_many`` -- tables on slot runs share their launches (one launch per super-step serves the whole
     window: a coverage-15 table alone is 8 workgroups on 256 CUs), up to four full-width tables keep their own streams --
-    while ``create_threads`` host threads build the tables of the next window.
+    while ``create_threads`` host threads build the tables of the next window.  ``windows_on_device=2`` collects a window only after
+    the next one has been submitted and ``eager_create`` queues every create at once; both were measured (scripts/gpu_e2e_trace.py,
+    24 coverage-15 tables) and gain nothing on a 32-thread host: a window costs about 35 ms from enqueue to collect whatever its size
+    (the length of the launch sequence) and the creates are bound by the host's cores (24 of them: 35 ms), so one window of
+    everything is the fastest schedule there.  ``trace``: a list that receives (event, window, ms) tuples.
 
     Several devices (``devices=[0, 1, ...]``; an index may repeat: two workers on one device): the blocks are assigned
     longest-processing-time-first to the least loaded device (``assign_blocks``; ``weights`` defaults to the number of
@@ -141,16 +146,40 @@ def solve_blocks(problems: Sequence[ProblemArrays], device: int = 0, path=None, 
                 opts = options_of(window)
                 return [pool.submit(create, sub, opts) for sub in window]
 
-            pending = submit_window(windows[0]) if windows else []
+            all_pending = [submit_window(w) for w in windows] if eager_create else None   # every create queued at once, in table order
+            pending = (all_pending[0] if eager_create else submit_window(windows[0])) if windows else []
             releases = []
+            in_flight = None              # the window submitted before this one: collected AFTER the next one is on the device
+
+            def collect(window):
+                wait_many(window)         # (device + the host-side result extraction, on several threads)
+                if release:               # (stream synchronisation, buffers back to the pools: off the critical path)
+                    releases.extend(pool.submit(t.release_device) for t in window)
+                tables.extend(window)
+
+            import time
+            t_begin = time.perf_counter()
+
+            def mark(what, wi):
+                if trace is not None:
+                    trace.append((what, wi, (time.perf_counter() - t_begin) * 1e3))
+
             for wi in range(len(windows)):
                 window = [f.result() for f in pending]
-                enqueue_many(window)
-                pending = submit_window(windows[wi + 1]) if wi + 1 < len(windows) else []   # built while the device solves this window
-                wait_many(window)
-                if release:               # (stream synchronisation, buffers back to the pools: off the critical path)
-                    releases += [pool.submit(t.release_device) for t in window]
-                tables.extend(window)
+                mark("created", wi)
+                enqueue_many(window)      # queued behind (and beside) the previous window: the device never waits for the host
+                mark("enqueued", wi)
+                pending = ((all_pending[wi + 1] if eager_create else submit_window(windows[wi + 1])) if wi + 1 < len(windows) else [])   # built while the device solves
+                if windows_on_device < 2:
+                    collect(window)
+                    mark("collected", wi)
+                    continue
+                if in_flight is not None:
+                    collect(in_flight)
+                    mark("collected", wi - 1)
+                in_flight = window
+            if in_flight is not None:
+                collect(in_flight)
             for f in releases:
                 f.result()
         return tables
