@@ -361,18 +361,19 @@ __global__ __launch_bounds__(256) void geno_slot_combine(GsDev G, const GsCombin
 	__shared__ __attribute__((aligned(16))) double gv[GS_COMBINE_LANES * 4u][T * E];   // G[workgroup] * V[wave] of the 32 (lane group, wave) pieces of this block
 	const GsCol cd = G.cols[c];
 	const uint32_t localmask = (1u << cc.L) - 1u;
-	const uint32_t n_lanes = cc.threads << cc.g;
+	const uint32_t n_lanes = cc.threads << cc.g, tshift = 31u - (uint32_t)__clz((int)cc.threads);
 	const double* __restrict__ tab = G.tab + cc.tab_off;
 	const size_t col_at = cc.store_off + (size_t)cc.ci * n_lanes;
 	const uint32_t lane = threadIdx.x & 63u, i = lane & (T - 1u);
-	// all the loads of the thread's lanes first: one memory round trip
-	double fb[GS_COMBINE_LANES];
+	// all the loads of the thread's lanes first: one memory round trip.  UNCONDITIONAL loads (the address clamped into the column, the value
+	// dropped afterwards): under `counts ? load : 0` every pair of loads sat in its own branch with a wait behind it -- eight round trips in a row.
+	double fv[GS_COMBINE_LANES], bv[GS_COMBINE_LANES], fb[GS_COMBINE_LANES];
 #pragma unroll
 	for (uint32_t j = 0; j < GS_COMBINE_LANES; ++j) {
 		const uint32_t gt = (blockIdx.x * GS_COMBINE_LANES + j) * 256u + threadIdx.x;   // lane of the column: workgroup * threads + tid
-		const uint32_t lcell = (gt % cc.threads) >> TB;
-		const bool counts = gt < n_lanes && (lcell & ~cd.active & localmask) == 0u;   // one lane per DISTINCT cell: free-slot bits zero
-		fb[j] = counts ? G.fstore[col_at + gt] * G.bstore[col_at + gt] : 0.0;
+		const size_t at = col_at + (gt < n_lanes ? gt : 0u);
+		fv[j] = G.fstore[at];
+		bv[j] = G.bstore[at];
 	}
 	double sw[E];   // the lane part of W is the same for all of the thread's lanes
 	{
@@ -382,15 +383,33 @@ __global__ __launch_bounds__(256) void geno_slot_combine(GsDev G, const GsCombin
 	}
 	// the workgroup and wave parts of W: the same T x E numbers for the 64 lanes of a piece -- fetched once per block, coalesced, into LDS (as
 	// per-lane loads they were 2 E loads with four distinct addresses per piece and lane: the kernel waited on them, 24 ms for a trio's 42 GB)
-	for (uint32_t idx = threadIdx.x; idx < GS_COMBINE_LANES * 4u * T * E; idx += 256u) {
-		const uint32_t piece = idx / (T * E), q = idx % (T * E);
-		const uint32_t gt0 = ((blockIdx.x * GS_COMBINE_LANES + (piece >> 2)) * 4u + (piece & 3u)) * 64u;   // first lane of the piece
-		if (gt0 < n_lanes) {
-			const uint32_t w = gt0 / cc.threads, wave = (gt0 % cc.threads) >> 6;
-			gv[piece][q] = tab[((size_t)(w * cc.ncols + cc.ci) * T) * E + q] * tab[cc.v_off + ((size_t)(wave * cc.ncols + cc.ci) * T) * E + q];
+	{
+		constexpr uint32_t N_GV = GS_COMBINE_LANES * 4u * T * E, PER = (N_GV + 255u) / 256u;
+		double gq[PER], vq[PER];
+#pragma unroll
+		for (uint32_t u = 0; u < PER; ++u) {   // (loads first, unconditional: a piece beyond the column reads the column's first one)
+			const uint32_t idx = u * 256u + threadIdx.x, piece = (idx / (T * E)) % (GS_COMBINE_LANES * 4u), q = idx % (T * E);
+			const uint32_t gt0 = ((blockIdx.x * GS_COMBINE_LANES + (piece >> 2)) * 4u + (piece & 3u)) * 64u;   // first lane of the piece
+			const uint32_t g0 = gt0 < n_lanes ? gt0 : 0u;
+			const uint32_t w = g0 >> tshift, wave = (g0 & (cc.threads - 1u)) >> 6;
+			gq[u] = tab[((size_t)(w * cc.ncols + cc.ci) * T) * E + q];
+			vq[u] = tab[cc.v_off + ((size_t)(wave * cc.ncols + cc.ci) * T) * E + q];
+		}
+#pragma unroll
+		for (uint32_t u = 0; u < PER; ++u) {
+			const uint32_t idx = u * 256u + threadIdx.x;
+			if (idx < N_GV) gv[idx / (T * E)][idx % (T * E)] = gq[u] * vq[u];
 		}
 	}
 	__syncthreads();
+	// (the stored values are first used here, behind the table loads: everything above is one memory round trip)
+#pragma unroll
+	for (uint32_t j = 0; j < GS_COMBINE_LANES; ++j) {
+		const uint32_t gt = (blockIdx.x * GS_COMBINE_LANES + j) * 256u + threadIdx.x;
+		const uint32_t lcell = (gt & (cc.threads - 1u)) >> TB;   // (threads = 64 << lw: a power of two)
+		const bool counts = gt < n_lanes && (lcell & ~cd.active & localmask) == 0u;   // one lane per DISTINCT cell: free-slot bits zero
+		fb[j] = counts ? fv[j] * bv[j] : 0.0;
+	}
 	double acc[A];
 #pragma unroll
 	for (uint32_t a = 0; a < A; ++a) acc[a] = 0.0;
