@@ -184,54 +184,121 @@ __global__ __launch_bounds__(512) void geno_slot_run(GsDev G, GsRun run, const d
 	double* red = rho_lds + ((ncols + 1u) & ~1u);
 	GsCol* col_lds = reinterpret_cast<GsCol*>(red + 16);
 	const double* __restrict__ tabG = G.tab + run.tab_off;
-	// ---- prologue: tables, priors, descriptors, the entering value, the scale of the entering column
-	{
-		const uint32_t per_wave = ncols * T * E;   // A = G[w] * V[wave]
-		const double* __restrict__ g = tabG + (size_t)w * per_wave;
-		const double* __restrict__ v = tabG + run.v_off + (size_t)wave * per_wave;
-		for (uint32_t q0 = 0; q0 < per_wave; q0 += 512u) {   // eight loads in flight per lane before the first is used
-			double gv[8], vv[8];
-#pragma unroll
-			for (uint32_t u = 0; u < 8; ++u) {
-				const uint32_t q = q0 + u * 64u + lane;
-				gv[u] = q < per_wave ? g[q] : 0.0;
-				vv[u] = q < per_wave ? v[q] : 0.0;
-			}
-#pragma unroll
-			for (uint32_t u = 0; u < 8; ++u) {
-				const uint32_t q = q0 + u * 64u + lane;
-				if (q < per_wave) a_lds[(size_t)wave * per_wave + q] = gv[u] * vv[u];
-			}
-		}
-		const double* __restrict__ pr = G.prior + (size_t)run.c0 * T * A;
-		for (uint32_t q = tid; q < ncols * T * A; q += threads) pr_lds[q] = pr[q];
-		for (uint32_t q = tid; q < ncols; q += threads) rho_lds[q] = G.rho[run.c0 + q];
-		const uint4* __restrict__ cg = reinterpret_cast<const uint4*>(G.cols + run.c0);
-		for (uint32_t q = tid; q < ncols * 2u; q += threads) reinterpret_cast<uint4*>(col_lds)[q] = cg[q];
-	}
-	GS_STAMP(0);   // prologue loads issued and staged
 	const bool from_other = DIR == 0 ? run.has_prev != 0u : run.has_next != 0u;
+	const uint32_t np = DIR == 0 ? run.n_part_in_f : run.n_part_in_b;   // partial sums of the entering column (0: this run does not rescale)
 	double val = 1.0;   // forward: column 0 starts from 1 (:313, `prev ? ... : 1`); backward: B of the last column is 1
 	double psum = 0.0;
-	if (from_other) {
-		// forward reads the exchange column in its ENTRY layout, backward in its EXIT layout (the same index space: the reads that
-		// continue across the boundary)
-		const uint32_t occ = DIR == 0 ? run.in_occ : run.out_occ;
-		uint32_t idx = 0;
-		if (DIR == 0 && run.in_identity) idx = Pcell & occ;
-		else {
-#pragma unroll
-			for (int s = 0; s < SLOT_MAXSLOTS; ++s) idx |= (((Pcell & occ) >> s) & 1u) << (DIR == 0 ? gs_pos(run.in_pos, s) : gs_pos(run.out_pos, s));
+	// Two shapes of prologue and column loop, chosen by measurement: a single individual (TB = 0) gains 8 % from every prologue load in one
+	// batch and the lane tables requested three columns ahead; a pedigree (16 table words per lane and column, 114 VGPRs that way) loses 4 %.
+	if constexpr (TB == 0) {
+		// ---- prologue: tables, priors, descriptors, the entering value, the partial sums of the entering column.  EVERY global load is issued before
+		// the first wait -- unconditional loads from clamped addresses, the values stored (or dropped) afterwards: written as `q < n ? src[q] : 0`
+		// loops each copy was load, wait, store, and the prologue a chain of seven L2 round trips (a quarter of a launch).
+		const uint32_t per_wave = ncols * T * E;   // A = G[w] * V[wave]
+		const double* __restrict__ gsrc = tabG + (size_t)w * per_wave;
+		const double* __restrict__ vsrc = tabG + run.v_off + (size_t)wave * per_wave;
+		double gv[8], vv[8];
+	#pragma unroll
+		for (uint32_t u = 0; u < 8; ++u) {
+			const uint32_t q = min(u * 64u + lane, per_wave - 1u);
+			gv[u] = gsrc[q];
+			vv[u] = vsrc[q];
 		}
-		val = prev[(size_t)idx * T + i];
-	}
-	// total of the entering column when this run rescales (every thread ends up with the same number): wave sums, then across the waves
-	const uint32_t np = DIR == 0 ? run.n_part_in_f : run.n_part_in_b;
-	if (np) {
+		constexpr uint32_t PR_N = 4, PS_N = 4;
+		const uint32_t n_pr = ncols * T * A;
+		const double* __restrict__ pr = G.prior + (size_t)run.c0 * T * A;
+		double prv[PR_N];
+	#pragma unroll
+		for (uint32_t u = 0; u < PR_N; ++u) prv[u] = pr[min(u * threads + tid, n_pr - 1u)];
+		const double rho_v = G.rho[run.c0 + min(tid, ncols - 1u)];
+		const uint4 col_v = reinterpret_cast<const uint4*>(G.cols + run.c0)[min(tid, ncols * 2u - 1u)];
+		{
+			// forward reads the exchange column in its ENTRY layout, backward in its EXIT layout (the same index space: the reads that
+			// continue across the boundary)
+			const uint32_t occ = from_other ? (DIR == 0 ? run.in_occ : run.out_occ) : 0u;   // (nothing to read: entry 0 is fetched and dropped)
+			uint32_t idx = 0;
+			if (DIR == 0 && run.in_identity) idx = Pcell & occ;
+			else {
+	#pragma unroll
+				for (int s = 0; s < SLOT_MAXSLOTS; ++s) idx |= (((Pcell & occ) >> s) & 1u) << (DIR == 0 ? gs_pos(run.in_pos, s) : gs_pos(run.out_pos, s));
+			}
+			val = prev[(size_t)idx * T + i];
+		}
+		// total of the entering column when this run rescales (every thread ends up with the same number): wave sums, then across the waves
 		const uint32_t p0 = DIR == 0 ? run.part_in_f : run.part_in_b;
-		for (uint32_t q = tid; q < np; q += threads) psum += G.partials[p0 + q];
-		for (int off = 32; off > 0; off >>= 1) psum += __shfl_xor(psum, off);
-		if (lane == 0) red[wave] = psum;
+		double psv[PS_N];
+	#pragma unroll
+		for (uint32_t u = 0; u < PS_N; ++u) psv[u] = G.partials[np ? p0 + min(u * threads + tid, np - 1u) : 0u];
+		// ---- (everything requested) now the copies into LDS
+	#pragma unroll
+		for (uint32_t u = 0; u < 8; ++u) {
+			const uint32_t q = u * 64u + lane;
+			if (q < per_wave) a_lds[(size_t)wave * per_wave + q] = gv[u] * vv[u];
+		}
+		for (uint32_t q = 512u + lane; q < per_wave; q += 64u) a_lds[(size_t)wave * per_wave + q] = gsrc[q] * vsrc[q];   // (runs beyond 512 table entries per wave)
+	#pragma unroll
+		for (uint32_t u = 0; u < PR_N; ++u) {
+			const uint32_t q = u * threads + tid;
+			if (q < n_pr) pr_lds[q] = prv[u];
+		}
+		for (uint32_t q = PR_N * threads + tid; q < n_pr; q += threads) pr_lds[q] = pr[q];
+		if (tid < ncols) rho_lds[tid] = rho_v;
+		if (tid < ncols * 2u) reinterpret_cast<uint4*>(col_lds)[tid] = col_v;
+		GS_STAMP(0);   // prologue loads issued and staged
+		if (!from_other) val = 1.0;
+		if (np) {
+	#pragma unroll
+			for (uint32_t u = 0; u < PS_N; ++u) if (u * threads + tid < np) psum += psv[u];
+			for (uint32_t q = PS_N * threads + tid; q < np; q += threads) psum += G.partials[p0 + q];
+			for (int off = 32; off > 0; off >>= 1) psum += __shfl_xor(psum, off);
+			if (lane == 0) red[wave] = psum;
+		}
+	} else {
+		// ---- prologue: tables, priors, descriptors, the entering value, the scale of the entering column
+		{
+			const uint32_t per_wave = ncols * T * E;   // A = G[w] * V[wave]
+			const double* __restrict__ g = tabG + (size_t)w * per_wave;
+			const double* __restrict__ v = tabG + run.v_off + (size_t)wave * per_wave;
+			for (uint32_t q0 = 0; q0 < per_wave; q0 += 512u) {   // eight loads in flight per lane before the first is used
+				double gv[8], vv[8];
+	#pragma unroll
+				for (uint32_t u = 0; u < 8; ++u) {
+					const uint32_t q = q0 + u * 64u + lane;
+					gv[u] = q < per_wave ? g[q] : 0.0;
+					vv[u] = q < per_wave ? v[q] : 0.0;
+				}
+	#pragma unroll
+				for (uint32_t u = 0; u < 8; ++u) {
+					const uint32_t q = q0 + u * 64u + lane;
+					if (q < per_wave) a_lds[(size_t)wave * per_wave + q] = gv[u] * vv[u];
+				}
+			}
+			const double* __restrict__ pr = G.prior + (size_t)run.c0 * T * A;
+			for (uint32_t q = tid; q < ncols * T * A; q += threads) pr_lds[q] = pr[q];
+			for (uint32_t q = tid; q < ncols; q += threads) rho_lds[q] = G.rho[run.c0 + q];
+			const uint4* __restrict__ cg = reinterpret_cast<const uint4*>(G.cols + run.c0);
+			for (uint32_t q = tid; q < ncols * 2u; q += threads) reinterpret_cast<uint4*>(col_lds)[q] = cg[q];
+		}
+		GS_STAMP(0);   // prologue loads issued and staged
+		if (from_other) {
+			// forward reads the exchange column in its ENTRY layout, backward in its EXIT layout (the same index space: the reads that
+			// continue across the boundary)
+			const uint32_t occ = DIR == 0 ? run.in_occ : run.out_occ;
+			uint32_t idx = 0;
+			if (DIR == 0 && run.in_identity) idx = Pcell & occ;
+			else {
+	#pragma unroll
+				for (int s = 0; s < SLOT_MAXSLOTS; ++s) idx |= (((Pcell & occ) >> s) & 1u) << (DIR == 0 ? gs_pos(run.in_pos, s) : gs_pos(run.out_pos, s));
+			}
+			val = prev[(size_t)idx * T + i];
+		}
+		// total of the entering column when this run rescales (every thread ends up with the same number): wave sums, then across the waves
+		if (np) {
+			const uint32_t p0 = DIR == 0 ? run.part_in_f : run.part_in_b;
+			for (uint32_t q = tid; q < np; q += threads) psum += G.partials[p0 + q];
+			for (int off = 32; off > 0; off >>= 1) psum += __shfl_xor(psum, off);
+			if (lane == 0) red[wave] = psum;
+		}
 	}
 	__syncthreads();
 	GS_STAMP(1);   // entering value loaded, partial sums reduced, barrier
@@ -282,33 +349,71 @@ __global__ __launch_bounds__(512) void geno_slot_run(GsDev G, GsRun run, const d
 		for (uint32_t a = 0; a < A; ++a) s = fma(pp[a], prod[a], s);
 		return s;
 	};
-	double s_cur[E], s_next[E];
-	if (DIR == 0) {
-		load_s(0, s_cur);
-		for (uint32_t ci = 0; ci < ncols; ++ci) {
+	if constexpr (TB == 0) {
+		// The lane part of W is requested THREE columns ahead, into four register sets used in rotation (the loop is unrolled four times, no set is
+		// ever copied): the counter that orders vector-memory operations is shared by loads and stores and retires in order, so the wait for a
+		// column's S is also a wait for every store issued before that load -- one column ahead (and a copy of the set at the end of each
+		// column, which waited for the load just issued) a column cost a full store + load round trip.
+		double r0[E], r1[E], r2[E], r3[E];
+		auto col_at = [&](uint32_t k) { return DIR == 0 ? k : ncols - 1u - k; };        // k-th column of the walk
+		auto request = [&](uint32_t k, double (&sv)[E]) { load_s(col_at(k < ncols ? k : ncols - 1u), sv); };
+		auto column = [&](uint32_t k, const double (&sv)[E], double (&fill)[E]) -> bool {   // false: the walk ends here (backward, first column of the table)
+			const uint32_t ci = col_at(k);
 			const GsCol& cd = col_lds[ci];
-			const uint32_t n_end = gs_uni(cd.n_end), first = gs_uni(cd.first_of_table);
-			load_s(ci + 1 < ncols ? ci + 1 : ci, s_next);
-			if (!first) transition(rho_lds[ci]);
-			store[(size_t)ci * col_stride] = val;   // sum_j A_{c-1}[back(x)][j] P(j -> i): what the likelihood sums need
-			val *= cell_sum(ci, s_cur);
-			for (uint32_t e = 0; e < n_end; ++e) sum_out(gs_uni(cd.end_slot[e]));
-#pragma unroll
-			for (uint32_t q = 0; q < E; ++q) s_cur[q] = s_next[q];
-		}
-	} else {
-		load_s(ncols - 1u, s_cur);
-		for (uint32_t ci = ncols; ci-- > 0;) {
-			const GsCol& cd = col_lds[ci];
-			const uint32_t n_start = gs_uni(cd.n_start), first = gs_uni(cd.first_of_table);
-			load_s(ci ? ci - 1 : 0u, s_next);
+			const uint32_t first = gs_uni(cd.first_of_table);
+			request(k + 3u, fill);
+			if (DIR == 0) {
+				const uint32_t n_end = gs_uni(cd.n_end);
+				if (!first) transition(rho_lds[ci]);
+				store[(size_t)ci * col_stride] = val;   // sum_j A_{c-1}[back(x)][j] P(j -> i): what the likelihood sums need
+				val *= cell_sum(ci, sv);
+				for (uint32_t e = 0; e < n_end; ++e) sum_out(gs_uni(cd.end_slot[e]));
+				return true;
+			}
+			const uint32_t n_start = gs_uni(cd.n_start);
 			store[(size_t)ci * col_stride] = val;   // B_c[fwd(x)][i]
-			if (first) break;                       // (B_{-1} is never needed, :200-289 stops at column 1)
-			val *= cell_sum(ci, s_cur);
+			if (first) return false;                // (B_{-1} is never needed, :200-289 stops at column 1)
+			val *= cell_sum(ci, sv);
 			for (uint32_t e = 0; e < n_start; ++e) sum_out(gs_uni(cd.start_slot[e]));
 			transition(rho_lds[ci]);
-#pragma unroll
-			for (uint32_t q = 0; q < E; ++q) s_cur[q] = s_next[q];
+			return true;
+		};
+		request(0, r0); request(1, r1); request(2, r2);
+		for (uint32_t k = 0; k < ncols; k += 4u) {
+			if (!column(k, r0, r3)) break;
+			if (k + 1u >= ncols || !column(k + 1u, r1, r0)) break;
+			if (k + 2u >= ncols || !column(k + 2u, r2, r1)) break;
+			if (k + 3u >= ncols || !column(k + 3u, r3, r2)) break;
+		}
+	} else {
+		double s_cur[E], s_next[E];
+		if (DIR == 0) {
+			load_s(0, s_cur);
+			for (uint32_t ci = 0; ci < ncols; ++ci) {
+				const GsCol& cd = col_lds[ci];
+				const uint32_t n_end = gs_uni(cd.n_end), first = gs_uni(cd.first_of_table);
+				load_s(ci + 1 < ncols ? ci + 1 : ci, s_next);
+				if (!first) transition(rho_lds[ci]);
+				store[(size_t)ci * col_stride] = val;   // sum_j A_{c-1}[back(x)][j] P(j -> i): what the likelihood sums need
+				val *= cell_sum(ci, s_cur);
+				for (uint32_t e = 0; e < n_end; ++e) sum_out(gs_uni(cd.end_slot[e]));
+	#pragma unroll
+				for (uint32_t q = 0; q < E; ++q) s_cur[q] = s_next[q];
+			}
+		} else {
+			load_s(ncols - 1u, s_cur);
+			for (uint32_t ci = ncols; ci-- > 0;) {
+				const GsCol& cd = col_lds[ci];
+				const uint32_t n_start = gs_uni(cd.n_start), first = gs_uni(cd.first_of_table);
+				load_s(ci ? ci - 1 : 0u, s_next);
+				store[(size_t)ci * col_stride] = val;   // B_c[fwd(x)][i]
+				if (first) break;                       // (B_{-1} is never needed, :200-289 stops at column 1)
+				val *= cell_sum(ci, s_cur);
+				for (uint32_t e = 0; e < n_start; ++e) sum_out(gs_uni(cd.start_slot[e]));
+				transition(rho_lds[ci]);
+	#pragma unroll
+				for (uint32_t q = 0; q < E; ++q) s_cur[q] = s_next[q];
+			}
 		}
 	}
 	GS_STAMP(2);   // column loop
