@@ -106,11 +106,16 @@ __device__ __forceinline__ void pedslot_run_body(const DevProblem& P, const Slot
 	uint4 hot_piece = make_uint4(0, 0, 0, 0);
 	if (tid < ncols * 2u) hot_piece = reinterpret_cast<const uint4*>(rows + (tid >> 1))[tid & 1u];
 	// (2) A = G[w] + W[wave]: every wave its own row
+	// (AB batches of 64 words requested here; what does not fit is copied by the loop below, whose every trip is load - wait - store: a quartet's
+	// 300 words were five L2 round trips in a row -- 1.26 -> 1.41 M columns/s with six batches.  A trio with trusted genotypes has 104 words:
+	// two batches, and four measured 7 % slower there.)
 	const uint32_t fwn = ex.fwn;
-	uint32_t ga[2] = {0, 0}, wa[2] = {0, 0};
+	constexpr int AB = (TB == 2 && NF == 2) ? 2 : 6;
+	uint32_t ga[AB], wa[AB];
 #pragma unroll
-	for (int u = 0; u < 2; ++u) {
+	for (int u = 0; u < AB; ++u) {
 		const uint32_t i = (uint32_t)u * 64u + lane;
+		ga[u] = 0; wa[u] = 0;
 		if (i < fwn) { ga[u] = tabG[(size_t)w * fwn + i]; wa[u] = tabG[ex.w_off + wave * fwn + i]; }
 	}
 	// (3) S: the same for every workgroup
@@ -142,11 +147,11 @@ __device__ __forceinline__ void pedslot_run_body(const DevProblem& P, const Slot
 	if (FACT && tid < ncols * T * (NK / 4)) reinterpret_cast<uint4*>(k_lds)[tid] = kp;
 	uint32_t* a_row = a_lds + wave * (ex.arow + 4u * T * NA);
 #pragma unroll
-	for (int u = 0; u < 2; ++u) {
+	for (int u = 0; u < AB; ++u) {
 		const uint32_t i = (uint32_t)u * 64u + lane;
 		if (i < fwn) a_row[i] = ga[u] + wa[u];
 	}
-	for (uint32_t i = 128u + lane; i < fwn; i += 64u) a_row[i] = tabG[(size_t)w * fwn + i] + tabG[ex.w_off + wave * fwn + i];   // long runs / many forms
+	for (uint32_t i = (uint32_t)AB * 64u + lane; i < fwn; i += 64u) a_row[i] = tabG[(size_t)w * fwn + i] + tabG[ex.w_off + wave * fwn + i];   // long runs / many forms
 #pragma unroll
 	for (int u = 0; u < 2; ++u) {
 		const uint32_t i = (uint32_t)u * threads + tid;
