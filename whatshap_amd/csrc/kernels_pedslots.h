@@ -127,9 +127,17 @@ __device__ __forceinline__ void pedslot_run_body(const DevProblem& P, const Slot
 		const uint32_t i = (uint32_t)u * threads + tid;
 		if (i < n_s4) sp[u] = tabS[i];
 	}
-	// (3b) K: the constants of the factorised lines, the same for every workgroup and wave (at most 32 * 4 * 12 words: one 16-byte piece per thread)
-	uint4 kp = make_uint4(0, 0, 0, 0);
-	if (FACT && tid < ncols * T * (NK / 4)) kp = reinterpret_cast<const uint4*>(tabG + ex.s_off + ncols * 64u * NS)[tid];
+	// (3b) K: the constants of the factorised lines, the same for every workgroup and wave: at most 32 * 4 * 12 words = 384 16-byte pieces -- one per
+	// thread of a full workgroup, up to six per thread of a 64-thread one (small tables)
+	constexpr int KB = FACT ? 6 : 1;
+	const uint32_t n_k4 = FACT ? ncols * T * (NK / 4) : 0u;
+	uint4 kp[KB];
+#pragma unroll
+	for (int u = 0; u < KB; ++u) {
+		const uint32_t i = (uint32_t)u * threads + tid;
+		kp[u] = make_uint4(0, 0, 0, 0);
+		if (i < n_k4) kp[u] = reinterpret_cast<const uint4*>(tabG + ex.s_off + ncols * 64u * NS)[i];
+	}
 	// (4) the entering value
 	uint32_t D = 0;
 	if (run.has_prev) {
@@ -144,7 +152,11 @@ __device__ __forceinline__ void pedslot_run_body(const DevProblem& P, const Slot
 		D = prev[(size_t)idx * T + t];
 	}
 	if (tid < ncols * 2u) reinterpret_cast<uint4*>(hot_lds)[tid] = hot_piece;
-	if (FACT && tid < ncols * T * (NK / 4)) reinterpret_cast<uint4*>(k_lds)[tid] = kp;
+#pragma unroll
+	for (int u = 0; u < KB; ++u) {
+		const uint32_t i = (uint32_t)u * threads + tid;
+		if (i < n_k4) reinterpret_cast<uint4*>(k_lds)[i] = kp[u];
+	}
 	uint32_t* a_row = a_lds + wave * (ex.arow + 4u * T * NA);
 #pragma unroll
 	for (int u = 0; u < AB; ++u) {
