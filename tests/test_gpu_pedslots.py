@@ -123,6 +123,21 @@ def test_full_size_trio_old_and_new_runs_agree():
     assert st_new["total_ms"] < st_old["total_ms"]
 
 
+@pytest.mark.parametrize("coverage", [3, 4, 5, 6, 7, 8, 10])
+def test_factorised_lines_in_workgroups_of_every_size(coverage, monkeypatch):
+    """An untrusted trio at coverage 3 ... 10: workgroups of 64 ... 512 threads.  The constants of the factorised lines (slots.h PSLOT_FACT, the K table)
+    are staged by however many threads the workgroup has; sixteen forms (WHAMD_NO_PED_FACT) give the same tuple; both == the oracle."""
+    p = synthetic_block(n_variants=90, coverage=coverage, seed=300 + coverage, trio=True, distrust_genotypes=True, mixed_genotypes=coverage % 2 == 0)
+    want = table_solution(oracle.OracleTable(p))
+    assert _native.plan_summary(p)["n_fact_runs"] > 0
+    got, _ = solve(p)
+    assert got == want, first_difference(want, got)
+    monkeypatch.setenv("WHAMD_NO_PED_FACT", "1")
+    assert _native.plan_summary(p)["n_fact_runs"] == 0
+    generic, _ = solve(p)
+    assert generic == want, first_difference(want, generic)
+
+
 @pytest.mark.parametrize("mode", ["three_children", "three_trios", "big_family"])
 def test_pedigrees_beyond_two_trios_and_six_individuals_vs_oracle(mode):
     """Three trios (T = 64: a family with three children, three unrelated trios) and seven individuals in one table: the
