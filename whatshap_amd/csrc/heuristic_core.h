@@ -256,12 +256,21 @@ HEUR_FN inline void heur_copy_row(float* dst, const float* src, size_t st, uint3
 #pragma unroll
 		for (uint32_t u = 0; u < HEUR_BATCH; ++u) dst[(size_t)(x0 + u) * st] = t[u];
 	}
+	// the last, partial batch: UNCONDITIONAL loads (element 0 of the row where there is nothing to fetch, the value dropped afterwards).  Written as
+	// `cond ? src[...] : 0` every element was its own branch with a wait behind the load -- up to seven memory round trips in a row, in a kernel
+	// whose one workgroup per CU has nothing else to run meanwhile.
 	for (; x0 < w; x0 += HEUR_BATCH) {
 		float t[HEUR_BATCH];
 #pragma unroll
-		for (uint32_t u = 0; u < HEUR_BATCH; ++u) t[u] = (x0 + u < w && x0 + u + shift < n_src) ? src[(size_t)(x0 + u + shift) * st] : 0.0f;
+		for (uint32_t u = 0; u < HEUR_BATCH; ++u) {
+			const bool has = x0 + u < w && x0 + u + shift < n_src;
+			t[u] = src[(size_t)(has ? x0 + u + shift : 0u) * st];
+		}
 #pragma unroll
-		for (uint32_t u = 0; u < HEUR_BATCH; ++u) if (x0 + u < w) dst[(size_t)(x0 + u) * st] = t[u];
+		for (uint32_t u = 0; u < HEUR_BATCH; ++u) {
+			const bool has = x0 + u < w && x0 + u + shift < n_src;
+			if (x0 + u < w) dst[(size_t)(x0 + u) * st] = has ? t[u] : 0.0f;
+		}
 	}
 }
 // the same for the two rows of one sample at once (rows come in pairs: haplotype 0 / 1): sixteen loads in flight per batch
@@ -293,12 +302,16 @@ HEUR_FN inline void heur_add_row(float* row, size_t st, const float* add, uint32
 #pragma unroll
 		for (uint32_t u = 0; u < HEUR_BATCH; ++u) row[(size_t)(x0 + u) * st] = t[u] + a[u];
 	}
-	for (; x0 < w; x0 += HEUR_BATCH) {
-		float t[HEUR_BATCH];
+	for (; x0 < w; x0 += HEUR_BATCH) {   // (the partial batch: unconditional loads from clamped positions, see heur_copy_row)
+		float t[HEUR_BATCH], a[HEUR_BATCH];
 #pragma unroll
-		for (uint32_t u = 0; u < HEUR_BATCH; ++u) t[u] = x0 + u < w ? row[(size_t)(x0 + u) * st] + add[x0 + u] : 0.0f;
+		for (uint32_t u = 0; u < HEUR_BATCH; ++u) {
+			const uint32_t x = x0 + u < w ? x0 + u : x0;   // (x0 < w: a valid position)
+			t[u] = row[(size_t)x * st];
+			a[u] = add[x];
+		}
 #pragma unroll
-		for (uint32_t u = 0; u < HEUR_BATCH; ++u) if (x0 + u < w) row[(size_t)(x0 + u) * st] = t[u];
+		for (uint32_t u = 0; u < HEUR_BATCH; ++u) if (x0 + u < w) row[(size_t)(x0 + u) * st] = t[u] + a[u];
 	}
 }
 
