@@ -907,24 +907,38 @@ def main():
                 t.release_device()
             problems = [build_block(args, *blocks[b]) for b in mine]
             best = None
+            tried = []
+            # host parallelism of the creates: (workers, threads per create) -- 16 x 2 is blocks.solve_blocks' default; one worker per table with four or
+            # eight threads each is tried beside it (the box has more hardware threads than 32; what wins is reported, nothing is assumed)
+            host_shapes = [(16, 2), (len(problems), 4), (len(problems), 8)]
             for window in sorted({min(len(problems), w) for w in (8, 12, args.in_flight)}):
-                te0 = time.perf_counter()
-                solved = solve_blocks(problems, device=device, path=None if args.path == "auto" else args.path, max_in_flight=window, release=True, create_threads=16)
-                checksum = 0
-                for t in solved:
-                    checksum += t.optimal_score()
-                    t.super_reads(), t.partitioning()
-                wall = time.perf_counter() - te0
-                for t in solved:
-                    t.close()
-                if checksum != int(totals[2]):
-                    raise SystemExit(f"end_to_end: cost checksum {checksum} of the pipelined solve differs from {int(totals[2])}")
-                if best is None or wall < best[0]:
-                    best = (wall, window)
-            out["end_to_end"] = {"value": cols_job / best[0], "unit": "variant-columns/s", "wall_ms": best[0] * 1e3, "tables_per_window": best[1], "create_threads": 16,
-                                 "fraction_of_device_only": (cols_job / best[0]) / out["value"],
-                                 "what": f"{len(problems)} fresh tables from host arrays through blocks.solve_blocks: create (flatten + plan + upload) of the next window on 16 host "
-                                         f"threads (two threads each) under the device solve of the current one, enqueue_many / wait_many per window, 3 getters per table; best of the window sizes tried"}
+                for workers, per_create in (host_shapes if window == min(len(problems), args.in_flight) else host_shapes[:1]):
+                    te0 = time.perf_counter()
+                    try:
+                        solved = solve_blocks(problems, device=device, path=None if args.path == "auto" else args.path, max_in_flight=window, release=True,
+                                              create_threads=workers, host_threads_per_create=per_create)
+                    except Exception as exc:  # noqa: BLE001 -- an exploratory host shape must not cost the line; the default shape (first) still raises
+                        if (workers, per_create) == host_shapes[0]:
+                            raise
+                        tried.append({"tables_per_window": window, "create_threads": workers, "host_threads_per_create": per_create, "error": repr(exc)})
+                        continue
+                    checksum = 0
+                    for t in solved:
+                        checksum += t.optimal_score()
+                        t.super_reads(), t.partitioning()
+                    wall = time.perf_counter() - te0
+                    for t in solved:
+                        t.close()
+                    if checksum != int(totals[2]):
+                        raise SystemExit(f"end_to_end: cost checksum {checksum} of the pipelined solve differs from {int(totals[2])}")
+                    tried.append({"tables_per_window": window, "create_threads": workers, "host_threads_per_create": per_create, "wall_ms": wall * 1e3})
+                    if best is None or wall < best[0]:
+                        best = (wall, window, workers, per_create)
+            out["end_to_end"] = {"value": cols_job / best[0], "unit": "variant-columns/s", "wall_ms": best[0] * 1e3, "tables_per_window": best[1], "create_threads": best[2],
+                                 "host_threads_per_create": best[3], "fraction_of_device_only": (cols_job / best[0]) / out["value"], "tried": tried,
+                                 "what": f"{len(problems)} fresh tables from host arrays through blocks.solve_blocks: create (flatten + plan + upload) of the next window on "
+                                         f"`create_threads` host workers (`host_threads_per_create` threads each) under the device solve of the current one, enqueue_many / wait_many "
+                                         f"per window, 3 getters per table; best of the window sizes and host shapes in `tried`"}
         # ---- counters of the dominant kernel
         pmc, pmc_note = None, "skipped"
         want_pmc = args.pmc == "on" or (args.pmc == "auto" and world == 1 and not column_path)

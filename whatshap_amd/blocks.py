@@ -98,7 +98,7 @@ def split_independent_blocks(problem: ProblemArrays) -> List[Tuple[ProblemArrays
 
 def solve_blocks(problems: Sequence[ProblemArrays], device: int = 0, path=None, max_in_flight: int = 8,
                  release: bool = True, devices: Sequence[int] = None, weights: Sequence[float] = None, create_threads: int = 16,
-                 windows_on_device: int = 1, trace: list = None, eager_create: bool = False):
+                 windows_on_device: int = 1, trace: list = None, eager_create: bool = False, host_threads_per_create: int = 2):
     """Host-side work queue (BASELINE north_star: "independent phasing blocks shard across the GPUs of one node via a
     host-side work queue"; scheduling precedent: whatshap/polyphase/algorithm.py:101-128).
 
@@ -109,7 +109,9 @@ def solve_blocks(problems: Sequence[ProblemArrays], device: int = 0, path=None, 
     the next one has been submitted and ``eager_create`` queues every create at once; both were measured (scripts/gpu_e2e_trace.py,
     24 coverage-15 tables) and gain nothing on a 32-thread host: a window costs about 35 ms from enqueue to collect whatever its size
     (the length of the launch sequence) and the creates are bound by the host's cores (24 of them: 35 ms), so one window of
-    everything is the fastest schedule there.  ``trace``: a list that receives (event, window, ms) tuples.
+    everything is the fastest schedule there.  ``create_threads`` x ``host_threads_per_create`` is the host parallelism of the creates (16 x 2 by
+    default; bench.py also tries one worker per table with four threads each and reports what it used).  ``trace``: a list that receives
+    (event, window, ms) tuples.
 
     Several devices (``devices=[0, 1, ...]``; an index may repeat: two workers on one device): the blocks are assigned
     longest-processing-time-first to the least loaded device (``assign_blocks``; ``weights`` defaults to the number of
@@ -135,8 +137,8 @@ def solve_blocks(problems: Sequence[ProblemArrays], device: int = 0, path=None, 
                 opts = {}
                 if len(window) > 4:       # more than four tables per window share their launches: the library picks the layout for that
                     opts["shared_launches"] = "1"
-                if n_workers > 1 and len(window) > 1:   # several creates at once: each keeps to two threads of its own (32 each would fight)
-                    opts["host_threads"] = "2"
+                if n_workers > 1 and len(window) > 1:   # several creates at once: each keeps to a few threads of its own (32 each would fight)
+                    opts["host_threads"] = str(max(1, int(host_threads_per_create)))
                 return opts or None
 
             def create(sub, opts):
