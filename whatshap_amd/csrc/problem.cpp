@@ -187,9 +187,18 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 		position_map.reserve(n * 2 + 1);
 		for (uint32_t i = 0; i < n; ++i) position_map[p.positions[i]] = i;
 	}
-	auto column_of = [&](uint32_t position, uint32_t& col) -> bool {
+	// (hint: a column at or before the answer -- the previous read's first column, this read's first column: the search gallops from there
+	// instead of bisecting the whole list, two cache misses instead of sixteen)
+	auto column_of = [&](uint32_t position, uint32_t& col, uint32_t hint = 0) -> bool {
 		if (positions_increase) {
-			const auto it = std::lower_bound(p.positions.begin(), p.positions.end(), position);
+			if (n == 0) return false;
+			const uint32_t* pos0 = p.positions.data();
+			size_t lo_i = hint < n ? hint : 0, step = 1;
+			if (pos0[lo_i] > position) lo_i = 0;   // (a hint beyond the answer: fall back to the whole list)
+			size_t hi_i = lo_i;
+			while (hi_i < n && pos0[hi_i] < position) { lo_i = hi_i; hi_i += step; step <<= 1; }
+			if (hi_i > n) hi_i = n;
+			const auto it = std::lower_bound(p.positions.begin() + lo_i, p.positions.begin() + hi_i + (hi_i < n ? 1 : 0), position);
 			if (it == p.positions.end() || *it != position) return false;
 			col = (uint32_t)(it - p.positions.begin());
 			return true;
@@ -212,6 +221,7 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 		const int32_t* vp = rs->var_position;
 		parallel_ranges(p.n_reads, n_threads, [&](uint64_t r0, uint64_t r1, uint32_t t) {
 			auto fail_read = [&](uint32_t r, whamd_status_t st, std::string m) { errors[t].read = r; errors[t].status = st; errors[t].msg = std::move(m); };
+			uint32_t hint_col = 0;
 			for (uint32_t r = (uint32_t)r0; r < (uint32_t)r1; ++r) {
 				const uint64_t lo = ptr[r], hi = ptr[r + 1];
 				if (hi <= lo || hi > nnz) return fail_read(r, WHAMD_ERR_INVALID, "No variants present");  // Read::firstPosition (src/read.cpp:75-78)
@@ -222,12 +232,13 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 					if (!(vp[i - 1] < vp[i])) return fail_read(r, WHAMD_ERR_UNSORTED, "ColumnIterator: encountered read with unsorted variants.");
 				}
 				uint32_t fc = 0, lc = 0;
-				if (vp[lo] < 0 || !column_of((uint32_t)vp[lo], fc) || !column_of((uint32_t)vp[hi - 1], lc) || fc > lc) {
+				if (vp[lo] < 0 || !column_of((uint32_t)vp[lo], fc, hint_col) || !column_of((uint32_t)vp[hi - 1], lc, fc) || fc > lc) {
 					// the reference asserts here (src/columniterator.cpp:36-39) and aborts the process
 					return fail_read(r, WHAMD_ERR_INVALID, "read " + std::to_string(r) + " starts or ends at a position that is not in the position list");
 				}
 				first_col[r] = fc;
 				last_col[r] = lc;
+				hint_col = fc;   // (the reads are sorted by their first position)
 			}
 		});
 		for (const ReadError& e : errors) {   // ranges are in read order

@@ -67,6 +67,8 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 	// planned independently -- in parallel -- and concatenated; a range boundary is just one more run boundary.
 	auto plan_range = [&](const uint32_t c_begin, const uint32_t c_end, SlotPlan& plan, std::vector<RunDraft>& drafts) {
 	std::vector<int8_t> slot_of(p.n_reads, -1);
+	SlotRow scratch_row{};       // (the row kind this table does not use is written here)
+	PedSlotRow scratch_prow{};
 	uint32_t c = c_begin;
 	while (c < c_end) {
 		auto column_step = [&]() { plan.steps.push_back(Step{0, c}); ++c; };
@@ -212,8 +214,10 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 				}
 			}
 			const int32_t* dl = genotype_mode ? nullptr : p.delta.data() + (size_t)p.col_ptr[c1] * p.n_ind;   // [individual][bit]; n_ind == 1 unless ped
-			SlotRow row{};
-			PedSlotRow prow{};
+			// the row is built IN PLACE (a row of a column that ends up outside every run is never read); the other kind goes to a scratch row
+			SlotRow& row = ped ? scratch_row : rows_g[c1];
+			PedSlotRow& prow = ped ? prows_g[c1] : scratch_prow;
+			if (ped) prow = PedSlotRow{}; else row = SlotRow{};
 			SlotBtCol bc_rec{};
 			bc_rec.k = (uint8_t)kc;
 			bc_rec.kf = (uint8_t)n_ends;
@@ -299,7 +303,6 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 			}
 			n_ends += en;
 			col_to_row[c1] = (int32_t)c1;
-			if (ped) prows_g[c1] = prow; else rows_g[c1] = row;
 			btc_g[c1] = bc_rec;
 			++c1;
 		}
