@@ -57,6 +57,7 @@ WORKLOADS = {
     "blocks3": dict(variants=100000, coverage=20, blocks=3, in_flight=3),          # three configs[4] blocks in flight on one GPU
     "blocks24": dict(variants=100000, coverage=20, blocks=24, in_flight=24, option=["shared_launches=1"]),       # BASELINE configs[4] on ONE GPU: all 24 blocks as one group of launches
     "config1_x24": dict(variants=50000, coverage=15, blocks=24, in_flight=24, option=["shared_launches=1"]),     # 24 tables at `whatshap phase`'s default coverage (24 chromosomes) on one GPU
+    "config1_x48": dict(variants=50000, coverage=15, blocks=48, in_flight=48, option=["shared_launches=1"]),     # twice that: 384 workgroups per launch (does the launch time hold?)
     "config3_distrust": dict(trio=True, distrust=True, variants=100000, coverage=15),   # configs[3]'s ReadSet, genotypes not trusted (16 allele assignments per value)
     "config3_x8": dict(trio=True, variants=100000, coverage=15, blocks=8, in_flight=8),  # eight trio tables (families / chromosomes) on one GPU
     "irregular": dict(irregular=True, variants=100000, coverage=20),               # Poisson starts, geometric lengths (mean 16), coverage capped
@@ -66,7 +67,7 @@ WORKLOADS = {
     "heuristic": dict(heuristic=True, variants=8000, coverage=30),                 # PedMecHeuristic, coverage beyond the exact DP
     "heuristic_x32": dict(heuristic=True, variants=8000, coverage=30, blocks=32),  # 32 PedMecHeuristic tables in ONE launch (one persistent workgroup each)
 }
-EXTRA_CONFIGS = ["config1", "config1_x24", "config3", "config3_distrust", "config3_x8", "blocks3", "blocks24", "irregular", "quartet", "genotype", "genotype_trio", "heuristic", "heuristic_x32"]
+EXTRA_CONFIGS = ["config1", "config1_x24", "config1_x48", "config3", "config3_distrust", "config3_x8", "blocks3", "blocks24", "irregular", "quartet", "genotype", "genotype_trio", "heuristic", "heuristic_x32"]
 
 
 def parse_args():
@@ -668,7 +669,7 @@ def run_extra_configs(args):
             "tables_in_flight": full["config"].get("blocks_in_flight_per_gpu"),
             "tables_per_launch": full["config"].get("tables_per_launch"),
             "identical_to_reference": full.get("identical_to_reference"),
-            "end_to_end": ({k: full["end_to_end"].get(k) for k in ("value", "fraction_of_device_only", "create_ms", "solve_and_getters_ms", "wall_ms", "tables_per_window")}
+            "end_to_end": ({k: full["end_to_end"].get(k) for k in ("value", "fraction_of_device_only", "create_ms", "solve_and_getters_ms", "wall_ms", "tables_per_window", "create_threads", "host_threads_per_create", "tried")}
                            if "end_to_end" in full else None),
             "bipartition_costs_per_s": full["bipartition_costs_per_s"],
             "optimal_cost_checksum": full["config"]["optimal_cost_checksum"],
