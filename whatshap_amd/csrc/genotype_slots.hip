@@ -552,10 +552,22 @@ __global__ __launch_bounds__(256) void geno_slot_finish(GsDev G, const double* _
 	const uint32_t c = c_first + blockIdx.x, TA = G.T * G.A, n_ind = G.n_ind, n_gl = 1u + 3u * n_ind, nb = ccols[c].n_blocks;
 	__shared__ double u[16 * GS_MAXA];
 	__shared__ double tot[GS_MAXGL];
+	__shared__ uint8_t gsh[16 * GS_MAXA * 4];   // gidx [T][A][n_ind <= 4]: read TA times per output below (from global memory: a round trip each)
+	for (uint32_t q = threadIdx.x; q < TA * n_ind; q += 256u) gsh[q] = G.gidx[q];
 	const double* p = u_partials + (size_t)blockIdx.x * max_blocks * TA;
 	if (threadIdx.x < TA) {
+		// (eight partial sums requested at a time, added in block order: written as one load per trip the loop was a memory round trip per block --
+		// 64 of them in a row for a trio's column)
 		double v = 0.0;
-		for (uint32_t blk = 0; blk < nb; ++blk) v += p[(size_t)blk * TA + threadIdx.x];
+		uint32_t blk = 0;
+		for (; blk + 8u <= nb; blk += 8u) {
+			double t8[8];
+#pragma unroll
+			for (uint32_t q = 0; q < 8u; ++q) t8[q] = p[(size_t)(blk + q) * TA + threadIdx.x];
+#pragma unroll
+			for (uint32_t q = 0; q < 8u; ++q) v += t8[q];
+		}
+		for (; blk < nb; ++blk) v += p[(size_t)blk * TA + threadIdx.x];
 		u[threadIdx.x] = v * G.prior[(size_t)c * TA + threadIdx.x];
 	}
 	__syncthreads();
@@ -563,7 +575,7 @@ __global__ __launch_bounds__(256) void geno_slot_finish(GsDev G, const double* _
 		double v = 0.0;
 		const uint32_t s = threadIdx.x ? (threadIdx.x - 1) / 3 : 0, g = threadIdx.x ? (threadIdx.x - 1) % 3 : 0;
 		for (uint32_t q = 0; q < TA; ++q)
-			if (threadIdx.x == 0 || G.gidx[(size_t)q * n_ind + s] == g) v += u[q];
+			if (threadIdx.x == 0 || gsh[q * n_ind + s] == g) v += u[q];
 		tot[threadIdx.x] = v;
 	}
 	__syncthreads();
