@@ -36,7 +36,9 @@
 extern "C" {
 #endif
 
-#define WHAMD_ABI_VERSION 1
+/* 2: whamd_plan_summary grew (n_yform_runs, n_fact_runs), whamd_solve_stats.group_tables / host_flatten_ms: a caller built against
+ * version 1 must not be handed the larger structs -- bindings compare whamd_abi_version() with the header they were built from. */
+#define WHAMD_ABI_VERSION 2
 
 /* allele codes, identical to Entry::allele_t (src/entry.h:8) */
 #define WHAMD_ALLELE_REF 0
@@ -106,6 +108,9 @@ typedef struct whamd_solve_stats {
 	uint32_t bt_rewalked;        /*   units walked again from the true state */
 	uint32_t group_tables;       /* tables that shared this solve's forward launches (whamd_dptable_enqueue_many groups tables of one device;
 	                              * 1: the table ran alone).  forward_ms / forward_launches then describe the GROUP's launches. */
+	double host_flatten_ms;      /* the part of host_prepare_ms spent flattening the ReadSet (ColumnIterator's work, src/columniterator.cpp:91-169):
+	                              * host_prepare_ms - host_flatten_ms = indexing scheme, cost terms, plan and upload -- what the reference's constructor
+	                              * does before compute_table (src/pedigreedptable.cpp:15-37; SURVEY.md 8d puts it inside the solve time) */
 } whamd_solve_stats;
 
 /* Library / device introspection. */
@@ -215,7 +220,8 @@ whamd_status_t whamd_dptable_get_index_path(const whamd_dptable* table, uint32_t
 whamd_status_t whamd_dptable_get_stats(const whamd_dptable* table, whamd_solve_stats* stats_out);
 
 /* Options (for A/B measurements and tests), effective at the next solve:
- *   "path"          "auto" (default: slot runs for a single individual, LDS-resident runs for a trio) | "slots" | "resident" |
+ *   "path"          "auto" (default: slot runs for a single individual and for one or two trios -- pedigree slot runs, csrc/kernels_pedslots.h --,
+ *                   the per-column kernels for larger pedigrees) | "slots" | "resident" (round 1's LDS-resident runs, kept for comparison) |
  *                   "column" (one launch per column, the general path) | "column_keys"
  *   "slot_l"        preferred number of local slots of a slot run (slot_r + 6 .. slot_r + 9: 1 .. 8 waves per workgroup)
  *   "slot_r"        reg slots of a slot run: "2" (4 cells per thread, default) or "3" (8 cells per thread)
@@ -236,7 +242,7 @@ whamd_status_t whamd_dptable_set_option(whamd_dptable* table, const char* key, c
  * whamd_dptable_create would and reports how the columns are scheduled.  Used by the CPU test-suite to check
  * the planner's invariants (every column in exactly one step, runs within the LDS budget, ...).
  */
-typedef struct whamd_plan_summary {
+typedef struct whamd_plan_summary {   /* (the CPU plan emulators that used to be declared below live in whatshap_amd_debug.h: test-only library) */
 	uint64_t n_columns;
 	uint64_t n_steps;             /* launches of the forward pass (runs + per-column steps) */
 	uint64_t n_runs;              /* resident runs (one launch each) */
@@ -258,28 +264,6 @@ whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uin
                                     const whamd_pedigree_view* pedigree, int distrust_genotypes,
                                     const uint32_t* positions, size_t n_positions, const char* path,
                                     whamd_plan_summary* out);
-
-/* Host-only diagnostic of the slot-run planner (no device needed, small inputs only): builds the forward plan of a
- * single-individual table exactly as whamd_dptable_create would (slot_l local slots preferred -- add 100 for 8 instead of 4 cells per thread --, symmetry level) and
- * executes it cell by cell on the CPU the way the kernels do -- same physical cell indices, decision bits, record
- * layout, exchange layouts and mirror rules.  index_out[n_columns]: the index path (index_path[c].index,
- * src/pedigreedptable.h:17-21), score_out: the optimal score.  Lets the CPU test-suite check the PLAN against the
- * oracle; not a solver and never used by one (WHAMD_ERR_UNSUPPORTED for pedigrees). */
-whamd_status_t whamd_debug_emulate_slot_plan(const whamd_readset_view* readset, const uint32_t* recombcost, size_t n_recombcost,
-                                            const whamd_pedigree_view* pedigree, int distrust_genotypes,
-                                            const uint32_t* positions, size_t n_positions, int slot_l, int symmetry,
-                                            uint32_t* index_out, uint32_t* score_out, uint64_t* n_run_columns_out);
-
-/* The same diagnostic for a pedigree table with one or two trios (T = 4 / 16): the pedigree slot plan (one (cell,
- * transmission value) per lane, cost forms split into per-workgroup / per-wave / per-lane tables, butterfly min-plus
- * step, one record byte per lane and column) executed on the CPU as kernels_pedslots.h does it.  slot_l <= 0: the
- * default number of local slots, else that many.  transmission_out[n_columns]: index_path[c].inheritance_value.
- * WHAMD_ERR_UNSUPPORTED when the table is not eligible for pedigree slot runs. */
-whamd_status_t whamd_debug_emulate_pedslot_plan(const whamd_readset_view* readset, const uint32_t* recombcost, size_t n_recombcost,
-                                               const whamd_pedigree_view* pedigree, int distrust_genotypes,
-                                               const uint32_t* positions, size_t n_positions, int slot_l,
-                                               uint32_t* index_out, uint32_t* transmission_out, uint32_t* score_out,
-                                               uint64_t* n_run_columns_out);
 
 /* ---- PedMecHeuristic: the beam-search sibling of PedigreeDPTable behind the same Python API -------------
  * Replaces cpp.PedMecHeuristic (whatshap/cpp.pxd:260-268; src/pedmecheuristic.h:56-120): constructor arguments of
@@ -320,12 +304,6 @@ typedef struct whamd_heuristic_job {
 } whamd_heuristic_job;
 whamd_status_t whamd_pedmec_heuristic_enqueue_many(const whamd_heuristic_job* jobs, size_t n_jobs, int device, whamd_heuristic** out);
 whamd_status_t whamd_pedmec_heuristic_wait(whamd_heuristic* h);
-/* HOST-ONLY DIAGNOSTIC: the same solver source run with one CPU thread (csrc/heuristic_host.cpp), for the CPU test-suite to
- * compare with the compiled reference; never what the drop-in class calls. */
-whamd_status_t whamd_debug_pedmec_heuristic_create_host(const whamd_readset_view* readset, const uint32_t* recombcost, size_t n_recombcost,
-                                                        const whamd_pedigree_view* pedigree, int distrust_genotypes,
-                                                        const uint32_t* positions, size_t n_positions, uint32_t row_limit, int allow_mutations,
-                                                        whamd_heuristic** out);
 uint64_t whamd_pedmec_heuristic_column_count(const whamd_heuristic* h);
 uint32_t whamd_pedmec_heuristic_sample_count(const whamd_heuristic* h);
 uint32_t whamd_pedmec_heuristic_read_count(const whamd_heuristic* h);

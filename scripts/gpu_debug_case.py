@@ -1,6 +1,7 @@
 import random, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from whatshap_amd import _native
+_native.use_debug_library()   # the timing switches and cycle stamps exist in libwhatshap_amd_debug.so only (csrc/debug_build.h)
 from whatshap_amd.synthetic import random_small_instance
 from oracle import OracleTable
 rng = random.Random(11)

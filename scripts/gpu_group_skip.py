@@ -7,6 +7,7 @@ n_cols = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
 cov = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 skips = [int(x) for x in (sys.argv[4].split(",") if len(sys.argv) > 4 else "0,1,2,3,8,11,15".split(","))]
 from whatshap_amd import _native
+_native.use_debug_library()   # the timing switches and cycle stamps exist in libwhatshap_amd_debug.so only (csrc/debug_build.h)
 from whatshap_amd.synthetic import synthetic_block
 problems = [synthetic_block(n_cols, cov, seed=100 + i) for i in range(n_tables)]
 for skip in skips:

@@ -3,6 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["WHAMD_SLOT_STAMPS"] = "1"
 from whatshap_amd import _native
+_native.use_debug_library()   # the timing switches and cycle stamps exist in libwhatshap_amd_debug.so only (csrc/debug_build.h)
 from whatshap_amd.synthetic import synthetic_block
 
 p = synthetic_block(int(sys.argv[1]) if len(sys.argv) > 1 else 20000, 20, seed=3)

@@ -3,6 +3,7 @@ invalid, timings only), next to the LDS-resident path.  Usage: python scripts/gp
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from whatshap_amd import _native
+_native.use_debug_library()   # the timing switches and cycle stamps exist in libwhatshap_amd_debug.so only (csrc/debug_build.h)
 from whatshap_amd.synthetic import synthetic_block
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60000

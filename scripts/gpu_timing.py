@@ -2,6 +2,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from whatshap_amd import _native
+_native.use_debug_library()   # the timing switches and cycle stamps exist in libwhatshap_amd_debug.so only (csrc/debug_build.h)
 from whatshap_amd.synthetic import synthetic_block
 cases = [dict(n_variants=5000, coverage=15, seed=2), dict(n_variants=4000, coverage=20, seed=3)]
 paths = sys.argv[1:] or ["resident", "column"]

@@ -2,6 +2,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from whatshap_amd import _native
+_native.use_debug_library()   # the timing switches and cycle stamps exist in libwhatshap_amd_debug.so only (csrc/debug_build.h)
 from whatshap_amd.synthetic import synthetic_block
 p = synthetic_block(n_variants=20000, coverage=15, seed=4, trio=True)
 print(_native.plan_summary(p))

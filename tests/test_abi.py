@@ -21,6 +21,11 @@ def declared_symbols():
     return sorted(set(re.findall(r"\b(whamd_[a-z_]+)\s*\(", text)))
 
 
+def header_abi_version():
+    text = open(os.path.join(ROOT, "include", "whatshap_amd.h")).read()
+    return int(re.search(r"#define WHAMD_ABI_VERSION (\d+)", text).group(1))
+
+
 def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_native.LIB_PATH)
     names = declared_symbols()
@@ -28,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), name
     assert sorted(_native.EXPORTED_SYMBOLS) == names
-    assert lib.whamd_abi_version() == 1
+    assert lib.whamd_abi_version() == _native.ABI_VERSION == header_abi_version()
 
 
 def het_pedigree(n_positions):
@@ -122,3 +127,18 @@ def test_read_sort_hash_is_libstdcxx_string_hash():
     h0 = _native.read_sort_hash("Read 1", 0)
     assert _native.read_sort_hash("Read 1", 5) == h0 ^ 5
     assert _native.read_sort_hash("Read 2", 0) != h0
+
+
+def test_the_product_library_carries_no_debug_code():
+    """the plan emulators, the host instantiation of the heuristic, the kernel instantiations with cycle stamps and the timing
+    switches that make results invalid live in libwhatshap_amd_debug.so (test infrastructure), not in what the drop-in classes load."""
+    import subprocess
+
+    exported = subprocess.run(["nm", "-D", "--defined-only", _native.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "whamd_debug" not in exported
+    blob = open(_native.LIB_PATH, "rb").read()
+    for marker in (b"WHAMD_SLOT_SKIP", b"WHAMD_SLOT_STAMPS", b"WHAMD_DEBUG_STAMPS", b"WHAMD_NO_YFORM", b"WHAMD_GROUP_PARTS"):
+        assert marker not in blob, marker
+    debug = subprocess.run(["nm", "-D", "--defined-only", _native.DEBUG_LIB_PATH], capture_output=True, text=True, check=True).stdout
+    for name in ("whamd_debug_emulate_slot_plan", "whamd_debug_emulate_pedslot_plan", "whamd_debug_pedmec_heuristic_create_host"):
+        assert name in debug

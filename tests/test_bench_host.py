@@ -86,3 +86,73 @@ def test_roofline_fractions_from_counters():
     assert abs(r["hbm_model_ratio"] - 2.0) < 0.01   # kept, labelled as a model ratio, never as `frac`
     empty = b.roofline_from_counters(None, 17.29, "resident_segment", 276.6e6, _args())
     assert empty["frac"] is None and empty["traffic"] is None
+
+
+def _canned_result(b, n_entries):
+    """A record shaped like round 4's 22.9 KB line: long notes, counters, samples, host shapes tried."""
+    roof = {"bound": "valu_issue", "kernel": "slot_run", "unit": "wave-instructions/cycle (chip)", "peak": 512.0, "avg_launch_us": 9.4371, "clock_ghz_assumed": 2.4,
+            "achieved": 58.812345, "frac": 0.1148678, "valu_issue_frac": 0.1148678, "valu_active_frac": 0.2301, "valu_active_note": "x" * 200, "traffic": 5946774.2, "hbm_frac": 0.0787,
+            "traffic_note": "y" * 150, "lds_pipe_frac": 0.1426, "hbm_model_ratio": 3.66, "hbm_model_note": "z" * 300, "counters_per_launch": {f"SQ_{i}": 1.5e6 + i for i in range(20)},
+            "counters_measured_on": "w" * 200, "pmc_note": "", "work_bound_frac": 0.0431, "work_bound_note": "v" * 150}
+    cpu = {"value": 13.2871, "unit": "variant-columns/s", "cores": 1, "kind": "reference", "sample": "columns 48..257 of the same seeded ReadSet " + "s" * 300, "seconds": 17.9,
+           "host": {"nproc": 256, "model": "AMD EPYC 9575F 64-Core Processor"}}
+    entries = []
+    for i in range(n_entries):
+        entries.append({"name": f"config1_x{i}", "workload": "t" * 160, "value": 28123456.789 + i, "unit": "variant-columns/s", "ms_per_step": 42.81234, "ms_per_step_min": 42.1, "ms_per_step_median": 42.7,
+                        "steps": 10, "warmup": 2, "tables_in_flight": 24, "tables_per_launch": 24, "identical_to_reference": True,
+                        "end_to_end": {"value": 12712345.6, "fraction_of_device_only": 0.45, "wall_ms": 94.4, "tried": [{"tables_per_window": w, "create_threads": 16, "host_threads_per_create": 2, "wall_ms": 99.0} for w in (8, 12, 24)]},
+                        "bipartition_costs_per_s": 9.2e11, "optimal_cost_checksum": 741432, "forward_launches_per_step": 3322.0,
+                        "roofline": {k: roof[k] for k in ("bound", "kernel", "frac", "valu_active_frac", "work_bound_frac", "avg_launch_us", "peak", "unit", "pmc_note")}, "wall_s": 9.3,
+                        "cpu_baseline": {k: cpu[k] for k in ("value", "unit", "cores", "kind", "sample")}, "speedup_vs_cpu_baseline_device_only": 69000.0})
+    entries.append({"name": "broken", "error": "rc=1 " + "e" * 300})
+    return {"metric": "variant-columns/sec at max-coverage 20 (bipartition-costs/sec reported alongside)", "value": 2251234.5678, "unit": "variant-columns/s", "bipartition_costs_per_s": 2.36e12,
+            "bipartition_costs_note": "n" * 250, "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 88.8512345, "ms_per_step_min": 88.1, "ms_per_step_median": 88.8, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "synthetic diploid single-individual, max-coverage 20: 1 block of 200000 SNVs (BASELINE configs[2])", "blocks": 1, "blocks_per_rank": [1], "block_seeds_per_rank": [[3]],
+                       "device_per_rank": [0], "blocks_in_flight_per_gpu": 1, "tables_per_launch": 1, "max_coverage": 20, "transmission_values": 1, "path": "auto", "options": [],
+                       "optimal_cost_checksum": 1611545, "optimal_cost_checksum_per_rank": [1611545], "rendezvous": "none"},
+            "rank0": {"forward_ms_per_step": 85.7, "backtrace_ms_per_step": 0.6, "forward_launches_per_step": 9099.0},
+            "end_to_end": {"value": 1781234.5, "unit": "variant-columns/s", "create_ms": 24.1, "solve_and_getters_ms": 88.2, "host_threads": 32, "fraction_of_device_only": 0.79, "what": "q" * 150},
+            "value_8d_strict": {"value": 1801234.5, "unit": "variant-columns/s", "ms": 111.0, "create_ms": 24.1, "columns_and_terms_ms": 9.9, "device_ms": 86.9, "superreads_ms_excluded": 1.3, "what": "p" * 200},
+            "roofline": roof, "cpu_baseline": cpu, "identical_to_reference": True, "identical_what": "i" * 150, "speedup_vs_cpu_baseline_device_only": 169432.1, "speedup_vs_cpu_baseline": 134000.0,
+            "configs": entries}
+
+
+def test_the_last_line_stays_small_and_parses():
+    """BENCH_r04.json had parsed = null because the single JSON line had grown to 22.9 KB.  The last stdout line is now a compact record
+    (head keys, the headline's roofline and cpu_baseline, one short record per `configs` entry); the detail goes to comment lines and a side file."""
+    import io
+    import json
+    from contextlib import redirect_stdout
+
+    b = _bench()
+    out = _canned_result(b, 18)
+    assert len(json.dumps(out)) > 20000                       # the full record is as large as round 4's
+    text = b.compact_line(out, "gpurun_out/bench_detail.json")
+    assert len(text) < 6000 and "\n" not in text
+    line = json.loads(text)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline",
+                "cpu_baseline", "identical_to_reference", "configs", "value_8d_strict"):
+        assert key in line, key
+    assert line["value"] == 2251235 and abs(line["ms_per_step"] - 88.85123) < 1e-4 and line["steps"] == 20 and line["warmup"] == 5
+    assert line["config"]["workload"].startswith("synthetic diploid") and "model" not in line["config"]
+    for key in ("kernel", "bound", "achieved", "peak", "unit", "frac", "valu_active_frac", "work_bound_frac", "traffic", "hbm_frac", "avg_launch_us"):
+        assert key in line["roofline"], key
+    assert set(line["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"} and len(line["cpu_baseline"]["sample"]) <= 140
+    assert len(line["configs"]) == 19 and line["configs"]["config1_x3"]["ident"] is True and line["configs"]["config1_x3"]["value"] == 28123460
+    assert "error" in line["configs"]["broken"]
+    # far more entries than bench.py has: the line sheds its optional parts instead of growing past the limit
+    huge = b.compact_line(_canned_result(b, 90), "gpurun_out/bench_detail.json")
+    assert len(huge) < 6000 and json.loads(huge)["roofline"]["frac"] and json.loads(huge)["cpu_baseline"]["value"]
+    # emit(): comment lines first, the compact line LAST
+    import tempfile
+    args = types.SimpleNamespace(sub=False, detail_file=os.path.join(tempfile.mkdtemp(), "d", "bench_detail.json"))
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        b.emit(out, args)
+    lines = buf.getvalue().strip().splitlines()
+    assert all(ln.startswith("# bench detail ") for ln in lines[:-1]) and len(lines) == 21
+    last = json.loads(lines[-1])
+    assert last["value"] == 2251235 and len(lines[-1]) < 6000
+    assert json.load(open(args.detail_file))["configs"][0]["end_to_end"]["tried"][0]["tables_per_window"] == 8   # nothing is lost: the side file has it all
+    assert sum(1 for ln in lines if ln.startswith("{")) == 1     # exactly one line a JSON-line parser can pick up

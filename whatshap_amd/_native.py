@@ -16,6 +16,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwhatshap_amd.so")
+DEBUG_LIB_PATH = os.path.join(_HERE, "libwhatshap_amd_debug.so")   # test infrastructure (debug_lib)
+ABI_VERSION = 2   # WHAMD_ABI_VERSION of include/whatshap_amd.h this file mirrors (struct layouts below)
 
 WHAMD_OK = 0
 WHAMD_ERR_INVALID = 1
@@ -80,6 +82,7 @@ class SolveStats(C.Structure):
         ("bt_missed", C.c_uint32),
         ("bt_rewalked", C.c_uint32),
         ("group_tables", C.c_uint32),
+        ("host_flatten_ms", C.c_double),
     ]
 
     def as_dict(self) -> dict:
@@ -221,6 +224,7 @@ class ProblemArrays:
 
 
 _lib = None
+_debug_lib = None
 
 
 def lib() -> C.CDLL:
@@ -234,7 +238,45 @@ def lib() -> C.CDLL:
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C whatshap_amd/csrc). "
             "whatshap_amd has no CPU fallback."
         )
-    L = C.CDLL(LIB_PATH)
+    _lib = _bind(C.CDLL(LIB_PATH), LIB_PATH)
+    return _lib
+
+
+def debug_lib() -> C.CDLL:
+    """TEST INFRASTRUCTURE: libwhatshap_amd_debug.so -- the same sources compiled with -DWHAMD_DEBUG_BUILD: the CPU plan emulators, the
+    host instantiation of the heuristic (include/whatshap_amd_debug.h), the kernel instantiations with cycle stamps and the timing switches
+    (WHAMD_SLOT_STAMPS, WHAMD_SLOT_SKIP: results invalid).  None of that is in the product library.  A handle made by one library is only
+    ever passed to functions of the same library."""
+    global _debug_lib
+    if _debug_lib is not None:
+        return _debug_lib
+    if not os.path.exists(DEBUG_LIB_PATH):
+        raise ImportError(f"{DEBUG_LIB_PATH} is missing: make -C whatshap_amd/csrc debug (tests and timing scripts only)")
+    L = _bind(C.CDLL(DEBUG_LIB_PATH), DEBUG_LIB_PATH)
+    L.whamd_debug_emulate_slot_plan.restype = C.c_int
+    L.whamd_debug_emulate_slot_plan.argtypes = [
+        C.POINTER(ReadSetView), C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(PedigreeView), C.c_int,
+        C.POINTER(C.c_uint32), C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
+    ]
+    L.whamd_debug_emulate_pedslot_plan.restype = C.c_int
+    L.whamd_debug_emulate_pedslot_plan.argtypes = [
+        C.POINTER(ReadSetView), C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(PedigreeView), C.c_int,
+        C.POINTER(C.c_uint32), C.c_size_t, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
+    ]
+    L.whamd_debug_pedmec_heuristic_create_host.restype = C.c_int
+    L.whamd_debug_pedmec_heuristic_create_host.argtypes = [C.POINTER(ReadSetView), C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(PedigreeView), C.c_int,
+                                                           C.POINTER(C.c_uint32), C.c_size_t, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]
+    _debug_lib = L
+    return L
+
+
+def use_debug_library() -> None:
+    """Timing scripts (scripts/gpu_slot_stamps.py ...): every later call of this process goes through the debug build."""
+    global _lib
+    _lib = debug_lib()
+
+
+def _bind(L: C.CDLL, path: str) -> C.CDLL:
     H = C.c_void_p
     L.whamd_abi_version.restype = C.c_int
     L.whamd_device_count.restype = C.c_int
@@ -290,22 +332,10 @@ def lib() -> C.CDLL:
         C.POINTER(ReadSetView), C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(PedigreeView), C.c_int,
         C.POINTER(C.c_uint32), C.c_size_t, C.c_char_p, C.POINTER(PlanSummary),
     ]
-    L.whamd_debug_emulate_slot_plan.restype = C.c_int
-    L.whamd_debug_emulate_slot_plan.argtypes = [
-        C.POINTER(ReadSetView), C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(PedigreeView), C.c_int,
-        C.POINTER(C.c_uint32), C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
-    ]
-    L.whamd_debug_emulate_pedslot_plan.restype = C.c_int
-    L.whamd_debug_emulate_pedslot_plan.argtypes = [
-        C.POINTER(ReadSetView), C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(PedigreeView), C.c_int,
-        C.POINTER(C.c_uint32), C.c_size_t, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
-    ]
     heur_args = [C.POINTER(ReadSetView), C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(PedigreeView), C.c_int,
                  C.POINTER(C.c_uint32), C.c_size_t, C.c_uint32, C.c_int]
     L.whamd_pedmec_heuristic_create.restype = C.c_int
     L.whamd_pedmec_heuristic_create.argtypes = heur_args + [C.c_int, C.POINTER(C.c_void_p)]
-    L.whamd_debug_pedmec_heuristic_create_host.restype = C.c_int
-    L.whamd_debug_pedmec_heuristic_create_host.argtypes = heur_args + [C.POINTER(C.c_void_p)]
     L.whamd_pedmec_heuristic_enqueue_many.restype = C.c_int
     L.whamd_pedmec_heuristic_enqueue_many.argtypes = [C.POINTER(HeuristicJob), C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
     L.whamd_pedmec_heuristic_wait.restype = C.c_int
@@ -335,9 +365,8 @@ def lib() -> C.CDLL:
         C.POINTER(ReadSetView), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_size_t, C.c_uint32, C.c_int,
         C.POINTER(C.c_uint8), C.POINTER(C.c_uint64),
     ]
-    if L.whamd_abi_version() != 1:
-        raise ImportError("libwhatshap_amd.so has an unexpected ABI version")
-    _lib = L
+    if L.whamd_abi_version() != ABI_VERSION:
+        raise ImportError(f"{path} has ABI version {L.whamd_abi_version()}, this binding was written for {ABI_VERSION} (stale library? run make)")
     return L
 
 
@@ -348,8 +377,8 @@ EXPORTED_SYMBOLS = [
     "whamd_dptable_read_count", "whamd_dptable_positions", "whamd_dptable_get_optimal_score",
     "whamd_dptable_get_super_reads", "whamd_dptable_get_optimal_partitioning", "whamd_dptable_get_index_path",
     "whamd_dptable_get_stats", "whamd_dptable_set_option", "whamd_read_sort_hash", "whamd_plan_summarize",
-    "whamd_dptable_enqueue", "whamd_dptable_wait", "whamd_dptable_enqueue_many", "whamd_dptable_wait_many", "whamd_debug_emulate_slot_plan",
-    "whamd_debug_emulate_pedslot_plan", "whamd_pedmec_heuristic_create", "whamd_debug_pedmec_heuristic_create_host",
+    "whamd_dptable_enqueue", "whamd_dptable_wait", "whamd_dptable_enqueue_many", "whamd_dptable_wait_many",
+    "whamd_pedmec_heuristic_create",
     "whamd_pedmec_heuristic_enqueue_many", "whamd_pedmec_heuristic_wait",
     "whamd_pedmec_heuristic_column_count", "whamd_pedmec_heuristic_sample_count", "whamd_pedmec_heuristic_read_count",
     "whamd_pedmec_heuristic_get", "whamd_pedmec_heuristic_get_stats", "whamd_pedmec_heuristic_destroy",
@@ -365,9 +394,9 @@ class SolverError(RuntimeError):
         self.status = status
 
 
-def _check(status: int):
+def _check(status: int, L=None):
     if status != WHAMD_OK:
-        raise SolverError(status, lib().whamd_last_error().decode("utf-8", "replace"))
+        raise SolverError(status, (L or lib()).whamd_last_error().decode("utf-8", "replace"))
 
 
 def enqueue_many(tables) -> None:
@@ -493,8 +522,9 @@ def emulate_slot_plan(problem: ProblemArrays, n_columns: int, slot_l: int = 11, 
     idx = np.zeros(max(n_columns, 1), dtype=np.uint32)
     score = C.c_uint32()
     ncols = C.c_uint64()
-    _check(lib().whamd_debug_emulate_slot_plan(*problem.call_args(), C.c_int(slot_l), C.c_int(symmetry), _ptr(idx, C.c_uint32),
-                                               C.byref(score), C.byref(ncols)))
+    D = debug_lib()
+    _check(D.whamd_debug_emulate_slot_plan(*problem.call_args(), C.c_int(slot_l), C.c_int(symmetry), _ptr(idx, C.c_uint32),
+                                           C.byref(score), C.byref(ncols)), D)
     return idx[:n_columns], int(score.value), int(ncols.value)
 
 
@@ -505,8 +535,9 @@ def emulate_pedslot_plan(problem: ProblemArrays, n_columns: int, slot_l: int = 0
     trans = np.zeros(max(n_columns, 1), dtype=np.uint32)
     score = C.c_uint32()
     ncols = C.c_uint64()
-    _check(lib().whamd_debug_emulate_pedslot_plan(*problem.call_args(), C.c_int(slot_l), _ptr(idx, C.c_uint32), _ptr(trans, C.c_uint32),
-                                                  C.byref(score), C.byref(ncols)))
+    D = debug_lib()
+    _check(D.whamd_debug_emulate_pedslot_plan(*problem.call_args(), C.c_int(slot_l), _ptr(idx, C.c_uint32), _ptr(trans, C.c_uint32),
+                                              C.byref(score), C.byref(ncols)), D)
     return idx[:n_columns], trans[:n_columns], int(score.value), int(ncols.value)
 
 
@@ -522,9 +553,9 @@ def _heuristic_result(L, h) -> dict:
     sid = np.zeros(max(ns, 1), dtype=np.uint32)
     pos = np.zeros(max(n, 1), dtype=np.uint32)
     _check(L.whamd_pedmec_heuristic_get(h, C.byref(score), _ptr(bip, C.c_uint8), _ptr(trans, C.c_uint32), haps.ctypes.data_as(C.POINTER(C.c_int8)),
-                                        _ptr(mut, C.c_uint8), _ptr(sid, C.c_uint32), _ptr(pos, C.c_uint32)))
+                                        _ptr(mut, C.c_uint8), _ptr(sid, C.c_uint32), _ptr(pos, C.c_uint32)), L)
     stats = HeuristicStats()
-    _check(L.whamd_pedmec_heuristic_get_stats(h, C.byref(stats)))
+    _check(L.whamd_pedmec_heuristic_get_stats(h, C.byref(stats)), L)
     return {"score": float(score.value), "bipartition": bip[:nr], "transmission": trans[:n], "haplotypes": haps[:ns, :, :n], "mutated": mut[:ns, :, :n],
             "sample_ids": sid[:ns], "positions": pos[:n], "stats": stats.as_dict()}
 
@@ -532,11 +563,11 @@ def _heuristic_result(L, h) -> dict:
 def pedmec_heuristic(problem: ProblemArrays, row_limit: int = 256, allow_mutations: bool = True, device: int = 0, host_diagnostic: bool = False) -> dict:
     """whamd_pedmec_heuristic_create + _get: the beam search of PedMecHeuristic (constructor + solve) and everything its getters
     return.  host_diagnostic: the same solver source on one CPU thread (tests only)."""
-    L = lib()
+    L = debug_lib() if host_diagnostic else lib()   # (the handle stays with the library that made it)
     h = C.c_void_p()
     a = problem.call_args()
     if host_diagnostic:
-        _check(L.whamd_debug_pedmec_heuristic_create_host(*a, C.c_uint32(int(row_limit)), C.c_int(1 if allow_mutations else 0), C.byref(h)))
+        _check(L.whamd_debug_pedmec_heuristic_create_host(*a, C.c_uint32(int(row_limit)), C.c_int(1 if allow_mutations else 0), C.byref(h)), L)
     else:
         _check(L.whamd_pedmec_heuristic_create(*a, C.c_uint32(int(row_limit)), C.c_int(1 if allow_mutations else 0), C.c_int(int(device)), C.byref(h)))
     try:

@@ -166,22 +166,33 @@ def solve_blocks(problems: Sequence[ProblemArrays], device: int = 0, path=None, 
                 if trace is not None:
                     trace.append((what, wi, (time.perf_counter() - t_begin) * 1e3))
 
-            for wi in range(len(windows)):
-                window = [f.result() for f in pending]
-                mark("created", wi)
-                enqueue_many(window)      # queued behind (and beside) the previous window: the device never waits for the host
-                mark("enqueued", wi)
-                pending = ((all_pending[wi + 1] if eager_create else submit_window(windows[wi + 1])) if wi + 1 < len(windows) else [])   # built while the device solves
-                if windows_on_device < 2:
-                    collect(window)
-                    mark("collected", wi)
-                    continue
+            try:
+                for wi in range(len(windows)):
+                    window = [f.result() for f in pending]
+                    mark("created", wi)
+                    enqueue_many(window)      # queued behind (and beside) the previous window: the device never waits for the host
+                    mark("enqueued", wi)
+                    pending = ((all_pending[wi + 1] if eager_create else submit_window(windows[wi + 1])) if wi + 1 < len(windows) else [])   # built while the device solves
+                    if windows_on_device < 2:
+                        collect(window)
+                        mark("collected", wi)
+                        continue
+                    if in_flight is not None:
+                        done, in_flight = in_flight, None
+                        collect(done)
+                        mark("collected", wi - 1)
+                    in_flight = window
                 if in_flight is not None:
-                    collect(in_flight)
-                    mark("collected", wi - 1)
-                in_flight = window
-            if in_flight is not None:
-                collect(in_flight)
+                    done, in_flight = in_flight, None
+                    collect(done)
+            finally:
+                if in_flight is not None:     # a create or an enqueue raised while a window was still on the device: collect it (its tables hold
+                    try:                      # streams and arena blocks) before the exception leaves
+                        wait_many(in_flight)
+                    except Exception:  # noqa: BLE001 -- the first error is the one to report
+                        pass
+                    for t in in_flight:
+                        t.close()
             for f in releases:
                 f.result()
         return tables
@@ -201,8 +212,11 @@ def solve_blocks(problems: Sequence[ProblemArrays], device: int = 0, path=None, 
     def worker(slot):
         try:
             share = shares[slot]
+            # every device worker builds its own tables: the host's create threads are shared out between them
             solved = solve_blocks([problems[b] for b in share], device=devices[slot], path=path,
-                                  max_in_flight=max_in_flight, release=release, create_threads=create_threads)
+                                  max_in_flight=max_in_flight, release=release, create_threads=max(1, create_threads // len(devices)),
+                                  host_threads_per_create=host_threads_per_create, windows_on_device=windows_on_device,
+                                  eager_create=eager_create, trace=trace)
             for b, t in zip(share, solved):
                 out[b] = t
         except BaseException as exc:  # noqa: BLE001 -- re-raised in the caller's thread

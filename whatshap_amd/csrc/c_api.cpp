@@ -9,6 +9,10 @@
 #include <stdexcept>
 #include <string>
 
+#include "debug_build.h"
+#ifdef WHAMD_DEBUG_BUILD
+#include "../../include/whatshap_amd_debug.h"
+#endif
 #include "device_table.h"
 #include "genotype.h"
 #include "heuristic.h"
@@ -109,6 +113,7 @@ whamd_status_t create_table(const whamd_readset_view* readset, const uint32_t* r
 		fprintf(stderr, "[whamd timing] create: flatten %.1f ms, plan + upload %.1f ms\n", t1 - t0, now_ms() - t1);
 	t->uploaded = true;
 	t->stats.host_prepare_ms = now_ms() - t0;
+	t->stats.host_flatten_ms = t1 - t0;
 	*out = t.release();
 	return WHAMD_OK;
 }
@@ -273,6 +278,11 @@ whamd_status_t whamd_dptable_wait_many(whamd_dptable* const* tables, size_t n_ta
 	for (size_t i = 0; i < n_tables; ++i) {
 		if (!tables[i]) return fail(WHAMD_ERR_INVALID, "table is NULL");
 		if (!tables[i]->in_flight) return fail(WHAMD_ERR_INVALID, "whamd_dptable_enqueue has not run");
+	}
+	{   // a table listed twice would be finished by two host threads at once
+		std::vector<const whamd_dptable*> seen(tables, tables + n_tables);
+		std::sort(seen.begin(), seen.end());
+		if (std::adjacent_find(seen.begin(), seen.end()) != seen.end()) return fail(WHAMD_ERR_INVALID, "a table appears twice in the list");
 	}
 	// the device side of every table first (stream by stream: paths and scores arrive in pinned buffers) ...
 	whamd_status_t first = WHAMD_OK;
@@ -458,7 +468,7 @@ whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uin
 			uint32_t expect = 0;
 			for (const Step& step : sp.steps) {
 				if (step.kind != 2) {
-					if (getenv("WHAMD_DEBUG_PLAN")) fprintf(stderr, "[plan] genotype: column %u outside runs (k=%u b=%u f=%u, next k=%u)\n", step.index, p.k[step.index], p.b[step.index], p.f[step.index], step.index + 1 < p.n_cols ? p.k[step.index + 1] : 0);
+					if (debug_env("WHAMD_DEBUG_PLAN")) fprintf(stderr, "[plan] genotype: column %u outside runs (k=%u b=%u f=%u, next k=%u)\n", step.index, p.k[step.index], p.b[step.index], p.f[step.index], step.index + 1 < p.n_cols ? p.k[step.index + 1] : 0);
 					ok = ok && step.index == expect; expect = step.index + 1; continue;
 				}
 				const SlotRun& run = sp.runs[step.index];
@@ -629,6 +639,7 @@ whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uin
 	});
 }
 
+#ifdef WHAMD_DEBUG_BUILD   // libwhatshap_amd_debug.so only (include/whatshap_amd_debug.h): test infrastructure
 whamd_status_t whamd_debug_emulate_slot_plan(const whamd_readset_view* readset, const uint32_t* recombcost, size_t n_recombcost,
                                             const whamd_pedigree_view* pedigree, int distrust_genotypes, const uint32_t* positions,
                                             size_t n_positions, int slot_l, int symmetry, uint32_t* index_out, uint32_t* score_out,
@@ -676,6 +687,7 @@ whamd_status_t whamd_debug_emulate_pedslot_plan(const whamd_readset_view* readse
 	return WHAMD_OK;
 	});
 }
+#endif   // WHAMD_DEBUG_BUILD
 
 }  // extern "C"
 
@@ -782,6 +794,9 @@ whamd_status_t heuristic_create_common(const whamd_readset_view* readset, const 
 		*out = h;
 		return WHAMD_OK;
 	}
+#ifndef WHAMD_DEBUG_BUILD
+	return fail(WHAMD_ERR_DEVICE, "the host instantiation of the heuristic exists in the debug library only");
+#else
 	const double t0 = now_ms();
 	std::unique_ptr<whamd_heuristic> h(new whamd_heuristic());
 	std::string msg;
@@ -800,6 +815,7 @@ whamd_status_t heuristic_create_common(const whamd_readset_view* readset, const 
 	h->finished = true;
 	*out = h.release();
 	return WHAMD_OK;
+#endif
 }
 }  // namespace
 
@@ -826,6 +842,7 @@ whamd_status_t whamd_pedmec_heuristic_wait(whamd_heuristic* h) {
 	});
 }
 
+#ifdef WHAMD_DEBUG_BUILD
 whamd_status_t whamd_debug_pedmec_heuristic_create_host(const whamd_readset_view* readset, const uint32_t* recombcost, size_t n_recombcost,
                                                         const whamd_pedigree_view* pedigree, int distrust_genotypes, const uint32_t* positions,
                                                         size_t n_positions, uint32_t row_limit, int allow_mutations, whamd_heuristic** out) {
@@ -833,6 +850,7 @@ whamd_status_t whamd_debug_pedmec_heuristic_create_host(const whamd_readset_view
 	return heuristic_create_common(readset, recombcost, n_recombcost, pedigree, distrust_genotypes, positions, n_positions, row_limit, allow_mutations, 0, true, out);
 	});
 }
+#endif
 
 uint64_t whamd_pedmec_heuristic_column_count(const whamd_heuristic* h) { return h ? h->plan.n_cols : 0; }
 uint32_t whamd_pedmec_heuristic_sample_count(const whamd_heuristic* h) { return h ? h->plan.n_samples : 0; }
@@ -860,7 +878,10 @@ whamd_status_t whamd_pedmec_heuristic_get_stats(const whamd_heuristic* h, whamd_
 
 void whamd_pedmec_heuristic_destroy(whamd_heuristic* h) {
 	if (h && h->batch) {   // still in flight: the batch reads this handle's plan -- collect it first (the other members keep their results)
-		(void)heuristic_collect(h);
+		try {
+			(void)heuristic_collect(h);   // allocates, runs host threads, waits for the device: nothing it throws may cross the C boundary
+		} catch (...) {
+		}
 	}
 	delete h;
 }

@@ -26,6 +26,7 @@
 #include <string>
 #include <vector>
 
+#include "debug_build.h"
 #include "device_pool.h"
 #include "device_table.h"
 #include "genotype.h"
@@ -244,7 +245,7 @@ void arena_give(int device, void* ptr, size_t bytes) {   // called with `device`
 		size_t idle = 0, total_b = 0, free_b = 0;
 		for (const ArenaCache::Block& b : g_arena.blocks) idle += b.bytes;
 		const bool room = hipMemGetInfo(&free_b, &total_b) == hipSuccess && idle + bytes <= total_b / 5 * 2;
-		if (room && g_arena.blocks.size() < ARENA_BLOCKS && bytes >= ((size_t)32 << 20) && getenv("WHAMD_NO_ARENA_CACHE") == nullptr) {
+		if (room && g_arena.blocks.size() < ARENA_BLOCKS && bytes >= ((size_t)32 << 20) && debug_env("WHAMD_NO_ARENA_CACHE") == nullptr) {
 			g_arena.blocks.push_back(ArenaCache::Block{ptr, bytes, device});
 			return;
 		}
@@ -260,7 +261,7 @@ struct StageSession {
 	int slot = -1;          // the area this session owns (g_stage.areas), -1: none (pageable copies)
 	char* base = nullptr;
 	size_t cap = 0;
-	explicit StageSession(hipStream_t s) : stream(s), enabled(getenv("WHAMD_NO_PINNED_STAGE") == nullptr) {
+	explicit StageSession(hipStream_t s) : stream(s), enabled(debug_env("WHAMD_NO_PINNED_STAGE") == nullptr) {
 		std::lock_guard<std::mutex> lock(g_stage.mu);
 		size_t best = g_stage.areas.size();
 		for (size_t i = 0; i < g_stage.areas.size(); ++i)
@@ -670,7 +671,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		plan_forward(p, want_resident, m.l_pref, m.fold, m.plan, m.symmetry);
 	}
 	const auto tu1 = std::chrono::steady_clock::now();
-	if (getenv("WHAMD_DEBUG_PLAN")) {
+	if (debug_env("WHAMD_DEBUG_PLAN")) {
 		for (const Step& st : m.plan.steps) {
 			if (st.kind == 0) { fprintf(stderr, "[plan] column %u k=%u b=%u f=%u\n", st.index, p.k[st.index], p.b[st.index], p.f[st.index]); continue; }
 			if (st.kind == 2) {
@@ -918,7 +919,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		final_job.final = true;
 		std::vector<Impl::Job> component_jobs;
 		const std::vector<uint32_t>& first = m.plan.component_first_step;
-		const bool split = m.max_lanes > 1 && first.size() > 1 && !getenv("WHAMD_DEBUG_STAMPS") && !m.windowed;
+		const bool split = m.max_lanes > 1 && first.size() > 1 && !debug_env("WHAMD_DEBUG_STAMPS") && !m.windowed;
 		if (!split) {
 			for (uint32_t si = 0; si < m.plan.steps.size(); ++si) final_job.steps.push_back(si);
 		} else {
@@ -1211,7 +1212,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 					e.bt = (uint8_t*)d_bt;
 					e.spec_keys = m.dp.spec_keys;
 					e.spec_stride = m.dp.spec_stride;
-					if (const char* skip = getenv("WHAMD_SLOT_SKIP")) e.pad2 = (uint32_t)atoi(skip);   // (timing experiments in a group launch)
+					if (const char* skip = debug_env("WHAMD_SLOT_SKIP")) e.pad2 = (uint32_t)atoi(skip);   // (timing experiments in a group launch)
 					ss.grid_x = std::max(ss.grid_x, 1u << (e.run.g - e.run.half));
 					ss.threads = std::max(ss.threads, e.run.threads);
 					m.slot_entries.push_back(e);
@@ -1319,16 +1320,16 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		fprintf(stderr, "[whamd timing] upload: plan %.1f ms, descriptors + copies %.1f ms, backtrace arena (%.2f GB) %.1f ms, rest %.1f ms\n",
 		        ms(tu0, tu1), ms(tu1, tu2), (double)bt / 1e9, ms(tu2, tu3), ms(tu3, std::chrono::steady_clock::now()));
 	}
-	if (getenv("WHAMD_DEBUG_STAMPS") && !m.use_slots) {   // in-kernel cycle stamps of the LDS-resident runs (WHAMD_DEBUG_TIMING: host phases only)
+	if (debug_env("WHAMD_DEBUG_STAMPS") && !m.use_slots) {   // in-kernel cycle stamps of the LDS-resident runs (WHAMD_DEBUG_TIMING: host phases only)
 		void* d_dbg = nullptr;
 		const size_t dbg_bytes = (m.plan.segments.size() + 1) * 64 + 4 * 512 * 16 + 64;
 		HIP_TRY(alloc(&d_dbg, dbg_bytes));
 		HIP_TRY(hipMemset(d_dbg, 0, dbg_bytes));
 		m.dp.dbg = (unsigned long long*)d_dbg;
 		m.dp.dbg_wg_off = (uint32_t)((m.plan.segments.size() + 1) * 8);
-		m.dp.dbg_flags = (uint32_t)atoi(getenv("WHAMD_DEBUG_STAMPS"));
+		m.dp.dbg_flags = (uint32_t)atoi(debug_env("WHAMD_DEBUG_STAMPS"));
 	}
-	if (getenv("WHAMD_SLOT_STAMPS") && m.use_slots) {   // in-kernel cycle stamps of workgroup 0 / wave 0 of every slot run
+	if (debug_env("WHAMD_SLOT_STAMPS") && m.use_slots) {   // in-kernel cycle stamps of workgroup 0 / wave 0 of every slot run
 		void* d_dbg = nullptr;
 		const size_t dbg_bytes = (m.splan.runs.size() + 1) * 48 * 8 + 4 * 512 * 16 + 128;   // + the backtrace kernel's own stamps
 		HIP_TRY(alloc(&d_dbg, dbg_bytes));
@@ -1337,7 +1338,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		m.dp.dbg_wg_off = (uint32_t)((m.splan.runs.size() + 1) * 48);
 		for (size_t i = 0; i < m.slot_entries.size(); ++i) m.slot_entries[i].run.pad = (uint32_t)i;
 	}
-	if (const char* skip = getenv("WHAMD_SLOT_SKIP")) m.dp.dbg_flags = (uint32_t)atoi(skip);  // timing experiments (results invalid): 1 no exit
+	if (const char* skip = debug_env("WHAMD_SLOT_SKIP")) m.dp.dbg_flags = (uint32_t)atoi(skip);  // timing experiments (results invalid): 1 no exit
 	                                                                                          // stores, 2 no records, 4 one column per run, 8 no ending reads, 16 no cost update
 	m.dp.n_cols = n;
 	m.dp.T = p.T;
@@ -1427,15 +1428,21 @@ void DeviceTable::Impl::launch_run(const ResBatchEntry& e, uint32_t step_index, 
 	if (sg.kind == 1) {
 		const size_t words = ((size_t)sg.ncols * (PED_LDSWORDS + PED_TABLE) + (size_t)sg.n_terms * 2 + 3) & ~(size_t)3;
 		const size_t lds_ped = words * 4 + 2 * ((size_t)16 << sg.max_l) + (size_t)sg.stage_words * 8;
+#ifdef WHAMD_DEBUG_BUILD
 		if (m.dp.dbg) hipLaunchKernelGGL(resident_segment_ped<true>, dim3(1u << sg.g), dim3(sg.threads), lds_ped, m.run_stream, m.dp, sg, e.prev, e.cur);
-		else if (sg.in_mirror_bit && m.use_chunks) hipLaunchKernelGGL((resident_segment_ped<false, true>), dim3(1u << sg.g), dim3(sg.threads), lds_ped, m.run_stream, m.dp, sg, e.prev, e.cur);
+		else
+#endif
+		if (sg.in_mirror_bit && m.use_chunks) hipLaunchKernelGGL((resident_segment_ped<false, true>), dim3(1u << sg.g), dim3(sg.threads), lds_ped, m.run_stream, m.dp, sg, e.prev, e.cur);
 		else hipLaunchKernelGGL(resident_segment_ped<false>, dim3(1u << sg.g), dim3(sg.threads), lds_ped, m.run_stream, m.dp, sg, e.prev, e.cur);
 	} else {
 		const size_t lds = (size_t)sg.ncols * (64 + RES_TABLE) * 4 + 2 * ((size_t)4 << sg.max_l) + (size_t)sg.stage_words * 8;
 		const bool sym = sg.half || sg.in_half || sg.mirror_out;
 		const dim3 grid(1u << (sg.g - sg.half)), block(sg.threads);
+#ifdef WHAMD_DEBUG_BUILD
 		if (m.dp.dbg) hipLaunchKernelGGL((resident_segment<true, true>), grid, block, lds, m.run_stream, m.dp, sg, e.prev, e.cur, e.score_out);
-		else if (sym) hipLaunchKernelGGL((resident_segment<false, true>), grid, block, lds, m.run_stream, m.dp, sg, e.prev, e.cur, e.score_out);
+		else
+#endif
+		if (sym) hipLaunchKernelGGL((resident_segment<false, true>), grid, block, lds, m.run_stream, m.dp, sg, e.prev, e.cur, e.score_out);
 		else hipLaunchKernelGGL((resident_segment<false, false>), grid, block, lds, m.run_stream, m.dp, sg, e.prev, e.cur, e.score_out);
 	}
 	launches += 1;
@@ -1445,7 +1452,7 @@ void DeviceTable::Impl::launch_run(const ResBatchEntry& e, uint32_t step_index, 
 void DeviceTable::Impl::launch_slot_run(const SlotBatchEntry& e, uint64_t& launches) {
 	Impl& m = *this;
 	const SlotRun& run = e.run;
-	const bool spec = run.spec_id != 0 && m.use_chunks && !getenv("WHAMD_NO_SPEC_KERNEL");
+	const bool spec = run.spec_id != 0 && m.use_chunks && !debug_env("WHAMD_NO_SPEC_KERNEL");
 	if (m.splan.ped) {
 		const PedSlotExtra& ex = m.splan.pextra[e.pad];
 		const size_t lds_ped = pedslot_lds_bytes(run.threads, run.ncols, ex);
@@ -1463,29 +1470,31 @@ void DeviceTable::Impl::launch_slot_run(const SlotBatchEntry& e, uint64_t& launc
 	}
 	const size_t lds = slot_run_lds_bytes(run.threads, run.lr, run.ncols);   // wave-slot exchange + hot lines + per-wave A + lane sums
 	const dim3 grid(1u << (run.g - run.half)), block(run.threads);
+	// (the instantiations with cycle stamps and timing switches exist in the debug library only: debug_build.h)
+#ifdef WHAMD_DEBUG_BUILD
 	const bool dbg = m.dp.dbg != nullptr || m.dp.dbg_flags != 0;
+#define WHAMD_IF_DBG(stmt) if (dbg) { stmt; } else
+#else
+#define WHAMD_IF_DBG(stmt)
+#endif
 #define WHAMD_SLOT_LAUNCH(LRV, DBGV, SPECV) hipLaunchKernelGGL((slot_run<LRV, DBGV, SPECV>), grid, block, lds, m.run_stream, m.dp, run, e.prev, e.cur, e.score_out)
 	if (run.lr == 3 && (run.yflags & 1u)) {   // Y-form run, eight cells per thread
 #define WHAMD_SLOT_LAUNCH_Y3(DBGV, SPECV) hipLaunchKernelGGL((slot_run<3, DBGV, SPECV, true>), grid, block, lds, m.run_stream, m.dp, run, e.prev, e.cur, e.score_out)
-		if (dbg) { if (spec) WHAMD_SLOT_LAUNCH_Y3(true, true); else WHAMD_SLOT_LAUNCH_Y3(true, false); }
-		else { if (spec) WHAMD_SLOT_LAUNCH_Y3(false, true); else WHAMD_SLOT_LAUNCH_Y3(false, false); }
+		WHAMD_IF_DBG(if (spec) WHAMD_SLOT_LAUNCH_Y3(true, true); else WHAMD_SLOT_LAUNCH_Y3(true, false)) { if (spec) WHAMD_SLOT_LAUNCH_Y3(false, true); else WHAMD_SLOT_LAUNCH_Y3(false, false); }
 #undef WHAMD_SLOT_LAUNCH_Y3
 	} else if (run.lr == 3) {
-		if (dbg) { if (spec) WHAMD_SLOT_LAUNCH(3, true, true); else WHAMD_SLOT_LAUNCH(3, true, false); }
-		else { if (spec) WHAMD_SLOT_LAUNCH(3, false, true); else WHAMD_SLOT_LAUNCH(3, false, false); }
+		WHAMD_IF_DBG(if (spec) WHAMD_SLOT_LAUNCH(3, true, true); else WHAMD_SLOT_LAUNCH(3, true, false)) { if (spec) WHAMD_SLOT_LAUNCH(3, false, true); else WHAMD_SLOT_LAUNCH(3, false, false); }
 	} else if (run.lr == 1) {
-		if (dbg) { if (spec) WHAMD_SLOT_LAUNCH(1, true, true); else WHAMD_SLOT_LAUNCH(1, true, false); }
-		else { if (spec) WHAMD_SLOT_LAUNCH(1, false, true); else WHAMD_SLOT_LAUNCH(1, false, false); }
+		WHAMD_IF_DBG(if (spec) WHAMD_SLOT_LAUNCH(1, true, true); else WHAMD_SLOT_LAUNCH(1, true, false)) { if (spec) WHAMD_SLOT_LAUNCH(1, false, true); else WHAMD_SLOT_LAUNCH(1, false, false); }
 	} else if (run.yflags & 1u) {   // Y-form run (slot_plan.cpp): one instruction per cell-column
 #define WHAMD_SLOT_LAUNCH_Y(DBGV, SPECV) hipLaunchKernelGGL((slot_run<2, DBGV, SPECV, true>), grid, block, lds, m.run_stream, m.dp, run, e.prev, e.cur, e.score_out)
-		if (dbg) { if (spec) WHAMD_SLOT_LAUNCH_Y(true, true); else WHAMD_SLOT_LAUNCH_Y(true, false); }
-		else { if (spec) WHAMD_SLOT_LAUNCH_Y(false, true); else WHAMD_SLOT_LAUNCH_Y(false, false); }
+		WHAMD_IF_DBG(if (spec) WHAMD_SLOT_LAUNCH_Y(true, true); else WHAMD_SLOT_LAUNCH_Y(true, false)) { if (spec) WHAMD_SLOT_LAUNCH_Y(false, true); else WHAMD_SLOT_LAUNCH_Y(false, false); }
 #undef WHAMD_SLOT_LAUNCH_Y
 	} else {
-		if (dbg) { if (spec) WHAMD_SLOT_LAUNCH(2, true, true); else WHAMD_SLOT_LAUNCH(2, true, false); }
-		else { if (spec) WHAMD_SLOT_LAUNCH(2, false, true); else WHAMD_SLOT_LAUNCH(2, false, false); }
+		WHAMD_IF_DBG(if (spec) WHAMD_SLOT_LAUNCH(2, true, true); else WHAMD_SLOT_LAUNCH(2, true, false)) { if (spec) WHAMD_SLOT_LAUNCH(2, false, true); else WHAMD_SLOT_LAUNCH(2, false, false); }
 	}
 #undef WHAMD_SLOT_LAUNCH
+#undef WHAMD_IF_DBG
 	launches += 1;
 }
 
@@ -1639,7 +1648,7 @@ bool DeviceTable::group_eligible(const Problem& p) const {
 	const Impl& m = *impl_;
 	if (p.n_cols == 0 || !m.use_slots || m.windowed || m.enqueue_open || m.dp.dbg || (m.dp.dbg_flags && m.splan.ped)) return false;
 	if (!m.splan.ped && m.slot_lr_used != 2 && m.slot_lr_used != 3) return false;   // (group kernels: four or eight cells per thread)
-	return getenv("WHAMD_NO_GROUP") == nullptr;
+	return debug_env("WHAMD_NO_GROUP") == nullptr;
 }
 
 int DeviceTable::device_index() const { return impl_->device; }
@@ -1657,9 +1666,9 @@ whamd_status_t DeviceTable::enqueue_group(DeviceTable* const* tables, const Prob
 	uint64_t width = 0;
 	for (size_t i = 0; i < n_tables; ++i) width += tables[i]->impl_->max_grid_x;
 	size_t n_parts = 1;
-	if (const char* e = getenv("WHAMD_GROUP_PARTS")) n_parts = (size_t)std::max(1, atoi(e));
+	if (const char* e = debug_env("WHAMD_GROUP_PARTS")) n_parts = (size_t)std::max(1, atoi(e));
 	n_parts = std::min(n_parts, n_tables);
-	const bool tight = width > 768 && !getenv("WHAMD_GROUP_LOOSE");   // more than three workgroups per CU: the variants held to 80 SGPRs (four workgroups per CU)
+	const bool tight = width > 768 && !debug_env("WHAMD_GROUP_LOOSE");   // more than three workgroups per CU: the variants held to 80 SGPRs (four workgroups per CU)
 	struct Batch { SlotGroupArgs args; uint32_t grid_x = 0, threads = 0; size_t lds = 0; };
 	struct Part {
 		std::vector<size_t> members;   // positions in `tables`
@@ -1699,8 +1708,11 @@ whamd_status_t DeviceTable::enqueue_group(DeviceTable* const* tables, const Prob
 		hipStream_t stream = part.lead->stream;
 		switch (variant) {
 			case 0:
+#ifdef WHAMD_DEBUG_BUILD
 				if (part.lead->dp.dbg_flags) hipLaunchKernelGGL((slot_group<2, true, false>), grid, block, b.lds, stream, b.args);
-				else if (tight) hipLaunchKernelGGL((slot_group<2, false, true>), grid, block, b.lds, stream, b.args);
+				else
+#endif
+				if (tight) hipLaunchKernelGGL((slot_group<2, false, true>), grid, block, b.lds, stream, b.args);
 				else hipLaunchKernelGGL((slot_group<2, false, false>), grid, block, b.lds, stream, b.args);
 				break;
 			case 1: hipLaunchKernelGGL((pedslot_group<2, 2>), grid, block, b.lds, stream, b.args); break;
@@ -1803,7 +1815,7 @@ whamd_status_t DeviceTable::wait(const Problem& p, Solution& s, whamd_solve_stat
 		st.bt_chunks = (uint32_t)m.chunks.size();
 		st.bt_missed = c[0];
 		st.bt_rewalked = c[1];
-		if (getenv("WHAMD_BT_STATS")) fprintf(stderr, "[whamd backtrace] %zu chunks, %u guesses missed (%u of them only in the transmission value), %u units walked again (of %zu)\n", m.chunks.size(), c[0], c[2], c[1], m.units.size());
+		if (debug_env("WHAMD_BT_STATS")) fprintf(stderr, "[whamd backtrace] %zu chunks, %u guesses missed (%u of them only in the transmission value), %u units walked again (of %zu)\n", m.chunks.size(), c[0], c[2], c[1], m.units.size());
 	}
 	if (m.dp.dbg && m.use_slots) {
 		std::vector<unsigned long long> d(m.splan.runs.size() * 48);

@@ -28,6 +28,8 @@
 #include <cstring>
 #include <mutex>
 
+#include "debug_build.h"
+#include "device_pool.h"
 #include "genotype.h"
 
 #define GENO_TRY(expr)                                                                                   \
@@ -497,14 +499,16 @@ std::mutex g_slab_mutex;
 }  // namespace
 
 void* genotype_slab_acquire(int device, size_t bytes) {
-	if (device < 0 || device >= 16 || getenv("WHAMD_GENOTYPE_NO_CACHE")) return nullptr;
+	if (device < 0 || device >= 16 || debug_env("WHAMD_GENOTYPE_NO_CACHE")) return nullptr;
 	std::lock_guard<std::mutex> lock(g_slab_mutex);
 	SlabCache& sc = g_slab[device];
 	if (sc.in_use) return nullptr;
 	if (sc.bytes < bytes) {
 		if (sc.ptr) (void)hipFree(sc.ptr);
 		sc = SlabCache();
-		if (hipMalloc(&sc.ptr, bytes) == hipSuccess) sc.bytes = bytes;
+		hipError_t e = hipMalloc(&sc.ptr, bytes);
+		if (e != hipSuccess) { (void)hipGetLastError(); devpool_release(); e = hipMalloc(&sc.ptr, bytes); }
+		if (e == hipSuccess) sc.bytes = bytes;
 		else { sc = SlabCache(); (void)hipGetLastError(); return nullptr; }
 	}
 	sc.in_use = true;
@@ -563,7 +567,7 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 	if (T != 1 && T != 4 && T != 16) { msg = "unsupported number of transmission values"; return WHAMD_ERR_UNSUPPORTED; }
 	GENO_TRY(hipSetDevice(device));
 	// the run-fused path wherever it applies (no forced window, every column in a run, stores fit in HBM)
-	if (!window_hint && !getenv("WHAMD_GENOTYPE_COLUMNS")) {
+	if (!window_hint && !debug_env("WHAMD_GENOTYPE_COLUMNS")) {
 		bool used = false;
 		const whamd_status_t sst = genotype_solve_slots(p, m, device, gl_out, st, used, msg);
 		if (sst != WHAMD_OK) return sst;
@@ -631,6 +635,11 @@ whamd_status_t genotype_solve_device(const Problem& p, const GenotypeModel& m, i
 #define GENO_DEV(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(e_, #expr); } while (0)
 	auto alloc = [&](void** dptr, size_t bytes) -> hipError_t {
 		hipError_t e = hipMalloc(dptr, std::max<size_t>(bytes, 16));
+		if (e != hipSuccess) {   // idle blocks of the phasing / heuristic pool may hold the memory: give them back, try once more
+			(void)hipGetLastError();
+			devpool_release();
+			e = hipMalloc(dptr, std::max<size_t>(bytes, 16));
+		}
 		if (e == hipSuccess) allocations.push_back(*dptr);
 		return e;
 	};

@@ -26,6 +26,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "debug_build.h"
+#include "device_pool.h"
 #include "genotype.h"
 #include "slots.h"
 
@@ -608,7 +610,7 @@ whamd_status_t genotype_solve_slots(const Problem& p, const GenotypeModel& m, in
 	const uint32_t n = p.n_cols, T = p.T, ni = p.n_ind;
 	if (n < 2 || ni == 0 || ni > 4 || !(p.P == 2 || p.P == 4) || !(T == 1 || T == 4 || T == 16) || (T == 1) != (p.P == 2)) return WHAMD_OK;
 	int l_pref = 0;
-	if (const char* e = getenv("WHAMD_GENO_SLOT_L")) l_pref = atoi(e);
+	if (const char* e = debug_env("WHAMD_GENO_SLOT_L")) l_pref = atoi(e);
 	SlotPlan plan;
 	if (!plan_forward_slots(p, l_pref > 0 ? -l_pref : 0, 0, plan, 0, /*genotype_mode=*/true)) return WHAMD_OK;
 	for (const Step& s : plan.steps) if (s.kind != 2) return WHAMD_OK;   // a column no run can take
@@ -748,9 +750,14 @@ whamd_status_t genotype_solve_slots(const Problem& p, const GenotypeModel& m, in
 	hipStream_t sf = nullptr, sb = nullptr, sc = nullptr;
 	GS_TRY(hipStreamCreateWithFlags(&sf, hipStreamNonBlocking)); keep.streams.push_back(sf);
 	GS_TRY(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking)); keep.streams.push_back(sb);
-	if (n_windows > 1 || getenv("WHAMD_GENO_PIECES")) { GS_TRY(hipStreamCreateWithFlags(&sc, hipStreamNonBlocking)); keep.streams.push_back(sc); }   // (likelihood sums beside the chains)
+	if (n_windows > 1 || debug_env("WHAMD_GENO_PIECES")) { GS_TRY(hipStreamCreateWithFlags(&sc, hipStreamNonBlocking)); keep.streams.push_back(sc); }   // (likelihood sums beside the chains)
 	auto alloc = [&](void** dptr, size_t bytes) -> hipError_t {
 		hipError_t e = hipMalloc(dptr, std::max<size_t>(bytes, 16));
+		if (e != hipSuccess) {   // idle blocks of the phasing / heuristic pool may hold the memory: give them back, try once more
+			(void)hipGetLastError();
+			devpool_release();
+			e = hipMalloc(dptr, std::max<size_t>(bytes, 16));
+		}
 		if (e == hipSuccess) keep.allocations.push_back(*dptr);
 		return e;
 	};
@@ -855,8 +862,8 @@ whamd_status_t genotype_solve_slots(const Problem& p, const GenotypeModel& m, in
 		// combine 24 -> 6 ms.  One piece after the chains is the default.)
 		const GsDev g = with_stores(0);
 		size_t n_pieces = 1;
-		const bool third_stream = getenv("WHAMD_GENO_PIECES") != nullptr;
-		if (const char* e = getenv("WHAMD_GENO_PIECES")) n_pieces = std::max<size_t>(1, std::min<size_t>((size_t)atoi(e), std::max<size_t>(1, n_runs / 64)));
+		const bool third_stream = debug_env("WHAMD_GENO_PIECES") != nullptr;
+		if (const char* e = debug_env("WHAMD_GENO_PIECES")) n_pieces = std::max<size_t>(1, std::min<size_t>((size_t)atoi(e), std::max<size_t>(1, n_runs / 64)));
 		auto piece_lo = [&](size_t k) { return n_runs * k / n_pieces; };
 		std::vector<hipEvent_t> pf(n_pieces), pb(n_pieces);
 		for (size_t k = 0; k < n_pieces; ++k)

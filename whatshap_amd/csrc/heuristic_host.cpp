@@ -1,7 +1,9 @@
-// heuristic_host.cpp -- HOST-ONLY DIAGNOSTIC: heuristic_core.h instantiated with ONE thread (barriers and atomics are plain
-// statements), so that the CPU test-suite can check the restated beam search against the compiled reference without a GPU
-// (whamd_debug_emulate_heuristic).  Not a product path: the PedMecHeuristic drop-in runs heuristic_device.hip and fails
-// loudly without a device.
+// heuristic_host.cpp -- heuristic_core.h instantiated for the host with ONE thread (barriers and atomics are plain statements).
+// Product part: heuristic_finish -- the allele votes and the per-column optimal phasing that follow the device's beam search
+// (src/pedmecheuristic.cpp:361-406 run on the host from the downloaded bipartition).  Debug part (WHAMD_DEBUG_BUILD, libwhatshap_amd_debug.so
+// only): heuristic_solve_host, the whole beam search on one CPU thread, so that the CPU test-suite can check the restated solver against
+// the compiled reference without a GPU (whamd_debug_pedmec_heuristic_create_host).  The PedMecHeuristic drop-in runs heuristic_device.hip
+// and fails loudly without a device.
 #include <algorithm>
 #include <cstring>
 
@@ -23,6 +25,7 @@ static inline unsigned long long heur_load64(const unsigned long long* p) { retu
 }  // namespace whamd
 #include "heuristic_core.h"
 
+#ifdef WHAMD_DEBUG_BUILD
 namespace whamd {
 
 whamd_status_t heuristic_solve_host(const HeurPlan& pl, HeurResult& out, std::string& msg) {
@@ -65,6 +68,7 @@ whamd_status_t heuristic_solve_host(const HeurPlan& pl, HeurResult& out, std::st
 }
 
 }  // namespace whamd
+#endif   // WHAMD_DEBUG_BUILD
 
 namespace whamd {
 

@@ -116,8 +116,10 @@ inline void parallel_ranges(uint64_t n, uint32_t n_threads, F&& fn) {
 		uint32_t started = 0;
 		for (; started + 1 < n_threads; ++started) {
 			const uint32_t t = started;
+			const uint32_t budget = host_threads_override();   // thread_local: a worker that sizes a nested range keeps to the caller's budget
 			try {
-				workers.emplace_back([&fn, &failed, n, n_threads, t, node_cpus]() {
+				workers.emplace_back([&fn, &failed, n, n_threads, t, node_cpus, budget]() {
+					host_threads_override() = budget;
 					if (node_cpus) (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), node_cpus);
 					try {
 						fn(n * t / n_threads, n * (t + 1) / n_threads, t);

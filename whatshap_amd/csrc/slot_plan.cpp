@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <thread>
 
+#include "debug_build.h"
 #include "slots.h"
 
 namespace whamd {
@@ -193,7 +194,7 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 				uint32_t most = 0;
 				for (uint32_t t = 0; t < p.T; ++t) most = std::max<uint32_t>(most, (uint32_t)(p.term_end(c1, t) - p.term_begin(c1, t)));
 				if (most > (uint32_t)PSLOT_MAXFORMS || (most > 4u && TB != 2u)) {   // (sixteen forms: the trio kernel only)
-					if (getenv("WHAMD_DEBUG_PLAN")) fprintf(stderr, "[plan] column %u: %u cost forms per transmission value: no pedigree run\n", c1, most);
+					if (debug_env("WHAMD_DEBUG_PLAN")) fprintf(stderr, "[plan] column %u: %u cost forms per transmission value: no pedigree run\n", c1, most);
 					break;
 				}
 				const uint32_t nf = fact ? pslot_na(PSLOT_FACT) : std::max(run_forms, most > 4 ? 16u : (most > 2 ? 4u : 2u));
@@ -430,7 +431,7 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 	// B_c is the same for every cell of column c (the prefix sum below): min(A, K - A) = (K - |2A - K|) / 2, so a cell-column is ONE absolute
 	// difference accumulated into Y (v_sad_u32) instead of subtract, min3, add; minima become maxima, the tie rule keeps its form.
 	// Between two such runs the exchange column stays in Y form; at any other neighbour the run converts (D = (B - Y) / 2 exactly).
-	if (!ped && (lr == 2 || lr == 3) && !getenv("WHAMD_NO_YFORM")) {
+	if (!ped && (lr == 2 || lr == 3) && !debug_env("WHAMD_NO_YFORM")) {
 		std::vector<uint8_t> pure(n, 0);
 		std::vector<uint64_t> B((size_t)n + 1, 0);   // B[c + 1] = base after column c
 		for (uint32_t c = 0; c < n; ++c) {
