@@ -660,9 +660,9 @@ def compact_line(out, detail_file=None):
     line["metric"] = _short(line.get("metric", ""), 110)
     cfg = out.get("config", {})
     line["config"] = {"workload": _short(cfg.get("workload", ""), 150)}
-    for k in ("blocks", "blocks_per_rank", "blocks_in_flight_per_gpu", "tables_per_launch", "max_coverage", "transmission_values", "path", "optimal_cost_checksum",
-              "optimal_cost_checksum_per_rank", "device_per_rank"):
-        if k in cfg and len(json.dumps(cfg[k])) <= 80:
+    for k in ("blocks", "blocks_per_rank", "block_seeds_per_rank", "blocks_in_flight_per_gpu", "tables_per_launch", "max_coverage", "transmission_values", "path", "optimal_cost_checksum",
+              "optimal_cost_checksum_per_rank", "device_per_rank", "rendezvous"):   # (what a SCALE record is audited with: which rank ran which blocks on which device)
+        if k in cfg and len(json.dumps(cfg[k])) <= 160:
             line["config"][k] = cfg[k]
     roof = out.get("roofline")
     if roof:

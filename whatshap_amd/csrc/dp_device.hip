@@ -891,8 +891,18 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 			run.tab_w = (uint32_t)slot_tab_words;
 			slot_tab_words += pad4((uint64_t)run.ncols * (run.threads >> 6));
 			run.tab_sl = (uint32_t)slot_tab_words;
-			slot_tab_words += (uint64_t)run.ncols * 64u;
+			// X runs (kernels_slots.h, slot_runx_body): a Y-form run with four cells per thread whose columns and ending reads fit the kernel's registers
+			const bool xrun = (run.yflags & 1u) && run.lr == 2u && run.ncols <= (uint32_t)SLOT_XCOLS && run.n_ends <= (uint32_t)SLOT_XENDS && !debug_env("WHAMD_NO_XRUN");
+			slot_tab_words += (uint64_t)(xrun ? ((run.ncols + 7u) & ~7u) : run.ncols) * 64u;   // (X runs: padded with zero columns to a pair of trips)
+			if (xrun) {
+				run.yflags |= 8u;
+				run.tab_kr = (uint32_t)slot_tab_words;
+				slot_tab_words += pad4(((uint64_t)run.ncols + SLOT_XPAD) << run.lr);
+				run.tab_par = (uint32_t)slot_tab_words;
+				slot_tab_words += pad4((uint64_t)run.threads + (1ull << (run.g - run.half)));
+			}
 		}
+		slot_tab_words += (uint64_t)SLOT_XCOLS * 64u;   // (an X run requests the lane parts of SLOT_XCOLS columns whatever its length)
 		if (slot_tab_words >= 0xFFFFFFFFull) { msg = "slot-run tables exceed 32-bit offsets"; return WHAMD_ERR_UNSUPPORTED; }
 		HIP_TRY(up(&d_sruns, m.splan.runs.data(), m.splan.runs.size() * sizeof(SlotRun)));
 		ulap("slot blobs, control words, runs: allocations + copies");
@@ -1353,13 +1363,27 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		if (device >= 64 || !((attr_done >> device) & 1ull)) {
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#ifdef WHAMD_DEBUG_BUILD
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#endif
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_batch<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_batch<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(backtrace_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment_ped<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#ifdef WHAMD_DEBUG_BUILD
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(resident_segment_ped<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#endif
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((resident_segment_ped<false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((slot_runx<2, 24, false, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((slot_runx<2, 24, false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((slot_runx<2, 32, false, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((slot_runx<2, 32, false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#ifdef WHAMD_DEBUG_BUILD
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((slot_runx<2, 24, true, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((slot_runx<2, 24, true, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((slot_runx<2, 32, true, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((slot_runx<2, 32, true, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#endif
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, 4, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, 4, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, 2, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1470,6 +1494,21 @@ void DeviceTable::Impl::launch_slot_run(const SlotBatchEntry& e, uint64_t& launc
 	}
 	const size_t lds = slot_run_lds_bytes(run.threads, run.lr, run.ncols);   // wave-slot exchange + hot lines + per-wave A + lane sums
 	const dim3 grid(1u << (run.g - run.half)), block(run.threads);
+	if (run.yflags & 8u) {   // X run: registers instead of LDS lines (LDS: the wave-slot exchange buffers only)
+		const size_t lds_x = slotx_lds_bytes(run.threads, run.ncols <= 24u ? 24u : 32u);
+#define WHAMD_SLOTX_LAUNCH(XCV, DBGV, SPECV) hipLaunchKernelGGL((slot_runx<2, XCV, DBGV, SPECV>), grid, block, lds_x, m.run_stream, m.dp, run, e.prev, e.cur, e.score_out)
+#ifdef WHAMD_DEBUG_BUILD
+		if (m.dp.dbg != nullptr || m.dp.dbg_flags != 0) {
+			if (run.ncols <= 24u) { if (spec) WHAMD_SLOTX_LAUNCH(24, true, true); else WHAMD_SLOTX_LAUNCH(24, true, false); }
+			else { if (spec) WHAMD_SLOTX_LAUNCH(32, true, true); else WHAMD_SLOTX_LAUNCH(32, true, false); }
+		} else
+#endif
+		if (run.ncols <= 24u) { if (spec) WHAMD_SLOTX_LAUNCH(24, false, true); else WHAMD_SLOTX_LAUNCH(24, false, false); }
+		else { if (spec) WHAMD_SLOTX_LAUNCH(32, false, true); else WHAMD_SLOTX_LAUNCH(32, false, false); }
+#undef WHAMD_SLOTX_LAUNCH
+		launches += 1;
+		return;
+	}
 	// (the instantiations with cycle stamps and timing switches exist in the debug library only: debug_build.h)
 #ifdef WHAMD_DEBUG_BUILD
 	const bool dbg = m.dp.dbg != nullptr || m.dp.dbg_flags != 0;

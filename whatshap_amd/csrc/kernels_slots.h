@@ -74,6 +74,12 @@ __device__ __forceinline__ uint32_t slot_y_sad(uint32_t x, uint32_t k, uint32_t 
 	asm("v_sad_u32 %0, %1, %2, %3" : "=v"(o) : "v"(x), "v"(k), "v"(acc));
 	return o;
 }
+// (the second operand wave-uniform, in an SGPR: X runs)
+__device__ __forceinline__ uint32_t slot_y_sad_s(uint32_t x, uint32_t k, uint32_t acc) {
+	uint32_t o;
+	asm("v_sad_u32 %0, %1, %2, %3" : "=v"(o) : "v"(x), "s"(k), "v"(acc));
+	return o;
+}
 __device__ __forceinline__ unsigned long long slot_y_borrow(uint32_t mine, uint32_t other, unsigned long long q) {
 	uint32_t d;
 	unsigned long long bo;
@@ -87,45 +93,13 @@ __device__ __forceinline__ uint32_t slot_y_shift_in(uint32_t takes, unsigned lon
 	return o;
 }
 
-template <int LR, bool DBG, bool SPEC, bool YF = false>
-__device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun& run, const uint32_t* __restrict__ prev,
-                                              uint32_t* __restrict__ cur, const uint32_t w, uint32_t* score_out) {
+// The entering cells of a run (raw loads only: nothing consumes them before the prologue has everything else in flight).  `flip`: the thread's
+// cells come from the mirrored group of a halved run, in reverse order.
+template <int LR, bool DBG>
+__device__ __forceinline__ void slot_enter_cells(const DevProblem& P, const SlotRun& run, const uint32_t* __restrict__ prev, const uint32_t Pthr,
+                                                 uint32_t (&Draw)[1 << LR], bool& flip) {
 	constexpr int R = 1 << LR;
-	static_assert(!YF || LR == 2 || LR == 3, "Y-form rows hold Kr[0 .. 2^LR): four or eight cells per thread");
-	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];   // wave-slot exchange: 2 x [threads][R]
-	const unsigned long long t_start = (DBG && P.dbg) ? __builtin_readcyclecounter() : 0ull;
-	const uint32_t tid = threadIdx.x, lane = tid & 63u;
-	const uint32_t wave = uni(tid >> 6);
-	const uint32_t L = run.L;
-	const uint32_t lthr = tid << LR;               // local index of this thread's cell 0
-	const uint32_t Pthr = (w << L) | lthr;         // its physical index
-	const SlotRow* __restrict__ rows = P.slot_rows + run.row_off;
-	const uint32_t ncols = run.ncols;
-
-	// ---- prologue: ONE batch of global loads, issued before anything waits (vector loads return in order, so the first
-	// consumers below wait only for what was issued first).
-	// (1) lane c of every wave fetches A of column c = Cp + (deltas of the set grid slots: table G of this workgroup) + (deltas of
-	//     the set wave slots: table W of this wave) -- slot_tables built both at create time; the cold part of SlotRow (80 bytes per
-	//     lane, an 18-slot loop) is no longer touched by a run
-	uint32_t a_g, a_w;
-	{
-		const uint32_t cl = lane < ncols ? lane : 0u;
-		a_g = a_w = 0;
-		if (!(DBG && (P.dbg_flags & 128u))) {   // (WHAMD_SLOT_SKIP 32 / 64 / 128: prologue loads switched off -- lane sums / entering cells / A, hot lines)
-			a_g = P.slot_tab[run.tab_g + w * ncols + cl];
-			a_w = P.slot_tab[run.tab_w + wave * ncols + cl];
-		}
-	}
-	//     ... and the lane part of S(column, lane), table SL: the same for every workgroup, 16 bytes per thread
-	const uint4* __restrict__ sl_src = reinterpret_cast<const uint4*>(P.slot_tab + run.tab_sl);
-	uint4 sl_piece = make_uint4(0, 0, 0, 0);
-	if (tid < ncols * 16u && !(DBG && (P.dbg_flags & 32u))) sl_piece = sl_src[tid];
-	// (2) one 16-byte piece of the hot lines per thread (they go to LDS below)
-	uint4 hot_piece = make_uint4(0, 0, 0, 0);
-	if (tid < ncols * 4u && !(DBG && (P.dbg_flags & 128u))) hot_piece = reinterpret_cast<const uint4*>(rows + (tid >> 2))[tid & 3u];
-	// (3) the entering cells: raw loads only (nothing consumes them before the hot lines and the lane sums are in LDS)
-	uint32_t Draw[R];
-	bool flip = false;
+	flip = false;
 	if (run.has_prev && !(DBG && (P.dbg_flags & 64u))) {
 		const uint32_t occ = run.in_occ;
 		if (run.in_identity && (occ & (uint32_t)(R - 1)) == (uint32_t)(R - 1) && (!run.in_half || run.in_mirror_pos >= (uint32_t)LR)) {
@@ -166,6 +140,140 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 #pragma unroll
 		for (int r = 0; r < R; ++r) Draw[r] = 0;
 	}
+}
+
+// ---- exit of a run: scatter into the next step's order (cells whose free-slot bits are zero hold the representatives), the seed of the
+// speculative backtrace (SPEC), Y form back to D form where the next step is not a Y-form run.
+template <int LR, bool DBG, bool SPEC, bool YF>
+__device__ __forceinline__ void slot_exit_cells(const DevProblem& P, const SlotRun& run, uint32_t* __restrict__ cur, uint32_t (&D)[1 << LR], const uint32_t w,
+                                                const uint32_t tid, const uint32_t lane, const uint32_t wave, const uint32_t L, const uint32_t lthr, const uint32_t Pthr,
+                                                const uint32_t threads) {
+	constexpr int R = 1 << LR;
+	const bool y_out = YF && (run.yflags & 4u);   // the next step is a Y-form run too: the column stays as it is
+	if (YF && !y_out) {
+#pragma unroll
+		for (int r = 0; r < R; ++r) D[r] = (run.base_out - D[r]) >> 1;   // D = (B - Y) / 2, exactly
+	}
+	const uint32_t key_flip = y_out ? 0xFFFFFFFFu : 0u;   // seeds of the speculative backtrace order by D: the largest Y is the smallest D
+	{
+		const uint32_t occ = run.out_occ;
+		const uint32_t localmask = (1u << L) - 1u;
+		const bool thread_writes = ((lthr & ~(uint32_t)(R - 1)) & ~occ & localmask) == 0u;
+		uint32_t pos[SLOT_MAXSLOTS];
+#pragma unroll
+		for (int s = 0; s < SLOT_MAXSLOTS; ++s) pos[s] = slot_pos_dev(run.out_pos, s);
+		uint32_t base = 0;
+#pragma unroll
+		for (int s = LR; s < SLOT_MAXSLOTS; ++s) base |= ((Pthr & occ) >> s & 1u) << pos[s];
+		const uint32_t mirror_x = run.mirror_out ? run.out_fullmask : 0u;
+		unsigned long long best_key = ~0ull;   // (value, exit index) of the smallest cell this thread stores (run.spec_id)
+		if (R == 2 && (occ & 1u) && pos[0] == 0u) {
+			// two cells per thread, the read of the reg slot is the lowest bit of the exit index: one 8-byte store
+			if (thread_writes && !(DBG && (P.dbg_flags & 1u))) {
+				*reinterpret_cast<uint2*>(cur + base) = make_uint2(D[0], D[R - 1]);
+				if (SPEC) best_key = min(min(best_key, ((unsigned long long)(D[0] ^ key_flip) << 32) | base), ((unsigned long long)(D[R - 1] ^ key_flip) << 32) | (base + 1u));
+				if (run.mirror_out) *reinterpret_cast<uint2*>(cur + ((base ^ mirror_x) & ~1u)) = make_uint2(D[R - 1], D[0]);
+			}
+		} else if (R >= 4 && (occ & 3u) == 3u && pos[0] == 0u && pos[1] == 1u) {
+			// the reads of reg slots 0 and 1 are the two lowest bits of the exit index (the planner arranges that for reads
+			// that stay local in the next run): 4 cells = one 16-byte store
+#pragma unroll
+			for (int r4 = 0; r4 < R; r4 += 4) {
+				bool writes = thread_writes;
+				uint32_t x = 0;
+#pragma unroll
+				for (int s = 2; s < LR; ++s) {
+					if ((r4 >> s) & 1) {
+						x |= 1u << pos[s];
+						writes = writes && ((occ >> s) & 1u);
+					}
+				}
+				if (writes && !(DBG && (P.dbg_flags & 1u))) {
+					const uint32_t idx = base | x;
+					*reinterpret_cast<uint4*>(cur + idx) = make_uint4(D[r4], D[r4 + 1], D[r4 + 2], D[r4 + 3]);
+					if (SPEC) {
+#pragma unroll
+						for (int j = 0; j < 4; ++j) best_key = min(best_key, ((unsigned long long)(D[r4 + j] ^ key_flip) << 32) | (idx + j));
+					}
+					if (run.mirror_out)   // the complement of a group of 4 is a group of 4 in reverse order
+						*reinterpret_cast<uint4*>(cur + ((idx ^ mirror_x) & ~3u)) = make_uint4(D[r4 + 3], D[r4 + 2], D[r4 + 1], D[r4]);
+				}
+			}
+		} else {
+#pragma unroll
+			for (int r = 0; r < R; ++r) {
+				bool writes = thread_writes;
+				uint32_t x = 0;
+#pragma unroll
+				for (int s = 0; s < LR; ++s) {
+					if ((r >> s) & 1) {
+						x |= 1u << pos[s];
+						writes = writes && ((occ >> s) & 1u);
+					}
+				}
+				if (writes && !(DBG && (P.dbg_flags & 1u))) {
+					const uint32_t idx = base | x;
+					cur[idx] = D[r];
+					if (run.mirror_out) cur[idx ^ mirror_x] = D[r];
+					if (SPEC) best_key = min(best_key, ((unsigned long long)(D[r] ^ key_flip) << 32) | idx);
+				}
+			}
+		}
+		if (SPEC && run.spec_id) {
+			// Seed of the speculative backtrace (kernels_backtrace.h): the smallest entry of the exit column.  Any entry would
+			// keep the result exact (the walk from the seed is verified against the true path); the minimum is what the true
+			// path almost always runs through.  One candidate per wave.
+#pragma unroll
+			for (int m = 1; m < 64; m <<= 1) {
+				const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)best_key, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(best_key >> 32), m);
+				best_key = min(best_key, ((unsigned long long)hi << 32) | lo);
+			}
+			// one plain store per wave (2048 atomics on one word would take ~25 us); the backtrace reduces the candidates
+			if (lane == 0) P.spec_keys[(size_t)(run.spec_id - 1u) * P.spec_stride + w * (threads >> 6) + wave] = best_key;
+		}
+	}
+}
+
+template <int LR, bool DBG, bool SPEC, bool YF = false>
+__device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun& run, const uint32_t* __restrict__ prev,
+                                              uint32_t* __restrict__ cur, const uint32_t w, uint32_t* score_out) {
+	constexpr int R = 1 << LR;
+	static_assert(!YF || LR == 2 || LR == 3, "Y-form rows hold Kr[0 .. 2^LR): four or eight cells per thread");
+	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];   // wave-slot exchange: 2 x [threads][R]
+	const unsigned long long t_start = (DBG && P.dbg) ? __builtin_readcyclecounter() : 0ull;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u;
+	const uint32_t wave = uni(tid >> 6);
+	const uint32_t L = run.L;
+	const uint32_t lthr = tid << LR;               // local index of this thread's cell 0
+	const uint32_t Pthr = (w << L) | lthr;         // its physical index
+	const SlotRow* __restrict__ rows = P.slot_rows + run.row_off;
+	const uint32_t ncols = run.ncols;
+
+	// ---- prologue: ONE batch of global loads, issued before anything waits (vector loads return in order, so the first
+	// consumers below wait only for what was issued first).
+	// (1) lane c of every wave fetches A of column c = Cp + (deltas of the set grid slots: table G of this workgroup) + (deltas of
+	//     the set wave slots: table W of this wave) -- slot_tables built both at create time; the cold part of SlotRow (80 bytes per
+	//     lane, an 18-slot loop) is no longer touched by a run
+	uint32_t a_g, a_w;
+	{
+		const uint32_t cl = lane < ncols ? lane : 0u;
+		a_g = a_w = 0;
+		if (!(DBG && (P.dbg_flags & 128u))) {   // (WHAMD_SLOT_SKIP 32 / 64 / 128: prologue loads switched off -- lane sums / entering cells / A, hot lines)
+			a_g = P.slot_tab[run.tab_g + w * ncols + cl];
+			a_w = P.slot_tab[run.tab_w + wave * ncols + cl];
+		}
+	}
+	//     ... and the lane part of S(column, lane), table SL: the same for every workgroup, 16 bytes per thread
+	const uint4* __restrict__ sl_src = reinterpret_cast<const uint4*>(P.slot_tab + run.tab_sl);
+	uint4 sl_piece = make_uint4(0, 0, 0, 0);
+	if (tid < ncols * 16u && !(DBG && (P.dbg_flags & 32u))) sl_piece = sl_src[tid];
+	// (2) one 16-byte piece of the hot lines per thread (they go to LDS below)
+	uint4 hot_piece = make_uint4(0, 0, 0, 0);
+	if (tid < ncols * 4u && !(DBG && (P.dbg_flags & 128u))) hot_piece = reinterpret_cast<const uint4*>(rows + (tid >> 2))[tid & 3u];
+	// (3) the entering cells: raw loads only (nothing consumes them before the hot lines and the lane sums are in LDS)
+	uint32_t Draw[R];
+	bool flip;
+	slot_enter_cells<LR, DBG>(P, run, prev, Pthr, Draw, flip);
 	// The hot lines of the run's columns go to LDS.  The column loop reads them back with uniform-address LDS reads one column
 	// ahead: LDS returns in order (lgkmcnt), so the read of the next column stays in flight while this one is evaluated --
 	// scalar loads cannot do that (they return out of order: every wait drains them all, and even a scalar-cache hit costs
@@ -386,90 +494,243 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 	}
 
 	const unsigned long long t_loop = (DBG && P.dbg) ? __builtin_readcyclecounter() + (D[0] & 0u) : 0ull;
-	// ---- exit: scatter into the next step's order (cells whose free-slot bits are zero hold the representatives)
-	const bool y_out = YF && (run.yflags & 4u);   // the next step is a Y-form run too: the column stays as it is
-	if (YF && !y_out) {
-#pragma unroll
-		for (int r = 0; r < R; ++r) D[r] = (run.base_out - D[r]) >> 1;   // D = (B - Y) / 2, exactly
+	slot_exit_cells<LR, DBG, SPEC, YF>(P, run, cur, D, w, tid, lane, wave, L, lthr, Pthr, threads);
+	if (score_out && w == 0 && tid == 0) *score_out = D[0];
+	if (DBG && P.dbg && w == 0 && tid == 0) {
+		unsigned long long* d = P.dbg + (size_t)run.pad * 48;
+		d[0] = t_issued - t_start; d[1] = t_loaded - t_start; d[2] = t_loop - t_loaded; d[3] = __builtin_readcyclecounter() - t_loop; d[4] = ncols; d[5] = 1;
 	}
-	const uint32_t key_flip = y_out ? 0xFFFFFFFFu : 0u;   // seeds of the speculative backtrace order by D: the largest Y is the smallest D
-	{
-		const uint32_t occ = run.out_occ;
-		const uint32_t localmask = (1u << L) - 1u;
-		const bool thread_writes = ((lthr & ~(uint32_t)(R - 1)) & ~occ & localmask) == 0u;
-		uint32_t pos[SLOT_MAXSLOTS];
+}
+
+// ---- X runs (round 5): the column loop of a Y-form run WITHOUT memory operations on the plain path ---------------------------------------
+// Round 4's stamps: a plain column of slot_run_body takes 230 - 250 cycles for 12 useful instructions -- four LDS reads per column requested
+// ahead, a wait the compiler places at the head of the four-column trip, the thread's operand rebuilt from two LDS words, a control word
+// through v_readlane, loop-carried LDS pointers merged at every break.  Measured on the device (scripts/micro/r5_probe.hip): four v_sad_u32,
+// a scalar test and a branch issue in 44 cycles; a scalar-cache hit costs 72 cycles, not 300; straight-line code runs as fast as a loop.
+// So a run of at most SLOT_XCOLS columns keeps, per thread, the operand X0 of EVERY column in a register of its own (built once in the
+// prologue from the create-time tables: lane part + workgroup part + wave part), the run's control words in 16 SGPRs, and the wave-uniform
+// Kr words of four columns at a time in 16 SGPRs fetched through the scalar cache one trip ahead (tab_kr: contiguous per run) -- a plain
+// column is  4 x v_sad_u32 (VGPR, SGPR, VGPR) + s_and + s_cbranch  and nothing else: no LDS, no wait, no address arithmetic.  The columns are
+// evaluated in pairs of trips of four; the columns behind the run's last are zero everywhere (harmless), so the loop is counted and has no way out in the middle.
+// An ending read: the tie parity of the thread under the read's mask is ONE bit of a per-thread word built at create time (tab_par: bit e for
+// the run's e-th ending read), so the kernel needs neither the mask nor a popcount; the partner cells are requested FIRST (ds_bpermute / LDS
+// exchange), the lane masks of the four cells are prepared on the scalar unit while they travel, one wait, then the decisions
+// (borrow / carry chain, kernels above) and the maxima: hand-written blocks (slotx_*), every wait count and hazard distance written out.
+// LDS holds the wave-slot exchange buffers only; the prologue has no barrier.
+typedef uint32_t slot_u32x4 __attribute__((ext_vector_type(4)));
+
+// ONE ending read of an X run, Y form, four cells per thread -- a single hand-scheduled block (the compiler sees no control flow and no LDS
+// operation of it; every wait and every hazard distance is written out):
+//   1. the partner cells are REQUESTED first, into v60 .. v63: ds_bpermute (lane slot: lane ^ 2^(slot - 2)), the 16 bytes of the partner wave's thread
+//      through LDS + barrier (wave slot; D travels as v[56:59]), or the thread's own cells (reg slot);
+//   2. while they travel, the scalar unit prepares the lane masks Q_r of the four cells: the thread's tie parity is bit e of `par` (tab_par), cell r flips it
+//      by bit r of qmask -- bit 0 of a qmask is never set (the planner asserts it), so Q_0 is the thread mask itself;
+//   3. one wait; the four borrows  Y_r - O_r - q_r  (v_subb with Q_r as carry-in) are formed first and consumed in the same order -- on gfx950 a VALU
+//      result in an SGPR may be read by a VALU two instructions later at the earliest -- and shifted into the record byte; the maxima in between.
+// slot, qmask, the bit of the ending read and the LDS offset of the current exchange buffer are scalars (two buffers, toggled by the caller: the
+// barrier of the next exchange also protects this one's reads).
+#define SLOTX_ENDING_ASM                                                                                               \
+	"s_cmp_lt_u32 %[slot], 8\n\t"                                                                                      \
+	"s_cbranch_scc0 .Lxw%=\n\t"                                                                                        \
+	"s_cmp_lt_u32 %[slot], 2\n\t"                                                                                      \
+	"s_cbranch_scc1 .Lxr%=\n\t"                                                                                        \
+	"s_lshl_b32 %[sa], 1, %[slot]\n\t"             /* lane slot: byte address of lane ^ 2^(slot - 2) = (lane * 4) ^ 2^slot */ \
+	"v_xor_b32_e32 %[a], %[sa], %[l4]\n\t"                                                                             \
+	"ds_bpermute_b32 v60, %[a], %[d0]\n\t"                                                                             \
+	"ds_bpermute_b32 v61, %[a], %[d1]\n\t"                                                                             \
+	"ds_bpermute_b32 v62, %[a], %[d2]\n\t"                                                                             \
+	"ds_bpermute_b32 v63, %[a], %[d3]\n\t"                                                                             \
+	"s_branch .Lxm%=\n"                                                                                                \
+	".Lxw%=:\n\t"                                  /* wave slot: partner thread = tid ^ (64 << (slot - 8)), 16 bytes each */ \
+	"s_sub_u32 %[sa], %[slot], 8\n\t"                                                                                  \
+	"s_lshl_b32 %[sa], 0x400, %[sa]\n\t"                                                                               \
+	"v_mov_b32_e32 v56, %[d0]\n\t"                                                                                     \
+	"v_mov_b32_e32 v57, %[d1]\n\t"                                                                                     \
+	"v_mov_b32_e32 v58, %[d2]\n\t"                                                                                     \
+	"v_mov_b32_e32 v59, %[d3]\n\t"                                                                                     \
+	"v_add_u32_e32 %[a], %[xb], %[t16]\n\t"                                                                            \
+	"ds_write_b128 %[a], v[56:59]\n\t"                                                                                 \
+	"v_xor_b32_e32 %[a], %[sa], %[t16]\n\t"                                                                            \
+	"v_add_u32_e32 %[a], %[xb], %[a]\n\t"                                                                              \
+	"s_waitcnt lgkmcnt(0)\n\t"                                                                                         \
+	"s_barrier\n\t"                                                                                                    \
+	"ds_read_b128 v[60:63], %[a]\n\t"                                                                                  \
+	"s_branch .Lxm%=\n"                                                                                                \
+	".Lxr%=:\n\t"                                  /* reg slot: the partners are the thread's own cells */             \
+	"s_cmp_eq_u32 %[slot], 0\n\t"                                                                                      \
+	"s_cbranch_scc0 .Lxq%=\n\t"                                                                                        \
+	"v_mov_b32_e32 v60, %[d1]\n\t"                                                                                     \
+	"v_mov_b32_e32 v61, %[d0]\n\t"                                                                                     \
+	"v_mov_b32_e32 v62, %[d3]\n\t"                                                                                     \
+	"v_mov_b32_e32 v63, %[d2]\n\t"                                                                                     \
+	"s_branch .Lxm%=\n"                                                                                                \
+	".Lxq%=:\n\t"                                                                                                      \
+	"v_mov_b32_e32 v60, %[d2]\n\t"                                                                                     \
+	"v_mov_b32_e32 v61, %[d3]\n\t"                                                                                     \
+	"v_mov_b32_e32 v62, %[d0]\n\t"                                                                                     \
+	"v_mov_b32_e32 v63, %[d1]\n"                                                                                       \
+	".Lxm%=:\n\t"                                  /* the lane masks, while the partner cells travel */                \
+	"v_and_b32_e32 %[t], %[eb], %[par]\n\t"                                                                            \
+	"v_cmp_ne_u32_e64 %[qt], 0, %[t]\n\t"                                                                              \
+	"s_not_b64 %[qn], %[qt]\n\t"                                                                                       \
+	"s_bitcmp1_b32 %[qm], 1\n\t"                                                                                       \
+	"s_cselect_b64 %[q1], %[qn], %[qt]\n\t"                                                                            \
+	"s_bitcmp1_b32 %[qm], 2\n\t"                                                                                       \
+	"s_cselect_b64 %[q2], %[qn], %[qt]\n\t"                                                                            \
+	"s_bitcmp1_b32 %[qm], 3\n\t"                                                                                       \
+	"s_cselect_b64 %[q3], %[qn], %[qt]\n\t"                                                                            \
+	"s_waitcnt lgkmcnt(0)\n\t"                                                                                         \
+	"v_subb_co_u32_e64 %[t], %[b3], %[d3], v63, %[q3]\n\t"                                                             \
+	"v_subb_co_u32_e64 %[t], %[b2], %[d2], v62, %[q2]\n\t"                                                             \
+	"v_subb_co_u32_e64 %[t], %[b1], %[d1], v61, %[q1]\n\t"                                                             \
+	"v_subb_co_u32_e64 %[t], %[b0], %[d0], v60, %[qt]\n\t"                                                             \
+	"v_cndmask_b32_e64 %[tk], 0, 1, %[b3]\n\t"                                                                         \
+	"v_max_u32_e32 %[d3], %[d3], v63\n\t"                                                                              \
+	"v_addc_co_u32_e64 %[tk], %[co], %[tk], %[tk], %[b2]\n\t"                                                          \
+	"v_max_u32_e32 %[d2], %[d2], v62\n\t"                                                                              \
+	"v_addc_co_u32_e64 %[tk], %[co], %[tk], %[tk], %[b1]\n\t"                                                          \
+	"v_max_u32_e32 %[d1], %[d1], v61\n\t"                                                                              \
+	"v_addc_co_u32_e64 %[tk], %[co], %[tk], %[tk], %[b0]\n\t"                                                          \
+	"v_max_u32_e32 %[d0], %[d0], v60"
+
+template <int LR, int XC, bool DBG, bool SPEC>
+__device__ __forceinline__ void slot_runx_body(const DevProblem& P, const SlotRun& run, const uint32_t* __restrict__ prev, uint32_t* __restrict__ cur, const uint32_t w,
+                                               uint32_t* score_out) {
+	static_assert(LR == 2, "X runs: four cells per thread (the masks, the decisions and the exchange are written for four)");
+	static_assert(XC % 4 == 0 && XC <= SLOT_XCOLS, "whole trips of four columns");
+	constexpr int R = 1 << LR;
+	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];   // wave-slot exchange 2 x [threads][R] | X0 [trip][thread][4 columns] (slotx_lds_bytes)
+	const unsigned long long t_start = (DBG && P.dbg) ? __builtin_readcyclecounter() : 0ull;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u;
+	const uint32_t wave = uni(tid >> 6);
+	const uint32_t L = run.L;
+	const uint32_t lthr = tid << LR;
+	const uint32_t Pthr = (w << L) | lthr;
+	const uint32_t ncols = run.ncols, threads = run.threads;
+	const uint32_t* __restrict__ tab = P.slot_tab;
+	// ---- prologue: one batch of loads.  Wave-uniform data through the scalar cache: the control words and the Kr words of the first trip, the
+	// workgroup's half of the tie parities.
+	const uint32_t* __restrict__ kr_tab = tab + run.tab_kr;
+	const uint32_t* __restrict__ cw_tab = P.slot_ctrl + run.ctrl_off;
+	slot_u32x16 krA = *(slot_cptr16)(unsigned long long)kr_tab, krB;
+	slot_u32x2 cwA = *(slot_cptr2)(unsigned long long)cw_tab, cwB;
+	const uint32_t par_w = *(const __attribute__((address_space(4))) uint32_t*)(unsigned long long)(tab + run.tab_par + threads + w);
+	// the entering cells first (they come from the other XCDs' stores: the longest latency of the prologue) ...
+	uint32_t Draw[R];
+	bool flip;
+	slot_enter_cells<LR, DBG>(P, run, prev, Pthr, Draw, flip);
+	// ... lane c of every wave fetches the workgroup + wave part of column c (tables G and W of slot_tables), the thread its tie parities ...
+	const uint32_t cl = lane < ncols ? lane : 0u;
+	const uint32_t a_g = tab[run.tab_g + w * ncols + cl], a_w = tab[run.tab_w + wave * ncols + cl];
+	const uint32_t par_l = tab[run.tab_par + tid];
+	// ... and the lane part of every column (table SL, [column][lane]: one coalesced 256-byte request per wave and column; columns behind the
+	// run's last read the tables that follow -- never used)
+	const uint32_t* __restrict__ sl_src = tab + run.tab_sl + lane;
+	uint32_t X[XC];
 #pragma unroll
-		for (int s = 0; s < SLOT_MAXSLOTS; ++s) pos[s] = slot_pos_dev(run.out_pos, s);
-		uint32_t base = 0;
+	for (int c = 0; c < XC; ++c) X[c] = sl_src[64 * c];
+	const unsigned long long t_issued = (DBG && P.dbg) ? __builtin_readcyclecounter() : 0ull;
+	// X0 of column c = 2 A(thread's cell 0) + bias = lane part + (workgroup + wave part, held by lane c): kept in the thread's OWN 16 bytes per trip of
+	// an LDS area (nobody else reads them: no barrier) -- a register per column would need the column loop unrolled over the whole run
+	const uint32_t Avec = lane < ncols ? a_g + a_w : 0u;   // (columns behind the run's last: zero)
+	uint4* __restrict__ xs = reinterpret_cast<uint4*>(smem + 2u * threads * R) + tid;   // + trip * threads  (behind the two exchange buffers)
 #pragma unroll
-		for (int s = LR; s < SLOT_MAXSLOTS; ++s) base |= ((Pthr & occ) >> s & 1u) << pos[s];
-		const uint32_t mirror_x = run.mirror_out ? run.out_fullmask : 0u;
-		unsigned long long best_key = ~0ull;   // (value, exit index) of the smallest cell this thread stores (run.spec_id)
-		if (R == 2 && (occ & 1u) && pos[0] == 0u) {
-			// two cells per thread, the read of the reg slot is the lowest bit of the exit index: one 8-byte store
-			if (thread_writes && !(DBG && (P.dbg_flags & 1u))) {
-				*reinterpret_cast<uint2*>(cur + base) = make_uint2(D[0], D[R - 1]);
-				if (SPEC) best_key = min(min(best_key, ((unsigned long long)(D[0] ^ key_flip) << 32) | base), ((unsigned long long)(D[R - 1] ^ key_flip) << 32) | (base + 1u));
-				if (run.mirror_out) *reinterpret_cast<uint2*>(cur + ((base ^ mirror_x) & ~1u)) = make_uint2(D[R - 1], D[0]);
-			}
-		} else if (R >= 4 && (occ & 3u) == 3u && pos[0] == 0u && pos[1] == 1u) {
-			// the reads of reg slots 0 and 1 are the two lowest bits of the exit index (the planner arranges that for reads
-			// that stay local in the next run): 4 cells = one 16-byte store
+	for (int t4 = 0; t4 < XC / 4; ++t4) {
+		uint32_t x[4];
 #pragma unroll
-			for (int r4 = 0; r4 < R; r4 += 4) {
-				bool writes = thread_writes;
-				uint32_t x = 0;
+		for (int k = 0; k < 4; ++k) x[k] = X[4 * t4 + k] + (uint32_t)__builtin_amdgcn_readlane((int)Avec, 4 * t4 + k);
+		xs[(uint32_t)t4 * threads] = make_uint4(x[0], x[1], x[2], x[3]);
+	}
+	const uint32_t par = par_l ^ par_w;
+	uint8_t* __restrict__ rec = P.bt + (((unsigned long long)run.rec_hi << 32) | run.rec_lo) + (size_t)w * run.n_ends * threads;   // (wave-uniform; the thread adds tid)
+	uint32_t D[R];   // Y = B - 2 D
 #pragma unroll
-				for (int s = 2; s < LR; ++s) {
-					if ((r4 >> s) & 1) {
-						x |= 1u << pos[s];
-						writes = writes && ((occ >> s) & 1u);
-					}
-				}
-				if (writes && !(DBG && (P.dbg_flags & 1u))) {
-					const uint32_t idx = base | x;
-					*reinterpret_cast<uint4*>(cur + idx) = make_uint4(D[r4], D[r4 + 1], D[r4 + 2], D[r4 + 3]);
-					if (SPEC) {
+	for (int r = 0; r < R; ++r) D[r] = flip ? Draw[R - 1 - r] : Draw[r];
+	if (!(run.yflags & 2u)) {   // the entering column is in D form
 #pragma unroll
-						for (int j = 0; j < 4; ++j) best_key = min(best_key, ((unsigned long long)(D[r4 + j] ^ key_flip) << 32) | (idx + j));
-					}
-					if (run.mirror_out)   // the complement of a group of 4 is a group of 4 in reverse order
-						*reinterpret_cast<uint4*>(cur + ((idx ^ mirror_x) & ~3u)) = make_uint4(D[r4 + 3], D[r4 + 2], D[r4 + 1], D[r4]);
-				}
-			}
-		} else {
-#pragma unroll
-			for (int r = 0; r < R; ++r) {
-				bool writes = thread_writes;
-				uint32_t x = 0;
-#pragma unroll
-				for (int s = 0; s < LR; ++s) {
-					if ((r >> s) & 1) {
-						x |= 1u << pos[s];
-						writes = writes && ((occ >> s) & 1u);
-					}
-				}
-				if (writes && !(DBG && (P.dbg_flags & 1u))) {
-					const uint32_t idx = base | x;
-					cur[idx] = D[r];
-					if (run.mirror_out) cur[idx ^ mirror_x] = D[r];
-					if (SPEC) best_key = min(best_key, ((unsigned long long)(D[r] ^ key_flip) << 32) | idx);
+		for (int r = 0; r < R; ++r) D[r] = run.base_in - 2u * D[r];
+	}
+	if (DBG && P.dbg) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	const unsigned long long t_loaded = (DBG && P.dbg) ? __builtin_readcyclecounter() + (D[0] & 0u) : 0ull;
+
+	const uint32_t lane4 = lane << 2, tid16 = tid << 4;
+	const uint32_t lds0 = (uint32_t)(unsigned long long)smem;   // LDS byte offset of the exchange buffers
+	uint32_t xb = lds0;                                          // the current exchange buffer ...
+	const uint32_t xtoggle = lds0 ^ (lds0 + threads * R * 4u);   // ... and what turns it into the other one
+	uint32_t ebit = 1u;
+	const SlotRow* __restrict__ rows = P.slot_rows + run.row_off;
+	// one ending read (slot and qmask are scalars): SLOTX_ENDING_ASM
+	auto ending = [&](const uint32_t slot, const uint32_t qm) {
+		unsigned long long q1, q2, q3, qt, qn, b0, b1, b2, b3, co;
+		uint32_t t, a, sa, takes;
+		asm volatile(SLOTX_ENDING_ASM
+		             : [d0] "+v"(D[0]), [d1] "+v"(D[1]), [d2] "+v"(D[2]), [d3] "+v"(D[3]), [tk] "=&v"(takes), [t] "=&v"(t), [a] "=&v"(a), [sa] "=&s"(sa),
+		               [q1] "=&s"(q1), [q2] "=&s"(q2), [q3] "=&s"(q3), [qt] "=&s"(qt), [qn] "=&s"(qn), [b0] "=&s"(b0), [b1] "=&s"(b1), [b2] "=&s"(b2), [b3] "=&s"(b3),
+		               [co] "=&s"(co)
+		             : [xb] "s"(xb), [slot] "s"(slot), [qm] "s"(qm), [eb] "s"(ebit), [par] "v"(par), [l4] "v"(lane4), [t16] "v"(tid16)
+		             : "memory", "scc", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+		if (!(DBG && (P.dbg_flags & 2u))) rec[tid] = (uint8_t)takes;
+		rec += threads;
+		ebit <<= 1;
+		xb ^= xtoggle & (0u - (slot >> 3));   // a wave-slot exchange (slots 8 .. 10) used the buffer: the next one takes the other
+	};
+	// column k of the current trip: its operand x, its four Kr words, its 16 control bits
+	uint32_t ci = 0;
+	auto column = [&](const uint32_t x, const uint32_t k0, const uint32_t k1, const uint32_t k2, const uint32_t k3, const uint32_t ctrl) {
+		D[0] = slot_y_sad_s(x, k0, D[0]);
+		D[1] = slot_y_sad_s(x, k1, D[1]);
+		D[2] = slot_y_sad_s(x, k2, D[2]);
+		D[3] = slot_y_sad_s(x, k3, D[3]);
+		if (DBG && P.dbg && w == 0 && tid == 0 && ci < 32u) P.dbg[(size_t)run.pad * 48 + 8 + ci] = __builtin_readcyclecounter() - t_loaded;
+		uint32_t n_end = (DBG && (P.dbg_flags & 8u)) ? 0u : (ctrl & 3u);   // reads ending here
+		if (n_end) {
+			ending((ctrl >> 2) & 31u, (ctrl >> 7) & 15u);
+			if (n_end > 1u) {   // several reads ending in one column are rare: slot and qmask of the later ones come from the row (scalar loads)
+				const unsigned long long row = (unsigned long long)(rows + ci);
+				if (n_end > 2u) n_end = *(const __attribute__((address_space(4))) uint32_t*)(row + 44);   // (a control field of 3 says "three or more")
+				for (uint32_t e = 1; e < n_end; ++e) {
+					const uint32_t info = *(const __attribute__((address_space(4))) uint32_t*)(row + 48 + 8 * e);
+					ending(info & 255u, (info >> 8) & 15u);
 				}
 			}
 		}
-		if (SPEC && run.spec_id) {
-			// Seed of the speculative backtrace (kernels_backtrace.h): the smallest entry of the exit column.  Any entry would
-			// keep the result exact (the walk from the seed is verified against the true path); the minimum is what the true
-			// path almost always runs through.  One candidate per wave.
-#pragma unroll
-			for (int m = 1; m < 64; m <<= 1) {
-				const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)best_key, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(best_key >> 32), m);
-				best_key = min(best_key, ((unsigned long long)hi << 32) | lo);
-			}
-			// one plain store per wave (2048 atomics on one word would take ~25 us); the backtrace reduces the candidates
-			if (lane == 0) P.spec_keys[(size_t)(run.spec_id - 1u) * P.spec_stride + w * (threads >> 6) + wave] = best_key;
-		}
+		++ci;
+	};
+	// Two trips per loop iteration (no register copies): while trip t is evaluated from set A, the operands, Kr words and control words of trip
+	// t + 1 travel into set B (one ds_read_b128 of the thread's own line, two scalar-cache loads), and the other way round.  Scalar loads return
+	// out of order, so a wait for set A would also wait for the requests of set B issued before it: the empty statements below USE set A first --
+	// the compiler's wait lands in front of them, before the next requests go out.
+	// A counted loop without a way out in the middle (a `break` per column made the compiler merge the loop's scalars with undefined values on the
+	// exit edge: five VALU -> SGPR copies per column): the columns behind the run's last -- up to seven, to a whole pair of trips -- are HARMLESS,
+	// their operands and Kr words are zero (slot_tables pads the lane parts and the Kr table, lanes >= ncols of Avec are zero: |0 - 0| = 0) and no
+	// read ends in them (the control words behind the run are zero).
+	const uint32_t xstride = threads * 16u;
+	uint32_t xaddr = lds0 + 2u * xstride + tid16;   // LDS byte address of the thread's line of trip 0
+	typedef __attribute__((address_space(3))) const slot_u32x4* lds_line;
+	slot_u32x4 xA = *(lds_line)(size_t)xaddr, xB;
+	for (uint32_t pairs = (ncols + 7u) >> 3; pairs; --pairs) {
+		asm volatile("" ::"s"(krA[0]), "s"(cwA[0]), "v"(xA.x));
+		krB = *(slot_cptr16)(unsigned long long)(kr_tab + 16u);
+		cwB = *(slot_cptr2)(unsigned long long)(cw_tab + 2u);
+		xB = *(lds_line)(size_t)(xaddr + xstride);
+		column(xA.x, krA[0], krA[1], krA[2], krA[3], cwA[0] & 0xFFFFu);
+		column(xA.y, krA[4], krA[5], krA[6], krA[7], cwA[0] >> 16);
+		column(xA.z, krA[8], krA[9], krA[10], krA[11], cwA[1] & 0xFFFFu);
+		column(xA.w, krA[12], krA[13], krA[14], krA[15], cwA[1] >> 16);
+		asm volatile("" ::"s"(krB[0]), "s"(cwB[0]), "v"(xB.x));
+		kr_tab += 32u;
+		cw_tab += 4u;
+		xaddr += 2u * xstride;
+		krA = *(slot_cptr16)(unsigned long long)kr_tab;
+		cwA = *(slot_cptr2)(unsigned long long)cw_tab;
+		xA = *(lds_line)(size_t)xaddr;
+		column(xB.x, krB[0], krB[1], krB[2], krB[3], cwB[0] & 0xFFFFu);
+		column(xB.y, krB[4], krB[5], krB[6], krB[7], cwB[0] >> 16);
+		column(xB.z, krB[8], krB[9], krB[10], krB[11], cwB[1] & 0xFFFFu);
+		column(xB.w, krB[12], krB[13], krB[14], krB[15], cwB[1] >> 16);
 	}
+	const unsigned long long t_loop = (DBG && P.dbg) ? __builtin_readcyclecounter() + (D[0] & 0u) : 0ull;
+	slot_exit_cells<LR, DBG, SPEC, true>(P, run, cur, D, w, tid, lane, wave, L, lthr, Pthr, threads);
 	if (score_out && w == 0 && tid == 0) *score_out = D[0];
 	if (DBG && P.dbg && w == 0 && tid == 0) {
 		unsigned long long* d = P.dbg + (size_t)run.pad * 48;
@@ -481,11 +742,28 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 __global__ __launch_bounds__(256) void slot_tables(DevProblem P, const SlotRun* __restrict__ runs, uint32_t* __restrict__ tab) {
 	const SlotRun& run = runs[blockIdx.y];
 	const uint32_t ncols = run.ncols, L = run.L, lr = run.lr, nwg = 1u << (run.g - run.half), nwaves = run.threads >> 6;
-	const uint32_t n_g = nwg * ncols, n_w = nwaves * ncols, n_sl = ncols * 64u;
+	const uint32_t n_g = nwg * ncols, n_w = nwaves * ncols, n_sl = ((run.yflags & 8u) ? ((ncols + 7u) & ~7u) : ncols) * 64u;   // (X runs: lane parts padded with zeros to a pair of trips)
+	// X runs (slot_runx_body): the Kr words of the run's columns side by side, and the tie parities -- bit e of a thread's word = parity of its local
+	// index under the mask of the run's e-th ending read (forward order: by column, then by position in the row), the same for a workgroup's grid bits
+	const bool xrun = (run.yflags & 8u) != 0u;
+	const uint32_t R = 1u << lr, n_kr = xrun ? (ncols + (uint32_t)SLOT_XPAD) * R : 0u, n_par = xrun ? run.threads + nwg : 0u;
 	const SlotRow* __restrict__ rows = P.slot_rows + run.row_off;
 	const uint32_t ysh = run.yflags & 1u, ybias = ysh ? SLOT_YBIAS : 0u;   // Y form: X0 = 2 A + bias = (2 G + bias) + 2 W + 2 SL
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_g + n_w + n_sl; i += gridDim.x * blockDim.x) {
-		if (i < n_g) {
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_g + n_w + n_sl + n_kr + n_par; i += gridDim.x * blockDim.x) {
+		if (i >= n_g + n_w + n_sl + n_kr) {
+			const uint32_t q = i - (n_g + n_w + n_sl + n_kr);
+			const uint32_t index = q < run.threads ? (q << lr) : ((q - run.threads) << L);   // a thread's local index / a workgroup's grid bits
+			const uint32_t keep = q < run.threads ? (1u << L) - 1u : ~((1u << L) - 1u);
+			uint32_t bits = 0, e = 0;
+			for (uint32_t c = 0; c < ncols; ++c) {
+				const uint32_t n_end = rows[c].n_end;
+				for (uint32_t k = 0; k < n_end; ++k, ++e) bits |= ((uint32_t)__popc(index & keep & rows[c].end[k].M) & 1u) << (e & 31u);
+			}
+			tab[run.tab_par + q] = bits;
+		} else if (i >= n_g + n_w + n_sl) {
+			const uint32_t q = i - (n_g + n_w + n_sl), c = q / R, r = q % R;
+			tab[run.tab_kr + q] = c < ncols ? reinterpret_cast<const uint32_t*>(rows + c)[r] : 0u;   // (a Y-form row holds Kr[0 .. R) in its first words)
+		} else if (i < n_g) {
 			const uint32_t w = i / ncols, c = i % ncols;
 			const SlotRow& row = rows[c];
 			uint32_t acc = row.Cp;
@@ -499,10 +777,10 @@ __global__ __launch_bounds__(256) void slot_tables(DevProblem P, const SlotRun* 
 			tab[run.tab_w + q] = acc << ysh;
 		} else {
 			const uint32_t q = i - n_g - n_w, c = q >> 6, lane = q & 63u;
-			const SlotRow& row = rows[c];
+			const SlotRow& row = rows[c < ncols ? c : 0u];
 			uint32_t acc = 0;
 			for (uint32_t j = 0; j < (uint32_t)SLOT_LANE; ++j) acc += (uint32_t)row.dslot[lr + j] & (0u - ((lane >> j) & 1u));   // (= dlane[j]; a Y-form row reuses those words)
-			tab[run.tab_sl + q] = acc << ysh;
+			tab[run.tab_sl + q] = c < ncols ? acc << ysh : 0u;
 		}
 	}
 }
@@ -512,6 +790,13 @@ __global__ __launch_bounds__(256) void slot_tables(DevProblem P, const SlotRun* 
 // scripts/micro/issue_rate.hip -- so every instruction on the column chain counts).
 // SPEC: the run ends a backtrace chunk and leaves the seed of the speculative walk (instantiated separately: the other runs
 // do not even carry the test).
+// One X run as a launch of its own: XC = 24 or 32 unrolled columns (a run of 22 columns does not fetch the lane parts of 32).
+template <int LR, int XC, bool DBG, bool SPEC>
+__global__ __launch_bounds__(512) void slot_runx(DevProblem P, SlotRun run, const uint32_t* __restrict__ prev, uint32_t* __restrict__ cur, uint32_t* __restrict__ score_out) {
+	touch_kernel_arguments<sizeof(DevProblem) + sizeof(SlotRun) + 24>();
+	slot_runx_body<LR, XC, DBG, SPEC>(P, run, prev, cur, blockIdx.x, score_out);
+}
+
 template <int LR, bool DBG, bool SPEC, bool YF = false>
 __global__ __launch_bounds__(512) void slot_run(DevProblem P, SlotRun run, const uint32_t* __restrict__ prev, uint32_t* __restrict__ cur,
                                                 uint32_t* __restrict__ score_out) {

@@ -272,6 +272,8 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 					if (s < lr) bit ^= ((r >> s) & 1u) & mflip;
 					qmask |= bit << r;
 				}
+				// (bit 0 of a qmask is never set: cell 0 of a thread has no reg-slot bit -- the X runs' ending block relies on it, kernels_slots.h)
+				if (qmask & 1u) { ok = false; break; }
 				if (en < (uint32_t)SLOT_MAXEND) {
 					row.end[en].info = (uint32_t)s | (qmask << 8) | (mflip << 24);
 					// (a read in a lane / wave slot: the kernel's parity also takes (side & mflip) -- the side is bit s of the thread's index,

@@ -76,6 +76,9 @@ static_assert(sizeof(SlotRow) == 256, "SlotRow must stay 64 dwords");
 constexpr int SLOT_CTRL_WORDS = 32;  // control words of a run: single individual 16 bits per column (n_end | slot of the first ending read << 2 | its
                                      // qmask << 7), SLOT_MAXCOLS columns; pedigree runs one byte per column (n_end | slot << 2), PSLOT_MAXCOLS columns
 constexpr uint32_t SLOT_YBIAS = 0x80000000u;   // Y-form rows and tables: both operands of the absolute difference carry this bias (unsigned compare)
+constexpr int SLOT_XCOLS = 32;      // X runs: columns whose per-thread operand stays in registers for the whole run (slot_runx_body)
+constexpr int SLOT_XENDS = 32;      // X runs: ending reads of a run (one tie-parity bit per thread each, one word)
+constexpr int SLOT_XPAD = 8;        // X runs: columns of slack behind the Kr table (the words of the next trip are requested a trip ahead)
 constexpr int SLOT_ROW_PAD = 64;     // rows appended to the array: the kernel touches a fixed number of rows to warm the scalar cache
 
 // One run, passed to the kernel by value.
@@ -94,10 +97,13 @@ struct SlotRun {
 	// Single-individual runs: what the prologue used to compute per launch from the cold part of SlotRow is a table built once
 	// at create time (slot_tables): G [launched workgroups][ncols] = Cp + deltas of the set grid slots, W [waves][ncols] = deltas
 	// of the set wave slots, SL [ncols][64] = deltas of the set lane slots.  Word offsets into DevProblem::slot_tab.
-	uint32_t tab_g, tab_w, tab_sl, tab_pad;
+	uint32_t tab_g, tab_w, tab_sl, tab_kr;   // tab_kr: X runs (below) -- the Kr words of the run's columns, contiguous: [ncols + SLOT_XPAD][2^lr]
 	// Y-form runs (kernels_slots.h, "Y form"): yflags bit 0 the run computes in Y form, bit 1 the entering column is already in Y form,
 	// bit 2 the exit column stays in Y form; base_in / base_out: the column-uniform base B at the run's entry and exit.
-	uint32_t yflags, base_in, base_out, ypad;
+	// bit 3: the run is eligible for the register-resident X kernel (slot_runx: Y form, <= SLOT_XCOLS columns, <= SLOT_XENDS ending reads);
+	// tab_par: its tie-parity table -- [threads] words (bit e: parity of the thread's local index under the mask of the run's e-th ending read)
+	// followed by [launched workgroups] words (the same for the workgroup's grid bits).
+	uint32_t yflags, base_in, base_out, tab_par;
 };
 // Dynamic LDS of a single-individual run: wave-slot exchange 2 x [threads][cells] | hot lines [ncols + 8][16] | A [8 waves][64] | lane sums
 // [ncols + 8][64] (eight lines of slack: lines are requested up to six columns ahead).  Sized by the run's own length -- at 22 columns
@@ -106,6 +112,9 @@ struct SlotRun {
 inline size_t slot_run_lds_bytes(uint32_t threads, uint32_t lr, uint32_t ncols) {
 	return (size_t)2 * threads * ((size_t)1 << lr) * 4 + (size_t)(ncols + 8) * 64 + 8 * 64 * 4 + (size_t)(ncols + 8) * 64 * 4;
 }
+// Dynamic LDS of an X run (slot_runx_body): wave-slot exchange 2 x [threads][4] | the threads' own operand lines [trips + 3][threads][4] (the line of
+// the next trip is requested a trip ahead, two trips per loop iteration)
+inline size_t slotx_lds_bytes(uint32_t threads, uint32_t ncols) { return (size_t)(2 + (ncols + 3) / 4 + 3) * threads * 16; }
 inline uint32_t slot_pos(const uint32_t (&w)[8], uint32_t s) { return (w[s >> 2] >> ((s & 3u) * 8u)) & 255u; }
 inline void slot_set_pos(uint32_t (&w)[8], uint32_t s, uint32_t pos) {
 	w[s >> 2] = (w[s >> 2] & ~(255u << ((s & 3u) * 8u))) | (pos << ((s & 3u) * 8u));
