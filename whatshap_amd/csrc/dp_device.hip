@@ -886,14 +886,16 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	if (m.use_slots && !ped_slots) {
 		for (SlotRun& run : m.splan.runs) {
 			auto pad4 = [](uint64_t v) { return (v + 3ull) & ~3ull; };
-			run.tab_g = (uint32_t)slot_tab_words;
-			slot_tab_words += pad4((uint64_t)run.ncols << (run.g - run.half));
-			run.tab_w = (uint32_t)slot_tab_words;
-			slot_tab_words += pad4((uint64_t)run.ncols * (run.threads >> 6));
-			run.tab_sl = (uint32_t)slot_tab_words;
-			// X runs (kernels_slots.h, slot_runx_body): a Y-form run with four cells per thread whose columns and ending reads fit the kernel's registers
+			// X runs (kernels_slots.h, slot_runx_body): a Y-form run with four cells per thread whose columns and ending reads fit the kernel's registers; the
+			// rows of its tables are padded with zero columns to a pair of trips
 			const bool xrun = (run.yflags & 1u) && run.lr == 2u && run.ncols <= (uint32_t)SLOT_XCOLS && run.n_ends <= (uint32_t)SLOT_XENDS && !debug_env("WHAMD_NO_XRUN");
-			slot_tab_words += (uint64_t)(xrun ? ((run.ncols + 7u) & ~7u) : run.ncols) * 64u;   // (X runs: padded with zero columns to a pair of trips)
+			const uint64_t ncp = xrun ? ((run.ncols + 7u) & ~7u) : run.ncols;
+			run.tab_g = (uint32_t)slot_tab_words;
+			slot_tab_words += pad4(ncp << (run.g - run.half));
+			run.tab_w = (uint32_t)slot_tab_words;
+			slot_tab_words += pad4(ncp * (run.threads >> 6));
+			run.tab_sl = (uint32_t)slot_tab_words;
+			slot_tab_words += ncp * 64u;
 			if (xrun) {
 				run.yflags |= 8u;
 				run.tab_kr = (uint32_t)slot_tab_words;
@@ -1223,6 +1225,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 					e.spec_keys = m.dp.spec_keys;
 					e.spec_stride = m.dp.spec_stride;
 					if (const char* skip = debug_env("WHAMD_SLOT_SKIP")) e.pad2 = (uint32_t)atoi(skip);   // (timing experiments in a group launch)
+					if (debug_env("WHAMD_NO_WARM")) e.pad2 |= 0x10000u;
 					ss.grid_x = std::max(ss.grid_x, 1u << (e.run.g - e.run.half));
 					ss.threads = std::max(ss.threads, e.run.threads);
 					m.slot_entries.push_back(e);
@@ -1278,7 +1281,9 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		HIP_TRY(up(&d_entries, m.entries.data(), m.entries.size() * sizeof(ResBatchEntry)));
 		m.d_entries = (ResBatchEntry*)d_entries;
 		void* d_slot_entries = nullptr;
+		m.slot_entries.resize(m.slot_entries.size() + 2);   // (two unused entries behind the last: a group launch warms 512 bytes behind its own entry, slot_runx_core)
 		HIP_TRY(up(&d_slot_entries, m.slot_entries.data(), m.slot_entries.size() * sizeof(SlotBatchEntry)));
+		m.slot_entries.resize(m.slot_entries.size() - 2);
 		m.d_slot_entries = (SlotBatchEntry*)d_slot_entries;
 		std::vector<BtJob> btjobs;
 		for (const Impl::Job& job : m.jobs) btjobs.push_back(BtJob{job.unit_off, job.unit_count, job.final ? 1u : 0u, 0u});
@@ -1304,7 +1309,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	}
 	if (m.use_slots && !ped_slots && !m.splan.runs.empty()) {
 		uint32_t most = 0;
-		for (const SlotRun& run : m.splan.runs) most = std::max<uint32_t>(most, (run.ncols << (run.g - run.half)) + run.ncols * ((run.threads >> 6) + 64u));
+		for (const SlotRun& run : m.splan.runs) most = std::max<uint32_t>(most, ((run.ncols + 8u) << (run.g - run.half)) + (run.ncols + 8u) * ((run.threads >> 6) + 64u));
 		const uint32_t bx = std::max(1u, std::min(64u, (most + 255u) / 256u));
 		for (size_t r0 = 0; r0 < m.splan.runs.size(); r0 += 32768) {
 			const uint32_t ny = (uint32_t)std::min<size_t>(32768, m.splan.runs.size() - r0);
@@ -1498,7 +1503,9 @@ void DeviceTable::Impl::launch_slot_run(const SlotBatchEntry& e, uint64_t& launc
 		const size_t lds_x = slotx_lds_bytes(run.threads, run.ncols <= 24u ? 24u : 32u);
 #define WHAMD_SLOTX_LAUNCH(XCV, DBGV, SPECV) hipLaunchKernelGGL((slot_runx<2, XCV, DBGV, SPECV>), grid, block, lds_x, m.run_stream, m.dp, run, e.prev, e.cur, e.score_out)
 #ifdef WHAMD_DEBUG_BUILD
-		if (m.dp.dbg != nullptr || m.dp.dbg_flags != 0) {
+		if (debug_env("WHAMD_XSTREAM")) {   // A/B: the streamed variant (what shared launches use) for a table of its own
+			if (spec) WHAMD_SLOTX_LAUNCH(0, false, true); else WHAMD_SLOTX_LAUNCH(0, false, false);
+		} else if (m.dp.dbg != nullptr || m.dp.dbg_flags != 0) {
 			if (run.ncols <= 24u) { if (spec) WHAMD_SLOTX_LAUNCH(24, true, true); else WHAMD_SLOTX_LAUNCH(24, true, false); }
 			else { if (spec) WHAMD_SLOTX_LAUNCH(32, true, true); else WHAMD_SLOTX_LAUNCH(32, true, false); }
 		} else
@@ -1716,7 +1723,7 @@ whamd_status_t DeviceTable::enqueue_group(DeviceTable* const* tables, const Prob
 	};
 	std::vector<Part> parts(n_parts);
 	for (size_t i = 0; i < n_tables; ++i) parts[i % n_parts].members.push_back(i);
-	constexpr int NV = 8;   // kernel variants (6: single individual, eight cells per thread; 7: trio, factorised lines)
+	constexpr int NV = 9;   // kernel variants (6: single individual, eight cells per thread; 7: trio, factorised lines; 8: X runs of a single individual, slot_groupx)
 	for (Part& part : parts) { part.lead = tables[part.members[0]]->impl_; part.batches.resize(NV); }
 	auto abort_all = [&]() {
 		for (Part& part : parts) (void)hipStreamSynchronize(part.lead->stream);
@@ -1760,6 +1767,7 @@ whamd_status_t DeviceTable::enqueue_group(DeviceTable* const* tables, const Prob
 			case 4: hipLaunchKernelGGL((pedslot_group<4, 4>), grid, block, b.lds, stream, b.args); break;
 			case 5: hipLaunchKernelGGL((pedslot_group<2, 16>), grid, block, b.lds, stream, b.args); break;
 			case 7: hipLaunchKernelGGL((pedslot_group<2, PSLOT_FACT>), grid, block, b.lds, stream, b.args); break;
+			case 8: hipLaunchKernelGGL((slot_groupx<false>), grid, block, b.lds, stream, b.args); break;
 			default:
 				if (tight) hipLaunchKernelGGL((slot_group<3, false, true>), grid, block, b.lds, stream, b.args);
 				else hipLaunchKernelGGL((slot_group<3, false, false>), grid, block, b.lds, stream, b.args);
@@ -1781,7 +1789,8 @@ whamd_status_t DeviceTable::enqueue_group(DeviceTable* const* tables, const Prob
 				const Impl::SuperStep& ss = m.schedule[k];
 				for (uint32_t q = 0; q < ss.entry_count; ++q) {
 					const SlotBatchEntry& he = m.slot_entries[ss.entry_off + q];
-					const int variant = m.splan.ped ? (he.ex.nf == (uint32_t)PSLOT_FACT ? 7 : (he.ex.nf == 16 ? 5 : 1 + (he.ex.tb == 4 ? 2 : 0) + (he.ex.nf == 4 ? 1 : 0))) : (he.run.lr == 3 ? 6 : 0);
+					const bool xrun = !m.splan.ped && (he.run.yflags & 8u) && !m.dp.dbg_flags;   // (the X kernel: operands streamed from the tables, 16 KB of LDS)
+					const int variant = m.splan.ped ? (he.ex.nf == (uint32_t)PSLOT_FACT ? 7 : (he.ex.nf == 16 ? 5 : 1 + (he.ex.tb == 4 ? 2 : 0) + (he.ex.nf == 4 ? 1 : 0))) : (he.run.lr == 3 ? 6 : (xrun ? 8 : 0));
 					Batch& b = part.batches[variant];
 					if (b.args.n == (uint32_t)SLOT_GROUP_MAX) {
 						flush(part, variant);
@@ -1790,7 +1799,7 @@ whamd_status_t DeviceTable::enqueue_group(DeviceTable* const* tables, const Prob
 					b.args.entry[b.args.n++] = m.d_slot_entries + ss.entry_off + q;
 					b.grid_x = std::max(b.grid_x, 1u << (he.run.g - he.run.half));
 					b.threads = std::max(b.threads, he.run.threads);
-					b.lds = std::max(b.lds, ss.lds);
+					b.lds = std::max(b.lds, xrun ? (size_t)2 * he.run.threads * 16 : ss.lds);
 					counted[i * NV + variant] = 1;
 				}
 			}

@@ -258,9 +258,10 @@ __device__ __forceinline__ void slot_run_body(const DevProblem& P, const SlotRun
 	{
 		const uint32_t cl = lane < ncols ? lane : 0u;
 		a_g = a_w = 0;
+		const uint32_t ncp = (run.yflags & 8u) ? (ncols + 7u) & ~7u : ncols;   // (the tables of a run that may take the X kernel have padded rows)
 		if (!(DBG && (P.dbg_flags & 128u))) {   // (WHAMD_SLOT_SKIP 32 / 64 / 128: prologue loads switched off -- lane sums / entering cells / A, hot lines)
-			a_g = P.slot_tab[run.tab_g + w * ncols + cl];
-			a_w = P.slot_tab[run.tab_w + wave * ncols + cl];
+			a_g = P.slot_tab[run.tab_g + w * ncp + cl];
+			a_w = P.slot_tab[run.tab_w + wave * ncp + cl];
 		}
 	}
 	//     ... and the lane part of S(column, lane), table SL: the same for every workgroup, 16 bytes per thread
@@ -527,14 +528,16 @@ typedef uint32_t slot_u32x4 __attribute__((ext_vector_type(4)));
 //      by bit r of qmask -- bit 0 of a qmask is never set (the planner asserts it), so Q_0 is the thread mask itself;
 //   3. one wait; the four borrows  Y_r - O_r - q_r  (v_subb with Q_r as carry-in) are formed first and consumed in the same order -- on gfx950 a VALU
 //      result in an SGPR may be read by a VALU two instructions later at the earliest -- and shifted into the record byte; the maxima in between.
-// slot, qmask, the bit of the ending read and the LDS offset of the current exchange buffer are scalars (two buffers, toggled by the caller: the
-// barrier of the next exchange also protects this one's reads).
+// The block reads the ending read's 16-bit control field (n_end | slot << 2 | qmask << 7 | exchange buffer << 15) from a scalar register; the thread's tie
+// parities move down one bit per ending read; the record byte is stored from inside (offset register advanced by the workgroup's size).  Two exchange
+// buffers: the barrier of the next exchange also protects this one's reads.
 #define SLOTX_ENDING_ASM                                                                                               \
-	"s_cmp_lt_u32 %[slot], 8\n\t"                                                                                      \
+	"s_bfe_u32 %[sl], %[cw], 0x50002\n\t"          /* slot of the ending read: bits 2 .. 6 of its control field */     \
+	"s_cmp_lt_u32 %[sl], 8\n\t"                                                                                        \
 	"s_cbranch_scc0 .Lxw%=\n\t"                                                                                        \
-	"s_cmp_lt_u32 %[slot], 2\n\t"                                                                                      \
+	"s_cmp_lt_u32 %[sl], 2\n\t"                                                                                        \
 	"s_cbranch_scc1 .Lxr%=\n\t"                                                                                        \
-	"s_lshl_b32 %[sa], 1, %[slot]\n\t"             /* lane slot: byte address of lane ^ 2^(slot - 2) = (lane * 4) ^ 2^slot */ \
+	"s_lshl_b32 %[sa], 1, %[sl]\n\t"               /* lane slot: byte address of lane ^ 2^(slot - 2) = (lane * 4) ^ 2^slot */ \
 	"v_xor_b32_e32 %[a], %[sa], %[l4]\n\t"                                                                             \
 	"ds_bpermute_b32 v60, %[a], %[d0]\n\t"                                                                             \
 	"ds_bpermute_b32 v61, %[a], %[d1]\n\t"                                                                             \
@@ -542,22 +545,24 @@ typedef uint32_t slot_u32x4 __attribute__((ext_vector_type(4)));
 	"ds_bpermute_b32 v63, %[a], %[d3]\n\t"                                                                             \
 	"s_branch .Lxm%=\n"                                                                                                \
 	".Lxw%=:\n\t"                                  /* wave slot: partner thread = tid ^ (64 << (slot - 8)), 16 bytes each */ \
-	"s_sub_u32 %[sa], %[slot], 8\n\t"                                                                                  \
+	"s_sub_u32 %[sa], %[sl], 8\n\t"                                                                                    \
 	"s_lshl_b32 %[sa], 0x400, %[sa]\n\t"                                                                               \
+	"s_bfe_u32 %[sl], %[cw], 0x1000f\n\t"          /* which of the two exchange buffers: bit 15 of the control field (the planner counts the exchanges) */ \
+	"s_mul_i32 %[sl], %[sl], %[xby]\n\t"                                                                               \
 	"v_mov_b32_e32 v56, %[d0]\n\t"                                                                                     \
 	"v_mov_b32_e32 v57, %[d1]\n\t"                                                                                     \
 	"v_mov_b32_e32 v58, %[d2]\n\t"                                                                                     \
 	"v_mov_b32_e32 v59, %[d3]\n\t"                                                                                     \
-	"v_add_u32_e32 %[a], %[xb], %[t16]\n\t"                                                                            \
+	"v_add_u32_e32 %[a], %[sl], %[t16]\n\t"                                                                            \
 	"ds_write_b128 %[a], v[56:59]\n\t"                                                                                 \
 	"v_xor_b32_e32 %[a], %[sa], %[t16]\n\t"                                                                            \
-	"v_add_u32_e32 %[a], %[xb], %[a]\n\t"                                                                              \
+	"v_add_u32_e32 %[a], %[sl], %[a]\n\t"                                                                              \
 	"s_waitcnt lgkmcnt(0)\n\t"                                                                                         \
 	"s_barrier\n\t"                                                                                                    \
 	"ds_read_b128 v[60:63], %[a]\n\t"                                                                                  \
 	"s_branch .Lxm%=\n"                                                                                                \
 	".Lxr%=:\n\t"                                  /* reg slot: the partners are the thread's own cells */             \
-	"s_cmp_eq_u32 %[slot], 0\n\t"                                                                                      \
+	"s_cmp_eq_u32 %[sl], 0\n\t"                                                                                        \
 	"s_cbranch_scc0 .Lxq%=\n\t"                                                                                        \
 	"v_mov_b32_e32 v60, %[d1]\n\t"                                                                                     \
 	"v_mov_b32_e32 v61, %[d0]\n\t"                                                                                     \
@@ -569,35 +574,42 @@ typedef uint32_t slot_u32x4 __attribute__((ext_vector_type(4)));
 	"v_mov_b32_e32 v61, %[d3]\n\t"                                                                                     \
 	"v_mov_b32_e32 v62, %[d0]\n\t"                                                                                     \
 	"v_mov_b32_e32 v63, %[d1]\n"                                                                                       \
-	".Lxm%=:\n\t"                                  /* the lane masks, while the partner cells travel */                \
-	"v_and_b32_e32 %[t], %[eb], %[par]\n\t"                                                                            \
+	".Lxm%=:\n\t"                                  /* the lane masks, while the partner cells travel: the thread's tie parity is bit 0 of par */ \
+	"v_and_b32_e32 %[t], 1, %[par]\n\t"                                                                                \
 	"v_cmp_ne_u32_e64 %[qt], 0, %[t]\n\t"                                                                              \
+	"v_lshrrev_b32_e32 %[par], 1, %[par]\n\t"      /* (the next ending read's bit moves down) */                       \
 	"s_not_b64 %[qn], %[qt]\n\t"                                                                                       \
-	"s_bitcmp1_b32 %[qm], 1\n\t"                                                                                       \
+	"s_bitcmp1_b32 %[cw], 8\n\t"                   /* qmask: bits 7 .. 10 of the control field; bit r flips cell r */  \
 	"s_cselect_b64 %[q1], %[qn], %[qt]\n\t"                                                                            \
-	"s_bitcmp1_b32 %[qm], 2\n\t"                                                                                       \
+	"s_bitcmp1_b32 %[cw], 9\n\t"                                                                                       \
 	"s_cselect_b64 %[q2], %[qn], %[qt]\n\t"                                                                            \
-	"s_bitcmp1_b32 %[qm], 3\n\t"                                                                                       \
+	"s_bitcmp1_b32 %[cw], 10\n\t"                                                                                      \
 	"s_cselect_b64 %[q3], %[qn], %[qt]\n\t"                                                                            \
 	"s_waitcnt lgkmcnt(0)\n\t"                                                                                         \
-	"v_subb_co_u32_e64 %[t], %[b3], %[d3], v63, %[q3]\n\t"                                                             \
-	"v_subb_co_u32_e64 %[t], %[b2], %[d2], v62, %[q2]\n\t"                                                             \
-	"v_subb_co_u32_e64 %[t], %[b1], %[d1], v61, %[q1]\n\t"                                                             \
-	"v_subb_co_u32_e64 %[t], %[b0], %[d0], v60, %[qt]\n\t"                                                             \
-	"v_cndmask_b32_e64 %[tk], 0, 1, %[b3]\n\t"                                                                         \
+	"v_subb_co_u32_e64 %[t], %[q3], %[d3], v63, %[q3]\n\t"        /* (a borrow overwrites its own carry-in mask) */                                                             \
+	"v_subb_co_u32_e64 %[t], %[q2], %[d2], v62, %[q2]\n\t"                                                             \
+	"v_subb_co_u32_e64 %[t], %[q1], %[d1], v61, %[q1]\n\t"                                                             \
+	"v_subb_co_u32_e64 %[t], %[qt], %[d0], v60, %[qt]\n\t"                                                             \
+	"v_cndmask_b32_e64 %[tk], 0, 1, %[q3]\n\t"                                                                         \
 	"v_max_u32_e32 %[d3], %[d3], v63\n\t"                                                                              \
-	"v_addc_co_u32_e64 %[tk], %[co], %[tk], %[tk], %[b2]\n\t"                                                          \
+	"v_addc_co_u32_e64 %[tk], %[qn], %[tk], %[tk], %[q2]\n\t"                                                          \
 	"v_max_u32_e32 %[d2], %[d2], v62\n\t"                                                                              \
-	"v_addc_co_u32_e64 %[tk], %[co], %[tk], %[tk], %[b1]\n\t"                                                          \
+	"v_addc_co_u32_e64 %[tk], %[qn], %[tk], %[tk], %[q1]\n\t"                                                          \
 	"v_max_u32_e32 %[d1], %[d1], v61\n\t"                                                                              \
-	"v_addc_co_u32_e64 %[tk], %[co], %[tk], %[tk], %[b0]\n\t"                                                          \
-	"v_max_u32_e32 %[d0], %[d0], v60"
+	"v_addc_co_u32_e64 %[tk], %[qn], %[tk], %[tk], %[qt]\n\t"                                                          \
+	"v_max_u32_e32 %[d0], %[d0], v60\n\t"                                                                              \
+	"global_store_byte %[ro], %[tk], %[rb]\n\t"    /* the record byte of this thread and ending read: fire and forget */ \
+	"v_add_u32_e32 %[ro], %[thr], %[ro]"
 
-template <int LR, int XC, bool DBG, bool SPEC>
-__device__ __forceinline__ void slot_runx_body(const DevProblem& P, const SlotRun& run, const uint32_t* __restrict__ prev, uint32_t* __restrict__ cur, const uint32_t w,
-                                               uint32_t* score_out) {
+// (prologue + column loop of an X run: leaves the thread's four cells in D; the exit -- slot_runx_exit -- is a call of its own so that a kernel whose run
+//  descriptor lives in memory can fetch the exit's half of it AFTER the loop instead of carrying ~30 scalars through it)
+struct SlotxStamps { unsigned long long t_start, t_issued, t_loaded, t_loop; };
+template <int LR, int XC, bool DBG>
+__device__ __forceinline__ void slot_runx_core(const DevProblem& P, const SlotRun& run, const uint32_t* __restrict__ prev, const uint32_t w, uint32_t (&D)[1 << LR],
+                                               SlotxStamps& stamps, const void* warm = nullptr) {
 	static_assert(LR == 2, "X runs: four cells per thread (the masks, the decisions and the exchange are written for four)");
 	static_assert(XC % 4 == 0 && XC <= SLOT_XCOLS, "whole trips of four columns");
+	constexpr bool STREAM = XC == 0;   // the operands of a trip are formed a trip ahead from the tables (no LDS lines: several workgroups per CU -- shared launches)
 	constexpr int R = 1 << LR;
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];   // wave-slot exchange 2 x [threads][R] | X0 [trip][thread][4 columns] (slotx_lds_bytes)
 	const unsigned long long t_start = (DBG && P.dbg) ? __builtin_readcyclecounter() : 0ull;
@@ -607,6 +619,7 @@ __device__ __forceinline__ void slot_runx_body(const DevProblem& P, const SlotRu
 	const uint32_t lthr = tid << LR;
 	const uint32_t Pthr = (w << L) | lthr;
 	const uint32_t ncols = run.ncols, threads = run.threads;
+	const uint32_t ncp = (ncols + 7u) & ~7u;   // row length of the tables G, W and SL of an X run: padded with zeros to a pair of trips (slot_tables)
 	const uint32_t* __restrict__ tab = P.slot_tab;
 	// ---- prologue: one batch of loads.  Wave-uniform data through the scalar cache: the control words and the Kr words of the first trip, the
 	// workgroup's half of the tie parities.
@@ -616,63 +629,81 @@ __device__ __forceinline__ void slot_runx_body(const DevProblem& P, const SlotRu
 	slot_u32x2 cwA = *(slot_cptr2)(unsigned long long)cw_tab, cwB;
 	const uint32_t par_w = *(const __attribute__((address_space(4))) uint32_t*)(unsigned long long)(tab + run.tab_par + threads + w);
 	// the entering cells first (they come from the other XCDs' stores: the longest latency of the prologue) ...
+	// Shared launches read their run descriptor from memory (SlotBatchEntry) BEFORE anything else can be requested: a miss all the way to HBM per launch.
+	// The entry of the table's next step lies behind this one; its lines are requested here, just before the entering cells (which miss to HBM anyway) --
+	// into this XCD's L2, where the next launch's workgroup (x, y) finds them.  The destination register stays reserved until the entering cells are used
+	// below: vector loads return in order, so by then this request has landed (the compiler cannot see a load inside an asm statement).
+	uint32_t warm_junk = 0;
+	if (warm) {
+		const unsigned long long line = (unsigned long long)warm + ((lane & 7u) << 6);
+		asm volatile("global_load_dword %0, %1, off" : "=v"(warm_junk) : "v"(line) : "memory");
+	}
 	uint32_t Draw[R];
 	bool flip;
 	slot_enter_cells<LR, DBG>(P, run, prev, Pthr, Draw, flip);
-	// ... lane c of every wave fetches the workgroup + wave part of column c (tables G and W of slot_tables), the thread its tie parities ...
-	const uint32_t cl = lane < ncols ? lane : 0u;
-	const uint32_t a_g = tab[run.tab_g + w * ncols + cl], a_w = tab[run.tab_w + wave * ncols + cl];
 	const uint32_t par_l = tab[run.tab_par + tid];
-	// ... and the lane part of every column (table SL, [column][lane]: one coalesced 256-byte request per wave and column; columns behind the
-	// run's last read the tables that follow -- never used)
-	const uint32_t* __restrict__ sl_src = tab + run.tab_sl + lane;
-	uint32_t X[XC];
+	const uint32_t* __restrict__ sl_src = tab + run.tab_sl + lane;   // the lane part of column c: sl_src[64 c] (one coalesced 256-byte request per wave and column)
+	const uint32_t* __restrict__ g_row = tab + run.tab_g + w * ncp;  // the workgroup's and the wave's part: rows of the tables G and W
+	const uint32_t* __restrict__ w_row = tab + run.tab_w + wave * ncp;
+	typedef uint32_t slot_u32x4s __attribute__((ext_vector_type(4)));
+	typedef const __attribute__((address_space(4))) slot_u32x4s* slot_cptr4;
+	slot_u32x4s gA, gB, wA, wB;
+	uint32_t slA[4], slB[4];
+	unsigned long long t_issued = 0ull;
+	if (STREAM) {
+		gA = *(slot_cptr4)(unsigned long long)g_row;
+		wA = *(slot_cptr4)(unsigned long long)w_row;
 #pragma unroll
-	for (int c = 0; c < XC; ++c) X[c] = sl_src[64 * c];
-	const unsigned long long t_issued = (DBG && P.dbg) ? __builtin_readcyclecounter() : 0ull;
-	// X0 of column c = 2 A(thread's cell 0) + bias = lane part + (workgroup + wave part, held by lane c): kept in the thread's OWN 16 bytes per trip of
-	// an LDS area (nobody else reads them: no barrier) -- a register per column would need the column loop unrolled over the whole run
-	const uint32_t Avec = lane < ncols ? a_g + a_w : 0u;   // (columns behind the run's last: zero)
-	uint4* __restrict__ xs = reinterpret_cast<uint4*>(smem + 2u * threads * R) + tid;   // + trip * threads  (behind the two exchange buffers)
+		for (int k = 0; k < 4; ++k) slA[k] = sl_src[64 * k];
+		t_issued = (DBG && P.dbg) ? __builtin_readcyclecounter() : 0ull;
+	} else {
+		// lane c of every wave fetches the workgroup + wave part of column c, the thread the lane part of every column (columns behind the run's last
+		// read zeros, further ones the tables that follow -- never used)
+		const uint32_t cl = lane < ncols ? lane : 0u;
+		const uint32_t a_g = g_row[cl], a_w = w_row[cl];
+		uint32_t X[XC > 0 ? XC : 4];
 #pragma unroll
-	for (int t4 = 0; t4 < XC / 4; ++t4) {
-		uint32_t x[4];
+		for (int c = 0; c < XC; ++c) X[c] = sl_src[64 * c];
+		t_issued = (DBG && P.dbg) ? __builtin_readcyclecounter() : 0ull;
+		// X0 of column c = 2 A(thread's cell 0) + bias = lane part + (workgroup + wave part, held by lane c): kept in the thread's OWN 16 bytes per trip of
+		// an LDS area (nobody else reads them: no barrier) -- a register per column would need the column loop unrolled over the whole run
+		const uint32_t Avec = lane < ncols ? a_g + a_w : 0u;   // (columns behind the run's last: zero)
+		uint4* __restrict__ xs = reinterpret_cast<uint4*>(smem + 2u * threads * R) + tid;   // + trip * threads  (behind the two exchange buffers)
 #pragma unroll
-		for (int k = 0; k < 4; ++k) x[k] = X[4 * t4 + k] + (uint32_t)__builtin_amdgcn_readlane((int)Avec, 4 * t4 + k);
-		xs[(uint32_t)t4 * threads] = make_uint4(x[0], x[1], x[2], x[3]);
+		for (int t4 = 0; t4 < XC / 4; ++t4) {
+			uint32_t x[4];
+#pragma unroll
+			for (int k = 0; k < 4; ++k) x[k] = X[4 * t4 + k] + (uint32_t)__builtin_amdgcn_readlane((int)Avec, 4 * t4 + k);
+			xs[(uint32_t)t4 * threads] = make_uint4(x[0], x[1], x[2], x[3]);
+		}
 	}
-	const uint32_t par = par_l ^ par_w;
+	uint32_t par = par_l ^ par_w;   // bit 0: the next ending read
 	uint8_t* __restrict__ rec = P.bt + (((unsigned long long)run.rec_hi << 32) | run.rec_lo) + (size_t)w * run.n_ends * threads;   // (wave-uniform; the thread adds tid)
-	uint32_t D[R];   // Y = B - 2 D
+	// D: Y = B - 2 D
 #pragma unroll
 	for (int r = 0; r < R; ++r) D[r] = flip ? Draw[R - 1 - r] : Draw[r];
 	if (!(run.yflags & 2u)) {   // the entering column is in D form
 #pragma unroll
 		for (int r = 0; r < R; ++r) D[r] = run.base_in - 2u * D[r];
 	}
+	if (warm) asm volatile("" ::"v"(warm_junk), "v"(D[0]));   // (the entering cells are here, so the request issued before them is too)
 	if (DBG && P.dbg) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	const unsigned long long t_loaded = (DBG && P.dbg) ? __builtin_readcyclecounter() + (D[0] & 0u) : 0ull;
 
-	const uint32_t lane4 = lane << 2, tid16 = tid << 4;
 	const uint32_t lds0 = (uint32_t)(unsigned long long)smem;   // LDS byte offset of the exchange buffers
-	uint32_t xb = lds0;                                          // the current exchange buffer ...
-	const uint32_t xtoggle = lds0 ^ (lds0 + threads * R * 4u);   // ... and what turns it into the other one
-	uint32_t ebit = 1u;
+	const uint32_t lane4 = lane << 2, tid16 = lds0 + (tid << 4);   // (tid16: this thread's 16 bytes of exchange buffer 0)
+	const uint32_t xbytes = threads * R * 4u;                   // one exchange buffer
+	uint32_t rec_off = tid;                                     // this thread's byte of the current ending read, relative to rec
 	const SlotRow* __restrict__ rows = P.slot_rows + run.row_off;
-	// one ending read (slot and qmask are scalars): SLOTX_ENDING_ASM
-	auto ending = [&](const uint32_t slot, const uint32_t qm) {
-		unsigned long long q1, q2, q3, qt, qn, b0, b1, b2, b3, co;
-		uint32_t t, a, sa, takes;
+	// one ending read (its control field is a scalar): SLOTX_ENDING_ASM
+	auto ending = [&](const uint32_t field) {
+		unsigned long long q1, q2, q3, qt, qn;
+		uint32_t t, a, sa, sl, takes;
 		asm volatile(SLOTX_ENDING_ASM
-		             : [d0] "+v"(D[0]), [d1] "+v"(D[1]), [d2] "+v"(D[2]), [d3] "+v"(D[3]), [tk] "=&v"(takes), [t] "=&v"(t), [a] "=&v"(a), [sa] "=&s"(sa),
-		               [q1] "=&s"(q1), [q2] "=&s"(q2), [q3] "=&s"(q3), [qt] "=&s"(qt), [qn] "=&s"(qn), [b0] "=&s"(b0), [b1] "=&s"(b1), [b2] "=&s"(b2), [b3] "=&s"(b3),
-		               [co] "=&s"(co)
-		             : [xb] "s"(xb), [slot] "s"(slot), [qm] "s"(qm), [eb] "s"(ebit), [par] "v"(par), [l4] "v"(lane4), [t16] "v"(tid16)
+		             : [d0] "+v"(D[0]), [d1] "+v"(D[1]), [d2] "+v"(D[2]), [d3] "+v"(D[3]), [par] "+v"(par), [ro] "+v"(rec_off), [tk] "=&v"(takes), [t] "=&v"(t), [a] "=&v"(a),
+		               [sa] "=&s"(sa), [sl] "=&s"(sl), [q1] "=&s"(q1), [q2] "=&s"(q2), [q3] "=&s"(q3), [qt] "=&s"(qt), [qn] "=&s"(qn)
+		             : [cw] "s"(field), [xby] "s"(xbytes), [thr] "s"(threads), [rb] "s"(rec), [l4] "v"(lane4), [t16] "v"(tid16)
 		             : "memory", "scc", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
-		if (!(DBG && (P.dbg_flags & 2u))) rec[tid] = (uint8_t)takes;
-		rec += threads;
-		ebit <<= 1;
-		xb ^= xtoggle & (0u - (slot >> 3));   // a wave-slot exchange (slots 8 .. 10) used the buffer: the next one takes the other
 	};
 	// column k of the current trip: its operand x, its four Kr words, its 16 control bits
 	uint32_t ci = 0;
@@ -682,15 +713,14 @@ __device__ __forceinline__ void slot_runx_body(const DevProblem& P, const SlotRu
 		D[2] = slot_y_sad_s(x, k2, D[2]);
 		D[3] = slot_y_sad_s(x, k3, D[3]);
 		if (DBG && P.dbg && w == 0 && tid == 0 && ci < 32u) P.dbg[(size_t)run.pad * 48 + 8 + ci] = __builtin_readcyclecounter() - t_loaded;
-		uint32_t n_end = (DBG && (P.dbg_flags & 8u)) ? 0u : (ctrl & 3u);   // reads ending here
-		if (n_end) {
-			ending((ctrl >> 2) & 31u, (ctrl >> 7) & 15u);
-			if (n_end > 1u) {   // several reads ending in one column are rare: slot and qmask of the later ones come from the row (scalar loads)
+		if (ctrl & 3u) {   // reads ending here
+			ending(ctrl);
+			if (ctrl & 2u) {   // several reads ending in one column are rare: the later ones are described in the row (scalar loads), same field layout once rearranged
 				const unsigned long long row = (unsigned long long)(rows + ci);
-				if (n_end > 2u) n_end = *(const __attribute__((address_space(4))) uint32_t*)(row + 44);   // (a control field of 3 says "three or more")
+				const uint32_t n_end = (ctrl & 1u) ? *(const __attribute__((address_space(4))) uint32_t*)(row + 44) : 2u;   // (a count of 3 says "three or more")
 				for (uint32_t e = 1; e < n_end; ++e) {
-					const uint32_t info = *(const __attribute__((address_space(4))) uint32_t*)(row + 48 + 8 * e);
-					ending(info & 255u, (info >> 8) & 15u);
+					const uint32_t info = *(const __attribute__((address_space(4))) uint32_t*)(row + 48 + 8 * e);   // slot | qmask << 8 | exchange buffer << 16
+					ending(((info & 31u) << 2) | (((info >> 8) & 15u) << 7) | (((info >> 16) & 1u) << 15));
 				}
 			}
 		}
@@ -704,8 +734,40 @@ __device__ __forceinline__ void slot_runx_body(const DevProblem& P, const SlotRu
 	// exit edge: five VALU -> SGPR copies per column): the columns behind the run's last -- up to seven, to a whole pair of trips -- are HARMLESS,
 	// their operands and Kr words are zero (slot_tables pads the lane parts and the Kr table, lanes >= ncols of Avec are zero: |0 - 0| = 0) and no
 	// read ends in them (the control words behind the run are zero).
+	if (STREAM) {
+		// the operands of a trip: lane part (four coalesced loads, a trip ahead) + the workgroup's and the wave's part (two scalar-cache loads of four words)
+		for (uint32_t pairs = (ncols + 7u) >> 3; pairs; --pairs) {
+			asm volatile("" ::"s"(krA[0]), "s"(cwA[0]), "s"(gA[0]), "s"(wA[0]));
+			krB = *(slot_cptr16)(unsigned long long)(kr_tab + 16u);
+			cwB = *(slot_cptr2)(unsigned long long)(cw_tab + 2u);
+			gB = *(slot_cptr4)(unsigned long long)(g_row + 4u);
+			wB = *(slot_cptr4)(unsigned long long)(w_row + 4u);
+#pragma unroll
+			for (int k = 0; k < 4; ++k) slB[k] = sl_src[64 * (4 + k)];
+			column(slA[0] + (gA[0] + wA[0]), krA[0], krA[1], krA[2], krA[3], cwA[0] & 0xFFFFu);
+			column(slA[1] + (gA[1] + wA[1]), krA[4], krA[5], krA[6], krA[7], cwA[0] >> 16);
+			column(slA[2] + (gA[2] + wA[2]), krA[8], krA[9], krA[10], krA[11], cwA[1] & 0xFFFFu);
+			column(slA[3] + (gA[3] + wA[3]), krA[12], krA[13], krA[14], krA[15], cwA[1] >> 16);
+			asm volatile("" ::"s"(krB[0]), "s"(cwB[0]), "s"(gB[0]), "s"(wB[0]));
+			kr_tab += 32u;
+			cw_tab += 4u;
+			g_row += 8u;
+			w_row += 8u;
+			sl_src += 512u;
+			krA = *(slot_cptr16)(unsigned long long)kr_tab;
+			cwA = *(slot_cptr2)(unsigned long long)cw_tab;
+			gA = *(slot_cptr4)(unsigned long long)g_row;
+			wA = *(slot_cptr4)(unsigned long long)w_row;
+#pragma unroll
+			for (int k = 0; k < 4; ++k) slA[k] = sl_src[64 * k];
+			column(slB[0] + (gB[0] + wB[0]), krB[0], krB[1], krB[2], krB[3], cwB[0] & 0xFFFFu);
+			column(slB[1] + (gB[1] + wB[1]), krB[4], krB[5], krB[6], krB[7], cwB[0] >> 16);
+			column(slB[2] + (gB[2] + wB[2]), krB[8], krB[9], krB[10], krB[11], cwB[1] & 0xFFFFu);
+			column(slB[3] + (gB[3] + wB[3]), krB[12], krB[13], krB[14], krB[15], cwB[1] >> 16);
+		}
+	} else {
 	const uint32_t xstride = threads * 16u;
-	uint32_t xaddr = lds0 + 2u * xstride + tid16;   // LDS byte address of the thread's line of trip 0
+	uint32_t xaddr = 2u * xstride + tid16;   // LDS byte address of the thread's line of trip 0 (behind the two exchange buffers)
 	typedef __attribute__((address_space(3))) const slot_u32x4* lds_line;
 	slot_u32x4 xA = *(lds_line)(size_t)xaddr, xB;
 	for (uint32_t pairs = (ncols + 7u) >> 3; pairs; --pairs) {
@@ -729,20 +791,39 @@ __device__ __forceinline__ void slot_runx_body(const DevProblem& P, const SlotRu
 		column(xB.z, krB[8], krB[9], krB[10], krB[11], cwB[1] & 0xFFFFu);
 		column(xB.w, krB[12], krB[13], krB[14], krB[15], cwB[1] >> 16);
 	}
-	const unsigned long long t_loop = (DBG && P.dbg) ? __builtin_readcyclecounter() + (D[0] & 0u) : 0ull;
-	slot_exit_cells<LR, DBG, SPEC, true>(P, run, cur, D, w, tid, lane, wave, L, lthr, Pthr, threads);
+	}
+	stamps.t_start = t_start; stamps.t_issued = t_issued; stamps.t_loaded = t_loaded;
+	stamps.t_loop = (DBG && P.dbg) ? __builtin_readcyclecounter() + (D[0] & 0u) : 0ull;
+}
+template <int LR, bool DBG, bool SPEC>
+__device__ __forceinline__ void slot_runx_exit(const DevProblem& P, const SlotRun& run, uint32_t* __restrict__ cur, uint32_t* score_out, const uint32_t w, uint32_t (&D)[1 << LR],
+                                               const SlotxStamps& stamps) {
+	const uint32_t tid = threadIdx.x, lane = tid & 63u;
+	const uint32_t wave = uni(tid >> 6);
+	const uint32_t L = run.L, lthr = tid << LR;
+	slot_exit_cells<LR, DBG, SPEC, true>(P, run, cur, D, w, tid, lane, wave, L, lthr, (w << L) | lthr, run.threads);
 	if (score_out && w == 0 && tid == 0) *score_out = D[0];
 	if (DBG && P.dbg && w == 0 && tid == 0) {
 		unsigned long long* d = P.dbg + (size_t)run.pad * 48;
-		d[0] = t_issued - t_start; d[1] = t_loaded - t_start; d[2] = t_loop - t_loaded; d[3] = __builtin_readcyclecounter() - t_loop; d[4] = ncols; d[5] = 1;
+		d[0] = stamps.t_issued - stamps.t_start; d[1] = stamps.t_loaded - stamps.t_start; d[2] = stamps.t_loop - stamps.t_loaded; d[3] = __builtin_readcyclecounter() - stamps.t_loop;
+		d[4] = run.ncols; d[5] = 1;
 	}
+}
+template <int LR, int XC, bool DBG, bool SPEC>
+__device__ __forceinline__ void slot_runx_body(const DevProblem& P, const SlotRun& run, const uint32_t* __restrict__ prev, uint32_t* __restrict__ cur, const uint32_t w,
+                                               uint32_t* score_out) {
+	uint32_t D[1 << LR];
+	SlotxStamps stamps;
+	slot_runx_core<LR, XC, DBG>(P, run, prev, w, D, stamps);
+	slot_runx_exit<LR, DBG, SPEC>(P, run, cur, score_out, w, D, stamps);
 }
 
 // The per-run tables of the prologue (SlotRun::tab_g / tab_w / tab_sl), once per table at create time: blockIdx.y = run.
 __global__ __launch_bounds__(256) void slot_tables(DevProblem P, const SlotRun* __restrict__ runs, uint32_t* __restrict__ tab) {
 	const SlotRun& run = runs[blockIdx.y];
 	const uint32_t ncols = run.ncols, L = run.L, lr = run.lr, nwg = 1u << (run.g - run.half), nwaves = run.threads >> 6;
-	const uint32_t n_g = nwg * ncols, n_w = nwaves * ncols, n_sl = ((run.yflags & 8u) ? ((ncols + 7u) & ~7u) : ncols) * 64u;   // (X runs: lane parts padded with zeros to a pair of trips)
+	const uint32_t ncp = (run.yflags & 8u) ? (ncols + 7u) & ~7u : ncols;   // X runs: every row padded with zeros to a pair of trips (the columns behind the run's last are harmless)
+	const uint32_t n_g = nwg * ncp, n_w = nwaves * ncp, n_sl = ncp * 64u;
 	// X runs (slot_runx_body): the Kr words of the run's columns side by side, and the tie parities -- bit e of a thread's word = parity of its local
 	// index under the mask of the run's e-th ending read (forward order: by column, then by position in the row), the same for a workgroup's grid bits
 	const bool xrun = (run.yflags & 8u) != 0u;
@@ -764,17 +845,17 @@ __global__ __launch_bounds__(256) void slot_tables(DevProblem P, const SlotRun* 
 			const uint32_t q = i - (n_g + n_w + n_sl), c = q / R, r = q % R;
 			tab[run.tab_kr + q] = c < ncols ? reinterpret_cast<const uint32_t*>(rows + c)[r] : 0u;   // (a Y-form row holds Kr[0 .. R) in its first words)
 		} else if (i < n_g) {
-			const uint32_t w = i / ncols, c = i % ncols;
-			const SlotRow& row = rows[c];
+			const uint32_t w = i / ncp, c = i % ncp;
+			const SlotRow& row = rows[c < ncols ? c : 0u];
 			uint32_t acc = row.Cp;
 			for (uint32_t s = L; s < L + run.g; ++s) acc += (uint32_t)row.dslot[s] & (0u - ((w >> (s - L)) & 1u));
-			tab[run.tab_g + i] = (acc << ysh) + ybias;
+			tab[run.tab_g + i] = c < ncols ? (acc << ysh) + ybias : 0u;
 		} else if (i < n_g + n_w) {
-			const uint32_t q = i - n_g, wave = q / ncols, c = q % ncols;
-			const SlotRow& row = rows[c];
+			const uint32_t q = i - n_g, wave = q / ncp, c = q % ncp;
+			const SlotRow& row = rows[c < ncols ? c : 0u];
 			uint32_t acc = 0;
 			for (uint32_t s = lr + 6u; s < L; ++s) acc += (uint32_t)row.dslot[s] & (0u - ((wave >> (s - lr - 6u)) & 1u));
-			tab[run.tab_w + q] = acc << ysh;
+			tab[run.tab_w + q] = c < ncols ? acc << ysh : 0u;
 		} else {
 			const uint32_t q = i - n_g - n_w, c = q >> 6, lane = q & 63u;
 			const SlotRow& row = rows[c < ncols ? c : 0u];
@@ -847,6 +928,41 @@ __device__ __forceinline__ DevProblem slot_entry_problem(const SlotBatchEntry& e
 	return P;
 }
 
+// Shared launches read their run descriptor from memory before anything else can be requested -- a miss all the way to HBM per launch.  The entry of a
+// table's next step lies behind the current one (the schedule's entries are consecutive): the kernel requests its lines with ONE vector load at its very
+// start -- into this XCD's L2, where the next launch's workgroup (x, y) finds them (measured: 24 coverage-15 tables 11.1 -> 10.5 us per launch).  The
+// destination register must stay reserved until the load has landed (the compiler cannot see a load inside an asm statement): slot_warm_done() at the
+// kernel's end -- vector loads return in order, and the body has consumed later ones by then.
+__device__ __forceinline__ uint32_t slot_warm_next(const SlotBatchEntry* ep) {
+	uint32_t junk;
+	const unsigned long long line = (unsigned long long)(ep + 1) + ((threadIdx.x & 7u) << 6);
+	asm volatile("global_load_dword %0, %1, off" : "=v"(junk) : "v"(line) : "memory");
+	return junk;
+}
+__device__ __forceinline__ void slot_warm_done(uint32_t junk) { asm volatile("" ::"v"(junk)); }
+
+// The X runs of several tables in one launch (the counterpart of slot_group below for runs that take the X kernel; the group's other runs go out as
+// a slot_group launch of their own).  The entry is read TWICE: the prologue's and the loop's half before the loop, the exit's half -- exchange layout,
+// masks, the speculative seed's slot -- after it (scalar-cache hits), so the loop's scalar budget is the loop's alone.
+template <bool DBG = false>
+__global__ __launch_bounds__(512, 4) void slot_groupx(SlotGroupArgs args) {
+	const SlotBatchEntry* ep = args.entry[blockIdx.y];
+	uint32_t D[4];
+	SlotxStamps stamps;
+	{
+		const SlotBatchEntry e = slot_scalar_copy(ep);
+		if (blockIdx.x >= (1u << (e.run.g - e.run.half)) || threadIdx.x >= e.run.threads) return;
+		DevProblem P = slot_entry_problem(e, false);
+		if (DBG) P.dbg_flags = e.pad2;
+		slot_runx_core<2, 0, DBG>(P, e.run, e.prev, blockIdx.x, D, stamps, (e.pad2 & 0x10000u) ? nullptr : (const void*)(ep + 1));   // (pad2 bit 16: timing experiment, debug library)
+	}
+	asm volatile("" : "+s"(ep));   // (opaque: what follows is fetched again, not kept in registers through the loop)
+	const SlotBatchEntry e = slot_scalar_copy(ep);
+	DevProblem P = slot_entry_problem(e, false);
+	if (e.run.spec_id) slot_runx_exit<2, DBG, true>(P, e.run, e.cur, e.score_out, blockIdx.x, D, stamps);
+	else slot_runx_exit<2, DBG, false>(P, e.run, e.cur, e.score_out, blockIdx.x, D, stamps);
+}
+
 // One launch = the next run of SEVERAL TABLES (whamd_dptable_enqueue_many: independent tables advance in lockstep on one stream):
 // blockIdx.y selects the table's entry, blockIdx.x the workgroup of that run.  The launch boundary between two dependent launches
 // (~2.5 us) and the prologue's round trips are then paid once per super-step of the whole group instead of once per table, and a
@@ -857,6 +973,7 @@ __device__ __forceinline__ DevProblem slot_entry_problem(const SlotBatchEntry& e
 // launch when the group is a handful of narrow tables and every workgroup has a CU to itself.
 template <int LR, bool DBG = false, bool TIGHT = false>
 __global__ __launch_bounds__(512, TIGHT ? (LR == 3 ? 6 : 8) : 2) void slot_group(SlotGroupArgs args) {
+	const uint32_t warm = slot_warm_next(args.entry[blockIdx.y]);
 	const SlotBatchEntry e = slot_scalar_copy(args.entry[blockIdx.y]);
 	const SlotRun& run = e.run;
 	if (blockIdx.x >= (1u << (run.g - run.half)) || threadIdx.x >= run.threads) return;
@@ -867,4 +984,5 @@ __global__ __launch_bounds__(512, TIGHT ? (LR == 3 ? 6 : 8) : 2) void slot_group
 		else slot_run_body<(LR == 3 ? 3 : 2), DBG, false, true>(P, run, e.prev, e.cur, blockIdx.x, e.score_out);
 	} else if (run.spec_id) slot_run_body<LR, DBG, true>(P, run, e.prev, e.cur, blockIdx.x, e.score_out);
 	else slot_run_body<LR, DBG, false>(P, run, e.prev, e.cur, blockIdx.x, e.score_out);
+	slot_warm_done(warm);
 }

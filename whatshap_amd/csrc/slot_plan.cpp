@@ -344,14 +344,24 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 		run.c0 = c; run.ncols = d.ncols; run.g = g; run.L = L; run.lw = d.lw;
 		run.ctrl_off = (uint32_t)plan.ctrl.size();
 		plan.ctrl.resize(plan.ctrl.size() + SLOT_CTRL_WORDS, 0);
+		uint32_t exchanges = 0;   // wave-slot endings so far (single individual): they alternate between two LDS exchange buffers -- which one travels with the ending read
 		for (uint32_t i = 0; i < d.ncols; ++i) {
+			if (!ped) {
+				SlotRow& xrow = rows_g[rows_mark + i];
+				for (uint32_t k = 0; k < std::min<uint32_t>(xrow.n_end, SLOT_MAXEND); ++k) {
+					if ((xrow.end[k].info & 31u) < (uint32_t)(lr + SLOT_LANE)) continue;
+					if (exchanges & 1u) xrow.end[k].info |= 1u << 16;   // (bits 16 .. 23 of info are free: slot | qmask << 8 | buffer << 16 | mflip << 24)
+					++exchanges;
+				}
+			}
 			const uint32_t ne = ped ? prows_g[rows_mark + i].n_end : rows_g[rows_mark + i].n_end;
 			const uint32_t s0 = ped ? prows_g[rows_mark + i].info0 : (rows_g[rows_mark + i].end[0].info & 31u);
 			const uint32_t byte = std::min(ne, 3u) | ((ne ? (s0 & 31u) : 0u) << 2);   // (3: three or more, the kernel reads the row's count)
 			if (ped) plan.ctrl[run.ctrl_off + (i >> 2)] |= byte << ((i & 3u) * 8u);
 			else {   // single individual: 16 bits per column, the first ending read's qmask (tie parity of the thread's cells) next to its slot
 				const uint32_t qm = ne ? ((rows_g[rows_mark + i].end[0].info >> 8) & 255u) : 0u;
-				plan.ctrl[run.ctrl_off + (i >> 1)] |= (byte | (qm << 7)) << ((i & 1u) * 16u);
+				const uint32_t xbuf = ne ? ((rows_g[rows_mark + i].end[0].info >> 16) & 1u) : 0u;   // (bit 15: read by the X runs only, kernels_slots.h)
+				plan.ctrl[run.ctrl_off + (i >> 1)] |= (byte | (qm << 7) | (xbuf << 15)) << ((i & 1u) * 16u);
 			}
 		}
 		run.lr = (uint32_t)lr;

@@ -193,7 +193,7 @@ static_assert(sizeof(SlotBatchEntry) == 320 && sizeof(SlotBatchEntry) % 64 == 0,
 
 // Kernel argument of a group launch: blockIdx.y selects the entry (a pointer into the owning table's own entry array -- the arrays are
 // built once per table at create time; a group launch only passes which of them take part).
-constexpr int SLOT_GROUP_MAX = 120;
+constexpr int SLOT_GROUP_MAX = 248;   // (2 KB of kernel arguments: a whole-genome cohort is hundreds of tables)
 struct SlotGroupArgs {
 	uint32_t n, pad;
 	const SlotBatchEntry* entry[SLOT_GROUP_MAX];
