@@ -888,7 +888,8 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 			auto pad4 = [](uint64_t v) { return (v + 3ull) & ~3ull; };
 			// X runs (kernels_slots.h, slot_runx_body): a Y-form run with four cells per thread whose columns and ending reads fit the kernel's registers; the
 			// rows of its tables are padded with zero columns to a pair of trips
-			const bool xrun = (run.yflags & 1u) && run.lr == 2u && run.ncols <= (uint32_t)SLOT_XCOLS && run.n_ends <= (uint32_t)SLOT_XENDS && !debug_env("WHAMD_NO_XRUN");
+			const bool xrun = (run.yflags & 1u) && (run.lr == 2u || (run.lr == 3u && !debug_env("WHAMD_NO_XRUN8"))) && run.ncols <= (uint32_t)SLOT_XCOLS &&
+			                  run.n_ends <= (uint32_t)SLOT_XENDS && !debug_env("WHAMD_NO_XRUN");
 			const uint64_t ncp = xrun ? ((run.ncols + 7u) & ~7u) : run.ncols;
 			run.tab_g = (uint32_t)slot_tab_words;
 			slot_tab_words += pad4(ncp << (run.g - run.half));
@@ -1499,7 +1500,7 @@ void DeviceTable::Impl::launch_slot_run(const SlotBatchEntry& e, uint64_t& launc
 	}
 	const size_t lds = slot_run_lds_bytes(run.threads, run.lr, run.ncols);   // wave-slot exchange + hot lines + per-wave A + lane sums
 	const dim3 grid(1u << (run.g - run.half)), block(run.threads);
-	if (run.yflags & 8u) {   // X run: registers instead of LDS lines (LDS: the wave-slot exchange buffers only)
+	if ((run.yflags & 8u) && run.lr == 2u) {   // X run with four cells per thread: registers instead of LDS lines (LDS: the wave-slot exchange buffers + the threads' own operand lines)
 		const size_t lds_x = slotx_lds_bytes(run.threads, run.ncols <= 24u ? 24u : 32u);
 #define WHAMD_SLOTX_LAUNCH(XCV, DBGV, SPECV) hipLaunchKernelGGL((slot_runx<2, XCV, DBGV, SPECV>), grid, block, lds_x, m.run_stream, m.dp, run, e.prev, e.cur, e.score_out)
 #ifdef WHAMD_DEBUG_BUILD
@@ -1723,7 +1724,7 @@ whamd_status_t DeviceTable::enqueue_group(DeviceTable* const* tables, const Prob
 	};
 	std::vector<Part> parts(n_parts);
 	for (size_t i = 0; i < n_tables; ++i) parts[i % n_parts].members.push_back(i);
-	constexpr int NV = 9;   // kernel variants (6: single individual, eight cells per thread; 7: trio, factorised lines; 8: X runs of a single individual, slot_groupx)
+	constexpr int NV = 10;  // kernel variants (6: single individual, eight cells per thread; 7: trio, factorised lines; 8 / 9: X runs of a single individual with four / eight cells per thread, slot_groupx)
 	for (Part& part : parts) { part.lead = tables[part.members[0]]->impl_; part.batches.resize(NV); }
 	auto abort_all = [&]() {
 		for (Part& part : parts) (void)hipStreamSynchronize(part.lead->stream);
@@ -1767,7 +1768,8 @@ whamd_status_t DeviceTable::enqueue_group(DeviceTable* const* tables, const Prob
 			case 4: hipLaunchKernelGGL((pedslot_group<4, 4>), grid, block, b.lds, stream, b.args); break;
 			case 5: hipLaunchKernelGGL((pedslot_group<2, 16>), grid, block, b.lds, stream, b.args); break;
 			case 7: hipLaunchKernelGGL((pedslot_group<2, PSLOT_FACT>), grid, block, b.lds, stream, b.args); break;
-			case 8: hipLaunchKernelGGL((slot_groupx<false>), grid, block, b.lds, stream, b.args); break;
+			case 8: hipLaunchKernelGGL((slot_groupx<2, false>), grid, block, b.lds, stream, b.args); break;
+			case 9: hipLaunchKernelGGL((slot_groupx<3, false>), grid, block, b.lds, stream, b.args); break;
 			default:
 				if (tight) hipLaunchKernelGGL((slot_group<3, false, true>), grid, block, b.lds, stream, b.args);
 				else hipLaunchKernelGGL((slot_group<3, false, false>), grid, block, b.lds, stream, b.args);
@@ -1790,7 +1792,7 @@ whamd_status_t DeviceTable::enqueue_group(DeviceTable* const* tables, const Prob
 				for (uint32_t q = 0; q < ss.entry_count; ++q) {
 					const SlotBatchEntry& he = m.slot_entries[ss.entry_off + q];
 					const bool xrun = !m.splan.ped && (he.run.yflags & 8u) && !m.dp.dbg_flags;   // (the X kernel: operands streamed from the tables, 16 KB of LDS)
-					const int variant = m.splan.ped ? (he.ex.nf == (uint32_t)PSLOT_FACT ? 7 : (he.ex.nf == 16 ? 5 : 1 + (he.ex.tb == 4 ? 2 : 0) + (he.ex.nf == 4 ? 1 : 0))) : (he.run.lr == 3 ? 6 : (xrun ? 8 : 0));
+					const int variant = m.splan.ped ? (he.ex.nf == (uint32_t)PSLOT_FACT ? 7 : (he.ex.nf == 16 ? 5 : 1 + (he.ex.tb == 4 ? 2 : 0) + (he.ex.nf == 4 ? 1 : 0))) : (he.run.lr == 3 ? (xrun ? 9 : 6) : (xrun ? 8 : 0));
 					Batch& b = part.batches[variant];
 					if (b.args.n == (uint32_t)SLOT_GROUP_MAX) {
 						flush(part, variant);
@@ -1799,7 +1801,7 @@ whamd_status_t DeviceTable::enqueue_group(DeviceTable* const* tables, const Prob
 					b.args.entry[b.args.n++] = m.d_slot_entries + ss.entry_off + q;
 					b.grid_x = std::max(b.grid_x, 1u << (he.run.g - he.run.half));
 					b.threads = std::max(b.threads, he.run.threads);
-					b.lds = std::max(b.lds, xrun ? (size_t)2 * he.run.threads * 16 : ss.lds);
+					b.lds = std::max(b.lds, xrun ? (size_t)2 * he.run.threads * (4u << he.run.lr) : ss.lds);
 					counted[i * NV + variant] = 1;
 				}
 			}

@@ -795,6 +795,214 @@ __device__ __forceinline__ void slot_runx_core(const DevProblem& P, const SlotRu
 	stamps.t_start = t_start; stamps.t_issued = t_issued; stamps.t_loaded = t_loaded;
 	stamps.t_loop = (DBG && P.dbg) ? __builtin_readcyclecounter() + (D[0] & 0u) : 0ull;
 }
+// ---- the same for EIGHT cells per thread (reg slots 0 .. 2: the layout of wide tables that share their launches, slot_plan.cpp `shared_launches`) ----
+// The partner cells travel in v56 .. v63, a wave-slot exchange is 32 bytes per thread (D as v[48:55]), seven lane masks (bit r of qmask flips cell r; bit 0 is
+// never set), eight borrows formed first and consumed in the same order.  Streamed operands only (several workgroups per CU): a trip is TWO columns -- their
+// sixteen Kr words are one scalar-cache load.
+#define SLOTX8_MOVS(a0, a1, a2, a3, a4, a5, a6, a7)                                                                    \
+	"v_mov_b32_e32 v56, %[d" #a0 "]\n\tv_mov_b32_e32 v57, %[d" #a1 "]\n\tv_mov_b32_e32 v58, %[d" #a2 "]\n\tv_mov_b32_e32 v59, %[d" #a3 "]\n\t" \
+	"v_mov_b32_e32 v60, %[d" #a4 "]\n\tv_mov_b32_e32 v61, %[d" #a5 "]\n\tv_mov_b32_e32 v62, %[d" #a6 "]\n\tv_mov_b32_e32 v63, %[d" #a7 "]\n"
+#define SLOTX8_ENDING_ASM                                                                                              \
+	"s_bfe_u32 %[sl], %[cw], 0x50002\n\t"          /* slot of the ending read */                                       \
+	"s_cmp_lt_u32 %[sl], 9\n\t"                                                                                        \
+	"s_cbranch_scc0 .Lyw%=\n\t"                                                                                        \
+	"s_cmp_lt_u32 %[sl], 3\n\t"                                                                                        \
+	"s_cbranch_scc1 .Lyr%=\n\t"                                                                                        \
+	"s_sub_u32 %[sa], %[sl], 1\n\t"                /* lane slot: byte address of lane ^ 2^(slot - 3) = (lane * 4) ^ 2^(slot - 1) */ \
+	"s_lshl_b32 %[sa], 1, %[sa]\n\t"                                                                                   \
+	"v_xor_b32_e32 %[t], %[sa], %[l4]\n\t"                                                                             \
+	"ds_bpermute_b32 v56, %[t], %[d0]\n\t"                                                                             \
+	"ds_bpermute_b32 v57, %[t], %[d1]\n\t"                                                                             \
+	"ds_bpermute_b32 v58, %[t], %[d2]\n\t"                                                                             \
+	"ds_bpermute_b32 v59, %[t], %[d3]\n\t"                                                                             \
+	"ds_bpermute_b32 v60, %[t], %[d4]\n\t"                                                                             \
+	"ds_bpermute_b32 v61, %[t], %[d5]\n\t"                                                                             \
+	"ds_bpermute_b32 v62, %[t], %[d6]\n\t"                                                                             \
+	"ds_bpermute_b32 v63, %[t], %[d7]\n\t"                                                                             \
+	"s_branch .Lym%=\n"                                                                                                \
+	".Lyw%=:\n\t"                                  /* wave slot: partner thread = tid ^ (64 << (slot - 9)), 32 bytes each */ \
+	"s_sub_u32 %[sa], %[sl], 9\n\t"                                                                                    \
+	"s_lshl_b32 %[sa], 0x800, %[sa]\n\t"                                                                               \
+	"s_bfe_u32 %[sl], %[cw], 0x1000f\n\t"          /* which of the two exchange buffers: bit 15 of the control field */ \
+	"s_mul_i32 %[sl], %[sl], %[xby]\n\t"                                                                               \
+	"v_mov_b32_e32 v48, %[d0]\n\tv_mov_b32_e32 v49, %[d1]\n\tv_mov_b32_e32 v50, %[d2]\n\tv_mov_b32_e32 v51, %[d3]\n\t" \
+	"v_mov_b32_e32 v52, %[d4]\n\tv_mov_b32_e32 v53, %[d5]\n\tv_mov_b32_e32 v54, %[d6]\n\tv_mov_b32_e32 v55, %[d7]\n\t" \
+	"v_add_u32_e32 %[t], %[sl], %[t32]\n\t"                                                                            \
+	"ds_write_b128 %[t], v[48:51]\n\t"                                                                                 \
+	"ds_write_b128 %[t], v[52:55] offset:16\n\t"                                                                       \
+	"v_xor_b32_e32 %[t], %[sa], %[t32]\n\t"                                                                            \
+	"v_add_u32_e32 %[t], %[sl], %[t]\n\t"                                                                              \
+	"s_waitcnt lgkmcnt(0)\n\t"                                                                                         \
+	"s_barrier\n\t"                                                                                                    \
+	"ds_read_b128 v[56:59], %[t]\n\t"                                                                                  \
+	"ds_read_b128 v[60:63], %[t] offset:16\n\t"                                                                        \
+	"s_branch .Lym%=\n"                                                                                                \
+	".Lyr%=:\n\t"                                  /* reg slot s: the partner of cell r is cell r ^ 2^s */             \
+	"s_cmp_eq_u32 %[sl], 0\n\t"                                                                                        \
+	"s_cbranch_scc0 .Lyq%=\n\t" SLOTX8_MOVS(1, 0, 3, 2, 5, 4, 7, 6)                                                    \
+	"\ts_branch .Lym%=\n"                                                                                              \
+	".Lyq%=:\n\t"                                                                                                      \
+	"s_cmp_eq_u32 %[sl], 1\n\t"                                                                                        \
+	"s_cbranch_scc0 .Lyp%=\n\t" SLOTX8_MOVS(2, 3, 0, 1, 6, 7, 4, 5)                                                    \
+	"\ts_branch .Lym%=\n"                                                                                              \
+	".Lyp%=:\n\t" SLOTX8_MOVS(4, 5, 6, 7, 0, 1, 2, 3)                                                                  \
+	".Lym%=:\n\t"                                  /* the lane masks, while the partner cells travel */                \
+	"v_and_b32_e32 %[t], 1, %[par]\n\t"                                                                                \
+	"v_cmp_ne_u32_e64 %[qt], 0, %[t]\n\t"                                                                              \
+	"v_lshrrev_b32_e32 %[par], 1, %[par]\n\t"                                                                          \
+	"s_not_b64 %[qn], %[qt]\n\t"                                                                                       \
+	"s_bitcmp1_b32 %[cw], 8\n\t"                                                                                       \
+	"s_cselect_b64 %[q1], %[qn], %[qt]\n\t"                                                                            \
+	"s_bitcmp1_b32 %[cw], 9\n\t"                                                                                       \
+	"s_cselect_b64 %[q2], %[qn], %[qt]\n\t"                                                                            \
+	"s_bitcmp1_b32 %[cw], 10\n\t"                                                                                      \
+	"s_cselect_b64 %[q3], %[qn], %[qt]\n\t"                                                                            \
+	"s_bitcmp1_b32 %[cw], 11\n\t"                                                                                      \
+	"s_cselect_b64 %[q4], %[qn], %[qt]\n\t"                                                                            \
+	"s_bitcmp1_b32 %[cw], 12\n\t"                                                                                      \
+	"s_cselect_b64 %[q5], %[qn], %[qt]\n\t"                                                                            \
+	"s_bitcmp1_b32 %[cw], 13\n\t"                                                                                      \
+	"s_cselect_b64 %[q6], %[qn], %[qt]\n\t"                                                                            \
+	"s_bitcmp1_b32 %[cw], 14\n\t"                                                                                      \
+	"s_cselect_b64 %[q7], %[qn], %[qt]\n\t"                                                                            \
+	"s_waitcnt lgkmcnt(0)\n\t"                                                                                         \
+	"v_subb_co_u32_e64 %[t], %[q7], %[d7], v63, %[q7]\n\t"        /* (a borrow overwrites its own carry-in mask) */    \
+	"v_subb_co_u32_e64 %[t], %[q6], %[d6], v62, %[q6]\n\t"                                                             \
+	"v_subb_co_u32_e64 %[t], %[q5], %[d5], v61, %[q5]\n\t"                                                             \
+	"v_subb_co_u32_e64 %[t], %[q4], %[d4], v60, %[q4]\n\t"                                                             \
+	"v_subb_co_u32_e64 %[t], %[q3], %[d3], v59, %[q3]\n\t"                                                             \
+	"v_subb_co_u32_e64 %[t], %[q2], %[d2], v58, %[q2]\n\t"                                                             \
+	"v_subb_co_u32_e64 %[t], %[q1], %[d1], v57, %[q1]\n\t"                                                             \
+	"v_subb_co_u32_e64 %[t], %[qt], %[d0], v56, %[qt]\n\t"                                                             \
+	"v_cndmask_b32_e64 %[tk], 0, 1, %[q7]\n\t"                                                                         \
+	"v_max_u32_e32 %[d7], %[d7], v63\n\t"                                                                              \
+	"v_addc_co_u32_e64 %[tk], %[qn], %[tk], %[tk], %[q6]\n\t"                                                          \
+	"v_max_u32_e32 %[d6], %[d6], v62\n\t"                                                                              \
+	"v_addc_co_u32_e64 %[tk], %[qn], %[tk], %[tk], %[q5]\n\t"                                                          \
+	"v_max_u32_e32 %[d5], %[d5], v61\n\t"                                                                              \
+	"v_addc_co_u32_e64 %[tk], %[qn], %[tk], %[tk], %[q4]\n\t"                                                          \
+	"v_max_u32_e32 %[d4], %[d4], v60\n\t"                                                                              \
+	"v_addc_co_u32_e64 %[tk], %[qn], %[tk], %[tk], %[q3]\n\t"                                                          \
+	"v_max_u32_e32 %[d3], %[d3], v59\n\t"                                                                              \
+	"v_addc_co_u32_e64 %[tk], %[qn], %[tk], %[tk], %[q2]\n\t"                                                          \
+	"v_max_u32_e32 %[d2], %[d2], v58\n\t"                                                                              \
+	"v_addc_co_u32_e64 %[tk], %[qn], %[tk], %[tk], %[q1]\n\t"                                                          \
+	"v_max_u32_e32 %[d1], %[d1], v57\n\t"                                                                              \
+	"v_addc_co_u32_e64 %[tk], %[qn], %[tk], %[tk], %[qt]\n\t"                                                          \
+	"v_max_u32_e32 %[d0], %[d0], v56\n\t"                                                                              \
+	"global_store_byte %[ro], %[tk], %[rb]\n\t"                                                                        \
+	"v_add_u32_e32 %[ro], %[thr], %[ro]"
+
+template <bool DBG>
+__device__ __forceinline__ void slot_runx8_core(const DevProblem& P, const SlotRun& run, const uint32_t* __restrict__ prev, const uint32_t w, uint32_t (&D)[8],
+                                                SlotxStamps& stamps, const void* warm = nullptr) {
+	constexpr int LR = 3, R = 8;
+	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];   // wave-slot exchange 2 x [threads][8]
+	const unsigned long long t_start = (DBG && P.dbg) ? __builtin_readcyclecounter() : 0ull;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u;
+	const uint32_t wave = uni(tid >> 6);
+	const uint32_t L = run.L;
+	const uint32_t Pthr = (w << L) | (tid << LR);
+	const uint32_t ncols = run.ncols, threads = run.threads;
+	const uint32_t ncp = (ncols + 7u) & ~7u;
+	const uint32_t* __restrict__ tab = P.slot_tab;
+	const uint32_t* __restrict__ kr_tab = tab + run.tab_kr;               // [column][8]: sixteen words = two columns
+	const uint32_t* __restrict__ cw_tab = P.slot_ctrl + run.ctrl_off;     // one word = two columns
+	typedef const __attribute__((address_space(4))) uint32_t* slot_cptr1;
+	slot_u32x16 krA = *(slot_cptr16)(unsigned long long)kr_tab, krB;
+	uint32_t cwA = *(slot_cptr1)(unsigned long long)cw_tab, cwB;
+	const uint32_t par_w = *(slot_cptr1)(unsigned long long)(tab + run.tab_par + threads + w);
+	uint32_t warm_junk = 0;
+	if (warm) {   // (the next step's entry into this XCD's L2: see slot_runx_core)
+		const unsigned long long line = (unsigned long long)warm + ((lane & 7u) << 6);
+		asm volatile("global_load_dword %0, %1, off" : "=v"(warm_junk) : "v"(line) : "memory");
+	}
+	uint32_t Draw[R];
+	bool flip;
+	slot_enter_cells<LR, DBG>(P, run, prev, Pthr, Draw, flip);
+	const uint32_t par_l = tab[run.tab_par + tid];
+	const uint32_t* __restrict__ sl_src = tab + run.tab_sl + lane;
+	const uint32_t* __restrict__ g_row = tab + run.tab_g + w * ncp;
+	const uint32_t* __restrict__ w_row = tab + run.tab_w + wave * ncp;
+	slot_u32x2 gA = *(slot_cptr2)(unsigned long long)g_row, gB;
+	slot_u32x2 wA = *(slot_cptr2)(unsigned long long)w_row, wB;
+	uint32_t slA[2] = {sl_src[0], sl_src[64]}, slB[2];
+	const unsigned long long t_issued = (DBG && P.dbg) ? __builtin_readcyclecounter() : 0ull;
+	uint32_t par = par_l ^ par_w;
+	uint8_t* __restrict__ rec = P.bt + (((unsigned long long)run.rec_hi << 32) | run.rec_lo) + (size_t)w * run.n_ends * threads;
+#pragma unroll
+	for (int r = 0; r < R; ++r) D[r] = flip ? Draw[R - 1 - r] : Draw[r];
+	if (!(run.yflags & 2u)) {
+#pragma unroll
+		for (int r = 0; r < R; ++r) D[r] = run.base_in - 2u * D[r];
+	}
+	if (warm) asm volatile("" ::"v"(warm_junk), "v"(D[0]));
+	if (DBG && P.dbg) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	const unsigned long long t_loaded = (DBG && P.dbg) ? __builtin_readcyclecounter() + (D[0] & 0u) : 0ull;
+
+	const uint32_t lds0 = (uint32_t)(unsigned long long)smem;
+	const uint32_t lane4 = lane << 2, tid32 = lds0 + (tid << 5);
+	const uint32_t xbytes = threads * R * 4u;
+	uint32_t rec_off = tid;
+	const SlotRow* __restrict__ rows = P.slot_rows + run.row_off;
+	auto ending = [&](const uint32_t field) {
+		unsigned long long q1, q2, q3, q4, q5, q6, q7, qt, qn;
+		uint32_t t, sa, sl, takes;
+		asm volatile(SLOTX8_ENDING_ASM
+		             : [d0] "+v"(D[0]), [d1] "+v"(D[1]), [d2] "+v"(D[2]), [d3] "+v"(D[3]), [d4] "+v"(D[4]), [d5] "+v"(D[5]), [d6] "+v"(D[6]), [d7] "+v"(D[7]), [par] "+v"(par),
+		               [ro] "+v"(rec_off), [tk] "=&v"(takes), [t] "=&v"(t), [sa] "=&s"(sa), [sl] "=&s"(sl), [q1] "=&s"(q1), [q2] "=&s"(q2), [q3] "=&s"(q3), [q4] "=&s"(q4),
+		               [q5] "=&s"(q5), [q6] "=&s"(q6), [q7] "=&s"(q7), [qt] "=&s"(qt), [qn] "=&s"(qn)
+		             : [cw] "s"(field), [xby] "s"(xbytes), [thr] "s"(threads), [rb] "s"(rec), [l4] "v"(lane4), [t32] "v"(tid32)
+		             : "memory", "scc", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+	};
+	uint32_t ci = 0;
+	auto column = [&](const uint32_t x, const slot_u32x16& kr, const int half, const uint32_t ctrl) {
+#pragma unroll
+		for (int r = 0; r < R; ++r) D[r] = slot_y_sad_s(x, kr[half * 8 + r], D[r]);
+		if (DBG && P.dbg && w == 0 && tid == 0 && ci < 32u) P.dbg[(size_t)run.pad * 48 + 8 + ci] = __builtin_readcyclecounter() - t_loaded;
+		if (ctrl & 3u) {
+			ending(ctrl);
+			if (ctrl & 2u) {
+				const unsigned long long row = (unsigned long long)(rows + ci);
+				const uint32_t n_end = (ctrl & 1u) ? *(slot_cptr1)(row + 44) : 2u;
+				for (uint32_t e = 1; e < n_end; ++e) {
+					const uint32_t info = *(slot_cptr1)(row + 48 + 8 * e);   // slot | qmask << 8 | exchange buffer << 16
+					ending(((info & 31u) << 2) | (((info >> 8) & 255u) << 7) | (((info >> 16) & 1u) << 15));
+				}
+			}
+		}
+		++ci;
+	};
+	// two trips (of two columns) per loop iteration; the columns behind the run's last are harmless (zeros), as in slot_runx_core
+	for (uint32_t quads = (ncols + 3u) >> 2; quads; --quads) {
+		asm volatile("" ::"s"(krA[0]), "s"(cwA), "s"(gA[0]), "s"(wA[0]));
+		krB = *(slot_cptr16)(unsigned long long)(kr_tab + 16u);
+		cwB = *(slot_cptr1)(unsigned long long)(cw_tab + 1u);
+		gB = *(slot_cptr2)(unsigned long long)(g_row + 2u);
+		wB = *(slot_cptr2)(unsigned long long)(w_row + 2u);
+		slB[0] = sl_src[128];
+		slB[1] = sl_src[192];
+		column(slA[0] + (gA[0] + wA[0]), krA, 0, cwA & 0xFFFFu);
+		column(slA[1] + (gA[1] + wA[1]), krA, 1, cwA >> 16);
+		asm volatile("" ::"s"(krB[0]), "s"(cwB), "s"(gB[0]), "s"(wB[0]));
+		kr_tab += 32u;
+		cw_tab += 2u;
+		g_row += 4u;
+		w_row += 4u;
+		sl_src += 256u;
+		krA = *(slot_cptr16)(unsigned long long)kr_tab;
+		cwA = *(slot_cptr1)(unsigned long long)cw_tab;
+		gA = *(slot_cptr2)(unsigned long long)g_row;
+		wA = *(slot_cptr2)(unsigned long long)w_row;
+		slA[0] = sl_src[0];
+		slA[1] = sl_src[64];
+		column(slB[0] + (gB[0] + wB[0]), krB, 0, cwB & 0xFFFFu);
+		column(slB[1] + (gB[1] + wB[1]), krB, 1, cwB >> 16);
+	}
+	stamps.t_start = t_start; stamps.t_issued = t_issued; stamps.t_loaded = t_loaded;
+	stamps.t_loop = (DBG && P.dbg) ? __builtin_readcyclecounter() + (D[0] & 0u) : 0ull;
+}
+
 template <int LR, bool DBG, bool SPEC>
 __device__ __forceinline__ void slot_runx_exit(const DevProblem& P, const SlotRun& run, uint32_t* __restrict__ cur, uint32_t* score_out, const uint32_t w, uint32_t (&D)[1 << LR],
                                                const SlotxStamps& stamps) {
@@ -944,23 +1152,25 @@ __device__ __forceinline__ void slot_warm_done(uint32_t junk) { asm volatile("" 
 // The X runs of several tables in one launch (the counterpart of slot_group below for runs that take the X kernel; the group's other runs go out as
 // a slot_group launch of their own).  The entry is read TWICE: the prologue's and the loop's half before the loop, the exit's half -- exchange layout,
 // masks, the speculative seed's slot -- after it (scalar-cache hits), so the loop's scalar budget is the loop's alone.
-template <bool DBG = false>
+template <int LR = 2, bool DBG = false>
 __global__ __launch_bounds__(512, 4) void slot_groupx(SlotGroupArgs args) {
 	const SlotBatchEntry* ep = args.entry[blockIdx.y];
-	uint32_t D[4];
+	uint32_t D[1 << LR];
 	SlotxStamps stamps;
 	{
 		const SlotBatchEntry e = slot_scalar_copy(ep);
 		if (blockIdx.x >= (1u << (e.run.g - e.run.half)) || threadIdx.x >= e.run.threads) return;
 		DevProblem P = slot_entry_problem(e, false);
 		if (DBG) P.dbg_flags = e.pad2;
-		slot_runx_core<2, 0, DBG>(P, e.run, e.prev, blockIdx.x, D, stamps, (e.pad2 & 0x10000u) ? nullptr : (const void*)(ep + 1));   // (pad2 bit 16: timing experiment, debug library)
+		const void* warm = (e.pad2 & 0x10000u) ? nullptr : (const void*)(ep + 1);   // (pad2 bit 16: timing experiment, debug library)
+		if constexpr (LR == 3) slot_runx8_core<DBG>(P, e.run, e.prev, blockIdx.x, D, stamps, warm);
+		else slot_runx_core<2, 0, DBG>(P, e.run, e.prev, blockIdx.x, D, stamps, warm);
 	}
 	asm volatile("" : "+s"(ep));   // (opaque: what follows is fetched again, not kept in registers through the loop)
 	const SlotBatchEntry e = slot_scalar_copy(ep);
 	DevProblem P = slot_entry_problem(e, false);
-	if (e.run.spec_id) slot_runx_exit<2, DBG, true>(P, e.run, e.cur, e.score_out, blockIdx.x, D, stamps);
-	else slot_runx_exit<2, DBG, false>(P, e.run, e.cur, e.score_out, blockIdx.x, D, stamps);
+	if (e.run.spec_id) slot_runx_exit<LR, DBG, true>(P, e.run, e.cur, e.score_out, blockIdx.x, D, stamps);
+	else slot_runx_exit<LR, DBG, false>(P, e.run, e.cur, e.score_out, blockIdx.x, D, stamps);
 }
 
 // One launch = the next run of SEVERAL TABLES (whamd_dptable_enqueue_many: independent tables advance in lockstep on one stream):
