@@ -58,6 +58,7 @@ WORKLOADS = {
     "blocks24": dict(variants=100000, coverage=20, blocks=24, in_flight=24, option=["shared_launches=1"]),       # BASELINE configs[4] on ONE GPU: all 24 blocks as one group of launches
     "config1_x24": dict(variants=50000, coverage=15, blocks=24, in_flight=24, option=["shared_launches=1"]),     # 24 tables at `whatshap phase`'s default coverage (24 chromosomes) on one GPU
     "config1_x48": dict(variants=50000, coverage=15, blocks=48, in_flight=48, option=["shared_launches=1"]),     # twice that: 384 workgroups per launch (does the launch time hold?)
+    "config1_x96": dict(variants=50000, coverage=15, blocks=96, in_flight=96, option=["shared_launches=1"]),     # a cohort's worth of chromosome x family tables: three workgroups per CU per launch
     "config3_distrust": dict(trio=True, distrust=True, variants=100000, coverage=15),   # configs[3]'s ReadSet, genotypes not trusted (16 allele assignments per value)
     "config3_x8": dict(trio=True, variants=100000, coverage=15, blocks=8, in_flight=8),  # eight trio tables (families / chromosomes) on one GPU
     "irregular": dict(irregular=True, variants=100000, coverage=20),               # Poisson starts, geometric lengths (mean 16), coverage capped
@@ -67,7 +68,7 @@ WORKLOADS = {
     "heuristic": dict(heuristic=True, variants=8000, coverage=30),                 # PedMecHeuristic, coverage beyond the exact DP
     "heuristic_x32": dict(heuristic=True, variants=8000, coverage=30, blocks=32),  # 32 PedMecHeuristic tables in ONE launch (one persistent workgroup each)
 }
-EXTRA_CONFIGS = ["config1", "config1_x24", "config1_x48", "config3", "config3_distrust", "config3_x8", "blocks3", "blocks24", "irregular", "quartet", "genotype", "genotype_trio", "heuristic", "heuristic_x32"]
+EXTRA_CONFIGS = ["config1", "config1_x24", "config1_x48", "config1_x96", "config3", "config3_distrust", "config3_x8", "blocks3", "blocks24", "irregular", "quartet", "genotype", "genotype_trio", "heuristic", "heuristic_x32"]
 
 
 def parse_args():
@@ -740,7 +741,7 @@ def dominant_kernel(args, grouped=False):
         return "column_step_fused"
     if args.trio or args.quartet:
         return "resident_segment_ped" if args.path == "resident" else ("pedslot_group" if grouped else "pedslot_run")
-    return "resident_segment" if args.path == "resident" else ("slot_group" if grouped else "slot_run")
+    return "resident_segment" if args.path == "resident" else ("slot_group" if grouped else "slot_run")   # (substring: also slot_groupx / slot_runx, the X kernels)
 
 
 def run_extra_configs(args):

@@ -169,6 +169,7 @@ whamd_status_t whamd_dptable_enqueue(whamd_dptable* t) {
 	whamd_status_t st = begin_enqueue(t);
 	if (st != WHAMD_OK) return st;
 	std::string msg;
+	t->device.set_side_by_side(false);   // (a table submitted by itself has the device to itself as far as the library knows: whamd_dptable_enqueue_many says otherwise)
 	st = t->device.enqueue(t->problem, t->solution, msg);
 	if (st != WHAMD_OK) return fail(st, msg);
 	t->in_flight = true;
@@ -228,6 +229,7 @@ whamd_status_t whamd_dptable_enqueue_many(whamd_dptable* const* tables, size_t n
 		std::sort(rest.begin(), rest.end());
 	}
 	// round robin over the remaining tables, a few launches each: their streams fill up side by side
+	for (size_t i : rest) tables[i]->device.set_side_by_side(rest.size() > 1);
 	constexpr uint64_t SLICE = 16;
 	std::vector<uint8_t> done(n_tables, 1);
 	for (size_t i : rest) done[i] = 0;

@@ -57,6 +57,8 @@ public:
 	// The table will be solved together with many others (whamd_dptable_enqueue_many): a wide single-individual table then plans eight cells
 	// per thread and twelve local slots (half the wavefronts per table); next upload().
 	void set_shared_launches(bool v);
+	// the table's launches will run BESIDE other tables' on the same device (own streams, whamd_dptable_enqueue_many): kernels that leave room on a CU
+	void set_side_by_side(bool v);
 
 private:
 	whamd_status_t enqueue_some_unguarded(const Problem& p, Solution& s, uint64_t budget, bool& done, std::string& msg);

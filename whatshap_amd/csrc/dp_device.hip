@@ -490,6 +490,8 @@ struct DeviceTable::Impl {
 	BtJob* d_btjobs = nullptr;
 	uint32_t* d_job_scores = nullptr;
 	bool shared_hint = false;   // option shared_launches: the table will be solved together with many others (enqueue_many)
+	bool side_by_side = false;  // this solve's launches run beside other tables' on their own streams: X runs take the streamed variant (16 KB of LDS instead of ~90:
+	                            // three tables on three streams, 3.1 M columns/s with the LDS lines -- one workgroup per CU, the streams take turns -- 5 M without)
 	int max_lanes = 32;
 	size_t next_super = 0;  // cursor of the resumable enqueue
 	// Windowed solve (backtrace arena larger than what HBM can hold): the steps are cut into WINDOWS whose records fit the
@@ -603,6 +605,7 @@ void DeviceTable::set_slot_lr(int lr) { impl_->slot_lr = lr >= 3 ? 3 : (lr <= 1 
 
 void DeviceTable::set_arena_limit(uint64_t bytes) { impl_->arena_limit = bytes; }
 void DeviceTable::set_shared_launches(bool v) { impl_->shared_hint = v; }
+void DeviceTable::set_side_by_side(bool v) { impl_->side_by_side = v; }
 void DeviceTable::set_symmetry(int level) { impl_->symmetry = level < 0 ? 0 : (level > 2 ? 2 : level); }
 
 whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& msg) {
@@ -900,12 +903,21 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 			if (xrun) {
 				run.yflags |= 8u;
 				run.tab_kr = (uint32_t)slot_tab_words;
-				slot_tab_words += pad4(((uint64_t)run.ncols + SLOT_XPAD) << run.lr);
+				slot_tab_words += pad4((((uint64_t)run.ncols + SLOT_XPAD) << run.lr) + run.ncols + SLOT_XPAD);   // Kr words, then one control word per column
 				run.tab_par = (uint32_t)slot_tab_words;
 				slot_tab_words += pad4((uint64_t)run.threads + (1ull << (run.g - run.half)));
 			}
 		}
 		slot_tab_words += (uint64_t)SLOT_XCOLS * 64u;   // (an X run requests the lane parts of SLOT_XCOLS columns whatever its length)
+		if (getenv("WHAMD_DEBUG_TIMING")) {
+			size_t nx = 0, not_y = 0, not_lr = 0, long_run = 0, many_ends = 0;
+			for (const SlotRun& run : m.splan.runs) {
+				nx += (run.yflags & 8u) != 0;
+				not_y += !(run.yflags & 1u); not_lr += run.lr != 2u && run.lr != 3u; long_run += run.ncols > (uint32_t)SLOT_XCOLS; many_ends += run.n_ends > (uint32_t)SLOT_XENDS;
+			}
+			fprintf(stderr, "[whamd timing]   X runs: %zu of %zu (not Y form %zu, cells per thread %zu, more than %d columns %zu, more than %d ending reads %zu)\n", nx, m.splan.runs.size(), not_y,
+			        not_lr, SLOT_XCOLS, long_run, SLOT_XENDS, many_ends);
+		}
 		if (slot_tab_words >= 0xFFFFFFFFull) { msg = "slot-run tables exceed 32-bit offsets"; return WHAMD_ERR_UNSUPPORTED; }
 		HIP_TRY(up(&d_sruns, m.splan.runs.data(), m.splan.runs.size() * sizeof(SlotRun)));
 		ulap("slot blobs, control words, runs: allocations + copies");
@@ -1501,17 +1513,21 @@ void DeviceTable::Impl::launch_slot_run(const SlotBatchEntry& e, uint64_t& launc
 	const size_t lds = slot_run_lds_bytes(run.threads, run.lr, run.ncols);   // wave-slot exchange + hot lines + per-wave A + lane sums
 	const dim3 grid(1u << (run.g - run.half)), block(run.threads);
 	if ((run.yflags & 8u) && run.lr == 2u) {   // X run with four cells per thread: registers instead of LDS lines (LDS: the wave-slot exchange buffers + the threads' own operand lines)
-		const size_t lds_x = slotx_lds_bytes(run.threads, run.ncols <= 24u ? 24u : 32u);
+		const bool streamed = m.side_by_side || debug_env("WHAMD_XSTREAM");   // (no LDS lines: room for other tables' workgroups on the CU)
+		const size_t lds_x = streamed ? (size_t)2 * run.threads * 16 : slotx_lds_bytes(run.threads, (run.ncols + 7u) & ~7u);
 #define WHAMD_SLOTX_LAUNCH(XCV, DBGV, SPECV) hipLaunchKernelGGL((slot_runx<2, XCV, DBGV, SPECV>), grid, block, lds_x, m.run_stream, m.dp, run, e.prev, e.cur, e.score_out)
-#ifdef WHAMD_DEBUG_BUILD
-		if (debug_env("WHAMD_XSTREAM")) {   // A/B: the streamed variant (what shared launches use) for a table of its own
+		if (streamed) {
 			if (spec) WHAMD_SLOTX_LAUNCH(0, false, true); else WHAMD_SLOTX_LAUNCH(0, false, false);
-		} else if (m.dp.dbg != nullptr || m.dp.dbg_flags != 0) {
+		} else
+#ifdef WHAMD_DEBUG_BUILD
+		if (m.dp.dbg != nullptr || m.dp.dbg_flags != 0) {
 			if (run.ncols <= 24u) { if (spec) WHAMD_SLOTX_LAUNCH(24, true, true); else WHAMD_SLOTX_LAUNCH(24, true, false); }
 			else { if (spec) WHAMD_SLOTX_LAUNCH(32, true, true); else WHAMD_SLOTX_LAUNCH(32, true, false); }
 		} else
 #endif
-		if (run.ncols <= 24u) { if (spec) WHAMD_SLOTX_LAUNCH(24, false, true); else WHAMD_SLOTX_LAUNCH(24, false, false); }
+		if (run.ncols <= 8u) { if (spec) WHAMD_SLOTX_LAUNCH(8, false, true); else WHAMD_SLOTX_LAUNCH(8, false, false); }       // (the prologue forms the operands of XC columns:
+		else if (run.ncols <= 16u) { if (spec) WHAMD_SLOTX_LAUNCH(16, false, true); else WHAMD_SLOTX_LAUNCH(16, false, false); }   //  an irregular layout's runs are ~10 columns long)
+		else if (run.ncols <= 24u) { if (spec) WHAMD_SLOTX_LAUNCH(24, false, true); else WHAMD_SLOTX_LAUNCH(24, false, false); }
 		else { if (spec) WHAMD_SLOTX_LAUNCH(32, false, true); else WHAMD_SLOTX_LAUNCH(32, false, false); }
 #undef WHAMD_SLOTX_LAUNCH
 		launches += 1;

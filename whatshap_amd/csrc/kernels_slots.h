@@ -624,9 +624,11 @@ __device__ __forceinline__ void slot_runx_core(const DevProblem& P, const SlotRu
 	// ---- prologue: one batch of loads.  Wave-uniform data through the scalar cache: the control words and the Kr words of the first trip, the
 	// workgroup's half of the tie parities.
 	const uint32_t* __restrict__ kr_tab = tab + run.tab_kr;
-	const uint32_t* __restrict__ cw_tab = P.slot_ctrl + run.ctrl_off;
+	const uint32_t* __restrict__ cw_tab = kr_tab + ((ncols + (uint32_t)SLOT_XPAD) << LR);   // one control word per column, behind the Kr words (slot_tables)
+	typedef uint32_t slot_u32x4c __attribute__((ext_vector_type(4)));
+	typedef const __attribute__((address_space(4))) slot_u32x4c* slot_cptr4c;
 	slot_u32x16 krA = *(slot_cptr16)(unsigned long long)kr_tab, krB;
-	slot_u32x2 cwA = *(slot_cptr2)(unsigned long long)cw_tab, cwB;
+	slot_u32x4c cwA = *(slot_cptr4c)(unsigned long long)cw_tab, cwB;
 	const uint32_t par_w = *(const __attribute__((address_space(4))) uint32_t*)(unsigned long long)(tab + run.tab_par + threads + w);
 	// the entering cells first (they come from the other XCDs' stores: the longest latency of the prologue) ...
 	// Shared launches read their run descriptor from memory (SlotBatchEntry) BEFORE anything else can be requested: a miss all the way to HBM per launch.
@@ -713,14 +715,21 @@ __device__ __forceinline__ void slot_runx_core(const DevProblem& P, const SlotRu
 		D[2] = slot_y_sad_s(x, k2, D[2]);
 		D[3] = slot_y_sad_s(x, k3, D[3]);
 		if (DBG && P.dbg && w == 0 && tid == 0 && ci < 32u) P.dbg[(size_t)run.pad * 48 + 8 + ci] = __builtin_readcyclecounter() - t_loaded;
-		if (ctrl & 3u) {   // reads ending here
+		if (ctrl & 3u) {   // reads ending here: the first two are described in the control word, a third and later ones in the row (scalar loads, requested
+			              // before the second ending read is evaluated)
 			ending(ctrl);
-			if (ctrl & 2u) {   // several reads ending in one column are rare: the later ones are described in the row (scalar loads), same field layout once rearranged
+			if (ctrl & 2u) {
 				const unsigned long long row = (unsigned long long)(rows + ci);
-				const uint32_t n_end = (ctrl & 1u) ? *(const __attribute__((address_space(4))) uint32_t*)(row + 44) : 2u;   // (a count of 3 says "three or more")
-				for (uint32_t e = 1; e < n_end; ++e) {
-					const uint32_t info = *(const __attribute__((address_space(4))) uint32_t*)(row + 48 + 8 * e);   // slot | qmask << 8 | exchange buffer << 16
-					ending(((info & 31u) << 2) | (((info >> 8) & 15u) << 7) | (((info >> 16) & 1u) << 15));
+				uint32_t n_end = 2u, info = 0u;
+				if (ctrl & 1u) {   // (a count of 3 says "three or more")
+					n_end = *(const __attribute__((address_space(4))) uint32_t*)(row + 44);
+					info = *(const __attribute__((address_space(4))) uint32_t*)(row + 64);
+				}
+				ending(ctrl >> 16);
+				for (uint32_t e = 2; e < n_end; ++e) {
+					const uint32_t field = ((info & 31u) << 2) | (((info >> 8) & 15u) << 7) | (((info >> 16) & 1u) << 15);   // info: slot | qmask << 8 | exchange buffer << 16
+					if (e + 1u < n_end) info = *(const __attribute__((address_space(4))) uint32_t*)(row + 56 + 8 * e);     // (the next one's, a read ahead)
+					ending(field);
 				}
 			}
 		}
@@ -739,31 +748,31 @@ __device__ __forceinline__ void slot_runx_core(const DevProblem& P, const SlotRu
 		for (uint32_t pairs = (ncols + 7u) >> 3; pairs; --pairs) {
 			asm volatile("" ::"s"(krA[0]), "s"(cwA[0]), "s"(gA[0]), "s"(wA[0]));
 			krB = *(slot_cptr16)(unsigned long long)(kr_tab + 16u);
-			cwB = *(slot_cptr2)(unsigned long long)(cw_tab + 2u);
+			cwB = *(slot_cptr4c)(unsigned long long)(cw_tab + 4u);
 			gB = *(slot_cptr4)(unsigned long long)(g_row + 4u);
 			wB = *(slot_cptr4)(unsigned long long)(w_row + 4u);
 #pragma unroll
 			for (int k = 0; k < 4; ++k) slB[k] = sl_src[64 * (4 + k)];
-			column(slA[0] + (gA[0] + wA[0]), krA[0], krA[1], krA[2], krA[3], cwA[0] & 0xFFFFu);
-			column(slA[1] + (gA[1] + wA[1]), krA[4], krA[5], krA[6], krA[7], cwA[0] >> 16);
-			column(slA[2] + (gA[2] + wA[2]), krA[8], krA[9], krA[10], krA[11], cwA[1] & 0xFFFFu);
-			column(slA[3] + (gA[3] + wA[3]), krA[12], krA[13], krA[14], krA[15], cwA[1] >> 16);
+			column(slA[0] + (gA[0] + wA[0]), krA[0], krA[1], krA[2], krA[3], cwA[0]);
+			column(slA[1] + (gA[1] + wA[1]), krA[4], krA[5], krA[6], krA[7], cwA[1]);
+			column(slA[2] + (gA[2] + wA[2]), krA[8], krA[9], krA[10], krA[11], cwA[2]);
+			column(slA[3] + (gA[3] + wA[3]), krA[12], krA[13], krA[14], krA[15], cwA[3]);
 			asm volatile("" ::"s"(krB[0]), "s"(cwB[0]), "s"(gB[0]), "s"(wB[0]));
 			kr_tab += 32u;
-			cw_tab += 4u;
+			cw_tab += 8u;
 			g_row += 8u;
 			w_row += 8u;
 			sl_src += 512u;
 			krA = *(slot_cptr16)(unsigned long long)kr_tab;
-			cwA = *(slot_cptr2)(unsigned long long)cw_tab;
+			cwA = *(slot_cptr4c)(unsigned long long)cw_tab;
 			gA = *(slot_cptr4)(unsigned long long)g_row;
 			wA = *(slot_cptr4)(unsigned long long)w_row;
 #pragma unroll
 			for (int k = 0; k < 4; ++k) slA[k] = sl_src[64 * k];
-			column(slB[0] + (gB[0] + wB[0]), krB[0], krB[1], krB[2], krB[3], cwB[0] & 0xFFFFu);
-			column(slB[1] + (gB[1] + wB[1]), krB[4], krB[5], krB[6], krB[7], cwB[0] >> 16);
-			column(slB[2] + (gB[2] + wB[2]), krB[8], krB[9], krB[10], krB[11], cwB[1] & 0xFFFFu);
-			column(slB[3] + (gB[3] + wB[3]), krB[12], krB[13], krB[14], krB[15], cwB[1] >> 16);
+			column(slB[0] + (gB[0] + wB[0]), krB[0], krB[1], krB[2], krB[3], cwB[0]);
+			column(slB[1] + (gB[1] + wB[1]), krB[4], krB[5], krB[6], krB[7], cwB[1]);
+			column(slB[2] + (gB[2] + wB[2]), krB[8], krB[9], krB[10], krB[11], cwB[2]);
+			column(slB[3] + (gB[3] + wB[3]), krB[12], krB[13], krB[14], krB[15], cwB[3]);
 		}
 	} else {
 	const uint32_t xstride = threads * 16u;
@@ -773,23 +782,23 @@ __device__ __forceinline__ void slot_runx_core(const DevProblem& P, const SlotRu
 	for (uint32_t pairs = (ncols + 7u) >> 3; pairs; --pairs) {
 		asm volatile("" ::"s"(krA[0]), "s"(cwA[0]), "v"(xA.x));
 		krB = *(slot_cptr16)(unsigned long long)(kr_tab + 16u);
-		cwB = *(slot_cptr2)(unsigned long long)(cw_tab + 2u);
+		cwB = *(slot_cptr4c)(unsigned long long)(cw_tab + 4u);
 		xB = *(lds_line)(size_t)(xaddr + xstride);
-		column(xA.x, krA[0], krA[1], krA[2], krA[3], cwA[0] & 0xFFFFu);
-		column(xA.y, krA[4], krA[5], krA[6], krA[7], cwA[0] >> 16);
-		column(xA.z, krA[8], krA[9], krA[10], krA[11], cwA[1] & 0xFFFFu);
-		column(xA.w, krA[12], krA[13], krA[14], krA[15], cwA[1] >> 16);
+		column(xA.x, krA[0], krA[1], krA[2], krA[3], cwA[0]);
+		column(xA.y, krA[4], krA[5], krA[6], krA[7], cwA[1]);
+		column(xA.z, krA[8], krA[9], krA[10], krA[11], cwA[2]);
+		column(xA.w, krA[12], krA[13], krA[14], krA[15], cwA[3]);
 		asm volatile("" ::"s"(krB[0]), "s"(cwB[0]), "v"(xB.x));
 		kr_tab += 32u;
-		cw_tab += 4u;
+		cw_tab += 8u;
 		xaddr += 2u * xstride;
 		krA = *(slot_cptr16)(unsigned long long)kr_tab;
-		cwA = *(slot_cptr2)(unsigned long long)cw_tab;
+		cwA = *(slot_cptr4c)(unsigned long long)cw_tab;
 		xA = *(lds_line)(size_t)xaddr;
-		column(xB.x, krB[0], krB[1], krB[2], krB[3], cwB[0] & 0xFFFFu);
-		column(xB.y, krB[4], krB[5], krB[6], krB[7], cwB[0] >> 16);
-		column(xB.z, krB[8], krB[9], krB[10], krB[11], cwB[1] & 0xFFFFu);
-		column(xB.w, krB[12], krB[13], krB[14], krB[15], cwB[1] >> 16);
+		column(xB.x, krB[0], krB[1], krB[2], krB[3], cwB[0]);
+		column(xB.y, krB[4], krB[5], krB[6], krB[7], cwB[1]);
+		column(xB.z, krB[8], krB[9], krB[10], krB[11], cwB[2]);
+		column(xB.w, krB[12], krB[13], krB[14], krB[15], cwB[3]);
 	}
 	}
 	stamps.t_start = t_start; stamps.t_issued = t_issued; stamps.t_loaded = t_loaded;
@@ -907,10 +916,10 @@ __device__ __forceinline__ void slot_runx8_core(const DevProblem& P, const SlotR
 	const uint32_t ncp = (ncols + 7u) & ~7u;
 	const uint32_t* __restrict__ tab = P.slot_tab;
 	const uint32_t* __restrict__ kr_tab = tab + run.tab_kr;               // [column][8]: sixteen words = two columns
-	const uint32_t* __restrict__ cw_tab = P.slot_ctrl + run.ctrl_off;     // one word = two columns
+	const uint32_t* __restrict__ cw_tab = kr_tab + ((ncols + (uint32_t)SLOT_XPAD) << LR);   // one control word per column, behind the Kr words (slot_tables)
 	typedef const __attribute__((address_space(4))) uint32_t* slot_cptr1;
 	slot_u32x16 krA = *(slot_cptr16)(unsigned long long)kr_tab, krB;
-	uint32_t cwA = *(slot_cptr1)(unsigned long long)cw_tab, cwB;
+	slot_u32x2 cwA = *(slot_cptr2)(unsigned long long)cw_tab, cwB;
 	const uint32_t par_w = *(slot_cptr1)(unsigned long long)(tab + run.tab_par + threads + w);
 	uint32_t warm_junk = 0;
 	if (warm) {   // (the next step's entry into this XCD's L2: see slot_runx_core)
@@ -960,14 +969,20 @@ __device__ __forceinline__ void slot_runx8_core(const DevProblem& P, const SlotR
 #pragma unroll
 		for (int r = 0; r < R; ++r) D[r] = slot_y_sad_s(x, kr[half * 8 + r], D[r]);
 		if (DBG && P.dbg && w == 0 && tid == 0 && ci < 32u) P.dbg[(size_t)run.pad * 48 + 8 + ci] = __builtin_readcyclecounter() - t_loaded;
-		if (ctrl & 3u) {
+		if (ctrl & 3u) {   // (the first two ending reads in the control word, later ones in the row: as in slot_runx_core)
 			ending(ctrl);
 			if (ctrl & 2u) {
 				const unsigned long long row = (unsigned long long)(rows + ci);
-				const uint32_t n_end = (ctrl & 1u) ? *(slot_cptr1)(row + 44) : 2u;
-				for (uint32_t e = 1; e < n_end; ++e) {
-					const uint32_t info = *(slot_cptr1)(row + 48 + 8 * e);   // slot | qmask << 8 | exchange buffer << 16
-					ending(((info & 31u) << 2) | (((info >> 8) & 255u) << 7) | (((info >> 16) & 1u) << 15));
+				uint32_t n_end = 2u, info = 0u;
+				if (ctrl & 1u) {
+					n_end = *(slot_cptr1)(row + 44);
+					info = *(slot_cptr1)(row + 64);
+				}
+				ending(ctrl >> 16);
+				for (uint32_t e = 2; e < n_end; ++e) {
+					const uint32_t field = ((info & 31u) << 2) | (((info >> 8) & 255u) << 7) | (((info >> 16) & 1u) << 15);
+					if (e + 1u < n_end) info = *(slot_cptr1)(row + 56 + 8 * e);
+					ending(field);
 				}
 			}
 		}
@@ -975,29 +990,29 @@ __device__ __forceinline__ void slot_runx8_core(const DevProblem& P, const SlotR
 	};
 	// two trips (of two columns) per loop iteration; the columns behind the run's last are harmless (zeros), as in slot_runx_core
 	for (uint32_t quads = (ncols + 3u) >> 2; quads; --quads) {
-		asm volatile("" ::"s"(krA[0]), "s"(cwA), "s"(gA[0]), "s"(wA[0]));
+		asm volatile("" ::"s"(krA[0]), "s"(cwA[0]), "s"(gA[0]), "s"(wA[0]));
 		krB = *(slot_cptr16)(unsigned long long)(kr_tab + 16u);
-		cwB = *(slot_cptr1)(unsigned long long)(cw_tab + 1u);
+		cwB = *(slot_cptr2)(unsigned long long)(cw_tab + 2u);
 		gB = *(slot_cptr2)(unsigned long long)(g_row + 2u);
 		wB = *(slot_cptr2)(unsigned long long)(w_row + 2u);
 		slB[0] = sl_src[128];
 		slB[1] = sl_src[192];
-		column(slA[0] + (gA[0] + wA[0]), krA, 0, cwA & 0xFFFFu);
-		column(slA[1] + (gA[1] + wA[1]), krA, 1, cwA >> 16);
-		asm volatile("" ::"s"(krB[0]), "s"(cwB), "s"(gB[0]), "s"(wB[0]));
+		column(slA[0] + (gA[0] + wA[0]), krA, 0, cwA[0]);
+		column(slA[1] + (gA[1] + wA[1]), krA, 1, cwA[1]);
+		asm volatile("" ::"s"(krB[0]), "s"(cwB[0]), "s"(gB[0]), "s"(wB[0]));
 		kr_tab += 32u;
-		cw_tab += 2u;
+		cw_tab += 4u;
 		g_row += 4u;
 		w_row += 4u;
 		sl_src += 256u;
 		krA = *(slot_cptr16)(unsigned long long)kr_tab;
-		cwA = *(slot_cptr1)(unsigned long long)cw_tab;
+		cwA = *(slot_cptr2)(unsigned long long)cw_tab;
 		gA = *(slot_cptr2)(unsigned long long)g_row;
 		wA = *(slot_cptr2)(unsigned long long)w_row;
 		slA[0] = sl_src[0];
 		slA[1] = sl_src[64];
-		column(slB[0] + (gB[0] + wB[0]), krB, 0, cwB & 0xFFFFu);
-		column(slB[1] + (gB[1] + wB[1]), krB, 1, cwB >> 16);
+		column(slB[0] + (gB[0] + wB[0]), krB, 0, cwB[0]);
+		column(slB[1] + (gB[1] + wB[1]), krB, 1, cwB[1]);
 	}
 	stamps.t_start = t_start; stamps.t_issued = t_issued; stamps.t_loaded = t_loaded;
 	stamps.t_loop = (DBG && P.dbg) ? __builtin_readcyclecounter() + (D[0] & 0u) : 0ull;
@@ -1035,7 +1050,10 @@ __global__ __launch_bounds__(256) void slot_tables(DevProblem P, const SlotRun* 
 	// X runs (slot_runx_body): the Kr words of the run's columns side by side, and the tie parities -- bit e of a thread's word = parity of its local
 	// index under the mask of the run's e-th ending read (forward order: by column, then by position in the row), the same for a workgroup's grid bits
 	const bool xrun = (run.yflags & 8u) != 0u;
-	const uint32_t R = 1u << lr, n_kr = xrun ? (ncols + (uint32_t)SLOT_XPAD) * R : 0u, n_par = xrun ? run.threads + nwg : 0u;
+	// ... and behind the Kr words one CONTROL WORD per column: the fields of its first two ending reads (n_end | slot << 2 | qmask << 7 | exchange buffer << 15,
+	// the second one in the high half) -- an irregular layout ends two reads in every third column, and fetching the second one's description from the row
+	// cost a scalar-cache miss each time
+	const uint32_t R = 1u << lr, n_krw = xrun ? (ncols + (uint32_t)SLOT_XPAD) * R : 0u, n_kr = xrun ? n_krw + ncols + (uint32_t)SLOT_XPAD : 0u, n_par = xrun ? run.threads + nwg : 0u;
 	const SlotRow* __restrict__ rows = P.slot_rows + run.row_off;
 	const uint32_t ysh = run.yflags & 1u, ybias = ysh ? SLOT_YBIAS : 0u;   // Y form: X0 = 2 A + bias = (2 G + bias) + 2 W + 2 SL
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_g + n_w + n_sl + n_kr + n_par; i += gridDim.x * blockDim.x) {
@@ -1049,6 +1067,16 @@ __global__ __launch_bounds__(256) void slot_tables(DevProblem P, const SlotRun* 
 				for (uint32_t k = 0; k < n_end; ++k, ++e) bits |= ((uint32_t)__popc(index & keep & rows[c].end[k].M) & 1u) << (e & 31u);
 			}
 			tab[run.tab_par + q] = bits;
+		} else if (i >= n_g + n_w + n_sl + n_krw) {
+			const uint32_t c = i - (n_g + n_w + n_sl + n_krw);
+			uint32_t word = 0;
+			if (c < ncols) {
+				const SlotRow& row = rows[c];
+				auto field = [](uint32_t info) { return ((info & 31u) << 2) | (((info >> 8) & 255u) << 7) | (((info >> 16) & 1u) << 15); };
+				if (row.n_end) word = (row.n_end < 3u ? row.n_end : 3u) | field(row.end[0].info);
+				if (row.n_end > 1u) word |= field(row.end[1].info) << 16;
+			}
+			tab[run.tab_kr + n_krw + c] = word;
 		} else if (i >= n_g + n_w + n_sl) {
 			const uint32_t q = i - (n_g + n_w + n_sl), c = q / R, r = q % R;
 			tab[run.tab_kr + q] = c < ncols ? reinterpret_cast<const uint32_t*>(rows + c)[r] : 0u;   // (a Y-form row holds Kr[0 .. R) in its first words)
