@@ -66,7 +66,7 @@ def test_the_x_run_column_trip_has_no_wait_and_no_memory_operation_on_the_plain_
     column is four v_sad_u32 with a scalar second operand, a scalar test and a branch -- nothing else, no wait, no LDS read, no address arithmetic; the
     waits of a trip stand at its head (before the next trip's requests go out) and inside the hand-written ending block."""
     text = _device_asm()
-    for frag, spills_ok in (("9slot_runxILi2ELi24ELb0ELb0E", 0), ("9slot_runxILi2ELi32ELb0ELb0E", 0), ("11slot_groupxILb0E", 0)):
+    for frag, spills_ok in (("9slot_runxILi2ELi24ELb0ELb0E", 0), ("9slot_runxILi2ELi32ELb0ELb0E", 0), ("11slot_groupxILi2ELb0E", 0)):
         body, meta = _kernel(text, frag)
         assert meta["vgpr_count"] <= 64 and meta["private_segment_fixed_size"] == 0 and meta["vgpr_spill_count"] == 0, (frag, meta)
         assert meta["sgpr_spill_count"] <= spills_ok, (frag, meta)   # (a spilled scalar is a v_readlane per use: round 5's first group kernel had 500 in its loop)
@@ -96,3 +96,7 @@ def test_the_x_run_column_trip_has_no_wait_and_no_memory_operation_on_the_plain_
         # and the rare second ending read of a column; none of them is a vector-memory wait
         assert not any(re.search(r"vmcnt\(0\)", ln) for ln in loop) or frag.startswith("11"), (frag, "a full vector-memory wait inside the column loop")
         assert sum(1 for ln in loop if ln.startswith("v_readfirstlane")) == 0, (frag, "VALU -> SGPR copies inside the column loop")
+    # eight cells per thread (wide tables that share their launches): the same budget of registers -- four workgroups per CU
+    body, meta = _kernel(text, "11slot_groupxILi3ELb0E")
+    assert meta["vgpr_count"] <= 64 and meta["private_segment_fixed_size"] == 0 and meta["vgpr_spill_count"] == 0 and meta["sgpr_spill_count"] == 0, meta
+    assert len(re.findall(r"v_sad_u32 v\d+, v\d+, s\d+, v\d+", body)) == 32      # two trips of two columns, eight cells each
