@@ -699,10 +699,10 @@ def compact_line(out, detail_file=None):
             r = c.get("roofline") or {}
             rec = {"value": _num(c.get("value")), "ms": _num(c.get("ms_per_step")), "frac": _num(r.get("frac"), 3), "active": _num(r.get("valu_active_frac"), 3),
                    "us": _num(r.get("avg_launch_us"), 3), "cpu": _num((c.get("cpu_baseline") or {}).get("value"), 3), "ident": c.get("identical_to_reference"),
-                   "e2e": _num((c.get("end_to_end") or {}).get("value"))}
+                   "e2e": _num((c.get("end_to_end") or {}).get("value")), "host8": _num((c.get("create_rate") or {}).get("host_over_8_devices"), 3)}
             short[c["name"]] = {k: v for k, v in rec.items() if v is not None}
         line["configs"] = short
-        line["configs_keys"] = "value columns/s; ms per step; frac VALU issue; active VALU busy; us per launch of the dominant kernel; cpu reference columns/s on 1 thread; ident == reference; e2e columns/s from host arrays"
+        line["configs_keys"] = "value columns/s; ms per step; frac VALU issue; active VALU busy; us per launch of the dominant kernel; cpu reference columns/s on 1 thread; ident == reference; e2e columns/s from host arrays; host8 fresh tables/s of this host / (8 x one device's tables/s)"
     if detail_file:
         line["detail"] = detail_file
     text = json.dumps(line, separators=(",", ":"))
@@ -785,6 +785,8 @@ def run_extra_configs(args):
             "roofline": {k: roof.get(k) for k in ("bound", "kernel", "frac", "valu_active_frac", "work_bound_frac", "avg_launch_us", "peak", "unit", "pmc_note")},
             "wall_s": time.perf_counter() - t0,
         }
+        if "create_rate" in full:
+            entry["create_rate"] = full["create_rate"]
         if "cpu_baseline" in full:
             entry["cpu_baseline"] = {k: full["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind", "sample")}
             entry["speedup_vs_cpu_baseline_device_only"] = full["value"] / full["cpu_baseline"]["value"]
@@ -1059,6 +1061,23 @@ def main():
                                  "what": f"{len(problems)} fresh tables from host arrays through blocks.solve_blocks: create (flatten + plan + upload) of the next window on "
                                          f"`create_threads` host workers (`host_threads_per_create` threads each) under the device solve of the current one, enqueue_many / wait_many "
                                          f"per window, 3 getters per table; best of the window sizes and host shapes in `tried`"}
+            # ---- how many fresh tables per second this host can hand to its devices (one node's host feeds eight GPUs): creates only,
+            # `create_threads` workers x `host_threads_per_create`, against the rate at which ONE device solves such tables
+            from concurrent.futures import ThreadPoolExecutor
+
+            workers, per_create = best[2], best[3]
+            opts = dict(option_dict(args), host_threads=str(per_create))
+            with ThreadPoolExecutor(max_workers=workers) as pool:
+                tc0 = time.perf_counter()
+                made = list(pool.map(lambda pr: _native.NativeTable(pr, device=device, path=None if args.path == "auto" else args.path, solve=False, options=opts), problems))
+                create_wall = time.perf_counter() - tc0
+            for t in made:
+                t.close()
+            device_tables_per_s = len(problems) * args.steps / elapsed
+            out["create_rate"] = {"tables_per_s": len(problems) / create_wall, "device_tables_per_s": device_tables_per_s, "host_over_8_devices": (len(problems) / create_wall) / (8.0 * device_tables_per_s),
+                                  "create_threads": workers, "host_threads_per_create": per_create, "host_nproc": os.cpu_count(),
+                                  "what": f"{len(problems)} whamd_dptable_create calls (flatten + plan + upload) on {workers} workers x {per_create} threads, no solve; next to the tables per second one "
+                                          f"device solves in the timed region: below 1.0 an 8-GPU node is bound by its host"}
         # ---- counters of the dominant kernel
         pmc, pmc_note = None, "skipped"
         want_pmc = args.pmc == "on" or (args.pmc == "auto" and world == 1 and not column_path)

@@ -186,3 +186,37 @@ def test_shared_launches_layout_eight_cells_per_thread_vs_oracle(monkeypatch):
         assert table_solution(t) == want[0], (extra, first_difference(want[0], table_solution(t)))
         t.close()
 
+
+
+def test_96_tables_in_one_group_vs_single_solves_and_the_oracle():
+    """a cohort's worth of tables per launch.  96 tables (more than three workgroups per CU in a launch, the X kernel's streamed variant
+    slot_groupx for the single individuals, slot_group for what it does not take, pedslot_group for the trios): every one equals its solve alone; ten of
+    them -- each kind, each layout -- equal the oracle."""
+    cases = []
+    for i in range(72):
+        cov, n = (15, 1300) if i % 3 == 0 else ((14, 900) if i % 3 == 1 else (12, 500))
+        kind = i % 6
+        if kind == 4:
+            cases.append(("irregular", irregular_block(n, cov, seed=300 + i)))
+        elif kind == 5:
+            cases.append(("ties", two_valued(synthetic_block(n_variants=n, coverage=cov, seed=300 + i), 400 + i)))
+        else:
+            cases.append(("single", synthetic_block(n_variants=n + 7 * i, coverage=cov, seed=300 + i)))
+    for i in range(24):
+        cases.append(("trio", synthetic_block(n_variants=400 + 20 * i, coverage=9 + i % 4, seed=500 + i, trio=True)))
+    assert len(cases) == 96
+    tables = [_native.NativeTable(p, solve=False, options={"shared_launches": "1"}) for _, p in cases]
+    _native.enqueue_many(tables)
+    _native.wait_many(tables)
+    assert max(t.stats()["group_tables"] for t in tables) >= 72
+    batched = [table_solution(t) for t in tables]
+    for t in tables:
+        t.close()
+    for k, (kind, p) in enumerate(cases):
+        alone = _native.NativeTable(p)
+        mine = table_solution(alone)
+        alone.close()
+        assert batched[k] == mine, (k, kind, first_difference(batched[k], mine))
+    for k in (0, 1, 2, 4, 5, 10, 11, 40, 72, 95):
+        want = table_solution(oracle.OracleTable(cases[k][1]))
+        assert batched[k] == want, (k, cases[k][0], first_difference(batched[k], want))
