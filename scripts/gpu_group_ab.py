@@ -9,13 +9,16 @@ from whatshap_amd.synthetic import synthetic_block
 nt, cov, n = (int(sys.argv[i]) if len(sys.argv) > i else d for i, d in ((1, 24), (2, 15), (3, 20000)))
 problems = [synthetic_block(n, cov, seed=100 + i) for i in range(nt)]
 want = None
-for name, env in (("lds runs", "1"), ("x runs", None), ("x no warm", "w"), ("lds runs", "1"), ("x runs", None), ("x no warm", "w")):
+for name, env in (("lds runs", "1"), ("x runs", None), ("x by wg", "g"), ("lds runs", "1"), ("x runs", None), ("x by wg", "g")):
     os.environ.pop("WHAMD_NO_XRUN", None)
     os.environ.pop("WHAMD_NO_WARM", None)
     if env == "1":
         os.environ["WHAMD_NO_XRUN"] = env
+    os.environ.pop("WHAMD_GROUP_BY_WORKGROUP", None)
     if env == "w":
         os.environ["WHAMD_NO_WARM"] = "1"
+    if env == "g":
+        os.environ["WHAMD_GROUP_BY_WORKGROUP"] = "1"
     tables = [_native.NativeTable(p, solve=False, options={"shared_launches": "1"}) for p in problems]
     best = None
     walls = []

@@ -4,12 +4,13 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 struct Big { unsigned w[120]; };
-template <bool READ, bool WRITE, bool REC, bool DEP = false>
+template <bool READ, bool WRITE, bool REC, bool DEP = false, bool SAMEXCD = false>
 __global__ __launch_bounds__(512) void k(Big big, const uint4* __restrict__ in, uint4* __restrict__ out, unsigned char* __restrict__ rec, unsigned iters) {
 	extern __shared__ unsigned sm[];
 	const unsigned gid = blockIdx.x * 512u + threadIdx.x;
 	uint4 v = make_uint4(gid, big.w[7], big.w[100], 3u);
-	if (READ) v = in[((blockIdx.x * 37u + 11u) & 255u) * 512u + threadIdx.x];   // another workgroup's 8 KB block (contiguous, like a run's entering cells): written by the previous launch
+	if (READ) v = in[(SAMEXCD ? ((blockIdx.x + 40u) & 255u) : ((blockIdx.x * 37u + 11u) & 255u)) * 512u + threadIdx.x];   // (SAMEXCD: a block written by a workgroup of the SAME XCD: workgroup b runs on XCD b mod 8)
+   // another workgroup's 8 KB block (contiguous, like a run's entering cells): written by the previous launch
 	unsigned a = DEP ? v.x : gid, b = big.w[3] | 5u;   // (DEP: the arithmetic starts from what was read -- the latency is exposed)
 	for (unsigned i = 0; i < iters; ++i) {
 #pragma unroll
@@ -37,10 +38,11 @@ int main() {
 	(void)hipFuncSetAttribute((const void*)k<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 	(void)hipFuncSetAttribute((const void*)k<true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 	(void)hipFuncSetAttribute((const void*)k<true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+	(void)hipFuncSetAttribute((const void*)k<true, true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 	Big big{};
 	const int N = 2000;
-	const char* names[8] = {"compute only, no LDS", "compute only, 90 KB LDS", "+ read", "+ write", "+ read + write", "+ read + write + records", "+ read (needed at once) + write + records", "+ read (needed at once), nothing written"};
-	for (int variant = (alloc ? 4 : 0); variant < 8; ++variant) {
+	const char* names[9] = {"compute only, no LDS", "compute only, 90 KB LDS", "+ read", "+ write", "+ read + write", "+ read + write + records", "+ read (needed at once) + write + records", "+ read (needed at once), nothing written", "+ read (needed at once, written on the SAME XCD) + write + records"};
+	for (int variant = (alloc ? 4 : 0); variant < 9; ++variant) {
 		const size_t lds = variant == 0 ? 0 : 90 * 1024;
 		float ms = 0, per[2] = {0, 0};
 		for (int rep = 0; rep < 4; ++rep) {
@@ -55,6 +57,7 @@ int main() {
 				if (variant == 5) hipLaunchKernelGGL((k<true, true, true>), dim3(256), dim3(512), lds, s, big, in, out, rec, iters);
 				if (variant == 6) hipLaunchKernelGGL((k<true, true, true, true>), dim3(256), dim3(512), lds, s, big, in, out, rec, iters);
 				if (variant == 7) hipLaunchKernelGGL((k<true, false, false, true>), dim3(256), dim3(512), lds, s, big, in, out, rec, iters);
+				if (variant == 8) hipLaunchKernelGGL((k<true, true, true, true, true>), dim3(256), dim3(512), lds, s, big, in, out, rec, iters);
 			}
 			(void)hipEventRecord(e1, s);
 			(void)hipStreamSynchronize(s);

@@ -286,28 +286,27 @@ whamd_status_t whamd_dptable_wait_many(whamd_dptable* const* tables, size_t n_ta
 		std::sort(seen.begin(), seen.end());
 		if (std::adjacent_find(seen.begin(), seen.end()) != seen.end()) return fail(WHAMD_ERR_INVALID, "a table appears twice in the list");
 	}
-	// the device side of every table first (stream by stream: paths and scores arrive in pinned buffers) ...
+	// Every table's device side (its stream drained: path and scores have arrived in the pinned buffer) and, right behind it, its host side (superreads,
+	// partitioning: get_super_reads / get_optimal_partitioning of the reference) -- on several host threads, a few tables each.  (Round 4 waited for the
+	// tables one after the other on the calling thread and only then finished them in parallel: 96 tables spent 30 ms in that first loop.)
 	whamd_status_t first = WHAMD_OK;
 	std::string first_msg;
-	std::vector<uint8_t> ok(n_tables, 0);
-	for (size_t i = 0; i < n_tables; ++i) {
-		whamd_dptable* t = tables[i];
-		t->in_flight = false;
-		std::string msg;
-		const whamd_status_t st = t->device.wait(t->problem, t->solution, t->stats, msg);
-		if (st != WHAMD_OK) { if (first == WHAMD_OK) { first = st; first_msg = msg; } continue; }
-		ok[i] = 1;
-	}
-	// ... then the host side (superreads, partitioning: get_super_reads / get_optimal_partitioning of the reference) of all of them at once
 	std::vector<whamd_status_t> status(n_tables, WHAMD_OK);
 	std::vector<std::string> messages(n_tables);
-	parallel_ranges(n_tables, host_threads(n_tables, 1), [&](uint64_t i0, uint64_t i1, uint32_t) {
+	for (size_t i = 0; i < n_tables; ++i) tables[i]->in_flight = false;
+	const uint32_t outer = host_threads(n_tables, 1);
+	const uint32_t inner = std::max(1u, host_threads(1u << 30, 1) / outer);   // (a table's own finish splits its columns over threads: not 32 x 7 of them at once)
+	parallel_ranges(n_tables, outer, [&](uint64_t i0, uint64_t i1, uint32_t) {
+		struct Budget { uint32_t saved = whamd::host_threads_override(); ~Budget() { whamd::host_threads_override() = saved; } } budget;
+		whamd::host_threads_override() = inner;
 		for (uint64_t i = i0; i < i1; ++i) {
-			if (!ok[i]) continue;
+			whamd_dptable* t = tables[i];
+			status[i] = t->device.wait(t->problem, t->solution, t->stats, messages[i]);
+			if (status[i] != WHAMD_OK) continue;
 			const double t0 = now_ms();
-			status[i] = finish_solution(tables[i]->problem, tables[i]->solution, messages[i]);
-			tables[i]->stats.host_finish_ms = now_ms() - t0;
-			tables[i]->solved = status[i] == WHAMD_OK;
+			status[i] = finish_solution(t->problem, t->solution, messages[i]);
+			t->stats.host_finish_ms = now_ms() - t0;
+			t->solved = status[i] == WHAMD_OK;
 		}
 	});
 	for (size_t i = 0; i < n_tables && first == WHAMD_OK; ++i)

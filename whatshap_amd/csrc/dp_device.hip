@@ -426,7 +426,7 @@ struct DeviceTable::Impl {
 	uint32_t max_grid_x = 1;    // widest launch of the schedule, in workgroups
 	bool enqueue_open = false;  // resumable enqueue (enqueue_some)
 	size_t h_pinned_bytes = 0;
-	uint32_t* h_pinned = nullptr;  // [2 n + 1 + jobs]: path index, path transmission, score of the final job, scores of the others
+	uint32_t* h_pinned = nullptr;  // [2 n + jobs + 3]: path index, path transmission, score of the final job, scores of the others, the chunked backtrace's three counters
 	// A job is a sequence of forward steps with its own backtrace.  Job 0 ("final") is the last connected component (it
 	// ends with the table's last column, whose optimum comes from the key scratch); every other job is one earlier
 	// connected component: it starts from cost 0, its last column projects onto a single entry -- that value is added on
@@ -1644,6 +1644,8 @@ whamd_status_t DeviceTable::Impl::submit_tail(const Problem& p, std::string& msg
 	HIP_TRY(hipMemcpyAsync(m.h_pinned + 2 * (size_t)n, m.d_score, 4, hipMemcpyDeviceToHost, m.stream));
 	if (m.jobs.size() > 1)
 		HIP_TRY(hipMemcpyAsync(m.h_pinned + 2 * (size_t)n + 1, m.d_job_scores + 1, (m.jobs.size() - 1) * 4, hipMemcpyDeviceToHost, m.stream));
+	// (the chunked backtrace's counters travel with the path: a synchronous 12-byte copy per table in wait() was a device round trip each -- 96 tables, 96 of them)
+	if (m.use_chunks) HIP_TRY(hipMemcpyAsync(m.h_pinned + 2 * (size_t)n + m.jobs.size(), m.d_bt_counters, 12, hipMemcpyDeviceToHost, m.stream));
 	HIP_TRY(hipEventRecord(m.ev3, m.stream));
 	return WHAMD_OK;
 }
@@ -1767,7 +1769,11 @@ whamd_status_t DeviceTable::enqueue_group(DeviceTable* const* tables, const Prob
 	auto flush = [&](Part& part, int variant) {
 		Batch& b = part.batches[variant];
 		if (!b.args.n) return;
-		const dim3 grid(b.grid_x, b.args.n), block(b.threads);
+		// a table's workgroups on ONE XCD (slot_group_who): the table is the fast grid dimension, padded to a multiple of eight -- where that spreads the tables
+		// evenly over the eight XCDs (a multiple of eight of them, or so many that the remainder does not matter)
+		const bool by_table = (b.args.n % 8u == 0u || b.args.n >= 40u) && !debug_env("WHAMD_GROUP_BY_WORKGROUP");
+		b.args.pad = by_table ? 1u : 0u;
+		const dim3 grid = by_table ? dim3((b.args.n + 7u) & ~7u, b.grid_x) : dim3(b.grid_x, b.args.n), block(b.threads);
 		hipStream_t stream = part.lead->stream;
 		switch (variant) {
 			case 0:
@@ -1876,8 +1882,7 @@ whamd_status_t DeviceTable::wait(const Problem& p, Solution& s, whamd_solve_stat
 	st.group_tables = m.group_tables;
 	st.bt_chunks = st.bt_missed = st.bt_rewalked = 0;
 	if (m.use_chunks) {
-		uint32_t c[3] = {0, 0, 0};
-		HIP_TRY(hipMemcpy(c, m.d_bt_counters, 12, hipMemcpyDeviceToHost));
+		const uint32_t* c = m.h_pinned + 2 * (size_t)n + m.jobs.size();   // (downloaded with the path)
 		st.bt_chunks = (uint32_t)m.chunks.size();
 		st.bt_missed = c[0];
 		st.bt_rewalked = c[1];

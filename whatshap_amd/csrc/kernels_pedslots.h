@@ -348,12 +348,14 @@ __global__ __launch_bounds__(512) void pedslot_run(DevProblem P, SlotRun run, Pe
 // One launch = the next run of SEVERAL pedigree tables (see slot_group, kernels_slots.h): blockIdx.y selects the table's entry.
 template <int TB, int NF>
 __global__ __launch_bounds__(512, NF == 2 ? 8 : (NF == 4 ? 4 : 2)) void pedslot_group(SlotGroupArgs args) {   // (NF = 2: four workgroups per CU -- at most 80 SGPRs, 64 VGPRs)
-	const uint32_t warm = slot_warm_next(args.entry[blockIdx.y]);   // (the next step's entry into this XCD's L2: kernels_slots.h)
-	const SlotBatchEntry e = slot_scalar_copy(args.entry[blockIdx.y]);
+	const SlotGroupWho who = slot_group_who(args);   // (the table as the fast grid dimension: a table's workgroups on one XCD, kernels_slots.h)
+	if (who.none) return;
+	const uint32_t warm = slot_warm_next(args.entry[who.table]);   // (the next step's entry into this XCD's L2: kernels_slots.h)
+	const SlotBatchEntry e = slot_scalar_copy(args.entry[who.table]);
 	const SlotRun& run = e.run;
-	if (blockIdx.x >= (1u << run.g) || threadIdx.x >= run.threads) return;
+	if (who.w >= (1u << run.g) || threadIdx.x >= run.threads) return;
 	const DevProblem P = slot_entry_problem(e, true);
-	if (run.spec_id) pedslot_run_body<TB, NF, true>(P, run, e.ex, e.prev, e.cur, blockIdx.x);
-	else pedslot_run_body<TB, NF, false>(P, run, e.ex, e.prev, e.cur, blockIdx.x);
+	if (run.spec_id) pedslot_run_body<TB, NF, true>(P, run, e.ex, e.prev, e.cur, who.w);
+	else pedslot_run_body<TB, NF, false>(P, run, e.ex, e.prev, e.cur, who.w);
 	slot_warm_done(warm);
 }

@@ -1177,28 +1177,43 @@ __device__ __forceinline__ uint32_t slot_warm_next(const SlotBatchEntry* ep) {
 }
 __device__ __forceinline__ void slot_warm_done(uint32_t junk) { asm volatile("" ::"v"(junk)); }
 
+// Which table and which workgroup of its run a workgroup of a group launch is.  Workgroups go to the XCDs round robin in their linear order (x fastest):
+// with the TABLE as x -- `args.pad` != 0, the table dimension padded to a multiple of eight -- every workgroup of a table runs on ONE XCD, and the column a run
+// hands to the next stays in that XCD's L2 instead of crossing to another one (scripts/micro/r5_boundary.hip: 2.26 us instead of 2.89 per dependent launch).
+// DeviceTable::enqueue_group chooses it where the tables spread evenly over the eight XCDs.
+struct SlotGroupWho { uint32_t table, w; bool none; };
+__device__ __forceinline__ SlotGroupWho slot_group_who(const SlotGroupArgs& args) {
+	SlotGroupWho who;
+	who.table = args.pad ? blockIdx.x : blockIdx.y;
+	who.w = args.pad ? blockIdx.y : blockIdx.x;
+	who.none = who.table >= args.n;
+	return who;
+}
+
 // The X runs of several tables in one launch (the counterpart of slot_group below for runs that take the X kernel; the group's other runs go out as
 // a slot_group launch of their own).  The entry is read TWICE: the prologue's and the loop's half before the loop, the exit's half -- exchange layout,
 // masks, the speculative seed's slot -- after it (scalar-cache hits), so the loop's scalar budget is the loop's alone.
 template <int LR = 2, bool DBG = false>
 __global__ __launch_bounds__(512, 4) void slot_groupx(SlotGroupArgs args) {
-	const SlotBatchEntry* ep = args.entry[blockIdx.y];
+	const SlotGroupWho who = slot_group_who(args);
+	if (who.none) return;
+	const SlotBatchEntry* ep = args.entry[who.table];
 	uint32_t D[1 << LR];
 	SlotxStamps stamps;
 	{
 		const SlotBatchEntry e = slot_scalar_copy(ep);
-		if (blockIdx.x >= (1u << (e.run.g - e.run.half)) || threadIdx.x >= e.run.threads) return;
+		if (who.w >= (1u << (e.run.g - e.run.half)) || threadIdx.x >= e.run.threads) return;
 		DevProblem P = slot_entry_problem(e, false);
 		if (DBG) P.dbg_flags = e.pad2;
 		const void* warm = (e.pad2 & 0x10000u) ? nullptr : (const void*)(ep + 1);   // (pad2 bit 16: timing experiment, debug library)
-		if constexpr (LR == 3) slot_runx8_core<DBG>(P, e.run, e.prev, blockIdx.x, D, stamps, warm);
-		else slot_runx_core<2, 0, DBG>(P, e.run, e.prev, blockIdx.x, D, stamps, warm);
+		if constexpr (LR == 3) slot_runx8_core<DBG>(P, e.run, e.prev, who.w, D, stamps, warm);
+		else slot_runx_core<2, 0, DBG>(P, e.run, e.prev, who.w, D, stamps, warm);
 	}
 	asm volatile("" : "+s"(ep));   // (opaque: what follows is fetched again, not kept in registers through the loop)
 	const SlotBatchEntry e = slot_scalar_copy(ep);
 	DevProblem P = slot_entry_problem(e, false);
-	if (e.run.spec_id) slot_runx_exit<LR, DBG, true>(P, e.run, e.cur, e.score_out, blockIdx.x, D, stamps);
-	else slot_runx_exit<LR, DBG, false>(P, e.run, e.cur, e.score_out, blockIdx.x, D, stamps);
+	if (e.run.spec_id) slot_runx_exit<LR, DBG, true>(P, e.run, e.cur, e.score_out, who.w, D, stamps);
+	else slot_runx_exit<LR, DBG, false>(P, e.run, e.cur, e.score_out, who.w, D, stamps);
 }
 
 // One launch = the next run of SEVERAL TABLES (whamd_dptable_enqueue_many: independent tables advance in lockstep on one stream):
@@ -1211,16 +1226,18 @@ __global__ __launch_bounds__(512, 4) void slot_groupx(SlotGroupArgs args) {
 // launch when the group is a handful of narrow tables and every workgroup has a CU to itself.
 template <int LR, bool DBG = false, bool TIGHT = false>
 __global__ __launch_bounds__(512, TIGHT ? (LR == 3 ? 6 : 8) : 2) void slot_group(SlotGroupArgs args) {
-	const uint32_t warm = slot_warm_next(args.entry[blockIdx.y]);
-	const SlotBatchEntry e = slot_scalar_copy(args.entry[blockIdx.y]);
+	const SlotGroupWho who = slot_group_who(args);
+	if (who.none) return;
+	const uint32_t warm = slot_warm_next(args.entry[who.table]);
+	const SlotBatchEntry e = slot_scalar_copy(args.entry[who.table]);
 	const SlotRun& run = e.run;
-	if (blockIdx.x >= (1u << (run.g - run.half)) || threadIdx.x >= run.threads) return;
+	if (who.w >= (1u << (run.g - run.half)) || threadIdx.x >= run.threads) return;
 	DevProblem P = slot_entry_problem(e, false);
 	if (DBG) P.dbg_flags = e.pad2;   // timing experiments (WHAMD_SLOT_SKIP: results invalid)
 	if ((LR == 2 || LR == 3) && (run.yflags & 1u)) {
-		if (run.spec_id) slot_run_body<(LR == 3 ? 3 : 2), DBG, true, true>(P, run, e.prev, e.cur, blockIdx.x, e.score_out);
-		else slot_run_body<(LR == 3 ? 3 : 2), DBG, false, true>(P, run, e.prev, e.cur, blockIdx.x, e.score_out);
-	} else if (run.spec_id) slot_run_body<LR, DBG, true>(P, run, e.prev, e.cur, blockIdx.x, e.score_out);
-	else slot_run_body<LR, DBG, false>(P, run, e.prev, e.cur, blockIdx.x, e.score_out);
+		if (run.spec_id) slot_run_body<(LR == 3 ? 3 : 2), DBG, true, true>(P, run, e.prev, e.cur, who.w, e.score_out);
+		else slot_run_body<(LR == 3 ? 3 : 2), DBG, false, true>(P, run, e.prev, e.cur, who.w, e.score_out);
+	} else if (run.spec_id) slot_run_body<LR, DBG, true>(P, run, e.prev, e.cur, who.w, e.score_out);
+	else slot_run_body<LR, DBG, false>(P, run, e.prev, e.cur, who.w, e.score_out);
 	slot_warm_done(warm);
 }

@@ -195,7 +195,7 @@ static_assert(sizeof(SlotBatchEntry) == 320 && sizeof(SlotBatchEntry) % 64 == 0,
 // built once per table at create time; a group launch only passes which of them take part).
 constexpr int SLOT_GROUP_MAX = 248;   // (2 KB of kernel arguments: a whole-genome cohort is hundreds of tables)
 struct SlotGroupArgs {
-	uint32_t n, pad;
+	uint32_t n, pad;   // pad != 0: the TABLE is the fast grid dimension (blockIdx.x, padded to a multiple of eight): a table's workgroups on one XCD (slot_group_who)
 	const SlotBatchEntry* entry[SLOT_GROUP_MAX];
 };
 
