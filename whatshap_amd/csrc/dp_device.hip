@@ -1515,7 +1515,10 @@ void DeviceTable::Impl::launch_slot_run(const SlotBatchEntry& e, uint64_t& launc
 	if ((run.yflags & 8u) && run.lr == 2u) {   // X run with four cells per thread: registers instead of LDS lines (LDS: the wave-slot exchange buffers + the threads' own operand lines)
 		const bool streamed = m.side_by_side || debug_env("WHAMD_XSTREAM");   // (no LDS lines: room for other tables' workgroups on the CU)
 		const size_t lds_x = streamed ? (size_t)2 * run.threads * 16 : slotx_lds_bytes(run.threads, (run.ncols + 7u) & ~7u);
-#define WHAMD_SLOTX_LAUNCH(XCV, DBGV, SPECV) hipLaunchKernelGGL((slot_runx<2, XCV, DBGV, SPECV>), grid, block, lds_x, m.run_stream, m.dp, run, e.prev, e.cur, e.score_out)
+		// narrow tables: the run's workgroups packed onto one XCD (slot_runx: eight times the grid, every eighth workgroup works)
+		const uint32_t pack = (grid.x <= 32u && !m.side_by_side && !debug_env("WHAMD_NO_XCD_PACK")) ? 1u : 0u;
+		const dim3 xgrid(pack ? grid.x * 8u : grid.x);
+#define WHAMD_SLOTX_LAUNCH(XCV, DBGV, SPECV) hipLaunchKernelGGL((slot_runx<2, XCV, DBGV, SPECV>), xgrid, block, lds_x, m.run_stream, m.dp, run, e.prev, e.cur, e.score_out, pack)
 		if (streamed) {
 			if (spec) WHAMD_SLOTX_LAUNCH(0, false, true); else WHAMD_SLOTX_LAUNCH(0, false, false);
 		} else

@@ -1108,10 +1108,15 @@ __global__ __launch_bounds__(256) void slot_tables(DevProblem P, const SlotRun* 
 // SPEC: the run ends a backtrace chunk and leaves the seed of the speculative walk (instantiated separately: the other runs
 // do not even carry the test).
 // One X run as a launch of its own: XC = 24 or 32 unrolled columns (a run of 22 columns does not fetch the lane parts of 32).
+// `pack` != 0 (narrow tables: at most 32 workgroups): the launch has EIGHT times the run's workgroups and only every eighth works -- workgroups go to the XCDs
+// round robin, so the run's workgroups all sit on XCD 0 and the column they hand to the next launch stays in one L2 (2.26 us instead of 2.89 per dependent
+// launch, scripts/micro/r5_boundary.hip; the seven idle workgroups per real one leave at once).
 template <int LR, int XC, bool DBG, bool SPEC>
-__global__ __launch_bounds__(512) void slot_runx(DevProblem P, SlotRun run, const uint32_t* __restrict__ prev, uint32_t* __restrict__ cur, uint32_t* __restrict__ score_out) {
-	touch_kernel_arguments<sizeof(DevProblem) + sizeof(SlotRun) + 24>();
-	slot_runx_body<LR, XC, DBG, SPEC>(P, run, prev, cur, blockIdx.x, score_out);
+__global__ __launch_bounds__(512) void slot_runx(DevProblem P, SlotRun run, const uint32_t* __restrict__ prev, uint32_t* __restrict__ cur, uint32_t* __restrict__ score_out,
+                                                 uint32_t pack) {
+	if (pack && (blockIdx.x & 7u)) return;
+	touch_kernel_arguments<sizeof(DevProblem) + sizeof(SlotRun) + 28>();
+	slot_runx_body<LR, XC, DBG, SPEC>(P, run, prev, cur, pack ? blockIdx.x >> 3 : blockIdx.x, score_out);
 }
 
 template <int LR, bool DBG, bool SPEC, bool YF = false>
