@@ -1402,6 +1402,13 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((slot_runx<2, 32, true, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((slot_runx<2, 32, true, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #endif
+#ifdef WHAMD_DEBUG_BUILD
+#define WHAMD_PSLOTX_ATTR(TBV, NFV) \
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_runx<TBV, NFV, 32, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_runx<TBV, NFV, 32, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		WHAMD_PSLOTX_ATTR(2, 2) WHAMD_PSLOTX_ATTR(2, 4) WHAMD_PSLOTX_ATTR(4, 2) WHAMD_PSLOTX_ATTR(4, 4) WHAMD_PSLOTX_ATTR(2, 16) WHAMD_PSLOTX_ATTR(2, PSLOT_FACT)
+#undef WHAMD_PSLOTX_ATTR
+#endif
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, 4, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, 4, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, 2, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1499,6 +1506,24 @@ void DeviceTable::Impl::launch_slot_run(const SlotBatchEntry& e, uint64_t& launc
 		const PedSlotExtra& ex = m.splan.pextra[e.pad];
 		const size_t lds_ped = pedslot_lds_bytes(run.threads, run.ncols, ex);
 		const dim3 grid(1u << run.g), block(run.threads);
+#ifdef WHAMD_DEBUG_BUILD
+		if ((run.yflags & 8u) && !m.side_by_side) {   // X run (kernels_pedslots.h, pedslot_runx; WHAMD_PED_XRUN=1): the costs of every column formed in the prologue, scalars through the scalar cache
+#define WHAMD_PSLOTX_LAUNCH2(TBV, NFV, XCV) do { const size_t lds_x = pedslotx_lds_bytes(run.threads, XCV); \
+		if (spec) hipLaunchKernelGGL((pedslot_runx<TBV, NFV, XCV, true>), grid, block, lds_x, m.run_stream, m.dp, run, ex, e.prev, e.cur); \
+		else hipLaunchKernelGGL((pedslot_runx<TBV, NFV, XCV, false>), grid, block, lds_x, m.run_stream, m.dp, run, ex, e.prev, e.cur); } while (0)
+#define WHAMD_PSLOTX_LAUNCH(TBV, NFV) do { if (run.ncols <= 16u) WHAMD_PSLOTX_LAUNCH2(TBV, NFV, 16); else WHAMD_PSLOTX_LAUNCH2(TBV, NFV, 32); } while (0)
+			if (ex.tb == 2 && ex.nf == (uint32_t)PSLOT_FACT) WHAMD_PSLOTX_LAUNCH(2, PSLOT_FACT);
+			else if (ex.tb == 2 && ex.nf == 16) WHAMD_PSLOTX_LAUNCH(2, 16);
+			else if (ex.tb == 2 && ex.nf == 2) WHAMD_PSLOTX_LAUNCH(2, 2);
+			else if (ex.tb == 2) WHAMD_PSLOTX_LAUNCH(2, 4);
+			else if (ex.nf == 2) WHAMD_PSLOTX_LAUNCH(4, 2);
+			else WHAMD_PSLOTX_LAUNCH(4, 4);
+#undef WHAMD_PSLOTX_LAUNCH
+#undef WHAMD_PSLOTX_LAUNCH2
+			launches += 1;
+			return;
+		}
+#endif
 #define WHAMD_PSLOT_LAUNCH(TBV, NFV, SPECV) hipLaunchKernelGGL((pedslot_run<TBV, NFV, SPECV>), grid, block, lds_ped, m.run_stream, m.dp, run, ex, e.prev, e.cur)
 		if (ex.tb == 2 && ex.nf == (uint32_t)PSLOT_FACT) { if (spec) WHAMD_PSLOT_LAUNCH(2, PSLOT_FACT, true); else WHAMD_PSLOT_LAUNCH(2, PSLOT_FACT, false); }
 		else if (ex.tb == 2 && ex.nf == 16) { if (spec) WHAMD_PSLOT_LAUNCH(2, 16, true); else WHAMD_PSLOT_LAUNCH(2, 16, false); }

@@ -22,6 +22,43 @@ __global__ __launch_bounds__(256) void pedslot_tables(DevProblem P, const SlotRu
 	const uint32_t TB = ex.tb, T = 1u << TB, NA = pslot_na(ex.nf), NS = pslot_ns(ex.nf), fwn = ex.fwn, L = run.L, nls = 6u - TB;
 	const uint32_t n_g = fwn << run.g, n_w = fwn << run.lw, n_s = run.ncols * 64u * NS, n_k = run.ncols * T * pslot_nk(ex.nf);
 	uint32_t* __restrict__ out = tab + (((unsigned long long)ex.g_hi << 32) | ex.g_lo);
+	// X runs (pedslot_runx_body): recombination cost and control word per column, the lanes' and the workgroups' tie parities (slots.h PedSlotExtra::x_off)
+	const uint32_t n_x = (run.yflags & 8u) ? (uint32_t)pslotx_words(run.ncols, run.threads, run.g) : 0u;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_x; i += gridDim.x * blockDim.x) {
+		const uint32_t ncp = run.ncols + (uint32_t)SLOT_XPAD;
+		const PedSlotRow* __restrict__ rows = P.pslot_rows + run.row_off;
+		auto end_info = [&](const PedSlotRow& row, uint32_t k, uint32_t& slot, uint32_t& M) {
+			if (k == 0) { slot = row.info0 & 255u; M = row.M0; }
+			else if (k == 1) { slot = row.info1 & 255u; M = row.M1; }
+			else if (k == 2) { slot = row.info2 & 255u; M = row.M2; }
+			else { slot = row.pad[2] & 255u; M = row.pad[3]; }
+		};
+		uint32_t word = 0;
+		if (i < ncp) word = i < run.ncols ? rows[i].recomb : 0xFFFFFFFFu;
+		else if (i < 2u * ncp) {
+			const uint32_t c = i - ncp;
+			if (c < run.ncols) {
+				uint32_t exchanges = 0;   // wave-slot endings of the run before this column: they alternate between two LDS buffers
+				for (uint32_t c2 = 0; c2 < c; ++c2)
+					for (uint32_t k = 0; k < rows[c2].n_end; ++k) { uint32_t sl, M; end_info(rows[c2], k, sl, M); exchanges += sl >= nls; }
+				word = rows[c].n_end;
+				for (uint32_t k = 0; k < rows[c].n_end; ++k) {
+					uint32_t sl, M;
+					end_info(rows[c], k, sl, M);
+					word |= (sl | ((sl >= nls ? exchanges & 1u : 0u) << 3)) << (3u + 4u * k);
+					exchanges += sl >= nls;
+				}
+			}
+		} else {
+			const uint32_t q = i - 2u * ncp;
+			const uint32_t index = q < run.threads ? (q >> TB) : ((q - run.threads) << L);   // a lane's local cell index / a workgroup's grid bits
+			const uint32_t keep = q < run.threads ? (1u << L) - 1u : ~((1u << L) - 1u);
+			uint32_t e = 0;
+			for (uint32_t c = 0; c < run.ncols; ++c)
+				for (uint32_t k = 0; k < rows[c].n_end; ++k, ++e) { uint32_t sl, M; end_info(rows[c], k, sl, M); word |= ((uint32_t)__popc(index & keep & M) & 1u) << (e & 31u); }
+		}
+		out[ex.x_off + i] = word;
+	}
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_g + n_w + n_s + n_k; i += gridDim.x * blockDim.x) {
 		uint32_t kind, unit, c, t, f;
 		if (i >= n_g + n_w + n_s) {   // K [c][t][12]: the constants of the factorised line (entries 4 .. 15 of the column's sixteen)
@@ -337,6 +374,228 @@ __device__ __forceinline__ void pedslot_run_body(const DevProblem& P, const Slot
 		}
 	}
 }
+
+#ifdef WHAMD_DEBUG_BUILD
+// ---- X runs for pedigrees (round 5; the single individual's are in kernels_slots.h, where the reasons are) ---------------------------------------------
+// NOT in the product library: correct (bit-identical solutions on trio, quartet and the factorised line) but slower than pedslot_run below -- 8.4 against
+// 6.1 us per launch on a trio at coverage 15, 12.7 against 7.6 with untrusted genotypes (scripts/gpu_pedx_ab.py with WHAMD_PED_XRUN=1 in the debug library).
+// A pedigree column is the butterfly (16 - 40 DPP operations) whichever way its cost arrives, and forming the costs per thread is ~100 four-byte loads.
+// The cost of a lane's (cell, transmission value) in a column does not depend on the column before: the prologue forms the costs of EVERY column of the
+// run straight from the tables (whatever the number of forms: NF = 2, 4, 16 or the factorised line -- the same loop below for all of them) and keeps them
+// in the thread's own 16 bytes per trip of an LDS area (no staging of tables in LDS, no barrier).  The loop -- counted, over pairs of trips of four columns --
+// fetches per trip one such line, four recombination costs and four control words through the scalar cache; a column is the butterfly over the previous
+// transmission value, one saturating add and the record byte.  Columns behind the run's last are harmless: their recombination cost is all-ones (no
+// candidate of the butterfly ever wins) and their cost is zero.  An ending read is one hand-written block (the partner's value requested first, the
+// lane's tie parity a bit of a create-time word); all four ending reads of a column are described in its control word.
+#define PSLOTX_ENDING_ASM                                                                                              \
+	"s_and_b32 %[sl], %[f], 7\n\t"                 /* slot of the ending read (bit 3 of the field: the exchange buffer) */ \
+	"s_cmp_lt_u32 %[sl], %[nls]\n\t"                                                                                   \
+	"s_cbranch_scc0 .Lpw%=\n\t"                                                                                        \
+	"s_add_u32 %[sa], %[sl], %[tb2]\n\t"           /* lane slot: byte address of lane ^ 2^(slot + TB) = (lane * 4) ^ 2^(slot + TB + 2) */ \
+	"s_lshl_b32 %[sa], 1, %[sa]\n\t"                                                                                   \
+	"v_xor_b32_e32 %[t], %[sa], %[l4]\n\t"                                                                             \
+	"ds_bpermute_b32 %[o], %[t], %[d]\n\t"                                                                             \
+	"s_branch .Lpm%=\n"                                                                                                \
+	".Lpw%=:\n\t"                                  /* wave slot: partner thread = tid ^ (64 << (slot - NLS)), 4 bytes each */ \
+	"s_sub_u32 %[sa], %[sl], %[nls]\n\t"                                                                               \
+	"s_lshl_b32 %[sa], 0x100, %[sa]\n\t"                                                                               \
+	"s_bfe_u32 %[sl], %[f], 0x10003\n\t"                                                                               \
+	"s_mul_i32 %[sl], %[sl], %[xby]\n\t"                                                                               \
+	"v_add_u32_e32 %[t], %[sl], %[t4]\n\t"                                                                             \
+	"ds_write_b32 %[t], %[d]\n\t"                                                                                      \
+	"v_xor_b32_e32 %[t], %[sa], %[t4]\n\t"                                                                             \
+	"v_add_u32_e32 %[t], %[sl], %[t]\n\t"                                                                              \
+	"s_waitcnt lgkmcnt(0)\n\t"                                                                                         \
+	"s_barrier\n\t"                                                                                                    \
+	"ds_read_b32 %[o], %[t]\n"                                                                                         \
+	".Lpm%=:\n\t"                                                                                                      \
+	"v_and_b32_e32 %[q], 1, %[par]\n\t"            /* the lane's tie parity: bit 0 of par; the next ending read's moves down */ \
+	"v_lshrrev_b32_e32 %[par], 1, %[par]\n\t"                                                                          \
+	"v_add_u32_e64 %[q], %[d], %[q] clamp\n\t"     /* mine + q, saturating */                                          \
+	"s_waitcnt lgkmcnt(0)\n\t"                                                                                         \
+	"v_cmp_lt_u32_e64 %[m], %[o], %[q]\n\t"        /* other < mine + q: the pair's decision (read at the side-0 lane only) */ \
+	"v_min_u32_e32 %[d], %[d], %[o]\n\t"                                                                               \
+	"s_nop 0\n\t"                                  /* (gfx950: a VALU result in an SGPR may be read by a VALU two instructions later at the earliest) */ \
+	"v_cndmask_b32_e64 %[q], 0, 1, %[m]\n\t"                                                                           \
+	"v_lshl_or_b32 %[by], %[q], %[sh], %[by]"
+
+template <int SH, int TB>
+__device__ __forceinline__ void pslotx_ending(uint32_t& D, uint32_t& byte, uint32_t& par, const uint32_t field, const uint32_t xbytes, const uint32_t lane4, const uint32_t tid4) {
+	unsigned long long m;
+	uint32_t tmp, o, q, sa, sl;
+	asm volatile(PSLOTX_ENDING_ASM
+	             : [d] "+v"(D), [by] "+v"(byte), [par] "+v"(par), [t] "=&v"(tmp), [o] "=&v"(o), [q] "=&v"(q), [sa] "=&s"(sa), [sl] "=&s"(sl), [m] "=&s"(m)
+	             : [f] "s"(field), [xby] "s"(xbytes), [l4] "v"(lane4), [t4] "v"(tid4), [nls] "n"(6 - TB), [tb2] "n"(TB + 2), [sh] "n"(SH)
+	             : "memory", "scc");
+}
+
+template <int TB, int NF, int XC, bool SPEC>
+__device__ __forceinline__ void pedslot_runx_body(const DevProblem& P, const SlotRun& run, const PedSlotExtra& ex, const uint32_t* __restrict__ prev,
+                                                  uint32_t* __restrict__ cur, const uint32_t w) {
+	constexpr uint32_t T = 1u << TB;
+	constexpr int NLS = 6 - TB;
+	constexpr bool FACT = NF == PSLOT_FACT;
+	constexpr int NA = (int)pslot_na(NF), NS = (int)pslot_ns(NF), NK = (int)pslot_nk(NF);
+	static_assert(XC % 8 == 0 && XC <= SLOT_XCOLS, "whole pairs of trips of four columns");
+	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];   // wave-slot exchange 2 x [threads] | the lanes' cost lines [XC / 4 + 3][threads][4]
+	const uint32_t tid = threadIdx.x, lane = tid & 63u;
+	const uint32_t wave = uni(tid >> 6);
+	const uint32_t threads = run.threads, ncols = run.ncols, L = run.L;
+	const uint32_t t = lane & (T - 1u);
+	const uint32_t lcell = tid >> TB;
+	const uint32_t Pcell = (w << L) | lcell;
+	const uint32_t* __restrict__ tabG = P.pslot_tab + (((unsigned long long)ex.g_hi << 32) | ex.g_lo);
+	const uint32_t fwn = ex.fwn;
+	typedef const __attribute__((address_space(4))) uint32_t* cptr1;
+	typedef uint32_t u32x4c __attribute__((ext_vector_type(4)));
+	typedef const __attribute__((address_space(4))) u32x4c* cptr4;
+	// ---- prologue: one batch of loads.  Scalars of the first trip through the scalar cache ...
+	const uint32_t* __restrict__ rc_tab = tabG + ex.x_off;                            // recombination cost per column
+	const uint32_t* __restrict__ cw_tab = rc_tab + ncols + (uint32_t)SLOT_XPAD;       // control word per column
+	const uint32_t* __restrict__ par_tab = cw_tab + ncols + (uint32_t)SLOT_XPAD;      // tie parities: [threads], then [workgroups]
+	u32x4c rcA = *(cptr4)(unsigned long long)rc_tab, rcB;
+	u32x4c cwA = *(cptr4)(unsigned long long)cw_tab, cwB;
+	const uint32_t par_w = *(cptr1)(unsigned long long)(par_tab + threads + w);
+	// ... the entering value first (written by the previous launch on other XCDs: the longest latency) ...
+	uint32_t D = 0;
+	if (run.has_prev) {
+		const uint32_t occ = run.in_occ;
+		uint32_t idx;
+		if (run.in_identity) idx = Pcell & occ;
+		else {
+			idx = 0;
+#pragma unroll
+			for (int s = 0; s < SLOT_MAXSLOTS; ++s) idx |= (((Pcell & occ) >> s) & 1u) << slot_pos_dev(run.in_pos, s);
+		}
+		D = prev[(size_t)idx * T + t];
+	}
+	const uint32_t par_l = par_tab[tid];
+	// ... and the cost entries of every column: workgroup part, wave part, lane part (+ the constants of a factorised line)
+	const uint32_t* __restrict__ g_src = tabG + (size_t)w * fwn + t * NA;
+	const uint32_t* __restrict__ w_src = tabG + ex.w_off + wave * fwn + t * NA;
+	const uint32_t* __restrict__ s_src = tabG + ex.s_off + lane * NS;
+	const uint32_t* __restrict__ k_src = tabG + ex.s_off + ncols * 64u * NS + t * NK;
+	uint32_t cost[XC];
+#pragma unroll
+	for (int c = 0; c < XC; ++c) {
+		uint32_t a[NA], sv[NS];
+#pragma unroll
+		for (int f = 0; f < NA; ++f) a[f] = g_src[c * (int)T * NA + f] + w_src[c * (int)T * NA + f];
+#pragma unroll
+		for (int f = 0; f < NS; ++f) sv[f] = s_src[c * 64 * NS + f];
+		uint32_t v;
+		if constexpr (FACT) {   // (slots.h: the minimum over the sixteen allele assignments, the untransmitted alleles first; 19 operations)
+			uint32_t k[NK > 0 ? NK : 1];
+#pragma unroll
+			for (int f = 0; f < NK; ++f) k[f] = k_src[c * (int)T * NK + f];
+			const uint32_t X = a[0] + sv[0], Y = a[1] + sv[1], C = a[2] + sv[2];
+			const uint32_t M0 = min(k[0], k[1] + X), M1 = min(k[2], k[3] - X);
+			const uint32_t F0 = min(k[4], k[5] + Y), F1 = min(k[6], k[7] - Y);
+			const uint32_t t00 = k[8] + M0 + F0, t01 = k[9] + C + M0 + F1;
+			const uint32_t t10 = k[10] - C + M1 + F0, t11 = k[11] + M1 + F1;
+			v = min(min(t00, t01), min(t10, t11));
+		} else {
+			v = a[0] + sv[0];
+#pragma unroll
+			for (int f = 1; f < NF; ++f) v = min(v, a[f] + sv[f]);
+		}
+		cost[c] = (uint32_t)c < ncols ? v : 0u;   // (behind the run: the tables that follow were read -- the column must change nothing)
+	}
+	uint4* __restrict__ xs = reinterpret_cast<uint4*>(smem + 2u * threads) + tid;   // + trip * threads (behind the two exchange buffers)
+#pragma unroll
+	for (int t4 = 0; t4 < XC / 4; ++t4) xs[(uint32_t)t4 * threads] = make_uint4(cost[4 * t4], cost[4 * t4 + 1], cost[4 * t4 + 2], cost[4 * t4 + 3]);
+	uint32_t par = par_l ^ par_w;
+	uint32_t* __restrict__ rec = reinterpret_cast<uint32_t*>(P.bt + (((unsigned long long)run.rec_hi << 32) | run.rec_lo)) + (size_t)w * ex.rec_words + tid;
+	uint32_t tbit[TB > 0 ? TB : 1];
+#pragma unroll
+	for (int s = 0; s < TB; ++s) tbit[s] = (t >> s) & 1u;
+
+	const uint32_t lds0 = (uint32_t)(unsigned long long)smem;
+	const uint32_t lane4 = lane << 2, tid4 = lds0 + (tid << 2);
+	const uint32_t xbytes = threads * 4u;
+	// one column: the butterfly over the previous transmission value (lowest j on ties), the cost, the ending reads; returns the record byte
+	auto column = [&](const uint32_t cst, const uint32_t rc, const uint32_t ctrl) -> uint32_t {
+		uint32_t v = D, j = t;
+		if (TB >= 1) { const uint32_t pv = pslot_lane_xor<1>(v), pj = pslot_lane_xor<1>(j); const uint32_t cand = pslot_sat_add(pv, rc); const bool take = cand < pslot_sat_add(v, tbit[0]); v = take ? cand : v; j = take ? pj : j; }
+		if (TB >= 2) { const uint32_t pv = pslot_lane_xor<2>(v), pj = pslot_lane_xor<2>(j); const uint32_t cand = pslot_sat_add(pv, rc); const bool take = cand < pslot_sat_add(v, tbit[TB >= 2 ? 1 : 0]); v = take ? cand : v; j = take ? pj : j; }
+		if (TB >= 3) { const uint32_t pv = pslot_lane_xor<4>(v), pj = pslot_lane_xor<4>(j); const uint32_t cand = pslot_sat_add(pv, rc); const bool take = cand < pslot_sat_add(v, tbit[TB >= 3 ? 2 : 0]); v = take ? cand : v; j = take ? pj : j; }
+		if (TB >= 4) { const uint32_t pv = pslot_lane_xor<8>(v), pj = pslot_lane_xor<8>(j); const uint32_t cand = pslot_sat_add(pv, rc); const bool take = cand < pslot_sat_add(v, tbit[TB >= 4 ? 3 : 0]); v = take ? cand : v; j = take ? pj : j; }
+		D = pslot_sat_add(v, cst);
+		uint32_t byte = j;
+		const uint32_t n_end = ctrl & 7u;
+		if (n_end) {
+			pslotx_ending<4, TB>(D, byte, par, ctrl >> 3, xbytes, lane4, tid4);
+			if (n_end > 1u) {   // several reads ending in one column are rare; all four fields are in the control word
+				pslotx_ending<5, TB>(D, byte, par, ctrl >> 7, xbytes, lane4, tid4);
+				if (n_end > 2u) {
+					pslotx_ending<6, TB>(D, byte, par, ctrl >> 11, xbytes, lane4, tid4);
+					if (n_end > 3u) pslotx_ending<7, TB>(D, byte, par, ctrl >> 15, xbytes, lane4, tid4);
+				}
+			}
+		}
+		return byte;
+	};
+	const uint32_t xstride = threads * 16u;
+	uint32_t xaddr = lds0 + 2u * xbytes + (tid << 4);   // LDS byte address of the lane's cost line of trip 0 (behind the two exchange buffers)
+	typedef __attribute__((address_space(3))) const u32x4c* lds_line;
+	u32x4c xA = *(lds_line)(size_t)xaddr, xB;
+	for (uint32_t pairs = (ncols + 7u) >> 3; pairs; --pairs) {
+		asm volatile("" ::"s"(rcA[0]), "s"(cwA[0]), "v"(xA[0]));
+		rcB = *(cptr4)(unsigned long long)(rc_tab + 4u);
+		cwB = *(cptr4)(unsigned long long)(cw_tab + 4u);
+		xB = *(lds_line)(size_t)(xaddr + xstride);
+		uint32_t recacc = column(xA[0], rcA[0], cwA[0]);
+		recacc |= column(xA[1], rcA[1], cwA[1]) << 8;
+		recacc |= column(xA[2], rcA[2], cwA[2]) << 16;
+		recacc |= column(xA[3], rcA[3], cwA[3]) << 24;
+		rec[0] = recacc;   // fire and forget (a trip behind the run's last writes a word of the next run's record: never -- the planner's rec_words is whole trips,
+		                   // and a pad trip only exists in the second half below)
+		asm volatile("" ::"s"(rcB[0]), "s"(cwB[0]), "v"(xB[0]));
+		rc_tab += 8u;
+		cw_tab += 8u;
+		xaddr += 2u * xstride;
+		rcA = *(cptr4)(unsigned long long)rc_tab;
+		cwA = *(cptr4)(unsigned long long)cw_tab;
+		xA = *(lds_line)(size_t)xaddr;
+		recacc = column(xB[0], rcB[0], cwB[0]);
+		recacc |= column(xB[1], rcB[1], cwB[1]) << 8;
+		recacc |= column(xB[2], rcB[2], cwB[2]) << 16;
+		recacc |= column(xB[3], rcB[3], cwB[3]) << 24;
+		if (pairs > 1u || ((ncols + 3u) >> 2 & 1u) == 0u) rec[threads] = recacc;   // (the second trip of the last pair may lie behind the run)
+		rec += 2u * (size_t)threads;
+	}
+
+	// ---- exit: scatter into the next step's order (lanes whose free-slot bits are zero hold the representatives)
+	{
+		const uint32_t occ = run.out_occ;
+		const uint32_t localmask = (1u << L) - 1u;
+		const bool writes = (lcell & ~occ & localmask) == 0u;
+		uint32_t idx = 0;
+#pragma unroll
+		for (int s = 0; s < SLOT_MAXSLOTS; ++s) idx |= (((Pcell & occ) >> s) & 1u) << slot_pos_dev(run.out_pos, s);
+		unsigned long long best_key = ~0ull;
+		if (writes) {
+			cur[(size_t)idx * T + t] = D;
+			if (SPEC) best_key = ((unsigned long long)D << 32) | (idx * T + t);
+		}
+		if (SPEC && run.spec_id) {
+#pragma unroll
+			for (int m = 1; m < 64; m <<= 1) {
+				const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)best_key, m), hi = (uint32_t)__shfl_xor((int)(uint32_t)(best_key >> 32), m);
+				best_key = min(best_key, ((unsigned long long)hi << 32) | lo);
+			}
+			if (lane == 0) P.spec_keys[(size_t)(run.spec_id - 1u) * P.spec_stride + w * (threads >> 6) + wave] = best_key;
+		}
+	}
+}
+inline size_t pedslotx_lds_bytes(uint32_t threads, uint32_t xc) { return (size_t)threads * 8 + (size_t)(xc / 4 + 3) * threads * 16; }
+
+template <int TB, int NF, int XC, bool SPEC>
+__global__ __launch_bounds__(512) void pedslot_runx(DevProblem P, SlotRun run, PedSlotExtra ex, const uint32_t* __restrict__ prev, uint32_t* __restrict__ cur) {
+	touch_kernel_arguments<sizeof(DevProblem) + sizeof(SlotRun) + sizeof(PedSlotExtra) + 16>();
+	pedslot_runx_body<TB, NF, XC, SPEC>(P, run, ex, prev, cur, blockIdx.x);
+}
+#endif
 
 template <int TB, int NF, bool SPEC>
 __global__ __launch_bounds__(512) void pedslot_run(DevProblem P, SlotRun run, PedSlotExtra ex, const uint32_t* __restrict__ prev,

@@ -510,7 +510,16 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 			ex.w_off = (uint32_t)gsz;
 			ex.s_off = (uint32_t)(gsz + ((uint64_t)1 << run.lw) * ex.fwn);
 			words += (uint64_t)ex.s_off + (uint64_t)run.ncols * 64u * pslot_ns(ex.nf) + (uint64_t)run.ncols * p.T * pslot_nk(ex.nf);
+			// X runs (kernels_pedslots.h, pedslot_runx): per-column scalars and the lanes' tie parities behind the cost tables.  An experiment of the debug
+			// library only (WHAMD_PED_XRUN=1): bit-identical, but 8.4 against 6.1 us per launch on a trio at coverage 15 -- the costs of every column formed by
+			// every thread are ~100 four-byte loads per thread, where pedslot_run stages the tables once per wave.
+			if (run.ncols <= (uint32_t)SLOT_XCOLS && run.n_ends <= (uint32_t)SLOT_XENDS && debug_env("WHAMD_PED_XRUN") && !debug_env("WHAMD_NO_XRUN")) {
+				plan.runs[ri].yflags |= 8u;
+				ex.x_off = (uint32_t)(words - (((uint64_t)ex.g_hi << 32) | ex.g_lo));
+				words += (pslotx_words(run.ncols, run.threads, run.g) + 3u) & ~(uint64_t)3;
+			}
 		}
+		if (debug_env("WHAMD_PED_XRUN")) words += 65536;   // (an X run requests the cost entries of up to SLOT_XCOLS columns whatever its length: room behind the last run)
 		plan.table_words = words;
 	}
 	// ---- entry / exit layouts.  Exit index of a run in LOGICAL order: bit j = j-th continuing read of its last column.

@@ -162,8 +162,12 @@ static_assert(sizeof(PedSlotRow) == 192, "PedSlotRow must stay 48 words");
 struct PedSlotExtra {
 	uint32_t tb, nf, fwn, arow;      // log2 T; forms per value (or PSLOT_FACT); ncols * T * pslot_na(nf); fwn rounded up to 4 (row stride of A in LDS)
 	uint32_t g_lo, g_hi, w_off, s_off;   // word offsets into the table array: G [2^g][fwn]; W and S relative to G: [2^lw][fwn], [ncols][64][pslot_ns(nf)] (then K [ncols][T][pslot_nk(nf)])
-	uint32_t rec_words, pad[3];      // record of one workgroup: one byte per thread and column, 4 columns per word: ceil(ncols / 4) * threads words
+	uint32_t rec_words, x_off, pad[2];   // record of one workgroup: one byte per thread and column, 4 columns per word: ceil(ncols / 4) * threads words
+	                                 // x_off (SlotRun::yflags bit 3, pedslot_runx): relative to G like s_off -- recombination cost [ncols + SLOT_XPAD] (all-ones behind the
+	                                 // run: such a column changes nothing) | control word [ncols + SLOT_XPAD] (n_end | four fields of (slot | exchange buffer << 3) from bit 3) |
+	                                 // tie parities: [threads] words (bit e: parity of the lane's local cell index under the mask of the run's e-th ending read), [2^g] words
 };
+constexpr uint64_t pslotx_words(uint32_t ncols, uint32_t threads, uint32_t g) { return (uint64_t)2 * (ncols + SLOT_XPAD) + threads + ((uint64_t)1 << g); }
 static_assert(sizeof(PedSlotExtra) == 48, "PedSlotExtra layout");
 // LDS of one pedigree run: wave-slot exchange 2 x [threads] | hot lines | A [waves][arow] | S [ncols][64][ns] | K [ncols][T][nk]  (four columns
 // of slack behind the rows of A, S and K: lines are requested ahead)
