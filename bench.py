@@ -63,12 +63,13 @@ WORKLOADS = {
     "config3_x8": dict(trio=True, variants=100000, coverage=15, blocks=8, in_flight=8),  # eight trio tables (families / chromosomes) on one GPU
     "irregular": dict(irregular=True, variants=100000, coverage=20),               # Poisson starts, geometric lengths (mean 16), coverage capped
     "quartet": dict(quartet=True, variants=50000, coverage=13),                    # two trios sharing parents, T = 16
+    "quartet_distrust": dict(quartet=True, distrust=True, variants=50000, coverage=13),   # the same, genotypes not trusted: the quartet's factorised lines (slots.h PSLOT_FACT4)
     "genotype": dict(genotype=True, variants=50000, coverage=15),                  # GenotypeDPTable, single individual
     "genotype_trio": dict(genotype=True, trio=True, variants=20000, coverage=15),  # GenotypeDPTable, trio
     "heuristic": dict(heuristic=True, variants=8000, coverage=30),                 # PedMecHeuristic, coverage beyond the exact DP
     "heuristic_x32": dict(heuristic=True, variants=8000, coverage=30, blocks=32),  # 32 PedMecHeuristic tables in ONE launch (one persistent workgroup each)
 }
-EXTRA_CONFIGS = ["config1", "config1_x24", "config1_x48", "config1_x96", "config3", "config3_distrust", "config3_x8", "blocks3", "blocks24", "irregular", "quartet", "genotype", "genotype_trio", "heuristic", "heuristic_x32"]
+EXTRA_CONFIGS = ["config1", "config1_x24", "config1_x48", "config1_x96", "config3", "config3_distrust", "config3_x8", "blocks3", "blocks24", "irregular", "quartet", "quartet_distrust", "genotype", "genotype_trio", "heuristic", "heuristic_x32"]
 
 
 def parse_args():
@@ -935,7 +936,7 @@ def main():
         bytes_per_launch = bytes_rank / max(launches / args.steps, 1)
         column_path = args.path in ("column", "column_keys")
         kernel = dominant_kernel(args, grouped)
-        kind = ("synthetic trio PedMEC, genotypes not trusted" if args.distrust else "synthetic trio PedMEC") if args.trio else ("synthetic quartet PedMEC (two trios sharing parents)" if args.quartet else "synthetic diploid single-individual")
+        kind = ("synthetic trio PedMEC, genotypes not trusted" if args.distrust else "synthetic trio PedMEC") if args.trio else (("synthetic quartet PedMEC (two trios sharing parents), genotypes not trusted" if args.distrust else "synthetic quartet PedMEC (two trios sharing parents)") if args.quartet else "synthetic diploid single-individual")
         out = {
             "metric": "variant-columns/sec at max-coverage %d (bipartition-costs/sec reported alongside)" % args.coverage,
             "value": cols_job * args.steps / elapsed,

@@ -117,6 +117,41 @@ def test_factorised_lines_with_any_role_order_and_uneven_likelihoods():
         assert ok, roles
 
 
+@pytest.mark.parametrize("kw", [dict(n_variants=60, coverage=6, seed=1, quartet=True, distrust_genotypes=True),
+                                dict(n_variants=200, coverage=7, seed=2, quartet=True, distrust_genotypes=True),
+                                dict(n_variants=150, coverage=8, seed=3, quartet=True, distrust_genotypes=True, mixed_genotypes=True)], ids=str)
+def test_untrusted_genotypes_of_a_quartet_on_factorised_lines(kw):
+    """Two children of the same two founders, genotypes not trusted (T = 16, sixteen allele assignments per value,
+    src/pedigreecolumncostcomputer.cpp:14-50): sixteen forms per (column, value, lane) would be four columns per run, so these tables ran on the
+    per-column kernels.  In haplotype space the line does not depend on the transmission value (slots.h PSLOT_FACT4: four signed sums and sixteen
+    constants per COLUMN; the value only wires the children to the founders' haplotypes) and the minimum is taken by elimination -- every run of
+    the plan is such a run, and plan, tables, records and walk emulated on the CPU equal the oracle."""
+    p = synthetic_block(**kw)
+    summary = _native.plan_summary(p, "slots")
+    assert summary["invariants_ok"] == 1 and summary["n_fact_runs"] == summary["n_runs"] > 0, summary
+    ok, run_columns = agrees(p)
+    assert ok, kw
+    assert run_columns > 0.8 * p.n_variants, (kw, run_columns)
+
+
+def test_a_quartets_factorised_lines_with_any_role_order_and_uneven_likelihoods():
+    """Which individuals are the founders, which the children, and the order of the two trios are read off the haplotype-to-partition maps; the
+    genotype likelihoods differ per individual, genotype and column.  A pedigree the wiring does not describe (the founders swap their roles
+    between the trios) keeps the generic term list -- and is still solved exactly by the plan's per-column steps."""
+    rng = np.random.default_rng(9)
+    base = synthetic_block(n_variants=90, coverage=7, seed=21, quartet=True, distrust_genotypes=True)
+    ids = [int(v) for v in base.individual_id]
+    for triples in ([0, 1, 2, 0, 1, 3], [0, 1, 3, 0, 1, 2], [2, 3, 0, 2, 3, 1], [3, 1, 0, 3, 1, 2], [1, 2, 3, 1, 2, 0]):   # (mother, father, child) x 2 as positions in individual_id
+        gl = rng.integers(0, 60, size=base.genotype_likelihoods.shape).astype(np.float64)
+        p = _native.ProblemArrays(base.read_ptr, base.var_position, base.var_allele, base.var_quality, base.read_sample_id, base.individual_id,
+                                  np.array([ids[r] for r in triples], dtype=np.uint32), base.genotype, gl, base.recombcost, base.positions, True,
+                                  n_variants=base.n_variants)
+        summary = _native.plan_summary(p, "slots")
+        assert summary["invariants_ok"] == 1 and summary["n_fact_runs"] == summary["n_runs"] > 0, (triples, summary)
+        ok, _ = agrees(p)
+        assert ok, triples
+
+
 def _trio_reads_problem(reads, n_variants, seed):
     """A trio problem from explicit reads [(first variant, last variant)], samples round-robin, alleles / qualities seeded."""
     rng = np.random.default_rng(seed)

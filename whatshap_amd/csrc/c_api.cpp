@@ -520,7 +520,7 @@ whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uin
 			if (sp.ped) {
 				const PedSlotExtra& ex = sp.pextra[step.index];
 				ok = ok && sp.pextra.size() == sp.runs.size() && run.lr == 0 && !run.half && (1u << ex.tb) == p.T && run.L == 6u - ex.tb + run.lw;
-				ok = ok && (ex.nf == 2 || ex.nf == 4 || ((ex.nf == 16 || ex.nf == (uint32_t)PSLOT_FACT) && ex.tb == 2)) && ex.fwn == run.ncols * p.T * pslot_na(ex.nf) && ex.fwn <= (uint32_t)PSLOT_FORMWORDS && ex.rec_words == ((run.ncols + 3) / 4) * run.threads;
+				ok = ok && (ex.nf == 2 || ex.nf == 4 || ((ex.nf == 16 || ex.nf == (uint32_t)PSLOT_FACT) && ex.tb == 2) || (ex.nf == (uint32_t)PSLOT_FACT4 && ex.tb == 4)) && ex.fwn == run.ncols * pslot_ta(ex.nf, p.T) * pslot_na(ex.nf) && ex.fwn <= (uint32_t)PSLOT_FORMWORDS && ex.rec_words == ((run.ncols + 3) / 4) * run.threads;
 				ok = ok && run.lw <= (uint32_t)SLOT_LWMAX && run.threads == (64u << run.lw);
 			} else
 			ok = ok && run.lr >= 1 && run.lr <= (uint32_t)SLOT_LR && run.L == run.lr + (uint32_t)SLOT_LANE + run.lw && run.lw <= (uint32_t)SLOT_LWMAX && run.threads == (64u << run.lw);
@@ -533,7 +533,8 @@ whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uin
 				const uint32_t row_n_end = sp.ped ? sp.prows[run.row_off + i].n_end : sp.rows[run.row_off + i].n_end;
 				const SlotBtCol& bc = sp.bt_cols[run.row_off + i];
 				ok = ok && bc.k == p.k[c] && bc.kf == ends && row_n_end == (uint32_t)p.k[c] - p.f[c] && row_n_end <= (uint32_t)(sp.ped ? PSLOT_MAXEND : SLOT_MAXEND);
-				if (sp.ped && sp.pextra[step.index].nf == (uint32_t)PSLOT_FACT) ok = ok && p.fterms.size() == (size_t)p.n_cols * p.T * 16;
+				if (sp.ped && sp.pextra[step.index].nf == (uint32_t)PSLOT_FACT) ok = ok && p.fterm_kind == 1 && p.fterms.size() == (size_t)p.n_cols * p.T * 16;
+				else if (sp.ped && sp.pextra[step.index].nf == (uint32_t)PSLOT_FACT4) ok = ok && p.fterm_kind == 2 && p.fterms.size() == (size_t)p.n_cols * PSLOT_FSTRIDE4;
 				else if (sp.ped) for (uint32_t t = 0; t < p.T; ++t) ok = ok && p.term_end(c, t) - p.term_begin(c, t) <= sp.pextra[step.index].nf;
 				uint32_t used = 0;
 				for (uint32_t j = 0; j < bc.k; ++j) {   // distinct slots, ending reads local
@@ -553,7 +554,7 @@ whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uin
 			if (sp.ped) {
 				const PedSlotExtra& ex = sp.pextra[step.index];
 				s.max_lds_bytes = std::max<uint64_t>(s.max_lds_bytes, pedslot_lds_bytes(run.threads, run.ncols, ex));
-				if (ex.nf == (uint32_t)PSLOT_FACT) s.n_fact_runs++;
+				if (pslot_is_fact(ex.nf)) s.n_fact_runs++;
 				s.backtrace_bytes += ((uint64_t)ex.rec_words * 4) << run.g;
 			} else {
 				s.max_lds_bytes = std::max<uint64_t>(s.max_lds_bytes, slot_run_lds_bytes(run.threads, run.lr, run.ncols));

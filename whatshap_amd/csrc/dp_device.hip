@@ -1421,6 +1421,9 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, PSLOT_FACT, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, PSLOT_FACT, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_group<2, PSLOT_FACT>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, PSLOT_FACT4, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, PSLOT_FACT4, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_group<4, PSLOT_FACT4>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_group<2, 2>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_group<2, 4>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_group<4, 2>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1526,6 +1529,7 @@ void DeviceTable::Impl::launch_slot_run(const SlotBatchEntry& e, uint64_t& launc
 #endif
 #define WHAMD_PSLOT_LAUNCH(TBV, NFV, SPECV) hipLaunchKernelGGL((pedslot_run<TBV, NFV, SPECV>), grid, block, lds_ped, m.run_stream, m.dp, run, ex, e.prev, e.cur)
 		if (ex.tb == 2 && ex.nf == (uint32_t)PSLOT_FACT) { if (spec) WHAMD_PSLOT_LAUNCH(2, PSLOT_FACT, true); else WHAMD_PSLOT_LAUNCH(2, PSLOT_FACT, false); }
+		else if (ex.tb == 4 && ex.nf == (uint32_t)PSLOT_FACT4) { if (spec) WHAMD_PSLOT_LAUNCH(4, PSLOT_FACT4, true); else WHAMD_PSLOT_LAUNCH(4, PSLOT_FACT4, false); }
 		else if (ex.tb == 2 && ex.nf == 16) { if (spec) WHAMD_PSLOT_LAUNCH(2, 16, true); else WHAMD_PSLOT_LAUNCH(2, 16, false); }
 		else if (ex.tb == 2 && ex.nf == 2) { if (spec) WHAMD_PSLOT_LAUNCH(2, 2, true); else WHAMD_PSLOT_LAUNCH(2, 2, false); }
 		else if (ex.tb == 2) { if (spec) WHAMD_PSLOT_LAUNCH(2, 4, true); else WHAMD_PSLOT_LAUNCH(2, 4, false); }
@@ -1770,7 +1774,7 @@ whamd_status_t DeviceTable::enqueue_group(DeviceTable* const* tables, const Prob
 	};
 	std::vector<Part> parts(n_parts);
 	for (size_t i = 0; i < n_tables; ++i) parts[i % n_parts].members.push_back(i);
-	constexpr int NV = 10;  // kernel variants (6: single individual, eight cells per thread; 7: trio, factorised lines; 8 / 9: X runs of a single individual with four / eight cells per thread, slot_groupx)
+	constexpr int NV = 11;  // kernel variants (6: single individual, eight cells per thread; 7: trio, factorised lines; 8 / 9: X runs of a single individual with four / eight cells per thread, slot_groupx; 10: quartet, factorised lines)
 	for (Part& part : parts) { part.lead = tables[part.members[0]]->impl_; part.batches.resize(NV); }
 	auto abort_all = [&]() {
 		for (Part& part : parts) (void)hipStreamSynchronize(part.lead->stream);
@@ -1818,6 +1822,7 @@ whamd_status_t DeviceTable::enqueue_group(DeviceTable* const* tables, const Prob
 			case 4: hipLaunchKernelGGL((pedslot_group<4, 4>), grid, block, b.lds, stream, b.args); break;
 			case 5: hipLaunchKernelGGL((pedslot_group<2, 16>), grid, block, b.lds, stream, b.args); break;
 			case 7: hipLaunchKernelGGL((pedslot_group<2, PSLOT_FACT>), grid, block, b.lds, stream, b.args); break;
+			case 10: hipLaunchKernelGGL((pedslot_group<4, PSLOT_FACT4>), grid, block, b.lds, stream, b.args); break;
 			case 8: hipLaunchKernelGGL((slot_groupx<2, false>), grid, block, b.lds, stream, b.args); break;
 			case 9: hipLaunchKernelGGL((slot_groupx<3, false>), grid, block, b.lds, stream, b.args); break;
 			default:
@@ -1842,7 +1847,7 @@ whamd_status_t DeviceTable::enqueue_group(DeviceTable* const* tables, const Prob
 				for (uint32_t q = 0; q < ss.entry_count; ++q) {
 					const SlotBatchEntry& he = m.slot_entries[ss.entry_off + q];
 					const bool xrun = !m.splan.ped && (he.run.yflags & 8u) && !m.dp.dbg_flags;   // (the X kernel: operands streamed from the tables, 16 KB of LDS)
-					const int variant = m.splan.ped ? (he.ex.nf == (uint32_t)PSLOT_FACT ? 7 : (he.ex.nf == 16 ? 5 : 1 + (he.ex.tb == 4 ? 2 : 0) + (he.ex.nf == 4 ? 1 : 0))) : (he.run.lr == 3 ? (xrun ? 9 : 6) : (xrun ? 8 : 0));
+					const int variant = m.splan.ped ? (he.ex.nf == (uint32_t)PSLOT_FACT4 ? 10 : he.ex.nf == (uint32_t)PSLOT_FACT ? 7 : (he.ex.nf == 16 ? 5 : 1 + (he.ex.tb == 4 ? 2 : 0) + (he.ex.nf == 4 ? 1 : 0))) : (he.run.lr == 3 ? (xrun ? 9 : 6) : (xrun ? 8 : 0));
 					Batch& b = part.batches[variant];
 					if (b.args.n == (uint32_t)SLOT_GROUP_MAX) {
 						flush(part, variant);

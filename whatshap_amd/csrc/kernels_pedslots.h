@@ -18,8 +18,9 @@ __global__ __launch_bounds__(256) void pedslot_tables(DevProblem P, const SlotRu
                                                        uint32_t* __restrict__ tab, const DevTerm* __restrict__ fterms) {
 	const SlotRun& run = runs[blockIdx.y];
 	const PedSlotExtra& ex = extras[blockIdx.y];
-	const bool fact = ex.nf == (uint32_t)PSLOT_FACT;   // entries of the factorised line (Problem::fterms) instead of cost forms
-	const uint32_t TB = ex.tb, T = 1u << TB, NA = pslot_na(ex.nf), NS = pslot_ns(ex.nf), fwn = ex.fwn, L = run.L, nls = 6u - TB;
+	const bool fact4 = ex.nf == (uint32_t)PSLOT_FACT4;   // a quartet's line: per COLUMN (twenty entries), the same for every transmission value
+	const bool fact = ex.nf == (uint32_t)PSLOT_FACT || fact4;   // entries of the factorised line (Problem::fterms) instead of cost forms
+	const uint32_t TB = ex.tb, T = 1u << TB, TA = pslot_ta(ex.nf, T), NA = pslot_na(ex.nf), NS = pslot_ns(ex.nf), fwn = ex.fwn, L = run.L, nls = 6u - TB;
 	const uint32_t n_g = fwn << run.g, n_w = fwn << run.lw, n_s = run.ncols * 64u * NS, n_k = run.ncols * T * pslot_nk(ex.nf);
 	uint32_t* __restrict__ out = tab + (((unsigned long long)ex.g_hi << 32) | ex.g_lo);
 	// X runs (pedslot_runx_body): recombination cost and control word per column, the lanes' and the workgroups' tie parities (slots.h PedSlotExtra::x_off)
@@ -63,7 +64,8 @@ __global__ __launch_bounds__(256) void pedslot_tables(DevProblem P, const SlotRu
 		uint32_t kind, unit, c, t, f;
 		if (i >= n_g + n_w + n_s) {   // K [c][t][12]: the constants of the factorised line (entries 4 .. 15 of the column's sixteen)
 			const uint32_t r = i - n_g - n_w - n_s;
-			out[i] = fterms[((size_t)run.c0 * T + r / PSLOT_NK) * 16u + 4u + r % PSLOT_NK].c;
+			out[i] = fact4 ? fterms[((size_t)run.c0 + r / PSLOT_NK4) * PSLOT_FSTRIDE4 + 4u + r % PSLOT_NK4].c
+			               : fterms[((size_t)run.c0 * T + r / PSLOT_NK) * 16u + 4u + r % PSLOT_NK].c;
 			continue;
 		}
 		if (i < n_g + n_w) {
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(256) void pedslot_tables(DevProblem P, const SlotRu
 			const uint32_t r = kind ? i - n_g : i;
 			unit = r / fwn;
 			const uint32_t q = r % fwn;   // [c][t][f]
-			c = q / (T * NA); t = (q / NA) % T; f = q % NA;
+			c = q / (TA * NA); t = (q / NA) % TA; f = q % NA;
 		} else {
 			kind = 2u;
 			const uint32_t r = i - n_g - n_w;   // [c][lane][f]
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(256) void pedslot_tables(DevProblem P, const SlotRu
 		const uint32_t q0 = P.term_ptr[col.term_off + t] + f, q1 = P.term_ptr[col.term_off + t + 1];
 		uint32_t acc = kind == 0u ? 0xFFFFFFFFu : 0u;   // absent form: INF + 0 + 0
 		if (fact || q0 < q1) {
-			const DevTerm tm = fact ? fterms[((size_t)(run.c0 + c) * T + t) * 16u + f] : P.terms[q0];
+			const DevTerm tm = fact4 ? fterms[(size_t)(run.c0 + c) * PSLOT_FSTRIDE4 + f] : (fact ? fterms[((size_t)(run.c0 + c) * T + t) * 16u + f] : P.terms[q0]);
 			acc = kind == 0u ? tm.c : 0u;
 			uint32_t s0, s1, bits;
 			if (kind == 0u) { s0 = L; s1 = L + run.g; bits = unit; }
@@ -122,6 +124,10 @@ __device__ __forceinline__ void pedslot_run_body(const DevProblem& P, const Slot
 	constexpr uint32_t T = 1u << TB;
 	constexpr int NLS = 6 - TB;   // lane slots
 	constexpr bool FACT = NF == PSLOT_FACT;          // the factorised line of a trio with untrusted genotypes (slots.h)
+	constexpr bool FACT4 = NF == PSLOT_FACT4;        // ... of a quartet: A and K per column (the same for every transmission value), sixteen constants
+	static_assert(!FACT4 || TB == 4, "PSLOT_FACT4 is the line of a quartet");
+	constexpr uint32_t TA = FACT4 ? 1u : T;          // values per column in A (and K)
+	constexpr int KL = FACT4 ? (int)PSLOT_NK4 : (NF == PSLOT_FACT ? (int)PSLOT_NK : 1);   // constants a lane reads per column
 	constexpr int NA = (int)pslot_na(NF), NS = (int)pslot_ns(NF), NK = (int)pslot_nk(NF);   // words per (column, value) of A, per (column, lane) of S, per (column, value) of K
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
 	const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -147,7 +153,7 @@ __device__ __forceinline__ void pedslot_run_body(const DevProblem& P, const Slot
 	// 300 words were five L2 round trips in a row -- 1.26 -> 1.41 M columns/s with six batches.  A trio with trusted genotypes has 104 words:
 	// two batches, and four measured 7 % slower there.)
 	const uint32_t fwn = ex.fwn;
-	constexpr int AB = (TB == 2 && NF == 2) ? 2 : 6;
+	constexpr int AB = ((TB == 2 && NF == 2) || FACT4) ? 2 : 6;
 	uint32_t ga[AB], wa[AB];
 #pragma unroll
 	for (int u = 0; u < AB; ++u) {
@@ -167,7 +173,7 @@ __device__ __forceinline__ void pedslot_run_body(const DevProblem& P, const Slot
 	// (3b) K: the constants of the factorised lines, the same for every workgroup and wave: at most 32 * 4 * 12 words = 384 16-byte pieces -- one per
 	// thread of a full workgroup, up to six per thread of a 64-thread one (small tables)
 	constexpr int KB = FACT ? 6 : 1;
-	const uint32_t n_k4 = FACT ? ncols * T * (NK / 4) : 0u;
+	const uint32_t n_k4 = FACT ? ncols * T * (NK / 4) : (FACT4 ? ncols * (PSLOT_NK4 / 4) : 0u);   // (a quartet's: at most 128 pieces, the loop below takes what a 64-thread workgroup leaves)
 	uint4 kp[KB];
 #pragma unroll
 	for (int u = 0; u < KB; ++u) {
@@ -194,6 +200,7 @@ __device__ __forceinline__ void pedslot_run_body(const DevProblem& P, const Slot
 		const uint32_t i = (uint32_t)u * threads + tid;
 		if (i < n_k4) reinterpret_cast<uint4*>(k_lds)[i] = kp[u];
 	}
+	if (FACT4) for (uint32_t i = (uint32_t)KB * threads + tid; i < n_k4; i += threads) reinterpret_cast<uint4*>(k_lds)[i] = reinterpret_cast<const uint4*>(tabG + ex.s_off + ncols * 64u * NS)[i];
 	uint32_t* a_row = a_lds + wave * (ex.arow + 4u * T * NA);
 #pragma unroll
 	for (int u = 0; u < AB; ++u) {
@@ -219,11 +226,14 @@ __device__ __forceinline__ void pedslot_run_body(const DevProblem& P, const Slot
 
 	// What a column needs from LDS, requested ahead (LDS returns in order): {recomb, M0} of the hot line (wave-uniform words in
 	// VECTOR registers, see kernels_slots.h), the lane's NF entries of A and of S.
-	struct Line { uint2 h; uint32_t a[NA]; uint32_t s[NS]; uint32_t k[NK > 0 ? NK : 1]; };
-	const uint32_t a_base = wave * (ex.arow + 4u * T * NA) + t * NA;
+	struct Line { uint2 h; uint32_t a[NA]; uint32_t s[NS]; uint32_t k[KL]; };
+	const uint32_t a_base = wave * (ex.arow + 4u * T * NA) + (FACT4 ? 0u : t * NA);
+	// a quartet's factorised line: how this lane's transmission value wires the children to the founders' haplotypes (slots.h, Problem::fact4_roles)
+	const bool r_u1 = FACT4 && ((ex.pad[0] >> t) & 1u), r_v1 = FACT4 && ((ex.pad[0] >> (16u + t)) & 1u);
+	const bool r_su = FACT4 && ((ex.pad[1] >> t) & 1u), r_sv = FACT4 && ((ex.pad[1] >> (16u + t)) & 1u);
 	// (lines are requested in column order: three running word offsets advance by a constant per request -- kernels_slots.h; the one of
 	// the hot line starts from an opaque move so that the compiler does not learn that its loads are wave-uniform)
-	uint32_t hot_at = 0, a_at = a_base, s_at = lane * NS, k_at = t * NK;
+	uint32_t hot_at = 0, a_at = a_base, s_at = lane * NS, k_at = FACT4 ? 0u : t * NK;
 	asm volatile("" : "+v"(hot_at));
 	auto load_line = [&](uint32_t) -> Line {   // (the argument documents which column a call site requests: always the next one)
 		Line ln;
@@ -231,7 +241,7 @@ __device__ __forceinline__ void pedslot_run_body(const DevProblem& P, const Slot
 		const uint32_t* ap = a_lds + a_at;
 		const uint32_t* spn = s_lds + s_at;
 		hot_at += 8u;
-		a_at += T * NA;
+		a_at += TA * NA;
 		s_at += 64u * NS;
 		if constexpr (FACT) {   // one 16-byte read of A, one of S, three of K
 			const uint4 av = *reinterpret_cast<const uint4*>(ap), sv = *reinterpret_cast<const uint4*>(spn);
@@ -241,6 +251,14 @@ __device__ __forceinline__ void pedslot_run_body(const DevProblem& P, const Slot
 			k_at += T * NK;
 #pragma unroll
 			for (int q = 0; q < 3; ++q) { const uint4 kv = kq[q]; ln.k[4 * q] = kv.x; ln.k[4 * q + 1] = kv.y; ln.k[4 * q + 2] = kv.z; ln.k[4 * q + 3] = kv.w; }
+		} else if constexpr (FACT4) {   // one 16-byte read of A, one of S, four of K (the same addresses for the sixteen lanes of a cell / for every lane)
+			const uint4 av = *reinterpret_cast<const uint4*>(ap), sv = *reinterpret_cast<const uint4*>(spn);
+			ln.a[0] = av.x; ln.a[1] = av.y; ln.a[2] = av.z; ln.a[3] = av.w;
+			ln.s[0] = sv.x; ln.s[1] = sv.y; ln.s[2] = sv.z; ln.s[3] = sv.w;
+			const uint4* kq = reinterpret_cast<const uint4*>(k_lds + k_at);
+			k_at += PSLOT_NK4;
+#pragma unroll
+			for (int q = 0; q < 4; ++q) { const uint4 kv = kq[q]; ln.k[4 * q] = kv.x; ln.k[4 * q + 1] = kv.y; ln.k[4 * q + 2] = kv.z; ln.k[4 * q + 3] = kv.w; }
 		} else if (NF == 2) {
 			const uint2 av = *reinterpret_cast<const uint2*>(ap), sv = *reinterpret_cast<const uint2*>(spn);
 			ln.a[0] = av.x; ln.a[1] = av.y; ln.s[0] = sv.x; ln.s[1] = sv.y;
@@ -266,6 +284,8 @@ __device__ __forceinline__ void pedslot_run_body(const DevProblem& P, const Slot
 			const uint32_t t00 = ln.k[8] + M0 + F0, t01 = ln.k[9] + C + M0 + F1;
 			const uint32_t t10 = ln.k[10] - C + M1 + F0, t11 = ln.k[11] + M1 + F1;
 			cost = min(min(t00, t01), min(t10, t11));
+		} else if constexpr (FACT4) {   // (slots.h: the minimum over the sixteen allele assignments by elimination)
+			cost = pslot_fact4_cost(ln.a[0] + ln.s[0], ln.a[1] + ln.s[1], ln.a[2] + ln.s[2], ln.a[3] + ln.s[3], ln.k, r_u1, r_v1, r_su, r_sv);
 		} else {
 			cost = ln.a[0] + ln.s[0];
 #pragma unroll

@@ -50,10 +50,11 @@ uint32_t pedslot_table_entry(const Problem& p, const SlotPlan& plan, uint32_t ru
 	const PedSlotExtra& ex = plan.pextra[run_index];
 	const PedSlotRow& row = plan.prows[run.row_off + c];
 	const uint32_t col = run.c0 + c;
-	const bool fact = ex.nf == (uint32_t)PSLOT_FACT;   // entry f of the factorised line (Problem::fterms): always present
+	const bool fact4 = ex.nf == (uint32_t)PSLOT_FACT4;   // a quartet's line: per column, the same for every transmission value
+	const bool fact = ex.nf == (uint32_t)PSLOT_FACT || fact4;   // entry f of the factorised line (Problem::fterms): always present
 	const uint64_t q = p.term_begin(col, t) + f;
 	if (!fact && q >= p.term_end(col, t)) return kind == 0 ? INF : 0u;   // absent form: INF + 0 + 0
-	const CostTerm& tm = fact ? p.fterms[((size_t)col * p.T + t) * 16 + f] : p.terms[q];
+	const CostTerm& tm = fact4 ? p.fterms[(size_t)col * PSLOT_FSTRIDE4 + f] : (fact ? p.fterms[((size_t)col * p.T + t) * 16 + f] : p.terms[q]);
 	const uint32_t nls = 6u - ex.tb;
 	uint32_t acc = kind == 0 ? tm.c : 0u;
 	uint32_t s0, s1, bits;
@@ -163,6 +164,12 @@ bool emulate_pedslot_plan(const Problem& p, const SlotPlan& plan, std::vector<ui
 						const uint32_t M0 = std::min(a[4], a[5] + X), M1 = std::min(a[6], a[7] - X);
 						const uint32_t F0 = std::min(a[8], a[9] + Y), F1 = std::min(a[10], a[11] - Y);
 						cost = std::min(std::min(a[12] + M0 + F0, a[13] + C + M0 + F1), std::min(a[14] - C + M1 + F0, a[15] + M1 + F1));
+					} else if (ex.nf == (uint32_t)PSLOT_FACT4) {   // a quartet's factorised line: the tables per column, the wiring from the lane's transmission value
+						uint32_t L4[4], k[16];
+						for (uint32_t f = 0; f < 4; ++f)
+							L4[f] = pedslot_table_entry(p, plan, st.index, 0, w, ci, 0, f) + pedslot_table_entry(p, plan, st.index, 1, wave, ci, 0, f) + pedslot_table_entry(p, plan, st.index, 2, lane, ci, t, f);
+						for (uint32_t f = 0; f < 16; ++f) k[f] = p.fterms[(size_t)(run.c0 + ci) * PSLOT_FSTRIDE4 + 4 + f].c;
+						cost = pslot_fact4_cost(L4[0], L4[1], L4[2], L4[3], k, bit(ex.pad[0], t), bit(ex.pad[0], 16 + t), bit(ex.pad[1], t), bit(ex.pad[1], 16 + t));
 					} else
 					for (uint32_t f = 0; f < ex.nf; ++f) {
 						const uint32_t a = pedslot_table_entry(p, plan, st.index, 0, w, ci, t, f) + pedslot_table_entry(p, plan, st.index, 1, wave, ci, t, f);

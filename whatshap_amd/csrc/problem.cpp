@@ -372,7 +372,92 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 		if (!r.ok) want_fact = false;
 		roles[t] = r;
 	}
-	if (want_fact) p.fterms.resize((size_t)n * p.T * 16);   // (every entry is written below)
+	if (want_fact) { p.fterms.resize((size_t)n * p.T * 16); p.fterm_kind = 1; }   // (every entry is written below)
+	// ---- a quartet (two children of the same two founders, T = 16): the same idea in HAPLOTYPE space (slots.h PSLOT_FACT4).  With (a0, a1) the alleles on X's
+	// haplotypes and (b0, b1) on Y's, child k carries (a_uk, b_vk) where (u_k, v_k) is read off the haplotype-to-partition map of the transmission value:
+	//   cost = g_X[a0 + a1] + cost_X(a0, a1) + g_Y[b0 + b1] + cost_Y(b0, b1) + sum over the children of g_Ck[a_uk + b_vk] + cost_Ck(a_uk, b_vk).
+	// Nothing but the wiring depends on the value: ONE line of twenty entries per column.  Checked like the trio's: every (column, value, assignment) against the generic term.
+	struct Fact4Roles {
+		int X = -1, Y = -1, C1 = -1, C2 = -1;
+		uint32_t px[2] = {0, 0}, py[2] = {0, 0};   // partitions of X's and Y's haplotypes
+		uint32_t u[2][16], v[2][16];               // per child and transmission value
+		bool ok = false;
+	} roles4;
+	bool want_fact4 = distrust && p.n_ind == 4 && p.P == 4 && p.T == 16 && p.n_triples == 2 && !columns_only && !getenv("WHAMD_NO_PED_FACT");
+	if (want_fact4) {
+		Fact4Roles& r = roles4;
+		const int8_t* map0 = p.h2p.data();
+		int n_children = 0;
+		for (uint32_t s = 0; s < 4; ++s) {
+			bool varies = false;
+			for (uint32_t tt = 1; tt < p.T; ++tt) {
+				const int8_t* mt = p.h2p.data() + (size_t)tt * p.n_ind * 2;
+				varies = varies || mt[2 * s] != map0[2 * s] || mt[2 * s + 1] != map0[2 * s + 1];
+			}
+			if (varies) { (n_children == 0 ? r.C1 : r.C2) = (int)s; ++n_children; }
+		}
+		r.ok = n_children == 2;
+		for (uint32_t s = 0; s < 4 && r.ok; ++s) {   // X transmits to haplotype 0 of child 1, Y to its haplotype 1
+			if ((int)s == r.C1 || (int)s == r.C2) continue;
+			for (int h = 0; h < 2; ++h) {
+				if (map0[2 * s + h] == map0[2 * r.C1]) r.X = (int)s;
+				if (map0[2 * s + h] == map0[2 * r.C1 + 1]) r.Y = (int)s;
+			}
+		}
+		r.ok = r.ok && r.X >= 0 && r.Y >= 0 && r.X != r.Y;
+		if (r.ok) {
+			for (int h = 0; h < 2; ++h) { r.px[h] = (uint32_t)map0[2 * r.X + h]; r.py[h] = (uint32_t)map0[2 * r.Y + h]; }
+			for (uint32_t t = 0; t < 16 && r.ok; ++t) {
+				const int8_t* mt = p.h2p.data() + (size_t)t * p.n_ind * 2;
+				r.ok = r.ok && (uint32_t)mt[2 * r.X] == r.px[0] && (uint32_t)mt[2 * r.X + 1] == r.px[1] && (uint32_t)mt[2 * r.Y] == r.py[0] && (uint32_t)mt[2 * r.Y + 1] == r.py[1];
+				for (int k = 0; k < 2 && r.ok; ++k) {
+					const int c = k == 0 ? r.C1 : r.C2;
+					const uint32_t h0 = (uint32_t)mt[2 * c], h1 = (uint32_t)mt[2 * c + 1];
+					r.ok = (h0 == r.px[0] || h0 == r.px[1]) && (h1 == r.py[0] || h1 == r.py[1]);
+					r.u[k][t] = h0 == r.px[1] ? 1u : 0u;
+					r.v[k][t] = h1 == r.py[1] ? 1u : 0u;
+				}
+			}
+		}
+		want_fact4 = r.ok;
+		if (want_fact4) {
+			p.fterms.resize((size_t)n * 20);
+			p.fterm_kind = 2;
+			p.fact4_roles[0] = p.fact4_roles[1] = 0;
+			for (uint32_t t = 0; t < 16; ++t) {
+				p.fact4_roles[0] |= (r.u[0][t] << t) | (r.v[0][t] << (16 + t));
+				p.fact4_roles[1] |= ((r.u[0][t] == r.u[1][t] ? 1u : 0u) << t) | ((r.v[0][t] == r.v[1][t] ? 1u : 0u) << (16 + t));
+			}
+		}
+	}
+	// the twenty entries of column c: the signed sums L_X, L_Y, L_C1, L_C2, then per individual the cost of carrying (h0, h1) = 00, 01 (+ L), 10 (- L), 11
+	auto factorised_line4 = [&](uint32_t c, const std::vector<uint32_t>& R, const std::vector<uint32_t>& W) -> CostTerm* {
+		const Fact4Roles& r = roles4;
+		auto g = [&](int s, uint32_t k) { return (uint32_t)(0.0 + p.gl[((size_t)s * p.n_variants + c) * 3 + k]); };
+		CostTerm* ft = p.fterms.data() + (size_t)c * 20;
+		const int who[4] = {r.X, r.Y, r.C1, r.C2};
+		for (int i = 0; i < 4; ++i) {
+			const int s = who[i];
+			ft[i] = CostTerm{0, 1u << s, 0};
+			ft[4 + 4 * i + 0] = CostTerm{g(s, 0) + R[s], 0, 0};
+			ft[4 + 4 * i + 1] = CostTerm{g(s, 1) + R[s], 0, 0};          // + L_s
+			ft[4 + 4 * i + 2] = CostTerm{g(s, 1) + W[s] - R[s], 0, 0};   // - L_s
+			ft[4 + 4 * i + 3] = CostTerm{g(s, 2) + W[s] - R[s], 0, 0};
+		}
+		return ft;
+	};
+	auto factorised_form4 = [&](const CostTerm* ft, uint32_t t, uint32_t asg) -> CostTerm {
+		const Fact4Roles& r = roles4;
+		const uint32_t a[2] = {(asg >> r.px[0]) & 1u, (asg >> r.px[1]) & 1u}, b[2] = {(asg >> r.py[0]) & 1u, (asg >> r.py[1]) & 1u};
+		const uint32_t h[4][2] = {{a[0], a[1]}, {b[0], b[1]}, {a[r.u[0][t]], b[r.v[0][t]]}, {a[r.u[1][t]], b[r.v[1][t]]}};
+		const int who[4] = {r.X, r.Y, r.C1, r.C2};
+		CostTerm tm{0, 0, 0};
+		for (int i = 0; i < 4; ++i) {
+			tm.c += ft[4 + 4 * i + h[i][0] * 2 + h[i][1]].c;
+			if (h[i][0] != h[i][1]) (h[i][0] == 0 ? tm.plus : tm.minus) |= 1u << who[i];
+		}
+		return tm;
+	};
 	// the sixteen entries of (c, t): three signed sums {X_L, Y_L, C_L, 0}, then kx[4], ky[4], cc[4]
 	auto factorised_line = [&](uint32_t c, uint32_t t, const std::vector<uint32_t>& R, const std::vector<uint32_t>& W) -> CostTerm* {
 		const FactRoles& r = roles[t];
@@ -435,6 +520,7 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 			const int8_t* map = p.h2p.data() + (size_t)t * p.n_ind * 2;
 			const size_t begin = out.terms.size();
 			const CostTerm* fline = (want_fact && out.fact_ok) ? factorised_line(c, t, R, W) : nullptr;
+			const CostTerm* fline4 = (want_fact4 && out.fact_ok) ? (t == 0 ? factorised_line4(c, R, W) : p.fterms.data() + (size_t)c * 20) : nullptr;
 			for (uint32_t a = 0; a < (1u << p.P); ++a) {  // src/pedigreecolumncostcomputer.cpp:25-49
 				bool compatible = true;
 				uint32_t acost = 0;
@@ -461,6 +547,10 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 				if (fline) {
 					const CostTerm pred = factorised_form(fline, t, a);
 					if (pred.c != term.c || pred.plus != term.plus || pred.minus != term.minus) { out.fact_ok = false; fline = nullptr; }
+				}
+				if (fline4) {
+					const CostTerm pred = factorised_form4(fline4, t, a);
+					if (pred.c != term.c || pred.plus != term.plus || pred.minus != term.minus) { out.fact_ok = false; fline4 = nullptr; }
 				}
 				// a term with the same L-dependence and a constant that is not smaller can never be the strict minimum
 				bool dominated = false;
@@ -553,7 +643,7 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 			}
 			base[t + 1] = base[t] + parts[t].terms.size();
 			bound += parts[t].bound;
-			if (!parts[t].fact_ok) p.fterms.clear();
+			if (!parts[t].fact_ok) { p.fterms.clear(); p.fterm_kind = 0; }
 			p.n_cells += parts[t].n_cells;
 			p.algorithmic_bytes += parts[t].algorithmic_bytes;
 		}

@@ -77,6 +77,12 @@ struct Problem {
 	// individuals (build_problem; kernels_pedslots.h PSLOT_FACT) -- 16 entries per (column, transmission value): three signed sums
 	// {L_X, L_Y, L_child, 0} and twelve constants.  Empty when the table is not of that shape.
 	RawVec<CostTerm> fterms;         // [n_cols * T * 16]
+	// fterm_kind 2: a QUARTET (two children of the same two founders) whose genotypes are not trusted -- in haplotype space the line does not depend on the
+	// transmission value: fterms is [n_cols * 20] (four signed sums L_X, L_Y, L_C1, L_C2, then the costs of X, Y, C1, C2 carrying (h0, h1) = 00, 01, 10, 11), and the
+	// value only wires the children to the founders' haplotypes: fact4_roles = {u_1 | v_1 << 16, (u_1 == u_2) | (v_1 == v_2) << 16}, bit t of each 16-bit mask
+	// (slots.h PSLOT_FACT4).
+	uint32_t fterm_kind = 0;         // 0 none, 1 trio (16 entries per (column, value)), 2 quartet (20 per column)
+	uint32_t fact4_roles[2] = {0, 0};
 	// per column and individual: signed per-bit deltas d (REF +q, ALT -q, BLANK 0) of L_s(x) - R_s
 	RawVec<int32_t> delta;  // [col_ptr[c] * n_ind ... ): for column c, delta[(col_ptr[c] * n_ind) + s * k_c + bit]
 	uint32_t max_k = 0;

@@ -43,7 +43,9 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 	if (!ped && !(p.T == 1 && p.n_ind == 1)) return false;
 	if (!genotype_mode && !(p.value_bound < 1073741824.0)) return false;
 	plan.ped = ped;
-	const bool fact = ped && !genotype_mode && TB == 2 && !p.fterms.empty();   // a trio with untrusted genotypes: factorised lines (PSLOT_FACT)
+	// a trio / a quartet with untrusted genotypes: factorised lines (PSLOT_FACT, PSLOT_FACT4)
+	const uint32_t fact_nf = (ped && !genotype_mode && !p.fterms.empty()) ? (TB == 2 && p.fterm_kind == 1 ? (uint32_t)PSLOT_FACT : (TB == 4 && p.fterm_kind == 2 ? (uint32_t)PSLOT_FACT4 : 0u)) : 0u;
+	const bool fact = fact_nf != 0;
 	lr = ped ? 0 : std::max(1, std::min(lr, SLOT_LR));
 	const int n_lane = ped ? 6 - (int)TB : SLOT_LANE;
 	plan.col_to_row.assign(n, -1);
@@ -193,12 +195,12 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 				// at most PSLOT_MAXFORMS forms per transmission value; the run's tables grow with the widest column (NF 2 -> 4)
 				uint32_t most = 0;
 				for (uint32_t t = 0; t < p.T; ++t) most = std::max<uint32_t>(most, (uint32_t)(p.term_end(c1, t) - p.term_begin(c1, t)));
-				if (most > (uint32_t)PSLOT_MAXFORMS || (most > 4u && TB != 2u)) {   // (sixteen forms: the trio kernel only)
+				if (!fact && (most > (uint32_t)PSLOT_MAXFORMS || (most > 4u && TB != 2u))) {   // (sixteen forms: the trio kernel only)
 					if (debug_env("WHAMD_DEBUG_PLAN")) fprintf(stderr, "[plan] column %u: %u cost forms per transmission value: no pedigree run\n", c1, most);
 					break;
 				}
-				const uint32_t nf = fact ? pslot_na(PSLOT_FACT) : std::max(run_forms, most > 4 ? 16u : (most > 2 ? 4u : 2u));
-				if ((c1 - c + 1) * p.T * nf > (uint32_t)PSLOT_FORMWORDS) break;
+				const uint32_t nf = fact ? pslot_na(fact_nf) : std::max(run_forms, most > 4 ? 16u : (most > 2 ? 4u : 2u));
+				if ((c1 - c + 1) * pslot_ta(fact_nf, p.T) * nf > (uint32_t)PSLOT_FORMWORDS) break;
 				run_forms = nf;
 			}
 			for (uint32_t j = 0; j < bc && ok; ++j) ok = slot_of[col[j].read_id] >= 0;   // every shared read is tracked
@@ -377,8 +379,9 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 					const uint32_t cnt = (uint32_t)(p.term_end(c + i, t) - p.term_begin(c + i, t));
 					ex.nf = std::max(ex.nf, cnt > 4 ? 16u : (cnt > 2 ? 4u : 2u));
 				}
-			if (fact) ex.nf = PSLOT_FACT;
-			ex.fwn = d.ncols * p.T * pslot_na(ex.nf);
+			if (fact) ex.nf = fact_nf;
+			if (fact_nf == (uint32_t)PSLOT_FACT4) { ex.pad[0] = p.fact4_roles[0]; ex.pad[1] = p.fact4_roles[1]; }
+			ex.fwn = d.ncols * pslot_ta(ex.nf, p.T) * pslot_na(ex.nf);
 			ex.arow = (ex.fwn + 3u) & ~3u;
 			ex.rec_words = ((d.ncols + 3u) / 4u) * (64u << d.lw);
 			plan.pextra.push_back(ex);
@@ -513,7 +516,7 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 			// X runs (kernels_pedslots.h, pedslot_runx): per-column scalars and the lanes' tie parities behind the cost tables.  An experiment of the debug
 			// library only (WHAMD_PED_XRUN=1): bit-identical, but 8.4 against 6.1 us per launch on a trio at coverage 15 -- the costs of every column formed by
 			// every thread are ~100 four-byte loads per thread, where pedslot_run stages the tables once per wave.
-			if (run.ncols <= (uint32_t)SLOT_XCOLS && run.n_ends <= (uint32_t)SLOT_XENDS && debug_env("WHAMD_PED_XRUN") && !debug_env("WHAMD_NO_XRUN")) {
+			if (run.ncols <= (uint32_t)SLOT_XCOLS && run.n_ends <= (uint32_t)SLOT_XENDS && ex.nf != (uint32_t)PSLOT_FACT4 && debug_env("WHAMD_PED_XRUN") && !debug_env("WHAMD_NO_XRUN")) {
 				plan.runs[ri].yflags |= 8u;
 				ex.x_off = (uint32_t)(words - (((uint64_t)ex.g_hi << 32) | ex.g_lo));
 				words += (pslotx_words(run.ncols, run.threads, run.g) + 3u) & ~(uint64_t)3;

@@ -142,9 +142,48 @@ constexpr int PSLOT_FORMWORDS = 1024;  // ncols * T * NF of one run (one row per
 // 19 operations per cell instead of 16 adds and 15 minima; a quarter of the per-wave and lane tables.
 constexpr int PSLOT_FACT = 1;
 constexpr uint32_t PSLOT_NK = 12;   // constants per (column, value) of a factorised line
-constexpr uint32_t pslot_na(uint32_t nf) { return nf == (uint32_t)PSLOT_FACT ? 4u : nf; }    // words per (column, value) of G / W / A
-constexpr uint32_t pslot_ns(uint32_t nf) { return nf == (uint32_t)PSLOT_FACT ? 4u : nf; }    // words per (column, lane) of S
-constexpr uint32_t pslot_nk(uint32_t nf) { return nf == (uint32_t)PSLOT_FACT ? PSLOT_NK : 0u; }   // words per (column, value) of K
+// NF = PSLOT_FACT4: the factorised line of a QUARTET (two children of the same two founders, T = 16) with untrusted genotypes (Problem::fterms, fterm_kind 2).
+// In haplotype space nothing depends on the transmission value: four signed sums {L_X, L_Y, L_C1, L_C2} and sixteen constants k[4 i + (h0 h1)] -- the cost of
+// individual i = X, Y, C1, C2 carrying alleles (h0, h1): 00, 01 (+ L_i), 10 (- L_i), 11 -- per COLUMN; the tables G, W, A hold four words per column (not per
+// value), K sixteen.  The transmission value only WIRES the children to the founders' haplotypes: child k carries X's haplotype u_k and Y's haplotype v_k, and
+// a lane reads four predicates of its value from two words of PedSlotExtra (u_1, v_1, u_1 == u_2, v_1 == v_2).  pslot_fact4_cost below is the minimum over the
+// sixteen allele assignments by elimination (55 operations; 16 forms would be 16 words per (column, value, lane) -- four columns per run).
+constexpr int PSLOT_FACT4 = 3;
+constexpr uint32_t PSLOT_NK4 = 16;  // constants per COLUMN of a quartet's factorised line
+constexpr uint32_t PSLOT_FSTRIDE4 = 20;   // Problem::fterms entries per column (fterm_kind 2): 4 signed sums + 16 constants
+constexpr bool pslot_is_fact(uint32_t nf) { return nf == (uint32_t)PSLOT_FACT || nf == (uint32_t)PSLOT_FACT4; }
+constexpr uint32_t pslot_na(uint32_t nf) { return pslot_is_fact(nf) ? 4u : nf; }    // words per (column, value) of G / W / A
+constexpr uint32_t pslot_ns(uint32_t nf) { return pslot_is_fact(nf) ? 4u : nf; }    // words per (column, lane) of S
+constexpr uint32_t pslot_nk(uint32_t nf) { return nf == (uint32_t)PSLOT_FACT ? PSLOT_NK : (nf == (uint32_t)PSLOT_FACT4 ? 1u : 0u); }   // words per (column, value) of K (PSLOT_FACT4: T * 1 = 16 per column)
+constexpr uint32_t pslot_ta(uint32_t nf, uint32_t T) { return nf == (uint32_t)PSLOT_FACT4 ? 1u : T; }   // values per column in the tables G / W / A
+// The cost of one cell of a quartet whose genotypes are not trusted (shared by the kernel, kernels_pedslots.h, and the CPU emulation of the plan).
+//   cost = min over the founders' alleles (a0, a1) of X, (b0, b1) of Y of  Mo[a0 a1] + Fa[b0 b1] + C1[a_u1, b_v1] + C2[a_u2, b_v2]
+// In "transmitted" coordinates of child 1 -- a = a_u1, a' = X's other allele, b = b_v1, b' -- the founders' mixed entries swap with u_1 / v_1, child 1 reads
+// (a, b) and child 2 reads (a or a', b or b').  Elimination: Z_q[b] = min over b' of Fa'[b b'] + C2[q, b or b'];  H[p][q] = min over b of C1[p b] + Z_q[b];
+// cost = min over (a, a') of Mo'[a a'] + H[a][a or a'].  Every entry is a true cost (non-negative, below 2^30: Problem::value_bound), BIG only ever loses.
+#if defined(__HIPCC__)
+#define WHAMD_HD __host__ __device__
+#else
+#define WHAMD_HD
+#endif
+WHAMD_HD inline uint32_t pslot_min2(uint32_t a, uint32_t b) { return a < b ? a : b; }
+WHAMD_HD inline uint32_t pslot_fact4_cost(uint32_t LX, uint32_t LY, uint32_t L1, uint32_t L2, const uint32_t (&k)[16], bool u1, bool v1, bool same_u, bool same_v) {
+	constexpr uint32_t BIG = 0x40000000u;
+	const uint32_t mo01 = k[1] + LX, mo10 = k[2] - LX, fa01 = k[5] + LY, fa10 = k[6] - LY;
+	const uint32_t c1[2][2] = {{k[8], k[9] + L1}, {k[10] - L1, k[11]}}, c2[2][2] = {{k[12], k[13] + L2}, {k[14] - L2, k[15]}};
+	const uint32_t m01 = u1 ? mo10 : mo01, m10 = u1 ? mo01 : mo10;   // Mo'[a a']
+	const uint32_t f01 = v1 ? fa10 : fa01, f10 = v1 ? fa01 : fa10;   // Fa'[b b']
+	// child 2 reads b: the other allele b' is free -- Fa' collapses to its row minima on the diagonal
+	const uint32_t F0 = pslot_min2(k[4], f01), F1 = pslot_min2(f10, k[7]);
+	const uint32_t fs00 = same_v ? F0 : k[4], fs01 = same_v ? BIG : f01, fs10 = same_v ? BIG : f10, fs11 = same_v ? F1 : k[7];
+	uint32_t H[2][2];
+	for (int q = 0; q < 2; ++q) {
+		const uint32_t z0 = pslot_min2(fs00 + c2[q][0], fs01 + c2[q][1]), z1 = pslot_min2(fs10 + c2[q][0], fs11 + c2[q][1]);
+		for (int p = 0; p < 2; ++p) H[p][q] = pslot_min2(c1[p][0] + z0, c1[p][1] + z1);
+	}
+	const uint32_t h01 = same_u ? H[0][0] : H[0][1], h10 = same_u ? H[1][1] : H[1][0];
+	return pslot_min2(pslot_min2(k[0] + H[0][0], k[3] + H[1][1]), pslot_min2(m01 + h01, m10 + h10));
+}
 struct PedSlotRow {
 	// ---- hot: copied to LDS by the run kernel (8 words)
 	uint32_t recomb;
@@ -160,9 +199,10 @@ struct PedSlotRow {
 static_assert(sizeof(PedSlotRow) == 192, "PedSlotRow must stay 48 words");
 // Per run, next to its SlotRun (kernel argument by value).
 struct PedSlotExtra {
-	uint32_t tb, nf, fwn, arow;      // log2 T; forms per value (or PSLOT_FACT); ncols * T * pslot_na(nf); fwn rounded up to 4 (row stride of A in LDS)
+	uint32_t tb, nf, fwn, arow;      // log2 T; forms per value (or PSLOT_FACT / PSLOT_FACT4); ncols * pslot_ta(nf, T) * pslot_na(nf); fwn rounded up to 4 (row stride of A in LDS)
 	uint32_t g_lo, g_hi, w_off, s_off;   // word offsets into the table array: G [2^g][fwn]; W and S relative to G: [2^lw][fwn], [ncols][64][pslot_ns(nf)] (then K [ncols][T][pslot_nk(nf)])
 	uint32_t rec_words, x_off, pad[2];   // record of one workgroup: one byte per thread and column, 4 columns per word: ceil(ncols / 4) * threads words
+	                                 // pad (PSLOT_FACT4): bit t of the 16-bit masks u_1 | v_1 << 16 and (u_1 == u_2) | (v_1 == v_2) << 16 (Problem::fact4_roles)
 	                                 // x_off (SlotRun::yflags bit 3, pedslot_runx): relative to G like s_off -- recombination cost [ncols + SLOT_XPAD] (all-ones behind the
 	                                 // run: such a column changes nothing) | control word [ncols + SLOT_XPAD] (n_end | four fields of (slot | exchange buffer << 3) from bit 3) |
 	                                 // tie parities: [threads] words (bit e: parity of the lane's local cell index under the mask of the run's e-th ending read), [2^g] words
