@@ -1409,20 +1409,32 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		WHAMD_PSLOTX_ATTR(2, 2) WHAMD_PSLOTX_ATTR(2, 4) WHAMD_PSLOTX_ATTR(4, 2) WHAMD_PSLOTX_ATTR(4, 4) WHAMD_PSLOTX_ATTR(2, 16) WHAMD_PSLOTX_ATTR(2, PSLOT_FACT)
 #undef WHAMD_PSLOTX_ATTR
 #endif
-		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, 4, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, 4, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, 2, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, 2, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, 4, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, 4, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, 16, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, 16, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, 4, false, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, 4, false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, 4, true, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, 4, true, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, 2, false, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, 2, false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, 2, true, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, 2, true, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, 4, false, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, 4, false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, 4, true, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, 4, true, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, 16, false, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, 16, false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, 16, true, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, 16, true, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_group<2, 16>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, PSLOT_FACT, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, PSLOT_FACT, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, PSLOT_FACT, false, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, PSLOT_FACT, false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, PSLOT_FACT, true, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<2, PSLOT_FACT, true, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_group<2, PSLOT_FACT>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, PSLOT_FACT4, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, PSLOT_FACT4, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, PSLOT_FACT4, false, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, PSLOT_FACT4, false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, PSLOT_FACT4, true, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_run<4, PSLOT_FACT4, true, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_group<4, PSLOT_FACT4>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_group<2, 2>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((pedslot_group<2, 4>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1527,7 +1539,8 @@ void DeviceTable::Impl::launch_slot_run(const SlotBatchEntry& e, uint64_t& launc
 			return;
 		}
 #endif
-#define WHAMD_PSLOT_LAUNCH(TBV, NFV, SPECV) hipLaunchKernelGGL((pedslot_run<TBV, NFV, SPECV>), grid, block, lds_ped, m.run_stream, m.dp, run, ex, e.prev, e.cur)
+#define WHAMD_PSLOT_LAUNCH(TBV, NFV, SPECV) do { if (run.yflags & 16u) hipLaunchKernelGGL((pedslot_run<TBV, NFV, SPECV, true>), grid, block, lds_ped, m.run_stream, m.dp, run, ex, e.prev, e.cur); \
+		else hipLaunchKernelGGL((pedslot_run<TBV, NFV, SPECV, false>), grid, block, lds_ped, m.run_stream, m.dp, run, ex, e.prev, e.cur); } while (0)
 		if (ex.tb == 2 && ex.nf == (uint32_t)PSLOT_FACT) { if (spec) WHAMD_PSLOT_LAUNCH(2, PSLOT_FACT, true); else WHAMD_PSLOT_LAUNCH(2, PSLOT_FACT, false); }
 		else if (ex.tb == 4 && ex.nf == (uint32_t)PSLOT_FACT4) { if (spec) WHAMD_PSLOT_LAUNCH(4, PSLOT_FACT4, true); else WHAMD_PSLOT_LAUNCH(4, PSLOT_FACT4, false); }
 		else if (ex.tb == 2 && ex.nf == 16) { if (spec) WHAMD_PSLOT_LAUNCH(2, 16, true); else WHAMD_PSLOT_LAUNCH(2, 16, false); }

@@ -111,14 +111,13 @@ __device__ __forceinline__ uint32_t pslot_lane_xor(uint32_t v) {
 		const int h = __builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);
 		return (uint32_t)__builtin_amdgcn_mov_dpp(h, 0x1B, 0xF, 0xF, true);
 	}
-	// X == 8: row_mirror (i ^ 15) then row_half_mirror (i ^ 7)
-	const int h = __builtin_amdgcn_mov_dpp((int)v, 0x140, 0xF, 0xF, true);
-	return (uint32_t)__builtin_amdgcn_mov_dpp(h, 0x141, 0xF, 0xF, true);
+	// X == 8: row_ror:8 -- a rotation by half a row of sixteen lanes is i ^ 8 (one move; row_mirror then row_half_mirror were two)
+	return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xF, 0xF, true);
 }
 
 __device__ __forceinline__ uint32_t pslot_sat_add(uint32_t a, uint32_t b) { return __builtin_elementwise_add_sat(a, b); }
 
-template <int TB, int NF, bool SPEC>
+template <int TB, int NF, bool SPEC, bool PACKED>
 __device__ __forceinline__ void pedslot_run_body(const DevProblem& P, const SlotRun& run, const PedSlotExtra& ex, const uint32_t* __restrict__ prev,
                                                  uint32_t* __restrict__ cur, const uint32_t w) {
 	constexpr uint32_t T = 1u << TB;
@@ -273,6 +272,7 @@ __device__ __forceinline__ void pedslot_run_body(const DevProblem& P, const Slot
 		return ln;
 	};
 	uint32_t recacc = 0;
+	constexpr bool packed = PACKED;   // (SlotRun::yflags bit 4, slot_plan.cpp: every finite value of the table below 2^(31 - TB) - 1; chosen at the launch)
 	auto column = [&](const Line& ln, const uint32_t ci, const uint32_t ctrl, const int sub) {
 		const uint32_t rc = ln.h.x;
 		// cost of this lane's (cell, transmission value)
@@ -293,10 +293,27 @@ __device__ __forceinline__ void pedslot_run_body(const DevProblem& P, const Slot
 		}
 		// min over the previous transmission value j, argmin = lowest j
 		uint32_t v = D, j = t;
+		if constexpr (packed) {
+			// (value, j) as ONE key, value << TB | j: the minimum of two keys is the smaller value and, on ties, the lower j -- the rule of the staged
+			// comparison below, and a minimum is a minimum in any order.  A stage is the partner's key + the scaled recombination cost (the DPP move folds
+			// into the add) and a v_min: 2 instructions instead of 7 -- 9.  Nothing can wrap: the planner sets the flag when every finite value is below
+			// CL = 2^(31 - TB) - 1 (Problem::value_bound; it bounds 2 * triples * recomb of every column too), values at or above CL mean INFINITE and are
+			// clamped to CL when the key is formed -- keys stay below 2^31, key + cost below 2^32.
+			constexpr uint32_t CL = (1u << (31 - TB)) - 1u;
+			const uint32_t rcs = rc << TB;
+			uint32_t key = (min(D, CL) << TB) | t;
+			if (TB >= 1) key = min(key, pslot_lane_xor<1>(key) + rcs);
+			if (TB >= 2) key = min(key, pslot_lane_xor<2>(key) + rcs);
+			if (TB >= 3) key = min(key, pslot_lane_xor<4>(key) + rcs);
+			if (TB >= 4) key = min(key, pslot_lane_xor<8>(key) + rcs);
+			v = key >> TB;
+			j = key & (T - 1u);
+		} else {
 		if (TB >= 1) { const uint32_t pv = pslot_lane_xor<1>(v), pj = pslot_lane_xor<1>(j); const uint32_t cand = pslot_sat_add(pv, rc); const bool take = cand < pslot_sat_add(v, tbit[0]); v = take ? cand : v; j = take ? pj : j; }
 		if (TB >= 2) { const uint32_t pv = pslot_lane_xor<2>(v), pj = pslot_lane_xor<2>(j); const uint32_t cand = pslot_sat_add(pv, rc); const bool take = cand < pslot_sat_add(v, tbit[TB >= 2 ? 1 : 0]); v = take ? cand : v; j = take ? pj : j; }
 		if (TB >= 3) { const uint32_t pv = pslot_lane_xor<4>(v), pj = pslot_lane_xor<4>(j); const uint32_t cand = pslot_sat_add(pv, rc); const bool take = cand < pslot_sat_add(v, tbit[TB >= 3 ? 2 : 0]); v = take ? cand : v; j = take ? pj : j; }
 		if (TB >= 4) { const uint32_t pv = pslot_lane_xor<8>(v), pj = pslot_lane_xor<8>(j); const uint32_t cand = pslot_sat_add(pv, rc); const bool take = cand < pslot_sat_add(v, tbit[TB >= 4 ? 3 : 0]); v = take ? cand : v; j = take ? pj : j; }
+		}
 		D = pslot_sat_add(v, cost);
 		uint32_t byte = j;
 		const uint32_t n_end = ctrl & 3u;
@@ -379,6 +396,7 @@ __device__ __forceinline__ void pedslot_run_body(const DevProblem& P, const Slot
 #pragma unroll
 		for (int s = 0; s < SLOT_MAXSLOTS; ++s) idx |= (((Pcell & occ) >> s) & 1u) << slot_pos_dev(run.out_pos, s);
 		unsigned long long best_key = ~0ull;
+		if (packed && D >= (1u << (31 - TB)) - 1u) D = 0xFFFFFFFFu;   // (the keys' "infinite" back to the value every other kernel tests for)
 		if (writes) {
 			cur[(size_t)idx * T + t] = D;
 			if (SPEC) best_key = ((unsigned long long)D << 32) | (idx * T + t);
@@ -617,11 +635,11 @@ __global__ __launch_bounds__(512) void pedslot_runx(DevProblem P, SlotRun run, P
 }
 #endif
 
-template <int TB, int NF, bool SPEC>
+template <int TB, int NF, bool SPEC, bool PACKED>
 __global__ __launch_bounds__(512) void pedslot_run(DevProblem P, SlotRun run, PedSlotExtra ex, const uint32_t* __restrict__ prev,
                                                    uint32_t* __restrict__ cur) {
 	touch_kernel_arguments<sizeof(DevProblem) + sizeof(SlotRun) + sizeof(PedSlotExtra) + 16>();
-	pedslot_run_body<TB, NF, SPEC>(P, run, ex, prev, cur, blockIdx.x);
+	pedslot_run_body<TB, NF, SPEC, PACKED>(P, run, ex, prev, cur, blockIdx.x);
 }
 
 // One launch = the next run of SEVERAL pedigree tables (see slot_group, kernels_slots.h): blockIdx.y selects the table's entry.
@@ -634,7 +652,12 @@ __global__ __launch_bounds__(512, NF == 2 ? 8 : (NF == 4 ? 4 : 2)) void pedslot_
 	const SlotRun& run = e.run;
 	if (who.w >= (1u << run.g) || threadIdx.x >= run.threads) return;
 	const DevProblem P = slot_entry_problem(e, true);
-	if (run.spec_id) pedslot_run_body<TB, NF, true>(P, run, e.ex, e.prev, e.cur, who.w);
-	else pedslot_run_body<TB, NF, false>(P, run, e.ex, e.prev, e.cur, who.w);
+	if (run.yflags & 16u) {   // the min-plus step on packed keys (one branch per launch, wave-uniform)
+		if (run.spec_id) pedslot_run_body<TB, NF, true, true>(P, run, e.ex, e.prev, e.cur, who.w);
+		else pedslot_run_body<TB, NF, false, true>(P, run, e.ex, e.prev, e.cur, who.w);
+	} else {
+		if (run.spec_id) pedslot_run_body<TB, NF, true, false>(P, run, e.ex, e.prev, e.cur, who.w);
+		else pedslot_run_body<TB, NF, false, false>(P, run, e.ex, e.prev, e.cur, who.w);
+	}
 	slot_warm_done(warm);
 }

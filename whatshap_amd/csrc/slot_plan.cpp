@@ -509,6 +509,9 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 			PedSlotExtra& ex = plan.pextra[ri];
 			ex.g_lo = (uint32_t)words;
 			ex.g_hi = (uint32_t)(words >> 32);
+			// the min-plus step over the previous transmission value on packed keys value << TB | j (kernels_pedslots.h): every finite value of the table --
+			// and 2 * triples * recomb of every column, part of the bound -- must stay below 2^(31 - TB) - 1
+			if (p.value_bound < (double)((1u << (31u - TB)) - 1u) && !debug_env("WHAMD_NO_PED_KEYS")) plan.runs[ri].yflags |= 16u;
 			const uint64_t gsz = ((uint64_t)1 << run.g) * ex.fwn;
 			ex.w_off = (uint32_t)gsz;
 			ex.s_off = (uint32_t)(gsz + ((uint64_t)1 << run.lw) * ex.fwn);

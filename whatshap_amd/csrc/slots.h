@@ -103,7 +103,7 @@ struct SlotRun {
 	// bit 3: the run is eligible for the register-resident X kernel (slot_runx: Y form, <= SLOT_XCOLS columns, <= SLOT_XENDS ending reads);
 	// tab_par: its tie-parity table -- [threads] words (bit e: parity of the thread's local index under the mask of the run's e-th ending read)
 	// followed by [launched workgroups] words (the same for the workgroup's grid bits).
-	uint32_t yflags, base_in, base_out, tab_par;
+	uint32_t yflags, base_in, base_out, tab_par;   // (yflags bit 4, pedigree runs: the min-plus step on packed keys value << TB | j -- kernels_pedslots.h)
 };
 // Dynamic LDS of a single-individual run: wave-slot exchange 2 x [threads][cells] | hot lines [ncols + 8][16] | A [8 waves][64] | lane sums
 // [ncols + 8][64] (eight lines of slack: lines are requested up to six columns ahead).  Sized by the run's own length -- at 22 columns
