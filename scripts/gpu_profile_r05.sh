@@ -17,7 +17,7 @@ for f in $(find gpurun_out/pmc_live -name "*_counter_collection.csv"); do
 done
 rm -rf gpurun_out/pmc_live
 cd /tmp && export TMPDIR=/tmp
-for w in ${WHAMD_PROFILE_SET:-config2 config1 blocks24 config1_x96 config3_x8 irregular config3}; do
+for w in ${WHAMD_PROFILE_SET:-config2 config1 blocks24 config1_x96 config3_x8 irregular config3 quartet_distrust}; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$w -o p -- python $REPO/bench.py --workload $w --sub --steps 3 --warmup 1 --pmc off --cpu-baseline-columns 0 --configs off > $OUT/trace_$w.log 2>&1
   f=$(find $OUT/trace_$w -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp $f $OUT/rocprof_kernel_stats_$w.csv && head -3 $f | cut -c1-200
