@@ -258,7 +258,7 @@ typedef struct whamd_plan_summary {   /* (the CPU plan emulators that used to be
 	uint32_t max_coverage;
 	uint32_t invariants_ok;       /* 1 if the internal consistency checks passed */
 	uint64_t n_yform_runs;        /* slot runs that compute in Y form (one absolute difference per cell-column; slots.h) */
-	uint64_t n_fact_runs;         /* pedigree slot runs on factorised lines (a trio whose genotypes are not trusted; slots.h PSLOT_FACT) */
+	uint64_t n_fact_runs;         /* pedigree slot runs on factorised lines (a trio or a quartet whose genotypes are not trusted; slots.h PSLOT_FACT, PSLOT_FACT4) */
 } whamd_plan_summary;
 whamd_status_t whamd_plan_summarize(const whamd_readset_view* readset, const uint32_t* recombcost, size_t n_recombcost,
                                     const whamd_pedigree_view* pedigree, int distrust_genotypes,

@@ -1,4 +1,4 @@
-"""Soak of round 4's paths on the device against the oracle, beyond the test-suite: random batches of irregular / regular / tie-heavy tables
+"""Soak of the round-4 / round-5 paths on the device against the oracle, beyond the test-suite: random batches of irregular / regular / tie-heavy tables
 (single individuals with mixed genotypes -- Y-form and general runs in one table --, components, trios with trusted and untrusted genotypes,
 quartets) solved through whamd_dptable_enqueue_many (shared launches), with and without the shared_launches layout (eight cells per thread for
 the wide ones), and alone.  Prints the number of mismatches."""
@@ -38,7 +38,7 @@ def make(seed):
     elif kind == 4:
         p = synthetic_block(int(rng.integers(150, 400)), int(rng.integers(8, 13)), seed=seed, trio=True, distrust_genotypes=bool(rng.integers(0, 2)))
     elif kind == 5:
-        p = synthetic_block(int(rng.integers(150, 300)), int(rng.integers(7, 11)), seed=seed, quartet=True)
+        p = synthetic_block(int(rng.integers(150, 300)), int(rng.integers(7, 11)), seed=seed, quartet=True, distrust_genotypes=bool(rng.integers(0, 2)))   # (round 5: factorised lines of a quartet)
     elif kind == 6:
         p = synthetic_block(int(rng.integers(300, 1500)), int(rng.integers(12, 19)), seed=seed, distrust_genotypes=bool(rng.integers(0, 2)))
     else:
@@ -63,6 +63,13 @@ for b in range(n_batches):
                 bad += 1
                 print("MISMATCH batch", b, "table", i, opts, first_difference(w, got), flush=True)
             t.close()
+    for i, (p, w) in enumerate(zip(problems, want)):   # alone with the default layout (round 5: X runs on the thread's own LDS lines, narrow tables packed onto one XCD)
+        n += 1
+        t = _native.NativeTable(p)
+        if table_solution(t) != w:
+            bad += 1
+            print("MISMATCH alone", b, i, first_difference(w, table_solution(t)), flush=True)
+        t.close()
     for i, (p, w) in enumerate(zip(problems, want)):   # alone, eight cells per thread
         n += 1
         t = _native.NativeTable(p, options={"slot_r": "3", "slot_l": "12"})

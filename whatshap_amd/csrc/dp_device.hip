@@ -462,6 +462,13 @@ struct DeviceTable::Impl {
 	std::vector<Job> jobs;
 	std::vector<Lane> lanes;
 	std::vector<SuperStep> schedule;
+	// What a GROUP submission (enqueue_group) needs of a super-step and of its entries, a few bytes each: with 96 tables per launch the submitting thread read a
+	// 320-byte SlotBatchEntry and a SuperStep per table and super-step out of cold memory -- 31 ms of host time for 2 276 super-steps, 13 ms with these
+	// (scripts/gpu_group_submit_ab.py).  Built at create time (where the entries are made, on the create's own threads).
+	struct StepBrief { uint32_t entry_off, lds; uint16_t entry_count; uint8_t has_singles, pad; };
+	struct EntryBrief { uint16_t grid_x, threads; uint32_t lds_x; uint8_t variant, variant_x, pad[2]; };   // variant_x: the X kernel's variant where the run is eligible (else = variant)
+	std::vector<StepBrief> step_brief;
+	std::vector<EntryBrief> entry_brief;
 	std::vector<ResBatchEntry> entries;
 	ResBatchEntry* d_entries = nullptr;
 	// chunked speculative backtrace (kernels_backtrace.h) of a table made of slot runs
@@ -1290,6 +1297,30 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 				}
 			}
 		}
+		m.step_brief.clear();
+		m.entry_brief.clear();
+		if (m.use_slots) {
+			m.step_brief.reserve(m.schedule.size());
+			m.entry_brief.reserve(m.slot_entries.size());
+			for (const Impl::SuperStep& ss : m.schedule) {
+				m.step_brief.push_back(Impl::StepBrief{(uint32_t)m.entry_brief.size(), (uint32_t)ss.lds, (uint16_t)ss.entry_count, (uint8_t)(ss.singles.empty() ? 0 : 1), 0});
+				for (uint32_t q = 0; q < ss.entry_count; ++q) {
+					const SlotBatchEntry& he = m.slot_entries[ss.entry_off + q];
+					Impl::EntryBrief eb{};
+					eb.grid_x = (uint16_t)(1u << (he.run.g - he.run.half));
+					eb.threads = (uint16_t)he.run.threads;
+					eb.lds_x = (uint32_t)((size_t)2 * he.run.threads * (4u << he.run.lr));
+					// kernel variants of a group launch: 0 single individual (four cells per thread); 1 .. 5 pedigree runs (TB, NF) = (2,2) (2,4) (4,2) (4,4) (2,16); 6 single, eight cells;
+					// 7 trio on factorised lines; 8 / 9 X runs with four / eight cells (slot_groupx); 10 quartet on factorised lines
+					if (m.splan.ped) eb.variant = eb.variant_x = (uint8_t)(he.ex.nf == (uint32_t)PSLOT_FACT4 ? 10 : he.ex.nf == (uint32_t)PSLOT_FACT ? 7 : (he.ex.nf == 16 ? 5 : 1 + (he.ex.tb == 4 ? 2 : 0) + (he.ex.nf == 4 ? 1 : 0)));
+					else {
+						eb.variant = (uint8_t)(he.run.lr == 3 ? 6 : 0);
+						eb.variant_x = (he.run.yflags & 8u) ? (uint8_t)(he.run.lr == 3 ? 9 : 8) : eb.variant;
+					}
+					m.entry_brief.push_back(eb);
+				}
+			}
+		}
 		void* d_entries = nullptr;
 		HIP_TRY(up(&d_entries, m.entries.data(), m.entries.size() * sizeof(ResBatchEntry)));
 		m.d_entries = (ResBatchEntry*)d_entries;
@@ -1850,26 +1881,36 @@ whamd_status_t DeviceTable::enqueue_group(DeviceTable* const* tables, const Prob
 	std::vector<uint64_t> table_launches(n_tables, 0);
 	std::vector<uint8_t> counted(n_tables * NV, 0);
 	const auto t_submit0 = std::chrono::steady_clock::now();
+#ifdef WHAMD_DEBUG_BUILD
+	const bool touch_fat = debug_env("WHAMD_GROUP_TOUCH_ENTRIES") != nullptr;
+	volatile uint64_t fat_sink = 0;
+#endif
 	for (size_t k = 0; k < max_steps; ++k) {
 		for (Part& part : parts) {
 			for (size_t i : part.members) std::fill(counted.begin() + i * NV, counted.begin() + i * NV + NV, 0);
 			for (size_t i : part.members) {
 				Impl& m = *tables[i]->impl_;
-				if (k >= m.schedule.size()) continue;
-				const Impl::SuperStep& ss = m.schedule[k];
-				for (uint32_t q = 0; q < ss.entry_count; ++q) {
-					const SlotBatchEntry& he = m.slot_entries[ss.entry_off + q];
-					const bool xrun = !m.splan.ped && (he.run.yflags & 8u) && !m.dp.dbg_flags;   // (the X kernel: operands streamed from the tables, 16 KB of LDS)
-					const int variant = m.splan.ped ? (he.ex.nf == (uint32_t)PSLOT_FACT4 ? 10 : he.ex.nf == (uint32_t)PSLOT_FACT ? 7 : (he.ex.nf == 16 ? 5 : 1 + (he.ex.tb == 4 ? 2 : 0) + (he.ex.nf == 4 ? 1 : 0))) : (he.run.lr == 3 ? (xrun ? 9 : 6) : (xrun ? 8 : 0));
+				if (k >= m.step_brief.size()) continue;
+				const Impl::StepBrief& sb = m.step_brief[k];   // (a few bytes per table and super-step: Impl::StepBrief)
+#ifdef WHAMD_DEBUG_BUILD
+				if (touch_fat) {   // (A/B of the round-5 change: read what the loop used to read -- the super-step and its 320-byte entries)
+					const Impl::SuperStep& ss = m.schedule[k];
+					for (uint32_t q = 0; q < ss.entry_count; ++q) { const SlotBatchEntry& he = m.slot_entries[ss.entry_off + q]; fat_sink += he.run.yflags + he.run.g + he.run.threads + he.ex.nf + (uint32_t)ss.lds; }
+				}
+#endif
+				for (uint32_t q = 0; q < sb.entry_count; ++q) {
+					const Impl::EntryBrief& eb = m.entry_brief[sb.entry_off + q];
+					const bool xrun = eb.variant_x != eb.variant && !m.dp.dbg_flags;   // (the X kernel: operands streamed from the tables, 16 KB of LDS)
+					const int variant = xrun ? eb.variant_x : eb.variant;
 					Batch& b = part.batches[variant];
 					if (b.args.n == (uint32_t)SLOT_GROUP_MAX) {
 						flush(part, variant);
 						for (size_t j : part.members) if (counted[j * NV + variant]) { table_launches[j] += 1; counted[j * NV + variant] = 0; }
 					}
-					b.args.entry[b.args.n++] = m.d_slot_entries + ss.entry_off + q;
-					b.grid_x = std::max(b.grid_x, 1u << (he.run.g - he.run.half));
-					b.threads = std::max(b.threads, he.run.threads);
-					b.lds = std::max(b.lds, xrun ? (size_t)2 * he.run.threads * (4u << he.run.lr) : ss.lds);
+					b.args.entry[b.args.n++] = m.d_slot_entries + sb.entry_off + q;
+					b.grid_x = std::max<uint32_t>(b.grid_x, eb.grid_x);
+					b.threads = std::max<uint32_t>(b.threads, eb.threads);
+					b.lds = std::max<size_t>(b.lds, xrun ? eb.lds_x : sb.lds);
 					counted[i * NV + variant] = 1;
 				}
 			}
@@ -1879,7 +1920,7 @@ whamd_status_t DeviceTable::enqueue_group(DeviceTable* const* tables, const Prob
 			}
 			for (size_t i : part.members) {
 				Impl& m = *tables[i]->impl_;
-				if (k >= m.schedule.size() || m.schedule[k].singles.empty()) continue;
+				if (k >= m.step_brief.size() || !m.step_brief[k].has_singles) continue;
 				const whamd_status_t st = m.submit_singles(*problems[i], m.schedule[k], table_launches[i], msg);
 				if (st != WHAMD_OK) { abort_all(); return st; }
 			}
