@@ -9,7 +9,7 @@ mkdir -p $OUT
 T0=$SECONDS
 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; tail -2 $OUT/pytest_gpu.log; echo "pytest: $((SECONDS - T0)) s"
 T0=$SECONDS
-python bench.py --detail-file $OUT/bench_detail.json > $OUT/bench_default.out 2> $OUT/bench_default.err; echo "bench: $((SECONDS - T0)) s"
+python bench.py --steps 20 --warmup 5 --detail-file $OUT/bench_detail.json > $OUT/bench_default.out 2> $OUT/bench_default.err; echo "bench: $((SECONDS - T0)) s"
 tail -1 $OUT/bench_default.out > $OUT/bench_default_last_line.json; wc -c $OUT/bench_default_last_line.json; head -c 400 $OUT/bench_default_last_line.json; echo
 for f in $(find gpurun_out/pmc_live -name "*_counter_collection.csv"); do
   name=$(echo ${f#gpurun_out/pmc_live/} | tr '/' '_')
