@@ -100,3 +100,21 @@ def test_the_x_run_column_trip_has_no_wait_and_no_memory_operation_on_the_plain_
     body, meta = _kernel(text, "11slot_groupxILi3ELb0E")
     assert meta["vgpr_count"] <= 64 and meta["private_segment_fixed_size"] == 0 and meta["vgpr_spill_count"] == 0 and meta["sgpr_spill_count"] == 0, meta
     assert len(re.findall(r"v_sad_u32 v\d+, v\d+, s\d+, v\d+", body)) == 32      # two trips of two columns, eight cells each
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc (cross-compiles without a GPU)")
+def test_the_pedigree_runs_min_plus_step_on_packed_keys_is_an_add_with_dpp_and_a_min_per_stage():
+    """Round 5 (kernels_pedslots.h): with (value, j) packed into one key a stage of the butterfly over the previous transmission value is the partner's key +
+    the scaled recombination cost -- the DPP move folded into the add -- and a v_min; the staged comparison it replaces (kept for tables whose values do
+    not leave the room) needs two DPP moves, two saturating adds, a compare and two selects."""
+    text = _device_asm()
+    packed, meta = _kernel(text, "11pedslot_runILi2ELi2ELb0ELb1E")
+    staged, _ = _kernel(text, "11pedslot_runILi2ELi2ELb0ELb0E")
+    assert meta["private_segment_fixed_size"] == 0 and meta["vgpr_spill_count"] == 0 and meta["sgpr_spill_count"] == 0, meta
+    folded = len(re.findall(r"v_add_u32_dpp", packed))
+    assert folded == 8, folded                                    # four columns per trip, two stages each (T = 4)
+    assert len(re.findall(r"v_mov_b32_dpp", packed)) == 0         # no DPP move left on its own
+    assert len(re.findall(r"v_add_u32_dpp", staged)) == 0 and len(re.findall(r"v_mov_b32_dpp", staged)) == 16
+    # a quartet: four stages; bit 3 is ONE row rotation (row_ror:8), bit 2 a half-mirror move + a folded quad permute
+    quartet, _ = _kernel(text, "11pedslot_runILi4ELi2ELb0ELb1E")
+    assert len(re.findall(r"row_ror:8", quartet)) == 4 and len(re.findall(r"v_add_u32_dpp", quartet)) == 16, (len(re.findall(r"row_ror:8", quartet)), len(re.findall(r"v_add_u32_dpp", quartet)))

@@ -909,6 +909,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 			slot_tab_words += ncp * 64u;
 			if (xrun) {
 				run.yflags |= 8u;
+				slot_tab_words = (slot_tab_words + 15u) & ~(uint64_t)15;   // (a trip's sixteen Kr words are ONE 64-byte line of the scalar cache)
 				run.tab_kr = (uint32_t)slot_tab_words;
 				slot_tab_words += pad4((((uint64_t)run.ncols + SLOT_XPAD) << run.lr) + run.ncols + SLOT_XPAD);   // Kr words, then one control word per column
 				run.tab_par = (uint32_t)slot_tab_words;

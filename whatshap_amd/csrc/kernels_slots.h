@@ -630,6 +630,12 @@ __device__ __forceinline__ void slot_runx_core(const DevProblem& P, const SlotRu
 	slot_u32x16 krA = *(slot_cptr16)(unsigned long long)kr_tab, krB;
 	slot_u32x4c cwA = *(slot_cptr4c)(unsigned long long)cw_tab, cwB;
 	const uint32_t par_w = *(const __attribute__((address_space(4))) uint32_t*)(unsigned long long)(tab + run.tab_par + threads + w);
+	// The Kr words of a trip are one 64-byte line, requested a trip ahead -- a MISS of the scalar cache every trip, and scalar loads share their counter with LDS
+	// operations: an ending read in the first columns of a trip waited for it with its own `s_waitcnt lgkmcnt(0)` (stamps: 500 - 600 cycles there against 400 in a
+	// trip's last column).  The lines of the whole run are touched here, under the prologue's long waits, so that the loop's requests HIT (72 cycles).  One word of
+	// each line into a register that stays reserved until the first wait for scalar data below (the loads return in any order; the compiler must not reuse the
+	// registers before they have).  Lines behind a short run's last belong to the tables that follow (slot_tables leaves room behind the last run).
+	uint32_t kr_touch[XC > 0 ? XC / 4 + 1 : 1], cw_touch[2] = {0, 0};
 	// the entering cells first (they come from the other XCDs' stores: the longest latency of the prologue) ...
 	// Shared launches read their run descriptor from memory (SlotBatchEntry) BEFORE anything else can be requested: a miss all the way to HBM per launch.
 	// The entry of the table's next step lies behind this one; its lines are requested here, just before the entering cells (which miss to HBM anyway) --
@@ -666,6 +672,14 @@ __device__ __forceinline__ void slot_runx_core(const DevProblem& P, const SlotRu
 		uint32_t X[XC > 0 ? XC : 4];
 #pragma unroll
 		for (int c = 0; c < XC; ++c) X[c] = sl_src[64 * c];
+		// (issued HERE, behind every request of the prologue: in front of the entering cells' loads the scalar waits of their index arithmetic would have
+		// waited for these misses first)
+#pragma unroll
+		for (int i = 0; i < XC / 4 + 1; ++i)
+			asm volatile("s_load_dword %0, %1, %2" : "=s"(kr_touch[i]) : "s"((unsigned long long)kr_tab), "n"(64 * (i + 1)) : "memory");
+		// (... and the control words': sixteen columns per line)
+		asm volatile("s_load_dword %0, %1, 64" : "=s"(cw_touch[0]) : "s"((unsigned long long)cw_tab) : "memory");
+		if (XC > 24) asm volatile("s_load_dword %0, %1, 128" : "=s"(cw_touch[1]) : "s"((unsigned long long)cw_tab) : "memory");
 		t_issued = (DBG && P.dbg) ? __builtin_readcyclecounter() : 0ull;
 		// X0 of column c = 2 A(thread's cell 0) + bias = lane part + (workgroup + wave part, held by lane c): kept in the thread's OWN 16 bytes per trip of
 		// an LDS area (nobody else reads them: no barrier) -- a register per column would need the column loop unrolled over the whole run
@@ -779,6 +793,12 @@ __device__ __forceinline__ void slot_runx_core(const DevProblem& P, const SlotRu
 	uint32_t xaddr = 2u * xstride + tid16;   // LDS byte address of the thread's line of trip 0 (behind the two exchange buffers)
 	typedef __attribute__((address_space(3))) const slot_u32x4* lds_line;
 	slot_u32x4 xA = *(lds_line)(size_t)xaddr, xB;
+	{   // (the first use of the trip's scalars: the compiler's wait for them lands here and covers the touches of the prologue -- their registers are free from here on)
+		asm volatile("" ::"s"(krA[0]), "s"(cwA[0]));
+#pragma unroll
+		for (int i = 0; i < XC / 4 + 1; ++i) asm volatile("" ::"s"(kr_touch[i]));
+		asm volatile("" ::"s"(cw_touch[0]), "s"(cw_touch[1]));
+	}
 	for (uint32_t pairs = (ncols + 7u) >> 3; pairs; --pairs) {
 		asm volatile("" ::"s"(krA[0]), "s"(cwA[0]), "v"(xA.x));
 		krB = *(slot_cptr16)(unsigned long long)(kr_tab + 16u);
