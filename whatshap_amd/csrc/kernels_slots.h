@@ -603,6 +603,25 @@ typedef uint32_t slot_u32x4 __attribute__((ext_vector_type(4)));
 
 // (prologue + column loop of an X run: leaves the thread's four cells in D; the exit -- slot_runx_exit -- is a call of its own so that a kernel whose run
 //  descriptor lives in memory can fetch the exit's half of it AFTER the loop instead of carrying ~30 scalars through it)
+// One word of each of the N 64-byte lines behind `base` requested into ONE scalar register (the values are never read; loads that return in any order into the
+// same register are harmless): the lines are in the scalar cache when the loop asks for them.  The register stays reserved -- slot_touch_done -- until a wait
+// for scalar data has passed, or the compiler would hand it to a live value that a late return then overwrites.
+#define SLOT_TOUCH_1(o) "s_load_dword %0, %1, " #o "\n\t"
+#define SLOT_TOUCH_4(a, b, c, d) SLOT_TOUCH_1(a) SLOT_TOUCH_1(b) SLOT_TOUCH_1(c) SLOT_TOUCH_1(d)
+template <int N>
+__device__ __forceinline__ uint32_t slot_touch_lines(const void* base) {   // lines 1 .. N (line 0 is what the prologue loads anyway)
+	static_assert(N == 2 || N == 4 || N == 8 || N == 12 || N == 16, "touch counts that are written out");
+	uint32_t junk;
+	const unsigned long long b = (unsigned long long)base;
+	if (N == 2) asm volatile(SLOT_TOUCH_1(64) SLOT_TOUCH_1(128) : "=s"(junk) : "s"(b) : "memory");
+	if (N == 4) asm volatile(SLOT_TOUCH_4(64, 128, 192, 256) : "=s"(junk) : "s"(b) : "memory");
+	if (N == 8) asm volatile(SLOT_TOUCH_4(64, 128, 192, 256) SLOT_TOUCH_4(320, 384, 448, 512) : "=s"(junk) : "s"(b) : "memory");
+	if (N == 12) asm volatile(SLOT_TOUCH_4(64, 128, 192, 256) SLOT_TOUCH_4(320, 384, 448, 512) SLOT_TOUCH_4(576, 640, 704, 768) : "=s"(junk) : "s"(b) : "memory");
+	if (N == 16) asm volatile(SLOT_TOUCH_4(64, 128, 192, 256) SLOT_TOUCH_4(320, 384, 448, 512) SLOT_TOUCH_4(576, 640, 704, 768) SLOT_TOUCH_4(832, 896, 960, 1024) : "=s"(junk) : "s"(b) : "memory");
+	return junk;
+}
+__device__ __forceinline__ void slot_touch_done(uint32_t junk) { asm volatile("" ::"s"(junk)); }
+
 struct SlotxStamps { unsigned long long t_start, t_issued, t_loaded, t_loop; };
 template <int LR, int XC, bool DBG>
 __device__ __forceinline__ void slot_runx_core(const DevProblem& P, const SlotRun& run, const uint32_t* __restrict__ prev, const uint32_t w, uint32_t (&D)[1 << LR],
@@ -635,7 +654,7 @@ __device__ __forceinline__ void slot_runx_core(const DevProblem& P, const SlotRu
 	// trip's last column).  The lines of the whole run are touched here, under the prologue's long waits, so that the loop's requests HIT (72 cycles).  One word of
 	// each line into a register that stays reserved until the first wait for scalar data below (the loads return in any order; the compiler must not reuse the
 	// registers before they have).  Lines behind a short run's last belong to the tables that follow (slot_tables leaves room behind the last run).
-	uint32_t kr_touch[XC > 0 ? XC / 4 + 1 : 1], cw_touch[2] = {0, 0};
+	uint32_t touch_kr = 0, touch_kr2 = 0, touch_cw = 0, touch_g = 0, touch_w = 0;
 	// the entering cells first (they come from the other XCDs' stores: the longest latency of the prologue) ...
 	// Shared launches read their run descriptor from memory (SlotBatchEntry) BEFORE anything else can be requested: a miss all the way to HBM per launch.
 	// The entry of the table's next step lies behind this one; its lines are requested here, just before the entering cells (which miss to HBM anyway) --
@@ -663,6 +682,11 @@ __device__ __forceinline__ void slot_runx_core(const DevProblem& P, const SlotRu
 		wA = *(slot_cptr4)(unsigned long long)w_row;
 #pragma unroll
 		for (int k = 0; k < 4; ++k) slA[k] = sl_src[64 * k];
+		// (shared launches: the scalar lines of the whole run -- Kr and control words, the workgroup's and the wave's row of G / W -- touched behind the prologue's requests)
+		touch_kr = slot_touch_lines<8>(kr_tab);
+		touch_cw = slot_touch_lines<2>(cw_tab);
+		touch_g = slot_touch_lines<2>(g_row);
+		touch_w = slot_touch_lines<2>(w_row);
 		t_issued = (DBG && P.dbg) ? __builtin_readcyclecounter() : 0ull;
 	} else {
 		// lane c of every wave fetches the workgroup + wave part of column c, the thread the lane part of every column (columns behind the run's last
@@ -674,12 +698,9 @@ __device__ __forceinline__ void slot_runx_core(const DevProblem& P, const SlotRu
 		for (int c = 0; c < XC; ++c) X[c] = sl_src[64 * c];
 		// (issued HERE, behind every request of the prologue: in front of the entering cells' loads the scalar waits of their index arithmetic would have
 		// waited for these misses first)
-#pragma unroll
-		for (int i = 0; i < XC / 4 + 1; ++i)
-			asm volatile("s_load_dword %0, %1, %2" : "=s"(kr_touch[i]) : "s"((unsigned long long)kr_tab), "n"(64 * (i + 1)) : "memory");
-		// (... and the control words': sixteen columns per line)
-		asm volatile("s_load_dword %0, %1, 64" : "=s"(cw_touch[0]) : "s"((unsigned long long)cw_tab) : "memory");
-		if (XC > 24) asm volatile("s_load_dword %0, %1, 128" : "=s"(cw_touch[1]) : "s"((unsigned long long)cw_tab) : "memory");
+		touch_kr = slot_touch_lines<(XC <= 8 ? 4 : 8)>(kr_tab);   // (XC / 4 + 2 lines of Kr words; a short run's touches reach into the tables behind it: harmless)
+		if (XC > 24) touch_kr2 = slot_touch_lines<2>(kr_tab + 128);   // (lines 9, 10 of a 32-column run)
+		touch_cw = slot_touch_lines<2>(cw_tab);   // (... and the control words': sixteen columns per line)
 		t_issued = (DBG && P.dbg) ? __builtin_readcyclecounter() : 0ull;
 		// X0 of column c = 2 A(thread's cell 0) + bias = lane part + (workgroup + wave part, held by lane c): kept in the thread's OWN 16 bytes per trip of
 		// an LDS area (nobody else reads them: no barrier) -- a register per column would need the column loop unrolled over the whole run
@@ -758,6 +779,10 @@ __device__ __forceinline__ void slot_runx_core(const DevProblem& P, const SlotRu
 	// their operands and Kr words are zero (slot_tables pads the lane parts and the Kr table, lanes >= ncols of Avec are zero: |0 - 0| = 0) and no
 	// read ends in them (the control words behind the run are zero).
 	if (STREAM) {
+		{   // (the first wait for scalar data: the touches of the prologue have returned, their registers are free)
+			asm volatile("" ::"s"(krA[0]), "s"(cwA[0]), "s"(gA[0]), "s"(wA[0]));
+			slot_touch_done(touch_kr); slot_touch_done(touch_cw); slot_touch_done(touch_g); slot_touch_done(touch_w);
+		}
 		// the operands of a trip: lane part (four coalesced loads, a trip ahead) + the workgroup's and the wave's part (two scalar-cache loads of four words)
 		for (uint32_t pairs = (ncols + 7u) >> 3; pairs; --pairs) {
 			asm volatile("" ::"s"(krA[0]), "s"(cwA[0]), "s"(gA[0]), "s"(wA[0]));
@@ -795,9 +820,7 @@ __device__ __forceinline__ void slot_runx_core(const DevProblem& P, const SlotRu
 	slot_u32x4 xA = *(lds_line)(size_t)xaddr, xB;
 	{   // (the first use of the trip's scalars: the compiler's wait for them lands here and covers the touches of the prologue -- their registers are free from here on)
 		asm volatile("" ::"s"(krA[0]), "s"(cwA[0]));
-#pragma unroll
-		for (int i = 0; i < XC / 4 + 1; ++i) asm volatile("" ::"s"(kr_touch[i]));
-		asm volatile("" ::"s"(cw_touch[0]), "s"(cw_touch[1]));
+		slot_touch_done(touch_kr); slot_touch_done(touch_kr2); slot_touch_done(touch_cw);
 	}
 	for (uint32_t pairs = (ncols + 7u) >> 3; pairs; --pairs) {
 		asm volatile("" ::"s"(krA[0]), "s"(cwA[0]), "v"(xA.x));
@@ -956,6 +979,8 @@ __device__ __forceinline__ void slot_runx8_core(const DevProblem& P, const SlotR
 	slot_u32x2 gA = *(slot_cptr2)(unsigned long long)g_row, gB;
 	slot_u32x2 wA = *(slot_cptr2)(unsigned long long)w_row, wB;
 	uint32_t slA[2] = {sl_src[0], sl_src[64]}, slB[2];
+	// (the scalar lines of the whole run touched behind the prologue's requests, as in slot_runx_core: a trip of TWO columns is one line of Kr words)
+	const uint32_t touch_kr = slot_touch_lines<16>(kr_tab), touch_cw = slot_touch_lines<2>(cw_tab), touch_g = slot_touch_lines<2>(g_row), touch_w = slot_touch_lines<2>(w_row);
 	const unsigned long long t_issued = (DBG && P.dbg) ? __builtin_readcyclecounter() : 0ull;
 	uint32_t par = par_l ^ par_w;
 	uint8_t* __restrict__ rec = P.bt + (((unsigned long long)run.rec_hi << 32) | run.rec_lo) + (size_t)w * run.n_ends * threads;
@@ -1008,6 +1033,10 @@ __device__ __forceinline__ void slot_runx8_core(const DevProblem& P, const SlotR
 		}
 		++ci;
 	};
+	{   // (the first wait for scalar data: the touches of the prologue have returned, their registers are free)
+		asm volatile("" ::"s"(krA[0]), "s"(cwA[0]), "s"(gA[0]), "s"(wA[0]));
+		slot_touch_done(touch_kr); slot_touch_done(touch_cw); slot_touch_done(touch_g); slot_touch_done(touch_w);
+	}
 	// two trips (of two columns) per loop iteration; the columns behind the run's last are harmless (zeros), as in slot_runx_core
 	for (uint32_t quads = (ncols + 3u) >> 2; quads; --quads) {
 		asm volatile("" ::"s"(krA[0]), "s"(cwA[0]), "s"(gA[0]), "s"(wA[0]));
