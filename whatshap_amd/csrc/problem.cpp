@@ -578,7 +578,7 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 	};
 	auto columns_range = [&](uint32_t c_begin, uint32_t c_end, RangeResult& out) {
 		if (c_begin >= c_end) return;
-		out.terms.reserve(columns_only ? 0 : (size_t)(c_end - c_begin) * p.T * 2);
+		out.terms.reserve(columns_only ? 0 : (size_t)(c_end - c_begin) * p.T * (distrust ? (size_t)1 << p.P : 2));   // (untrusted genotypes: every allele assignment is a term -- a vector that grows by doubling copied 150 MB several times)
 		std::vector<uint32_t> R(p.n_ind), W(p.n_ind);
 		// Read-major: every read that touches the range writes its entry into each of its columns, in read order -- the rank of a read in a
 		// column is the number of earlier reads active there, a counter per column.  (Column-major -- a list of active reads with a cursor each,
