@@ -217,3 +217,22 @@ def test_full_width_pedigree_runs_vs_oracle(name, kw, ties):
         assert stats["bt_chunks"] >= 2, "the table did not go through the chunked backtrace"
     col, _ = solve(p, "column")
     assert col == want, (name, "column", first_difference(want, col))
+
+
+@pytest.mark.parametrize("kw,recomb", [(dict(n_variants=300, coverage=10, seed=611, trio=True), 1 << 20),
+                                      (dict(n_variants=300, coverage=9, seed=612, quartet=True), 1 << 18),
+                                      (dict(n_variants=260, coverage=9, seed=613, quartet=True, distrust_genotypes=True), 1 << 18)], ids=str)
+def test_tables_whose_values_leave_no_room_for_packed_keys_take_the_staged_step(kw, recomb):
+    """Round 5: the min-plus step over the previous transmission value runs on packed keys value << TB | j where every finite value of the table stays below
+    2^(31 - TB) - 1 (slot_plan.cpp, SlotRun::yflags bit 4); beyond that -- here: recombination costs of 2^20 (trio) / 2^18 (quartet) per column, an upper bound
+    of the table's values above 2^29 / 2^27 but below the 2^30 the slot runs need -- the staged comparison of rounds 3 - 4 runs (the other template
+    instantiation).  Both against the oracle; the same tables with cheap recombination are what every other pedigree test solves."""
+    p = synthetic_block(**kw)
+    rng = np.random.default_rng(kw["seed"])
+    rc = rng.choice(np.array([recomb, recomb + 1, recomb // 2], dtype=np.uint32), size=p.recombcost.size)
+    q = _native.ProblemArrays(p.read_ptr, p.var_position, p.var_allele, p.var_quality, p.read_sample_id, p.individual_id, p.triple_ids,
+                              p.genotype.reshape(p.n_individuals, p.n_variants), p.genotype_likelihoods, rc, p.positions, p.distrust_genotypes, n_variants=p.n_variants)
+    want = table_solution(oracle.OracleTable(q))
+    got, stats = solve(q)
+    assert got == want, first_difference(want, got)
+    assert stats["forward_launches"] <= p.n_variants // 3, "the table did not run on pedigree slot runs"
