@@ -732,6 +732,9 @@ def test_shim_with_compiled_ingestion_on_plain_reference_objects():
             ped.add_relationship("0", "1", "2")
         recomb, positions = problem.recombcost.tolist(), problem.positions.tolist()
         want = table_outputs(ref.PedigreeDPTable(rs, recomb, ped, problem.distrust_genotypes, positions))
+        shim.reset_stats()
         table = shim.table_factory(ref)(rs, recomb, ped, problem.distrust_genotypes, positions)
         assert type(table).__name__ == "_TableAdapter"   # the device table, not the fallback
         assert table_outputs(table) == want
+        # the superreads were built in C++ and adopted (whamd_ingest.emit_superreads; whatshap/core.pyx:388-400), no Python loop per variant
+        assert shim.stats()["compiled_emits"] == 1 and all(type(x) is ref.ReadSet for x in table.get_super_reads()[0])

@@ -8,6 +8,7 @@ import pytest
 
 import oracle
 from reference_cases import all_cases
+from oracle import build_cython_ref
 from refobjects import reference_core, table_outputs, to_reference
 from whatshap_amd.core import problem_from_objects
 
@@ -59,12 +60,31 @@ def test_shim_install_rebinds_a_phase_like_module():
     from whatshap_amd.core import Pedigree as MirrorPedigree
 
     ref = reference_core()
-    phase = types.SimpleNamespace(Pedigree=ref.Pedigree, PedigreeDPTable=ref.PedigreeDPTable, PedMecHeuristic=ref.PedMecHeuristic)
+    def reference_readselection(readset, max_cov, preferred_source_ids=None, bridging=True):   # stands for whatshap.readselect's
+        raise AssertionError("the reference's readselection must not be called once the shim is installed")
+
+    phase = types.SimpleNamespace(Pedigree=ref.Pedigree, PedigreeDPTable=ref.PedigreeDPTable, PedMecHeuristic=ref.PedMecHeuristic,
+                                  readselection=reference_readselection)
     previous = shim.install(phase, ref)
     assert previous == (ref.Pedigree, ref.PedigreeDPTable)
     assert phase.PedMecHeuristic is not ref.PedMecHeuristic and previous.bindings["PedMecHeuristic"] is ref.PedMecHeuristic
-    previous.restore()   # every rebound name goes back, the heuristic factory included
-    assert (phase.Pedigree, phase.PedigreeDPTable, phase.PedMecHeuristic) == (ref.Pedigree, ref.PedigreeDPTable, ref.PedMecHeuristic)
+    # cli/phase.py:43,163: `select_reads` calls the module-level name `readselection` -- rebound too, and it takes reference ReadSets
+    assert phase.readselection is not reference_readselection and previous.bindings["readselection"] is reference_readselection
+    rs = ref.ReadSet()
+    for r in range(12):
+        read = ref.Read(f"r{r}", 60, r % 2, 0)
+        for i in range(3):
+            read.add_variant(100 * (r // 2 + i + 1), (r + i) % 2, 10 + r)
+        rs.add(read)
+    rs.sort()
+    shim.reset_stats()
+    for preferred in (None, {1}):
+        got = phase.readselection(rs, 3, preferred)
+        assert isinstance(got, set) and got and got <= set(range(len(rs)))
+        assert got == __import__("whatshap.readselect", fromlist=["readselection"]).readselection(rs, 3, preferred)
+    assert shim.stats()["read_selections"] == 2
+    previous.restore()   # every rebound name goes back, the heuristic factory and the read selection included
+    assert (phase.Pedigree, phase.PedigreeDPTable, phase.PedMecHeuristic, phase.readselection) == (ref.Pedigree, ref.PedigreeDPTable, ref.PedMecHeuristic, reference_readselection)
     previous = shim.install(phase, ref)
     assert issubclass(phase.Pedigree, ref.Pedigree) and phase.Pedigree is not ref.Pedigree
     ids = ref.NumericSampleIds()
@@ -266,3 +286,60 @@ def test_ingest_refuses_the_objects_of_another_whatshap_release(monkeypatch):
         warnings.simplefilter("always")
         assert ingest.load() is None
     assert any("built against WhatsHap" in str(w.message) for w in caught)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c.name for c in CASES])
+def test_compiled_emit_of_superreads_equals_the_reference_class(case):
+    """whamd_ingest.emit_superreads (C++ `new Read` / `addVariant` / `new ReadSet`, adopted as whatshap/core.pyx:388-400 does) on
+    the arrays of the C-ABI getter: names, sample ids, source ids, mapqs and every (position, allele, quality) of the objects equal
+    what whatshap.core.PedigreeDPTable.get_super_reads returns -- here with the oracle's arrays (CPU); test_gpu_parity.py does the
+    same with the device's through shim.table_factory."""
+    from whatshap_amd import ingest
+
+    ref = reference_core()
+    compiled = ingest.load()
+    if compiled is None or not hasattr(compiled, "emit_superreads"):
+        pytest.skip("compiled ingestion not built")
+    rs, ped = to_reference(case, ref)
+    want = table_outputs(ref.PedigreeDPTable(rs, case.recombcost, ped, case.distrust_genotypes, case.positions))
+    problem = problem_from_objects(rs, case.recombcost, ped.amd, case.distrust_genotypes, case.positions)
+    table = oracle.OracleTable(problem)
+    a0, a1, q, tv, sid = table.super_reads()
+    sets = compiled.emit_superreads(table.positions(), a0, a1, q, sid)
+    assert all(type(s) is ref.ReadSet for s in sets) and len(sets) == len(sid)
+    got = []
+    for readset in sets:
+        assert len(readset) == 2
+        for read in readset:
+            got.append((read.name, read.sample_id, read.source_id, tuple(read.mapqs), [(v.position, v.allele, v.quality) for v in read]))
+    assert got == want["superreads"]
+
+
+def test_compiled_emit_edge_cases_and_heuristic_names():
+    from whatshap_amd import ingest
+
+    ref = reference_core()
+    compiled = ingest.load()
+    if compiled is None or not hasattr(compiled, "emit_superreads"):
+        pytest.skip("compiled ingestion not built")
+    empty = compiled.emit_superreads(np.zeros(0, np.uint32), np.zeros((2, 0), np.uint8), np.zeros((2, 0), np.uint8), np.zeros((2, 0), np.uint32), [7, 9])
+    assert [[(r.name, r.sample_id, len(r)) for r in s] for s in empty] == [[("superread_0_0", 7, 0), ("superread_1_0", 7, 0)],
+                                                                          [("superread_0_1", 9, 0), ("superread_1_1", 9, 0)]]
+    assert compiled.emit_superreads(np.zeros(0, np.uint32), np.zeros((0, 0), np.uint8), np.zeros((0, 0), np.uint8), np.zeros((0, 0), np.uint32), []) == []
+    plain = compiled.emit_superreads(np.array([5, 9], np.uint32), np.array([[0, 3]], np.uint8), np.array([[1, 3]], np.uint8),
+                                     np.array([[30, 30]], np.uint32), [4], numbered=False)   # PedMecHeuristic::getSuperReads' names
+    assert [(r.name, [(v.position, v.allele, v.quality) for v in r]) for r in plain[0]] == [("superread_0", [(5, 0, 30), (9, 3, 30)]),
+                                                                                           ("superread_1", [(5, 1, 30), (9, 3, 30)])]
+    with pytest.raises(ValueError):
+        compiled.emit_superreads(np.zeros(3, np.uint32), np.zeros((1, 2), np.uint8), np.zeros((1, 2), np.uint8), np.zeros((1, 2), np.uint32), [0])
+    # the point of compiling it: 200 000 columns in milliseconds, not the 254 ms of a Python loop per individual
+    import time
+
+    n = 200_000
+    pos = np.arange(n, dtype=np.uint32) * 1000
+    a = np.zeros((1, n), np.uint8)
+    t0 = time.perf_counter()
+    big = compiled.emit_superreads(pos, a, 1 - a, np.full((1, n), 17, np.uint32), [0])
+    dt = time.perf_counter() - t0
+    assert len(big[0][1]) == n and big[0][1][n - 1].allele == 1
+    assert dt < 0.1, f"compiled emit took {dt * 1e3:.1f} ms for one individual x 200 000 columns"

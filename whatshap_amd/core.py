@@ -493,6 +493,12 @@ class PedigreeDPTable:
         tv = np.concatenate([p[3] for p in parts])
         return a0, a1, q, tv, parts[0][4], positions
 
+    def raw_super_reads(self):
+        """The superreads as arrays, for a compiled emitter (``whatshap_amd.ingest.emit_superreads``): ``(positions u32 [n],
+        allele0 u8 [individuals, n], allele1, quality u32 [individuals, n], sample ids, transmission vector, numbered names)``."""
+        a0, a1, q, tv, sid, positions = self._merged()
+        return positions, a0, a1, q, sid, tv, True
+
     def get_super_reads(self) -> Tuple[List[ReadSet], List[int]]:
         """Optimal-score haplotypes as one ReadSet of two superreads per individual, plus the
         transmission vector (core.pyx:381-404, src/pedigreedptable.cpp:344-388)."""

@@ -22,6 +22,17 @@ class PedMecHeuristic:
         self._out = _native.pedmec_heuristic(problem, row_limit=row_limit, allow_mutations=allow_mutations, device=device)
         self.pedigree = pedigree
 
+    def raw_super_reads(self):
+        """Same tuple as ``core.PedigreeDPTable.raw_super_reads``: every variant has quality 30 and the reads are not numbered."""
+        import numpy as np
+
+        out = self._out
+        hap = np.asarray(out["haplotypes"])
+        a0 = np.ascontiguousarray(hap[:, 0, :], dtype=np.uint8)
+        a1 = np.ascontiguousarray(hap[:, 1, :], dtype=np.uint8)
+        return (np.asarray(out["positions"], dtype=np.uint32), a0, a1, np.full(a0.shape, 30, dtype=np.uint32),
+                np.asarray(out["sample_ids"]), np.asarray(out["transmission"]), False)
+
     def get_super_reads(self) -> Tuple[List[core.ReadSet], List[int]]:
         """One ReadSet per sample (two reads ``superread_0`` / ``superread_1``, quality 30, src/pedmecheuristic.cpp:105-121) and
         the transmission value of every column."""

@@ -17,6 +17,8 @@ cdef extern from "whamd_ingest_helpers.h":
     size_t whamd_readset_variant_count(cpp.ReadSet*) except +
     void whamd_flatten_readset(cpp.ReadSet*, uint64_t*, int32_t*, uint8_t*, uint32_t*, int32_t*) except +
     int whamd_flatten_pedigree(cpp.Pedigree*, uint32_t*, uint32_t*, uint8_t*, double*) except +
+    cpp.ReadSet* whamd_emit_superread_set(unsigned int, int, int, size_t, const uint32_t*, const uint8_t*, const uint8_t*, const uint32_t*) except +
+    void whamd_read_source_ids(cpp.ReadSet*, int32_t*) except +
 
 
 def flatten_readset(ReadSet readset):
@@ -54,3 +56,47 @@ def flatten_pedigree(Pedigree pedigree):
     cdef int any_gl = whamd_flatten_pedigree(pedigree.thisptr, &v_ids[0], &v_triples[0], &v_genotype[0], &v_gl[0])
     return (ids[:n_ind], triples[:3 * n_tri], genotype[:n_ind * n_var].reshape(n_ind, n_var),
             gl[:n_ind * n_var * 3].reshape(n_ind, n_var, 3) if any_gl else None)
+
+
+def read_source_ids(ReadSet readset):
+    """``read.source_id`` of every read as one int32 array (``whatshap/readselect.pyx:52-56`` asks read by read)."""
+    cdef size_t n_reads = readset.thisptr.size()
+    out = np.zeros(max(n_reads, 1), dtype=np.int32)
+    cdef int32_t[::1] v_out = out
+    whamd_read_source_ids(readset.thisptr, &v_out[0])
+    return out[:n_reads]
+
+
+def emit_superreads(positions, allele0, allele1, quality, sample_ids, numbered=True):
+    """The C-ABI arrays of ``whamd_dptable_get_super_reads`` (``allele0 / allele1`` u8 ``[individuals, columns]``, ``quality`` u32
+    ``[individuals, columns]``, ``sample_ids`` ``[individuals]``) + the column positions -> one reference ``ReadSet`` per individual,
+    built in C++ and adopted by a ``whatshap.core.ReadSet`` exactly as ``whatshap/core.pyx:388-400`` adopts what
+    ``PedigreeDPTable::get_super_reads`` (``src/pedigreedptable.cpp:344-388``) filled: no Python object per variant.
+    ``numbered=False``: the read names of ``PedMecHeuristic::getSuperReads`` (``src/pedmecheuristic.cpp:105-121``)."""
+    pos = np.ascontiguousarray(positions, dtype=np.uint32)
+    a0 = np.ascontiguousarray(allele0, dtype=np.uint8)
+    a1 = np.ascontiguousarray(allele1, dtype=np.uint8)
+    q = np.ascontiguousarray(quality, dtype=np.uint32)
+    cdef size_t n_ind = a0.shape[0] if a0.ndim == 2 else 0
+    cdef size_t n = pos.shape[0]
+    if n_ind and (a0.shape[1] != n or a1.shape != a0.shape or q.shape != a0.shape or len(sample_ids) != n_ind):
+        raise ValueError("emit_superreads: array shapes disagree")
+    # one padded row so that &v[i, 0] is valid for an empty table
+    if n == 0:
+        pos = np.zeros(1, dtype=np.uint32)
+        a0 = np.zeros((n_ind, 1), dtype=np.uint8); a1 = a0; q = np.zeros((n_ind, 1), dtype=np.uint32)
+    cdef const uint32_t[::1] v_pos = pos
+    cdef const uint8_t[:, ::1] v_a0 = a0
+    cdef const uint8_t[:, ::1] v_a1 = a1
+    cdef const uint32_t[:, ::1] v_q = q
+    cdef size_t i
+    cdef ReadSet rs
+    cdef cpp.ReadSet* built
+    results = []
+    for i in range(n_ind):
+        built = whamd_emit_superread_set(<unsigned int>i, 1 if numbered else 0, <int>int(sample_ids[i]), n, &v_pos[0], &v_a0[i, 0], &v_a1[i, 0], &v_q[i, 0])
+        rs = ReadSet()
+        del rs.thisptr
+        rs.thisptr = built
+        results.append(rs)
+    return results

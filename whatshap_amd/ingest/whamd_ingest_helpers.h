@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <limits>
 #include <stdexcept>
+#include <string>
 #include <vector>
 
 #include "pedigree.h"
@@ -71,4 +72,30 @@ static inline int whamd_flatten_pedigree(Pedigree* ped, uint32_t* ids, uint32_t*
 	for (size_t t = 0; t < triples.size(); ++t)
 		for (int m = 0; m < 3; ++m) triple_ids[3 * t + m] = ped->index_to_id(triples[t][m]);
 	return any_gl;
+}
+
+// One individual's two superreads as a fresh reference ReadSet -- what PedigreeDPTable::get_super_reads builds per individual
+// (src/pedigreedptable.cpp:354-387: Read("superread_<h>_<i>", mapq -1, source id -1, sample id = numeric id), one variant per
+// column in column order, both haplotypes carry the SAME quality; the output set holds [superread_0, superread_1]).  The caller
+// adopts the returned object exactly as whatshap/core.pyx:388-400 adopts the reference's.
+// `numbered` == 0: the names of PedMecHeuristic::getSuperReads, "superread_0" / "superread_1" (src/pedmecheuristic.cpp:105-121).
+static inline ReadSet* whamd_emit_superread_set(unsigned individual, int numbered, int sample_id, size_t n, const uint32_t* positions,
+                                                const uint8_t* allele0, const uint8_t* allele1, const uint32_t* quality) {
+	const std::string suffix = numbered ? "_" + std::to_string(individual) : std::string();
+	Read* r0 = new Read("superread_0" + suffix, -1, -1, sample_id);
+	Read* r1 = new Read("superread_1" + suffix, -1, -1, sample_id);
+	for (size_t c = 0; c < n; ++c) {
+		r0->addVariant((int)positions[c], (int)allele0[c], (int)quality[c]);
+		r1->addVariant((int)positions[c], (int)allele1[c], (int)quality[c]);
+	}
+	ReadSet* out = new ReadSet();
+	out->add(r0);
+	out->add(r1);
+	return out;
+}
+
+// source id of every read (whatshap/readselect.pyx:52-56 reads them one by one through Read.source_id)
+static inline void whamd_read_source_ids(ReadSet* rs, int32_t* out) {
+	const int reads = (int)rs->size();
+	for (int r = 0; r < reads; ++r) out[r] = (int32_t)rs->get(r)->getSourceID();
 }

@@ -74,9 +74,18 @@ class _TableAdapter:
         return self._table.get_optimal_partitioning()
 
     def get_super_reads(self):
-        superreads, transmission = self._table.get_super_reads()
         if self._ref is None:
-            return superreads, transmission
+            return self._table.get_super_reads()
+        from . import ingest as _ingest
+
+        compiled = _ingest.load()
+        if compiled is not None and hasattr(compiled, "emit_superreads"):
+            # compiled emit: the reference builds these ReadSets in C++ and adopts them (core.pyx:388-400,
+            # src/pedigreedptable.cpp:344-388); so does whamd_ingest.emit_superreads, from the C-ABI arrays
+            positions, a0, a1, q, sid, tv, numbered = self._table.raw_super_reads()
+            _counters["compiled_emits"] += 1
+            return compiled.emit_superreads(positions, a0, a1, q, sid, numbered), tv.tolist()
+        superreads, transmission = self._table.get_super_reads()
         converted = []
         for readset in superreads:
             out = self._ref.ReadSet()
@@ -94,7 +103,8 @@ class _TableAdapter:
 # fault must surface, not turn into a silent CPU run.
 _DEVICE_LIMIT_STATUSES = (4, 6)  # WHAMD_ERR_UNSUPPORTED, WHAMD_ERR_OVERFLOW
 
-_counters = {"device_tables": 0, "cpu_fallbacks": 0, "device_genotype_tables": 0, "cpu_genotype_fallbacks": 0}
+_counters = {"device_tables": 0, "cpu_fallbacks": 0, "device_genotype_tables": 0, "cpu_genotype_fallbacks": 0, "compiled_emits": 0,
+             "read_selections": 0}
 _fallback_reasons = []
 
 
@@ -200,6 +210,19 @@ class _HeuristicAdapter(_TableAdapter):
         return self._table.get_mutations()
 
 
+def readselection_factory():
+    """Callable with the signature of ``whatshap.readselect.readselection`` (``readselect.pyx:240``; bound by name in
+    ``whatshap/cli/phase.py:43`` and called by ``select_reads``, ``:157-170`` -- which ``whatshap genotype`` imports too,
+    ``cli/genotype.py:34``): ``whamd_readselection`` behind it, reference ReadSets flattened by the compiled ingestion."""
+    from . import readselect as _readselect
+
+    def readselection(readset, max_cov, preferred_source_ids=None, bridging=True):
+        _counters["read_selections"] += 1
+        return _readselect.readselection(readset, max_cov, preferred_source_ids, bridging)
+
+    return readselection
+
+
 class _Previous(tuple):
     """What ``install`` replaced: unpacks as ``(Pedigree, PedigreeDPTable)`` like the tuple earlier versions returned, and
     ``restore()`` puts EVERY rebound name back -- ``PedMecHeuristic`` included."""
@@ -216,9 +239,10 @@ class _Previous(tuple):
 
 
 def install(phase_module, reference_core=None, allow_cpu_fallback=False, **solver_options):
-    """Rebinds ``Pedigree``, ``PedigreeDPTable`` and (where the module has it) ``PedMecHeuristic`` in ``phase_module`` (normally
-    ``whatshap.cli.phase``).  Returns the previous bindings: a tuple ``(Pedigree, PedigreeDPTable)`` with ``.restore()`` (all three
-    names) and ``.bindings`` (dict).  ``allow_cpu_fallback`` defaults to **False**: an input beyond the device path's INPUT limits
+    """Rebinds ``Pedigree``, ``PedigreeDPTable`` and (where the module has them) ``PedMecHeuristic`` and ``readselection``
+    (``whatshap/cli/phase.py:43,163``: the step in front of the table) in ``phase_module`` (normally
+    ``whatshap.cli.phase``).  Returns the previous bindings: a tuple ``(Pedigree, PedigreeDPTable)`` with ``.restore()`` (every
+    rebound name) and ``.bindings`` (dict).  ``allow_cpu_fallback`` defaults to **False**: an input beyond the device path's INPUT limits
     (more than 25 reads in a column, more than three trios) raises instead of silently running on the class that was replaced; with
     ``True`` such inputs are handed to that class (see ``table_factory``; never a missing GPU or a HIP error)."""
     bindings = {"Pedigree": phase_module.Pedigree, "PedigreeDPTable": phase_module.PedigreeDPTable}
@@ -228,6 +252,9 @@ def install(phase_module, reference_core=None, allow_cpu_fallback=False, **solve
     if hasattr(phase_module, "PedMecHeuristic"):   # `--algorithm heuristic` (whatshap/cli/phase.py:589-603)
         bindings["PedMecHeuristic"] = phase_module.PedMecHeuristic
         phase_module.PedMecHeuristic = heuristic_factory(reference_core, bindings["PedMecHeuristic"] if allow_cpu_fallback else None)
+    if hasattr(phase_module, "readselection"):     # `select_reads` looks the name up in the module at call time (cli/phase.py:163)
+        bindings["readselection"] = phase_module.readselection
+        phase_module.readselection = readselection_factory()
     return _Previous(phase_module, bindings)
 
 
