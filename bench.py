@@ -62,14 +62,19 @@ WORKLOADS = {
     "config3_distrust": dict(trio=True, distrust=True, variants=100000, coverage=15),   # configs[3]'s ReadSet, genotypes not trusted (16 allele assignments per value)
     "config3_x8": dict(trio=True, variants=100000, coverage=15, blocks=8, in_flight=8),  # eight trio tables (families / chromosomes) on one GPU
     "irregular": dict(irregular=True, variants=100000, coverage=20),               # Poisson starts, geometric lengths (mean 16), coverage capped
+    "irregular_x24": dict(irregular=True, variants=50000, coverage=15, blocks=24, in_flight=24, option=["shared_launches=1"]),   # what `whatshap phase` produces: default --internal-downsampling 15 (cli/phase.py:1066-1069), real read lengths, 24 chromosomes
+    "irregular_cov20_x12": dict(irregular=True, variants=100000, coverage=20, blocks=12, in_flight=12, option=["shared_launches=1"]),   # twelve irregular coverage-20 tables sharing their launches
+    "config_cov23": dict(variants=20000, coverage=23),                             # the CLI's cap (cli/phase.py:1181-1182): ONE table fills the chip -- 2 048 workgroups per launch
     "quartet": dict(quartet=True, variants=50000, coverage=13),                    # two trios sharing parents, T = 16
     "quartet_distrust": dict(quartet=True, distrust=True, variants=50000, coverage=13),   # the same, genotypes not trusted: the quartet's factorised lines (slots.h PSLOT_FACT4)
     "genotype": dict(genotype=True, variants=50000, coverage=15),                  # GenotypeDPTable, single individual
     "genotype_trio": dict(genotype=True, trio=True, variants=20000, coverage=15),  # GenotypeDPTable, trio
+    "config2_shim": dict(shim=True, variants=200000, coverage=20),                 # configs[2] entered as `whatshap phase` enters: WhatsHap's own ReadSet / Pedigree in, its ReadSets out
+    "config3_shim": dict(shim=True, trio=True, variants=100000, coverage=15),      # configs[3] the same way (three individuals' superreads)
     "heuristic": dict(heuristic=True, variants=8000, coverage=30),                 # PedMecHeuristic, coverage beyond the exact DP
     "heuristic_x32": dict(heuristic=True, variants=8000, coverage=30, blocks=32),  # 32 PedMecHeuristic tables in ONE launch (one persistent workgroup each)
 }
-EXTRA_CONFIGS = ["config1", "config1_x24", "config1_x48", "config1_x96", "config3", "config3_distrust", "config3_x8", "blocks3", "blocks24", "irregular", "quartet", "quartet_distrust", "genotype", "genotype_trio", "heuristic", "heuristic_x32"]
+EXTRA_CONFIGS = ["config2_shim", "config3_shim", "config1", "config1_x24", "config1_x48", "config1_x96", "config3", "config3_distrust", "config3_x8", "blocks3", "blocks24", "irregular", "irregular_x24", "irregular_cov20_x12", "config_cov23", "quartet", "quartet_distrust", "genotype", "genotype_trio", "heuristic", "heuristic_x32"]
 
 
 def parse_args():
@@ -88,6 +93,7 @@ def parse_args():
     ap.add_argument("--irregular", action="store_true", help="irregular read layout (whatshap_amd.synthetic.irregular_block, seed 7)")
     ap.add_argument("--genotype", action="store_true", help="the genotyping row: GenotypeDPTable (forward-backward, f64) instead of the phasing table")
     ap.add_argument("--heuristic", action="store_true", help="the PedMecHeuristic row: beam search at a coverage the exact DP cannot afford (row limit 256)")
+    ap.add_argument("--shim", action="store_true", help="enter through whatshap_amd.shim with the reference's own ReadSet / Pedigree objects (the compiled whatshap.core of oracle/_ref/cy as the container types)")
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="a named workload (sets the flags above)")
     ap.add_argument("--configs", default="auto", choices=["auto", "on", "off"],
                     help="append the other single-GPU workloads as `configs` (auto: N=1 and no workload flags)")
@@ -107,6 +113,8 @@ def parse_args():
     ap.add_argument("--pmc-inner", action="store_true", help=argparse.SUPPRESS)     # the profiled child: solve and exit
     ap.add_argument("--cpu-sample-worker", type=int, default=0, help=argparse.SUPPRESS)  # child of --cpu-baseline-procs
     ap.add_argument("--heuristic-cpu-worker", type=int, default=0, help=argparse.SUPPRESS)  # child of the batched heuristic entry
+    ap.add_argument("--create-rate-worker", default=None, help=argparse.SUPPRESS)   # "r/n": child of the create_rate entry, bound to the CPU slice of rank r of n
+    ap.add_argument("--no-affinity", action="store_true", help="do not bind a rank's host threads to the CPU slice of its GPU (N > 1)")
     return ap.parse_args()
 
 
@@ -135,6 +143,8 @@ def resolve_workload(args, world):
     n = args.blocks or CONFIG4_BLOCKS
     v = args.variants or CONFIG4_VARIANTS
     tag = " (BASELINE configs[4])" if (n == CONFIG4_BLOCKS and v == CONFIG4_VARIANTS and cov == 20 and not args.trio) else ""
+    if args.irregular:
+        tag = f", irregular read layout (Poisson starts, geometric lengths of mean {0.8 * cov:.0f})"
     return [(CONFIG4_SEED0 + b, v) for b in range(n)], "strong", f"{n} independent blocks x {v} SNVs, LPT over {world} GPU(s){tag}"
 
 
@@ -150,7 +160,7 @@ def build_block(args, seed, n_variants, n_columns_limit=None):
 
 def workload_flags(args):
     out = []
-    for flag in ("trio", "quartet", "distrust", "irregular", "genotype", "heuristic"):
+    for flag in ("trio", "quartet", "distrust", "irregular", "genotype", "heuristic", "shim"):
         if getattr(args, flag):
             out.append("--" + flag)
     return out
@@ -212,11 +222,16 @@ def cpu_baseline(args, seed):
     ramp = 2 * args.coverage
     n_cpu = args.cpu_baseline_columns
     ta, ca, _, kind = reference_seconds(args, seed, ramp + 8)
+    done = None
     if n_cpu < 0:
-        tb, cb, _, _ = reference_seconds(args, seed, ramp + 24)
+        tb, cb, score_b, _, want_b, prefix_b = reference_seconds(args, seed, ramp + 24, want_solution=True)
         per_col = max((tb - ta) / max(cb - ca, 1), 1e-6)
-        n_cpu = int(max(24, min(args.variants_for_cpu - ramp - 8, (4.0 if args.sub else 15.0) / per_col)))
-    tc, cc, score, _, want, prefix = reference_seconds(args, seed, ramp + 8 + n_cpu, want_solution=True)
+        budget = 4.0 if args.sub else 15.0
+        n_cpu = int(max(24, min(args.variants_for_cpu - ramp - 8, budget / per_col)))
+        if budget / per_col <= (cb - ca) * 1.5:
+            # wide columns (coverage 22-23: seconds per column on the reference): the second prefix already is a sample of the budget's size
+            done = (tb, cb, score_b, kind, want_b, prefix_b)
+    tc, cc, score, _, want, prefix = done if done is not None else reference_seconds(args, seed, ramp + 8 + n_cpu, want_solution=True)
     steady_cols, steady_s = cc - ca, max(tc - ta, 1e-9)
     info = cpu_info()
     # the parity bit of this line: the SAME prefix on the device (the product path, through the C ABI), full tuple compared
@@ -338,6 +353,8 @@ def run_pmc_passes(args, kernel_substring, keep_dir):
             counts[c] = cnt[c]
         averages["_grid_size"] = full
         averages["_workgroup_size"] = int(kept[0]["Workgroup_Size"])
+        names = collections.Counter(r["Kernel_Name"] for r in kept)
+        averages["_kernel_name"] = names.most_common(1)[0][0]
         with open(os.path.join(keep_dir, f"{name}_counter_collection.csv"), "w", newline="") as f:
             w = csv.DictWriter(f, fieldnames=list(kept[0].keys()))
             w.writeheader()
@@ -364,6 +381,11 @@ def roofline_from_counters(pmc, avg_launch_us, kernel, bytes_per_launch_model, a
     if pmc is None:
         out.update({"achieved": None, "frac": None, "traffic": None})
         return out
+    if pmc.get("_kernel_name"):
+        # the instantiation the counters were taken from (`kernel` was the filter: "slot_run" also matches slot_runx<2, 24, false, false>)
+        out["kernel_filter"] = kernel
+        name = str(pmc["_kernel_name"])
+        out["kernel"] = name.split("(")[0].replace("void ", "").replace("whamd::", "").replace("(anonymous namespace)::", "").strip() or kernel
     valu = pmc.get("SQ_INSTS_VALU")
     if valu is not None:
         out["achieved"] = valu / cycles
@@ -397,6 +419,7 @@ def roofline_from_counters(pmc, avg_launch_us, kernel, bytes_per_launch_model, a
     out["hbm_model_note"] = ("SURVEY.md 8(d) algorithmic bytes (4*T*2^b + 12*T*2^f + 12*k per column: the reference's three tables) per "
                              "launch / launch time / 8 TB/s -- NOT a roofline fraction: those tables are never materialised here")
     out["counters_per_launch"] = {k: v for k, v in pmc.items() if not k.startswith("_")}
+    out["counters_kernel_name"] = pmc.get("_kernel_name")
     out["counters_measured_on"] = (f"{pmc.get('_dispatches')} full-width dispatches ({pmc.get('_grid_size')} work-items, "
                                    f"{pmc.get('_workgroup_size')} per workgroup) of `bench.py --variants {args.pmc_variants}` "
                                    f"(same seed, coverage {args.coverage}), rocprofv3 --kernel-trace --pmc, one pass per counter group")
@@ -621,6 +644,152 @@ def heuristic_main(args):
         sys.exit(3)
 
 
+def shim_main(args):
+    """`--shim`: the drop-in as `whatshap phase` sees it.  WhatsHap's OWN `ReadSet` / `Pedigree` objects go in (the compiled
+    `whatshap.core` of oracle/_ref/cy provides the container types -- nothing of it computes here), `shim.install` rebinds a phase-like module,
+    and a step is what `cli/phase.py:604-612` does with the table: constructor (compiled ingestion through thisptr + whamd_dptable_create + solve),
+    `get_super_reads()` (reference ReadSets, emitted in C++ and adopted), `get_optimal_cost()`, `get_optimal_partitioning()`.  `value` = columns / median
+    wall time of a step; `native_end_to_end` = the same table from host arrays through the C ABI (create + solve + 3 getters) in the same process."""
+    import types
+
+    from whatshap_amd import _native, ingest, shim
+    from oracle import build_cython_ref
+
+    if _native.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if not build_cython_ref.available():
+        raise SystemExit("bench.py --shim needs the reference's compiled whatshap.core (oracle/_ref/cy) as the container types")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from refobjects import problem_to_reference, table_outputs
+
+    ref = build_cython_ref.import_reference()
+    if args.trio and args.coverage == 20:
+        args.coverage = 15
+    v = args.variants or (100000 if args.trio else 200000)
+    seed = 4 if args.trio else 3
+    problem = build_block(args, seed, v)
+    rs, ped = problem_to_reference(problem, ref)
+    recomb, positions = problem.recombcost.tolist(), problem.positions.tolist()     # Python lists, as cli/phase.py passes them
+    phase = types.SimpleNamespace(Pedigree=ref.Pedigree, PedigreeDPTable=ref.PedigreeDPTable)
+    shim.install(phase, ref)
+    shim.reset_stats()
+
+    def step():
+        t0 = time.perf_counter()
+        table = phase.PedigreeDPTable(rs, recomb, ped, args.distrust, positions)
+        t1 = time.perf_counter()
+        sets, tv = table.get_super_reads()
+        t2 = time.perf_counter()
+        cost = table.get_optimal_cost()
+        part = table.get_optimal_partitioning()
+        t3 = time.perf_counter()
+        st = table._table.get_stats()
+        return (t3 - t0, t1 - t0, t2 - t1, t3 - t2), cost, st
+
+    def native_step():
+        t0 = time.perf_counter()
+        t = _native.NativeTable(problem, solve=False)
+        t1 = time.perf_counter()
+        t.solve()
+        t.optimal_score(), t.super_reads(), t.partitioning()
+        t2 = time.perf_counter()
+        t.close()
+        return t2 - t0, t1 - t0
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+        native_step()
+    if args.pmc_inner:
+        step()
+        return
+    walls, natives, st, cost = [], [], None, 0
+    for _ in range(args.steps):
+        w, cost, st = step()
+        walls.append(w)
+        natives.append(native_step())
+    med = sorted(walls)[len(walls) // 2]
+    nat = sorted(natives)[len(natives) // 2]
+    T = 4 if args.trio else 1
+    kernel = dominant_kernel(args)
+    out = {
+        "metric": "variant-columns/sec at max-coverage %d through whatshap_amd.shim: reference ReadSet / Pedigree objects in, reference ReadSets out" % args.coverage,
+        "value": v / med[0], "unit": "variant-columns/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": med[0] * 1e3,
+        "ms_per_step_min": min(w[0] for w in walls) * 1e3, "ms_per_step_median": med[0] * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "bipartition_costs_per_s": st["n_costs"] / med[0],
+        "config": {"workload": f"synthetic {'trio PedMEC' if args.trio else 'diploid single-individual'}, {v} SNVs, max-coverage {args.coverage}, entered through whatshap_amd.shim.install with "
+                               f"the reference's own ReadSet ({len(rs)} reads) / Pedigree objects; a step = constructor + get_super_reads + get_optimal_cost + get_optimal_partitioning",
+                   "optimal_cost_checksum": int(cost), "transmission_values": T, "max_coverage": args.coverage,
+                   "compiled_ingestion": ingest.load() is not None, "shim_stats": shim.stats()},
+        "rank0": {"forward_ms_per_step": st["forward_ms"], "backtrace_ms_per_step": st["backtrace_ms"], "forward_launches_per_step": float(st["forward_launches"])},
+        "step_pieces_ms": {"constructor": med[1] * 1e3, "get_super_reads": med[2] * 1e3, "cost_and_partitioning": med[3] * 1e3, "device_total": st["total_ms"],
+                           "host_prepare": st["host_prepare_ms"]},
+        "native_end_to_end": {"value": v / nat[0], "ms": nat[0] * 1e3, "create_ms": nat[1] * 1e3,
+                              "what": "the same table from host arrays through the C ABI in the same process: whamd_dptable_create + solve + 3 getters (arrays out)"},
+        "end_to_end": {"value": v / med[0], "wall_ms": med[0] * 1e3, "fraction_of_device_only": (v / med[0]) / (v / (st["total_ms"] * 1e-3)),
+                       "what": "the step itself: reference objects in, reference objects out"},
+        "shim_over_native": med[0] / nat[0],
+    }
+    roof = roofline_from_counters(None, st["forward_ms"] * 1e3 / max(st["forward_launches"], 1), kernel, 0.0, args)
+    roof.pop("hbm_model_ratio", None)
+    roof["pmc_note"] = "the device work is the headline's (config2) / config3's: counters there"
+    out["roofline"] = roof
+    if args.cpu_baseline_columns != 0:
+        # the reference CLASS on a prefix of the same objects' data: the CPU rate of the step, and the parity bit -- objects compared with objects
+        ramp = 2 * args.coverage
+        times = {}
+        for cols in (ramp + 8, ramp + 8 + (args.cpu_baseline_columns if args.cpu_baseline_columns > 0 else (60 if args.trio else 40))):
+            prefix = build_block(args, seed, v, n_columns_limit=cols)
+            prs, pped = problem_to_reference(prefix, ref)
+            pr, pp = prefix.recombcost.tolist(), prefix.positions.tolist()
+            t0 = time.perf_counter()
+            want = table_outputs(ref.PedigreeDPTable(prs, pr, pped, args.distrust, pp))
+            times[cols] = time.perf_counter() - t0
+        got = table_outputs(phase.PedigreeDPTable(prs, pr, pped, args.distrust, pp))
+        lo, hi = sorted(times)
+        out["cpu_baseline"] = {"value": (hi - lo) / max(times[hi] - times[lo], 1e-9), "unit": "variant-columns/s", "cores": 1, "kind": "reference",
+                               "sample": f"whatshap.core.PedigreeDPTable (the compiled reference class) constructor + 3 getters on columns {lo}..{hi} of the same data as reference objects "
+                                         f"(steady state: prefix of {hi} minus prefix of {lo}), {times[hi]:.1f} s", "host": cpu_info()}
+        out["identical_to_reference"] = got == want
+        out["identical_what"] = f"cost, partitioning, transmission vector and the superread OBJECTS (names, sample ids, source ids, mapqs, every position / allele / quality) of the first {hi} columns: shim vs the reference class"
+        out["speedup_vs_cpu_baseline_device_only"] = out["value"] / out["cpu_baseline"]["value"]
+    emit(out, args)
+    if out.get("identical_to_reference") is False:
+        sys.exit(3)
+
+
+def create_rate_worker(args):
+    """Child of the `create_rate` entry: binds itself to the CPU slice rank r of n would get (BEFORE the library sizes its workers), then times
+    whamd_dptable_create of every table of the workload on a pool of host workers -- no solve; prints one JSON object."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from whatshap_amd import _native
+    from whatshap_amd.blocks import bind_rank_to_device_cpus
+
+    r, _, n = args.create_rate_worker.partition("/")
+    visible = max(_native.device_count(), 1)
+    binding = bind_rank_to_device_cpus(int(r), int(n), devices=[i % visible for i in range(int(n))])
+    n_cpus = len(os.sched_getaffinity(0))
+    n_tables = args.blocks or 1
+    problems = [build_block(args, CONFIG4_SEED0 + i, args.variants or CONFIG4_VARIANTS) for i in range(n_tables)]
+    native_path = None if args.path == "auto" else args.path
+    best = None
+    shapes = list(dict.fromkeys([(max(1, min(n_tables, n_cpus // 2)), 2), (max(1, min(n_tables, n_cpus // 4)), 4), (max(1, min(n_tables, n_cpus)), 1)]))
+    for rep in range(2):    # (the first round also sizes the pools)
+        for workers, per_create in shapes:
+            opts = dict(option_dict(args), host_threads=str(per_create))
+            with ThreadPoolExecutor(max_workers=workers) as pool:
+                t0 = time.perf_counter()
+                made = list(pool.map(lambda pr: _native.NativeTable(pr, device=0, path=native_path, solve=False, options=opts), problems))
+                wall = time.perf_counter() - t0
+            for t in made:
+                t.close()
+            if rep and (best is None or wall < best[0]):
+                best = (wall, workers, per_create)
+    print(json.dumps({"tables_per_s": n_tables / best[0], "create_wall_ms": best[0] * 1e3, "create_threads": best[1], "host_threads_per_create": best[2],
+                      "thread_ms_per_table": best[0] * 1e3 * min(best[1] * best[2], n_cpus) / n_tables, "cpus": n_cpus, "cpu_source": binding.get("source"), "numa_node": binding.get("node")}))
+
+
 def heuristic_cpu_worker(args):
     """Child of heuristic_main: the compiled reference's solve() on a prefix of one seeded ReadSet; prints columns/s."""
     import oracle
@@ -650,8 +819,14 @@ def _num(x, digits=4):
 
 
 def _short(text, limit):
+    """At most `limit` characters, cut at a word boundary (never mid-word) with a trailing ellipsis mark."""
     text = " ".join(str(text).split())
-    return text if len(text) <= limit else text[:limit - 1] + "~"
+    if len(text) <= limit:
+        return text
+    cut = text[:limit - 2]
+    if " " in cut[limit // 2:]:
+        cut = cut[:cut.rindex(" ")]
+    return cut.rstrip(" ,;:(") + " ~"
 
 
 def compact_line(out, detail_file=None):
@@ -663,7 +838,7 @@ def compact_line(out, detail_file=None):
     cfg = out.get("config", {})
     line["config"] = {"workload": _short(cfg.get("workload", ""), 150)}
     for k in ("blocks", "blocks_per_rank", "block_seeds_per_rank", "blocks_in_flight_per_gpu", "tables_per_launch", "max_coverage", "transmission_values", "path", "optimal_cost_checksum",
-              "optimal_cost_checksum_per_rank", "device_per_rank", "rendezvous"):   # (what a SCALE record is audited with: which rank ran which blocks on which device)
+              "optimal_cost_checksum_per_rank", "device_per_rank", "rendezvous", "cpu_binding"):   # (what a SCALE record is audited with: which rank ran which blocks on which device)
         if k in cfg and len(json.dumps(cfg[k])) <= 160:
             line["config"][k] = cfg[k]
     roof = out.get("roofline")
@@ -685,6 +860,11 @@ def compact_line(out, detail_file=None):
     e2e = out.get("end_to_end")
     if e2e:
         line["end_to_end"] = {k: _num(e2e[k]) for k in ("value", "create_ms", "solve_and_getters_ms", "wall_ms", "fraction_of_device_only") if e2e.get(k) is not None}
+    res = out.get("value_resident")
+    if res:
+        line["value_resident"] = {k: _num(res[k], 7 if k == "value" else 4) for k in ("value", "ms_per_step", "bipartition_costs_per_s") if res.get(k) is not None}
+    if out.get("per_rank"):
+        line["per_rank"] = [{k: _num(r.get(k), 3) for k in ("rank", "device", "tables", "create_ms", "solve_ms", "step_ms", "cpus", "numa_node") if r.get(k) is not None} for r in out["per_rank"][:8]]
     strict = out.get("value_8d_strict")
     if strict:
         line["value_8d_strict"] = {k: _num(v) if not isinstance(v, str) else _short(v, 120) for k, v in strict.items()}
@@ -698,21 +878,28 @@ def compact_line(out, detail_file=None):
                 short[c["name"]] = {"error": _short(c["error"], 60)}
                 continue
             r = c.get("roofline") or {}
-            rec = {"value": _num(c.get("value")), "ms": _num(c.get("ms_per_step")), "frac": _num(r.get("frac"), 3), "active": _num(r.get("valu_active_frac"), 3),
+            rec = {"value": _num(c.get("value")), "res": _num((c.get("value_resident") or {}).get("value")), "ms": _num(c.get("ms_per_step")), "frac": _num(r.get("frac"), 3), "active": _num(r.get("valu_active_frac"), 3),
                    "us": _num(r.get("avg_launch_us"), 3), "cpu": _num((c.get("cpu_baseline") or {}).get("value"), 3), "ident": c.get("identical_to_reference"),
-                   "e2e": _num((c.get("end_to_end") or {}).get("value")), "host8": _num((c.get("create_rate") or {}).get("host_over_8_devices"), 3)}
+                   "e2e": _num((c.get("end_to_end") or {}).get("value")), "host8": _num((c.get("create_rate") or {}).get("host_over_8_devices"), 3),
+                   "shim": _num(c.get("shim_over_native"), 3), "strict": _num((c.get("value_8d_strict") or {}).get("value"))}
             short[c["name"]] = {k: v for k, v in rec.items() if v is not None}
         line["configs"] = short
-        line["configs_keys"] = "value columns/s; ms per step; frac VALU issue; active VALU busy; us per launch of the dominant kernel; cpu reference columns/s on 1 thread; ident == reference; e2e columns/s from host arrays; host8 fresh tables/s of this host / (8 x one device's tables/s)"
+        line["configs_keys"] = "value columns/s, fresh tables (create inside the clock; genotype / heuristic / shim entries: as defined in the detail record); res columns/s with the tables resident; ms per step; frac VALU issue; active VALU busy; us per launch of the dominant kernel; cpu reference columns/s on 1 thread; ident == reference; e2e columns/s from host arrays; host8 fresh tables/s of this host / (8 x one device's tables/s); shim step time / native end to end; strict columns/s with whamd_dptable_create inside the clock (SURVEY 8d)"
     if detail_file:
         line["detail"] = detail_file
     text = json.dumps(line, separators=(",", ":"))
     if len(text) > LINE_LIMIT:   # never again a line the driver cannot parse: drop the optional parts, largest first
-        for key in ("configs_keys", "create_rate", "end_to_end", "value_8d_strict", "configs"):
+        for key in ("configs_keys", "create_rate", "per_rank", "end_to_end", "value_8d_strict", "configs"):
             line.pop(key, None)
             text = json.dumps(line, separators=(",", ":"))
             if len(text) <= LINE_LIMIT:
                 break
+    if len(text) > LINE_LIMIT:   # still too long (a very long roofline / config string): the contract's head keys alone, whatever they hold
+        head = {k: line[k] for k in HEAD_KEYS if k in line}
+        head["config"] = {"workload": _short(cfg.get("workload", ""), 150)}
+        if detail_file:
+            head["detail"] = detail_file
+        text = json.dumps(head, separators=(",", ":"))
     return text
 
 
@@ -788,6 +975,9 @@ def run_extra_configs(args):
         }
         if "create_rate" in full:
             entry["create_rate"] = full["create_rate"]
+        for key in ("shim_over_native", "native_end_to_end", "step_pieces_ms", "value_resident", "value_8d_strict", "per_table"):
+            if key in full:
+                entry[key] = full[key]
         if "cpu_baseline" in full:
             entry["cpu_baseline"] = {k: full["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind", "sample")}
             entry["speedup_vs_cpu_baseline_device_only"] = full["value"] / full["cpu_baseline"]["value"]
@@ -801,7 +991,12 @@ def main():
         return cpu_sample_worker(args)
     if args.heuristic_cpu_worker:
         return heuristic_cpu_worker(args)
-    explicit = any(a in sys.argv[1:] for a in ("--workload", "--trio", "--quartet", "--distrust", "--irregular", "--genotype", "--heuristic", "--variants", "--coverage", "--blocks", "--blocks-per-gpu", "--path", "--option"))
+    if args.create_rate_worker:
+        if args.workload:
+            for key, value in WORKLOADS[args.workload].items():
+                setattr(args, key, value)
+        return create_rate_worker(args)
+    explicit = any(a in sys.argv[1:] for a in ("--workload", "--trio", "--quartet", "--distrust", "--irregular", "--genotype", "--heuristic", "--shim", "--variants", "--coverage", "--blocks", "--blocks-per-gpu", "--path", "--option"))
     if args.workload:
         for key, value in WORKLOADS[args.workload].items():
             setattr(args, key, value)
@@ -813,6 +1008,8 @@ def main():
         return genotype_main(args)
     if args.heuristic:
         return heuristic_main(args)
+    if args.shim:
+        return shim_main(args)
     if args.gpus > 1 and "RANK" not in os.environ:
         return self_launch(args)
 
@@ -857,11 +1054,18 @@ def main():
         args.in_flight = max(args.in_flight, len(mine))
         if len(mine) > 4 and not args.option:
             args.option = ["shared_launches=1"]
+    # one process per GPU: this rank's host threads (creates, result extraction) stay on the CPUs next to ITS GPU (whatshap_amd.blocks.bind_rank_to_device_cpus)
+    cpu_binding = None
+    if (world > 1 or "RANK" in os.environ) and not args.no_affinity:
+        from whatshap_amd.blocks import bind_rank_to_device_cpus
+
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        cpu_binding = bind_rank_to_device_cpus(local_rank, local_world, devices=[(r % visible if args.oversubscribe else r) for r in range(local_world)])
+    problems = [build_block(args, *blocks[b]) for b in mine]
+    native_path = None if args.path == "auto" else args.path
     tables = []
-    for b in mine:
-        seed, v = blocks[b]
-        problem = build_block(args, seed, v)
-        t = _native.NativeTable(problem, device=device, path=None if args.path == "auto" else args.path, solve=False, options=option_dict(args))
+    for problem in problems:
+        t = _native.NativeTable(problem, device=device, path=native_path, solve=False, options=option_dict(args))
         tables.append(t)
 
     def step():
@@ -880,6 +1084,7 @@ def main():
         if torch is not None:
             torch.cuda.synchronize()
 
+    # ---------------------------------------------------------------- region 1: tables RESIDENT (created before the clock) -> value_resident, roofline
     for _ in range(args.warmup):
         step()
     if args.pmc_inner:
@@ -908,23 +1113,109 @@ def main():
                 launches += sum(x["forward_launches"] for x in st)
             bt_ms += sum(x["backtrace_ms"] for x in st)
     sync()
-    elapsed = time.perf_counter() - t0
+    elapsed_resident = time.perf_counter() - t0
+    resident_step_s = list(step_s)
     stats = [t.stats() for t in tables]
     totals = [float(sum(s["n_columns"] for s in stats)), float(sum(s["n_costs"] for s in stats)), float(sum(t.optimal_score() for t in tables))]
+    for t in tables:   # the fresh tables below need the room (arena blocks go back to the cache)
+        t.release_device()
+
+    # ---------------------------------------------------------------- region 2: FRESH tables, SURVEY.md 8(d)'s clock: "from entering the constructor" --
+    # every step creates its tables from the flattened host arrays (whamd_dptable_create: columns, indexing schemes, cost terms, plan, upload), solves them
+    # (forward, backtrace, path download, superread assembly) and destroys them.  Several tables: the host-side work queue (blocks.solve_blocks) creates the
+    # next window under the device solve of the current one.  This is `value`.
+    from whatshap_amd.blocks import solve_blocks
+
+    n_cpus = len(os.sched_getaffinity(0))
+    if len(problems) == 1:
+        host_shapes = [(1, 0)]
+    elif world > 1:
+        host_shapes = [(max(1, min(len(problems), n_cpus // 2)), 2), (max(1, min(len(problems), n_cpus // 4)), 4)]
+    else:
+        host_shapes = [(16, 2), (len(problems), 4), (len(problems), 8)]
+    host_shapes = list(dict.fromkeys(host_shapes))
+
+    def fresh_step(shape):
+        ta = time.perf_counter()
+        if len(problems) == 1:
+            t = _native.NativeTable(problems[0], device=device, path=native_path, solve=False, options=option_dict(args))
+            tb = time.perf_counter()
+            _native.enqueue_many([t])
+            _native.wait_many([t])
+            tc = time.perf_counter()
+            st = t.stats()
+            checksum = int(t.optimal_score())
+            t.close()
+            td = time.perf_counter()
+            return {"wall_ms": (td - ta) * 1e3, "create_ms": (tb - ta) * 1e3, "solve_ms": (tc - tb) * 1e3, "close_ms": (td - tc) * 1e3,
+                    "device_ms": st["total_ms"], "superreads_ms": st["host_finish_ms"], "flatten_ms": st.get("host_flatten_ms"), "checksum": checksum}
+        trace = []
+        solved = solve_blocks(problems, device=device, path=native_path, max_in_flight=args.in_flight, release=True,
+                              create_threads=shape[0], host_threads_per_create=shape[1], trace=trace)
+        tc = time.perf_counter()
+        checksum = int(sum(t.optimal_score() for t in solved))
+        for t in solved:
+            t.close()
+        td = time.perf_counter()
+        # the submitting thread's time line: waiting for a window's creates (not hidden under a solve) / enqueue + device + result extraction
+        create_wait = solve_ms = 0.0
+        last = 0.0
+        for what, _wi, ms in trace:
+            if what == "created":
+                create_wait += ms - last
+            elif what == "collected":
+                solve_ms += ms - last
+            elif what == "enqueued":
+                solve_ms += ms - last
+            last = ms
+        return {"wall_ms": (td - ta) * 1e3, "create_ms": create_wait, "solve_ms": solve_ms, "close_ms": (td - tc) * 1e3, "checksum": checksum}
+
+    tried = []
+    shape = host_shapes[0]
+    for cand in host_shapes:       # untimed: one step per host shape (the first also warms the pools); the fastest is the one that is timed
+        rec = fresh_step(cand)
+        tried.append({"create_threads": cand[0], "host_threads_per_create": cand[1], "wall_ms": rec["wall_ms"]})
+    if len(host_shapes) > 1:
+        best = min(tried, key=lambda r: r["wall_ms"])
+        shape = (best["create_threads"], best["host_threads_per_create"])
+    for _ in range(max(0, args.warmup - len(host_shapes))):
+        fresh_step(shape)
+    sync()
+    t0 = time.perf_counter()
+    fresh = []
+    for _ in range(args.steps):
+        fresh.append(fresh_step(shape))
+    sync()
+    elapsed = time.perf_counter() - t0
+    step_s = [r["wall_ms"] * 1e-3 for r in fresh]
+    if any(r["checksum"] != int(totals[2]) for r in fresh):
+        raise SystemExit(f"rank {rank}: a fresh solve's cost checksum {[r['checksum'] for r in fresh]} differs from the resident tables' {int(totals[2])}")
+
+    def med(key):
+        vals = sorted(r[key] for r in fresh if r.get(key) is not None)
+        return vals[len(vals) // 2] if vals else None
+
+    per_rank = {"rank": rank, "device": device, "tables": len(problems), "create_ms": med("create_ms"), "solve_ms": med("solve_ms"), "close_ms": med("close_ms"),
+                "step_ms": med("wall_ms"), "resident_step_ms": sorted(resident_step_s)[len(resident_step_s) // 2] * 1e3,
+                "cpus": (cpu_binding or {}).get("n_cpus", n_cpus), "numa_node": (cpu_binding or {}).get("node"), "cpu_source": (cpu_binding or {}).get("source", "unbound"),
+                "create_threads": shape[0], "host_threads_per_create": shape[1]}
     per_rank_checksums = [int(totals[2])]
     # what a SCALE record can be audited with: which rank ran which blocks on which device, and for how long
-    print(f"[bench rank {rank}/{world}] device {device}, blocks {[blocks[b][0] for b in mine]} (seeds), {len(mine)} table(s), "
-          f"{elapsed:.3f} s for {args.steps} step(s), cost checksum {int(totals[2])}", file=sys.stderr, flush=True)
+    print(f"[bench rank {rank}/{world}] device {device}, blocks {[blocks[b][0] for b in mine]} (seeds), {len(mine)} table(s), fresh: {elapsed:.3f} s for {args.steps} step(s) "
+          f"(create {per_rank['create_ms']:.1f} ms + solve {per_rank['solve_ms']:.1f} ms + close {per_rank['close_ms']:.1f} ms per step), resident: {elapsed_resident:.3f} s, "
+          f"cpus {per_rank['cpus']} ({per_rank['cpu_source']}, node {per_rank['numa_node']}), cost checksum {int(totals[2])}", file=sys.stderr, flush=True)
+    per_rank_all = [per_rank]
     if dist is not None:
         import torch as _torch
 
-        tmax = _torch.tensor([elapsed], dtype=_torch.float64)
+        tmax = _torch.tensor([elapsed, elapsed_resident], dtype=_torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        elapsed, elapsed_resident = float(tmax[0].item()), float(tmax[1].item())
         gathered = [None] * world
-        dist.all_gather_object(gathered, totals + [float(device)])
+        dist.all_gather_object(gathered, totals + [float(device), per_rank])
         per_rank_checksums = [int(g[2]) for g in gathered]
         per_rank_devices = [int(g[3]) for g in gathered]
+        per_rank_all = [g[4] for g in gathered]
         totals = [sum(g[i] for g in gathered) for i in range(3)]
     else:
         per_rank_devices = [device]
@@ -974,7 +1265,18 @@ def main():
             },
             "rank0": {"forward_ms_per_step": fwd_ms / args.steps, "backtrace_ms_per_step": bt_ms / args.steps,
                       "forward_launches_per_step": launches / args.steps},
+            "value_is": "FRESH tables: every timed step runs whamd_dptable_create (columns, indexing schemes, cost terms, plan, upload) from the flattened host arrays, the "
+                        "solve (forward, backtrace, path download, superread assembly) and the destroy of every table of the rank -- SURVEY.md 8(d)'s clock starts at the "
+                        "constructor; several tables go through the host-side work queue (next window created under the current solve)",
+            "value_resident": {"value": cols_job * args.steps / elapsed_resident, "ms_per_step": elapsed_resident / args.steps * 1e3,
+                               "ms_per_step_min": min(resident_step_s) * 1e3, "ms_per_step_median": sorted(resident_step_s)[len(resident_step_s) // 2] * 1e3,
+                               "bipartition_costs_per_s": costs_job * args.steps / elapsed_resident,
+                               "what": "the same steps on tables created BEFORE the clock (plan and operand tables resident in HBM): forward + backtrace + result extraction only -- what "
+                                       "rounds 1-5 reported as `value`; the roofline's launch time is measured here"},
+            "per_rank": per_rank_all,
+            "host_shapes_tried": tried,
         }
+        out["config"]["cpu_binding"] = "rank r bound to the CPUs of its GPU's NUMA node (whatshap_amd.blocks.bind_rank_to_device_cpus)" if cpu_binding is not None else "none (one rank: the whole host)"
         # ---- fresh tables end to end (host-inclusive): create + solve + getters
         if world == 1 and len(blocks) == 1:
             seed, v = blocks[mine[0]]
@@ -1001,12 +1303,13 @@ def main():
             # plus the device's forward pass, backtrace and path download; whamd_dptable_wait's superread assembly (host_finish_ms) stays outside.
             strict_ms = create_ms + fresh_stats["total_ms"]
             out["value_8d_strict"] = {"value": v / (strict_ms * 1e-3), "unit": "variant-columns/s", "ms": strict_ms, "create_ms": create_ms,
-                                      "columns_and_terms_ms": fresh_stats.get("host_flatten_ms"), "device_ms": fresh_stats["total_ms"],
-                                      "superreads_ms_excluded": fresh_stats["host_finish_ms"],
-                                      "what": "SURVEY 8(d) timing of ONE fresh table: whamd_dptable_create (columns, indexing scheme, cost terms, plan, upload) + forward + backtrace + path download; superread assembly excluded"}
+                                      "flatten_ms": fresh_stats.get("host_flatten_ms"),
+                                      "terms_plan_upload_ms": (create_ms - fresh_stats["host_flatten_ms"]) if fresh_stats.get("host_flatten_ms") is not None else None,
+                                      "device_ms": fresh_stats["total_ms"], "superreads_ms_excluded": fresh_stats["host_finish_ms"],
+                                      "what": "SURVEY 8(d) to the letter for ONE fresh table: whamd_dptable_create (flatten_ms = ColumnIterator's columns; the rest = indexing scheme, cost terms, plan, upload) + forward + backtrace + path download; superread assembly and destroy excluded (`value` includes both)"}
             out["end_to_end"] = {"value": v / ((create_ms + rest_ms) * 1e-3), "unit": "variant-columns/s", "create_ms": create_ms,
                                  "solve_and_getters_ms": rest_ms, "host_threads": min(os.cpu_count() or 1, 32),
-                                 "fraction_of_device_only": (v / ((create_ms + rest_ms) * 1e-3)) / out["value"],
+                                 "fraction_of_device_only": (v / ((create_ms + rest_ms) * 1e-3)) / out["value_resident"]["value"],
                                  "what": "whamd_dptable_create (flatten + plan + upload) + solve + 3 getters of ONE fresh table from host arrays"}
             if not args.sub:
                 # the same with the create path held to 8 host threads (WHAMD_PLAN_THREADS; the default is min(hardware threads, 32))
@@ -1022,63 +1325,44 @@ def main():
                 out["end_to_end"]["create_ms_8_threads"] = create8
                 out["end_to_end"]["value_8_threads"] = v / ((create8 + rest8) * 1e-3)
         elif world == 1:
-            # several tables: the host-side work queue of whatshap_amd.blocks.solve_blocks -- tables are created by a few host threads while the
-            # device solves the window before (create of window k + 1 under the solve of window k), collected with wait_many, then the getters
-            from whatshap_amd.blocks import solve_blocks
-
-            for t in tables:
-                t.release_device()
-            problems = [build_block(args, *blocks[b]) for b in mine]
-            best = None
-            tried = []
-            # host parallelism of the creates: (workers, threads per create) -- 16 x 2 is blocks.solve_blocks' default; one worker per table with four or
-            # eight threads each is tried beside it (the box has more hardware threads than 32; what wins is reported, nothing is assumed)
-            host_shapes = [(16, 2), (len(problems), 4), (len(problems), 8)]
-            for window in sorted({min(len(problems), w) for w in (8, 12, args.in_flight)}):
-                for workers, per_create in (host_shapes if window == min(len(problems), args.in_flight) else host_shapes[:1]):
-                    te0 = time.perf_counter()
-                    try:
-                        solved = solve_blocks(problems, device=device, path=None if args.path == "auto" else args.path, max_in_flight=window, release=True,
-                                              create_threads=workers, host_threads_per_create=per_create)
-                    except Exception as exc:  # noqa: BLE001 -- an exploratory host shape must not cost the line; the default shape (first) still raises
-                        if (workers, per_create) == host_shapes[0]:
-                            raise
-                        tried.append({"tables_per_window": window, "create_threads": workers, "host_threads_per_create": per_create, "error": repr(exc)})
-                        continue
-                    checksum = 0
-                    for t in solved:
-                        checksum += t.optimal_score()
-                        t.super_reads(), t.partitioning()
-                    wall = time.perf_counter() - te0
-                    for t in solved:
-                        t.close()
-                    if checksum != int(totals[2]):
-                        raise SystemExit(f"end_to_end: cost checksum {checksum} of the pipelined solve differs from {int(totals[2])}")
-                    tried.append({"tables_per_window": window, "create_threads": workers, "host_threads_per_create": per_create, "wall_ms": wall * 1e3})
-                    if best is None or wall < best[0]:
-                        best = (wall, window, workers, per_create)
-            out["end_to_end"] = {"value": cols_job / best[0], "unit": "variant-columns/s", "wall_ms": best[0] * 1e3, "tables_per_window": best[1], "create_threads": best[2],
-                                 "host_threads_per_create": best[3], "fraction_of_device_only": (cols_job / best[0]) / out["value"], "tried": tried,
-                                 "what": f"{len(problems)} fresh tables from host arrays through blocks.solve_blocks: create (flatten + plan + upload) of the next window on "
-                                         f"`create_threads` host workers (`host_threads_per_create` threads each) under the device solve of the current one, enqueue_many / wait_many "
-                                         f"per window, 3 getters per table; best of the window sizes and host shapes in `tried`"}
-            # ---- how many fresh tables per second this host can hand to its devices (one node's host feeds eight GPUs): creates only,
-            # `create_threads` workers x `host_threads_per_create`, against the rate at which ONE device solves such tables
-            from concurrent.futures import ThreadPoolExecutor
-
-            workers, per_create = best[2], best[3]
-            opts = dict(option_dict(args), host_threads=str(per_create))
-            with ThreadPoolExecutor(max_workers=workers) as pool:
-                tc0 = time.perf_counter()
-                made = list(pool.map(lambda pr: _native.NativeTable(pr, device=device, path=None if args.path == "auto" else args.path, solve=False, options=opts), problems))
-                create_wall = time.perf_counter() - tc0
-            for t in made:
+            # several tables: `value` already is the host-side work queue from host arrays (region 2); end to end adds the three getters of every table
+            te0 = time.perf_counter()
+            solved = solve_blocks(problems, device=device, path=native_path, max_in_flight=args.in_flight, release=True, create_threads=shape[0], host_threads_per_create=shape[1])
+            checksum = 0
+            for t in solved:
+                checksum += t.optimal_score()
+                t.super_reads(), t.partitioning()
+            wall = time.perf_counter() - te0
+            for t in solved:
                 t.close()
-            device_tables_per_s = len(problems) * args.steps / elapsed
-            out["create_rate"] = {"tables_per_s": len(problems) / create_wall, "device_tables_per_s": device_tables_per_s, "host_over_8_devices": (len(problems) / create_wall) / (8.0 * device_tables_per_s),
-                                  "create_threads": workers, "host_threads_per_create": per_create, "host_nproc": os.cpu_count(),
-                                  "what": f"{len(problems)} whamd_dptable_create calls (flatten + plan + upload) on {workers} workers x {per_create} threads, no solve; next to the tables per second one "
-                                          f"device solves in the timed region: below 1.0 an 8-GPU node is bound by its host"}
+            if checksum != int(totals[2]):
+                raise SystemExit(f"end_to_end: cost checksum {checksum} of the pipelined solve differs from {int(totals[2])}")
+            out["end_to_end"] = {"value": cols_job / wall, "unit": "variant-columns/s", "wall_ms": wall * 1e3, "tables_per_window": min(args.in_flight, len(problems)), "create_threads": shape[0],
+                                 "host_threads_per_create": shape[1], "fraction_of_device_only": (cols_job / wall) / out["value_resident"]["value"], "tried": tried,
+                                 "what": f"{len(problems)} fresh tables from host arrays through blocks.solve_blocks (create of the next window on `create_threads` host workers x "
+                                         f"`host_threads_per_create` threads under the device solve of the current one, enqueue_many / wait_many per window) + 3 getters per table"}
+            # ---- how many fresh tables per second ONE RANK'S SHARE of this host hands to its device (one node's host feeds eight GPUs): creates only, in a child process
+            # bound to the CPU slice rank 0 of 8 would get (bind_rank_to_device_cpus), against the rate at which one device solves such tables with its tables resident
+            device_tables_per_s = len(problems) * args.steps / elapsed_resident
+            rate = {"device_tables_per_s": device_tables_per_s, "host_nproc": os.cpu_count()}
+            try:
+                cmd = [sys.executable, os.path.abspath(__file__), "--create-rate-worker", "0/8", "--coverage", str(args.coverage), "--variants", str(blocks[0][1]),
+                       "--blocks", str(len(problems)), "--path", args.path] + workload_flags(args)
+                for kv in args.option:
+                    cmd += ["--option", kv]
+                res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+                line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+                if res.returncode == 0 and line:
+                    rate.update(json.loads(line[-1]))
+                    rate["host_over_8_devices"] = rate["tables_per_s"] / device_tables_per_s
+                    rate["what"] = (f"{len(problems)} whamd_dptable_create calls (flatten + plan + upload, no solve) in a process held to the CPUs rank 0 of 8 gets "
+                                    f"({rate.get('cpus')} of {os.cpu_count()}: the NUMA node of its GPU shared evenly), best of the host shapes tried; against the tables per second ONE device "
+                                    f"solves with its tables resident: below 1.0 an 8-GPU node is bound by its host.  (Rounds 4-5 divided the WHOLE host's single-process rate by 8.)")
+                else:
+                    rate["error"] = f"rc={res.returncode} {res.stderr[-200:]}"
+            except Exception as exc:  # noqa: BLE001 -- never costs the line
+                rate["error"] = repr(exc)
+            out["create_rate"] = rate
         # ---- counters of the dominant kernel
         pmc, pmc_note = None, "skipped"
         want_pmc = args.pmc == "on" or (args.pmc == "auto" and world == 1 and not column_path)
@@ -1109,9 +1393,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, blocks[0][0])
             out["identical_to_reference"] = out["cpu_baseline"].pop("identical_to_reference")
             out["identical_what"] = out["cpu_baseline"].pop("identical_what")
-            out["speedup_vs_cpu_baseline_device_only"] = out["value"] / out["cpu_baseline"]["value"]
-            if "end_to_end" in out:
-                out["speedup_vs_cpu_baseline"] = out["end_to_end"]["value"] / out["cpu_baseline"]["value"]
+            out["speedup_vs_cpu_baseline_device_only"] = out["value_resident"]["value"] / out["cpu_baseline"]["value"]
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         procs = args.cpu_baseline_procs if args.cpu_baseline_procs >= 0 else (os.cpu_count() or 1)
         if world == 1 and procs > 0:
             out["cpu_baseline_all_cores"] = cpu_baseline_procs(args, procs)

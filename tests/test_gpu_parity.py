@@ -694,6 +694,11 @@ def test_bench_with_two_ranks_on_one_device_matches_a_single_rank():
     assert len(two["config"]["optimal_cost_checksum_per_rank"]) == 2 and all(c > 0 for c in two["config"]["optimal_cost_checksum_per_rank"])
     assert sum(two["config"]["optimal_cost_checksum_per_rank"]) == one["config"]["optimal_cost_checksum"] == two["config"]["optimal_cost_checksum"]
     assert "gloo" in two["config"]["rendezvous"]
+    # `value` times FRESH tables (create inside the clock), the resident figure rides beside it; every rank reports its create / solve walls and its CPU slice
+    for line in (one, two):
+        assert line["value_resident"]["value"] > line["value"] > 0
+    assert [r["rank"] for r in two["per_rank"]] == [0, 1] and all(r["create_ms"] >= 0 and r["solve_ms"] > 0 and r["cpus"] >= 1 for r in two["per_rank"])
+    assert sum(r["tables"] for r in two["per_rank"]) == 6 and "bound to the CPUs" in (two["config"].get("cpu_binding") or "bound to the CPUs")
     # per-rank checksums against single-rank solves of exactly those blocks
     for seeds, checksum in zip(two["config"]["block_seeds_per_rank"], two["config"]["optimal_cost_checksum_per_rank"]):
         assert checksum == sum(_native.NativeTable(synthetic_block(4000, 14, seed=s)).optimal_score() for s in seeds)

@@ -372,7 +372,7 @@ def _bind(L: C.CDLL, path: str) -> C.CDLL:
 
 # every symbol include/whatshap_amd.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = [
-    "whamd_abi_version", "whamd_device_count", "whamd_last_error", "whamd_dptable_create", "whamd_dptable_create_with_options", "whamd_dptable_solve",
+    "whamd_abi_version", "whamd_device_count", "whamd_device_pci_bus_id", "whamd_last_error", "whamd_dptable_create", "whamd_dptable_create_with_options", "whamd_dptable_solve",
     "whamd_dptable_release_device", "whamd_dptable_destroy", "whamd_dptable_column_count", "whamd_dptable_individual_count",
     "whamd_dptable_read_count", "whamd_dptable_positions", "whamd_dptable_get_optimal_score",
     "whamd_dptable_get_super_reads", "whamd_dptable_get_optimal_partitioning", "whamd_dptable_get_index_path",
@@ -399,13 +399,21 @@ def _check(status: int, L=None):
         raise SolverError(status, (L or lib()).whamd_last_error().decode("utf-8", "replace"))
 
 
+def _library_of(tables):
+    """The library that created these tables (product or debug build: never mixed in one call)."""
+    libs = {id(getattr(t, "_L", None)): getattr(t, "_L", None) for t in tables}
+    if len(libs) != 1:
+        raise ValueError("tables of the product and of the debug library cannot share a call")
+    return next(iter(libs.values())) or lib()
+
+
 def enqueue_many(tables) -> None:
     """whamd_dptable_enqueue_many: submits the solves of several tables with interleaved launch sequences."""
     tables = list(tables)
     if not tables:
         return
     arr = (C.c_void_p * len(tables))(*[t._h.value for t in tables])
-    _check(lib().whamd_dptable_enqueue_many(arr, len(tables)))
+    _check(_library_of(tables).whamd_dptable_enqueue_many(arr, len(tables)))
 
 
 def wait_many(tables) -> None:
@@ -414,14 +422,14 @@ def wait_many(tables) -> None:
     if not tables:
         return
     arr = (C.c_void_p * len(tables))(*[t._h.value for t in tables])
-    _check(lib().whamd_dptable_wait_many(arr, len(tables)))
+    _check(_library_of(tables).whamd_dptable_wait_many(arr, len(tables)))
 
 
 class NativeTable:
     """Thin RAII wrapper of whamd_dptable: create -> (set_option) -> solve -> getters."""
 
     def __init__(self, problem: ProblemArrays, device: int = 0, path: Optional[str] = None, solve: bool = True, options: Optional[dict] = None):
-        L = lib()
+        L = self._L = lib()   # the library that makes the handle also queries and destroys it (the debug build has pools and arenas of its own)
         self._h = C.c_void_p()
         self._problem = problem  # keep the arrays alive while create() reads them
         opts = dict(options or {})
@@ -440,25 +448,25 @@ class NativeTable:
             self.solve()
 
     def set_option(self, key: str, value: str):
-        _check(lib().whamd_dptable_set_option(self._h, key.encode(), value.encode()))
+        _check(self._L.whamd_dptable_set_option(self._h, key.encode(), value.encode()))
 
     def solve(self):
-        _check(lib().whamd_dptable_solve(self._h))
+        _check(self._L.whamd_dptable_solve(self._h))
 
     def enqueue(self):
         """Submit the solve to the table's stream without waiting (pair with wait())."""
-        _check(lib().whamd_dptable_enqueue(self._h))
+        _check(self._L.whamd_dptable_enqueue(self._h))
 
     def wait(self):
-        _check(lib().whamd_dptable_wait(self._h))
+        _check(self._L.whamd_dptable_wait(self._h))
 
     def release_device(self):
         """Frees the device side of a solved table; the getters keep working."""
-        _check(lib().whamd_dptable_release_device(self._h))
+        _check(self._L.whamd_dptable_release_device(self._h))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            lib().whamd_dptable_destroy(self._h)
+            self._L.whamd_dptable_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -469,12 +477,12 @@ class NativeTable:
 
     def positions(self) -> np.ndarray:
         out = np.zeros(self.n_columns, dtype=np.uint32)
-        _check(lib().whamd_dptable_positions(self._h, _ptr(out, C.c_uint32)))
+        _check(self._L.whamd_dptable_positions(self._h, _ptr(out, C.c_uint32)))
         return out
 
     def optimal_score(self) -> int:
         v = C.c_uint32()
-        _check(lib().whamd_dptable_get_optimal_score(self._h, C.byref(v)))
+        _check(self._L.whamd_dptable_get_optimal_score(self._h, C.byref(v)))
         return int(v.value)
 
     def super_reads(self):
@@ -484,24 +492,24 @@ class NativeTable:
         q = np.zeros((ni, n), dtype=np.uint32)
         tv = np.zeros(n, dtype=np.uint32)
         sid = np.zeros(ni, dtype=np.uint32)
-        _check(lib().whamd_dptable_get_super_reads(
+        _check(self._L.whamd_dptable_get_super_reads(
             self._h, _ptr(a0, C.c_uint8), _ptr(a1, C.c_uint8), _ptr(q, C.c_uint32), _ptr(tv, C.c_uint32), _ptr(sid, C.c_uint32)))
         return a0, a1, q, tv, sid
 
     def partitioning(self) -> np.ndarray:
         out = np.zeros(self.n_reads, dtype=np.uint8)
-        _check(lib().whamd_dptable_get_optimal_partitioning(self._h, _ptr(out, C.c_uint8)))
+        _check(self._L.whamd_dptable_get_optimal_partitioning(self._h, _ptr(out, C.c_uint8)))
         return out
 
     def index_path(self):
         idx = np.zeros(self.n_columns, dtype=np.uint32)
         tv = np.zeros(self.n_columns, dtype=np.uint32)
-        _check(lib().whamd_dptable_get_index_path(self._h, _ptr(idx, C.c_uint32), _ptr(tv, C.c_uint32)))
+        _check(self._L.whamd_dptable_get_index_path(self._h, _ptr(idx, C.c_uint32), _ptr(tv, C.c_uint32)))
         return idx, tv
 
     def stats(self) -> dict:
         s = SolveStats()
-        _check(lib().whamd_dptable_get_stats(self._h, C.byref(s)))
+        _check(self._L.whamd_dptable_get_stats(self._h, C.byref(s)))
         return s.as_dict()
 
 
@@ -631,6 +639,16 @@ def pedmec_heuristic_many(problems, row_limit: int = 256, allow_mutations: bool 
 
 def device_count() -> int:
     return int(lib().whamd_device_count())
+
+
+def device_pci_bus_id(device: int) -> str:
+    """whamd_device_pci_bus_id: "0000:c5:00.0" of HIP device `device` (raises SolverError / WHAMD_ERR_DEVICE if there is none)."""
+    buf = C.create_string_buffer(64)
+    fn = lib().whamd_device_pci_bus_id
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
+    _check(fn(int(device), buf, 64))
+    return buf.value.decode()
 
 
 def readselection(read_ptr, var_position, var_quality, max_cov: int, read_source_id=None, preferred_source_ids=None,

@@ -166,33 +166,56 @@ def solve_blocks(problems: Sequence[ProblemArrays], device: int = 0, path=None, 
                 if trace is not None:
                     trace.append((what, wi, (time.perf_counter() - t_begin) * 1e3))
 
+            window = None                 # the window being enqueued / collected right now
+            ok = False
             try:
                 for wi in range(len(windows)):
                     window = [f.result() for f in pending]
+                    pending = []
                     mark("created", wi)
                     enqueue_many(window)      # queued behind (and beside) the previous window: the device never waits for the host
                     mark("enqueued", wi)
                     pending = ((all_pending[wi + 1] if eager_create else submit_window(windows[wi + 1])) if wi + 1 < len(windows) else [])   # built while the device solves
                     if windows_on_device < 2:
                         collect(window)
+                        window = None
                         mark("collected", wi)
                         continue
                     if in_flight is not None:
                         done, in_flight = in_flight, None
                         collect(done)
                         mark("collected", wi - 1)
-                    in_flight = window
+                    in_flight, window = window, None
                 if in_flight is not None:
                     done, in_flight = in_flight, None
                     collect(done)
+                ok = True
             finally:
-                if in_flight is not None:     # a create or an enqueue raised while a window was still on the device: collect it (its tables hold
-                    try:                      # streams and arena blocks) before the exception leaves
-                        wait_many(in_flight)
-                    except Exception:  # noqa: BLE001 -- the first error is the one to report
+                if not ok:
+                    # a create, an enqueue or a collect raised: nothing may stay on the device or in the pool behind the exception -- the window in
+                    # flight, the window that was being enqueued / collected and every table whose create is still running hold streams and arena
+                    # blocks.  Secondary errors are swallowed: the first one is the one to report.
+                    leftovers = list(in_flight or []) + [t for t in (window or []) if t not in (in_flight or [])]
+                    try:
+                        if leftovers:
+                            wait_many(leftovers)
+                    except Exception:  # noqa: BLE001
                         pass
-                    for t in in_flight:
-                        t.close()
+                    futures = list(pending) + ([f for w in all_pending for f in w] if eager_create and all_pending else [])
+                    for f in futures:
+                        try:
+                            t = f.result()
+                        except Exception:  # noqa: BLE001
+                            continue
+                        if t not in tables and t not in leftovers:
+                            leftovers.append(t)
+                    for t in leftovers:
+                        if t in tables:
+                            continue
+                        try:
+                            t.close()
+                        except Exception:  # noqa: BLE001
+                            pass
             for f in releases:
                 f.result()
         return tables
@@ -230,6 +253,141 @@ def solve_blocks(problems: Sequence[ProblemArrays], device: int = 0, path=None, 
     if errors:
         raise errors[0]
     return out
+
+
+# ------------------------------------------------------------------------------------------------ host CPUs of a rank
+def parse_cpulist(text: str) -> List[int]:
+    """"0-63,128-191" (sysfs cpulist) -> sorted CPU numbers."""
+    out = []
+    for tok in text.replace("\n", "").split(","):
+        tok = tok.strip()
+        if not tok:
+            continue
+        lo, _, hi = tok.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return sorted(set(out))
+
+
+def rank_cpu_slices(n_ranks: int, allowed: Sequence[int], node_of_rank: Sequence[int] = None, node_cpus: Dict[int, Sequence[int]] = None,
+                    core_of_cpu: Dict[int, int] = None) -> List[List[int]]:
+    """The CPUs rank r's host threads (creates, result extraction) are bound to -- pure function of the topology, one entry per rank.
+
+    With ``node_of_rank`` (NUMA node of rank r's GPU) and ``node_cpus`` (CPUs of a node): the ranks whose GPUs hang off one node share THAT
+    node's CPUs evenly, in rank order; a rank whose node is unknown (-1) or has no allowed CPU takes part in an even split of the CPUs
+    no node-bound rank uses (all allowed CPUs when nobody is node-bound).  Hardware threads of one core stay together (``core_of_cpu``:
+    CPUs are ordered by core before they are cut, so two ranks never share a core unless there are more ranks than cores).  More ranks
+    than CPUs in a share (oversubscribed tests): the CPUs are dealt out round-robin -- never an empty slice."""
+    allowed = sorted(set(int(c) for c in allowed))
+    if not allowed or n_ranks <= 0:
+        return [[] for _ in range(max(n_ranks, 0))]
+    core_of_cpu = core_of_cpu or {}
+    def by_core(cpus):
+        return sorted(cpus, key=lambda c: (core_of_cpu.get(c, c), c))
+    def deal(cpus, ranks, out):
+        cpus = by_core(cpus)
+        k = len(ranks)
+        if len(cpus) >= k:
+            # whole cores where possible: cut at core boundaries nearest to the even split
+            cores = []
+            for c in cpus:
+                key = core_of_cpu.get(c, c)
+                if cores and cores[-1][0] == key:
+                    cores[-1][1].append(c)
+                else:
+                    cores.append((key, [c]))
+            units = cores if len(cores) >= k else [(c, [c]) for c in cpus]
+            for i, r in enumerate(ranks):
+                lo, hi = len(units) * i // k, len(units) * (i + 1) // k
+                out[r] = sorted(c for _, group in units[lo:hi] for c in group)
+        else:
+            for i, r in enumerate(ranks):
+                out[r] = [cpus[i % len(cpus)]]
+    out = [None] * n_ranks
+    bound = {}
+    if node_of_rank is not None and node_cpus:
+        for r in range(n_ranks):
+            node = node_of_rank[r] if r < len(node_of_rank) else -1
+            share = [c for c in node_cpus.get(node, ()) if c in set(allowed)] if node is not None and node >= 0 else []
+            if share:
+                bound.setdefault(node, []).append(r)
+        for node, ranks in bound.items():
+            deal([c for c in node_cpus[node] if c in set(allowed)], ranks, out)
+    rest = [r for r in range(n_ranks) if out[r] is None]
+    if rest:
+        used = set(c for cpus in out if cpus for c in cpus)
+        free = [c for c in allowed if c not in used] or allowed
+        deal(free, rest, out)
+    return out
+
+
+def _sysfs(path: str):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def machine_topology():
+    """(node -> CPUs, CPU -> core key) from sysfs; empty dicts where the files are absent."""
+    import glob
+    import os
+
+    node_cpus = {}
+    for path in sorted(glob.glob("/sys/devices/system/node/node[0-9]*/cpulist")):
+        text = _sysfs(path)
+        if text is not None:
+            node_cpus[int(os.path.basename(os.path.dirname(path))[4:])] = parse_cpulist(text)
+    core_of_cpu = {}
+    for path in glob.glob("/sys/devices/system/cpu/cpu[0-9]*/topology/thread_siblings_list"):
+        text = _sysfs(path)
+        if text:
+            cpu = int(path.split("/cpu/cpu")[1].split("/")[0])
+            core_of_cpu[cpu] = min(parse_cpulist(text))
+    return node_cpus, core_of_cpu
+
+
+def device_numa_node(device: int) -> int:
+    """NUMA node of HIP device ``device`` (sysfs ``numa_node`` of its PCI function, found through ``whamd_device_pci_bus_id``); -1 if unknown."""
+    from . import _native
+
+    try:
+        bus = _native.device_pci_bus_id(device)
+    except Exception:  # noqa: BLE001 -- no device, an older library: unknown
+        return -1
+    text = _sysfs(f"/sys/bus/pci/devices/{bus}/numa_node")
+    try:
+        return int(text) if text is not None else -1
+    except ValueError:
+        return -1
+
+
+def bind_rank_to_device_cpus(local_rank: int, local_world: int, devices: Sequence[int] = None, apply: bool = True) -> dict:
+    """One process per GPU: keeps rank ``local_rank``'s host threads -- the creates of ``whamd_dptable_create`` (csrc/host_parallel.h binds its
+    workers inside the process's affinity mask), ``wait_many``'s result extraction, Python's own worker threads -- on the CPUs next to ITS GPU:
+    the NUMA node of device ``devices[local_rank]`` (default: device = local rank), shared evenly with the other ranks whose GPUs hang off the
+    same node; where the node is unknown, an even split of ``sched_getaffinity``.  Without this eight torchrun ranks pile onto whatever socket the
+    scheduler picks and every rank's workers bind to "the node the first caller ran on" (host_parallel.h).  Call BEFORE the first create.
+    No reference counterpart (the reference has no threads): this is the host half of the north star's "near-linear scaling to 8 GPUs".
+    Returns what it did: ``{"cpus": [...], "node": n, "source": "numa" | "even split", "applied": bool}``; ``WHAMD_NO_AFFINITY=1`` disables it."""
+    import os
+
+    allowed = sorted(os.sched_getaffinity(0))
+    devices = list(range(local_world)) if devices is None else list(devices)
+    node_cpus, core_of_cpu = machine_topology()
+    node_of_rank = [device_numa_node(d) for d in devices] if node_cpus else None
+    slices = rank_cpu_slices(local_world, allowed, node_of_rank, node_cpus, core_of_cpu)
+    mine = slices[local_rank] if 0 <= local_rank < len(slices) else []
+    node = node_of_rank[local_rank] if node_of_rank and local_rank < len(node_of_rank) else -1
+    info = {"cpus": mine, "n_cpus": len(mine), "node": node, "source": "numa" if node is not None and node >= 0 and node_cpus.get(node) else "even split",
+            "applied": False}
+    if apply and mine and not os.environ.get("WHAMD_NO_AFFINITY"):
+        try:
+            os.sched_setaffinity(0, mine)
+            info["applied"] = True
+        except OSError as exc:
+            info["error"] = str(exc)
+    return info
 
 
 def merge_block_solutions(n_reads: int, n_individuals: int, blocks, solutions: Dict[int, dict]) -> dict:

@@ -436,9 +436,10 @@ def problem_from_reference_objects(ingest, readset, recombcost, pedigree, distru
     precedent), no Python object is created per variant and the pedigree needs no recording subclass."""
     read_ptr, pos, alle, qual, samples = ingest.flatten_readset(readset)
     ids, triples, genotype, gl = ingest.flatten_pedigree(pedigree)
+    u32 = getattr(ingest, "u32_array", lambda values: np.asarray(list(values), dtype=np.uint32))
     return _native.ProblemArrays(
-        read_ptr, pos, alle, qual, samples, ids, triples, genotype, gl, np.asarray(list(recombcost), dtype=np.uint32),
-        None if positions is None else np.asarray(list(positions), dtype=np.uint32), distrust_genotypes,
+        read_ptr, pos, alle, qual, samples, ids, triples, genotype, gl, u32(recombcost),
+        None if positions is None else u32(positions), distrust_genotypes,
         n_variants=genotype.shape[1] if genotype.ndim == 2 else 0,
     )
 
@@ -522,7 +523,7 @@ class PedigreeDPTable:
 
     def get_optimal_partitioning(self) -> List[int]:
         if self._blocks is None:
-            return [int(x) for x in self._tables[0].partitioning()]
+            return self._tables[0].partitioning().tolist()
         out = [1] * self._problem.n_reads
         for (_, reads, _), t in zip(self._blocks, self._tables):
             part = t.partitioning().tolist()  # one native call (and one copy) per block

@@ -77,6 +77,15 @@ int whamd_abi_version(void) { return WHAMD_ABI_VERSION; }
 
 int whamd_device_count(void) { return DeviceTable::device_count(); }
 
+whamd_status_t whamd_device_pci_bus_id(int device, char* out, size_t capacity) {
+	if (!out || capacity < 16) return fail(WHAMD_ERR_INVALID, "whamd_device_pci_bus_id: buffer of at least 16 bytes expected");
+	std::string id;
+	if (!DeviceTable::device_pci_bus_id(device, id)) return fail(WHAMD_ERR_DEVICE, "no HIP device " + std::to_string(device));
+	if (id.size() + 1 > capacity) return fail(WHAMD_ERR_INVALID, "whamd_device_pci_bus_id: buffer too small");
+	std::memcpy(out, id.c_str(), id.size() + 1);
+	return WHAMD_OK;
+}
+
 const char* whamd_last_error(void) { return g_last_error.c_str(); }
 
 namespace {
@@ -294,7 +303,7 @@ whamd_status_t whamd_dptable_wait_many(whamd_dptable* const* tables, size_t n_ta
 	std::vector<whamd_status_t> status(n_tables, WHAMD_OK);
 	std::vector<std::string> messages(n_tables);
 	for (size_t i = 0; i < n_tables; ++i) tables[i]->in_flight = false;
-	const uint32_t outer = host_threads(n_tables, 1);
+	const uint32_t outer = (uint32_t)std::min<uint64_t>(host_threads(n_tables, 1), n_tables);   // (host_threads() returns n / grain + 1: never more workers than tables)
 	const uint32_t inner = std::max(1u, host_threads(1u << 30, 1) / outer);   // (a table's own finish splits its columns over threads: not 32 x 7 of them at once)
 	parallel_ranges(n_tables, outer, [&](uint64_t i0, uint64_t i1, uint32_t) {
 		struct Budget { uint32_t saved = whamd::host_threads_override(); ~Budget() { whamd::host_threads_override() = saved; } } budget;
@@ -331,7 +340,18 @@ whamd_status_t whamd_dptable_release_device(whamd_dptable* t) {
 	return WHAMD_OK;
 }
 
-void whamd_dptable_destroy(whamd_dptable* t) { delete t; }
+void whamd_dptable_destroy(whamd_dptable* t) {
+	if (!t) return;
+	if (getenv("WHAMD_DEBUG_TIMING")) {
+		const double t0 = now_ms();
+		t->device.release_device();
+		const double t1 = now_ms();
+		delete t;
+		fprintf(stderr, "[whamd timing] destroy: device side %.2f ms, host side %.2f ms\n", t1 - t0, now_ms() - t1);
+		return;
+	}
+	delete t;
+}
 
 uint64_t whamd_dptable_column_count(const whamd_dptable* t) { return t ? t->problem.n_cols : 0; }
 uint32_t whamd_dptable_individual_count(const whamd_dptable* t) { return t ? t->problem.n_ind : 0; }
@@ -930,6 +950,7 @@ void whamd_release_caches(void) {
 	genotype_release_cache();
 	whamd::heuristic_release_cache();
 	whamd::dptable_release_caches();
+	whamd::huge_block_release();   // the host side's kept blocks (host_parallel.h)
 }
 
 }  // extern "C"

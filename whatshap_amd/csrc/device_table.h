@@ -15,6 +15,7 @@ public:
 	DeviceTable& operator=(const DeviceTable&) = delete;
 
 	static int device_count();
+	static bool device_pci_bus_id(int device, std::string& out);   // "0000:c5:00.0"; false if there is no such device
 	// Builds the per-column descriptors for `p` and uploads everything the kernels read.
 	whamd_status_t upload(const Problem& p, int device, std::string& msg);
 	// Forward pass + backtrace on the device; fills s.path_*, s.optimal_score and the timing fields of st.

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cctype>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -580,6 +581,16 @@ int DeviceTable::device_count() {
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
 	return n;
+}
+
+bool DeviceTable::device_pci_bus_id(int device, std::string& out) {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return false;
+	char text[64] = {0};
+	if (hipDeviceGetPCIBusId(text, (int)sizeof text - 1, device) != hipSuccess) return false;
+	out = text;
+	for (char& ch : out) ch = (char)tolower((unsigned char)ch);   // (sysfs spells the id in lower case)
+	return true;
 }
 
 // Runs of set bits of `mask` as deposit segments (compact position | mask position << 8 | length << 16).
@@ -1428,6 +1439,16 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((slot_runx<2, 24, false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((slot_runx<2, 32, false, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((slot_runx<2, 32, false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		// every instantiation launch_slot_run / enqueue_group may pick: a 9..16-column run of 512 threads needs slotx_lds_bytes(512, 16) = 72 KB, above the
+		// 64 KB a kernel gets without the attribute (XC = 0: streamed operands, 16 KB; XC = 8: 56 KB -- registered all the same, the limit is per function)
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((slot_runx<2, 0, false, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((slot_runx<2, 0, false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((slot_runx<2, 8, false, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((slot_runx<2, 8, false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((slot_runx<2, 16, false, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((slot_runx<2, 16, false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((slot_groupx<2, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((slot_groupx<3, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #ifdef WHAMD_DEBUG_BUILD
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((slot_runx<2, 24, true, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 		HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>((slot_runx<2, 24, true, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

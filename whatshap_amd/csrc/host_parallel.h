@@ -3,7 +3,13 @@
 // the page faults of a 30 MB array are spread over the threads as well).
 #pragma once
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdint>
+#include <deque>
+#include <mutex>
+#include <type_traits>
+#include <unordered_map>
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
@@ -27,8 +33,19 @@ inline uint32_t& host_threads_override() {
 	static thread_local uint32_t value = 0;
 	return value;
 }
+// CPUs this process may run on (sched_getaffinity: a rank bound to the CPU slice of its GPU -- whatshap_amd.blocks.bind_rank_to_device_cpus --
+// sizes its workers by the slice, not by the machine), read once.
+inline uint32_t usable_cpus() {
+	static const uint32_t n = [] {
+		cpu_set_t allowed;
+		CPU_ZERO(&allowed);
+		if (sched_getaffinity(0, sizeof allowed, &allowed) == 0 && CPU_COUNT(&allowed) > 0) return (uint32_t)CPU_COUNT(&allowed);
+		return std::max(1u, std::thread::hardware_concurrency());
+	}();
+	return n;
+}
 inline uint32_t host_threads(uint64_t n_items, uint64_t grain) {
-	uint32_t n_threads = std::min<uint32_t>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+	uint32_t n_threads = std::min<uint32_t>(usable_cpus(), 32u);
 	if (const char* e = getenv("WHAMD_PLAN_THREADS")) n_threads = (uint32_t)std::max(1, atoi(e));
 	if (host_threads_override()) n_threads = host_threads_override();
 	return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_threads, n_items / std::max<uint64_t>(grain, 1) + 1));
@@ -84,63 +101,231 @@ inline const cpu_set_t* caller_node_cpus() {
 	return CPU_COUNT(set) > 0 ? set : nullptr;
 }
 
-// fn(begin, end, t) for n_threads contiguous ranges of [0, n); the calling thread takes the last range.
-// Exception-safe: the guard that joins the workers and gives the caller its affinity mask back exists BEFORE the first worker does; a
-// worker that cannot be started (std::system_error: EAGAIN under a pids limit) leaves its range and the following ones to the caller;
-// an exception inside a worker's fn is carried to the caller and rethrown after the join (the C ABI turns it into a status).
+// ---- a persistent pool of host workers.  parallel_ranges used to start and join n - 1 std::threads per call: ~40 us each, ten calls per create --
+// a millisecond of the caller's time per call at 32 threads, and a clone / mmap / munmap per worker of CPU time.  The workers now exist once per
+// process (started on first use, bound to the caller's NUMA node like the per-call threads were) and sleep on a condition variable between calls.
+// A call publishes ONE job (ranges are handed out by an atomic counter) and n - 1 tickets for it; the caller takes ranges itself until none is
+// left -- so a call never waits for a worker to wake up, nested calls cannot deadlock, and a pool that is busy with other tables' creates simply
+// leaves more ranges to the caller.  WHAMD_NO_WORKER_POOL=1: the previous thread-per-call behaviour.
+struct RangeJob {
+	void (*run)(void* ctx, uint64_t begin, uint64_t end, uint32_t t) = nullptr;
+	void* ctx = nullptr;
+	uint64_t n = 0;
+	uint32_t n_threads = 0, budget = 0;
+	std::atomic<uint32_t> next{0}, done{0};
+	std::mutex mu;                      // guards `failed` and the completion wait
+	std::condition_variable finished;
+	std::exception_ptr failed;
+	// one range; returns false when none is left
+	bool take_one() {
+		const uint32_t t = next.fetch_add(1, std::memory_order_relaxed);
+		if (t >= n_threads) return false;
+		try {
+			run(ctx, n * t / n_threads, t + 1 == n_threads ? n : n * (t + 1) / n_threads, t);
+		} catch (...) {
+			std::lock_guard<std::mutex> lock(mu);
+			if (!failed) failed = std::current_exception();
+		}
+		if (done.fetch_add(1, std::memory_order_acq_rel) + 1 == n_threads) {
+			std::lock_guard<std::mutex> lock(mu);
+			finished.notify_all();
+		}
+		return true;
+	}
+};
+
+class WorkerPool {
+public:
+	static WorkerPool& instance() {
+		static WorkerPool* pool = new WorkerPool();   // (never destroyed: workers may be asleep in it when the process exits)
+		return *pool;
+	}
+	// tickets for `extra` more workers on `job`
+	void offer(const std::shared_ptr<RangeJob>& job, uint32_t extra) {
+		{
+			std::lock_guard<std::mutex> lock(mu_);
+			grow(extra);
+			for (uint32_t i = 0; i < extra; ++i) tickets_.push_back(job);
+		}
+		if (extra == 1) wake_.notify_one(); else wake_.notify_all();
+	}
+private:
+	std::mutex mu_;
+	std::condition_variable wake_;
+	std::deque<std::shared_ptr<RangeJob>> tickets_;
+	uint32_t n_workers_ = 0, idle_ = 0;
+	void grow(uint32_t wanted) {   // mu_ held: at most as many workers as CPUs this process may use (and 64)
+		const uint32_t cap = std::min<uint32_t>(std::max(1u, usable_cpus()), 64u);
+		const uint32_t pending = (uint32_t)tickets_.size() + wanted;   // tickets waiting for a worker once `wanted` more are queued
+		while (n_workers_ < cap && idle_ < pending) {
+			try {
+				std::thread([this] { loop(); }).detach();
+			} catch (const std::system_error&) {
+				break;   // no more threads to be had: the callers run what is left themselves
+			}
+			++n_workers_;
+			++idle_;     // (counts as idle until it picks its first ticket)
+		}
+	}
+	void loop() {
+		if (const cpu_set_t* node_cpus = caller_node_cpus()) (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), node_cpus);
+		std::unique_lock<std::mutex> lock(mu_);
+		for (;;) {
+			while (tickets_.empty()) wake_.wait(lock);
+			std::shared_ptr<RangeJob> job = std::move(tickets_.front());
+			tickets_.pop_front();
+			--idle_;
+			lock.unlock();
+			const uint32_t saved = host_threads_override();
+			host_threads_override() = job->budget;   // thread_local: a worker that sizes a nested range keeps to the caller's budget
+			while (job->take_one()) {}
+			host_threads_override() = saved;
+			job.reset();
+			lock.lock();
+			++idle_;
+		}
+	}
+};
+
+// fn(begin, end, t) for n_threads contiguous ranges of [0, n); range t is executed exactly once, by the caller or by a pool worker.
+// Exception-safe: an exception inside fn is carried to the caller and rethrown after every range has finished (the C ABI turns it into a
+// status); the caller gets its affinity mask back on every way out.
 template <class F>
 inline void parallel_ranges(uint64_t n, uint32_t n_threads, F&& fn) {
 	if (n_threads <= 1) {
 		fn((uint64_t)0, n, 0u);
 		return;
 	}
+	static const bool no_pool = getenv("WHAMD_NO_WORKER_POOL") != nullptr;
 	const cpu_set_t* node_cpus = caller_node_cpus();
-	// (the calling thread takes the last range: it joins the workers on their node for the duration)
+	// (the calling thread joins the workers on their node for the duration)
 	cpu_set_t caller_mask;
 	const bool rebind = node_cpus && pthread_getaffinity_np(pthread_self(), sizeof caller_mask, &caller_mask) == 0 &&
 	                    pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), node_cpus) == 0;
-	std::vector<std::thread> workers;
-	std::vector<std::exception_ptr> failed(n_threads);
-	struct Finish {   // on every way out: join, give the caller its mask back
-		std::vector<std::thread>& workers;
+	struct Restore {
 		const bool rebind;
 		const cpu_set_t& mask;
-		~Finish() {
-			for (std::thread& w : workers) if (w.joinable()) w.join();
-			if (rebind) (void)pthread_setaffinity_np(pthread_self(), sizeof mask, &mask);
-		}
-	};
-	{
-		Finish finish{workers, rebind, caller_mask};
-		workers.reserve(n_threads - 1);
-		uint32_t started = 0;
-		for (; started + 1 < n_threads; ++started) {
-			const uint32_t t = started;
-			const uint32_t budget = host_threads_override();   // thread_local: a worker that sizes a nested range keeps to the caller's budget
+		~Restore() { if (rebind) (void)pthread_setaffinity_np(pthread_self(), sizeof mask, &mask); }
+	} restore{rebind, caller_mask};
+	using Fn = typename std::remove_reference<F>::type;
+	auto job = std::make_shared<RangeJob>();
+	job->run = [](void* ctx, uint64_t b, uint64_t e, uint32_t t) { (*static_cast<Fn*>(ctx))(b, e, t); };
+	job->ctx = const_cast<void*>(static_cast<const void*>(&fn));
+	job->n = n;
+	job->n_threads = n_threads;
+	job->budget = host_threads_override();
+	std::vector<std::thread> own;
+	if (no_pool) {
+		for (uint32_t i = 0; i + 1 < n_threads; ++i) {
 			try {
-				workers.emplace_back([&fn, &failed, n, n_threads, t, node_cpus, budget]() {
-					host_threads_override() = budget;
+				own.emplace_back([job, node_cpus] {
+					host_threads_override() = job->budget;
 					if (node_cpus) (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), node_cpus);
-					try {
-						fn(n * t / n_threads, n * (t + 1) / n_threads, t);
-					} catch (...) {
-						failed[t] = std::current_exception();
-					}
+					while (job->take_one()) {}
 				});
 			} catch (const std::system_error&) {
-				break;   // no more threads to be had: the caller runs what is left
+				break;
 			}
 		}
-		for (uint32_t t = started; t < n_threads; ++t) fn(n * t / n_threads, t + 1 == n_threads ? n : n * (t + 1) / n_threads, t);
+	} else {
+		WorkerPool::instance().offer(job, n_threads - 1);
 	}
-	for (const std::exception_ptr& e : failed)
-		if (e) std::rethrow_exception(e);
+	while (job->take_one()) {}
+	for (std::thread& w : own) w.join();
+	if (job->done.load(std::memory_order_acquire) != n_threads) {   // ranges still running on workers: `fn` and its captures must outlive them
+		std::unique_lock<std::mutex> lock(job->mu);
+		job->finished.wait(lock, [&] { return job->done.load(std::memory_order_acquire) == n_threads; });
+	}
+	if (job->failed) std::rethrow_exception(job->failed);
 }
 
 // Allocator of the create path's large arrays: the value-less construct() default-initialises (resize() of a vector of trivial
 // elements does not write them), and blocks of 4 MB and more are 2 MB-aligned and advised as transparent huge pages -- a fresh
 // 50 MB array is then 25 page faults instead of 12 800 (the range workers fault their own parts in; with 4 KB pages the faults
 // of 16 threads serialise in the kernel and were most of the flatten / plan time).
+// The large blocks themselves are KEPT between tables (a process-wide cache, like the device side's pools): freeing 200 MB of a closed table is an
+// munmap of every page -- 5.8 ms of whamd_dptable_destroy for configs[2] -- and the next create faults the same pages in again.  A freed block goes to
+// the cache (at most WHAMD_HOST_POOL_MB, default 4096 MB; the oldest blocks leave first), an allocation takes the smallest cached block that fits and
+// wastes at most a quarter.  Contents are indeterminate either way (NoInitAlloc never promised zeros).
+struct HugeBlockCache {
+	std::mutex mu;
+	struct Block { void* ptr; size_t bytes; };
+	std::deque<Block> idle;                       // oldest first
+	std::unordered_map<void*, size_t> size_of;    // every live or idle block -> its real size
+	size_t idle_bytes = 0, keep = 0;
+	HugeBlockCache() {
+		const char* e = getenv("WHAMD_HOST_POOL_MB");
+		keep = (size_t)(e ? std::max(0, atoi(e)) : 4096) << 20;
+	}
+};
+inline HugeBlockCache& huge_block_cache() {
+	static HugeBlockCache* cache = new HugeBlockCache();   // (never destroyed: vectors may be freed during static destruction)
+	return *cache;
+}
+inline void* huge_block_take(size_t bytes) {
+	constexpr size_t HUGE_PAGE = (size_t)2 << 20;
+	const size_t rounded = (bytes + HUGE_PAGE - 1) / HUGE_PAGE * HUGE_PAGE;
+	HugeBlockCache& c = huge_block_cache();
+	{
+		std::lock_guard<std::mutex> lock(c.mu);
+		size_t best = c.idle.size();
+		for (size_t i = 0; i < c.idle.size(); ++i) {
+			const size_t have = c.idle[i].bytes;
+			if (have < rounded || have > rounded + rounded / 4 + HUGE_PAGE) continue;
+			if (best == c.idle.size() || have < c.idle[best].bytes) best = i;
+		}
+		if (best != c.idle.size()) {
+			void* ptr = c.idle[best].ptr;
+			c.idle_bytes -= c.idle[best].bytes;
+			c.idle.erase(c.idle.begin() + (long)best);
+			return ptr;
+		}
+	}
+	void* ptr = std::aligned_alloc(HUGE_PAGE, rounded);
+	if (!ptr) throw std::bad_alloc();
+	static const bool advise = getenv("WHAMD_NO_HUGEPAGES") == nullptr;
+	if (advise) (void)madvise(ptr, rounded, MADV_HUGEPAGE);
+	std::lock_guard<std::mutex> lock(c.mu);
+	c.size_of[ptr] = rounded;
+	return ptr;
+}
+inline void huge_block_give(void* ptr) noexcept {
+	if (!ptr) return;
+	HugeBlockCache& c = huge_block_cache();
+	std::vector<void*> drop;
+	{
+		std::lock_guard<std::mutex> lock(c.mu);
+		const auto it = c.size_of.find(ptr);
+		const size_t bytes = it == c.size_of.end() ? 0 : it->second;
+		if (bytes == 0 || bytes > c.keep) {
+			if (it != c.size_of.end()) c.size_of.erase(it);
+			drop.push_back(ptr);
+		} else {
+			c.idle.push_back(HugeBlockCache::Block{ptr, bytes});
+			c.idle_bytes += bytes;
+			while (c.idle_bytes > c.keep && !c.idle.empty()) {   // over the budget: the oldest idle blocks go back to the system
+				c.idle_bytes -= c.idle.front().bytes;
+				c.size_of.erase(c.idle.front().ptr);
+				drop.push_back(c.idle.front().ptr);
+				c.idle.pop_front();
+			}
+		}
+	}
+	for (void* p : drop) std::free(p);
+}
+// Everything idle goes back to the system (whamd_release_caches).
+inline void huge_block_release() {
+	HugeBlockCache& c = huge_block_cache();
+	std::vector<void*> drop;
+	{
+		std::lock_guard<std::mutex> lock(c.mu);
+		for (const auto& b : c.idle) { c.size_of.erase(b.ptr); drop.push_back(b.ptr); }
+		c.idle.clear();
+		c.idle_bytes = 0;
+	}
+	for (void* p : drop) std::free(p);
+}
+
 template <class T>
 struct NoInitAlloc {
 	using value_type = T;
@@ -150,18 +335,11 @@ struct NoInitAlloc {
 	template <class U> struct rebind { using other = NoInitAlloc<U>; };
 	T* allocate(size_t n) {
 		const size_t bytes = n * sizeof(T);
-		if (bytes >= HUGE_FROM) {
-			const size_t rounded = (bytes + HUGE_PAGE - 1) / HUGE_PAGE * HUGE_PAGE;
-			void* ptr = std::aligned_alloc(HUGE_PAGE, rounded);
-			if (!ptr) throw std::bad_alloc();
-			static const bool advise = getenv("WHAMD_NO_HUGEPAGES") == nullptr;
-			if (advise) (void)madvise(ptr, rounded, MADV_HUGEPAGE);
-			return static_cast<T*>(ptr);
-		}
+		if (bytes >= HUGE_FROM) return static_cast<T*>(huge_block_take(bytes));
 		return static_cast<T*>(::operator new(bytes));
 	}
 	void deallocate(T* ptr, size_t n) noexcept {
-		if (n * sizeof(T) >= HUGE_FROM) std::free(ptr);
+		if (n * sizeof(T) >= HUGE_FROM) huge_block_give(ptr);
 		else ::operator delete(ptr);
 	}
 	template <class U> void construct(U* ptr) { ::new ((void*)ptr) U; }

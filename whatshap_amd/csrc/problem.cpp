@@ -493,6 +493,8 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 		if (a != b) (a == 0 ? tm.plus : tm.minus) |= 1u << r.child;
 		return tm;
 	};
+	// (h2p of one individual without a trio: haplotype 0 -> partition 0, haplotype 1 -> partition 1)
+	const bool single_trusted = p.n_ind == 1 && p.T == 1 && p.P == 2 && !distrust && p.h2p.size() >= 2 && p.h2p[0] == 0 && p.h2p[1] == 1 && !getenv("WHAMD_NO_SINGLE_FAST_TERMS");
 	// deltas and cost terms of column c (its entries and indexing scheme are in place); false: Mendelian conflict
 	auto column_terms = [&](uint32_t c, RangeResult& out, std::vector<uint32_t>& R, std::vector<uint32_t>& W) -> bool {
 		const ColumnEntry* col = p.col_begin(c);
@@ -516,6 +518,24 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 		}
 		double max_acost = 0.0;
 		bool any = false;
+		if (single_trusted) {
+			// ONE individual, genotypes trusted (every table of `whatshap phase` without a pedigree): the enumeration below visits a = 0 .. 3 with
+			// (a0, a1) = (a & 1, a >> 1) and keeps the assignments whose allele count equals the genotype -- written out: 0/0 -> {R}, 1/1 -> {W - R},
+			// 0/1 -> a = 1: (1, 0) = W - R - L, then a = 2: (0, 1) = R + L (the same terms in the same order, src/pedigreecolumncostcomputer.cpp:25-49)
+			const uint8_t g = p.genotype[c];
+			if (g == 1) {
+				out.terms.push_back(CostTerm{W[0] - R[0], 0, 1u});
+				out.terms.push_back(CostTerm{R[0], 1u, 0});
+				any = true;
+			} else if (g == 0) {
+				out.terms.push_back(CostTerm{R[0], 0, 0});
+				any = true;
+			} else if (g == 2) {
+				out.terms.push_back(CostTerm{W[0] - R[0], 0, 0});
+				any = true;
+			}
+			p.term_ptr[(size_t)c + 1] = out.terms.size();
+		} else
 		for (uint32_t t = 0; t < p.T; ++t) {
 			const int8_t* map = p.h2p.data() + (size_t)t * p.n_ind * 2;
 			const size_t begin = out.terms.size();

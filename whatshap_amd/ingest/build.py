@@ -39,7 +39,7 @@ def build(force=False):
     cpp = os.path.join(gen, "whamd_ingest.cpp")
     subprocess.check_call([sys.executable, "-m", "cython", "--cplus", "-3", "-I", REFERENCE, sources[0], "-o", cpp],
                           stdout=subprocess.DEVNULL)
-    subprocess.check_call(["g++", "-std=c++11", "-O2", "-fPIC", "-shared", "-w", "-Werror=return-type",
+    subprocess.check_call(["g++", "-std=c++11", "-O2", "-fPIC", "-shared", "-pthread", "-w", "-Werror=return-type",
                            "-I" + os.path.join(REFERENCE, "src"), "-I" + HERE, "-I" + sysconfig.get_paths()["include"],
                            "-o", target(), cpp])
     with open(os.path.join(HERE, "whamd_ingest.built_for"), "w") as f:   # read by load(): class layouts are per WhatsHap release

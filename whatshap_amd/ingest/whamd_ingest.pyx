@@ -6,6 +6,9 @@ C-ABI views (``whatshap_amd._native.ProblemArrays``), walking the C++ objects th
 ``whatshap_amd/ingest/build.py`` (as any sibling extension of WhatsHap would be); import ``whatshap.core`` first
 (``RTLD_GLOBAL``, as ``whatshap/__init__.py`` does) so that the C++ symbols resolve."""
 from libc.stdint cimport int32_t, uint8_t, uint32_t, uint64_t
+from libc.stdlib cimport free
+from libcpp.vector cimport vector
+from cython.view cimport array as cvarray
 
 import numpy as np
 
@@ -14,28 +17,58 @@ from whatshap cimport cpp
 
 
 cdef extern from "whamd_ingest_helpers.h":
-    size_t whamd_readset_variant_count(cpp.ReadSet*) except +
-    void whamd_flatten_readset(cpp.ReadSet*, uint64_t*, int32_t*, uint8_t*, uint32_t*, int32_t*) except +
+    void* whamd_ingest_alloc(size_t)
+    size_t whamd_readset_scan(cpp.ReadSet*, vector[cpp.Read*]&, uint64_t*) except +
+    void whamd_flatten_readset(const vector[cpp.Read*]&, const uint64_t*, int32_t*, uint8_t*, uint32_t*, int32_t*) except +
     int whamd_flatten_pedigree(cpp.Pedigree*, uint32_t*, uint32_t*, uint8_t*, double*) except +
-    cpp.ReadSet* whamd_emit_superread_set(unsigned int, int, int, size_t, const uint32_t*, const uint8_t*, const uint8_t*, const uint32_t*) except +
+    void whamd_emit_superread_sets(size_t, int, const int32_t*, size_t, const uint32_t*, const uint8_t*, const uint8_t*, const uint32_t*, cpp.ReadSet**) except +
     void whamd_read_source_ids(cpp.ReadSet*, int32_t*) except +
+
+
+cdef _uninitialised(size_t n, dtype):
+    """1-d array of ``n`` items whose memory comes from ``whamd_ingest_alloc`` (huge pages for large arrays), freed with the array."""
+    cdef size_t itemsize = np.dtype(dtype).itemsize
+    cdef void* ptr = whamd_ingest_alloc(n * itemsize)
+    if ptr == NULL:
+        raise MemoryError()
+    cdef cvarray owner = <char[:n * itemsize]> <char*> ptr
+    owner.callback_free_data = free
+    return np.frombuffer(owner, dtype=dtype, count=n)
+
+
+def u32_array(values):
+    """A Python sequence of non-negative ints (``recombcost``, ``positions`` as ``whatshap/cli/phase.py:604-612`` passes them: lists of
+    200 000 ints) -> uint32 array, one typed loop instead of ``np.asarray(list(...))``'s generic conversion (7 ms per list)."""
+    if isinstance(values, np.ndarray):
+        return np.ascontiguousarray(values, dtype=np.uint32)
+    if not isinstance(values, (list, tuple)):
+        values = list(values)
+    cdef size_t n = len(values), i
+    out = np.empty(max(n, 1), dtype=np.uint32)
+    cdef uint32_t[::1] v = out
+    cdef object item
+    for i in range(n):
+        item = values[i]
+        v[i] = <uint32_t>(<unsigned long>item)   # raises OverflowError for negative values, like vector[unsigned int] from a list
+    return out[:n]
 
 
 def flatten_readset(ReadSet readset):
     """(read_ptr, var_position, var_allele, var_quality, read_sample_id) of a reference ReadSet."""
     cdef size_t n_reads = readset.thisptr.size()
-    cdef size_t nnz = whamd_readset_variant_count(readset.thisptr)
+    cdef vector[cpp.Read*] reads
     read_ptr = np.zeros(n_reads + 1, dtype=np.uint64)
-    position = np.zeros(max(nnz, 1), dtype=np.int32)
-    allele = np.zeros(max(nnz, 1), dtype=np.uint8)
-    quality = np.zeros(max(nnz, 1), dtype=np.uint32)
-    sample = np.zeros(max(n_reads, 1), dtype=np.int32)
     cdef uint64_t[::1] v_ptr = read_ptr
+    cdef size_t nnz = whamd_readset_scan(readset.thisptr, reads, &v_ptr[0])
+    position = _uninitialised(max(nnz, 1), np.int32)
+    allele = _uninitialised(max(nnz, 1), np.uint8)
+    quality = _uninitialised(max(nnz, 1), np.uint32)
+    sample = np.zeros(max(n_reads, 1), dtype=np.int32)
     cdef int32_t[::1] v_pos = position
     cdef uint8_t[::1] v_allele = allele
     cdef uint32_t[::1] v_quality = quality
     cdef int32_t[::1] v_sample = sample
-    whamd_flatten_readset(readset.thisptr, &v_ptr[0], &v_pos[0], &v_allele[0], &v_quality[0], &v_sample[0])
+    whamd_flatten_readset(reads, &v_ptr[0], &v_pos[0], &v_allele[0], &v_quality[0], &v_sample[0])
     return read_ptr, position[:nnz], allele[:nnz], quality[:nnz], sample[:n_reads]
 
 
@@ -89,14 +122,19 @@ def emit_superreads(positions, allele0, allele1, quality, sample_ids, numbered=T
     cdef const uint8_t[:, ::1] v_a0 = a0
     cdef const uint8_t[:, ::1] v_a1 = a1
     cdef const uint32_t[:, ::1] v_q = q
+    sid = np.ascontiguousarray(np.asarray(sample_ids, dtype=np.int64).astype(np.int32))
+    cdef const int32_t[::1] v_sid = sid
     cdef size_t i
     cdef ReadSet rs
-    cdef cpp.ReadSet* built
+    cdef vector[cpp.ReadSet*] built
+    if n_ind == 0:
+        return []
+    built.resize(n_ind)
+    whamd_emit_superread_sets(n_ind, 1 if numbered else 0, &v_sid[0], n, &v_pos[0], &v_a0[0, 0], &v_a1[0, 0], &v_q[0, 0], built.data())
     results = []
     for i in range(n_ind):
-        built = whamd_emit_superread_set(<unsigned int>i, 1 if numbered else 0, <int>int(sample_ids[i]), n, &v_pos[0], &v_a0[i, 0], &v_a1[i, 0], &v_q[i, 0])
         rs = ReadSet()
         del rs.thisptr
-        rs.thisptr = built
+        rs.thisptr = built[i]
         results.append(rs)
     return results
