@@ -768,7 +768,7 @@ def create_rate_worker(args):
 
     r, _, n = args.create_rate_worker.partition("/")
     visible = max(_native.device_count(), 1)
-    binding = bind_rank_to_device_cpus(int(r), int(n), devices=[i % visible for i in range(int(n))])
+    binding = bind_rank_to_device_cpus(int(r), int(n), devices=[i % visible for i in range(int(n))], spread_nodes=visible < int(n))
     n_cpus = len(os.sched_getaffinity(0))
     n_tables = args.blocks or 1
     problems = [build_block(args, CONFIG4_SEED0 + i, args.variants or CONFIG4_VARIANTS) for i in range(n_tables)]

@@ -362,13 +362,14 @@ def device_numa_node(device: int) -> int:
         return -1
 
 
-def bind_rank_to_device_cpus(local_rank: int, local_world: int, devices: Sequence[int] = None, apply: bool = True) -> dict:
+def bind_rank_to_device_cpus(local_rank: int, local_world: int, devices: Sequence[int] = None, apply: bool = True, spread_nodes: bool = False) -> dict:
     """One process per GPU: keeps rank ``local_rank``'s host threads -- the creates of ``whamd_dptable_create`` (csrc/host_parallel.h binds its
     workers inside the process's affinity mask), ``wait_many``'s result extraction, Python's own worker threads -- on the CPUs next to ITS GPU:
     the NUMA node of device ``devices[local_rank]`` (default: device = local rank), shared evenly with the other ranks whose GPUs hang off the
     same node; where the node is unknown, an even split of ``sched_getaffinity``.  Without this eight torchrun ranks pile onto whatever socket the
     scheduler picks and every rank's workers bind to "the node the first caller ran on" (host_parallel.h).  Call BEFORE the first create.
     No reference counterpart (the reference has no threads): this is the host half of the north star's "near-linear scaling to 8 GPUs".
+    ``spread_nodes``: ignore where the visible devices sit and spread the ranks evenly over the NUMA nodes (what a full 8-GPU node looks like).
     Returns what it did: ``{"cpus": [...], "node": n, "source": "numa" | "even split", "applied": bool}``; ``WHAMD_NO_AFFINITY=1`` disables it."""
     import os
 
@@ -376,6 +377,11 @@ def bind_rank_to_device_cpus(local_rank: int, local_world: int, devices: Sequenc
     devices = list(range(local_world)) if devices is None else list(devices)
     node_cpus, core_of_cpu = machine_topology()
     node_of_rank = [device_numa_node(d) for d in devices] if node_cpus else None
+    if spread_nodes and node_cpus:
+        # a dry run of "rank r of n" on a box with fewer GPUs than ranks (bench.py's create_rate): the GPUs of a full node are spread evenly over its
+        # NUMA nodes, so the ranks are too
+        nodes = sorted(node_cpus)
+        node_of_rank = [nodes[r * len(nodes) // local_world] for r in range(local_world)]
     slices = rank_cpu_slices(local_world, allowed, node_of_rank, node_cpus, core_of_cpu)
     mine = slices[local_rank] if 0 <= local_rank < len(slices) else []
     node = node_of_rank[local_rank] if node_of_rank and local_rank < len(node_of_rank) else -1

@@ -950,7 +950,7 @@ void whamd_release_caches(void) {
 	genotype_release_cache();
 	whamd::heuristic_release_cache();
 	whamd::dptable_release_caches();
-	whamd::huge_block_release();   // the host side's kept blocks (host_parallel.h)
+	whamd::host_pool_release();   // the host side's kept blocks (host_memory.cpp)
 }
 
 }  // extern "C"

@@ -191,7 +191,7 @@ constexpr size_t STAGE_MAX = (size_t)1 << 30, STAGE_MIN_COPY = (size_t)256 << 10
 // ---------------------------------------------------------------------------------------------- arenas kept between tables
 // hipFree + hipMalloc of a 13 GB backtrace arena per table stalls for up to a second every few tables (measured: create 26 ms,
 // 26 ms, 26 ms, 997 ms; 24 tables of 100 000 columns created and released one after the other: 50 - 100 ms each).  The arenas of closed
-// tables stay allocated (a few blocks per process, at most 40 % of the device); the next table takes the smallest one that is large enough
+// tables stay allocated (a few blocks per process, at most 60 % of the device); the next table takes the smallest one that is large enough
 // and not wastefully large.  Counted as free memory when a table sizes its arena; given back when memory is tight.
 struct ArenaCache {
 	std::mutex mu;
@@ -245,7 +245,7 @@ void arena_give(int device, void* ptr, size_t bytes) {   // called with `device`
 		std::lock_guard<std::mutex> lock(g_arena.mu);
 		size_t idle = 0, total_b = 0, free_b = 0;
 		for (const ArenaCache::Block& b : g_arena.blocks) idle += b.bytes;
-		const bool room = hipMemGetInfo(&free_b, &total_b) == hipSuccess && idle + bytes <= total_b / 5 * 2;
+		const bool room = hipMemGetInfo(&free_b, &total_b) == hipSuccess && idle + bytes <= total_b / 5 * 3;   // (eight trio tables of 100 000 columns: 8 x 15 GB)
 		if (room && g_arena.blocks.size() < ARENA_BLOCKS && bytes >= ((size_t)32 << 20) && debug_env("WHAMD_NO_ARENA_CACHE") == nullptr) {
 			g_arena.blocks.push_back(ArenaCache::Block{ptr, bytes, device});
 			return;
@@ -676,6 +676,10 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	// 7.7 M columns/s instead of 6.4 M; alone the same table is slower that way (1.87 M against 2.26 M), and narrow tables gain nothing.
 	int slot_lr = m.slot_lr, slot_l = m.slot_l;
 	if (m.shared_hint && p.T == 1 && p.max_k >= 18 && !m.slot_l_set && m.slot_lr == 2) { slot_lr = 3; slot_l = 12; }
+	// Coverage 21 and 22 (512 / 1 024 workgroups of four cells per launch: the table fills the chip by itself, rounds of workgroups queue behind each
+	// other) take the eight-cell layout ALONE as well: 14.0 against 17.9 us per launch at 21, 20.3 against 30.1 at 22 (scripts/gpu_wide_ab.py; the same
+	// kernels with their operands streamed: 14.4 / 22.6).  At 23 the four-cell kernel with streamed operands wins (36.2 against 43.0 us): launch_slot_run.
+	if (p.T == 1 && p.max_k >= 21 && p.max_k <= 22 && !m.slot_l_set && m.slot_lr == 2 && !debug_env("WHAMD_NO_WIDE_LAYOUT")) { slot_lr = 3; slot_l = 12; }
 	m.slot_lr_used = slot_lr;
 	m.use_slots = (m.path == "auto" || m.path == "slots") && !m.wide && plan_forward_slots(p, p.T > 1 ? (m.slot_l_set ? -m.slot_l : 0) : std::max(8, slot_l), m.symmetry, m.splan, slot_lr);
 	// pedigree slot runs keep their cost-form tables in HBM (slots.h): at most a quarter of what is free, else the older paths
@@ -879,18 +883,29 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	m.dp.ped_terms = (const PedTerm*)d_pterm;
 	ulap("column arrays: allocations + copies");
 	// slot runs: per-column descriptors and the backtrace blobs ([ncols] SlotBtCol + ending slots per run)
-	std::vector<uint32_t> slot_blob;
+	RawVec<uint32_t> slot_blob;
 	std::vector<uint32_t> slot_blob_off(m.splan.runs.size(), 0), slot_blob_words(m.splan.runs.size(), 0);
-	for (size_t ri = 0; ri < m.splan.runs.size(); ++ri) {
-		const SlotRun& run = m.splan.runs[ri];
-		slot_blob_off[ri] = (uint32_t)slot_blob.size();
-		const uint32_t* cols32 = reinterpret_cast<const uint32_t*>(m.splan.bt_cols.data() + run.row_off);
-		slot_blob.insert(slot_blob.end(), cols32, cols32 + (size_t)run.ncols * (sizeof(SlotBtCol) / 4));
-		const size_t end_words = (run.n_ends + 3) / 4 + 1;
-		const size_t at = slot_blob.size();
-		slot_blob.resize(at + end_words, 0);
-		if (run.n_ends) std::memcpy(slot_blob.data() + at, m.splan.end_slots.data() + m.splan.end_off[ri], run.n_ends);
-		slot_blob_words[ri] = (uint32_t)(slot_blob.size() - slot_blob_off[ri]);
+	{
+		// offsets first (one pass over the runs), then every run copies its own piece (8 MB for configs[2]: 0.9 ms when it was one growing vector)
+		size_t words = 0;
+		for (size_t ri = 0; ri < m.splan.runs.size(); ++ri) {
+			const SlotRun& run = m.splan.runs[ri];
+			slot_blob_off[ri] = (uint32_t)words;
+			slot_blob_words[ri] = (uint32_t)((size_t)run.ncols * (sizeof(SlotBtCol) / 4) + (run.n_ends + 3) / 4 + 1);
+			words += slot_blob_words[ri];
+		}
+		slot_blob.resize(words);
+		parallel_ranges(m.splan.runs.size(), host_threads(m.splan.runs.size(), 512), [&](uint64_t r0, uint64_t r1, uint32_t) {
+			for (size_t ri = r0; ri < r1; ++ri) {
+				const SlotRun& run = m.splan.runs[ri];
+				uint32_t* dst = slot_blob.data() + slot_blob_off[ri];
+				const size_t col_words = (size_t)run.ncols * (sizeof(SlotBtCol) / 4);
+				std::memcpy(dst, m.splan.bt_cols.data() + run.row_off, col_words * 4);
+				const size_t end_words = (run.n_ends + 3) / 4 + 1;
+				std::memset(dst + col_words, 0, end_words * 4);
+				if (run.n_ends) std::memcpy(dst + col_words, m.splan.end_slots.data() + m.splan.end_off[ri], run.n_ends);
+			}
+		});
 	}
 	ulap("slot backtrace blobs (host)");
 	void *d_srows = nullptr, *d_sblob = nullptr;
@@ -1608,7 +1623,9 @@ void DeviceTable::Impl::launch_slot_run(const SlotBatchEntry& e, uint64_t& launc
 	const size_t lds = slot_run_lds_bytes(run.threads, run.lr, run.ncols);   // wave-slot exchange + hot lines + per-wave A + lane sums
 	const dim3 grid(1u << (run.g - run.half)), block(run.threads);
 	if ((run.yflags & 8u) && run.lr == 2u) {   // X run with four cells per thread: registers instead of LDS lines (LDS: the wave-slot exchange buffers + the threads' own operand lines)
-		const bool streamed = m.side_by_side || debug_env("WHAMD_XSTREAM");   // (no LDS lines: room for other tables' workgroups on the CU)
+		// (no LDS lines: room for other tables' workgroups on the CU -- or, from 1 024 workgroups on, for FOUR of this table's own instead of two:
+		// a launch of 2 048 workgroups -- coverage 23 -- takes 36.2 instead of 56.2 us, scripts/gpu_wide_ab.py)
+		const bool streamed = m.side_by_side || debug_env("WHAMD_XSTREAM") || (grid.x >= 1024u && !debug_env("WHAMD_NO_WIDE_LAYOUT"));
 		const size_t lds_x = streamed ? (size_t)2 * run.threads * 16 : slotx_lds_bytes(run.threads, (run.ncols + 7u) & ~7u);
 		// narrow tables: the run's workgroups packed onto one XCD (slot_runx: eight times the grid, every eighth workgroup works)
 		const uint32_t pack = (grid.x <= 32u && !m.side_by_side && !debug_env("WHAMD_NO_XCD_PACK")) ? 1u : 0u;

@@ -243,105 +243,22 @@ inline void parallel_ranges(uint64_t n, uint32_t n_threads, F&& fn) {
 // elements does not write them), and blocks of 4 MB and more are 2 MB-aligned and advised as transparent huge pages -- a fresh
 // 50 MB array is then 25 page faults instead of 12 800 (the range workers fault their own parts in; with 4 KB pages the faults
 // of 16 threads serialise in the kernel and were most of the flatten / plan time).
-// The large blocks themselves are KEPT between tables (a process-wide cache, like the device side's pools): freeing 200 MB of a closed table is an
-// munmap of every page -- 5.8 ms of whamd_dptable_destroy for configs[2] -- and the next create faults the same pages in again.  A freed block goes to
-// the cache (at most WHAMD_HOST_POOL_MB, default 4096 MB; the oldest blocks leave first), an allocation takes the smallest cached block that fits and
-// wastes at most a quarter.  Contents are indeterminate either way (NoInitAlloc never promised zeros).
-struct HugeBlockCache {
-	std::mutex mu;
-	struct Block { void* ptr; size_t bytes; };
-	std::deque<Block> idle;                       // oldest first
-	std::unordered_map<void*, size_t> size_of;    // every live or idle block -> its real size
-	size_t idle_bytes = 0, keep = 0;
-	HugeBlockCache() {
-		const char* e = getenv("WHAMD_HOST_POOL_MB");
-		keep = (size_t)(e ? std::max(0, atoi(e)) : 4096) << 20;
-	}
-};
-inline HugeBlockCache& huge_block_cache() {
-	static HugeBlockCache* cache = new HugeBlockCache();   // (never destroyed: vectors may be freed during static destruction)
-	return *cache;
-}
-inline void* huge_block_take(size_t bytes) {
-	constexpr size_t HUGE_PAGE = (size_t)2 << 20;
-	const size_t rounded = (bytes + HUGE_PAGE - 1) / HUGE_PAGE * HUGE_PAGE;
-	HugeBlockCache& c = huge_block_cache();
-	{
-		std::lock_guard<std::mutex> lock(c.mu);
-		size_t best = c.idle.size();
-		for (size_t i = 0; i < c.idle.size(); ++i) {
-			const size_t have = c.idle[i].bytes;
-			if (have < rounded || have > rounded + rounded / 4 + HUGE_PAGE) continue;
-			if (best == c.idle.size() || have < c.idle[best].bytes) best = i;
-		}
-		if (best != c.idle.size()) {
-			void* ptr = c.idle[best].ptr;
-			c.idle_bytes -= c.idle[best].bytes;
-			c.idle.erase(c.idle.begin() + (long)best);
-			return ptr;
-		}
-	}
-	void* ptr = std::aligned_alloc(HUGE_PAGE, rounded);
-	if (!ptr) throw std::bad_alloc();
-	static const bool advise = getenv("WHAMD_NO_HUGEPAGES") == nullptr;
-	if (advise) (void)madvise(ptr, rounded, MADV_HUGEPAGE);
-	std::lock_guard<std::mutex> lock(c.mu);
-	c.size_of[ptr] = rounded;
-	return ptr;
-}
-inline void huge_block_give(void* ptr) noexcept {
-	if (!ptr) return;
-	HugeBlockCache& c = huge_block_cache();
-	std::vector<void*> drop;
-	{
-		std::lock_guard<std::mutex> lock(c.mu);
-		const auto it = c.size_of.find(ptr);
-		const size_t bytes = it == c.size_of.end() ? 0 : it->second;
-		if (bytes == 0 || bytes > c.keep) {
-			if (it != c.size_of.end()) c.size_of.erase(it);
-			drop.push_back(ptr);
-		} else {
-			c.idle.push_back(HugeBlockCache::Block{ptr, bytes});
-			c.idle_bytes += bytes;
-			while (c.idle_bytes > c.keep && !c.idle.empty()) {   // over the budget: the oldest idle blocks go back to the system
-				c.idle_bytes -= c.idle.front().bytes;
-				c.size_of.erase(c.idle.front().ptr);
-				drop.push_back(c.idle.front().ptr);
-				c.idle.pop_front();
-			}
-		}
-	}
-	for (void* p : drop) std::free(p);
-}
-// Everything idle goes back to the system (whamd_release_caches).
-inline void huge_block_release() {
-	HugeBlockCache& c = huge_block_cache();
-	std::vector<void*> drop;
-	{
-		std::lock_guard<std::mutex> lock(c.mu);
-		for (const auto& b : c.idle) { c.size_of.erase(b.ptr); drop.push_back(b.ptr); }
-		c.idle.clear();
-		c.idle_bytes = 0;
-	}
-	for (void* p : drop) std::free(p);
-}
+// The blocks themselves come from the library's own allocation functions (host_memory.cpp): requests of 64 KB and more are served from blocks
+// kept between tables, 2 MB-aligned and advised as huge pages from 2 MB on.
+void* host_pool_take(size_t bytes);
+bool host_pool_give(void* ptr);
+void host_pool_release();      // everything idle goes back to the system (whamd_release_caches)
+size_t host_pool_idle_bytes();
+bool host_pool_enabled();
 
 template <class T>
 struct NoInitAlloc {
 	using value_type = T;
-	static constexpr size_t HUGE_FROM = (size_t)4 << 20, HUGE_PAGE = (size_t)2 << 20;
 	NoInitAlloc() = default;
 	template <class U> NoInitAlloc(const NoInitAlloc<U>&) {}
 	template <class U> struct rebind { using other = NoInitAlloc<U>; };
-	T* allocate(size_t n) {
-		const size_t bytes = n * sizeof(T);
-		if (bytes >= HUGE_FROM) return static_cast<T*>(huge_block_take(bytes));
-		return static_cast<T*>(::operator new(bytes));
-	}
-	void deallocate(T* ptr, size_t n) noexcept {
-		if (n * sizeof(T) >= HUGE_FROM) huge_block_give(ptr);
-		else ::operator delete(ptr);
-	}
+	T* allocate(size_t n) { return static_cast<T*>(::operator new(n * sizeof(T))); }
+	void deallocate(T* ptr, size_t) noexcept { ::operator delete(ptr); }
 	template <class U> void construct(U* ptr) { ::new ((void*)ptr) U; }
 	template <class U, class... A> void construct(U* ptr, A&&... args) { ::new ((void*)ptr) U(std::forward<A>(args)...); }
 	template <class U> bool operator==(const NoInitAlloc<U>&) const { return true; }
