@@ -74,7 +74,7 @@ WORKLOADS = {
     "heuristic": dict(heuristic=True, variants=8000, coverage=30),                 # PedMecHeuristic, coverage beyond the exact DP
     "heuristic_x32": dict(heuristic=True, variants=8000, coverage=30, blocks=32),  # 32 PedMecHeuristic tables in ONE launch (one persistent workgroup each)
 }
-EXTRA_CONFIGS = ["config2_shim", "config3_shim", "config1", "config1_x24", "config1_x48", "config1_x96", "config3", "config3_distrust", "config3_x8", "blocks3", "blocks24", "irregular", "irregular_x24", "irregular_cov20_x12", "config_cov23", "quartet", "quartet_distrust", "genotype", "genotype_trio", "heuristic", "heuristic_x32"]
+EXTRA_CONFIGS = ["config2_shim", "config3_shim", "config1", "config1_x24", "config1_x96", "config3", "config3_distrust", "config3_x8", "blocks3", "blocks24", "irregular", "irregular_x24", "irregular_cov20_x12", "config_cov23", "quartet", "quartet_distrust", "genotype", "genotype_trio", "heuristic", "heuristic_x32"]
 
 
 def parse_args():
@@ -936,7 +936,7 @@ def run_extra_configs(args):
     """The other single-GPU workloads, one child process each (own tables, own counters, own CPU sample)."""
     out = []
     for name in EXTRA_CONFIGS:
-        cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--sub", "--steps", "10", "--warmup", "2",
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--sub", "--steps", "6", "--warmup", "2",
                "--configs", "off", "--pmc", args.pmc, "--pmc-keep", os.path.join(args.pmc_keep, name)]
         if args.cpu_baseline_columns == 0:
             cmd += ["--cpu-baseline-columns", "0"]
@@ -1056,11 +1056,16 @@ def main():
             args.option = ["shared_launches=1"]
     # one process per GPU: this rank's host threads (creates, result extraction) stay on the CPUs next to ITS GPU (whatshap_amd.blocks.bind_rank_to_device_cpus)
     cpu_binding = None
-    if (world > 1 or "RANK" in os.environ) and not args.no_affinity:
+    if not args.no_affinity:
         from whatshap_amd.blocks import bind_rank_to_device_cpus
 
-        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-        cpu_binding = bind_rank_to_device_cpus(local_rank, local_world, devices=[(r % visible if args.oversubscribe else r) for r in range(local_world)])
+        if world > 1 or "RANK" in os.environ:
+            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+            cpu_binding = bind_rank_to_device_cpus(local_rank, local_world, devices=[(r % visible if args.oversubscribe else r) for r in range(local_world)])
+        else:
+            # one rank: the whole NUMA node of its GPU, not the whole host -- unbound, Python's worker threads (the creates of blocks.solve_blocks) land on
+            # both sockets while the library's own workers stay on one: 24 creates took 55 ms on 256 unbound CPUs and 31 ms in a process held to 32
+            cpu_binding = bind_rank_to_device_cpus(0, 1, devices=[device])
     problems = [build_block(args, *blocks[b]) for b in mine]
     native_path = None if args.path == "auto" else args.path
     tables = []
@@ -1127,12 +1132,17 @@ def main():
     from whatshap_amd.blocks import solve_blocks
 
     n_cpus = len(os.sched_getaffinity(0))
+    whole = min(args.in_flight, len(problems))
     if len(problems) == 1:
-        host_shapes = [(1, 0)]
+        host_shapes = [(1, 0, 1)]
     elif world > 1:
-        host_shapes = [(max(1, min(len(problems), n_cpus // 2)), 2), (max(1, min(len(problems), n_cpus // 4)), 4)]
+        host_shapes = [(max(1, min(len(problems), n_cpus // 2)), 2, whole), (max(1, min(len(problems), n_cpus // 4)), 4, whole)]
     else:
-        host_shapes = [(16, 2), (len(problems), 4), (len(problems), 8)]
+        # (workers, threads per create, tables per window): one window of everything keeps the device's launch sequence shortest; two or three windows let the
+        # creates of the next one run under the solve of the current one -- what wins depends on the table shape and is measured, not assumed
+        host_shapes = [(16, 2, whole), (len(problems), 1, whole), (len(problems), 2, whole), (len(problems), 4, whole)]
+        if whole >= 24:
+            host_shapes += [(16, 2, (whole + 1) // 2), (min(len(problems), 32), 2, (whole + 1) // 2), (16, 2, (whole + 2) // 3)]
     host_shapes = list(dict.fromkeys(host_shapes))
 
     def fresh_step(shape):
@@ -1150,7 +1160,7 @@ def main():
             return {"wall_ms": (td - ta) * 1e3, "create_ms": (tb - ta) * 1e3, "solve_ms": (tc - tb) * 1e3, "close_ms": (td - tc) * 1e3,
                     "device_ms": st["total_ms"], "superreads_ms": st["host_finish_ms"], "flatten_ms": st.get("host_flatten_ms"), "checksum": checksum}
         trace = []
-        solved = solve_blocks(problems, device=device, path=native_path, max_in_flight=args.in_flight, release=True,
+        solved = solve_blocks(problems, device=device, path=native_path, max_in_flight=shape[2], release=True,
                               create_threads=shape[0], host_threads_per_create=shape[1], trace=trace)
         tc = time.perf_counter()
         checksum = int(sum(t.optimal_score() for t in solved))
@@ -1174,10 +1184,10 @@ def main():
     shape = host_shapes[0]
     for cand in host_shapes:       # untimed: one step per host shape (the first also warms the pools); the fastest is the one that is timed
         rec = fresh_step(cand)
-        tried.append({"create_threads": cand[0], "host_threads_per_create": cand[1], "wall_ms": rec["wall_ms"]})
+        tried.append({"create_threads": cand[0], "host_threads_per_create": cand[1], "tables_per_window": cand[2], "wall_ms": rec["wall_ms"]})
     if len(host_shapes) > 1:
         best = min(tried, key=lambda r: r["wall_ms"])
-        shape = (best["create_threads"], best["host_threads_per_create"])
+        shape = (best["create_threads"], best["host_threads_per_create"], best["tables_per_window"])
     for _ in range(max(0, args.warmup - len(host_shapes))):
         fresh_step(shape)
     sync()
@@ -1198,7 +1208,7 @@ def main():
     per_rank = {"rank": rank, "device": device, "tables": len(problems), "create_ms": med("create_ms"), "solve_ms": med("solve_ms"), "close_ms": med("close_ms"),
                 "step_ms": med("wall_ms"), "resident_step_ms": sorted(resident_step_s)[len(resident_step_s) // 2] * 1e3,
                 "cpus": (cpu_binding or {}).get("n_cpus", n_cpus), "numa_node": (cpu_binding or {}).get("node"), "cpu_source": (cpu_binding or {}).get("source", "unbound"),
-                "create_threads": shape[0], "host_threads_per_create": shape[1]}
+                "create_threads": shape[0], "host_threads_per_create": shape[1], "tables_per_window": shape[2]}
     per_rank_checksums = [int(totals[2])]
     # what a SCALE record can be audited with: which rank ran which blocks on which device, and for how long
     print(f"[bench rank {rank}/{world}] device {device}, blocks {[blocks[b][0] for b in mine]} (seeds), {len(mine)} table(s), fresh: {elapsed:.3f} s for {args.steps} step(s) "
@@ -1276,7 +1286,8 @@ def main():
             "per_rank": per_rank_all,
             "host_shapes_tried": tried,
         }
-        out["config"]["cpu_binding"] = "rank r bound to the CPUs of its GPU's NUMA node (whatshap_amd.blocks.bind_rank_to_device_cpus)" if cpu_binding is not None else "none (one rank: the whole host)"
+        out["config"]["cpu_binding"] = (f"rank r bound to the CPUs of its GPU's NUMA node, shared evenly between the ranks of that node (whatshap_amd.blocks.bind_rank_to_device_cpus): "
+                                        f"{(cpu_binding or {}).get('n_cpus')} CPUs, {(cpu_binding or {}).get('source')}") if cpu_binding is not None else "none (--no-affinity)"
         # ---- fresh tables end to end (host-inclusive): create + solve + getters
         if world == 1 and len(blocks) == 1:
             seed, v = blocks[mine[0]]
@@ -1327,7 +1338,7 @@ def main():
         elif world == 1:
             # several tables: `value` already is the host-side work queue from host arrays (region 2); end to end adds the three getters of every table
             te0 = time.perf_counter()
-            solved = solve_blocks(problems, device=device, path=native_path, max_in_flight=args.in_flight, release=True, create_threads=shape[0], host_threads_per_create=shape[1])
+            solved = solve_blocks(problems, device=device, path=native_path, max_in_flight=shape[2], release=True, create_threads=shape[0], host_threads_per_create=shape[1])
             checksum = 0
             for t in solved:
                 checksum += t.optimal_score()
@@ -1337,7 +1348,7 @@ def main():
                 t.close()
             if checksum != int(totals[2]):
                 raise SystemExit(f"end_to_end: cost checksum {checksum} of the pipelined solve differs from {int(totals[2])}")
-            out["end_to_end"] = {"value": cols_job / wall, "unit": "variant-columns/s", "wall_ms": wall * 1e3, "tables_per_window": min(args.in_flight, len(problems)), "create_threads": shape[0],
+            out["end_to_end"] = {"value": cols_job / wall, "unit": "variant-columns/s", "wall_ms": wall * 1e3, "tables_per_window": shape[2], "create_threads": shape[0],
                                  "host_threads_per_create": shape[1], "fraction_of_device_only": (cols_job / wall) / out["value_resident"]["value"], "tried": tried,
                                  "what": f"{len(problems)} fresh tables from host arrays through blocks.solve_blocks (create of the next window on `create_threads` host workers x "
                                          f"`host_threads_per_create` threads under the device solve of the current one, enqueue_many / wait_many per window) + 3 getters per table"}

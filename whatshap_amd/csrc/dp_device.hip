@@ -186,7 +186,7 @@ struct UploadStage {
 	bool broken = false;   // hipHostMalloc failed once: pageable copies from then on
 };
 UploadStage g_stage;
-constexpr size_t STAGE_MAX = (size_t)1 << 30, STAGE_MIN_COPY = (size_t)256 << 10, STAGE_GRAIN = (size_t)16 << 20, STAGE_AREAS = 8;
+constexpr size_t STAGE_MAX = (size_t)1 << 30, STAGE_MIN_COPY = (size_t)256 << 10, STAGE_GRAIN = (size_t)16 << 20, STAGE_AREAS = 32;   // (eight areas: the ninth and later of 64 concurrent creates fell back to pageable copies, 9.5 GB/s and synchronous)
 
 // ---------------------------------------------------------------------------------------------- arenas kept between tables
 // hipFree + hipMalloc of a 13 GB backtrace arena per table stalls for up to a second every few tables (measured: create 26 ms,
@@ -308,7 +308,7 @@ struct StageSession {
 		return true;
 	}
 	hipError_t copy(void* dst, const void* src, size_t bytes) {
-		if (!enabled || g_stage.broken || slot < 0 || bytes < STAGE_MIN_COPY) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream);
+		if (!enabled || g_stage.broken || slot < 0 || bytes < STAGE_MIN_COPY || image) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream);
 		total += (bytes + 255) & ~(size_t)255;
 		size_t done = 0;
 		while (done < bytes) {
@@ -331,6 +331,14 @@ struct StageSession {
 			done += chunk;
 		}
 		return hipSuccess;
+	}
+	// One image of everything a table uploads (DeviceTable::upload): the area holds `bytes` and copy() leaves it alone (pieces that do not fit the image go
+	// out as copies of their own, straight from the caller's memory).
+	bool image = false;
+	bool begin_image(size_t bytes) {
+		if (!enabled || g_stage.broken || slot < 0 || pending || used != 0) return false;
+		image = ensure(bytes);
+		return image;
 	}
 	void expect(size_t bytes) {   // before the first copy: one allocation
 		std::lock_guard<std::mutex> lock(g_stage.mu);
@@ -852,21 +860,50 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		if (e == hipSuccess) m.allocations.emplace_back(*dptr, got);
 		return e;
 	};
-	auto up = [&](void** dptr, const void* src, size_t bytes) -> hipError_t {
-		hipError_t e = alloc(dptr, bytes);
-		if (e != hipSuccess) return e;
-		if (bytes) e = stage.copy(*dptr, src, bytes);
-		return e;
-	};
 	std::vector<int32_t> delta_fallback;
 	const int32_t* delta_src = p.delta.data();
 	size_t delta_count = (size_t)p.col_ptr[n] * p.n_ind;
 	if (p.n_ind == 0) { delta_fallback.assign(std::max<size_t>(p.col_ptr[n], 1), 0); delta_src = delta_fallback.data(); delta_count = delta_fallback.size(); }
 	void *d_delta, *d_term_ptr, *d_terms, *d_segs, *d_bt, *d_keys, *d_last_keys, *d_rcol, *d_rbt, *d_fterms = nullptr;
-	stage.expect(m.cols.size() * sizeof(DevColumn) + delta_count * sizeof(int32_t) + term_ptr32.size() * 4 + (terms.size() + p.fterms.size()) * sizeof(DevTerm) + segs.size() * 4 +
+	const size_t upload_bytes = m.cols.size() * sizeof(DevColumn) + delta_count * sizeof(int32_t) + term_ptr32.size() * 4 + (terms.size() + p.fterms.size()) * sizeof(DevTerm) + segs.size() * 4 +
 	             m.plan.columns.size() * (sizeof(ResColumn) + sizeof(ResBacktrace) + sizeof(PedColumn)) + m.plan.ped_terms.size() * sizeof(PedTerm) +
 	             (m.splan.rows.size() + SLOT_ROW_PAD) * sizeof(SlotRow) + m.splan.prows.size() * sizeof(PedSlotRow) + m.splan.bt_cols.size() * (sizeof(SlotBtCol) + 8) +
-	             m.splan.runs.size() * (sizeof(SlotRun) + sizeof(PedSlotExtra) + sizeof(BtUnit) + 64) + ((size_t)8 << 20));
+	             m.splan.runs.size() * (sizeof(SlotRun) + sizeof(PedSlotExtra) + sizeof(BtUnit) + sizeof(SlotBatchEntry) + 64) + m.plan.segments.size() * (sizeof(ResBatchEntry) + sizeof(BtUnit)) + ((size_t)8 << 20);
+	stage.expect(upload_bytes);
+	// ONE device block and ONE staging image per table: every uploaded array is a piece of the block at the offset it has in the pinned area, and the pieces
+	// leave as a few large copies.  (Per-array copies of ~1 MB ran at 25 GB/s -- 96 coverage-15 tables, 28 MB each, spent their creates waiting for the link --;
+	// pieces of 32 MB and more reach 56 GB/s: scripts/micro/r6_h2d_rate.py.)
+	char* d_slab = nullptr;
+	size_t slab_cap = 0, slab_used = 0, slab_flushed = 0;
+	if (upload_bytes <= STAGE_MAX && !debug_env("WHAMD_NO_UPLOAD_SLAB") && stage.begin_image(upload_bytes)) {
+		void* ptr = nullptr;
+		if (alloc(&ptr, upload_bytes) == hipSuccess) { d_slab = (char*)ptr; slab_cap = upload_bytes; }
+		else { (void)hipGetLastError(); stage.image = false; }
+	}
+	auto flush_slab = [&]() -> hipError_t {
+		if (!d_slab || slab_used == slab_flushed) return hipSuccess;
+		const hipError_t e = hipMemcpyAsync(d_slab + slab_flushed, stage.base + slab_flushed, slab_used - slab_flushed, hipMemcpyHostToDevice, m.stream);
+		stage.pending = true;
+		slab_flushed = slab_used;
+		return e;
+	};
+	auto up = [&](void** dptr, const void* src, size_t bytes) -> hipError_t {
+		const size_t padded = (bytes + 255) & ~(size_t)255;
+		if (d_slab && slab_used + padded <= slab_cap) {
+			*dptr = d_slab + slab_used;
+			char* at = stage.base + slab_used;
+			const char* from = (const char*)src;
+			if (bytes >= ((size_t)4 << 20)) parallel_ranges(bytes, host_threads(bytes, (size_t)2 << 20), [&](uint64_t b0, uint64_t b1, uint32_t) { std::memcpy(at + b0, from + b0, b1 - b0); });
+			else if (bytes) std::memcpy(at, from, bytes);
+			slab_used += padded;
+			stage.total += padded;
+			return slab_used - slab_flushed >= ((size_t)32 << 20) ? flush_slab() : hipSuccess;
+		}
+		hipError_t e = alloc(dptr, bytes);
+		if (e != hipSuccess) return e;
+		if (bytes) e = stage.copy(*dptr, src, bytes);
+		return e;
+	};
 	HIP_TRY(up((void**)&m.d_cols, m.cols.data(), m.cols.size() * sizeof(DevColumn)));
 	HIP_TRY(up(&d_delta, delta_src, delta_count * sizeof(int32_t)));
 	HIP_TRY(up(&d_term_ptr, term_ptr32.data(), term_ptr32.size() * sizeof(uint32_t)));
@@ -1362,6 +1399,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		HIP_TRY(up(&d_btjobs, btjobs.data(), btjobs.size() * sizeof(BtJob)));
 		m.d_btjobs = (BtJob*)d_btjobs;
 	}
+	HIP_TRY(flush_slab());   // (everything is staged; the table kernels below read it)
 	m.dp.cols = m.d_cols;
 	m.dp.term_ptr = (const uint32_t*)d_term_ptr;
 	m.dp.terms = (const DevTerm*)d_terms;

@@ -7,7 +7,7 @@
 // (measured: profiles/r06/, MALLOC_MMAP_THRESHOLD_ experiment).  This file replaces the global allocation functions FOR THIS SHARED OBJECT ONLY
 // (the link's version script keeps every symbol but whamd_* local and binds references inside the library: Python, libstdc++ and HIP keep the
 // process's own malloc): requests below 64 KB go to malloc unchanged; larger ones are rounded to a size class (eight per octave: at most 12.5 %
-// slack), served from the idle blocks of that class, and returned to them -- up to WHAMD_HOST_POOL_MB (default 4096; 0 switches the pool off), the
+// slack), served from the idle blocks of that class, and returned to them -- up to WHAMD_HOST_POOL_MB (default 16384 -- 96 coverage-15 tables hold 4.3 GB; 0 switches the pool off), the
 // rest goes back to the system.  Blocks of 2 MB and more are 2 MB-aligned and advised as transparent huge pages (a fresh 50 MB array is 25 page
 // faults instead of 12 800).  Every block comes from posix_memalign, so a pointer that leaves through somebody else's free() is still valid C;
 // a pointer this library frees that it did not allocate (a std::string grown inside libstdc++.so) is recognised by the block table and handed to
@@ -37,7 +37,7 @@ struct HostPool {
 	bool advise = true;
 	HostPool() {
 		const char* e = getenv("WHAMD_HOST_POOL_MB");
-		keep = (size_t)(e ? std::max(0, atoi(e)) : 4096) << 20;
+		keep = (size_t)(e ? std::max(0, atoi(e)) : 16384) << 20;
 		advise = getenv("WHAMD_NO_HUGEPAGES") == nullptr;
 	}
 };

@@ -147,15 +147,15 @@ public:
 			grow(extra);
 			for (uint32_t i = 0; i < extra; ++i) tickets_.push_back(job);
 		}
-		if (extra == 1) wake_.notify_one(); else wake_.notify_all();
+		for (uint32_t i = 0; i < extra; ++i) wake_.notify_one();   // (one sleeper per ticket: waking every worker of a 256-thread host for two tickets is a herd)
 	}
 private:
 	std::mutex mu_;
 	std::condition_variable wake_;
 	std::deque<std::shared_ptr<RangeJob>> tickets_;
 	uint32_t n_workers_ = 0, idle_ = 0;
-	void grow(uint32_t wanted) {   // mu_ held: at most as many workers as CPUs this process may use (and 64)
-		const uint32_t cap = std::min<uint32_t>(std::max(1u, usable_cpus()), 64u);
+	void grow(uint32_t wanted) {   // mu_ held: at most as many workers as CPUs this process may use
+		const uint32_t cap = std::max(1u, usable_cpus());   // (many tables are created at once, each with a few workers: blocks.solve_blocks)
 		const uint32_t pending = (uint32_t)tickets_.size() + wanted;   // tickets waiting for a worker once `wanted` more are queued
 		while (n_workers_ < cap && idle_ < pending) {
 			try {
