@@ -1357,6 +1357,7 @@ def main():
             device_tables_per_s = len(problems) * args.steps / elapsed_resident
             rate = {"device_tables_per_s": device_tables_per_s, "host_nproc": os.cpu_count()}
             try:
+                _native.release_caches()   # (the child sizes its arenas by the device's FREE memory: this process's kept arenas and pools go back first -- eight trio tables are 127 GB)
                 cmd = [sys.executable, os.path.abspath(__file__), "--create-rate-worker", "0/8", "--coverage", str(args.coverage), "--variants", str(blocks[0][1]),
                        "--blocks", str(len(problems)), "--path", args.path] + workload_flags(args)
                 for kv in args.option:
