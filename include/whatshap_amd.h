@@ -367,6 +367,12 @@ whamd_status_t whamd_genotype_likelihoods(const whamd_readset_view* readset, con
  * (commonly > 10 GB), the pinned upload staging area of whamd_dptable_create (up to 1 GiB of host memory) and the device buffers of
  * the PedMecHeuristic solves.  Blocks in use are not touched. */
 void whamd_release_caches(void);
+/* Host memory the library keeps idle between tables, in bytes: a table's large arrays (columns, entries, plan rows, descriptors, solution -- 45 MB for a
+ * coverage-15 table of 50 000 columns, 200 MB for configs[2]) go back to a process-wide pool when the table is destroyed and are reused by the next create
+ * (csrc/host_memory.cpp: freeing and re-faulting them was 6 ms per configs[2] table and 0.7 ms per small one, and serialised concurrent creates).
+ * whamd_release_caches() returns them to the system; WHAMD_HOST_POOL_MB bounds the pool (default 16384, 0 switches it off).  No reference counterpart:
+ * the reference frees everything with the table. */
+uint64_t whamd_host_pool_idle_bytes(void);
 
 #ifdef __cplusplus
 }

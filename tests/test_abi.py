@@ -142,3 +142,46 @@ def test_the_product_library_carries_no_debug_code():
     debug = subprocess.run(["nm", "-D", "--defined-only", _native.DEBUG_LIB_PATH], capture_output=True, text=True, check=True).stdout
     for name in ("whamd_debug_emulate_slot_plan", "whamd_debug_emulate_pedslot_plan", "whamd_debug_pedmec_heuristic_create_host"):
         assert name in debug
+
+
+def test_only_the_c_abi_is_exported_and_the_host_pool_keeps_blocks_between_tables():
+    """csrc/exports.map + csrc/host_memory.cpp: the shared objects export the C ABI and nothing else -- in particular not the allocation functions the
+    library replaces FOR ITSELF (a process that loads it keeps its own malloc / operator new) --, a destroyed table's large arrays stay in the host pool,
+    the next create of the same shape reuses them (the pool does not grow), and whamd_release_caches() returns them to the system."""
+    import subprocess
+
+    from whatshap_amd.synthetic import synthetic_block
+
+    for path in (_native.LIB_PATH, _native.DEBUG_LIB_PATH):
+        if not os.path.exists(path):
+            continue
+        names = [ln.split()[-1] for ln in subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout.splitlines() if ln.strip()]
+        assert names and all(n.startswith("whamd_") for n in names), [n for n in names if not n.startswith("whamd_")][:5]
+        assert not any(n.startswith("_Zn") or n.startswith("_Zd") for n in names)     # operator new / delete stay local
+    p = synthetic_block(6000, 12, seed=5)
+    _native.release_caches()
+    assert _native.host_pool_idle_bytes() == 0
+    first = _native.plan_summary(p)          # host only: flatten + plan, everything freed at the end of the call
+    kept = _native.host_pool_idle_bytes()
+    assert kept >= 1 << 20                   # the arrays of 64 KB and more went to the pool (entries alone: 6000 x 12 x 12 B)
+    for _ in range(3):
+        assert _native.plan_summary(p) == first
+    assert _native.host_pool_idle_bytes() == kept      # reused, not grown
+    _native.release_caches()
+    assert _native.host_pool_idle_bytes() == 0
+    assert _native.plan_summary(p) == first
+
+
+def test_concurrent_creates_share_the_worker_pool():
+    """csrc/host_parallel.h WorkerPool: plans made by eight Python threads at once -- each splitting its ranges over pool workers -- equal the plan one
+    thread makes alone (ranges are handed out by an atomic counter: every range runs exactly once whoever takes it)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from whatshap_amd.synthetic import irregular_block, synthetic_block
+
+    problems = [synthetic_block(30000, 10 + i % 4, seed=40 + i) for i in range(6)] + [irregular_block(20000, 12, seed=3), synthetic_block(9000, 9, seed=2, trio=True)]
+    alone = [_native.plan_summary(p) for p in problems]
+    for _ in range(3):
+        with ThreadPoolExecutor(max_workers=8) as pool:
+            together = list(pool.map(_native.plan_summary, problems))
+        assert together == alone

@@ -382,7 +382,7 @@ EXPORTED_SYMBOLS = [
     "whamd_pedmec_heuristic_enqueue_many", "whamd_pedmec_heuristic_wait",
     "whamd_pedmec_heuristic_column_count", "whamd_pedmec_heuristic_sample_count", "whamd_pedmec_heuristic_read_count",
     "whamd_pedmec_heuristic_get", "whamd_pedmec_heuristic_get_stats", "whamd_pedmec_heuristic_destroy",
-    "whamd_readselection", "whamd_genotype_likelihoods", "whamd_release_caches",
+    "whamd_readselection", "whamd_genotype_likelihoods", "whamd_release_caches", "whamd_host_pool_idle_bytes",
 ]
 
 
@@ -635,6 +635,13 @@ class HeuristicBatch:
 def pedmec_heuristic_many(problems, row_limit: int = 256, allow_mutations: bool = True, device: int = 0):
     """Several tables through one batched launch; one result dict per table."""
     return HeuristicBatch(problems, row_limit, allow_mutations, device).results()
+
+
+def host_pool_idle_bytes() -> int:
+    """whamd_host_pool_idle_bytes: host memory the library keeps between tables (given back by release_caches())."""
+    fn = lib().whamd_host_pool_idle_bytes
+    fn.restype = C.c_uint64
+    return int(fn())
 
 
 def device_count() -> int:

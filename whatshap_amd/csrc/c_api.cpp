@@ -946,6 +946,8 @@ whamd_status_t whamd_genotype_likelihoods(const whamd_readset_view* readset, con
 	});
 }
 
+uint64_t whamd_host_pool_idle_bytes(void) { return (uint64_t)whamd::host_pool_idle_bytes(); }
+
 void whamd_release_caches(void) {
 	genotype_release_cache();
 	whamd::heuristic_release_cache();
