@@ -1134,16 +1134,18 @@ def main():
     n_cpus = len(os.sched_getaffinity(0))
     whole = min(args.in_flight, len(problems))
     if len(problems) == 1:
-        host_shapes = [(1, 0, 1)]
+        host_shapes = [(1, 0, 1, 1)]
     elif world > 1:
         host_shapes = [(max(1, min(len(problems), n_cpus // 2)), 2, whole), (max(1, min(len(problems), n_cpus // 4)), 4, whole)]
     else:
         # (workers, threads per create, tables per window): one window of everything keeps the device's launch sequence shortest; two or three windows let the
         # creates of the next one run under the solve of the current one -- what wins depends on the table shape and is measured, not assumed
-        host_shapes = [(16, 2, whole), (len(problems), 1, whole), (len(problems), 2, whole), (len(problems), 4, whole)]
+        host_shapes = [(16, 2, whole), (len(problems), 2, whole), (len(problems), 4, whole)]
         if whole >= 24:
-            host_shapes += [(16, 2, (whole + 1) // 2), (min(len(problems), 32), 2, (whole + 1) // 2), (16, 2, (whole + 2) // 3)]
-    host_shapes = list(dict.fromkeys(host_shapes))
+            # ... two or three windows (the creates of the next one under the solve of the current one), and two windows on the device at once: window k + 1
+            # is enqueued -- its own stream -- before window k is collected
+            host_shapes += [(16, 2, (whole + 1) // 2), (16, 2, (whole + 2) // 3), (16, 2, (whole + 1) // 2, 2)]
+    host_shapes = list(dict.fromkeys(tuple(h) + (1,) * (4 - len(h)) for h in host_shapes))   # (workers, threads per create, tables per window, windows on the device)
 
     def fresh_step(shape):
         ta = time.perf_counter()
@@ -1161,7 +1163,7 @@ def main():
                     "device_ms": st["total_ms"], "superreads_ms": st["host_finish_ms"], "flatten_ms": st.get("host_flatten_ms"), "checksum": checksum}
         trace = []
         solved = solve_blocks(problems, device=device, path=native_path, max_in_flight=shape[2], release=True,
-                              create_threads=shape[0], host_threads_per_create=shape[1], trace=trace)
+                              create_threads=shape[0], host_threads_per_create=shape[1], windows_on_device=shape[3], trace=trace)
         tc = time.perf_counter()
         checksum = int(sum(t.optimal_score() for t in solved))
         for t in solved:
@@ -1182,13 +1184,14 @@ def main():
 
     tried = []
     shape = host_shapes[0]
-    for cand in host_shapes:       # untimed: one step per host shape (the first also warms the pools); the fastest is the one that is timed
-        rec = fresh_step(cand)
-        tried.append({"create_threads": cand[0], "host_threads_per_create": cand[1], "tables_per_window": cand[2], "wall_ms": rec["wall_ms"]})
+    fresh_step(shape)              # untimed: the first fresh step of the process also sizes the host and device pools
+    for cand in host_shapes:       # untimed: two steps per host shape, the faster one counts (one step alone is too noisy to choose by); the fastest shape is the one that is timed
+        walls = [fresh_step(cand)["wall_ms"] for _ in range(2 if len(host_shapes) > 1 else 1)]
+        tried.append({"create_threads": cand[0], "host_threads_per_create": cand[1], "tables_per_window": cand[2], "windows_on_device": cand[3], "wall_ms": min(walls)})
     if len(host_shapes) > 1:
         best = min(tried, key=lambda r: r["wall_ms"])
-        shape = (best["create_threads"], best["host_threads_per_create"], best["tables_per_window"])
-    for _ in range(max(0, args.warmup - len(host_shapes))):
+        shape = (best["create_threads"], best["host_threads_per_create"], best["tables_per_window"], best["windows_on_device"])
+    for _ in range(max(0, args.warmup - 1 - len(host_shapes))):
         fresh_step(shape)
     sync()
     t0 = time.perf_counter()
@@ -1208,7 +1211,7 @@ def main():
     per_rank = {"rank": rank, "device": device, "tables": len(problems), "create_ms": med("create_ms"), "solve_ms": med("solve_ms"), "close_ms": med("close_ms"),
                 "step_ms": med("wall_ms"), "resident_step_ms": sorted(resident_step_s)[len(resident_step_s) // 2] * 1e3,
                 "cpus": (cpu_binding or {}).get("n_cpus", n_cpus), "numa_node": (cpu_binding or {}).get("node"), "cpu_source": (cpu_binding or {}).get("source", "unbound"),
-                "create_threads": shape[0], "host_threads_per_create": shape[1], "tables_per_window": shape[2]}
+                "create_threads": shape[0], "host_threads_per_create": shape[1], "tables_per_window": shape[2], "windows_on_device": shape[3]}
     per_rank_checksums = [int(totals[2])]
     # what a SCALE record can be audited with: which rank ran which blocks on which device, and for how long
     print(f"[bench rank {rank}/{world}] device {device}, blocks {[blocks[b][0] for b in mine]} (seeds), {len(mine)} table(s), fresh: {elapsed:.3f} s for {args.steps} step(s) "
@@ -1338,7 +1341,7 @@ def main():
         elif world == 1:
             # several tables: `value` already is the host-side work queue from host arrays (region 2); end to end adds the three getters of every table
             te0 = time.perf_counter()
-            solved = solve_blocks(problems, device=device, path=native_path, max_in_flight=shape[2], release=True, create_threads=shape[0], host_threads_per_create=shape[1])
+            solved = solve_blocks(problems, device=device, path=native_path, max_in_flight=shape[2], release=True, create_threads=shape[0], host_threads_per_create=shape[1], windows_on_device=shape[3])
             checksum = 0
             for t in solved:
                 checksum += t.optimal_score()
