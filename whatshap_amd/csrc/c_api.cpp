@@ -303,6 +303,8 @@ whamd_status_t whamd_dptable_wait_many(whamd_dptable* const* tables, size_t n_ta
 	std::vector<whamd_status_t> status(n_tables, WHAMD_OK);
 	std::vector<std::string> messages(n_tables);
 	for (size_t i = 0; i < n_tables; ++i) tables[i]->in_flight = false;
+	// (at most 32 workers: one per table up to the CPUs of the host was tried -- 96 threads inside hipStreamSynchronize at once made a 96-table step 178 ms
+	// instead of 98, the runtime's waiters contend)
 	const uint32_t outer = (uint32_t)std::min<uint64_t>(host_threads(n_tables, 1), n_tables);   // (host_threads() returns n / grain + 1: never more workers than tables)
 	const uint32_t inner = std::max(1u, host_threads(1u << 30, 1) / outer);   // (a table's own finish splits its columns over threads: not 32 x 7 of them at once)
 	parallel_ranges(n_tables, outer, [&](uint64_t i0, uint64_t i1, uint32_t) {
