@@ -100,7 +100,7 @@ size_t pool_class(size_t bytes) {
 // A table's stream and events, and its pinned download buffer, come from pools as well: creating and destroying them per table (a stream,
 // five events, hipHostMalloc / hipHostFree of the path buffer) was as expensive as the whole create of a coverage-15 table
 // (24 tables: create 103 ms on 8 threads, close 110 ms).
-struct StreamSet { hipStream_t stream = nullptr; hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; int device = -1; };
+struct StreamSet { hipStream_t stream = nullptr; hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; int device = -1; };
 struct HostBlock { void* ptr; size_t bytes; };
 struct MiscPool {
 	std::mutex mu;
@@ -123,7 +123,7 @@ bool streamset_take(int device, StreamSet& out) {
 	out = StreamSet();
 	out.device = device;
 	if (hipStreamCreateWithFlags(&out.stream, hipStreamNonBlocking) != hipSuccess) return false;
-	for (int k = 0; k < 5; ++k)
+	for (int k = 0; k < 6; ++k)
 		if ((k < 4 ? hipEventCreate(&out.ev[k]) : hipEventCreateWithFlags(&out.ev[k], hipEventDisableTiming)) != hipSuccess) return false;
 	return true;
 }
@@ -180,7 +180,7 @@ void misc_pool_release() {
 
 struct UploadStage {
 	std::mutex mu;
-	struct Area { char* base = nullptr; size_t cap = 0; bool busy = false; };
+	struct Area { char* base = nullptr; size_t cap = 0; bool busy = false; hipEvent_t ev = nullptr; bool parked = false; };   // parked: the last session left copies in flight, `ev` says when they are done
 	std::vector<Area> areas;   // a few pinned areas: tables created by several host threads at once (blocks.solve_blocks) do not wait for each other
 	size_t want = 0;
 	bool broken = false;   // hipHostMalloc failed once: pageable copies from then on
@@ -266,14 +266,31 @@ struct StageSession {
 		std::lock_guard<std::mutex> lock(g_stage.mu);
 		size_t best = g_stage.areas.size();
 		for (size_t i = 0; i < g_stage.areas.size(); ++i)
-			if (!g_stage.areas[i].busy && (best == g_stage.areas.size() || g_stage.areas[i].cap > g_stage.areas[best].cap)) best = i;
+			if (!g_stage.areas[i].busy && (best == g_stage.areas.size() || (g_stage.areas[best].parked && !g_stage.areas[i].parked) ||
+			                               (g_stage.areas[best].parked == g_stage.areas[i].parked && g_stage.areas[i].cap > g_stage.areas[best].cap))) best = i;
 		if (best == g_stage.areas.size() && g_stage.areas.size() < STAGE_AREAS) { g_stage.areas.emplace_back(); best = g_stage.areas.size() - 1; }
+		hipEvent_t wait_for = nullptr;
 		if (best != g_stage.areas.size()) {
 			slot = (int)best;
 			g_stage.areas[best].busy = true;
 			base = g_stage.areas[best].base;
 			cap = g_stage.areas[best].cap;
+			if (g_stage.areas[best].parked) wait_for = g_stage.areas[best].ev;
+			g_stage.areas[best].parked = false;
 		}
+		if (wait_for) (void)hipEventSynchronize(wait_for);   // (the previous table's copies out of this area: normally long done)
+	}
+	// The table's create returns without waiting for the copies (DeviceTable::upload): the area stays reserved -- for the NEXT session -- behind an event.
+	bool park() {
+		if (slot < 0 || !pending) return true;
+		std::lock_guard<std::mutex> lock(g_stage.mu);
+		UploadStage::Area& a = g_stage.areas[slot];
+		if (!a.ev && hipEventCreateWithFlags(&a.ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); a.ev = nullptr; return false; }
+		if (hipEventRecord(a.ev, stream) != hipSuccess) { (void)hipGetLastError(); return false; }
+		a.parked = true;
+		pending = false;
+		used = 0;
+		return true;
 	}
 	~StageSession() {
 		if (pending) (void)hipStreamSynchronize(stream);
@@ -407,6 +424,7 @@ struct DeviceTable::Impl {
 	hipStream_t run_stream = nullptr;   // where the forward steps of the solve being submitted go: `stream`, or the stream of the group's first table (enqueue_group)
 	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
 	hipEvent_t ev_group = nullptr;      // group solve: "the forward pass of every table of the group is submitted up to here"
+	hipEvent_t ev_upload = nullptr;     // "everything upload() put on `stream` -- the copies, the table kernels -- is done": a solve waits for it ON THE DEVICE (begin_solve)
 	std::vector<std::pair<void*, size_t>> allocations;   // (pointer, size class) of device_pool.h
 	void* d_arena = nullptr;    // the backtrace arena: not in `allocations`, handed to the arena cache on release
 	size_t arena_bytes = 0;
@@ -578,11 +596,11 @@ void DeviceTable::release_device() {
 	if (m.stream) {
 		(void)hipStreamSynchronize(m.stream);
 		StreamSet ss;
-		ss.stream = m.stream; ss.ev[0] = m.ev0; ss.ev[1] = m.ev1; ss.ev[2] = m.ev2; ss.ev[3] = m.ev3; ss.ev[4] = m.ev_group; ss.device = m.device;
+		ss.stream = m.stream; ss.ev[0] = m.ev0; ss.ev[1] = m.ev1; ss.ev[2] = m.ev2; ss.ev[3] = m.ev3; ss.ev[4] = m.ev_group; ss.ev[5] = m.ev_upload; ss.device = m.device;
 		streamset_give(ss);
 	}
 	m.stream = m.run_stream = nullptr;
-	m.ev0 = m.ev1 = m.ev2 = m.ev3 = m.ev_group = nullptr;
+	m.ev0 = m.ev1 = m.ev2 = m.ev3 = m.ev_group = m.ev_upload = nullptr;
 }
 
 int DeviceTable::device_count() {
@@ -650,7 +668,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	if (!m.stream) {
 		StreamSet ss;
 		if (!streamset_take(device, ss)) { msg = "could not create the table's stream and events"; return WHAMD_ERR_DEVICE; }
-		m.stream = ss.stream; m.ev0 = ss.ev[0]; m.ev1 = ss.ev[1]; m.ev2 = ss.ev[2]; m.ev3 = ss.ev[3]; m.ev_group = ss.ev[4];
+		m.stream = ss.stream; m.ev0 = ss.ev[0]; m.ev1 = ss.ev[1]; m.ev2 = ss.ev[2]; m.ev3 = ss.ev[3]; m.ev_group = ss.ev[4]; m.ev_upload = ss.ev[5];
 	}
 	m.release();
 	const uint32_t n = p.n_cols;
@@ -1426,8 +1444,14 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		}
 		HIP_TRY(hipGetLastError());
 	}
-	HIP_TRY(hipStreamSynchronize(m.stream));
-	stage.finish();
+	// No host wait: the solve is ordered behind `ev_upload` on the device (begin_solve) and the staging area behind its own event (StageSession::park) -- a create
+	// used to end with hipStreamSynchronize: 1.5 - 2 ms of copy tail and table kernel for configs[2], and under many concurrent creates every worker thread sat in
+	// the queue of the others' copies (half of a create's wall time at 16 workers).  WHAMD_SYNC_UPLOAD=1 (debug library) restores the wait.
+	HIP_TRY(hipEventRecord(m.ev_upload, m.stream));
+	if (debug_env("WHAMD_SYNC_UPLOAD") || !stage.park()) {
+		HIP_TRY(hipStreamSynchronize(m.stream));
+		stage.finish();
+	}
 	m.dp.delta = (const int32_t*)d_delta;
 	m.dp.term_ptr = (const uint32_t*)d_term_ptr;
 	m.dp.terms = (const DevTerm*)d_terms;
@@ -1745,6 +1769,7 @@ whamd_status_t DeviceTable::Impl::begin_solve(const Problem& p, Solution& s, std
 	m.launches = 0;
 	m.next_super = 0;
 	if (n == 0) return WHAMD_OK;
+	if (m.ev_upload && m.run_stream != m.stream) HIP_TRY(hipStreamWaitEvent(m.run_stream, m.ev_upload, 0));   // (the same stream is ordered by itself)
 	for (const Impl::Lane& lane : m.lanes) HIP_TRY(hipMemsetAsync(lane.d_keys, 0xFF, m.key_entries * 8, m.run_stream));
 	HIP_TRY(hipMemsetAsync(m.dp.last_keys, 0xFF, (size_t)MAX_T_WIDE * 8, m.run_stream));
 	if (m.use_chunks) HIP_TRY(hipMemsetAsync(m.dp.spec_keys, 0xFF, ((size_t)m.n_spec + 1) * m.dp.spec_stride * 8, m.run_stream));
@@ -2129,6 +2154,8 @@ void dptable_release_caches() {
 	std::lock_guard<std::mutex> lock(g_stage.mu);
 	for (UploadStage::Area& a : g_stage.areas) {
 		if (a.busy) continue;   // (an upload in flight on another thread keeps its area)
+		if (a.parked && a.ev) (void)hipEventSynchronize(a.ev);   // (copies of a finished create may still be reading it)
+		a.parked = false;
 		if (a.base) (void)hipHostFree(a.base);
 		a.base = nullptr;
 		a.cap = 0;
