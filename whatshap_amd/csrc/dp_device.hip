@@ -898,6 +898,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		if (alloc(&ptr, upload_bytes) == hipSuccess) { d_slab = (char*)ptr; slab_cap = upload_bytes; }
 		else { (void)hipGetLastError(); stage.image = false; }
 	}
+	bool unstaged_copies = false;   // a copy whose source is pageable memory of this call: the create must wait for it
 	auto flush_slab = [&]() -> hipError_t {
 		if (!d_slab || slab_used == slab_flushed) return hipSuccess;
 		const hipError_t e = hipMemcpyAsync(d_slab + slab_flushed, stage.base + slab_flushed, slab_used - slab_flushed, hipMemcpyHostToDevice, m.stream);
@@ -920,12 +921,72 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 		hipError_t e = alloc(dptr, bytes);
 		if (e != hipSuccess) return e;
 		if (bytes) e = stage.copy(*dptr, src, bytes);
+		if (bytes && stage.image) unstaged_copies = true;   // (did not fit the image: copied straight from the caller's memory)
 		return e;
 	};
+	// A single-individual table on slot runs: no kernel reads the per-column arrays (descriptor, deltas, term offsets, terms) of a column INSIDE a run -- the run
+	// kernels and slot_tables work from the rows, the backtrace from its units -- so only the columns outside runs travel (the coverage ramp, the last column, what an
+	// irregular layout leaves between runs): 96 of a column's 450 bytes, and concurrent creates are bound by bytes through the link.  The arrays keep
+	// their size and indexing on the device; the pieces that are not sent are never read.
+	std::vector<std::pair<uint32_t, uint32_t>> sent;   // [first, last) column ranges that are uploaded
+	const bool sparse_columns = m.use_slots && !ped_slots && p.T == 1 && !m.windowed && !debug_env("WHAMD_DENSE_COLUMN_UPLOAD");
+	if (sparse_columns) {
+		for (uint32_t c = 0; c < n;) {
+			if (m.splan.col_to_row[c] >= 0) { ++c; continue; }
+			uint32_t e = c + 1;
+			while (e < n && m.splan.col_to_row[e] < 0) ++e;
+			sent.emplace_back(c, e);
+			c = e;
+		}
+	}
+	// reserves [count x elem] bytes like `up`, sends only the element ranges of `pieces` (element index = f(column))
+	auto up_pieces = [&](void** dptr, const void* src, size_t bytes, const std::vector<std::pair<size_t, size_t>>& pieces) -> hipError_t {
+		const size_t padded = (bytes + 255) & ~(size_t)255;
+		const bool in_slab = d_slab && slab_used + padded <= slab_cap;
+		if (in_slab) {
+			hipError_t e = flush_slab();   // what is staged so far leaves as it is; this array's pieces go out on their own
+			if (e != hipSuccess) return e;
+			*dptr = d_slab + slab_used;
+			slab_used += padded;
+			slab_flushed = slab_used;      // (nothing of this array is in the staging image)
+		} else {
+			hipError_t e = alloc(dptr, bytes);
+			if (e != hipSuccess) return e;
+		}
+		const size_t image_at = slab_used - padded;   // (in_slab: where the array lies in the block AND in the staging image)
+		for (const auto& pc : pieces) {
+			if (pc.second <= pc.first) continue;
+			const char* from = (const char*)src + pc.first;
+			if (in_slab) {   // through the pinned image, like everything else: the copy's source outlives the create
+				std::memcpy(stage.base + image_at + pc.first, from, pc.second - pc.first);
+				from = stage.base + image_at + pc.first;
+				stage.pending = true;
+			} else {
+				unstaged_copies = true;   // (straight from the caller's pageable memory: upload() ends with a host wait)
+			}
+			hipError_t e = hipMemcpyAsync((char*)*dptr + pc.first, from, pc.second - pc.first, hipMemcpyHostToDevice, m.stream);
+			if (e != hipSuccess) return e;
+		}
+		return hipSuccess;
+	};
+	if (sparse_columns) {
+		std::vector<std::pair<size_t, size_t>> pc_cols, pc_delta, pc_tptr, pc_terms;
+		for (const auto& r : sent) {
+			pc_cols.emplace_back((size_t)r.first * sizeof(DevColumn), (size_t)r.second * sizeof(DevColumn));
+			pc_delta.emplace_back((size_t)p.col_ptr[r.first] * p.n_ind * sizeof(int32_t), (size_t)p.col_ptr[r.second] * p.n_ind * sizeof(int32_t));
+			pc_tptr.emplace_back((size_t)r.first * (p.T + 1) * sizeof(uint32_t), (size_t)r.second * (p.T + 1) * sizeof(uint32_t));
+			pc_terms.emplace_back((size_t)p.term_ptr[(size_t)r.first * p.T] * sizeof(DevTerm), (size_t)p.term_ptr[(size_t)r.second * p.T] * sizeof(DevTerm));
+		}
+		HIP_TRY(up_pieces((void**)&m.d_cols, m.cols.data(), m.cols.size() * sizeof(DevColumn), pc_cols));
+		HIP_TRY(up_pieces(&d_delta, delta_src, delta_count * sizeof(int32_t), pc_delta));
+		HIP_TRY(up_pieces(&d_term_ptr, term_ptr32.data(), term_ptr32.size() * sizeof(uint32_t), pc_tptr));
+		HIP_TRY(up_pieces(&d_terms, terms.data(), terms.size() * sizeof(DevTerm), pc_terms));
+	} else {
 	HIP_TRY(up((void**)&m.d_cols, m.cols.data(), m.cols.size() * sizeof(DevColumn)));
 	HIP_TRY(up(&d_delta, delta_src, delta_count * sizeof(int32_t)));
 	HIP_TRY(up(&d_term_ptr, term_ptr32.data(), term_ptr32.size() * sizeof(uint32_t)));
 	HIP_TRY(up(&d_terms, terms.data(), terms.size() * sizeof(DevTerm)));
+	}
 	if (!p.fterms.empty()) HIP_TRY(up(&d_fterms, p.fterms.data(), p.fterms.size() * sizeof(DevTerm)));   // factorised lines (pedslot_tables, PSLOT_FACT)
 	HIP_TRY(up(&d_segs, segs.data(), segs.size() * sizeof(uint32_t)));
 	HIP_TRY(up(&d_rcol, m.plan.columns.data(), m.plan.columns.size() * sizeof(ResColumn)));
@@ -1448,7 +1509,7 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	// used to end with hipStreamSynchronize: 1.5 - 2 ms of copy tail and table kernel for configs[2], and under many concurrent creates every worker thread sat in
 	// the queue of the others' copies (half of a create's wall time at 16 workers).  WHAMD_SYNC_UPLOAD=1 (debug library) restores the wait.
 	HIP_TRY(hipEventRecord(m.ev_upload, m.stream));
-	if (debug_env("WHAMD_SYNC_UPLOAD") || !stage.park()) {
+	if (debug_env("WHAMD_SYNC_UPLOAD") || unstaged_copies || !stage.image || !stage.park()) {
 		HIP_TRY(hipStreamSynchronize(m.stream));
 		stage.finish();
 	}
