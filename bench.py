@@ -975,7 +975,7 @@ def run_extra_configs(args):
         }
         if "create_rate" in full:
             entry["create_rate"] = full["create_rate"]
-        for key in ("shim_over_native", "native_end_to_end", "step_pieces_ms", "value_resident", "value_8d_strict", "per_table"):
+        for key in ("shim_over_native", "native_end_to_end", "step_pieces_ms", "value_resident", "value_8d_strict", "per_rank", "host_shapes_tried"):
             if key in full:
                 entry[key] = full[key]
         if "cpu_baseline" in full:
