@@ -37,6 +37,16 @@ whamd_status_t whamd_debug_emulate_pedslot_plan(const whamd_readset_view* readse
                                                uint32_t* index_out, uint32_t* transmission_out, uint32_t* score_out,
                                                uint64_t* n_run_columns_out);
 
+/* Host-only check of the LAZY generic term lists (csrc/problem.cpp build_problem `lazy_fact_terms` + fill_lazy_terms: what whamd_dptable_create does for a
+ * trio / quartet with untrusted genotypes whose runs read the factorised line): the problem is built twice -- every term list at once, and lazily with the
+ * lists of the columns whose bit is set in need[n_columns] (NULL: every column) filled in afterwards, in `rounds` calls (the columns dealt out round robin) --
+ * and the two are compared term by term on the needed columns.  *lazy_out: 1 if the table took the lazy route at all (0: not a factorised table, nothing to
+ * compare); *differences_out: columns whose lists differ (0 expected); *built_before_out / *built_after_out: columns with term lists before / after the fills. */
+whamd_status_t whamd_debug_lazy_terms_check(const whamd_readset_view* readset, const uint32_t* recombcost, size_t n_recombcost,
+                                            const whamd_pedigree_view* pedigree, int distrust_genotypes,
+                                            const uint32_t* positions, size_t n_positions, const uint8_t* need, int rounds,
+                                            int* lazy_out, uint64_t* differences_out, uint64_t* built_before_out, uint64_t* built_after_out);
+
 /* HOST-ONLY DIAGNOSTIC: the same solver source run with one CPU thread (csrc/heuristic_host.cpp), for the CPU test-suite to
  * compare with the compiled reference; never what the drop-in class calls. */
 whamd_status_t whamd_debug_pedmec_heuristic_create_host(const whamd_readset_view* readset, const uint32_t* recombcost, size_t n_recombcost,

@@ -185,3 +185,31 @@ def test_four_reads_ending_in_one_column_of_a_pedigree_run(seed):
         ok, run_columns = agrees(p, slot_l=slot_l)
         assert ok, (seed, slot_l)
         assert run_columns >= n - 5, run_columns
+
+
+def test_lazy_generic_terms_equal_the_eager_ones():
+    """Round 6 (csrc/problem.cpp `lazy_fact_terms`, fill_lazy_terms): whamd_dptable_create builds the generic term lists of a trio / quartet with untrusted genotypes
+    only for a sample of columns (where the factorised line is checked) and, after planning, for the columns outside runs.  Whatever columns are asked for, in however
+    many calls: the lists equal the eagerly built ones term by term, the factorised line is the same, the value bound is not smaller; tables without a factorised line
+    (trusted genotypes, one individual) do not take the route at all."""
+    import numpy as np
+
+    from whatshap_amd import _native
+    from whatshap_amd.synthetic import synthetic_block
+
+    for kw in (dict(trio=True, distrust_genotypes=True), dict(quartet=True, distrust_genotypes=True)):
+        p = synthetic_block(700, 7, seed=11, **kw)
+        n = p.n_variants
+        everything = _native.debug_lazy_terms_check(p)
+        assert everything["lazy"] and everything["differences"] == 0
+        assert everything["built_before"] < n // 2 and everything["built_after"] == n      # the sample (first 256 + every 64th), then all
+        rng = np.random.default_rng(3)
+        need = (rng.random(n) < 0.1).astype(np.uint8)
+        need[[0, n - 1, 300, 301]] = 1
+        some = _native.debug_lazy_terms_check(p, need=need, rounds=3)                       # three fills, each merging into what is there
+        assert some["lazy"] and some["differences"] == 0
+        assert some["built_before"] <= some["built_after"] < n
+        none = _native.debug_lazy_terms_check(p, need=np.zeros(n, np.uint8))
+        assert none["differences"] == 0 and none["built_after"] == none["built_before"]
+    for kw in (dict(trio=True), dict()):
+        assert not _native.debug_lazy_terms_check(synthetic_block(300, 7, seed=11, **kw))["lazy"]

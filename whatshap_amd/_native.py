@@ -549,6 +549,18 @@ def emulate_pedslot_plan(problem: ProblemArrays, n_columns: int, slot_l: int = 0
     return idx[:n_columns], trans[:n_columns], int(score.value), int(ncols.value)
 
 
+def debug_lazy_terms_check(problem: ProblemArrays, need=None, rounds: int = 1) -> dict:
+    """whamd_debug_lazy_terms_check: the lazily built generic term lists (+ fill_lazy_terms on the columns of `need`, in `rounds` calls) against the eager ones."""
+    D = debug_lib()
+    fn = D.whamd_debug_lazy_terms_check
+    fn.restype = C.c_int
+    lazy, diff, before, after = C.c_int(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+    need_arr = None if need is None else np.ascontiguousarray(need, dtype=np.uint8)
+    _check(fn(*problem.call_args(), None if need_arr is None else _ptr(need_arr, C.c_uint8), C.c_int(int(rounds)), C.byref(lazy), C.byref(diff),
+              C.byref(before), C.byref(after)), D)
+    return {"lazy": bool(lazy.value), "differences": int(diff.value), "built_before": int(before.value), "built_after": int(after.value)}
+
+
 def _heuristic_result(L, h) -> dict:
     n = int(L.whamd_pedmec_heuristic_column_count(h))
     ns = int(L.whamd_pedmec_heuristic_sample_count(h))

@@ -107,7 +107,7 @@ whamd_status_t create_table(const whamd_readset_view* readset, const uint32_t* r
 		if (std::string(keys[i]) == "host_threads") whamd::host_threads_override() = (uint32_t)std::max(0, std::atoi(values[i]));
 	}
 	whamd_status_t st = build_problem(readset, recombcost, n_recombcost, pedigree, distrust_genotypes != 0,
-	                                  positions, n_positions, t->problem, msg);
+	                                  positions, n_positions, t->problem, msg, /*columns_only=*/false, /*lazy_fact_terms=*/true);
 	if (st != WHAMD_OK) return fail(st, msg);
 	const double t1 = now_ms();
 	t->device_index = device;
@@ -708,6 +708,52 @@ whamd_status_t whamd_debug_emulate_pedslot_plan(const whamd_readset_view* readse
 	if (transmission_out && !trans.empty()) std::memcpy(transmission_out, trans.data(), trans.size() * sizeof(uint32_t));
 	if (score_out) *score_out = score;
 	if (n_run_columns_out) *n_run_columns_out = sp.n_run_columns;
+	return WHAMD_OK;
+	});
+}
+whamd_status_t whamd_debug_lazy_terms_check(const whamd_readset_view* readset, const uint32_t* recombcost, size_t n_recombcost,
+                                            const whamd_pedigree_view* pedigree, int distrust_genotypes, const uint32_t* positions, size_t n_positions,
+                                            const uint8_t* need_in, int rounds, int* lazy_out, uint64_t* differences_out, uint64_t* built_before_out,
+                                            uint64_t* built_after_out) {
+	return guarded([&]() -> whamd_status_t {
+	Problem eager, lazy;
+	std::string msg;
+	whamd_status_t st = build_problem(readset, recombcost, n_recombcost, pedigree, distrust_genotypes != 0, positions, n_positions, eager, msg);
+	if (st != WHAMD_OK) return fail(st, msg);
+	st = build_problem(readset, recombcost, n_recombcost, pedigree, distrust_genotypes != 0, positions, n_positions, lazy, msg, false, /*lazy_fact_terms=*/true);
+	if (st != WHAMD_OK) return fail(st, msg);
+	if (lazy_out) *lazy_out = lazy.lazy_terms ? 1 : 0;
+	const uint32_t n = eager.n_cols;
+	uint64_t before = 0, after = 0, diff = 0;
+	for (uint32_t c = 0; c < n; ++c) before += lazy.term_end(c, lazy.T - 1) > lazy.term_begin(c, 0);
+	std::vector<uint8_t> need(n, 1);
+	if (need_in) for (uint32_t c = 0; c < n; ++c) need[c] = need_in[c] != 0;
+	rounds = std::max(1, rounds);
+	for (int r = 0; r < rounds; ++r) {
+		std::vector<uint8_t> part(n, 0);
+		for (uint32_t c = 0; c < n; ++c) part[c] = need[c] && (int)(c % (uint32_t)rounds) == r;
+		st = fill_lazy_terms(lazy, part, msg);
+		if (st != WHAMD_OK) return fail(st, msg);
+	}
+	for (uint32_t c = 0; c < n; ++c) {
+		after += lazy.term_end(c, lazy.T - 1) > lazy.term_begin(c, 0);
+		if (!need[c]) continue;
+		bool same = true;
+		for (uint32_t t = 0; t < eager.T && same; ++t) {
+			const uint64_t a0 = eager.term_begin(c, t), a1 = eager.term_end(c, t), b0 = lazy.term_begin(c, t), b1 = lazy.term_end(c, t);
+			same = a1 - a0 == b1 - b0;
+			for (uint64_t i = 0; same && i < a1 - a0; ++i)
+				same = eager.terms[a0 + i].c == lazy.terms[b0 + i].c && eager.terms[a0 + i].plus == lazy.terms[b0 + i].plus && eager.terms[a0 + i].minus == lazy.terms[b0 + i].minus;
+		}
+		diff += !same;
+	}
+	// what does not depend on the route: the factorised line itself and the problem's shape
+	if (eager.fterm_kind != lazy.fterm_kind || eager.fterms.size() != lazy.fterms.size()) diff += n;
+	else for (size_t i = 0; i < eager.fterms.size(); ++i) if (eager.fterms[i].c != lazy.fterms[i].c || eager.fterms[i].plus != lazy.fterms[i].plus || eager.fterms[i].minus != lazy.fterms[i].minus) { ++diff; break; }
+	if (lazy.value_bound < eager.value_bound) diff += n;   // (the lazy bound may only be LARGER: it is what rules 32-bit wrap-around out)
+	if (differences_out) *differences_out = diff;
+	if (built_before_out) *built_before_out = before;
+	if (built_after_out) *built_after_out = after;
 	return WHAMD_OK;
 	});
 }

@@ -17,7 +17,8 @@ public:
 	static int device_count();
 	static bool device_pci_bus_id(int device, std::string& out);   // "0000:c5:00.0"; false if there is no such device
 	// Builds the per-column descriptors for `p` and uploads everything the kernels read.
-	whamd_status_t upload(const Problem& p, int device, std::string& msg);
+	// (`p` is not const: a table with lazy generic terms -- Problem::lazy_terms -- gets the term lists of the columns its plan leaves outside runs here)
+	whamd_status_t upload(Problem& p, int device, std::string& msg);
 	// Forward pass + backtrace on the device; fills s.path_*, s.optimal_score and the timing fields of st.
 	whamd_status_t solve(const Problem& p, Solution& s, whamd_solve_stats& st, std::string& msg);
 	// The two halves of solve(): enqueue() only submits the launches to the table's stream (several tables can be in

@@ -652,7 +652,7 @@ void DeviceTable::set_shared_launches(bool v) { impl_->shared_hint = v; }
 void DeviceTable::set_side_by_side(bool v) { impl_->side_by_side = v; }
 void DeviceTable::set_symmetry(int level) { impl_->symmetry = level < 0 ? 0 : (level > 2 ? 2 : level); }
 
-whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& msg) {
+whamd_status_t DeviceTable::upload(Problem& p, int device, std::string& msg) {
 	Impl& m = *impl_;
 	m.device = device;
 	int ndev = 0;
@@ -711,6 +711,13 @@ whamd_status_t DeviceTable::upload(const Problem& p, int device, std::string& ms
 	// pedigree slot runs keep their cost-form tables in HBM (slots.h): at most a quarter of what is free, else the older paths
 	if (m.use_slots && m.splan.ped && m.splan.table_words * 4ull > free_b / 4) m.use_slots = false;
 	m.table_bytes = m.use_slots && m.splan.ped ? m.splan.table_words * 4ull : 0ull;
+	if (p.lazy_terms) {
+		// generic term lists where something will read them: the columns a pedigree slot plan leaves to the per-column kernels; every column on any other path
+		std::vector<uint8_t> need(p.n_cols, 1);
+		if (m.use_slots && m.splan.ped) for (uint32_t c = 0; c < p.n_cols; ++c) need[c] = m.splan.col_to_row[c] < 0;
+		const whamd_status_t st = fill_lazy_terms(p, need, msg);
+		if (st != WHAMD_OK) return st;
+	}
 	if (m.use_slots) {
 		// the driver below walks plan.steps / plan.component_first_step; slot runs are steps of kind 2
 		m.plan = ResidentPlan();

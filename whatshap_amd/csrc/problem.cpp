@@ -86,7 +86,7 @@ bool build_partitions(Problem& p, std::string& msg) {
 
 whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recombcost, size_t n_recombcost,
                              const whamd_pedigree_view* ped, bool distrust, const uint32_t* positions,
-                             size_t n_positions, Problem& p, std::string& msg, bool columns_only) {
+                             size_t n_positions, Problem& p, std::string& msg, bool columns_only, bool lazy_fact_terms) {
 	if (!rs || !ped) {
 		msg = "null readset or pedigree view";
 		return WHAMD_ERR_INVALID;
@@ -493,6 +493,10 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 		if (a != b) (a == 0 ? tm.plus : tm.minus) |= 1u << r.child;
 		return tm;
 	};
+	// lazy generic terms (see column_terms): only where a factorised line exists
+	bool lazy = lazy_fact_terms && (want_fact || want_fact4) && !getenv("WHAMD_EAGER_TERMS");   // (switched off below if a sampled check fails)
+	auto lazy_sample = [](uint32_t c) { return c < 256u || (c & 63u) == 0u; };
+	p.lazy_terms = false;
 	// (h2p of one individual without a trio: haplotype 0 -> partition 0, haplotype 1 -> partition 1)
 	const bool single_trusted = p.n_ind == 1 && p.T == 1 && p.P == 2 && !distrust && p.h2p.size() >= 2 && p.h2p[0] == 0 && p.h2p[1] == 1 && !getenv("WHAMD_NO_SINGLE_FAST_TERMS");
 	// deltas and cost terms of column c (its entries and indexing scheme are in place); false: Mendelian conflict
@@ -535,6 +539,21 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 				any = true;
 			}
 			p.term_ptr[(size_t)c + 1] = out.terms.size();
+		} else if (lazy && out.fact_ok && !lazy_sample(c)) {
+			// A table whose runs read the FACTORISED line (Problem::fterms): the generic term list of this column -- sixteen terms per transmission value, 3 KB per column
+			// of a quartet -- is read by nobody unless the column ends up outside every run, which the planner decides later: fill_lazy_terms builds those.  The
+			// line itself is written here; its check against the generic enumeration runs on the sampled columns (the first 256 and every 64th: the identity is
+			// algebraic in R, W and the likelihoods, what can be wrong is the role assignment, which is per table) and on every column built later.
+			for (uint32_t t = 0; t < p.T; ++t) {
+				if (want_fact) (void)factorised_line(c, t, R, W);
+				else if (t == 0) (void)factorised_line4(c, R, W);
+				p.term_ptr[(size_t)c * p.T + t + 1] = out.terms.size();
+			}
+			for (uint32_t s2 = 0; s2 < p.n_ind; ++s2) {   // (an upper bound of the largest likelihood sum of an assignment: every individual's largest)
+				const double* g3 = p.gl.data() + ((size_t)s2 * p.n_variants + c) * 3;
+				max_acost += std::max(g3[0], std::max(g3[1], g3[2]));
+			}
+			any = true;   // (untrusted genotypes: every assignment is allowed, a column cannot be infeasible)
 		} else
 		for (uint32_t t = 0; t < p.T; ++t) {
 			const int8_t* map = p.h2p.data() + (size_t)t * p.n_ind * 2;
@@ -652,6 +671,17 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 		std::vector<uint32_t> bounds(n_threads + 1);
 		for (uint32_t t = 0; t <= n_threads; ++t) bounds[t] = (uint32_t)((uint64_t)n * t / n_threads);
 		parallel_ranges(n, n_threads, [&](uint64_t c0, uint64_t c1, uint32_t t) { columns_range((uint32_t)c0, (uint32_t)c1, parts[t]); });
+		if (lazy) {
+			bool all_ok = true;
+			for (uint32_t t = 0; t < n_threads; ++t) all_ok = all_ok && parts[t].fact_ok;
+			if (!all_ok) {
+				// a sampled column's line disagrees with the generic terms: the table keeps its generic forms -- for EVERY column, so the pass runs again without the shortcut
+				lazy = false;
+				for (RangeResult& part : parts) part = RangeResult();
+				parallel_ranges(n, n_threads, [&](uint64_t c0, uint64_t c1, uint32_t t) { columns_range((uint32_t)c0, (uint32_t)c1, parts[t]); });
+			}
+		}
+		p.lazy_terms = lazy;
 		for (uint32_t t = 0; t < n_threads; ++t) p.max_k = std::max(p.max_k, parts[t].max_k);
 		lap("column entries, indexing scheme, deltas + cost terms");
 		if (columns_only) return WHAMD_OK;   // the genotyping path (genotype.cpp) has its own per-column model
@@ -682,6 +712,102 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 		msg = "costs may exceed 32 bits (upper bound " + std::to_string(bound) + "); the reference's unsigned arithmetic wraps there and results are undefined";
 		return WHAMD_ERR_OVERFLOW;
 	}
+	return WHAMD_OK;
+}
+
+// The generic term lists of the columns in `need` that do not have them yet (Problem::lazy_terms: build_problem left them out where the runs read the
+// factorised line).  The enumeration is the one of build_problem's column_terms (src/pedigreecolumncostcomputer.cpp:25-49: every allele assignment, its likelihood
+// cost accumulated as `(u32)((double)cost + gl)`, terms with the same L-dependence merged into the cheaper one, in ascending assignment order).
+whamd_status_t fill_lazy_terms(Problem& p, const std::vector<uint8_t>& need, std::string& msg) {
+	if (!p.lazy_terms) return WHAMD_OK;
+	const uint32_t n = p.n_cols;
+	if (p.terms_built.size() != n) {   // first call: what build_problem built (the sampled columns)
+		p.terms_built.assign(n, 0);
+		for (uint32_t c = 0; c < n; ++c) p.terms_built[c] = p.term_end(c, p.T - 1) > p.term_begin(c, 0);
+	}
+	std::vector<uint32_t> todo;
+	for (uint32_t c = 0; c < n; ++c) if (need[c] && !p.terms_built[c]) todo.push_back(c);
+	if (todo.empty()) return WHAMD_OK;
+	// per column its new terms, then one merge pass over all columns
+	std::vector<std::vector<CostTerm>> fresh(todo.size());
+	std::vector<std::vector<uint32_t>> fresh_count(todo.size());
+	parallel_ranges(todo.size(), host_threads(todo.size(), 256), [&](uint64_t i0, uint64_t i1, uint32_t) {
+		std::vector<uint32_t> R(p.n_ind), W(p.n_ind);
+		for (size_t i = i0; i < i1; ++i) {
+			const uint32_t c = todo[i];
+			const ColumnEntry* col = p.col_begin(c);
+			std::fill(R.begin(), R.end(), 0u);
+			std::fill(W.begin(), W.end(), 0u);
+			for (uint32_t j = 0; j < p.k[c]; ++j) {
+				const ColumnEntry& e = col[j];
+				if (e.allele == WHAMD_ALLELE_BLANK) continue;
+				W[e.sample] += e.phred;
+				if (e.allele == WHAMD_ALLELE_ALT) R[e.sample] += e.phred;
+			}
+			std::vector<CostTerm>& out = fresh[i];
+			fresh_count[i].assign(p.T, 0);
+			for (uint32_t t = 0; t < p.T; ++t) {
+				const int8_t* map = p.h2p.data() + (size_t)t * p.n_ind * 2;
+				const size_t begin = out.size();
+				for (uint32_t a = 0; a < (1u << p.P); ++a) {
+					bool compatible = true;
+					uint32_t acost = 0;
+					CostTerm term{0, 0, 0};
+					for (uint32_t s = 0; s < p.n_ind; ++s) {
+						const uint32_t a0 = (a >> map[2 * s]) & 1, a1 = (a >> map[2 * s + 1]) & 1;
+						const size_t gi = (size_t)s * p.n_variants + c;
+						if (p.distrust) acost = (uint32_t)((double)acost + p.gl[gi * 3 + a0 + a1]);
+						else if (p.genotype[gi] != a0 + a1) { compatible = false; break; }
+						if (a0 == 0 && a1 == 0) term.c += R[s];
+						else if (a0 == 1 && a1 == 1) term.c += W[s] - R[s];
+						else if (a0 == 0) { term.c += R[s]; term.plus |= 1u << s; }
+						else { term.c += W[s] - R[s]; term.minus |= 1u << s; }
+					}
+					if (!compatible) continue;
+					term.c += acost;
+					bool dominated = false;
+					for (size_t q = begin; q < out.size(); ++q) {
+						if (out[q].plus == term.plus && out[q].minus == term.minus) {
+							if (term.c < out[q].c) out[q].c = term.c;
+							dominated = true;
+							break;
+						}
+					}
+					if (!dominated) out.push_back(term);
+				}
+				fresh_count[i][t] = (uint32_t)(out.size() - begin);
+			}
+		}
+	});
+	RawVec<CostTerm> merged;
+	std::vector<uint64_t> ptr((size_t)n * p.T + 1, 0);
+	size_t total = p.terms.size();
+	for (const auto& v : fresh) total += v.size();
+	merged.resize(total);
+	size_t at = 0, ti = 0;
+	for (uint32_t c = 0; c < n; ++c) {
+		const bool is_new = ti < todo.size() && todo[ti] == c;
+		size_t off = 0;
+		for (uint32_t t = 0; t < p.T; ++t) {
+			ptr[(size_t)c * p.T + t] = at;
+			if (is_new) {
+				const uint32_t cnt = fresh_count[ti][t];
+				if (cnt) std::memcpy(merged.data() + at, fresh[ti].data() + off, cnt * sizeof(CostTerm));
+				off += cnt;
+				at += cnt;
+			} else {
+				const uint64_t b = p.term_begin(c, t), e = p.term_end(c, t);
+				if (e > b) std::memcpy(merged.data() + at, p.terms.data() + b, (e - b) * sizeof(CostTerm));
+				at += e - b;
+			}
+		}
+		if (is_new) { p.terms_built[c] = 1; ++ti; }
+	}
+	ptr[(size_t)n * p.T] = at;
+	merged.resize(at);
+	p.terms.swap(merged);
+	p.term_ptr.swap(ptr);
+	(void)msg;
 	return WHAMD_OK;
 }
 

@@ -82,6 +82,8 @@ struct Problem {
 	// value only wires the children to the founders' haplotypes: fact4_roles = {u_1 | v_1 << 16, (u_1 == u_2) | (v_1 == v_2) << 16}, bit t of each 16-bit mask
 	// (slots.h PSLOT_FACT4).
 	uint32_t fterm_kind = 0;         // 0 none, 1 trio (16 entries per (column, value)), 2 quartet (20 per column)
+	bool lazy_terms = false;         // generic terms exist only for the columns of `terms_built` (build_problem's sample, fill_lazy_terms' additions)
+	std::vector<uint8_t> terms_built;
 	uint32_t fact4_roles[2] = {0, 0};
 	// per column and individual: signed per-bit deltas d (REF +q, ALT -q, BLANK 0) of L_s(x) - R_s
 	RawVec<int32_t> delta;  // [col_ptr[c] * n_ind ... ): for column c, delta[(col_ptr[c] * n_ind) + s * k_c + bit]
@@ -97,7 +99,11 @@ struct Problem {
 // Builds the problem; on failure returns a status != WHAMD_OK and sets msg.
 whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recombcost, size_t n_recombcost,
                              const whamd_pedigree_view* ped, bool distrust, const uint32_t* positions,
-                             size_t n_positions, Problem& out, std::string& msg, bool columns_only = false);
+                             size_t n_positions, Problem& out, std::string& msg, bool columns_only = false, bool lazy_fact_terms = false);
+// `lazy_fact_terms`: a table whose runs will read the factorised line (Problem::fterms: a trio or a quartet with untrusted genotypes) gets its generic term
+// lists only for a sample of columns (on which the line is checked); fill_lazy_terms(p, need) builds them for the columns that turn out to need them -- those
+// the planner leaves outside runs, or all of them when the table takes another path.  150 MB less to build, join and upload for a quartet of 50 000 columns.
+whamd_status_t fill_lazy_terms(Problem& p, const std::vector<uint8_t>& need, std::string& msg);
 
 // Host part of get_super_reads (src/pedigreedptable.cpp:344-388 + get_alleles,
 // src/pedigreecolumncostcomputer.cpp:117-175) and get_optimal_partitioning (:391-406) from a finished path.
