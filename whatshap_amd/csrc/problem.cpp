@@ -500,7 +500,22 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 	// (h2p of one individual without a trio: haplotype 0 -> partition 0, haplotype 1 -> partition 1)
 	const bool single_trusted = p.n_ind == 1 && p.T == 1 && p.P == 2 && !distrust && p.h2p.size() >= 2 && p.h2p[0] == 0 && p.h2p[1] == 1 && !getenv("WHAMD_NO_SINGLE_FAST_TERMS");
 	// deltas and cost terms of column c (its entries and indexing scheme are in place); false: Mendelian conflict
-	auto column_terms = [&](uint32_t c, RangeResult& out, std::vector<uint32_t>& R, std::vector<uint32_t>& W) -> bool {
+	struct CompatCache {   // per worker: compatible allele assignments by (genotype vector, transmission value)
+		bool enabled = false;
+		std::vector<uint8_t> known;
+		std::vector<std::vector<uint8_t>> lists;
+	};
+	auto make_compat = [&]() {
+		CompatCache cc;
+		cc.enabled = !distrust && p.n_ind >= 2 && p.n_ind <= 6 && p.P <= 8 && !getenv("WHAMD_NO_COMPAT_CACHE");
+		if (cc.enabled) {
+			const size_t slots = ((size_t)1 << (2 * p.n_ind)) * p.T;
+			cc.known.assign(slots, 0);
+			cc.lists.resize(slots);
+		}
+		return cc;
+	};
+	auto column_terms = [&](uint32_t c, RangeResult& out, std::vector<uint32_t>& R, std::vector<uint32_t>& W, CompatCache& compat) -> bool {
 		const ColumnEntry* col = p.col_begin(c);
 		const uint32_t kc = p.k[c];
 		std::fill(R.begin(), R.end(), 0u);
@@ -560,7 +575,28 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 			const size_t begin = out.terms.size();
 			const CostTerm* fline = (want_fact && out.fact_ok) ? factorised_line(c, t, R, W) : nullptr;
 			const CostTerm* fline4 = (want_fact4 && out.fact_ok) ? (t == 0 ? factorised_line4(c, R, W) : p.fterms.data() + (size_t)c * 20) : nullptr;
-			for (uint32_t a = 0; a < (1u << p.P); ++a) {  // src/pedigreecolumncostcomputer.cpp:25-49
+			// trusted genotypes: WHICH assignments are compatible depends on the column only through its genotype vector -- looked up (a thread-local table
+			// filled on first use) instead of tested sixteen times per transmission value and column: a quartet's 1 024 inner steps per column were 15 us
+			const std::vector<uint8_t>* shortlist = nullptr;
+			if (!distrust && compat.enabled) {
+				uint32_t key = 0;
+				for (uint32_t s = 0; s < p.n_ind; ++s) key = key * 4u + std::min<uint32_t>(p.genotype[(size_t)s * p.n_variants + c], 3u);
+				const size_t slot = (size_t)key * p.T + t;
+				if (!compat.known[slot]) {
+					std::vector<uint8_t>& list = compat.lists[slot];
+					for (uint32_t a = 0; a < (1u << p.P); ++a) {
+						bool ok = true;
+						for (uint32_t s = 0; s < p.n_ind && ok; ++s)
+							ok = p.genotype[(size_t)s * p.n_variants + c] == ((a >> map[2 * s]) & 1) + ((a >> map[2 * s + 1]) & 1);
+						if (ok) list.push_back((uint8_t)a);
+					}
+					compat.known[slot] = 1;
+				}
+				shortlist = &compat.lists[slot];
+			}
+			const uint32_t n_try = shortlist ? (uint32_t)shortlist->size() : (1u << p.P);
+			for (uint32_t ai = 0; ai < n_try; ++ai) {  // src/pedigreecolumncostcomputer.cpp:25-49 (ascending assignment order either way)
+				const uint32_t a = shortlist ? (*shortlist)[ai] : ai;
 				bool compatible = true;
 				uint32_t acost = 0;
 				CostTerm term{0, 0, 0};
@@ -619,6 +655,7 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 		if (c_begin >= c_end) return;
 		out.terms.reserve(columns_only ? 0 : (size_t)(c_end - c_begin) * p.T * (distrust ? (size_t)1 << p.P : 2));   // (untrusted genotypes: every allele assignment is a term -- a vector that grows by doubling copied 150 MB several times)
 		std::vector<uint32_t> R(p.n_ind), W(p.n_ind);
+		CompatCache compat = make_compat();
 		// Read-major: every read that touches the range writes its entry into each of its columns, in read order -- the rank of a read in a
 		// column is the number of earlier reads active there, a counter per column.  (Column-major -- a list of active reads with a cursor each,
 		// compacted and walked per column -- was 35 cycles per entry of dependent loads; this is sequential reads and one store per entry.)
@@ -661,7 +698,7 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 			p.fwd_mask[c] = mask;   // last column: everything is minimised out (global optimum, src/pedigreedptable.cpp:306-315)
 			p.f[c] = (uint8_t)__builtin_popcount(mask);
 			out.max_k = std::max(out.max_k, kc);
-			if (!columns_only && !column_terms(c, out, R, W)) return;
+			if (!columns_only && !column_terms(c, out, R, W, compat)) return;
 		}
 	};
 	double bound = 0.0;  // upper bound on any DP value, to rule out 32-bit wrap-around
