@@ -1136,7 +1136,9 @@ def main():
     if len(problems) == 1:
         host_shapes = [(1, 0, 1, 1)]
     elif world > 1:
-        host_shapes = [(max(1, min(len(problems), n_cpus // 2)), 2, whole), (max(1, min(len(problems), n_cpus // 4)), 4, whole)]
+        # a rank's CPU slice (32 hardware threads of the box at N = 8) over its tables: few large tables (configs[4] at N = 8: three per rank) get many threads each
+        workers = max(1, min(len(problems), n_cpus))
+        host_shapes = [(workers, max(2, min(32, n_cpus // workers)), whole), (max(1, min(len(problems), n_cpus // 2)), 2, whole), (max(1, min(len(problems), n_cpus // 4)), 4, whole)]
     else:
         # (workers, threads per create, tables per window): one window of everything keeps the device's launch sequence shortest; two or three windows let the
         # creates of the next one run under the solve of the current one -- what wins depends on the table shape and is measured, not assumed
