@@ -1182,7 +1182,8 @@ def main():
             elif what == "enqueued":
                 solve_ms += ms - last
             last = ms
-        return {"wall_ms": (td - ta) * 1e3, "create_ms": create_wait, "solve_ms": solve_ms, "close_ms": (td - tc) * 1e3, "checksum": checksum}
+        return {"wall_ms": (td - ta) * 1e3, "create_ms": create_wait, "solve_ms": solve_ms, "close_ms": (td - tc) * 1e3, "checksum": checksum,
+                "other_ms": (tc - ta) * 1e3 - create_wait - solve_ms}   # (the work queue's own tail: device releases on the pool's threads, the pool's shutdown)
 
     tried = []
     shape = host_shapes[0]
@@ -1215,7 +1216,7 @@ def main():
         vals = sorted(r[key] for r in fresh if r.get(key) is not None)
         return vals[len(vals) // 2] if vals else None
 
-    per_rank = {"rank": rank, "device": device, "tables": len(problems), "create_ms": med("create_ms"), "solve_ms": med("solve_ms"), "close_ms": med("close_ms"),
+    per_rank = {"rank": rank, "device": device, "tables": len(problems), "create_ms": med("create_ms"), "solve_ms": med("solve_ms"), "close_ms": med("close_ms"), "other_ms": med("other_ms"),
                 "step_ms": med("wall_ms"), "resident_step_ms": sorted(resident_step_s)[len(resident_step_s) // 2] * 1e3,
                 "cpus": (cpu_binding or {}).get("n_cpus", n_cpus), "numa_node": (cpu_binding or {}).get("node"), "cpu_source": (cpu_binding or {}).get("source", "unbound"),
                 "create_threads": shape[0], "host_threads_per_create": shape[1], "tables_per_window": shape[2], "windows_on_device": shape[3]}
