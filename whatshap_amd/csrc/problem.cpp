@@ -855,6 +855,52 @@ namespace {
 
 whamd_status_t finish_columns(const Problem& p, Solution& s, uint32_t c_begin, uint32_t c_end, std::string& msg) {
 	const uint32_t n = p.n_cols;
+	if (p.n_ind == 1 && p.T == 1 && p.P == 2 && !p.distrust && p.h2p.size() >= 2 && p.h2p[0] == 0 && p.h2p[1] == 1 && !getenv("WHAMD_GENERIC_FINISH")) {
+		// ONE individual, genotypes trusted (every table of `whatshap phase` without a pedigree): the loops below written out.  Partition p = side of the read;
+		// cp[p][1] += q for REF, cp[p][0] += q for ALT (set_partitioning, :53-76); the assignments compatible with genotype 0/1 are a = 1 (haplotype 0 carries ALT:
+		// cost cp[0][1] + cp[1][0]) then a = 2 (cost cp[0][0] + cp[1][1]), `<=` lets the later one win a tie (:131); both haplotypes' quality is the absolute
+		// difference of the two; a homozygous genotype has ONE assignment and the other allele's best stays INF = -1 as an int (:162): quality cost + 1.
+		// (96 coverage-15 tables spent 600 thread-ms per step in the general loop: 5 ms per table, the tail of every shared solve.)
+		for (uint32_t c = c_begin; c < c_end; ++c) {
+			const uint32_t x = s.path_index[c];
+			const ColumnEntry* col = p.col_begin(c);
+			const uint32_t kc = p.k[c];
+			uint32_t cp[2][2] = {{0, 0}, {0, 0}};
+			for (uint32_t j = 0; j < kc; ++j) {
+				const ColumnEntry& e = col[j];
+				const uint32_t side = (x >> j) & 1u;
+				if (side == 0) __atomic_store_n(&s.partition[e.read_id], (uint8_t)0, __ATOMIC_RELAXED);
+				if (e.allele == WHAMD_ALLELE_REF) cp[side][1] += e.phred;
+				else if (e.allele == WHAMD_ALLELE_ALT) cp[side][0] += e.phred;
+			}
+			const uint8_t g = p.genotype[c];
+			uint8_t a0, a1;
+			uint32_t quality;
+			if (g == 1) {
+				const uint32_t cost1 = cp[0][1] + cp[1][0], cost2 = cp[0][0] + cp[1][1];
+				const bool second = cost2 <= cost1;           // a = 2 is visited last
+				if ((second ? cost2 : cost1) == INF) { msg = "Error: Mendelian conflict"; return WHAMD_ERR_MENDELIAN_CONFLICT; }
+				a0 = second ? 0 : 1;
+				a1 = second ? 1 : 0;
+				quality = (uint32_t)std::abs((int)cost1 - (int)cost2);   // |best[h][0] - best[h][1]| for either haplotype
+				if (quality == 0) a0 = a1 = WHAMD_ALLELE_EQUAL_SCORES;
+			} else if (g == 0 || g == 2) {
+				const uint32_t al = g == 2 ? 1u : 0u;
+				const uint32_t cost = cp[0][al] + cp[1][al];
+				if (cost == INF) { msg = "Error: Mendelian conflict"; return WHAMD_ERR_MENDELIAN_CONFLICT; }
+				a0 = a1 = (uint8_t)al;
+				quality = (uint32_t)std::abs((int)cost - (int)INF);     // the other allele was never feasible: INF reads as -1 (:162)
+				if (quality == 0) a0 = a1 = WHAMD_ALLELE_EQUAL_SCORES;
+			} else {
+				msg = "Error: Mendelian conflict";
+				return WHAMD_ERR_MENDELIAN_CONFLICT;
+			}
+			s.allele0[c] = a0;
+			s.allele1[c] = a1;
+			s.quality[c] = quality;
+		}
+		return WHAMD_OK;
+	}
 	std::vector<std::array<uint32_t, 2>> cp(std::max<uint32_t>(p.P, 1));
 	std::vector<std::array<uint32_t, 4>> best_for(std::max<uint32_t>(p.n_ind, 1));  // [ind][hap*2 + allele]
 	for (uint32_t c = c_begin; c < c_end; ++c) {
