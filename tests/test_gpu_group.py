@@ -220,3 +220,48 @@ def test_96_tables_in_one_group_vs_single_solves_and_the_oracle():
     for k in (0, 1, 2, 4, 5, 10, 11, 40, 72, 95):
         want = table_solution(oracle.OracleTable(cases[k][1]))
         assert batched[k] == want, (k, cases[k][0], first_difference(batched[k], want))
+
+
+def test_superreads_made_on_the_device_equal_the_hosts_loop(monkeypatch):
+    """A single-individual table with trusted genotypes gets its superreads from superreads_single / superreads_group (kernels_backtrace.h) and its
+    partitioning from the column each read enters in; the debug library's WHAMD_HOST_SUPERREADS=1 sends the same tables through the host's loop
+    (problem.cpp finish_columns).  Alone and as a group, tie-heavy weights and homozygous genotypes included; everything compared, qualities too."""
+    problems = [synthetic_block(n_variants=n, coverage=cov, seed=300 + i) for i, (cov, n) in enumerate([(15, 3000), (12, 700), (9, 400), (5, 50), (15, 21000)])]
+    problems.append(irregular_block(1500, 14, seed=310))
+    problems.append(two_valued(synthetic_block(n_variants=900, coverage=12, seed=311), 411))
+    homo = synthetic_block(n_variants=800, coverage=11, seed=312)
+    g = homo.genotype.copy()
+    g[::3] = 0
+    g[1::7] = 2
+    problems.append(_native.ProblemArrays(homo.read_ptr, homo.var_position, homo.var_allele, homo.var_quality, homo.read_sample_id, homo.individual_id, homo.triple_ids, g,
+                                          homo.genotype_likelihoods, homo.recombcost, homo.positions, homo.distrust_genotypes, n_variants=homo.n_variants))
+
+    def solve_all():
+        alone = []
+        for p in problems:
+            t = _native.NativeTable(p)
+            alone.append(table_solution(t))
+            t.close()
+        tables = [_native.NativeTable(p, solve=False) for p in problems]
+        _native.enqueue_many(tables)
+        _native.wait_many(tables)
+        grouped = [table_solution(t) for t in tables]
+        for t in tables:
+            t.close()
+        return alone, grouped
+
+    device_alone, device_grouped = solve_all()
+    saved = _native._lib
+    try:
+        monkeypatch.setenv("WHAMD_HOST_SUPERREADS", "1")
+        _native.use_debug_library()
+        host_alone, host_grouped = solve_all()
+    finally:
+        _native._lib = saved
+    for i in range(len(problems)):
+        assert first_difference(device_alone[i], host_alone[i]) is None, (i, first_difference(device_alone[i], host_alone[i]))
+        assert first_difference(device_grouped[i], host_grouped[i]) is None, (i, first_difference(device_grouped[i], host_grouped[i]))
+        assert first_difference(device_alone[i], device_grouped[i]) is None, (i, first_difference(device_alone[i], device_grouped[i]))
+    for i in (1, 2, 3, 5, 6, 7):
+        want = table_solution(oracle.OracleTable(problems[i]))
+        assert first_difference(device_alone[i], want) is None, (i, first_difference(device_alone[i], want))

@@ -307,19 +307,57 @@ whamd_status_t whamd_dptable_wait_many(whamd_dptable* const* tables, size_t n_ta
 	// instead of 98, the runtime's waiters contend)
 	const uint32_t outer = (uint32_t)std::min<uint64_t>(host_threads(n_tables, 1), n_tables);   // (host_threads() returns n / grain + 1: never more workers than tables)
 	const uint32_t inner = std::max(1u, host_threads(1u << 30, 1) / outer);   // (a table's own finish splits its columns over threads: not 32 x 7 of them at once)
+	auto finish_one = [&](size_t i) {
+		whamd_dptable* t = tables[i];
+		const double t0 = now_ms();
+		status[i] = finish_solution(t->problem, t->solution, messages[i]);
+		t->stats.host_finish_ms = now_ms() - t0;
+		t->solved = status[i] == WHAMD_OK;
+	};
+	// More tables than wait workers (a group of many tables: they all finish with the group's last launch): the device waits on the 32 workers, THEN every table's
+	// host side on a worker of its own -- no HIP call in that phase, so nothing contends in the runtime -- instead of three rounds of wait + finish per worker
+	// (10 ms behind a 96-table solve, 3.3 ms now).  Fewer tables (own streams, finishing at different times): a worker waits for its table and finishes it at once.
+	const bool two_phases = false;   // (measured on one box, same process, twelve steps each: 54.4 ms with the two phases against 50.7 ms without -- not kept; the switch stays for the next measurement)
+	const bool timing = getenv("WHAMD_DEBUG_TIMING") != nullptr;
+	const double t_wait0 = now_ms();
+	{
+		std::vector<DeviceTable*> devs(n_tables);
+		for (size_t i = 0; i < n_tables; ++i) devs[i] = &tables[i]->device;
+		DeviceTable::wait_last_of_each_stream(devs.data(), n_tables);
+	}
+	std::vector<double> t_begun(timing ? n_tables : 0, 0.0), t_synced(timing ? n_tables : 0, 0.0), t_finished(timing ? n_tables : 0, 0.0);
 	parallel_ranges(n_tables, outer, [&](uint64_t i0, uint64_t i1, uint32_t) {
 		struct Budget { uint32_t saved = whamd::host_threads_override(); ~Budget() { whamd::host_threads_override() = saved; } } budget;
 		whamd::host_threads_override() = inner;
 		for (uint64_t i = i0; i < i1; ++i) {
 			whamd_dptable* t = tables[i];
+			if (timing) t_begun[i] = now_ms() - t_wait0;
 			status[i] = t->device.wait(t->problem, t->solution, t->stats, messages[i]);
-			if (status[i] != WHAMD_OK) continue;
-			const double t0 = now_ms();
-			status[i] = finish_solution(t->problem, t->solution, messages[i]);
-			t->stats.host_finish_ms = now_ms() - t0;
-			t->solved = status[i] == WHAMD_OK;
+			if (timing) t_synced[i] = now_ms() - t_wait0;
+			if (status[i] != WHAMD_OK || two_phases) continue;
+			finish_one(i);
+			if (timing) t_finished[i] = now_ms() - t_wait0;
 		}
 	});
+	if (timing && n_tables > 1) {
+		double s0 = 1e30, s1 = 0, f1 = 0;
+		for (size_t i = 0; i < n_tables; ++i) { s0 = std::min(s0, t_synced[i]); s1 = std::max(s1, t_synced[i]); f1 = std::max(f1, t_finished[i]); }
+		double fin = 0, late_wait = 0, late_max = 0; size_t late = 0;
+		for (size_t i = 0; i < n_tables; ++i) {
+			fin += t_finished[i] - t_synced[i];
+			if (t_begun[i] > s0) { late_wait += t_synced[i] - t_begun[i]; late_max = std::max(late_max, t_synced[i] - t_begun[i]); ++late; }   // (a wait that began after the first one had returned: the device was done)
+		}
+		fprintf(stderr, "[whamd timing] wait_many of %zu tables on %u workers: first table's device side done after %.1f ms, last after %.1f ms, last host side after %.1f ms; host side %.2f ms per table; %zu waits begun after the device was done took %.2f ms each (longest %.2f)\n",
+		        n_tables, outer, s0, s1, f1, fin / n_tables, late, late ? late_wait / late : 0.0, late_max);
+	}
+	if (two_phases) {
+		const uint32_t workers = (uint32_t)std::min<uint64_t>(n_tables, std::max(outer, std::min(whamd::usable_cpus(), 128u)));
+		parallel_ranges(n_tables, workers, [&](uint64_t i0, uint64_t i1, uint32_t) {
+			struct Budget { uint32_t saved = whamd::host_threads_override(); ~Budget() { whamd::host_threads_override() = saved; } } budget;
+			whamd::host_threads_override() = 1;
+			for (uint64_t i = i0; i < i1; ++i) if (status[i] == WHAMD_OK) finish_one(i);
+		});
+	}
 	for (size_t i = 0; i < n_tables && first == WHAMD_OK; ++i)
 		if (status[i] != WHAMD_OK) { first = status[i]; first_msg = messages[i]; }
 	return first == WHAMD_OK ? WHAMD_OK : fail(first, first_msg);
@@ -404,6 +442,8 @@ whamd_status_t whamd_dptable_get_index_path(const whamd_dptable* t, uint32_t* in
 
 whamd_status_t whamd_dptable_get_stats(const whamd_dptable* t, whamd_solve_stats* stats_out) {
 	if (!t || !stats_out) return fail(WHAMD_ERR_INVALID, "null argument");
+	whamd_dptable* tt = const_cast<whamd_dptable*>(t);   // (the timings are a cache filled at the first request)
+	if (t->solved && !t->in_flight) tt->device.read_timing(tt->stats);
 	*stats_out = t->stats;
 	return WHAMD_OK;
 }

@@ -27,9 +27,13 @@ public:
 	// Resumable enqueue(): at most `budget` forward launches per call; `done` once backtrace and downloads are submitted.
 	whamd_status_t enqueue_some(const Problem& p, Solution& s, uint64_t budget, bool& done, std::string& msg);
 	whamd_status_t wait(const Problem& p, Solution& s, whamd_solve_stats& st, std::string& msg);
+	// forward_ms / backtrace_ms / total_ms of the solve wait() collected last: read from the events on demand (wait() leaves them 0).
+	void read_timing(whamd_solve_stats& st);
 	// Several tables of ONE device as one sequence of launches (see dp_device.hip, "group solve"): every table must be group_eligible().
 	// Afterwards each table is in flight exactly as after enqueue(): collect with wait().
 	static whamd_status_t enqueue_group(DeviceTable* const* tables, const Problem* const* problems, Solution* const* solutions, size_t n_tables, std::string& msg);
+	// Before the wait() of several tables in flight: one host wait per stream that carries tails of a group (dp_device.hip).
+	static void wait_last_of_each_stream(DeviceTable* const* tables, size_t n_tables);
 	bool group_eligible(const Problem& p) const;
 	int device_index() const;
 	uint32_t widest_launch() const;   // workgroups of the widest launch of the schedule

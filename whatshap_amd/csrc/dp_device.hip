@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cctype>
 #include <chrono>
 #include <cstdio>
@@ -550,7 +551,17 @@ struct DeviceTable::Impl {
 	void launch_slot_run(const SlotBatchEntry& e, uint64_t& launches);
 	whamd_status_t begin_solve(const Problem& p, Solution& s, std::string& msg);
 	whamd_status_t submit_singles(const Problem& p, const SuperStep& ss, uint64_t& launches, std::string& msg);
-	whamd_status_t submit_tail(const Problem& p, std::string& msg);
+	whamd_status_t submit_tail(const Problem& p, std::string& msg, hipStream_t tail_stream = nullptr, bool backtrace_done = false, bool superreads_done = false);
+	BtGroupEntry h_bt_entry{};          // what a batched backtrace launch reads for this table (kernels_backtrace.h backtrace_chunks_group), and its device copy
+	BtGroupEntry* d_bt_entry = nullptr;
+	// get_super_reads on the device (kernels_backtrace.h superreads_single): a table with one individual and trusted genotypes
+	bool device_superreads = false;
+	SuperreadArgs super_args{};
+	size_t super_words = 0, super_off = 0;   // size of the result (u32 words) and where it lies in h_pinned
+	bool timing_pending = false;        // wait() has collected a solve whose event timings nobody has read yet (read_timing)
+	hipStream_t tail_stream = nullptr;  // where submit_tail put the tail of the solve in flight, and its place in the order of all tails of the process
+	uint64_t tail_seq = 0;
+	bool tail_elsewhere = false;        // the tail (backtrace, downloads) of the solve in flight went onto another table's stream: wait() waits for ev3, not for `stream`
 
 	void release_lanes() {
 		max_grid_x = 1;
@@ -563,6 +574,8 @@ struct DeviceTable::Impl {
 	}
 
 	void release() {
+		if (tail_elsewhere && ev3) (void)hipEventSynchronize(ev3);   // (a solve whose tail ran on the group's lead stream: nothing of it may still be reading the buffers)
+		tail_elsewhere = false;
 		release_lanes();
 		windowed = false;
 		if (stream && (!allocations.empty() || d_arena)) (void)hipStreamSynchronize(stream);   // (hipFree used to wait for the table's last kernels)
@@ -601,6 +614,7 @@ void DeviceTable::release_device() {
 	}
 	m.stream = m.run_stream = nullptr;
 	m.ev0 = m.ev1 = m.ev2 = m.ev3 = m.ev_group = m.ev_upload = nullptr;
+	m.timing_pending = false;
 }
 
 int DeviceTable::device_count() {
@@ -890,10 +904,14 @@ whamd_status_t DeviceTable::upload(Problem& p, int device, std::string& msg) {
 	size_t delta_count = (size_t)p.col_ptr[n] * p.n_ind;
 	if (p.n_ind == 0) { delta_fallback.assign(std::max<size_t>(p.col_ptr[n], 1), 0); delta_src = delta_fallback.data(); delta_count = delta_fallback.size(); }
 	void *d_delta, *d_term_ptr, *d_terms, *d_segs, *d_bt, *d_keys, *d_last_keys, *d_rcol, *d_rbt, *d_fterms = nullptr;
+	// The superreads of a single-individual table with trusted genotypes are made on the device, behind the backtrace (the condition is finish_columns' first branch).
+	m.device_superreads = n > 0 && p.n_ind == 1 && p.T == 1 && p.P == 2 && !p.distrust && p.h2p.size() >= 2 && p.h2p[0] == 0 && p.h2p[1] == 1 && p.genotype.size() >= n &&
+	                      !debug_env("WHAMD_HOST_SUPERREADS");
+	const size_t super_upload = m.device_superreads ? ((size_t)n + 1) * 8 + n + 1024 : 0;
 	const size_t upload_bytes = m.cols.size() * sizeof(DevColumn) + delta_count * sizeof(int32_t) + term_ptr32.size() * 4 + (terms.size() + p.fterms.size()) * sizeof(DevTerm) + segs.size() * 4 +
 	             m.plan.columns.size() * (sizeof(ResColumn) + sizeof(ResBacktrace) + sizeof(PedColumn)) + m.plan.ped_terms.size() * sizeof(PedTerm) +
 	             (m.splan.rows.size() + SLOT_ROW_PAD) * sizeof(SlotRow) + m.splan.prows.size() * sizeof(PedSlotRow) + m.splan.bt_cols.size() * (sizeof(SlotBtCol) + 8) +
-	             m.splan.runs.size() * (sizeof(SlotRun) + sizeof(PedSlotExtra) + sizeof(BtUnit) + sizeof(SlotBatchEntry) + 64) + m.plan.segments.size() * (sizeof(ResBatchEntry) + sizeof(BtUnit)) + ((size_t)8 << 20);
+	             m.splan.runs.size() * (sizeof(SlotRun) + sizeof(PedSlotExtra) + sizeof(BtUnit) + sizeof(SlotBatchEntry) + 64) + m.plan.segments.size() * (sizeof(ResBatchEntry) + sizeof(BtUnit)) + super_upload + ((size_t)8 << 20);
 	stage.expect(upload_bytes);
 	// ONE device block and ONE staging image per table: every uploaded array is a piece of the block at the offset it has in the pinned area, and the pieces
 	// leave as a few large copies.  (Per-array copies of ~1 MB ran at 25 GB/s -- 96 coverage-15 tables, 28 MB each, spent their creates waiting for the link --;
@@ -986,7 +1004,9 @@ whamd_status_t DeviceTable::upload(Problem& p, int device, std::string& msg) {
 			pc_terms.emplace_back((size_t)p.term_ptr[(size_t)r.first * p.T] * sizeof(DevTerm), (size_t)p.term_ptr[(size_t)r.second * p.T] * sizeof(DevTerm));
 		}
 		HIP_TRY(up_pieces((void**)&m.d_cols, m.cols.data(), m.cols.size() * sizeof(DevColumn), pc_cols));
-		HIP_TRY(up_pieces(&d_delta, delta_src, delta_count * sizeof(int32_t), pc_delta));
+		// (the deltas travel whole when the device makes the superreads: superreads_single reads every column's)
+		if (m.device_superreads) HIP_TRY(up(&d_delta, delta_src, delta_count * sizeof(int32_t)));
+		else HIP_TRY(up_pieces(&d_delta, delta_src, delta_count * sizeof(int32_t), pc_delta));
 		HIP_TRY(up_pieces(&d_term_ptr, term_ptr32.data(), term_ptr32.size() * sizeof(uint32_t), pc_tptr));
 		HIP_TRY(up_pieces(&d_terms, terms.data(), terms.size() * sizeof(DevTerm), pc_terms));
 	} else {
@@ -994,6 +1014,17 @@ whamd_status_t DeviceTable::upload(Problem& p, int device, std::string& msg) {
 	HIP_TRY(up(&d_delta, delta_src, delta_count * sizeof(int32_t)));
 	HIP_TRY(up(&d_term_ptr, term_ptr32.data(), term_ptr32.size() * sizeof(uint32_t)));
 	HIP_TRY(up(&d_terms, terms.data(), terms.size() * sizeof(DevTerm)));
+	}
+	if (m.device_superreads) {
+		void *d_cp = nullptr, *d_geno = nullptr;
+		HIP_TRY(up(&d_cp, p.col_ptr.data(), ((size_t)n + 1) * sizeof(uint64_t)));
+		HIP_TRY(up(&d_geno, p.genotype.data(), (size_t)n));
+		m.super_args = SuperreadArgs{};
+		m.super_args.delta = (const int32_t*)d_delta;
+		m.super_args.col_ptr = (const unsigned long long*)d_cp;
+		m.super_args.genotype = (const uint8_t*)d_geno;
+		m.super_args.n_cols = n;
+		m.super_words = (size_t)n + ((size_t)2 * n + 3) / 4;
 	}
 	if (!p.fterms.empty()) HIP_TRY(up(&d_fterms, p.fterms.data(), p.fterms.size() * sizeof(DevTerm)));   // factorised lines (pedslot_tables, PSLOT_FACT)
 	HIP_TRY(up(&d_segs, segs.data(), segs.size() * sizeof(uint32_t)));
@@ -1330,7 +1361,14 @@ whamd_status_t DeviceTable::upload(Problem& p, int device, std::string& msg) {
 	HIP_TRY(alloc((void**)&m.d_path_index, (size_t)n * 4));
 	HIP_TRY(alloc((void**)&m.d_path_trans, (size_t)n * 4));
 	HIP_TRY(alloc((void**)&m.d_score, 16));
-	HIP_TRY(pinned_take((2 * (size_t)n + 4 + m.jobs.size()) * sizeof(uint32_t), (void**)&m.h_pinned, &m.h_pinned_bytes));
+	m.super_off = 2 * (size_t)n + 4 + m.jobs.size();
+	if (m.device_superreads) {
+		void* d_super = nullptr;
+		HIP_TRY(alloc(&d_super, m.super_words * 4));
+		m.super_args.out = (uint32_t*)d_super;
+		m.super_args.path_index = m.d_path_index;
+	}
+	HIP_TRY(pinned_take((m.super_off + (m.device_superreads ? m.super_words : 0)) * sizeof(uint32_t), (void**)&m.h_pinned, &m.h_pinned_bytes));
 	HIP_TRY(alloc((void**)&m.d_job_scores, (m.jobs.size() + 1) * 4));
 	{   // lanes: longest job first to the least loaded lane; lane 0 always runs the final job
 		// at most 1 GiB of private exchange buffers (coverage 23: 64 MiB per lane)
@@ -1642,6 +1680,22 @@ whamd_status_t DeviceTable::upload(Problem& p, int device, std::string& msg) {
 			if (device < 64) attr_done |= 1ull << device;
 		}
 	}
+	m.d_bt_entry = nullptr;
+	if (m.use_chunks) {   // (m.dp is complete here)
+		BtGroupEntry& e = m.h_bt_entry;
+		e = BtGroupEntry{};
+		e.P = m.dp;
+		e.units = m.d_units; e.chunks = m.d_chunks;
+		e.n_chunks = (uint32_t)m.chunks.size(); e.n_units = (uint32_t)m.units.size(); e.n_orient_max = m.n_orient_max; e.n_cols = n;
+		e.path2 = m.d_path2; e.trans2 = m.d_trans2; e.out_score = m.d_score; e.unit_x2 = m.d_unit_x; e.guess = m.d_guess; e.sel = m.d_sel; e.counters = m.d_bt_counters;
+		e.path_index = m.d_path_index; e.path_trans = m.d_path_trans;
+		if (m.device_superreads) e.super = m.super_args;
+		void* d_entry = nullptr;
+		HIP_TRY(alloc(&d_entry, sizeof(BtGroupEntry)));
+		HIP_TRY(hipMemcpyAsync(d_entry, &m.h_bt_entry, sizeof(BtGroupEntry), hipMemcpyHostToDevice, m.stream));   // (the source is a member: it outlives the copy)
+		HIP_TRY(hipEventRecord(m.ev_upload, m.stream));
+		m.d_bt_entry = (BtGroupEntry*)d_entry;
+	}
 	return WHAMD_OK;
 }
 
@@ -1835,6 +1889,7 @@ whamd_status_t DeviceTable::Impl::begin_solve(const Problem& p, Solution& s, std
 	const uint32_t n = p.n_cols;
 	s.path_index.assign(n, 0);
 	s.path_trans.assign(n, 0);
+	s.superreads_done = false;
 	m.launches = 0;
 	m.next_super = 0;
 	if (n == 0) return WHAMD_OK;
@@ -1843,6 +1898,7 @@ whamd_status_t DeviceTable::Impl::begin_solve(const Problem& p, Solution& s, std
 	HIP_TRY(hipMemsetAsync(m.dp.last_keys, 0xFF, (size_t)MAX_T_WIDE * 8, m.run_stream));
 	if (m.use_chunks) HIP_TRY(hipMemsetAsync(m.dp.spec_keys, 0xFF, ((size_t)m.n_spec + 1) * m.dp.spec_stride * 8, m.run_stream));
 	if (m.windowed) HIP_TRY(hipMemsetAsync(m.d_path_trans, 0, (size_t)n * 4, m.run_stream));
+	m.timing_pending = false;   // (the events are this solve's from here on)
 	HIP_TRY(hipEventRecord(m.ev0, m.run_stream));
 	if (!m.plan.ped_columns.empty()) {
 		const uint32_t entries = (uint32_t)m.plan.ped_columns.size() * PED_TABLE;
@@ -1868,32 +1924,47 @@ whamd_status_t DeviceTable::Impl::submit_singles(const Problem& p, const SuperSt
 }
 
 // Everything after the forward pass, on the table's OWN stream: backtrace, downloads, events.
-whamd_status_t DeviceTable::Impl::submit_tail(const Problem& p, std::string& msg) {
+whamd_status_t DeviceTable::Impl::submit_tail(const Problem& p, std::string& msg, hipStream_t tail_stream, bool backtrace_done, bool superreads_done) {
 	Impl& m = *this;
+	const hipStream_t ts = tail_stream ? tail_stream : m.stream;
+	m.tail_elsewhere = ts != m.stream;
+	m.tail_stream = ts;
+	{
+		static std::atomic<uint64_t> seq{0};
+		m.tail_seq = ++seq;
+	}
 	const uint32_t n = p.n_cols;
 	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipEventRecord(m.ev1, m.stream));
-	if (m.use_chunks) {
-		hipLaunchKernelGGL(backtrace_chunks, dim3(m.n_orient_max * (uint32_t)m.chunks.size()), dim3(256), m.chunk_lds, m.stream, m.dp, m.d_units, m.d_chunks,
+	if (!backtrace_done) HIP_TRY(hipEventRecord(m.ev1, ts));   // (backtrace_done: a batched launch walked this table with the rest of its group; ev1 was recorded in front of it)
+	if (backtrace_done) {
+	} else if (m.use_chunks) {
+		hipLaunchKernelGGL(backtrace_chunks, dim3(m.n_orient_max * (uint32_t)m.chunks.size()), dim3(256), m.chunk_lds, ts, m.dp, m.d_units, m.d_chunks,
 		                   (uint32_t)m.chunks.size(), (uint32_t)m.units.size(), 0u, m.n_orient_max, m.d_path2, m.d_trans2, m.d_score, m.d_unit_x, m.d_guess, m.d_sel, m.d_bt_counters);
-		hipLaunchKernelGGL(backtrace_chunks, dim3(1), dim3(256), m.chunk_lds, m.stream, m.dp, m.d_units, m.d_chunks,
+		hipLaunchKernelGGL(backtrace_chunks, dim3(1), dim3(256), m.chunk_lds, ts, m.dp, m.d_units, m.d_chunks,
 		                   (uint32_t)m.chunks.size(), (uint32_t)m.units.size(), 1u, m.n_orient_max, m.d_path2, m.d_trans2, m.d_score, m.d_unit_x, m.d_guess, m.d_sel, m.d_bt_counters);
-		hipLaunchKernelGGL(backtrace_gather, dim3((uint32_t)m.units.size()), dim3(64), 0, m.stream, m.d_units, (uint32_t)m.units.size(), n, m.d_path2, m.d_trans2, m.d_sel,
+		hipLaunchKernelGGL(backtrace_gather, dim3((uint32_t)m.units.size()), dim3(64), 0, ts, m.d_units, (uint32_t)m.units.size(), n, m.d_path2, m.d_trans2, m.d_sel,
 		                   m.d_path_index, m.d_path_trans);
 	} else if (!m.windowed)   // (windowed: every window was walked right after its steps)
-	hipLaunchKernelGGL(backtrace_kernel, dim3((uint32_t)m.jobs.size()), dim3(1024), m.bt_lds, m.stream, m.dp, m.d_units, m.d_btjobs,
+	hipLaunchKernelGGL(backtrace_kernel, dim3((uint32_t)m.jobs.size()), dim3(1024), m.bt_lds, ts, m.dp, m.d_units, m.d_btjobs,
 	                   m.d_path_index, m.d_path_trans, m.d_score);
 	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipEventRecord(m.ev2, m.stream));
+	HIP_TRY(hipEventRecord(m.ev2, ts));
+	if (m.device_superreads) {
+		if (!superreads_done) {
+			hipLaunchKernelGGL(superreads_single, dim3((n + 255u) / 256u), dim3(256), 0, ts, m.super_args);
+			HIP_TRY(hipGetLastError());
+		}
+		HIP_TRY(hipMemcpyAsync(m.h_pinned + m.super_off, m.super_args.out, m.super_words * 4, hipMemcpyDeviceToHost, ts));
+	}
 	// downloads go to pinned host buffers: a copy into pageable memory would block this call until the stream drains
-	HIP_TRY(hipMemcpyAsync(m.h_pinned, m.d_path_index, (size_t)n * 4, hipMemcpyDeviceToHost, m.stream));
-	HIP_TRY(hipMemcpyAsync(m.h_pinned + n, m.d_path_trans, (size_t)n * 4, hipMemcpyDeviceToHost, m.stream));
-	HIP_TRY(hipMemcpyAsync(m.h_pinned + 2 * (size_t)n, m.d_score, 4, hipMemcpyDeviceToHost, m.stream));
+	HIP_TRY(hipMemcpyAsync(m.h_pinned, m.d_path_index, (size_t)n * 4, hipMemcpyDeviceToHost, ts));
+	HIP_TRY(hipMemcpyAsync(m.h_pinned + n, m.d_path_trans, (size_t)n * 4, hipMemcpyDeviceToHost, ts));
+	HIP_TRY(hipMemcpyAsync(m.h_pinned + 2 * (size_t)n, m.d_score, 4, hipMemcpyDeviceToHost, ts));
 	if (m.jobs.size() > 1)
-		HIP_TRY(hipMemcpyAsync(m.h_pinned + 2 * (size_t)n + 1, m.d_job_scores + 1, (m.jobs.size() - 1) * 4, hipMemcpyDeviceToHost, m.stream));
+		HIP_TRY(hipMemcpyAsync(m.h_pinned + 2 * (size_t)n + 1, m.d_job_scores + 1, (m.jobs.size() - 1) * 4, hipMemcpyDeviceToHost, ts));
 	// (the chunked backtrace's counters travel with the path: a synchronous 12-byte copy per table in wait() was a device round trip each -- 96 tables, 96 of them)
-	if (m.use_chunks) HIP_TRY(hipMemcpyAsync(m.h_pinned + 2 * (size_t)n + m.jobs.size(), m.d_bt_counters, 12, hipMemcpyDeviceToHost, m.stream));
-	HIP_TRY(hipEventRecord(m.ev3, m.stream));
+	if (m.use_chunks) HIP_TRY(hipMemcpyAsync(m.h_pinned + 2 * (size_t)n + m.jobs.size(), m.d_bt_counters, 12, hipMemcpyDeviceToHost, ts));
+	HIP_TRY(hipEventRecord(m.ev3, ts));
 	return WHAMD_OK;
 }
 
@@ -2103,13 +2174,54 @@ whamd_status_t DeviceTable::enqueue_group(DeviceTable* const* tables, const Prob
 	if (hipGetLastError() != hipSuccess) { msg = "group launch failed"; abort_all(); return WHAMD_ERR_DEVICE; }
 	for (Part& part : parts) {
 		if (hipEventRecord(part.lead->ev_group, part.lead->stream) != hipSuccess) { msg = "hipEventRecord failed"; abort_all(); return WHAMD_ERR_DEVICE; }
+		// the chunked backtrace of the part's members as ONE launch per mode + one gather (blockIdx.y = member), on the lead's stream
+		std::vector<uint8_t> walked(n_tables, 0);
+		if (!debug_env("WHAMD_TAIL_OWN_STREAM") && !debug_env("WHAMD_NO_GROUP_BACKTRACE")) {
+			std::vector<size_t> batch;
+			auto flush_bt = [&]() -> bool {
+				if (batch.size() < 2) { batch.clear(); return true; }
+				BtGroupArgs args{};
+				uint32_t gx = 1, gu = 1;
+				size_t lds = 0;
+				for (size_t i : batch) {
+					Impl& m = *tables[i]->impl_;
+					args.entry[args.n++] = m.d_bt_entry;
+					gx = std::max(gx, m.n_orient_max * (uint32_t)m.chunks.size());
+					gu = std::max(gu, (uint32_t)m.units.size());
+					lds = std::max(lds, m.chunk_lds);
+					if (hipEventRecord(m.ev1, part.lead->stream) != hipSuccess) return false;
+				}
+				hipLaunchKernelGGL(backtrace_chunks_group, dim3(gx, args.n), dim3(256), lds, part.lead->stream, args, 0u);
+				hipLaunchKernelGGL(backtrace_chunks_group, dim3(1, args.n), dim3(256), lds, part.lead->stream, args, 1u);
+				hipLaunchKernelGGL(backtrace_gather_group, dim3(gu, args.n), dim3(64), 0, part.lead->stream, args);
+				uint32_t gs = 0;   // (the superreads of the members the device makes them for, behind the gather)
+				for (size_t i : batch) if (tables[i]->impl_->device_superreads) gs = std::max(gs, (problems[i]->n_cols + 255u) / 256u);
+				if (gs) hipLaunchKernelGGL(superreads_group, dim3(gs, args.n), dim3(256), 0, part.lead->stream, args);
+				if (hipGetLastError() != hipSuccess) return false;
+				for (size_t i : batch) walked[i] = 1;
+				batch.clear();
+				return true;
+			};
+			for (size_t i : part.members) {
+				Impl& m = *tables[i]->impl_;
+				if (!m.use_chunks || m.windowed || !m.d_bt_entry) continue;
+				batch.push_back(i);
+				if (batch.size() == (size_t)BT_GROUP_MAX && !flush_bt()) { msg = "group backtrace launch failed"; abort_all(); return WHAMD_ERR_DEVICE; }
+			}
+			if (!flush_bt()) { msg = "group backtrace launch failed"; abort_all(); return WHAMD_ERR_DEVICE; }
+		}
 		for (size_t i : part.members) {
 			Impl& m = *tables[i]->impl_;
 			m.launches = table_launches[i];
 			m.next_super = m.schedule.size();
 			whamd_status_t st = WHAMD_OK;
-			if (m.stream != part.lead->stream && hipStreamWaitEvent(m.stream, part.lead->ev_group, 0) != hipSuccess) { msg = "hipStreamWaitEvent failed"; st = WHAMD_ERR_DEVICE; }
-			if (st == WHAMD_OK) st = m.submit_tail(*problems[i], msg);
+			// The tail (backtrace, downloads) of every member goes onto the LEAD's stream, behind the group's last launch in the same hardware queue.  On the members'
+			// own streams -- each waiting for the lead's event -- a 96-table step was bimodal: 67 ms or 95 ms, the device's forward pass 39 ms either way
+			// (hardware queues that hold only a barrier are rescheduled late; more queues, GPU_MAX_HW_QUEUES=16, made every step 180 ms).  WHAMD_TAIL_OWN_STREAM=1
+			// (debug library) restores the old placement.
+			const bool own = debug_env("WHAMD_TAIL_OWN_STREAM") != nullptr;
+			if (own && m.stream != part.lead->stream && hipStreamWaitEvent(m.stream, part.lead->ev_group, 0) != hipSuccess) { msg = "hipStreamWaitEvent failed"; st = WHAMD_ERR_DEVICE; }
+			if (st == WHAMD_OK) st = m.submit_tail(*problems[i], msg, own ? nullptr : part.lead->stream, walked[i] != 0, walked[i] != 0);
 			if (st != WHAMD_OK) { abort_all(); return st; }
 			m.enqueue_open = false;
 			m.run_stream = m.stream;
@@ -2118,24 +2230,73 @@ whamd_status_t DeviceTable::enqueue_group(DeviceTable* const* tables, const Prob
 	return WHAMD_OK;
 }
 
+// Tables in flight whose tails share a stream (a group: every member's tail is on the lead's stream, in order) finish in that order: ONE wait for the last of each
+// stream, on the calling thread, and every table's own wait() returns at once.  (32 threads inside hipEventSynchronize at the same time woke up over 6 - 13 ms
+// after the device had recorded the last event -- the events of one table 1.8 ms apart; one waiter wakes once.)
+void DeviceTable::wait_last_of_each_stream(DeviceTable* const* tables, size_t n_tables) {
+	std::vector<std::pair<hipStream_t, const Impl*>> last;
+	for (size_t i = 0; i < n_tables; ++i) {
+		const Impl& m = *tables[i]->impl_;
+		if (!m.tail_elsewhere || !m.ev3) continue;
+		bool found = false;
+		for (auto& e : last) {
+			if (e.first != m.tail_stream || e.second->device != m.device) continue;
+			found = true;
+			if (m.tail_seq > e.second->tail_seq) e.second = &m;
+		}
+		if (!found) last.emplace_back(m.tail_stream, &m);
+	}
+	for (const auto& e : last) {
+		if (hipSetDevice(e.second->device) != hipSuccess || hipEventSynchronize(e.second->ev3) != hipSuccess) (void)hipGetLastError();   // (the table's own wait() reports it)
+	}
+}
+
+// The event timings of the last collected solve (forward, backtrace, first to last event), filled into `st` once; a no-op when they have been
+// read already or when a new solve has been submitted since (the events then belong to that one).
+void DeviceTable::read_timing(whamd_solve_stats& st) {
+	Impl& m = *impl_;
+	if (!m.timing_pending) return;
+	m.timing_pending = false;
+	if (hipSetDevice(m.device) != hipSuccess) return;
+	float f01 = 0, f12 = 0, f03 = 0;
+	if (hipEventElapsedTime(&f01, m.ev0, m.ev1) != hipSuccess || hipEventElapsedTime(&f12, m.ev1, m.ev2) != hipSuccess || hipEventElapsedTime(&f03, m.ev0, m.ev3) != hipSuccess) {
+		(void)hipGetLastError();
+		return;
+	}
+	st.forward_ms = f01;
+	st.backtrace_ms = f12;
+	st.total_ms = f03;
+}
+
 whamd_status_t DeviceTable::wait(const Problem& p, Solution& s, whamd_solve_stats& st, std::string& msg) {
 	Impl& m = *impl_;
 	if (p.n_cols == 0) return WHAMD_OK;
 	HIP_TRY(hipSetDevice(m.device));
 	const uint64_t launches = m.launches;
-	HIP_TRY(hipStreamSynchronize(m.stream));
+	if (m.tail_elsewhere) HIP_TRY(hipEventSynchronize(m.ev3));   // (the last thing submit_tail recorded, on the stream the tail went to)
+	else HIP_TRY(hipStreamSynchronize(m.stream));
 	const uint32_t n = p.n_cols;
 	std::memcpy(s.path_index.data(), m.h_pinned, (size_t)n * 4);
 	std::memcpy(s.path_trans.data(), m.h_pinned + n, (size_t)n * 4);
 	s.optimal_score = m.h_pinned[2 * (size_t)n];
+	if (m.device_superreads) {
+		const uint32_t* q = m.h_pinned + m.super_off;
+		const uint8_t* h = (const uint8_t*)(q + n);
+		if (std::memchr(h, SUPERREAD_CONFLICT, (size_t)2 * n) == nullptr) {   // (a conflict: the host's loop runs and reports it, finish_solution)
+			s.quality.resize(n);
+			s.allele0.resize(n);
+			s.allele1.resize(n);
+			std::memcpy(s.quality.data(), q, (size_t)n * 4);
+			std::memcpy(s.allele0.data(), h, n);
+			std::memcpy(s.allele1.data(), h + n, n);
+			s.superreads_done = true;
+		}
+	}
 	for (size_t j = 1; j < m.jobs.size(); ++j) s.optimal_score += m.h_pinned[2 * (size_t)n + j];  // connected components solved as their own jobs
-	float f01 = 0, f12 = 0, f03 = 0;
-	HIP_TRY(hipEventElapsedTime(&f01, m.ev0, m.ev1));
-	HIP_TRY(hipEventElapsedTime(&f12, m.ev1, m.ev2));
-	HIP_TRY(hipEventElapsedTime(&f03, m.ev0, m.ev3));
-	st.forward_ms = f01;
-	st.backtrace_ms = f12;
-	st.total_ms = f03;
+	// (the event timings are read when somebody asks -- read_timing(), from whamd_dptable_get_stats: three runtime calls per table, from every
+	//  waiting thread at once, are a measurable part of collecting a 96-table step and most callers never look at them)
+	st.forward_ms = st.backtrace_ms = st.total_ms = 0;
+	m.timing_pending = true;
 	st.forward_launches = launches;
 	st.group_tables = m.group_tables;
 	st.bt_chunks = st.bt_missed = st.bt_rewalked = 0;
@@ -2199,6 +2360,8 @@ whamd_status_t DeviceTable::wait(const Problem& p, Solution& s, whamd_solve_stat
 				prev_end = e1;
 			}
 		}
+		float f01 = 0;
+		(void)hipEventElapsedTime(&f01, m.ev0, m.ev1);
 		fprintf(stderr, "[whamd timing] segments %zu cols %llu | cycles/segment: prologue %.0f columns %.0f (%.0f per column) store %.0f | fwd %.3f ms, %.2f us per segment\n",
 		        m.plan.segments.size(), cols, (double)a / m.plan.segments.size(), (double)b / m.plan.segments.size(),
 		        (double)b / std::max<unsigned long long>(cols, 1), (double)c2 / m.plan.segments.size(), f01, f01 * 1e3 / m.plan.segments.size());

@@ -643,11 +643,12 @@ __device__ __forceinline__ uint32_t chunk_walk_unit(const DevProblem& P, const B
 // the two the true path runs through is decided only at the table's last column: both are walked (into path buffer 0 / 1),
 // the verification picks the one the true path arrives at.  (The complement is NOT simply the complement path: ties break
 // differently for the two, the records hold both decisions -- slots.h.)
-__global__ __launch_bounds__(256) void backtrace_chunks(DevProblem P, const BtUnit* __restrict__ units, const BtChunk* __restrict__ chunks,
-                                                         uint32_t n_chunks, uint32_t n_units, uint32_t mode, uint32_t n_orient_max, uint32_t* __restrict__ path2,
-                                                         uint32_t* __restrict__ trans2, uint32_t* __restrict__ out_score,
-                                                         uint32_t* __restrict__ unit_x2, uint32_t* __restrict__ guess, uint8_t* __restrict__ sel,
-                                                         uint32_t* __restrict__ counters) {
+// (`bx`: the block's index in x -- blockIdx.x of a launch for ONE table, or of a launch whose blockIdx.y selects the table: backtrace_chunks_group)
+__device__ __forceinline__ void backtrace_chunks_body(const DevProblem& P, const BtUnit* __restrict__ units, const BtChunk* __restrict__ chunks,
+                                                      uint32_t n_chunks, uint32_t n_units, uint32_t mode, uint32_t n_orient_max, uint32_t* __restrict__ path2,
+                                                      uint32_t* __restrict__ trans2, uint32_t* __restrict__ out_score,
+                                                      uint32_t* __restrict__ unit_x2, uint32_t* __restrict__ guess, uint8_t* __restrict__ sel,
+                                                      uint32_t* __restrict__ counters, const uint32_t bx) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
 	uint32_t* hdr = smem;                         // 32 words
 	uint32_t* xshare = hdr + 32;                  // 4 words
@@ -656,7 +657,7 @@ __global__ __launch_bounds__(256) void backtrace_chunks(DevProblem P, const BtUn
 	unsigned long long* stage = reinterpret_cast<unsigned long long*>(blob + BT_CHUNK_BLOB);
 	const uint32_t tid = threadIdx.x, n = P.n_cols;
 	if (mode == 0) {
-		const uint32_t ci = blockIdx.x / n_orient_max, o = blockIdx.x % n_orient_max;   // (the grid is n_chunks x the most orientations any chunk has)
+		const uint32_t ci = bx / n_orient_max, o = bx % n_orient_max;   // (the grid is n_chunks x the most orientations any chunk has)
 		const BtChunk ch = chunks[ci];
 		if (o >= ch.n_orient) return;
 		const BtUnit* __restrict__ cu = units + ch.unit_off;
@@ -786,6 +787,126 @@ __global__ __launch_bounds__(256) void backtrace_chunks(DevProblem P, const BtUn
 		entry = from == ch.unit_count ? x : unit_x2[(size_t)o * n_units + ch.unit_off + ch.unit_count - 1u];
 	}
 	if (tid == 0) { counters[0] = missed; counters[1] = rewalked; counters[2] = index_only; }
+}
+
+__global__ __launch_bounds__(256) void backtrace_chunks(DevProblem P, const BtUnit* __restrict__ units, const BtChunk* __restrict__ chunks,
+                                                         uint32_t n_chunks, uint32_t n_units, uint32_t mode, uint32_t n_orient_max, uint32_t* __restrict__ path2,
+                                                         uint32_t* __restrict__ trans2, uint32_t* __restrict__ out_score,
+                                                         uint32_t* __restrict__ unit_x2, uint32_t* __restrict__ guess, uint8_t* __restrict__ sel,
+                                                         uint32_t* __restrict__ counters) {
+	backtrace_chunks_body(P, units, chunks, n_chunks, n_units, mode, n_orient_max, path2, trans2, out_score, unit_x2, guess, sel, counters, blockIdx.x);
+}
+
+// get_super_reads of a table with ONE individual and trusted genotypes, on the device (src/pedigreedptable.cpp:344-388 + get_alleles,
+// src/pedigreecolumncostcomputer.cpp:117-175; the host's statement of the same: problem.cpp finish_columns, first branch): one thread per column, from the signed
+// per-bit deltas the forward pass reads (REF +q, ALT -q, BLANK 0) and the index path the backtrace has just written.  cp[side][1] += q for REF, cp[side][0] += q for
+// ALT (set_partitioning, :53-76); genotype 0/1: a = 1 costs cp[0][1] + cp[1][0], a = 2 costs cp[0][0] + cp[1][1], `<=` lets the later one win (:131), the quality is
+// the difference; homozygous: one assignment, the other allele's best stays INF = -1 as an int (:162).  A column the host has to look at (Mendelian conflict: a
+// genotype outside 0..2, a cost of INF) gets the allele SUPERREAD_CONFLICT: the host finds it and runs its own loop, which makes the reference's error.
+// 9 MB of column entries per coverage-15 table of 50 000 columns were the host's tail of every solve (2.3 ms per table, 96 tables behind one group launch);
+// here they are 3 MB of deltas that are in HBM anyway.
+struct SuperreadArgs {
+	const int32_t* delta;                // [entries]  (n_ind == 1: a column's deltas lie at its entry offset)
+	const unsigned long long* col_ptr;   // [n_cols + 1] entry offsets
+	const uint8_t* genotype;             // [n_cols]
+	const uint32_t* path_index;          // [n_cols]
+	uint32_t* out;                       // [n_cols] qualities, then n_cols bytes haplotype 0, then n_cols bytes haplotype 1
+	uint32_t n_cols, pad;
+};
+constexpr uint8_t SUPERREAD_CONFLICT = 0xFF;
+__device__ __forceinline__ void superreads_column(const SuperreadArgs& a, uint32_t c) {
+	const uint32_t x = a.path_index[c];
+	const unsigned long long off = a.col_ptr[c];
+	const uint32_t k = (uint32_t)(a.col_ptr[c + 1] - off);
+	const int32_t* __restrict__ d = a.delta + off;
+	uint32_t cp[2][2] = {{0u, 0u}, {0u, 0u}};
+	for (uint32_t j = 0; j < k; ++j) {
+		const int32_t v = d[j];
+		const uint32_t ref = v > 0 ? (uint32_t)v : 0u, alt = v < 0 ? (uint32_t)(-v) : 0u;
+		if ((x >> j) & 1u) { cp[1][1] += ref; cp[1][0] += alt; }
+		else { cp[0][1] += ref; cp[0][0] += alt; }
+	}
+	const uint32_t g = a.genotype[c];
+	uint8_t a0, a1;
+	uint32_t quality = 0;
+	if (g == 1u) {
+		const uint32_t cost1 = cp[0][1] + cp[1][0], cost2 = cp[0][0] + cp[1][1];
+		const bool second = cost2 <= cost1;
+		a0 = second ? 0 : 1;
+		a1 = second ? 1 : 0;
+		const int diff = (int)cost1 - (int)cost2;
+		quality = (uint32_t)(diff < 0 ? -diff : diff);
+		if (quality == 0u) a0 = a1 = 3;   // WHAMD_ALLELE_EQUAL_SCORES
+		if ((second ? cost2 : cost1) == 0xFFFFFFFFu) a0 = a1 = SUPERREAD_CONFLICT;
+	} else if (g == 0u || g == 2u) {
+		const uint32_t al = g == 2u ? 1u : 0u;
+		const uint32_t cost = cp[0][al] + cp[1][al];
+		a0 = a1 = (uint8_t)al;
+		const int diff = (int)cost - (int)0xFFFFFFFFu;
+		quality = (uint32_t)(diff < 0 ? -diff : diff);
+		if (quality == 0u) a0 = a1 = 3;
+		if (cost == 0xFFFFFFFFu) a0 = a1 = SUPERREAD_CONFLICT;
+	} else {
+		a0 = a1 = SUPERREAD_CONFLICT;
+	}
+	a.out[c] = quality;
+	uint8_t* h = (uint8_t*)(a.out + a.n_cols);
+	h[c] = a0;
+	h[(size_t)a.n_cols + c] = a1;
+}
+__global__ __launch_bounds__(256) void superreads_single(SuperreadArgs a) {
+	const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+	if (c < a.n_cols) superreads_column(a, c);
+}
+
+// The chunked backtrace of SEVERAL tables in one launch (whamd_dptable_enqueue_many: the tables of a group finish their forward passes together): blockIdx.y
+// selects the table's record, which holds what the single-table launch takes as arguments.  One launch per mode and one gather for the whole group, on the
+// group's stream -- 96 tables used to be 288 launches on 96 streams, each behind a barrier on the group's event.
+struct BtGroupEntry {
+	DevProblem P;
+	const BtUnit* units;
+	const BtChunk* chunks;
+	uint32_t n_chunks, n_units, n_orient_max, n_cols;
+	uint32_t* path2;
+	uint32_t* trans2;
+	uint32_t* out_score;
+	uint32_t* unit_x2;
+	uint32_t* guess;
+	uint8_t* sel;
+	uint32_t* counters;
+	uint32_t* path_index;
+	uint32_t* path_trans;
+	SuperreadArgs super;   // (delta == nullptr: the host makes this table's superreads)
+};
+constexpr int BT_GROUP_MAX = 248;
+struct BtGroupArgs {
+	uint32_t n, pad;
+	const BtGroupEntry* entry[BT_GROUP_MAX];
+};
+__global__ __launch_bounds__(256) void backtrace_chunks_group(BtGroupArgs args, uint32_t mode) {
+	const BtGroupEntry& e = *args.entry[blockIdx.y];
+	if (mode == 0 ? blockIdx.x >= e.n_orient_max * e.n_chunks : blockIdx.x != 0u) return;   // (uniform per block: the whole block leaves)
+	backtrace_chunks_body(e.P, e.units, e.chunks, e.n_chunks, e.n_units, mode, e.n_orient_max, e.path2, e.trans2, e.out_score, e.unit_x2, e.guess, e.sel, e.counters, blockIdx.x);
+}
+__global__ __launch_bounds__(64) void backtrace_gather_group(BtGroupArgs args) {
+	const BtGroupEntry& e = *args.entry[blockIdx.y];
+	const uint32_t u = blockIdx.x;
+	if (u >= e.n_units) return;
+	const uint32_t c0 = e.units[u].c0, ncols = e.units[u].ncols;
+	const uint32_t* __restrict__ src = e.path2 + (size_t)e.sel[u] * e.n_cols;
+	const uint32_t* __restrict__ tsrc = e.trans2 + (size_t)e.sel[u] * e.n_cols;
+	for (uint32_t c = threadIdx.x; c < ncols; c += blockDim.x) {
+		e.path_index[c0 + c] = src[c0 + c];
+		e.path_trans[c0 + c] = tsrc[c0 + c];
+	}
+}
+
+// The superreads of the group's tables (those whose record carries the arrays), behind the gather: blockIdx.y = table.
+__global__ __launch_bounds__(256) void superreads_group(BtGroupArgs args) {
+	const BtGroupEntry& e = *args.entry[blockIdx.y];
+	const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+	if (e.super.delta == nullptr || c >= e.super.n_cols) return;
+	superreads_column(e.super, c);
 }
 
 // Gathers the final index path: unit u's columns from the path buffer the verification selected.

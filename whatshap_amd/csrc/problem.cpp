@@ -1,5 +1,6 @@
 // problem.cpp -- host precompute for the device DP and host post-processing of its result.
 // See problem.h for the map to the reference's classes.
+#include "debug_build.h"
 #include "problem.h"
 
 #include <algorithm>
@@ -494,11 +495,11 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 		return tm;
 	};
 	// lazy generic terms (see column_terms): only where a factorised line exists
-	bool lazy = lazy_fact_terms && (want_fact || want_fact4) && !getenv("WHAMD_EAGER_TERMS");   // (switched off below if a sampled check fails)
+	bool lazy = lazy_fact_terms && (want_fact || want_fact4) && !debug_env("WHAMD_EAGER_TERMS");   // (switched off below if a sampled check fails)
 	auto lazy_sample = [](uint32_t c) { return c < 256u || (c & 63u) == 0u; };
 	p.lazy_terms = false;
 	// (h2p of one individual without a trio: haplotype 0 -> partition 0, haplotype 1 -> partition 1)
-	const bool single_trusted = p.n_ind == 1 && p.T == 1 && p.P == 2 && !distrust && p.h2p.size() >= 2 && p.h2p[0] == 0 && p.h2p[1] == 1 && !getenv("WHAMD_NO_SINGLE_FAST_TERMS");
+	const bool single_trusted = p.n_ind == 1 && p.T == 1 && p.P == 2 && !distrust && p.h2p.size() >= 2 && p.h2p[0] == 0 && p.h2p[1] == 1 && !debug_env("WHAMD_NO_SINGLE_FAST_TERMS");
 	// deltas and cost terms of column c (its entries and indexing scheme are in place); false: Mendelian conflict
 	struct CompatCache {   // per worker: compatible allele assignments by (genotype vector, transmission value)
 		bool enabled = false;
@@ -507,7 +508,7 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 	};
 	auto make_compat = [&]() {
 		CompatCache cc;
-		cc.enabled = !distrust && p.n_ind >= 2 && p.n_ind <= 6 && p.P <= 8 && !getenv("WHAMD_NO_COMPAT_CACHE");
+		cc.enabled = !distrust && p.n_ind >= 2 && p.n_ind <= 6 && p.P <= 8 && !debug_env("WHAMD_NO_COMPAT_CACHE");
 		if (cc.enabled) {
 			const size_t slots = ((size_t)1 << (2 * p.n_ind)) * p.T;
 			cc.known.assign(slots, 0);
@@ -855,7 +856,7 @@ namespace {
 
 whamd_status_t finish_columns(const Problem& p, Solution& s, uint32_t c_begin, uint32_t c_end, std::string& msg) {
 	const uint32_t n = p.n_cols;
-	if (p.n_ind == 1 && p.T == 1 && p.P == 2 && !p.distrust && p.h2p.size() >= 2 && p.h2p[0] == 0 && p.h2p[1] == 1 && !getenv("WHAMD_GENERIC_FINISH")) {
+	if (p.n_ind == 1 && p.T == 1 && p.P == 2 && !p.distrust && p.h2p.size() >= 2 && p.h2p[0] == 0 && p.h2p[1] == 1 && !debug_env("WHAMD_GENERIC_FINISH")) {
 		// ONE individual, genotypes trusted (every table of `whatshap phase` without a pedigree): the loops below written out.  Partition p = side of the read;
 		// cp[p][1] += q for REF, cp[p][0] += q for ALT (set_partitioning, :53-76); the assignments compatible with genotype 0/1 are a = 1 (haplotype 0 carries ALT:
 		// cost cp[0][1] + cp[1][0]) then a = 2 (cost cp[0][0] + cp[1][1]), `<=` lets the later one win a tie (:131); both haplotypes' quality is the absolute
@@ -865,14 +866,19 @@ whamd_status_t finish_columns(const Problem& p, Solution& s, uint32_t c_begin, u
 			const uint32_t x = s.path_index[c];
 			const ColumnEntry* col = p.col_begin(c);
 			const uint32_t kc = p.k[c];
-			uint32_t cp[2][2] = {{0, 0}, {0, 0}};
+			// (no branch on the side or on the allele: both are coin flips per entry, and a mispredicted branch costs more than the whole rest of the
+			//  iteration -- 3.3 ms per coverage-15 table of 50 000 columns with the branches.  acc[side][allele]: REF 0, ALT 1, BLANK 2 is added and ignored;
+			//  the store of a read on side 1 goes to a scratch byte.)
+			uint32_t acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+			uint8_t scratch;
 			for (uint32_t j = 0; j < kc; ++j) {
 				const ColumnEntry& e = col[j];
 				const uint32_t side = (x >> j) & 1u;
-				if (side == 0) __atomic_store_n(&s.partition[e.read_id], (uint8_t)0, __ATOMIC_RELAXED);
-				if (e.allele == WHAMD_ALLELE_REF) cp[side][1] += e.phred;
-				else if (e.allele == WHAMD_ALLELE_ALT) cp[side][0] += e.phred;
+				uint8_t* dst = side ? &scratch : &s.partition[e.read_id];
+				__atomic_store_n(dst, (uint8_t)0, __ATOMIC_RELAXED);
+				acc[side][e.allele & 3u] += e.phred;
 			}
+			const uint32_t cp[2][2] = {{acc[0][WHAMD_ALLELE_ALT], acc[0][WHAMD_ALLELE_REF]}, {acc[1][WHAMD_ALLELE_ALT], acc[1][WHAMD_ALLELE_REF]}};
 			const uint8_t g = p.genotype[c];
 			uint8_t a0, a1;
 			uint32_t quality;
@@ -969,6 +975,23 @@ whamd_status_t finish_columns(const Problem& p, Solution& s, uint32_t c_begin, u
 
 whamd_status_t finish_solution(const Problem& p, Solution& s, std::string& msg) {
 	const uint32_t n = p.n_cols;
+	if (s.superreads_done && p.n_ind == 1 && s.allele0.size() == n && s.allele1.size() == n && s.quality.size() == n) {
+		// The device made the superreads; what is left is get_optimal_partitioning (src/pedigreedptable.cpp:391-406): a read is in partition 0 if its bit of the
+		// index is 0.  The bit of a read is the same in every column it covers (the backtrace carries it from column to column through the projection), so the
+		// column where the read enters decides: its entries are the last k - b of that column.
+		s.partition.assign(p.n_reads, 1);
+		for (uint32_t r = 0; r < p.n_reads; ++r) {
+			const uint32_t c = p.read_first_col[r];
+			if (c >= n) continue;
+			const ColumnEntry* col = p.col_begin(c);
+			const uint32_t kc = p.k[c];
+			uint32_t j = std::min<uint32_t>(p.b[c], kc);
+			while (j < kc && col[j].read_id != r) ++j;
+			if (j == kc) for (j = 0; j < kc && col[j].read_id != r; ++j) {}
+			if (j < kc) s.partition[r] = (uint8_t)((s.path_index[c] >> j) & 1u);
+		}
+		return WHAMD_OK;
+	}
 	s.allele0.assign((size_t)p.n_ind * n, 0);
 	s.allele1.assign((size_t)p.n_ind * n, 0);
 	s.quality.assign((size_t)p.n_ind * n, 0);

@@ -113,6 +113,7 @@ struct Solution {
 	std::vector<uint8_t> allele0, allele1;         // [n_ind * n_cols]
 	std::vector<uint32_t> quality;                 // [n_ind * n_cols]
 	std::vector<uint8_t> partition;                // [n_reads]
+	bool superreads_done = false;                  // allele0 / allele1 / quality came from the device (dp_device.hip: a single individual, trusted genotypes): finish_solution only makes the partition
 };
 whamd_status_t finish_solution(const Problem& p, Solution& s, std::string& msg);
 
