@@ -1142,11 +1142,11 @@ def main():
     else:
         # (workers, threads per create, tables per window): one window of everything keeps the device's launch sequence shortest; two or three windows let the
         # creates of the next one run under the solve of the current one -- what wins depends on the table shape and is measured, not assumed
-        host_shapes = [(16, 2, whole), (len(problems), 2, whole), (len(problems), 4, whole)]
+        host_shapes = [(16, 2, whole), (len(problems), 2, whole), (32, 1, whole)]   # (one worker per table with four threads each lost every time it was tried; 32 x 1 made 96 creates in 73 ms against 92 ms, scripts/gpu_create_rate_ab.py)
         if whole >= 24:
             # ... two or three windows (the creates of the next one under the solve of the current one), and two windows on the device at once: window k + 1
             # is enqueued -- its own stream -- before window k is collected
-            host_shapes += [(16, 2, (whole + 1) // 2), (16, 2, (whole + 2) // 3), (16, 2, (whole + 1) // 2, 2)]
+            host_shapes += [(16, 2, (whole + 1) // 2), (16, 2, (whole + 2) // 3), (16, 2, (whole + 1) // 2, 2), (32, 1, (whole + 1) // 2)]
     host_shapes = list(dict.fromkeys(tuple(h) + (1,) * (4 - len(h)) for h in host_shapes))   # (workers, threads per create, tables per window, windows on the device)
 
     def fresh_step(shape):

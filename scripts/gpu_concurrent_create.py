@@ -6,7 +6,7 @@ if len(sys.argv) > 1 and sys.argv[1] != "--inner":
     print(out.stdout, end="")
     sums, cnt = {}, {}
     for line in out.stderr.splitlines():
-        if "rep 0" in line:
+        if line.strip() == "rep 1":
             sums, cnt = {}, {}     # (the first round sizes the pools)
         for m in re.finditer(r"(flatten|plan \+ upload|plan|descriptors \+ copies|rest|column ranges|layouts|concatenation) ([0-9.]+) ms", line):
             key = ("create: " if line.startswith("[whamd timing] create") else ("upload: " if "upload:" in line else "slot plan: ")) + m.group(1)

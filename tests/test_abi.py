@@ -138,7 +138,7 @@ def test_the_product_library_carries_no_debug_code():
     assert "whamd_debug" not in exported
     blob = open(_native.LIB_PATH, "rb").read()
     for marker in (b"WHAMD_SLOT_SKIP", b"WHAMD_SLOT_STAMPS", b"WHAMD_DEBUG_STAMPS", b"WHAMD_NO_YFORM", b"WHAMD_GROUP_PARTS", b"WHAMD_EAGER_TERMS", b"WHAMD_GENERIC_FINISH",
-                   b"WHAMD_NO_COMPAT_CACHE", b"WHAMD_HOST_SUPERREADS", b"WHAMD_TAIL_OWN_STREAM", b"WHAMD_NO_GROUP_BACKTRACE", b"WHAMD_SYNC_UPLOAD", b"WHAMD_DENSE_COLUMN_UPLOAD", b"WHAMD_NO_WIDE_LAYOUT", b"WHAMD_NO_UPLOAD_SLAB"):
+                   b"WHAMD_NO_COMPAT_CACHE", b"WHAMD_HOST_SUPERREADS", b"WHAMD_UPLOAD_ON_TABLE_STREAM", b"WHAMD_TAIL_OWN_STREAM", b"WHAMD_NO_GROUP_BACKTRACE", b"WHAMD_SYNC_UPLOAD", b"WHAMD_DENSE_COLUMN_UPLOAD", b"WHAMD_NO_WIDE_LAYOUT", b"WHAMD_NO_UPLOAD_SLAB"):
         assert marker not in blob, marker
     debug = subprocess.run(["nm", "-D", "--defined-only", _native.DEBUG_LIB_PATH], capture_output=True, text=True, check=True).stdout
     for name in ("whamd_debug_emulate_slot_plan", "whamd_debug_emulate_pedslot_plan", "whamd_debug_pedmec_heuristic_create_host"):
@@ -186,3 +186,16 @@ def test_concurrent_creates_share_the_worker_pool():
         with ThreadPoolExecutor(max_workers=8) as pool:
             together = list(pool.map(_native.plan_summary, problems))
         assert together == alone
+
+
+def test_the_library_is_loaded_once_when_many_threads_ask_first():
+    """blocks.solve_blocks' create workers may be the first callers of _native.lib(): sixteen of them at once must get ONE CDLL object (two objects made
+    enqueue_many refuse their tables as "of the product and of the debug library")."""
+    import subprocess, sys
+    code = ("import threading\nfrom whatshap_amd import _native\nout = []\nbarrier = threading.Barrier(16)\n"
+            "def ask():\n    barrier.wait()\n    out.append(id(_native.lib()))\n"
+            "ts = [threading.Thread(target=ask) for _ in range(16)]\n[t.start() for t in ts]\n[t.join() for t in ts]\nprint(len(set(out)))\n")
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, check=True).stdout.strip()
+    assert got == "1"

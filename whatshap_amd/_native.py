@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from typing import Optional, Sequence
 
 import numpy as np
@@ -225,6 +226,7 @@ class ProblemArrays:
 
 _lib = None
 _debug_lib = None
+_load_lock = threading.Lock()   # (the first call may come from several threads at once -- blocks.solve_blocks' create workers: ONE CDLL object per library)
 
 
 def lib() -> C.CDLL:
@@ -232,13 +234,16 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise ImportError(
-            f"{LIB_PATH} is missing: build the HIP extension first "
-            "(python -c 'import __graft_entry__ as g; g.build()' or make -C whatshap_amd/csrc). "
-            "whatshap_amd has no CPU fallback."
-        )
-    _lib = _bind(C.CDLL(LIB_PATH), LIB_PATH)
+    with _load_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()' or make -C whatshap_amd/csrc). "
+                "whatshap_amd has no CPU fallback."
+            )
+        _lib = _bind(C.CDLL(LIB_PATH), LIB_PATH)
     return _lib
 
 

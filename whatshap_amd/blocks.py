@@ -218,6 +218,7 @@ def solve_blocks(problems: Sequence[ProblemArrays], device: int = 0, path=None, 
                             pass
             for f in releases:
                 f.result()
+            mark("released", len(windows))
         return tables
 
     import threading

@@ -135,6 +135,35 @@ void streamset_give(const StreamSet& ss) {   // (the stream is idle: the caller 
 	for (hipEvent_t e : ss.ev) if (e) (void)hipEventDestroy(e);
 	(void)hipStreamDestroy(ss.stream);
 }
+// The streams the UPLOADS of all tables of a device go through: four, of the highest priority the device offers, shared.  A table's own stream carries its solve;
+// the runtime maps streams of one priority onto a few hardware queues, and an upload that shared its queue with a group solve -- 2 300 dependent launches -- completed
+// only when the solve had drained: the staging areas came back late and 96 creates under a running solve took 153 - 180 ms instead of 88 - 129 ms
+// (scripts/gpu_create_under_solve.py).  Streams of another priority have hardware queues of their own.
+struct UploadStreams {
+	std::mutex mu;
+	std::vector<std::pair<int, hipStream_t>> streams;   // (device, stream); never destroyed: they live as long as the process
+	std::atomic<uint32_t> next{0};
+};
+UploadStreams g_upload_streams;
+constexpr uint32_t UPLOAD_STREAMS = 4;
+hipStream_t upload_stream_of(int device) {
+	const uint32_t slot = g_upload_streams.next.fetch_add(1, std::memory_order_relaxed) % UPLOAD_STREAMS;
+	std::lock_guard<std::mutex> lock(g_upload_streams.mu);
+	uint32_t seen = 0;
+	for (const auto& e : g_upload_streams.streams)
+		if (e.first == device && seen++ == slot) return e.second;
+	hipStream_t made = nullptr;
+	while (seen <= slot) {
+		int least = 0, greatest = 0;
+		(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+		hipStream_t st = nullptr;
+		if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+		g_upload_streams.streams.emplace_back(device, st);
+		made = st;
+		++seen;
+	}
+	return made;
+}
 hipError_t pinned_take(size_t bytes, void** out, size_t* got) {
 	const size_t want = pool_class(bytes);
 	*got = want;
@@ -558,6 +587,8 @@ struct DeviceTable::Impl {
 	bool device_superreads = false;
 	SuperreadArgs super_args{};
 	size_t super_words = 0, super_off = 0;   // size of the result (u32 words) and where it lies in h_pinned
+	bool upload_pending = false;        // the uploads went through a shared upload stream and no solve has been ordered behind `ev_upload` yet
+	hipStream_t upload_stream = nullptr;
 	bool timing_pending = false;        // wait() has collected a solve whose event timings nobody has read yet (read_timing)
 	hipStream_t tail_stream = nullptr;  // where submit_tail put the tail of the solve in flight, and its place in the order of all tails of the process
 	uint64_t tail_seq = 0;
@@ -576,6 +607,8 @@ struct DeviceTable::Impl {
 	void release() {
 		if (tail_elsewhere && ev3) (void)hipEventSynchronize(ev3);   // (a solve whose tail ran on the group's lead stream: nothing of it may still be reading the buffers)
 		tail_elsewhere = false;
+		if (upload_pending && ev_upload) (void)hipEventSynchronize(ev_upload);   // (a table closed without a solve: its copies may still be on the upload stream)
+		upload_pending = false;
 		release_lanes();
 		windowed = false;
 		if (stream && (!allocations.empty() || d_arena)) (void)hipStreamSynchronize(stream);   // (hipFree used to wait for the table's last kernels)
@@ -892,7 +925,12 @@ whamd_status_t DeviceTable::upload(Problem& p, int device, std::string& msg) {
 		return WHAMD_ERR_UNSUPPORTED;
 	}
 	// ---- allocate + upload
-	StageSession stage(m.stream);
+	// Everything this function sends or launches goes through one of the device's upload streams (upload_stream_of); begin_solve orders the solve behind ev_upload.
+	// WHAMD_UPLOAD_ON_TABLE_STREAM=1 (debug library): the table's own stream, as before.
+	hipStream_t us = debug_env("WHAMD_UPLOAD_ON_TABLE_STREAM") ? nullptr : upload_stream_of(device);
+	if (!us) us = m.stream;
+	m.upload_stream = us;
+	StageSession stage(us);
 	auto alloc = [&](void** dptr, size_t bytes) -> hipError_t {
 		size_t got = 0;
 		hipError_t e = devpool_take(device, std::max<size_t>(bytes, 16), dptr, &got);
@@ -924,10 +962,11 @@ whamd_status_t DeviceTable::upload(Problem& p, int device, std::string& msg) {
 		else { (void)hipGetLastError(); stage.image = false; }
 	}
 	bool unstaged_copies = false;   // a copy whose source is pageable memory of this call: the create must wait for it
-	const hipStream_t copy_stream = m.stream;   // (all tables' images on ONE shared stream instead of sixteen at once was measured: 1 055 - 1 273 against 1 015 - 1 153 creates/s, noise)
+	const hipStream_t copy_stream = us;   // (all tables' images on ONE shared stream instead of sixteen at once was measured: 1 055 - 1 273 against 1 015 - 1 153 creates/s, noise)
 	auto flush_slab = [&]() -> hipError_t {
 		if (!d_slab || slab_used == slab_flushed) return hipSuccess;
-		const hipError_t e = hipMemcpyAsync(d_slab + slab_flushed, stage.base + slab_flushed, slab_used - slab_flushed, hipMemcpyHostToDevice, copy_stream);
+		// (WHAMD_SKIP_SLAB_COPY=1, debug library, RESULTS INVALID: the image is built but does not travel -- what the creates cost without the link)
+		const hipError_t e = debug_env("WHAMD_SKIP_SLAB_COPY") ? hipSuccess : hipMemcpyAsync(d_slab + slab_flushed, stage.base + slab_flushed, slab_used - slab_flushed, hipMemcpyHostToDevice, copy_stream);
 		stage.pending = true;
 		slab_flushed = slab_used;
 		return e;
@@ -990,7 +1029,7 @@ whamd_status_t DeviceTable::upload(Problem& p, int device, std::string& msg) {
 			} else {
 				unstaged_copies = true;   // (straight from the caller's pageable memory: upload() ends with a host wait)
 			}
-			hipError_t e = hipMemcpyAsync((char*)*dptr + pc.first, from, pc.second - pc.first, hipMemcpyHostToDevice, m.stream);
+			hipError_t e = hipMemcpyAsync((char*)*dptr + pc.first, from, pc.second - pc.first, hipMemcpyHostToDevice, us);
 			if (e != hipSuccess) return e;
 		}
 		return hipSuccess;
@@ -1536,7 +1575,7 @@ whamd_status_t DeviceTable::upload(Problem& p, int device, std::string& msg) {
 		const uint32_t bx = std::max(1u, std::min(1024u, (most + 255u) / 256u));
 		for (size_t r0 = 0; r0 < m.splan.runs.size(); r0 += 32768) {   // (gridDim.y <= 65535)
 			const uint32_t ny = (uint32_t)std::min<size_t>(32768, m.splan.runs.size() - r0);
-			hipLaunchKernelGGL(pedslot_tables, dim3(bx, ny), dim3(256), 0, m.stream, m.dp, (const SlotRun*)d_pruns + r0, (const PedSlotExtra*)d_pextra + r0, (uint32_t*)d_ptab,
+			hipLaunchKernelGGL(pedslot_tables, dim3(bx, ny), dim3(256), 0, us, m.dp, (const SlotRun*)d_pruns + r0, (const PedSlotExtra*)d_pextra + r0, (uint32_t*)d_ptab,
 			                   (const DevTerm*)d_fterms);
 		}
 		HIP_TRY(hipGetLastError());
@@ -1547,16 +1586,17 @@ whamd_status_t DeviceTable::upload(Problem& p, int device, std::string& msg) {
 		const uint32_t bx = std::max(1u, std::min(64u, (most + 255u) / 256u));
 		for (size_t r0 = 0; r0 < m.splan.runs.size(); r0 += 32768) {
 			const uint32_t ny = (uint32_t)std::min<size_t>(32768, m.splan.runs.size() - r0);
-			hipLaunchKernelGGL(slot_tables, dim3(bx, ny), dim3(256), 0, m.stream, m.dp, (const SlotRun*)d_sruns + r0, (uint32_t*)d_stab);
+			hipLaunchKernelGGL(slot_tables, dim3(bx, ny), dim3(256), 0, us, m.dp, (const SlotRun*)d_sruns + r0, (uint32_t*)d_stab);
 		}
 		HIP_TRY(hipGetLastError());
 	}
 	// No host wait: the solve is ordered behind `ev_upload` on the device (begin_solve) and the staging area behind its own event (StageSession::park) -- a create
 	// used to end with hipStreamSynchronize: 1.5 - 2 ms of copy tail and table kernel for configs[2], and under many concurrent creates every worker thread sat in
 	// the queue of the others' copies (half of a create's wall time at 16 workers).  WHAMD_SYNC_UPLOAD=1 (debug library) restores the wait.
-	HIP_TRY(hipEventRecord(m.ev_upload, m.stream));
+	HIP_TRY(hipEventRecord(m.ev_upload, us));
+	m.upload_pending = true;
 	if (debug_env("WHAMD_SYNC_UPLOAD") || unstaged_copies || !stage.image || !stage.park()) {
-		HIP_TRY(hipStreamSynchronize(m.stream));
+		HIP_TRY(hipStreamSynchronize(us));
 		stage.finish();
 	}
 	m.dp.delta = (const int32_t*)d_delta;
@@ -1692,8 +1732,8 @@ whamd_status_t DeviceTable::upload(Problem& p, int device, std::string& msg) {
 		if (m.device_superreads) e.super = m.super_args;
 		void* d_entry = nullptr;
 		HIP_TRY(alloc(&d_entry, sizeof(BtGroupEntry)));
-		HIP_TRY(hipMemcpyAsync(d_entry, &m.h_bt_entry, sizeof(BtGroupEntry), hipMemcpyHostToDevice, m.stream));   // (the source is a member: it outlives the copy)
-		HIP_TRY(hipEventRecord(m.ev_upload, m.stream));
+		HIP_TRY(hipMemcpyAsync(d_entry, &m.h_bt_entry, sizeof(BtGroupEntry), hipMemcpyHostToDevice, us));   // (the source is a member: it outlives the copy)
+		HIP_TRY(hipEventRecord(m.ev_upload, us));
 		m.d_bt_entry = (BtGroupEntry*)d_entry;
 	}
 	return WHAMD_OK;
@@ -1893,7 +1933,7 @@ whamd_status_t DeviceTable::Impl::begin_solve(const Problem& p, Solution& s, std
 	m.launches = 0;
 	m.next_super = 0;
 	if (n == 0) return WHAMD_OK;
-	if (m.ev_upload && m.run_stream != m.stream) HIP_TRY(hipStreamWaitEvent(m.run_stream, m.ev_upload, 0));   // (the same stream is ordered by itself)
+	if (m.ev_upload && (m.upload_pending || m.run_stream != m.stream)) HIP_TRY(hipStreamWaitEvent(m.run_stream, m.ev_upload, 0));   // (the uploads went through an upload stream; once a solve has been collected they are known to be there)
 	for (const Impl::Lane& lane : m.lanes) HIP_TRY(hipMemsetAsync(lane.d_keys, 0xFF, m.key_entries * 8, m.run_stream));
 	HIP_TRY(hipMemsetAsync(m.dp.last_keys, 0xFF, (size_t)MAX_T_WIDE * 8, m.run_stream));
 	if (m.use_chunks) HIP_TRY(hipMemsetAsync(m.dp.spec_keys, 0xFF, ((size_t)m.n_spec + 1) * m.dp.spec_stride * 8, m.run_stream));
@@ -2275,6 +2315,7 @@ whamd_status_t DeviceTable::wait(const Problem& p, Solution& s, whamd_solve_stat
 	const uint64_t launches = m.launches;
 	if (m.tail_elsewhere) HIP_TRY(hipEventSynchronize(m.ev3));   // (the last thing submit_tail recorded, on the stream the tail went to)
 	else HIP_TRY(hipStreamSynchronize(m.stream));
+	m.upload_pending = false;   // (the solve ran behind ev_upload: the uploads are there)
 	const uint32_t n = p.n_cols;
 	std::memcpy(s.path_index.data(), m.h_pinned, (size_t)n * 4);
 	std::memcpy(s.path_trans.data(), m.h_pinned + n, (size_t)n * 4);
