@@ -9,9 +9,13 @@ from whatshap_amd.synthetic import synthetic_block
 if os.environ.get("WHAMD_USE_DEBUG_LIB"):
     _native.use_debug_library()
 k, n, cov = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (96, 50000, 15)
-bind_rank_to_device_cpus(0, 1, devices=[0])
+if not os.environ.get("WHAMD_NO_BIND"):   # (WHAMD_NO_BIND=1: both sockets -- twice the memory channels)
+    bind_rank_to_device_cpus(0, 1, devices=[0])
 problems = [synthetic_block(n, cov, seed=100 + i) for i in range(k)]
-for workers, per in ((16, 2), (32, 2), (32, 1), (64, 1), (96, 1), (8, 4)):
+shapes = ((16, 2), (32, 2), (32, 1), (64, 1), (96, 1), (8, 4))
+if os.environ.get("WHAMD_RATE_SHAPES"):   # e.g. "32x1,16x2"
+    shapes = tuple(tuple(int(v) for v in item.split("x")) for item in os.environ["WHAMD_RATE_SHAPES"].split(","))
+for workers, per in shapes:
     opts = {"shared_launches": "1", "host_threads": str(per)}
     walls = []
     for rep in range(4):

@@ -229,7 +229,7 @@ struct ArenaCache {
 	std::vector<Block> blocks;
 };
 ArenaCache g_arena;
-constexpr size_t ARENA_BLOCKS = 32;
+constexpr size_t ARENA_BLOCKS = 512;   // (32 until round 6: the 96 tables of one step kept 32 arenas and hipFree-d 64 -- 13 ms of their releases -- and the next step allocated them again; the bytes are bounded separately, arena_give)
 size_t arena_idle_bytes(int device) {
 	std::lock_guard<std::mutex> lock(g_arena.mu);
 	size_t sum = 0;
@@ -587,6 +587,8 @@ struct DeviceTable::Impl {
 	bool device_superreads = false;
 	SuperreadArgs super_args{};
 	size_t super_words = 0, super_off = 0;   // size of the result (u32 words) and where it lies in h_pinned
+	bool own_stream_used = false;       // something has been submitted to `stream` since it was last synchronised (a member of a group solve never touches its own: its
+	                                    // solve and tail are on the lead's stream, its uploads on an upload stream -- release() then has nothing to wait for there)
 	bool upload_pending = false;        // the uploads went through a shared upload stream and no solve has been ordered behind `ev_upload` yet
 	hipStream_t upload_stream = nullptr;
 	bool timing_pending = false;        // wait() has collected a solve whose event timings nobody has read yet (read_timing)
@@ -611,7 +613,7 @@ struct DeviceTable::Impl {
 		upload_pending = false;
 		release_lanes();
 		windowed = false;
-		if (stream && (!allocations.empty() || d_arena)) (void)hipStreamSynchronize(stream);   // (hipFree used to wait for the table's last kernels)
+		if (stream && own_stream_used && (!allocations.empty() || d_arena)) { (void)hipStreamSynchronize(stream); own_stream_used = false; }   // (hipFree used to wait for the table's last kernels)
 		for (auto& a : allocations) devpool_give(device, a.first, a.second);
 		allocations.clear();
 		arena_give(device, d_arena, arena_bytes);
@@ -640,7 +642,8 @@ void DeviceTable::release_device() {
 	(void)hipSetDevice(m.device);
 	m.release();   // (synchronises the stream before anything is handed back)
 	if (m.stream) {
-		(void)hipStreamSynchronize(m.stream);
+		if (m.own_stream_used) (void)hipStreamSynchronize(m.stream);   // (13 ms for the 96 tables of a step when every table waited for a stream it had never used)
+		m.own_stream_used = false;
 		StreamSet ss;
 		ss.stream = m.stream; ss.ev[0] = m.ev0; ss.ev[1] = m.ev1; ss.ev[2] = m.ev2; ss.ev[3] = m.ev3; ss.ev[4] = m.ev_group; ss.ev[5] = m.ev_upload; ss.device = m.device;
 		streamset_give(ss);
@@ -930,6 +933,7 @@ whamd_status_t DeviceTable::upload(Problem& p, int device, std::string& msg) {
 	hipStream_t us = debug_env("WHAMD_UPLOAD_ON_TABLE_STREAM") ? nullptr : upload_stream_of(device);
 	if (!us) us = m.stream;
 	m.upload_stream = us;
+	if (us == m.stream) m.own_stream_used = true;
 	StageSession stage(us);
 	auto alloc = [&](void** dptr, size_t bytes) -> hipError_t {
 		size_t got = 0;
@@ -1933,6 +1937,7 @@ whamd_status_t DeviceTable::Impl::begin_solve(const Problem& p, Solution& s, std
 	m.launches = 0;
 	m.next_super = 0;
 	if (n == 0) return WHAMD_OK;
+	if (m.run_stream == m.stream) m.own_stream_used = true;
 	if (m.ev_upload && (m.upload_pending || m.run_stream != m.stream)) HIP_TRY(hipStreamWaitEvent(m.run_stream, m.ev_upload, 0));   // (the uploads went through an upload stream; once a solve has been collected they are known to be there)
 	for (const Impl::Lane& lane : m.lanes) HIP_TRY(hipMemsetAsync(lane.d_keys, 0xFF, m.key_entries * 8, m.run_stream));
 	HIP_TRY(hipMemsetAsync(m.dp.last_keys, 0xFF, (size_t)MAX_T_WIDE * 8, m.run_stream));
@@ -1968,6 +1973,7 @@ whamd_status_t DeviceTable::Impl::submit_tail(const Problem& p, std::string& msg
 	Impl& m = *this;
 	const hipStream_t ts = tail_stream ? tail_stream : m.stream;
 	m.tail_elsewhere = ts != m.stream;
+	if (ts == m.stream) m.own_stream_used = true;
 	m.tail_stream = ts;
 	{
 		static std::atomic<uint64_t> seq{0};
@@ -2260,6 +2266,7 @@ whamd_status_t DeviceTable::enqueue_group(DeviceTable* const* tables, const Prob
 			// (hardware queues that hold only a barrier are rescheduled late; more queues, GPU_MAX_HW_QUEUES=16, made every step 180 ms).  WHAMD_TAIL_OWN_STREAM=1
 			// (debug library) restores the old placement.
 			const bool own = debug_env("WHAMD_TAIL_OWN_STREAM") != nullptr;
+			if (own) m.own_stream_used = true;
 			if (own && m.stream != part.lead->stream && hipStreamWaitEvent(m.stream, part.lead->ev_group, 0) != hipSuccess) { msg = "hipStreamWaitEvent failed"; st = WHAMD_ERR_DEVICE; }
 			if (st == WHAMD_OK) st = m.submit_tail(*problems[i], msg, own ? nullptr : part.lead->stream, walked[i] != 0, walked[i] != 0);
 			if (st != WHAMD_OK) { abort_all(); return st; }
@@ -2314,7 +2321,7 @@ whamd_status_t DeviceTable::wait(const Problem& p, Solution& s, whamd_solve_stat
 	HIP_TRY(hipSetDevice(m.device));
 	const uint64_t launches = m.launches;
 	if (m.tail_elsewhere) HIP_TRY(hipEventSynchronize(m.ev3));   // (the last thing submit_tail recorded, on the stream the tail went to)
-	else HIP_TRY(hipStreamSynchronize(m.stream));
+	else { HIP_TRY(hipStreamSynchronize(m.stream)); m.own_stream_used = false; }
 	m.upload_pending = false;   // (the solve ran behind ev_upload: the uploads are there)
 	const uint32_t n = p.n_cols;
 	std::memcpy(s.path_index.data(), m.h_pinned, (size_t)n * 4);
