@@ -769,7 +769,7 @@ def create_rate_worker(args):
     r, _, n = args.create_rate_worker.partition("/")
     visible = max(_native.device_count(), 1)
     binding = bind_rank_to_device_cpus(int(r), int(n), devices=[i % visible for i in range(int(n))], spread_nodes=visible < int(n))
-    n_cpus = len(os.sched_getaffinity(0))
+    n_cpus = min(len(os.sched_getaffinity(0)), int(binding.get("cpu_budget") or 1 << 30))   # (the slice, capped by the rank's share of the control group's CPU quota)
     n_tables = args.blocks or 1
     problems = [build_block(args, CONFIG4_SEED0 + i, args.variants or CONFIG4_VARIANTS) for i in range(n_tables)]
     native_path = None if args.path == "auto" else args.path
@@ -1132,21 +1132,30 @@ def main():
     from whatshap_amd.blocks import solve_blocks
 
     n_cpus = len(os.sched_getaffinity(0))
+    from whatshap_amd.blocks import cpu_quota, host_cpu_budget
+    quota = cpu_quota()
+    budget = host_cpu_budget(n_cpus, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))) if world > 1 else 1, quota)   # threads this rank can keep busy: its CPU slice, capped by its share of the control group's quota
     whole = min(args.in_flight, len(problems))
     if len(problems) == 1:
         host_shapes = [(1, 0, 1, 1)]
     elif world > 1:
         # a rank's CPU slice (32 hardware threads of the box at N = 8) over its tables: few large tables (configs[4] at N = 8: three per rank) get many threads each
         workers = max(1, min(len(problems), n_cpus))
-        host_shapes = [(workers, max(2, min(32, n_cpus // workers)), whole), (max(1, min(len(problems), n_cpus // 2)), 2, whole), (max(1, min(len(problems), n_cpus // 4)), 4, whole)]
+        host_shapes = [(workers, max(1, min(32, n_cpus // workers)), whole), (max(1, min(len(problems), n_cpus // 2)), 2, whole), (max(1, min(len(problems), n_cpus // 4)), 4, whole)]
     else:
         # (workers, threads per create, tables per window): one window of everything keeps the device's launch sequence shortest; two or three windows let the
-        # creates of the next one run under the solve of the current one -- what wins depends on the table shape and is measured, not assumed
-        host_shapes = [(16, 2, whole), (len(problems), 2, whole), (32, 1, whole)]   # (one worker per table with four threads each lost every time it was tried; 32 x 1 made 96 creates in 73 ms against 92 ms, scripts/gpu_create_rate_ab.py)
+        # creates of the next one run under the solve of the current one -- what wins depends on the table shape and is measured, not assumed.  The busy threads of
+        # the default shape are the rank's CPU budget: more than the control group's quota and the whole process is frozen for the rest of every period
+        # (blocks.cpu_quota: 16 CPUs on the boxes this was measured on -- 16 workers x 2 threads, the default until then, was twice the budget)
+        # default: a burst (16 workers x 2 threads); one single-threaded worker per CPU of the control group's quota (paced: never frozen) is tried beside it
+        w1 = max(1, min(len(problems), budget))
+        burst, paced = (max(1, min(16, len(problems))), 2, whole), (w1, 1, whole)
+        host_shapes = [burst, paced]
+        host_shapes += [(max(1, min(len(problems), 32)), 1, whole)]
         if whole >= 24:
-            # ... two or three windows (the creates of the next one under the solve of the current one), and two windows on the device at once: window k + 1
-            # is enqueued -- its own stream -- before window k is collected
-            host_shapes += [(16, 2, (whole + 1) // 2), (16, 2, (whole + 2) // 3), (16, 2, (whole + 1) // 2, 2), (32, 1, (whole + 1) // 2)]
+            # ... two or three windows, and two windows on the device at once: window k + 1 is enqueued -- its own stream -- before window k is collected
+            first = host_shapes[0]
+            host_shapes += [(first[0], first[1], (whole + 1) // 2), (first[0], first[1], (whole + 2) // 3), (first[0], first[1], (whole + 1) // 2, 2)]
     host_shapes = list(dict.fromkeys(tuple(h) + (1,) * (4 - len(h)) for h in host_shapes))   # (workers, threads per create, tables per window, windows on the device)
 
     def fresh_step(shape):
@@ -1218,7 +1227,7 @@ def main():
 
     per_rank = {"rank": rank, "device": device, "tables": len(problems), "create_ms": med("create_ms"), "solve_ms": med("solve_ms"), "close_ms": med("close_ms"), "other_ms": med("other_ms"),
                 "step_ms": med("wall_ms"), "resident_step_ms": sorted(resident_step_s)[len(resident_step_s) // 2] * 1e3,
-                "cpus": (cpu_binding or {}).get("n_cpus", n_cpus), "numa_node": (cpu_binding or {}).get("node"), "cpu_source": (cpu_binding or {}).get("source", "unbound"),
+                "cpus": (cpu_binding or {}).get("n_cpus", n_cpus), "cpu_quota": quota, "cpu_budget": budget, "numa_node": (cpu_binding or {}).get("node"), "cpu_source": (cpu_binding or {}).get("source", "unbound"),
                 "create_threads": shape[0], "host_threads_per_create": shape[1], "tables_per_window": shape[2], "windows_on_device": shape[3]}
     per_rank_checksums = [int(totals[2])]
     # what a SCALE record can be audited with: which rank ran which blocks on which device, and for how long

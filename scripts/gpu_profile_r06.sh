@@ -24,6 +24,13 @@ python scripts/gpu_wide_ab.py 4000 > $OUT/wide_tables_ab.txt 2>&1
 hipcc --offload-arch=gfx950 -O3 -o /tmp/r6pb scripts/micro/r6_persistent_barrier.hip && timeout 120 /tmp/r6pb > $OUT/persistent_barrier_probe.txt 2>&1
 python scripts/micro/r6_h2d_rate.py > $OUT/h2d_rate.txt 2>&1
 python scripts/gpu_shim_e2e.py 200000 20 > $OUT/shim_config2_pieces.txt 2>&1
+# the round's late probes: what bounds concurrent creates (the same rate with the staging image not sent), creates under a running solve (upload streams against the
+# tables' own streams), the pieces of a resident 96-table step, the time line of a fresh 96-table step
+{ echo "== product library"; python scripts/gpu_create_rate_ab.py; echo "== staging image built, not sent (debug library, WHAMD_SKIP_SLAB_COPY=1: results invalid)"; WHAMD_USE_DEBUG_LIB=1 WHAMD_SKIP_SLAB_COPY=1 python scripts/gpu_create_rate_ab.py; echo "== product library, process not bound to one socket"; WHAMD_NO_BIND=1 WHAMD_RATE_SHAPES=32x1,64x1,96x1 python scripts/gpu_create_rate_ab.py; } > $OUT/create_rate_ab.txt 2>&1
+{ echo "== upload streams (product)"; python scripts/gpu_create_under_solve.py; echo "== the tables' own streams (debug library, WHAMD_UPLOAD_ON_TABLE_STREAM=1)"; WHAMD_USE_DEBUG_LIB=1 WHAMD_UPLOAD_ON_TABLE_STREAM=1 python scripts/gpu_create_under_solve.py; } > $OUT/create_under_solve.txt 2>&1
+WHAMD_DEBUG_TIMING=1 python scripts/gpu_group_step_pieces.py 96 15 50000 2>&1 | grep "^rep\|wait_many of" > $OUT/group_step_pieces_96.txt
+WHAMD_E2E_WINDOWS=96,48,32 python scripts/gpu_e2e_trace.py 96 50000 15 > $OUT/fresh_step_trace_96.txt 2>&1
+python scripts/gpu_close_timing.py 50000 15 96 2>/dev/null > $OUT/release_and_close_96.txt
 cd /tmp && export TMPDIR=/tmp
 for w in ${WHAMD_PROFILE_SET:-config2 config1 blocks24 config1_x96 config3_x8 irregular irregular_x24 config_cov23 config3}; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$w -o p -- python $REPO/bench.py --workload $w --sub --steps 3 --warmup 1 --pmc off --cpu-baseline-columns 0 --configs off > $OUT/trace_$w.log 2>&1

@@ -213,3 +213,45 @@ def test_binding_applies_in_a_child_process_and_sizes_the_library_workers():
     assert res.returncode == 0, res.stderr
     before, after, applied, same = res.stdout.split()
     assert applied == "True" and same == "True" and int(after) == max(1, int(before) // 4)
+
+
+def test_cpu_quota_of_the_control_group_caps_the_thread_budget(tmp_path):
+    """blocks.cpu_quota reads cgroup v2 ``cpu.max`` (at the mount and in the group's own directory) and v1 ``cpu.cfs_quota_us``; host_cpu_budget caps a rank's
+    threads by its share.  (The MI355X boxes: 256 CPUs in the mask, a quota of 16 -- thirty-two busy threads froze the process for half of every period.)"""
+    from whatshap_amd import blocks
+
+    root = tmp_path / "cg"
+    (root / "process_api" / "x").mkdir(parents=True)
+    self_cgroup = tmp_path / "self"
+    self_cgroup.write_text("0::/process_api/x\n")
+    assert blocks.cpu_quota(str(root), str(self_cgroup)) == 0.0            # nothing to read: unlimited
+    (root / "cpu.max").write_text("max 100000\n")
+    assert blocks.cpu_quota(str(root), str(self_cgroup)) == 0.0
+    (root / "cpu.max").write_text("1600000 100000\n")
+    assert blocks.cpu_quota(str(root), str(self_cgroup)) == 16.0
+    (root / "process_api" / "x" / "cpu.max").write_text("400000 100000\n")   # the group's own, tighter
+    assert blocks.cpu_quota(str(root), str(self_cgroup)) == 4.0
+    v1 = tmp_path / "v1"
+    (v1 / "cpu").mkdir(parents=True)
+    (v1 / "cpu" / "cpu.cfs_quota_us").write_text("250000\n")
+    (v1 / "cpu" / "cpu.cfs_period_us").write_text("100000\n")
+    assert blocks.cpu_quota(str(v1), str(tmp_path / "missing")) == 2.5
+    (v1 / "cpu" / "cpu.cfs_quota_us").write_text("-1\n")
+    assert blocks.cpu_quota(str(v1), str(tmp_path / "missing")) == 0.0
+    assert blocks.host_cpu_budget(128, 1, 16.0) == 16
+    assert blocks.host_cpu_budget(32, 8, 16.0) == 2
+    assert blocks.host_cpu_budget(32, 8, 4.0) == 1      # never zero
+    assert blocks.host_cpu_budget(32, 8, 0.0) == 32     # no quota: the slice
+    assert blocks.host_cpu_budget(8, 1, 16.0) == 8
+
+
+def test_the_library_sizes_its_workers_by_WHAMD_HOST_CPUS():
+    """usable_cpus() (csrc/host_parallel.h) = affinity mask, capped by the control group's quota and by WHAMD_HOST_CPUS (what bind_rank_to_device_cpus exports
+    for a rank's share): observed through the pool of host workers -- a parallel flatten of a table must still give the same plan with ONE usable CPU."""
+    import os, subprocess, sys
+    code = ("import os\nos.environ['WHAMD_HOST_CPUS'] = '1'\nfrom whatshap_amd import _native\nfrom whatshap_amd.synthetic import synthetic_block\n"
+            "p = synthetic_block(30000, 12, seed=3)\nprint(_native.plan_summary(p)['n_steps'])\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    one = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, check=True).stdout.strip()
+    many = subprocess.run([sys.executable, "-c", code.replace("os.environ['WHAMD_HOST_CPUS'] = '1'\n", "")], capture_output=True, text=True, cwd=root, check=True).stdout.strip()
+    assert one == many and int(one) > 0

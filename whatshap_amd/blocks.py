@@ -97,8 +97,8 @@ def split_independent_blocks(problem: ProblemArrays) -> List[Tuple[ProblemArrays
 
 
 def solve_blocks(problems: Sequence[ProblemArrays], device: int = 0, path=None, max_in_flight: int = 8,
-                 release: bool = True, devices: Sequence[int] = None, weights: Sequence[float] = None, create_threads: int = 16,
-                 windows_on_device: int = 1, trace: list = None, eager_create: bool = False, host_threads_per_create: int = 2):
+                 release: bool = True, devices: Sequence[int] = None, weights: Sequence[float] = None, create_threads: int = None,
+                 windows_on_device: int = 1, trace: list = None, eager_create: bool = False, host_threads_per_create: int = None):
     """Host-side work queue (BASELINE north_star: "independent phasing blocks shard across the GPUs of one node via a
     host-side work queue"; scheduling precedent: whatshap/polyphase/algorithm.py:101-128).
 
@@ -110,7 +110,7 @@ def solve_blocks(problems: Sequence[ProblemArrays], device: int = 0, path=None, 
     24 coverage-15 tables) and gain nothing on a 32-thread host: a window costs about 35 ms from enqueue to collect whatever its size
     (the length of the launch sequence) and the creates are bound by the host's cores (24 of them: 35 ms), so one window of
     everything is the fastest schedule there.  ``create_threads`` x ``host_threads_per_create`` is the host parallelism of the creates (16 x 2 by
-    default; bench.py also tries one worker per table with four threads each and reports what it used).  ``trace``: a list that receives
+    default, less where the process's CPU budget -- ``host_cpu_budget`` -- is smaller; bench.py also tries one worker per table with four threads each and reports what it used).  ``trace``: a list that receives
     (event, window, ms) tuples.
 
     Several devices (``devices=[0, 1, ...]``; an index may repeat: two workers on one device): the blocks are assigned
@@ -124,6 +124,17 @@ def solve_blocks(problems: Sequence[ProblemArrays], device: int = 0, path=None, 
     from ._native import NativeTable, device_count, enqueue_many, wait_many
 
     problems = list(problems)
+    if create_threads is None or host_threads_per_create is None:
+        # 16 workers x 2 threads where the host has them.  (``cpu_quota``: the boxes this was measured on grant a job 16 CPUs of time per 100 ms period with 256 in its
+        # mask; as many single-threaded workers as the quota has CPUs was tried as the default for calls whose creates exceed a period's budget -- 96 coverage-15
+        # tables: 154 - 156 ms per step, every step, against 121 - 170 ms for the bursts, 145 on average -- and not kept.)
+        import os
+
+        n_cpus = len(os.sched_getaffinity(0))
+        if create_threads is None:
+            create_threads = max(1, min(16, n_cpus))
+        if host_threads_per_create is None:
+            host_threads_per_create = max(1, min(2, n_cpus // max(1, create_threads)))
     if devices is None:
         # create (flatten + plan + upload: host work, the C library releases the GIL) of the NEXT window runs on a few threads while the
         # device solves the current one; the windows' host-side result extraction runs in parallel as well (wait_many)
@@ -363,6 +374,51 @@ def device_numa_node(device: int) -> int:
         return -1
 
 
+def cpu_quota(root: str = "/sys/fs/cgroup", self_cgroup: str = "/proc/self/cgroup") -> float:
+    """CPU time the process's control group may use, in CPUs (cgroup v2 ``cpu.max`` "quota period", v1 ``cpu.cfs_quota_us`` / ``cpu.cfs_period_us``);
+    0.0 if unlimited or unknown.  The same reading as csrc/host_parallel.h ``cgroup_cpu_quota``: the MI355X boxes of this project give a job all 256 hardware
+    threads in its affinity mask and a quota of 16 CPUs -- more busy threads than that and the whole process is frozen for the rest of every 100 ms period."""
+    import os
+
+    best = 0.0
+    dirs = [root]
+    try:
+        with open(self_cgroup) as f:
+            for line in f:
+                line = line.strip()
+                if line.startswith("0::") and len(line) > 4:
+                    dirs.append(root + line[3:])
+    except OSError:
+        pass
+    for d in dirs:
+        try:
+            with open(os.path.join(d, "cpu.max")) as f:
+                words = f.read().split()
+            if len(words) == 2 and words[0] != "max" and float(words[1]) > 0:
+                cpus = float(words[0]) / float(words[1])
+                best = cpus if best == 0.0 else min(best, cpus)
+        except (OSError, ValueError):
+            pass
+    try:
+        with open(os.path.join(root, "cpu", "cpu.cfs_quota_us")) as f:
+            quota = float(f.read().split()[0])
+        with open(os.path.join(root, "cpu", "cpu.cfs_period_us")) as f:
+            period = float(f.read().split()[0])
+        if quota > 0 and period > 0:
+            best = quota / period if best == 0.0 else min(best, quota / period)
+    except (OSError, ValueError, IndexError):
+        pass
+    return best
+
+
+def host_cpu_budget(n_cpus: int, local_world: int = 1, quota: float = None) -> int:
+    """Threads one rank should keep busy: its CPU slice, capped by its share of the control group's quota (``cpu_quota``; the ranks of a node live in one group)."""
+    quota = cpu_quota() if quota is None else quota
+    if quota and quota > 0:
+        return max(1, min(int(n_cpus), int(quota // max(1, local_world)) or 1))
+    return max(1, int(n_cpus))
+
+
 def bind_rank_to_device_cpus(local_rank: int, local_world: int, devices: Sequence[int] = None, apply: bool = True, spread_nodes: bool = False) -> dict:
     """One process per GPU: keeps rank ``local_rank``'s host threads -- the creates of ``whamd_dptable_create`` (csrc/host_parallel.h binds its
     workers inside the process's affinity mask), ``wait_many``'s result extraction, Python's own worker threads -- on the CPUs next to ITS GPU:
@@ -386,8 +442,9 @@ def bind_rank_to_device_cpus(local_rank: int, local_world: int, devices: Sequenc
     slices = rank_cpu_slices(local_world, allowed, node_of_rank, node_cpus, core_of_cpu)
     mine = slices[local_rank] if 0 <= local_rank < len(slices) else []
     node = node_of_rank[local_rank] if node_of_rank and local_rank < len(node_of_rank) else -1
+    quota = cpu_quota()
     info = {"cpus": mine, "n_cpus": len(mine), "node": node, "source": "numa" if node is not None and node >= 0 and node_cpus.get(node) else "even split",
-            "applied": False}
+            "applied": False, "cpu_quota": quota, "cpu_budget": host_cpu_budget(len(mine) or len(allowed), local_world, quota)}
     if apply and mine and not os.environ.get("WHAMD_NO_AFFINITY"):
         try:
             os.sched_setaffinity(0, mine)

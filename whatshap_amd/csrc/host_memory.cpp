@@ -12,9 +12,11 @@
 // faults instead of 12 800).  Every block comes from posix_memalign, so a pointer that leaves through somebody else's free() is still valid C;
 // a pointer this library frees that it did not allocate (a std::string grown inside libstdc++.so) is recognised by the block table and handed to
 // free().  whamd_release_caches() empties the pool.
+#include <atomic>
 #include <cstdint>
 #include <cstdlib>
 #include <malloc.h>
+#include <sched.h>
 #include <mutex>
 #include <new>
 #include <sys/mman.h>
@@ -29,8 +31,23 @@ namespace {
 
 constexpr size_t POOL_FROM = (size_t)64 << 10, HUGE_PAGE = (size_t)2 << 20, SMALL_PAGE = 4096;
 
+// The pool's lock is held for a hash look-up and a vector push or pop (~100 ns), ~200 times per table.  As a std::mutex it made a convoy of sixty-four concurrent
+// creates: a waiter SLEEPS, and every hand-over then costs a futex wake (21 us of waiting per acquisition measured, 2 - 6 s in total for 480 tables on 32 - 64
+// threads: threads asleep half of the time, scripts/micro/r6_plan_scaling.cpp).  Spinning for a critical section this short costs its length.
+struct SpinLock {
+	std::atomic<bool> held{false};
+	void lock() {
+		for (uint32_t spins = 0;; ++spins) {
+			if (!held.load(std::memory_order_relaxed) && !held.exchange(true, std::memory_order_acquire)) return;
+			if (spins < 4096) __builtin_ia32_pause();
+			else sched_yield();
+		}
+	}
+	void unlock() { held.store(false, std::memory_order_release); }
+};
+
 struct HostPool {
-	std::mutex mu;
+	SpinLock mu;
 	std::unordered_map<size_t, std::vector<void*>> idle;   // class size -> blocks
 	std::unordered_map<void*, size_t> size_of;            // every block handed out or idle -> its class size
 	size_t idle_bytes = 0, keep = 0;
@@ -45,8 +62,7 @@ HostPool& pool() {
 	static HostPool* p = new HostPool();   // (never destroyed: vectors are freed during static destruction too)
 	return *p;
 }
-thread_local bool g_inside = false;   // the pool's own containers allocate: those requests bypass it
-
+thread_local bool g_inside = false;
 size_t class_of(size_t bytes) {
 	size_t top = (size_t)1 << (63 - __builtin_clzll((unsigned long long)bytes));   // largest power of two <= bytes
 	size_t granule = std::max(SMALL_PAGE, top >> 3);
@@ -64,7 +80,7 @@ void* host_pool_take(size_t bytes) {
 	const size_t size = class_of(std::max(bytes, POOL_FROM));
 	struct Inside { Inside() { g_inside = true; } ~Inside() { g_inside = false; } } inside;
 	{
-		std::lock_guard<std::mutex> lock(p.mu);
+		std::lock_guard<SpinLock> lock(p.mu);
 		auto it = p.idle.find(size);
 		if (it != p.idle.end() && !it->second.empty()) {
 			void* ptr = it->second.back();
@@ -76,7 +92,7 @@ void* host_pool_take(size_t bytes) {
 	void* ptr = nullptr;
 	if (posix_memalign(&ptr, size >= HUGE_PAGE ? HUGE_PAGE : SMALL_PAGE, size) != 0 || !ptr) return nullptr;
 	if (size >= HUGE_PAGE && p.advise) (void)madvise(ptr, size, MADV_HUGEPAGE);
-	std::lock_guard<std::mutex> lock(p.mu);
+	std::lock_guard<SpinLock> lock(p.mu);
 	p.size_of[ptr] = size;
 	return ptr;
 }
@@ -87,7 +103,7 @@ bool host_pool_give(void* ptr) {
 	struct Inside { Inside() { g_inside = true; } ~Inside() { g_inside = false; } } inside;
 	bool release = false;
 	{
-		std::lock_guard<std::mutex> lock(p.mu);
+		std::lock_guard<SpinLock> lock(p.mu);
 		const auto it = p.size_of.find(ptr);
 		if (it == p.size_of.end()) return false;
 		const size_t size = it->second;
@@ -109,7 +125,7 @@ void host_pool_release() {
 	struct Inside { Inside() { g_inside = true; } ~Inside() { g_inside = false; } } inside;
 	std::vector<void*> drop;
 	{
-		std::lock_guard<std::mutex> lock(p.mu);
+		std::lock_guard<SpinLock> lock(p.mu);
 		for (auto& kv : p.idle) {
 			for (void* ptr : kv.second) { p.size_of.erase(ptr); drop.push_back(ptr); }
 			kv.second.clear();
@@ -121,7 +137,7 @@ void host_pool_release() {
 
 size_t host_pool_idle_bytes() {
 	HostPool& p = pool();
-	std::lock_guard<std::mutex> lock(p.mu);
+	std::lock_guard<SpinLock> lock(p.mu);
 	return p.idle_bytes;
 }
 

@@ -95,10 +95,13 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 	// ---- copy the views
 	const bool timing = getenv("WHAMD_DEBUG_TIMING") != nullptr;
 	auto lap_t = std::chrono::steady_clock::now();
+	long lap_faults = timing ? thread_minor_faults() : 0;
 	auto lap = [&](const char* what) {
 		if (!timing) return;
 		const auto now = std::chrono::steady_clock::now();
-		fprintf(stderr, "[whamd timing]   flatten: %s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - lap_t).count());
+		const long faults = thread_minor_faults();
+		fprintf(stderr, "[whamd timing]   flatten: %s %.2f ms (%ld page faults of this thread)\n", what, std::chrono::duration<double, std::milli>(now - lap_t).count(), faults - lap_faults);
+		lap_faults = faults;
 		lap_t = now;
 	};
 	p.n_reads = rs->n_reads;

@@ -34,6 +34,7 @@ inline uint32_t parity32(uint32_t v) { return (uint32_t)__builtin_popcount(v) & 
 
 bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan& plan, int lr, bool genotype_mode) {
 	const auto tp0 = std::chrono::steady_clock::now();
+	const long pf0 = thread_minor_faults();
 	plan = SlotPlan();
 	const uint32_t n = p.n_cols;
 	// pedigree tables (one or two trios): a lane holds ONE (cell, transmission value); no reg slots, 6 - TB lane slots
@@ -405,6 +406,8 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 	};
 	std::vector<RunDraft> drafts;
 	const auto tp1 = std::chrono::steady_clock::now();
+	const long pf1 = thread_minor_faults();
+	long pf2 = pf1;
 	auto tp2 = tp1;
 	{
 		// The ranges planned independently become run boundaries: they follow from the INPUT alone (fixed pieces of ~PLAN_PIECE columns), not
@@ -419,6 +422,7 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 			for (uint64_t q = q0; q < q1; ++q) plan_range(bounds[q], bounds[q + 1], parts[q], part_drafts[q]);
 		});
 		tp2 = std::chrono::steady_clock::now();
+		pf2 = thread_minor_faults();
 		const uint32_t n_threads = n_pieces;
 		{
 			size_t n_steps = 0, n_runs = 0, n_ends_all = 0, n_starts = 0, n_ctrl = 0, n_extra = 0;
@@ -447,6 +451,7 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 		}
 	}
 	const auto tp3 = std::chrono::steady_clock::now();
+	const long pf3 = thread_minor_faults();
 	for (size_t si = 0; si < plan.steps.size(); ++si) {
 		const uint32_t c0 = plan.steps[si].kind == 2 ? plan.runs[plan.steps[si].index].c0 : plan.steps[si].index;
 		// (a pedigree table is ONE job: across a column no read spans the T transmission values still couple the two sides)
@@ -632,8 +637,8 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 	});
 	if (getenv("WHAMD_DEBUG_TIMING")) {
 		auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-		fprintf(stderr, "[whamd timing] slot plan: setup %.1f ms, column ranges %.1f ms, concatenation %.1f ms, layouts %.1f ms\n",
-		        ms(tp0, tp1), ms(tp1, tp2), ms(tp2, tp3), ms(tp3, std::chrono::steady_clock::now()));
+		fprintf(stderr, "[whamd timing] slot plan: setup %.1f ms, column ranges %.1f ms, concatenation %.1f ms, layouts %.1f ms (page faults of this thread: %ld, %ld, %ld, %ld)\n",
+		        ms(tp0, tp1), ms(tp1, tp2), ms(tp2, tp3), ms(tp3, std::chrono::steady_clock::now()), pf1 - pf0, pf2 - pf1, pf3 - pf2, thread_minor_faults() - pf3);
 	}
 	return true;
 }
