@@ -135,7 +135,7 @@ void streamset_give(const StreamSet& ss) {   // (the stream is idle: the caller 
 	for (hipEvent_t e : ss.ev) if (e) (void)hipEventDestroy(e);
 	(void)hipStreamDestroy(ss.stream);
 }
-// The streams the UPLOADS of all tables of a device go through: four, of the highest priority the device offers, shared.  A table's own stream carries its solve;
+// The streams the UPLOADS of all tables of a device go through: two, of the highest priority the device offers, shared.  A table's own stream carries its solve;
 // the runtime maps streams of one priority onto a few hardware queues, and an upload that shared its queue with a group solve -- 2 300 dependent launches -- completed
 // only when the solve had drained: the staging areas came back late and 96 creates under a running solve took 153 - 180 ms instead of 88 - 129 ms
 // (scripts/gpu_create_under_solve.py).  Streams of another priority have hardware queues of their own.
@@ -145,7 +145,7 @@ struct UploadStreams {
 	std::atomic<uint32_t> next{0};
 };
 UploadStreams g_upload_streams;
-constexpr uint32_t UPLOAD_STREAMS = 4;
+constexpr uint32_t UPLOAD_STREAMS = 2;   // (creating one costs ~10 ms, paid by the first creates of a process; the link serialises the copies anyway)
 hipStream_t upload_stream_of(int device) {
 	const uint32_t slot = g_upload_streams.next.fetch_add(1, std::memory_order_relaxed) % UPLOAD_STREAMS;
 	std::lock_guard<std::mutex> lock(g_upload_streams.mu);
@@ -935,6 +935,7 @@ whamd_status_t DeviceTable::upload(Problem& p, int device, std::string& msg) {
 	m.upload_stream = us;
 	if (us == m.stream) m.own_stream_used = true;
 	StageSession stage(us);
+	ulap("staging area taken");
 	auto alloc = [&](void** dptr, size_t bytes) -> hipError_t {
 		size_t got = 0;
 		hipError_t e = devpool_take(device, std::max<size_t>(bytes, 16), dptr, &got);
@@ -965,6 +966,7 @@ whamd_status_t DeviceTable::upload(Problem& p, int device, std::string& msg) {
 		if (alloc(&ptr, upload_bytes) == hipSuccess) { d_slab = (char*)ptr; slab_cap = upload_bytes; }
 		else { (void)hipGetLastError(); stage.image = false; }
 	}
+	ulap("staging image sized, device block taken");
 	bool unstaged_copies = false;   // a copy whose source is pageable memory of this call: the create must wait for it
 	const hipStream_t copy_stream = us;   // (all tables' images on ONE shared stream instead of sixteen at once was measured: 1 055 - 1 273 against 1 015 - 1 153 creates/s, noise)
 	auto flush_slab = [&]() -> hipError_t {

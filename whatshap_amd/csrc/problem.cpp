@@ -525,8 +525,26 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 		std::fill(R.begin(), R.end(), 0u);
 		std::fill(W.begin(), W.end(), 0u);
 		int32_t* dl = p.delta.data() + (size_t)p.col_ptr[c] * p.n_ind;
-		std::fill(dl, dl + (size_t)kc * p.n_ind, 0);
 		double wsum = 0.0;
+		if (p.n_ind == 1) {
+			// (one individual: every delta of the column is written, and REF / ALT is a coin flip per entry -- selects instead of branches: a mispredicted branch per
+			//  entry was a quarter of this pass)
+			uint32_t w = 0, r = 0;
+			uint64_t wide = 0;
+			for (uint32_t j = 0; j < kc; ++j) {
+				const ColumnEntry& e = col[j];
+				const uint32_t q = e.allele == WHAMD_ALLELE_BLANK ? 0u : e.phred;
+				const uint32_t alt = e.allele == WHAMD_ALLELE_ALT ? q : 0u;
+				w += q;
+				wide += q;
+				r += alt;
+				dl[j] = (int32_t)(q - 2u * alt);   // REF +q, ALT -q, BLANK 0
+			}
+			W[0] = w;
+			R[0] = r;
+			wsum = (double)wide;
+		} else {
+		std::fill(dl, dl + (size_t)kc * p.n_ind, 0);
 		for (uint32_t j = 0; j < kc; ++j) {
 			const ColumnEntry& e = col[j];
 			if (e.allele == WHAMD_ALLELE_BLANK) continue;
@@ -538,6 +556,7 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 			} else {
 				dl[(size_t)e.sample * kc + j] = (int32_t)e.phred;
 			}
+		}
 		}
 		double max_acost = 0.0;
 		bool any = false;
