@@ -545,18 +545,17 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 			wsum = (double)wide;
 		} else {
 		std::fill(dl, dl + (size_t)kc * p.n_ind, 0);
-		for (uint32_t j = 0; j < kc; ++j) {
+		uint64_t wide = 0;
+		for (uint32_t j = 0; j < kc; ++j) {   // (the same selects; an entry writes the delta of ITS individual's row, the others stay 0)
 			const ColumnEntry& e = col[j];
-			if (e.allele == WHAMD_ALLELE_BLANK) continue;
-			W[e.sample] += e.phred;
-			wsum += e.phred;
-			if (e.allele == WHAMD_ALLELE_ALT) {
-				R[e.sample] += e.phred;
-				dl[(size_t)e.sample * kc + j] = (int32_t)(0u - e.phred);
-			} else {
-				dl[(size_t)e.sample * kc + j] = (int32_t)e.phred;
-			}
+			const uint32_t q = e.allele == WHAMD_ALLELE_BLANK ? 0u : e.phred;
+			const uint32_t alt = e.allele == WHAMD_ALLELE_ALT ? q : 0u;
+			W[e.sample] += q;
+			wide += q;
+			R[e.sample] += alt;
+			dl[(size_t)e.sample * kc + j] = (int32_t)(q - 2u * alt);
 		}
+		wsum = (double)wide;
 		}
 		double max_acost = 0.0;
 		bool any = false;
@@ -942,11 +941,11 @@ whamd_status_t finish_columns(const Problem& p, Solution& s, uint32_t c_begin, u
 		}
 		// set_partitioning (src/pedigreecolumncostcomputer.cpp:53-76)
 		for (auto& v : cp) v = {0, 0};
-		for (uint32_t j = 0; j < kc; ++j) {
+		for (uint32_t j = 0; j < kc; ++j) {   // (selects, not branches: REF / ALT is a coin flip per entry)
 			const ColumnEntry& e = col[j];
 			const int part = map[2 * e.sample + ((x >> j) & 1u)];
-			if (e.allele == WHAMD_ALLELE_REF) cp[part][1] += e.phred;
-			else if (e.allele == WHAMD_ALLELE_ALT) cp[part][0] += e.phred;
+			cp[part][1] += e.allele == WHAMD_ALLELE_REF ? e.phred : 0u;
+			cp[part][0] += e.allele == WHAMD_ALLELE_ALT ? e.phred : 0u;
 		}
 		// get_alleles (src/pedigreecolumncostcomputer.cpp:117-175)
 		uint32_t best = INF;
