@@ -192,7 +192,13 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 			for (uint32_t s = 0; s < L; ++s) n_free += cur[s] < 0;
 			if (n_new > n_free) break;
 			bool ok = true;
-			if (!ped) for (uint32_t j = 0; j < kc && ok; ++j) ok = std::abs(p.delta[(size_t)p.col_ptr[c1] + j]) < SLOT_DELTA_LIMIT;
+			if (!ped) {   // (one pass, no early exit: every delta within the limit and every shared read tracked)
+				const int32_t* dcol = p.delta.data() + (size_t)p.col_ptr[c1];
+				uint32_t bad = 0;
+				for (uint32_t j = 0; j < kc; ++j) bad |= (uint32_t)(std::abs(dcol[j]) >= SLOT_DELTA_LIMIT);
+				for (uint32_t j = 0; j < bc; ++j) bad |= (uint32_t)(slot_of[col[j].read_id] < 0);
+				ok = bad == 0;
+			}
 			if (ped && !genotype_mode) {
 				// at most PSLOT_MAXFORMS forms per transmission value; the run's tables grow with the widest column (NF 2 -> 4)
 				uint32_t most = 0;
@@ -205,7 +211,7 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 				if ((c1 - c + 1) * pslot_ta(fact_nf, p.T) * nf > (uint32_t)PSLOT_FORMWORDS) break;
 				run_forms = nf;
 			}
-			for (uint32_t j = 0; j < bc && ok; ++j) ok = slot_of[col[j].read_id] >= 0;   // every shared read is tracked
+			if (ped) for (uint32_t j = 0; j < bc && ok; ++j) ok = slot_of[col[j].read_id] >= 0;   // every shared read is tracked
 			if (!ok) break;
 			// reads that start here take the lowest free local slots
 			{
@@ -262,8 +268,9 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 			}
 			// ending reads, ascending logical position
 			uint32_t en = 0;
-			for (uint32_t j = 0; j < kc; ++j) {
-				if ((p.fwd_mask[c1] >> j) & 1u) continue;
+			const uint32_t ending_bits = ~p.fwd_mask[c1] & (kc >= 32 ? 0xFFFFFFFFu : ((1u << kc) - 1u));   // (one or two of fifteen: the set bits, not a scan)
+			for (uint32_t rest = ending_bits; rest; rest &= rest - 1u) {
+				const uint32_t j = (uint32_t)__builtin_ctz(rest);
 				if (genotype_mode && c1 + 1 == n) break;   // (the last column of the table: nothing is summed out)
 				const int s = slot_of[col[j].read_id];
 				if (s >= (int)L) { ok = false; break; }   // a grid read would end (excluded by grid_end)
@@ -304,10 +311,7 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 				prow.pad[1] = (uint32_t)(plan.start_slots.size() - starts_mark) - n_new;
 			}
 			// after the projection the ended reads' slots are free again
-			for (uint32_t j = 0; j < kc; ++j) {
-				if ((p.fwd_mask[c1] >> j) & 1u) continue;
-				cur[slot_of[col[j].read_id]] = -1;
-			}
+			for (uint32_t rest = ending_bits; rest; rest &= rest - 1u) cur[slot_of[col[__builtin_ctz(rest)].read_id]] = -1;
 			n_ends += en;
 			col_to_row[c1] = (int32_t)c1;
 			btc_g[c1] = bc_rec;
