@@ -474,16 +474,25 @@ bool plan_forward_slots(const Problem& p, int l_pref, int use_symmetry, SlotPlan
 			for (uint32_t c = (uint32_t)c_lo; c < (uint32_t)c_hi; ++c) {
 				uint64_t kstar = 0;
 				uint32_t Cp = RES_ABSENT, Cm = RES_ABSENT, Cc = INF;
-				uint64_t dabs = 0, ub = ~0ull;
-				const int32_t* dl = p.delta.data() + (size_t)p.col_ptr[c];
-				for (uint32_t j = 0; j < p.k[c]; ++j) dabs += (uint64_t)std::abs((int64_t)dl[j]);
 				for (uint64_t q = p.term_begin(c, 0); q < p.term_end(c, 0); ++q) {
 					const CostTerm& t = p.terms[q];
 					if (t.plus) Cp = t.c; else if (t.minus) Cm = t.c; else Cc = std::min(Cc, t.c);
-					ub = std::min<uint64_t>(ub, (uint64_t)t.c + ((t.plus || t.minus) ? dabs : 0));
 				}
 				pure[c] = Cp != RES_ABSENT && Cm != RES_ABSENT && Cc == INF;
-				kstar = pure[c] ? (uint64_t)(uint32_t)(Cp + Cm) : 2 * (ub == ~0ull ? 0 : ub);   // (2 D grows by at most this much in column c)
+				if (pure[c]) {
+					kstar = (uint64_t)(uint32_t)(Cp + Cm);
+				} else {
+					// (the bound of a column that is not pure: its cheapest term at its largest -- the sum of the |deltas| is read only here, not for the
+					//  heterozygous columns that make up a `whatshap phase` table)
+					uint64_t dabs = 0, ub = ~0ull;
+					const int32_t* dl = p.delta.data() + (size_t)p.col_ptr[c];
+					for (uint32_t j = 0; j < p.k[c]; ++j) dabs += (uint64_t)std::abs((int64_t)dl[j]);
+					for (uint64_t q = p.term_begin(c, 0); q < p.term_end(c, 0); ++q) {
+						const CostTerm& t = p.terms[q];
+						ub = std::min<uint64_t>(ub, (uint64_t)t.c + ((t.plus || t.minus) ? dabs : 0));
+					}
+					kstar = 2 * (ub == ~0ull ? 0 : ub);   // (2 D grows by at most this much in column c)
+				}
 				B[c + 1] = kstar;
 			}
 		});
