@@ -135,10 +135,9 @@ void streamset_give(const StreamSet& ss) {   // (the stream is idle: the caller 
 	for (hipEvent_t e : ss.ev) if (e) (void)hipEventDestroy(e);
 	(void)hipStreamDestroy(ss.stream);
 }
-// The streams the UPLOADS of all tables of a device go through: two, of the highest priority the device offers, shared.  A table's own stream carries its solve;
-// the runtime maps streams of one priority onto a few hardware queues, and an upload that shared its queue with a group solve -- 2 300 dependent launches -- completed
-// only when the solve had drained: the staging areas came back late and 96 creates under a running solve took 153 - 180 ms instead of 88 - 129 ms
-// (scripts/gpu_create_under_solve.py).  Streams of another priority have hardware queues of their own.
+// The streams the UPLOADS of all tables of a device go through: two, shared, used for nothing else.  A table's own stream carries its solve; an upload that went
+// through it completed, under a running group solve, only when that solve's queue had drained: the staging areas came back late and 96 creates under a running solve
+// took 137 - 190 ms instead of 81 - 93 ms alone (scripts/gpu_create_under_solve.py); on streams of their own: 72 - 101 ms.
 struct UploadStreams {
 	std::mutex mu;
 	std::vector<std::pair<int, hipStream_t>> streams;   // (device, stream); never destroyed: they live as long as the process
@@ -157,7 +156,11 @@ hipStream_t upload_stream_of(int device) {
 		int least = 0, greatest = 0;
 		(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
 		hipStream_t st = nullptr;
-		if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+		// (default priority.  Streams of the HIGHEST priority -- debug library, WHAMD_UPLOAD_STREAMS_HIGH=1 -- were the first version: the creates under a running solve
+		//  gained the same, but the mere existence of such streams made three full-width tables solved at once on their own streams 3.2 x slower, 177 ms against 55:
+		//  scripts/gpu_wide_tables_concurrent.py)
+		const bool high = debug_env("WHAMD_UPLOAD_STREAMS_HIGH") != nullptr;
+		if ((high ? hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest) : hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
 		g_upload_streams.streams.emplace_back(device, st);
 		made = st;
 		++seen;
