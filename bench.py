@@ -385,7 +385,7 @@ def roofline_from_counters(pmc, avg_launch_us, kernel, bytes_per_launch_model, a
         # the instantiation the counters were taken from (`kernel` was the filter: "slot_run" also matches slot_runx<2, 24, false, false>)
         out["kernel_filter"] = kernel
         name = str(pmc["_kernel_name"])
-        out["kernel"] = name.split("(")[0].replace("void ", "").replace("whamd::", "").replace("(anonymous namespace)::", "").strip() or kernel
+        out["kernel"] = name.replace("(anonymous namespace)::", "").replace("void ", "").replace("whamd::", "").split("(")[0].strip() or kernel   # ("(anonymous namespace)" goes first: its bracket is not the argument list's)
     valu = pmc.get("SQ_INSTS_VALU")
     if valu is not None:
         out["achieved"] = valu / cycles

@@ -255,3 +255,16 @@ def test_the_library_sizes_its_workers_by_WHAMD_HOST_CPUS():
     one = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, check=True).stdout.strip()
     many = subprocess.run([sys.executable, "-c", code.replace("os.environ['WHAMD_HOST_CPUS'] = '1'\n", "")], capture_output=True, text=True, cwd=root, check=True).stdout.strip()
     assert one == many and int(one) > 0
+
+
+def test_roofline_names_the_kernel_instantiation_the_counters_came_from():
+    """`roofline.kernel` said "slot_run" (the filter) where the counters were taken from `slot_runx<2, 24, false, false>`: the demangled name starts with
+    "void whamd::(anonymous namespace)::" -- the bracket of "(anonymous namespace)" is not the argument list's."""
+    import argparse
+    import bench as b
+
+    pmc = {"_kernel_name": "void whamd::(anonymous namespace)::slot_runx<2, 24, false, false>(whamd::DevProblem, whamd::SlotRun, unsigned int const*, unsigned int*, unsigned int*, unsigned int)",
+           "SQ_INSTS_VALU": 1.0e6}
+    out = b.roofline_from_counters(pmc, 8.0, "slot_run", 0.0, argparse.Namespace(pmc_variants=8000, coverage=20))
+    assert out["kernel"] == "slot_runx<2, 24, false, false>"
+    assert out["kernel_filter"] == "slot_run"

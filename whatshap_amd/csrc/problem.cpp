@@ -108,9 +108,8 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 	const uint64_t nnz = rs->n_reads ? rs->read_ptr[rs->n_reads] : 0;
 	p.read_ptr.assign(rs->n_reads + 1, 0);
 	if (rs->n_reads) std::copy(rs->read_ptr, rs->read_ptr + rs->n_reads + 1, p.read_ptr.begin());
-	p.var_position.resize(nnz);
-	p.var_allele.resize(nnz);
-	p.var_quality.resize(nnz);
+	// (the per-variant arrays of the view are read where they lie: the entries are the table's own copy of everything it needs later -- Problem::var_* stay empty;
+	//  copying 7 MB per coverage-15 table was 0.3 of a create's 10 thread-ms)
 	{
 		// Entry::BLANK (2) inside a read is accepted and skipped by the reference (pedigreecolumncostcomputer.cpp:69-70,
 		// 93-94), exactly like the BLANK entries ColumnIterator inserts; only EQUAL_SCORES (3) and beyond reach its
@@ -119,9 +118,6 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 		std::vector<uint8_t> bad(n_threads, 0);
 		parallel_ranges(nnz, n_threads, [&](uint64_t i0, uint64_t i1, uint32_t t) {
 			if (i1 <= i0) return;
-			std::memcpy(p.var_position.data() + i0, rs->var_position + i0, (i1 - i0) * sizeof(int32_t));
-			std::memcpy(p.var_allele.data() + i0, rs->var_allele + i0, (i1 - i0) * sizeof(uint8_t));
-			std::memcpy(p.var_quality.data() + i0, rs->var_quality + i0, (i1 - i0) * sizeof(uint32_t));
 			uint8_t worst = 0;
 			for (uint64_t i = i0; i < i1; ++i) worst = std::max(worst, rs->var_allele[i]);
 			bad[t] = worst > WHAMD_ALLELE_BLANK;
@@ -173,7 +169,7 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 	// ---- ColumnIterator::ColumnIterator (src/columniterator.cpp:10-59): positions + validation
 	if (positions == nullptr) {  // ReadSet::get_positions (src/readset.cpp:54-62)
 		p.positions.resize(nnz);
-		for (uint64_t i = 0; i < nnz; ++i) p.positions[i] = (uint32_t)p.var_position[i];
+		for (uint64_t i = 0; i < nnz; ++i) p.positions[i] = (uint32_t)rs->var_position[i];
 		std::sort(p.positions.begin(), p.positions.end());
 		p.positions.erase(std::unique(p.positions.begin(), p.positions.end()), p.positions.end());
 	} else {
@@ -690,22 +686,22 @@ whamd_status_t build_problem(const whamd_readset_view* rs, const uint32_t* recom
 			const uint32_t first = first_col[r];
 			uint64_t v = p.read_ptr[r];
 			if (first < c_begin) {   // started before the range: its first variant at or after the range's first position
-				const int32_t* lo = p.var_position.data() + p.read_ptr[r];
-				const int32_t* hi = p.var_position.data() + p.read_ptr[r + 1];
-				v = (uint64_t)(std::lower_bound(lo, hi, (int32_t)p.positions[c_begin]) - p.var_position.data());
+				const int32_t* lo = rs->var_position + p.read_ptr[r];
+				const int32_t* hi = rs->var_position + p.read_ptr[r + 1];
+				v = (uint64_t)(std::lower_bound(lo, hi, (int32_t)p.positions[c_begin]) - rs->var_position);
 			}
 			const uint8_t sample = (uint8_t)p.read_source[r];
 			const uint32_t c_hi = std::min(last, c_end - 1u);
 			for (uint32_t c = std::max(first, c_begin); c <= c_hi; ++c) {
 				const int cpos = (int)p.positions[c];
-				while (p.var_position[v] < cpos) ++v;   // (the read's last variant lies in column `last`: v stays inside the read)
+				while (rs->var_position[v] < cpos) ++v;   // (the read's last variant lies in column `last`: v stays inside the read)
 				const uint32_t j = cnt[c - c_begin]++;
 				ColumnEntry& e = p.entries[p.col_ptr[c] + j];
 				e.read_id = r;
 				e.sample = sample;
-				if (p.var_position[v] == cpos) {
-					e.allele = p.var_allele[v];
-					e.phred = p.var_quality[v];
+				if (rs->var_position[v] == cpos) {
+					e.allele = rs->var_allele[v];
+					e.phred = rs->var_quality[v];
 				} else {
 					e.allele = WHAMD_ALLELE_BLANK;
 					e.phred = 0;

@@ -48,7 +48,7 @@ struct Problem {
 	// ---- inputs (copied from the views)
 	uint32_t n_reads = 0;
 	std::vector<uint64_t> read_ptr;
-	RawVec<int32_t> var_position;   // (RawVec: sized without being zero-filled, host_parallel.h)
+	RawVec<int32_t> var_position;   // (RawVec: sized without being zero-filled, host_parallel.h.  Since round 6 the three var_* arrays stay EMPTY: build_problem reads the view's)
 	RawVec<uint8_t> var_allele;
 	RawVec<uint32_t> var_quality;
 	std::vector<uint32_t> read_source;
