@@ -392,7 +392,7 @@ def device_numa_node(device: int) -> int:
 
 def cpu_quota(root: str = "/sys/fs/cgroup", self_cgroup: str = "/proc/self/cgroup") -> float:
     """CPU time the process's control group may use, in CPUs (cgroup v2 ``cpu.max`` "quota period", v1 ``cpu.cfs_quota_us`` / ``cpu.cfs_period_us``);
-    0.0 if unlimited or unknown.  The same reading as csrc/host_parallel.h ``cgroup_cpu_quota``: the MI355X boxes of this project give a job all 256 hardware
+    0.0 if unlimited or unknown.  The MI355X boxes of this project give a job all 256 hardware
     threads in its affinity mask and a quota of 16 CPUs -- more busy threads than that and the whole process is frozen for the rest of every 100 ms period."""
     import os
 

@@ -41,46 +41,10 @@ inline uint32_t& host_threads_override() {
 	static thread_local uint32_t value = 0;
 	return value;
 }
-// CPU time the process's control group may use, in CPUs (cgroup v2 cpu.max "quota period", v1 cpu.cfs_quota_us / cpu.cfs_period_us), 0 if unlimited or unknown.
-// The MI355X boxes of this project run a job with ALL 256 hardware threads in its affinity mask and a quota of 16 CPUs: thirty-two busy threads use the period's
-// budget up in half of it and the whole process -- the thread that feeds the device included -- is frozen for the other half (scripts/micro/r6_cpu_quota_probe.cpp:
-// 32, 64, 128 spinning threads get 17 CPUs' worth; what rounds 4 - 6 recorded as "creates do not scale past 32 threads", "more workers are slower" and steps that
-// were 33 ms late every now and then).
-inline uint32_t cgroup_cpu_quota() {
-	auto read_two = [](const std::string& path, double& a, double& b) -> int {   // numbers read (a word "max" counts as -1)
-		FILE* f = fopen(path.c_str(), "r");
-		if (!f) return 0;
-		char w0[64] = {0}, w1[64] = {0};
-		const int got = fscanf(f, "%63s %63s", w0, w1);
-		fclose(f);
-		if (got >= 1) a = (w0[0] == 'm') ? -1.0 : atof(w0);
-		if (got >= 2) b = atof(w1);
-		return got;
-	};
-	double best = 0.0;
-	auto consider = [&](double quota, double period) { if (quota > 0 && period > 0) { const double cpus = quota / period; if (best == 0.0 || cpus < best) best = cpus; } };
-	std::vector<std::string> dirs = {"/sys/fs/cgroup"};
-	if (FILE* f = fopen("/proc/self/cgroup", "r")) {   // "0::/path" (v2): the group's own directory below the mount, where the namespace shows it
-		char line[512];
-		while (fgets(line, sizeof line, f)) {
-			std::string l(line);
-			while (!l.empty() && (l.back() == '\n' || l.back() == ' ')) l.pop_back();
-			if (l.rfind("0::", 0) == 0 && l.size() > 4) dirs.push_back("/sys/fs/cgroup" + l.substr(3));
-		}
-		fclose(f);
-	}
-	for (const std::string& d : dirs) {
-		double q = 0, per = 0;
-		if (read_two(d + "/cpu.max", q, per) == 2) consider(q, per);
-	}
-	{
-		double q = 0, per = 0, unused = 0;
-		if (read_two("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", q, unused) >= 1 && read_two("/sys/fs/cgroup/cpu/cpu.cfs_period_us", per, unused) >= 1) consider(q, per);
-	}
-	return best > 0.0 ? (uint32_t)std::max(1.0, best) : 0u;   // (rounded down: the budget is a ceiling)
-}
 // CPUs this process may keep busy: its affinity mask (a rank bound to the CPU slice of its GPU -- whatshap_amd.blocks.bind_rank_to_device_cpus -- sizes its workers by
-// the slice, not by the machine), capped by WHAMD_HOST_CPUS; read once.  NOT capped by the control group's quota: the quota limits CPU time per period, not threads --
+// the slice, not by the machine), capped by WHAMD_HOST_CPUS; read once.  NOT capped by the control group's CPU quota (cgroup cpu.max: the MI355X boxes of this project
+// give a job all 256 hardware threads in its mask and 16 CPUs of time per 100 ms -- whatshap_amd.blocks.cpu_quota reads it, scripts/micro/r6_cpu_quota_probe.cpp
+// shows it): the quota limits CPU time per period, not threads --
 // one create is a burst of a few thread-milliseconds and is fastest on all the threads it can use (configs[2]: 14.0 ms on 32 threads, 16.5 on 16); it is the SUSTAINED
 // work of many creates that has to stay under the quota, and that is decided where the tables are queued (whatshap_amd.blocks.solve_blocks, bench.py's host shapes).
 inline uint32_t usable_cpus() {
