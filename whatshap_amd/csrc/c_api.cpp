@@ -314,10 +314,8 @@ whamd_status_t whamd_dptable_wait_many(whamd_dptable* const* tables, size_t n_ta
 		t->stats.host_finish_ms = now_ms() - t0;
 		t->solved = status[i] == WHAMD_OK;
 	};
-	// More tables than wait workers (a group of many tables: they all finish with the group's last launch): the device waits on the 32 workers, THEN every table's
-	// host side on a worker of its own -- no HIP call in that phase, so nothing contends in the runtime -- instead of three rounds of wait + finish per worker
-	// (10 ms behind a 96-table solve, 3.3 ms now).  Fewer tables (own streams, finishing at different times): a worker waits for its table and finishes it at once.
-	const bool two_phases = false;   // (measured on one box, same process, twelve steps each: 54.4 ms with the two phases against 50.7 ms without -- not kept; the switch stays for the next measurement)
+	// (A second phase -- the device waits on the 32 workers first, then every table's host side on a worker of its own -- was measured on one box, same process,
+	// twelve steps each: 54.4 ms against 50.7 ms without; not kept.  Since then the host side of a single-individual table is 0.3 ms: nothing to spread.)
 	const bool timing = getenv("WHAMD_DEBUG_TIMING") != nullptr;
 	const double t_wait0 = now_ms();
 	{
@@ -334,7 +332,7 @@ whamd_status_t whamd_dptable_wait_many(whamd_dptable* const* tables, size_t n_ta
 			if (timing) t_begun[i] = now_ms() - t_wait0;
 			status[i] = t->device.wait(t->problem, t->solution, t->stats, messages[i]);
 			if (timing) t_synced[i] = now_ms() - t_wait0;
-			if (status[i] != WHAMD_OK || two_phases) continue;
+			if (status[i] != WHAMD_OK) continue;
 			finish_one(i);
 			if (timing) t_finished[i] = now_ms() - t_wait0;
 		}
@@ -349,14 +347,6 @@ whamd_status_t whamd_dptable_wait_many(whamd_dptable* const* tables, size_t n_ta
 		}
 		fprintf(stderr, "[whamd timing] wait_many of %zu tables on %u workers: first table's device side done after %.1f ms, last after %.1f ms, last host side after %.1f ms; host side %.2f ms per table; %zu waits begun after the device was done took %.2f ms each (longest %.2f)\n",
 		        n_tables, outer, s0, s1, f1, fin / n_tables, late, late ? late_wait / late : 0.0, late_max);
-	}
-	if (two_phases) {
-		const uint32_t workers = (uint32_t)std::min<uint64_t>(n_tables, std::max(outer, std::min(whamd::usable_cpus(), 128u)));
-		parallel_ranges(n_tables, workers, [&](uint64_t i0, uint64_t i1, uint32_t) {
-			struct Budget { uint32_t saved = whamd::host_threads_override(); ~Budget() { whamd::host_threads_override() = saved; } } budget;
-			whamd::host_threads_override() = 1;
-			for (uint64_t i = i0; i < i1; ++i) if (status[i] == WHAMD_OK) finish_one(i);
-		});
 	}
 	for (size_t i = 0; i < n_tables && first == WHAMD_OK; ++i)
 		if (status[i] != WHAMD_OK) { first = status[i]; first_msg = messages[i]; }
