@@ -138,7 +138,7 @@ def test_the_product_library_carries_no_debug_code():
     assert "whamd_debug" not in exported
     blob = open(_native.LIB_PATH, "rb").read()
     for marker in (b"WHAMD_SLOT_SKIP", b"WHAMD_SLOT_STAMPS", b"WHAMD_DEBUG_STAMPS", b"WHAMD_NO_YFORM", b"WHAMD_GROUP_PARTS", b"WHAMD_EAGER_TERMS", b"WHAMD_GENERIC_FINISH",
-                   b"WHAMD_NO_COMPAT_CACHE", b"WHAMD_HOST_SUPERREADS", b"WHAMD_UPLOAD_ON_TABLE_STREAM", b"WHAMD_UPLOAD_STREAMS_HIGH", b"WHAMD_SKIP_SLAB_COPY", b"WHAMD_TAIL_OWN_STREAM", b"WHAMD_NO_GROUP_BACKTRACE", b"WHAMD_SYNC_UPLOAD", b"WHAMD_DENSE_COLUMN_UPLOAD", b"WHAMD_NO_WIDE_LAYOUT", b"WHAMD_NO_UPLOAD_SLAB"):
+                   b"WHAMD_NO_COMPAT_CACHE", b"WHAMD_HOST_SUPERREADS", b"WHAMD_UPLOAD_ON_TABLE_STREAM", b"WHAMD_UPLOAD_STREAMS_HIGH", b"WHAMD_SPLIT_COMPONENTS", b"WHAMD_SKIP_SLAB_COPY", b"WHAMD_TAIL_OWN_STREAM", b"WHAMD_NO_GROUP_BACKTRACE", b"WHAMD_SYNC_UPLOAD", b"WHAMD_DENSE_COLUMN_UPLOAD", b"WHAMD_NO_WIDE_LAYOUT", b"WHAMD_NO_UPLOAD_SLAB"):
         assert marker not in blob, marker
     debug = subprocess.run(["nm", "-D", "--defined-only", _native.DEBUG_LIB_PATH], capture_output=True, text=True, check=True).stdout
     for name in ("whamd_debug_emulate_slot_plan", "whamd_debug_emulate_pedslot_plan", "whamd_debug_pedmec_heuristic_create_host"):

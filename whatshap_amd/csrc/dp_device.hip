@@ -1181,7 +1181,14 @@ whamd_status_t DeviceTable::upload(Problem& p, int device, std::string& msg) {
 		final_job.final = true;
 		std::vector<Impl::Job> component_jobs;
 		const std::vector<uint32_t>& first = m.plan.component_first_step;
-		const bool split = m.max_lanes > 1 && first.size() > 1 && !debug_env("WHAMD_DEBUG_STAMPS") && !m.windowed;
+		// Components as jobs of their own run side by side on lanes -- and walk back one after the other through the SEQUENTIAL backtrace (the chunked one takes a
+		// single job): 16 ms for an irregular coverage-20 table of 200 000 columns whose forward pass is 57 ms, nearly all of it one giant component (a Poisson layout
+		// leaves a gap every few ten thousand columns).  A table whose largest component holds four fifths of its steps or more stays ONE job: the lanes would gain
+		// less than the walk loses ((1 - s) x forward against s x 16 ms).  WHAMD_SPLIT_COMPONENTS=1 (debug library): always split, as before.
+		size_t largest = 0;
+		for (size_t k = 0; k < first.size(); ++k) largest = std::max<size_t>(largest, (k + 1 < first.size() ? first[k + 1] : m.plan.steps.size()) - first[k]);
+		const bool worth_splitting = largest * 5 < m.plan.steps.size() * 4 || debug_env("WHAMD_SPLIT_COMPONENTS");
+		const bool split = m.max_lanes > 1 && first.size() > 1 && worth_splitting && !debug_env("WHAMD_DEBUG_STAMPS") && !m.windowed;
 		if (!split) {
 			for (uint32_t si = 0; si < m.plan.steps.size(); ++si) final_job.steps.push_back(si);
 		} else {
