@@ -2277,7 +2277,9 @@ whamd_status_t DeviceTable::enqueue_group(DeviceTable* const* tables, const Prob
 			// own streams -- each waiting for the lead's event -- a 96-table step was bimodal: 67 ms or 95 ms, the device's forward pass 39 ms either way
 			// (hardware queues that hold only a barrier are rescheduled late; more queues, GPU_MAX_HW_QUEUES=16, made every step 180 ms).  WHAMD_TAIL_OWN_STREAM=1
 			// (debug library) restores the old placement.
-			const bool own = debug_env("WHAMD_TAIL_OWN_STREAM") != nullptr;
+			// ... except a member that walks back through the SEQUENTIAL kernel (several jobs, or too few units for chunks): milliseconds of one workgroup per table --
+			// those run side by side on the members' own streams, behind the group's event, instead of one after the other on the lead's.
+			const bool own = debug_env("WHAMD_TAIL_OWN_STREAM") != nullptr || (!walked[i] && !m.use_chunks && !m.windowed && m.stream != part.lead->stream);
 			if (own) m.own_stream_used = true;
 			if (own && m.stream != part.lead->stream && hipStreamWaitEvent(m.stream, part.lead->ev_group, 0) != hipSuccess) { msg = "hipStreamWaitEvent failed"; st = WHAMD_ERR_DEVICE; }
 			if (st == WHAMD_OK) st = m.submit_tail(*problems[i], msg, own ? nullptr : part.lead->stream, walked[i] != 0, walked[i] != 0);
