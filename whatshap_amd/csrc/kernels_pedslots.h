@@ -60,7 +60,42 @@ __global__ __launch_bounds__(256) void pedslot_tables(DevProblem P, const SlotRu
 		}
 		out[ex.x_off + i] = word;
 	}
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_g + n_w + n_s + n_k; i += gridDim.x * blockDim.x) {
+	// ---- G [unit][c][t][f] and W: ONE thread per (column, value, form) walks the 2^g workgroups (2^lw waves) in Gray order -- every step flips one slot: one add.
+	// (One thread per WORD -- five runtime divisions, a dozen scattered loads and a loop over the set bits each -- built configs[3]'s 0.9 GB in 3.7 ms, 243 GB/s,
+	//  exposed between the end of a create and the first launch of a fresh table; u32 sums are modular: the order of the additions does not matter.)
+	__shared__ uint32_t sd[SLOT_GMAX + 1][256];   // [slot of the unit's bits][thread]: the signed delta the form takes from that slot (0: none)
+	for (uint32_t item = blockIdx.x * blockDim.x + threadIdx.x; item < 2u * fwn; item += gridDim.x * blockDim.x) {
+		const uint32_t kind = item >= fwn ? 1u : 0u, q = item - kind * fwn;   // q: [c][t][f]
+		const uint32_t c = q / (TA * NA), t = (q / NA) % TA, f = q % NA;
+		const PedSlotRow& row = P.pslot_rows[run.row_off + c];
+		const DevColumn& col = P.cols[run.c0 + c];
+		const uint32_t q0 = P.term_ptr[col.term_off + t] + f, q1 = P.term_ptr[col.term_off + t + 1];
+		const bool present = fact || q0 < q1;
+		DevTerm tm{};
+		if (present) tm = fact4 ? fterms[(size_t)(run.c0 + c) * PSLOT_FSTRIDE4 + f] : (fact ? fterms[((size_t)(run.c0 + c) * T + t) * 16u + f] : P.terms[q0]);
+		const uint32_t s0 = kind ? nls : L, nb = kind ? L - nls : run.g;
+		uint32_t acc = kind == 0u ? (present ? tm.c : 0xFFFFFFFFu) : 0u;   // absent form: INF + 0 + 0
+		for (uint32_t b = 0; b < nb && b <= (uint32_t)SLOT_GMAX; ++b) {
+			uint32_t d = 0;
+			if (present) {
+				const uint32_t ind = row.ind[s0 + b];
+				if ((tm.plus >> ind) & 1u) d = (uint32_t)row.dslot[s0 + b];
+				else if ((tm.minus >> ind) & 1u) d = 0u - (uint32_t)row.dslot[s0 + b];
+			}
+			sd[b][threadIdx.x] = d;
+		}
+		uint32_t* __restrict__ dst = out + (kind ? n_g : 0u) + q;
+		dst[0] = acc;
+		uint32_t gray = 0;
+		for (uint32_t u = 1; u < (1u << nb); ++u) {
+			const uint32_t b = (uint32_t)__builtin_ctz(u);
+			gray ^= 1u << b;
+			const uint32_t d = sd[b][threadIdx.x];
+			acc = ((gray >> b) & 1u) ? acc + d : acc - d;
+			dst[(size_t)gray * fwn] = acc;
+		}
+	}
+	for (uint32_t i = n_g + n_w + blockIdx.x * blockDim.x + threadIdx.x; i < n_g + n_w + n_s + n_k; i += gridDim.x * blockDim.x) {
 		uint32_t kind, unit, c, t, f;
 		if (i >= n_g + n_w + n_s) {   // K [c][t][12]: the constants of the factorised line (entries 4 .. 15 of the column's sixteen)
 			const uint32_t r = i - n_g - n_w - n_s;
@@ -68,15 +103,9 @@ __global__ __launch_bounds__(256) void pedslot_tables(DevProblem P, const SlotRu
 			               : fterms[((size_t)run.c0 * T + r / PSLOT_NK) * 16u + 4u + r % PSLOT_NK].c;
 			continue;
 		}
-		if (i < n_g + n_w) {
-			kind = i < n_g ? 0u : 1u;
-			const uint32_t r = kind ? i - n_g : i;
-			unit = r / fwn;
-			const uint32_t q = r % fwn;   // [c][t][f]
-			c = q / (TA * NA); t = (q / NA) % TA; f = q % NA;
-		} else {
+		{   // S [c][lane][f]: the lane-slot part of a form, per lane
 			kind = 2u;
-			const uint32_t r = i - n_g - n_w;   // [c][lane][f]
+			const uint32_t r = i - n_g - n_w;
 			c = r / (64u * NS); unit = (r / NS) & 63u; f = r % NS;
 			t = unit & (T - 1u);
 		}
