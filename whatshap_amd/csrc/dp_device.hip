@@ -1287,6 +1287,24 @@ whamd_status_t DeviceTable::upload(Problem& p, int device, std::string& msg) {
 		HIP_TRY(alloc((void**)&m.d_bt_state, 16));
 		if (getenv("WHAMD_DEBUG_TIMING")) fprintf(stderr, "[whamd timing] windowed solve: %zu windows, arena %.2f GB\n", m.windows.size(), (double)bt / 1e9);
 	}
+	// ---- everything a solve hands back lies in ONE device block, laid out like the pinned buffer it is downloaded into: [n] path index, [n] path transmission, the
+	// final job's score with the other jobs' behind it (d_job_scores[0] IS d_score: job 0 is the final one and has no entry of its own), four words of backtrace
+	// counters, the superreads.  Five copies per table -- 4.6 us each as blit kernels, one after the other on a group's stream: 2.6 ms behind a 96-table solve -- are one.
+	m.super_off = 2 * (size_t)n + 4 + m.jobs.size();
+	{
+		void* d_res = nullptr;
+		HIP_TRY(alloc(&d_res, (m.super_off + (m.device_superreads ? m.super_words : 0)) * sizeof(uint32_t) + 16));
+		uint32_t* res = (uint32_t*)d_res;
+		m.d_path_index = res;
+		m.d_path_trans = res + n;
+		m.d_score = res + 2 * (size_t)n;
+		m.d_job_scores = res + 2 * (size_t)n;
+		m.d_bt_counters = res + 2 * (size_t)n + m.jobs.size();
+		if (m.device_superreads) {
+			m.super_args.out = res + m.super_off;
+			m.super_args.path_index = m.d_path_index;
+		}
+	}
 	// ---- chunks of the speculative backtrace: a new chunk starts at every BT_CHUNK_RUNS-th slot run (single job only)
 	m.use_chunks = false;
 	m.chunks.clear();
@@ -1370,7 +1388,6 @@ whamd_status_t DeviceTable::upload(Problem& p, int device, std::string& msg) {
 		HIP_TRY(alloc((void**)&m.d_trans2, (size_t)m.n_orient_max * n * 4));
 		HIP_TRY(alloc((void**)&m.d_sel, m.units.size() + 16));
 		HIP_TRY(alloc((void**)&m.d_guess, m.chunks.size() * 4));
-		HIP_TRY(alloc((void**)&m.d_bt_counters, 16));
 		uint32_t stride = 64;
 		for (const SlotRun& run : m.splan.runs) if (run.spec_id) stride = std::max(stride, (run.threads >> 6) << (run.g - run.half));
 		if (trio_runs) for (const ResSegment& sgm : m.plan.segments) if (sgm.in_mirror_bit) stride = std::max(stride, (sgm.threads >> 6) << sgm.g);
@@ -1413,18 +1430,7 @@ whamd_status_t DeviceTable::upload(Problem& p, int device, std::string& msg) {
 	HIP_TRY(alloc(&d_last_keys, (size_t)MAX_T_WIDE * 8));
 	HIP_TRY(alloc((void**)&m.d_pr[0], (size_t)(1ull << max_f) * p.T * 4));
 	HIP_TRY(alloc((void**)&m.d_pr[1], (size_t)(1ull << max_f) * p.T * 4));
-	HIP_TRY(alloc((void**)&m.d_path_index, (size_t)n * 4));
-	HIP_TRY(alloc((void**)&m.d_path_trans, (size_t)n * 4));
-	HIP_TRY(alloc((void**)&m.d_score, 16));
-	m.super_off = 2 * (size_t)n + 4 + m.jobs.size();
-	if (m.device_superreads) {
-		void* d_super = nullptr;
-		HIP_TRY(alloc(&d_super, m.super_words * 4));
-		m.super_args.out = (uint32_t*)d_super;
-		m.super_args.path_index = m.d_path_index;
-	}
 	HIP_TRY(pinned_take((m.super_off + (m.device_superreads ? m.super_words : 0)) * sizeof(uint32_t), (void**)&m.h_pinned, &m.h_pinned_bytes));
-	HIP_TRY(alloc((void**)&m.d_job_scores, (m.jobs.size() + 1) * 4));
 	{   // lanes: longest job first to the least loaded lane; lane 0 always runs the final job
 		// at most 1 GiB of private exchange buffers (coverage 23: 64 MiB per lane)
 		const size_t lane_bytes = 2 * ((size_t)(1ull << max_f) * p.T * 4);
@@ -2012,16 +2018,9 @@ whamd_status_t DeviceTable::Impl::submit_tail(const Problem& p, std::string& msg
 			hipLaunchKernelGGL(superreads_single, dim3((n + 255u) / 256u), dim3(256), 0, ts, m.super_args);
 			HIP_TRY(hipGetLastError());
 		}
-		HIP_TRY(hipMemcpyAsync(m.h_pinned + m.super_off, m.super_args.out, m.super_words * 4, hipMemcpyDeviceToHost, ts));
 	}
-	// downloads go to pinned host buffers: a copy into pageable memory would block this call until the stream drains
-	HIP_TRY(hipMemcpyAsync(m.h_pinned, m.d_path_index, (size_t)n * 4, hipMemcpyDeviceToHost, ts));
-	HIP_TRY(hipMemcpyAsync(m.h_pinned + n, m.d_path_trans, (size_t)n * 4, hipMemcpyDeviceToHost, ts));
-	HIP_TRY(hipMemcpyAsync(m.h_pinned + 2 * (size_t)n, m.d_score, 4, hipMemcpyDeviceToHost, ts));
-	if (m.jobs.size() > 1)
-		HIP_TRY(hipMemcpyAsync(m.h_pinned + 2 * (size_t)n + 1, m.d_job_scores + 1, (m.jobs.size() - 1) * 4, hipMemcpyDeviceToHost, ts));
-	// (the chunked backtrace's counters travel with the path: a synchronous 12-byte copy per table in wait() was a device round trip each -- 96 tables, 96 of them)
-	if (m.use_chunks) HIP_TRY(hipMemcpyAsync(m.h_pinned + 2 * (size_t)n + m.jobs.size(), m.d_bt_counters, 12, hipMemcpyDeviceToHost, ts));
+	// ONE download per table (the device block has the pinned buffer's layout, upload()); pinned: a copy into pageable memory would block this call until the stream drains
+	HIP_TRY(hipMemcpyAsync(m.h_pinned, m.d_path_index, (m.super_off + (m.device_superreads ? m.super_words : 0)) * sizeof(uint32_t), hipMemcpyDeviceToHost, ts));
 	HIP_TRY(hipEventRecord(m.ev3, ts));
 	return WHAMD_OK;
 }
